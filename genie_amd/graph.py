@@ -1,0 +1,134 @@
+"""Host-side graph construction for the station x source-grid product graph.
+
+Mirrors the *layout contract* of the reference's one-time graph setup
+(`/root/reference/Code/process_utils.py:701-742`, same code in `train_GENIE_model.py:1140-1149`):
+
+* base kNN graphs `A_sta_sta [2, S*ks]`, `A_src_src [2, G*kp]` with row 0 = neighbour (message
+  source j), row 1 = centre (message target i), grouped by centre, self loops removed
+  (`process_utils.py:718-719`: `remove_self_loops(knn(x/1000, x/1000, k+1).flip(0))`);
+* product-graph node id `p = g*S + s`;
+* `A_prod_sta_sta = A_sta_sta.repeat(1, G) + S*arange(G).repeat_interleave(S*ks)`  (:720)
+* `A_prod_src_src = S*A_src_src.repeat(1, S) + arange(S).repeat_interleave(G*kp)`  (:721)
+* `A_src_in_prod  = [arange(P); arange(G).repeat_interleave(S)]`                     (:722)
+* `A_src_in_sta   = [tile(arange(S), G); arange(G).repeat(S)]`  (`process_continuous_days.py:629`)
+
+The HIP path never consumes the `[2, E]` product edge lists: `base_tables_from_product` recovers the
+dense neighbour tables `sta_nbr[S, ks]`, `src_nbr[G, kp]` (int32) and verifies the Cartesian structure.
+"""
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+
+def knn_graph(points, k):
+    """Exact kNN graph of a point set with itself, self excluded.
+
+    Returns int64 ndarray [2, N*k]: row 0 = neighbour j, row 1 = centre i, grouped by i
+    (the layout of `remove_self_loops(knn(x, x, k+1).flip(0))`, process_utils.py:718).
+    `points` are used as given (the reference passes coordinates in km).
+    """
+    pts = np.asarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    k = int(min(k, n - 1))
+    _, idx = cKDTree(pts).query(pts, k=k + 1)
+    idx = np.asarray(idx).reshape(n, k + 1)
+    out = np.empty((n, k), dtype=np.int64)
+    for i in range(n):  # drop self (robust to the self not being returned first on exact ties)
+        row = idx[i]
+        row = row[row != i]
+        out[i] = row[:k]
+    centre = np.repeat(np.arange(n, dtype=np.int64), k)
+    return np.stack([out.reshape(-1), centre], axis=0)
+
+
+def k_sta_effective(k_sta_edges, n_sta):
+    """`k_sta_edges = np.minimum(k_sta_edges, len(ind_use) - 2)` (process_utils.py:712)."""
+    return int(min(k_sta_edges, n_sta - 2))
+
+
+def cartesian_product_edges(A_sta_sta, A_src_src, n_sta, n_grid, device="cpu"):
+    """Explicit product-graph edge lists exactly as the reference builds them (process_utils.py:720-722).
+
+    Only for small/medium sizes (E = P*(ks+kp) int64 pairs); the HIP path does not need them.
+    """
+    A_sta_sta = torch.as_tensor(A_sta_sta, dtype=torch.long, device=device)
+    A_src_src = torch.as_tensor(A_src_src, dtype=torch.long, device=device)
+    e_sta = A_sta_sta.shape[1]
+    e_src = A_src_src.shape[1]
+    ar = torch.arange
+    A_prod_sta_sta = (A_sta_sta.repeat(1, n_grid)
+                      + n_sta * ar(n_grid, device=device).repeat_interleave(e_sta).view(1, -1)).contiguous()
+    A_prod_src_src = (n_sta * A_src_src.repeat(1, n_sta)
+                      + ar(n_sta, device=device).repeat_interleave(e_src).view(1, -1)).contiguous()
+    A_src_in_prod = torch.cat((ar(n_sta * n_grid, device=device).view(1, -1),
+                               ar(n_grid, device=device).repeat_interleave(n_sta).view(1, -1)), dim=0).contiguous()
+    A_src_in_sta = torch.cat((ar(n_sta, device=device).repeat(n_grid).view(1, -1),
+                              ar(n_grid, device=device).repeat_interleave(n_sta).view(1, -1)), dim=0).contiguous()
+    return A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta
+
+
+class GraphEdges(object):
+    """Duck-typed stand-in for PyG `Data(x=..., edge_index=...)` (process_continuous_days.py:631-632)."""
+
+    def __init__(self, x=None, edge_index=None):
+        self.x = x
+        self.edge_index = edge_index
+
+    def to(self, device):
+        if self.x is not None:
+            self.x = self.x.to(device)
+        if self.edge_index is not None:
+            self.edge_index = self.edge_index.to(device)
+        return self
+
+
+def neighbour_table(edge_index, n_nodes):
+    """[2, n*k] edge list (row0 = j, row1 = i, every node exactly k in-edges) -> int32 table [n, k].
+
+    Order of neighbours within a row follows the edge order (stable), so means are summed in the
+    reference's edge order. Raises ValueError if in-degrees are not uniform.
+    """
+    ei = torch.as_tensor(edge_index).long().cpu()
+    if ei.numel() == 0:
+        return torch.zeros((n_nodes, 0), dtype=torch.int32)
+    j, i = ei[0], ei[1]
+    deg = torch.bincount(i, minlength=n_nodes)
+    k = int(deg.max().item())
+    if int(deg.min().item()) != k:
+        raise ValueError("neighbour_table: non-uniform in-degree (min %d, max %d); use the CSR path"
+                         % (int(deg.min().item()), k))
+    order = torch.sort(i, stable=True)[1]
+    return j[order].view(n_nodes, k).to(torch.int32).contiguous()
+
+
+def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
+    """Recover base tables from the reference's product edge lists and verify the Cartesian structure.
+
+    A_in_sta [2, P*ks], A_in_src [2, P*kp] as built at process_utils.py:720-721. Returns
+    (sta_nbr int32 [S, ks], src_nbr int32 [G, kp]). Raises ValueError when the lists are not the
+    full Cartesian product of two uniform-degree base graphs (e.g. `use_subgraph: True`).
+    """
+    A_in_sta = torch.as_tensor(A_in_sta)
+    A_in_src = torch.as_tensor(A_in_src)
+    S, G = int(n_sta), int(n_grid)
+    if A_in_sta.shape[1] % G != 0 or A_in_src.shape[1] % S != 0:
+        raise ValueError("product edge lists are not a multiple of (n_grid, n_sta): not Cartesian")
+    e_sta = A_in_sta.shape[1] // G
+    e_src = A_in_src.shape[1] // S
+    base_sta = A_in_sta[:, :e_sta]
+    if int(base_sta.max().item()) >= S:
+        raise ValueError("first block of A_in_sta leaves source node 0: not Cartesian")
+    # A_in_src block for station 0: ids are S*g + 0
+    blk = A_in_src[:, :e_src]
+    if int((blk % S).abs().max().item()) != 0:
+        raise ValueError("first block of A_in_src is not station 0: not Cartesian")
+    base_src = torch.div(blk, S, rounding_mode="floor")
+    if check:
+        dev = A_in_sta.device
+        off = S * torch.arange(G, device=dev).repeat_interleave(e_sta).view(1, -1)
+        if not torch.equal(A_in_sta, base_sta.repeat(1, G) + off):
+            raise ValueError("A_in_sta is not A_sta_sta (x) I_G: not Cartesian")
+        off = torch.arange(S, device=dev).repeat_interleave(e_src).view(1, -1)
+        if not torch.equal(A_in_src, S * base_src.repeat(1, S) + off):
+            raise ValueError("A_in_src is not I_S (x) A_src_src: not Cartesian")
+    return neighbour_table(base_sta, S), neighbour_table(base_src, G)

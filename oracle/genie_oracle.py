@@ -1,0 +1,273 @@
+"""ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (PyTorch CPU tensors, fp32 or fp64, no PyG / torch_scatter / torch_cluster) of the
+reference's station<->source-grid message-passing path and of the read-out heads needed to return
+`(y, x)` from `GCN_Detection_Network_extended.forward_fixed_source`
+(`/root/reference/Code/module.py:999-1020`). Every function cites the reference lines it follows.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module,
+and only as the checker / reported baseline. `genie_amd/` never imports it.
+
+Pinning: the reference has no tests and no golden vectors, and the arithmetic of
+`propagate` / `scatter` / `knn` / `softmax` lives in un-vendored, un-pinned third-party packages
+(`module.py:14-20`; `Code/install_dependencies.txt:7-17`) -> at that boundary the reference itself
+leaves parity unpinned. This oracle is pinned against outputs of the reference's own `module.py`
+executed in the build container (PyG replaced by the documented-semantics shim in `oracle/ref_shim`)
+and committed as fixtures under `tests/golden/` by `oracle/make_golden.py`
+(`tests/test_oracle_golden.py` checks every one of them).
+
+Two formulations are provided and checked against each other:
+* "literal": explicit `[2, E]` product edge lists, gather + scatter-mean, exactly the reference dataflow;
+* "structured": base kNN tables on a `[G, S, C]` view (no product edge lists), used at sizes where the
+  literal form does not fit in memory.
+
+Weights are a dict keyed by the reference's `state_dict` names (e.g. `DataAggregation.init_trns.weight`).
+"""
+import math
+
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+SCALE_REL = 30000.0          # config.yaml:73
+KERNEL_SIG_T = 3.0           # train_config.yaml:17
+SCALE_T = 3.0 * KERNEL_SIG_T  # module.py:40
+
+
+def prelu(x, a):
+    """nn.PReLU with a single scalar slope: max(0,x) + a*min(0,x)."""
+    return torch.where(x >= 0, x, a * x)
+
+
+def linear(x, w, prefix):
+    """nn.Linear `prefix` (weight [out,in], bias [out])."""
+    return x @ w[prefix + ".weight"].T + w[prefix + ".bias"]
+
+
+def act(x, w, prefix):
+    return prelu(x, w[prefix + ".weight"])
+
+
+def scatter_sum(msg, index, n):
+    out = torch.zeros((n,) + tuple(msg.shape[1:]), dtype=msg.dtype)
+    return out.index_add_(0, index, msg)
+
+
+def scatter_mean(msg, index, n):
+    """torch_scatter 'mean': sum / clamp(count, 1); empty segment -> 0."""
+    s = scatter_sum(msg, index, n)
+    cnt = torch.zeros(n, dtype=msg.dtype).index_add_(0, index, torch.ones(index.shape[0], dtype=msg.dtype))
+    return s / cnt.clamp(min=1).view((-1,) + (1,) * (msg.dim() - 1))
+
+
+def propagate_mean(x, edge_index):
+    """MessagePassing('mean').propagate(edge_index, x=x) with the default message x_j
+    (module.py:54,90): out[i] = mean_{(j,i) in E} x[j]."""
+    return scatter_mean(x[edge_index[0]], edge_index[1], x.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------
+# a-1  DataAggregation.forward  (module.py:85-98)
+# ----------------------------------------------------------------------------------------------
+def data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, pre="DataAggregation", full=False):
+    tr = torch.cat((Slice, Mask), dim=-1)                                        # :87
+    h0 = act(linear(tr, w, pre + ".init_trns"), w, pre + ".activate")            # :88
+    n1 = propagate_mean(act(h0, w, pre + ".activate11"), A_in_sta)               # :90
+    n2 = propagate_mean(act(h0, w, pre + ".activate12"), A_in_src)               # :91
+    tr1 = linear(torch.cat((h0, n1, Mask), dim=1), w, pre + ".l1_t1_2")          # :90
+    tr2 = linear(torch.cat((h0, n2, Mask), dim=1), w, pre + ".l1_t2_2")          # :91
+    h1 = act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate1")                # :92
+    u = act(linear(h1, w, pre + ".l2_t1_1"), w, pre + ".activate21")             # :94
+    v = act(linear(h1, w, pre + ".l2_t2_1"), w, pre + ".activate22")             # :95
+    o1 = linear(torch.cat((h1, propagate_mean(u, A_in_sta), Mask), dim=1), w, pre + ".l2_t1_2")  # :94
+    o2 = linear(torch.cat((h1, propagate_mean(v, A_in_src), Mask), dim=1), w, pre + ".l2_t2_2")  # :95
+    x_latent = act(torch.cat((o1, o2), dim=1), w, pre + ".activate2")            # :96
+    if full:
+        return {"h0": h0, "h1": h1, "u": u, "v": v, "x_latent": x_latent}
+    return x_latent
+
+
+def _gather_mean_sta(x3, sta_nbr):
+    """x3 [G,S,C]; mean over station neighbours within the same source node: [G,S,C]."""
+    if sta_nbr.shape[1] == 0:
+        return torch.zeros_like(x3)
+    return x3[:, sta_nbr.long(), :].mean(dim=2)
+
+
+def _gather_mean_src(x3, src_nbr):
+    """x3 [G,S,C]; mean over source-node neighbours for the same station: [G,S,C]."""
+    if src_nbr.shape[1] == 0:
+        return torch.zeros_like(x3)
+    out = torch.zeros_like(x3)
+    for k in range(src_nbr.shape[1]):          # accumulate in edge order
+        out += x3[src_nbr[:, k].long()]
+    return out / src_nbr.shape[1]
+
+
+def data_aggregation_structured(w, Slice, Mask, sta_nbr, src_nbr, n_sta, n_grid,
+                                pre="DataAggregation", full=False):
+    """Same as `data_aggregation` on the full Cartesian product graph, but from the base kNN tables
+    `sta_nbr[S,ks]`, `src_nbr[G,kp]` (identity (4) of SURVEY.md Appendix A); p = g*S + s."""
+    S, G = n_sta, n_grid
+
+    def v3(t):
+        return t.view(G, S, -1)
+
+    def v2(t):
+        return t.reshape(G * S, -1)
+
+    tr = torch.cat((Slice, Mask), dim=-1)
+    h0 = act(linear(tr, w, pre + ".init_trns"), w, pre + ".activate")
+    n1 = v2(_gather_mean_sta(v3(act(h0, w, pre + ".activate11")), sta_nbr))
+    n2 = v2(_gather_mean_src(v3(act(h0, w, pre + ".activate12")), src_nbr))
+    tr1 = linear(torch.cat((h0, n1, Mask), dim=1), w, pre + ".l1_t1_2")
+    tr2 = linear(torch.cat((h0, n2, Mask), dim=1), w, pre + ".l1_t2_2")
+    h1 = act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate1")
+    u = act(linear(h1, w, pre + ".l2_t1_1"), w, pre + ".activate21")
+    v = act(linear(h1, w, pre + ".l2_t2_1"), w, pre + ".activate22")
+    n1b = v2(_gather_mean_sta(v3(u), sta_nbr))
+    n2b = v2(_gather_mean_src(v3(v), src_nbr))
+    o1 = linear(torch.cat((h1, n1b, Mask), dim=1), w, pre + ".l2_t1_2")
+    o2 = linear(torch.cat((h1, n2b, Mask), dim=1), w, pre + ".l2_t2_2")
+    x_latent = act(torch.cat((o1, o2), dim=1), w, pre + ".activate2")
+    if full:
+        return {"h0": h0, "h1": h1, "u": u, "v": v, "x_latent": x_latent}
+    return x_latent
+
+
+# ----------------------------------------------------------------------------------------------
+# a-2  BipartiteGraphOperator.forward  (module.py:224-229)
+# ----------------------------------------------------------------------------------------------
+def bipartite_read_in(w, x_latent, edge_attr, edge_index, Mask, pre="Bipartite_ReadIn"):
+    N = int(edge_index[0].max().item()) + 1                                      # :226
+    M = int(edge_index[1].max().item()) + 1                                      # :227
+    assert N == x_latent.shape[0]
+    m = Mask.max(1, keepdim=True)[0]                                             # :229
+    msg = m * act(linear(torch.cat((x_latent, edge_attr), dim=-1), w, pre + ".fc1"), w, pre + ".activate1")
+    r = scatter_sum(msg[edge_index[0]], edge_index[1], M)                        # propagate 'add', size=(N,M)
+    return act(linear(r, w, pre + ".fc2"), w, pre + ".activate2")
+
+
+def bipartite_read_in_structured(w, x_latent, edge_attr, Mask, n_sta, n_grid, pre="Bipartite_ReadIn"):
+    m = Mask.max(1, keepdim=True)[0]
+    msg = m * act(linear(torch.cat((x_latent, edge_attr), dim=-1), w, pre + ".fc1"), w, pre + ".activate1")
+    r = msg.view(n_grid, n_sta, -1).sum(dim=1)
+    return act(linear(r, w, pre + ".fc2"), w, pre + ".activate2")
+
+
+# ----------------------------------------------------------------------------------------------
+# a-3  SpatialAggregation.forward / message  (module.py:243-249)
+# ----------------------------------------------------------------------------------------------
+def spatial_aggregation(w, tr, A_src, pos, pre, scale_rel=SCALE_REL):
+    j, i = A_src[0], A_src[1]
+    p = pos / scale_rel                                                          # :245
+    x_j = tr[j]
+    c = act(linear(x_j, w, pre + ".fglobal"), w, pre + ".activate3").mean(0, keepdim=True)   # :249 mean over ALL edges
+    msg = act(linear(torch.cat((x_j, p[i] - p[j], c.repeat(x_j.shape[0], 1)), dim=-1), w, pre + ".fc1"),
+              w, pre + ".activate1")                                             # :249
+    a = scatter_mean(msg, i, tr.shape[0])                                        # 'mean' aggregation :233
+    return act(linear(torch.cat((tr, a), dim=-1), w, pre + ".fc2"), w, pre + ".activate2")   # :245
+
+
+# ----------------------------------------------------------------------------------------------
+# a-6  read-out heads needed for (y, x)
+# ----------------------------------------------------------------------------------------------
+def spatial_direct(w, x, pre="SpatialDirect"):
+    """module.py:251-260."""
+    return act(linear(x, w, pre + ".f_direct"), w, pre + ".activate")
+
+
+def temporal_attention(w, inpts, t_query, pre="TemporalAttention", n_heads=5, n_latent=15, scale_t=SCALE_T):
+    """module.py:325-331 (no softmax: score * value, mean over heads)."""
+    H, L = n_heads, n_latent
+    context = linear(act(linear(inpts, w, pre + ".f_context_1"), w, pre + ".activate1"), w, pre + ".f_context_2").view(-1, H, L)
+    values = linear(act(linear(inpts, w, pre + ".f_values_1"), w, pre + ".activate2"), w, pre + ".f_values_2").view(-1, H, L)
+    query = linear(act(linear(t_query / scale_t, w, pre + ".temporal_query_1"), w, pre + ".activate3"),
+                   w, pre + ".temporal_query_2").view(-1, H, L)
+    score = (context.unsqueeze(1) * query.unsqueeze(0)).sum(-1, keepdim=True) / math.sqrt(L)   # [N,T,H,1]
+    z = (score * values.unsqueeze(1)).mean(2)                                                  # [N,T,L]
+    return linear(act(linear(act(z, w, pre + ".activate4"), w, pre + ".proj_1"), w, pre + ".activate5"), w, pre + ".proj_2")
+
+
+def knn_edges(x_context, x_query, k):
+    """`knn(x_context/1000, x_query/1000, k).flip(0)` (module.py:282): row0 = context j, row1 = query i."""
+    xc = x_context.detach().double().numpy() / 1000.0
+    xq = x_query.detach().double().numpy() / 1000.0
+    k = min(k, xc.shape[0])
+    _, idx = cKDTree(xc).query(xq, k=k)
+    idx = np.asarray(idx).reshape(xq.shape[0], k)
+    row_q = np.repeat(np.arange(xq.shape[0]), k)
+    return torch.from_numpy(np.stack([idx.reshape(-1), row_q], axis=0)).long()
+
+
+def segment_softmax(src, index, n):
+    """torch_geometric.utils.softmax."""
+    idx = index.view(-1, 1).expand_as(src)
+    mx = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype).scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    den = torch.zeros((n, src.shape[1]), dtype=src.dtype).index_add_(0, index, out)
+    return out / (den[index] + 1e-16)
+
+
+def spatial_attention(w, inpts, x_query, x_context, k=10, pre="SpatialAttention", n_heads=5, n_latent=15,
+                      scale_rel=SCALE_REL, edge_index=None):
+    """module.py:280-297."""
+    H, L = n_heads, n_latent
+    if edge_index is None:
+        edge_index = knn_edges(x_context, x_query, k)                            # :282
+    j, i = edge_index[0], edge_index[1]
+    edge_attr = (x_query[i] - x_context[j]) / scale_rel                          # :283
+    x_j = inpts[j]
+    q = linear(edge_attr, w, pre + ".f_queries").view(-1, H, L)                  # :289
+    c = linear(torch.cat((x_j, edge_attr), dim=-1), w, pre + ".f_context").view(-1, H, L)   # :290
+    v = linear(torch.cat((x_j, edge_attr), dim=-1), w, pre + ".f_values").view(-1, H, L)    # :291
+    alpha = act((q * c).sum(-1) / math.sqrt(L), w, pre + ".activate1")           # :293
+    alpha = segment_softmax(alpha, i, x_query.shape[0])                          # :295
+    agg = scatter_sum(alpha.unsqueeze(-1) * v, i, x_query.shape[0])              # 'add' :264, size=(ctx, query)
+    return act(linear(agg.mean(1), w, pre + ".proj"), w, pre + ".activate2")     # :285
+
+
+# ----------------------------------------------------------------------------------------------
+# a-4  forward_fixed_source  (module.py:999-1020)
+# ----------------------------------------------------------------------------------------------
+def forward_fixed_source(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src,
+                         x_grid_cart, x_query_cart, t_query, full=False, query_edges=None):
+    """Literal formulation. `use_absolute_pos=False` (config.yaml:92). Returns (y, x) or a dict."""
+    da = data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, full=True)                         # :1010
+    bip = bipartite_read_in(w, da["x_latent"], edge_attr, A_src_in_prod, Mask)                   # :1011
+    sa1 = spatial_aggregation(w, bip, A_src, x_grid_cart, "SpatialAggregation1")                 # :1012
+    sa2 = spatial_aggregation(w, sa1, A_src, x_grid_cart, "SpatialAggregation2")                 # :1013
+    sa3 = spatial_aggregation(w, sa2, A_src, x_grid_cart, "SpatialAggregation3")                 # :1014
+    y_latent = spatial_direct(w, sa3)                                                            # :1015
+    y = temporal_attention(w, y_latent, t_query)                                                 # :1016
+    xq = spatial_attention(w, sa3, x_query_cart, x_grid_cart, edge_index=query_edges)            # :1017
+    x = temporal_attention(w, xq, t_query)                                                       # :1018
+    if full:
+        out = dict(da)
+        out.update({"bip": bip, "sa1": sa1, "sa2": sa2, "sa3": sa3, "y_latent": y_latent, "xq": xq, "y": y, "x": x})
+        return out
+    return y, x
+
+
+def forward_fixed_source_structured(w, Slice, Mask, sta_nbr, src_nbr, edge_attr, A_src, x_grid_cart,
+                                    x_query_cart, t_query, n_sta, n_grid, full=False, query_edges=None):
+    """Structured formulation (no product edge lists); identical math, different summation grouping."""
+    da = data_aggregation_structured(w, Slice, Mask, sta_nbr, src_nbr, n_sta, n_grid, full=True)
+    bip = bipartite_read_in_structured(w, da["x_latent"], edge_attr, Mask, n_sta, n_grid)
+    sa1 = spatial_aggregation(w, bip, A_src, x_grid_cart, "SpatialAggregation1")
+    sa2 = spatial_aggregation(w, sa1, A_src, x_grid_cart, "SpatialAggregation2")
+    sa3 = spatial_aggregation(w, sa2, A_src, x_grid_cart, "SpatialAggregation3")
+    y_latent = spatial_direct(w, sa3)
+    y = temporal_attention(w, y_latent, t_query)
+    xq = spatial_attention(w, sa3, x_query_cart, x_grid_cart, edge_index=query_edges)
+    x = temporal_attention(w, xq, t_query)
+    if full:
+        out = dict(da)
+        out.update({"bip": bip, "sa1": sa1, "sa2": sa2, "sa3": sa3, "y_latent": y_latent, "xq": xq, "y": y, "x": x})
+        return out
+    return y, x
+
+
+def weights_from_npz(z, dtype=torch.float32, prefix="w/"):
+    """Load a weight dict from an npz whose keys are `w/<state_dict name>`."""
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(z[k])).to(dtype) for k in z.files if k.startswith(prefix)}

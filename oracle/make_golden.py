@@ -1,0 +1,156 @@
+"""Golden-vector generator — runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own `Code/module.py` (with the third-party PyG stack replaced by the
+documented-semantics shim in `oracle/ref_shim`, see its README), instantiates the live model
+`GCN_Detection_Network_extended` (`module.py:882`), runs `forward_fixed_source` (`module.py:999`) on
+seeded synthetic inputs from `genie_amd.synthetic`, and writes inputs + reference outputs +
+intermediates (captured with forward hooks on the reference's sub-modules) to `tests/golden/*.npz`.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+The fixtures are data (inputs, weights, expected outputs); no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CODE = "/root/reference/Code"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
+    sys.path.insert(0, REF_CODE)
+    sys.path.insert(0, REPO)
+    os.chdir(REF_CODE)            # module.py:27-31 reads config.yaml / train_config.yaml from the CWD
+    import module as ref_module   # noqa: E402
+    return ref_module
+
+
+def _hook_intermediates(mz):
+    store = {}
+
+    def mk(name, multi=False):
+        def hook(_m, _inp, out):
+            if multi:
+                store.setdefault(name, []).append(out.detach().clone())
+            else:
+                store[name] = out.detach().clone()
+        return hook
+
+    da = mz.DataAggregation
+    handles = [
+        da.activate.register_forward_hook(mk("h0")),          # module.py:88
+        da.activate1.register_forward_hook(mk("h1")),         # :92
+        da.activate21.register_forward_hook(mk("u")),         # :94
+        da.activate22.register_forward_hook(mk("v")),         # :95
+        da.register_forward_hook(mk("x_latent")),             # :916
+        mz.Bipartite_ReadIn.register_forward_hook(mk("bip")),
+        mz.SpatialAggregation1.register_forward_hook(mk("sa1")),
+        mz.SpatialAggregation2.register_forward_hook(mk("sa2")),
+        mz.SpatialAggregation3.register_forward_hook(mk("sa3")),
+        mz.SpatialDirect.register_forward_hook(mk("y_latent")),
+        mz.SpatialAttention.register_forward_hook(mk("xq")),
+    ]
+    return store, handles
+
+
+def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, window=None,
+             keep=("h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"),
+             row_stride=1, keep64=None):
+    import torch
+    from genie_amd import graph as G
+
+    S, Gn = geom.n_sta, geom.n_grid
+    A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
+        geom.A_sta_sta, geom.A_src_src, S, Gn)
+    A_src_src = torch.from_numpy(geom.A_src_src).long()
+    spatial_vals = torch.from_numpy(geom.edge_attr())
+    results = {}
+    for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
+        torch.manual_seed(weights_seed)
+        np.random.seed(weights_seed)
+        mz = ref.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+        if perturb_prelu:
+            g = torch.Generator().manual_seed(1234)
+            for n_, p_ in mz.named_parameters():
+                if p_.numel() == 1:
+                    p_.data.fill_(float(0.05 + 0.45 * torch.rand(1, generator=g)))
+        sd32 = {k: v.detach().clone().numpy() for k, v in mz.state_dict().items()}
+        mz = mz.to(dtype).eval()
+        store, handles = _hook_intermediates(mz)
+        Data = sys.modules["torch_geometric"].data.Data
+        A_src_in_edges = Data(x=spatial_vals.to(dtype), edge_index=A_src_in_prod)
+        A_Lg_in_src = Data(x=spatial_vals.to(dtype), edge_index=A_src_in_prod.flip(0).contiguous())
+        tlatent = torch.from_numpy(geom.travel_times().reshape(-1, 2)).to(dtype)
+        # set_adjacencies as process_continuous_days.py:634 does (association tables unused on this path)
+        mz.set_adjacencies(A_prod_sta_sta, A_prod_src_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src_src,
+                           torch.zeros(0).long(), torch.zeros(0).long(), torch.zeros(2).to(dtype), tlatent,
+                           torch.from_numpy(geom.locs).to(dtype), torch.from_numpy(geom.x_grid).to(dtype))
+        with torch.no_grad():
+            tp = torch.from_numpy(window["tpick"]).to(dtype) if window else torch.zeros(1).to(dtype)
+            ip = torch.from_numpy(window["ipick"]).long() if window else torch.zeros(1).long()
+            ph = torch.from_numpy(window["phase_label"]).to(dtype) if window else torch.zeros(1, 1).to(dtype)
+            y, x = mz.forward_fixed_source(torch.from_numpy(Slice).to(dtype), torch.from_numpy(Mask).to(dtype),
+                                           tp, ip, ph, torch.from_numpy(geom.locs).to(dtype),
+                                           torch.from_numpy(geom.x_grid).to(dtype),
+                                           torch.from_numpy(geom.x_query).to(dtype),
+                                           torch.from_numpy(geom.t_query).to(dtype))
+        for h in handles:
+            h.remove()
+        results["y" + tag] = y.numpy()
+        results["x" + tag] = x.numpy()
+        for k in (keep if (tag == "" or keep64 is None) else keep64):
+            v = store[k].numpy()
+            if v.shape[0] == S * Gn and row_stride > 1:
+                v = v[::row_stride]
+            results[k + tag] = v
+        if tag == "":
+            for k, v in sd32.items():
+                results["w/" + k] = v.astype(np.float32)
+    results.update({
+        "n_sta": np.int64(S), "n_grid": np.int64(Gn), "row_stride": np.int64(row_stride),
+        "locs": geom.locs, "x_grid": geom.x_grid, "x_query": geom.x_query, "t_query": geom.t_query,
+        "A_sta_sta": geom.A_sta_sta, "A_src_src": geom.A_src_src,
+        "edge_attr": geom.edge_attr(), "Slice": Slice.astype(np.float32), "Mask": Mask.astype(np.uint8),
+    })
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **results)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0),
+          "| y max %.3e x max %.3e" % (np.abs(results["y"]).max(), np.abs(results["x"]).max()))
+
+
+def main():
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+
+    os.makedirs(OUT, exist_ok=True)
+
+    # (i) tiny, exhaustive intermediates, fp32 + fp64, distinct PReLU slopes, event-structured picks
+    geom = syn.Geometry(6, 40, L=60e3, n_query=25, seed=11)
+    win = syn.make_window(geom, 60, seed=12)
+    run_case(ref, "tiny_6x40", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win)
+
+    # (ii) config-1 shape: 20 stations / 500 grid nodes / 2k picks, default init under seed 0
+    geom = syn.Geometry(20, 500, L=100e3, n_query=300, seed=1)
+    win = syn.make_window(geom, 2000, seed=2)
+    run_case(ref, "cfg1_20x500", geom, win["Slice"], win["Mask"], window=win, row_stride=7,
+             keep=("x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"), keep64=("bip", "sa3"))
+
+    # (iii) odd sizes; Slice random in [0,1], Mask an INDEPENDENT random {0,1} pattern with all-zero rows
+    geom = syn.Geometry(33, 257, L=150e3, n_query=77, seed=21)
+    rng = np.random.default_rng(22)
+    P = geom.n_prod
+    Slice = rng.random((P, 4)).astype(np.float32)
+    Mask = (rng.random((P, 4)) < 0.4).astype(np.float32)
+    Mask[rng.random(P) < 0.3] = 0.0
+    Slice[rng.random(P) < 0.1] = 0.0
+    run_case(ref, "odd_33x257", geom, Slice, Mask, perturb_prelu=True, row_stride=11,
+             keep=("h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"), keep64=("bip", "sa3"))
+
+
+if __name__ == "__main__":
+    main()

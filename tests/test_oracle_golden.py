@@ -1,0 +1,47 @@
+"""CPU: pin the oracle (oracle/genie_oracle.py) against every golden vector produced by the
+reference's own module.py (oracle/make_golden.py). fp32 tolerance 1e-6 relative to max|ref| on
+intermediates and 1e-6 absolute on the outputs (y, x); fp64 tolerance 1e-12."""
+import pytest
+import torch
+
+from tests.util import GOLDEN_CASES, Case, max_abs
+
+INTERMEDIATES = ["h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("structured", [False, True])
+def test_oracle_matches_reference_fp32(name, structured):
+    c = Case(name)
+    out = c.oracle_forward(torch.float32, structured=structured)
+    for k in INTERMEDIATES:
+        if k not in c.z.files:
+            continue
+        ref = c.ref(k)
+        got = c.strided(out[k])
+        tol = 2e-6 * max(1.0, float(ref.abs().max()))
+        assert got.shape == ref.shape, k
+        assert max_abs(got, ref) <= tol, (k, max_abs(got, ref), tol)
+    assert max_abs(out["y"], c.ref("y")) <= 1e-6
+    assert max_abs(out["x"], c.ref("x")) <= 1e-6
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("structured", [False, True])
+def test_oracle_matches_reference_fp64(name, structured):
+    c = Case(name)
+    out = c.oracle_forward(torch.float64, structured=structured)
+    for k in INTERMEDIATES + ["y", "x"]:
+        if k + "64" not in c.z.files:
+            continue
+        ref = c.ref(k + "64")
+        got = c.strided(out[k])
+        assert max_abs(got, ref) <= 1e-12 * max(1.0, float(ref.abs().max())), (k, max_abs(got, ref))
+
+
+def test_reference_fp32_vs_fp64_drift_is_small():
+    """Document the reference's own fp32 drift on the outputs."""
+    for name in GOLDEN_CASES:
+        c = Case(name)
+        assert max_abs(c.ref("y"), c.ref("y64")) < 1e-6
+        assert max_abs(c.ref("x"), c.ref("x64")) < 1e-6
