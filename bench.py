@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — picks/sec through GCN_Detection_Network_extended.forward_fixed_source on MI355X.
+
+One "step" = one forward window (`forward_fixed_source`, reference module.py:999) on fixed shapes with the
+graphs already set (`set_adjacencies` runs once per day in the reference, process_continuous_days.py:622-649),
+inputs (`Slice`, `Mask`) resident in HBM. picks/sec = N_picks x windows/sec.
+
+N = 1 workload: BASELINE.json configs[1] = 200 stations / 10 000 grid nodes / 50 000 picks.
+N > 1: window-parallel replicas (BASELINE config 5 — every GPU holds the 200-station model and graph and
+processes its own windows; no data-path collective) => weak scaling, value = sum over ranks.
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel, HIP-event timed on the launch
+stream) and `cpu_baseline` (the oracle's reference-formulation forward on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from genie_amd import graph, module, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
+
+# Algorithmic bytes: whole path B_alg = 1532*P + 816*G bytes per window.
+# Per product node and per kernel (fp32, each tensor written once / read once, gathers counted once per row):
+#   k_stage0: Slice+Mask 32 R, h0 120 W                                  = 152 B
+#   k_stage1: h0 120 R, Mask 16 R, h1 240 W, u+v 240 W                    = 616 B
+#   k_stage2: h1 240 R, u+v 240 R, Mask 16 R, edge_attr 12 R              = 508 B   (x_latent stays in registers)
+B_NODE_STAGE = {"k_stage0": 152.0, "k_stage1": 616.0, "k_stage2": 508.0}
+FLOP_NODE = 22980.0 + 1380.0   # dense + gather adds per product node
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2_200x10k", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
+    return ap.parse_args()
+
+
+def build_model(geom, dev, seed=0):
+    torch.manual_seed(seed)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev).eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src),
+                             torch.from_numpy(geom.edge_attr()).to(dev),
+                             torch.from_numpy(geom.locs).float().to(dev), torch.from_numpy(geom.x_grid).float().to(dev))
+    return net
+
+
+def cpu_baseline(net, geom, win):
+    """Oracle ('port' of the reference formulation: explicit product edge lists, gather + scatter-mean) timed on
+    this box's host cores for ONE window of the same workload."""
+    from oracle import genie_oracle as O
+    w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    S, G = geom.n_sta, geom.n_grid
+    A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    args = (w, torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"]), A_in_sta, A_in_src,
+            torch.from_numpy(geom.edge_attr()), A_src_in_prod, torch.from_numpy(geom.A_src_src),
+            torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+            torch.from_numpy(geom.t_query).float())
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        y, x = O.forward_fixed_source(*args)
+        dt = time.perf_counter() - t0
+    return y, x, dt
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    S, G, n_picks, L, nq = synthetic.CONFIGS[a.config]
+    geom = synthetic.Geometry(S, G, L=L, n_query=nq, seed=1)
+    net = build_model(geom, dev)
+    # synthetic pick windows of the fixed shape, resident in HBM (each rank its own windows)
+    wins = [synthetic.make_window(geom, n_picks, seed=2, window=rank * 1000 + i) for i in range(a.windows)]
+    dS = [torch.from_numpy(w["Slice"]).to(dev) for w in wins]
+    dM = [torch.from_numpy(w["Mask"]).to(dev) for w in wins]
+    locs = torch.from_numpy(geom.locs).float().to(dev)
+    xg = torch.from_numpy(geom.x_grid).float().to(dev)
+    xq = torch.from_numpy(geom.x_query).float().to(dev)
+    tq = torch.from_numpy(geom.t_query).float().to(dev)
+
+    def step(i):
+        k = i % a.windows
+        return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            y, x = step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    windows_per_s = world * a.steps / dt
+    value = windows_per_s * n_picks
+
+    # ---- dominant-kernel timing with HIP events on the launch stream (staged API = same kernels) ----
+    hp = net._hip
+    P = S * G
+    ev = {k: [] for k in ("k_stage0", "k_stage1", "k_stage2", "path")}
+    with torch.no_grad():
+        for i in range(min(a.steps, 20)):
+            k = i % a.windows
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            e[0].record()
+            hp.da_stage0(dS[k], dM[k])
+            e[1].record()
+            hp.da_stage1(dM[k])
+            e[2].record()
+            _, bip = hp.da_stage2_bipartite(dM[k], net._edge_attr)
+            e[3].record()
+            o = bip
+            for l in (1, 2, 3):
+                o = hp.spatial_agg(l, o, xg)
+            e[4].record()
+            torch.cuda.synchronize()
+            ev["k_stage0"].append(e[0].elapsed_time(e[1]))
+            ev["k_stage1"].append(e[1].elapsed_time(e[2]))
+            ev["k_stage2"].append(e[2].elapsed_time(e[3]))
+            ev["path"].append(e[0].elapsed_time(e[4]))
+    kms = {k: float(np.median(v)) for k, v in ev.items()}
+    dom = max(("k_stage0", "k_stage1", "k_stage2"), key=lambda k: kms[k])
+    dom_bytes = B_NODE_STAGE[dom] * P
+    dom_gbs = dom_bytes / (kms[dom] * 1e-3) / 1e9
+    b_alg = 1532.0 * P + 816.0 * G
+    path_gbs = b_alg * (windows_per_s / world) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+        "path": {"alg_bytes_per_window": b_alg, "achieved": round(path_gbs, 1), "frac": round(path_gbs / HBM_PEAK_GBS, 4),
+                 "fp32_tflops": round(FLOP_NODE * P * (windows_per_s / world) / 1e12, 2),
+                 "fp32_frac_of_mfma_peak": round(FLOP_NODE * P * (windows_per_s / world) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
+    }
+
+    out = {
+        "metric": "picks/sec through GCN_Detection_Network_extended.forward_fixed_source (GCS_Network.forward)",
+        "value": round(value, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, "
+                               "graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
+                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
+                   "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
+        "windows_per_s": round(windows_per_s, 2),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        yc, xc, cdt = cpu_baseline(net, geom, wins[0])
+        with torch.no_grad():
+            yg, xgq = net.forward_fixed_source(dS[0], dM[0], None, None, None, locs, xg, xq, tq)
+        out["cpu_baseline"] = {
+            "value": round(n_picks / cdt, 1), "unit": "picks/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "1 window of the same workload (oracle, reference formulation with explicit product edge "
+                      "lists, torch CPU fp32), %.1f s" % cdt,
+            "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xgq.cpu() - xc).abs().max()),
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

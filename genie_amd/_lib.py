@@ -1,0 +1,96 @@
+"""ctypes binding of libgenie_hip.so (the C ABI declared in include/genie_hip.h).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded this module
+raises, and every op that needs it raises with it. Build it with `python __graft_entry__.py build`
+(or `genie_amd._lib.build()`), which runs `hipcc --offload-arch=gfx950` on `genie_amd/csrc/genie_hip.hip`.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+SRC = os.path.join(_HERE, "csrc", "genie_hip.hip")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgenie_hip.so")
+INCLUDE = os.path.join(REPO, "include")
+
+# every symbol include/genie_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+SYMBOLS = [
+    ("genie_version", _c.c_int, []),
+    ("genie_last_error", _c.c_char_p, []),
+    ("genie_ctx_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_float]),
+    ("genie_ctx_destroy", _c.c_int, [_P]),
+    ("genie_weights_count", _c.c_int, []),
+    ("genie_weights_name", _c.c_char_p, [_c.c_int]),
+    ("genie_weights_numel", _c.c_int64, [_c.c_int]),
+    ("genie_weights_offset", _c.c_int64, [_c.c_int]),
+    ("genie_weights_blob_floats", _c.c_int64, []),
+    ("genie_weights_set", _c.c_int, [_P, _c.c_char_p, _P, _c.c_int64, _P]),
+    ("genie_weights_set_blob", _c.c_int, [_P, _P, _c.c_int64, _P]),
+    ("genie_weights_commit", _c.c_int, [_P, _P]),
+    ("genie_workspace_bytes", _c.c_size_t, [_P]),
+    ("genie_da_stage0", _c.c_int, [_P, _P, _P, _P, _P]),
+    ("genie_da_stage1", _c.c_int, [_P, _P, _P, _P]),
+    ("genie_ws_v_ptr", _P, [_P, _P]),
+    ("genie_ws_v_pitch", _c.c_int, [_P]),
+    ("genie_da_stage2_bipartite", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
+    ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_ws_export", _c.c_int, [_P, _c.c_int, _P, _P, _P]),
+]
+
+
+class GenieHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False, extra_flags=()):
+    """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I", INCLUDE, SRC, "-o", LIB_PATH] + list(extra_flags)
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise GenieHipError("hipcc failed:\n" + r.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libgenie_hip.so and bind every declared symbol. Raises GenieHipError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GenieHipError(
+            "libgenie_hip.so not found at %s — the HIP extension is not built. Run "
+            "`python __graft_entry__.py build` (needs hipcc); there is no CPU or PyTorch fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GenieHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise GenieHipError("libgenie_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().genie_last_error()
+        raise GenieHipError("%s failed (%d): %s" % (what or "libgenie_hip call", rc, (msg or b"").decode()))

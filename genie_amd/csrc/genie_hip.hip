@@ -1,0 +1,1063 @@
+// genie_hip.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for GENIE's station <-> source-grid
+// message-passing hot path (see include/genie_hip.h for the boundary and the reference lines replaced).
+//
+// Design (DESIGN.md has the long form):
+//  * product node p = g*S + s. A wave owns a TILE of 16 product nodes of ONE source node g
+//    (16 consecutive stations), so g, its source-neighbour list and all row bases are wave-uniform (SGPR).
+//  * every per-node Linear is an exact-fp32 MFMA chain: D[ch, node] += W[ch, k] * X[k, node] with
+//    v_mfma_f32_16x16x4_f32. Output channels are MFMA rows, nodes are MFMA columns, so the accumulator of
+//    one layer (lane (j = lane&15, q = lane>>4) holds channels 16t+4q+{0..3} of node j) IS the B operand of
+//    the next layer: k-step r of a 16-channel block consumes channel 4q+r from lane (j,q). Weights are
+//    pre-permuted into that k order ("A fragments") once per weight update and live in LDS.
+//  * the neighbour means gather 128-B rows (32 fp32 channels, 4 lanes x 16 B per node) straight into that
+//    same fragment layout, apply the per-graph PReLU on the fly, and never materialise an edge list.
+//  * Bipartite station sum: wave-level reduction over the 16 nodes of a tile, one partial row per tile,
+//    summed in fixed order by the read-out kernel (bitwise deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "genie_hip.h"
+
+#ifndef GENIE_HOIST_WEIGHTS
+#define GENIE_HOIST_WEIGHTS 0
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(GENIE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Weight registry: the path's parameters under the reference's state_dict names.
+// ------------------------------------------------------------------------------------------------
+struct Param {
+    const char* name;
+    int numel;
+    int off;
+};
+
+enum {
+    W_DA_INIT_W, W_DA_INIT_B, W_DA_L1T12_W, W_DA_L1T12_B, W_DA_L1T22_W, W_DA_L1T22_B,
+    W_DA_L2T11_W, W_DA_L2T11_B, W_DA_L2T21_W, W_DA_L2T21_B, W_DA_L2T12_W, W_DA_L2T12_B,
+    W_DA_L2T22_W, W_DA_L2T22_B, W_DA_ACT, W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22, W_DA_ACT2,
+    W_BP_FC1_W, W_BP_FC1_B, W_BP_FC2_W, W_BP_FC2_B, W_BP_ACT1, W_BP_ACT2,
+    W_SA1_FC1_W, W_SA1_FC1_B, W_SA1_FC2_W, W_SA1_FC2_B, W_SA1_FG_W, W_SA1_FG_B, W_SA1_ACT1, W_SA1_ACT2, W_SA1_ACT3,
+    W_SA2_FC1_W, W_SA2_FC1_B, W_SA2_FC2_W, W_SA2_FC2_B, W_SA2_FG_W, W_SA2_FG_B, W_SA2_ACT1, W_SA2_ACT2, W_SA2_ACT3,
+    W_SA3_FC1_W, W_SA3_FC1_B, W_SA3_FC2_W, W_SA3_FC2_B, W_SA3_FG_W, W_SA3_FG_B, W_SA3_ACT1, W_SA3_ACT2, W_SA3_ACT3,
+    W_COUNT
+};
+
+Param g_params[W_COUNT] = {
+    {"DataAggregation.init_trns.weight", 30 * 8, 0}, {"DataAggregation.init_trns.bias", 30, 0},
+    {"DataAggregation.l1_t1_2.weight", 30 * 64, 0}, {"DataAggregation.l1_t1_2.bias", 30, 0},
+    {"DataAggregation.l1_t2_2.weight", 30 * 64, 0}, {"DataAggregation.l1_t2_2.bias", 30, 0},
+    {"DataAggregation.l2_t1_1.weight", 30 * 60, 0}, {"DataAggregation.l2_t1_1.bias", 30, 0},
+    {"DataAggregation.l2_t2_1.weight", 30 * 60, 0}, {"DataAggregation.l2_t2_1.bias", 30, 0},
+    {"DataAggregation.l2_t1_2.weight", 15 * 94, 0}, {"DataAggregation.l2_t1_2.bias", 15, 0},
+    {"DataAggregation.l2_t2_2.weight", 15 * 94, 0}, {"DataAggregation.l2_t2_2.bias", 15, 0},
+    {"DataAggregation.activate.weight", 1, 0}, {"DataAggregation.activate11.weight", 1, 0},
+    {"DataAggregation.activate12.weight", 1, 0}, {"DataAggregation.activate1.weight", 1, 0},
+    {"DataAggregation.activate21.weight", 1, 0}, {"DataAggregation.activate22.weight", 1, 0},
+    {"DataAggregation.activate2.weight", 1, 0},
+    {"Bipartite_ReadIn.fc1.weight", 30 * 33, 0}, {"Bipartite_ReadIn.fc1.bias", 30, 0},
+    {"Bipartite_ReadIn.fc2.weight", 15 * 30, 0}, {"Bipartite_ReadIn.fc2.bias", 15, 0},
+    {"Bipartite_ReadIn.activate1.weight", 1, 0}, {"Bipartite_ReadIn.activate2.weight", 1, 0},
+    {"SpatialAggregation1.fc1.weight", 30 * 23, 0}, {"SpatialAggregation1.fc1.bias", 30, 0},
+    {"SpatialAggregation1.fc2.weight", 30 * 45, 0}, {"SpatialAggregation1.fc2.bias", 30, 0},
+    {"SpatialAggregation1.fglobal.weight", 5 * 15, 0}, {"SpatialAggregation1.fglobal.bias", 5, 0},
+    {"SpatialAggregation1.activate1.weight", 1, 0}, {"SpatialAggregation1.activate2.weight", 1, 0},
+    {"SpatialAggregation1.activate3.weight", 1, 0},
+    {"SpatialAggregation2.fc1.weight", 30 * 38, 0}, {"SpatialAggregation2.fc1.bias", 30, 0},
+    {"SpatialAggregation2.fc2.weight", 30 * 60, 0}, {"SpatialAggregation2.fc2.bias", 30, 0},
+    {"SpatialAggregation2.fglobal.weight", 5 * 30, 0}, {"SpatialAggregation2.fglobal.bias", 5, 0},
+    {"SpatialAggregation2.activate1.weight", 1, 0}, {"SpatialAggregation2.activate2.weight", 1, 0},
+    {"SpatialAggregation2.activate3.weight", 1, 0},
+    {"SpatialAggregation3.fc1.weight", 30 * 38, 0}, {"SpatialAggregation3.fc1.bias", 30, 0},
+    {"SpatialAggregation3.fc2.weight", 30 * 60, 0}, {"SpatialAggregation3.fc2.bias", 30, 0},
+    {"SpatialAggregation3.fglobal.weight", 5 * 30, 0}, {"SpatialAggregation3.fglobal.bias", 5, 0},
+    {"SpatialAggregation3.activate1.weight", 1, 0}, {"SpatialAggregation3.activate2.weight", 1, 0},
+    {"SpatialAggregation3.activate3.weight", 1, 0},
+};
+
+int g_raw_total = 0;
+
+void init_registry() {
+    if (g_raw_total) return;
+    int off = 0;
+    for (int i = 0; i < W_COUNT; ++i) {
+        g_params[i].off = off;
+        off += (g_params[i].numel + 3) & ~3;  // keep every tensor 16-B aligned in the mirror
+    }
+    g_raw_total = off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A-fragment packing. One MFMA "step" = one v_mfma_f32_16x16x4_f32: lane (i = lane&15, q = lane>>4)
+// supplies A[i][q] = W[o0+i][col[q]]. Four steps (k-steps r = 0..3 of one 16-channel input block) form a
+// GROUP stored as [lane][r] so a lane fetches its four A values with one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+struct StepDesc {
+    int32_t mat_off;  // offset of W in the raw mirror, <0 = unused step (zeros)
+    int32_t ld;       // input dimension of W
+    int32_t o0;       // first output row of this 16-row tile
+    int32_t rows;     // valid rows from o0 (<=16)
+    int32_t col[4];   // input column supplied by lanes with q = 0..3, <0 = zero
+};
+struct BiasDesc {
+    int32_t off, o0, rows, pad;
+};
+
+struct StagePlan {
+    std::vector<StepDesc> steps;  // 4 per group
+    std::vector<BiasDesc> bias;   // one per 16-row output tile
+    std::vector<int32_t> scal;    // raw offsets of PReLU slopes
+    int n_groups() const { return (int)steps.size() / 4; }
+    int packed_floats() const { return n_groups() * 256 + (int)bias.size() * 16 + 16; }
+};
+
+StepDesc unused_step() {
+    StepDesc d;
+    d.mat_off = -1; d.ld = 0; d.o0 = 0; d.rows = 0;
+    d.col[0] = d.col[1] = d.col[2] = d.col[3] = -1;
+    return d;
+}
+
+// group whose k-step r supplies input channel (c0 + 4q + r), valid while (4q+r) < nvalid
+void add_block_group(StagePlan& p, int mat, int ld, int o0, int rows, int c0, int nvalid) {
+    for (int r = 0; r < 4; ++r) {
+        StepDesc d;
+        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows;
+        for (int q = 0; q < 4; ++q) d.col[q] = (4 * q + r < nvalid) ? (c0 + 4 * q + r) : -1;
+        p.steps.push_back(d);
+    }
+}
+// group with explicit single steps: step r supplies column cols[r] + q for q < nq (else unused)
+void add_scalar_group(StagePlan& p, int mat, int ld, int o0, int rows, const int* c0s, const int* nqs, int nsteps) {
+    for (int r = 0; r < 4; ++r) {
+        if (r >= nsteps) { p.steps.push_back(unused_step()); continue; }
+        StepDesc d;
+        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows;
+        for (int q = 0; q < 4; ++q) d.col[q] = (q < nqs[r]) ? (c0s[r] + q) : -1;
+        p.steps.push_back(d);
+    }
+}
+void add_bias(StagePlan& p, int vec, int o0, int rows) {
+    BiasDesc b; b.off = g_params[vec].off; b.o0 = o0; b.rows = rows; b.pad = 0;
+    p.bias.push_back(b);
+}
+
+// Group index maps shared by host plan and device kernels --------------------------------------
+// stage 0: group t (t = 0,1): step 0 = Slice cols q, step 1 = Mask cols 4+q
+#define G0_GROUPS 2
+// stage 1: layer-1 groups (half h = tr1/tr2, out tile t, input block b: 0,1 = h0; 2,3 = neighbour mean; 4 = Mask)
+#define G1_L1(h, t, b) (((h) * 2 + (t)) * 5 + (b))
+// stage 1: u/v groups (w = u/v, out tile t, input block hb = h1 block 0..3)
+#define G1_UV(w, t, hb) (20 + ((w) * 2 + (t)) * 4 + (hb))
+#define G1_GROUPS 36
+#define G1_BIAS 8
+// stage 2: o1/o2 groups (w, b: 0..3 = h1 blocks, 4,5 = neighbour mean, 6 = Mask)
+#define G2_O(w, b) ((w) * 7 + (b))
+// stage 2: bipartite fc1 groups (out tile t, b: 0 = o1 block, 1 = o2 block, 2 = edge_attr)
+#define G2_BP(t, b) (14 + (t) * 3 + (b))
+#define G2_GROUPS 20
+#define G2_BIAS 4
+
+void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
+    // ---- stage 0: init_trns (30 x 8)
+    for (int t = 0; t < 2; ++t) {
+        const int c0s[2] = {0, 4}, nqs[2] = {4, 4};
+        add_scalar_group(p0, W_DA_INIT_W, 8, 16 * t, std::min(16, 30 - 16 * t), c0s, nqs, 2);
+        add_bias(p0, W_DA_INIT_B, 16 * t, std::min(16, 30 - 16 * t));
+    }
+    p0.scal.push_back(g_params[W_DA_ACT].off);
+    // ---- stage 1
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 2; ++t) {
+            const int mat = h == 0 ? W_DA_L1T12_W : W_DA_L1T22_W;
+            const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
+            add_block_group(p1, mat, 64, o0, rows, 0, 16);        // h0 ch 0..15
+            add_block_group(p1, mat, 64, o0, rows, 16, 14);       // h0 ch 16..29
+            add_block_group(p1, mat, 64, o0, rows, 30, 16);       // mean ch 0..15
+            add_block_group(p1, mat, 64, o0, rows, 46, 14);       // mean ch 16..29
+            const int c0s[1] = {60}, nqs[1] = {4};
+            add_scalar_group(p1, mat, 64, o0, rows, c0s, nqs, 1);  // Mask
+        }
+    for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 2; ++t) {
+            const int mat = w == 0 ? W_DA_L2T11_W : W_DA_L2T21_W;
+            const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
+            for (int hb = 0; hb < 4; ++hb)  // h1 block hb = (half, tile): channels half*30 + 16*tile + ...
+                add_block_group(p1, mat, 60, o0, rows, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
+        }
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 2; ++t) add_bias(p1, h == 0 ? W_DA_L1T12_B : W_DA_L1T22_B, 16 * t, std::min(16, 30 - 16 * t));
+    for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 2; ++t) add_bias(p1, w == 0 ? W_DA_L2T11_B : W_DA_L2T21_B, 16 * t, std::min(16, 30 - 16 * t));
+    p1.scal.push_back(g_params[W_DA_ACT11].off);
+    p1.scal.push_back(g_params[W_DA_ACT12].off);
+    p1.scal.push_back(g_params[W_DA_ACT1].off);
+    p1.scal.push_back(g_params[W_DA_ACT21].off);
+    p1.scal.push_back(g_params[W_DA_ACT22].off);
+    // ---- stage 2
+    for (int w = 0; w < 2; ++w) {
+        const int mat = w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W;
+        for (int hb = 0; hb < 4; ++hb)
+            add_block_group(p2, mat, 94, 0, 15, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
+        add_block_group(p2, mat, 94, 0, 15, 60, 16);
+        add_block_group(p2, mat, 94, 0, 15, 76, 14);
+        const int c0s[1] = {90}, nqs[1] = {4};
+        add_scalar_group(p2, mat, 94, 0, 15, c0s, nqs, 1);
+    }
+    for (int t = 0; t < 2; ++t) {
+        const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
+        add_block_group(p2, W_BP_FC1_W, 33, o0, rows, 0, 15);    // o1 = x_latent[0:15]
+        add_block_group(p2, W_BP_FC1_W, 33, o0, rows, 15, 15);   // o2 = x_latent[15:30]
+        const int c0s[1] = {30}, nqs[1] = {3};
+        add_scalar_group(p2, W_BP_FC1_W, 33, o0, rows, c0s, nqs, 1);  // edge_attr (3)
+    }
+    add_bias(p2, W_DA_L2T12_B, 0, 15);
+    add_bias(p2, W_DA_L2T22_B, 0, 15);
+    add_bias(p2, W_BP_FC1_B, 0, 16);
+    add_bias(p2, W_BP_FC1_B, 16, 14);
+    p2.scal.push_back(g_params[W_DA_ACT2].off);
+    p2.scal.push_back(g_params[W_BP_ACT1].off);
+}
+
+__global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict__ steps, int n_groups,
+                       const BiasDesc* __restrict__ bias, int n_bias, const int32_t* __restrict__ scal, int n_scal,
+                       float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nw = n_groups * 256;
+    if (idx < nw) {
+        const int grp = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
+        const StepDesc d = steps[grp * 4 + r];
+        const int i = lane & 15, q = lane >> 4;
+        float v = 0.f;
+        if (d.mat_off >= 0 && i < d.rows && d.col[q] >= 0) v = raw[d.mat_off + (d.o0 + i) * d.ld + d.col[q]];
+        out[idx] = v;
+    } else if (idx < nw + n_bias * 16) {
+        const int k = idx - nw, t = k >> 4, i = k & 15;
+        const BiasDesc b = bias[t];
+        out[idx] = i < b.rows ? raw[b.off + b.o0 + i] : 0.f;
+    } else if (idx < nw + n_bias * 16 + 16) {
+        const int k = idx - nw - n_bias * 16;
+        out[idx] = k < n_scal ? raw[scal[k]] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float prelu1(float x, float a) { return x >= 0.f ? x : a * x; }
+__device__ __forceinline__ f32x4 prelu4(f32x4 x, float a) {
+    f32x4 y;
+    y.x = prelu1(x.x, a); y.y = prelu1(x.y, a); y.z = prelu1(x.z, a); y.w = prelu1(x.w, a);
+    return y;
+}
+// one 16-channel input block (k-steps r = 0..3) into one accumulator
+__device__ __forceinline__ f32x4 mma_block(f32x4 acc, const f32x4 w, const f32x4 x) {
+    acc = MFMA16(w.x, x.x, acc);
+    acc = MFMA16(w.y, x.y, acc);
+    acc = MFMA16(w.z, x.z, acc);
+    acc = MFMA16(w.w, x.w, acc);
+    return acc;
+}
+
+constexpr int ROWP = 32;   // padded row pitch (floats) of h0 / u / v : 30 channels + 2 zeros = 128 B
+constexpr int ROWP2 = 64;  // padded row pitch of h1: [tr1 0..15 | tr1 16..29,0,0 | tr2 0..15 | tr2 16..29,0,0]
+constexpr int WAVES = 4;   // waves per workgroup
+
+struct DaArgs {
+    int S, G, T;               // stations, owned source nodes, tiles per source node = ceil(S/16)
+    long long P_ext;           // rows incl. halo
+    const int32_t* sta_rowptr; const int32_t* sta_col;
+    const int32_t* src_rowptr; const int32_t* src_col;
+    const int32_t* order;
+    const float* slice; const float* mask; const float* edge_attr;
+    float* h0; float* h1; float* u; float* v;
+    float* part;               // [G*T, 32] bipartite partial sums
+    float* x_latent;           // optional [P,30]
+    const float* packed;       // packed A fragments for the stage
+};
+
+// wave-uniform work item iterator: XCD x sweeps its contiguous chunk of the processing order
+struct ItemIter {
+    int gbeg, gend;
+    long long it, stride, nitems;
+    int T;
+    __device__ ItemIter(int G, int T_, int wave) {
+        const int nx = (gridDim.x >= 8 && (gridDim.x & 7) == 0) ? 8 : 1;
+        const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+        gbeg = (int)((long long)G * xcd / nx);
+        gend = (int)((long long)G * (xcd + 1) / nx);
+        T = T_;
+        nitems = (long long)(gend - gbeg) * T;
+        it = (long long)lb * WAVES + wave;
+        stride = (long long)nbx * WAVES;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// stage 0: h0 = PReLU(init_trns [Slice || Mask])            module.py:87-88
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage0(DaArgs a) {
+    __shared__ f32x4 lw[(G0_GROUPS * 256 + 2 * 16 + 16) / 4];
+    for (int i = threadIdx.x; i < (G0_GROUPS * 256 + 2 * 16 + 16) / 4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G0_GROUPS * 64);
+    const float act = lbias[2 * 16];
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long ntiles = (a.P_ext + 15) >> 4;
+    for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
+        const long long p = tile * 16 + j;
+        const bool valid = p < a.P_ext;
+        const long long pc = valid ? p : a.P_ext - 1;
+        const float xs = a.slice[pc * 4 + q];
+        const float xm = a.mask[pc * 4 + q];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 acc = *(const f32x4*)(lbias + t * 16 + 4 * q);
+            const f32x4 w = lw[t * 64 + lane];
+            acc = MFMA16(w.x, xs, acc);
+            acc = MFMA16(w.y, xm, acc);
+            acc = prelu4(acc, act);
+            if (valid) *(f32x4*)(a.h0 + p * ROWP + 16 * t + 4 * q) = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: neighbour means of PReLU11/12(h0), layer-1 Linear pair, PReLU1, l2_t*_1 + PReLU21/22
+// module.py:90-95
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
+    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
+    const float* lscal = lbias + G1_BIAS * 16;
+    const float a11 = lscal[0], a12 = lscal[1], a1 = lscal[2], a21 = lscal[3], a22 = lscal[4];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        const int gi = w.gbeg + (int)(w.it / w.T);
+        const int tb = (int)(w.it % w.T);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
+#endif
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const long long p = (long long)g * S + sc;
+        // own row
+        const f32x4* own = (const f32x4*)(a.h0 + p * ROWP) + q;
+        const f32x4 x0 = own[0], x1 = own[4];
+        const float mq = a.mask[p * 4 + q];
+        // station-neighbour mean of PReLU11(h0): rows of the same source node
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
+            const float* base = a.h0 + (long long)g * S * ROWP + 4 * q;
+#pragma unroll 4
+            for (int e = eb; e < ee; ++e) {
+                const f32x4* r = (const f32x4*)(base + (long long)a.sta_col[e] * ROWP);
+                const f32x4 y0 = r[0], y1 = r[4];
+                n1a += prelu4(y0, a11);
+                n1b += prelu4(y1, a11);
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        // source-neighbour mean of PReLU12(h0): same station, neighbouring source nodes (wave-uniform list)
+        f32x4 n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
+            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
+            const float* base = a.h0 + (long long)sc * ROWP + 4 * q;
+#pragma unroll 5
+            for (int e = eb; e < ee; ++e) {
+                const int gn = __builtin_amdgcn_readfirstlane(a.src_col[e]);
+                const f32x4* r = (const f32x4*)(base + (long long)gn * S * ROWP);
+                const f32x4 y0 = r[0], y1 = r[4];
+                n2a += prelu4(y0, a12);
+                n2b += prelu4(y1, a12);
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + k * 16 + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = k >> 1, t = k & 1;
+            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 0) * 64 + lane], x0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = k >> 1, t = k & 1;
+            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 1) * 64 + lane], x1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = k >> 1, t = k & 1;
+            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 2) * 64 + lane], h == 0 ? n1a : n2a);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = k >> 1, t = k & 1;
+            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 3) * 64 + lane], h == 0 ? n1b : n2b);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = k >> 1, t = k & 1;
+            acc[k] = MFMA16(lw[G1_L1(h, t, 4) * 64 + lane].x, mq, acc[k]);
+            acc[k] = prelu4(acc[k], a1);                      // h1 block k
+            if (valid) *(f32x4*)(a.h1 + p * ROWP2 + 16 * k + 4 * q) = acc[k];
+        }
+        // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)
+        f32x4 uv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) uv[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) uv[k] = mma_block(uv[k], lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane], acc[hb]);
+        }
+        if (valid) {
+            *(f32x4*)(a.u + p * ROWP + 4 * q) = prelu4(uv[0], a21);
+            *(f32x4*)(a.u + p * ROWP + 16 + 4 * q) = prelu4(uv[1], a21);
+            *(f32x4*)(a.v + p * ROWP + 4 * q) = prelu4(uv[2], a22);
+            *(f32x4*)(a.v + p * ROWP + 16 + 4 * q) = prelu4(uv[3], a22);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: neighbour means of u / v, layer-2 Linear pair, PReLU2 -> x_latent; Bipartite fc1 + PReLU, mask
+// gate, and the per-tile station sum.                      module.py:94-96, :229
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        const int gi = w.gbeg + (int)(w.it / w.T);
+        const int tb = (int)(w.it % w.T);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
+#endif
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const long long p = (long long)g * S + sc;
+        const f32x4* own = (const f32x4*)(a.h1 + p * ROWP2) + q;
+        f32x4 hb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hb[k] = own[4 * k];
+        const float mq = a.mask[p * 4 + q];
+        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
+            const float* base = a.u + (long long)g * S * ROWP + 4 * q;
+#pragma unroll 4
+            for (int e = eb; e < ee; ++e) {
+                const f32x4* r = (const f32x4*)(base + (long long)a.sta_col[e] * ROWP);
+                n1a += r[0];
+                n1b += r[4];
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        f32x4 n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
+            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
+            const float* base = a.v + (long long)sc * ROWP + 4 * q;
+#pragma unroll 5
+            for (int e = eb; e < ee; ++e) {
+                const int gn = __builtin_amdgcn_readfirstlane(a.src_col[e]);
+                const f32x4* r = (const f32x4*)(base + (long long)gn * S * ROWP);
+                n2a += r[0];
+                n2b += r[4];
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        o[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            o[0] = mma_block(o[0], lw[G2_O(0, b) * 64 + lane], hb[b]);
+            o[1] = mma_block(o[1], lw[G2_O(1, b) * 64 + lane], hb[b]);
+        }
+        o[0] = mma_block(o[0], lw[G2_O(0, 4) * 64 + lane], n1a);
+        o[1] = mma_block(o[1], lw[G2_O(1, 4) * 64 + lane], n2a);
+        o[0] = mma_block(o[0], lw[G2_O(0, 5) * 64 + lane], n1b);
+        o[1] = mma_block(o[1], lw[G2_O(1, 5) * 64 + lane], n2b);
+        o[0] = MFMA16(lw[G2_O(0, 6) * 64 + lane].x, mq, o[0]);
+        o[1] = MFMA16(lw[G2_O(1, 6) * 64 + lane].x, mq, o[1]);
+        o[0] = prelu4(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
+        o[1] = prelu4(o[1], a2);   // x_latent[15:30]
+        if (a.x_latent != nullptr && valid) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * q + r < 15) {
+                    xl[4 * q + r] = o[0][r];
+                    xl[15 + 4 * q + r] = o[1][r];
+                }
+            }
+        }
+        // Bipartite message: m_p * PReLU_b1(fc1 [x_latent || edge_attr])
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 2 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 3 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            bp[t] = prelu4(bp[t], ab1);
+        }
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (!valid) mm = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = bp[t] * mm;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                v.x += __shfl_xor(v.x, d);
+                v.y += __shfl_xor(v.y, d);
+                v.z += __shfl_xor(v.z, d);
+                v.w += __shfl_xor(v.w, d);
+            }
+            if (j == 0) *(f32x4*)(a.part + ((long long)g * a.T + tb) * 32 + 16 * t + 4 * q) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small G-sized kernels: 32 lanes per source node (2 nodes per wave, 8 per workgroup), weights transposed
+// in LDS ([k][32], lane = output channel), inputs broadcast with width-32 shuffles.
+// ------------------------------------------------------------------------------------------------
+constexpr int NPB = 8;  // nodes per 256-thread block
+
+__device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
+    for (int i = threadIdx.x; i < ld * 32; i += blockDim.x) {  // dst[k*32 + c] = W[c][k] (c < rows) else 0
+        const int k = i >> 5, c = i & 31;
+        dst[i] = c < rows ? W[c * ld + k] : 0.f;
+    }
+}
+
+// Bipartite read-out: r_g = sum over tiles in fixed order; out = PReLU_b2(fc2 r_g)              module.py:229
+__global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part, int G, int T,
+                                                const float* __restrict__ raw, int off_w, int off_b, int off_a,
+                                                float* __restrict__ out) {
+    __shared__ float wt[30 * 32];
+    stage_transposed(wt, raw + off_w, 15, 30);
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float bias = c < 15 ? raw[off_b + c] : 0.f;
+    const float act = raw[off_a];
+    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
+        const int g = g0 + grp;
+        const bool ok = g < G;
+        float r = 0.f;
+        if (ok)
+            for (int tb = 0; tb < T; ++tb) r += part[((long long)g * T + tb) * 32 + c];
+        float o = bias;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * __shfl(r, k, 32);
+        if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
+    }
+}
+
+// out-degree of every source node (number of edges whose message source is j)
+__global__ void k_outdeg(const int32_t* __restrict__ col, long long E, int32_t* __restrict__ deg) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) atomicAdd(&deg[col[i]], 1);
+}
+
+struct SaArgs {
+    int G, C;
+    long long E;
+    const float* x_in; const float* pos;
+    const int32_t* rowptr; const int32_t* col; const int32_t* outdeg;
+    const float* raw;
+    int fc1_w, fc1_b, fc2_w, fc2_b, fg_w, fg_b, act1, act2, act3;
+    float scale_rel;
+    float* gpart;  // [gridDim][8] partial sums of outdeg * PReLU3(fglobal x)
+    float* glob;   // [8]
+    float* out;
+};
+
+// SpatialAggregation global term, pass 1: per-block partial of sum_j outdeg(j) PReLU3(fglobal x_j)  module.py:249
+template <int C>
+__global__ __launch_bounds__(256) void k_sa_global(SaArgs a) {
+    __shared__ float wt[C * 32];
+    __shared__ float red[NPB][8];
+    stage_transposed(wt, a.raw + a.fg_w, 5, C);
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float bias = c < 5 ? a.raw[a.fg_b + c] : 0.f;
+    const float act = a.raw[a.act3];
+    float acc = 0.f;
+    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
+        const int g = g0 + grp;
+        const bool ok = g < a.G;
+        const float x = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
+        float o = bias;
+#pragma unroll
+        for (int k = 0; k < C; ++k) o += wt[k * 32 + c] * __shfl(x, k, 32);
+        if (ok) acc += (float)a.outdeg[g] * prelu1(o, act);
+    }
+    if (c < 8) red[grp][c] = c < 5 ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int k = 0; k < NPB; ++k) s += red[k][threadIdx.x];
+        a.gpart[blockIdx.x * 8 + threadIdx.x] = s;
+    }
+}
+__global__ void k_sa_global_final(const float* __restrict__ gpart, int nblocks, float* __restrict__ glob) {
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += gpart[b * 8 + threadIdx.x];
+        glob[threadIdx.x] = s;
+    }
+}
+
+// SpatialAggregation message + mean + update                                                module.py:245,249
+template <int C>
+__global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
+    __shared__ float w1t[(C + 8) * 32];
+    __shared__ float w2t[(C + 30) * 32];
+    stage_transposed(w1t, a.raw + a.fc1_w, 30, C + 8);
+    stage_transposed(w2t, a.raw + a.fc2_w, 30, C + 30);
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float act1 = a.raw[a.act1], act2 = a.raw[a.act2];
+    const float b2 = c < 30 ? a.raw[a.fc2_b + c] : 0.f;
+    // message bias + global-term contribution (same for every edge)
+    float base = c < 30 ? a.raw[a.fc1_b + c] : 0.f;
+    {
+        const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) base += w1t[(C + 3 + m) * 32 + c] * (a.glob[m] * invE);
+    }
+    const float wp0 = w1t[(C + 0) * 32 + c], wp1 = w1t[(C + 1) * 32 + c], wp2 = w1t[(C + 2) * 32 + c];
+    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
+        const int i = g0 + grp;
+        const bool ok = i < a.G;
+        const int ic = ok ? i : a.G - 1;
+        const float xi = c < C ? a.x_in[(long long)ic * C + c] : 0.f;
+        const float pi0 = a.pos[ic * 3 + 0] / a.scale_rel, pi1 = a.pos[ic * 3 + 1] / a.scale_rel,
+                    pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
+        const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
+        // both half-waves must run the same number of shuffle rounds: loop to the wave-wide max degree
+        int nmax = ee - eb;
+        nmax = max(nmax, __shfl_xor(nmax, 32));
+        float asum = 0.f;
+        for (int k = 0; k < nmax; ++k) {
+            const bool live = k < ee - eb;
+            const int jn = live ? a.col[eb + k] : ic;
+            const float xj = c < C ? a.x_in[(long long)jn * C + c] : 0.f;
+            float m = base;
+#pragma unroll
+            for (int kk = 0; kk < C; ++kk) m += w1t[kk * 32 + c] * __shfl(xj, kk, 32);
+            m += wp0 * (pi0 - a.pos[jn * 3 + 0] / a.scale_rel);
+            m += wp1 * (pi1 - a.pos[jn * 3 + 1] / a.scale_rel);
+            m += wp2 * (pi2 - a.pos[jn * 3 + 2] / a.scale_rel);
+            if (live) asum += prelu1(m, act1);
+        }
+        const float av = asum / (float)max(ee - eb, 1);
+        float o = b2;
+#pragma unroll
+        for (int kk = 0; kk < C; ++kk) o += w2t[kk * 32 + c] * __shfl(xi, kk, 32);
+#pragma unroll
+        for (int kk = 0; kk < 30; ++kk) o += w2t[(C + kk) * 32 + c] * __shfl(av, kk, 32);
+        if (ok && c < 30) a.out[(long long)i * 30 + c] = prelu1(o, act2);
+    }
+}
+
+// de-pad rows of a workspace tensor for parity tests
+__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int nblk, int blkw, int blkv,
+                         float* __restrict__ dst) {
+    // row layout: nblk blocks of blkw floats, of which the first/second alternate (16, blkv) valid ...
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = nblk * 30;
+    if (idx >= rows * ncol) return;
+    const long long r = idx / ncol;
+    const int cc = (int)(idx % ncol);
+    const int half = cc / 30, ch = cc % 30;
+    dst[idx] = src[r * pitch + half * 32 + ch];
+    (void)blkw; (void)blkv;
+}
+
+}  // namespace
+
+// ================================================================================================
+// context + C ABI
+// ================================================================================================
+struct genie_ctx {
+    int S, G, G_ext, T;
+    float scale_rel;
+    long long P, P_ext, E_src;
+    int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
+    float* raw;
+    bool dirty;
+    StagePlan plan[3];
+    StepDesc* d_steps[3];
+    BiasDesc* d_bias[3];
+    int32_t* d_scal[3];
+    float* packed[3];
+    int num_cu;
+    // workspace offsets (floats)
+    size_t o_h0, o_h1, o_u, o_v, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_glob, ws_floats;
+};
+
+namespace {
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+void layout_ws(genie_ctx* c) {
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 64); return r; };
+    c->o_h0 = take((size_t)c->P_ext * ROWP);
+    c->o_h1 = take((size_t)c->P * ROWP2);
+    c->o_u = take((size_t)c->P * ROWP);
+    c->o_v = take((size_t)c->P_ext * ROWP);
+    c->o_part = take((size_t)c->G * c->T * 32);
+    c->o_sa0 = take((size_t)c->G * 32);
+    c->o_sa1 = take((size_t)c->G * 32);
+    c->o_bip = take((size_t)c->G * 16);
+    c->o_gpart = take(1024 * 8);
+    c->o_glob = take(64);
+    c->ws_floats = o;
+}
+
+template <typename T>
+int dev_copy(T** dst, const T* src_dev, size_t n) {
+    *dst = nullptr;
+    if (n == 0) n = 1;
+    HIP_TRY(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src_dev) HIP_TRY(hipMemcpy(*dst, src_dev, n * sizeof(T), hipMemcpyDeviceToDevice));
+    return GENIE_OK;
+}
+
+int ensure_packed(genie_ctx* c, hipStream_t st) {
+    if (!c->dirty) return GENIE_OK;
+    for (int s = 0; s < 3; ++s) {
+        const StagePlan& p = c->plan[s];
+        const int total = p.packed_floats();
+        k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
+                                                   (int)p.bias.size(), c->d_scal[s], (int)p.scal.size(), c->packed[s]);
+    }
+    HIP_TRY(hipGetLastError());
+    c->dirty = false;
+    return GENIE_OK;
+}
+
+int da_grid(const genie_ctx* c, long long nitems_waves, int blocks_per_cu) {
+    long long need = (nitems_waves + WAVES - 1) / WAVES;
+    long long cap = (long long)c->num_cu * blocks_per_cu;
+    long long g = std::min(need, cap);
+    g = std::max<long long>(8, (g + 7) / 8 * 8);
+    return (int)g;
+}
+
+DaArgs make_da_args(const genie_ctx* c, float* ws) {
+    DaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = c->S; a.G = c->G; a.T = c->T; a.P_ext = c->P_ext;
+    a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
+    a.order = c->order;
+    a.h0 = ws + c->o_h0; a.h1 = ws + c->o_h1; a.u = ws + c->o_u; a.v = ws + c->o_v; a.part = ws + c->o_part;
+    return a;
+}
+
+int check_ws(const genie_ctx* c, const void* ws) {
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    if (!ws) return fail(GENIE_ERR_ARG, "null workspace");
+    if (((uintptr_t)ws & 255) != 0) return fail(GENIE_ERR_ARG, "workspace must be 256-byte aligned");
+    return GENIE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int genie_version(void) { return 100; }
+const char* genie_last_error(void) { return g_err.c_str(); }
+
+int genie_weights_count(void) { init_registry(); return W_COUNT; }
+const char* genie_weights_name(int i) { init_registry(); return (i >= 0 && i < W_COUNT) ? g_params[i].name : ""; }
+int64_t genie_weights_numel(int i) { init_registry(); return (i >= 0 && i < W_COUNT) ? g_params[i].numel : -1; }
+
+int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, const int32_t* sta_rowptr,
+                     const int32_t* sta_col, const int32_t* src_rowptr, const int32_t* src_col,
+                     const int32_t* grid_order, float scale_rel) {
+    init_registry();
+    if (!out) return fail(GENIE_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (n_sta < 1 || n_grid < 1 || n_grid_ext < n_grid) return fail(GENIE_ERR_ARG, "bad n_sta / n_grid / n_grid_ext");
+    if (!sta_rowptr || !src_rowptr) return fail(GENIE_ERR_ARG, "null rowptr");
+    genie_ctx* c = new genie_ctx();
+    memset((void*)&c->S, 0, sizeof(int) * 4);
+    c->S = n_sta; c->G = n_grid; c->G_ext = n_grid_ext; c->T = (n_sta + 15) / 16;
+    c->scale_rel = scale_rel;
+    c->P = (long long)n_grid * n_sta; c->P_ext = (long long)n_grid_ext * n_sta;
+    int32_t e_sta = 0, e_src = 0;
+    HIP_TRY(hipMemcpy(&e_sta, sta_rowptr + n_sta, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&e_src, src_rowptr + n_grid, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (e_sta < 0 || e_src < 0) return fail(GENIE_ERR_ARG, "negative edge count in rowptr");
+    if ((e_sta > 0 && !sta_col) || (e_src > 0 && !src_col)) return fail(GENIE_ERR_ARG, "null col array");
+    c->E_src = e_src;
+    int rc;
+    if ((rc = dev_copy(&c->sta_rowptr, sta_rowptr, (size_t)n_sta + 1))) return rc;
+    if ((rc = dev_copy(&c->sta_col, sta_col, (size_t)e_sta))) return rc;
+    if ((rc = dev_copy(&c->src_rowptr, src_rowptr, (size_t)n_grid + 1))) return rc;
+    if ((rc = dev_copy(&c->src_col, src_col, (size_t)e_src))) return rc;
+    if (grid_order) {
+        if ((rc = dev_copy(&c->order, grid_order, (size_t)n_grid))) return rc;
+    } else {
+        std::vector<int32_t> id(n_grid);
+        for (int i = 0; i < n_grid; ++i) id[i] = i;
+        HIP_TRY(hipMalloc((void**)&c->order, sizeof(int32_t) * n_grid));
+        HIP_TRY(hipMemcpy(c->order, id.data(), sizeof(int32_t) * n_grid, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&c->outdeg, sizeof(int32_t) * (size_t)n_grid_ext));
+    HIP_TRY(hipMemset(c->outdeg, 0, sizeof(int32_t) * (size_t)n_grid_ext));
+    if (e_src > 0) k_outdeg<<<(e_src + 255) / 256, 256>>>(c->src_col, e_src, c->outdeg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc((void**)&c->raw, sizeof(float) * g_raw_total));
+    HIP_TRY(hipMemset(c->raw, 0, sizeof(float) * g_raw_total));
+    build_plans(c->plan[0], c->plan[1], c->plan[2]);
+    if (c->plan[0].n_groups() != G0_GROUPS || c->plan[1].n_groups() != G1_GROUPS || c->plan[2].n_groups() != G2_GROUPS ||
+        (int)c->plan[1].bias.size() != G1_BIAS || (int)c->plan[2].bias.size() != G2_BIAS)
+        return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
+    for (int s = 0; s < 3; ++s) {
+        const StagePlan& p = c->plan[s];
+        HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
+        HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_bias[s], sizeof(BiasDesc) * p.bias.size()));
+        HIP_TRY(hipMemcpy(c->d_bias[s], p.bias.data(), sizeof(BiasDesc) * p.bias.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_scal[s], sizeof(int32_t) * 16));
+        HIP_TRY(hipMemcpy(c->d_scal[s], p.scal.data(), sizeof(int32_t) * p.scal.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
+    }
+    c->dirty = true;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    layout_ws(c);
+    HIP_TRY(hipDeviceSynchronize());
+    *out = c;
+    return GENIE_OK;
+}
+
+int genie_ctx_destroy(genie_ctx* c) {
+    if (!c) return GENIE_OK;
+    void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
+                    c->d_steps[0], c->d_steps[1], c->d_steps[2], c->d_bias[0], c->d_bias[1], c->d_bias[2],
+                    c->d_scal[0], c->d_scal[1], c->d_scal[2], c->packed[0], c->packed[1], c->packed[2]};
+    for (void* p : ptrs) (void)hipFree(p);
+    delete c;
+    return GENIE_OK;
+}
+
+int genie_weights_set(genie_ctx* c, const char* name, const float* dev_ptr, int64_t numel, void* stream) {
+    if (!c || !name || !dev_ptr) return fail(GENIE_ERR_ARG, "genie_weights_set: null argument");
+    for (int i = 0; i < W_COUNT; ++i) {
+        if (strcmp(name, g_params[i].name) == 0) {
+            if (numel != g_params[i].numel)
+                return fail(GENIE_ERR_ARG, std::string("genie_weights_set: wrong numel for ") + name);
+            HIP_TRY(hipMemcpyAsync(c->raw + g_params[i].off, dev_ptr, sizeof(float) * numel, hipMemcpyDeviceToDevice,
+                                   (hipStream_t)stream));
+            c->dirty = true;
+            return GENIE_OK;
+        }
+    }
+    return fail(GENIE_ERR_ARG, std::string("genie_weights_set: unknown parameter ") + name);
+}
+
+int64_t genie_weights_offset(int i) { init_registry(); return (i >= 0 && i < W_COUNT) ? g_params[i].off : -1; }
+int64_t genie_weights_blob_floats(void) { init_registry(); return g_raw_total; }
+
+int genie_weights_set_blob(genie_ctx* c, const float* blob_dev, int64_t n_floats, void* stream) {
+    if (!c || !blob_dev) return fail(GENIE_ERR_ARG, "genie_weights_set_blob: null argument");
+    if (n_floats != g_raw_total) return fail(GENIE_ERR_ARG, "genie_weights_set_blob: wrong blob size");
+    HIP_TRY(hipMemcpyAsync(c->raw, blob_dev, sizeof(float) * n_floats, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->dirty = true;
+    return GENIE_OK;
+}
+
+int genie_weights_commit(genie_ctx* c, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    return ensure_packed(c, (hipStream_t)stream);
+}
+
+size_t genie_workspace_bytes(const genie_ctx* c) { return c ? c->ws_floats * sizeof(float) : 0; }
+
+int genie_da_stage0(genie_ctx* c, const float* slice, const float* mask, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!slice || !mask) return fail(GENIE_ERR_ARG, "genie_da_stage0: null input");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    DaArgs a = make_da_args(c, (float*)ws);
+    a.slice = slice; a.mask = mask; a.packed = c->packed[0];
+    const long long ntiles = (c->P_ext + 15) / 16;
+    k_stage0<<<da_grid(c, ntiles, 8), 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_da_stage1(genie_ctx* c, const float* mask, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!mask) return fail(GENIE_ERR_ARG, "genie_da_stage1: null mask");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    DaArgs a = make_da_args(c, (float*)ws);
+    a.mask = mask; a.packed = c->packed[1];
+    k_stage1<<<da_grid(c, (long long)c->G * c->T, 4), 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_v : nullptr; }
+int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWP; }
+
+int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out,
+                              float* bip_out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!mask || !edge_attr || !bip_out) return fail(GENIE_ERR_ARG, "genie_da_stage2_bipartite: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    DaArgs a = make_da_args(c, (float*)ws);
+    a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[2];
+    k_stage2<<<da_grid(c, (long long)c->G * c->T, 4), 256, 0, st>>>(a);
+    const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
+    k_bip_out<<<nb, 256, 0, st>>>(a.part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off,
+                                  g_params[W_BP_ACT2].off, bip_out);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_spatial_agg_fwd(genie_ctx* c, int layer, const float* x_in, const float* pos, float* out, void* ws,
+                          void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (layer < 1 || layer > 3) return fail(GENIE_ERR_ARG, "genie_spatial_agg_fwd: layer must be 1, 2 or 3");
+    if (!x_in || !pos || !out) return fail(GENIE_ERR_ARG, "genie_spatial_agg_fwd: null argument");
+    if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_spatial_agg_fwd needs an unsharded source graph");
+    hipStream_t st = (hipStream_t)stream;
+    const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
+    SaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src;
+    a.x_in = x_in; a.pos = pos; a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg;
+    a.raw = c->raw;
+    a.fc1_w = g_params[base + 0].off; a.fc1_b = g_params[base + 1].off;
+    a.fc2_w = g_params[base + 2].off; a.fc2_b = g_params[base + 3].off;
+    a.fg_w = g_params[base + 4].off; a.fg_b = g_params[base + 5].off;
+    a.act1 = g_params[base + 6].off; a.act2 = g_params[base + 7].off; a.act3 = g_params[base + 8].off;
+    a.scale_rel = c->scale_rel;
+    a.gpart = (float*)ws + c->o_gpart; a.glob = (float*)ws + c->o_glob; a.out = out;
+    const int nb_g = std::min((c->G + NPB - 1) / NPB, 256);
+    const int nb_a = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
+    if (layer == 1) {
+        k_sa_global<15><<<nb_g, 256, 0, st>>>(a);
+        k_sa_global_final<<<1, 64, 0, st>>>(a.gpart, nb_g, a.glob);
+        k_sa_apply<15><<<nb_a, 256, 0, st>>>(a);
+    } else {
+        k_sa_global<30><<<nb_g, 256, 0, st>>>(a);
+        k_sa_global_final<<<1, 64, 0, st>>>(a.gpart, nb_g, a.glob);
+        k_sa_apply<30><<<nb_a, 256, 0, st>>>(a);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* pos,
+                   float* x_spatial_out, float* x_latent_out, float* bip_out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!x_spatial_out || !pos) return fail(GENIE_ERR_ARG, "genie_path_fwd: null argument");
+    float* w = (float*)ws;
+    float* bip = bip_out ? bip_out : w + c->o_bip;
+    if ((rc = genie_da_stage0(c, slice, mask, ws, stream))) return rc;
+    if ((rc = genie_da_stage1(c, mask, ws, stream))) return rc;
+    if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
+    if ((rc = genie_spatial_agg_fwd(c, 1, bip, pos, w + c->o_sa0, ws, stream))) return rc;
+    if ((rc = genie_spatial_agg_fwd(c, 2, w + c->o_sa0, pos, w + c->o_sa1, ws, stream))) return rc;
+    if ((rc = genie_spatial_agg_fwd(c, 3, w + c->o_sa1, pos, x_spatial_out, ws, stream))) return rc;
+    return GENIE_OK;
+}
+
+int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!out) return fail(GENIE_ERR_ARG, "genie_ws_export: null out");
+    float* w = (float*)ws;
+    const float* src; long long rows; int pitch, nblk;
+    switch (which) {
+        case 0: src = w + c->o_h0; rows = c->P_ext; pitch = ROWP; nblk = 1; break;
+        case 1: src = w + c->o_h1; rows = c->P; pitch = ROWP2; nblk = 2; break;
+        case 2: src = w + c->o_u; rows = c->P; pitch = ROWP; nblk = 1; break;
+        case 3: src = w + c->o_v; rows = c->P; pitch = ROWP; nblk = 1; break;
+        default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..3");
+    }
+    const long long n = rows * nblk * 30;
+    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, nblk, 0, 0, out);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+}  // extern "C"

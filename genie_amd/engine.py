@@ -1,0 +1,197 @@
+"""Host-side owner of one libgenie_hip context: graphs in CSR form, weight mirror, workspace.
+
+PyTorch is plumbing here (device memory, current stream); every compute call goes through the C ABI
+of `include/genie_hip.h` with raw device pointers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name, shape=None):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s: expected shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    return t
+
+
+def csr_from_edges(edge_index, n_target):
+    """[2,E] edge list (row0 = j source, row1 = i target) -> (rowptr int32 [n+1], col int32 [E]);
+    in-edges grouped by target in stable edge order."""
+    ei = torch.as_tensor(edge_index).long().cpu()
+    if ei.numel() == 0:
+        return torch.zeros(n_target + 1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)
+    j, i = ei[0], ei[1]
+    if int(i.max()) >= n_target or int(i.min()) < 0:
+        raise ValueError("edge target out of range")
+    order = torch.sort(i, stable=True)[1]
+    deg = torch.bincount(i, minlength=n_target)
+    rowptr = torch.zeros(n_target + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    return rowptr.to(torch.int32), j[order].to(torch.int32).contiguous()
+
+
+def csr_from_table(nbr):
+    """Uniform-degree neighbour table [n, k] -> CSR."""
+    nbr = torch.as_tensor(nbr).to(torch.int32).cpu()
+    n, k = nbr.shape
+    rowptr = (torch.arange(n + 1, dtype=torch.int64) * k).to(torch.int32)
+    return rowptr, nbr.reshape(-1).contiguous()
+
+
+def morton_order(points):
+    """Space-filling-curve (Morton, 10 bits/axis) order of a point set: int32 permutation [n]."""
+    x = np.asarray(points, dtype=np.float64)
+    lo, hi = x.min(0), x.max(0)
+    q = np.clip(((x - lo) / np.maximum(hi - lo, 1e-9) * 1023.0).astype(np.int64), 0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return np.argsort(code, kind="stable").astype(np.int32)
+
+
+class HipPath(object):
+    """One libgenie_hip context bound to the current CUDA(HIP) device.
+
+    sta_csr / src_csr: (rowptr, col) int32 CPU or GPU tensors for the base station graph and the base
+    source graph (in-edges grouped by target). `n_grid_ext > n_grid` marks halo source nodes (sharded use).
+    """
+
+    def __init__(self, n_sta, n_grid, sta_csr, src_csr, n_grid_ext=None, grid_order=None, scale_rel=30000.0,
+                 device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GenieHipError("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.n_sta, self.n_grid = int(n_sta), int(n_grid)
+        self.n_grid_ext = int(n_grid_ext) if n_grid_ext is not None else self.n_grid
+        self.scale_rel = float(scale_rel)
+        dev = self.device
+        self._keep = [t.to(dev, torch.int32).contiguous() for t in (sta_csr[0], sta_csr[1], src_csr[0], src_csr[1])]
+        order = None
+        if grid_order is not None:
+            order = torch.as_tensor(np.asarray(grid_order)).to(dev, torch.int32).contiguous()
+            if order.numel() != self.n_grid:
+                raise ValueError("grid_order must have n_grid entries")
+        self.ctx = ctypes.c_void_p(0)
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize()
+            rc = self.lib.genie_ctx_create(ctypes.byref(self.ctx), self.n_sta, self.n_grid, self.n_grid_ext,
+                                           _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
+                                           _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
+        _lib.check(rc, "genie_ctx_create")
+        self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
+        off = (-self.ws.data_ptr()) % 256
+        self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
+        # weight mirror
+        n = self.lib.genie_weights_count()
+        self.w_names = [self.lib.genie_weights_name(i).decode() for i in range(n)]
+        self.w_numel = [int(self.lib.genie_weights_numel(i)) for i in range(n)]
+        self.w_off = [int(self.lib.genie_weights_offset(i)) for i in range(n)]
+        self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
+        self._w_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None) and self.ctx.value:
+                self.lib.genie_ctx_destroy(self.ctx)
+                self.ctx = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+    @property
+    def n_prod(self):
+        return self.n_sta * self.n_grid
+
+    # ---- weights -------------------------------------------------------------------------------
+    def set_weights(self, named_tensors):
+        """Upload the path's parameters (dict name -> tensor, the reference's state_dict names)."""
+        with torch.no_grad():
+            for name, n, off in zip(self.w_names, self.w_numel, self.w_off):
+                if name not in named_tensors:
+                    raise KeyError("missing parameter %s" % name)
+                t = named_tensors[name]
+                if t.numel() != n:
+                    raise ValueError("parameter %s: expected %d elements, got %d" % (name, n, t.numel()))
+                self._blob[off:off + n].copy_(t.detach().reshape(-1))
+        _lib.check(self.lib.genie_weights_set_blob(self.ctx, _ptr(self._blob), self._blob.numel(), _stream()),
+                   "genie_weights_set_blob")
+
+    def sync_weights(self, params):
+        """Re-upload only when any of the parameter tensors changed (data_ptr / in-place version)."""
+        key = tuple((p.data_ptr(), p._version) for p in params.values())
+        if key != self._w_key:
+            self.set_weights(params)
+            self._w_key = key
+
+    # ---- stages --------------------------------------------------------------------------------
+    def da_stage0(self, Slice, Mask):
+        Slice = _f32(Slice, "Slice", (self.n_grid_ext * self.n_sta, 4))
+        Mask = _f32(Mask, "Mask", (self.n_grid_ext * self.n_sta, 4))
+        _lib.check(self.lib.genie_da_stage0(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage0")
+        return Slice, Mask
+
+    def da_stage1(self, Mask):
+        _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage1")
+
+    def da_stage2_bipartite(self, Mask, edge_attr, want_x_latent=False):
+        edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
+        x_latent = torch.empty((self.n_prod, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
+        bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_da_stage2_bipartite(self.ctx, _ptr(Mask), _ptr(edge_attr), _ptr(x_latent), _ptr(bip),
+                                                      self._ws_ptr, _stream()), "genie_da_stage2_bipartite")
+        return x_latent, bip
+
+    def spatial_agg(self, layer, x_in, pos):
+        c_in = 15 if layer == 1 else 30
+        x_in = _f32(x_in, "x_in", (self.n_grid, c_in))
+        pos = _f32(pos, "pos", (self.n_grid, 3))
+        out = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_spatial_agg_fwd(self.ctx, layer, _ptr(x_in), _ptr(pos), _ptr(out), self._ws_ptr,
+                                                  _stream()), "genie_spatial_agg_fwd")
+        return out
+
+    def path_fwd(self, Slice, Mask, edge_attr, pos, want_x_latent=False, want_bip=False):
+        """Fused DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3 (module.py:1010-1014)."""
+        P = self.n_prod
+        Slice = _f32(Slice, "Slice", (P, 4))
+        Mask = _f32(Mask, "Mask", (P, 4))
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        pos = _f32(pos, "pos", (self.n_grid, 3))
+        out = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        x_latent = torch.empty((P, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
+        bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device) if want_bip else None
+        _lib.check(self.lib.genie_path_fwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(pos), _ptr(out),
+                                           _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
+        return out, x_latent, bip
+
+    def export(self, which):
+        """Parity/debug: de-padded copy of a workspace intermediate (0=h0, 1=h1, 2=u, 3=v)."""
+        rows = self.n_grid_ext * self.n_sta if which == 0 else self.n_prod
+        cols = 60 if which == 1 else 30
+        out = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_ws_export(self.ctx, which, self._ws_ptr, _ptr(out), _stream()), "genie_ws_export")
+        return out

@@ -1,0 +1,356 @@
+"""Host-side mirror of the reference model interface for the hot path.
+
+Class / attribute / parameter names follow `/root/reference/Code/module.py` so that `state_dict()` keys
+(158 tensors) and the `forward*` / `set_adjacencies` signatures are drop-in compatible:
+
+    GCN_Detection_Network_extended            module.py:882-1020 (live variant, use_updated_model_definition=False)
+      .DataAggregation        DataAggregation          module.py:52-98     -> HIP (libgenie_hip)
+      .Bipartite_ReadIn       BipartiteGraphOperator   module.py:214-229   -> HIP
+      .SpatialAggregation1..3 SpatialAggregation       module.py:231-249   -> HIP
+      .SpatialDirect / .TemporalAttention / .SpatialAttention               module.py:251-331 (read-out, PyTorch-ROCm)
+
+The three starred modules have NO PyTorch implementation here: their `forward` hands device pointers to
+`libgenie_hip.so` and raises if the library or a GPU is missing (no CPU / eager fallback).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import engine as _engine
+from . import graph as _graph
+
+SCALE_REL = 30000.0         # config.yaml:73
+KERNEL_SIG_T = 3.0          # train_config.yaml:17
+SCALE_T = 3.0 * KERNEL_SIG_T  # module.py:40
+EPS = 5.0 * KERNEL_SIG_T      # module.py:41
+
+
+def _path_param_dict(net):
+    """state_dict-name -> Parameter for the modules that run in HIP."""
+    out = {}
+    for mod_name in ("DataAggregation", "Bipartite_ReadIn", "SpatialAggregation1", "SpatialAggregation2",
+                     "SpatialAggregation3"):
+        mod = getattr(net, mod_name)
+        for n, p in mod.named_parameters():
+            out[mod_name + "." + n] = p
+    return out
+
+
+class DataAggregation(nn.Module):
+    """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
+    applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
+
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4):
+        super().__init__()
+        self.in_channels, self.out_channels, self.n_hidden = in_channels, out_channels, n_hidden
+        self.activate = nn.PReLU()
+        self.init_trns = nn.Linear(in_channels + n_dim_mask, n_hidden)
+        self.l1_t1_1 = nn.Linear(n_hidden, n_hidden)
+        self.l1_t1_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.l1_t2_1 = nn.Linear(in_channels, n_hidden)
+        self.l1_t2_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.activate11 = nn.PReLU()
+        self.activate12 = nn.PReLU()
+        self.activate1 = nn.PReLU()
+        self.l2_t1_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t1_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.l2_t2_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t2_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.activate21 = nn.PReLU()
+        self.activate22 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+class BipartiteGraphOperator(nn.Module):
+    """Parameters of reference `BipartiteGraphOperator` (module.py:215-222)."""
+
+    def __init__(self, ndim_in, ndim_out, ndim_edges=3):
+        super().__init__()
+        self.fc1 = nn.Linear(ndim_in + ndim_edges, ndim_in)
+        self.fc2 = nn.Linear(ndim_in, ndim_out)
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+class SpatialAggregation(nn.Module):
+    """Parameters of reference `SpatialAggregation` (module.py:232-241)."""
+
+    def __init__(self, in_channels, out_channels, scale_rel=SCALE_REL, n_dim=3, n_global=5, n_hidden=30):
+        super().__init__()
+        self.fc1 = nn.Linear(in_channels + n_dim + n_global, n_hidden)
+        self.fc2 = nn.Linear(n_hidden + in_channels, out_channels)
+        self.fglobal = nn.Linear(in_channels, n_global)
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+        self.activate3 = nn.PReLU()
+        self.scale_rel = scale_rel
+
+
+class SpatialDirect(nn.Module):
+    """module.py:251-260."""
+
+    def __init__(self, inpt_dim, out_channels):
+        super().__init__()
+        self.f_direct = nn.Linear(inpt_dim, out_channels)
+        self.activate = nn.PReLU()
+
+    def forward(self, inpts):
+        return self.activate(self.f_direct(inpts))
+
+
+def knn_query_edges(x_context, x_query, k):
+    """Exact kNN of each query in the context set on `x/1000` (module.py:282), evaluated in fp64 on the device.
+    Returns LongTensor [2, Q*k]: row 0 = context j, row 1 = query i (the `.flip(0)` layout)."""
+    xc = (x_context.double() / 1000.0)
+    xq = (x_query.double() / 1000.0)
+    k = min(k, xc.shape[0])
+    idx = torch.empty((xq.shape[0], k), dtype=torch.long, device=xq.device)
+    chunk = max(1, min(xq.shape[0], int(4e7 // max(1, xc.shape[0]))))
+    for a in range(0, xq.shape[0], chunk):
+        d = ((xq[a:a + chunk, None, :] - xc[None, :, :]) ** 2).sum(-1)
+        idx[a:a + chunk] = torch.topk(d, k, dim=1, largest=False, sorted=True)[1]
+    row_q = torch.arange(xq.shape[0], device=xq.device).repeat_interleave(k)
+    return torch.stack([idx.reshape(-1), row_q], dim=0)
+
+
+class SpatialAttention(nn.Module):
+    """module.py:262-297 (kNN k=10 of the queries into the grid, per-edge q/c/v, segment softmax, mean over heads)."""
+
+    def __init__(self, inpt_dim, out_channels, n_dim, n_latent, n_hidden=30, n_heads=5, scale_rel=SCALE_REL):
+        super().__init__()
+        self.param_vector = nn.Parameter(nn.init.xavier_uniform_(torch.empty(1, n_heads, n_latent)))  # unused (module.py:266,292)
+        self.f_queries = nn.Linear(n_dim, n_heads * n_latent)
+        self.f_context = nn.Linear(inpt_dim + n_dim, n_heads * n_latent)
+        self.f_values = nn.Linear(inpt_dim + n_dim, n_heads * n_latent)
+        self.f_direct = nn.Linear(inpt_dim, out_channels)                                            # unused (module.py:270)
+        self.proj = nn.Linear(n_latent, out_channels)
+        self.scale = math.sqrt(n_latent)
+        self.n_heads, self.n_latent, self.scale_rel = n_heads, n_latent, scale_rel
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+        self._edge_cache = {}
+
+    def query_edges(self, x_query, x_context, k):
+        key = (x_query.data_ptr(), x_query._version, tuple(x_query.shape), x_context.data_ptr(), x_context._version,
+               tuple(x_context.shape), k)
+        hit = self._edge_cache.get("key") == key
+        if not hit:
+            self._edge_cache = {"key": key, "edges": knn_query_edges(x_context, x_query, k)}
+        return self._edge_cache["edges"]
+
+    def forward(self, inpts, x_query, x_context, k=10):
+        H, L = self.n_heads, self.n_latent
+        edge_index = self.query_edges(x_query, x_context, k)
+        j, i = edge_index[0], edge_index[1]
+        kk = edge_index.shape[1] // x_query.shape[0]
+        edge_attr = (x_query[i] - x_context[j]) / self.scale_rel
+        x_j = inpts[j]
+        cat = torch.cat((x_j, edge_attr), dim=-1)
+        q = self.f_queries(edge_attr).view(-1, H, L)
+        c = self.f_context(cat).view(-1, H, L)
+        v = self.f_values(cat).view(-1, H, L)
+        alpha = self.activate1((q * c).sum(-1) / self.scale)                       # [E, H]
+        # segment softmax over the k edges of each query (edges are grouped by query, k each)
+        alpha = alpha.view(-1, kk, H)
+        alpha = alpha - alpha.max(dim=1, keepdim=True)[0]
+        alpha = alpha.exp()
+        alpha = alpha / (alpha.sum(dim=1, keepdim=True) + 1e-16)
+        agg = (alpha.unsqueeze(-1) * v.view(-1, kk, H, L)).sum(dim=1)               # [Q, H, L]
+        return self.activate2(self.proj(agg.mean(1)))
+
+
+class TemporalAttention(nn.Module):
+    """module.py:299-331 (dense: score * value, mean over heads; no softmax)."""
+
+    def __init__(self, inpt_dim, out_channels, n_latent, n_hidden=30, n_heads=5, scale_t=SCALE_T):
+        super().__init__()
+        self.temporal_query_1 = nn.Linear(1, n_hidden)
+        self.temporal_query_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.f_context_1 = nn.Linear(inpt_dim, n_hidden)
+        self.f_context_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.f_values_1 = nn.Linear(inpt_dim, n_hidden)
+        self.f_values_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.proj_1 = nn.Linear(n_latent, n_hidden)
+        self.proj_2 = nn.Linear(n_hidden, out_channels)
+        self.scale = math.sqrt(n_latent)
+        self.n_heads, self.n_latent, self.scale_t = n_heads, n_latent, scale_t
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+        self.activate3 = nn.PReLU()
+        self.activate4 = nn.PReLU()
+        self.activate5 = nn.PReLU()
+
+    def forward(self, inpts, t_query):
+        H, L = self.n_heads, self.n_latent
+        context = self.f_context_2(self.activate1(self.f_context_1(inpts))).view(-1, H, L)
+        values = self.f_values_2(self.activate2(self.f_values_1(inpts))).view(-1, H, L)
+        query = self.temporal_query_2(self.activate3(self.temporal_query_1(t_query / self.scale_t))).view(-1, H, L)
+        score = torch.einsum("nhl,thl->nth", context, query) / self.scale           # [N, T, H]
+        z = torch.einsum("nth,nhl->ntl", score, values) / H                         # mean over heads
+        return self.proj_2(self.activate5(self.proj_1(self.activate4(z))))
+
+
+class _ParamsOnly(nn.Module):
+    """Association-head parameter containers (not on the hot path): keep the reference's
+    state_dict keys so checkpoints load strictly; `forward` is not provided yet."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            "%s: association heads (module.py:333-775) are outside the accelerated path in this round; "
+            "use forward_fixed_source for (y, x)" % type(self).__name__)
+
+
+class BipartiteGraphReadOutOperator(_ParamsOnly):
+    def __init__(self, ndim_in, ndim_out, ndim_edges=3):
+        super().__init__()
+        self.fc1 = nn.Linear(ndim_in + ndim_edges, ndim_in)
+        self.fc2 = nn.Linear(ndim_in, ndim_out)
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+class DataAggregationAssociationPhase(_ParamsOnly):
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5):
+        super().__init__()
+        self.activate = nn.PReLU()
+        self.init_trns = nn.Linear(in_channels + n_dim_latent + n_dim_mask, n_hidden)
+        self.l1_t1_1 = nn.Linear(n_hidden, n_hidden)
+        self.l1_t1_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.l1_t2_1 = nn.Linear(n_hidden, n_hidden)
+        self.l1_t2_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.activate11 = nn.PReLU()
+        self.activate12 = nn.PReLU()
+        self.activate1 = nn.PReLU()
+        self.l2_t1_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t1_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.l2_t2_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t2_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.activate21 = nn.PReLU()
+        self.activate22 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+class LocalSliceLgCollapse(_ParamsOnly):
+    def __init__(self, ndim_in, ndim_out, n_edge=2, n_hidden=30):
+        super().__init__()
+        self.fc1 = nn.Linear(ndim_in + n_edge, n_hidden)
+        self.fc2 = nn.Linear(n_hidden, ndim_out)
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+class StationSourceAttentionMergedPhases(_ParamsOnly):
+    def __init__(self, ndim_src_in, ndim_arv_in, ndim_out, n_latent, ndim_extra=1, n_heads=5, n_hidden=30):
+        super().__init__()
+        self.f_arrival_query_1 = nn.Linear(2 * ndim_arv_in + 6, n_hidden)
+        self.f_arrival_query_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.f_src_context_1 = nn.Linear(ndim_src_in + ndim_extra + 2, n_hidden)
+        self.f_src_context_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.f_values_1 = nn.Linear(2 * ndim_arv_in + ndim_extra + 7, n_hidden)
+        self.f_values_2 = nn.Linear(n_hidden, n_heads * n_latent)
+        self.proj_1 = nn.Linear(n_latent, n_hidden)
+        self.proj_2 = nn.Linear(n_hidden, ndim_out)
+        self.activate1 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+        self.activate3 = nn.PReLU()
+        self.activate4 = nn.PReLU()
+
+
+class GCN_Detection_Network_extended(nn.Module):
+    """Drop-in for the reference class of the same name (module.py:882-1020).
+
+    `forward_fixed_source` (module.py:999) runs DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3
+    as ONE fused call into libgenie_hip (`genie_path_fwd`) on the graphs cached by `set_adjacencies`, then the
+    read-out heads on PyTorch-ROCm. `use_absolute_pos=True` (config.yaml:92, +6 input channels) is not
+    supported by the kernels and raises.
+    """
+
+    def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda"):
+        super().__init__()
+        if use_absolute_pos:
+            raise NotImplementedError("use_absolute_pos=True is not supported by the HIP path")
+        self.DataAggregation = DataAggregation(4, 15).to(device)
+        self.Bipartite_ReadIn = BipartiteGraphOperator(30, 15, ndim_edges=3).to(device)
+        self.SpatialAggregation1 = SpatialAggregation(15, 30, scale_rel=scale_rel).to(device)
+        self.SpatialAggregation2 = SpatialAggregation(30, 30, scale_rel=scale_rel).to(device)
+        self.SpatialAggregation3 = SpatialAggregation(30, 30, scale_rel=scale_rel).to(device)
+        self.SpatialDirect = SpatialDirect(30, 30).to(device)
+        self.SpatialAttention = SpatialAttention(30, 30, 3, 15, scale_rel=scale_rel).to(device)
+        self.TemporalAttention = TemporalAttention(30, 1, 15).to(device)
+        self.BipartiteGraphReadOutOperator = BipartiteGraphReadOutOperator(30, 15).to(device)
+        self.DataAggregationAssociationPhase = DataAggregationAssociationPhase(15, 15).to(device)
+        self.LocalSliceLgCollapseP = LocalSliceLgCollapse(30, 15).to(device)
+        self.LocalSliceLgCollapseS = LocalSliceLgCollapse(30, 15).to(device)
+        self.Arrivals = StationSourceAttentionMergedPhases(30, 15, 2, 15, n_heads=3).to(device)
+        self.use_absolute_pos = use_absolute_pos
+        self.scale_rel = scale_rel
+        self.ftrns1 = ftrns1
+        self.ftrns2 = ftrns2
+        self._hip = None
+        self._path_params = None
+        self._edge_attr = None
+
+    # ---- graphs --------------------------------------------------------------------------------
+    def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src):
+        order = _engine.morton_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
+        dev = next(self.parameters()).device
+        self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
+                                    device=dev)
+        self._path_params = _path_param_dict(self)
+
+    def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
+                        A_edges_s, dt_partition, tlatent, pos_loc, pos_src):
+        """Same 12 arguments as module.py:941. The product edge lists are reduced to the base kNN graphs (the
+        Cartesian structure is verified) and handed to libgenie_hip once; nothing is rebuilt per window."""
+        self.A_in_sta, self.A_in_src = A_in_sta, A_in_src
+        self.A_src_in_edges, self.A_Lg_in_src = A_src_in_edges, A_Lg_in_src
+        self.A_src_in_sta, self.A_src = A_src_in_sta, A_src
+        self.A_edges_p, self.A_edges_s = A_edges_p, A_edges_s
+        self.dt_partition, self.tlatent = dt_partition, tlatent
+        n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
+        sta_nbr, src_nbr = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid)
+        src_from_A = _engine.csr_from_edges(A_src, n_grid)
+        src_csr = _engine.csr_from_table(src_nbr)
+        if not (torch.equal(src_from_A[0], src_csr[0]) and torch.equal(src_from_A[1], src_csr[1])):
+            raise ValueError("A_src is not the base graph of A_in_src")
+        self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src)
+        self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
+
+    def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src):
+        """Same effect as `set_adjacencies` from the BASE graphs only (process_utils.py:718-719), for sizes
+        where the explicit product edge lists cannot be materialised (config 4: 2.3 G edges)."""
+        n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
+        self.A_src = torch.as_tensor(A_src_src)
+        self._build_engine(_engine.csr_from_edges(A_sta_sta, n_sta), _engine.csr_from_edges(A_src_src, n_grid),
+                           n_sta, n_grid, pos_src)
+        self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
+        self._hip.sync_weights(self._path_params)
+        return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
+
+    def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
+                             x_query_cart, t_query):
+        """module.py:999-1020. `tpick`, `ipick`, `phase_label` are accepted and ignored, as in the reference."""
+        x_spatial, _, _ = self._path(Slice, Mask, x_temp_cuda_cart)                       # :1010-1014
+        y_latent = self.SpatialDirect(x_spatial)                                           # :1015
+        y = self.TemporalAttention(y_latent, t_query)                                      # :1016
+        x = self.SpatialAttention(x_spatial, x_query_cart, x_temp_cuda_cart)               # :1017
+        x = self.TemporalAttention(x, t_query)                                             # :1018
+        return y, x
+
+    def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
+                      x_query_src_cart, t_query, tq_sample, trv_out_q):
+        raise NotImplementedError("forward_fixed (module.py:963) needs the association heads (SURVEY.md 8f-2); "
+                                  "this round accelerates forward_fixed_source")
+
+    def forward(self, Slice, Mask, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
+                A_edges_s, dt_partition, tlatent, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
+                x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q):
+        raise NotImplementedError("forward (module.py:908) needs the association heads (SURVEY.md 8f-2); "
+                                  "this round accelerates forward_fixed_source")

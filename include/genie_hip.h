@@ -1,0 +1,141 @@
+/*
+ * genie_hip.h — C ABI of libgenie_hip.so: MI355X (gfx950) kernels for GENIE's station <-> source-grid
+ * message-passing hot path.
+ *
+ * The reference (imcbrearty/GENIE) is pure Python: it has NO plugin / FFI interface. The boundary this
+ * library replaces is the body of three `torch.nn.Module.forward` methods and the third-party kernels they
+ * call (PyG `MessagePassing.propagate`, `torch_scatter.scatter`):
+ *
+ *   DataAggregation.forward            /root/reference/Code/module.py:85-98
+ *   BipartiteGraphOperator.forward     /root/reference/Code/module.py:224-229
+ *   SpatialAggregation.forward/message /root/reference/Code/module.py:243-249
+ *
+ * as called from GCN_Detection_Network_extended.forward / forward_fixed / forward_fixed_source
+ * (module.py:916-920, :973-977, :1010-1014). Each entry point below cites the lines it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous memory (e.g. torch `tensor.data_ptr()`), fp32 or int32;
+ *  - `stream` is a `hipStream_t` passed as `void*` (NULL = default stream); calls enqueue work and return,
+ *    they never synchronise and never allocate in the hot path;
+ *  - the caller owns every input / output / workspace buffer; the library owns only what `genie_ctx_create`
+ *    copies (base graphs, processing order) and its weight mirror; `genie_ctx_destroy` frees them;
+ *  - return value 0 = ok, negative = error; `genie_last_error()` gives the message (thread-local);
+ *  - product-graph node id p = g * n_sta + s (process_utils.py:720-722). Source nodes [0, n_grid) are OWNED by
+ *    this context; source nodes [n_grid, n_grid_ext) are HALO rows (owned by another GPU when the grid is
+ *    sharded over source nodes) that only appear as neighbours in `src_col`.
+ */
+#ifndef GENIE_HIP_H
+#define GENIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct genie_ctx genie_ctx;
+
+#define GENIE_OK 0
+#define GENIE_ERR_ARG (-1)
+#define GENIE_ERR_HIP (-2)
+#define GENIE_ERR_STATE (-3)
+
+/* Library / ABI version (major*100 + minor). */
+int genie_version(void);
+/* Message of the last error raised on this thread ("" if none). */
+const char* genie_last_error(void);
+
+/*
+ * Create a context for one (stations x source-grid) product graph.
+ * Replaces the graph objects cached by `set_adjacencies` (module.py:941-961); the inputs are the BASE kNN
+ * graphs of process_utils.py:718-719 in CSR form (in-edges grouped by target), not the [2,E] product lists
+ * of :720-721 — the Cartesian structure makes those implicit.
+ *   sta_rowptr[n_sta+1], sta_col[sta_rowptr[n_sta]]   : station j -> station i edges, col = neighbour j
+ *   src_rowptr[n_grid+1], src_col[src_rowptr[n_grid]] : source-node edges for OWNED nodes; col in [0,n_grid_ext)
+ *   grid_order[n_grid]   : processing order of owned source nodes (a space-filling-curve order keeps the
+ *                          neighbour rows of concurrently processed nodes in one XCD's L2); NULL = identity
+ * All index arrays are int32 DEVICE pointers and are copied.
+ */
+int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
+                     const int32_t* sta_rowptr, const int32_t* sta_col,
+                     const int32_t* src_rowptr, const int32_t* src_col,
+                     const int32_t* grid_order, float scale_rel);
+int genie_ctx_destroy(genie_ctx* ctx);
+
+/*
+ * Weight mirror. Parameter names are the reference's state_dict keys (e.g. "DataAggregation.l1_t1_2.weight",
+ * layout [out, in] row-major exactly as nn.Linear stores it; PReLU slopes are 1-element tensors).
+ * Enumerate with genie_weights_count/name/numel; copy with genie_weights_set (async D2D on `stream`).
+ * The MFMA-fragment repack happens lazily on the next forward call (or explicitly with genie_weights_commit).
+ */
+int genie_weights_count(void);
+const char* genie_weights_name(int i);
+int64_t genie_weights_numel(int i);
+int64_t genie_weights_offset(int i);      /* offset (floats) of parameter i inside the flat mirror */
+int64_t genie_weights_blob_floats(void);  /* size (floats) of the flat mirror; every offset is 16-B aligned */
+int genie_weights_set(genie_ctx* ctx, const char* name, const float* dev_ptr, int64_t numel, void* stream);
+/* Upload the whole mirror at once: `blob` holds every parameter at genie_weights_offset(i). */
+int genie_weights_set_blob(genie_ctx* ctx, const float* blob_dev, int64_t n_floats, void* stream);
+int genie_weights_commit(genie_ctx* ctx, void* stream);
+
+/* Bytes of caller-provided workspace the forward calls need (256-B aligned base required). */
+size_t genie_workspace_bytes(const genie_ctx* ctx);
+
+/*
+ * DataAggregation, stage 0 (module.py:87-88): h0 = PReLU(init_trns([Slice || Mask])) for ALL n_grid_ext*n_sta
+ * rows (owned + halo; halo rows of Slice/Mask are shipped raw, 8 floats per row, and recomputed locally).
+ *   slice, mask : [n_grid_ext*n_sta, 4] fp32. Result is kept in the workspace.
+ */
+int genie_da_stage0(genie_ctx* ctx, const float* slice, const float* mask, void* ws, void* stream);
+/*
+ * DataAggregation, stage 1 (module.py:90-95 up to the second pair of `propagate` calls): for OWNED rows
+ *   h1 = PReLU1([l1_t1_2[h0||mean_sta PReLU11(h0)||M] || l1_t2_2[h0||mean_src PReLU12(h0)||M]]),
+ *   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1). Kept in the workspace.
+ */
+int genie_da_stage1(genie_ctx* ctx, const float* mask, void* ws, void* stream);
+/*
+ * Halo access for the sharded case: device pointer / row pitch (floats) of the `v` activations inside the
+ * workspace, laid out [n_grid_ext*n_sta, pitch]; rows >= n_grid*n_sta must be filled by the caller (RCCL)
+ * between stage 1 and stage 2.
+ */
+float* genie_ws_v_ptr(const genie_ctx* ctx, void* ws);
+int genie_ws_v_pitch(const genie_ctx* ctx);
+/*
+ * DataAggregation stage 2 + BipartiteGraphOperator (module.py:94-96 and :224-229), OWNED rows:
+ *   x_latent = PReLU2([l2_t1_2[h1||mean_sta u||M] || l2_t2_2[h1||mean_src v||M]])          -> optional output
+ *   out_g    = PReLU_b2(fc2( sum_s max_c(M) * PReLU_b1(fc1[x_latent || edge_attr]) ))       -> bip_out[n_grid,15]
+ *   edge_attr : [n_grid*n_sta, 3] (`A_src_in_edges.x`, process_continuous_days.py:630)
+ *   x_latent_out : [n_grid*n_sta, 30] or NULL when the caller does not need it (forward_fixed_source)
+ */
+int genie_da_stage2_bipartite(genie_ctx* ctx, const float* mask, const float* edge_attr,
+                              float* x_latent_out, float* bip_out, void* ws, void* stream);
+/*
+ * SpatialAggregation (module.py:243-249; instances :889-891) on the source graph of this context.
+ * Requires an UNSHARDED source graph (n_grid_ext == n_grid): when the product graph is sharded over source
+ * nodes, the [G,15] Bipartite output is all-gathered and the three G-sized layers run on a second context
+ * that holds the whole source graph (n_sta = 1).
+ *   layer : 1, 2 or 3 (c_in = 15 for layer 1 else 30)
+ *   x_in  : [n_grid, c_in], pos : [n_grid, 3] metres (divided by scale_rel inside, module.py:245)
+ *   out   : [n_grid, 30]
+ * The edge-mean of PReLU3(fglobal(x_j)) over ALL edges (module.py:249) is an out-degree weighted node mean.
+ */
+int genie_spatial_agg_fwd(genie_ctx* ctx, int layer, const float* x_in, const float* pos, float* out,
+                          void* ws, void* stream);
+
+/*
+ * Fused single-GPU path = module.py:1010-1014: DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3.
+ *   x_spatial_out : [n_grid, 30]; x_latent_out optional ([P,30] or NULL); bip_out optional ([n_grid,15] or NULL)
+ */
+int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr,
+                   const float* pos, float* x_spatial_out, float* x_latent_out, float* bip_out,
+                   void* ws, void* stream);
+
+/* Debug/parity access to intermediates kept in the workspace (which: 0=h0 [P_ext,30], 1=h1 [P,60], 2=u [P,30],
+ * 3=v [P,30]); copies de-padded rows into `out` (async). */
+int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENIE_HIP_H */

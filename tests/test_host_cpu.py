@@ -1,0 +1,132 @@
+"""CPU: host logic — state_dict compatibility, graph layout contract, C-ABI symbols, failure behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from genie_amd import _lib, engine, graph, module, synthetic
+from tests.util import Case, GOLDEN_CASES
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    """The golden fixtures carry the reference model's full state_dict (158 tensors, 65 311 parameters)."""
+    c = Case("tiny_6x40")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+    sd = net.state_dict()
+    ref = c.weights
+    assert list(sd.keys()) == list(ref.keys())
+    assert len(sd) == 158
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    assert sum(p.numel() for p in net.parameters()) == 65311
+    net.load_state_dict({k: v.clone() for k, v in ref.items()}, strict=True)
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    _lib.build()
+    lib = _lib.load()
+    header = open(os.path.join(repo_root, "include", "genie_hip.h")).read()
+    declared = set(re.findall(r"\b(genie_[a-z0-9_]+)\s*\(", header))
+    declared.discard("genie_ctx")
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.genie_version() >= 100
+    names = [lib.genie_weights_name(i).decode() for i in range(lib.genie_weights_count())]
+    ref = Case("tiny_6x40").weights
+    for n_, i in zip(names, range(len(names))):
+        assert n_ in ref, n_
+        assert ref[n_].numel() == lib.genie_weights_numel(i)
+        assert lib.genie_weights_offset(i) % 4 == 0
+
+
+def test_cartesian_edges_roundtrip():
+    geom = synthetic.Geometry(7, 31, L=50e3, n_query=5, seed=3)
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, 7, 31)
+    assert A_in_sta.shape == (2, 7 * 31 * geom.k_sta) and A_in_src.shape == (2, 7 * 31 * geom.k_spc)
+    sta_nbr, src_nbr = graph.base_tables_from_product(A_in_sta, A_in_src, 7, 31)
+    assert torch.equal(sta_nbr, graph.neighbour_table(geom.A_sta_sta, 7))
+    assert torch.equal(src_nbr, graph.neighbour_table(geom.A_src_src, 31))
+    # every product edge stays inside one source node (sta graph) / one station (src graph)
+    assert torch.equal(A_in_sta[0] // 7, A_in_sta[1] // 7)
+    assert torch.equal(A_in_src[0] % 7, A_in_src[1] % 7)
+    assert torch.equal(A_src_in_prod[1], torch.arange(7 * 31) // 7)
+    assert torch.equal(A_src_in_sta[0], torch.arange(7 * 31) % 7)
+    bad = A_in_sta.clone()
+    bad[0, 5] = (bad[0, 5] + 7) % (7 * 31)
+    with pytest.raises(ValueError):
+        graph.base_tables_from_product(bad, A_in_src, 7, 31)
+
+
+def test_knn_graph_matches_bruteforce():
+    rng = np.random.default_rng(0)
+    x = rng.random((60, 3))
+    A = graph.knn_graph(x, 5)
+    d = ((x[:, None] - x[None]) ** 2).sum(-1)
+    np.fill_diagonal(d, np.inf)
+    want = np.argsort(d, axis=1)[:, :5]
+    assert np.array_equal(A[0].reshape(60, 5), want)
+    assert np.array_equal(A[1], np.repeat(np.arange(60), 5))
+
+
+def test_csr_and_morton():
+    ei = torch.tensor([[3, 1, 2, 0, 1], [0, 0, 2, 2, 1]])
+    rowptr, col = engine.csr_from_edges(ei, 4)
+    assert rowptr.tolist() == [0, 2, 3, 5, 5] and col.tolist() == [3, 1, 1, 2, 0]
+    order = engine.morton_order(np.random.default_rng(1).random((100, 3)))
+    assert sorted(order.tolist()) == list(range(100))
+
+
+def test_synthetic_window_semantics():
+    geom = synthetic.Geometry(12, 50, L=80e3, n_query=10, seed=5)
+    win = synthetic.make_window(geom, 300, seed=6)
+    S, G = 12, 50
+    assert win["Slice"].shape == (S * G, 4) and win["Mask"].shape == (S * G, 4)
+    assert win["n_picks"] == 300
+    assert np.array_equal(win["Mask"], (win["Slice"] > 0.01).astype(np.float32))
+    # brute-force check of feature 0 (nearest pick of any phase to the theoretical P arrival)
+    P = win["P"]
+    tt = geom.travel_times()
+    for g, s in [(0, 0), (17, 5), (49, 11)]:
+        t = P[P[:, 1] == s, 0]
+        want = np.exp(-0.5 * np.min(np.abs(t - tt[g, s, 0])) ** 2 / 9.0) if t.size else 0.0
+        assert abs(win["Slice"][g * S + s, 0] - want) < 1e-6
+    # phase-restricted features never exceed the any-phase ones
+    assert (win["Slice"][:, 2] <= win["Slice"][:, 0] + 1e-7).all()
+    assert (win["Slice"][:, 3] <= win["Slice"][:, 1] + 1e-7).all()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    c = Case("tiny_6x40")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr, edge_index=A_src_in_prod)
+    with pytest.raises(_lib.GenieHipError):
+        net.set_adjacencies(A_in_sta, A_in_src, ea, ea, A_src_in_sta, c.A_src_src, None, None, None, None,
+                            c.locs.float(), c.x_grid.float())
+    with pytest.raises(RuntimeError):
+        net.forward_fixed_source(c.Slice, c.Mask, None, None, None, c.locs.float(), c.x_grid.float(),
+                                 c.x_query.float(), c.t_query.float())
+
+
+def test_readout_heads_match_oracle_cpu():
+    """The PyTorch read-out heads (SpatialDirect / TemporalAttention / SpatialAttention) against the golden
+    vectors, fed with the reference's own sa3 — isolates the heads from the HIP path."""
+    for name in GOLDEN_CASES:
+        c = Case(name)
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+        net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+        with torch.no_grad():
+            sa3 = c.ref("sa3")
+            y = net.TemporalAttention(net.SpatialDirect(sa3), c.t_query.float())
+            xq = net.SpatialAttention(sa3, c.x_query.float(), c.x_grid.float())
+            x = net.TemporalAttention(xq, c.t_query.float())
+        assert float((y - c.ref("y")).abs().max()) < 1e-6
+        assert float((xq - c.ref("xq")).abs().max()) < 2e-6
+        assert float((x - c.ref("x")).abs().max()) < 1e-6
