@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "genie_hip.hip")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libgenie_hip.so")
+LIB_PATH = os.environ.get("GENIE_LIB_PATH", os.path.join(LIB_DIR, "libgenie_hip.so"))  # override: tuning builds only
 INCLUDE = os.path.join(REPO, "include")
 
 # every symbol include/genie_hip.h declares: (name, restype, argtypes)
@@ -47,20 +47,20 @@ class GenieHipError(RuntimeError):
     pass
 
 
-def build(verbose=False, extra_flags=()):
+def build(verbose=False, extra_flags=(), out_path=None):
     """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", INCLUDE, SRC, "-o", LIB_PATH] + list(extra_flags)
+           "-I", INCLUDE, SRC, "-o", out_path or LIB_PATH] + list(extra_flags)
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise GenieHipError("hipcc failed:\n" + r.stdout)
-    return LIB_PATH
+    return out_path or LIB_PATH
 
 
 _lib = None

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -23,6 +24,17 @@
 #include <vector>
 
 #include "genie_hip.h"
+
+// GENIE_TUNING=1 builds (tools/tune.py only) add run-time ablation switches (env GENIE_ABLATE) that SKIP parts of
+// a kernel to attribute its time; they break the results and are compiled out of the product library.
+#ifndef GENIE_TUNING
+#define GENIE_TUNING 0
+#endif
+#if GENIE_TUNING
+#define ABL(a, bit) (((a).abl >> (bit)) & 1)
+#else
+#define ABL(a, bit) 0
+#endif
 
 #ifndef GENIE_HOIST_WEIGHTS
 #define GENIE_HOIST_WEIGHTS 0
@@ -172,13 +184,15 @@ void add_bias(StagePlan& p, int vec, int o0, int rows) {
 #define G1_L1(h, t, b) (((h) * 2 + (t)) * 5 + (b))
 // stage 1: u/v groups (w = u/v, out tile t, input block hb = h1 block 0..3)
 #define G1_UV(w, t, hb) (20 + ((w) * 2 + (t)) * 4 + (hb))
-#define G1_GROUPS 36
+// stage 1: projected gather operands wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v (w, input tile b of u/v)
+#define G1_W(w, b) (36 + (w) * 2 + (b))
+#define G1_GROUPS 40
 #define G1_BIAS 8
-// stage 2: o1/o2 groups (w, b: 0..3 = h1 blocks, 4,5 = neighbour mean, 6 = Mask)
-#define G2_O(w, b) ((w) * 7 + (b))
+// stage 2: o1/o2 groups (w, b: 0..3 = h1 blocks, 4 = Mask); the neighbour-mean term arrives already projected
+#define G2_O(w, b) ((w) * 5 + (b))
 // stage 2: bipartite fc1 groups (out tile t, b: 0 = o1 block, 1 = o2 block, 2 = edge_attr)
-#define G2_BP(t, b) (14 + (t) * 3 + (b))
-#define G2_GROUPS 20
+#define G2_BP(t, b) (10 + (t) * 3 + (b))
+#define G2_GROUPS 16
 #define G2_BIAS 4
 
 void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
@@ -208,6 +222,11 @@ void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
             for (int hb = 0; hb < 4; ++hb)  // h1 block hb = (half, tile): channels half*30 + 16*tile + ...
                 add_block_group(p1, mat, 60, o0, rows, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
         }
+    // mean_N(W x) = W mean_N(x): project u / v through the neighbour-mean columns of l2_t1_2 / l2_t2_2 (15 x 30) here,
+    // so stage 2 gathers 16-float rows instead of 32-float rows and adds the mean straight into its accumulator
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < 2; ++b)
+            add_block_group(p1, w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W, 94, 0, 15, 60 + 16 * b, b ? 14 : 16);
     for (int h = 0; h < 2; ++h)
         for (int t = 0; t < 2; ++t) add_bias(p1, h == 0 ? W_DA_L1T12_B : W_DA_L1T22_B, 16 * t, std::min(16, 30 - 16 * t));
     for (int w = 0; w < 2; ++w)
@@ -222,8 +241,6 @@ void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
         const int mat = w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W;
         for (int hb = 0; hb < 4; ++hb)
             add_block_group(p2, mat, 94, 0, 15, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
-        add_block_group(p2, mat, 94, 0, 15, 60, 16);
-        add_block_group(p2, mat, 94, 0, 15, 76, 14);
         const int c0s[1] = {90}, nqs[1] = {4};
         add_scalar_group(p2, mat, 94, 0, 15, c0s, nqs, 1);
     }
@@ -267,7 +284,12 @@ __global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+#if GENIE_TUNING
+__device__ int g_abl_mfma;  // set from the host in tuning builds
+#define MFMA16(a, b, c) (g_abl_mfma ? ((c) + (a) * (b)) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0))
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 
 __device__ __forceinline__ float prelu1(float x, float a) { return x >= 0.f ? x : a * x; }
 __device__ __forceinline__ f32x4 prelu4(f32x4 x, float a) {
@@ -284,12 +306,57 @@ __device__ __forceinline__ f32x4 mma_block(f32x4 acc, const f32x4 w, const f32x4
     return acc;
 }
 
+// Sum over the neighbour rows col[eb..ee) of (ACT ? PReLU(row) : row) for the two 16-channel blocks of a
+// 32-float row, in edge order. Rows are fetched CH at a time (2*CH independent 16-B loads in flight per lane)
+// so a tile pays ceil(deg/CH) memory round trips instead of deg. `base` already points at this lane's
+// 4-channel slot (+4q); row(c) = base + c*stride. UNI: the edge list is wave-uniform (source-node graph).
+template <int CH, bool ACT, bool UNI, int NB>
+__device__ __forceinline__ void gather_sum(const float* __restrict__ base, long long stride,
+                                           const int32_t* __restrict__ col, int eb, int ee, float slope,
+                                           f32x4& s0, f32x4& s1) {
+    for (int e0 = eb; e0 < ee; e0 += CH) {
+        const f32x4* r[CH];
+        bool ok[CH];
+        int cv = 0;
+        if (UNI) cv = col[min(e0 + (int)(__lane_id() & (CH - 1)), ee - 1)];  // one coalesced load, broadcast below
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            ok[k] = e0 + k < ee;
+            const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : ee - 1];
+            r[k] = (const f32x4*)(base + (long long)c * stride);
+        }
+        f32x4 y0[CH], y1[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            y0[k] = r[k][0];
+            if (NB == 2) y1[k] = r[k][4];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (ok[k]) {
+                s0 += ACT ? prelu4(y0[k], slope) : y0[k];
+                if (NB == 2) s1 += ACT ? prelu4(y1[k], slope) : y1[k];
+            }
+        }
+    }
+}
+
+// streaming (non-temporal) accesses for tensors that are written once / read once by a kernel, so they do not
+// evict the neighbour rows the gathers want to find in L2
+__device__ __forceinline__ void st_stream(float* p, f32x4 v) { __builtin_nontemporal_store(v, (f32x4*)p); }
+__device__ __forceinline__ f32x4 ld_stream(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
+
 constexpr int ROWP = 32;   // padded row pitch (floats) of h0 / u / v : 30 channels + 2 zeros = 128 B
+constexpr int ROWW = 16;   // row pitch of the projected gather operands wu / wv: 15 channels + 1 zero = 64 B
 constexpr int ROWP2 = 64;  // padded row pitch of h1: [tr1 0..15 | tr1 16..29,0,0 | tr2 0..15 | tr2 16..29,0,0]
 constexpr int WAVES = 4;   // waves per workgroup
 
 struct DaArgs {
     int S, G, T;               // stations, owned source nodes, tiles per source node = ceil(S/16)
+    int seg;                   // source nodes per scheduling segment
+    int nt;                    // use streaming loads/stores for write-once/read-once tensors
+    int abl;                   // GENIE_TUNING only: ablation bits
+    int nxcd;                  // XCD-chunked sweep (8) or flat (1)
     long long P_ext;           // rows incl. halo
     const int32_t* sta_rowptr; const int32_t* sta_col;
     const int32_t* src_rowptr; const int32_t* src_col;
@@ -301,20 +368,35 @@ struct DaArgs {
     const float* packed;       // packed A fragments for the stage
 };
 
-// wave-uniform work item iterator: XCD x sweeps its contiguous chunk of the processing order
+// wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
+// its contiguous chunk of the processing order. Inside the chunk items are ordered in SEGMENTS of `seg` source
+// nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ... so that the
+// waves in flight on one XCD share the 2-KB (source node, station tile) row blocks of their source
+// neighbours in that XCD's L2 while the segment's own rows (station-neighbour gathers) stay resident too.
 struct ItemIter {
-    int gbeg, gend;
+    int gbeg, gend, T, seg;
     long long it, stride, nitems;
-    int T;
-    __device__ ItemIter(int G, int T_, int wave) {
-        const int nx = (gridDim.x >= 8 && (gridDim.x & 7) == 0) ? 8 : 1;
+    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave) {
+        const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
         const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
         gbeg = (int)((long long)G * xcd / nx);
         gend = (int)((long long)G * (xcd + 1) / nx);
         T = T_;
+        seg = seg_;
         nitems = (long long)(gend - gbeg) * T;
         it = (long long)lb * WAVES + wave;
         stride = (long long)nbx * WAVES;
+    }
+    // item -> (index into the processing order, station tile); 32-bit arithmetic (a chunk has < 2^31 items)
+    __device__ void decode(int& gi, int& tb) const {
+        const unsigned per_seg = (unsigned)seg * (unsigned)T;
+        const unsigned i = (unsigned)it;
+        const unsigned sidx = i / per_seg;
+        const unsigned rem = i - sidx * per_seg;
+        const int g0 = (int)(sidx * (unsigned)seg);
+        const int n = min(seg, gend - gbeg - g0);   // nodes in this (possibly last, short) segment
+        tb = (int)(rem / (unsigned)n);
+        gi = gbeg + g0 + (int)rem - tb * n;
     }
 };
 
@@ -364,10 +446,10 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
-        const int gi = w.gbeg + (int)(w.it / w.T);
-        const int tb = (int)(w.it % w.T);
+        int gi, tb;
+        w.decode(gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
@@ -385,13 +467,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
         {
             const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
             const float* base = a.h0 + (long long)g * S * ROWP + 4 * q;
-#pragma unroll 4
-            for (int e = eb; e < ee; ++e) {
-                const f32x4* r = (const f32x4*)(base + (long long)a.sta_col[e] * ROWP);
-                const f32x4 y0 = r[0], y1 = r[4];
-                n1a += prelu4(y0, a11);
-                n1b += prelu4(y1, a11);
-            }
+            if (!ABL(a, 0)) gather_sum<8, true, false, 2>(base, ROWP, a.sta_col, eb, ee, a11, n1a, n1b);
             const float inv = 1.f / (float)max(ee - eb, 1);
             n1a *= inv; n1b *= inv;
         }
@@ -401,14 +477,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
             const float* base = a.h0 + (long long)sc * ROWP + 4 * q;
-#pragma unroll 5
-            for (int e = eb; e < ee; ++e) {
-                const int gn = __builtin_amdgcn_readfirstlane(a.src_col[e]);
-                const f32x4* r = (const f32x4*)(base + (long long)gn * S * ROWP);
-                const f32x4 y0 = r[0], y1 = r[4];
-                n2a += prelu4(y0, a12);
-                n2b += prelu4(y1, a12);
-            }
+            if (!ABL(a, 1)) gather_sum<8, true, true, 2>(base, (long long)S * ROWP, a.src_col, eb, ee, a12, n2a, n2b);
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }
@@ -441,7 +510,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             const int h = k >> 1, t = k & 1;
             acc[k] = MFMA16(lw[G1_L1(h, t, 4) * 64 + lane].x, mq, acc[k]);
             acc[k] = prelu4(acc[k], a1);                      // h1 block k
-            if (valid) *(f32x4*)(a.h1 + p * ROWP2 + 16 * k + 4 * q) = acc[k];
+            if (valid && !ABL(a, 3)) { if (a.nt & 1) st_stream(a.h1 + p * ROWP2 + 16 * k + 4 * q, acc[k]); else *(f32x4*)(a.h1 + p * ROWP2 + 16 * k + 4 * q) = acc[k]; }
         }
         // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)
         f32x4 uv[4];
@@ -452,11 +521,17 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) uv[k] = mma_block(uv[k], lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane], acc[hb]);
         }
-        if (valid) {
-            *(f32x4*)(a.u + p * ROWP + 4 * q) = prelu4(uv[0], a21);
-            *(f32x4*)(a.u + p * ROWP + 16 + 4 * q) = prelu4(uv[1], a21);
-            *(f32x4*)(a.v + p * ROWP + 4 * q) = prelu4(uv[2], a22);
-            *(f32x4*)(a.v + p * ROWP + 16 + 4 * q) = prelu4(uv[3], a22);
+        // wu = l2_t1_2[:, 60:90] PReLU21(.), wv = l2_t2_2[:, 60:90] PReLU22(.): the operands stage 2 gathers
+        uv[0] = prelu4(uv[0], a21); uv[1] = prelu4(uv[1], a21);
+        uv[2] = prelu4(uv[2], a22); uv[3] = prelu4(uv[3], a22);
+        f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+        wu = mma_block(wu, lw[G1_W(0, 0) * 64 + lane], uv[0]);
+        wv = mma_block(wv, lw[G1_W(1, 0) * 64 + lane], uv[2]);
+        wu = mma_block(wu, lw[G1_W(0, 1) * 64 + lane], uv[1]);
+        wv = mma_block(wv, lw[G1_W(1, 1) * 64 + lane], uv[3]);
+        if (valid && !ABL(a, 3)) {
+            *(f32x4*)(a.u + p * ROWW + 4 * q) = wu;
+            *(f32x4*)(a.v + p * ROWW + 4 * q) = wv;
         }
     }
 }
@@ -477,10 +552,10 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
-        const int gi = w.gbeg + (int)(w.it / w.T);
-        const int tb = (int)(w.it % w.T);
+        int gi, tb;
+        w.decode(gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
@@ -492,51 +567,34 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
         const f32x4* own = (const f32x4*)(a.h1 + p * ROWP2) + q;
         f32x4 hb[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) hb[k] = own[4 * k];
+        for (int k = 0; k < 4; ++k) hb[k] = (a.nt & 2) ? ld_stream((const float*)(own + 4 * k)) : own[4 * k];
         const float mq = a.mask[p * 4 + q];
         const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
+        // neighbour means of the projected operands (16-float rows): they ARE the accumulator contributions
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n2a = {0.f, 0.f, 0.f, 0.f}, dummy = {0.f, 0.f, 0.f, 0.f};
         {
             const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            const float* base = a.u + (long long)g * S * ROWP + 4 * q;
-#pragma unroll 4
-            for (int e = eb; e < ee; ++e) {
-                const f32x4* r = (const f32x4*)(base + (long long)a.sta_col[e] * ROWP);
-                n1a += r[0];
-                n1b += r[4];
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n1a *= inv; n1b *= inv;
+            const float* base = a.u + (long long)g * S * ROWW + 4 * q;
+            if (!ABL(a, 0)) gather_sum<8, false, false, 1>(base, ROWW, a.sta_col, eb, ee, 0.f, n1a, dummy);
+            n1a *= 1.f / (float)max(ee - eb, 1);
         }
-        f32x4 n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
         {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.v + (long long)sc * ROWP + 4 * q;
-#pragma unroll 5
-            for (int e = eb; e < ee; ++e) {
-                const int gn = __builtin_amdgcn_readfirstlane(a.src_col[e]);
-                const f32x4* r = (const f32x4*)(base + (long long)gn * S * ROWP);
-                n2a += r[0];
-                n2b += r[4];
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n2a *= inv; n2b *= inv;
+            const float* base = a.v + (long long)sc * ROWW + 4 * q;
+            if (!ABL(a, 1)) gather_sum<8, false, true, 1>(base, (long long)S * ROWW, a.src_col, eb, ee, 0.f, n2a, dummy);
+            n2a *= 1.f / (float)max(ee - eb, 1);
         }
         f32x4 o[2];
-        o[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        o[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        o[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q) + n1a;
+        o[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q) + n2a;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             o[0] = mma_block(o[0], lw[G2_O(0, b) * 64 + lane], hb[b]);
             o[1] = mma_block(o[1], lw[G2_O(1, b) * 64 + lane], hb[b]);
         }
-        o[0] = mma_block(o[0], lw[G2_O(0, 4) * 64 + lane], n1a);
-        o[1] = mma_block(o[1], lw[G2_O(1, 4) * 64 + lane], n2a);
-        o[0] = mma_block(o[0], lw[G2_O(0, 5) * 64 + lane], n1b);
-        o[1] = mma_block(o[1], lw[G2_O(1, 5) * 64 + lane], n2b);
-        o[0] = MFMA16(lw[G2_O(0, 6) * 64 + lane].x, mq, o[0]);
-        o[1] = MFMA16(lw[G2_O(1, 6) * 64 + lane].x, mq, o[1]);
+        o[0] = MFMA16(lw[G2_O(0, 4) * 64 + lane].x, mq, o[0]);
+        o[1] = MFMA16(lw[G2_O(1, 4) * 64 + lane].x, mq, o[1]);
         o[0] = prelu4(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
         o[1] = prelu4(o[1], a2);   // x_latent[15:30]
         if (a.x_latent != nullptr && valid) {
@@ -628,8 +686,8 @@ struct SaArgs {
     const float* raw;
     int fc1_w, fc1_b, fc2_w, fc2_b, fg_w, fg_b, act1, act2, act3;
     float scale_rel;
-    float* gpart;  // [gridDim][8] partial sums of outdeg * PReLU3(fglobal x)
-    float* glob;   // [8]
+    float* gpart;  // [n_gpart][8] partial sums of outdeg * PReLU3(fglobal x)
+    int n_gpart;
     float* out;
 };
 
@@ -661,14 +719,6 @@ __global__ __launch_bounds__(256) void k_sa_global(SaArgs a) {
         a.gpart[blockIdx.x * 8 + threadIdx.x] = s;
     }
 }
-__global__ void k_sa_global_final(const float* __restrict__ gpart, int nblocks, float* __restrict__ glob) {
-    if (threadIdx.x < 8) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += gpart[b * 8 + threadIdx.x];
-        glob[threadIdx.x] = s;
-    }
-}
-
 // SpatialAggregation message + mean + update                                                module.py:245,249
 template <int C>
 __global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
@@ -680,12 +730,20 @@ __global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const float act1 = a.raw[a.act1], act2 = a.raw[a.act2];
     const float b2 = c < 30 ? a.raw[a.fc2_b + c] : 0.f;
+    // global term: fixed-order sum of the per-block partials written by k_sa_global (deterministic)
+    __shared__ float gsum[8];
+    if (threadIdx.x < 8) {
+        float sgl = 0.f;
+        for (int b = 0; b < a.n_gpart; ++b) sgl += a.gpart[b * 8 + threadIdx.x];
+        gsum[threadIdx.x] = sgl;
+    }
+    __syncthreads();
     // message bias + global-term contribution (same for every edge)
     float base = c < 30 ? a.raw[a.fc1_b + c] : 0.f;
     {
         const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
 #pragma unroll
-        for (int m = 0; m < 5; ++m) base += w1t[(C + 3 + m) * 32 + c] * (a.glob[m] * invE);
+        for (int m = 0; m < 5; ++m) base += w1t[(C + 3 + m) * 32 + c] * (gsum[m] * invE);
     }
     const float wp0 = w1t[(C + 0) * 32 + c], wp1 = w1t[(C + 1) * 32 + c], wp2 = w1t[(C + 2) * 32 + c];
     for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
@@ -722,18 +780,21 @@ __global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
     }
 }
 
+#if GENIE_TUNING
+__global__ void k_xcc_probe(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;  // HW_REG_XCC_ID[3:0]
+}
+#endif
+
 // de-pad rows of a workspace tensor for parity tests
-__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int nblk, int blkw, int blkv,
-                         float* __restrict__ dst) {
-    // row layout: nblk blocks of blkw floats, of which the first/second alternate (16, blkv) valid ...
+__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
+    // padded rows are [30 valid, 2 pad] per 32-float half (h0, h1) or [15 valid, 1 pad] (wu, wv)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncol = nblk * 30;
     if (idx >= rows * ncol) return;
     const long long r = idx / ncol;
     const int cc = (int)(idx % ncol);
-    const int half = cc / 30, ch = cc % 30;
-    dst[idx] = src[r * pitch + half * 32 + ch];
-    (void)blkw; (void)blkv;
+    const int off = ncol == 15 ? cc : (cc / 30) * 32 + cc % 30;
+    dst[idx] = src[r * pitch + off];
 }
 
 }  // namespace
@@ -754,6 +815,7 @@ struct genie_ctx {
     int32_t* d_scal[3];
     float* packed[3];
     int num_cu;
+    int seg, nt, bpc1, bpc2;   // tuning knobs (env GENIE_SEG / GENIE_NT / GENIE_BPC1 / GENIE_BPC2)
     // workspace offsets (floats)
     size_t o_h0, o_h1, o_u, o_v, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_glob, ws_floats;
 };
@@ -767,8 +829,8 @@ void layout_ws(genie_ctx* c) {
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 64); return r; };
     c->o_h0 = take((size_t)c->P_ext * ROWP);
     c->o_h1 = take((size_t)c->P * ROWP2);
-    c->o_u = take((size_t)c->P * ROWP);
-    c->o_v = take((size_t)c->P_ext * ROWP);
+    c->o_u = take((size_t)c->P * ROWW);
+    c->o_v = take((size_t)c->P_ext * ROWW);
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
     c->o_sa1 = take((size_t)c->G * 32);
@@ -814,6 +876,9 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.S = c->S; a.G = c->G; a.T = c->T; a.P_ext = c->P_ext;
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
+    a.seg = std::max(1, c->seg); a.nt = c->nt;
+    { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
+    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
     a.h0 = ws + c->o_h0; a.h1 = ws + c->o_h1; a.u = ws + c->o_u; a.v = ws + c->o_v; a.part = ws + c->o_part;
     return a;
 }
@@ -894,6 +959,24 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const char* e;
+        c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : 1;
+        c->nt = (e = getenv("GENIE_NT")) ? atoi(e) : 0;
+        // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
+        int occ1 = 0, occ2 = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
+        c->bpc1 = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1);
+        c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
+    }
+#if GENIE_TUNING
+    {
+        const char* e = getenv("GENIE_ABLATE");
+        int v = (e && (atoi(e) & 4)) ? 1 : 0;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_abl_mfma), &v, sizeof(int)));
+    }
+#endif
     layout_ws(c);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
@@ -965,13 +1048,13 @@ int genie_da_stage1(genie_ctx* c, const float* mask, void* ws, void* stream) {
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.packed = c->packed[1];
-    k_stage1<<<da_grid(c, (long long)c->G * c->T, 4), 256, 0, st>>>(a);
+    k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 
 float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_v : nullptr; }
-int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWP; }
+int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
 int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out,
                               float* bip_out, void* ws, void* stream) {
@@ -982,7 +1065,7 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[2];
-    k_stage2<<<da_grid(c, (long long)c->G * c->T, 4), 256, 0, st>>>(a);
+    k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
     const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
     k_bip_out<<<nb, 256, 0, st>>>(a.part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off,
                                   g_params[W_BP_ACT2].off, bip_out);
@@ -1009,16 +1092,15 @@ int genie_spatial_agg_fwd(genie_ctx* c, int layer, const float* x_in, const floa
     a.fg_w = g_params[base + 4].off; a.fg_b = g_params[base + 5].off;
     a.act1 = g_params[base + 6].off; a.act2 = g_params[base + 7].off; a.act3 = g_params[base + 8].off;
     a.scale_rel = c->scale_rel;
-    a.gpart = (float*)ws + c->o_gpart; a.glob = (float*)ws + c->o_glob; a.out = out;
-    const int nb_g = std::min((c->G + NPB - 1) / NPB, 256);
+    a.gpart = (float*)ws + c->o_gpart; a.out = out;
+    const int nb_g = std::min((c->G + NPB - 1) / NPB, 64);
+    a.n_gpart = nb_g;
     const int nb_a = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
     if (layer == 1) {
         k_sa_global<15><<<nb_g, 256, 0, st>>>(a);
-        k_sa_global_final<<<1, 64, 0, st>>>(a.gpart, nb_g, a.glob);
         k_sa_apply<15><<<nb_a, 256, 0, st>>>(a);
     } else {
         k_sa_global<30><<<nb_g, 256, 0, st>>>(a);
-        k_sa_global_final<<<1, 64, 0, st>>>(a.gpart, nb_g, a.glob);
         k_sa_apply<30><<<nb_a, 256, 0, st>>>(a);
     }
     HIP_TRY(hipGetLastError());
@@ -1041,21 +1123,29 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     return GENIE_OK;
 }
 
+#if GENIE_TUNING
+int genie_debug_xcc_map(int* out_dev, int nblocks, void* stream) {
+    k_xcc_probe<<<nblocks, 64, 0, (hipStream_t)stream>>>(out_dev);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+#endif
+
 int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!out) return fail(GENIE_ERR_ARG, "genie_ws_export: null out");
     float* w = (float*)ws;
-    const float* src; long long rows; int pitch, nblk;
+    const float* src; long long rows; int pitch, ncol;
     switch (which) {
-        case 0: src = w + c->o_h0; rows = c->P_ext; pitch = ROWP; nblk = 1; break;
-        case 1: src = w + c->o_h1; rows = c->P; pitch = ROWP2; nblk = 2; break;
-        case 2: src = w + c->o_u; rows = c->P; pitch = ROWP; nblk = 1; break;
-        case 3: src = w + c->o_v; rows = c->P; pitch = ROWP; nblk = 1; break;
+        case 0: src = w + c->o_h0; rows = c->P_ext; pitch = ROWP; ncol = 30; break;
+        case 1: src = w + c->o_h1; rows = c->P; pitch = ROWP2; ncol = 60; break;
+        case 2: src = w + c->o_u; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 3: src = w + c->o_v; rows = c->P; pitch = ROWW; ncol = 15; break;
         default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..3");
     }
-    const long long n = rows * nblk * 30;
-    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, nblk, 0, 0, out);
+    const long long n = rows * ncol;
+    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

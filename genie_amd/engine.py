@@ -189,9 +189,10 @@ class HipPath(object):
         return out, x_latent, bip
 
     def export(self, which):
-        """Parity/debug: de-padded copy of a workspace intermediate (0=h0, 1=h1, 2=u, 3=v)."""
+        """Parity/debug: de-padded copy of a workspace intermediate (0=h0 [.,30], 1=h1 [.,60], 2=wu [.,15],
+        3=wv [.,15]; wu/wv are u/v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2)."""
         rows = self.n_grid_ext * self.n_sta if which == 0 else self.n_prod
-        cols = 60 if which == 1 else 30
+        cols = {0: 30, 1: 60, 2: 15, 3: 15}[which]
         out = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_ws_export(self.ctx, which, self._ws_ptr, _ptr(out), _stream()), "genie_ws_export")
         return out

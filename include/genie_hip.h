@@ -91,13 +91,16 @@ int genie_da_stage0(genie_ctx* ctx, const float* slice, const float* mask, void*
 /*
  * DataAggregation, stage 1 (module.py:90-95 up to the second pair of `propagate` calls): for OWNED rows
  *   h1 = PReLU1([l1_t1_2[h0||mean_sta PReLU11(h0)||M] || l1_t2_2[h0||mean_src PReLU12(h0)||M]]),
- *   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1). Kept in the workspace.
+ *   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1), and — because mean_N(W x) = W mean_N(x) — the
+ *   projections the second pair of propagate calls will average:
+ *   wu = l2_t1_2.weight[:, 60:90] u,  wv = l2_t2_2.weight[:, 60:90] v   (15 channels each).
+ *   h1, wu, wv are kept in the workspace (u, v themselves are never stored).
  */
 int genie_da_stage1(genie_ctx* ctx, const float* mask, void* ws, void* stream);
 /*
- * Halo access for the sharded case: device pointer / row pitch (floats) of the `v` activations inside the
- * workspace, laid out [n_grid_ext*n_sta, pitch]; rows >= n_grid*n_sta must be filled by the caller (RCCL)
- * between stage 1 and stage 2.
+ * Halo access for the sharded case: device pointer / row pitch (floats) of the projected `wv` activations
+ * inside the workspace, laid out [n_grid_ext*n_sta, pitch] (pitch = 16: 15 channels + 1 zero); rows
+ * >= n_grid*n_sta must be filled by the caller (RCCL) between stage 1 and stage 2.
  */
 float* genie_ws_v_ptr(const genie_ctx* ctx, void* ws);
 int genie_ws_v_pitch(const genie_ctx* ctx);
@@ -131,8 +134,8 @@ int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const 
                    const float* pos, float* x_spatial_out, float* x_latent_out, float* bip_out,
                    void* ws, void* stream);
 
-/* Debug/parity access to intermediates kept in the workspace (which: 0=h0 [P_ext,30], 1=h1 [P,60], 2=u [P,30],
- * 3=v [P,30]); copies de-padded rows into `out` (async). */
+/* Debug/parity access to intermediates kept in the workspace (which: 0=h0 [P_ext,30], 1=h1 [P,60], 2=wu [P,15],
+ * 3=wv [P,15]); copies de-padded rows into `out` (async). */
 int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -35,7 +35,14 @@ def test_stages_match_golden_intermediates(name):
     Slice, Mask = hp.da_stage0(c.Slice.to(DEV), c.Mask.to(DEV))
     hp.da_stage1(Mask)
     x_latent, bip = hp.da_stage2_bipartite(Mask, c.edge_attr.to(DEV), want_x_latent=True)
-    got = {"h0": hp.export(0), "h1": hp.export(1), "u": hp.export(2), "v": hp.export(3), "x_latent": x_latent, "bip": bip}
+    got = {"h0": hp.export(0), "h1": hp.export(1), "x_latent": x_latent, "bip": bip}
+    # stage 1 stores u / v already projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2
+    w = c.weights
+    for key, which, lin in (("u", 2, "DataAggregation.l2_t1_2.weight"), ("v", 3, "DataAggregation.l2_t2_2.weight")):
+        proj = hp.export(which).cpu()
+        if key in c.z.files:
+            ref = c.ref(key) @ w[lin][:, 60:90].T
+            assert max_abs(c.strided(proj), ref) <= rel_tol(ref), ("projected " + key, max_abs(c.strided(proj), ref))
     pos = c.x_grid.float().to(DEV)
     got["sa1"] = hp.spatial_agg(1, bip, pos)
     got["sa2"] = hp.spatial_agg(2, got["sa1"], pos)

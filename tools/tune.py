@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Sweep the scheduling / cache-policy knobs of the DataAggregation kernels on one config and print the
+HIP-event time of every stage. Usage: python tools/tune.py [config] "SEG=1,NT=0" "SEG=64,NT=3" ..."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from genie_amd import engine, synthetic  # noqa: E402
+from tests.util import Case  # noqa: E402
+
+
+def main():
+    cfg = sys.argv[1]
+    S, G, n_picks, L, nq = synthetic.CONFIGS[cfg]
+    geom = synthetic.Geometry(S, G, L=L, n_query=10, seed=1)
+    win = synthetic.make_window(geom, n_picks, seed=2)
+    dev = "cuda:0"
+    Slice, Mask = torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev)
+    ea, pos = torch.from_numpy(geom.edge_attr()).to(dev), torch.from_numpy(geom.x_grid).float().to(dev)
+    w = {k: v.to(dev) for k, v in Case("cfg1_20x500").weights.items()}
+    sta = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
+    src = engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G)
+    order = engine.morton_order(geom.x_grid)
+    ref = None
+    for spec in sys.argv[2:]:
+        for kv in spec.split(","):
+            k, v = kv.split("=")
+            os.environ["GENIE_" + k] = v
+        hp = engine.HipPath(S, G, sta, src, grid_order=order if os.environ.get("GENIE_ORDER", "morton") == "morton" else None, device=dev)
+        hp.set_weights(w)
+        ts = {k: [] for k in ("s0", "s1", "s2", "rest")}
+        for i in range(12):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            e[0].record(); hp.da_stage0(Slice, Mask)
+            e[1].record(); hp.da_stage1(Mask)
+            e[2].record(); _, bip = hp.da_stage2_bipartite(Mask, ea)
+            e[3].record()
+            o = bip
+            for l in (1, 2, 3):
+                o = hp.spatial_agg(l, o, pos)
+            e[4].record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                for n, k in enumerate(("s0", "s1", "s2", "rest")):
+                    ts[k].append(e[n].elapsed_time(e[n + 1]))
+        if ref is None:
+            ref = o.clone()
+        same = bool(torch.equal(ref, o))
+        print("%-40s s0 %.3f  s1 %.3f  s2 %.3f  bip+sa %.3f  total %.3f ms  bitwise_same=%s" % (
+            spec, *[float(np.median(ts[k])) for k in ("s0", "s1", "s2", "rest")],
+            sum(float(np.median(ts[k])) for k in ts), same), flush=True)
+        del hp
+
+
+if __name__ == "__main__":
+    main()
