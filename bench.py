@@ -136,9 +136,8 @@ def main():
             k = i % a.windows
             e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             e[0].record()
-            hp.da_stage0(dS[k], dM[k])
             e[1].record()
-            hp.da_stage1(dM[k])
+            hp.da_stage1(dS[k], dM[k])
             e[2].record()
             _, bip = hp.da_stage2_bipartite(dM[k], net._edge_attr)
             e[3].record()

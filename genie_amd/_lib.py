@@ -32,8 +32,8 @@ SYMBOLS = [
     ("genie_weights_set_blob", _c.c_int, [_P, _P, _c.c_int64, _P]),
     ("genie_weights_commit", _c.c_int, [_P, _P]),
     ("genie_workspace_bytes", _c.c_size_t, [_P]),
-    ("genie_da_stage0", _c.c_int, [_P, _P, _P, _P, _P]),
-    ("genie_da_stage1", _c.c_int, [_P, _P, _P, _P]),
+    ("genie_da_stage1", _c.c_int, [_P, _P, _P, _P, _P]),
+    ("genie_da_stage1_debug", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("genie_ws_v_ptr", _P, [_P, _P]),
     ("genie_ws_v_pitch", _c.c_int, [_P]),
     ("genie_da_stage2_bipartite", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
@@ -53,7 +53,10 @@ def build(verbose=False, extra_flags=(), out_path=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
+    # -fno-honor-nans: no NaN-canonicalisation v_max before every fmaxf/fminf (no reassociation is enabled);
+    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs + v_accvgpr_read copies
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I", INCLUDE, SRC, "-o", out_path or LIB_PATH] + list(extra_flags)
     if verbose:
         print(" ".join(cmd))

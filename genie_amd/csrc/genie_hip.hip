@@ -178,32 +178,31 @@ void add_bias(StagePlan& p, int vec, int o0, int rows) {
 }
 
 // Group index maps shared by host plan and device kernels --------------------------------------
-// stage 0: group t (t = 0,1): step 0 = Slice cols q, step 1 = Mask cols 4+q
-#define G0_GROUPS 2
-// stage 1: layer-1 groups (half h = tr1/tr2, out tile t, input block b: 0,1 = h0; 2,3 = neighbour mean; 4 = Mask)
-#define G1_L1(h, t, b) (((h) * 2 + (t)) * 5 + (b))
-// stage 1: u/v groups (w = u/v, out tile t, input block hb = h1 block 0..3)
-#define G1_UV(w, t, hb) (20 + ((w) * 2 + (t)) * 4 + (hb))
-// stage 1: projected gather operands wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v (w, input tile b of u/v)
-#define G1_W(w, b) (36 + (w) * 2 + (b))
-#define G1_GROUPS 40
-#define G1_BIAS 8
-// stage 2: o1/o2 groups (w, b: 0..3 = h1 blocks, 4 = Mask); the neighbour-mean term arrives already projected
-#define G2_O(w, b) ((w) * 5 + (b))
-// stage 2: bipartite fc1 groups (out tile t, b: 0 = o1 block, 1 = o2 block, 2 = edge_attr)
-#define G2_BP(t, b) (10 + (t) * 3 + (b))
-#define G2_GROUPS 16
-#define G2_BIAS 4
+// STAGE 1 (all dense work of DataAggregation up to the second pair of neighbour means)
+//  init_trns (recomputed for the node itself AND for every gathered neighbour): out tile t; step 0 = Slice, 1 = Mask
+#define G1_INIT(t) (t)
+//  layer 1 (half h = l1_t1_2 / l1_t2_2, out tile t, input block b: 0,1 = h0; 2,3 = neighbour mean; 4 = Mask)
+#define G1_L1(h, t, b) (2 + ((h) * 2 + (t)) * 5 + (b))
+//  u / v (w = l2_t1_1 / l2_t2_1, out tile t, input block hb = h1 block 0..3)
+#define G1_UV(w, t, hb) (22 + ((w) * 2 + (t)) * 4 + (hb))
+//  projected gather operands wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v (w, input tile b of u / v)
+#define G1_W(w, b) (38 + (w) * 2 + (b))
+//  node-local part of layer 2: c_w = l2_t?_2[:, 0:60] h1 + l2_t?_2[:, 90:94] M + bias (b: 0..3 = h1 blocks, 4 = Mask)
+#define G1_C(w, b) (42 + (w) * 5 + (b))
+#define G1_GROUPS 52
+//  bias tiles: 0,1 init_trns; 2..5 layer 1 (h,t); 6..9 u/v (w,t); 10,11 c (w)
+#define G1_BIAS 12
+// STAGE 2: bipartite fc1 (out tile t, b: 0 = o1 block, 1 = o2 block, 2 = edge_attr)
+#define G2_BP(t, b) ((t) * 3 + (b))
+#define G2_GROUPS 6
+#define G2_BIAS 2
 
-void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
-    // ---- stage 0: init_trns (30 x 8)
+void build_plans(StagePlan& p1, StagePlan& p2) {
+    // ---- stage 1
     for (int t = 0; t < 2; ++t) {
         const int c0s[2] = {0, 4}, nqs[2] = {4, 4};
-        add_scalar_group(p0, W_DA_INIT_W, 8, 16 * t, std::min(16, 30 - 16 * t), c0s, nqs, 2);
-        add_bias(p0, W_DA_INIT_B, 16 * t, std::min(16, 30 - 16 * t));
+        add_scalar_group(p1, W_DA_INIT_W, 8, 16 * t, std::min(16, 30 - 16 * t), c0s, nqs, 2);
     }
-    p0.scal.push_back(g_params[W_DA_ACT].off);
-    // ---- stage 1
     for (int h = 0; h < 2; ++h)
         for (int t = 0; t < 2; ++t) {
             const int mat = h == 0 ? W_DA_L1T12_W : W_DA_L1T22_W;
@@ -223,27 +222,32 @@ void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
                 add_block_group(p1, mat, 60, o0, rows, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
         }
     // mean_N(W x) = W mean_N(x): project u / v through the neighbour-mean columns of l2_t1_2 / l2_t2_2 (15 x 30) here,
-    // so stage 2 gathers 16-float rows instead of 32-float rows and adds the mean straight into its accumulator
+    // so stage 2 gathers 16-float rows and adds their mean straight into its accumulator
     for (int w = 0; w < 2; ++w)
         for (int b = 0; b < 2; ++b)
             add_block_group(p1, w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W, 94, 0, 15, 60 + 16 * b, b ? 14 : 16);
+    // node-local part of layer 2 (h1 and Mask columns + bias), so h1 itself never leaves the registers
+    for (int w = 0; w < 2; ++w) {
+        const int mat = w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W;
+        for (int hb = 0; hb < 4; ++hb)
+            add_block_group(p1, mat, 94, 0, 15, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
+        const int c0s[1] = {90}, nqs[1] = {4};
+        add_scalar_group(p1, mat, 94, 0, 15, c0s, nqs, 1);
+    }
+    for (int t = 0; t < 2; ++t) add_bias(p1, W_DA_INIT_B, 16 * t, std::min(16, 30 - 16 * t));
     for (int h = 0; h < 2; ++h)
         for (int t = 0; t < 2; ++t) add_bias(p1, h == 0 ? W_DA_L1T12_B : W_DA_L1T22_B, 16 * t, std::min(16, 30 - 16 * t));
     for (int w = 0; w < 2; ++w)
         for (int t = 0; t < 2; ++t) add_bias(p1, w == 0 ? W_DA_L2T11_B : W_DA_L2T21_B, 16 * t, std::min(16, 30 - 16 * t));
+    add_bias(p1, W_DA_L2T12_B, 0, 15);
+    add_bias(p1, W_DA_L2T22_B, 0, 15);
+    p1.scal.push_back(g_params[W_DA_ACT].off);
     p1.scal.push_back(g_params[W_DA_ACT11].off);
     p1.scal.push_back(g_params[W_DA_ACT12].off);
     p1.scal.push_back(g_params[W_DA_ACT1].off);
     p1.scal.push_back(g_params[W_DA_ACT21].off);
     p1.scal.push_back(g_params[W_DA_ACT22].off);
     // ---- stage 2
-    for (int w = 0; w < 2; ++w) {
-        const int mat = w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W;
-        for (int hb = 0; hb < 4; ++hb)
-            add_block_group(p2, mat, 94, 0, 15, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
-        const int c0s[1] = {90}, nqs[1] = {4};
-        add_scalar_group(p2, mat, 94, 0, 15, c0s, nqs, 1);
-    }
     for (int t = 0; t < 2; ++t) {
         const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
         add_block_group(p2, W_BP_FC1_W, 33, o0, rows, 0, 15);    // o1 = x_latent[0:15]
@@ -251,8 +255,6 @@ void build_plans(StagePlan& p0, StagePlan& p1, StagePlan& p2) {
         const int c0s[1] = {30}, nqs[1] = {3};
         add_scalar_group(p2, W_BP_FC1_W, 33, o0, rows, c0s, nqs, 1);  // edge_attr (3)
     }
-    add_bias(p2, W_DA_L2T12_B, 0, 15);
-    add_bias(p2, W_DA_L2T22_B, 0, 15);
     add_bias(p2, W_BP_FC1_B, 0, 16);
     add_bias(p2, W_BP_FC1_B, 16, 14);
     p2.scal.push_back(g_params[W_DA_ACT2].off);
@@ -306,73 +308,52 @@ __device__ __forceinline__ f32x4 mma_block(f32x4 acc, const f32x4 w, const f32x4
     return acc;
 }
 
-// Sum over the neighbour rows col[eb..ee) of (ACT ? PReLU(row) : row) for the two 16-channel blocks of a
-// 32-float row, in edge order. Rows are fetched CH at a time (2*CH independent 16-B loads in flight per lane)
-// so a tile pays ceil(deg/CH) memory round trips instead of deg. `base` already points at this lane's
-// 4-channel slot (+4q); row(c) = base + c*stride. UNI: the edge list is wave-uniform (source-node graph).
-template <int CH, bool ACT, bool UNI, int NB>
-__device__ __forceinline__ void gather_sum(const float* __restrict__ base, long long stride,
-                                           const int32_t* __restrict__ col, int eb, int ee, float slope,
-                                           f32x4& s0, f32x4& s1) {
-    for (int e0 = eb; e0 < ee; e0 += CH) {
-        const f32x4* r[CH];
-        bool ok[CH];
-        int cv = 0;
-        if (UNI) cv = col[min(e0 + (int)(__lane_id() & (CH - 1)), ee - 1)];  // one coalesced load, broadcast below
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            ok[k] = e0 + k < ee;
-            const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : ee - 1];
-            r[k] = (const f32x4*)(base + (long long)c * stride);
-        }
-        f32x4 y0[CH], y1[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            y0[k] = r[k][0];
-            if (NB == 2) y1[k] = r[k][4];
-        }
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (ok[k]) {
-                s0 += ACT ? prelu4(y0[k], slope) : y0[k];
-                if (NB == 2) s1 += ACT ? prelu4(y1[k], slope) : y1[k];
-            }
-        }
-    }
+// Exact branch-free PReLU: max(x,0) + s*min(x,0) (one of the two terms is always zero)
+__device__ __forceinline__ f32x4 prelu4u(f32x4 x, float s) {
+    f32x4 y;
+    y.x = fmaf(s, fminf(x.x, 0.f), fmaxf(x.x, 0.f));
+    y.y = fmaf(s, fminf(x.y, 0.f), fmaxf(x.y, 0.f));
+    y.z = fmaf(s, fminf(x.z, 0.f), fmaxf(x.z, 0.f));
+    y.w = fmaf(s, fminf(x.w, 0.f), fmaxf(x.w, 0.f));
+    return y;
 }
+// PReLU in two VALU ops when the side of the slope is known at compile time: max(x, s*x) for s <= 1, min(x, s*x)
+// for s > 1 (exact: s*x is the exact PReLU value on the negative side and never wins on the positive side)
+template <bool LE1>
+__device__ __forceinline__ f32x4 prelu4s(f32x4 x, float s) {
+    const f32x4 t = x * s;
+    f32x4 y;
+    if (LE1) { y.x = fmaxf(x.x, t.x); y.y = fmaxf(x.y, t.y); y.z = fmaxf(x.z, t.z); y.w = fmaxf(x.w, t.w); }
+    else     { y.x = fminf(x.x, t.x); y.y = fminf(x.y, t.y); y.z = fminf(x.z, t.z); y.w = fminf(x.w, t.w); }
+    return y;
+}
+// PReLU_b(PReLU_a(z)) is again one PReLU: slope a*b on the negative side when a >= 0; when a < 0 the inner
+// PReLU maps z < 0 to a*z > 0, which the outer one passes through: slope a.
+__device__ __forceinline__ float compose_slopes(float a, float b) { return a >= 0.f ? a * b : a; }
 
-// streaming (non-temporal) accesses for tensors that are written once / read once by a kernel, so they do not
-// evict the neighbour rows the gathers want to find in L2
-__device__ __forceinline__ void st_stream(float* p, f32x4 v) { __builtin_nontemporal_store(v, (f32x4*)p); }
-__device__ __forceinline__ f32x4 ld_stream(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
-
-constexpr int ROWP = 32;   // padded row pitch (floats) of h0 / u / v : 30 channels + 2 zeros = 128 B
+constexpr int ROWC = 32;   // row pitch (floats) of c = [c1 0..14,0 | c2 0..14,0]: the node-local layer-2 terms, 128 B
 constexpr int ROWW = 16;   // row pitch of the projected gather operands wu / wv: 15 channels + 1 zero = 64 B
-constexpr int ROWP2 = 64;  // padded row pitch of h1: [tr1 0..15 | tr1 16..29,0,0 | tr2 0..15 | tr2 16..29,0,0]
 constexpr int WAVES = 4;   // waves per workgroup
 
 struct DaArgs {
     int S, G, T;               // stations, owned source nodes, tiles per source node = ceil(S/16)
     int seg;                   // source nodes per scheduling segment
-    int nt;                    // use streaming loads/stores for write-once/read-once tensors
     int abl;                   // GENIE_TUNING only: ablation bits
     int nxcd;                  // XCD-chunked sweep (8) or flat (1)
-    long long P_ext;           // rows incl. halo
     const int32_t* sta_rowptr; const int32_t* sta_col;
     const int32_t* src_rowptr; const int32_t* src_col;
     const int32_t* order;
     const float* slice; const float* mask; const float* edge_attr;
-    float* h0; float* h1; float* u; float* v;
+    float* c; float* wu; float* wv;
     float* part;               // [G*T, 32] bipartite partial sums
     float* x_latent;           // optional [P,30]
+    float* dbg_h0; float* dbg_h1;  // optional parity outputs [P,30] / [P,60]
     const float* packed;       // packed A fragments for the stage
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
 // its contiguous chunk of the processing order. Inside the chunk items are ordered in SEGMENTS of `seg` source
-// nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ... so that the
-// waves in flight on one XCD share the 2-KB (source node, station tile) row blocks of their source
-// neighbours in that XCD's L2 while the segment's own rows (station-neighbour gathers) stay resident too.
+// nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ...
 struct ItemIter {
     int gbeg, gend, T, seg;
     long long it, stride, nitems;
@@ -388,9 +369,9 @@ struct ItemIter {
         stride = (long long)nbx * WAVES;
     }
     // item -> (index into the processing order, station tile); 32-bit arithmetic (a chunk has < 2^31 items)
-    __device__ void decode(int& gi, int& tb) const {
+    __device__ void decode(long long item, int& gi, int& tb) const {
         const unsigned per_seg = (unsigned)seg * (unsigned)T;
-        const unsigned i = (unsigned)it;
+        const unsigned i = (unsigned)item;
         const unsigned sidx = i / per_seg;
         const unsigned rem = i - sidx * per_seg;
         const int g0 = (int)(sidx * (unsigned)seg);
@@ -400,40 +381,194 @@ struct ItemIter {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// stage 0: h0 = PReLU(init_trns [Slice || Mask])            module.py:87-88
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stage0(DaArgs a) {
-    __shared__ f32x4 lw[(G0_GROUPS * 256 + 2 * 16 + 16) / 4];
-    for (int i = threadIdx.x; i < (G0_GROUPS * 256 + 2 * 16 + 16) / 4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G0_GROUPS * 64);
-    const float act = lbias[2 * 16];
-    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long ntiles = (a.P_ext + 15) >> 4;
-    for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
-        const long long p = tile * 16 + j;
-        const bool valid = p < a.P_ext;
-        const long long pc = valid ? p : a.P_ext - 1;
-        const float xs = a.slice[pc * 4 + q];
-        const float xm = a.mask[pc * 4 + q];
+// Neighbour sum of PReLU_s(init_trns [Slice || Mask]) with the 30-channel hidden state RECOMPUTED from the raw
+// 8 input floats of every neighbour (2 k-steps x 2 out tiles = 4 MFMAs) instead of gathered from memory: a
+// gathered row is 32 B instead of 128 B, so the whole neighbourhood working set stays in L2, and h0 is never
+// stored. One call handles CH consecutive edges starting at e0 (2*CH dword loads per lane in flight); PRED adds
+// the per-lane bound check used only for ragged (non-uniform degree) graphs. row(c) = row0 + c*stride.
+template <int CH, bool UNI, bool LE1, bool PRED>
+__device__ __forceinline__ void recompute_chunk(const float* __restrict__ slice, const float* __restrict__ mask,
+                                                long long row0, long long stride, int q,
+                                                const int32_t* __restrict__ col, int e0, int ee,
+                                                f32x4 w0, f32x4 w1, f32x4 b0, f32x4 b1, float slope,
+                                                f32x4& s0, f32x4& s1) {
+    long long off[CH];
+    bool ok[CH];
+    int cv = 0;
+    if (UNI) cv = col[e0 + min((int)(__lane_id() & 7), CH - 1)];  // one coalesced load, broadcast below
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 acc = *(const f32x4*)(lbias + t * 16 + 4 * q);
-            const f32x4 w = lw[t * 64 + lane];
-            acc = MFMA16(w.x, xs, acc);
-            acc = MFMA16(w.y, xm, acc);
-            acc = prelu4(acc, act);
-            if (valid) *(f32x4*)(a.h0 + p * ROWP + 16 * t + 4 * q) = acc;
+    for (int k = 0; k < CH; ++k) {
+        ok[k] = PRED ? (e0 + k < ee) : true;
+        const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : max(ee - 1, 0)];
+        off[k] = (row0 + (long long)c * stride) * 4 + q;
+    }
+    float xs[CH], xm[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        xs[k] = slice[off[k]];
+        xm[k] = mask[off[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        f32x4 h_a = MFMA16(w0.x, xs[k], b0);
+        f32x4 h_b = MFMA16(w1.x, xs[k], b1);
+        h_a = MFMA16(w0.y, xm[k], h_a);
+        h_b = MFMA16(w1.y, xm[k], h_b);
+        h_a = prelu4s<LE1>(h_a, slope);
+        h_b = prelu4s<LE1>(h_b, slope);
+        if (PRED) {
+            const float m = ok[k] ? 1.f : 0.f;
+            h_a *= m; h_b *= m;
         }
+        s0 += h_a;
+        s1 += h_b;
+    }
+}
+
+// Driver: uniform-degree neighbourhoods (every kNN graph) run as full chunks 8,4,2,1 with no predication and no
+// divergent branch; ragged ones fall back to predicated chunks of 8. Edge order (= summation order) is kept.
+template <bool UNI, bool LE1>
+__device__ __forceinline__ void gather_recompute(const float* __restrict__ slice, const float* __restrict__ mask,
+                                                 long long row0, long long stride, int q,
+                                                 const int32_t* __restrict__ col, int eb, int ee,
+                                                 f32x4 w0, f32x4 w1, f32x4 b0, f32x4 b1, float slope,
+                                                 f32x4& s0, f32x4& s1) {
+    const int n = ee - eb;
+    const int nu = __builtin_amdgcn_readfirstlane(n);
+    if (UNI || __all(n == nu)) {
+        int e = eb, r = nu;
+        for (; r >= 8; r -= 8, e += 8)
+            recompute_chunk<8, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1);
+        if (r & 4) { recompute_chunk<4, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); e += 4; }
+        if (r & 2) { recompute_chunk<2, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); e += 2; }
+        if (r & 1) { recompute_chunk<1, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); }
+    } else {
+        for (int e = eb; __any(e < ee); e += 8)
+            recompute_chunk<8, false, LE1, true>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1);
+    }
+}
+
+// Same structure for the 16-float projected operands wu / wv (one 16-B load per lane per neighbour).
+template <int CH, bool UNI, bool PRED>
+__device__ __forceinline__ void sum16_chunk(const float* __restrict__ base, long long stride,
+                                            const int32_t* __restrict__ col, int e0, int ee, f32x4& s0) {
+    const f32x4* r[CH];
+    bool ok[CH];
+    int cv = 0;
+    if (UNI) cv = col[e0 + min((int)(__lane_id() & 7), CH - 1)];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        ok[k] = PRED ? (e0 + k < ee) : true;
+        const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : max(ee - 1, 0)];
+        r[k] = (const f32x4*)(base + (long long)c * stride);
+    }
+    f32x4 y[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) y[k] = r[k][0];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        if (PRED) y[k] *= ok[k] ? 1.f : 0.f;
+        s0 += y[k];
+    }
+}
+template <bool UNI>
+__device__ __forceinline__ void gather_sum16(const float* __restrict__ base, long long stride,
+                                             const int32_t* __restrict__ col, int eb, int ee, f32x4& s0) {
+    const int n = ee - eb;
+    const int nu = __builtin_amdgcn_readfirstlane(n);
+    if (UNI || __all(n == nu)) {
+        int e = eb, r = nu;
+        for (; r >= 8; r -= 8, e += 8) sum16_chunk<8, UNI, false>(base, stride, col, e, ee, s0);
+        if (r & 4) { sum16_chunk<4, UNI, false>(base, stride, col, e, ee, s0); e += 4; }
+        if (r & 2) { sum16_chunk<2, UNI, false>(base, stride, col, e, ee, s0); e += 2; }
+        if (r & 1) { sum16_chunk<1, UNI, false>(base, stride, col, e, ee, s0); }
+    } else {
+        for (int e = eb; __any(e < ee); e += 8) sum16_chunk<8, false, true>(base, stride, col, e, ee, s0);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 1: neighbour means of PReLU11/12(h0), layer-1 Linear pair, PReLU1, l2_t*_1 + PReLU21/22
-// module.py:90-95
+// stage 1: everything of DataAggregation that does not need the SECOND pair of neighbour means
+//   h0 = PReLU(init_trns [X || M])                                        module.py:87-88 (own node + every neighbour)
+//   h1 = PReLU1([l1_t1_2 [h0 || mean_sta PReLU11(h0) || M] || l1_t2_2 [h0 || mean_src PReLU12(h0) || M]])   :90-92
+//   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)                      :94-95
+//   wu = l2_t1_2[:, 60:90] u,  wv = l2_t2_2[:, 60:90] v                  (operands of the second pair of means)
+//   c  = [l2_t1_2[:, 0:60] h1 + l2_t1_2[:, 90:94] M + b || l2_t2_2[...]]  (node-local part of :94-95)
+// Reads 32 B per product node (+ its neighbours' 32-B rows from L2), writes 256 B; h0 / h1 / u / v stay in VGPRs.
 // ------------------------------------------------------------------------------------------------
+// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
+// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
+__device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, const float* lbias, int lane, int q,
+                                             bool valid, long long p, float mq, f32x4 x0, f32x4 x1, f32x4 n1a, f32x4 n1b,
+                                             f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
+    if (a.dbg_h0 != nullptr && valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.dbg_h0[p * 30 + 4 * q + r] = x0[r];
+            if (16 + 4 * q + r < 30) a.dbg_h0[p * 30 + 16 + 4 * q + r] = x1[r];
+        }
+    }
+    // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + (2 + k) * 16 + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane], x0);
+    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 1) * 64 + lane], x1);
+    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 2) * 64 + lane], (k >> 1) == 0 ? n1a : n2a);
+    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 3) * 64 + lane], (k >> 1) == 0 ? n1b : n2b);
+    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+        acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
+    }
+    if (a.dbg_h1 != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * (k & 1) + 4 * q + r < 30) a.dbg_h1[p * 60 + 30 * (k >> 1) + 16 * (k & 1) + 4 * q + r] = acc[k][r];
+    }
+    // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1); c_w = node-local layer-2 terms
+    f32x4 uv[4], cc[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) uv[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
+    cc[0] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
+    cc[1] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+        __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) uv[k] = mma_block(uv[k], lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane], acc[hb]);
+        cc[0] = mma_block(cc[0], lw[G1_C(0, hb) * 64 + lane], acc[hb]);
+        cc[1] = mma_block(cc[1], lw[G1_C(1, hb) * 64 + lane], acc[hb]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+    cc[0] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, cc[0]);
+    cc[1] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, cc[1]);
+    uv[0] = prelu4u(uv[0], a21); uv[1] = prelu4u(uv[1], a21);
+    uv[2] = prelu4u(uv[2], a22); uv[3] = prelu4u(uv[3], a22);
+    f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+    wu = mma_block(wu, lw[G1_W(0, 0) * 64 + lane], uv[0]);
+    wv = mma_block(wv, lw[G1_W(1, 0) * 64 + lane], uv[2]);
+    wu = mma_block(wu, lw[G1_W(0, 1) * 64 + lane], uv[1]);
+    wv = mma_block(wv, lw[G1_W(1, 1) * 64 + lane], uv[3]);
+    if (valid && !ABL(a, 3)) {
+        *(f32x4*)(a.c + p * ROWC + 4 * q) = cc[0];
+        *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = cc[1];
+        *(f32x4*)(a.wu + p * ROWW + 4 * q) = wu;
+        *(f32x4*)(a.wv + p * ROWW + 4 * q) = wv;
+    }
+}
+
+// generic stage 1: any CSR graphs (ragged degrees, empty neighbourhoods)
 __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
     constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -441,7 +576,8 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
     __syncthreads();
     const float* lbias = (const float*)(lw + G1_GROUPS * 64);
     const float* lscal = lbias + G1_BIAS * 16;
-    const float a11 = lscal[0], a12 = lscal[1], a1 = lscal[2], a21 = lscal[3], a22 = lscal[4];
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -449,7 +585,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
         int gi, tb;
-        w.decode(gi, tb);
+        w.decode(w.it, gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
@@ -458,16 +594,28 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
         const bool valid = s < S;
         const int sc = valid ? s : S - 1;
         const long long p = (long long)g * S + sc;
-        // own row
-        const f32x4* own = (const f32x4*)(a.h0 + p * ROWP) + q;
-        const f32x4 x0 = own[0], x1 = own[4];
+        const float xs = a.slice[p * 4 + q];
         const float mq = a.mask[p * 4 + q];
+        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
+        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        // own hidden state
+        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
+        x0 = MFMA16(wi0.y, mq, x0);
+        x1 = MFMA16(wi1.y, mq, x1);
+        x0 = prelu4u(x0, a0);
+        x1 = prelu4u(x1, a0);
         // station-neighbour mean of PReLU11(h0): rows of the same source node
         f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
         {
             const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            const float* base = a.h0 + (long long)g * S * ROWP + 4 * q;
-            if (!ABL(a, 0)) gather_sum<8, true, false, 2>(base, ROWP, a.sta_col, eb, ee, a11, n1a, n1b);
+            if (!ABL(a, 0)) {
+                if (s11 <= 1.f)
+                    gather_recompute<false, true>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
+                                                  bi1, s11, n1a, n1b);
+                else
+                    gather_recompute<false, false>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
+                                                   bi1, s11, n1a, n1b);
+            }
             const float inv = 1.f / (float)max(ee - eb, 1);
             n1a *= inv; n1b *= inv;
         }
@@ -476,69 +624,200 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
         {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.h0 + (long long)sc * ROWP + 4 * q;
-            if (!ABL(a, 1)) gather_sum<8, true, true, 2>(base, (long long)S * ROWP, a.src_col, eb, ee, a12, n2a, n2b);
+            if (!ABL(a, 1)) {
+                if (s12 <= 1.f)
+                    gather_recompute<true, true>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
+                                                 bi0, bi1, s12, n2a, n2b);
+                else
+                    gather_recompute<true, false>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
+                                                  bi0, bi1, s12, n2a, n2b);
+            }
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }
-        // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]
-        f32x4 acc[4];
+        stage1_dense(a, lw, lbias, lane, q, valid, p, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+    }
+}
+
+// Fast stage 1 for UNIFORM-degree graphs with exactly KS station and KP source neighbours per node (the
+// reference's kNN graphs: k_sta_edges = 8, k_spc_edges = 15, config.yaml:79-80). Same arithmetic in the same
+// order as k_stage1 (bitwise identical results), software-pipelined across tiles: while tile i runs its ~180
+// dense MFMAs the 2*(1+KS+KP) raw dwords of tile i+1 are already in flight, and the neighbour ids of tile i+2
+// are fetched one tile ahead, so no memory round trip sits on the critical path.
+template <bool LE1>
+__device__ __forceinline__ void nbr_pipe_step(f32x4& h_a, f32x4& h_b, bool has_next, float xs, float xm, f32x4 wi0, f32x4 wi1,
+                                              f32x4 bi0, f32x4 bi1, float slope, f32x4& s0, f32x4& s1) {
+    // one step of the 1-deep MFMA/VALU software pipeline over neighbours: issue the 4 MFMAs of the NEXT neighbour,
+    // then PReLU + accumulate the CURRENT one while they run; fences keep the compiler from hoisting every MFMA first
+    // (empty asm statements are ordered among themselves and pin the operands they touch: the next neighbour's
+    // MFMAs cannot be hoisted above the previous accumulate, so at most two neighbours' results are ever alive;
+    // __builtin_amdgcn_sched_barrier alone did not stop hipcc from issuing all 4*(KS+KP) MFMAs up front)
+    f32x4 g_a = h_a, g_b = h_b;
+    if (has_next) {
+        asm volatile("" : "+v"(xs), "+v"(xm));
+        g_a = MFMA16(wi0.x, xs, bi0);
+        g_b = MFMA16(wi1.x, xs, bi1);
+        g_a = MFMA16(wi0.y, xm, g_a);
+        g_b = MFMA16(wi1.y, xm, g_b);
+    }
+    s0 += prelu4s<LE1>(h_a, slope);
+    s1 += prelu4s<LE1>(h_b, slope);
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    h_a = g_a; h_b = g_b;
+}
+
+template <int KS, int KP, bool LE11, bool LE12>
+__device__ __forceinline__ void stage1_fast_loop(const DaArgs& a, const f32x4* lw, const float* lbias, int lane_in,
+                                                 int wave, float a0, float a1, float a21, float a22, float s11, float s12) {
+    static_assert(KP > 8 && KP <= 16, "source-neighbour count handled as chunks of 8 and KP-8");
+    int lane = lane_in;
+    const int j = lane & 15, q = lane >> 4;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    if (w.it >= w.nitems) return;
+    // 32-bit BYTE offsets from the (uniform) array bases: one VGPR per address (the host only selects this kernel
+    // when n_grid_ext * n_sta * 16 B < 4 GiB)
+    const char* sl = (const char*)a.slice;
+    const char* mk = (const char*)a.mask;
+    const unsigned q4 = 4u * (unsigned)q;
+
+    // tile descriptor of the tile being computed (c) and of the next one (n)
+    int g_c, sc_c, g_n = 0, sc_n = 0;
+    bool valid_c, valid_n = false;
+    int sta_n[KS];          // station-neighbour ids of the next tile
+    int srcv_c, srcv_n = 0; // lane k holds source-neighbour id k
+    float os_c, om_c, ss_c[KS], sm_c[KS];   // own + station-neighbour raw inputs of the current tile (prefetched)
+    float os_n = 0.f, om_n = 0.f, ss_n[KS], sm_n[KS];
+
+    auto decode = [&](long long item, int& g, int& sc, bool& valid) {
+        int gi, tb;
+        w.decode(item, gi, tb);
+        g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        const int s = tb * 16 + j;
+        valid = s < S;
+        sc = valid ? s : S - 1;
+    };
+    // prologue: everything of tile 0 that later tiles get prefetched
+    decode(w.it, g_c, sc_c, valid_c);
+    {
+        const unsigned gS = (unsigned)g_c * (unsigned)S;
+        const unsigned oo = (gS + (unsigned)sc_c) * 16u + q4;
+        os_c = *(const float*)(sl + oo);
+        om_c = *(const float*)(mk + oo);
+        srcv_c = a.src_col[(long long)g_c * KP + min(lane_in & 15, KP - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + k * 16 + 4 * q);
+        for (int k = 0; k < KS; ++k) {
+            const unsigned o = (gS + (unsigned)a.sta_col[sc_c * KS + k]) * 16u + q4;
+            ss_c[k] = *(const float*)(sl + o);
+            sm_c[k] = *(const float*)(mk + o);
+        }
+    }
+    for (;;) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const bool has_next = w.it + w.stride < w.nitems;
+        // (1) ids of the NEXT tile (consumed before the dense phase of this one)
+        if (has_next) {
+            decode(w.it + w.stride, g_n, sc_n, valid_n);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = k >> 1, t = k & 1;
-            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 0) * 64 + lane], x0);
+            for (int k = 0; k < KS; ++k) sta_n[k] = a.sta_col[sc_n * KS + k];
+            srcv_n = a.src_col[(long long)g_n * KP + min(lane_in & 15, KP - 1)];
+        }
+        // (2) first 8 source neighbours of THIS tile: in flight while own + station neighbours are computed
+        const unsigned so = (unsigned)sc_c * 16u + q4;
+        const unsigned gstride = (unsigned)S * 16u;
+        float rs1[8], rm1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane(srcv_c, k) * gstride + so;
+            rs1[k] = *(const float*)(sl + o);
+            rm1[k] = *(const float*)(mk + o);
+        }
+        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
+        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        // own hidden state
+        f32x4 x0 = MFMA16(wi0.x, os_c, bi0), x1 = MFMA16(wi1.x, os_c, bi1);
+        x0 = MFMA16(wi0.y, om_c, x0);
+        x1 = MFMA16(wi1.y, om_c, x1);
+        x0 = prelu4u(x0, a0);
+        x1 = prelu4u(x1, a0);
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f}, n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
+        // station neighbours (raw inputs prefetched one tile ago)
+        f32x4 h_a = MFMA16(wi0.x, ss_c[0], bi0), h_b = MFMA16(wi1.x, ss_c[0], bi1);
+        h_a = MFMA16(wi0.y, sm_c[0], h_a);
+        h_b = MFMA16(wi1.y, sm_c[0], h_b);
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            nbr_pipe_step<LE11>(h_a, h_b, true, k + 1 < KS ? ss_c[k + 1 < KS ? k + 1 : 0] : rs1[0],
+                                k + 1 < KS ? sm_c[k + 1 < KS ? k + 1 : 0] : rm1[0], wi0, wi1, bi0, bi1, s11, n1a, n1b);
+        // (3) remaining source neighbours: in flight while the first 8 are computed
+        float rs2[KP - 8], rm2[KP - 8];
+#pragma unroll
+        for (int k = 0; k < KP - 8; ++k) {
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane(srcv_c, 8 + k) * gstride + so;
+            rs2[k] = *(const float*)(sl + o);
+            rm2[k] = *(const float*)(mk + o);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = k >> 1, t = k & 1;
-            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 1) * 64 + lane], x1);
-        }
+        for (int k = 0; k < 8; ++k)
+            nbr_pipe_step<LE12>(h_a, h_b, true, k + 1 < 8 ? rs1[k + 1 < 8 ? k + 1 : 0] : rs2[0],
+                                k + 1 < 8 ? rm1[k + 1 < 8 ? k + 1 : 0] : rm2[0], wi0, wi1, bi0, bi1, s12, n2a, n2b);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = k >> 1, t = k & 1;
-            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 2) * 64 + lane], h == 0 ? n1a : n2a);
+        for (int k = 0; k < KP - 8; ++k)
+            nbr_pipe_step<LE12>(h_a, h_b, k + 1 < KP - 8, rs2[k + 1 < KP - 8 ? k + 1 : 0], rm2[k + 1 < KP - 8 ? k + 1 : 0], wi0,
+                                wi1, bi0, bi1, s12, n2a, n2b);
+        {
+            const float i1 = 1.f / (float)KS, i2 = 1.f / (float)KP;
+            n1a *= i1; n1b *= i1; n2a *= i2; n2b *= i2;
         }
+        // (4) own + station-neighbour raw inputs of the NEXT tile: in flight during the dense phase
+        if (has_next) {
+            const unsigned gS = (unsigned)g_n * (unsigned)S;
+            const unsigned oo = (gS + (unsigned)sc_n) * 16u + q4;
+            os_n = *(const float*)(sl + oo);
+            om_n = *(const float*)(mk + oo);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = k >> 1, t = k & 1;
-            acc[k] = mma_block(acc[k], lw[G1_L1(h, t, 3) * 64 + lane], h == 0 ? n1b : n2b);
+            for (int k = 0; k < KS; ++k) {
+                const unsigned o = (gS + (unsigned)sta_n[k]) * 16u + q4;
+                ss_n[k] = *(const float*)(sl + o);
+                sm_n[k] = *(const float*)(mk + o);
+            }
         }
+        // (5) dense tail + stores of this tile
+        stage1_dense(a, lw, lbias, lane, q, valid_c, (long long)g_c * S + sc_c, om_c, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+        if (!has_next) break;
+        g_c = g_n; sc_c = sc_n; valid_c = valid_n; srcv_c = srcv_n; os_c = os_n; om_c = om_n;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = k >> 1, t = k & 1;
-            acc[k] = MFMA16(lw[G1_L1(h, t, 4) * 64 + lane].x, mq, acc[k]);
-            acc[k] = prelu4(acc[k], a1);                      // h1 block k
-            if (valid && !ABL(a, 3)) { if (a.nt & 1) st_stream(a.h1 + p * ROWP2 + 16 * k + 4 * q, acc[k]); else *(f32x4*)(a.h1 + p * ROWP2 + 16 * k + 4 * q) = acc[k]; }
-        }
-        // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)
-        f32x4 uv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) uv[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) uv[k] = mma_block(uv[k], lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane], acc[hb]);
-        }
-        // wu = l2_t1_2[:, 60:90] PReLU21(.), wv = l2_t2_2[:, 60:90] PReLU22(.): the operands stage 2 gathers
-        uv[0] = prelu4(uv[0], a21); uv[1] = prelu4(uv[1], a21);
-        uv[2] = prelu4(uv[2], a22); uv[3] = prelu4(uv[3], a22);
-        f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-        wu = mma_block(wu, lw[G1_W(0, 0) * 64 + lane], uv[0]);
-        wv = mma_block(wv, lw[G1_W(1, 0) * 64 + lane], uv[2]);
-        wu = mma_block(wu, lw[G1_W(0, 1) * 64 + lane], uv[1]);
-        wv = mma_block(wv, lw[G1_W(1, 1) * 64 + lane], uv[3]);
-        if (valid && !ABL(a, 3)) {
-            *(f32x4*)(a.u + p * ROWW + 4 * q) = wu;
-            *(f32x4*)(a.v + p * ROWW + 4 * q) = wv;
-        }
+        for (int k = 0; k < KS; ++k) { ss_c[k] = ss_n[k]; sm_c[k] = sm_n[k]; }
+        w.it += w.stride;
+    }
+}
+
+template <int KS, int KP>
+__global__ __launch_bounds__(256) void k_stage1_fast(DaArgs a) {
+    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
+    const float* lscal = lbias + G1_BIAS * 16;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (s11 <= 1.f) {
+        if (s12 <= 1.f) stage1_fast_loop<KS, KP, true, true>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
+        else stage1_fast_loop<KS, KP, true, false>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
+    } else {
+        if (s12 <= 1.f) stage1_fast_loop<KS, KP, false, true>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
+        else stage1_fast_loop<KS, KP, false, false>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 2: neighbour means of u / v, layer-2 Linear pair, PReLU2 -> x_latent; Bipartite fc1 + PReLU, mask
-// gate, and the per-tile station sum.                      module.py:94-96, :229
+// stage 2: second pair of neighbour means (of the projected operands), PReLU2 -> x_latent; Bipartite fc1 + PReLU,
+// mask gate, and the per-tile station sum.                      module.py:94-96, :229
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
@@ -555,48 +834,37 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
         int gi, tb;
-        w.decode(gi, tb);
+        w.decode(w.it, gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
 #if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
+        asm volatile("" : "+v"(lane));
 #endif
         const int s = tb * 16 + j;
         const bool valid = s < S;
         const int sc = valid ? s : S - 1;
         const long long p = (long long)g * S + sc;
-        const f32x4* own = (const f32x4*)(a.h1 + p * ROWP2) + q;
-        f32x4 hb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) hb[k] = (a.nt & 2) ? ld_stream((const float*)(own + 4 * k)) : own[4 * k];
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
         const float mq = a.mask[p * 4 + q];
         const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
         // neighbour means of the projected operands (16-float rows): they ARE the accumulator contributions
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n2a = {0.f, 0.f, 0.f, 0.f}, dummy = {0.f, 0.f, 0.f, 0.f};
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
         {
             const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            const float* base = a.u + (long long)g * S * ROWW + 4 * q;
-            if (!ABL(a, 0)) gather_sum<8, false, false, 1>(base, ROWW, a.sta_col, eb, ee, 0.f, n1a, dummy);
-            n1a *= 1.f / (float)max(ee - eb, 1);
+            const float* base = a.wu + (long long)g * S * ROWW + 4 * q;
+            if (!ABL(a, 0)) gather_sum16<false>(base, ROWW, a.sta_col, eb, ee, n1);
+            n1 *= 1.f / (float)max(ee - eb, 1);
         }
         {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.v + (long long)sc * ROWW + 4 * q;
-            if (!ABL(a, 1)) gather_sum<8, false, true, 1>(base, (long long)S * ROWW, a.src_col, eb, ee, 0.f, n2a, dummy);
-            n2a *= 1.f / (float)max(ee - eb, 1);
+            const float* base = a.wv + (long long)sc * ROWW + 4 * q;
+            if (!ABL(a, 1)) gather_sum16<true>(base, (long long)S * ROWW, a.src_col, eb, ee, n2);
+            n2 *= 1.f / (float)max(ee - eb, 1);
         }
-        f32x4 o[2];
-        o[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q) + n1a;
-        o[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q) + n2a;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            o[0] = mma_block(o[0], lw[G2_O(0, b) * 64 + lane], hb[b]);
-            o[1] = mma_block(o[1], lw[G2_O(1, b) * 64 + lane], hb[b]);
-        }
-        o[0] = MFMA16(lw[G2_O(0, 4) * 64 + lane].x, mq, o[0]);
-        o[1] = MFMA16(lw[G2_O(1, 4) * 64 + lane].x, mq, o[1]);
-        o[0] = prelu4(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
-        o[1] = prelu4(o[1], a2);   // x_latent[15:30]
+        o[0] = prelu4u(o[0] + n1, a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
+        o[1] = prelu4u(o[1] + n2, a2);   // x_latent[15:30]
         if (a.x_latent != nullptr && valid) {
             float* xl = a.x_latent + p * 30;
 #pragma unroll
@@ -609,14 +877,14 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
         }
         // Bipartite message: m_p * PReLU_b1(fc1 [x_latent || edge_attr])
         f32x4 bp[2];
-        bp[0] = *(const f32x4*)(lbias + 2 * 16 + 4 * q);
-        bp[1] = *(const f32x4*)(lbias + 3 * 16 + 4 * q);
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
             bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-            bp[t] = prelu4(bp[t], ab1);
+            bp[t] = prelu4u(bp[t], ab1);
         }
         float mm = fmaxf(mq, __shfl_xor(mq, 16));
         mm = fmaxf(mm, __shfl_xor(mm, 32));
@@ -788,12 +1056,12 @@ __global__ void k_xcc_probe(int* out) {
 
 // de-pad rows of a workspace tensor for parity tests
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
-    // padded rows are [30 valid, 2 pad] per 32-float half (h0, h1) or [15 valid, 1 pad] (wu, wv)
+    // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * ncol) return;
     const long long r = idx / ncol;
     const int cc = (int)(idx % ncol);
-    const int off = ncol == 15 ? cc : (cc / 30) * 32 + cc % 30;
+    const int off = ncol == 15 ? cc : (cc / 15) * 16 + cc % 15;   // c = [c1 15,0 | c2 15,0]
     dst[idx] = src[r * pitch + off];
 }
 
@@ -809,15 +1077,17 @@ struct genie_ctx {
     int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
     float* raw;
     bool dirty;
-    StagePlan plan[3];
-    StepDesc* d_steps[3];
-    BiasDesc* d_bias[3];
-    int32_t* d_scal[3];
-    float* packed[3];
+    StagePlan plan[2];
+    StepDesc* d_steps[2];
+    BiasDesc* d_bias[2];
+    int32_t* d_scal[2];
+    float* packed[2];
     int num_cu;
-    int seg, nt, bpc1, bpc2;   // tuning knobs (env GENIE_SEG / GENIE_NT / GENIE_BPC1 / GENIE_BPC2)
+    int seg, bpc1, bpc1f, bpc2;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
+    int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
+    int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     // workspace offsets (floats)
-    size_t o_h0, o_h1, o_u, o_v, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_glob, ws_floats;
+    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, ws_floats;
 };
 
 namespace {
@@ -827,16 +1097,14 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 void layout_ws(genie_ctx* c) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 64); return r; };
-    c->o_h0 = take((size_t)c->P_ext * ROWP);
-    c->o_h1 = take((size_t)c->P * ROWP2);
-    c->o_u = take((size_t)c->P * ROWW);
-    c->o_v = take((size_t)c->P_ext * ROWW);
+    c->o_c = take((size_t)c->P * ROWC);
+    c->o_wu = take((size_t)c->P * ROWW);
+    c->o_wv = take((size_t)c->P_ext * ROWW);
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
     c->o_sa1 = take((size_t)c->G * 32);
     c->o_bip = take((size_t)c->G * 16);
     c->o_gpart = take(1024 * 8);
-    c->o_glob = take(64);
     c->ws_floats = o;
 }
 
@@ -851,7 +1119,7 @@ int dev_copy(T** dst, const T* src_dev, size_t n) {
 
 int ensure_packed(genie_ctx* c, hipStream_t st) {
     if (!c->dirty) return GENIE_OK;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 2; ++s) {
         const StagePlan& p = c->plan[s];
         const int total = p.packed_floats();
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
@@ -873,13 +1141,13 @@ int da_grid(const genie_ctx* c, long long nitems_waves, int blocks_per_cu) {
 DaArgs make_da_args(const genie_ctx* c, float* ws) {
     DaArgs a;
     memset(&a, 0, sizeof(a));
-    a.S = c->S; a.G = c->G; a.T = c->T; a.P_ext = c->P_ext;
+    a.S = c->S; a.G = c->G; a.T = c->T;
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
-    a.seg = std::max(1, c->seg); a.nt = c->nt;
+    a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
-    a.h0 = ws + c->o_h0; a.h1 = ws + c->o_h1; a.u = ws + c->o_u; a.v = ws + c->o_v; a.part = ws + c->o_part;
+    a.c = ws + c->o_c; a.wu = ws + c->o_wu; a.wv = ws + c->o_wv; a.part = ws + c->o_part;
     return a;
 }
 
@@ -920,6 +1188,18 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     if (e_sta < 0 || e_src < 0) return fail(GENIE_ERR_ARG, "negative edge count in rowptr");
     if ((e_sta > 0 && !sta_col) || (e_src > 0 && !src_col)) return fail(GENIE_ERR_ARG, "null col array");
     c->E_src = e_src;
+    {   // uniform-degree detection (kNN graphs) selects the pipelined stage-1 kernel
+        std::vector<int32_t> rp((size_t)std::max(n_sta, n_grid) + 1);
+        auto uniform = [&](const int32_t* dev, int n) -> int {
+            if (hipMemcpy(rp.data(), dev, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            const int k = rp[1] - rp[0];
+            for (int i = 0; i < n; ++i)
+                if (rp[i + 1] - rp[i] != k) return -1;
+            return k;
+        };
+        c->ks_uni = uniform(sta_rowptr, n_sta);
+        c->kp_uni = uniform(src_rowptr, n_grid);
+    }
     int rc;
     if ((rc = dev_copy(&c->sta_rowptr, sta_rowptr, (size_t)n_sta + 1))) return rc;
     if ((rc = dev_copy(&c->sta_col, sta_col, (size_t)e_sta))) return rc;
@@ -939,11 +1219,11 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMalloc((void**)&c->raw, sizeof(float) * g_raw_total));
     HIP_TRY(hipMemset(c->raw, 0, sizeof(float) * g_raw_total));
-    build_plans(c->plan[0], c->plan[1], c->plan[2]);
-    if (c->plan[0].n_groups() != G0_GROUPS || c->plan[1].n_groups() != G1_GROUPS || c->plan[2].n_groups() != G2_GROUPS ||
-        (int)c->plan[1].bias.size() != G1_BIAS || (int)c->plan[2].bias.size() != G2_BIAS)
+    build_plans(c->plan[0], c->plan[1]);
+    if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
+        (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS)
         return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 2; ++s) {
         const StagePlan& p = c->plan[s];
         HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
         HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
@@ -962,12 +1242,15 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     {
         const char* e;
         c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : 1;
-        c->nt = (e = getenv("GENIE_NT")) ? atoi(e) : 0;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
         int occ1 = 0, occ2 = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
+        int occ1f = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1f, k_stage1_fast<8, 15>, 256, 0));
         c->bpc1 = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1);
+        c->bpc1f = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1f);
+        c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
         c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
 #if GENIE_TUNING
@@ -986,8 +1269,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
-                    c->d_steps[0], c->d_steps[1], c->d_steps[2], c->d_bias[0], c->d_bias[1], c->d_bias[2],
-                    c->d_scal[0], c->d_scal[1], c->d_scal[2], c->packed[0], c->packed[1], c->packed[2]};
+                    c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1]};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -1026,34 +1309,36 @@ int genie_weights_commit(genie_ctx* c, void* stream) {
 
 size_t genie_workspace_bytes(const genie_ctx* c) { return c ? c->ws_floats * sizeof(float) : 0; }
 
-int genie_da_stage0(genie_ctx* c, const float* slice, const float* mask, void* ws, void* stream) {
+namespace {
+int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h0, float* dbg_h1, void* ws, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
-    if (!slice || !mask) return fail(GENIE_ERR_ARG, "genie_da_stage0: null input");
+    if (!slice || !mask) return fail(GENIE_ERR_ARG, "genie_da_stage1: null input");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
-    const long long ntiles = (c->P_ext + 15) / 16;
-    k_stage0<<<da_grid(c, ntiles, 8), 256, 0, st>>>(a);
+    a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
+    if (c->use_fast)
+        k_stage1_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc1f), 256, 0, st>>>(a);
+    else
+        k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
+}  // namespace
 
-int genie_da_stage1(genie_ctx* c, const float* mask, void* ws, void* stream) {
-    int rc = check_ws(c, ws);
-    if (rc) return rc;
-    if (!mask) return fail(GENIE_ERR_ARG, "genie_da_stage1: null mask");
-    hipStream_t st = (hipStream_t)stream;
-    if ((rc = ensure_packed(c, st))) return rc;
-    DaArgs a = make_da_args(c, (float*)ws);
-    a.mask = mask; a.packed = c->packed[1];
-    k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
-    HIP_TRY(hipGetLastError());
-    return GENIE_OK;
+int genie_da_stage1(genie_ctx* c, const float* slice, const float* mask, void* ws, void* stream) {
+    return run_stage1(c, slice, mask, nullptr, nullptr, ws, stream);
 }
 
-float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_v : nullptr; }
+int genie_da_stage1_debug(genie_ctx* c, const float* slice, const float* mask, float* h0_out, float* h1_out, void* ws,
+                          void* stream) {
+    if (!h0_out || !h1_out) return fail(GENIE_ERR_ARG, "genie_da_stage1_debug: null output");
+    return run_stage1(c, slice, mask, h0_out, h1_out, ws, stream);
+}
+
+float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_wv : nullptr; }
 int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
 int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out,
@@ -1064,7 +1349,7 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
-    a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[2];
+    a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
     const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
     k_bip_out<<<nb, 256, 0, st>>>(a.part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off,
@@ -1114,8 +1399,7 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     if (!x_spatial_out || !pos) return fail(GENIE_ERR_ARG, "genie_path_fwd: null argument");
     float* w = (float*)ws;
     float* bip = bip_out ? bip_out : w + c->o_bip;
-    if ((rc = genie_da_stage0(c, slice, mask, ws, stream))) return rc;
-    if ((rc = genie_da_stage1(c, mask, ws, stream))) return rc;
+    if ((rc = genie_da_stage1(c, slice, mask, ws, stream))) return rc;
     if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
     if ((rc = genie_spatial_agg_fwd(c, 1, bip, pos, w + c->o_sa0, ws, stream))) return rc;
     if ((rc = genie_spatial_agg_fwd(c, 2, w + c->o_sa0, pos, w + c->o_sa1, ws, stream))) return rc;
@@ -1138,11 +1422,10 @@ int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream)
     float* w = (float*)ws;
     const float* src; long long rows; int pitch, ncol;
     switch (which) {
-        case 0: src = w + c->o_h0; rows = c->P_ext; pitch = ROWP; ncol = 30; break;
-        case 1: src = w + c->o_h1; rows = c->P; pitch = ROWP2; ncol = 60; break;
-        case 2: src = w + c->o_u; rows = c->P; pitch = ROWW; ncol = 15; break;
-        case 3: src = w + c->o_v; rows = c->P; pitch = ROWW; ncol = 15; break;
-        default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..3");
+        case 0: src = w + c->o_c; rows = c->P; pitch = ROWC; ncol = 30; break;
+        case 1: src = w + c->o_wu; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 2: src = w + c->o_wv; rows = c->P; pitch = ROWW; ncol = 15; break;
+        default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..2");
     }
     const long long n = rows * ncol;
     k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out);

@@ -148,14 +148,18 @@ class HipPath(object):
             self._w_key = key
 
     # ---- stages --------------------------------------------------------------------------------
-    def da_stage0(self, Slice, Mask):
+    def da_stage1(self, Slice, Mask, debug=False):
+        """Stage 1 (genie_da_stage1). Returns the validated (Slice, Mask) [, h0, h1 when debug]."""
         Slice = _f32(Slice, "Slice", (self.n_grid_ext * self.n_sta, 4))
         Mask = _f32(Mask, "Mask", (self.n_grid_ext * self.n_sta, 4))
-        _lib.check(self.lib.genie_da_stage0(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage0")
-        return Slice, Mask
-
-    def da_stage1(self, Mask):
-        _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage1")
+        if not debug:
+            _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage1")
+            return Slice, Mask
+        h0 = torch.empty((self.n_prod, 30), dtype=torch.float32, device=self.device)
+        h1 = torch.empty((self.n_prod, 60), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_da_stage1_debug(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(h0), _ptr(h1), self._ws_ptr,
+                                                  _stream()), "genie_da_stage1_debug")
+        return Slice, Mask, h0, h1
 
     def da_stage2_bipartite(self, Mask, edge_attr, want_x_latent=False):
         edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
@@ -189,10 +193,9 @@ class HipPath(object):
         return out, x_latent, bip
 
     def export(self, which):
-        """Parity/debug: de-padded copy of a workspace intermediate (0=h0 [.,30], 1=h1 [.,60], 2=wu [.,15],
-        3=wv [.,15]; wu/wv are u/v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2)."""
-        rows = self.n_grid_ext * self.n_sta if which == 0 else self.n_prod
-        cols = {0: 30, 1: 60, 2: 15, 3: 15}[which]
-        out = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
+        """Parity/debug: de-padded copy of a workspace intermediate: 0 = c [P,30] (node-local layer-2 terms),
+        1 = wu [P,15], 2 = wv [P,15] (u / v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2)."""
+        cols = {0: 30, 1: 15, 2: 15}[which]
+        out = torch.empty((self.n_prod, cols), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_ws_export(self.ctx, which, self._ws_ptr, _ptr(out), _stream()), "genie_ws_export")
         return out

@@ -83,20 +83,21 @@ int genie_weights_commit(genie_ctx* ctx, void* stream);
 size_t genie_workspace_bytes(const genie_ctx* ctx);
 
 /*
- * DataAggregation, stage 0 (module.py:87-88): h0 = PReLU(init_trns([Slice || Mask])) for ALL n_grid_ext*n_sta
- * rows (owned + halo; halo rows of Slice/Mask are shipped raw, 8 floats per row, and recomputed locally).
- *   slice, mask : [n_grid_ext*n_sta, 4] fp32. Result is kept in the workspace.
+ * DataAggregation, stage 1 = everything that does not need the SECOND pair of neighbour means (module.py:87-95).
+ * For every OWNED product node, with h0 = PReLU(init_trns([Slice || Mask])) recomputed on the fly for the node and
+ * for each of its neighbours from their raw 8 input floats (h0 is never stored):
+ *   h1 = PReLU1([l1_t1_2[h0||mean_sta PReLU11(h0)||M] || l1_t2_2[h0||mean_src PReLU12(h0)||M]])
+ *   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)
+ *   wu = l2_t1_2.weight[:, 60:90] u,  wv = l2_t2_2.weight[:, 60:90] v      (mean_N(W x) = W mean_N(x): the 15-channel
+ *                                                                         operands the second pair of means averages)
+ *   c  = [l2_t1_2.weight[:, 0:60] h1 + l2_t1_2.weight[:, 90:94] M + bias || same for l2_t2_2]   (node-local part)
+ *   slice, mask : [n_grid_ext*n_sta, 4] fp32 — halo rows (sharded case) are shipped raw, 8 floats per row.
+ * c, wu, wv are kept in the workspace; h1, u, v never leave the registers.
  */
-int genie_da_stage0(genie_ctx* ctx, const float* slice, const float* mask, void* ws, void* stream);
-/*
- * DataAggregation, stage 1 (module.py:90-95 up to the second pair of `propagate` calls): for OWNED rows
- *   h1 = PReLU1([l1_t1_2[h0||mean_sta PReLU11(h0)||M] || l1_t2_2[h0||mean_src PReLU12(h0)||M]]),
- *   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1), and — because mean_N(W x) = W mean_N(x) — the
- *   projections the second pair of propagate calls will average:
- *   wu = l2_t1_2.weight[:, 60:90] u,  wv = l2_t2_2.weight[:, 60:90] v   (15 channels each).
- *   h1, wu, wv are kept in the workspace (u, v themselves are never stored).
- */
-int genie_da_stage1(genie_ctx* ctx, const float* mask, void* ws, void* stream);
+int genie_da_stage1(genie_ctx* ctx, const float* slice, const float* mask, void* ws, void* stream);
+/* Parity/debug variant: additionally writes h0 [n_grid*n_sta, 30] and h1 [n_grid*n_sta, 60]. */
+int genie_da_stage1_debug(genie_ctx* ctx, const float* slice, const float* mask, float* h0_out, float* h1_out,
+                          void* ws, void* stream);
 /*
  * Halo access for the sharded case: device pointer / row pitch (floats) of the projected `wv` activations
  * inside the workspace, laid out [n_grid_ext*n_sta, pitch] (pitch = 16: 15 channels + 1 zero); rows
@@ -106,7 +107,7 @@ float* genie_ws_v_ptr(const genie_ctx* ctx, void* ws);
 int genie_ws_v_pitch(const genie_ctx* ctx);
 /*
  * DataAggregation stage 2 + BipartiteGraphOperator (module.py:94-96 and :224-229), OWNED rows:
- *   x_latent = PReLU2([l2_t1_2[h1||mean_sta u||M] || l2_t2_2[h1||mean_src v||M]])          -> optional output
+ *   x_latent = PReLU2(c + [mean_sta wu || mean_src wv])                                      -> optional output
  *   out_g    = PReLU_b2(fc2( sum_s max_c(M) * PReLU_b1(fc1[x_latent || edge_attr]) ))       -> bip_out[n_grid,15]
  *   edge_attr : [n_grid*n_sta, 3] (`A_src_in_edges.x`, process_continuous_days.py:630)
  *   x_latent_out : [n_grid*n_sta, 30] or NULL when the caller does not need it (forward_fixed_source)
@@ -134,8 +135,8 @@ int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const 
                    const float* pos, float* x_spatial_out, float* x_latent_out, float* bip_out,
                    void* ws, void* stream);
 
-/* Debug/parity access to intermediates kept in the workspace (which: 0=h0 [P_ext,30], 1=h1 [P,60], 2=wu [P,15],
- * 3=wv [P,15]); copies de-padded rows into `out` (async). */
+/* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
+ * copies de-padded rows into `out` (async). */
 int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);
 
 #ifdef __cplusplus

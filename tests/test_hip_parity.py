@@ -32,17 +32,24 @@ def test_stages_match_golden_intermediates(name):
     """Every stage of the HIP path against the reference's own intermediates (golden fixtures)."""
     c = Case(name)
     hp = make_engine(c)
-    Slice, Mask = hp.da_stage0(c.Slice.to(DEV), c.Mask.to(DEV))
-    hp.da_stage1(Mask)
+    Slice, Mask, h0, h1 = hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV), debug=True)
     x_latent, bip = hp.da_stage2_bipartite(Mask, c.edge_attr.to(DEV), want_x_latent=True)
-    got = {"h0": hp.export(0), "h1": hp.export(1), "x_latent": x_latent, "bip": bip}
-    # stage 1 stores u / v already projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2
+    got = {"h0": h0, "h1": h1, "x_latent": x_latent, "bip": bip}
+    # stage 1 stores u / v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2, and the node-local
+    # part of layer 2 (c) instead of h1
     w = c.weights
-    for key, which, lin in (("u", 2, "DataAggregation.l2_t1_2.weight"), ("v", 3, "DataAggregation.l2_t2_2.weight")):
+    W1, W2 = w["DataAggregation.l2_t1_2.weight"], w["DataAggregation.l2_t2_2.weight"]
+    for key, which, W in (("u", 1, W1), ("v", 2, W2)):
         proj = hp.export(which).cpu()
         if key in c.z.files:
-            ref = c.ref(key) @ w[lin][:, 60:90].T
+            ref = c.ref(key) @ W[:, 60:90].T
             assert max_abs(c.strided(proj), ref) <= rel_tol(ref), ("projected " + key, max_abs(c.strided(proj), ref))
+    if "h1" in c.z.files and c.row_stride == 1:
+        cc = hp.export(0).cpu()
+        M = c.Mask
+        ref = torch.cat((c.ref("h1") @ W1[:, 0:60].T + M @ W1[:, 90:94].T + w["DataAggregation.l2_t1_2.bias"],
+                         c.ref("h1") @ W2[:, 0:60].T + M @ W2[:, 90:94].T + w["DataAggregation.l2_t2_2.bias"]), dim=1)
+        assert max_abs(cc, ref) <= rel_tol(ref), ("c", max_abs(cc, ref))
     pos = c.x_grid.float().to(DEV)
     got["sa1"] = hp.spatial_agg(1, bip, pos)
     got["sa2"] = hp.spatial_agg(2, got["sa1"], pos)
