@@ -75,6 +75,10 @@ enum {
     W_SA1_FC1_W, W_SA1_FC1_B, W_SA1_FC2_W, W_SA1_FC2_B, W_SA1_FG_W, W_SA1_FG_B, W_SA1_ACT1, W_SA1_ACT2, W_SA1_ACT3,
     W_SA2_FC1_W, W_SA2_FC1_B, W_SA2_FC2_W, W_SA2_FC2_B, W_SA2_FG_W, W_SA2_FG_B, W_SA2_ACT1, W_SA2_ACT2, W_SA2_ACT3,
     W_SA3_FC1_W, W_SA3_FC1_B, W_SA3_FC2_W, W_SA3_FC2_B, W_SA3_FG_W, W_SA3_FG_B, W_SA3_ACT1, W_SA3_ACT2, W_SA3_ACT3,
+    W_SD_W, W_SD_B, W_SD_ACT,
+    W_TA_Q1_W, W_TA_Q1_B, W_TA_Q2_W, W_TA_Q2_B, W_TA_C1_W, W_TA_C1_B, W_TA_C2_W, W_TA_C2_B, W_TA_V1_W, W_TA_V1_B,
+    W_TA_V2_W, W_TA_V2_B, W_TA_P1_W, W_TA_P1_B, W_TA_P2_W, W_TA_P2_B, W_TA_ACT1, W_TA_ACT2, W_TA_ACT3, W_TA_ACT4, W_TA_ACT5,
+    W_SAT_Q_W, W_SAT_Q_B, W_SAT_C_W, W_SAT_C_B, W_SAT_V_W, W_SAT_V_B, W_SAT_P_W, W_SAT_P_B, W_SAT_ACT1, W_SAT_ACT2,
     W_COUNT
 };
 
@@ -108,6 +112,23 @@ Param g_params[W_COUNT] = {
     {"SpatialAggregation3.fglobal.weight", 5 * 30, 0}, {"SpatialAggregation3.fglobal.bias", 5, 0},
     {"SpatialAggregation3.activate1.weight", 1, 0}, {"SpatialAggregation3.activate2.weight", 1, 0},
     {"SpatialAggregation3.activate3.weight", 1, 0},
+    {"SpatialDirect.f_direct.weight", 30 * 30, 0}, {"SpatialDirect.f_direct.bias", 30, 0}, {"SpatialDirect.activate.weight", 1, 0},
+    {"TemporalAttention.temporal_query_1.weight", 30, 0}, {"TemporalAttention.temporal_query_1.bias", 30, 0},
+    {"TemporalAttention.temporal_query_2.weight", 75 * 30, 0}, {"TemporalAttention.temporal_query_2.bias", 75, 0},
+    {"TemporalAttention.f_context_1.weight", 30 * 30, 0}, {"TemporalAttention.f_context_1.bias", 30, 0},
+    {"TemporalAttention.f_context_2.weight", 75 * 30, 0}, {"TemporalAttention.f_context_2.bias", 75, 0},
+    {"TemporalAttention.f_values_1.weight", 30 * 30, 0}, {"TemporalAttention.f_values_1.bias", 30, 0},
+    {"TemporalAttention.f_values_2.weight", 75 * 30, 0}, {"TemporalAttention.f_values_2.bias", 75, 0},
+    {"TemporalAttention.proj_1.weight", 30 * 15, 0}, {"TemporalAttention.proj_1.bias", 30, 0},
+    {"TemporalAttention.proj_2.weight", 30, 0}, {"TemporalAttention.proj_2.bias", 1, 0},
+    {"TemporalAttention.activate1.weight", 1, 0}, {"TemporalAttention.activate2.weight", 1, 0},
+    {"TemporalAttention.activate3.weight", 1, 0}, {"TemporalAttention.activate4.weight", 1, 0},
+    {"TemporalAttention.activate5.weight", 1, 0},
+    {"SpatialAttention.f_queries.weight", 75 * 3, 0}, {"SpatialAttention.f_queries.bias", 75, 0},
+    {"SpatialAttention.f_context.weight", 75 * 33, 0}, {"SpatialAttention.f_context.bias", 75, 0},
+    {"SpatialAttention.f_values.weight", 75 * 33, 0}, {"SpatialAttention.f_values.bias", 75, 0},
+    {"SpatialAttention.proj.weight", 30 * 15, 0}, {"SpatialAttention.proj.bias", 30, 0},
+    {"SpatialAttention.activate1.weight", 1, 0}, {"SpatialAttention.activate2.weight", 1, 0},
 };
 
 int g_raw_total = 0;
@@ -1054,6 +1075,253 @@ __global__ void k_xcc_probe(int* out) {
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Read-out heads (module.py:251-331), G- / Q-sized: 32 lanes per node, 8 nodes per workgroup, weights transposed in
+// LDS, per-node vectors exchanged through LDS. MODE 0: y = TemporalAttention(SpatialDirect(x_spatial)) per grid
+// node (module.py:1015-1016); MODE 1: x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query
+// (module.py:1017-1018), the K = 10 nearest grid nodes of every query given as an index table.
+// ------------------------------------------------------------------------------------------------
+struct RoArgs {
+    int N, G, T;                 // nodes handled (G for MODE 0, Q for MODE 1), grid size, number of time queries (<= 16)
+    const float* x_spatial;      // [G,30]
+    const float* x_grid;         // [G,3]   (MODE 1)
+    const float* x_query;        // [Q,3]   (MODE 1)
+    const int32_t* knn;          // [Q,10]  (MODE 1)
+    const float* t_query;        // [T]
+    const float* raw;
+    float scale_rel, scale_t;
+    float* out;                  // [N,T]
+    int o_sd_w, o_sd_b, o_sd_a;
+    int o_q1w, o_q1b, o_q2w, o_q2b, o_c1w, o_c1b, o_c2w, o_c2b, o_v1w, o_v1b, o_v2w, o_v2b, o_p1w, o_p1b, o_p2w, o_p2b;
+    int o_a1, o_a2, o_a3, o_a4, o_a5;
+    int o_sq_w, o_sq_b, o_sc_w, o_sc_b, o_sv_w, o_sv_b, o_sp_w, o_sp_b, o_sa1, o_sa2;
+};
+
+// dst[k*ldo + c] = W[c][k] for c < rows (else 0), c < ldo
+__device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
+    for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
+        const int k = i / ldo, c = i - k * ldo;
+        dst[i] = c < rows ? W[c * ld + k] : 0.f;
+    }
+}
+
+constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
+constexpr int RO_TMAX = 16;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_readout(RoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    // ---- LDS carve (floats)
+    float* w_c1 = sm;                    // [30][32]
+    float* w_v1 = w_c1 + 30 * 32;        // [30][32]
+    float* w_c2 = w_v1 + 30 * 32;        // [30][96]
+    float* w_v2 = w_c2 + 30 * 96;        // [30][96]
+    float* w_p1 = w_v2 + 30 * 96;        // [15][32]
+    float* w_p2 = w_p1 + 15 * 32;        // [32]
+    float* qry = w_p2 + 32;              // [RO_TMAX][96]
+    float* w_x0 = qry + RO_TMAX * 96;    // MODE 0: f_direct [30][32];  MODE 1: f_queries [3][96]
+    float* w_fc = w_x0 + (MODE == 0 ? 30 * 32 : 3 * 96);   // MODE 1: f_context [33][96]
+    float* w_fv = w_fc + (MODE == 0 ? 0 : 33 * 96);        // MODE 1: f_values [33][96]
+    float* w_pr = w_fv + (MODE == 0 ? 0 : 33 * 96);        // MODE 1: proj [15][32]
+    float* scr = w_pr + (MODE == 0 ? 0 : 15 * 32);         // per-group scratch
+    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96 + (MODE == 1 ? RO_K * 96 : 0);   // floats per group
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
+    float* h1 = xin + 40;                // [32]
+    float* h2 = h1 + 32;                 // [32]
+    float* ctx = h2 + 32;                // [96]
+    float* val = ctx + 96;               // [96]
+    float* scs = val + 96;               // [48]  score[t*5+h]
+    float* zs = scs + 48;                // [T][16]
+    float* p1s = zs + RO_TMAX * 16;      // [T][32]
+    float* prd = p1s + RO_TMAX * 32;     // [96]  q*c products / aggregated values (MODE 1)
+    float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
+    float* vst = als + 96;               // [10][96] per-edge value embeddings (MODE 1)
+
+    stage_transposed_ld(w_c1, a.raw + a.o_c1w, 30, 30, 32);
+    stage_transposed_ld(w_v1, a.raw + a.o_v1w, 30, 30, 32);
+    stage_transposed_ld(w_c2, a.raw + a.o_c2w, 75, 30, 96);
+    stage_transposed_ld(w_v2, a.raw + a.o_v2w, 75, 30, 96);
+    stage_transposed_ld(w_p1, a.raw + a.o_p1w, 30, 15, 32);
+    if (threadIdx.x < 32) w_p2[threadIdx.x] = threadIdx.x < 30 ? a.raw[a.o_p2w + threadIdx.x] : 0.f;
+    if (MODE == 0) {
+        stage_transposed_ld(w_x0, a.raw + a.o_sd_w, 30, 30, 32);
+    } else {
+        stage_transposed_ld(w_x0, a.raw + a.o_sq_w, 75, 3, 96);
+        stage_transposed_ld(w_fc, a.raw + a.o_sc_w, 75, 33, 96);
+        stage_transposed_ld(w_fv, a.raw + a.o_sv_w, 75, 33, 96);
+        stage_transposed_ld(w_pr, a.raw + a.o_sp_w, 30, 15, 32);
+    }
+    // temporal queries: qry[t][ch] = temporal_query_2(PReLU3(temporal_query_1(t_query/scale_t)))   module.py:329
+    {
+        const float act3 = a.raw[a.o_a3];
+        for (int i = threadIdx.x; i < RO_TMAX * 96; i += blockDim.x) {
+            const int t = i / 96, ch = i - t * 96;
+            float v = 0.f;
+            if (t < a.T && ch < 75) {
+                const float tq = a.t_query[t] / a.scale_t;
+                v = a.raw[a.o_q2b + ch];
+                for (int k = 0; k < 30; ++k) {
+                    const float hq = prelu1(a.raw[a.o_q1w + k] * tq + a.raw[a.o_q1b + k], act3);
+                    v += a.raw[a.o_q2w + ch * 30 + k] * hq;
+                }
+            }
+            qry[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const float act1 = a.raw[a.o_a1], act2 = a.raw[a.o_a2], act4 = a.raw[a.o_a4], act5 = a.raw[a.o_a5];
+    const float b_c1 = c < 30 ? a.raw[a.o_c1b + c] : 0.f, b_v1 = c < 30 ? a.raw[a.o_v1b + c] : 0.f;
+    const float b_c2[3] = {a.raw[a.o_c2b + c], a.raw[a.o_c2b + 32 + c], c < 11 ? a.raw[a.o_c2b + 64 + c] : 0.f};
+    const float b_v2[3] = {a.raw[a.o_v2b + c], a.raw[a.o_v2b + 32 + c], c < 11 ? a.raw[a.o_v2b + 64 + c] : 0.f};
+    const float b_p1 = c < 30 ? a.raw[a.o_p1b + c] : 0.f, b_p2 = a.raw[a.o_p2b];
+    const float inv_sqrt_l = 1.f / sqrtf(15.f);
+
+    for (int n0 = blockIdx.x * NPB; n0 < a.N; n0 += gridDim.x * NPB) {
+        const int n = n0 + grp;
+        const bool ok = n < a.N;
+        const int nc = ok ? n : a.N - 1;
+        // ------------------------------------------------------------------ front end -> 30-vector in xin
+        if (MODE == 0) {
+            xin[c] = c < 30 ? a.x_spatial[(long long)nc * 30 + c] : 0.f;
+            __syncthreads();
+            float y = c < 30 ? a.raw[a.o_sd_b + c] : 0.f;                               // SpatialDirect, module.py:258-260
+#pragma unroll
+            for (int k = 0; k < 30; ++k) y += w_x0[k * 32 + c] * xin[k];
+            y = prelu1(y, a.raw[a.o_sd_a]);
+            __syncthreads();
+            xin[c] = c < 30 ? y : 0.f;
+            __syncthreads();
+        } else {
+            const float sa1 = a.raw[a.o_sa1], sa2 = a.raw[a.o_sa2];
+            const float bq[3] = {a.raw[a.o_sq_b + c], a.raw[a.o_sq_b + 32 + c], c < 11 ? a.raw[a.o_sq_b + 64 + c] : 0.f};
+            const float bc[3] = {a.raw[a.o_sc_b + c], a.raw[a.o_sc_b + 32 + c], c < 11 ? a.raw[a.o_sc_b + 64 + c] : 0.f};
+            const float bv[3] = {a.raw[a.o_sv_b + c], a.raw[a.o_sv_b + 32 + c], c < 11 ? a.raw[a.o_sv_b + 64 + c] : 0.f};
+#pragma unroll 1
+            for (int k = 0; k < RO_K; ++k) {
+                const int jn = a.knn[(long long)nc * RO_K + k];
+                if (c < 30) xin[c] = a.x_spatial[(long long)jn * 30 + c];
+                if (c < 3) xin[30 + c] = (a.x_query[nc * 3 + c] - a.x_grid[jn * 3 + c]) / a.scale_rel;                 // :283
+                __syncthreads();
+                float q3[3] = {bq[0], bq[1], bq[2]}, c3[3] = {bc[0], bc[1], bc[2]};
+                float v3[3] = {bv[0], bv[1], bv[2]};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float e = xin[30 + d];
+                    q3[0] += w_x0[d * 96 + c] * e; q3[1] += w_x0[d * 96 + 32 + c] * e; q3[2] += w_x0[d * 96 + 64 + c] * e;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 33; ++kk) {
+                    const float xv = xin[kk];
+                    c3[0] += w_fc[kk * 96 + c] * xv; c3[1] += w_fc[kk * 96 + 32 + c] * xv; c3[2] += w_fc[kk * 96 + 64 + c] * xv;
+                    v3[0] += w_fv[kk * 96 + c] * xv; v3[1] += w_fv[kk * 96 + 32 + c] * xv; v3[2] += w_fv[kk * 96 + 64 + c] * xv;
+                }
+                prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
+                vst[k * 96 + c] = v3[0]; vst[k * 96 + 32 + c] = v3[1]; vst[k * 96 + 64 + c] = v3[2];
+                __syncthreads();
+                if (c < 5) {                                                            // alpha = PReLU1(sum_l q*c / sqrt(L))  :293
+                    float sdot = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 15; ++l) sdot += prd[c * 15 + l];
+                    als[k * 8 + c] = prelu1(sdot * inv_sqrt_l, sa1);
+                }
+                __syncthreads();
+            }
+            if (c < 5) {                                                                // segment softmax over the K edges  :295
+                float m = als[c];
+#pragma unroll
+                for (int k = 1; k < RO_K; ++k) m = fmaxf(m, als[k * 8 + c]);
+                float ssum = 0.f, ek[RO_K];
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) { ek[k] = expf(als[k * 8 + c] - m); ssum += ek[k]; }
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) als[k * 8 + c] = ek[k] / (ssum + 1e-16f);
+            }
+            __syncthreads();
+            {
+                const int hd0 = c / 15, hd1 = (32 + c) / 15, hd2 = min((64 + c) / 15, 4);
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f;                                     // 'add' aggregation of alpha * v  :264,297
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) {
+                    g0 += als[k * 8 + hd0] * vst[k * 96 + c];
+                    g1 += als[k * 8 + hd1] * vst[k * 96 + 32 + c];
+                    g2 += als[k * 8 + hd2] * vst[k * 96 + 64 + c];
+                }
+                prd[c] = g0; prd[32 + c] = g1; prd[64 + c] = g2;
+            }
+            __syncthreads();
+            float xm = 0.f;                                                             // mean over heads  :285
+            if (c < 15) {
+#pragma unroll
+                for (int hh = 0; hh < 5; ++hh) xm += prd[hh * 15 + c];
+                xm *= 0.2f;
+            }
+            __syncthreads();
+            xin[c] = xm;
+            __syncthreads();
+            float xo = c < 30 ? a.raw[a.o_sp_b + c] : 0.f;                              // PReLU2(proj(.))  :285
+#pragma unroll
+            for (int l = 0; l < 15; ++l) xo += w_pr[l * 32 + c] * xin[l];
+            xo = prelu1(xo, sa2);
+            __syncthreads();
+            xin[c] = c < 30 ? xo : 0.f;
+            __syncthreads();
+        }
+        // ------------------------------------------------------------------ TemporalAttention on xin[0..29]  :325-331
+        {
+            float t1 = b_c1, t2 = b_v1;
+#pragma unroll
+            for (int k = 0; k < 30; ++k) { const float xv = xin[k]; t1 += w_c1[k * 32 + c] * xv; t2 += w_v1[k * 32 + c] * xv; }
+            h1[c] = c < 30 ? prelu1(t1, act1) : 0.f;
+            h2[c] = c < 30 ? prelu1(t2, act2) : 0.f;
+        }
+        __syncthreads();
+        {
+            float cx[3] = {b_c2[0], b_c2[1], b_c2[2]}, vx[3] = {b_v2[0], b_v2[1], b_v2[2]};
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                const float u1 = h1[k], u2 = h2[k];
+                cx[0] += w_c2[k * 96 + c] * u1; cx[1] += w_c2[k * 96 + 32 + c] * u1; cx[2] += w_c2[k * 96 + 64 + c] * u1;
+                vx[0] += w_v2[k * 96 + c] * u2; vx[1] += w_v2[k * 96 + 32 + c] * u2; vx[2] += w_v2[k * 96 + 64 + c] * u2;
+            }
+            ctx[c] = cx[0]; ctx[32 + c] = cx[1]; ctx[64 + c] = cx[2];
+            val[c] = vx[0]; val[32 + c] = vx[1]; val[64 + c] = vx[2];
+        }
+        __syncthreads();
+        for (int idx = c; idx < a.T * 5; idx += 32) {                                    // score[t,h] = ctx[h,:].qry[t,h,:]/sqrt(L)
+            const int t = idx / 5, hh = idx - t * 5;
+            float sdot = 0.f;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) sdot += ctx[hh * 15 + l] * qry[t * 96 + hh * 15 + l];
+            scs[idx] = sdot * inv_sqrt_l;
+        }
+        __syncthreads();
+        for (int idx = c; idx < a.T * 15; idx += 32) {                                   // z[t,l] = mean_h score[t,h] * val[h,l]
+            const int t = idx / 15, l = idx - t * 15;
+            float z = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 5; ++hh) z += scs[t * 5 + hh] * val[hh * 15 + l];
+            zs[t * 16 + l] = prelu1(z * 0.2f, act4);
+        }
+        __syncthreads();
+        for (int t = 0; t < a.T; ++t) {                                                  // PReLU5(proj_1(.))
+            float pv = b_p1;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) pv += w_p1[l * 32 + c] * zs[t * 16 + l];
+            p1s[t * 32 + c] = c < 30 ? prelu1(pv, act5) : 0.f;
+        }
+        __syncthreads();
+        if (c < a.T) {                                                                   // proj_2: 30 -> 1
+            float o = b_p2;
+#pragma unroll
+            for (int k = 0; k < 30; ++k) o += w_p2[k] * p1s[c * 32 + k];
+            if (ok) a.out[(long long)n * a.T + c] = o;
+        }
+        __syncthreads();
+    }
+}
+
 // de-pad rows of a workspace tensor for parity tests
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
     // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one)
@@ -1072,7 +1340,7 @@ __global__ void k_export(const float* __restrict__ src, long long rows, int pitc
 // ================================================================================================
 struct genie_ctx {
     int S, G, G_ext, T;
-    float scale_rel;
+    float scale_rel, scale_t;
     long long P, P_ext, E_src;
     int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
     float* raw;
@@ -1181,6 +1449,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     memset((void*)&c->S, 0, sizeof(int) * 4);
     c->S = n_sta; c->G = n_grid; c->G_ext = n_grid_ext; c->T = (n_sta + 15) / 16;
     c->scale_rel = scale_rel;
+    c->scale_t = 9.0f;  // 3 * kernel_sig_t (module.py:40, train_config.yaml:17); override with genie_set_scale_t
     c->P = (long long)n_grid * n_sta; c->P_ext = (long long)n_grid_ext * n_sta;
     int32_t e_sta = 0, e_src = 0;
     HIP_TRY(hipMemcpy(&e_sta, sta_rowptr + n_sta, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1263,6 +1532,12 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     layout_ws(c);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
+    return GENIE_OK;
+}
+
+int genie_set_scale_t(genie_ctx* c, float scale_t) {
+    if (!c || !(scale_t > 0.f)) return fail(GENIE_ERR_ARG, "genie_set_scale_t: bad argument");
+    c->scale_t = scale_t;
     return GENIE_OK;
 }
 
@@ -1404,6 +1679,57 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     if ((rc = genie_spatial_agg_fwd(c, 1, bip, pos, w + c->o_sa0, ws, stream))) return rc;
     if ((rc = genie_spatial_agg_fwd(c, 2, w + c->o_sa0, pos, w + c->o_sa1, ws, stream))) return rc;
     if ((rc = genie_spatial_agg_fwd(c, 3, w + c->o_sa1, pos, x_spatial_out, ws, stream))) return rc;
+    return GENIE_OK;
+}
+
+namespace {
+RoArgs make_ro_args(const genie_ctx* c) {
+    RoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.raw = c->raw; a.scale_rel = c->scale_rel; a.scale_t = c->scale_t; a.G = c->G;
+    a.o_sd_w = g_params[W_SD_W].off; a.o_sd_b = g_params[W_SD_B].off; a.o_sd_a = g_params[W_SD_ACT].off;
+    a.o_q1w = g_params[W_TA_Q1_W].off; a.o_q1b = g_params[W_TA_Q1_B].off; a.o_q2w = g_params[W_TA_Q2_W].off; a.o_q2b = g_params[W_TA_Q2_B].off;
+    a.o_c1w = g_params[W_TA_C1_W].off; a.o_c1b = g_params[W_TA_C1_B].off; a.o_c2w = g_params[W_TA_C2_W].off; a.o_c2b = g_params[W_TA_C2_B].off;
+    a.o_v1w = g_params[W_TA_V1_W].off; a.o_v1b = g_params[W_TA_V1_B].off; a.o_v2w = g_params[W_TA_V2_W].off; a.o_v2b = g_params[W_TA_V2_B].off;
+    a.o_p1w = g_params[W_TA_P1_W].off; a.o_p1b = g_params[W_TA_P1_B].off; a.o_p2w = g_params[W_TA_P2_W].off; a.o_p2b = g_params[W_TA_P2_B].off;
+    a.o_a1 = g_params[W_TA_ACT1].off; a.o_a2 = g_params[W_TA_ACT2].off; a.o_a3 = g_params[W_TA_ACT3].off;
+    a.o_a4 = g_params[W_TA_ACT4].off; a.o_a5 = g_params[W_TA_ACT5].off;
+    a.o_sq_w = g_params[W_SAT_Q_W].off; a.o_sq_b = g_params[W_SAT_Q_B].off; a.o_sc_w = g_params[W_SAT_C_W].off; a.o_sc_b = g_params[W_SAT_C_B].off;
+    a.o_sv_w = g_params[W_SAT_V_W].off; a.o_sv_b = g_params[W_SAT_V_B].off; a.o_sp_w = g_params[W_SAT_P_W].off; a.o_sp_b = g_params[W_SAT_P_B].off;
+    a.o_sa1 = g_params[W_SAT_ACT1].off; a.o_sa2 = g_params[W_SAT_ACT2].off;
+    return a;
+}
+constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96;
+constexpr size_t RO_LDS0 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 30 * 32 + NPB * RO_SCR);
+constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 + 33 * 96 * 2 + 15 * 32 + NPB * (RO_SCR + RO_K * 96));
+}  // namespace
+
+int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
+    if (!c || !x_spatial || !t_query || !y_out) return fail(GENIE_ERR_ARG, "genie_readout_grid: null argument");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 16 required");
+    RoArgs a = make_ro_args(c);
+    a.N = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
+    const int nb = std::min((a.N + NPB - 1) / NPB, c->num_cu * 2);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS0));
+    k_readout<0><<<nb, 256, RO_LDS0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
+                        int n_query, int k, const float* t_query, int n_t, float* x_out, void* stream) {
+    if (!c || !x_spatial || !x_grid || !x_query || !knn || !t_query || !x_out)
+        return fail(GENIE_ERR_ARG, "genie_readout_query: null argument");
+    if (k != RO_K) return fail(GENIE_ERR_ARG, "genie_readout_query: k must be 10 (module.py:280)");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_query: 1 <= n_t <= 16 required");
+    if (n_query < 1) return fail(GENIE_ERR_ARG, "genie_readout_query: n_query < 1");
+    RoArgs a = make_ro_args(c);
+    a.N = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
+    a.t_query = t_query; a.out = x_out;
+    const int nb = std::min((a.N + NPB - 1) / NPB, c->num_cu * 1);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
+    k_readout<1><<<nb, 256, RO_LDS1, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 

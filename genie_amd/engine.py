@@ -192,6 +192,34 @@ class HipPath(object):
                                            _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
         return out, x_latent, bip
 
+    def readout_grid(self, x_spatial, t_query):
+        """y[n_grid, T, 1] = TemporalAttention(SpatialDirect(x_spatial), t_query) (module.py:1015-1016)."""
+        x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))
+        tq = _f32(t_query, "t_query").reshape(-1)
+        out = torch.empty((self.n_grid, tq.numel(), 1), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_readout_grid(self.ctx, _ptr(x_spatial), _ptr(tq), tq.numel(), _ptr(out), _stream()),
+                   "genie_readout_grid")
+        return out
+
+    def readout_query(self, x_spatial, x_grid, x_query, knn_idx, t_query):
+        """x[Q, T, 1] = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid), t_query) (module.py:1017-1018);
+        knn_idx int32 [Q, 10] = the 10 nearest grid nodes of every query."""
+        x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))
+        x_grid = _f32(x_grid, "x_grid", (self.n_grid, 3))
+        x_query = _f32(x_query, "x_query")
+        nq = x_query.shape[0]
+        if tuple(knn_idx.shape) != (nq, 10) or knn_idx.dtype != torch.int32 or not knn_idx.is_cuda:
+            raise ValueError("knn_idx must be an int32 GPU tensor of shape [n_query, 10]")
+        knn_idx = knn_idx.contiguous()
+        tq = _f32(t_query, "t_query").reshape(-1)
+        out = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_readout_query(self.ctx, _ptr(x_spatial), _ptr(x_grid), _ptr(x_query), _ptr(knn_idx), nq, 10,
+                                                _ptr(tq), tq.numel(), _ptr(out), _stream()), "genie_readout_query")
+        return out
+
+    def set_scale_t(self, scale_t):
+        _lib.check(self.lib.genie_set_scale_t(self.ctx, ctypes.c_float(float(scale_t))), "genie_set_scale_t")
+
     def export(self, which):
         """Parity/debug: de-padded copy of a workspace intermediate: 0 = c [P,30] (node-local layer-2 terms),
         1 = wu [P,15], 2 = wv [P,15] (u / v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2)."""

@@ -31,7 +31,7 @@ def _path_param_dict(net):
     """state_dict-name -> Parameter for the modules that run in HIP."""
     out = {}
     for mod_name in ("DataAggregation", "Bipartite_ReadIn", "SpatialAggregation1", "SpatialAggregation2",
-                     "SpatialAggregation3"):
+                     "SpatialAggregation3", "SpatialDirect", "TemporalAttention", "SpatialAttention"):
         mod = getattr(net, mod_name)
         for n, p in mod.named_parameters():
             out[mod_name + "." + n] = p
@@ -137,8 +137,15 @@ class SpatialAttention(nn.Module):
                tuple(x_context.shape), k)
         hit = self._edge_cache.get("key") == key
         if not hit:
-            self._edge_cache = {"key": key, "edges": knn_query_edges(x_context, x_query, k)}
+            edges = knn_query_edges(x_context, x_query, k)
+            self._edge_cache = {"key": key, "edges": edges,
+                                "table": edges[0].view(x_query.shape[0], -1).to(torch.int32).contiguous()}
         return self._edge_cache["edges"]
+
+    def query_table(self, x_query, x_context, k=10):
+        """int32 [Q, k] table of the k nearest context nodes of every query (cached per query set)."""
+        self.query_edges(x_query, x_context, k)
+        return self._edge_cache["table"]
 
     def forward(self, inpts, x_query, x_context, k=10):
         H, L = self.n_heads, self.n_latent
@@ -299,6 +306,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev)
         self._path_params = _path_param_dict(self)
+        self._hip.set_scale_t(self.TemporalAttention.scale_t)
 
     def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                         A_edges_s, dt_partition, tlatent, pos_loc, pos_src):
@@ -338,10 +346,9 @@ class GCN_Detection_Network_extended(nn.Module):
                              x_query_cart, t_query):
         """module.py:999-1020. `tpick`, `ipick`, `phase_label` are accepted and ignored, as in the reference."""
         x_spatial, _, _ = self._path(Slice, Mask, x_temp_cuda_cart)                       # :1010-1014
-        y_latent = self.SpatialDirect(x_spatial)                                           # :1015
-        y = self.TemporalAttention(y_latent, t_query)                                      # :1016
-        x = self.SpatialAttention(x_spatial, x_query_cart, x_temp_cuda_cart)               # :1017
-        x = self.TemporalAttention(x, t_query)                                             # :1018
+        y = self._hip.readout_grid(x_spatial, t_query)                                     # :1015-1016
+        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)        # :282 (cached per query set)
+        x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)   # :1017-1018
         return y, x
 
     def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,

@@ -62,6 +62,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
                      const int32_t* src_rowptr, const int32_t* src_col,
                      const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
+/* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
+int genie_set_scale_t(genie_ctx* ctx, float scale_t);
 
 /*
  * Weight mirror. Parameter names are the reference's state_dict keys (e.g. "DataAggregation.l1_t1_2.weight",
@@ -134,6 +136,19 @@ int genie_spatial_agg_fwd(genie_ctx* ctx, int layer, const float* x_in, const fl
 int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr,
                    const float* pos, float* x_spatial_out, float* x_latent_out, float* bip_out,
                    void* ws, void* stream);
+
+/*
+ * Read-out heads needed to return (y, x) from forward_fixed_source (module.py:1015-1018).
+ *   genie_readout_grid : y[n_grid, n_t]  = TemporalAttention(SpatialDirect(x_spatial), t_query)     module.py:251-260, 299-331
+ *   genie_readout_query: x[n_query, n_t] = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid), t_query)
+ *                        module.py:262-297; `knn` [n_query, 10] int32 = indices of the 10 nearest grid nodes of every
+ *                        query (the `knn(x_context/1000, x_query/1000, k=10)` of module.py:282, computed by the caller
+ *                        once per query set); softmax is over those 10 edges per head, aggregation 'add', mean over heads.
+ *   x_spatial [n_grid,30]; x_grid [n_grid,3], x_query [n_query,3] in metres; t_query [n_t] seconds, n_t <= 16.
+ */
+int genie_readout_grid(genie_ctx* ctx, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream);
+int genie_readout_query(genie_ctx* ctx, const float* x_spatial, const float* x_grid, const float* x_query,
+                        const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out, void* stream);
 
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */

@@ -86,6 +86,23 @@ def test_forward_fixed_source_drop_in(name):
     assert max_abs(x.cpu(), c.ref("x64")) <= 1e-5
 
 
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_readout_kernels_match_golden(name):
+    """HIP read-out heads fed with the reference's own sa3: isolates them from the message-passing kernels."""
+    c = Case(name)
+    hp = make_engine(c)
+    sa3 = c.ref("sa3").to(DEV)
+    tq = c.t_query.float().to(DEV)
+    y = hp.readout_grid(sa3, tq)
+    from genie_amd.module import knn_query_edges
+    xg, xq = c.x_grid.float().to(DEV), c.x_query.float().to(DEV)
+    table = knn_query_edges(xg, xq, 10)[0].view(xq.shape[0], -1).to(torch.int32).contiguous()
+    x = hp.readout_query(sa3, xg, xq, table, tq)
+    assert y.shape == tuple(c.ref("y").shape) and x.shape == tuple(c.ref("x").shape)
+    assert max_abs(y.cpu(), c.ref("y")) <= 1e-6
+    assert max_abs(x.cpu(), c.ref("x")) <= 1e-6
+
+
 def _random_case(S, G, seed, n_picks):
     geom = synthetic.Geometry(S, G, L=200e3, n_query=50, seed=seed)
     win = synthetic.make_window(geom, n_picks, seed=seed + 1)
