@@ -41,6 +41,7 @@ SYMBOLS = [
     ("genie_ws_v_pitch", _c.c_int, [_P]),
     ("genie_da_stage2_bipartite", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
+    ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_ws_export", _c.c_int, [_P, _c.c_int, _P, _P, _P]),
 ]

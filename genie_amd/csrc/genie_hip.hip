@@ -938,6 +938,22 @@ __device__ __forceinline__ void stage_transposed(float* dst, const float* __rest
     }
 }
 
+// dst[k*ldo + c] = W[c][k] for c < rows (else 0), c < ldo
+__device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
+    for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
+        const int k = i / ldo, c = i - k * ldo;
+        dst[i] = c < rows ? W[c * ld + k] : 0.f;
+    }
+}
+
+// dst[k*32 + c] = W[c][k] for the first kcols input columns only (c < rows else 0)
+__device__ __forceinline__ void stage_transposed_cols(float* dst, const float* __restrict__ W, int rows, int ld, int kcols) {
+    for (int i = threadIdx.x; i < kcols * 32; i += blockDim.x) {
+        const int k = i >> 5, c = i & 31;
+        dst[i] = c < rows ? W[c * ld + k] : 0.f;
+    }
+}
+
 // Bipartite read-out: r_g = sum over tiles in fixed order; out = PReLU_b2(fc2 r_g)              module.py:229
 __global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part, int G, int T,
                                                 const float* __restrict__ raw, int off_w, int off_b, int off_a,
@@ -973,68 +989,108 @@ struct SaArgs {
     const float* x_in; const float* pos;
     const int32_t* rowptr; const int32_t* col; const int32_t* outdeg;
     const float* raw;
-    int fc1_w, fc1_b, fc2_w, fc2_b, fg_w, fg_b, act1, act2, act3;
+    int fc1_w, fc1_b, fc2_w, fc2_b, fg_w, fg_b, act1, act2, act3;     // this layer
+    int nx_fc1_w, nx_fg_w, nx_fg_b, nx_act3;                           // next layer (k_sa_layer<.., NEXT = true>)
     float scale_rel;
-    float* gpart;  // [n_gpart][8] partial sums of outdeg * PReLU3(fglobal x)
-    int n_gpart;
-    float* out;
+    const float* pj_in;    // [G,32] x-part of this layer's messages: fc1.weight[:, 0:C] x_j
+    const float* gpart_in; // [n_gpart_in][8] per-block partials of sum_j outdeg(j) PReLU3(fglobal x_j)
+    int n_gpart_in;
+    float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
+    float* gpart_out;      // [gridDim][8]
+    float* out;            // [G,30]
 };
 
-// SpatialAggregation global term, pass 1: per-block partial of sum_j outdeg(j) PReLU3(fglobal x_j)  module.py:249
-template <int C>
-__global__ __launch_bounds__(256) void k_sa_global(SaArgs a) {
-    __shared__ float wt[C * 32];
+// fixed-order block reduction of the per-lane global-term partials (lanes c < 5 of every node group) -> gpart[block]
+__device__ __forceinline__ void sa_store_gpart(float acc, int c, int grp, float* gpart_out) {
     __shared__ float red[NPB][8];
-    stage_transposed(wt, a.raw + a.fg_w, 5, C);
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float bias = c < 5 ? a.raw[a.fg_b + c] : 0.f;
-    const float act = a.raw[a.act3];
-    float acc = 0.f;
-    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < a.G;
-        const float x = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
-        float o = bias;
-#pragma unroll
-        for (int k = 0; k < C; ++k) o += wt[k * 32 + c] * __shfl(x, k, 32);
-        if (ok) acc += (float)a.outdeg[g] * prelu1(o, act);
-    }
     if (c < 8) red[grp][c] = c < 5 ? acc : 0.f;
     __syncthreads();
     if (threadIdx.x < 8) {
         float s = 0.f;
         for (int k = 0; k < NPB; ++k) s += red[k][threadIdx.x];
-        a.gpart[blockIdx.x * 8 + threadIdx.x] = s;
+        gpart_out[blockIdx.x * 8 + threadIdx.x] = s;
     }
 }
-// SpatialAggregation message + mean + update                                                module.py:245,249
+
+// Per-node pre-pass of a SpatialAggregation layer (module.py:249): the x_j part of the message Linear
+//   pj[j] = fc1.weight[:, 0:C] x_j                      (shared by every edge leaving j)
+// and this block's partial of the edge-mean term  sum_j outdeg(j) PReLU3(fglobal x_j).
 template <int C>
-__global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
-    __shared__ float w1t[(C + 8) * 32];
+__global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
+    __shared__ float wx[C * 32];
+    __shared__ float wg[C * 32];
+    stage_transposed_cols(wx, a.raw + a.fc1_w, 30, C + 8, C);
+    stage_transposed(wg, a.raw + a.fg_w, 5, C);
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float bg = c < 5 ? a.raw[a.fg_b + c] : 0.f;
+    const float act3 = a.raw[a.act3];
+    float acc = 0.f;
+    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
+        const int g = g0 + grp;
+        const bool ok = g < a.G;
+        const float x = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
+        float pj = 0.f, gl = bg;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const float xk = __shfl(x, k, 32);
+            pj += wx[k * 32 + c] * xk;
+            gl += wg[k * 32 + c] * xk;
+        }
+        if (ok) {
+            a.pj_out[(long long)g * 32 + c] = c < 30 ? pj : 0.f;
+            acc += (float)a.outdeg[g] * prelu1(gl, act3);
+        }
+    }
+    sa_store_gpart(acc, c, grp, a.gpart_out);
+}
+
+// One SpatialAggregation layer (module.py:245,249): message = PReLU1(pj[j] + fc1_pos (p_i - p_j) + fc1_glob c + b1),
+// mean over in-edges, update out_i = PReLU2(fc2 [x_i || mean]). With NEXT the kernel also emits the pre-pass of the
+// following layer (pj' = fc1'.weight[:, 0:30] out_i and the partial of its edge-mean term) while out_i is in registers.
+template <int C, bool NEXT>
+__global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
+    __shared__ float w1p[8 * 32];            // fc1 columns C..C+7 (3 position + 5 global), transposed
     __shared__ float w2t[(C + 30) * 32];
-    stage_transposed(w1t, a.raw + a.fc1_w, 30, C + 8);
+    __shared__ float wxn[NEXT ? 30 * 32 : 32];
+    __shared__ float wgn[NEXT ? 30 * 32 : 32];
+    __shared__ float gsum[8];
+    for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
+        const int k = i >> 5, cc = i & 31;
+        w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
+    }
     stage_transposed(w2t, a.raw + a.fc2_w, 30, C + 30);
+    if (NEXT) {
+        stage_transposed_cols(wxn, a.raw + a.nx_fc1_w, 30, 30 + 8, 30);
+        stage_transposed(wgn, a.raw + a.nx_fg_w, 5, 30);
+    }
+    {   // global term: sum of the producer's per-block partials in a FIXED two-level order (deterministic, parallel)
+        __shared__ float gred[32][8];
+        const int m = threadIdx.x & 7, chunk = threadIdx.x >> 3;
+        float sgl = 0.f;
+        for (int b = chunk; b < a.n_gpart_in; b += 32) sgl += a.gpart_in[b * 8 + m];
+        gred[chunk][m] = sgl;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float t = 0.f;
+            for (int k = 0; k < 32; ++k) t += gred[k][threadIdx.x];
+            gsum[threadIdx.x] = t;
+        }
+    }
     __syncthreads();
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const float act1 = a.raw[a.act1], act2 = a.raw[a.act2];
     const float b2 = c < 30 ? a.raw[a.fc2_b + c] : 0.f;
-    // global term: fixed-order sum of the per-block partials written by k_sa_global (deterministic)
-    __shared__ float gsum[8];
-    if (threadIdx.x < 8) {
-        float sgl = 0.f;
-        for (int b = 0; b < a.n_gpart; ++b) sgl += a.gpart[b * 8 + threadIdx.x];
-        gsum[threadIdx.x] = sgl;
-    }
-    __syncthreads();
-    // message bias + global-term contribution (same for every edge)
-    float base = c < 30 ? a.raw[a.fc1_b + c] : 0.f;
+    float base = c < 30 ? a.raw[a.fc1_b + c] : 0.f;       // message bias + global-term contribution (same for every edge)
     {
         const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
 #pragma unroll
-        for (int m = 0; m < 5; ++m) base += w1t[(C + 3 + m) * 32 + c] * (gsum[m] * invE);
+        for (int m = 0; m < 5; ++m) base += w1p[(3 + m) * 32 + c] * (gsum[m] * invE);
     }
-    const float wp0 = w1t[(C + 0) * 32 + c], wp1 = w1t[(C + 1) * 32 + c], wp2 = w1t[(C + 2) * 32 + c];
+    const float wp0 = w1p[0 * 32 + c], wp1 = w1p[1 * 32 + c], wp2 = w1p[2 * 32 + c];
+    const float bgn = (NEXT && c < 5) ? a.raw[a.nx_fg_b + c] : 0.f;
+    const float act3n = NEXT ? a.raw[a.nx_act3] : 0.f;
+    float acc = 0.f;
     for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
         const int i = g0 + grp;
         const bool ok = i < a.G;
@@ -1043,21 +1099,14 @@ __global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
         const float pi0 = a.pos[ic * 3 + 0] / a.scale_rel, pi1 = a.pos[ic * 3 + 1] / a.scale_rel,
                     pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
         const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
-        // both half-waves must run the same number of shuffle rounds: loop to the wave-wide max degree
-        int nmax = ee - eb;
-        nmax = max(nmax, __shfl_xor(nmax, 32));
         float asum = 0.f;
-        for (int k = 0; k < nmax; ++k) {
-            const bool live = k < ee - eb;
-            const int jn = live ? a.col[eb + k] : ic;
-            const float xj = c < C ? a.x_in[(long long)jn * C + c] : 0.f;
-            float m = base;
-#pragma unroll
-            for (int kk = 0; kk < C; ++kk) m += w1t[kk * 32 + c] * __shfl(xj, kk, 32);
+        for (int e = eb; e < ee; ++e) {          // no cross-lane op inside: the two half-waves may differ in trip count
+            const int jn = a.col[e];
+            float m = a.pj_in[(long long)jn * 32 + c] + base;
             m += wp0 * (pi0 - a.pos[jn * 3 + 0] / a.scale_rel);
             m += wp1 * (pi1 - a.pos[jn * 3 + 1] / a.scale_rel);
             m += wp2 * (pi2 - a.pos[jn * 3 + 2] / a.scale_rel);
-            if (live) asum += prelu1(m, act1);
+            asum += prelu1(m, act1);
         }
         const float av = asum / (float)max(ee - eb, 1);
         float o = b2;
@@ -1065,15 +1114,24 @@ __global__ __launch_bounds__(256) void k_sa_apply(SaArgs a) {
         for (int kk = 0; kk < C; ++kk) o += w2t[kk * 32 + c] * __shfl(xi, kk, 32);
 #pragma unroll
         for (int kk = 0; kk < 30; ++kk) o += w2t[(C + kk) * 32 + c] * __shfl(av, kk, 32);
-        if (ok && c < 30) a.out[(long long)i * 30 + c] = prelu1(o, act2);
+        o = c < 30 ? prelu1(o, act2) : 0.f;
+        if (ok && c < 30) a.out[(long long)i * 30 + c] = o;
+        if (NEXT) {
+            float pj = 0.f, gl = bgn;
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                const float ok_ = __shfl(o, k, 32);
+                pj += wxn[k * 32 + c] * ok_;
+                gl += wgn[k * 32 + c] * ok_;
+            }
+            if (ok) {
+                a.pj_out[(long long)i * 32 + c] = c < 30 ? pj : 0.f;
+                acc += (float)a.outdeg[i] * prelu1(gl, act3n);
+            }
+        }
     }
+    if (NEXT) sa_store_gpart(acc, c, grp, a.gpart_out);
 }
-
-#if GENIE_TUNING
-__global__ void k_xcc_probe(int* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;  // HW_REG_XCC_ID[3:0]
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Read-out heads (module.py:251-331), G- / Q-sized: 32 lanes per node, 8 nodes per workgroup, weights transposed in
@@ -1096,14 +1154,6 @@ struct RoArgs {
     int o_a1, o_a2, o_a3, o_a4, o_a5;
     int o_sq_w, o_sq_b, o_sc_w, o_sc_b, o_sv_w, o_sv_b, o_sp_w, o_sp_b, o_sa1, o_sa2;
 };
-
-// dst[k*ldo + c] = W[c][k] for c < rows (else 0), c < ldo
-__device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
-    for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
-        const int k = i / ldo, c = i - k * ldo;
-        dst[i] = c < rows ? W[c * ld + k] : 0.f;
-    }
-}
 
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
 constexpr int RO_TMAX = 16;
@@ -1355,7 +1405,7 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     // workspace offsets (floats)
-    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, ws_floats;
+    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, ws_floats;
 };
 
 namespace {
@@ -1372,7 +1422,9 @@ void layout_ws(genie_ctx* c) {
     c->o_sa0 = take((size_t)c->G * 32);
     c->o_sa1 = take((size_t)c->G * 32);
     c->o_bip = take((size_t)c->G * 16);
-    c->o_gpart = take(1024 * 8);
+    c->o_gpart = take(2 * 1024 * 8);
+    c->o_pj0 = take((size_t)c->G * 32);
+    c->o_pj1 = take((size_t)c->G * 32);
     c->ws_floats = o;
 }
 
@@ -1633,6 +1685,59 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
     return GENIE_OK;
 }
 
+namespace {
+void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
+    const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
+    a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src;
+    a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg;
+    a.raw = c->raw; a.scale_rel = c->scale_rel;
+    a.fc1_w = g_params[base + 0].off; a.fc1_b = g_params[base + 1].off;
+    a.fc2_w = g_params[base + 2].off; a.fc2_b = g_params[base + 3].off;
+    a.fg_w = g_params[base + 4].off; a.fg_b = g_params[base + 5].off;
+    a.act1 = g_params[base + 6].off; a.act2 = g_params[base + 7].off; a.act3 = g_params[base + 8].off;
+    if (layer < 3) {
+        const int nb = layer == 1 ? W_SA2_FC1_W : W_SA3_FC1_W;
+        a.nx_fc1_w = g_params[nb + 0].off; a.nx_fg_w = g_params[nb + 4].off; a.nx_fg_b = g_params[nb + 5].off;
+        a.nx_act3 = g_params[nb + 8].off;
+    }
+}
+int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, 1024); }
+
+// chain = true: the pre-pass of `layer` was already produced (by k_sa_pre or by the previous layer's NEXT tail) in
+// pj/gpart buffer `cur`; with_next emits the next layer's pre-pass into the other buffer.
+int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos, float* out, float* ws, int cur,
+                    bool with_next, hipStream_t st) {
+    SaArgs a;
+    memset(&a, 0, sizeof(a));
+    sa_fill_layer(c, layer, a);
+    a.x_in = x_in; a.pos = pos; a.out = out;
+    float* pj[2] = {ws + c->o_pj0, ws + c->o_pj1};
+    float* gp[2] = {ws + c->o_gpart, ws + c->o_gpart + 1024 * 8};
+    a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_blocks(c);
+    a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
+    const int nb = sa_blocks(c);
+    if (layer == 1) {
+        if (with_next) k_sa_layer<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<15, false><<<nb, 256, 0, st>>>(a);
+    } else {
+        if (with_next) k_sa_layer<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<30, false><<<nb, 256, 0, st>>>(a);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+int sa_launch_pre(genie_ctx* c, int layer, const float* x_in, float* ws, int cur, hipStream_t st) {
+    SaArgs a;
+    memset(&a, 0, sizeof(a));
+    sa_fill_layer(c, layer, a);
+    a.x_in = x_in;
+    a.pj_out = ws + (cur ? c->o_pj1 : c->o_pj0);
+    a.gpart_out = ws + c->o_gpart + (cur ? 1024 * 8 : 0);
+    const int nb = sa_blocks(c);
+    if (layer == 1) k_sa_pre<15><<<nb, 256, 0, st>>>(a); else k_sa_pre<30><<<nb, 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+}  // namespace
+
 int genie_spatial_agg_fwd(genie_ctx* c, int layer, const float* x_in, const float* pos, float* out, void* ws,
                           void* stream) {
     int rc = check_ws(c, ws);
@@ -1641,30 +1746,21 @@ int genie_spatial_agg_fwd(genie_ctx* c, int layer, const float* x_in, const floa
     if (!x_in || !pos || !out) return fail(GENIE_ERR_ARG, "genie_spatial_agg_fwd: null argument");
     if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_spatial_agg_fwd needs an unsharded source graph");
     hipStream_t st = (hipStream_t)stream;
-    const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
-    SaArgs a;
-    memset(&a, 0, sizeof(a));
-    a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src;
-    a.x_in = x_in; a.pos = pos; a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg;
-    a.raw = c->raw;
-    a.fc1_w = g_params[base + 0].off; a.fc1_b = g_params[base + 1].off;
-    a.fc2_w = g_params[base + 2].off; a.fc2_b = g_params[base + 3].off;
-    a.fg_w = g_params[base + 4].off; a.fg_b = g_params[base + 5].off;
-    a.act1 = g_params[base + 6].off; a.act2 = g_params[base + 7].off; a.act3 = g_params[base + 8].off;
-    a.scale_rel = c->scale_rel;
-    a.gpart = (float*)ws + c->o_gpart; a.out = out;
-    const int nb_g = std::min((c->G + NPB - 1) / NPB, 64);
-    a.n_gpart = nb_g;
-    const int nb_a = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
-    if (layer == 1) {
-        k_sa_global<15><<<nb_g, 256, 0, st>>>(a);
-        k_sa_apply<15><<<nb_a, 256, 0, st>>>(a);
-    } else {
-        k_sa_global<30><<<nb_g, 256, 0, st>>>(a);
-        k_sa_apply<30><<<nb_a, 256, 0, st>>>(a);
-    }
-    HIP_TRY(hipGetLastError());
-    return GENIE_OK;
+    if ((rc = sa_launch_pre(c, layer, x_in, (float*)ws, 0, st))) return rc;
+    return sa_launch_layer(c, layer, x_in, pos, out, (float*)ws, 0, false, st);
+}
+
+int genie_spatial_agg3_fwd(genie_ctx* c, const float* x_in15, const float* pos, float* out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!x_in15 || !pos || !out) return fail(GENIE_ERR_ARG, "genie_spatial_agg3_fwd: null argument");
+    if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_spatial_agg3_fwd needs an unsharded source graph");
+    hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
+    if ((rc = sa_launch_pre(c, 1, x_in15, w, 0, st))) return rc;
+    if ((rc = sa_launch_layer(c, 1, x_in15, pos, w + c->o_sa0, w, 0, true, st))) return rc;
+    if ((rc = sa_launch_layer(c, 2, w + c->o_sa0, pos, w + c->o_sa1, w, 1, true, st))) return rc;
+    return sa_launch_layer(c, 3, w + c->o_sa1, pos, out, w, 0, false, st);
 }
 
 int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* pos,
@@ -1676,10 +1772,7 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     float* bip = bip_out ? bip_out : w + c->o_bip;
     if ((rc = genie_da_stage1(c, slice, mask, ws, stream))) return rc;
     if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
-    if ((rc = genie_spatial_agg_fwd(c, 1, bip, pos, w + c->o_sa0, ws, stream))) return rc;
-    if ((rc = genie_spatial_agg_fwd(c, 2, w + c->o_sa0, pos, w + c->o_sa1, ws, stream))) return rc;
-    if ((rc = genie_spatial_agg_fwd(c, 3, w + c->o_sa1, pos, x_spatial_out, ws, stream))) return rc;
-    return GENIE_OK;
+    return genie_spatial_agg3_fwd(c, bip, pos, x_spatial_out, ws, stream);
 }
 
 namespace {

@@ -128,6 +128,9 @@ int genie_da_stage2_bipartite(genie_ctx* ctx, const float* mask, const float* ed
  */
 int genie_spatial_agg_fwd(genie_ctx* ctx, int layer, const float* x_in, const float* pos, float* out,
                           void* ws, void* stream);
+/* SpatialAggregation1 -> 2 -> 3 chained (module.py:1012-1014): every layer kernel also emits the per-node pre-pass
+ * of the next one (x-part of the message Linear and the edge-mean partials). x_in15 [n_grid,15] -> out [n_grid,30]. */
+int genie_spatial_agg3_fwd(genie_ctx* ctx, const float* x_in15, const float* pos, float* out, void* ws, void* stream);
 
 /*
  * Fused single-GPU path = module.py:1010-1014: DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3.
