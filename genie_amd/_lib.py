@@ -25,7 +25,7 @@ SYMBOLS = [
     ("genie_ctx_destroy", _c.c_int, [_P]),
     ("genie_set_scale_t", _c.c_int, [_P, _c.c_float]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),
-    ("genie_readout_query", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P]),
+    ("genie_readout_query", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P]),
     ("genie_weights_count", _c.c_int, []),
     ("genie_weights_name", _c.c_char_p, [_c.c_int]),
     ("genie_weights_numel", _c.c_int64, [_c.c_int]),

@@ -1145,6 +1145,7 @@ struct RoArgs {
     const float* x_grid;         // [G,3]   (MODE 1)
     const float* x_query;        // [Q,3]   (MODE 1)
     const int32_t* knn;          // [Q,10]  (MODE 1)
+    const float* cv;             // [G,160] per-grid-node parts of f_context / f_values (MODE 1)
     const float* t_query;        // [T]
     const float* raw;
     float scale_rel, scale_t;
@@ -1154,6 +1155,40 @@ struct RoArgs {
     int o_a1, o_a2, o_a3, o_a4, o_a5;
     int o_sq_w, o_sq_b, o_sc_w, o_sc_b, o_sv_w, o_sv_b, o_sp_w, o_sp_b, o_sa1, o_sa2;
 };
+
+// Per-grid-node part of SpatialAttention's edge Linears (module.py:290-291): f_context / f_values act on
+// [x_j || edge_attr]; the x_j part  C_j = f_context.weight[:, 0:30] x_j,  V_j = f_values.weight[:, 0:30] x_j  is the same
+// for every query that has j as a neighbour, so it is computed once per grid node: cv[j] = [C_j (75, pad 80) | V_j].
+constexpr int CVP = 160;
+__global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spatial, int G, const float* __restrict__ raw,
+                                                int o_cw, int o_vw, float* __restrict__ cv) {
+    __shared__ float wc[30 * 96];
+    __shared__ float wv[30 * 96];
+    for (int i = threadIdx.x; i < 30 * 96; i += blockDim.x) {
+        const int k = i / 96, ch = i - k * 96;
+        wc[i] = ch < 75 ? raw[o_cw + ch * 33 + k] : 0.f;
+        wv[i] = ch < 75 ? raw[o_vw + ch * 33 + k] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
+        const int g = g0 + grp;
+        const bool ok = g < G;
+        const float x = (ok && c < 30) ? x_spatial[(long long)g * 30 + c] : 0.f;
+        float cc[3] = {0.f, 0.f, 0.f}, vv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 30; ++k) {
+            const float xk = __shfl(x, k, 32);
+            cc[0] += wc[k * 96 + c] * xk; cc[1] += wc[k * 96 + 32 + c] * xk; cc[2] += wc[k * 96 + 64 + c] * xk;
+            vv[0] += wv[k * 96 + c] * xk; vv[1] += wv[k * 96 + 32 + c] * xk; vv[2] += wv[k * 96 + 64 + c] * xk;
+        }
+        if (ok) {
+            float* o = cv + (long long)g * CVP;
+            o[c] = cc[0]; o[32 + c] = cc[1]; if (c < 16) o[64 + c] = cc[2];
+            o[80 + c] = vv[0]; o[112 + c] = vv[1]; if (c < 16) o[144 + c] = vv[2];
+        }
+    }
+}
 
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
 constexpr int RO_TMAX = 16;
@@ -1170,9 +1205,9 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
     float* w_p2 = w_p1 + 15 * 32;        // [32]
     float* qry = w_p2 + 32;              // [RO_TMAX][96]
     float* w_x0 = qry + RO_TMAX * 96;    // MODE 0: f_direct [30][32];  MODE 1: f_queries [3][96]
-    float* w_fc = w_x0 + (MODE == 0 ? 30 * 32 : 3 * 96);   // MODE 1: f_context [33][96]
-    float* w_fv = w_fc + (MODE == 0 ? 0 : 33 * 96);        // MODE 1: f_values [33][96]
-    float* w_pr = w_fv + (MODE == 0 ? 0 : 33 * 96);        // MODE 1: proj [15][32]
+    float* w_fc = w_x0 + (MODE == 0 ? 30 * 32 : 3 * 96);   // MODE 1: f_context, edge-attr columns [3][96]
+    float* w_fv = w_fc + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: f_values, edge-attr columns [3][96]
+    float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
     float* scr = w_pr + (MODE == 0 ? 0 : 15 * 32);         // per-group scratch
     constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96 + (MODE == 1 ? RO_K * 96 : 0);   // floats per group
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -1198,8 +1233,11 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
         stage_transposed_ld(w_x0, a.raw + a.o_sd_w, 30, 30, 32);
     } else {
         stage_transposed_ld(w_x0, a.raw + a.o_sq_w, 75, 3, 96);
-        stage_transposed_ld(w_fc, a.raw + a.o_sc_w, 75, 33, 96);
-        stage_transposed_ld(w_fv, a.raw + a.o_sv_w, 75, 33, 96);
+        for (int i = threadIdx.x; i < 3 * 96; i += blockDim.x) {
+            const int d = i / 96, ch = i - d * 96;
+            w_fc[i] = ch < 75 ? a.raw[a.o_sc_w + ch * 33 + 30 + d] : 0.f;
+            w_fv[i] = ch < 75 ? a.raw[a.o_sv_w + ch * 33 + 30 + d] : 0.f;
+        }
         stage_transposed_ld(w_pr, a.raw + a.o_sp_w, 30, 15, 32);
     }
     // temporal queries: qry[t][ch] = temporal_query_2(PReLU3(temporal_query_1(t_query/scale_t)))   module.py:329
@@ -1251,21 +1289,18 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
 #pragma unroll 1
             for (int k = 0; k < RO_K; ++k) {
                 const int jn = a.knn[(long long)nc * RO_K + k];
-                if (c < 30) xin[c] = a.x_spatial[(long long)jn * 30 + c];
-                if (c < 3) xin[30 + c] = (a.x_query[nc * 3 + c] - a.x_grid[jn * 3 + c]) / a.scale_rel;                 // :283
-                __syncthreads();
-                float q3[3] = {bq[0], bq[1], bq[2]}, c3[3] = {bc[0], bc[1], bc[2]};
-                float v3[3] = {bv[0], bv[1], bv[2]};
+                float e[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) e[d] = (a.x_query[nc * 3 + d] - a.x_grid[jn * 3 + d]) / a.scale_rel;           // :283
+                const float* cvj = a.cv + (long long)jn * CVP;
+                float q3[3] = {bq[0], bq[1], bq[2]};
+                float c3[3] = {bc[0] + cvj[c], bc[1] + cvj[32 + c], bc[2] + (c < 16 ? cvj[64 + c] : 0.f)};
+                float v3[3] = {bv[0] + cvj[80 + c], bv[1] + cvj[112 + c], bv[2] + (c < 16 ? cvj[144 + c] : 0.f)};
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    const float e = xin[30 + d];
-                    q3[0] += w_x0[d * 96 + c] * e; q3[1] += w_x0[d * 96 + 32 + c] * e; q3[2] += w_x0[d * 96 + 64 + c] * e;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 33; ++kk) {
-                    const float xv = xin[kk];
-                    c3[0] += w_fc[kk * 96 + c] * xv; c3[1] += w_fc[kk * 96 + 32 + c] * xv; c3[2] += w_fc[kk * 96 + 64 + c] * xv;
-                    v3[0] += w_fv[kk * 96 + c] * xv; v3[1] += w_fv[kk * 96 + 32 + c] * xv; v3[2] += w_fv[kk * 96 + 64 + c] * xv;
+                    q3[0] += w_x0[d * 96 + c] * e[d]; q3[1] += w_x0[d * 96 + 32 + c] * e[d]; q3[2] += w_x0[d * 96 + 64 + c] * e[d];
+                    c3[0] += w_fc[d * 96 + c] * e[d]; c3[1] += w_fc[d * 96 + 32 + c] * e[d]; c3[2] += w_fc[d * 96 + 64 + c] * e[d];
+                    v3[0] += w_fv[d * 96 + c] * e[d]; v3[1] += w_fv[d * 96 + 32 + c] * e[d]; v3[2] += w_fv[d * 96 + 64 + c] * e[d];
                 }
                 prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
                 vst[k * 96 + c] = v3[0]; vst[k * 96 + 32 + c] = v3[1]; vst[k * 96 + 64 + c] = v3[2];
@@ -1405,7 +1440,7 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     // workspace offsets (floats)
-    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, ws_floats;
+    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
 };
 
 namespace {
@@ -1425,6 +1460,7 @@ void layout_ws(genie_ctx* c) {
     c->o_gpart = take(2 * 1024 * 8);
     c->o_pj0 = take((size_t)c->G * 32);
     c->o_pj1 = take((size_t)c->G * 32);
+    c->o_cv = take((size_t)c->G * CVP);
     c->ws_floats = o;
 }
 
@@ -1794,7 +1830,7 @@ RoArgs make_ro_args(const genie_ctx* c) {
 }
 constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96;
 constexpr size_t RO_LDS0 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 30 * 32 + NPB * RO_SCR);
-constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 + 33 * 96 * 2 + 15 * 32 + NPB * (RO_SCR + RO_K * 96));
+constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 * 3 + 15 * 32 + NPB * (RO_SCR + RO_K * 96));
 }  // namespace
 
 int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
@@ -1810,7 +1846,8 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
 }
 
 int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
-                        int n_query, int k, const float* t_query, int n_t, float* x_out, void* stream) {
+                        int n_query, int k, const float* t_query, int n_t, float* x_out, void* ws, void* stream) {
+    { int rcw = check_ws(c, ws); if (rcw) return rcw; }
     if (!c || !x_spatial || !x_grid || !x_query || !knn || !t_query || !x_out)
         return fail(GENIE_ERR_ARG, "genie_readout_query: null argument");
     if (k != RO_K) return fail(GENIE_ERR_ARG, "genie_readout_query: k must be 10 (module.py:280)");
@@ -1819,6 +1856,10 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     RoArgs a = make_ro_args(c);
     a.N = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
     a.t_query = t_query; a.out = x_out;
+    float* cvbuf = (float*)ws + c->o_cv;
+    a.cv = cvbuf;
+    k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, (hipStream_t)stream>>>(
+        x_spatial, c->G, c->raw, g_params[W_SAT_C_W].off, g_params[W_SAT_V_W].off, cvbuf);
     const int nb = std::min((a.N + NPB - 1) / NPB, c->num_cu * 1);
     HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
     k_readout<1><<<nb, 256, RO_LDS1, (hipStream_t)stream>>>(a);

@@ -214,7 +214,7 @@ class HipPath(object):
         tq = _f32(t_query, "t_query").reshape(-1)
         out = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_readout_query(self.ctx, _ptr(x_spatial), _ptr(x_grid), _ptr(x_query), _ptr(knn_idx), nq, 10,
-                                                _ptr(tq), tq.numel(), _ptr(out), _stream()), "genie_readout_query")
+                                                _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
         return out
 
     def set_scale_t(self, scale_t):

@@ -151,7 +151,8 @@ int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const 
  */
 int genie_readout_grid(genie_ctx* ctx, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream);
 int genie_readout_query(genie_ctx* ctx, const float* x_spatial, const float* x_grid, const float* x_query,
-                        const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out, void* stream);
+                        const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out,
+                        void* ws, void* stream);
 
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */
