@@ -319,3 +319,38 @@ def test_sharded_kernels_two_virtual_ranks_match_unsharded():
         o = ranks[0].full.spatial_agg(layer, o, pos.to(DEV))
     assert torch.equal(o, out_ref)
     assert min(sp.plan.n_halo for sp in ranks) > 0
+
+
+def test_apply_loop_matches_oracle_windows():
+    """The sliding-window caller (process_continuous_days.py:761-810): Out_2 stacked on the GPU over the kept windows
+    equals the same stacking of the oracle's per-window outputs."""
+    from genie_amd import apply
+    from oracle import genie_oracle as O
+    S, G = 12, 80
+    geom = synthetic.Geometry(S, G, L=60e3, n_query=15, seed=51)
+    P = synthetic.make_picks(geom, 150, seed=52)
+    P[:, 0] = P[:, 0] * 0.2 + 300.0                 # squeeze into a short interval -> a handful of windows
+    c = Case("tiny_6x40")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src),
+                             torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.locs).float().to(DEV),
+                             torch.from_numpy(geom.x_grid).float().to(DEV))
+    Out_2, times = apply.apply_windows(net, geom, P, step_size="half", min_required_picks=5)
+    assert 2 <= len(times) <= 40
+    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], geom.max_t, t_win=6.0, step_size="half")
+    tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
+    want = torch.zeros(Out_2.shape)
+    sta_nbr = graph.neighbour_table(geom.A_sta_sta, S)
+    src_nbr = graph.neighbour_table(geom.A_src_src, G)
+    for t0 in times:
+        sel = (P[:, 0] > t0 - 6.0) & (P[:, 0] < t0 + geom.max_t + 6.0)
+        Slice, Mask = synthetic.make_slice_mask(geom, P[sel], t0)
+        _, x = O.forward_fixed_source_structured(c.weights, torch.from_numpy(Slice), torch.from_numpy(Mask), sta_nbr, src_nbr,
+                                                 torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.A_src_src),
+                                                 torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+                                                 torch.from_numpy(offsets.reshape(-1, 1)).float(), S, G)
+        ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)
+        want[:, ip[:-1]] += x[:, :-1, 0] / 2.0
+    assert max_abs(Out_2.cpu(), want) <= 1e-5
