@@ -925,6 +925,124 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     }
 }
 
+// Fast stage 2 for uniform-degree graphs (KS station / KP source neighbours): the neighbour ids of tile i+1 are
+// fetched while tile i computes, and the 1 + KS + KP row loads of a tile are all issued before the first is consumed,
+// so a tile pays ONE memory round trip. Same arithmetic and summation order as k_stage2 (bitwise identical).
+template <int KS, int KP>
+__global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int lane0 = lane;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    if (w.it >= w.nitems) return;
+    const char* wub = (const char*)a.wu;
+    const char* wvb = (const char*)a.wv;
+    const unsigned q16 = 16u * (unsigned)q;          // byte offset of this lane's 4 channels inside a 64-B row
+
+    int g_c, sc_c, tb_c, g_n = 0, sc_n = 0, tb_n = 0;
+    bool valid_c, valid_n = false;
+    int sta_c[KS], sta_n[KS], srcv_c, srcv_n = 0;
+    auto decode = [&](long long item, int& g, int& sc, int& tb, bool& valid) {
+        int gi;
+        w.decode(item, gi, tb);
+        g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        const int s = tb * 16 + j;
+        valid = s < S;
+        sc = valid ? s : S - 1;
+    };
+    decode(w.it, g_c, sc_c, tb_c, valid_c);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) sta_c[k] = a.sta_col[sc_c * KS + k];
+    srcv_c = a.src_col[(long long)g_c * KP + min(lane0 & 15, KP - 1)];
+    for (;;) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const long long p = (long long)g_c * S + sc_c;
+        // (1) every load of this tile
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        const float mq = a.mask[p * 4 + q];
+        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        f32x4 ru[KS], rv[KP];
+        const unsigned gS = (unsigned)g_c * (unsigned)S;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) ru[k] = *(const f32x4*)(wub + ((gS + (unsigned)sta_c[k]) * 64u + q16));
+        const unsigned so = (unsigned)sc_c * 64u + q16;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            rv[k] = *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(srcv_c, k) * ((unsigned)S * 64u) + so));
+        // (2) ids of the next tile
+        const bool has_next = w.it + w.stride < w.nitems;
+        if (has_next) {
+            decode(w.it + w.stride, g_n, sc_n, tb_n, valid_n);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) sta_n[k] = a.sta_col[sc_n * KS + k];
+            srcv_n = a.src_col[(long long)g_n * KP + min(lane0 & 15, KP - 1)];
+        }
+        // (3) neighbour means of the projected operands, in edge order
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) n1 += ru[k];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) n2 += rv[k];
+        n1 *= 1.f / (float)KS;
+        n2 *= 1.f / (float)KP;
+        o[0] = prelu4u(o[0] + n1, a2);
+        o[1] = prelu4u(o[1] + n2, a2);
+        if (a.x_latent != nullptr && valid_c) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * q + r < 15) {
+                    xl[4 * q + r] = o[0][r];
+                    xl[15 + 4 * q + r] = o[1][r];
+                }
+            }
+        }
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            bp[t] = prelu4u(bp[t], ab1);
+        }
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (!valid_c) mm = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = bp[t] * mm;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                v.x += __shfl_xor(v.x, d);
+                v.y += __shfl_xor(v.y, d);
+                v.z += __shfl_xor(v.z, d);
+                v.w += __shfl_xor(v.w, d);
+            }
+            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
+        }
+        if (!has_next) break;
+        g_c = g_n; sc_c = sc_n; tb_c = tb_n; valid_c = valid_n; srcv_c = srcv_n;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_c[k] = sta_n[k];
+        w.it += w.stride;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small G-sized kernels: 32 lanes per source node (2 nodes per wave, 8 per workgroup), weights transposed
 // in LDS ([k][32], lane = output channel), inputs broadcast with width-32 shuffles.
@@ -1436,7 +1554,7 @@ struct genie_ctx {
     int32_t* d_scal[2];
     float* packed[2];
     int num_cu;
-    int seg, bpc1, bpc1f, bpc2;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
+    int seg, bpc1, bpc1f, bpc2, bpc2f;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     // workspace offsets (floats)
@@ -1607,6 +1725,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1f, k_stage1_fast<8, 15>, 256, 0));
         c->bpc1 = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1);
         c->bpc1f = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1f);
+        int occ2f = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
+        c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
         c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
@@ -1713,7 +1834,10 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
-    k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
+    if (c->use_fast)
+        k_stage2_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc2f), 256, 0, st>>>(a);
+    else
+        k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
     const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
     k_bip_out<<<nb, 256, 0, st>>>(a.part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off,
                                   g_params[W_BP_ACT2].off, bip_out);

@@ -109,9 +109,10 @@ def _random_case(S, G, seed, n_picks):
     return geom, win
 
 
-@pytest.mark.parametrize("S,G", [(1 + 2, 9), (16, 64), (17, 33), (50, 700), (200, 300)])
+@pytest.mark.parametrize("S,G", [(1 + 2, 9), (16, 64), (17, 33), (50, 700), (200, 300), (2000, 40)])
 def test_random_shapes_vs_structured_oracle(S, G):
-    """Ragged tile edges (S not a multiple of 16), S < 16, S = 16 exactly, and the config-2 station count."""
+    """Ragged tile edges (S not a multiple of 16), S < 16, S = 16 exactly, the config-2 station count (200) and the
+    config-4 station count (2000: 125 tiles per source node, station sum over 2000 terms)."""
     from oracle import genie_oracle as O
     geom, win = _random_case(S, G, seed=100 + S, n_picks=10 * S)
     c = Case("tiny_6x40")  # weights only
