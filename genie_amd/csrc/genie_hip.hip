@@ -1049,22 +1049,18 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int NPB = 8;  // nodes per 256-thread block
 
-__device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
-    for (int i = threadIdx.x; i < ld * 32; i += blockDim.x) {  // dst[k*32 + c] = W[c][k] (c < rows) else 0
-        const int k = i >> 5, c = i & 31;
-        dst[i] = c < rows ? W[c * ld + k] : 0.f;
-    }
-}
-
-// dst[k*ldo + c] = W[c][k] for c < rows (else 0), c < ldo
+// Weight staging: global [rows][ld] row-major (nn.Linear layout) -> LDS [k][ldo] (k = input index, lane = output
+// channel; conflict-free LDS writes and reads, strided but L1-resident global reads)
 __device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
     for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
         const int k = i / ldo, c = i - k * ldo;
         dst[i] = c < rows ? W[c * ld + k] : 0.f;
     }
 }
-
-// dst[k*32 + c] = W[c][k] for the first kcols input columns only (c < rows else 0)
+__device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
+    stage_transposed_ld(dst, W, rows, ld, 32);
+}
+// first kcols input columns only: dst[k*32 + c] = W[c][k], k < kcols
 __device__ __forceinline__ void stage_transposed_cols(float* dst, const float* __restrict__ W, int rows, int ld, int kcols) {
     for (int i = threadIdx.x; i < kcols * 32; i += blockDim.x) {
         const int k = i >> 5, c = i & 31;
@@ -1218,13 +1214,26 @@ __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
                     pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
         const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
         float asum = 0.f;
-        for (int e = eb; e < ee; ++e) {          // no cross-lane op inside: the two half-waves may differ in trip count
-            const int jn = a.col[e];
-            float m = a.pj_in[(long long)jn * 32 + c] + base;
-            m += wp0 * (pi0 - a.pos[jn * 3 + 0] / a.scale_rel);
-            m += wp1 * (pi1 - a.pos[jn * 3 + 1] / a.scale_rel);
-            m += wp2 * (pi2 - a.pos[jn * 3 + 2] / a.scale_rel);
-            asum += prelu1(m, act1);
+        // edges in chunks of 8: ids, then all gathered rows / positions in flight, then the arithmetic in edge order
+        // (no cross-lane op inside: the two half-waves of a wave may differ in trip count)
+        for (int e0 = eb; e0 < ee; e0 += 8) {
+            int jn[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) jn[k] = a.col[min(e0 + k, ee - 1)];
+            float pjv[8], q0[8], q1[8], q2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pjv[k] = a.pj_in[(long long)jn[k] * 32 + c];
+                q0[k] = a.pos[jn[k] * 3 + 0]; q1[k] = a.pos[jn[k] * 3 + 1]; q2[k] = a.pos[jn[k] * 3 + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float m = pjv[k] + base;
+                m += wp0 * (pi0 - q0[k] / a.scale_rel);
+                m += wp1 * (pi1 - q1[k] / a.scale_rel);
+                m += wp2 * (pi2 - q2[k] / a.scale_rel);
+                if (e0 + k < ee) asum += prelu1(m, act1);
+            }
         }
         const float av = asum / (float)max(ee - eb, 1);
         float o = b2;
@@ -1861,7 +1870,7 @@ void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
         a.nx_act3 = g_params[nb + 8].off;
     }
 }
-int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, 1024); }
+int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, c->num_cu * 2); }
 
 // chain = true: the pre-pass of `layer` was already produced (by k_sa_pre or by the previous layer's NEXT tail) in
 // pj/gpart buffer `cur`; with_next emits the next layer's pre-pass into the other buffer.
