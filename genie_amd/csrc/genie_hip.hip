@@ -1266,6 +1266,28 @@ __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
 // node (module.py:1015-1016); MODE 1: x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query
 // (module.py:1017-1018), the K = 10 nearest grid nodes of every query given as an index table.
 // ------------------------------------------------------------------------------------------------
+// Pre-transposed weight images for the G-/Q-sized kernels: built once per weight update (ensure_packed) so that a
+// workgroup fills its LDS with ONE linear, coalesced copy instead of a strided transpose of ~20k floats.
+// image element (k, c) of one matrix = W[c][col0 + k] (c < rows, k < ncols) at dst + k*ldo + c, zero padded.
+struct TDesc {
+    int32_t dst, raw, rows, ld, ldo, col0, ncols, pad;
+};
+__global__ void k_pack_t(const float* __restrict__ raw, const TDesc* __restrict__ d, int nd, float* __restrict__ img) {
+    for (int m = 0; m < nd; ++m) {
+        const TDesc t = d[m];
+        const int n = t.ncols * t.ldo;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const int k = i / t.ldo, c = i - k * t.ldo;
+            img[t.dst + i] = c < t.rows ? raw[t.raw + c * t.ld + t.col0 + k] : 0.f;
+        }
+    }
+}
+// read-out images (floats): common part, then MODE-specific part
+constexpr int RO_IMG_COMMON = 30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32;     // w_c1 w_v1 w_c2 w_v2 w_p1 w_p2
+constexpr int RO_IMG0 = RO_IMG_COMMON + 30 * 32;                              // + f_direct
+constexpr int RO_IMG1 = RO_IMG_COMMON + 3 * 96 * 3 + 15 * 32;                 // + f_queries, f_context[e], f_values[e], proj
+constexpr int RO_IMGCV = 2 * 30 * 96;                                         // f_context / f_values x-columns (k_ro_pre)
+
 struct RoArgs {
     int N, G, T;                 // nodes handled (G for MODE 0, Q for MODE 1), grid size, number of time queries (<= 16)
     const float* x_spatial;      // [G,30]
@@ -1273,6 +1295,7 @@ struct RoArgs {
     const float* x_query;        // [Q,3]   (MODE 1)
     const int32_t* knn;          // [Q,10]  (MODE 1)
     const float* cv;             // [G,160] per-grid-node parts of f_context / f_values (MODE 1)
+    const float* img;            // pre-transposed weight image of this MODE (k_pack_t)
     const float* t_query;        // [T]
     const float* raw;
     float scale_rel, scale_t;
@@ -1287,14 +1310,13 @@ struct RoArgs {
 // [x_j || edge_attr]; the x_j part  C_j = f_context.weight[:, 0:30] x_j,  V_j = f_values.weight[:, 0:30] x_j  is the same
 // for every query that has j as a neighbour, so it is computed once per grid node: cv[j] = [C_j (75, pad 80) | V_j].
 constexpr int CVP = 160;
-__global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spatial, int G, const float* __restrict__ raw,
-                                                int o_cw, int o_vw, float* __restrict__ cv) {
-    __shared__ float wc[30 * 96];
-    __shared__ float wv[30 * 96];
-    for (int i = threadIdx.x; i < 30 * 96; i += blockDim.x) {
-        const int k = i / 96, ch = i - k * 96;
-        wc[i] = ch < 75 ? raw[o_cw + ch * 33 + k] : 0.f;
-        wv[i] = ch < 75 ? raw[o_vw + ch * 33 + k] : 0.f;
+__global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spatial, int G, const float* __restrict__ imgcv,
+                                                float* __restrict__ cv) {
+    __shared__ __attribute__((aligned(16))) float wc[30 * 96];
+    __shared__ __attribute__((aligned(16))) float wv[30 * 96];
+    for (int i = threadIdx.x; i < 30 * 96 / 4; i += blockDim.x) {
+        ((f32x4*)wc)[i] = ((const f32x4*)imgcv)[i];
+        ((f32x4*)wv)[i] = ((const f32x4*)(imgcv + 30 * 96))[i];
     }
     __syncthreads();
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -1317,11 +1339,16 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
     }
 }
 
+// The 32 lanes of a node group live in ONE wave and only exchange data among themselves through their private LDS
+// scratch, so a wave-level ordering point (LDS ops of a wave complete in order) replaces __syncthreads(): waves do
+// not wait for each other between the ~35 short phases of a node batch.
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
 constexpr int RO_TMAX = 16;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_readout(RoArgs a) {
+template <int MODE, int NG>
+__global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // ---- LDS carve (floats)
     float* w_c1 = sm;                    // [30][32]
@@ -1330,13 +1357,13 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
     float* w_v2 = w_c2 + 30 * 96;        // [30][96]
     float* w_p1 = w_v2 + 30 * 96;        // [15][32]
     float* w_p2 = w_p1 + 15 * 32;        // [32]
-    float* qry = w_p2 + 32;              // [RO_TMAX][96]
-    float* w_x0 = qry + RO_TMAX * 96;    // MODE 0: f_direct [30][32];  MODE 1: f_queries [3][96]
+    float* w_x0 = w_p2 + 32;             // MODE 0: f_direct [30][32];  MODE 1: f_queries [3][96]
     float* w_fc = w_x0 + (MODE == 0 ? 30 * 32 : 3 * 96);   // MODE 1: f_context, edge-attr columns [3][96]
     float* w_fv = w_fc + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: f_values, edge-attr columns [3][96]
     float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
-    float* scr = w_pr + (MODE == 0 ? 0 : 15 * 32);         // per-group scratch
-    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96 + (MODE == 1 ? RO_K * 96 : 0);   // floats per group
+    float* qry = w_pr + (MODE == 0 ? 0 : 15 * 32);         // [RO_TMAX][96]
+    float* scr = qry + RO_TMAX * 96;                       // per-group scratch
+    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96 + (MODE == 1 ? RO_K * 96 : 0);   // floats per group
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
     float* h1 = xin + 40;                // [32]
@@ -1345,27 +1372,15 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
     float* val = ctx + 96;               // [96]
     float* scs = val + 96;               // [48]  score[t*5+h]
     float* zs = scs + 48;                // [T][16]
-    float* p1s = zs + RO_TMAX * 16;      // [T][32]
-    float* prd = p1s + RO_TMAX * 32;     // [96]  q*c products / aggregated values (MODE 1)
+    float* prd = zs + RO_TMAX * 16;      // [96]  q*c products / aggregated values (MODE 1)
     float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
     float* vst = als + 96;               // [10][96] per-edge value embeddings (MODE 1)
 
-    stage_transposed_ld(w_c1, a.raw + a.o_c1w, 30, 30, 32);
-    stage_transposed_ld(w_v1, a.raw + a.o_v1w, 30, 30, 32);
-    stage_transposed_ld(w_c2, a.raw + a.o_c2w, 75, 30, 96);
-    stage_transposed_ld(w_v2, a.raw + a.o_v2w, 75, 30, 96);
-    stage_transposed_ld(w_p1, a.raw + a.o_p1w, 30, 15, 32);
-    if (threadIdx.x < 32) w_p2[threadIdx.x] = threadIdx.x < 30 ? a.raw[a.o_p2w + threadIdx.x] : 0.f;
-    if (MODE == 0) {
-        stage_transposed_ld(w_x0, a.raw + a.o_sd_w, 30, 30, 32);
-    } else {
-        stage_transposed_ld(w_x0, a.raw + a.o_sq_w, 75, 3, 96);
-        for (int i = threadIdx.x; i < 3 * 96; i += blockDim.x) {
-            const int d = i / 96, ch = i - d * 96;
-            w_fc[i] = ch < 75 ? a.raw[a.o_sc_w + ch * 33 + 30 + d] : 0.f;
-            w_fv[i] = ch < 75 ? a.raw[a.o_sv_w + ch * 33 + 30 + d] : 0.f;
-        }
-        stage_transposed_ld(w_pr, a.raw + a.o_sp_w, 30, 15, 32);
+    {   // static weights: one linear copy of the pre-transposed image (same layout as the carve above)
+        constexpr int NIMG = (MODE == 0 ? RO_IMG0 : RO_IMG1) / 4;
+        const f32x4* src = (const f32x4*)a.img;
+        f32x4* dst = (f32x4*)sm;
+        for (int i = threadIdx.x; i < NIMG; i += blockDim.x) dst[i] = src[i];
     }
     // temporal queries: qry[t][ch] = temporal_query_2(PReLU3(temporal_query_1(t_query/scale_t)))   module.py:329
     {
@@ -1393,21 +1408,21 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
     const float b_p1 = c < 30 ? a.raw[a.o_p1b + c] : 0.f, b_p2 = a.raw[a.o_p2b];
     const float inv_sqrt_l = 1.f / sqrtf(15.f);
 
-    for (int n0 = blockIdx.x * NPB; n0 < a.N; n0 += gridDim.x * NPB) {
+    for (int n0 = blockIdx.x * NG; n0 < a.N; n0 += gridDim.x * NG) {
         const int n = n0 + grp;
         const bool ok = n < a.N;
         const int nc = ok ? n : a.N - 1;
         // ------------------------------------------------------------------ front end -> 30-vector in xin
         if (MODE == 0) {
             xin[c] = c < 30 ? a.x_spatial[(long long)nc * 30 + c] : 0.f;
-            __syncthreads();
+            GSYNC();
             float y = c < 30 ? a.raw[a.o_sd_b + c] : 0.f;                               // SpatialDirect, module.py:258-260
 #pragma unroll
             for (int k = 0; k < 30; ++k) y += w_x0[k * 32 + c] * xin[k];
             y = prelu1(y, a.raw[a.o_sd_a]);
-            __syncthreads();
+            GSYNC();
             xin[c] = c < 30 ? y : 0.f;
-            __syncthreads();
+            GSYNC();
         } else {
             const float sa1 = a.raw[a.o_sa1], sa2 = a.raw[a.o_sa2];
             const float bq[3] = {a.raw[a.o_sq_b + c], a.raw[a.o_sq_b + 32 + c], c < 11 ? a.raw[a.o_sq_b + 64 + c] : 0.f};
@@ -1431,14 +1446,14 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
                 }
                 prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
                 vst[k * 96 + c] = v3[0]; vst[k * 96 + 32 + c] = v3[1]; vst[k * 96 + 64 + c] = v3[2];
-                __syncthreads();
+                GSYNC();
                 if (c < 5) {                                                            // alpha = PReLU1(sum_l q*c / sqrt(L))  :293
                     float sdot = 0.f;
 #pragma unroll
                     for (int l = 0; l < 15; ++l) sdot += prd[c * 15 + l];
                     als[k * 8 + c] = prelu1(sdot * inv_sqrt_l, sa1);
                 }
-                __syncthreads();
+                GSYNC();
             }
             if (c < 5) {                                                                // segment softmax over the K edges  :295
                 float m = als[c];
@@ -1450,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
 #pragma unroll
                 for (int k = 0; k < RO_K; ++k) als[k * 8 + c] = ek[k] / (ssum + 1e-16f);
             }
-            __syncthreads();
+            GSYNC();
             {
                 const int hd0 = c / 15, hd1 = (32 + c) / 15, hd2 = min((64 + c) / 15, 4);
                 float g0 = 0.f, g1 = 0.f, g2 = 0.f;                                     // 'add' aggregation of alpha * v  :264,297
@@ -1462,23 +1477,23 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
                 }
                 prd[c] = g0; prd[32 + c] = g1; prd[64 + c] = g2;
             }
-            __syncthreads();
+            GSYNC();
             float xm = 0.f;                                                             // mean over heads  :285
             if (c < 15) {
 #pragma unroll
                 for (int hh = 0; hh < 5; ++hh) xm += prd[hh * 15 + c];
                 xm *= 0.2f;
             }
-            __syncthreads();
+            GSYNC();
             xin[c] = xm;
-            __syncthreads();
+            GSYNC();
             float xo = c < 30 ? a.raw[a.o_sp_b + c] : 0.f;                              // PReLU2(proj(.))  :285
 #pragma unroll
             for (int l = 0; l < 15; ++l) xo += w_pr[l * 32 + c] * xin[l];
             xo = prelu1(xo, sa2);
-            __syncthreads();
+            GSYNC();
             xin[c] = c < 30 ? xo : 0.f;
-            __syncthreads();
+            GSYNC();
         }
         // ------------------------------------------------------------------ TemporalAttention on xin[0..29]  :325-331
         {
@@ -1488,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
             h1[c] = c < 30 ? prelu1(t1, act1) : 0.f;
             h2[c] = c < 30 ? prelu1(t2, act2) : 0.f;
         }
-        __syncthreads();
+        GSYNC();
         {
             float cx[3] = {b_c2[0], b_c2[1], b_c2[2]}, vx[3] = {b_v2[0], b_v2[1], b_v2[2]};
 #pragma unroll
@@ -1500,7 +1515,7 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
             ctx[c] = cx[0]; ctx[32 + c] = cx[1]; ctx[64 + c] = cx[2];
             val[c] = vx[0]; val[32 + c] = vx[1]; val[64 + c] = vx[2];
         }
-        __syncthreads();
+        GSYNC();
         for (int idx = c; idx < a.T * 5; idx += 32) {                                    // score[t,h] = ctx[h,:].qry[t,h,:]/sqrt(L)
             const int t = idx / 5, hh = idx - t * 5;
             float sdot = 0.f;
@@ -1508,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
             for (int l = 0; l < 15; ++l) sdot += ctx[hh * 15 + l] * qry[t * 96 + hh * 15 + l];
             scs[idx] = sdot * inv_sqrt_l;
         }
-        __syncthreads();
+        GSYNC();
         for (int idx = c; idx < a.T * 15; idx += 32) {                                   // z[t,l] = mean_h score[t,h] * val[h,l]
             const int t = idx / 15, l = idx - t * 15;
             float z = 0.f;
@@ -1516,21 +1531,17 @@ __global__ __launch_bounds__(256) void k_readout(RoArgs a) {
             for (int hh = 0; hh < 5; ++hh) z += scs[t * 5 + hh] * val[hh * 15 + l];
             zs[t * 16 + l] = prelu1(z * 0.2f, act4);
         }
-        __syncthreads();
-        for (int t = 0; t < a.T; ++t) {                                                  // PReLU5(proj_1(.))
+        GSYNC();
+        for (int t = 0; t < a.T; ++t) {                                                  // proj_2(PReLU5(proj_1(.))): 15 -> 30 -> 1
             float pv = b_p1;
 #pragma unroll
             for (int l = 0; l < 15; ++l) pv += w_p1[l * 32 + c] * zs[t * 16 + l];
-            p1s[t * 32 + c] = c < 30 ? prelu1(pv, act5) : 0.f;
-        }
-        __syncthreads();
-        if (c < a.T) {                                                                   // proj_2: 30 -> 1
-            float o = b_p2;
+            float o = c < 30 ? w_p2[c] * prelu1(pv, act5) : 0.f;
 #pragma unroll
-            for (int k = 0; k < 30; ++k) o += w_p2[k] * p1s[c * 32 + k];
-            if (ok) a.out[(long long)n * a.T + c] = o;
+            for (int d = 16; d >= 1; d >>= 1) o += __shfl_xor(o, d, 32);                     // fixed butterfly order
+            if (ok && c == 0) a.out[(long long)n * a.T + t] = o + b_p2;
         }
-        __syncthreads();
+        GSYNC();
     }
 }
 
@@ -1563,6 +1574,8 @@ struct genie_ctx {
     int32_t* d_scal[2];
     float* packed[2];
     int num_cu;
+    float* ro_img;             // [RO_IMG0 | RO_IMG1 | RO_IMGCV] pre-transposed read-out weight images
+    TDesc* d_tdesc; int n_tdesc;
     int seg, bpc1, bpc1f, bpc2, bpc2f;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
@@ -1608,6 +1621,7 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
                                                    (int)p.bias.size(), c->d_scal[s], (int)p.scal.size(), c->packed[s]);
     }
+    k_pack_t<<<8, 256, 0, st>>>(c->raw, c->d_tdesc, c->n_tdesc, c->ro_img);
     HIP_TRY(hipGetLastError());
     c->dirty = false;
     return GENIE_OK;
@@ -1717,6 +1731,36 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMemcpy(c->d_scal[s], p.scal.data(), sizeof(int32_t) * p.scal.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
     }
+    {
+        std::vector<TDesc> td;
+        auto add = [&](int dst, int w, int rows, int ld, int ldo, int col0, int ncols) {
+            TDesc t; t.dst = dst; t.raw = g_params[w].off; t.rows = rows; t.ld = ld; t.ldo = ldo; t.col0 = col0; t.ncols = ncols; t.pad = 0;
+            td.push_back(t);
+        };
+        for (int m = 0; m < 2; ++m) {                       // common part of both images
+            const int b = m == 0 ? 0 : RO_IMG0;
+            add(b + 0, W_TA_C1_W, 30, 30, 32, 0, 30);
+            add(b + 960, W_TA_V1_W, 30, 30, 32, 0, 30);
+            add(b + 1920, W_TA_C2_W, 75, 30, 96, 0, 30);
+            add(b + 4800, W_TA_V2_W, 75, 30, 96, 0, 30);
+            add(b + 7680, W_TA_P1_W, 30, 15, 32, 0, 15);
+            add(b + 8160, W_TA_P2_W, 1, 30, 32, 0, 0);      // placeholder, proj_2 (a [1,30] row) handled below
+        }
+        // proj_2.weight is [1,30]: image element k (k < 30) = W[0][k] -> rows = 30 "channels" read along the row
+        td[5].rows = 30; td[5].ld = 1; td[5].ldo = 32; td[5].col0 = 0; td[5].ncols = 1;
+        td[11] = td[5]; td[11].dst = RO_IMG0 + 8160;
+        add(RO_IMG_COMMON, W_SD_W, 30, 30, 32, 0, 30);                                   // MODE 0: f_direct
+        add(RO_IMG0 + RO_IMG_COMMON, W_SAT_Q_W, 75, 3, 96, 0, 3);                        // MODE 1: f_queries
+        add(RO_IMG0 + RO_IMG_COMMON + 288, W_SAT_C_W, 75, 33, 96, 30, 3);                //          f_context[:, 30:33]
+        add(RO_IMG0 + RO_IMG_COMMON + 576, W_SAT_V_W, 75, 33, 96, 30, 3);                //          f_values[:, 30:33]
+        add(RO_IMG0 + RO_IMG_COMMON + 864, W_SAT_P_W, 30, 15, 32, 0, 15);                //          proj
+        add(RO_IMG0 + RO_IMG1, W_SAT_C_W, 75, 33, 96, 0, 30);                            // k_ro_pre: f_context[:, 0:30]
+        add(RO_IMG0 + RO_IMG1 + 2880, W_SAT_V_W, 75, 33, 96, 0, 30);                     //           f_values[:, 0:30]
+        c->n_tdesc = (int)td.size();
+        HIP_TRY(hipMalloc((void**)&c->d_tdesc, sizeof(TDesc) * td.size()));
+        HIP_TRY(hipMemcpy(c->d_tdesc, td.data(), sizeof(TDesc) * td.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->ro_img, sizeof(float) * (RO_IMG0 + RO_IMG1 + RO_IMGCV)));
+    }
     c->dirty = true;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1763,7 +1807,7 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
-                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1]};
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -1961,19 +2005,22 @@ RoArgs make_ro_args(const genie_ctx* c) {
     a.o_sa1 = g_params[W_SAT_ACT1].off; a.o_sa2 = g_params[W_SAT_ACT2].off;
     return a;
 }
-constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + RO_TMAX * 32 + 96 + 96;
-constexpr size_t RO_LDS0 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 30 * 32 + NPB * RO_SCR);
-constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 * 3 + 15 * 32 + NPB * (RO_SCR + RO_K * 96));
+constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;
+constexpr int RO_NG0 = 24, RO_NG1 = 12;   // node groups (of 32 lanes) per workgroup: 1024 / 512 threads share one weight image
+constexpr size_t RO_LDS0 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 30 * 32 + RO_NG0 * RO_SCR);
+constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 * 3 + 15 * 32 + RO_NG1 * (RO_SCR + RO_K * 96));
 }  // namespace
 
 int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
     if (!c || !x_spatial || !t_query || !y_out) return fail(GENIE_ERR_ARG, "genie_readout_grid: null argument");
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 16 required");
     RoArgs a = make_ro_args(c);
+    { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
-    const int nb = std::min((a.N + NPB - 1) / NPB, c->num_cu * 2);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS0));
-    k_readout<0><<<nb, 256, RO_LDS0, (hipStream_t)stream>>>(a);
+    a.img = c->ro_img;
+    const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS0));
+    k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, RO_LDS0, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -1989,13 +2036,15 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     RoArgs a = make_ro_args(c);
     a.N = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
     a.t_query = t_query; a.out = x_out;
+    { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
+    a.img = c->ro_img + RO_IMG0;
     float* cvbuf = (float*)ws + c->o_cv;
     a.cv = cvbuf;
     k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, (hipStream_t)stream>>>(
-        x_spatial, c->G, c->raw, g_params[W_SAT_C_W].off, g_params[W_SAT_V_W].off, cvbuf);
-    const int nb = std::min((a.N + NPB - 1) / NPB, c->num_cu * 1);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
-    k_readout<1><<<nb, 256, RO_LDS1, (hipStream_t)stream>>>(a);
+        x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf);
+    const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
+    k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, RO_LDS1, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
