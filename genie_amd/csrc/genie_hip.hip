@@ -1545,6 +1545,68 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pick -> Slice/Mask embedding on device: `extract_input_from_data`,
+// /root/reference/Code/process_utils.py:460-642 (use_sign_input = False). Step 1: per-station Gaussian-kernel time
+// series of the P- and S-labelled picks by scatter-max (:499-569; max is order independent -> deterministic atomics).
+// Step 2: every product node reads the series of its station at the theoretical P / S arrival index (:599-629).
+// ------------------------------------------------------------------------------------------------
+struct EmbArgs {
+    const double* pick_t; const int32_t* pick_sta; const int32_t* pick_phase;
+    int n_picks, n_time, n_extra, S;
+    double t0, tref0, dt, sigma;
+    float* emb;            // [2][S][n_time]: P-labelled series, then S-labelled
+    const float* trv;      // [rows, 2] theoretical P / S travel time of every product node
+    long long rows;
+    float* slice; float* mask;
+};
+
+__global__ void k_embed_scatter(EmbArgs a) {
+    const int per = 2 * a.n_extra + 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)a.n_picks * per) return;
+    const int pk = (int)(i / per), off = (int)(i - (long long)pk * per) - a.n_extra;
+    const int sta = a.pick_sta[pk];
+    const int ph = a.pick_phase[pk];
+    if (sta < 0 || sta >= a.S || (ph != 0 && ph != 1)) return;
+    const double t = a.pick_t[pk];
+    const int idx = (int)((t - a.tref0) / a.dt) + off;                 // :514-515, :534
+    if (idx < 0 || idx >= a.n_time) return;                            // :537
+    const double tv = t - (a.tref0 + (double)idx * a.dt);              // abs_time_ref[idx] = arange(...)[idx]
+    const float val = (float)exp(-0.5 * tv * tv / (a.sigma * a.sigma));   // :545, cast at torch.Tensor(vals) :563
+    atomicMax((int*)(a.emb + ((long long)ph * a.S + sta) * a.n_time + idx), __float_as_int(val));   // val >= 0
+}
+
+__global__ void k_embed_edges(EmbArgs a) {   // overflow guard: first / last sample of every series is zero (:565-568)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * a.S) return;
+    a.emb[(long long)i * a.n_time] = 0.f;
+    a.emb[(long long)i * a.n_time + a.n_time - 1] = 0.f;
+}
+
+__global__ void k_embed_gather(EmbArgs a) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.rows) return;
+    const int sta = (int)(p % a.S);
+    const float2 tt = *(const float2*)(a.trv + p * 2);
+    int ip = (int)((((double)tt.x + a.t0) - a.tref0) / a.dt);           // :605 (float64 arithmetic, truncation)
+    int is = (int)((((double)tt.y + a.t0) - a.tref0) / a.dt);
+    ip = min(max(ip, 0), a.n_time - 1);
+    is = min(max(is, 0), a.n_time - 1);
+    const float* ep = a.emb + (long long)sta * a.n_time;
+    const float* es = a.emb + ((long long)a.S + sta) * a.n_time;
+    f32x4 sl;
+    sl.x = fmaxf(ep[ip], es[ip]);                                        // any-phase series = max(P, S)  :569, :612
+    sl.y = fmaxf(ep[is], es[is]);                                        // :613
+    sl.z = ep[ip];                                                       // :614
+    sl.w = es[is];                                                       // :615
+    f32x4 mk;
+    mk.x = fabsf(sl.x) > 0.01f ? 1.f : 0.f; mk.y = fabsf(sl.y) > 0.01f ? 1.f : 0.f;      // :629
+    mk.z = fabsf(sl.z) > 0.01f ? 1.f : 0.f; mk.w = fabsf(sl.w) > 0.01f ? 1.f : 0.f;
+    *(f32x4*)(a.slice + p * 4) = sl;
+    *(f32x4*)(a.mask + p * 4) = mk;
+}
+
 // de-pad rows of a workspace tensor for parity tests
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
     // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one)
@@ -2045,6 +2107,37 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
     HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
     k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, RO_LDS1, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_embed_ntime(double t0, double max_t, double kernel_sig_t, double dt) {
+    // len(np.arange(t0 - 3 sigma, t0 + max_t + 3 sigma + dt, dt))                        process_utils.py:499-504
+    const double start = t0 - 3.0 * kernel_sig_t, stop = t0 + max_t + 3.0 * kernel_sig_t + dt;
+    return (int)ceil((stop - start) / dt);
+}
+
+int genie_embed_window(genie_ctx* c, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
+                       double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
+                       float* slice_out, float* mask_out, void* stream) {
+    if (!c || !trv || !emb_ws || !slice_out || !mask_out) return fail(GENIE_ERR_ARG, "genie_embed_window: null argument");
+    if (n_picks > 0 && (!pick_t || !pick_sta || !pick_phase)) return fail(GENIE_ERR_ARG, "genie_embed_window: null pick array");
+    if (!(dt > 0.0) || !(kernel_sig_t > 0.0) || !(max_t > 0.0)) return fail(GENIE_ERR_ARG, "genie_embed_window: bad dt / sigma / max_t");
+    hipStream_t st = (hipStream_t)stream;
+    EmbArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pick_t = pick_t; a.pick_sta = pick_sta; a.pick_phase = pick_phase; a.n_picks = n_picks;
+    a.S = c->S; a.t0 = t0; a.tref0 = t0 - 3.0 * kernel_sig_t; a.dt = dt; a.sigma = kernel_sig_t;
+    a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
+    a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
+    a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out;
+    HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
+    if (n_picks > 0) {
+        const long long n = (long long)n_picks * (2 * a.n_extra + 1);
+        k_embed_scatter<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(a);
+    }
+    k_embed_edges<<<(2 * a.S + 255) / 256, 256, 0, st>>>(a);
+    k_embed_gather<<<(unsigned)((a.rows + 255) / 256), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

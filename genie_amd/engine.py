@@ -220,6 +220,29 @@ class HipPath(object):
     def set_scale_t(self, scale_t):
         _lib.check(self.lib.genie_set_scale_t(self.ctx, ctypes.c_float(float(scale_t))), "genie_set_scale_t")
 
+    def embed_window(self, pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv):
+        """Slice, Mask [n_grid_ext*n_sta, 4] for the window starting at t0, from picks resident on the GPU
+        (process_utils.py:460-642). pick_t float64, pick_sta / pick_phase int32 GPU tensors; trv [rows, 2] fp32."""
+        rows = self.n_grid_ext * self.n_sta
+        trv = _f32(trv, "trv", (rows, 2))
+        n = int(pick_t.numel())
+        if n:
+            if pick_t.dtype != torch.float64 or pick_sta.dtype != torch.int32 or pick_phase.dtype != torch.int32:
+                raise ValueError("pick_t must be float64, pick_sta / pick_phase int32")
+            if not (pick_t.is_cuda and pick_sta.is_cuda and pick_phase.is_cuda):
+                raise ValueError("pick arrays must live on the GPU")
+        n_time = int(self.lib.genie_embed_ntime(float(t0), float(max_t), float(kernel_sig_t), float(dt)))
+        need = 2 * self.n_sta * n_time
+        if getattr(self, "_emb", None) is None or self._emb.numel() < need:
+            self._emb = torch.empty(need, dtype=torch.float32, device=self.device)
+        Slice = torch.empty((rows, 4), dtype=torch.float32, device=self.device)
+        Mask = torch.empty((rows, 4), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_embed_window(self.ctx, _ptr(pick_t) if n else None, _ptr(pick_sta) if n else None,
+                                               _ptr(pick_phase) if n else None, n, float(t0), float(max_t), float(kernel_sig_t),
+                                               float(dt), _ptr(trv), _ptr(self._emb), _ptr(Slice), _ptr(Mask), _stream()),
+                   "genie_embed_window")
+        return Slice, Mask
+
     def export(self, which):
         """Parity/debug: de-padded copy of a workspace intermediate: 0 = c [P,30] (node-local layer-2 terms),
         1 = wu [P,15], 2 = wv [P,15] (u / v projected through the neighbour-mean columns of l2_t1_2 / l2_t2_2)."""

@@ -154,6 +154,19 @@ int genie_readout_query(genie_ctx* ctx, const float* x_spatial, const float* x_g
                         const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out,
                         void* ws, void* stream);
 
+/*
+ * Pick -> Slice/Mask embedding on device = `extract_input_from_data` (process_utils.py:460-642, use_sign_input False),
+ * the step that feeds the path once per window. Removes the [P,8] fp32 H2D copy per window.
+ *   pick_t [n] float64 absolute pick times, pick_sta [n] int32 station index in the model's station order (-1 = not
+ *   used), pick_phase [n] int32 (0 = P, 1 = S); the caller passes the picks inside (t0 - 2 sigma, t0 + max_t + 2 sigma)
+ *   (process_utils.py:476). trv [n_grid_ext*n_sta, 2] fp32 theoretical P / S travel times per product node (static).
+ *   emb_ws: scratch of 2 * n_sta * genie_embed_ntime(...) floats. Outputs slice_out / mask_out [n_grid_ext*n_sta, 4].
+ */
+int genie_embed_ntime(double t0, double max_t, double kernel_sig_t, double dt);
+int genie_embed_window(genie_ctx* ctx, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
+                       double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
+                       float* slice_out, float* mask_out, void* stream);
+
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */
 int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);

@@ -1,0 +1,69 @@
+"""ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy restatement of the pick -> per-product-node feature embedding that feeds the hot path,
+`extract_input_from_data` (`/root/reference/Code/process_utils.py:460-642`, live path `use_updated_input = True`,
+`process_continuous_days.py:607,776`; `use_sign_input = False`, `trv_times` given, `batch_grids = False`).
+
+Pinned by `tests/golden/embed_*.npz`, produced by the reference's own function in the build container
+(`oracle/make_golden.py`); checked in `tests/test_embed_cpu.py`.
+"""
+import numpy as np
+
+
+def embed_time_series(P_slice, t0, max_t, kernel_sig_t, dt, sta_index, n_sta):
+    """Per-station Gaussian-kernel time series of the P- and S-labelled picks (process_utils.py:499-569).
+
+    P_slice [n,5] (t, station, amp, prob, phase); sta_index[n] = row of each pick's station in the output (0..n_sta-1).
+    Returns embed_p, embed_s float32 [n_sta, n_time], abs_time_ref float64 [n_time]."""
+    t_offset = 3.0 * kernel_sig_t
+    abs_time_ref = np.arange(t0 - t_offset, t0 + max_t + t_offset + dt, dt)                                  # :501
+    n_time = len(abs_time_ref)
+    num_index_extra = np.ceil(3 * kernel_sig_t / dt)                                                         # :518
+    vec_repeat = np.arange(-num_index_extra, num_index_extra + 1).astype("int")
+    out = []
+    for phase in (0, 1):
+        sel = np.where(P_slice[:, 4] == phase)[0]                                                            # :507-508
+        emb = np.zeros((n_sta, n_time), dtype=np.float32)
+        if sel.size:
+            nearest = ((P_slice[sel, 0] - abs_time_ref[0]) / dt).astype("int")                               # :514-515
+            idx = nearest.reshape(-1, 1) + vec_repeat.reshape(1, -1)                                         # :534
+            inside = (idx >= 0) * (idx < n_time)                                                             # :537
+            idx = np.minimum(np.maximum(0, idx), n_time - 1)                                                 # :540
+            tv = P_slice[sel, 0].reshape(-1, 1) - abs_time_ref[idx]                                          # :543
+            vals = (inside * np.exp(-0.5 * (tv ** 2) / (kernel_sig_t ** 2))).astype(np.float32)              # :545, torch.Tensor() cast :563
+            rows = np.repeat(sta_index[sel], idx.shape[1])
+            np.maximum.at(emb, (rows, idx.reshape(-1)), vals.reshape(-1))                                    # scatter 'max' :563
+        emb[:, 0] = 0.0                                                                                      # :565-568
+        emb[:, n_time - 1] = 0.0
+        out.append(emb)
+    return out[0], out[1], abs_time_ref
+
+
+def extract_input_from_data(P, t0, ind_use, n_sta_all, trv_times, A_src_in_sta, max_t, kernel_sig_t, dt):
+    """Slice [P,4], Mask [P,4] float32 for the window starting at t0 (process_utils.py:460-642).
+
+    trv_times [G, n_sta_all, 2]; A_src_in_sta [2, P] = [station index within ind_use; source node] per product node."""
+    ineed = np.where((P[:, 0] > (t0 - 2.0 * kernel_sig_t)) * (P[:, 0] < (t0 + max_t + 2.0 * kernel_sig_t)))[0]   # :476
+    P_slice = P[ineed]
+    perm = -1 * np.ones(n_sta_all, dtype="int")
+    perm[ind_use] = np.arange(len(ind_use))                                                                   # :486-487
+    P_slice = P_slice[perm[P_slice[:, 1].astype("int")] > -1]                                                 # :480-483
+    sta_index = perm[P_slice[:, 1].astype("int")]
+    embed_p, embed_s, abs_time_ref = embed_time_series(P_slice, t0, max_t, kernel_sig_t, dt, sta_index, len(ind_use))
+    embed = np.maximum(embed_p, embed_s)                                                                      # :569
+    n_time = embed.shape[1]
+    sta = np.asarray(A_src_in_sta[0]).astype("int")
+    src = np.asarray(A_src_in_sta[1]).astype("int")
+    # t0 is a float64 ARRAY in the reference (tsteps_slice), so the float32 travel times are promoted to float64 here
+    trv_ind = ((trv_times[src, ind_use[sta], :].astype(np.float64) + t0 - abs_time_ref[0]) / dt).astype("int")   # :605
+    ip, is_ = trv_ind[:, 0], trv_ind[:, 1]
+    has_picks = np.zeros(len(ind_use), dtype=bool)
+    has_picks[np.unique(sta_index)] = True        # stations without any pick in the window are not embedded -> 0 (:598-600)
+    ok = has_picks[sta]
+    Slice = np.zeros((len(sta), 4), dtype=np.float32)
+    Slice[ok, 0] = embed[sta[ok], ip[ok]]                                                                     # :612
+    Slice[ok, 1] = embed[sta[ok], is_[ok]]                                                                    # :613
+    Slice[ok, 2] = embed_p[sta[ok], ip[ok]]                                                                   # :614
+    Slice[ok, 3] = embed_s[sta[ok], is_[ok]]                                                                  # :615
+    Mask = (np.abs(Slice) > 0.01).astype(np.float32)                                                          # :629
+    return Slice, Mask

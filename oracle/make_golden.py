@@ -123,11 +123,42 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
           "| y max %.3e x max %.3e" % (np.abs(results["y"]).max(), np.abs(results["x"]).max()))
 
 
+def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
+    """Golden vector for the pick -> Slice/Mask embedding: the reference's own `extract_input_from_data`
+    (process_utils.py:460-642) on synthetic picks."""
+    import torch
+    import process_utils as ref_pu   # noqa: E402  (importable once _import_reference() set sys.path / CWD)
+    S, Gn = geom.n_sta, geom.n_grid
+    ind_use = np.arange(S)
+    trv_times = geom.travel_times().astype(np.float32)                     # [G, S, 2] (x_grids_trv, utils.py:669)
+    A_src_in_sta = np.stack([np.tile(np.arange(S), Gn), np.repeat(np.arange(Gn), S)], axis=0)   # process_continuous_days.py:629
+    dt = np.round(kernel_sig_t / 10.0, 2)                                  # process_continuous_days.py:608
+    max_t = float(np.ceil(trv_times.max() + 1.0))
+    [Inpts, Masks], _ = ref_pu.extract_input_from_data(None, P, np.array([t0]), ind_use, geom.locs, geom.x_grid, A_src_in_sta,
+                                                        trv_times=trv_times, max_t=max_t, kernel_sig_t=kernel_sig_t, dt=dt,
+                                                        use_sign_input=False, device="cpu")
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, P=P, t0=np.float64(t0), n_sta=np.int64(S), n_grid=np.int64(Gn), trv_times=trv_times,
+                        max_t=np.float64(max_t), kernel_sig_t=np.float64(kernel_sig_t), dt=np.float64(dt),
+                        Slice=Inpts[0].numpy().astype(np.float32), Mask=Masks[0].numpy().astype(np.uint8))
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "nonzero rows", int((Inpts[0].abs().sum(1) > 0).sum()))
+
+
 def main():
     ref = _import_reference()
     from genie_amd import synthetic as syn
 
     os.makedirs(OUT, exist_ok=True)
+
+    # (iv) pick -> Slice/Mask embedding (row f-1): two windows, one late in the day (large absolute times)
+    geom = syn.Geometry(14, 60, L=90e3, n_query=5, seed=61)
+    P = syn.make_picks(geom, 260, seed=62)
+    P[:, 0] += 1000.0
+    run_embed_case("embed_14x60_a", geom, P, 1000.0)
+    P2 = P.copy()
+    P2[:, 0] += 80000.3
+    P2 = P2[P2[:, 1] != 5]                                                  # one station without any pick
+    run_embed_case("embed_14x60_b", geom, P2, 81003.1)
 
     # (i) tiny, exhaustive intermediates, fp32 + fp64, distinct PReLU slopes, event-structured picks
     geom = syn.Geometry(6, 40, L=60e3, n_query=25, seed=11)

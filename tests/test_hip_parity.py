@@ -355,3 +355,29 @@ def test_apply_loop_matches_oracle_windows():
         ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)
         want[:, ip[:-1]] += x[:, :-1, 0] / 2.0
     assert max_abs(Out_2.cpu(), want) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["embed_14x60_a", "embed_14x60_b"])
+def test_device_embedding_matches_reference_and_oracle(name):
+    """Pick -> Slice/Mask embedding kernels (f-1) against the reference's extract_input_from_data golden vectors
+    (process_utils.py:460-642). fp32 tolerance 1e-6 on Slice (float cast of a float64 exp), Mask exact."""
+    import os
+    from tests.util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t0, max_t, sig, dt = float(z["t0"]), float(z["max_t"]), float(z["kernel_sig_t"]), float(z["dt"])
+    geom = synthetic.Geometry(S, G, L=90e3, n_query=5, seed=61)
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                        engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), device=DEV)
+    P = z["P"]
+    sel = (P[:, 0] > t0 - 2.0 * sig) & (P[:, 0] < t0 + max_t + 2.0 * sig)           # process_utils.py:476
+    Ps = P[sel]
+    Slice, Mask = hp.embed_window(torch.from_numpy(Ps[:, 0].copy()).to(DEV), torch.from_numpy(Ps[:, 1].astype(np.int32)).to(DEV),
+                                  torch.from_numpy(Ps[:, 4].astype(np.int32)).to(DEV), t0, max_t, sig, dt,
+                                  torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
+    assert float((Slice.cpu() - torch.from_numpy(z["Slice"])).abs().max()) <= 1e-6
+    assert torch.equal(Mask.cpu(), torch.from_numpy(z["Mask"].astype(np.float32)))
+    # no picks at all -> all zero
+    e = torch.zeros(0, device=DEV)
+    S0, M0 = hp.embed_window(e.double(), e.int(), e.int(), t0, max_t, sig, dt, torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
+    assert float(S0.abs().max()) == 0.0 and float(M0.abs().max()) == 0.0
