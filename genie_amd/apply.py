@@ -11,8 +11,10 @@ Semantics kept from the reference:
 Differences by design: `Out_2` stays on the GPU and is accumulated with `index_add_` (the reference copies every window's
 output to the host, `:803-805`); nothing in the loop synchronises with the host.
 
-The pick -> `Slice/Mask` embedding is still a host (numpy) step here (`genie_amd.synthetic.make_slice_mask`, the exact
-nearest-pick semantics of `process_utils.py:262-275`); moving it on device is row f-1 of SURVEY.md section 8.
+`apply_windows` takes any host embedding callable (default: `genie_amd.synthetic.make_slice_mask`, the exact
+nearest-pick semantics of `process_utils.py:262-275`). `apply_windows_device` is the GPU-only loop: picks and the static
+travel-time table stay resident on the device and every window's `Slice/Mask` is produced by `genie_embed_window`
+(`extract_input_from_data`, `process_utils.py:460-642`), so a window costs no host->device copy at all.
 """
 import numpy as np
 import torch
@@ -77,4 +79,45 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
             cols = torch.from_numpy(ip[:-1] if drop_last else ip).to(dev)
             vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
             Out_2.index_add_(1, cols, vals / (n_overlap * n_grids))
+    return Out_2, times
+
+
+def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1,
+                         n_grids=1.0, day_len=86400.0, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, max_t=None,
+                         times=None):
+    """GPU-only apply loop: `P` [n,5] (t, station index in the model's station order, amp, prob, phase) sorted by time,
+    `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used)."""
+    hp = net._hip
+    dev = hp.device
+    max_t = float(max_t if max_t is not None else np.ceil(trv_times.max() + 1.0))
+    dt_embed = float(dt_embed if dt_embed is not None else np.round(kernel_sig_t / 10.0, 2))      # process_continuous_days.py:608
+    tsteps, offsets, step, n_overlap, dt_win = window_schedule(P[:, 0], max_t, day_len, t_win, 9, step_size)
+    if tsteps_abs is None:
+        tsteps_abs = np.arange(tsteps.min() - t_win / 2.0, tsteps.max() + t_win / 2.0 + dt_win, dt_win)
+    if times is None:
+        times = windows_with_enough_picks(P[:, 0], tsteps, max_t, t_win, min_required_picks)
+    order = np.argsort(P[:, 0], kind="stable")
+    Ps = P[order]
+    d_t = torch.from_numpy(Ps[:, 0].copy()).to(dev)
+    d_sta = torch.from_numpy(Ps[:, 1].astype(np.int32)).to(dev)
+    d_ph = torch.from_numpy(Ps[:, 4].astype(np.int32)).to(dev)
+    d_trv = torch.from_numpy(np.ascontiguousarray(trv_times, dtype=np.float32).reshape(-1, 2)).to(dev)
+    Out_2 = torch.zeros((geom.x_query.shape[0], len(tsteps_abs)), dtype=torch.float32, device=dev)
+    locs = torch.from_numpy(geom.locs).float().to(dev)
+    xg = torch.from_numpy(geom.x_grid).float().to(dev)
+    xq = torch.from_numpy(geom.x_query).float().to(dev)
+    tq = torch.from_numpy(offsets.reshape(-1, 1)).float().to(dev)
+    drop_last = step_size == "half"
+    # per-window pick ranges and Out_2 column indices are host arithmetic on tiny arrays, done up front
+    lo = np.searchsorted(Ps[:, 0], times - 2.0 * kernel_sig_t, side="right")                      # strict >, process_utils.py:476
+    hi = np.searchsorted(Ps[:, 0], times + max_t + 2.0 * kernel_sig_t, side="left")               # strict <
+    ipn = np.abs(tsteps_abs.reshape(-1, 1, 1) - (times.reshape(1, -1, 1) + offsets.reshape(1, 1, -1))).argmin(0)
+    cols = torch.from_numpy(ipn[:, :-1] if drop_last else ipn).to(dev)
+    with torch.no_grad():
+        for w, t0 in enumerate(times):
+            a, b = int(lo[w]), int(hi[w])
+            Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv)
+            y, x = net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
+            vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
+            Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
     return Out_2, times

@@ -381,3 +381,42 @@ def test_device_embedding_matches_reference_and_oracle(name):
     e = torch.zeros(0, device=DEV)
     S0, M0 = hp.embed_window(e.double(), e.int(), e.int(), t0, max_t, sig, dt, torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
     assert float(S0.abs().max()) == 0.0 and float(M0.abs().max()) == 0.0
+
+
+def test_device_apply_loop_matches_oracle():
+    """GPU-only apply loop (device embedding + forward + Out_2 stacking) vs the oracle chain
+    embed_oracle.extract_input_from_data -> genie_oracle.forward_fixed_source_structured -> same stacking."""
+    from genie_amd import apply
+    from oracle import embed_oracle as E
+    from oracle import genie_oracle as O
+    S, G = 10, 70
+    geom = synthetic.Geometry(S, G, L=60e3, n_query=12, seed=71)
+    P = synthetic.make_picks(geom, 120, seed=72)
+    P[:, 0] = P[:, 0] * 0.25 + 5000.0
+    P = P[np.argsort(P[:, 0], kind="stable")]
+    trv = geom.travel_times().astype(np.float32)
+    c = Case("tiny_6x40")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src),
+                             torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.locs).float().to(DEV),
+                             torch.from_numpy(geom.x_grid).float().to(DEV))
+    max_t = float(np.ceil(trv.max() + 1.0))
+    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size="half", min_required_picks=5, max_t=max_t)
+    assert 2 <= len(times) <= 40
+    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size="half")
+    tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
+    A = np.stack([np.tile(np.arange(S), G), np.repeat(np.arange(G), S)], axis=0)
+    sta_nbr = graph.neighbour_table(geom.A_sta_sta, S)
+    src_nbr = graph.neighbour_table(geom.A_src_src, G)
+    want = torch.zeros(Out_2.shape)
+    for t0 in times:
+        Slice, Mask = E.extract_input_from_data(P, float(t0), np.arange(S), S, trv, A, max_t, 3.0, 0.3)
+        _, x = O.forward_fixed_source_structured(c.weights, torch.from_numpy(Slice), torch.from_numpy(Mask), sta_nbr, src_nbr,
+                                                 torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.A_src_src),
+                                                 torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+                                                 torch.from_numpy(offsets.reshape(-1, 1)).float(), S, G)
+        ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)
+        want[:, ip[:-1]] += x[:, :-1, 0] / 2.0
+    assert max_abs(Out_2.cpu(), want) <= 1e-5
