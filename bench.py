@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--config", default="cfg2_200x10k", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded", "stream"],
                     help="N>1: window-parallel replicas (weak scaling, default) or ONE window sharded over source nodes "
                          "with an RCCL halo all-to-all + all-gather per window (strong scaling; use with --config cfg4_2000x50k)")
     return ap.parse_args()
@@ -83,6 +83,78 @@ def cpu_baseline(net, geom, win):
         y, x = O.forward_fixed_source(*args)
         dt = time.perf_counter() - t0
     return y, x, dt
+
+
+def main_stream(a, geom, nq, rank, world, dev, dist):
+    """BASELINE config 5: continuous-day sliding-window inference (86 400 s at 1 s stride), every rank holds the model
+    and takes every world-th window; picks + travel-time table resident on the GPU, Slice/Mask embedded on device
+    (genie_embed_window), Out_2 stacked on device. No collective in the loop (replicas)."""
+    S, G = geom.n_sta, geom.n_grid
+    net = build_model(geom, dev)
+    hp = net._hip
+    rng = np.random.default_rng(5)
+    n_day = 250 * S                                                      # ~250 picks / station / day (BSSA NC data, SURVEY.md 6)
+    P = np.stack([np.sort(rng.uniform(0.0, 86400.0, n_day)), rng.integers(0, S, n_day).astype(np.float64), np.ones(n_day),
+                  np.ones(n_day), rng.integers(0, 2, n_day).astype(np.float64)], axis=1)
+    trv = geom.travel_times().astype(np.float32)
+    max_t, sig, dt = float(np.ceil(trv.max() + 1.0)), synthetic.KERNEL_SIG_T, 0.3
+    d_t = torch.from_numpy(P[:, 0].copy()).to(dev)
+    d_sta = torch.from_numpy(P[:, 1].astype(np.int32)).to(dev)
+    d_ph = torch.from_numpy(P[:, 4].astype(np.int32)).to(dev)
+    d_trv = torch.from_numpy(trv.reshape(-1, 2)).to(dev)
+    locs = torch.from_numpy(geom.locs).float().to(dev)
+    xg = torch.from_numpy(geom.x_grid).float().to(dev)
+    xq = torch.from_numpy(geom.x_query).float().to(dev)
+    tq = torch.from_numpy(geom.t_query).float().to(dev)
+    stride = 1.0
+    n_cols = 86400 * 2
+    Out_2 = torch.zeros((xq.shape[0], n_cols), dtype=torch.float32, device=dev)
+    base = torch.arange(9, device=dev)
+    t_all = 1000.0 + stride * (rank + world * np.arange(a.warmup + a.steps))
+    lo = np.searchsorted(P[:, 0], t_all - 2.0 * sig, side="right")
+    hi = np.searchsorted(P[:, 0], t_all + max_t + 2.0 * sig, side="left")
+
+    def step(i):
+        Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv)
+        y, x = net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
+        Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            step(i)
+        barrier()
+        dtm = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtm = float(t.item())
+    wps = world * a.steps / dtm
+    ppw = float(np.mean(hi - lo))
+    out = {
+        "metric": "picks/sec through GCN_Detection_Network_extended.forward_fixed_source (GCS_Network.forward)",
+        "value": round(wps * ppw, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dtm / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config 5: continuous-day sliding-window inference, %d stations / %d grid nodes, 1 s stride, "
+                               "%.0f picks in a window's range, device embedding + forward + Out_2 stacking" % (S, G, ppw),
+                   "n_stations": S, "n_grid": G, "n_picks": ppw, "n_query": nq,
+                   "parallelism": "window-parallel replicas x%d" % world},
+        "windows_per_s": round(wps, 2), "seconds_of_data_per_wall_second": round(wps * stride, 2),
+        "day_86400_windows_wall_s": round(86400.0 / wps, 1),
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
@@ -167,6 +239,8 @@ def main():
     geom = synthetic.Geometry(S, G, L=L, n_query=nq, seed=1)
     if a.mode == "sharded":
         return main_sharded(a, geom, n_picks, nq, rank, world, dev, dist)
+    if a.mode == "stream":
+        return main_stream(a, geom, nq, rank, world, dev, dist)
     net = build_model(geom, dev)
     # synthetic pick windows of the fixed shape, resident in HBM (each rank its own windows)
     wins = [synthetic.make_window(geom, n_picks, seed=2, window=rank * 1000 + i) for i in range(a.windows)]
