@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--config", default="cfg2_200x10k", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
+    ap.add_argument("--no-pipeline", action="store_true", help="single-stream forward_fixed_source per window")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded", "stream"],
                     help="N>1: window-parallel replicas (weak scaling, default) or ONE window sharded over source nodes "
                          "with an RCCL halo all-to-all + all-gather per window (strong scaling; use with --config cfg4_2000x50k)")
@@ -116,8 +117,9 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
 
     def step(i):
         Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv)
-        y, x = net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
-        Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
+        y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+        with torch.cuda.stream(hp.side_stream):
+            Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
 
     def barrier():
         if dist is not None:
@@ -252,8 +254,12 @@ def main():
     tq = torch.from_numpy(geom.t_query).float().to(dev)
 
     def step(i):
+        # windows are independent: the two-stream pipelined call overlaps the G-sized tail of window i with the P-sized
+        # kernels of window i+1 (bitwise-identical results, tests/test_hip_parity.py); --no-pipeline = single stream
         k = i % a.windows
-        return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
+        if a.no_pipeline:
+            return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
+        return net.forward_fixed_source_pipelined(dS[k], dM[k], None, None, None, locs, xg, xq, tq)[:2]
 
     def barrier():
         if dist is not None:
@@ -305,8 +311,11 @@ def main():
     b_alg = 1532.0 * P + 816.0 * G
     path_gbs = b_alg * (windows_per_s / world) / 1e9
     if dom == "k_stage1":   # dense per-node MLP chain on fp32 MFMA: compute roofline
+        # traffic: HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> B), measured on this
+        # exact workload and committed as profiles/r01_c_pmc_stage_kernels.txt; null for other workloads
+        traffic = (2 * 200.7e6 + 500.0e6) if a.config == "cfg2_200x10k" else None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 2), "peak": FP32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
                     "executed_tflops_incl_recompute": round(F_NODE_EXEC[dom] * P / (kms[dom] * 1e-3) / 1e12, 2),
                     "hbm_equiv_GBs": round(dom_gbs, 1)}
     else:
@@ -327,7 +336,7 @@ def main():
                                "graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
-        "windows_per_s": round(windows_per_s, 2),
+        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -24,6 +24,8 @@ SYMBOLS = [
     ("genie_ctx_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_float]),
     ("genie_ctx_destroy", _c.c_int, [_P]),
     ("genie_set_scale_t", _c.c_int, [_P, _c.c_float]),
+    ("genie_set_slot", _c.c_int, [_P, _c.c_int]),
+    ("genie_set_tail_mode", _c.c_int, [_P, _c.c_int]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),
     ("genie_readout_query", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P]),
     ("genie_weights_count", _c.c_int, []),
@@ -40,6 +42,8 @@ SYMBOLS = [
     ("genie_ws_v_ptr", _P, [_P, _P]),
     ("genie_ws_v_pitch", _c.c_int, [_P]),
     ("genie_da_stage2_bipartite", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("genie_da_stage2_partials", _c.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("genie_bipartite_readout", _c.c_int, [_P, _P, _P, _P]),
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

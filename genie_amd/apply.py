@@ -117,7 +117,9 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
         for w, t0 in enumerate(times):
             a, b = int(lo[w]), int(hi[w])
             Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv)
-            y, x = net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
-            vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
-            Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
+            y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+            with torch.cuda.stream(hp.side_stream):           # the read-out lives on the side stream of the pipeline
+                vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
+                Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
+        torch.cuda.current_stream(dev).wait_stream(hp.side_stream)
     return Out_2, times

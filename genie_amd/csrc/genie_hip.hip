@@ -386,8 +386,9 @@ struct ItemIter {
         T = T_;
         seg = seg_;
         nitems = (long long)(gend - gbeg) * T;
-        it = (long long)lb * WAVES + wave;
-        stride = (long long)nbx * WAVES;
+        const int wpb = blockDim.x >> 6;           // waves per workgroup
+        it = (long long)lb * wpb + wave;
+        stride = (long long)nbx * wpb;
     }
     // item -> (index into the processing order, station tile); 32-bit arithmetic (a chunk has < 2^31 items)
     __device__ void decode(long long item, int& gi, int& tb) const {
@@ -815,11 +816,14 @@ __device__ __forceinline__ void stage1_fast_loop(const DaArgs& a, const f32x4* l
     }
 }
 
+constexpr int S1F_THREADS = 512;   // 8 waves share one 54-KB weight image: ONE workgroup per CU gives the same 8 waves / CU
+                                   // as two 256-thread ones but leaves 106 KB of LDS free for the tail kernels of the
+                                   // previous window running on a second stream
 template <int KS, int KP>
-__global__ __launch_bounds__(256) void k_stage1_fast(DaArgs a) {
+__global__ __launch_bounds__(S1F_THREADS) void k_stage1_fast(DaArgs a) {
     constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    for (int i = threadIdx.x; i < NF4; i += S1F_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + G1_GROUPS * 64);
     const float* lscal = lbias + G1_BIAS * 16;
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
-constexpr int RO_TMAX = 16;
+constexpr int RO_TMAX = 10;   // time queries per call (the reference uses 9, process_continuous_days.py:359)
 
 template <int MODE, int NG>
 __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
@@ -1363,7 +1367,7 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
     float* qry = w_pr + (MODE == 0 ? 0 : 15 * 32);         // [RO_TMAX][96]
     float* scr = qry + RO_TMAX * 96;                       // per-group scratch
-    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96 + (MODE == 1 ? RO_K * 96 : 0);   // floats per group
+    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96 + (MODE == 1 ? RO_K * 80 : 0);   // floats per group
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
     float* h1 = xin + 40;                // [32]
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     float* zs = scs + 48;                // [T][16]
     float* prd = zs + RO_TMAX * 16;      // [96]  q*c products / aggregated values (MODE 1)
     float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
-    float* vst = als + 96;               // [10][96] per-edge value embeddings (MODE 1)
+    float* vst = als + 96;               // [10][80] per-edge value embeddings (MODE 1)
 
     {   // static weights: one linear copy of the pre-transposed image (same layout as the carve above)
         constexpr int NIMG = (MODE == 0 ? RO_IMG0 : RO_IMG1) / 4;
@@ -1445,7 +1449,7 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
                     v3[0] += w_fv[d * 96 + c] * e[d]; v3[1] += w_fv[d * 96 + 32 + c] * e[d]; v3[2] += w_fv[d * 96 + 64 + c] * e[d];
                 }
                 prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
-                vst[k * 96 + c] = v3[0]; vst[k * 96 + 32 + c] = v3[1]; vst[k * 96 + 64 + c] = v3[2];
+                vst[k * 80 + c] = v3[0]; vst[k * 80 + 32 + c] = v3[1]; if (c < 16) vst[k * 80 + 64 + c] = v3[2];
                 GSYNC();
                 if (c < 5) {                                                            // alpha = PReLU1(sum_l q*c / sqrt(L))  :293
                     float sdot = 0.f;
@@ -1471,9 +1475,9 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
                 float g0 = 0.f, g1 = 0.f, g2 = 0.f;                                     // 'add' aggregation of alpha * v  :264,297
 #pragma unroll
                 for (int k = 0; k < RO_K; ++k) {
-                    g0 += als[k * 8 + hd0] * vst[k * 96 + c];
-                    g1 += als[k * 8 + hd1] * vst[k * 96 + 32 + c];
-                    g2 += als[k * 8 + hd2] * vst[k * 96 + 64 + c];
+                    g0 += als[k * 8 + hd0] * vst[k * 80 + c];
+                    g1 += als[k * 8 + hd1] * vst[k * 80 + 32 + c];
+                    g2 += als[k * 8 + hd2] * (c < 16 ? vst[k * 80 + 64 + c] : 0.f);
                 }
                 prd[c] = g0; prd[32 + c] = g1; prd[64 + c] = g2;
             }
@@ -1643,6 +1647,9 @@ struct genie_ctx {
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     // workspace offsets (floats)
     size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
+    size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist twice; `slot` selects the copy
+    int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
+    int slot;                  // lets window i+1's stage 1/2 overlap window i's G-sized kernels on another stream
 };
 
 namespace {
@@ -1655,6 +1662,7 @@ void layout_ws(genie_ctx* c) {
     c->o_c = take((size_t)c->P * ROWC);
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
+    const size_t small0 = o;
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
     c->o_sa1 = take((size_t)c->G * 32);
@@ -1663,6 +1671,8 @@ void layout_ws(genie_ctx* c) {
     c->o_pj0 = take((size_t)c->G * 32);
     c->o_pj1 = take((size_t)c->G * 32);
     c->o_cv = take((size_t)c->G * CVP);
+    c->slot_stride = o - small0;
+    o += c->slot_stride;       // second copy (slot 1)
     c->ws_floats = o;
 }
 
@@ -1689,6 +1699,13 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
     return GENIE_OK;
 }
 
+int da_grid_w(const genie_ctx* c, long long nitems_waves, int blocks_per_cu, int waves_per_block) {
+    long long need = (nitems_waves + waves_per_block - 1) / waves_per_block;
+    long long cap = (long long)c->num_cu * blocks_per_cu;
+    long long g = std::min(need, cap);
+    g = std::max<long long>(8, (g + 7) / 8 * 8);
+    return (int)g;
+}
 int da_grid(const genie_ctx* c, long long nitems_waves, int blocks_per_cu) {
     long long need = (nitems_waves + WAVES - 1) / WAVES;
     long long cap = (long long)c->num_cu * blocks_per_cu;
@@ -1706,7 +1723,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
-    a.c = ws + c->o_c; a.wu = ws + c->o_wu; a.wv = ws + c->o_wv; a.part = ws + c->o_part;
+    a.c = ws + c->o_c; a.wu = ws + c->o_wu; a.wv = ws + c->o_wv; a.part = ws + c->o_part + c->slot * c->slot_stride;
     return a;
 }
 
@@ -1837,9 +1854,11 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
         int occ1f = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1f, k_stage1_fast<8, 15>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1f, k_stage1_fast<8, 15>, S1F_THREADS, 0));
         c->bpc1 = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1);
-        c->bpc1f = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1f);
+        // 2 workgroups per CU run as fast as 3 (the kernel is MFMA-pipe bound) and leave 52 KB of LDS + wave slots for the
+        // G-sized tail kernels of the previous window on a second stream
+        c->bpc1f = (e = getenv("GENIE_BPC1")) ? atoi(e) : 1;
         int occ2f = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
@@ -1862,6 +1881,18 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
 int genie_set_scale_t(genie_ctx* c, float scale_t) {
     if (!c || !(scale_t > 0.f)) return fail(GENIE_ERR_ARG, "genie_set_scale_t: bad argument");
     c->scale_t = scale_t;
+    return GENIE_OK;
+}
+
+int genie_set_tail_mode(genie_ctx* c, int slim) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_tail_mode: null context");
+    c->tail_slim = slim ? 1 : 0;
+    return GENIE_OK;
+}
+
+int genie_set_slot(genie_ctx* c, int slot) {
+    if (!c || (slot != 0 && slot != 1)) return fail(GENIE_ERR_ARG, "genie_set_slot: slot must be 0 or 1");
+    c->slot = slot;
     return GENIE_OK;
 }
 
@@ -1919,7 +1950,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
     if (c->use_fast)
-        k_stage1_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc1f), 256, 0, st>>>(a);
+        k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     else
         k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
@@ -1940,11 +1971,11 @@ int genie_da_stage1_debug(genie_ctx* c, const float* slice, const float* mask, f
 float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_wv : nullptr; }
 int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
-int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out,
-                              float* bip_out, void* ws, void* stream) {
+int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
+                             void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
-    if (!mask || !edge_attr || !bip_out) return fail(GENIE_ERR_ARG, "genie_da_stage2_bipartite: null argument");
+    if (!mask || !edge_attr) return fail(GENIE_ERR_ARG, "genie_da_stage2_partials: null argument");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
@@ -1953,11 +1984,28 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
         k_stage2_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc2f), 256, 0, st>>>(a);
     else
         k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
-    const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
-    k_bip_out<<<nb, 256, 0, st>>>(a.part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off,
-                                  g_params[W_BP_ACT2].off, bip_out);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
+}
+
+int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!bip_out) return fail(GENIE_ERR_ARG, "genie_bipartite_readout: null output");
+    const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
+    const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
+    k_bip_out<<<nb, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off,
+                                                  g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out,
+                              float* bip_out, void* ws, void* stream) {
+    if (!bip_out) return fail(GENIE_ERR_ARG, "genie_da_stage2_bipartite: null argument");
+    int rc = genie_da_stage2_partials(c, mask, edge_attr, x_latent_out, ws, stream);
+    if (rc) return rc;
+    return genie_bipartite_readout(c, bip_out, ws, stream);
 }
 
 namespace {
@@ -1986,8 +2034,9 @@ int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos
     memset(&a, 0, sizeof(a));
     sa_fill_layer(c, layer, a);
     a.x_in = x_in; a.pos = pos; a.out = out;
-    float* pj[2] = {ws + c->o_pj0, ws + c->o_pj1};
-    float* gp[2] = {ws + c->o_gpart, ws + c->o_gpart + 1024 * 8};
+    const size_t so = c->slot * c->slot_stride;
+    float* pj[2] = {ws + c->o_pj0 + so, ws + c->o_pj1 + so};
+    float* gp[2] = {ws + c->o_gpart + so, ws + c->o_gpart + so + 1024 * 8};
     a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_blocks(c);
     a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
     const int nb = sa_blocks(c);
@@ -2004,8 +2053,8 @@ int sa_launch_pre(genie_ctx* c, int layer, const float* x_in, float* ws, int cur
     memset(&a, 0, sizeof(a));
     sa_fill_layer(c, layer, a);
     a.x_in = x_in;
-    a.pj_out = ws + (cur ? c->o_pj1 : c->o_pj0);
-    a.gpart_out = ws + c->o_gpart + (cur ? 1024 * 8 : 0);
+    a.pj_out = ws + (cur ? c->o_pj1 : c->o_pj0) + c->slot * c->slot_stride;
+    a.gpart_out = ws + c->o_gpart + c->slot * c->slot_stride + (cur ? 1024 * 8 : 0);
     const int nb = sa_blocks(c);
     if (layer == 1) k_sa_pre<15><<<nb, 256, 0, st>>>(a); else k_sa_pre<30><<<nb, 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
@@ -2033,9 +2082,10 @@ int genie_spatial_agg3_fwd(genie_ctx* c, const float* x_in15, const float* pos, 
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;
     if ((rc = sa_launch_pre(c, 1, x_in15, w, 0, st))) return rc;
-    if ((rc = sa_launch_layer(c, 1, x_in15, pos, w + c->o_sa0, w, 0, true, st))) return rc;
-    if ((rc = sa_launch_layer(c, 2, w + c->o_sa0, pos, w + c->o_sa1, w, 1, true, st))) return rc;
-    return sa_launch_layer(c, 3, w + c->o_sa1, pos, out, w, 0, false, st);
+    const size_t so = c->slot * c->slot_stride;
+    if ((rc = sa_launch_layer(c, 1, x_in15, pos, w + c->o_sa0 + so, w, 0, true, st))) return rc;
+    if ((rc = sa_launch_layer(c, 2, w + c->o_sa0 + so, pos, w + c->o_sa1 + so, w, 1, true, st))) return rc;
+    return sa_launch_layer(c, 3, w + c->o_sa1 + so, pos, out, w, 0, false, st);
 }
 
 int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* pos,
@@ -2044,7 +2094,7 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     if (rc) return rc;
     if (!x_spatial_out || !pos) return fail(GENIE_ERR_ARG, "genie_path_fwd: null argument");
     float* w = (float*)ws;
-    float* bip = bip_out ? bip_out : w + c->o_bip;
+    float* bip = bip_out ? bip_out : w + c->o_bip + c->slot * c->slot_stride;
     if ((rc = genie_da_stage1(c, slice, mask, ws, stream))) return rc;
     if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
     return genie_spatial_agg3_fwd(c, bip, pos, x_spatial_out, ws, stream);
@@ -2068,21 +2118,31 @@ RoArgs make_ro_args(const genie_ctx* c) {
     return a;
 }
 constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;
-constexpr int RO_NG0 = 24, RO_NG1 = 12;   // node groups (of 32 lanes) per workgroup: 1024 / 512 threads share one weight image
-constexpr size_t RO_LDS0 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 30 * 32 + RO_NG0 * RO_SCR);
-constexpr size_t RO_LDS1 = sizeof(float) * (30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32 + RO_TMAX * 96 + 3 * 96 * 3 + 15 * 32 + RO_NG1 * (RO_SCR + RO_K * 96));
+// node groups (of 32 lanes) per workgroup. "fat": many groups share one weight image (best standalone latency);
+// "slim": <= 52 KB of LDS so that a read-out workgroup co-resides with two k_stage1_fast workgroups (2 x 54 KB) when the
+// G-sized tail of window i runs on a side stream under the P-sized kernels of window i+1 (genie_set_tail_mode).
+constexpr int RO_NG0 = 24, RO_NG1 = 16, RO_NG0_SLIM = 4, RO_NG1_SLIM = 2;
+constexpr size_t ro_lds(int mode, int ng) {
+    return sizeof(float) * ((mode == 0 ? RO_IMG0 : RO_IMG1) + RO_TMAX * 96 + ng * (RO_SCR + (mode == 1 ? RO_K * 80 : 0)));
+}
 }  // namespace
 
 int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
     if (!c || !x_spatial || !t_query || !y_out) return fail(GENIE_ERR_ARG, "genie_readout_grid: null argument");
-    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 16 required");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 10 required");
     RoArgs a = make_ro_args(c);
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
     a.img = c->ro_img;
-    const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS0));
-    k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, RO_LDS0, (hipStream_t)stream>>>(a);
+    if (c->tail_slim) {
+        const int nb = std::min((a.N + RO_NG0_SLIM - 1) / RO_NG0_SLIM, c->num_cu);
+        k_readout<0, RO_NG0_SLIM><<<nb, RO_NG0_SLIM * 32, ro_lds(0, RO_NG0_SLIM), (hipStream_t)stream>>>(a);
+    } else {
+        const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ro_lds(0, RO_NG0)));
+        k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), (hipStream_t)stream>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -2093,20 +2153,26 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     if (!c || !x_spatial || !x_grid || !x_query || !knn || !t_query || !x_out)
         return fail(GENIE_ERR_ARG, "genie_readout_query: null argument");
     if (k != RO_K) return fail(GENIE_ERR_ARG, "genie_readout_query: k must be 10 (module.py:280)");
-    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_query: 1 <= n_t <= 16 required");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_query: 1 <= n_t <= 10 required");
     if (n_query < 1) return fail(GENIE_ERR_ARG, "genie_readout_query: n_query < 1");
     RoArgs a = make_ro_args(c);
     a.N = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
     a.t_query = t_query; a.out = x_out;
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.img = c->ro_img + RO_IMG0;
-    float* cvbuf = (float*)ws + c->o_cv;
+    float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
     k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, (hipStream_t)stream>>>(
         x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf);
-    const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RO_LDS1));
-    k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, RO_LDS1, (hipStream_t)stream>>>(a);
+    if (c->tail_slim) {
+        const int nb = std::min((a.N + RO_NG1_SLIM - 1) / RO_NG1_SLIM, c->num_cu);
+        k_readout<1, RO_NG1_SLIM><<<nb, RO_NG1_SLIM * 32, ro_lds(1, RO_NG1_SLIM), (hipStream_t)stream>>>(a);
+    } else {
+        const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ro_lds(1, RO_NG1)));
+        k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), (hipStream_t)stream>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -192,6 +192,52 @@ class HipPath(object):
                                            _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
         return out, x_latent, bip
 
+    # ---- two-stream window pipeline ----------------------------------------------------------------
+    def forward_pipelined(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query):
+        """One forward_fixed_source window with the G-sized tail (Bipartite read-out, SpatialAggregation x3, read-out
+        heads: short latency-bound kernels) on a SIDE stream, so that it overlaps the NEXT window's stage 1 / stage 2
+        (MFMA- / HBM-bound) issued on the current stream. Returns (y, x, done_event); y / x are produced on
+        `self.side_stream` — consume them there or wait for `done_event`."""
+        P = self.n_prod
+        Slice = _f32(Slice, "Slice", (P, 4))
+        Mask = _f32(Mask, "Mask", (P, 4))
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        pos = _f32(pos, "pos", (self.n_grid, 3))
+        if getattr(self, "side_stream", None) is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+            self._slot = 0
+            self._ev_done = [None, None]
+        main = torch.cuda.current_stream(self.device)
+        slot = self._slot
+        self._slot ^= 1
+        if self._ev_done[slot] is not None:
+            main.wait_event(self._ev_done[slot])          # the tail that last used this slot's scratch has finished
+        _lib.check(self.lib.genie_set_slot(self.ctx, slot), "genie_set_slot")
+        st = ctypes.c_void_p(main.cuda_stream)
+        _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, st), "genie_da_stage1")
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.side_stream):
+            bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
+            x_spatial = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        # stage 2 writes the per-tile partials of `slot` and needs bip only in the tail: split = stage-2 kernel on main,
+        # read-out of the partials on the side stream
+        _lib.check(self.lib.genie_da_stage2_partials(self.ctx, _ptr(Mask), _ptr(edge_attr), None, self._ws_ptr, st),
+                   "genie_da_stage2_partials")
+        ev.record(main)
+        self.side_stream.wait_event(ev)
+        with torch.cuda.stream(self.side_stream):
+            ss = ctypes.c_void_p(self.side_stream.cuda_stream)
+            _lib.check(self.lib.genie_bipartite_readout(self.ctx, _ptr(bip), self._ws_ptr, ss), "genie_bipartite_readout")
+            _lib.check(self.lib.genie_spatial_agg3_fwd(self.ctx, _ptr(bip), _ptr(pos), _ptr(x_spatial), self._ws_ptr, ss),
+                       "genie_spatial_agg3_fwd")
+            y = self.readout_grid(x_spatial, t_query)
+            x = self.readout_query(x_spatial, pos, x_query, knn_idx, t_query)
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+        self._ev_done[slot] = done
+        _lib.check(self.lib.genie_set_slot(self.ctx, self._slot), "genie_set_slot")
+        return y, x, done
+
     def readout_grid(self, x_spatial, t_query):
         """y[n_grid, T, 1] = TemporalAttention(SpatialDirect(x_spatial), t_query) (module.py:1015-1016)."""
         x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))

@@ -351,6 +351,18 @@ class GCN_Detection_Network_extended(nn.Module):
         x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)   # :1017-1018
         return y, x
 
+    def forward_fixed_source_pipelined(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
+                                       x_query_cart, t_query):
+        """Throughput variant of `forward_fixed_source` for loops over independent windows (the apply loop,
+        process_continuous_days.py:761-810): same arithmetic and results, but the G-sized tail of the window runs on
+        `self._hip.side_stream` so it overlaps the next window's P-sized kernels. Returns (y, x, done_event): consume
+        y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
+        self._hip.sync_weights(self._path_params)
+        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+        return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
+
     def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
                       x_query_src_cart, t_query, tq_sample, trv_out_q):
         raise NotImplementedError("forward_fixed (module.py:963) needs the association heads (SURVEY.md 8f-2); "

@@ -62,6 +62,13 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
                      const int32_t* src_rowptr, const int32_t* src_col,
                      const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
+/* The G-sized scratch buffers of the workspace (Bipartite partials, SpatialAggregation / read-out scratch) exist twice;
+ * `slot` (0/1) selects the copy used by the calls issued next. With two HIP streams a caller can overlap window i+1's
+ * stage 1/2 with window i's G-sized tail: stage 2 + tail of one window must use the same slot. Default 0. */
+int genie_set_slot(genie_ctx* ctx, int slot);
+/* slim != 0: launch the read-out kernels in their small-LDS shape (<= 52 KB, one workgroup per CU) so they co-reside
+ * with the stage-1 workgroups of the next window on another stream; 0 (default): large workgroups, lowest latency. */
+int genie_set_tail_mode(genie_ctx* ctx, int slim);
 /* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
 int genie_set_scale_t(genie_ctx* ctx, float scale_t);
 
@@ -116,6 +123,11 @@ int genie_ws_v_pitch(const genie_ctx* ctx);
  */
 int genie_da_stage2_bipartite(genie_ctx* ctx, const float* mask, const float* edge_attr,
                               float* x_latent_out, float* bip_out, void* ws, void* stream);
+/* The two halves of genie_da_stage2_bipartite as separate calls (so they can sit on different streams):
+ * per-tile station-sum partials (the P-sized kernel), then r_g = sum of partials and out_g = PReLU_b2(fc2 r_g). */
+int genie_da_stage2_partials(genie_ctx* ctx, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
+                             void* stream);
+int genie_bipartite_readout(genie_ctx* ctx, float* bip_out, void* ws, void* stream);
 /*
  * SpatialAggregation (module.py:243-249; instances :889-891) on the source graph of this context.
  * Requires an UNSHARDED source graph (n_grid_ext == n_grid): when the product graph is sharded over source
@@ -147,7 +159,7 @@ int genie_path_fwd(genie_ctx* ctx, const float* slice, const float* mask, const 
  *                        module.py:262-297; `knn` [n_query, 10] int32 = indices of the 10 nearest grid nodes of every
  *                        query (the `knn(x_context/1000, x_query/1000, k=10)` of module.py:282, computed by the caller
  *                        once per query set); softmax is over those 10 edges per head, aggregation 'add', mean over heads.
- *   x_spatial [n_grid,30]; x_grid [n_grid,3], x_query [n_query,3] in metres; t_query [n_t] seconds, n_t <= 16.
+ *   x_spatial [n_grid,30]; x_grid [n_grid,3], x_query [n_query,3] in metres; t_query [n_t] seconds, n_t <= 10.
  */
 int genie_readout_grid(genie_ctx* ctx, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream);
 int genie_readout_query(genie_ctx* ctx, const float* x_spatial, const float* x_grid, const float* x_query,

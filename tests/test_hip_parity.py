@@ -420,3 +420,26 @@ def test_device_apply_loop_matches_oracle():
         ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)
         want[:, ip[:-1]] += x[:, :-1, 0] / 2.0
     assert max_abs(Out_2.cpu(), want) <= 1e-5
+
+
+def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
+    """Two-stream window pipeline (G-sized tail of window i overlaps stage 1/2 of window i+1, double-buffered scratch):
+    every window's (y, x) must be bit-identical to the single-stream forward_fixed_source."""
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    rng = np.random.default_rng(3)
+    wins = []
+    for k in range(6):
+        S_ = torch.from_numpy(rng.random((c.S * c.G, 4)).astype(np.float32)) * (torch.rand(c.S * c.G, 1) < 0.3)
+        wins.append((S_.to(DEV), (S_ > 0.01).float().to(DEV)))
+    fixed = (None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    with torch.no_grad():
+        plain = [net.forward_fixed_source(s_, m_, *fixed) for s_, m_ in wins]
+        torch.cuda.synchronize()
+        piped = [net.forward_fixed_source_pipelined(s_, m_, *fixed) for s_, m_ in wins]
+        torch.cuda.synchronize()
+    for (y0, x0), (y1, x1, ev) in zip(plain, piped):
+        assert torch.equal(y0, y1) and torch.equal(x0, x1)
