@@ -1645,9 +1645,11 @@ struct genie_ctx {
     int seg, bpc1, bpc1f, bpc2, bpc2f;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
+    int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
     // workspace offsets (floats)
     size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist twice; `slot` selects the copy
+    size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
     int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
     int slot;                  // lets window i+1's stage 1/2 overlap window i's G-sized kernels on another stream
 };
@@ -1662,6 +1664,8 @@ void layout_ws(genie_ctx* c) {
     c->o_c = take((size_t)c->P * ROWC);
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
+    c->big_stride = o;
+    o += c->big_stride;        // second copy (slot 1): stage 1 of window i+1 may run while stage 2 of window i reads
     const size_t small0 = o;
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
@@ -1723,7 +1727,9 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
-    a.c = ws + c->o_c; a.wu = ws + c->o_wu; a.wv = ws + c->o_wv; a.part = ws + c->o_part + c->slot * c->slot_stride;
+    const size_t bo = c->slot * c->big_stride;
+    a.c = ws + c->o_c + bo; a.wu = ws + c->o_wu + bo; a.wv = ws + c->o_wv + bo;
+    a.part = ws + c->o_part + c->slot * c->slot_stride;
     return a;
 }
 
@@ -1862,6 +1868,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         int occ2f = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
+        c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
         c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
         c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
@@ -1968,7 +1975,9 @@ int genie_da_stage1_debug(genie_ctx* c, const float* slice, const float* mask, f
     return run_stage1(c, slice, mask, h0_out, h1_out, ws, stream);
 }
 
-float* genie_ws_v_ptr(const genie_ctx* c, void* ws) { return (c && ws) ? (float*)ws + c->o_wv : nullptr; }
+float* genie_ws_v_ptr(const genie_ctx* c, void* ws) {
+    return (c && ws) ? (float*)ws + c->o_wv + c->slot * c->big_stride : nullptr;
+}
 int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
 int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
@@ -1980,7 +1989,7 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
-    if (c->use_fast)
+    if (c->use_fast && !c->nofast2)
         k_stage2_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc2f), 256, 0, st>>>(a);
     else
         k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
@@ -2223,9 +2232,9 @@ int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream)
     float* w = (float*)ws;
     const float* src; long long rows; int pitch, ncol;
     switch (which) {
-        case 0: src = w + c->o_c; rows = c->P; pitch = ROWC; ncol = 30; break;
-        case 1: src = w + c->o_wu; rows = c->P; pitch = ROWW; ncol = 15; break;
-        case 2: src = w + c->o_wv; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 0: src = w + c->o_c + c->slot * c->big_stride; rows = c->P; pitch = ROWC; ncol = 30; break;
+        case 1: src = w + c->o_wu + c->slot * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 2: src = w + c->o_wv + c->slot * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
         default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..2");
     }
     const long long n = rows * ncol;

@@ -194,10 +194,14 @@ class HipPath(object):
 
     # ---- two-stream window pipeline ----------------------------------------------------------------
     def forward_pipelined(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query):
-        """One forward_fixed_source window with the G-sized tail (Bipartite read-out, SpatialAggregation x3, read-out
-        heads: short latency-bound kernels) on a SIDE stream, so that it overlaps the NEXT window's stage 1 / stage 2
-        (MFMA- / HBM-bound) issued on the current stream. Returns (y, x, done_event); y / x are produced on
-        `self.side_stream` — consume them there or wait for `done_event`."""
+        """One forward_fixed_source window as a two-stream pipeline over independent windows: the P-sized kernels (stage 1,
+        fp32-MFMA bound; stage 2, HBM bound) on the current stream, the G-sized tail (Bipartite read-out,
+        SpatialAggregation x3, read-out heads: short latency-bound kernels) on `self.side_stream`, where it overlaps the
+        NEXT window's stage 1 (whose single 512-thread workgroup per CU leaves LDS and wave slots free). Every buffer
+        that crosses the stream boundary is double-buffered (`genie_set_slot`). Results are bit-identical to `path_fwd` +
+        read-outs. Returns (y, x, done_event); y / x are produced on `self.side_stream` — consume them there or wait for
+        `done_event`. (Measured alternative, rejected: also moving stage 2 to its own stream so that it overlaps the
+        next stage 1 — the two P-sized kernels slow each other down more than the overlap gains)"""
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -206,27 +210,24 @@ class HipPath(object):
         if getattr(self, "side_stream", None) is None:
             self.side_stream = torch.cuda.Stream(device=self.device)
             self._slot = 0
-            self._ev_done = [None, None]
+            self._ev_tail = [None, None]
         main = torch.cuda.current_stream(self.device)
         slot = self._slot
         self._slot ^= 1
-        if self._ev_done[slot] is not None:
-            main.wait_event(self._ev_done[slot])          # the tail that last used this slot's scratch has finished
         _lib.check(self.lib.genie_set_slot(self.ctx, slot), "genie_set_slot")
+        if self._ev_tail[slot] is not None:
+            main.wait_event(self._ev_tail[slot])          # the tail that last used this slot's scratch has finished
         st = ctypes.c_void_p(main.cuda_stream)
         _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, st), "genie_da_stage1")
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(self.side_stream):
-            bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
-            x_spatial = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
-        # stage 2 writes the per-tile partials of `slot` and needs bip only in the tail: split = stage-2 kernel on main,
-        # read-out of the partials on the side stream
         _lib.check(self.lib.genie_da_stage2_partials(self.ctx, _ptr(Mask), _ptr(edge_attr), None, self._ws_ptr, st),
                    "genie_da_stage2_partials")
+        ev = torch.cuda.Event()
         ev.record(main)
         self.side_stream.wait_event(ev)
         with torch.cuda.stream(self.side_stream):
             ss = ctypes.c_void_p(self.side_stream.cuda_stream)
+            bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
+            x_spatial = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
             _lib.check(self.lib.genie_bipartite_readout(self.ctx, _ptr(bip), self._ws_ptr, ss), "genie_bipartite_readout")
             _lib.check(self.lib.genie_spatial_agg3_fwd(self.ctx, _ptr(bip), _ptr(pos), _ptr(x_spatial), self._ws_ptr, ss),
                        "genie_spatial_agg3_fwd")
@@ -234,8 +235,8 @@ class HipPath(object):
             x = self.readout_query(x_spatial, pos, x_query, knn_idx, t_query)
             done = torch.cuda.Event()
             done.record(self.side_stream)
-        self._ev_done[slot] = done
-        _lib.check(self.lib.genie_set_slot(self.ctx, self._slot), "genie_set_slot")
+        self._ev_tail[slot] = done
+        _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
         return y, x, done
 
     def readout_grid(self, x_spatial, t_query):
