@@ -199,17 +199,28 @@ class TemporalAttention(nn.Module):
         return self.proj_2(self.activate5(self.proj_1(self.activate4(z))))
 
 
-class _ParamsOnly(nn.Module):
-    """Association-head parameter containers (not on the hot path): keep the reference's
-    state_dict keys so checkpoints load strictly; `forward` is not provided yet."""
-
-    def forward(self, *a, **k):
-        raise NotImplementedError(
-            "%s: association heads (module.py:333-775) are outside the accelerated path in this round; "
-            "use forward_fixed_source for (y, x)" % type(self).__name__)
+def _mean_over_sta(x, sta_nbr, n_sta, n_grid):
+    """mean over the station neighbours inside the same source node; x [P,C], sta_nbr Long [S,ks]."""
+    if sta_nbr.shape[1] == 0:
+        return torch.zeros_like(x)
+    return x.view(n_grid, n_sta, -1)[:, sta_nbr, :].mean(dim=2).reshape(n_grid * n_sta, -1)
 
 
-class BipartiteGraphReadOutOperator(_ParamsOnly):
+def _mean_over_src(x, src_nbr, n_sta, n_grid):
+    """mean over the source-node neighbours for the same station; x [P,C], src_nbr Long [G,kp] (summed in edge order)."""
+    if src_nbr.shape[1] == 0:
+        return torch.zeros_like(x)
+    x3 = x.view(n_grid, n_sta, -1)
+    out = torch.zeros_like(x3)
+    for k in range(src_nbr.shape[1]):
+        out += x3[src_nbr[:, k]]
+    return (out / src_nbr.shape[1]).reshape(n_grid * n_sta, -1)
+
+
+class BipartiteGraphReadOutOperator(nn.Module):
+    """Association head, module.py:333-352 (PyTorch-ROCm restatement; not part of the HIP hot path).
+    `A_Lg_in_src.edge_index = [g(p); p]`: one edge per product node, so the 'add' aggregation is the identity."""
+
     def __init__(self, ndim_in, ndim_out, ndim_edges=3):
         super().__init__()
         self.fc1 = nn.Linear(ndim_in + ndim_edges, ndim_in)
@@ -217,8 +228,16 @@ class BipartiteGraphReadOutOperator(_ParamsOnly):
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
+    def forward(self, inpt, edge_attr, mask, n_sta):
+        g = torch.arange(edge_attr.shape[0], device=edge_attr.device) // n_sta
+        msg = mask[g] * self.activate1(self.fc1(torch.cat((inpt[g], edge_attr), dim=-1)))            # :352
+        return self.activate2(self.fc2(msg)), mask[g]                                                # :348
 
-class DataAggregationAssociationPhase(_ParamsOnly):
+
+class DataAggregationAssociationPhase(nn.Module):
+    """Association head, module.py:356-403: the dual-graph aggregation of DataAggregation on a 50-channel input, with
+    l1_t1_1 / l1_t2_1 applied (module.py:395-396). Structured form on the Cartesian product (base kNN tables)."""
+
     def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5):
         super().__init__()
         self.activate = nn.PReLU()
@@ -238,18 +257,62 @@ class DataAggregationAssociationPhase(_ParamsOnly):
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
+    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid):
+        mask = torch.cat((mask1, mask2), dim=-1)
+        tr = self.activate(self.init_trns(torch.cat((tr, latent, mask), dim=-1)))
+        a1 = _mean_over_sta(self.activate11(self.l1_t1_1(tr)), sta_nbr, n_sta, n_grid)
+        a2 = _mean_over_src(self.activate12(self.l1_t2_1(tr)), src_nbr, n_sta, n_grid)
+        tr = self.activate1(torch.cat((self.l1_t1_2(torch.cat((tr, a1, mask), dim=1)),
+                                       self.l1_t2_2(torch.cat((tr, a2, mask), dim=1))), dim=1))
+        b1 = _mean_over_sta(self.activate21(self.l2_t1_1(tr)), sta_nbr, n_sta, n_grid)
+        b2 = _mean_over_src(self.activate22(self.l2_t2_1(tr)), src_nbr, n_sta, n_grid)
+        return self.activate2(torch.cat((self.l2_t1_2(torch.cat((tr, b1, mask), dim=1)),
+                                         self.l2_t2_2(torch.cat((tr, b2, mask), dim=1))), dim=1))
 
-class LocalSliceLgCollapse(_ParamsOnly):
-    def __init__(self, ndim_in, ndim_out, n_edge=2, n_hidden=30):
+
+def _segment_softmax(src, index, n):
+    """torch_geometric.utils.softmax semantics: per-segment max subtraction, exp, / (sum + 1e-16)."""
+    idx = index.view(-1, 1).expand_as(src)
+    mx = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype, device=src.device).scatter_reduce(
+        0, idx, src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    den = torch.zeros((n, src.shape[1]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
+    return out / (den[index] + 1e-16)
+
+
+class LocalSliceLgCollapse(nn.Module):
+    """Association head, module.py:610-659: per pick, the k = 10 product nodes of its station whose theoretical arrival is
+    nearest the pick time (time-pointer table `A_edges`), edge MLP, mean."""
+
+    def __init__(self, ndim_in, ndim_out, n_edge=2, n_hidden=30, eps=EPS):
         super().__init__()
         self.fc1 = nn.Linear(ndim_in + n_edge, n_hidden)
         self.fc2 = nn.Linear(n_hidden, ndim_out)
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
+        self.eps = eps
+
+    def forward(self, A_edges, dt_partition, tpick, ipick, phase_label, inpt, tlatent, k_infer=10):
+        dev = inpt.device
+        n_arvs, l_dt = len(tpick), len(dt_partition)
+        dt = dt_partition[1] - dt_partition[0]
+        t_index = torch.floor((tpick - dt_partition[0]) / dt).long()                                           # :635
+        t_index = ((ipick * l_dt * k_infer + t_index * k_infer).view(-1, 1) + torch.arange(k_infer, device=dev).view(1, -1)).reshape(-1)
+        e1 = torch.arange(n_arvs, device=dev).view(-1, 1).repeat(1, k_infer).view(-1)                         # :638
+        e0 = A_edges[t_index].long()
+        keep = torch.where((tpick[e1] - tlatent[e0, 0]).abs() < 2.0 * self.eps)[0]                             # :642-645
+        e0, e1 = e0[keep], e1[keep]
+        msg = self.activate1(self.fc1(torch.cat((inpt[e0], (tpick.view(-1, 1)[e1] - tlatent[e0]) / self.eps, phase_label[e1]), dim=-1)))
+        agg = torch.zeros((n_arvs, msg.shape[1]), dtype=msg.dtype, device=dev).index_add_(0, e1, msg)
+        cnt = torch.zeros(n_arvs, dtype=msg.dtype, device=dev).index_add_(0, e1, torch.ones_like(e1, dtype=msg.dtype))
+        return self.activate2(self.fc2(agg / cnt.clamp(min=1).view(-1, 1)))                                    # 'mean' :612
 
 
-class StationSourceAttentionMergedPhases(_ParamsOnly):
-    def __init__(self, ndim_src_in, ndim_arv_in, ndim_out, n_latent, ndim_extra=1, n_heads=5, n_hidden=30):
+class StationSourceAttentionMergedPhases(nn.Module):
+    """Association head, module.py:662-775 (use_sparse = True, use_neighbor_assoc_edges = False). The pick x pick edge
+    list per station is built on the host exactly as the reference does (module.py:703-718)."""
+
+    def __init__(self, ndim_src_in, ndim_arv_in, ndim_out, n_latent, ndim_extra=1, n_heads=5, n_hidden=30, eps=EPS):
         super().__init__()
         self.f_arrival_query_1 = nn.Linear(2 * ndim_arv_in + 6, n_hidden)
         self.f_arrival_query_2 = nn.Linear(n_hidden, n_heads * n_latent)
@@ -263,6 +326,46 @@ class StationSourceAttentionMergedPhases(_ParamsOnly):
         self.activate2 = nn.PReLU()
         self.activate3 = nn.PReLU()
         self.activate4 = nn.PReLU()
+        self.n_heads, self.n_latent, self.eps = n_heads, n_latent, eps
+
+    def forward(self, n_src, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label):
+        dev, dt_ = tpick.device, tpick.dtype
+        n_sta, n_arv, H, L, eps = trv_src.shape[1], len(tpick), self.n_heads, self.n_latent, self.eps
+        ip = ipick.detach().cpu().numpy()
+        lists = [np.where(ip == u)[0] for u in np.unique(ip)]
+        pairs = [np.stack(np.meshgrid(l, np.concatenate((l, [n_arv])), indexing="ij"), 0).reshape(2, -1) for l in lists]   # (a; b), a-major
+        edges = torch.from_numpy(np.ascontiguousarray(np.hstack(pairs)[::-1])).long().to(dev)                   # rows (b; a)  :713
+        n_edge = edges.shape[1]
+        edges = edges.repeat(1, n_src) + torch.cat((torch.zeros(1, n_src * n_edge, dtype=torch.long, device=dev),
+                                                    (torch.arange(n_src, device=dev) * n_arv).repeat_interleave(n_edge).view(1, -1)), 0)
+        sidx = torch.arange(n_src, device=dev).repeat_interleave(n_edge)
+        arrival = torch.cat((torch.cat((arrival_p, arrival_p.new_zeros(1, arrival_p.shape[1])), 0),
+                             torch.cat((arrival_s, arrival_s.new_zeros(1, arrival_s.shape[1])), 0)), dim=1)
+        atime = torch.cat((tpick, tpick.new_full((1,), -eps)))
+        stindex = torch.cat((ipick, ipick.new_full((1,), n_sta)))
+        tsrc_p = torch.cat((trv_src[:, :, 0], trv_src.new_full((n_src, 1), -eps)), dim=1)
+        tsrc_s = torch.cat((trv_src[:, :, 1], trv_src.new_full((n_src, 1), -eps)), dim=1)
+        phase = torch.cat((phase_label, phase_label.new_full((1, 1), -1.0)), dim=0)
+
+        def rel(e0, si, tsrc):
+            return atime[e0] - (tsrc[si, stindex[e0]] + stime[si])
+        keep = torch.where((rel(edges[0], sidx, tsrc_p).abs() < 2.0 * eps) | (rel(edges[0], sidx, tsrc_s).abs() < 2.0 * eps))[0]
+        edges, sidx = edges[:, keep], sidx[keep]
+        e0, e1 = edges[0], edges[1]
+        e0max = int(e0.max().item())                                                                            # :762-763
+        rp, rs = rel(e0, sidx, tsrc_p).view(-1, 1), rel(e0, sidx, tsrc_s).view(-1, 1)
+        fp = torch.cat((torch.exp(-0.5 * rp ** 2 / eps ** 2), torch.sign(rp), phase[e0]), dim=1)
+        fs = torch.cat((torch.exp(-0.5 * rs ** 2 / eps ** 2), torch.sign(rs), phase[e0]), dim=1)
+        self_link = (e0 == torch.remainder(e1, e0max)).view(-1, 1).to(dt_)
+        null_link = (e0 == e0max).view(-1, 1).to(dt_)
+        x_j = arrival[e0]
+        ctx = self.f_src_context_2(self.activate1(self.f_src_context_1(
+            torch.cat((src_embed[sidx], stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
+        qry = self.f_arrival_query_2(self.activate2(self.f_arrival_query_1(torch.cat((x_j, fp, fs), dim=1)))).view(-1, H, L)
+        val = self.f_values_2(self.activate3(self.f_values_1(torch.cat((x_j, fp, fs, self_link, null_link), dim=1)))).view(-1, H, L)
+        alpha = _segment_softmax((qry * ctx).sum(-1) / math.sqrt(L), e1, n_arv * n_src)
+        agg = torch.zeros((n_arv * n_src, H, L), dtype=dt_, device=dev).index_add_(0, e1, alpha.unsqueeze(-1) * val)
+        return self.proj_2(self.activate4(self.proj_1(agg.mean(1)))).view(n_src, n_arv, -1)
 
 
 class GCN_Detection_Network_extended(nn.Module):
@@ -325,6 +428,8 @@ class GCN_Detection_Network_extended(nn.Module):
             raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
+        dev = self._edge_attr.device
+        self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
 
     def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src):
         """Same effect as `set_adjacencies` from the BASE graphs only (process_utils.py:718-719), for sizes
@@ -365,11 +470,42 @@ class GCN_Detection_Network_extended(nn.Module):
 
     def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
                       x_query_src_cart, t_query, tq_sample, trv_out_q):
-        raise NotImplementedError("forward_fixed (module.py:963) needs the association heads (SURVEY.md 8f-2); "
-                                  "this round accelerates forward_fixed_source")
+        """module.py:963-997: (y, x, arv_p, arv_s). The shared front (DataAggregation -> Bipartite_ReadIn ->
+        SpatialAggregation1..3 and the two read-outs) runs in HIP; the association heads (pick-count
+        dependent, host-built edge lists) are a PyTorch-ROCm restatement of module.py:333-775."""
+        S, G = self._hip.n_sta, self._hip.n_grid
+        x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)      # :973-977
+        y_latent = self.SpatialDirect(x_spatial)                                                     # :978
+        y = self._hip.readout_grid(x_spatial, t_query)                                               # :979
+        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+        x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)         # :980,982
+        x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)      # :981
+        mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
+        s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
+        Maskf = _engine._f32(Mask, "Mask")
+        s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G)   # :990
+        tl = self.tlatent
+        arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
+        arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
+        arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
+        return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
+
+    def _spatial_attention_uncached(self, x_spatial, x_query, x_context):
+        cache = self.SpatialAttention._edge_cache
+        self.SpatialAttention._edge_cache = {}
+        out = self.SpatialAttention(x_spatial, x_query, x_context)
+        self.SpatialAttention._edge_cache = cache
+        return out
 
     def forward(self, Slice, Mask, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                 A_edges_s, dt_partition, tlatent, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
                 x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q):
-        raise NotImplementedError("forward (module.py:908) needs the association heads (SURVEY.md 8f-2); "
-                                  "this round accelerates forward_fixed_source")
+        """module.py:908-939: same as `forward_fixed` with the graphs passed per call (the training call convention,
+        train_GENIE_model.py:1786). The HIP context is rebuilt only when the graph tensors change identity."""
+        key = (A_in_sta.data_ptr(), A_in_src.data_ptr(), A_src.data_ptr(), tuple(A_in_sta.shape), tuple(A_in_src.shape))
+        if getattr(self, "_fwd_key", None) != key:
+            self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
+                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart)
+            self._fwd_key = key
+        return self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
+                                  x_query_src_cart, t_query, tq_sample, trv_out_q)

@@ -271,3 +271,117 @@ def forward_fixed_source_structured(w, Slice, Mask, sta_nbr, src_nbr, edge_attr,
 def weights_from_npz(z, dtype=torch.float32, prefix="w/"):
     """Load a weight dict from an npz whose keys are `w/<state_dict name>`."""
     return {k[len(prefix):]: torch.from_numpy(np.asarray(z[k])).to(dtype) for k in z.files if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------------------------
+# f-2  association heads of forward / forward_fixed  (module.py:928-937, :985-995)
+# ----------------------------------------------------------------------------------------------
+EPS = 5.0 * KERNEL_SIG_T     # module.py:41
+
+
+def bipartite_read_out(w, y_latent, edge_attr, mask_src, n_sta, pre="BipartiteGraphReadOutOperator"):
+    """module.py:343-352 with A_Lg_in_src.edge_index = [g(p); p] (one edge per product node, in product order):
+    s_p = PReLU2(fc2(mask[g] * PReLU1(fc1([y_latent[g] || edge_attr[p]])))); second output mask[g(p)]."""
+    P = edge_attr.shape[0]
+    g = torch.arange(P) // n_sta
+    msg = mask_src[g] * act(linear(torch.cat((y_latent[g], edge_attr), dim=-1), w, pre + ".fc1"), w, pre + ".activate1")
+    return act(linear(msg, w, pre + ".fc2"), w, pre + ".activate2"), mask_src[g]
+
+
+def data_aggregation_association(w, s, latent, mask1, mask2, A_in_sta, A_in_src, pre="DataAggregationAssociationPhase"):
+    """module.py:389-403 (unlike DataAggregation, l1_t1_1 / l1_t2_1 ARE applied before the layer-1 activations)."""
+    mask = torch.cat((mask1, mask2), dim=-1)                                                          # :391
+    tr = act(linear(torch.cat((s, latent, mask), dim=-1), w, pre + ".init_trns"), w, pre + ".activate")   # :392-393
+    a1 = propagate_mean(act(linear(tr, w, pre + ".l1_t1_1"), w, pre + ".activate11"), A_in_sta)       # :395
+    a2 = propagate_mean(act(linear(tr, w, pre + ".l1_t2_1"), w, pre + ".activate12"), A_in_src)       # :396
+    tr1 = linear(torch.cat((tr, a1, mask), dim=1), w, pre + ".l1_t1_2")
+    tr2 = linear(torch.cat((tr, a2, mask), dim=1), w, pre + ".l1_t2_2")
+    tr = act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate1")                                     # :397
+    b1 = propagate_mean(act(linear(tr, w, pre + ".l2_t1_1"), w, pre + ".activate21"), A_in_sta)       # :399
+    b2 = propagate_mean(act(linear(tr, w, pre + ".l2_t2_1"), w, pre + ".activate22"), A_in_src)       # :400
+    tr1 = linear(torch.cat((tr, b1, mask), dim=1), w, pre + ".l2_t1_2")
+    tr2 = linear(torch.cat((tr, b2, mask), dim=1), w, pre + ".l2_t2_2")
+    return act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate2")                                   # :401
+
+
+def local_slice_collapse(w, A_edges, dt_partition, tpick, ipick, phase_label, inpt, tlatent, pre, k_infer=10, eps=EPS):
+    """LocalSliceLgCollapse.forward / message (module.py:623-659), aggr 'mean', use_phase_types = True (config.yaml:91)."""
+    n_arvs, l_dt = len(tpick), len(dt_partition)
+    dt = dt_partition[1] - dt_partition[0]
+    t_index = torch.floor((tpick - dt_partition[0]) / dt).long()                                       # :635
+    t_index = ((ipick * l_dt * k_infer + t_index * k_infer).view(-1, 1) + torch.arange(k_infer).view(1, -1)).reshape(-1).long()
+    src_index = torch.arange(n_arvs).view(-1, 1).repeat(1, k_infer).view(-1)                           # :638
+    e0, e1 = A_edges[t_index].long(), src_index                                                        # :640
+    t_rel = tpick[e1] - tlatent[e0, 0]                                                                 # :642
+    keep = torch.where(t_rel.abs() < 2.0 * eps)[0]                                                     # :645
+    e0, e1 = e0[keep], e1[keep]
+    msg = act(linear(torch.cat((inpt[e0], (tpick.view(-1, 1)[e1] - tlatent[e0]) / eps, phase_label[e1]), dim=-1), w, pre + ".fc1"),
+              w, pre + ".activate1")                                                                   # :659
+    agg = scatter_mean(msg, e1, n_arvs)                                                                # 'mean', size=(N, M=n_arvs)
+    return act(linear(agg, w, pre + ".fc2"), w, pre + ".activate2")                                    # :652
+
+
+def station_source_attention(w, n_src, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label,
+                             pre="Arrivals", n_heads=3, n_latent=15, eps=EPS):
+    """StationSourceAttentionMergedPhases.forward / message (module.py:698-775), use_sparse = True,
+    use_neighbor_assoc_edges = False, use_phase_types = True."""
+    import itertools
+    n_sta, n_arv = trv_src.shape[1], len(tpick)
+    H, L = n_heads, n_latent
+    ip = ipick.numpy()
+    lists = [np.where(ip == u)[0] for u in np.unique(ip)]                                              # :703-705 (same stations, sorted)
+    arrival = torch.cat((torch.cat((arrival_p, torch.zeros(1, arrival_p.shape[1])), 0),
+                         torch.cat((arrival_s, torch.zeros(1, arrival_s.shape[1])), 0)), dim=1)        # :709-711
+    pairs = [np.array(list(itertools.product(l, np.concatenate((l, [n_arv]))))).T for l in lists]      # rows (a; b)
+    edges = torch.from_numpy(np.flip(np.hstack(pairs), axis=0).copy()).long()                          # :713 -> rows (b; a)
+    n_edge = edges.shape[1]
+    edges = edges.repeat(1, n_src) + torch.cat((torch.zeros(1, n_src * n_edge, dtype=torch.long),
+                                                (torch.arange(n_src) * n_arv).repeat_interleave(n_edge).view(1, -1)), dim=0)   # :717
+    src_index = torch.arange(n_src).repeat_interleave(n_edge)                                          # :718
+    atime = torch.cat((tpick, torch.tensor([-eps], dtype=tpick.dtype)))
+    stindex = torch.cat((ipick, torch.tensor([n_sta])))
+    tsrc_p = torch.cat((trv_src[:, :, 0], -eps * torch.ones(n_src, 1, dtype=trv_src.dtype)), dim=1)
+    tsrc_s = torch.cat((trv_src[:, :, 1], -eps * torch.ones(n_src, 1, dtype=trv_src.dtype)), dim=1)
+    phase = torch.cat((phase_label, torch.tensor([[-1.0]], dtype=phase_label.dtype)), dim=0)
+    rel_p = atime[edges[0]] - (tsrc_p[src_index, stindex[edges[0]]] + stime[src_index])                # :724
+    rel_s = atime[edges[0]] - (tsrc_s[src_index, stindex[edges[0]]] + stime[src_index])                # :725
+    keep = torch.where((rel_p.abs() < 2.0 * eps) | (rel_s.abs() < 2.0 * eps))[0]                       # :726
+    edges, src_index = edges[:, keep].contiguous(), src_index[keep]
+    e0, e1 = edges[0], edges[1]
+    e0max = int(e0.max().item())
+    rel_p = (atime[e0] - (tsrc_p[src_index, stindex[e0]] + stime[src_index])).view(-1, 1)             # :755
+    rel_s = (atime[e0] - (tsrc_s[src_index, stindex[e0]] + stime[src_index])).view(-1, 1)             # :758
+    t2 = eps ** 2
+    fp = torch.cat((torch.exp(-0.5 * rel_p ** 2 / t2), torch.sign(rel_p), phase[e0]), dim=1)           # :756
+    fs = torch.cat((torch.exp(-0.5 * rel_s ** 2 / t2), torch.sign(rel_s), phase[e0]), dim=1)           # :759
+    self_link = (e0 == torch.remainder(e1, e0max)).view(-1, 1).to(tpick.dtype)                        # :762
+    null_link = (e0 == e0max).view(-1, 1).to(tpick.dtype)                                              # :763
+    x_j = arrival[e0]
+    ctx = linear(act(linear(torch.cat((src_embed[src_index], stime[src_index].view(-1, 1), self_link, null_link), dim=1),
+                            w, pre + ".f_src_context_1"), w, pre + ".activate1"), w, pre + ".f_src_context_2").view(-1, H, L)   # :764
+    qry = linear(act(linear(torch.cat((x_j, fp, fs), dim=1), w, pre + ".f_arrival_query_1"), w, pre + ".activate2"),
+                 w, pre + ".f_arrival_query_2").view(-1, H, L)                                          # :765
+    val = linear(act(linear(torch.cat((x_j, fp, fs, self_link, null_link), dim=1), w, pre + ".f_values_1"), w, pre + ".activate3"),
+                 w, pre + ".f_values_2").view(-1, H, L)                                                 # :766
+    scores = (qry * ctx).sum(-1) / math.sqrt(L)                                                        # :772
+    alpha = segment_softmax(scores, e1, n_arv * n_src)                                                 # :773
+    agg = scatter_sum(alpha.unsqueeze(-1) * val, e1, n_arv * n_src)                                    # 'add', size=(N, M)
+    out = linear(act(linear(agg.mean(1), w, pre + ".proj_1"), w, pre + ".activate4"), w, pre + ".proj_2")   # :745
+    return out.view(n_src, n_arv, -1)                                                                  # :747
+
+
+def forward_fixed(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src, A_edges_p, A_edges_s, dt_partition,
+                  tlatent, tpick, ipick, phase_label, x_grid_cart, x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q,
+                  n_sta):
+    """forward_fixed (module.py:963-997): (y, x, arv_p, arv_s)."""
+    o = forward_fixed_source(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src, x_grid_cart, x_query_cart,
+                             t_query, full=True)
+    x_src = spatial_attention(w, o["sa3"], x_query_src_cart, x_grid_cart)                              # :981
+    mask_out = 1.0 * (o["y"][:, :, 0].max(1, keepdim=True)[0] > 0.01)                                  # :985
+    s, m1 = bipartite_read_out(w, o["y_latent"], edge_attr, mask_out.to(Slice.dtype), n_sta)           # :986
+    s = data_aggregation_association(w, s, o["x_latent"], m1, Mask, A_in_sta, A_in_src)                # :990
+    arv_p = local_slice_collapse(w, A_edges_p, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 0:1], "LocalSliceLgCollapseP")
+    arv_s = local_slice_collapse(w, A_edges_s, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 1:2], "LocalSliceLgCollapseS")
+    arv = station_source_attention(w, x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick,
+                                   phase_label)                                                         # :993
+    return o["y"], o["x"], arv[:, :, 0:1], arv[:, :, 1:2]

@@ -144,11 +144,78 @@ def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "nonzero rows", int((Inpts[0].abs().sum(1) > 0).sum()))
 
 
+def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0):
+    """Golden vector for the 4-output `forward_fixed` (module.py:963-997): source branch + association heads
+    (BipartiteGraphReadOutOperator, DataAggregationAssociationPhase, LocalSliceLgCollapse P/S,
+    StationSourceAttentionMergedPhases), with the time-pointer tables built by the reference's own
+    `utils.assemble_time_pointers_for_stations` (utils.py:602-622, called as at train_GENIE_model.py:1364)."""
+    import torch
+    import utils as ref_utils   # noqa: E402
+    from genie_amd import graph as G
+    S, Gn = geom.n_sta, geom.n_grid
+    A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
+        geom.A_sta_sta, geom.A_src_src, S, Gn)
+    trv = geom.travel_times().astype(np.float32)                                   # [G,S,2]
+    max_t = float(np.ceil(trv.max()))
+    A_edges_p, A_edges_s, dt_partition = ref_utils.assemble_time_pointers_for_stations(trv, k=10, max_t=max_t, dt=3.0 / 5.0, win=6.0)
+    torch.manual_seed(weights_seed)
+    np.random.seed(weights_seed)
+    mz = ref.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+    g = torch.Generator().manual_seed(4321)
+    for n_, p_ in mz.named_parameters():
+        if p_.numel() == 1:
+            p_.data.fill_(float(0.05 + 0.45 * torch.rand(1, generator=g)))
+    sd32 = {k: v.detach().clone().numpy() for k, v in mz.state_dict().items()}
+    mz.eval()
+    Data = sys.modules["torch_geometric"].data.Data
+    spatial_vals = torch.from_numpy(geom.edge_attr())
+    A_src_in_edges = Data(x=spatial_vals, edge_index=A_src_in_prod)
+    A_Lg_in_src = Data(x=spatial_vals, edge_index=A_src_in_prod.flip(0).contiguous())
+    tlatent = torch.from_numpy(trv.reshape(-1, 2))
+    mz.set_adjacencies(A_prod_sta_sta, A_prod_src_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, torch.from_numpy(geom.A_src_src).long(),
+                       torch.from_numpy(A_edges_p).long(), torch.from_numpy(A_edges_s).long(), torch.from_numpy(dt_partition).float(),
+                       tlatent, torch.from_numpy(geom.locs).float(), torch.from_numpy(geom.x_grid).float())
+    rng = np.random.default_rng(77)
+    src_nodes = rng.choice(Gn, n_src, replace=False)
+    x_query_src = geom.x_grid[src_nodes] + rng.normal(0, 500.0, (n_src, 3))
+    tq_sample = rng.uniform(-2.0, 2.0, n_src).astype(np.float32)
+    d = np.linalg.norm(x_query_src[:, None, :] - geom.locs[None, :, :], axis=2)
+    trv_out_q = np.stack([d / syn_VP, d / syn_VS], axis=2).astype(np.float32)    # [n_src, S, 2]
+    # picks inside the embedding range of the time-pointer table (tpick - dt_partition[0] >= 0)
+    keep = (win["tpick"] > dt_partition[0] + 0.5) & (win["tpick"] < dt_partition[-1] - 0.5)
+    tpick, ipick, phase = win["tpick"][keep], win["ipick"][keep], win["phase_label"][keep]
+    with torch.no_grad():
+        out = mz.forward_fixed(torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"]), torch.from_numpy(tpick),
+                               torch.from_numpy(ipick).long(), torch.from_numpy(phase), torch.from_numpy(geom.locs).float(),
+                               torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+                               torch.from_numpy(x_query_src).float(), torch.from_numpy(geom.t_query).float(),
+                               torch.from_numpy(tq_sample), torch.from_numpy(trv_out_q))
+    res = {"w/" + k: v.astype(np.float32) for k, v in sd32.items()}
+    res.update({"y": out[0].numpy(), "x": out[1].numpy(), "arv_p": out[2].numpy(), "arv_s": out[3].numpy(),
+                "n_sta": np.int64(S), "n_grid": np.int64(Gn), "locs": geom.locs, "x_grid": geom.x_grid, "x_query": geom.x_query,
+                "t_query": geom.t_query, "A_sta_sta": geom.A_sta_sta, "A_src_src": geom.A_src_src, "edge_attr": geom.edge_attr(),
+                "Slice": win["Slice"], "Mask": win["Mask"].astype(np.uint8), "tpick": tpick, "ipick": ipick, "phase_label": phase,
+                "x_query_src": x_query_src, "tq_sample": tq_sample, "trv_out_q": trv_out_q, "tlatent": trv.reshape(-1, 2),
+                "A_edges_p": A_edges_p, "A_edges_s": A_edges_s, "dt_partition": dt_partition, "max_t": np.float64(max_t)})
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **res)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "| picks", len(tpick),
+          "arv_p max %.3e arv_s max %.3e" % (np.abs(res["arv_p"]).max(), np.abs(res["arv_s"]).max()))
+
+
+syn_VP, syn_VS = 6000.0, 3400.0
+
+
 def main():
     ref = _import_reference()
     from genie_amd import synthetic as syn
 
     os.makedirs(OUT, exist_ok=True)
+
+    # (v) 4-output forward_fixed with the association heads
+    geom = syn.Geometry(7, 45, L=60e3, n_query=20, seed=81)
+    win = syn.make_window(geom, 90, seed=82)
+    run_assoc_case(ref, "assoc_7x45", geom, win)
 
     # (iv) pick -> Slice/Mask embedding (row f-1): two windows, one late in the day (large absolute times)
     geom = syn.Geometry(14, 60, L=90e3, n_query=5, seed=61)

@@ -1,0 +1,60 @@
+"""CPU: the 4-output forward_fixed (association heads, module.py:963-997) — oracle restatement against the golden
+vector produced by the reference's own forward_fixed (tests/golden/assoc_7x45.npz)."""
+import os
+
+import numpy as np
+import torch
+
+from genie_amd import graph
+from oracle import genie_oracle as O
+from tests.util import GOLDEN_DIR, max_abs
+
+
+def load():
+    z = np.load(os.path.join(GOLDEN_DIR, "assoc_7x45.npz"))
+    w = O.weights_from_npz(z)
+    t = lambda k, dt=torch.float32: torch.from_numpy(np.asarray(z[k])).to(dt)
+    return z, w, t
+
+
+def test_oracle_forward_fixed_matches_reference():
+    z, w, t = load()
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    y, x, arv_p, arv_s = O.forward_fixed(
+        w, t("Slice"), t("Mask"), A_in_sta, A_in_src, t("edge_attr"), A_src_in_prod, t("A_src_src", torch.long),
+        t("A_edges_p", torch.long), t("A_edges_s", torch.long), t("dt_partition"), t("tlatent"), t("tpick"), t("ipick", torch.long),
+        t("phase_label"), t("x_grid"), t("x_query"), t("x_query_src"), t("t_query"), t("tq_sample"), t("trv_out_q"), S)
+    assert max_abs(y, t("y")) <= 1e-6 and max_abs(x, t("x")) <= 1e-6
+    assert arv_p.shape == tuple(z["arv_p"].shape) and arv_s.shape == tuple(z["arv_s"].shape)
+    assert max_abs(arv_p, t("arv_p")) <= 2e-6
+    assert max_abs(arv_s, t("arv_s")) <= 2e-6
+    assert float(t("arv_p").abs().max()) > 1e-2          # non-trivial fixture
+
+
+def test_product_heads_match_reference_given_oracle_front():
+    """The PyTorch association heads shipped in genie_amd/module.py (CPU run), fed with the oracle's front-end
+    intermediates, reproduce the reference's arv_p / arv_s."""
+    from genie_amd import module
+    z, w, t = load()
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    o = O.forward_fixed_source(w, t("Slice"), t("Mask"), A_in_sta, A_in_src, t("edge_attr"), A_src_in_prod,
+                               t("A_src_src", torch.long), t("x_grid"), t("x_query"), t("t_query"), full=True)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+    net.load_state_dict({k: v.clone() for k, v in w.items()}, strict=True)
+    sta_tab = graph.neighbour_table(z["A_sta_sta"], S).long()
+    src_tab = graph.neighbour_table(z["A_src_src"], G).long()
+    with torch.no_grad():
+        x_src = net.SpatialAttention(o["sa3"], t("x_query_src"), t("x_grid"))
+        mask_out = 1.0 * (o["y"][:, :, 0].max(1, keepdim=True)[0] > 0.01)
+        s, m1 = net.BipartiteGraphReadOutOperator(o["y_latent"], t("edge_attr"), mask_out, S)
+        s = net.DataAggregationAssociationPhase(s, o["x_latent"], m1, t("Mask"), sta_tab, src_tab, S, G)
+        tl = t("tlatent")
+        arv_p = net.LocalSliceLgCollapseP(t("A_edges_p", torch.long), t("dt_partition"), t("tpick"), t("ipick", torch.long),
+                                          t("phase_label"), s, tl[:, 0:1])
+        arv_s = net.LocalSliceLgCollapseS(t("A_edges_s", torch.long), t("dt_partition"), t("tpick"), t("ipick", torch.long),
+                                          t("phase_label"), s, tl[:, 1:2])
+        arv = net.Arrivals(4, t("tq_sample"), x_src, t("trv_out_q"), arv_p, arv_s, t("tpick"), t("ipick", torch.long), t("phase_label"))
+    assert max_abs(arv[:, :, 0:1], t("arv_p")) <= 2e-6
+    assert max_abs(arv[:, :, 1:2], t("arv_s")) <= 2e-6

@@ -443,3 +443,35 @@ def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
         torch.cuda.synchronize()
     for (y0, x0), (y1, x1, ev) in zip(plain, piped):
         assert torch.equal(y0, y1) and torch.equal(x0, x1)
+
+
+def test_forward_fixed_and_forward_four_outputs_match_reference():
+    """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) with the HIP front end and the PyTorch-ROCm association heads,
+    against the reference's own forward_fixed golden vector."""
+    import os
+    from tests.util import GOLDEN_DIR
+    from oracle import genie_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "assoc_7x45.npz"))
+    w = O.weights_from_npz(z)
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t = lambda k, dt=torch.float32: torch.from_numpy(np.asarray(z[k])).to(dt).to(DEV)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in w.items()}, strict=True)
+    net.eval()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    ea = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.to(DEV))
+    ea_flip = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.flip(0).contiguous().to(DEV))
+    graphs = (A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea_flip, A_src_in_sta.to(DEV), t("A_src_src", torch.long),
+              t("A_edges_p", torch.long), t("A_edges_s", torch.long), t("dt_partition"), t("tlatent"))
+    tail = (t("tpick"), t("ipick", torch.long), t("phase_label"), t("locs"), t("x_grid"), t("x_query"), t("x_query_src"),
+            t("t_query"), t("tq_sample"), t("trv_out_q"))
+    with torch.no_grad():
+        net.set_adjacencies(*graphs, t("locs"), t("x_grid"))
+        out_fixed = net.forward_fixed(t("Slice"), t("Mask"), *tail)
+        out_full = net(t("Slice"), t("Mask"), *graphs, *tail)
+    for out in (out_fixed, out_full):
+        assert max_abs(out[0].cpu(), torch.from_numpy(z["y"])) <= 1e-5
+        assert max_abs(out[1].cpu(), torch.from_numpy(z["x"])) <= 1e-5
+        assert out[2].shape == tuple(z["arv_p"].shape) and out[3].shape == tuple(z["arv_s"].shape)
+        assert max_abs(out[2].cpu(), torch.from_numpy(z["arv_p"])) <= 1e-5
+        assert max_abs(out[3].cpu(), torch.from_numpy(z["arv_s"])) <= 1e-5
