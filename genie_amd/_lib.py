@@ -67,7 +67,7 @@ def build(verbose=False, extra_flags=(), out_path=None):
     # -fno-honor-nans: no NaN-canonicalisation v_max before every fmaxf/fminf (no reassociation is enabled);
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs + v_accvgpr_read copies
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I", INCLUDE, SRC, "-o", out_path or LIB_PATH] + list(extra_flags)
     if verbose:
         print(" ".join(cmd))

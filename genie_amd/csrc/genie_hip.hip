@@ -218,6 +218,86 @@ void add_bias(StagePlan& p, int vec, int o0, int rows) {
 #define G2_GROUPS 6
 #define G2_BIAS 2
 
+// STAGE 1, bf16x3 form (k_stage1_b3): 1-KB A fragments of v_mfma_f32_32x32x16_bf16, lane (i = lane&31, h = lane>>5) holds
+// 8 bf16 = K slots (h, e = 0..7). Fragment ids: init_trns (3 mixed-piece fragments), then [block][K-step][piece].
+constexpr int B3_FA = 0;        // + m: [W1|W1], [W2|W2], [W1|W3] of init_trns (K = two 8-wide input slices)
+constexpr int B3_FL1 = 3;       // + ((t*4 + ks)*3 + piece): layer 1, half t, K-steps 0,1 = h0 block, 2,3 = mean block
+constexpr int B3_FUVC = 27;     // + ((blk*4 + ks)*3 + piece): blk 0 = u, 1 = v, 2 = c; K-steps over h1 = [half 0 | half 1]
+constexpr int B3_FW = 63;       // + (ks*3 + piece): [wu | wv] rows, K-steps 0,1 = u block, 2,3 = v block
+constexpr int B3_FRAGS = 75;
+constexpr int B3_NBIAS = 6;     // init_trns, l1_t1_2, l1_t2_2, l2_t1_1, l2_t2_1, [l2_t1_2 | l2_t2_2]
+constexpr int B3_IMG_FLOATS = B3_FRAGS * 256 + B3_NBIAS * 32 + 16;
+constexpr int B3_TBL = B3_FRAGS * 512 + B3_NBIAS * 32 + 16;
+
+// table entry: raw-mirror offset | piece << 28, or -1 for zero. Slot (h, e) of K-step kb (0/1) of a 32-channel block is
+// channel 16 kb + 8 (e >> 2) + 4 h + (e & 3): registers 8kb..8kb+7 of the producing accumulator (see k_stage1_b3).
+void build_b3_table(std::vector<int32_t>& tbl) {
+    tbl.assign(B3_TBL, -1);
+    auto put = [&](int f, int i, int h, int e, int piece, int off) {
+        tbl[((size_t)f * 64 + (h * 32 + i)) * 8 + e] = off < 0 ? -1 : (off | (piece << 28));
+    };
+    for (int i = 0; i < 32; ++i)
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) {
+                const int off = i < 30 ? g_params[W_DA_INIT_W].off + i * 8 + e : -1;
+                put(B3_FA + 0, i, h, e, 0, off);
+                put(B3_FA + 1, i, h, e, 1, off);
+                put(B3_FA + 2, i, h, e, h == 0 ? 0 : 2, off);
+            }
+    // src(i, ch): raw offset of the weight multiplying channel ch (0..31) of the K-step's block into output row i
+    auto dense = [&](int f0, int kb, auto src) {
+        for (int i = 0; i < 32; ++i)
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = 16 * kb + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const int off = src(i, ch);
+                    for (int piece = 0; piece < 3; ++piece) put(f0 + piece, i, h, e, piece, off);
+                }
+    };
+    for (int t = 0; t < 2; ++t)
+        for (int ks = 0; ks < 4; ++ks) {
+            const int mat = g_params[t == 0 ? W_DA_L1T12_W : W_DA_L1T22_W].off, blk = ks >> 1;
+            dense(B3_FL1 + (t * 4 + ks) * 3, ks & 1, [&](int i, int ch) {
+                if (i >= 30) return -1;
+                return mat + i * 64 + (ch < 30 ? 30 * blk + ch : 60 + 2 * blk + (ch - 30));   // pads: Mask columns
+            });
+        }
+    for (int b = 0; b < 3; ++b)
+        for (int ks = 0; ks < 4; ++ks) {
+            const int half = ks >> 1;
+            dense(B3_FUVC + (b * 4 + ks) * 3, ks & 1, [&](int i, int ch) {
+                if (b < 2) {
+                    if (i >= 30 || ch >= 30) return -1;
+                    return g_params[b == 0 ? W_DA_L2T11_W : W_DA_L2T21_W].off + i * 60 + 30 * half + ch;
+                }
+                int mat, row;
+                if (i < 15) { mat = g_params[W_DA_L2T12_W].off; row = i; }
+                else if (i >= 16 && i < 31) { mat = g_params[W_DA_L2T22_W].off; row = i - 16; }
+                else return -1;
+                return mat + row * 94 + (ch < 30 ? 30 * half + ch : 90 + 2 * half + (ch - 30));
+            });
+        }
+    for (int ks = 0; ks < 4; ++ks) {
+        const int blk = ks >> 1;
+        dense(B3_FW + ks * 3, ks & 1, [&](int i, int ch) {
+            if (ch >= 30) return -1;
+            if (blk == 0) return i < 15 ? g_params[W_DA_L2T12_W].off + i * 94 + 60 + ch : -1;
+            return (i >= 16 && i < 31) ? g_params[W_DA_L2T22_W].off + (i - 16) * 94 + 60 + ch : -1;
+        });
+    }
+    int32_t* bias = tbl.data() + (size_t)B3_FRAGS * 512;
+    const int bvec[5] = {W_DA_INIT_B, W_DA_L1T12_B, W_DA_L1T22_B, W_DA_L2T11_B, W_DA_L2T21_B};
+    for (int b = 0; b < 5; ++b)
+        for (int i = 0; i < 30; ++i) bias[b * 32 + i] = g_params[bvec[b]].off + i;
+    for (int i = 0; i < 15; ++i) {
+        bias[5 * 32 + i] = g_params[W_DA_L2T12_B].off + i;
+        bias[5 * 32 + 16 + i] = g_params[W_DA_L2T22_B].off + i;
+    }
+    int32_t* scal = bias + B3_NBIAS * 32;
+    const int sv[6] = {W_DA_ACT, W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22};
+    for (int k = 0; k < 6; ++k) scal[k] = g_params[sv[k]].off;
+}
+
 void build_plans(StagePlan& p1, StagePlan& p2) {
     // ---- stage 1
     for (int t = 0; t < 2; ++t) {
@@ -370,6 +450,8 @@ struct DaArgs {
     float* x_latent;           // optional [P,30]
     float* dbg_h0; float* dbg_h1;  // optional parity outputs [P,30] / [P,60]
     const float* packed;       // packed A fragments for the stage
+    const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
+    const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
@@ -520,6 +602,20 @@ __device__ __forceinline__ void gather_sum16(const float* __restrict__ base, lon
 // ------------------------------------------------------------------------------------------------
 // dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
 // projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
+// N independent accumulators x one 16-channel input block, k-step OUTER and accumulator INNER: consecutive MFMAs never
+// target the same accumulator, so the 40-cycle dependent-issue latency of v_mfma_f32_16x16x4_f32 (32-cycle issue) is
+// always covered (hipcc otherwise keeps the 4 dependent k-steps of one accumulator back to back).
+template <int N>
+__device__ __forceinline__ void mma_blocks(f32x4 (&acc)[N], const f32x4 (&w)[N], const f32x4 x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = MFMA16(w[k][r], x[r], acc[k]);
+    }
+}
+
+// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
+// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
 __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, const float* lbias, int lane, int q,
                                              bool valid, long long p, float mq, f32x4 x0, f32x4 x1, f32x4 n1a, f32x4 n1b,
                                              f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
@@ -530,27 +626,39 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
             if (16 + 4 * q + r < 30) a.dbg_h0[p * 30 + 16 + 4 * q + r] = x1[r];
         }
     }
-    // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]
-    f32x4 acc[4];
+    // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]; acc[k]: k = (half, tile)
+    f32x4 acc[4], w4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + (2 + k) * 16 + 4 * q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane], x0);
-    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane];
+    mma_blocks<4>(acc, w4, x0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 1) * 64 + lane], x1);
-    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 1) * 64 + lane];
+    mma_blocks<4>(acc, w4, x1);
+    {   // the neighbour-mean blocks feed only their own half: two accumulators per operand, interleave the two operands
+        f32x4 wa[2], wb[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 2) * 64 + lane], (k >> 1) == 0 ? n1a : n2a);
-    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 na = b == 0 ? n1a : n1b, nb = b == 0 ? n2a : n2b;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = mma_block(acc[k], lw[G1_L1(k >> 1, k & 1, 3) * 64 + lane], (k >> 1) == 0 ? n1b : n2b);
-    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
+            for (int t = 0; t < 2; ++t) {
+                wa[t] = lw[G1_L1(0, t, 2 + b) * 64 + lane];
+                wb[t] = lw[G1_L1(1, t, 2 + b) * 64 + lane];
+            }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
-        acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
+            for (int r = 0; r < 4; ++r) {
+                acc[0] = MFMA16(wa[0][r], na[r], acc[0]);
+                acc[2] = MFMA16(wb[0][r], nb[r], acc[2]);
+                acc[1] = MFMA16(wa[1][r], na[r], acc[1]);
+                acc[3] = MFMA16(wb[1][r], nb[r], acc[3]);
+            }
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
     if (a.dbg_h1 != nullptr && valid) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -558,35 +666,41 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
             for (int r = 0; r < 4; ++r)
                 if (16 * (k & 1) + 4 * q + r < 30) a.dbg_h1[p * 60 + 30 * (k >> 1) + 16 * (k & 1) + 4 * q + r] = acc[k][r];
     }
-    // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1); c_w = node-local layer-2 terms
-    f32x4 uv[4], cc[2];
+    // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1); c_w = node-local layer-2 terms: 6 independent accumulators
+    f32x4 o6[6], w6[6];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) uv[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
-    cc[0] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
-    cc[1] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
+    for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
+    o6[4] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
+    o6[5] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
-        __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) uv[k] = mma_block(uv[k], lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane], acc[hb]);
-        cc[0] = mma_block(cc[0], lw[G1_C(0, hb) * 64 + lane], acc[hb]);
-        cc[1] = mma_block(cc[1], lw[G1_C(1, hb) * 64 + lane], acc[hb]);
+        for (int k = 0; k < 4; ++k) w6[k] = lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane];
+        w6[4] = lw[G1_C(0, hb) * 64 + lane];
+        w6[5] = lw[G1_C(1, hb) * 64 + lane];
+        mma_blocks<6>(o6, w6, acc[hb]);
     }
-    __builtin_amdgcn_sched_barrier(0);  // bound the compiler's LDS-fragment prefetch depth (register pressure)
-    cc[0] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, cc[0]);
-    cc[1] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, cc[1]);
-    uv[0] = prelu4u(uv[0], a21); uv[1] = prelu4u(uv[1], a21);
-    uv[2] = prelu4u(uv[2], a22); uv[3] = prelu4u(uv[3], a22);
-    f32x4 wu = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-    wu = mma_block(wu, lw[G1_W(0, 0) * 64 + lane], uv[0]);
-    wv = mma_block(wv, lw[G1_W(1, 0) * 64 + lane], uv[2]);
-    wu = mma_block(wu, lw[G1_W(0, 1) * 64 + lane], uv[1]);
-    wv = mma_block(wv, lw[G1_W(1, 1) * 64 + lane], uv[3]);
+    o6[4] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, o6[4]);
+    o6[5] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, o6[5]);
+    o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
+    o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
+    // wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v: two accumulators, interleaved
+    f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        w2[0] = lw[G1_W(0, b) * 64 + lane];
+        w2[1] = lw[G1_W(1, b) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wuv[0] = MFMA16(w2[0][r], o6[b][r], wuv[0]);
+            wuv[1] = MFMA16(w2[1][r], o6[2 + b][r], wuv[1]);
+        }
+    }
     if (valid && !ABL(a, 3)) {
-        *(f32x4*)(a.c + p * ROWC + 4 * q) = cc[0];
-        *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = cc[1];
-        *(f32x4*)(a.wu + p * ROWW + 4 * q) = wu;
-        *(f32x4*)(a.wv + p * ROWW + 4 * q) = wv;
+        *(f32x4*)(a.c + p * ROWC + 4 * q) = o6[4];
+        *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = o6[5];
+        *(f32x4*)(a.wu + p * ROWW + 4 * q) = wuv[0];
+        *(f32x4*)(a.wv + p * ROWW + 4 * q) = wuv[1];
     }
 }
 
@@ -674,16 +788,36 @@ __device__ __forceinline__ void nbr_pipe_step(f32x4& h_a, f32x4& h_b, bool has_n
     // (empty asm statements are ordered among themselves and pin the operands they touch: the next neighbour's
     // MFMAs cannot be hoisted above the previous accumulate, so at most two neighbours' results are ever alive;
     // __builtin_amdgcn_sched_barrier alone did not stop hipcc from issuing all 4*(KS+KP) MFMAs up front)
+    // The PReLU + accumulate of the current neighbour is cut into four 2-channel chunks and one chunk is pinned behind
+    // each MFMA, so a single wave keeps the matrix pipe busy (an in-order wave that issues its 4 MFMAs back to back
+    // sits in the issue queue for 3 x 32 cycles and only then starts its ~20 VALU ops: 65 % pipe utilisation).
     f32x4 g_a = h_a, g_b = h_b;
+#define GENIE_CHUNK(S, H, c0, c1)                                                    \
+    {                                                                                \
+        const float t0 = H[c0] * slope, t1 = H[c1] * slope;                          \
+        S[c0] += LE1 ? fmaxf(H[c0], t0) : fminf(H[c0], t0);                          \
+        S[c1] += LE1 ? fmaxf(H[c1], t1) : fminf(H[c1], t1);                          \
+    }
     if (has_next) {
         asm volatile("" : "+v"(xs), "+v"(xm));
         g_a = MFMA16(wi0.x, xs, bi0);
+        GENIE_CHUNK(s0, h_a, 0, 1)
+        asm volatile("" : "+v"(s0), "+v"(xs));
         g_b = MFMA16(wi1.x, xs, bi1);
+        GENIE_CHUNK(s0, h_a, 2, 3)
+        asm volatile("" : "+v"(s0), "+v"(xm));
         g_a = MFMA16(wi0.y, xm, g_a);
+        GENIE_CHUNK(s1, h_b, 0, 1)
+        asm volatile("" : "+v"(s1), "+v"(xm));
         g_b = MFMA16(wi1.y, xm, g_b);
+        GENIE_CHUNK(s1, h_b, 2, 3)
+    } else {
+        GENIE_CHUNK(s0, h_a, 0, 1)
+        GENIE_CHUNK(s0, h_a, 2, 3)
+        GENIE_CHUNK(s1, h_b, 0, 1)
+        GENIE_CHUNK(s1, h_b, 2, 3)
     }
-    s0 += prelu4s<LE1>(h_a, slope);
-    s1 += prelu4s<LE1>(h_b, slope);
+#undef GENIE_CHUNK
     asm volatile("" : "+v"(s0), "+v"(s1));
     h_a = g_a; h_b = g_b;
 }
@@ -837,6 +971,364 @@ __global__ __launch_bounds__(S1F_THREADS) void k_stage1_fast(DaArgs a) {
     } else {
         if (s12 <= 1.f) stage1_fast_loop<KS, KP, false, true>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
         else stage1_fast_loop<KS, KP, false, false>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1 on the bf16 matrix pipe with fp32-exact operands ("bf16x3").
+//
+// Measured on MI355X (tools/mfma_peak*.hip, tools/valu_rate.hip): v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR
+// rate and does NOT overlap with VALU work (time = 32 cyc x MFMAs + ~3.3 cyc x VALU ops), so the fp32-MFMA kernel
+// above is bound by the sum of both. The bf16 matrix pipe is 16x faster. Every fp32 value is split EXACTLY into three
+// bf16 pieces by truncation (8 + 8 + 8 mantissa bits: x = x1 + x2 + x3) and a product keeps the six partial products
+// above 2^-24: W1x1 + W1x2 + W2x1 + W1x3 + W2x2 + W3x1, accumulated in fp32 by the MFMA. Error is that of an fp32 dot
+// product (oracle/genie_oracle.py parity stays ~1e-7; tests/test_hip_parity.py).
+//
+//  * v_mfma_f32_32x32x16_bf16: D[ch, node] for 32 channels x 32 nodes. A wave owns TWO 16-station tiles (lanes
+//    0-15/32-47 and 16-31/48-63). Lane (j = lane&31, h = lane>>5) holds D channels 8*(r>>2) + 4h + (r&3), r = 0..15,
+//    of node j; K-step ks of the next layer consumes registers 8ks..8ks+7 of both lanes of a node (16 channels), so an
+//    accumulator block becomes B operands without any cross-lane movement. All our channel groups are 30 wide: one
+//    32-block each; the two padding slots of a block (channels 30, 31: lane h = 1, registers 14, 15) carry the Mask
+//    inputs of `cat(h, n, Mask)`.
+//  * raw inputs arrive as 48-B rows [x1 | x2 | x3] of 8 bf16 each (x = Slice || Mask), written by k_split_rows. A
+//    neighbour's hidden state is 3 MFMAs: [W1|W1][x1;x2] + [W2|W2][x1;x2] + [W1|W3][x3;x1] (K = 16 = two 8-wide slices).
+//  * sum_k PReLU_s(z_k) = ((1+s)/2) sum z_k + ((1-s)/2) sum |z_k|: two VALU adds per neighbour value.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA32(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+constexpr int XROW = 48;                 // bytes per split input row
+constexpr int B3_THREADS = 512;
+
+__device__ __forceinline__ float bf_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+// bf16 pair (lo in bits 0..15) made of the high halves of two fp32 values (= truncation to bf16)
+__device__ __forceinline__ unsigned pk_hi(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ unsigned bf16_piece(float v, int piece) {
+    const float a = bf_hi(v);
+    if (piece == 0) return __float_as_uint(a) >> 16;
+    const float r = v - a, b = bf_hi(r);
+    if (piece == 1) return __float_as_uint(b) >> 16;
+    return __float_as_uint(r - b) >> 16;
+}
+
+__global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < B3_FRAGS * 64) {
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned u[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int32_t ent = tbl[idx * 8 + 2 * d + k];
+                u[k] = ent < 0 ? 0u : bf16_piece(raw[ent & 0x0fffffff], (ent >> 28) & 3);
+            }
+            o[d] = u[0] | (u[1] << 16);
+        }
+        ((u32x4*)out)[idx] = o;
+    } else if (idx < B3_FRAGS * 64 + B3_NBIAS * 32 + 16) {
+        const int k = idx - B3_FRAGS * 64;
+        const int32_t ent = tbl[B3_FRAGS * 512 + k];
+        out[B3_FRAGS * 256 + k] = ent < 0 ? 0.f : raw[ent];
+    }
+}
+
+// [Slice || Mask] rows (8 fp32) -> 48-B rows of three bf16x8 pieces
+__global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
+                             unsigned* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    const f32x4 s = *(const f32x4*)(slice + p * 4), m = *(const f32x4*)(mask + p * 4);
+    const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece) {
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
+        *(u32x4*)(out + p * (XROW / 4) + piece * 4) = o;
+    }
+}
+
+// registers 8ks..8ks+7 of an accumulator block -> the three bf16x8 pieces of one B operand
+template <int KS_>
+__device__ __forceinline__ void split8(const f32x16& v, u32x4 (&p)[3]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float a = v[8 * KS_ + 2 * d], b = v[8 * KS_ + 2 * d + 1];
+        p[0][d] = pk_hi(a, b);
+        const float ra = a - bf_hi(a), rb = b - bf_hi(b);
+        p[1][d] = pk_hi(ra, rb);
+        p[2][d] = pk_hi(ra - bf_hi(ra), rb - bf_hi(rb));
+    }
+}
+// exact PReLU in two VALU ops for any slope: max(x, s*x) when s <= 1, min(x, s*x) otherwise, as med3(x, s*x, +-inf)
+__device__ __forceinline__ f32x16 prelu16(f32x16 x, float s, float sel) {
+    f32x16 y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = __builtin_amdgcn_fmed3f(x[r], x[r] * s, sel);
+    return y;
+}
+__device__ __forceinline__ f32x16 bias16(const float* lbias, int blk, int h) {
+    f32x16 y;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x4 t = *(const f32x4*)(lbias + blk * 32 + 8 * b + 4 * h);
+        y[4 * b] = t.x; y[4 * b + 1] = t.y; y[4 * b + 2] = t.z; y[4 * b + 3] = t.w;
+    }
+    return y;
+}
+// the six partial products of one K-step for N independent accumulators sharing the B pieces (smallest terms first);
+// consecutive MFMAs go to different accumulators
+template <int N>
+__device__ __forceinline__ void mma6(f32x16 (&acc)[N], const f32x4* lw, const int (&f0)[N], int lane, const u32x4 (&b)[3]) {
+    f32x4 w[N][3];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[k][p] = lw[(f0[k] + p) * 64 + lane];
+    constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, BP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = MFMA32(w[k][WP[t]], b[BP[t]], acc[k]);
+}
+
+template <int KS, int KP>
+__global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
+    constexpr int NF4 = B3_IMG_FLOATS / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += B3_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + B3_FRAGS * 64);
+    const float* lscal = lbias + B3_NBIAS * 32;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    const float inf = __builtin_inff();
+    const float sel0 = a0 <= 1.f ? inf : -inf, sel1 = a1 <= 1.f ? inf : -inf;
+    const float sel21 = a21 <= 1.f ? inf : -inf, sel22 = a22 <= 1.f ? inf : -inf;
+    // mean_k PReLU_s(z_k) = al * sum z_k + be * sum |z_k|
+    const float al1 = (1.f + s11) / (2.f * KS), be1 = (1.f - s11) / (2.f * KS);
+    const float al2 = (1.f + s12) / (2.f * KP), be2 = (1.f - s12) / (2.f * KP);
+
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
+    const bool hi = h != 0;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    const char* xs = (const char*)a.xs;
+    const unsigned la = hi ? 16u : 0u, lb = hi ? 0u : 32u;       // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]
+    const unsigned gstride = (unsigned)S * (unsigned)XROW;
+
+    const f32x4 fa0 = lw[(B3_FA + 0) * 64 + lane], fa1 = lw[(B3_FA + 1) * 64 + lane], fa2 = lw[(B3_FA + 2) * 64 + lane];
+    const f32x16 biasA = bias16(lbias, 0, h);
+
+    // ids of a tile pair: idv = row of src_tab (lane jj = 0: the tile's source node, jj = 1..KP: its source neighbours),
+    // clamped station index, validity, station-neighbour ids. All addresses follow from the item number alone, so the
+    // ids of the NEXT pair are fetched before the dense phase of the current one and no dependent load chain remains.
+    int jt = jj;
+    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, bool& valid_, int (&sta_)[KS]) {
+        int gi0, tb0, gi1, tb1;
+        w.decode(2 * pit_, gi0, tb0);
+        const bool second = 2 * pit_ + 1 < w.nitems;
+        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
+        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
+        const int s = (half ? tb1 : tb0) * 16 + jt;
+        valid_ = s < S && (second || !half);
+        sc_ = s < S ? s : S - 1;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_[k] = a.sta_col[sc_ * KS + k];
+    };
+    int idv = 0, sc = 0, sta_id[KS];
+    bool valid = false;
+    if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, valid, sta_id);
+    for (long long pit = w.it; 2 * pit < w.nitems; pit += w.stride) {
+        asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park all 75 in VGPRs)
+        const bool has_next = 2 * (pit + w.stride) < w.nitems;
+        const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
+        const int g = half ? g1 : g0;
+        const long long p = (long long)g * S + sc;
+        unsigned gbase = (unsigned)g * gstride;                         // byte offset of source node g in xs
+        unsigned sbase = (unsigned)sc * (unsigned)XROW;
+        const int srcv = idv;
+
+        // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
+        constexpr int NU = 1 + KS + KP;
+        static_assert(NU % 2 == 0, "units are processed in pairs");
+        constexpr int DEPTH = 4;
+        u32x4 bufa[NU], bufb[NU];
+        auto issue = [&](int u) {
+            unsigned off;
+            if (u == 0) off = gbase + sbase;
+            else if (u <= KS) off = gbase + __umul24((unsigned)sta_id[u - 1], (unsigned)XROW);
+            else {
+                const int n0 = __builtin_amdgcn_readlane(srcv, u - KS), n1 = __builtin_amdgcn_readlane(srcv, 16 + u - KS);
+                off = __umul24((unsigned)(half ? n1 : n0), gstride) + sbase;
+            }
+            const unsigned oa = off + la, ob = off + lb;      // 32-bit offsets from the uniform base (saddr addressing)
+            bufa[u] = *(const u32x4*)(xs + oa);
+            bufb[u] = *(const u32x4*)(xs + ob);
+        };
+        const u32x4 own3 = *(const u32x4*)(xs + (gbase + sbase + 32u));         // piece 3 of the own row (Mask pads)
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) issue(u);
+
+        f32x16 sz, sa, h0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sz[r] = 0.f; sa[r] = 0.f; }
+        u32x4 h0p[2][3], n1p[2][3], n2p[2][3];
+        unsigned m01[3], m23[3];          // Mask pieces (lanes h = 1): bf16 pairs (M0,M1) and (M2,M3)
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                if (u + DEPTH + d < NU) issue(u + DEPTH + d);
+            // empty asm statements are ordered among themselves: this pair's MFMAs stay behind the previous pair's
+            // accumulate and the loads issued above stay ahead of them (hipcc otherwise issues the MFMAs of many pairs
+            // first and spills their 16-register results)
+            asm volatile("" : "+v"(bufa[u]), "+v"(bufa[u + 1]));
+            f32x16 z0 = MFMA32(fa0, bufa[u], biasA), z1 = MFMA32(fa0, bufa[u + 1], biasA);
+            z0 = MFMA32(fa1, bufa[u], z0);
+            z1 = MFMA32(fa1, bufa[u + 1], z1);
+            z0 = MFMA32(fa2, bufb[u], z0);
+            z1 = MFMA32(fa2, bufb[u + 1], z1);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const f32x16 z = d == 0 ? z0 : z1;
+                const int uu = u + d;
+                if (uu == 0) {
+                    h0 = prelu16(z, a0, sel0);
+                    m01[0] = bufb[0].z; m23[0] = bufb[0].w;      // lane h = 1: bufb = x1, bufa = x2
+                    m01[1] = bufa[0].z; m23[1] = bufa[0].w;
+                    m01[2] = own3.z;    m23[2] = own3.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { sz[r] += z[r]; sa[r] += __builtin_fabsf(z[r]); }
+                }
+                if (uu == KS || uu == NU - 1) {
+                    const float al = uu == KS ? al1 : al2, be = uu == KS ? be1 : be2;
+                    f32x16 n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { n[r] = fmaf(al, sz[r], be * sa[r]); sz[r] = 0.f; sa[r] = 0.f; }
+                    if (uu == KS) { split8<0>(n, n1p[0]); split8<1>(n, n1p[1]); }
+                    else { split8<0>(n, n2p[0]); split8<1>(n, n2p[1]); }
+                }
+            }
+            asm volatile("" : "+v"(sz), "+v"(sa), "+v"(gbase), "+v"(sbase), "+v"(jt));
+        }
+        int idv_n = 0, sc_n = 0, sta_n[KS];
+        bool valid_n = false;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
+        if (has_next) fetch_ids(pit + w.stride, idv_n, sc_n, valid_n, sta_n);
+        if (a.dbg_h0 != nullptr && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < 30) a.dbg_h0[p * 30 + ch] = h0[r];
+            }
+        }
+        split8<0>(h0, h0p[0]);
+        split8<1>(h0, h0p[1]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {     // padding slots (channels 30, 31) carry the Mask: [h0 | M0 M1], [n | M2 M3]
+            h0p[1][q].w = hi ? m01[q] : h0p[1][q].w;
+            n1p[1][q].w = hi ? m23[q] : n1p[1][q].w;
+            n2p[1][q].w = hi ? m23[q] : n2p[1][q].w;
+        }
+        // ---- layer 1: tr_t = l1_t{1,2}_2 [h0 || n_t || Mask], both halves at once
+        f32x16 acc[2] = {bias16(lbias, 1, h), bias16(lbias, 2, h)};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int f0[2] = {B3_FL1 + (0 * 4 + ks) * 3, B3_FL1 + (1 * 4 + ks) * 3};
+            mma6<2>(acc, lw, f0, lane, h0p[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {     // the neighbour-mean blocks differ per half: interleave by hand
+            const int fa_ = B3_FL1 + (0 * 4 + 2 + ks) * 3, fb_ = B3_FL1 + (1 * 4 + 2 + ks) * 3;
+            f32x4 wa[3], wb[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { wa[q] = lw[(fa_ + q) * 64 + lane]; wb[q] = lw[(fb_ + q) * 64 + lane]; }
+            constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, BP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                acc[0] = MFMA32(wa[WP[t]], n1p[ks][BP[t]], acc[0]);
+                acc[1] = MFMA32(wb[WP[t]], n2p[ks][BP[t]], acc[1]);
+            }
+        }
+        acc[0] = prelu16(acc[0], a1, sel1);
+        acc[1] = prelu16(acc[1], a1, sel1);
+        if (a.dbg_h1 != nullptr && valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (ch < 30) a.dbg_h1[p * 60 + 30 * t + ch] = acc[t][r];
+                }
+        }
+        // ---- u, v and the node-local layer-2 terms c from h1 = [h1a (30) | M0 M1 | h1b (30) | M2 M3]
+        f32x16 o3[3] = {bias16(lbias, 3, h), bias16(lbias, 4, h), bias16(lbias, 5, h)};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 hp[2][3];
+            split8<0>(acc[t], hp[0]);
+            split8<1>(acc[t], hp[1]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) hp[1][q].w = hi ? (t == 0 ? m01[q] : m23[q]) : hp[1][q].w;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int ks = 2 * t + kb;
+                const int f0[3] = {B3_FUVC + (0 * 4 + ks) * 3, B3_FUVC + (1 * 4 + ks) * 3, B3_FUVC + (2 * 4 + ks) * 3};
+                mma6<3>(o3, lw, f0, lane, hp[kb]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
+        }
+        o3[0] = prelu16(o3[0], a21, sel21);
+        o3[1] = prelu16(o3[1], a22, sel22);
+        // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
+        //      (the u K-steps only reach rows 0..14, the v K-steps rows 16..30: two independent accumulator chains)
+        f32x16 ow[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ow[0][r] = 0.f; ow[1][r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 up[3], vp[3];
+            if (kb == 0) { split8<0>(o3[0], up); split8<0>(o3[1], vp); }
+            else { split8<1>(o3[0], up); split8<1>(o3[1], vp); }
+            f32x4 wa[3], wb[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                wa[q] = lw[(B3_FW + (0 + kb) * 3 + q) * 64 + lane];
+                wb[q] = lw[(B3_FW + (2 + kb) * 3 + q) * 64 + lane];
+            }
+            constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, BP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                ow[0] = MFMA32(wa[WP[t]], up[BP[t]], ow[0]);
+                ow[1] = MFMA32(wb[WP[t]], vp[BP[t]], ow[1]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                *(f32x4*)(a.wu + p * ROWW + 8 * b + 4 * h) = f32x4{ow[0][4 * b], ow[0][4 * b + 1], ow[0][4 * b + 2], ow[0][4 * b + 3]};
+                *(f32x4*)(a.wv + p * ROWW + 8 * b + 4 * h) =
+                    f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
+            }
+        }
+        idv = idv_n; sc = sc_n; valid = valid_n;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
     }
 }
 
@@ -1639,6 +2131,9 @@ struct genie_ctx {
     BiasDesc* d_bias[2];
     int32_t* d_scal[2];
     float* packed[2];
+    int32_t* d_b3tbl;          // k_pack_b3 source table
+    int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
+    float* packed_b3;          // bf16x3 weight image of k_stage1_b3
     int num_cu;
     float* ro_img;             // [RO_IMG0 | RO_IMG1 | RO_IMGCV] pre-transposed read-out weight images
     TDesc* d_tdesc; int n_tdesc;
@@ -1646,8 +2141,9 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
+    int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
-    size_t o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
+    size_t o_xs, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist twice; `slot` selects the copy
     size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
     int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
@@ -1661,10 +2157,12 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 void layout_ws(genie_ctx* c) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 64); return r; };
+    c->o_xs = take((size_t)c->P_ext * (XROW / 4));   // single copy: written and read inside stage 1 only
+    const size_t big0 = o;
     c->o_c = take((size_t)c->P * ROWC);
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
-    c->big_stride = o;
+    c->big_stride = o - big0;
     o += c->big_stride;        // second copy (slot 1): stage 1 of window i+1 may run while stage 2 of window i reads
     const size_t small0 = o;
     c->o_part = take((size_t)c->G * c->T * 32);
@@ -1697,6 +2195,7 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
                                                    (int)p.bias.size(), c->d_scal[s], (int)p.scal.size(), c->packed[s]);
     }
+    k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3);
     k_pack_t<<<8, 256, 0, st>>>(c->raw, c->d_tdesc, c->n_tdesc, c->ro_img);
     HIP_TRY(hipGetLastError());
     c->dirty = false;
@@ -1724,6 +2223,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.S = c->S; a.G = c->G; a.T = c->T;
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
+    a.src_tab = c->src_tab;
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
@@ -1817,6 +2317,27 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
     }
     {
+        std::vector<int32_t> tbl;
+        build_b3_table(tbl);
+        HIP_TRY(hipMalloc((void**)&c->d_b3tbl, sizeof(int32_t) * tbl.size()));
+        HIP_TRY(hipMemcpy(c->d_b3tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->packed_b3, sizeof(float) * B3_IMG_FLOATS));
+    }
+    c->src_tab = nullptr;
+    if (c->kp_uni == 15) {
+        std::vector<int32_t> ord(n_grid), col((size_t)e_src), tab((size_t)n_grid * 16);
+        HIP_TRY(hipMemcpy(ord.data(), c->order, sizeof(int32_t) * n_grid, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(col.data(), c->src_col, sizeof(int32_t) * (size_t)e_src, hipMemcpyDeviceToHost));
+        for (int gi = 0; gi < n_grid; ++gi) {
+            const int gg = ord[gi];
+            if (gg < 0 || gg >= n_grid) return fail(GENIE_ERR_ARG, "grid_order is not a permutation of the source nodes");
+            tab[(size_t)gi * 16] = gg;
+            for (int k = 0; k < 15; ++k) tab[(size_t)gi * 16 + 1 + k] = col[(size_t)gg * 15 + k];
+        }
+        HIP_TRY(hipMalloc((void**)&c->src_tab, sizeof(int32_t) * tab.size()));
+        HIP_TRY(hipMemcpy(c->src_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
+    }
+    {
         std::vector<TDesc> td;
         auto add = [&](int dst, int w, int rows, int ld, int ldo, int col0, int ncols) {
             TDesc t; t.dst = dst; t.raw = g_params[w].off; t.rows = rows; t.ld = ld; t.ldo = ldo; t.col0 = col0; t.ncols = ncols; t.pad = 0;
@@ -1870,6 +2391,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
         c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
+        // bf16x3 stage 1: same graph shape, 32-bit byte offsets into the 48-B input rows, 24-bit multiplicands
+        c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * XROW < (1ll << 32) && n_grid_ext < (1 << 24) &&
+                     (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
         c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
 #if GENIE_TUNING
@@ -1907,7 +2431,7 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
-                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc};
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -1956,7 +2480,12 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     DaArgs a = make_da_args(c, (float*)ws);
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
-    if (c->use_fast)
+    if (c->use_b3) {
+        unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
+        k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
+        a.xs = xs; a.packed = c->packed_b3;
+        k_stage1_b3<8, 15><<<da_grid_w(c, ((long long)c->G * c->T + 1) / 2, 1, B3_THREADS / 64), B3_THREADS, 0, st>>>(a);
+    } else if (c->use_fast)
         k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     else
         k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
