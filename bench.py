@@ -32,15 +32,18 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
 
 # Algorithmic bytes: whole path B_alg = 1532*P + 816*G bytes per window (reference dataflow at layer
 # granularity). The HIP path moves fewer real bytes than that because h0/h1/u/v never leave the registers; per
-# product node and per kernel (fp32; gathers counted once per row = perfect cache):
-#   k_stage1(_fast): Slice+Mask 32 R, c 120 W, wu+wv 120 W            = 272 B   (MFMA-bound: dense per-node MLP chain)
-#   k_stage2       : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R  = 268 B   (HBM/L2-bound gather + 33->30 MLP)
-B_NODE = {"k_stage1": 272.0, "k_stage2": 268.0}
+# product node and per kernel group (gathers counted once per row = perfect cache):
+#   stage 1 = k_split_rows + k_stage1_b3: Slice+Mask 32 R, split rows 48 W + 48 R, c 120 W, wu+wv 120 W = 368 B
+#   stage 2 = k_stage2_fast             : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R               = 268 B
+B_NODE = {"k_stage1": 368.0, "k_stage2": 268.0}
 # ALGORITHMIC FLOPs per product node (SURVEY.md 8d split by kernel; 2 per MAC): stage 1 = init_trns 240 + layer-1 3840
 # + l2_t*_1 3600 + l2_t*_2 2820 MACs + 690 layer-1 gather adds; stage 2 = Bipartite fc1 990 MACs + 690 gather adds.
-# (The kernel EXECUTES more: it recomputes init_trns for 23 neighbours, +5520 MACs/node; not counted as achieved.)
 F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 * 990 + 690.0}
-F_NODE_EXEC = {"k_stage1": 2.0 * (240 + 23 * 240 + 3840 + 3600 + 900 + 1920), "k_stage2": 2.0 * 990 + 690.0}
+# What k_stage1_b3 EXECUTES on the bf16 matrix pipe: 216 v_mfma_f32_32x32x16_bf16 (32768 FLOP each) per 32 nodes = six
+# bf16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
+BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
+BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
+S1_TRAFFIC_CFG2 = None       # filled from the committed PMC passes
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -310,13 +313,19 @@ def main():
     dom_tf = F_NODE[dom] * P / (kms[dom] * 1e-3) / 1e12
     b_alg = 1532.0 * P + 816.0 * G
     path_gbs = b_alg * (windows_per_s / world) / 1e9
-    if dom == "k_stage1":   # dense per-node MLP chain on fp32 MFMA: compute roofline
+    if dom == "k_stage1":   # dense per-node MLP chain: compute roofline
+        # `achieved` = ALGORITHMIC fp32 FLOPs / time against the fp32 matrix peak (the dtype the path computes in). The
+        # kernel gets past what fp32 MFMAs can deliver by running exact 3-way bf16 splits on the bf16 matrix pipe; the
+        # bf16 FLOPs it really executes are reported next to the bf16 peak.
         # traffic: HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> B), measured on this
-        # exact workload and committed as profiles/r01_c_pmc_stage_kernels.txt; null for other workloads
-        traffic = (2 * 200.7e6 + 500.0e6) if a.config == "cfg2_200x10k" else None
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 2), "peak": FP32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
-                    "executed_tflops_incl_recompute": round(F_NODE_EXEC[dom] * P / (kms[dom] * 1e-3) / 1e12, 2),
+        # exact workload and committed under profiles/ (r01_e_pmc_stage_kernels.txt); null for other workloads
+        traffic = S1_TRAFFIC_CFG2 if a.config == "cfg2_200x10k" else None
+        exec_tf = BF16_EXEC_FLOP_NODE * P / (kms[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_stage1_b3 (+ k_split_rows)", "achieved": round(dom_tf, 2),
+                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4),
+                    "traffic": traffic,
+                    "executed": {"bf16_tflops": round(exec_tf, 1), "bf16_peak": BF16_MFMA_PEAK_TF,
+                                 "frac": round(exec_tf / BF16_MFMA_PEAK_TF, 4)},
                     "hbm_equiv_GBs": round(dom_gbs, 1)}
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

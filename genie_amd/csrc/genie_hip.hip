@@ -36,6 +36,16 @@
 #define ABL(a, bit) 0
 #endif
 
+// read-once rows (c, Mask, edge_attr of k_stage2_b3) as non-temporal loads: measured SLOWER (0.354 vs 0.326 ms), off
+#ifndef GENIE_S2_NT
+#define GENIE_S2_NT 0
+#endif
+#if GENIE_S2_NT
+#define GENIE_LD_STREAM(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define GENIE_LD_STREAM(ptr) (*(ptr))
+#endif
+
 #ifndef GENIE_HOIST_WEIGHTS
 #define GENIE_HOIST_WEIGHTS 0
 #endif
@@ -296,6 +306,40 @@ void build_b3_table(std::vector<int32_t>& tbl) {
     int32_t* scal = bias + B3_NBIAS * 32;
     const int sv[6] = {W_DA_ACT, W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22};
     for (int k = 0; k < 6; ++k) scal[k] = g_params[sv[k]].off;
+}
+
+// STAGE 2, bf16x3 form (k_stage2_b3): Bipartite fc1 on x_latent in the 32-slot layout [o1 (15), 0, o2 (15), 0] of the c rows.
+// Fragments: ks*3 + piece (K-steps 0,1 of that block), then 6 + m: [W1|W1], [W2|W2], [W1|W3] of the 3 edge_attr columns.
+constexpr int B3S2_FRAGS = 9;
+constexpr int B3S2_IMG_FLOATS = B3S2_FRAGS * 256 + 32 + 16;
+constexpr int B3S2_TBL = B3S2_FRAGS * 512 + 32 + 16;
+
+void build_b3_table_stage2(std::vector<int32_t>& tbl) {
+    tbl.assign(B3S2_TBL, -1);
+    auto put = [&](int f, int i, int h, int e, int piece, int off) {
+        tbl[((size_t)f * 64 + (h * 32 + i)) * 8 + e] = off < 0 ? -1 : (off | (piece << 28));
+    };
+    const int W = g_params[W_BP_FC1_W].off;
+    for (int i = 0; i < 32; ++i)
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) {
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int ch = 16 * kb + 8 * (e >> 2) + 4 * h + (e & 3);
+                    int col = -1;
+                    if (ch < 15) col = ch;
+                    else if (ch >= 16 && ch < 31) col = 15 + (ch - 16);
+                    const int off = (i < 30 && col >= 0) ? W + i * 33 + col : -1;
+                    for (int piece = 0; piece < 3; ++piece) put(kb * 3 + piece, i, h, e, piece, off);
+                }
+                const int offe = (i < 30 && e < 3) ? W + i * 33 + 30 + e : -1;
+                put(6, i, h, e, 0, offe);
+                put(7, i, h, e, 1, offe);
+                put(8, i, h, e, h == 0 ? 0 : 2, offe);
+            }
+    int32_t* tail = tbl.data() + (size_t)B3S2_FRAGS * 512;
+    for (int i = 0; i < 30; ++i) tail[i] = g_params[W_BP_FC1_B].off + i;
+    tail[32] = g_params[W_DA_ACT2].off;
+    tail[33] = g_params[W_BP_ACT1].off;
 }
 
 void build_plans(StagePlan& p1, StagePlan& p2) {
@@ -1016,9 +1060,10 @@ __device__ __forceinline__ unsigned bf16_piece(float v, int piece) {
     return __float_as_uint(r - b) >> 16;
 }
 
-__global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out) {
+__global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out, int nfrag,
+                          int ntail) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < B3_FRAGS * 64) {
+    if (idx < nfrag * 64) {
         u32x4 o;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -1031,10 +1076,10 @@ __global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restri
             o[d] = u[0] | (u[1] << 16);
         }
         ((u32x4*)out)[idx] = o;
-    } else if (idx < B3_FRAGS * 64 + B3_NBIAS * 32 + 16) {
-        const int k = idx - B3_FRAGS * 64;
-        const int32_t ent = tbl[B3_FRAGS * 512 + k];
-        out[B3_FRAGS * 256 + k] = ent < 0 ? 0.f : raw[ent];
+    } else if (idx < nfrag * 64 + ntail) {     // fp32 tail: bias blocks and PReLU slopes
+        const int k = idx - nfrag * 64;
+        const int32_t ent = tbl[nfrag * 512 + k];
+        out[nfrag * 256 + k] = ent < 0 ? 0.f : raw[ent];
     }
 }
 
@@ -1466,18 +1511,21 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
         const long long p = (long long)g_c * S + sc_c;
         // (1) every load of this tile
         f32x4 o[2];
-        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        o[0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[1] = o[0];
+        if (!ABL(a, 5)) {
+            o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+            o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        }
         const float mq = a.mask[p * 4 + q];
         const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
         f32x4 ru[KS], rv[KP];
         const unsigned gS = (unsigned)g_c * (unsigned)S;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) ru[k] = *(const f32x4*)(wub + ((gS + (unsigned)sta_c[k]) * 64u + q16));
+        for (int k = 0; k < KS; ++k) ru[k] = ABL(a, 0) ? o[0] : *(const f32x4*)(wub + ((gS + (unsigned)sta_c[k]) * 64u + q16));
         const unsigned so = (unsigned)sc_c * 64u + q16;
 #pragma unroll
         for (int k = 0; k < KP; ++k)
-            rv[k] = *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(srcv_c, k) * ((unsigned)S * 64u) + so));
+            rv[k] = ABL(a, 1) ? o[1] : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(srcv_c, k) * ((unsigned)S * 64u) + so));
         // (2) ids of the next tile
         const bool has_next = w.it + w.stride < w.nitems;
         if (has_next) {
@@ -1509,6 +1557,15 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        if (ABL(a, 6)) {
+            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
+            if (!has_next) break;
+            g_c = g_n; sc_c = sc_n; tb_c = tb_n; valid_c = valid_n; srcv_c = srcv_n;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) sta_c[k] = sta_n[k];
+            w.it += w.stride;
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
@@ -1536,6 +1593,153 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_c[k] = sta_n[k];
         w.it += w.stride;
+    }
+}
+
+// Stage 2 in the layout of k_stage1_b3: a wave owns two 16-station tiles, lane (j = lane&31, h = lane>>5) holds channels
+// 8*(r>>2) + 4h + (r&3) of x_latent in the 32-slot order of the c rows ([o1 (15), 0 | o2 (15), 0]); a gathered 64-B row is two
+// 16-B chunks per lane. Bipartite fc1 runs as 12 + 3 bf16x3 MFMAs; the station sum over the 16 nodes of a tile is a DPP row
+// reduction (a DPP row = 16 lanes = one tile), no LDS traffic. Summation orders differ from k_stage2 / k_stage2_fast.
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+template <int KS, int KP>
+__global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
+    constexpr int NF4 = B3S2_IMG_FLOATS / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + B3S2_FRAGS * 64);
+    const float* lscal = lbias + 32;
+    const float a2 = lscal[0], ab1 = lscal[1];
+    const float inf = __builtin_inff();
+    const float sel2 = a2 <= 1.f ? inf : -inf, selb = ab1 <= 1.f ? inf : -inf;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
+    const bool hi = h != 0;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    const char* wub = (const char*)a.wu;
+    const char* wvb = (const char*)a.wv;
+    const unsigned h16 = 16u * (unsigned)h;
+    const unsigned gstride = (unsigned)S * 64u;
+
+    int jt = jj;
+    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, int& tb_, bool& valid_, bool& tile_, int (&sta_)[KS]) {
+        int gi0, tb0, gi1, tb1;
+        w.decode(2 * pit_, gi0, tb0);
+        const bool second = 2 * pit_ + 1 < w.nitems;
+        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
+        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
+        tb_ = half ? tb1 : tb0;
+        const int s = tb_ * 16 + jt;
+        tile_ = second || !half;
+        valid_ = s < S && tile_;
+        sc_ = s < S ? s : S - 1;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_[k] = a.sta_col[sc_ * KS + k];
+    };
+    int idv = 0, sc = 0, tb = 0, sta_id[KS];
+    bool valid = false, tile = false;
+    if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, tb, valid, tile, sta_id);
+    for (long long pit = w.it; 2 * pit < w.nitems; pit += w.stride) {
+        asm volatile("" : "+v"(lane));
+        const bool has_next = 2 * (pit + w.stride) < w.nitems;
+        const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
+        const int g = half ? g1 : g0;
+        const long long p = (long long)g * S + sc;
+        // (1) every load of this tile pair
+        f32x4 cc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cc[b] = GENIE_LD_STREAM((const f32x4*)(a.c + p * ROWC + 8 * b + 4 * h));
+        const f32x4 m4 = GENIE_LD_STREAM((const f32x4*)(a.mask + p * 4));
+        const float e0 = GENIE_LD_STREAM(a.edge_attr + p * 3), e1 = GENIE_LD_STREAM(a.edge_attr + p * 3 + 1),
+                    e2 = GENIE_LD_STREAM(a.edge_attr + p * 3 + 2);
+        f32x4 ru[KS][2], rv[KP][2];
+        const unsigned gS = (unsigned)g * (unsigned)S;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const unsigned o = (gS + (unsigned)sta_id[k]) * 64u + h16;
+            ru[k][0] = *(const f32x4*)(wub + o);
+            ru[k][1] = *(const f32x4*)(wub + (o + 32u));
+        }
+        const unsigned so = (unsigned)sc * 64u + h16;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int n0 = __builtin_amdgcn_readlane(idv, 1 + k), n1 = __builtin_amdgcn_readlane(idv, 17 + k);
+            const unsigned o = __umul24((unsigned)(half ? n1 : n0), gstride) + so;
+            rv[k][0] = *(const f32x4*)(wvb + o);
+            rv[k][1] = *(const f32x4*)(wvb + (o + 32u));
+        }
+        // (2) ids of the next tile pair
+        int idv_n = 0, sc_n = 0, tb_n = 0, sta_n[KS];
+        bool valid_n = false, tile_n = false;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
+        if (has_next) fetch_ids(pit + w.stride, idv_n, sc_n, tb_n, valid_n, tile_n, sta_n);
+        // (3) neighbour means of the projected operands + node-local terms, PReLU2 -> x_latent (32-slot order)
+        f32x4 su[2] = {ru[0][0], ru[0][1]}, sv[2] = {rv[0][0], rv[0][1]};
+#pragma unroll
+        for (int k = 1; k < KS; ++k) { su[0] += ru[k][0]; su[1] += ru[k][1]; }
+#pragma unroll
+        for (int k = 1; k < KP; ++k) { sv[0] += rv[k][0]; sv[1] += rv[k][1]; }
+        f32x16 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x[r] = fmaf(su[0][r], 1.f / (float)KS, cc[0][r]);
+            x[4 + r] = fmaf(su[1][r], 1.f / (float)KS, cc[1][r]);
+            x[8 + r] = fmaf(sv[0][r], 1.f / (float)KP, cc[2][r]);
+            x[12 + r] = fmaf(sv[1][r], 1.f / (float)KP, cc[3][r]);
+        }
+        x = prelu16(x, a2, sel2);
+        if (a.x_latent != nullptr && valid) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < 15) xl[ch] = x[r];
+                else if (ch >= 16 && ch < 31) xl[ch - 1] = x[r];
+            }
+        }
+        // (4) Bipartite fc1 [x_latent || edge_attr] + PReLU, mask gate
+        u32x4 xp[2][3];
+        split8<0>(x, xp[0]);
+        split8<1>(x, xp[1]);
+        u32x4 ea, eb;      // edge_attr slices: lane h = 0 supplies [e1 ; e3], lane h = 1 [e2 ; e1] (as the raw rows of stage 1)
+        {
+            const float r0 = e0 - bf_hi(e0), r1 = e1 - bf_hi(e1), r2 = e2 - bf_hi(e2);
+            const unsigned p1a = pk_hi(e0, e1), p1b = __float_as_uint(e2) >> 16;
+            const unsigned p2a = pk_hi(r0, r1), p2b = __float_as_uint(r2) >> 16;
+            const unsigned p3a = pk_hi(r0 - bf_hi(r0), r1 - bf_hi(r1)), p3b = __float_as_uint(r2 - bf_hi(r2)) >> 16;
+            ea = u32x4{hi ? p2a : p1a, hi ? p2b : p1b, 0u, 0u};
+            eb = u32x4{hi ? p1a : p3a, hi ? p1b : p3b, 0u, 0u};
+        }
+        f32x16 acc[1] = {bias16(lbias, 0, h)};
+        acc[0] = MFMA32(lw[6 * 64 + lane], ea, acc[0]);
+        acc[0] = MFMA32(lw[7 * 64 + lane], ea, acc[0]);
+        acc[0] = MFMA32(lw[8 * 64 + lane], eb, acc[0]);
+        { const int f0[1] = {0}; mma6<1>(acc, lw, f0, lane, xp[0]); }
+        { const int f0[1] = {3}; mma6<1>(acc, lw, f0, lane, xp[1]); }
+        acc[0] = prelu16(acc[0], ab1, selb);
+        const float mm = valid ? fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)) : 0.f;
+        // (5) station sum over the 16 nodes of each tile
+        f32x16 rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = row_sum16(acc[0][r] * mm);
+        if (jj == 0 && tile) {
+            float* dst = a.part + ((long long)g * a.T + tb) * 32 + 4 * h;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) *(f32x4*)(dst + 8 * b) = f32x4{rs[4 * b], rs[4 * b + 1], rs[4 * b + 2], rs[4 * b + 3]};
+        }
+        idv = idv_n; sc = sc_n; tb = tb_n; valid = valid_n; tile = tile_n;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
     }
 }
 
@@ -2104,6 +2308,15 @@ __global__ void k_embed_gather(EmbArgs a) {
 }
 
 // de-pad rows of a workspace tensor for parity tests
+#if GENIE_TUNING
+// which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
+__global__ void k_xcc_probe(int* __restrict__ out) {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+#endif
+
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
     // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2132,6 +2345,8 @@ struct genie_ctx {
     int32_t* d_scal[2];
     float* packed[2];
     int32_t* d_b3tbl;          // k_pack_b3 source table
+    int32_t* d_b3tbl2;         // ... of the stage-2 image
+    float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
     float* packed_b3;          // bf16x3 weight image of k_stage1_b3
     int num_cu;
@@ -2141,6 +2356,7 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
+    int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
     size_t o_xs, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
@@ -2195,7 +2411,9 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
                                                    (int)p.bias.size(), c->d_scal[s], (int)p.scal.size(), c->packed[s]);
     }
-    k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3);
+    k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3, B3_FRAGS,
+                                                                               B3_NBIAS * 32 + 16);
+    k_pack_b3<<<(B3S2_FRAGS * 64 + 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl2, c->packed_b3s2, B3S2_FRAGS, 32 + 16);
     k_pack_t<<<8, 256, 0, st>>>(c->raw, c->d_tdesc, c->n_tdesc, c->ro_img);
     HIP_TRY(hipGetLastError());
     c->dirty = false;
@@ -2322,6 +2540,10 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->d_b3tbl, sizeof(int32_t) * tbl.size()));
         HIP_TRY(hipMemcpy(c->d_b3tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_b3, sizeof(float) * B3_IMG_FLOATS));
+        build_b3_table_stage2(tbl);
+        HIP_TRY(hipMalloc((void**)&c->d_b3tbl2, sizeof(int32_t) * tbl.size()));
+        HIP_TRY(hipMemcpy(c->d_b3tbl2, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->packed_b3s2, sizeof(float) * B3S2_IMG_FLOATS));
     }
     c->src_tab = nullptr;
     if (c->kp_uni == 15) {
@@ -2394,6 +2616,15 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // bf16x3 stage 1: same graph shape, 32-bit byte offsets into the 48-B input rows, 24-bit multiplicands
         c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * XROW < (1ll << 32) && n_grid_ext < (1 << 24) &&
                      (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
+        // station-tile-major sweeps over segments of 512 source nodes keep the neighbour rows of a segment in L2
+        // (tools/tune.py: k_stage1_b3 0.51 -> 0.47 ms at config 2; the fp32 kernels did not care)
+        if (c->use_b3 && !getenv("GENIE_SEG")) c->seg = 512;
+        // k_stage2_b3 is no faster than k_stage2_fast (stage 2 is bound by L2-miss traffic, not by its arithmetic) and its 240
+        // VGPRs leave no room for the G-sized tail kernels of the previous window: opt-in only (GENIE_S2=b3)
+        c->nob3s2 = ((e = getenv("GENIE_S2")) && strcmp(e, "b3") == 0) ? 0 : 1;
+        int occ2b = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2b, k_stage2_b3<8, 15>, 256, 0));
+        c->bpc2b = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2b);
         c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
 #if GENIE_TUNING
@@ -2431,7 +2662,7 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
-                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab};
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -2518,7 +2749,10 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
-    if (c->use_fast && !c->nofast2)
+    if (c->use_b3 && !c->nob3s2) {
+        a.packed = c->packed_b3s2;
+        k_stage2_b3<8, 15><<<da_grid(c, ((long long)c->G * c->T + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
+    } else if (c->use_fast && !c->nofast2)
         k_stage2_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc2f), 256, 0, st>>>(a);
     else
         k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);

@@ -184,6 +184,43 @@ def test_bitwise_deterministic_and_order_independent():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", ["cfg1_20x500", "random_50x700"])
+def test_kernel_variants_agree(case, monkeypatch):
+    """The stage kernels exist in three forms: generic CSR fp32-MFMA (any graph), software-pipelined fp32-MFMA (uniform
+    8 / 15 degrees; same arithmetic order as the generic one: bitwise equal) and the exact-split bf16 matrix-pipe form
+    (k_stage1_b3 default, k_stage2_b3 opt-in; different summation order: fp32 tolerance)."""
+    if case == "cfg1_20x500":
+        c = Case(case)
+        S, G, w = c.S, c.G, c.weights
+        sta_nbr, src_nbr = c.tables()
+        Slice, Mask, ea, pos, xg = c.Slice, c.Mask, c.edge_attr, c.x_grid.float(), c.x_grid.numpy()
+    else:
+        S, G = 50, 700
+        geom, win = _random_case(S, G, seed=77, n_picks=600)
+        w = Case("tiny_6x40").weights
+        sta_nbr, src_nbr = graph.neighbour_table(geom.A_sta_sta, S), graph.neighbour_table(geom.A_src_src, G)
+        Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
+        ea, pos, xg = torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.x_grid).float(), geom.x_grid
+    res = {}
+    for name, env in (("generic", {"GENIE_S1": "f32", "GENIE_NOFAST": "1", "GENIE_NOFAST2": "1"}), ("fast", {"GENIE_S1": "f32"}),
+                      ("b3", {}), ("b3_s2", {"GENIE_S2": "b3"})):
+        for k in ("GENIE_S1", "GENIE_S2", "GENIE_NOFAST", "GENIE_NOFAST2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hp = engine.HipPath(S, G, engine.csr_from_table(sta_nbr), engine.csr_from_table(src_nbr),
+                            grid_order=engine.morton_order(xg), device=DEV)
+        hp.set_weights({k: v.to(DEV) for k, v in w.items()})
+        _, _, h0, h1 = hp.da_stage1(Slice.to(DEV), Mask.to(DEV), debug=True)
+        xl, bip = hp.da_stage2_bipartite(Mask.to(DEV), ea.to(DEV), want_x_latent=True)
+        res[name] = [t.cpu() for t in (h0, h1, xl, bip)]
+    for a_, b_ in zip(res["generic"], res["fast"]):
+        assert torch.equal(a_, b_)
+    for other in ("b3", "b3_s2"):
+        for a_, b_ in zip(res["fast"], res[other]):
+            assert max_abs(a_, b_) <= 0.2 * rel_tol(a_), (other, max_abs(a_, b_))     # 2e-6 x max(1, max|ref|)
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")
