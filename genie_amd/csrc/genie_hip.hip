@@ -46,6 +46,10 @@
 #define GENIE_LD_STREAM(ptr) (*(ptr))
 #endif
 
+#ifndef GENIE_S2_WAVES
+#define GENIE_S2_WAVES 3   // minimum waves per SIMD the register allocator of k_stage2_fast is held to
+#endif
+
 #ifndef GENIE_HOIST_WEIGHTS
 #define GENIE_HOIST_WEIGHTS 0
 #endif
@@ -503,7 +507,18 @@ struct DaArgs {
 // nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ...
 struct ItemIter {
     int gbeg, gend, T, seg;
+    unsigned per_seg, m_per_seg, n_full, m_full, n_last, m_last, last_seg;   // divisors and their 2^32 reciprocals
     long long it, stride, nitems;
+    // floor(x / d) for x < 2^31 with m = floor(2^32 / d): scalar multiply-high + at most two corrections (a hardware
+    // integer division is ~30 dependent VALU ops + readfirstlanes per call, on every tile's critical path)
+    static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned d, unsigned m, unsigned& r) {
+        unsigned q = __umulhi(x, m);
+        r = x - q * d;
+        if (r >= d) { r -= d; ++q; }
+        if (r >= d) { r -= d; ++q; }
+        return q;
+    }
+    static __device__ __forceinline__ unsigned recip(unsigned d) { return d <= 1u ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
     __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave) {
         const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
         const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
@@ -515,17 +530,24 @@ struct ItemIter {
         const int wpb = blockDim.x >> 6;           // waves per workgroup
         it = (long long)lb * wpb + wave;
         stride = (long long)nbx * wpb;
+        per_seg = (unsigned)seg * (unsigned)T;
+        m_per_seg = recip(per_seg);
+        n_full = (unsigned)seg;
+        m_full = recip(n_full);
+        last_seg = (unsigned)((gend - gbeg) / seg);            // index of the (possibly short or empty) last segment
+        n_last = (unsigned)((gend - gbeg) - (int)last_seg * seg);
+        if (n_last == 0) n_last = 1;
+        m_last = recip(n_last);
     }
     // item -> (index into the processing order, station tile); 32-bit arithmetic (a chunk has < 2^31 items)
     __device__ void decode(long long item, int& gi, int& tb) const {
-        const unsigned per_seg = (unsigned)seg * (unsigned)T;
-        const unsigned i = (unsigned)item;
-        const unsigned sidx = i / per_seg;
-        const unsigned rem = i - sidx * per_seg;
-        const int g0 = (int)(sidx * (unsigned)seg);
-        const int n = min(seg, gend - gbeg - g0);   // nodes in this (possibly last, short) segment
-        tb = (int)(rem / (unsigned)n);
-        gi = gbeg + g0 + (int)rem - tb * n;
+        unsigned rem, r2;
+        const unsigned sidx = per_seg <= 1u ? (rem = 0u, (unsigned)item) : fdiv((unsigned)item, per_seg, m_per_seg, rem);
+        const bool last = sidx >= last_seg;
+        const unsigned n = last ? n_last : n_full;   // nodes in this (possibly last, short) segment
+        const unsigned q = n <= 1u ? (r2 = 0u, rem) : fdiv(rem, n, last ? m_last : m_full, r2);
+        tb = (int)q;
+        gi = gbeg + (int)(sidx * (unsigned)seg) + (int)r2;
     }
 };
 
@@ -1466,11 +1488,14 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     }
 }
 
-// Fast stage 2 for uniform-degree graphs (KS station / KP source neighbours): the neighbour ids of tile i+1 are
-// fetched while tile i computes, and the 1 + KS + KP row loads of a tile are all issued before the first is consumed,
-// so a tile pays ONE memory round trip. Same arithmetic and summation order as k_stage2 (bitwise identical).
+// Fast stage 2 for uniform-degree graphs (KS station / KP source neighbours), software-pipelined across tiles: the
+// 1 + KS + KP row loads of tile i+1 are issued BEFORE the MFMA / shuffle phase of tile i, and the ids of tile i+2 are
+// fetched one iteration earlier still, so no memory round trip sits on a wave's critical path. (Without this every wave
+// of a CU moves through "load, wait, compute" in lockstep: the texture path and the VALU take turns instead of
+// overlapping, and the kernel ran 0.33 ms regardless of occupancy or cache hit rate.) Same arithmetic and summation order
+// as k_stage2 (bitwise identical).
 template <int KS, int KP>
-__global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
+__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
@@ -1479,7 +1504,6 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
     const float* lscal = lbias + G2_BIAS * 16;
     const float a2 = lscal[0], ab1 = lscal[1];
     int lane = threadIdx.x & 63;
-    const int lane0 = lane;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
@@ -1489,62 +1513,68 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
     const char* wvb = (const char*)a.wv;
     const unsigned q16 = 16u * (unsigned)q;          // byte offset of this lane's 4 channels inside a 64-B row
 
-    int g_c, sc_c, tb_c, g_n = 0, sc_n = 0, tb_n = 0;
-    bool valid_c, valid_n = false;
-    int sta_c[KS], sta_n[KS], srcv_c, srcv_n = 0;
-    auto decode = [&](long long item, int& g, int& sc, int& tb, bool& valid) {
+    // ids of a tile: idv = row of src_tab (lane j = 0: source node, j = 1..KP: its source neighbours), station-neighbour ids
+    struct Ids { int idv, sc, tb; bool valid; int sta[KS]; };
+    auto fetch_ids = [&](long long item, Ids& t) {
         int gi;
-        w.decode(item, gi, tb);
-        g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        const int s = tb * 16 + j;
-        valid = s < S;
-        sc = valid ? s : S - 1;
-    };
-    decode(w.it, g_c, sc_c, tb_c, valid_c);
+        w.decode(item, gi, t.tb);
+        t.idv = a.src_tab[gi * 16 + j];
+        const int s = t.tb * 16 + j;
+        t.valid = s < S;
+        t.sc = t.valid ? s : S - 1;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) sta_c[k] = a.sta_col[sc_c * KS + k];
-    srcv_c = a.src_col[(long long)g_c * KP + min(lane0 & 15, KP - 1)];
+        for (int k = 0; k < KS; ++k) t.sta[k] = a.sta_col[t.sc * KS + k];
+    };
+    struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; };
+    auto issue = [&](const Ids& t, Rows& r) {
+        const int g = __builtin_amdgcn_readlane(t.idv, 0);
+        long long p = (long long)g * S + t.sc;
+        if (ABL(a, 9)) p &= 4095;     // tuning: streamed rows (c, Mask, edge_attr) from a cache-resident region
+        r.o[0] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        r.mq = a.mask[p * 4 + q];
+        r.eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        const unsigned gS = (unsigned)g * (unsigned)S;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wub + ((gS + (unsigned)t.sta[k]) * 64u + q16));
+        const unsigned so = (unsigned)t.sc * 64u + q16;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            r.rv[k] = ABL(a, 1) ? r.o[1]
+                                : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((unsigned)S * 64u) + so));
+    };
+    Ids cur, nxt, nn;
+    Rows rows;
+    fetch_ids(w.it, cur);
+    nxt = cur;
+    if (w.it + w.stride < w.nitems) fetch_ids(w.it + w.stride, nxt);
+    issue(cur, rows);
     for (;;) {
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
 #endif
-        const long long p = (long long)g_c * S + sc_c;
-        // (1) every load of this tile
-        f32x4 o[2];
-        o[0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[1] = o[0];
-        if (!ABL(a, 5)) {
-            o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-            o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
-        }
-        const float mq = a.mask[p * 4 + q];
-        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
-        f32x4 ru[KS], rv[KP];
-        const unsigned gS = (unsigned)g_c * (unsigned)S;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) ru[k] = ABL(a, 0) ? o[0] : *(const f32x4*)(wub + ((gS + (unsigned)sta_c[k]) * 64u + q16));
-        const unsigned so = (unsigned)sc_c * 64u + q16;
-#pragma unroll
-        for (int k = 0; k < KP; ++k)
-            rv[k] = ABL(a, 1) ? o[1] : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(srcv_c, k) * ((unsigned)S * 64u) + so));
-        // (2) ids of the next tile
         const bool has_next = w.it + w.stride < w.nitems;
-        if (has_next) {
-            decode(w.it + w.stride, g_n, sc_n, tb_n, valid_n);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) sta_n[k] = a.sta_col[sc_n * KS + k];
-            srcv_n = a.src_col[(long long)g_n * KP + min(lane0 & 15, KP - 1)];
-        }
-        // (3) neighbour means of the projected operands, in edge order
+        const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
+        const long long p = (long long)g_c * S + cur.sc;
+        // (1) consume the rows of this tile: neighbour means of the projected operands, in edge order
+        f32x4 o[2] = {rows.o[0], rows.o[1]};
+        const float mq = rows.mq, eq = rows.eq;
         f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KS; ++k) n1 += ru[k];
+        for (int k = 0; k < KS; ++k) n1 += rows.ru[k];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) n2 += rv[k];
+        for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
+        asm volatile("" : "+v"(n1), "+v"(n2), "+v"(o[0]), "+v"(o[1]));
+        // (2) rows of the next tile: in flight during the MFMA / reduction phase below; ids of the tile after that
+        if (has_next) issue(nxt, rows);
+        nn = nxt;
+        if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
         n1 *= 1.f / (float)KS;
         n2 *= 1.f / (float)KP;
         o[0] = prelu4u(o[0] + n1, a2);
         o[1] = prelu4u(o[1] + n2, a2);
-        if (a.x_latent != nullptr && valid_c) {
+        if (a.x_latent != nullptr && cur.valid) {
             float* xl = a.x_latent + p * 30;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1557,41 +1587,35 @@ __global__ __launch_bounds__(256) void k_stage2_fast(DaArgs a) {
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-        if (ABL(a, 6)) {
-            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
-            if (!has_next) break;
-            g_c = g_n; sc_c = sc_n; tb_c = tb_n; valid_c = valid_n; srcv_c = srcv_n;
+        if (!ABL(a, 6)) {
 #pragma unroll
-            for (int k = 0; k < KS; ++k) sta_c[k] = sta_n[k];
-            w.it += w.stride;
-            continue;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-            bp[t] = prelu4u(bp[t], ab1);
-        }
-        float mm = fmaxf(mq, __shfl_xor(mq, 16));
-        mm = fmaxf(mm, __shfl_xor(mm, 32));
-        if (!valid_c) mm = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 v = bp[t] * mm;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                v.x += __shfl_xor(v.x, d);
-                v.y += __shfl_xor(v.y, d);
-                v.z += __shfl_xor(v.z, d);
-                v.w += __shfl_xor(v.w, d);
+            for (int t = 0; t < 2; ++t) {
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+                bp[t] = prelu4u(bp[t], ab1);
             }
-            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
+            float mm = fmaxf(mq, __shfl_xor(mq, 16));
+            mm = fmaxf(mm, __shfl_xor(mm, 32));
+            if (!cur.valid) mm = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 v = bp[t] * mm;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    v.x += __shfl_xor(v.x, d);
+                    v.y += __shfl_xor(v.y, d);
+                    v.z += __shfl_xor(v.z, d);
+                    v.w += __shfl_xor(v.w, d);
+                }
+                if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 16 * t + 4 * q) = v;
+            }
+        } else if (j == 0) {
+            *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
         }
         if (!has_next) break;
-        g_c = g_n; sc_c = sc_n; tb_c = tb_n; valid_c = valid_n; srcv_c = srcv_n;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_c[k] = sta_n[k];
+        cur = nxt;
+        nxt = nn;
         w.it += w.stride;
     }
 }
