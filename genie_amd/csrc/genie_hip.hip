@@ -1040,6 +1040,20 @@ __global__ __launch_bounds__(S1F_THREADS) void k_stage1_fast(DaArgs a) {
     }
 }
 
+// the KS station-neighbour ids of one station as wide loads: a dword load whose lanes hit 16 different 32-B segments costs the
+// texture path about as much as two and a half full 1-KB row loads (tools/: skeleton ablations of k_stage2_fast), and a tile
+// issued KS of them
+template <int KS>
+__device__ __forceinline__ void load_sta_ids(const int32_t* __restrict__ sta_col, int sc, int (&sta)[KS]) {
+    static_assert(KS % 4 == 0, "station-neighbour rows are read as 16-byte chunks");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int c = 0; c < KS / 4; ++c) {
+        const i32x4 v = *(const i32x4*)(sta_col + sc * KS + 4 * c);
+        sta[4 * c] = v.x; sta[4 * c + 1] = v.y; sta[4 * c + 2] = v.z; sta[4 * c + 3] = v.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stage 1 on the bf16 matrix pipe with fp32-exact operands ("bf16x3").
 //
@@ -1208,8 +1222,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         const int s = (half ? tb1 : tb0) * 16 + jt;
         valid_ = s < S && (second || !half);
         sc_ = s < S ? s : S - 1;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_[k] = a.sta_col[sc_ * KS + k];
+        load_sta_ids<KS>(a.sta_col, sc_, sta_);
     };
     int idv = 0, sc = 0, sta_id[KS];
     bool valid = false;
@@ -1522,34 +1535,51 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         const int s = t.tb * 16 + j;
         t.valid = s < S;
         t.sc = t.valid ? s : S - 1;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) t.sta[k] = a.sta_col[t.sc * KS + k];
+        load_sta_ids<KS>(a.sta_col, t.sc, t.sta);
     };
     struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; };
-    auto issue = [&](const Ids& t, Rows& r) {
+    // The row loads of a tile are issued in three bursts (part 0: c, Mask, edge_attr and the KS station rows; parts 1, 2: the
+    // source rows) placed BETWEEN the compute chunks of the previous tile. Every wave of a CU runs the same loop, so a single
+    // 38-load burst makes all of them queue on the texture path at once and then all compute at once (measured: half of a
+    // wave's time went into issuing loads); short bursts let the texture path and the VALU / MFMA work overlap.
+    // `tk` is an ordering token: it passes through an empty asm statement after the preceding compute chunk, so the loads
+    // that add it to their address cannot be hoisted above that chunk.
+    auto issue = [&](const Ids& t, Rows& r, int part, unsigned tk) {
         const int g = __builtin_amdgcn_readlane(t.idv, 0);
-        long long p = (long long)g * S + t.sc;
-        if (ABL(a, 9)) p &= 4095;     // tuning: streamed rows (c, Mask, edge_attr) from a cache-resident region
-        r.o[0] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
-        r.mq = a.mask[p * 4 + q];
-        r.eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
-        const unsigned gS = (unsigned)g * (unsigned)S;
+        if (part == 0) {
+            long long p = (long long)g * S + t.sc;
+            if (ABL(a, 9)) p &= 4095;     // tuning: streamed rows (c, Mask, edge_attr) from a cache-resident region
+            r.o[0] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 4 * q + tk);
+            r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
+            r.mq = a.mask[p * 4 + q + tk];
+            r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
+            const unsigned gS = (unsigned)g * (unsigned)S;
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
-            r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wub + ((gS + (unsigned)t.sta[k]) * 64u + q16));
-        const unsigned so = (unsigned)t.sc * 64u + q16;
+            for (int k = 0; k < KS; ++k)
+                r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wub + ((gS + (unsigned)t.sta[k]) * 64u + q16 + tk));
+        } else {
+            const unsigned so = (unsigned)t.sc * 64u + q16 + tk;
+            constexpr int KH = (KP + 1) / 2;
 #pragma unroll
-        for (int k = 0; k < KP; ++k)
-            r.rv[k] = ABL(a, 1) ? r.o[1]
-                                : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((unsigned)S * 64u) + so));
+            for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k)
+                r.rv[k] = ABL(a, 1) ? r.o[1]
+                                    : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((unsigned)S * 64u) + so));
+        }
     };
+#if GENIE_TUNING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define PH(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
+#else
+#define PH(k) do { } while (0)
+#endif
     Ids cur, nxt, nn;
     Rows rows;
     fetch_ids(w.it, cur);
     nxt = cur;
     if (w.it + w.stride < w.nitems) fetch_ids(w.it + w.stride, nxt);
-    issue(cur, rows);
+    issue(cur, rows, 0, 0u);
+    issue(cur, rows, 1, 0u);
+    issue(cur, rows, 2, 0u);
     for (;;) {
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
@@ -1557,6 +1587,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         const bool has_next = w.it + w.stride < w.nitems;
         const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
         const long long p = (long long)g_c * S + cur.sc;
+        PH(0);
         // (1) consume the rows of this tile: neighbour means of the projected operands, in edge order
         f32x4 o[2] = {rows.o[0], rows.o[1]};
         const float mq = rows.mq, eq = rows.eq;
@@ -1566,10 +1597,12 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
         asm volatile("" : "+v"(n1), "+v"(n2), "+v"(o[0]), "+v"(o[1]));
-        // (2) rows of the next tile: in flight during the MFMA / reduction phase below; ids of the tile after that
-        if (has_next) issue(nxt, rows);
-        nn = nxt;
-        if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+        PH(1);
+        // (2) first burst of the next tile's rows
+        unsigned tk = 0u;
+        asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
+        if (has_next) issue(nxt, rows, 0, tk);
+        PH(2);
         n1 *= 1.f / (float)KS;
         n2 *= 1.f / (float)KP;
         o[0] = prelu4u(o[0] + n1, a2);
@@ -1587,6 +1620,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        nn = nxt;
         if (!ABL(a, 6)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1594,7 +1628,12 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
                 bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
                 bp[t] = prelu4u(bp[t], ab1);
+                // (3) second / third burst, behind the first / second output tile of fc1
+                asm volatile("" : "+v"(tk), "+v"(bp[t]));
+                if (has_next) issue(nxt, rows, 1 + t, tk);
             }
+            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+            PH(3);
             float mm = fmaxf(mq, __shfl_xor(mq, 16));
             mm = fmaxf(mm, __shfl_xor(mm, 32));
             if (!cur.valid) mm = 0.f;
@@ -1610,14 +1649,22 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
                 }
                 if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 16 * t + 4 * q) = v;
             }
-        } else if (j == 0) {
-            *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
+        } else {
+            if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
+            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
         }
+        PH(4);
         if (!has_next) break;
         cur = nxt;
         nxt = nn;
         w.it += w.stride;
     }
+#if GENIE_TUNING
+    if (ABL(a, 10) && a.dbg_h0 != nullptr && lane == 0)
+        for (int k = 0; k < 5; ++k) a.dbg_h0[(blockIdx.x * 4 + wave) * 8 + k] = (float)tph[k];
+#endif
+#undef PH
 }
 
 // Stage 2 in the layout of k_stage1_b3: a wave owns two 16-station tiles, lane (j = lane&31, h = lane>>5) holds channels
@@ -1666,8 +1713,7 @@ __global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
         tile_ = second || !half;
         valid_ = s < S && tile_;
         sc_ = s < S ? s : S - 1;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_[k] = a.sta_col[sc_ * KS + k];
+        load_sta_ids<KS>(a.sta_col, sc_, sta_);
     };
     int idv = 0, sc = 0, tb = 0, sta_id[KS];
     bool valid = false, tile = false;
@@ -2773,6 +2819,22 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
+#if GENIE_TUNING
+    {   // per-wave phase timers of k_stage2_fast (GENIE_ABLATE bit 10): dumped to stderr by the host after a sync
+        static float* tbuf = nullptr;
+        if (!tbuf) { HIP_TRY(hipMalloc((void**)&tbuf, sizeof(float) * 8 * 4 * 4096)); HIP_TRY(hipMemset(tbuf, 0, sizeof(float) * 8 * 4 * 4096)); }
+        a.dbg_h0 = tbuf;
+        if (getenv("GENIE_DUMP_PHASES")) {
+            HIP_TRY(hipDeviceSynchronize());
+            std::vector<float> hbuf(8 * 4 * 4096);
+            HIP_TRY(hipMemcpy(hbuf.data(), tbuf, sizeof(float) * hbuf.size(), hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0}; int n = 0;
+            for (int wv = 0; wv < 4 * 4096; ++wv) if (hbuf[wv * 8] > 0) { for (int k = 0; k < 5; ++k) sum[k] += hbuf[wv * 8 + k]; ++n; }
+            if (n) fprintf(stderr, "[stage2 phases, avg memtime ticks per wave over %d waves] wait+loop %.0f sums %.0f issue+ids %.0f prelu+mfma %.0f reduce+store %.0f\n",
+                           n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+        }
+    }
+#endif
     if (c->use_b3 && !c->nob3s2) {
         a.packed = c->packed_b3s2;
         k_stage2_b3<8, 15><<<da_grid(c, ((long long)c->G * c->T + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
