@@ -2426,6 +2426,7 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
+    int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
     int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
@@ -2686,9 +2687,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // bf16x3 stage 1: same graph shape, 32-bit byte offsets into the 48-B input rows, 24-bit multiplicands
         c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * XROW < (1ll << 32) && n_grid_ext < (1 << 24) &&
                      (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
-        // station-tile-major sweeps over segments of 512 source nodes keep the neighbour rows of a segment in L2
-        // (tools/tune.py: k_stage1_b3 0.51 -> 0.47 ms at config 2; the fp32 kernels did not care)
-        if (c->use_b3 && !getenv("GENIE_SEG")) c->seg = 512;
+        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 1;
         // k_stage2_b3 is no faster than k_stage2_fast (stage 2 is bound by L2-miss traffic, not by its arithmetic) and its 240
         // VGPRs leave no room for the G-sized tail kernels of the previous window: opt-in only (GENIE_S2=b3)
         c->nob3s2 = ((e = getenv("GENIE_S2")) && strcmp(e, "b3") == 0) ? 0 : 1;
@@ -2785,7 +2784,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
         a.xs = xs; a.packed = c->packed_b3;
-        k_stage1_b3<8, 15><<<da_grid_w(c, ((long long)c->G * c->T + 1) / 2, 1, B3_THREADS / 64), B3_THREADS, 0, st>>>(a);
+        k_stage1_b3<8, 15><<<da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64), B3_THREADS, 0, st>>>(a);
     } else if (c->use_fast)
         k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     else
