@@ -93,6 +93,8 @@ enum {
     W_TA_Q1_W, W_TA_Q1_B, W_TA_Q2_W, W_TA_Q2_B, W_TA_C1_W, W_TA_C1_B, W_TA_C2_W, W_TA_C2_B, W_TA_V1_W, W_TA_V1_B,
     W_TA_V2_W, W_TA_V2_B, W_TA_P1_W, W_TA_P1_B, W_TA_P2_W, W_TA_P2_B, W_TA_ACT1, W_TA_ACT2, W_TA_ACT3, W_TA_ACT4, W_TA_ACT5,
     W_SAT_Q_W, W_SAT_Q_B, W_SAT_C_W, W_SAT_C_B, W_SAT_V_W, W_SAT_V_B, W_SAT_P_W, W_SAT_P_B, W_SAT_ACT1, W_SAT_ACT2,
+    // DataAggregationEdges (module.py:102-174): the 4 edge-feature columns of l1_t?_2 / l2_t?_2 (zero for DataAggregation)
+    W_DA_L1T12_P, W_DA_L1T22_P, W_DA_L2T12_P, W_DA_L2T22_P,
     W_COUNT
 };
 
@@ -143,6 +145,8 @@ Param g_params[W_COUNT] = {
     {"SpatialAttention.f_values.weight", 75 * 33, 0}, {"SpatialAttention.f_values.bias", 75, 0},
     {"SpatialAttention.proj.weight", 30 * 15, 0}, {"SpatialAttention.proj.bias", 30, 0},
     {"SpatialAttention.activate1.weight", 1, 0}, {"SpatialAttention.activate2.weight", 1, 0},
+    {"DataAggregation.l1_t1_2.weight_pos", 30 * 4, 0}, {"DataAggregation.l1_t2_2.weight_pos", 30 * 4, 0},
+    {"DataAggregation.l2_t1_2.weight_pos", 15 * 4, 0}, {"DataAggregation.l2_t2_2.weight_pos", 15 * 4, 0},
 };
 
 int g_raw_total = 0;
@@ -499,6 +503,8 @@ struct DaArgs {
     float* dbg_h0; float* dbg_h1;  // optional parity outputs [P,30] / [P,60]
     const float* packed;       // packed A fragments for the stage
     const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
+    const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
+    const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
 };
 
@@ -683,8 +689,8 @@ __device__ __forceinline__ void mma_blocks(f32x4 (&acc)[N], const f32x4 (&w)[N],
 // dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
 // projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
 __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, const float* lbias, int lane, int q,
-                                             bool valid, long long p, float mq, f32x4 x0, f32x4 x1, f32x4 n1a, f32x4 n1b,
-                                             f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
+                                             bool valid, long long p, int g, int sc, float mq, f32x4 x0, f32x4 x1, f32x4 n1a,
+                                             f32x4 n1b, f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
     if (a.dbg_h0 != nullptr && valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -696,6 +702,13 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
     f32x4 acc[4], w4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + (2 + k) * 16 + 4 * q);
+    if (a.eb_sta != nullptr) {   // DataAggregationEdges: the mean edge feature of a node is static, its Linear a per-node bias
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc[t] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 16 * t + 4 * q);
+            acc[2 + t] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 16 * t + 4 * q);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane];
     mma_blocks<4>(acc, w4, x0);
@@ -738,6 +751,10 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
     for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
     o6[4] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
     o6[5] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
+    if (a.eb_sta != nullptr) {
+        o6[4] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 4 * q);
+        o6[5] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 4 * q);
+    }
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }
-        stage1_dense(a, lw, lbias, lane, q, valid, p, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+        stage1_dense(a, lw, lbias, lane, q, valid, p, g, sc, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
     }
 }
 
@@ -1007,7 +1024,7 @@ __device__ __forceinline__ void stage1_fast_loop(const DaArgs& a, const f32x4* l
             }
         }
         // (5) dense tail + stores of this tile
-        stage1_dense(a, lw, lbias, lane, q, valid_c, (long long)g_c * S + sc_c, om_c, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+        stage1_dense(a, lw, lbias, lane, q, valid_c, (long long)g_c * S + sc_c, g_c, sc_c, om_c, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
         if (!has_next) break;
         g_c = g_n; sc_c = sc_n; valid_c = valid_n; srcv_c = srcv_n; os_c = os_n; om_c = om_n;
 #pragma unroll
@@ -1179,7 +1196,7 @@ __device__ __forceinline__ void mma6(f32x16 (&acc)[N], const f32x4* lw, const in
         for (int k = 0; k < N; ++k) acc[k] = MFMA32(w[k][WP[t]], b[BP[t]], acc[k]);
 }
 
-template <int KS, int KP>
+template <int KS, int KP, bool EDGES>
 __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     constexpr int NF4 = B3_IMG_FLOATS / 4;
     __shared__ f32x4 lw[NF4];
@@ -1323,6 +1340,15 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         }
         // ---- layer 1: tr_t = l1_t{1,2}_2 [h0 || n_t || Mask], both halves at once
         f32x16 acc[2] = {bias16(lbias, 1, h), bias16(lbias, 2, h)};
+        if (EDGES) {   // DataAggregationEdges: static per-station / per-source-node terms of layer 1
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[0][4 * b + e] += es[e]; acc[1][4 * b + e] += eg[e]; }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int f0[2] = {B3_FL1 + (0 * 4 + ks) * 3, B3_FL1 + (1 * 4 + ks) * 3};
@@ -1354,6 +1380,15 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         }
         // ---- u, v and the node-local layer-2 terms c from h1 = [h1a (30) | M0 M1 | h1b (30) | M2 M3]
         f32x16 o3[3] = {bias16(lbias, 3, h), bias16(lbias, 4, h), bias16(lbias, 5, h)};
+        if (EDGES) {   // ... and of the node-local layer-2 block c = [o1 (15), 0 | o2 (15), 0]
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o3[2][4 * b + e] += es[e]; o3[2][8 + 4 * b + e] += eg[e]; }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             u32x4 hp[2][3];
@@ -2378,6 +2413,43 @@ __global__ void k_embed_gather(EmbArgs a) {
 }
 
 // de-pad rows of a workspace tensor for parity tests
+// DataAggregationEdges (module.py:102-174, forward :1059-1072): every message carries phi(pos_j - pos_i) (3) and phi(|pos_j - pos_i|),
+// phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)); after mean aggregation that is a STATIC 4-vector per node of a base graph.
+__global__ void k_edge_feat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int n,
+                            const float* __restrict__ pos, float scale_rel, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int eb = rowptr[i], ee = rowptr[i + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float inv = 1.f / (scale_rel * scale_rel);
+    for (int e = eb; e < ee; ++e) {
+        const int j = col[e];
+        float d[4];
+        d[0] = pos[j * 3] - pos[i * 3]; d[1] = pos[j * 3 + 1] - pos[i * 3 + 1]; d[2] = pos[j * 3 + 2] - pos[i * 3 + 2];
+        d[3] = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = d[k] > 0.f ? 1.f : (d[k] < 0.f ? -1.f : 0.f);
+            acc[k] += sg * expf(-0.5f * d[k] * d[k] * inv);
+        }
+    }
+    const float w = ee > eb ? 1.f / (float)(ee - eb) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[i * 4 + k] = acc[k] * w;
+}
+// ... and its Linear a per-node additive term: row n = {W1pos (30x4) m_n, 0, 0, W2pos (15x4) m_n, 0}
+__global__ void k_edge_bias(const float* __restrict__ raw, int off1, int off2, const float* __restrict__ mpos, int n,
+                            float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 48) return;
+    const int i = idx / 48, ch = idx - i * 48;
+    const float* m = mpos + i * 4;
+    float v = 0.f;
+    if (ch < 30) { const float* wr = raw + off1 + ch * 4; v = wr[0] * m[0] + wr[1] * m[1] + wr[2] * m[2] + wr[3] * m[3]; }
+    else if (ch >= 32 && ch < 47) { const float* wr = raw + off2 + (ch - 32) * 4; v = wr[0] * m[0] + wr[1] * m[1] + wr[2] * m[2] + wr[3] * m[3]; }
+    out[idx] = v;
+}
+
 #if GENIE_TUNING
 // which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
 __global__ void k_xcc_probe(int* __restrict__ out) {
@@ -2417,6 +2489,8 @@ struct genie_ctx {
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
     float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
+    float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
+    bool has_edges;
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
     float* packed_b3;          // bf16x3 weight image of k_stage1_b3
     int num_cu;
@@ -2486,6 +2560,12 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
                                                                                B3_NBIAS * 32 + 16);
     k_pack_b3<<<(B3S2_FRAGS * 64 + 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl2, c->packed_b3s2, B3S2_FRAGS, 32 + 16);
     k_pack_t<<<8, 256, 0, st>>>(c->raw, c->d_tdesc, c->n_tdesc, c->ro_img);
+    if (c->has_edges) {
+        k_edge_bias<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
+                                                            c->mpos_sta, c->S, c->ebias_sta);
+        k_edge_bias<<<(c->G * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T22_P].off, g_params[W_DA_L2T22_P].off,
+                                                            c->mpos_src, c->G, c->ebias_src);
+    }
     HIP_TRY(hipGetLastError());
     c->dirty = false;
     return GENIE_OK;
@@ -2513,6 +2593,8 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
     a.src_tab = c->src_tab;
+    a.eb_sta = c->has_edges ? c->ebias_sta : nullptr;
+    a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
@@ -2616,6 +2698,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMemcpy(c->d_b3tbl2, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_b3s2, sizeof(float) * B3S2_IMG_FLOATS));
     }
+    c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
+    c->has_edges = false;
     c->src_tab = nullptr;
     if (c->kp_uni == 15) {
         std::vector<int32_t> ord(n_grid), col((size_t)e_src), tab((size_t)n_grid * 16);
@@ -2709,6 +2793,27 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     return GENIE_OK;
 }
 
+int genie_set_edge_features(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_edge_features: null context");
+    hipStream_t st = (hipStream_t)stream;
+    if (!pos_sta || !pos_src) {      // back to plain DataAggregation
+        c->has_edges = false;
+        return GENIE_OK;
+    }
+    if (!c->mpos_sta) {
+        HIP_TRY(hipMalloc((void**)&c->mpos_sta, sizeof(float) * 4 * (size_t)c->S));
+        HIP_TRY(hipMalloc((void**)&c->mpos_src, sizeof(float) * 4 * (size_t)c->G));
+        HIP_TRY(hipMalloc((void**)&c->ebias_sta, sizeof(float) * 48 * (size_t)c->S));
+        HIP_TRY(hipMalloc((void**)&c->ebias_src, sizeof(float) * 48 * (size_t)c->G));
+    }
+    k_edge_feat<<<(c->S + 255) / 256, 256, 0, st>>>(c->sta_rowptr, c->sta_col, c->S, pos_sta, c->scale_rel, c->mpos_sta);
+    k_edge_feat<<<(c->G + 255) / 256, 256, 0, st>>>(c->src_rowptr, c->src_col, c->G, pos_src, c->scale_rel, c->mpos_src);
+    HIP_TRY(hipGetLastError());
+    c->has_edges = true;
+    c->dirty = true;
+    return GENIE_OK;
+}
+
 int genie_set_scale_t(genie_ctx* c, float scale_t) {
     if (!c || !(scale_t > 0.f)) return fail(GENIE_ERR_ARG, "genie_set_scale_t: bad argument");
     c->scale_t = scale_t;
@@ -2731,7 +2836,8 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
-                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2};
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
+                    c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -2784,7 +2890,9 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
         a.xs = xs; a.packed = c->packed_b3;
-        k_stage1_b3<8, 15><<<da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64), B3_THREADS, 0, st>>>(a);
+        const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
+        if (c->has_edges) k_stage1_b3<8, 15, true><<<grid, B3_THREADS, 0, st>>>(a);
+        else k_stage1_b3<8, 15, false><<<grid, B3_THREADS, 0, st>>>(a);
     } else if (c->use_fast)
         k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     else

@@ -132,6 +132,9 @@ class HipPath(object):
         with torch.no_grad():
             for name, n, off in zip(self.w_names, self.w_numel, self.w_off):
                 if name not in named_tensors:
+                    if name.endswith(".weight_pos"):      # DataAggregationEdges columns: absent = plain DataAggregation
+                        self._blob[off:off + n].zero_()
+                        continue
                     raise KeyError("missing parameter %s" % name)
                 t = named_tensors[name]
                 if t.numel() != n:
@@ -140,11 +143,12 @@ class HipPath(object):
         _lib.check(self.lib.genie_weights_set_blob(self.ctx, _ptr(self._blob), self._blob.numel(), _stream()),
                    "genie_weights_set_blob")
 
-    def sync_weights(self, params):
-        """Re-upload only when any of the parameter tensors changed (data_ptr / in-place version)."""
+    def sync_weights(self, params, view=None):
+        """Re-upload only when any of the parameter tensors changed (data_ptr / in-place version). `view` maps the
+        state_dict-named tensors to the registry's names / layouts when they differ (DataAggregationEdges)."""
         key = tuple((p.data_ptr(), p._version) for p in params.values())
         if key != self._w_key:
-            self.set_weights(params)
+            self.set_weights(view(params) if view is not None else params)
             self._w_key = key
 
     # ---- stages --------------------------------------------------------------------------------
@@ -263,6 +267,17 @@ class HipPath(object):
         _lib.check(self.lib.genie_readout_query(self.ctx, _ptr(x_spatial), _ptr(x_grid), _ptr(x_query), _ptr(knn_idx), nq, 10,
                                                 _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
         return out
+
+    def set_edge_features(self, pos_sta, pos_src):
+        """DataAggregationEdges (module.py:102-174): station / source-node positions [n,3] from which the library derives
+        the mean edge features; `None, None` switches back to plain DataAggregation (genie_set_edge_features)."""
+        if pos_sta is None or pos_src is None:
+            _lib.check(self.lib.genie_set_edge_features(self.ctx, None, None, _stream()), "genie_set_edge_features")
+            return
+        pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
+        pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
+        _lib.check(self.lib.genie_set_edge_features(self.ctx, _ptr(pos_sta), _ptr(pos_src), _stream()), "genie_set_edge_features")
+        torch.cuda.current_stream(self.device).synchronize()     # the position tensors may be temporaries
 
     def set_scale_t(self, scale_t):
         _lib.check(self.lib.genie_set_scale_t(self.ctx, ctypes.c_float(float(scale_t))), "genie_set_scale_t")

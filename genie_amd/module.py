@@ -63,6 +63,44 @@ class DataAggregation(nn.Module):
         self.activate2 = nn.PReLU()
 
 
+class DataAggregationEdges(nn.Module):
+    """Parameters of the `use_updated_model_definition: True` variant (module.py:102-174): as DataAggregation, but every
+    message carries 4 edge features, so l1_t?_2 is [30, 68] and l2_t?_2 is [15, 98] (columns: node, neighbour mean, EDGE
+    FEATURES, Mask). Same state_dict keys and shapes as the reference class; computed by libgenie_hip."""
+
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4, ndim_proj=3):
+        super().__init__()
+        ne = ndim_proj + 1
+        self.activate = nn.PReLU()
+        self.init_trns = nn.Linear(in_channels + n_dim_mask, n_hidden)
+        self.l1_t1_1 = nn.Linear(n_hidden, n_hidden)                                  # unused by forward (module.py:157)
+        self.l1_t1_2 = nn.Linear(2 * n_hidden + n_dim_mask + ne, n_hidden)
+        self.l1_t2_1 = nn.Linear(in_channels, n_hidden)                               # unused
+        self.l1_t2_2 = nn.Linear(2 * n_hidden + n_dim_mask + ne, n_hidden)
+        self.activate11 = nn.PReLU()
+        self.activate12 = nn.PReLU()
+        self.activate1 = nn.PReLU()
+        self.l2_t1_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t1_2 = nn.Linear(3 * n_hidden + n_dim_mask + ne, out_channels)
+        self.l2_t2_1 = nn.Linear(2 * n_hidden, n_hidden)
+        self.l2_t2_2 = nn.Linear(3 * n_hidden + n_dim_mask + ne, out_channels)
+        self.activate21 = nn.PReLU()
+        self.activate22 = nn.PReLU()
+        self.activate2 = nn.PReLU()
+
+
+def _split_edge_columns(named):
+    """Registry view of DataAggregationEdges weights: the edge-feature columns of l?_t?_2 go to `<name>_pos`, the rest
+    keeps the DataAggregation column layout (include/genie_hip.h, genie_set_edge_features)."""
+    out = dict(named)
+    for lay, n_in in (("l1_t1_2", 60), ("l1_t2_2", 60), ("l2_t1_2", 90), ("l2_t2_2", 90)):
+        k = "DataAggregation.%s.weight" % lay
+        W = named[k].detach()
+        out[k] = torch.cat((W[:, :n_in], W[:, n_in + 4:]), dim=1).contiguous()
+        out[k + "_pos"] = W[:, n_in:n_in + 4].contiguous()
+    return out
+
+
 class BipartiteGraphOperator(nn.Module):
     """Parameters of reference `BipartiteGraphOperator` (module.py:215-222)."""
 
@@ -238,21 +276,22 @@ class DataAggregationAssociationPhase(nn.Module):
     """Association head, module.py:356-403: the dual-graph aggregation of DataAggregation on a 50-channel input, with
     l1_t1_1 / l1_t2_1 applied (module.py:395-396). Structured form on the Cartesian product (base kNN tables)."""
 
-    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5):
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5, n_edge=0):
         super().__init__()
+        # n_edge = 4 under use_updated_model_definition: edge-feature columns of l?_t?_2 (module.py:416-423)
         self.activate = nn.PReLU()
         self.init_trns = nn.Linear(in_channels + n_dim_latent + n_dim_mask, n_hidden)
         self.l1_t1_1 = nn.Linear(n_hidden, n_hidden)
-        self.l1_t1_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.l1_t1_2 = nn.Linear(2 * n_hidden + n_dim_mask + n_edge, n_hidden)
         self.l1_t2_1 = nn.Linear(n_hidden, n_hidden)
-        self.l1_t2_2 = nn.Linear(2 * n_hidden + n_dim_mask, n_hidden)
+        self.l1_t2_2 = nn.Linear(2 * n_hidden + n_dim_mask + n_edge, n_hidden)
         self.activate11 = nn.PReLU()
         self.activate12 = nn.PReLU()
         self.activate1 = nn.PReLU()
         self.l2_t1_1 = nn.Linear(2 * n_hidden, n_hidden)
-        self.l2_t1_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.l2_t1_2 = nn.Linear(3 * n_hidden + n_dim_mask + n_edge, out_channels)
         self.l2_t2_1 = nn.Linear(2 * n_hidden, n_hidden)
-        self.l2_t2_2 = nn.Linear(3 * n_hidden + n_dim_mask, out_channels)
+        self.l2_t2_2 = nn.Linear(3 * n_hidden + n_dim_mask + n_edge, out_channels)
         self.activate21 = nn.PReLU()
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
@@ -377,11 +416,15 @@ class GCN_Detection_Network_extended(nn.Module):
     supported by the kernels and raises.
     """
 
-    def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda"):
+    def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
+                 use_updated_model_definition=False):
         super().__init__()
         if use_absolute_pos:
             raise NotImplementedError("use_absolute_pos=True is not supported by the HIP path")
-        self.DataAggregation = DataAggregation(4, 15).to(device)
+        # config.yaml:95. True = the class of module.py:1022-1185: DataAggregationEdges on the hot path; its
+        # `forward_fixed_source` is served here, its 4-output `forward` / `forward_fixed` (different association heads) are not
+        self.use_updated_model_definition = bool(use_updated_model_definition)
+        self.DataAggregation = (DataAggregationEdges(4, 15) if self.use_updated_model_definition else DataAggregation(4, 15)).to(device)
         self.Bipartite_ReadIn = BipartiteGraphOperator(30, 15, ndim_edges=3).to(device)
         self.SpatialAggregation1 = SpatialAggregation(15, 30, scale_rel=scale_rel).to(device)
         self.SpatialAggregation2 = SpatialAggregation(30, 30, scale_rel=scale_rel).to(device)
@@ -390,7 +433,8 @@ class GCN_Detection_Network_extended(nn.Module):
         self.SpatialAttention = SpatialAttention(30, 30, 3, 15, scale_rel=scale_rel).to(device)
         self.TemporalAttention = TemporalAttention(30, 1, 15).to(device)
         self.BipartiteGraphReadOutOperator = BipartiteGraphReadOutOperator(30, 15).to(device)
-        self.DataAggregationAssociationPhase = DataAggregationAssociationPhase(15, 15).to(device)
+        self.DataAggregationAssociationPhase = DataAggregationAssociationPhase(
+            15, 15, n_edge=4 if self.use_updated_model_definition else 0).to(device)
         self.LocalSliceLgCollapseP = LocalSliceLgCollapse(30, 15).to(device)
         self.LocalSliceLgCollapseS = LocalSliceLgCollapse(30, 15).to(device)
         self.Arrivals = StationSourceAttentionMergedPhases(30, 15, 2, 15, n_heads=3).to(device)
@@ -403,13 +447,17 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr = None
 
     # ---- graphs --------------------------------------------------------------------------------
-    def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src):
+    def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         order = _engine.morton_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev)
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        if self.use_updated_model_definition:
+            if pos_loc is None or pos_src is None:
+                raise ValueError("use_updated_model_definition=True needs station and source positions")
+            self._hip.set_edge_features(pos_loc.to(dev), pos_src.to(dev))                 # module.py:1102-1111
 
     def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                         A_edges_s, dt_partition, tlatent, pos_loc, pos_src):
@@ -426,7 +474,7 @@ class GCN_Detection_Network_extended(nn.Module):
         src_csr = _engine.csr_from_table(src_nbr)
         if not (torch.equal(src_from_A[0], src_csr[0]) and torch.equal(src_from_A[1], src_csr[1])):
             raise ValueError("A_src is not the base graph of A_in_src")
-        self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src)
+        self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
         dev = self._edge_attr.device
         self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
@@ -437,14 +485,14 @@ class GCN_Detection_Network_extended(nn.Module):
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
         self.A_src = torch.as_tensor(A_src_src)
         self._build_engine(_engine.csr_from_edges(A_sta_sta, n_sta), _engine.csr_from_edges(A_src_src, n_grid),
-                           n_sta, n_grid, pos_src)
+                           n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
 
     # ---- hot path ------------------------------------------------------------------------------
     def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params)
+        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else None)
         return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
 
     def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
@@ -464,7 +512,7 @@ class GCN_Detection_Network_extended(nn.Module):
         y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params)
+        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else None)
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
 
@@ -473,6 +521,9 @@ class GCN_Detection_Network_extended(nn.Module):
         """module.py:963-997: (y, x, arv_p, arv_s). The shared front (DataAggregation -> Bipartite_ReadIn ->
         SpatialAggregation1..3 and the two read-outs) runs in HIP; the association heads (pick-count
         dependent, host-built edge lists) are a PyTorch-ROCm restatement of module.py:333-775."""
+        if self.use_updated_model_definition:
+            raise NotImplementedError("the 4-output forward of the use_updated_model_definition class (module.py:1128-1161) "
+                                      "has different association heads; only forward_fixed_source is provided")
         S, G = self._hip.n_sta, self._hip.n_grid
         x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)      # :973-977
         y_latent = self.SpatialDirect(x_spatial)                                                     # :978

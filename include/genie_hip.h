@@ -74,6 +74,15 @@ int genie_set_slot(genie_ctx* ctx, int slot);
 int genie_set_tail_mode(genie_ctx* ctx, int slim);
 /* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
 int genie_set_scale_t(genie_ctx* ctx, float scale_t);
+/* DataAggregationEdges variant (`use_updated_model_definition: True`, config.yaml:95; module.py:102-174): every message is
+ * [x_j || phi(pos_j - pos_i) || phi(|pos_j - pos_i|)], phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)) (forward :1059-1072,
+ * set_adjacencies :1102-1111). On the product graph the mean of those 4 edge features is a static vector per station
+ * (station graph) / per source node (source graph); the library computes them from the positions ([n_sta,3] and
+ * [n_grid_ext,3] device pointers, fp32) and applies the 4 edge-feature columns of l1_t?_2 / l2_t?_2 (registry entries
+ * "DataAggregation.l?_t?_2.weight_pos", [out,4]) as per-node additive terms. The other columns keep the DataAggregation
+ * layout: the caller passes `l1_t?_2.weight[:, [0:60, 64:68]]` and `l2_t?_2.weight[:, [0:90, 94:98]]` under the usual names.
+ * Null positions switch back to plain DataAggregation. */
+int genie_set_edge_features(genie_ctx* ctx, const float* pos_sta, const float* pos_src, void* stream);
 
 /*
  * Weight mirror. Parameter names are the reference's state_dict keys (e.g. "DataAggregation.l1_t1_2.weight",

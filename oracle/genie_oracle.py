@@ -87,6 +87,43 @@ def data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, pre="DataAggregation", 
     return x_latent
 
 
+def edge_pos_features(pos, edge_index, node_of=None, scale_rel=SCALE_REL):
+    """Edge features of the `use_updated_model_definition` variant (module.py:1059-1072 / :1102-1111): for an edge j -> i,
+    d = pos[j] - pos[i] (3), |d| (1), each through phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)). `node_of` maps product
+    nodes to base nodes (A_src_in_sta[0] for stations, [1] for source nodes)."""
+    j, i = edge_index[0], edge_index[1]
+    if node_of is not None:
+        j, i = node_of[j], node_of[i]
+    rel = pos[j] - pos[i]
+    rel = torch.cat((rel, torch.norm(rel, dim=1, keepdim=True)), dim=1)
+    return torch.sign(rel) * torch.exp(-0.5 * (rel ** 2) / (scale_rel ** 2))
+
+
+def propagate_mean_edges(x, edge_attr, edge_index):
+    """MessagePassing('mean') whose message is cat(x_j, edge_attr) (module.py:162-172)."""
+    return scatter_mean(torch.cat((x[edge_index[0]], edge_attr), dim=1), edge_index[1], x.shape[0])
+
+
+def data_aggregation_edges(w, Slice, Mask, A_in_sta, A_in_src, pos_rel_sta, pos_rel_src, pre="DataAggregation", full=False):
+    """DataAggregationEdges.forward (module.py:141-160): l1_t?_2 [30,68] and l2_t?_2 [15,98] see
+    cat(node, mean_j cat(x_j, edge features), Mask)."""
+    tr = torch.cat((Slice, Mask), dim=-1)                                                          # :143
+    h0 = act(linear(tr, w, pre + ".init_trns"), w, pre + ".activate")                              # :144
+    n1 = propagate_mean_edges(act(h0, w, pre + ".activate11"), pos_rel_sta, A_in_sta)              # :157
+    n2 = propagate_mean_edges(act(h0, w, pre + ".activate12"), pos_rel_src, A_in_src)              # :158
+    tr1 = linear(torch.cat((h0, n1, Mask), dim=1), w, pre + ".l1_t1_2")
+    tr2 = linear(torch.cat((h0, n2, Mask), dim=1), w, pre + ".l1_t2_2")
+    h1 = act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate1")                                  # :159
+    u = act(linear(h1, w, pre + ".l2_t1_1"), w, pre + ".activate21")
+    v = act(linear(h1, w, pre + ".l2_t2_1"), w, pre + ".activate22")
+    o1 = linear(torch.cat((h1, propagate_mean_edges(u, pos_rel_sta, A_in_sta), Mask), dim=1), w, pre + ".l2_t1_2")   # :161
+    o2 = linear(torch.cat((h1, propagate_mean_edges(v, pos_rel_src, A_in_src), Mask), dim=1), w, pre + ".l2_t2_2")   # :162
+    x_latent = act(torch.cat((o1, o2), dim=1), w, pre + ".activate2")                              # :163
+    if full:
+        return {"h0": h0, "h1": h1, "u": u, "v": v, "x_latent": x_latent}
+    return x_latent
+
+
 def _gather_mean_sta(x3, sta_nbr):
     """x3 [G,S,C]; mean over station neighbours within the same source node: [G,S,C]."""
     if sta_nbr.shape[1] == 0:
@@ -231,9 +268,13 @@ def spatial_attention(w, inpts, x_query, x_context, k=10, pre="SpatialAttention"
 # a-4  forward_fixed_source  (module.py:999-1020)
 # ----------------------------------------------------------------------------------------------
 def forward_fixed_source(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src,
-                         x_grid_cart, x_query_cart, t_query, full=False, query_edges=None):
-    """Literal formulation. `use_absolute_pos=False` (config.yaml:92). Returns (y, x) or a dict."""
-    da = data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, full=True)                         # :1010
+                         x_grid_cart, x_query_cart, t_query, full=False, query_edges=None, pos_rel=None):
+    """Literal formulation. `use_absolute_pos=False` (config.yaml:92). Returns (y, x) or a dict. `pos_rel` =
+    (pos_rel_sta, pos_rel_src) selects the DataAggregationEdges variant (module.py:1163-1185)."""
+    if pos_rel is not None:
+        da = data_aggregation_edges(w, Slice, Mask, A_in_sta, A_in_src, pos_rel[0], pos_rel[1], full=True)
+    else:
+        da = data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, full=True)                     # :1010
     bip = bipartite_read_in(w, da["x_latent"], edge_attr, A_src_in_prod, Mask)                   # :1011
     sa1 = spatial_aggregation(w, bip, A_src, x_grid_cart, "SpatialAggregation1")                 # :1012
     sa2 = spatial_aggregation(w, sa1, A_src, x_grid_cart, "SpatialAggregation2")                 # :1013

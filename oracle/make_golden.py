@@ -20,13 +20,27 @@ REF_CODE = "/root/reference/Code"
 OUT = os.path.join(REPO, "tests", "golden")
 
 
-def _import_reference():
+def _import_reference(updated_definition=False):
     sys.dont_write_bytecode = True
     sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
     sys.path.insert(0, REF_CODE)
     sys.path.insert(0, REPO)
-    os.chdir(REF_CODE)            # module.py:27-31 reads config.yaml / train_config.yaml from the CWD
+    cwd = REF_CODE                # module.py:27-31 reads config.yaml / train_config.yaml from the CWD
+    if updated_definition:
+        # `use_updated_model_definition` is read from config.yaml at import time (module.py:33): import the reference from a
+        # scratch directory holding its YAML files with that one flag flipped
+        import tempfile
+        cwd = tempfile.mkdtemp(prefix="genie_cfg_")
+        for f in os.listdir(REF_CODE):
+            if f.endswith(".yaml"):
+                txt = open(os.path.join(REF_CODE, f)).read()
+                if f == "config.yaml":
+                    assert "use_updated_model_definition: False" in txt
+                    txt = txt.replace("use_updated_model_definition: False", "use_updated_model_definition: True")
+                open(os.path.join(cwd, f), "w").write(txt)
+    os.chdir(cwd)
     import module as ref_module   # noqa: E402
+    assert bool(ref_module.use_updated_model_definition) == bool(updated_definition)
     return ref_module
 
 
@@ -206,7 +220,25 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0):
 syn_VP, syn_VS = 6000.0, 3400.0
 
 
+def main_edges():
+    """`python oracle/make_golden.py --edges`: fixtures of the use_updated_model_definition class (DataAggregationEdges,
+    module.py:102-174 / :1022-1185); a separate process because the flag is fixed when the reference is imported."""
+    ref = _import_reference(updated_definition=True)
+    from genie_amd import synthetic as syn
+
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(12, 60, L=80e3, n_query=30, seed=91)          # uniform 8 / 15 degrees: the bf16x3 kernels apply
+    win = syn.make_window(geom, 150, seed=92)
+    run_case(ref, "edges_12x60", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win, keep64=("bip", "sa3"))
+    geom = syn.Geometry(7, 13, L=50e3, n_query=9, seed=93)            # ks = 6, kp = 12: generic CSR kernels
+    win = syn.make_window(geom, 40, seed=94)
+    run_case(ref, "edges_7x13", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
+
+
 def main():
+    if "--edges" in sys.argv:
+        return main_edges()
     ref = _import_reference()
     from genie_amd import synthetic as syn
 

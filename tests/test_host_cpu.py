@@ -25,6 +25,22 @@ def test_state_dict_keys_and_shapes_match_reference():
     net.load_state_dict({k: v.clone() for k, v in ref.items()}, strict=True)
 
 
+def test_state_dict_of_updated_model_definition_matches_reference():
+    """`use_updated_model_definition: True` (config.yaml:95): the fixture holds the state_dict of the reference class of
+    module.py:1022 (DataAggregationEdges: l1_t?_2 [30,68], l2_t?_2 [15,98])."""
+    c = Case("edges_12x60")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu", use_updated_model_definition=True)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(c.weights.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(c.weights[k].shape), k
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    view = module._split_edge_columns({k: v for k, v in c.weights.items()})
+    W = c.weights["DataAggregation.l2_t1_2.weight"]
+    assert torch.equal(view["DataAggregation.l2_t1_2.weight"], torch.cat((W[:, :90], W[:, 94:]), 1))
+    assert torch.equal(view["DataAggregation.l2_t1_2.weight_pos"], W[:, 90:94])
+
+
 def test_library_exports_every_declared_symbol(repo_root):
     _lib.build()
     lib = _lib.load()
@@ -38,9 +54,13 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert lib.genie_version() >= 100
     names = [lib.genie_weights_name(i).decode() for i in range(lib.genie_weights_count())]
     ref = Case("tiny_6x40").weights
+    edges = module._split_edge_columns(Case("edges_12x60").weights)      # registry view of the DataAggregationEdges weights
     for n_, i in zip(names, range(len(names))):
+        if n_.endswith(".weight_pos"):      # the 4 edge-feature columns of the use_updated_model_definition variant
+            assert edges[n_].numel() == lib.genie_weights_numel(i)
+            continue
         assert n_ in ref, n_
-        assert ref[n_].numel() == lib.genie_weights_numel(i)
+        assert ref[n_].numel() == lib.genie_weights_numel(i) == edges[n_].numel()
         assert lib.genie_weights_offset(i) % 4 == 0
 
 

@@ -4,7 +4,7 @@ intermediates and 1e-6 absolute on the outputs (y, x); fp64 tolerance 1e-12."""
 import pytest
 import torch
 
-from tests.util import GOLDEN_CASES, Case, max_abs
+from tests.util import EDGES_CASES, GOLDEN_CASES, Case, max_abs
 
 INTERMEDIATES = ["h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"]
 
@@ -45,3 +45,20 @@ def test_reference_fp32_vs_fp64_drift_is_small():
         c = Case(name)
         assert max_abs(c.ref("y"), c.ref("y64")) < 1e-6
         assert max_abs(c.ref("x"), c.ref("x64")) < 1e-6
+
+
+@pytest.mark.parametrize("name", EDGES_CASES)
+def test_oracle_edges_variant_matches_reference(name):
+    """`use_updated_model_definition: True` (config.yaml:95): DataAggregationEdges (module.py:102-174) inside
+    forward_fixed_source (module.py:1163-1185); fixtures from the reference imported with that flag set."""
+    c = Case(name)
+    assert c.edges_variant
+    out = c.oracle_forward(torch.float32)
+    for k in ["h0", "h1", "x_latent", "bip", "sa3", "y", "x"]:
+        if k in c.z.files:
+            ref = c.ref(k)
+            assert max_abs(c.strided(out[k]) if out[k].shape[0] == c.S * c.G else out[k], ref) <= 1e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
