@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -1196,8 +1197,10 @@ __device__ __forceinline__ void mma6(f32x16 (&acc)[N], const f32x4* lw, const in
         for (int k = 0; k < N; ++k) acc[k] = MFMA32(w[k][WP[t]], b[BP[t]], acc[k]);
 }
 
-template <int KS, int KP, bool EDGES>
+template <int KS, int KP, bool EDGES, bool BIG>
 __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
+    // byte offsets into the split rows: 32 bits (one VGPR per address, SGPR base) unless P x 48 B >= 4 GiB (BIG)
+    typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
     constexpr int NF4 = B3_IMG_FLOATS / 4;
     __shared__ f32x4 lw[NF4];
     for (int i = threadIdx.x; i < NF4; i += B3_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
@@ -1221,7 +1224,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     const char* xs = (const char*)a.xs;
     const unsigned la = hi ? 16u : 0u, lb = hi ? 0u : 32u;       // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]
-    const unsigned gstride = (unsigned)S * (unsigned)XROW;
+    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XROW);
 
     const f32x4 fa0 = lw[(B3_FA + 0) * 64 + lane], fa1 = lw[(B3_FA + 1) * 64 + lane], fa2 = lw[(B3_FA + 2) * 64 + lane];
     const f32x16 biasA = bias16(lbias, 0, h);
@@ -1250,7 +1253,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
         const int g = half ? g1 : g0;
         const long long p = (long long)g * S + sc;
-        unsigned gbase = (unsigned)g * gstride;                         // byte offset of source node g in xs
+        off_t_ gbase = (off_t_)(unsigned)g * gstride;                   // byte offset of source node g in xs
         unsigned sbase = (unsigned)sc * (unsigned)XROW;
         const int srcv = idv;
 
@@ -1260,14 +1263,14 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         constexpr int DEPTH = 4;
         u32x4 bufa[NU], bufb[NU];
         auto issue = [&](int u) {
-            unsigned off;
+            off_t_ off;
             if (u == 0) off = gbase + sbase;
             else if (u <= KS) off = gbase + __umul24((unsigned)sta_id[u - 1], (unsigned)XROW);
             else {
                 const int n0 = __builtin_amdgcn_readlane(srcv, u - KS), n1 = __builtin_amdgcn_readlane(srcv, 16 + u - KS);
-                off = __umul24((unsigned)(half ? n1 : n0), gstride) + sbase;
+                off = (BIG ? (off_t_)(unsigned)(half ? n1 : n0) * gstride : (off_t_)__umul24((unsigned)(half ? n1 : n0), (unsigned)gstride)) + sbase;
             }
-            const unsigned oa = off + la, ob = off + lb;      // 32-bit offsets from the uniform base (saddr addressing)
+            const off_t_ oa = off + la, ob = off + lb;        // offsets from the uniform base (saddr addressing when 32-bit)
             bufa[u] = *(const u32x4*)(xs + oa);
             bufb[u] = *(const u32x4*)(xs + ob);
         };
@@ -1588,17 +1591,19 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
             r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
             r.mq = a.mask[p * 4 + q + tk];
             r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
-            const unsigned gS = (unsigned)g * (unsigned)S;
+            // wave-uniform 64-bit row-block bases (SGPR pairs) + 32-bit lane offsets: safe for P x 64 B >= 4 GiB (config 4)
+            const char* wug = wub + (size_t)g * (size_t)S * 64u;
 #pragma unroll
             for (int k = 0; k < KS; ++k)
-                r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wub + ((gS + (unsigned)t.sta[k]) * 64u + q16 + tk));
+                r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wug + ((unsigned)t.sta[k] * 64u + q16 + tk));
         } else {
             const unsigned so = (unsigned)t.sc * 64u + q16 + tk;
             constexpr int KH = (KP + 1) / 2;
 #pragma unroll
-            for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k)
-                r.rv[k] = ABL(a, 1) ? r.o[1]
-                                    : *(const f32x4*)(wvb + ((unsigned)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((unsigned)S * 64u) + so));
+            for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k) {
+                const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((size_t)S * 64u);
+                r.rv[k] = ABL(a, 1) ? r.o[1] : *(const f32x4*)(wvk + so);
+            }
         }
     };
 #if GENIE_TUNING
@@ -2768,8 +2773,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
         c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
-        // bf16x3 stage 1: same graph shape, 32-bit byte offsets into the 48-B input rows, 24-bit multiplicands
-        c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * XROW < (1ll << 32) && n_grid_ext < (1 << 24) &&
+        // bf16x3 stage 1: same graph shape, 24-bit multiplicands (64-bit row offsets are a template variant)
+        c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && n_grid_ext < (1 << 24) &&
                      (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
         c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 1;
         // k_stage2_b3 is no faster than k_stage2_fast (stage 2 is bound by L2-miss traffic, not by its arithmetic) and its 240
@@ -2891,8 +2896,14 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
         a.xs = xs; a.packed = c->packed_b3;
         const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
-        if (c->has_edges) k_stage1_b3<8, 15, true><<<grid, B3_THREADS, 0, st>>>(a);
-        else k_stage1_b3<8, 15, false><<<grid, B3_THREADS, 0, st>>>(a);
+        const bool big = c->P_ext * XROW >= (1ll << 32);
+        if (c->has_edges) {
+            if (big) k_stage1_b3<8, 15, true, true><<<grid, B3_THREADS, 0, st>>>(a);
+            else k_stage1_b3<8, 15, true, false><<<grid, B3_THREADS, 0, st>>>(a);
+        } else {
+            if (big) k_stage1_b3<8, 15, false, true><<<grid, B3_THREADS, 0, st>>>(a);
+            else k_stage1_b3<8, 15, false, false><<<grid, B3_THREADS, 0, st>>>(a);
+        }
     } else if (c->use_fast)
         k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     else
@@ -2942,7 +2953,7 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
         }
     }
 #endif
-    if (c->use_b3 && !c->nob3s2) {
+    if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
         a.packed = c->packed_b3s2;
         k_stage2_b3<8, 15><<<da_grid(c, ((long long)c->G * c->T + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2)

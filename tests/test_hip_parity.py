@@ -252,6 +252,39 @@ def test_kernel_variants_agree(case, monkeypatch):
             assert max_abs(a_, b_) <= 0.2 * rel_tol(a_), (other, max_abs(a_, b_))     # 2e-6 x max(1, max|ref|)
 
 
+def test_rows_beyond_4gib_offsets(monkeypatch):
+    """Config-4 scale on one GPU: P x 48 B (split rows) and P x 64 B (wu / wv rows) both exceed 4 GiB, so the kernels that
+    address rows with 32-bit byte offsets must switch to their 64-bit forms (k_stage1_b3<.., BIG>, wave-uniform 64-bit row
+    bases in k_stage2_fast). Property: same result as the generic CSR kernels (64-bit arithmetic throughout)."""
+    S, G = 2000, 46000
+    assert S * G * 48 > 2 ** 32
+    geom = synthetic.Geometry(S, G, L=2000e3, n_query=5, seed=301)
+    sta = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
+    src = engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G)
+    w = {k: v.to(DEV) for k, v in Case("tiny_6x40").weights.items()}
+    g = torch.Generator(device=DEV).manual_seed(5)
+    P = S * G
+    Slice = torch.rand((P, 4), device=DEV, generator=g)
+    Mask = (torch.rand((P, 4), device=DEV, generator=g) < 0.3).float()
+    ea = torch.rand((P, 3), device=DEV, generator=g) - 0.5
+    res = {}
+    for name, env in (("generic", {"GENIE_S1": "f32", "GENIE_NOFAST": "1", "GENIE_NOFAST2": "1"}), ("fast_f32", {"GENIE_S1": "f32"}),
+                      ("default", {})):
+        for k in ("GENIE_S1", "GENIE_S2", "GENIE_NOFAST", "GENIE_NOFAST2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hp = engine.HipPath(S, G, sta, src, grid_order=engine.morton_order(geom.x_grid), device=DEV)
+        hp.set_weights(w)
+        hp.da_stage1(Slice, Mask)
+        _, bip = hp.da_stage2_bipartite(Mask, ea)
+        res[name] = bip.cpu()
+        del hp
+        torch.cuda.empty_cache()
+    assert torch.equal(res["generic"], res["fast_f32"])
+    assert max_abs(res["generic"], res["default"]) <= 0.2 * rel_tol(res["generic"]), max_abs(res["generic"], res["default"])
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")
