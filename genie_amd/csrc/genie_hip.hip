@@ -2772,7 +2772,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
-        c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
+        // k_stage1_fast addresses the 16-B Slice / Mask rows with 32-bit byte offsets
+        c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * 16 < (1ll << 32) && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
         // bf16x3 stage 1: same graph shape, 24-bit multiplicands (64-bit row offsets are a template variant)
         c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && n_grid_ext < (1 << 24) &&
                      (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
