@@ -1247,8 +1247,15 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     int idv = 0, sc = 0, sta_id[KS];
     bool valid = false;
     if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, valid, sta_id);
+#if GENIE_TUNING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define PH1(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
+#else
+#define PH1(k) do { } while (0)
+#endif
     for (long long pit = w.it; 2 * pit < w.nitems; pit += w.stride) {
         asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park all 75 in VGPRs)
+        PH1(0);
         const bool has_next = 2 * (pit + w.stride) < w.nitems;
         const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
         const int g = half ? g1 : g0;
@@ -1326,6 +1333,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_n[k] = 0;
         if (has_next) fetch_ids(pit + w.stride, idv_n, sc_n, valid_n, sta_n);
+        PH1(1);
         if (a.dbg_h0 != nullptr && valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1372,6 +1380,8 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         }
         acc[0] = prelu16(acc[0], a1, sel1);
         acc[1] = prelu16(acc[1], a1, sel1);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        PH1(2);
         if (a.dbg_h1 != nullptr && valid) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1413,6 +1423,8 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         }
         o3[0] = prelu16(o3[0], a21, sel21);
         o3[1] = prelu16(o3[1], a22, sel22);
+        asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
+        PH1(3);
         // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
         //      (the u K-steps only reach rows 0..14, the v K-steps rows 16..30: two independent accumulator chains)
         f32x16 ow[2];
@@ -1444,10 +1456,16 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
                     f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
             }
         }
+        PH1(4);
         idv = idv_n; sc = sc_n; valid = valid_n;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
     }
+#if GENIE_TUNING
+    if (ABL(a, 10) && a.x_latent != nullptr && (threadIdx.x & 63) == 0)      // x_latent is unused by stage 1: timer dump
+        for (int k = 0; k < 5; ++k) a.x_latent[(blockIdx.x * 8 + wave) * 8 + k] = (float)tph[k];
+#endif
+#undef PH1
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2892,6 +2910,22 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     DaArgs a = make_da_args(c, (float*)ws);
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
+#if GENIE_TUNING
+    static float* tbuf1 = nullptr;
+    if (c->use_b3 && a.abl & 1024) {   // per-wave phase timers of k_stage1_b3 (GENIE_ABLATE bit 10), dumped with GENIE_DUMP_PHASES
+        if (!tbuf1) { HIP_TRY(hipMalloc((void**)&tbuf1, sizeof(float) * 8 * 8 * 4096)); HIP_TRY(hipMemset(tbuf1, 0, sizeof(float) * 8 * 8 * 4096)); }
+        if (getenv("GENIE_DUMP_PHASES")) {
+            HIP_TRY(hipDeviceSynchronize());
+            std::vector<float> hbuf(8 * 8 * 4096);
+            HIP_TRY(hipMemcpy(hbuf.data(), tbuf1, sizeof(float) * hbuf.size(), hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0}; int n = 0;
+            for (int wv = 0; wv < 8 * 4096; ++wv) if (hbuf[wv * 8 + 1] > 0) { for (int k = 0; k < 5; ++k) sum[k] += hbuf[wv * 8 + k]; ++n; }
+            if (n) fprintf(stderr, "[stage1_b3 phases, avg memtime ticks per wave over %d waves] loop+ids %.0f neighbours %.0f layer1 %.0f uvc %.0f w+stores+fetch %.0f\n",
+                           n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+        }
+        a.x_latent = tbuf1;
+    }
+#endif
     if (c->use_b3) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
