@@ -51,8 +51,11 @@ FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--settle", type=int, default=600,
+                    help="untimed windows run during set-up, before the W warm-up steps: the GPU clocks need ~0.5 s of sustained "
+                         "load to settle (a cold start reads 5-10 %% slow for the first few hundred windows; DESIGN.md section 5)")
     ap.add_argument("--config", default="cfg2_200x10k", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
@@ -271,6 +274,9 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        for i in range(a.settle):       # set-up (clock settle), not part of the W warm-up or the K timed steps
+            step(i)
+        torch.cuda.synchronize()
         for i in range(a.warmup):
             step(i)
         barrier()
@@ -346,7 +352,7 @@ def main():
                                "graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
-        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline,
+        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "settle_windows": a.settle,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
