@@ -2795,7 +2795,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // bf16x3 stage 1: same graph shape, 24-bit multiplicands (64-bit row offsets are a template variant)
         c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && n_grid_ext < (1 << 24) &&
                      (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
-        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 1;
+        // 4 workgroups per CU in the grid, one resident: a workgroup held up by a tail kernel of the previous window then costs a
+        // quarter of a share, not a whole one (pipelined window 0.877 -> 0.866 ms; no effect on the kernel alone)
+        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 4;
         // k_stage2_b3 is no faster than k_stage2_fast (stage 2 is bound by L2-miss traffic, not by its arithmetic) and its 240
         // VGPRs leave no room for the G-sized tail kernels of the previous window: opt-in only (GENIE_S2=b3)
         c->nob3s2 = ((e = getenv("GENIE_S2")) && strcmp(e, "b3") == 0) ? 0 : 1;

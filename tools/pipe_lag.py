@@ -33,7 +33,7 @@ def main():
     d = torch.cdist(xq.double(), pos.double())
     knn = d.topk(10, largest=False).indices.int().contiguous()
     tq = torch.arange(-4.5, 5.0, 1.0, device=dev)[:10].float()
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SIDE_PRIO", "0")))
     main_s = torch.cuda.current_stream(dev)
     lib, ctx, ws = hp.lib, hp.ctx, hp._ws_ptr
 
