@@ -2473,6 +2473,45 @@ __global__ void k_edge_bias(const float* __restrict__ raw, int off1, int off2, c
     out[idx] = v;
 }
 
+// Neighbour means on the implicit product graph for arbitrary row widths (association heads, module.py:389-403):
+//   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))],   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]
+// rows of C = 4*C4 floats; C4 lanes per node, every lane keeps up to 8 row chunks in flight; sums in edge order.
+template <int C4>
+__global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
+                                                  const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
+                                                  const float* __restrict__ x_sta, const float* __restrict__ x_src,
+                                                  float* __restrict__ out_sta, float* __restrict__ out_src) {
+    constexpr int NPB_ = 256 / C4;
+    const int c4 = threadIdx.x % C4;
+    const long long P = (long long)S * G;
+    for (long long p = (long long)blockIdx.x * NPB_ + threadIdx.x / C4; p < P; p += (long long)gridDim.x * NPB_) {
+        const int g = (int)(p / S), s = (int)(p - (long long)g * S);
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const float* x = which == 0 ? x_sta : x_src;
+            float* out = which == 0 ? out_sta : out_src;
+            if (x == nullptr) continue;
+            const int32_t* col = which == 0 ? sta_col : src_col;
+            const int eb = which == 0 ? sta_rowptr[s] : src_rowptr[g], ee = which == 0 ? sta_rowptr[s + 1] : src_rowptr[g + 1];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int e0 = eb; e0 < ee; e0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = col[min(e0 + k, ee - 1)];
+                    const long long row = which == 0 ? (long long)g * S + j : (long long)j * S + s;
+                    v[k] = *(const f32x4*)(x + row * (4 * C4) + 4 * c4);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (e0 + k < ee) acc += v[k];
+            }
+            const float w = ee > eb ? 1.f / (float)(ee - eb) : 0.f;
+            *(f32x4*)(out + p * (4 * C4) + 4 * c4) = acc * w;
+        }
+    }
+}
+
 #if GENIE_TUNING
 // which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
 __global__ void k_xcc_probe(int* __restrict__ out) {
@@ -3228,6 +3267,24 @@ int genie_debug_xcc_map(int* out_dev, int nblocks, void* stream) {
     return GENIE_OK;
 }
 #endif
+
+int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* out_sta, float* out_src, int row_floats,
+                   void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_nbr_mean: null context");
+    if ((x_sta && !out_sta) || (x_src && !out_src)) return fail(GENIE_ERR_ARG, "genie_nbr_mean: input without output");
+    if (!x_sta && !x_src) return GENIE_OK;
+    const int nb = std::min<long long>((c->P + 31) / 32, (long long)c->num_cu * 16);
+    hipStream_t st = (hipStream_t)stream;
+#define GENIE_NM(C4_) k_nbr_mean<C4_><<<nb, 256, 0, st>>>(c->S, c->G, c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, x_sta, x_src, out_sta, out_src)
+    switch (row_floats) {
+        case 16: GENIE_NM(4); break;
+        case 32: GENIE_NM(8); break;
+        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean: row_floats must be 16 or 32");
+    }
+#undef GENIE_NM
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
 
 int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream) {
     int rc = check_ws(c, ws);

@@ -268,6 +268,31 @@ class HipPath(object):
                                                 _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
         return out
 
+    def nbr_mean(self, x_sta=None, x_src=None):
+        """Neighbour means over the product graph of [P, C] rows (C <= 32): (mean over station neighbours of x_sta, mean over
+        source neighbours of x_src); genie_nbr_mean on rows padded to 16 / 32 floats."""
+        outs = []
+        args = []
+        width = None
+        for x in (x_sta, x_src):
+            if x is None:
+                args += [None, None]
+                outs.append(None)
+                continue
+            x = _f32(x, "x")
+            C = x.shape[1]
+            w = 16 if C <= 16 else 32
+            if C > 32 or x.shape[0] != self.n_prod or (width is not None and w != width):
+                raise ValueError("nbr_mean: rows must be [n_prod, C <= 32] of one padded width")
+            width = w
+            xp = x if C == w else torch.nn.functional.pad(x, (0, w - C))
+            o = torch.empty_like(xp)
+            args += [xp, o]
+            outs.append((o, C))
+        _lib.check(self.lib.genie_nbr_mean(self.ctx, _ptr(args[0]), _ptr(args[2]), _ptr(args[1]), _ptr(args[3]), width, _stream()),
+                   "genie_nbr_mean")
+        return tuple(None if o is None else o[0][:, :o[1]] for o in outs)
+
     def set_edge_features(self, pos_sta, pos_src):
         """DataAggregationEdges (module.py:102-174): station / source-node positions [n,3] from which the library derives
         the mean edge features; `None, None` switches back to plain DataAggregation (genie_set_edge_features)."""

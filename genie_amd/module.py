@@ -296,15 +296,20 @@ class DataAggregationAssociationPhase(nn.Module):
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid):
+    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid, hip=None):
+        """`hip`: an engine.HipPath on the same graphs -> the four neighbour means run as genie_nbr_mean (HIP) instead of
+        materialised index gathers (21 -> ~6 ms at config 2); the Linears stay on PyTorch-ROCm."""
+        def means(x1, x2):
+            if hip is not None and x1.is_cuda:
+                return hip.nbr_mean(x1, x2)
+            return _mean_over_sta(x1, sta_nbr, n_sta, n_grid), _mean_over_src(x2, src_nbr, n_sta, n_grid)
+
         mask = torch.cat((mask1, mask2), dim=-1)
         tr = self.activate(self.init_trns(torch.cat((tr, latent, mask), dim=-1)))
-        a1 = _mean_over_sta(self.activate11(self.l1_t1_1(tr)), sta_nbr, n_sta, n_grid)
-        a2 = _mean_over_src(self.activate12(self.l1_t2_1(tr)), src_nbr, n_sta, n_grid)
+        a1, a2 = means(self.activate11(self.l1_t1_1(tr)), self.activate12(self.l1_t2_1(tr)))
         tr = self.activate1(torch.cat((self.l1_t1_2(torch.cat((tr, a1, mask), dim=1)),
                                        self.l1_t2_2(torch.cat((tr, a2, mask), dim=1))), dim=1))
-        b1 = _mean_over_sta(self.activate21(self.l2_t1_1(tr)), sta_nbr, n_sta, n_grid)
-        b2 = _mean_over_src(self.activate22(self.l2_t2_1(tr)), src_nbr, n_sta, n_grid)
+        b1, b2 = means(self.activate21(self.l2_t1_1(tr)), self.activate22(self.l2_t2_1(tr)))
         return self.activate2(torch.cat((self.l2_t1_2(torch.cat((tr, b1, mask), dim=1)),
                                          self.l2_t2_2(torch.cat((tr, b2, mask), dim=1))), dim=1))
 
@@ -534,7 +539,8 @@ class GCN_Detection_Network_extended(nn.Module):
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
         s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
         Maskf = _engine._f32(Mask, "Mask")
-        s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G)   # :990
+        s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
+                                                 hip=self._hip)                                      # :990
         tl = self.tlatent
         arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
         arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))

@@ -191,6 +191,14 @@ int genie_embed_window(genie_ctx* ctx, const double* pick_t, const int32_t* pick
                        double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
                        float* slice_out, float* mask_out, void* stream);
 
+/* Neighbour means on the implicit product graph for [P, row_floats] fp32 rows (row_floats = 16 or 32, 16-byte aligned):
+ *   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))]      (MessagePassing('mean') over A_in_sta)
+ *   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]      (... over A_in_src; x_src has n_grid_ext * n_sta rows)
+ * Either pair may be null. Used by the association heads (DataAggregationAssociationPhase, module.py:395-400), whose
+ * per-node Linears run on PyTorch-ROCm; an empty neighbourhood gives 0. */
+int genie_nbr_mean(genie_ctx* ctx, const float* x_sta, const float* x_src, float* out_sta, float* out_src, int row_floats,
+                   void* stream);
+
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */
 int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);

@@ -285,6 +285,40 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
     assert max_abs(res["generic"], res["default"]) <= 0.2 * rel_tol(res["generic"]), max_abs(res["generic"], res["default"])
 
 
+@pytest.mark.parametrize("S,G,C", [(12, 60, 30), (21, 40, 15), (50, 300, 32)])
+def test_nbr_mean_matches_torch_gathers(S, G, C):
+    """genie_nbr_mean (neighbour means of arbitrary [P, C] rows on the product graph, used by the association heads) against the
+    index-gather formulation; (21, 40) uses ragged graphs with an empty neighbourhood."""
+    from genie_amd.module import _mean_over_src, _mean_over_sta
+    geom = synthetic.Geometry(S, G, L=100e3, n_query=5, seed=S + G)
+    A_sta, A_src = geom.A_sta_sta, geom.A_src_src
+    ragged = (S, G) == (21, 40)
+    if ragged:
+        rng = np.random.default_rng(3)
+        A_sta = A_sta[:, (rng.random(A_sta.shape[1]) < 0.7) & (A_sta[1] != 4)]
+        A_src = A_src[:, (rng.random(A_src.shape[1]) < 0.7) & (A_src[1] != 9)]
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(A_sta), S), engine.csr_from_edges(torch.from_numpy(A_src), G),
+                        device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x1 = torch.randn((S * G, C), device=DEV, generator=g)
+    x2 = torch.randn((S * G, C), device=DEV, generator=g)
+    o1, o2 = hp.nbr_mean(x1, x2)
+    x3a, x3b = x1.view(G, S, C).cpu(), x2.view(G, S, C).cpu()
+    ref1, ref2 = torch.zeros(G, S, C), torch.zeros(G, S, C)
+    deg1, deg2 = torch.zeros(S), torch.zeros(G)
+    for j, i in torch.from_numpy(A_sta).t().tolist():
+        ref1[:, i] += x3a[:, j]; deg1[i] += 1
+    for j, i in torch.from_numpy(A_src).t().tolist():
+        ref2[i] += x3b[j]; deg2[i] += 1
+    ref1 = ref1 / deg1.clamp(min=1).view(1, S, 1)
+    ref2 = ref2 / deg2.clamp(min=1).view(G, 1, 1)
+    assert max_abs(o1.cpu().view(G, S, C), ref1) <= 1e-6 and max_abs(o2.cpu().view(G, S, C), ref2) <= 1e-6
+    if not ragged:
+        t1 = _mean_over_sta(x1, graph.neighbour_table(A_sta, S).long().to(DEV), S, G)
+        t2 = _mean_over_src(x2, graph.neighbour_table(A_src, G).long().to(DEV), S, G)
+        assert max_abs(o1, t1) <= 1e-6 and max_abs(o2, t2) <= 1e-6
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")

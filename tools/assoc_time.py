@@ -26,14 +26,18 @@ def main():
         x_spatial, x_latent, _ = net._path(Slice, Mask, xg, want_x_latent=True)
         y_latent = net.SpatialDirect(x_spatial)
         mask_out = (torch.rand(G, 1, device=dev) > 0.5).float()
-        def heads():
-            s, m1 = net.BipartiteGraphReadOutOperator(y_latent, net._edge_attr, mask_out, S)
-            return net.DataAggregationAssociationPhase(s, x_latent, m1, Mask, net._sta_tab, net._src_tab, S, G)
-        for _ in range(2): heads()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5): heads()
-        torch.cuda.synchronize()
-        print("P-sized association heads (PyTorch-ROCm): %.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+        outs = {}
+        for name, hip in (("torch gathers", None), ("HIP neighbour means", net._hip)):
+            def heads():
+                s, m1 = net.BipartiteGraphReadOutOperator(y_latent, net._edge_attr, mask_out, S)
+                return net.DataAggregationAssociationPhase(s, x_latent, m1, Mask, net._sta_tab, net._src_tab, S, G, hip=hip)
+            for _ in range(2): outs[name] = heads()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5): heads()
+            torch.cuda.synchronize()
+            print("P-sized association heads, %s: %.2f ms" % (name, (time.perf_counter() - t0) / 5 * 1e3))
+        a_, b_ = outs["torch gathers"], outs["HIP neighbour means"]
+        print("max|diff| %.3e  max|ref| %.3e" % (float((a_ - b_).abs().max()), float(a_.abs().max())))
 
 if __name__ == "__main__":
     main()
