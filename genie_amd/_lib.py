@@ -22,6 +22,7 @@ SYMBOLS = [
     ("genie_version", _c.c_int, []),
     ("genie_last_error", _c.c_char_p, []),
     ("genie_ctx_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_float]),
+    ("genie_ctx_create_subgraph", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_int, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float]),
     ("genie_ctx_destroy", _c.c_int, [_P]),
     ("genie_set_scale_t", _c.c_int, [_P, _c.c_float]),
     ("genie_set_edge_features", _c.c_int, [_P, _P, _P, _P]),

@@ -504,6 +504,7 @@ struct DaArgs {
     float* dbg_h0; float* dbg_h1;  // optional parity outputs [P,30] / [P,60]
     const float* packed;       // packed A fragments for the stage
     const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
+    long long Pn;              // k_stage?_pcsr: number of product nodes (rowptr / col arrays are product-level there)
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
@@ -856,6 +857,57 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             n2a *= inv; n2b *= inv;
         }
         stage1_dense(a, lw, lbias, lane, q, valid, p, g, sc, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+    }
+}
+
+// Stage 1 on an IRREGULAR product graph (`use_subgraph: True`, process_utils.py:744-849): the product nodes are an arbitrary
+// list of (station, source) pairs and both edge sets are CSR lists over PRODUCT-node ids (a.sta_rowptr/col, a.src_rowptr/col
+// are indexed by product node here). A tile is 16 consecutive product nodes; same arithmetic as k_stage1.
+__global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
+    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
+    const float* lscal = lbias + G1_BIAS * 16;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const long long ntiles = (a.Pn + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
+         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const long long pr = tile * 16 + j;
+        const bool valid = pr < a.Pn;
+        const long long p = valid ? pr : a.Pn - 1;
+        const float xs = a.slice[p * 4 + q];
+        const float mq = a.mask[p * 4 + q];
+        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
+        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
+        x0 = MFMA16(wi0.y, mq, x0);
+        x1 = MFMA16(wi1.y, mq, x1);
+        x0 = prelu4u(x0, a0);
+        x1 = prelu4u(x1, a0);
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
+        {
+            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
+            if (s11 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        {
+            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
+            if (s12 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        stage1_dense(a, lw, lbias, lane, q, valid, p, 0, 0, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
     }
 }
 
@@ -1557,6 +1609,75 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     }
 }
 
+// Stage 2 on an irregular product graph (see k_stage1_pcsr). The Bipartite messages of a source node are not the rows of
+// whole tiles here, so every node's gated message row is written in place of its c row and k_bip_out_seg sums the row range
+// of each source node (product nodes are grouped by source node, process_utils.py:790-794) in row order.
+__global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const long long ntiles = (a.Pn + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
+         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const long long pr = tile * 16 + j;
+        const bool valid = pr < a.Pn;
+        const long long p = valid ? pr : a.Pn - 1;
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        const float mq = a.mask[p * 4 + q];
+        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
+            gather_sum16<false>(a.wu + 4 * q, ROWW, a.sta_col, eb, ee, n1);
+            n1 *= 1.f / (float)max(ee - eb, 1);
+        }
+        {
+            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
+            gather_sum16<false>(a.wv + 4 * q, ROWW, a.src_col, eb, ee, n2);
+            n2 *= 1.f / (float)max(ee - eb, 1);
+        }
+        o[0] = prelu4u(o[0] + n1, a2);
+        o[1] = prelu4u(o[1] + n2, a2);
+        if (a.x_latent != nullptr && valid) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * q + r < 15) {
+                    xl[4 * q + r] = o[0][r];
+                    xl[15 + 4 * q + r] = o[1][r];
+                }
+            }
+        }
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            bp[t] = prelu4u(bp[t], ab1);
+        }
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (valid) {      // the message row replaces the c row of the node (read above by these same lanes)
+            *(f32x4*)(a.c + p * ROWC + 4 * q) = bp[0] * mm;
+            *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = bp[1] * mm;
+        }
+    }
+}
+
 // Fast stage 2 for uniform-degree graphs (KS station / KP source neighbours), software-pipelined across tiles: the
 // 1 + KS + KP row loads of tile i+1 are issued BEFORE the MFMA / shuffle phase of tile i, and the ids of tile i+2 are
 // fetched one iteration earlier still, so no memory round trip sits on a wave's critical path. (Without this every wave
@@ -1912,6 +2033,28 @@ __global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part,
         float r = 0.f;
         if (ok)
             for (int tb = 0; tb < T; ++tb) r += part[((long long)g * T + tb) * 32 + c];
+        float o = bias;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * __shfl(r, k, 32);
+        if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
+    }
+}
+// same for an irregular product graph: source node g owns the message rows [seg[g], seg[g+1]) of a [P, 32] buffer
+__global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ rows, int G, const int32_t* __restrict__ seg,
+                                                    const float* __restrict__ raw, int off_w, int off_b, int off_a,
+                                                    float* __restrict__ out) {
+    __shared__ float wt[30 * 32];
+    stage_transposed(wt, raw + off_w, 15, 30);
+    __syncthreads();
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float bias = c < 15 ? raw[off_b + c] : 0.f;
+    const float act = raw[off_a];
+    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
+        const int g = g0 + grp;
+        const bool ok = g < G;
+        float r = 0.f;
+        if (ok)
+            for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) r += rows[pr * 32 + c];
         float o = bias;
 #pragma unroll
         for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * __shfl(r, k, 32);
@@ -2551,6 +2694,9 @@ struct genie_ctx {
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
     float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
+    // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
+    bool pcsr;
+    int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
     float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
     bool has_edges;
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
@@ -2655,6 +2801,10 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
     a.src_tab = c->src_tab;
+    if (c->pcsr) {
+        a.Pn = c->P;
+        a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
+    }
     a.eb_sta = c->has_edges ? c->ebias_sta : nullptr;
     a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
@@ -2762,6 +2912,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
+    c->pcsr = false;
+    c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
     if (c->kp_uni == 15) {
         std::vector<int32_t> ord(n_grid), col((size_t)e_src), tab((size_t)n_grid * 16);
@@ -2858,8 +3010,47 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     return GENIE_OK;
 }
 
+int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod, const int32_t* p_sta_rowptr,
+                              const int32_t* p_sta_col, const int32_t* p_src_rowptr, const int32_t* p_src_col,
+                              const int32_t* seg_rowptr, const int32_t* src_rowptr, const int32_t* src_col,
+                              const int32_t* grid_order, float scale_rel) {
+    if (!out) return fail(GENIE_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (n_prod < 1 || n_prod >= (1ll << 31)) return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: bad n_prod");
+    if (!p_sta_rowptr || !p_src_rowptr || !seg_rowptr) return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: null rowptr");
+    int32_t* zeros = nullptr;       // empty base station graph: the station edges live in the product-level CSR
+    HIP_TRY(hipMalloc((void**)&zeros, sizeof(int32_t) * ((size_t)n_sta + 1)));
+    HIP_TRY(hipMemset(zeros, 0, sizeof(int32_t) * ((size_t)n_sta + 1)));
+    genie_ctx* c = nullptr;
+    int rc = genie_ctx_create(&c, n_sta, n_grid, n_grid, zeros, nullptr, src_rowptr, src_col, grid_order, scale_rel);
+    (void)hipFree(zeros);
+    if (rc) return rc;
+    int32_t e1 = 0, e2 = 0, last = 0;
+    HIP_TRY(hipMemcpy(&e1, p_sta_rowptr + n_prod, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&e2, p_src_rowptr + n_prod, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last, seg_rowptr + n_grid, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (e1 < 0 || e2 < 0 || last != (int32_t)n_prod || (e1 > 0 && !p_sta_col) || (e2 > 0 && !p_src_col)) {
+        genie_ctx_destroy(c);
+        return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: inconsistent CSR arrays (seg_rowptr[n_grid] must equal n_prod)");
+    }
+    if ((rc = dev_copy(&c->p_sta_rowptr, p_sta_rowptr, (size_t)n_prod + 1)) || (rc = dev_copy(&c->p_sta_col, p_sta_col, (size_t)e1)) ||
+        (rc = dev_copy(&c->p_src_rowptr, p_src_rowptr, (size_t)n_prod + 1)) || (rc = dev_copy(&c->p_src_col, p_src_col, (size_t)e2)) ||
+        (rc = dev_copy(&c->seg_rowptr, seg_rowptr, (size_t)n_grid + 1))) {
+        genie_ctx_destroy(c);
+        return rc;
+    }
+    c->pcsr = true;
+    c->P = c->P_ext = n_prod;
+    c->use_fast = c->use_b3 = 0;
+    c->ks_uni = c->kp_uni = -1;
+    layout_ws(c);
+    *out = c;
+    return GENIE_OK;
+}
+
 int genie_set_edge_features(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_edge_features: null context");
+    if (c->pcsr && pos_sta) return fail(GENIE_ERR_STATE, "genie_set_edge_features: not available on an irregular product graph");
     hipStream_t st = (hipStream_t)stream;
     if (!pos_sta || !pos_src) {      // back to plain DataAggregation
         c->has_edges = false;
@@ -2902,7 +3093,8 @@ int genie_ctx_destroy(genie_ctx* c) {
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
-                    c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src};
+                    c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
+                    c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -2967,7 +3159,10 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         a.x_latent = tbuf1;
     }
 #endif
-    if (c->use_b3) {
+    if (c->pcsr) {
+        const long long ntiles = (c->P + 15) / 16;
+        k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
+    } else if (c->use_b3) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
         a.xs = xs; a.packed = c->packed_b3;
@@ -3029,7 +3224,10 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
         }
     }
 #endif
-    if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
+    if (c->pcsr) {
+        const long long ntiles = (c->P + 15) / 16;
+        k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
+    } else if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
         a.packed = c->packed_b3s2;
         k_stage2_b3<8, 15><<<da_grid(c, ((long long)c->G * c->T + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2)
@@ -3046,6 +3244,10 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
     if (!bip_out) return fail(GENIE_ERR_ARG, "genie_bipartite_readout: null output");
     const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
     const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
+    if (c->pcsr)       // the messages sit in the c rows (k_stage2_pcsr)
+        k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + c->slot * c->big_stride, c->G, c->seg_rowptr, c->raw,
+                                                          g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
+    else
     k_bip_out<<<nb, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off,
                                                   g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
     HIP_TRY(hipGetLastError());
@@ -3241,6 +3443,7 @@ int genie_embed_window(genie_ctx* c, const double* pick_t, const int32_t* pick_s
     if (!c || !trv || !emb_ws || !slice_out || !mask_out) return fail(GENIE_ERR_ARG, "genie_embed_window: null argument");
     if (n_picks > 0 && (!pick_t || !pick_sta || !pick_phase)) return fail(GENIE_ERR_ARG, "genie_embed_window: null pick array");
     if (!(dt > 0.0) || !(kernel_sig_t > 0.0) || !(max_t > 0.0)) return fail(GENIE_ERR_ARG, "genie_embed_window: bad dt / sigma / max_t");
+    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_embed_window: not available on an irregular product graph");
     hipStream_t st = (hipStream_t)stream;
     EmbArgs a;
     memset(&a, 0, sizeof(a));
@@ -3272,6 +3475,7 @@ int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* 
                    void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_nbr_mean: null context");
     if ((x_sta && !out_sta) || (x_src && !out_src)) return fail(GENIE_ERR_ARG, "genie_nbr_mean: input without output");
+    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_nbr_mean: not available on an irregular product graph");
     if (!x_sta && !x_src) return GENIE_OK;
     const int nb = std::min<long long>((c->P + 31) / 32, (long long)c->num_cu * 16);
     hipStream_t st = (hipStream_t)stream;

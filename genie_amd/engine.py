@@ -81,7 +81,9 @@ class HipPath(object):
     """
 
     def __init__(self, n_sta, n_grid, sta_csr, src_csr, n_grid_ext=None, grid_order=None, scale_rel=30000.0,
-                 device=None):
+                 device=None, subgraph=None):
+        """`subgraph` = dict(n_prod, sta_csr, src_csr, seg_rowptr): an irregular product graph (`use_subgraph`) given as
+        product-level CSRs + the row range of every source node (genie_ctx_create_subgraph); `sta_csr` is then ignored."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GenieHipError("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
@@ -89,20 +91,38 @@ class HipPath(object):
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
         self.n_grid_ext = int(n_grid_ext) if n_grid_ext is not None else self.n_grid
         self.scale_rel = float(scale_rel)
+        self._n_prod = None
         dev = self.device
-        self._keep = [t.to(dev, torch.int32).contiguous() for t in (sta_csr[0], sta_csr[1], src_csr[0], src_csr[1])]
         order = None
         if grid_order is not None:
             order = torch.as_tensor(np.asarray(grid_order)).to(dev, torch.int32).contiguous()
             if order.numel() != self.n_grid:
                 raise ValueError("grid_order must have n_grid entries")
         self.ctx = ctypes.c_void_p(0)
-        with torch.cuda.device(dev):
-            torch.cuda.synchronize()
-            rc = self.lib.genie_ctx_create(ctypes.byref(self.ctx), self.n_sta, self.n_grid, self.n_grid_ext,
-                                           _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
-                                           _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
-        _lib.check(rc, "genie_ctx_create")
+        if subgraph is not None:
+            if self.n_grid_ext != self.n_grid:
+                raise ValueError("an irregular product graph cannot be sharded")
+            self._n_prod = int(subgraph["n_prod"])
+            self._keep = [t.to(dev, torch.int32).contiguous() for t in (
+                subgraph["sta_csr"][0], subgraph["sta_csr"][1], subgraph["src_csr"][0], subgraph["src_csr"][1],
+                subgraph["seg_rowptr"], src_csr[0], src_csr[1])]
+            k = self._keep
+            if k[0].numel() != self._n_prod + 1 or k[2].numel() != self._n_prod + 1 or k[4].numel() != self.n_grid + 1:
+                raise ValueError("subgraph CSR arrays do not match n_prod / n_grid")
+            with torch.cuda.device(dev):
+                torch.cuda.synchronize()
+                rc = self.lib.genie_ctx_create_subgraph(ctypes.byref(self.ctx), self.n_sta, self.n_grid, self._n_prod,
+                                                        _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]),
+                                                        _ptr(k[6]), _ptr(order), ctypes.c_float(self.scale_rel))
+            _lib.check(rc, "genie_ctx_create_subgraph")
+        else:
+            self._keep = [t.to(dev, torch.int32).contiguous() for t in (sta_csr[0], sta_csr[1], src_csr[0], src_csr[1])]
+            with torch.cuda.device(dev):
+                torch.cuda.synchronize()
+                rc = self.lib.genie_ctx_create(ctypes.byref(self.ctx), self.n_sta, self.n_grid, self.n_grid_ext,
+                                               _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
+                                               _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
+            _lib.check(rc, "genie_ctx_create")
         self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
@@ -124,7 +144,11 @@ class HipPath(object):
 
     @property
     def n_prod(self):
-        return self.n_sta * self.n_grid
+        return self._n_prod if self._n_prod is not None else self.n_sta * self.n_grid
+
+    @property
+    def n_prod_ext(self):
+        return self._n_prod if self._n_prod is not None else self.n_sta * self.n_grid_ext
 
     # ---- weights -------------------------------------------------------------------------------
     def set_weights(self, named_tensors):
@@ -154,8 +178,8 @@ class HipPath(object):
     # ---- stages --------------------------------------------------------------------------------
     def da_stage1(self, Slice, Mask, debug=False):
         """Stage 1 (genie_da_stage1). Returns the validated (Slice, Mask) [, h0, h1 when debug]."""
-        Slice = _f32(Slice, "Slice", (self.n_grid_ext * self.n_sta, 4))
-        Mask = _f32(Mask, "Mask", (self.n_grid_ext * self.n_sta, 4))
+        Slice = _f32(Slice, "Slice", (self.n_prod_ext, 4))
+        Mask = _f32(Mask, "Mask", (self.n_prod_ext, 4))
         if not debug:
             _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, _stream()), "genie_da_stage1")
             return Slice, Mask

@@ -132,3 +132,45 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
         if not torch.equal(A_in_src, S * base_src.repeat(1, S) + off):
             raise ValueError("A_in_src is not I_S (x) A_src_src: not Cartesian")
     return neighbour_table(base_sta, S), neighbour_table(base_src, G)
+
+
+def subgraph_product_edges(A_sta_sta, A_src_src, A_src_in_sta):
+    """Edge lists of the IRREGULAR product graph of `use_subgraph: True` (process_utils.py:744-849).
+
+    A_src_in_sta [2, N] lists the product nodes as (station, source) pairs, sorted by (source, station)
+    (process_utils.py:790-794). Product node n is connected
+      * in A_prod_sta_sta to node m when both have the same source node and (sta_m -> sta_n) is an edge of A_sta_sta
+        (the station graph induced on the station set of that source node, process_utils.py:824-826);
+      * in A_prod_src_src to node m when both have the same station and (src_m -> src_n) is an edge of A_src_src
+        (the source graph induced on the source set of that station, :828-839).
+    Returns (A_prod_sta_sta [2,E1], A_prod_src_src [2,E2], A_src_in_prod [2,N]) with row 0 = neighbour j, row 1 = centre i,
+    in-edges grouped by centre."""
+    A_sta = np.asarray(A_sta_sta, dtype=np.int64)
+    A_src = np.asarray(A_src_src, dtype=np.int64)
+    pairs = np.asarray(A_src_in_sta, dtype=np.int64)
+    sta, src = pairs[0], pairs[1]
+    N = sta.size
+    if np.any(np.diff(src) < 0) or np.any((np.diff(src) == 0) & (np.diff(sta) <= 0)):
+        raise ValueError("A_src_in_sta must be sorted by (source, station) without duplicates")
+    node_of = {(int(a), int(b)): n for n, (a, b) in enumerate(zip(sta.tolist(), src.tolist()))}
+    in_sta = [[] for _ in range(int(A_sta.max()) + 1 if A_sta.size else 0)]
+    for j, i in A_sta.T.tolist():
+        in_sta[i].append(j)
+    in_src = [[] for _ in range(int(A_src.max()) + 1 if A_src.size else 0)]
+    for j, i in A_src.T.tolist():
+        in_src[i].append(j)
+    e1, e2 = [], []
+    for n in range(N):
+        s_, g_ = int(sta[n]), int(src[n])
+        for j in (in_sta[s_] if s_ < len(in_sta) else []):
+            m = node_of.get((j, g_))
+            if m is not None:
+                e1.append((m, n))
+        for j in (in_src[g_] if g_ < len(in_src) else []):
+            m = node_of.get((s_, j))
+            if m is not None:
+                e2.append((m, n))
+    A1 = torch.tensor(e1, dtype=torch.long).t().contiguous() if e1 else torch.zeros((2, 0), dtype=torch.long)
+    A2 = torch.tensor(e2, dtype=torch.long).t().contiguous() if e2 else torch.zeros((2, 0), dtype=torch.long)
+    A_src_in_prod = torch.stack((torch.arange(N), torch.from_numpy(src.copy())), dim=0)
+    return A1, A2, A_src_in_prod

@@ -474,7 +474,16 @@ class GCN_Detection_Network_extended(nn.Module):
         self.A_edges_p, self.A_edges_s = A_edges_p, A_edges_s
         self.dt_partition, self.tlatent = dt_partition, tlatent
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
-        sta_nbr, src_nbr = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid)
+        n_prod = int(A_src_in_sta.shape[1])
+        cartesian = n_prod == n_sta * n_grid
+        if cartesian:
+            try:
+                sta_nbr, src_nbr = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid)
+            except ValueError:
+                cartesian = False
+        if not cartesian:
+            return self._set_adjacencies_subgraph(A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid,
+                                                  pos_loc, pos_src)
         src_from_A = _engine.csr_from_edges(A_src, n_grid)
         src_csr = _engine.csr_from_table(src_nbr)
         if not (torch.equal(src_from_A[0], src_csr[0]) and torch.equal(src_from_A[1], src_csr[1])):
@@ -483,6 +492,29 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
         dev = self._edge_attr.device
         self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
+
+    def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
+        """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
+        A_src_in_sta (grouped by source node) and the edge lists are irregular: product-level CSRs, generic HIP kernels."""
+        if self.use_updated_model_definition:
+            raise NotImplementedError("use_updated_model_definition with use_subgraph")
+        pairs = torch.as_tensor(A_src_in_sta).long().cpu()
+        n_prod = int(pairs.shape[1])
+        src_of = pairs[1]
+        if n_prod == 0 or bool((src_of[1:] < src_of[:-1]).any()):
+            raise ValueError("A_src_in_sta must list the product nodes grouped by source node (process_utils.py:790-794)")
+        seg = torch.zeros(n_grid + 1, dtype=torch.int32)
+        seg[1:] = torch.cumsum(torch.bincount(src_of, minlength=n_grid), 0).to(torch.int32)
+        sub = {"n_prod": n_prod, "sta_csr": _engine.csr_from_edges(A_in_sta, n_prod),
+               "src_csr": _engine.csr_from_edges(A_in_src, n_prod), "seg_rowptr": seg}
+        order = _engine.morton_order(pos_src.detach().cpu().numpy())
+        dev = next(self.parameters()).device
+        self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
+                                    scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._path_params = _path_param_dict(self)
+        self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
+        self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
 
     def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src):
         """Same effect as `set_adjacencies` from the BASE graphs only (process_utils.py:718-719), for sizes
@@ -529,6 +561,9 @@ class GCN_Detection_Network_extended(nn.Module):
         if self.use_updated_model_definition:
             raise NotImplementedError("the 4-output forward of the use_updated_model_definition class (module.py:1128-1161) "
                                       "has different association heads; only forward_fixed_source is provided")
+        if getattr(self, "_sta_tab", None) is None:
+            raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
+                                      "set_adjacencies_base): only forward_fixed_source is available here")
         S, G = self._hip.n_sta, self._hip.n_grid
         x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)      # :973-977
         y_latent = self.SpatialDirect(x_spatial)                                                     # :978

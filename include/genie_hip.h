@@ -61,6 +61,18 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
                      const int32_t* sta_rowptr, const int32_t* sta_col,
                      const int32_t* src_rowptr, const int32_t* src_col,
                      const int32_t* grid_order, float scale_rel);
+/* Irregular product graph (`use_subgraph: True`, config.yaml:86; built by extract_inputs_adjacencies_subgraph,
+ * process_utils.py:744-849): the product nodes are an explicit list of n_prod (station, source) pairs GROUPED BY SOURCE NODE
+ * (process_utils.py:790-794), so `seg_rowptr[g] .. seg_rowptr[g+1]` is the row range of source node g (seg_rowptr[n_grid] =
+ * n_prod), and both DataAggregation edge sets are CSR lists over product-node ids: p_sta_* = in-edges of A_in_sta (same
+ * source node, neighbouring stations), p_src_* = in-edges of A_in_src, in stable edge order. src_rowptr / src_col = the base
+ * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The bf16x3 / pipelined
+ * kernels (which rely on p = g * n_sta + s) are not used; genie_embed_window, genie_set_edge_features and genie_nbr_mean are
+ * unavailable on such a context. */
+int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod,
+                              const int32_t* p_sta_rowptr, const int32_t* p_sta_col,
+                              const int32_t* p_src_rowptr, const int32_t* p_src_col, const int32_t* seg_rowptr,
+                              const int32_t* src_rowptr, const int32_t* src_col, const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
  * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists twice; `slot` (0/1) selects the copy used by

@@ -74,15 +74,22 @@ def _hook_intermediates(mz):
 
 def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, window=None,
              keep=("h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"),
-             row_stride=1, keep64=None):
+             row_stride=1, keep64=None, pairs=None):
+    """`pairs` [2, N] (station, source), sorted by (source, station): run the reference on the IRREGULAR product graph of
+    `use_subgraph: True` (process_utils.py:744-849) whose nodes are those pairs; Slice / Mask then have N rows."""
     import torch
     from genie_amd import graph as G
 
     S, Gn = geom.n_sta, geom.n_grid
-    A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
-        geom.A_sta_sta, geom.A_src_src, S, Gn)
+    if pairs is None:
+        A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
+            geom.A_sta_sta, geom.A_src_src, S, Gn)
+        spatial_vals = torch.from_numpy(geom.edge_attr())
+    else:
+        A_src_in_sta = torch.from_numpy(np.asarray(pairs)).long()
+        A_prod_sta_sta, A_prod_src_src, A_src_in_prod = G.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+        spatial_vals = torch.from_numpy(geom.edge_attr().reshape(Gn, S, 3)[pairs[1], pairs[0]].copy())
     A_src_src = torch.from_numpy(geom.A_src_src).long()
-    spatial_vals = torch.from_numpy(geom.edge_attr())
     results = {}
     for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
         torch.manual_seed(weights_seed)
@@ -119,7 +126,7 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
         results["x" + tag] = x.numpy()
         for k in (keep if (tag == "" or keep64 is None) else keep64):
             v = store[k].numpy()
-            if v.shape[0] == S * Gn and row_stride > 1:
+            if v.shape[0] == Slice.shape[0] and row_stride > 1:
                 v = v[::row_stride]
             results[k + tag] = v
         if tag == "":
@@ -129,8 +136,10 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
         "n_sta": np.int64(S), "n_grid": np.int64(Gn), "row_stride": np.int64(row_stride),
         "locs": geom.locs, "x_grid": geom.x_grid, "x_query": geom.x_query, "t_query": geom.t_query,
         "A_sta_sta": geom.A_sta_sta, "A_src_src": geom.A_src_src,
-        "edge_attr": geom.edge_attr(), "Slice": Slice.astype(np.float32), "Mask": Mask.astype(np.uint8),
+        "edge_attr": spatial_vals.numpy().astype(np.float32), "Slice": Slice.astype(np.float32), "Mask": Mask.astype(np.uint8),
     })
+    if pairs is not None:
+        results["pairs"] = np.asarray(pairs, dtype=np.int64)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **results)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0),
@@ -236,9 +245,40 @@ def main_edges():
              keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
 
 
+def main_subgraph():
+    """`python oracle/make_golden.py --subgraph`: the live model on an irregular product graph (`use_subgraph: True`): every
+    source node keeps its 6 nearest stations plus a few random ones, as the reference's builder keeps the k nearest pairs plus
+    those within a distance threshold (process_utils.py:777-794)."""
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    rng = np.random.default_rng(72)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)          # [G, S]
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(d.shape[0])[:, None], np.argsort(d, axis=1)[:, :6]] = True
+    keep |= rng.random(d.shape) < 0.12
+    src_i, sta_i = np.nonzero(keep)                                                         # row-major: sorted by (source, station)
+    pairs = np.stack((sta_i, src_i))
+    full = syn.make_window(geom, 180, seed=73)
+    rows = src_i * geom.n_sta + sta_i
+    run_case(ref, "subgraph_14x50", geom, full["Slice"][rows], full["Mask"][rows], perturb_prelu=True, window=full,
+             keep=("h0", "h1", "x_latent", "bip", "sa1", "sa3", "y_latent"), keep64=("bip", "sa3"), pairs=pairs)
+    # the reference's own builder (process_utils.py:744) on the same geometry: fixture for genie_amd.graph.subgraph_product_edges
+    import process_utils as pu
+    out = pu.extract_inputs_adjacencies_subgraph(geom.locs, geom.x_grid, lambda x: x, lambda x: x, max_deg_offset=0.15,
+                                                 k_nearest_pairs=6, k_sta_edges=8, k_spc_edges=15, scale_deg=110e3, device="cpu")
+    names = ("A_sta_sta", "A_src_src", "A_prod_sta_sta", "A_prod_src_src", "A_src_in_prod", "A_src_in_sta")
+    np.savez_compressed(os.path.join(OUT, "subgraph_builder_14x50.npz"), **{k: np.asarray(v).astype(np.int64) for k, v in zip(names, out)})
+    print("wrote subgraph_builder_14x50.npz: %d product nodes" % out[5].shape[1])
+
+
 def main():
     if "--edges" in sys.argv:
         return main_edges()
+    if "--subgraph" in sys.argv:
+        return main_subgraph()
     ref = _import_reference()
     from genie_amd import synthetic as syn
 

@@ -41,6 +41,18 @@ def test_state_dict_of_updated_model_definition_matches_reference():
     assert torch.equal(view["DataAggregation.l2_t1_2.weight_pos"], W[:, 90:94])
 
 
+def test_subgraph_product_edges_match_the_reference_builder():
+    """genie_amd.graph.subgraph_product_edges against the output of the reference's extract_inputs_adjacencies_subgraph
+    (process_utils.py:744-849; fixture written by oracle/make_golden.py --subgraph): same edge sets, same A_src_in_prod."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subgraph_builder_14x50.npz"))
+    A1, A2, Ap = graph.subgraph_product_edges(z["A_sta_sta"], z["A_src_src"], z["A_src_in_sta"])
+    assert set(map(tuple, A1.numpy().T.tolist())) == set(map(tuple, z["A_prod_sta_sta"].T.tolist()))
+    assert set(map(tuple, A2.numpy().T.tolist())) == set(map(tuple, z["A_prod_src_src"].T.tolist()))
+    assert np.array_equal(Ap.numpy(), z["A_src_in_prod"])
+    assert z["A_src_in_sta"].shape[1] < 14 * 50
+
+
 def test_library_exports_every_declared_symbol(repo_root):
     _lib.build()
     lib = _lib.load()

@@ -4,7 +4,7 @@ intermediates and 1e-6 absolute on the outputs (y, x); fp64 tolerance 1e-12."""
 import pytest
 import torch
 
-from tests.util import EDGES_CASES, GOLDEN_CASES, Case, max_abs
+from tests.util import EDGES_CASES, GOLDEN_CASES, SUBGRAPH_CASES, Case, max_abs
 
 INTERMEDIATES = ["h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"]
 
@@ -58,6 +58,22 @@ def test_oracle_edges_variant_matches_reference(name):
         if k in c.z.files:
             ref = c.ref(k)
             assert max_abs(c.strided(out[k]) if out[k].shape[0] == c.S * c.G else out[k], ref) <= 1e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
+
+
+@pytest.mark.parametrize("name", SUBGRAPH_CASES)
+def test_oracle_on_irregular_product_graph_matches_reference(name):
+    """`use_subgraph: True` (config.yaml:86): product nodes = an explicit list of (station, source) pairs, irregular edge
+    lists (process_utils.py:744-849). The reference module ran on such a graph to produce the fixture."""
+    c = Case(name)
+    out = c.oracle_forward(torch.float32)
+    assert out["x_latent"].shape[0] == c.z["pairs"].shape[1] < c.S * c.G
+    for k in ["h0", "h1", "x_latent", "bip", "sa1", "sa3", "y_latent", "y", "x"]:
+        ref = c.ref(k)
+        assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
     out64 = c.oracle_forward(torch.float64)
     for k in ["bip", "sa3", "y", "x"]:
         ref = c.ref(k + "64")

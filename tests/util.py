@@ -10,6 +10,7 @@ from oracle import genie_oracle as O
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["tiny_6x40", "cfg1_20x500", "odd_33x257"]
 EDGES_CASES = ["edges_12x60", "edges_7x13"]      # use_updated_model_definition class (DataAggregationEdges)
+SUBGRAPH_CASES = ["subgraph_14x50"]               # use_subgraph: irregular product graph
 
 
 class Case(object):
@@ -34,6 +35,10 @@ class Case(object):
         self.edges_variant = self.weights["DataAggregation.l1_t1_2.weight"].shape[1] == 68
 
     def product_edges(self):
+        if "pairs" in self.z.files:      # irregular product graph (use_subgraph, process_utils.py:744-849)
+            pairs = torch.from_numpy(self.z["pairs"]).long()
+            A1, A2, A_src_in_prod = G.subgraph_product_edges(self.A_sta_sta, self.A_src_src, pairs.numpy())
+            return A1, A2, A_src_in_prod, pairs
         return G.cartesian_product_edges(self.A_sta_sta, self.A_src_src, self.S, self.G)
 
     def tables(self):
