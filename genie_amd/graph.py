@@ -152,25 +152,29 @@ def subgraph_product_edges(A_sta_sta, A_src_src, A_src_in_sta):
     N = sta.size
     if np.any(np.diff(src) < 0) or np.any((np.diff(src) == 0) & (np.diff(sta) <= 0)):
         raise ValueError("A_src_in_sta must be sorted by (source, station) without duplicates")
-    node_of = {(int(a), int(b)): n for n, (a, b) in enumerate(zip(sta.tolist(), src.tolist()))}
-    in_sta = [[] for _ in range(int(A_sta.max()) + 1 if A_sta.size else 0)]
-    for j, i in A_sta.T.tolist():
-        in_sta[i].append(j)
-    in_src = [[] for _ in range(int(A_src.max()) + 1 if A_src.size else 0)]
-    for j, i in A_src.T.tolist():
-        in_src[i].append(j)
-    e1, e2 = [], []
-    for n in range(N):
-        s_, g_ = int(sta[n]), int(src[n])
-        for j in (in_sta[s_] if s_ < len(in_sta) else []):
-            m = node_of.get((j, g_))
-            if m is not None:
-                e1.append((m, n))
-        for j in (in_src[g_] if g_ < len(in_src) else []):
-            m = node_of.get((s_, j))
-            if m is not None:
-                e2.append((m, n))
-    A1 = torch.tensor(e1, dtype=torch.long).t().contiguous() if e1 else torch.zeros((2, 0), dtype=torch.long)
-    A2 = torch.tensor(e2, dtype=torch.long).t().contiguous() if e2 else torch.zeros((2, 0), dtype=torch.long)
+    n_sta_all = int(max(sta.max(initial=0), A_sta.max(initial=0))) + 1
+    keys = src * n_sta_all + sta                      # increasing: the node id of a (station, source) pair is its rank
+
+    def induced(A, centre_base, other_is_station):
+        """for every product node n and every base in-edge j -> centre_base[n]: the product node (j paired with n's other
+        coordinate), if it exists; in-edges of a node keep the base graph's edge order."""
+        order = np.argsort(A[1], kind="stable")
+        tgt, nb = A[1][order], A[0][order]
+        n_base = int(max(centre_base.max(initial=0), tgt.max(initial=-1))) + 1
+        ptr = np.zeros(n_base + 1, dtype=np.int64)
+        np.add.at(ptr, tgt + 1, 1)
+        ptr = np.cumsum(ptr)
+        deg = ptr[centre_base + 1] - ptr[centre_base]
+        centre = np.repeat(np.arange(N), deg)
+        first = np.repeat(ptr[centre_base], deg)
+        within = np.arange(centre.size) - np.repeat(np.cumsum(deg) - deg, deg)
+        j = nb[first + within]
+        key = (src[centre] * n_sta_all + j) if other_is_station else (j * n_sta_all + sta[centre])
+        pos = np.searchsorted(keys, key)
+        ok = (pos < N) & (keys[np.minimum(pos, N - 1)] == key)
+        return torch.from_numpy(np.stack((pos[ok], centre[ok])))
+
+    A1 = induced(A_sta, sta, True)
+    A2 = induced(A_src, src, False)
     A_src_in_prod = torch.stack((torch.arange(N), torch.from_numpy(src.copy())), dim=0)
     return A1, A2, A_src_in_prod
