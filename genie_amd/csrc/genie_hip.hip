@@ -96,6 +96,8 @@ enum {
     W_SAT_Q_W, W_SAT_Q_B, W_SAT_C_W, W_SAT_C_B, W_SAT_V_W, W_SAT_V_B, W_SAT_P_W, W_SAT_P_B, W_SAT_ACT1, W_SAT_ACT2,
     // DataAggregationEdges (module.py:102-174): the 4 edge-feature columns of l1_t?_2 / l2_t?_2 (zero for DataAggregation)
     W_DA_L1T12_P, W_DA_L1T22_P, W_DA_L2T12_P, W_DA_L2T22_P,
+    // use_absolute_pos (config.yaml:92): the 6 absolute-position columns of init_trns (zero otherwise)
+    W_DA_INIT_ABS,
     W_COUNT
 };
 
@@ -148,6 +150,7 @@ Param g_params[W_COUNT] = {
     {"SpatialAttention.activate1.weight", 1, 0}, {"SpatialAttention.activate2.weight", 1, 0},
     {"DataAggregation.l1_t1_2.weight_pos", 30 * 4, 0}, {"DataAggregation.l1_t2_2.weight_pos", 30 * 4, 0},
     {"DataAggregation.l2_t1_2.weight_pos", 15 * 4, 0}, {"DataAggregation.l2_t2_2.weight_pos", 15 * 4, 0},
+    {"DataAggregation.init_trns.weight_abs", 30 * 6, 0},
 };
 
 int g_raw_total = 0;
@@ -356,6 +359,12 @@ void build_plans(StagePlan& p1, StagePlan& p2) {
     for (int t = 0; t < 2; ++t) {
         const int c0s[2] = {0, 4}, nqs[2] = {4, 4};
         add_scalar_group(p1, W_DA_INIT_W, 8, 16 * t, std::min(16, 30 - 16 * t), c0s, nqs, 2);
+        // steps 2, 3 of the group: station / source absolute-position columns (use_absolute_pos; zero weights otherwise)
+        for (int r = 2; r < 4; ++r) {
+            StepDesc& d = p1.steps[p1.steps.size() - 4 + r];
+            d.mat_off = g_params[W_DA_INIT_ABS].off; d.ld = 6; d.o0 = 16 * t; d.rows = std::min(16, 30 - 16 * t);
+            for (int q = 0; q < 4; ++q) d.col[q] = q < 3 ? 3 * (r - 2) + q : -1;
+        }
     }
     for (int h = 0; h < 2; ++h)
         for (int t = 0; t < 2; ++t) {
@@ -505,6 +514,8 @@ struct DaArgs {
     const float* packed;       // packed A fragments for the stage
     const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
     long long Pn;              // k_stage?_pcsr: number of product nodes (rowptr / col arrays are product-level there)
+    const float* abs_sta;      // use_absolute_pos: [S][4] = {loc / (3 scale_rel), 0}, or null
+    const float* abs_src;      // ... [G_ext][4] = {x_grid / (3 scale_rel), 0}
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
@@ -564,12 +575,20 @@ struct ItemIter {
 // gathered row is 32 B instead of 128 B, so the whole neighbourhood working set stays in L2, and h0 is never
 // stored. One call handles CH consecutive edges starting at e0 (2*CH dword loads per lane in flight); PRED adds
 // the per-lane bound check used only for ragged (non-uniform degree) graphs. row(c) = row0 + c*stride.
+// use_absolute_pos: the neighbour's hidden state also sees its station / source position. One of the two is the same as
+// the centre node's (fixed value), the other is looked up by the neighbour id c in a [n][4] table.
+struct AbsNbr {
+    const float* tab;      // table indexed by the neighbour id, or null when absolute positions are off
+    bool tab_is_station;   // the table is the station table (station-graph neighbours) / the source table
+    float fixed;           // the centre node's value of the other coordinate (for this lane's q)
+};
+
 template <int CH, bool UNI, bool LE1, bool PRED>
 __device__ __forceinline__ void recompute_chunk(const float* __restrict__ slice, const float* __restrict__ mask,
                                                 long long row0, long long stride, int q,
                                                 const int32_t* __restrict__ col, int e0, int ee,
                                                 f32x4 w0, f32x4 w1, f32x4 b0, f32x4 b1, float slope,
-                                                f32x4& s0, f32x4& s1) {
+                                                f32x4& s0, f32x4& s1, const AbsNbr ab = AbsNbr{nullptr, false, 0.f}) {
     long long off[CH];
     bool ok[CH];
     int cv = 0;
@@ -580,11 +599,15 @@ __device__ __forceinline__ void recompute_chunk(const float* __restrict__ slice,
         const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : max(ee - 1, 0)];
         off[k] = (row0 + (long long)c * stride) * 4 + q;
     }
-    float xs[CH], xm[CH];
+    float xs[CH], xm[CH], xv[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         xs[k] = slice[off[k]];
         xm[k] = mask[off[k]];
+        if (ab.tab != nullptr) {
+            const int c = UNI ? __builtin_amdgcn_readlane(cv, k) : col[ok[k] ? e0 + k : max(ee - 1, 0)];
+            xv[k] = ab.tab[c * 4 + q];
+        }
     }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -592,6 +615,13 @@ __device__ __forceinline__ void recompute_chunk(const float* __restrict__ slice,
         f32x4 h_b = MFMA16(w1.x, xs[k], b1);
         h_a = MFMA16(w0.y, xm[k], h_a);
         h_b = MFMA16(w1.y, xm[k], h_b);
+        if (ab.tab != nullptr) {
+            const float lv = ab.tab_is_station ? xv[k] : ab.fixed, gv = ab.tab_is_station ? ab.fixed : xv[k];
+            h_a = MFMA16(w0.z, lv, h_a);
+            h_b = MFMA16(w1.z, lv, h_b);
+            h_a = MFMA16(w0.w, gv, h_a);
+            h_b = MFMA16(w1.w, gv, h_b);
+        }
         h_a = prelu4s<LE1>(h_a, slope);
         h_b = prelu4s<LE1>(h_b, slope);
         if (PRED) {
@@ -610,19 +640,19 @@ __device__ __forceinline__ void gather_recompute(const float* __restrict__ slice
                                                  long long row0, long long stride, int q,
                                                  const int32_t* __restrict__ col, int eb, int ee,
                                                  f32x4 w0, f32x4 w1, f32x4 b0, f32x4 b1, float slope,
-                                                 f32x4& s0, f32x4& s1) {
+                                                 f32x4& s0, f32x4& s1, const AbsNbr ab = AbsNbr{nullptr, false, 0.f}) {
     const int n = ee - eb;
     const int nu = __builtin_amdgcn_readfirstlane(n);
     if (UNI || __all(n == nu)) {
         int e = eb, r = nu;
         for (; r >= 8; r -= 8, e += 8)
-            recompute_chunk<8, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1);
-        if (r & 4) { recompute_chunk<4, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); e += 4; }
-        if (r & 2) { recompute_chunk<2, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); e += 2; }
-        if (r & 1) { recompute_chunk<1, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1); }
+            recompute_chunk<8, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1, ab);
+        if (r & 4) { recompute_chunk<4, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1, ab); e += 4; }
+        if (r & 2) { recompute_chunk<2, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1, ab); e += 2; }
+        if (r & 1) { recompute_chunk<1, UNI, LE1, false>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1, ab); }
     } else {
         for (int e = eb; __any(e < ee); e += 8)
-            recompute_chunk<8, false, LE1, true>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1);
+            recompute_chunk<8, false, LE1, true>(slice, mask, row0, stride, q, col, e, ee, w0, w1, b0, b1, slope, s0, s1, ab);
     }
 }
 
@@ -823,6 +853,13 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
         f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
         x0 = MFMA16(wi0.y, mq, x0);
         x1 = MFMA16(wi1.y, mq, x1);
+        float lq = 0.f, gq = 0.f;                 // use_absolute_pos: this node's station / source position channel q
+        if (a.abs_sta != nullptr) {
+            lq = a.abs_sta[sc * 4 + q];
+            gq = a.abs_src[g * 4 + q];
+            x0 = MFMA16(wi0.z, lq, x0); x1 = MFMA16(wi1.z, lq, x1);
+            x0 = MFMA16(wi0.w, gq, x0); x1 = MFMA16(wi1.w, gq, x1);
+        }
         x0 = prelu4u(x0, a0);
         x1 = prelu4u(x1, a0);
         // station-neighbour mean of PReLU11(h0): rows of the same source node
@@ -832,10 +869,10 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             if (!ABL(a, 0)) {
                 if (s11 <= 1.f)
                     gather_recompute<false, true>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
-                                                  bi1, s11, n1a, n1b);
+                                                  bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
                 else
                     gather_recompute<false, false>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
-                                                   bi1, s11, n1a, n1b);
+                                                   bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
             }
             const float inv = 1.f / (float)max(ee - eb, 1);
             n1a *= inv; n1b *= inv;
@@ -848,10 +885,10 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             if (!ABL(a, 1)) {
                 if (s12 <= 1.f)
                     gather_recompute<true, true>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
-                                                 bi0, bi1, s12, n2a, n2b);
+                                                 bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
                 else
                     gather_recompute<true, false>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
-                                                  bi0, bi1, s12, n2a, n2b);
+                                                  bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
             }
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
@@ -1151,6 +1188,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 constexpr int XROW = 48;                 // bytes per split input row
+constexpr bool B3_ABS_READY = false;      // the bf16x3 kernel has no absolute-position form yet: use_absolute_pos runs k_stage1
 constexpr int B3_THREADS = 512;
 
 __device__ __forceinline__ float bf_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
@@ -2579,6 +2617,14 @@ __global__ void k_embed_gather(EmbArgs a) {
 }
 
 // de-pad rows of a workspace tensor for parity tests
+// use_absolute_pos (config.yaml:92; module.py:1007): Slice gets locs[sta] / (3 scale_rel) and x_grid[src] / (3 scale_rel) appended
+__global__ void k_abs_table(const float* __restrict__ pos, int n, float inv, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 4) return;
+    const int r = i >> 2, k = i & 3;
+    out[i] = k < 3 ? pos[r * 3 + k] * inv : 0.f;
+}
+
 // DataAggregationEdges (module.py:102-174, forward :1059-1072): every message carries phi(pos_j - pos_i) (3) and phi(|pos_j - pos_i|),
 // phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)); after mean aggregation that is a STATIC 4-vector per node of a base graph.
 __global__ void k_edge_feat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int n,
@@ -2694,6 +2740,7 @@ struct genie_ctx {
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
     float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
+    float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
@@ -2805,6 +2852,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
         a.Pn = c->P;
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
     }
+    a.abs_sta = c->abs_sta; a.abs_src = c->abs_src;
     a.eb_sta = c->has_edges ? c->ebias_sta : nullptr;
     a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
@@ -2912,6 +2960,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
+    c->abs_sta = c->abs_src = nullptr;
     c->pcsr = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
@@ -3048,6 +3097,26 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
     return GENIE_OK;
 }
 
+int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_absolute_pos: null context");
+    if (!pos_sta || !pos_src) {
+        (void)hipFree(c->abs_sta); (void)hipFree(c->abs_src);
+        c->abs_sta = c->abs_src = nullptr;
+        return GENIE_OK;
+    }
+    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_set_absolute_pos: not available on an irregular product graph");
+    if (!c->abs_sta) {
+        HIP_TRY(hipMalloc((void**)&c->abs_sta, sizeof(float) * 4 * (size_t)c->S));
+        HIP_TRY(hipMalloc((void**)&c->abs_src, sizeof(float) * 4 * (size_t)c->G_ext));
+    }
+    const float inv = 1.f / (3.f * c->scale_rel);
+    hipStream_t st = (hipStream_t)stream;
+    k_abs_table<<<(c->S * 4 + 255) / 256, 256, 0, st>>>(pos_sta, c->S, inv, c->abs_sta);
+    k_abs_table<<<(c->G_ext * 4 + 255) / 256, 256, 0, st>>>(pos_src, c->G_ext, inv, c->abs_src);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
 int genie_set_edge_features(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_edge_features: null context");
     if (c->pcsr && pos_sta) return fail(GENIE_ERR_STATE, "genie_set_edge_features: not available on an irregular product graph");
@@ -3094,7 +3163,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
-                    c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr};
+                    c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -3159,7 +3228,9 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         a.x_latent = tbuf1;
     }
 #endif
-    if (c->pcsr) {
+    if (c->abs_sta && !c->pcsr && !(c->use_b3 && B3_ABS_READY)) {      // use_absolute_pos: generic kernel (64-bit safe, any graph)
+        k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
+    } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
     } else if (c->use_b3) {

@@ -156,7 +156,7 @@ class HipPath(object):
         with torch.no_grad():
             for name, n, off in zip(self.w_names, self.w_numel, self.w_off):
                 if name not in named_tensors:
-                    if name.endswith(".weight_pos"):      # DataAggregationEdges columns: absent = plain DataAggregation
+                    if name.endswith(".weight_pos") or name.endswith(".weight_abs"):   # optional columns: absent = plain DataAggregation
                         self._blob[off:off + n].zero_()
                         continue
                     raise KeyError("missing parameter %s" % name)
@@ -316,6 +316,17 @@ class HipPath(object):
         _lib.check(self.lib.genie_nbr_mean(self.ctx, _ptr(args[0]), _ptr(args[2]), _ptr(args[1]), _ptr(args[3]), width, _stream()),
                    "genie_nbr_mean")
         return tuple(None if o is None else o[0][:, :o[1]] for o in outs)
+
+    def set_absolute_pos(self, pos_sta, pos_src):
+        """`use_absolute_pos` (config.yaml:92): station [n_sta,3] / source [n_grid_ext,3] positions appended (scaled by
+        1 / (3 scale_rel)) to every product node's input; `None, None` = off (genie_set_absolute_pos)."""
+        if pos_sta is None or pos_src is None:
+            _lib.check(self.lib.genie_set_absolute_pos(self.ctx, None, None, _stream()), "genie_set_absolute_pos")
+            return
+        pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
+        pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
+        _lib.check(self.lib.genie_set_absolute_pos(self.ctx, _ptr(pos_sta), _ptr(pos_src), _stream()), "genie_set_absolute_pos")
+        torch.cuda.current_stream(self.device).synchronize()
 
     def set_edge_features(self, pos_sta, pos_src):
         """DataAggregationEdges (module.py:102-174): station / source-node positions [n,3] from which the library derives

@@ -42,8 +42,11 @@ class DataAggregation(nn.Module):
     """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
     applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
 
-    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4):
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4, use_absolute_pos=False):
         super().__init__()
+        if use_absolute_pos:
+            in_channels = in_channels + 3 * 2          # module.py:56-57
+
         self.in_channels, self.out_channels, self.n_hidden = in_channels, out_channels, n_hidden
         self.activate = nn.PReLU()
         self.init_trns = nn.Linear(in_channels + n_dim_mask, n_hidden)
@@ -87,6 +90,16 @@ class DataAggregationEdges(nn.Module):
         self.activate21 = nn.PReLU()
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
+
+
+def _split_abs_columns(named):
+    """Registry view under use_absolute_pos: init_trns.weight [30, 14] = [Slice 4 | station pos 3 | source pos 3 | Mask 4]
+    -> the usual [30, 8] plus `init_trns.weight_abs` [30, 6] (include/genie_hip.h, genie_set_absolute_pos)."""
+    out = dict(named)
+    W = named["DataAggregation.init_trns.weight"].detach()
+    out["DataAggregation.init_trns.weight"] = torch.cat((W[:, :4], W[:, 10:]), dim=1).contiguous()
+    out["DataAggregation.init_trns.weight_abs"] = W[:, 4:10].contiguous()
+    return out
 
 
 def _split_edge_columns(named):
@@ -424,12 +437,14 @@ class GCN_Detection_Network_extended(nn.Module):
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
                  use_updated_model_definition=False):
         super().__init__()
-        if use_absolute_pos:
-            raise NotImplementedError("use_absolute_pos=True is not supported by the HIP path")
+        # config.yaml:92: station / source positions appended to the inputs (module.py:916); forward_fixed_source only
+        if use_absolute_pos and use_updated_model_definition:
+            raise NotImplementedError("use_absolute_pos together with use_updated_model_definition")
         # config.yaml:95. True = the class of module.py:1022-1185: DataAggregationEdges on the hot path; its
         # `forward_fixed_source` is served here, its 4-output `forward` / `forward_fixed` (different association heads) are not
         self.use_updated_model_definition = bool(use_updated_model_definition)
-        self.DataAggregation = (DataAggregationEdges(4, 15) if self.use_updated_model_definition else DataAggregation(4, 15)).to(device)
+        self.DataAggregation = (DataAggregationEdges(4, 15) if self.use_updated_model_definition
+                                else DataAggregation(4, 15, use_absolute_pos=use_absolute_pos)).to(device)
         self.Bipartite_ReadIn = BipartiteGraphOperator(30, 15, ndim_edges=3).to(device)
         self.SpatialAggregation1 = SpatialAggregation(15, 30, scale_rel=scale_rel).to(device)
         self.SpatialAggregation2 = SpatialAggregation(30, 30, scale_rel=scale_rel).to(device)
@@ -439,7 +454,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self.TemporalAttention = TemporalAttention(30, 1, 15).to(device)
         self.BipartiteGraphReadOutOperator = BipartiteGraphReadOutOperator(30, 15).to(device)
         self.DataAggregationAssociationPhase = DataAggregationAssociationPhase(
-            15, 15, n_edge=4 if self.use_updated_model_definition else 0).to(device)
+            15 + (6 if use_absolute_pos else 0), 15, n_edge=4 if self.use_updated_model_definition else 0).to(device)
         self.LocalSliceLgCollapseP = LocalSliceLgCollapse(30, 15).to(device)
         self.LocalSliceLgCollapseS = LocalSliceLgCollapse(30, 15).to(device)
         self.Arrivals = StationSourceAttentionMergedPhases(30, 15, 2, 15, n_heads=3).to(device)
@@ -463,6 +478,10 @@ class GCN_Detection_Network_extended(nn.Module):
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_updated_model_definition=True needs station and source positions")
             self._hip.set_edge_features(pos_loc.to(dev), pos_src.to(dev))                 # module.py:1102-1111
+        if self.use_absolute_pos:
+            if pos_loc is None or pos_src is None:
+                raise ValueError("use_absolute_pos=True needs station and source positions")
+            self._hip.set_absolute_pos(pos_loc.to(dev), pos_src.to(dev))                  # module.py:1007
 
     def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                         A_edges_s, dt_partition, tlatent, pos_loc, pos_src):
@@ -496,8 +515,8 @@ class GCN_Detection_Network_extended(nn.Module):
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
         A_src_in_sta (grouped by source node) and the edge lists are irregular: product-level CSRs, generic HIP kernels."""
-        if self.use_updated_model_definition:
-            raise NotImplementedError("use_updated_model_definition with use_subgraph")
+        if self.use_updated_model_definition or self.use_absolute_pos:
+            raise NotImplementedError("use_updated_model_definition / use_absolute_pos with use_subgraph")
         pairs = torch.as_tensor(A_src_in_sta).long().cpu()
         n_prod = int(pairs.shape[1])
         src_of = pairs[1]
@@ -529,7 +548,7 @@ class GCN_Detection_Network_extended(nn.Module):
     def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else None)
+        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
         return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
 
     def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
@@ -549,7 +568,7 @@ class GCN_Detection_Network_extended(nn.Module):
         y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else None)
+        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
 
@@ -561,6 +580,8 @@ class GCN_Detection_Network_extended(nn.Module):
         if self.use_updated_model_definition:
             raise NotImplementedError("the 4-output forward of the use_updated_model_definition class (module.py:1128-1161) "
                                       "has different association heads; only forward_fixed_source is provided")
+        if self.use_absolute_pos:
+            raise NotImplementedError("forward_fixed with use_absolute_pos: only forward_fixed_source is provided")
         if getattr(self, "_sta_tab", None) is None:
             raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
                                       "set_adjacencies_base): only forward_fixed_source is available here")

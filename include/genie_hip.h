@@ -86,6 +86,12 @@ int genie_set_slot(genie_ctx* ctx, int slot);
 int genie_set_tail_mode(genie_ctx* ctx, int slim);
 /* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
 int genie_set_scale_t(genie_ctx* ctx, float scale_t);
+/* `use_absolute_pos: True` (config.yaml:92; module.py:916, :971, :1007): every product node's input gets its station position and
+ * its source position, each divided by 3 * scale_rel, appended (in_channels 4 -> 10). Positions are [n_sta,3] / [n_grid_ext,3]
+ * fp32 device pointers; the 6 extra columns of init_trns.weight go to the registry entry "DataAggregation.init_trns.weight_abs"
+ * ([30,6] = weight[:, 4:10]) and "DataAggregation.init_trns.weight" keeps the [30,8] layout (weight[:, [0:4, 10:14]]). Stage 1 then
+ * runs the generic fp32-MFMA kernel (the neighbours' hidden states are recomputed with their own positions). Null = off. */
+int genie_set_absolute_pos(genie_ctx* ctx, const float* pos_sta, const float* pos_src, void* stream);
 /* DataAggregationEdges variant (`use_updated_model_definition: True`, config.yaml:95; module.py:102-174): every message is
  * [x_j || phi(pos_j - pos_i) || phi(|pos_j - pos_i|)], phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)) (forward :1059-1072,
  * set_adjacencies :1102-1111). On the product graph the mean of those 4 edge features is a static vector per station

@@ -87,6 +87,12 @@ def data_aggregation(w, Slice, Mask, A_in_sta, A_in_src, pre="DataAggregation", 
     return x_latent
 
 
+def absolute_pos_inputs(Slice, locs, x_grid, A_src_in_sta, scale_rel=SCALE_REL):
+    """`use_absolute_pos: True` (config.yaml:92): module.py:1007 appends the station and the source position of every product
+    node, divided by 3 * scale_rel, to Slice (in_channels 4 -> 10)."""
+    return torch.cat((Slice, locs[A_src_in_sta[0]] / (3.0 * scale_rel), x_grid[A_src_in_sta[1]] / (3.0 * scale_rel)), dim=1)
+
+
 def edge_pos_features(pos, edge_index, node_of=None, scale_rel=SCALE_REL):
     """Edge features of the `use_updated_model_definition` variant (module.py:1059-1072 / :1102-1111): for an edge j -> i,
     d = pos[j] - pos[i] (3), |d| (1), each through phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)). `node_of` maps product
@@ -271,6 +277,8 @@ def forward_fixed_source(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in
                          x_grid_cart, x_query_cart, t_query, full=False, query_edges=None, pos_rel=None):
     """Literal formulation. `use_absolute_pos=False` (config.yaml:92). Returns (y, x) or a dict. `pos_rel` =
     (pos_rel_sta, pos_rel_src) selects the DataAggregationEdges variant (module.py:1163-1185)."""
+    if w["DataAggregation.init_trns.weight"].shape[1] == 14 and Slice.shape[1] == 4:
+        raise ValueError("use_absolute_pos weights: append the scaled positions to Slice first (absolute_pos_inputs)")
     if pos_rel is not None:
         da = data_aggregation_edges(w, Slice, Mask, A_in_sta, A_in_src, pos_rel[0], pos_rel[1], full=True)
     else:

@@ -20,27 +20,31 @@ REF_CODE = "/root/reference/Code"
 OUT = os.path.join(REPO, "tests", "golden")
 
 
-def _import_reference(updated_definition=False):
+def _import_reference(updated_definition=False, absolute_pos=False):
     sys.dont_write_bytecode = True
     sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
     sys.path.insert(0, REF_CODE)
     sys.path.insert(0, REPO)
     cwd = REF_CODE                # module.py:27-31 reads config.yaml / train_config.yaml from the CWD
-    if updated_definition:
-        # `use_updated_model_definition` is read from config.yaml at import time (module.py:33): import the reference from a
-        # scratch directory holding its YAML files with that one flag flipped
+    if updated_definition or absolute_pos:
+        # `use_updated_model_definition` / `use_absolute_pos` are read from config.yaml at import time (module.py:32-33): import
+        # the reference from a scratch directory holding its YAML files with that one flag flipped
         import tempfile
         cwd = tempfile.mkdtemp(prefix="genie_cfg_")
         for f in os.listdir(REF_CODE):
             if f.endswith(".yaml"):
                 txt = open(os.path.join(REF_CODE, f)).read()
-                if f == "config.yaml":
+                if f == "config.yaml" and updated_definition:
                     assert "use_updated_model_definition: False" in txt
                     txt = txt.replace("use_updated_model_definition: False", "use_updated_model_definition: True")
+                if f == "config.yaml" and absolute_pos:
+                    assert "use_absolute_pos: False" in txt
+                    txt = txt.replace("use_absolute_pos: False", "use_absolute_pos: True")
                 open(os.path.join(cwd, f), "w").write(txt)
     os.chdir(cwd)
     import module as ref_module   # noqa: E402
     assert bool(ref_module.use_updated_model_definition) == bool(updated_definition)
+    assert bool(ref_module.use_absolute_pos) == bool(absolute_pos)
     return ref_module
 
 
@@ -245,6 +249,23 @@ def main_edges():
              keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
 
 
+def main_abspos():
+    """`python oracle/make_golden.py --abspos`: fixtures of the live model with `use_absolute_pos: True` (config.yaml:92): station
+    and source positions / (3 scale_rel) appended to every product node's input (module.py:1007), in_channels 4 -> 10."""
+    ref = _import_reference(absolute_pos=True)
+    from genie_amd import synthetic as syn
+
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(12, 60, L=80e3, n_query=30, seed=101)          # uniform 8 / 15 degrees
+    win = syn.make_window(geom, 150, seed=102)
+    run_case(ref, "abspos_12x60", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
+    geom = syn.Geometry(7, 13, L=50e3, n_query=9, seed=103)            # ks = 6, kp = 12
+    win = syn.make_window(geom, 40, seed=104)
+    run_case(ref, "abspos_7x13", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
+
+
 def main_subgraph():
     """`python oracle/make_golden.py --subgraph`: the live model on an irregular product graph (`use_subgraph: True`): every
     source node keeps its 6 nearest stations plus a few random ones, as the reference's builder keeps the k nearest pairs plus
@@ -279,6 +300,8 @@ def main():
         return main_edges()
     if "--subgraph" in sys.argv:
         return main_subgraph()
+    if "--abspos" in sys.argv:
+        return main_abspos()
     ref = _import_reference()
     from genie_amd import synthetic as syn
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from genie_amd import engine, graph, module, synthetic
-from tests.util import EDGES_CASES, GOLDEN_CASES, SUBGRAPH_CASES, Case, max_abs
+from tests.util import ABSPOS_CASES, EDGES_CASES, GOLDEN_CASES, SUBGRAPH_CASES, Case, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -115,6 +115,31 @@ def test_updated_model_definition_forward_fixed_source(name, stage1, monkeypatch
     assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
     with pytest.raises(NotImplementedError):
         net.forward_fixed(c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, None, None, None, None, None, None, None)
+
+
+@pytest.mark.parametrize("name", ABSPOS_CASES)
+def test_use_absolute_pos_forward_fixed_source(name):
+    """`use_absolute_pos: True` (config.yaml:92, module.py:1007): every product node's input carries its station and source
+    position / (3 scale_rel); the neighbour recompute uses each NEIGHBOUR's positions (genie_set_absolute_pos)."""
+    c = Case(name)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_absolute_pos=True)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea, A_src_in_sta.to(DEV), c.A_src_src.to(DEV),
+                        None, None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    with torch.no_grad():
+        y, x = net.forward_fixed_source(c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV),
+                                        c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+        hp = net._hip
+        _, _, h0, h1 = hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV), debug=True)
+        x_latent, bip = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV), want_x_latent=True)
+    for k, v in (("h0", h0), ("h1", h1), ("x_latent", x_latent), ("bip", bip)):
+        ref = c.ref(k)
+        assert max_abs(v.cpu(), ref) <= rel_tol(ref), (k, max_abs(v.cpu(), ref))
+    assert max_abs(y.cpu(), c.ref("y")) <= 1e-5 and max_abs(x.cpu(), c.ref("x")) <= 1e-5
+    assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
 
 
 @pytest.mark.parametrize("name", SUBGRAPH_CASES)

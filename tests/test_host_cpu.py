@@ -41,6 +41,20 @@ def test_state_dict_of_updated_model_definition_matches_reference():
     assert torch.equal(view["DataAggregation.l2_t1_2.weight_pos"], W[:, 90:94])
 
 
+def test_state_dict_with_absolute_pos_matches_reference():
+    """`use_absolute_pos: True` (config.yaml:92): init_trns [30,14], l1_t2_1 [30,10], association init_trns [30,56]."""
+    c = Case("abspos_12x60")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu", use_absolute_pos=True)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(c.weights.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(c.weights[k].shape), k
+    view = module._split_abs_columns(c.weights)
+    W = c.weights["DataAggregation.init_trns.weight"]
+    assert torch.equal(view["DataAggregation.init_trns.weight"], torch.cat((W[:, :4], W[:, 10:]), 1))
+    assert torch.equal(view["DataAggregation.init_trns.weight_abs"], W[:, 4:10])
+
+
 def test_subgraph_product_edges_match_the_reference_builder():
     """genie_amd.graph.subgraph_product_edges against the output of the reference's extract_inputs_adjacencies_subgraph
     (process_utils.py:744-849; fixture written by oracle/make_golden.py --subgraph): same edge sets, same A_src_in_prod."""
@@ -70,6 +84,9 @@ def test_library_exports_every_declared_symbol(repo_root):
     for n_, i in zip(names, range(len(names))):
         if n_.endswith(".weight_pos"):      # the 4 edge-feature columns of the use_updated_model_definition variant
             assert edges[n_].numel() == lib.genie_weights_numel(i)
+            continue
+        if n_.endswith(".weight_abs"):      # the 6 absolute-position columns of init_trns (use_absolute_pos)
+            assert module._split_abs_columns(Case("abspos_12x60").weights)[n_].numel() == lib.genie_weights_numel(i)
             continue
         assert n_ in ref, n_
         assert ref[n_].numel() == lib.genie_weights_numel(i) == edges[n_].numel()

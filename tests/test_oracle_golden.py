@@ -4,7 +4,7 @@ intermediates and 1e-6 absolute on the outputs (y, x); fp64 tolerance 1e-12."""
 import pytest
 import torch
 
-from tests.util import EDGES_CASES, GOLDEN_CASES, SUBGRAPH_CASES, Case, max_abs
+from tests.util import ABSPOS_CASES, EDGES_CASES, GOLDEN_CASES, SUBGRAPH_CASES, Case, max_abs
 
 INTERMEDIATES = ["h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"]
 
@@ -72,6 +72,21 @@ def test_oracle_on_irregular_product_graph_matches_reference(name):
     out = c.oracle_forward(torch.float32)
     assert out["x_latent"].shape[0] == c.z["pairs"].shape[1] < c.S * c.G
     for k in ["h0", "h1", "x_latent", "bip", "sa1", "sa3", "y_latent", "y", "x"]:
+        ref = c.ref(k)
+        assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
+
+
+@pytest.mark.parametrize("name", ABSPOS_CASES)
+def test_oracle_with_absolute_positions_matches_reference(name):
+    """`use_absolute_pos: True` (config.yaml:92): fixtures from the reference imported with that flag (in_channels 10)."""
+    c = Case(name)
+    assert c.abspos_variant
+    out = c.oracle_forward(torch.float32)
+    for k in ["h0", "h1", "x_latent", "bip", "sa3", "y", "x"]:
         ref = c.ref(k)
         assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
     out64 = c.oracle_forward(torch.float64)

@@ -11,6 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["tiny_6x40", "cfg1_20x500", "odd_33x257"]
 EDGES_CASES = ["edges_12x60", "edges_7x13"]      # use_updated_model_definition class (DataAggregationEdges)
 SUBGRAPH_CASES = ["subgraph_14x50"]               # use_subgraph: irregular product graph
+ABSPOS_CASES = ["abspos_12x60", "abspos_7x13"]    # use_absolute_pos: positions appended to the inputs
 
 
 class Case(object):
@@ -33,6 +34,7 @@ class Case(object):
         self.t_query = torch.from_numpy(z["t_query"])
         self.weights = O.weights_from_npz(z, torch.float32)
         self.edges_variant = self.weights["DataAggregation.l1_t1_2.weight"].shape[1] == 68
+        self.abspos_variant = self.weights["DataAggregation.init_trns.weight"].shape[1] == 14
 
     def product_edges(self):
         if "pairs" in self.z.files:      # irregular product graph (use_subgraph, process_utils.py:744-849)
@@ -56,19 +58,22 @@ class Case(object):
     def oracle_forward(self, dtype=torch.float32, structured=False):
         w = {k: v.to(dtype) for k, v in self.weights.items()}
         args = dict(full=True)
-        if structured and not self.edges_variant:
+        if structured and not self.edges_variant and not self.abspos_variant:
             sta_nbr, src_nbr = self.tables()
             return O.forward_fixed_source_structured(
                 w, self.Slice.to(dtype), self.Mask.to(dtype), sta_nbr, src_nbr, self.edge_attr.to(dtype),
                 self.A_src_src, self.x_grid.to(dtype), self.x_query.to(dtype), self.t_query.to(dtype),
                 self.S, self.G, **args)
         A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = self.product_edges()
+        Slice = self.Slice.to(dtype)
+        if self.abspos_variant:
+            Slice = O.absolute_pos_inputs(Slice, self.locs.to(dtype), self.x_grid.to(dtype), A_src_in_sta)
         if self.edges_variant:
             assert not structured
             args["pos_rel"] = (O.edge_pos_features(self.locs.to(dtype), A_in_sta, A_src_in_sta[0]),
                                O.edge_pos_features(self.x_grid.to(dtype), A_in_src, A_src_in_sta[1]))
         return O.forward_fixed_source(
-            w, self.Slice.to(dtype), self.Mask.to(dtype), A_in_sta, A_in_src, self.edge_attr.to(dtype),
+            w, Slice, self.Mask.to(dtype), A_in_sta, A_in_src, self.edge_attr.to(dtype),
             A_src_in_prod, self.A_src_src, self.x_grid.to(dtype), self.x_query.to(dtype),
             self.t_query.to(dtype), **args)
 
