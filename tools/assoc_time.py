@@ -27,7 +27,11 @@ def main():
         y_latent = net.SpatialDirect(x_spatial)
         mask_out = (torch.rand(G, 1, device=dev) > 0.5).float()
         outs = {}
-        for name, hip in (("torch gathers", None), ("HIP neighbour means", net._hip)):
+        for name, hip in (("torch gathers", None), ("HIP neighbour means", net._hip), ("HIP means + blocked GEMMs", net._hip)):
+            if name == "HIP neighbour means":
+                os.environ["GENIE_ASSOC_PLAIN"] = "1"
+            else:
+                os.environ.pop("GENIE_ASSOC_PLAIN", None)
             def heads():
                 s, m1 = net.BipartiteGraphReadOutOperator(y_latent, net._edge_attr, mask_out, S)
                 return net.DataAggregationAssociationPhase(s, x_latent, m1, Mask, net._sta_tab, net._src_tab, S, G, hip=hip)
@@ -36,8 +40,9 @@ def main():
             for _ in range(5): heads()
             torch.cuda.synchronize()
             print("P-sized association heads, %s: %.2f ms" % (name, (time.perf_counter() - t0) / 5 * 1e3))
-        a_, b_ = outs["torch gathers"], outs["HIP neighbour means"]
-        print("max|diff| %.3e  max|ref| %.3e" % (float((a_ - b_).abs().max()), float(a_.abs().max())))
+        a_ = outs["torch gathers"]
+        for k in ("HIP neighbour means", "HIP means + blocked GEMMs"):
+            print("%s: max|diff| %.3e  max|ref| %.3e" % (k, float((a_ - outs[k]).abs().max()), float(a_.abs().max())))
 
 if __name__ == "__main__":
     main()
