@@ -2665,11 +2665,14 @@ __global__ void k_edge_bias(const float* __restrict__ raw, int off1, int off2, c
 // Neighbour means on the implicit product graph for arbitrary row widths (association heads, module.py:389-403):
 //   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))],   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]
 // rows of C = 4*C4 floats; C4 lanes per node, every lane keeps up to 8 row chunks in flight; sums in edge order.
+// With per-edge weights (w_sta / w_src non-null) the same kernel is the ADJOINT of the mean on the reversed graphs:
+//   dx[j] = sum_{i : j in N(i)} g[i] / deg(i)   (genie_nbr_mean_bwd; edge lists = out-edges of j, weights 1 / in-degree of i)
 template <int C4>
 __global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
                                                   const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
                                                   const float* __restrict__ x_sta, const float* __restrict__ x_src,
-                                                  float* __restrict__ out_sta, float* __restrict__ out_src) {
+                                                  float* __restrict__ out_sta, float* __restrict__ out_src,
+                                                  const float* __restrict__ w_sta = nullptr, const float* __restrict__ w_src = nullptr) {
     constexpr int NPB_ = 256 / C4;
     const int c4 = threadIdx.x % C4;
     const long long P = (long long)S * G;
@@ -2681,21 +2684,25 @@ __global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* _
             float* out = which == 0 ? out_sta : out_src;
             if (x == nullptr) continue;
             const int32_t* col = which == 0 ? sta_col : src_col;
+            const float* ew = which == 0 ? w_sta : w_src;
             const int eb = which == 0 ? sta_rowptr[s] : src_rowptr[g], ee = which == 0 ? sta_rowptr[s + 1] : src_rowptr[g + 1];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int e0 = eb; e0 < ee; e0 += 8) {
                 f32x4 v[8];
+                float wk[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int j = col[min(e0 + k, ee - 1)];
+                    const int e = min(e0 + k, ee - 1);
+                    const int j = col[e];
                     const long long row = which == 0 ? (long long)g * S + j : (long long)j * S + s;
                     v[k] = *(const f32x4*)(x + row * (4 * C4) + 4 * c4);
+                    wk[k] = ew ? ew[e] : 1.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (e0 + k < ee) acc += v[k];
+                    if (e0 + k < ee) acc += v[k] * wk[k];
             }
-            const float w = ee > eb ? 1.f / (float)(ee - eb) : 0.f;
+            const float w = ew ? 1.f : (ee > eb ? 1.f / (float)(ee - eb) : 0.f);
             *(f32x4*)(out + p * (4 * C4) + 4 * c4) = acc * w;
         }
     }
@@ -2740,6 +2747,9 @@ struct genie_ctx {
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
     float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
+    // reversed base graphs (out-edges, weights 1 / in-degree of the target): built on the first genie_nbr_mean_bwd
+    int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
+    float *r_sta_w, *r_src_w;
     float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
@@ -2961,6 +2971,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
     c->abs_sta = c->abs_src = nullptr;
+    c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
+    c->r_sta_w = c->r_src_w = nullptr;
     c->pcsr = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
@@ -3163,7 +3175,8 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
-                    c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src};
+                    c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
+                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -3557,6 +3570,68 @@ int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* 
         default: return fail(GENIE_ERR_ARG, "genie_nbr_mean: row_floats must be 16 or 32");
     }
 #undef GENIE_NM
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+namespace {
+// out-edge CSR of a graph given as in-edge CSR (rowptr by target i, col = source j): for every j the targets i in increasing
+// order, with weight 1 / in-degree(i)
+int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int n_src, int32_t** r_rowptr, int32_t** r_col, float** r_w) {
+    std::vector<int32_t> rp((size_t)n_tgt + 1);
+    HIP_TRY(hipMemcpy(rp.data(), d_rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+    const size_t E = (size_t)rp[n_tgt];
+    std::vector<int32_t> col(E);
+    if (E) HIP_TRY(hipMemcpy(col.data(), d_col, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
+    std::vector<int32_t> rrp((size_t)n_src + 1, 0), rcol(E);
+    std::vector<float> rw(E);
+    for (size_t e = 0; e < E; ++e) {
+        if (col[e] < 0 || col[e] >= n_src) return fail(GENIE_ERR_ARG, "neighbour id out of range");
+        ++rrp[(size_t)col[e] + 1];
+    }
+    for (int j = 0; j < n_src; ++j) rrp[(size_t)j + 1] += rrp[j];
+    std::vector<int32_t> fill(rrp.begin(), rrp.end() - 1);
+    for (int i = 0; i < n_tgt; ++i) {
+        const float w = 1.f / (float)std::max(1, rp[i + 1] - rp[i]);
+        for (int e = rp[i]; e < rp[i + 1]; ++e) {
+            const int32_t pos = fill[col[e]]++;
+            rcol[pos] = i;
+            rw[pos] = w;
+        }
+    }
+    HIP_TRY(hipMalloc((void**)r_rowptr, sizeof(int32_t) * rrp.size()));
+    HIP_TRY(hipMemcpy(*r_rowptr, rrp.data(), sizeof(int32_t) * rrp.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)r_col, sizeof(int32_t) * std::max<size_t>(E, 1)));
+    HIP_TRY(hipMalloc((void**)r_w, sizeof(float) * std::max<size_t>(E, 1)));
+    if (E) {
+        HIP_TRY(hipMemcpy(*r_col, rcol.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(*r_w, rw.data(), sizeof(float) * E, hipMemcpyHostToDevice));
+    }
+    return GENIE_OK;
+}
+}  // namespace
+
+int genie_nbr_mean_bwd(genie_ctx* c, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
+                       void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_nbr_mean_bwd: null context");
+    if ((g_sta && !dx_sta) || (g_src && !dx_src)) return fail(GENIE_ERR_ARG, "genie_nbr_mean_bwd: input without output");
+    if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_nbr_mean_bwd: needs an unsharded Cartesian product graph");
+    if (!g_sta && !g_src) return GENIE_OK;
+    if (!c->r_sta_rowptr) {
+        int rc;
+        if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w))) return rc;
+        if ((rc = build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w))) return rc;
+    }
+    const int nb = std::min<long long>((c->P + 31) / 32, (long long)c->num_cu * 16);
+    hipStream_t st = (hipStream_t)stream;
+#define GENIE_NMB(C4_) k_nbr_mean<C4_><<<nb, 256, 0, st>>>(c->S, c->G, c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, \
+                                                            g_sta, g_src, dx_sta, dx_src, c->r_sta_w, c->r_src_w)
+    switch (row_floats) {
+        case 16: GENIE_NMB(4); break;
+        case 32: GENIE_NMB(8); break;
+        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean_bwd: row_floats must be 16 or 32");
+    }
+#undef GENIE_NMB
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

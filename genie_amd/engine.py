@@ -317,6 +317,28 @@ class HipPath(object):
                    "genie_nbr_mean")
         return tuple(None if o is None else o[0][:, :o[1]] for o in outs)
 
+    def nbr_mean_bwd(self, g_sta=None, g_src=None):
+        """Adjoint of `nbr_mean` (genie_nbr_mean_bwd): gradients w.r.t. the rows that were averaged."""
+        outs, args, width = [], [], None
+        for g in (g_sta, g_src):
+            if g is None:
+                args += [None, None]
+                outs.append(None)
+                continue
+            g = _f32(g, "grad")
+            C = g.shape[1]
+            w = 16 if C <= 16 else 32
+            if C > 32 or g.shape[0] != self.n_prod or (width is not None and w != width):
+                raise ValueError("nbr_mean_bwd: rows must be [n_prod, C <= 32] of one padded width")
+            width = w
+            gp = g if C == w else torch.nn.functional.pad(g, (0, w - C))
+            o = torch.empty_like(gp)
+            args += [gp, o]
+            outs.append((o, C))
+        _lib.check(self.lib.genie_nbr_mean_bwd(self.ctx, _ptr(args[0]), _ptr(args[2]), _ptr(args[1]), _ptr(args[3]), width, _stream()),
+                   "genie_nbr_mean_bwd")
+        return tuple(None if o is None else o[0][:, :o[1]] for o in outs)
+
     def set_absolute_pos(self, pos_sta, pos_src):
         """`use_absolute_pos` (config.yaml:92): station [n_sta,3] / source [n_grid_ext,3] positions appended (scaled by
         1 / (3 scale_rel)) to every product node's input; `None, None` = off (genie_set_absolute_pos)."""

@@ -39,6 +39,27 @@ def _path_param_dict(net):
     return out
 
 
+class _NbrMean(torch.autograd.Function):
+    """Neighbour means over the product graph with HIP forward (genie_nbr_mean) and HIP adjoint (genie_nbr_mean_bwd): the
+    irregular, P-sized part of a training step; everything dense around it is differentiated by autograd."""
+
+    @staticmethod
+    def forward(ctx, x_sta, x_src, hip):
+        ctx.hip = hip
+        return hip.nbr_mean(x_sta.detach(), x_src.detach())
+
+    @staticmethod
+    def backward(ctx, g_sta, g_src):
+        d_sta, d_src = ctx.hip.nbr_mean_bwd(g_sta.contiguous(), g_src.contiguous())
+        return d_sta, d_src, None
+
+
+def _scatter_mean_rows(msg, index, n):
+    out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device).index_add_(0, index, msg)
+    cnt = torch.zeros(n, dtype=msg.dtype, device=msg.device).index_add_(0, index, torch.ones_like(index, dtype=msg.dtype))
+    return out / cnt.clamp(min=1).view(-1, 1)
+
+
 class DataAggregation(nn.Module):
     """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
     applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
@@ -65,6 +86,17 @@ class DataAggregation(nn.Module):
         self.activate21 = nn.PReLU()
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
+
+    def forward_train(self, Slice, Mask, hip):
+        """Differentiable restatement of module.py:85-98 for training steps (first pass): per-node Linears and
+        PReLUs on PyTorch-ROCm autograd, the four neighbour means through `_NbrMean` (HIP forward and adjoint)."""
+        tr = self.activate(self.init_trns(torch.cat((Slice, Mask), dim=-1)))
+        n1, n2 = _NbrMean.apply(self.activate11(tr), self.activate12(tr), hip)
+        tr = self.activate1(torch.cat((self.l1_t1_2(torch.cat((tr, n1, Mask), dim=1)),
+                                       self.l1_t2_2(torch.cat((tr, n2, Mask), dim=1))), dim=1))
+        m1, m2 = _NbrMean.apply(self.activate21(self.l2_t1_1(tr)), self.activate22(self.l2_t2_1(tr)), hip)
+        return self.activate2(torch.cat((self.l2_t1_2(torch.cat((tr, m1, Mask), dim=1)),
+                                         self.l2_t2_2(torch.cat((tr, m2, Mask), dim=1))), dim=1))
 
 
 class DataAggregationEdges(nn.Module):
@@ -125,6 +157,12 @@ class BipartiteGraphOperator(nn.Module):
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
+    def forward_train(self, x_latent, edge_attr, Mask, n_sta, n_grid):
+        """module.py:224-229, differentiable (the station sum is a view-sum on the Cartesian layout p = g * n_sta + s)."""
+        m = Mask.max(1, keepdim=True)[0]
+        msg = m * self.activate1(self.fc1(torch.cat((x_latent, edge_attr), dim=-1)))
+        return self.activate2(self.fc2(msg.view(n_grid, n_sta, -1).sum(dim=1)))
+
 
 class SpatialAggregation(nn.Module):
     """Parameters of reference `SpatialAggregation` (module.py:232-241)."""
@@ -138,6 +176,15 @@ class SpatialAggregation(nn.Module):
         self.activate2 = nn.PReLU()
         self.activate3 = nn.PReLU()
         self.scale_rel = scale_rel
+
+    def forward_train(self, tr, A_src, pos):
+        """module.py:243-249, differentiable (G-sized: plain index gathers / index_add)."""
+        j, i = A_src[0], A_src[1]
+        p = pos / self.scale_rel
+        x_j = tr[j]
+        c = self.activate3(self.fglobal(x_j)).mean(0, keepdim=True)
+        msg = self.activate1(self.fc1(torch.cat((x_j, p[i] - p[j], c.expand(x_j.shape[0], -1)), dim=-1)))
+        return self.activate2(self.fc2(torch.cat((tr, _scatter_mean_rows(msg, i, tr.shape[0])), dim=-1)))
 
 
 class SpatialDirect(nn.Module):
@@ -619,9 +666,36 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
         return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
 
+    def _differentiable(self):
+        return self.training and torch.is_grad_enabled()
+
+    def _path_train(self, Slice, Mask, x_temp_cuda_cart):
+        """Training-mode forward of the path (first pass): same arithmetic with autograd. The P-sized
+        neighbour means run in HIP in both directions (`_NbrMean`); the per-node Linears are rocBLAS GEMMs under autograd.
+        Used when the module is in train() mode with gradients enabled; eval / no_grad calls take the fused HIP path."""
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) first")
+        if self.use_updated_model_definition or self.use_absolute_pos or self._hip._n_prod is not None:
+            raise NotImplementedError("training-mode forward: default model definition on a Cartesian product graph only")
+        hp = self._hip
+        Slice = _engine._f32(Slice, "Slice", (hp.n_prod, 4))
+        Mask = _engine._f32(Mask, "Mask", (hp.n_prod, 4))
+        x_latent = self.DataAggregation.forward_train(Slice, Mask, hp)
+        x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid)
+        A_src = torch.as_tensor(self.A_src).long().to(x.device)
+        pos = x_temp_cuda_cart.float()
+        for sa in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3):
+            x = sa.forward_train(x, A_src, pos)
+        return x, x_latent
+
     def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
                              x_query_cart, t_query):
         """module.py:999-1020. `tpick`, `ipick`, `phase_label` are accepted and ignored, as in the reference."""
+        if self._differentiable():
+            x_spatial, _ = self._path_train(Slice, Mask, x_temp_cuda_cart)
+            y = self.TemporalAttention(self.SpatialDirect(x_spatial), t_query)
+            x = self.TemporalAttention(self._spatial_attention_uncached(x_spatial, x_query_cart, x_temp_cuda_cart), t_query)
+            return y, x
         x_spatial, _, _ = self._path(Slice, Mask, x_temp_cuda_cart)                       # :1010-1014
         y = self._hip.readout_grid(x_spatial, t_query)                                     # :1015-1016
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)        # :282 (cached per query set)

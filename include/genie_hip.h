@@ -216,6 +216,10 @@ int genie_embed_window(genie_ctx* ctx, const double* pick_t, const int32_t* pick
  * per-node Linears run on PyTorch-ROCm; an empty neighbourhood gives 0. */
 int genie_nbr_mean(genie_ctx* ctx, const float* x_sta, const float* x_src, float* out_sta, float* out_src, int row_floats,
                    void* stream);
+/* Adjoint of genie_nbr_mean (training): dx_sta[(g,j)] = sum_{i : j in N_sta(i)} g_sta[(g,i)] / deg(i), likewise for the source
+ * graph. Deterministic (a gather over the reversed graphs, built once per context); unsharded Cartesian contexts only. */
+int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
+                       void* stream);
 
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */

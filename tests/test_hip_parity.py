@@ -373,6 +373,48 @@ def test_nbr_mean_matches_torch_gathers(S, G, C):
         assert max_abs(o1, t1) <= 1e-6 and max_abs(o2, t2) <= 1e-6
 
 
+@pytest.mark.parametrize("name", ["tiny_6x40", "cfg1_20x500"])
+def test_training_mode_forward_and_gradients_match_oracle_autograd(name):
+    """a-8 (first pass): in train() mode with gradients enabled forward_fixed_source takes the differentiable formulation
+    (neighbour means through genie_nbr_mean / genie_nbr_mean_bwd, dense algebra under autograd). Its outputs equal the fused
+    HIP path and the gradient of a random linear functional of (y, x) w.r.t. every parameter of the path equals the oracle's
+    autograd gradient (fp32 CPU) to 1e-5 of the gradient scale."""
+    from oracle import genie_oracle as O
+    c = Case(name)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    args = (c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV),
+            c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    net.eval()
+    with torch.no_grad():
+        y_hip, x_hip = net.forward_fixed_source(*args)
+    net.train()
+    y, x = net.forward_fixed_source(*args)
+    assert y.requires_grad and x.requires_grad
+    assert max_abs(y.detach(), y_hip) <= 1e-6 and max_abs(x.detach(), x_hip) <= 1e-6
+    g = torch.Generator().manual_seed(7)
+    ay, ax = torch.randn(y.shape, generator=g), torch.randn(x.shape, generator=g)
+    (y * ay.to(DEV)).sum().add((x * ax.to(DEV)).sum()).backward()
+    # oracle autograd on the CPU
+    w = {k: v.clone().requires_grad_(True) for k, v in c.weights.items()}
+    A_in_sta, A_in_src, A_src_in_prod, _ = c.product_edges()
+    yo, xo = O.forward_fixed_source(w, c.Slice, c.Mask, A_in_sta, A_in_src, c.edge_attr, A_src_in_prod, c.A_src_src,
+                                    c.x_grid.float(), c.x_query.float(), c.t_query.float())
+    ((yo * ay).sum() + (xo * ax).sum()).backward()
+    checked = 0
+    for k, p in net.named_parameters():
+        if w[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = w[k].grad
+        assert p.grad is not None, k
+        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
+        checked += 1
+    assert checked >= 80          # every tensor of DataAggregation, Bipartite_ReadIn, SpatialAggregation1..3 and the read-outs
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")
@@ -388,7 +430,7 @@ def test_all_zero_mask_gates_bipartite_sum():
 def test_weight_updates_are_picked_up():
     """In-place parameter updates (optimizer steps, load_state_dict) must reach the HIP mirror."""
     c = Case("tiny_6x40")
-    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV).eval()
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
     net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
     args = (c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV),
