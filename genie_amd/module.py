@@ -328,7 +328,7 @@ class BipartiteGraphReadOutOperator(nn.Module):
         self.activate2 = nn.PReLU()
 
     def forward(self, inpt, edge_attr, mask, n_sta):
-        if inpt.is_cuda:
+        if inpt.is_cuda and not (torch.is_grad_enabled() and inpt.requires_grad):
             return self._forward_blocked(inpt, edge_attr, mask, n_sta)
         g = torch.arange(edge_attr.shape[0], device=edge_attr.device) // n_sta
         msg = mask[g] * self.activate1(self.fc1(torch.cat((inpt[g], edge_attr), dim=-1)))            # :352
@@ -424,12 +424,14 @@ class DataAggregationAssociationPhase(nn.Module):
     def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid, hip=None):
         """`hip`: an engine.HipPath on the same graphs -> the four neighbour means run as genie_nbr_mean (HIP) instead of
         materialised index gathers (21 -> ~6 ms at config 2); the Linears stay on PyTorch-ROCm."""
-        if hip is not None and tr.is_cuda and self.l1_t1_2.weight.shape[1] == 65 and os.environ.get("GENIE_ASSOC_PLAIN") is None:
+        grad = torch.is_grad_enabled() and tr.requires_grad
+        if (hip is not None and tr.is_cuda and not grad and self.l1_t1_2.weight.shape[1] == 65
+                and os.environ.get("GENIE_ASSOC_PLAIN") is None):
             return self._forward_blocked(tr, latent, mask1, mask2, n_sta, n_grid, hip)
 
         def means(x1, x2):
             if hip is not None and x1.is_cuda:
-                return hip.nbr_mean(x1, x2)
+                return _NbrMean.apply(x1, x2, hip) if grad else hip.nbr_mean(x1, x2)
             return _mean_over_sta(x1, sta_nbr, n_sta, n_grid), _mean_over_src(x2, src_nbr, n_sta, n_grid)
 
         mask = torch.cat((mask1, mask2), dim=-1)
@@ -728,11 +730,17 @@ class GCN_Detection_Network_extended(nn.Module):
             raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
                                       "set_adjacencies_base): only forward_fixed_source is available here")
         S, G = self._hip.n_sta, self._hip.n_grid
-        x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)      # :973-977
-        y_latent = self.SpatialDirect(x_spatial)                                                     # :978
-        y = self._hip.readout_grid(x_spatial, t_query)                                               # :979
-        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
-        x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)         # :980,982
+        if self._differentiable():       # training step (train_GENIE_model.py:1786): same arithmetic under autograd
+            x_spatial, x_latent = self._path_train(Slice, Mask, x_temp_cuda_cart)
+            y_latent = self.SpatialDirect(x_spatial)
+            y = self.TemporalAttention(y_latent, t_query)
+            x = self.TemporalAttention(self._spatial_attention_uncached(x_spatial, x_query_cart, x_temp_cuda_cart), t_query)
+        else:
+            x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)  # :973-977
+            y_latent = self.SpatialDirect(x_spatial)                                                 # :978
+            y = self._hip.readout_grid(x_spatial, t_query)                                           # :979
+            knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+            x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)     # :980,982
         x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)      # :981
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
         s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986

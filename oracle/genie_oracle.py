@@ -428,7 +428,7 @@ def forward_fixed(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, 
     x_src = spatial_attention(w, o["sa3"], x_query_src_cart, x_grid_cart)                              # :981
     mask_out = 1.0 * (o["y"][:, :, 0].max(1, keepdim=True)[0] > 0.01)                                  # :985
     s, m1 = bipartite_read_out(w, o["y_latent"], edge_attr, mask_out.to(Slice.dtype), n_sta)           # :986
-    s = data_aggregation_association(w, s, o["x_latent"], m1, Mask, A_in_sta, A_in_src)                # :990
+    s = data_aggregation_association(w, s, o["x_latent"].detach(), m1, Mask, A_in_sta, A_in_src)       # :990 (x_latent.detach())
     arv_p = local_slice_collapse(w, A_edges_p, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 0:1], "LocalSliceLgCollapseP")
     arv_s = local_slice_collapse(w, A_edges_s, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 1:2], "LocalSliceLgCollapseS")
     arv = station_source_attention(w, x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick,

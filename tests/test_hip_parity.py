@@ -706,3 +706,48 @@ def test_forward_fixed_and_forward_four_outputs_match_reference():
         assert out[2].shape == tuple(z["arv_p"].shape) and out[3].shape == tuple(z["arv_s"].shape)
         assert max_abs(out[2].cpu(), torch.from_numpy(z["arv_p"])) <= 1e-5
         assert max_abs(out[3].cpu(), torch.from_numpy(z["arv_s"])) <= 1e-5
+
+
+def test_training_mode_four_output_forward_gradients_match_oracle_autograd():
+    """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
+    mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones."""
+    import os
+    from tests.util import GOLDEN_DIR
+    from oracle import genie_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "assoc_7x45.npz"))
+    w0 = O.weights_from_npz(z)
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t = lambda k, dt=torch.float32, dev=DEV: torch.from_numpy(np.asarray(z[k])).to(dt).to(dev)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
+    net.train()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    ea = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.to(DEV))
+    ea_flip = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.flip(0).contiguous().to(DEV))
+    graphs = (A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea_flip, A_src_in_sta.to(DEV), t("A_src_src", torch.long),
+              t("A_edges_p", torch.long), t("A_edges_s", torch.long), t("dt_partition"), t("tlatent"))
+    tail = (t("tpick"), t("ipick", torch.long), t("phase_label"), t("locs"), t("x_grid"), t("x_query"), t("x_query_src"),
+            t("t_query"), t("tq_sample"), t("trv_out_q"))
+    outs = net(t("Slice"), t("Mask"), *graphs, *tail)
+    assert all(o.requires_grad for o in outs)
+    for o, k in zip(outs, ("y", "x", "arv_p", "arv_s")):
+        assert max_abs(o.detach().cpu(), torch.from_numpy(z[k])) <= 1e-5, k
+    g = torch.Generator().manual_seed(11)
+    coef = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * c_.to(DEV)).sum() for o, c_ in zip(outs, coef)).backward()
+    c = lambda k, dt=torch.float32: t(k, dt, "cpu")
+    w = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+    ref = O.forward_fixed(w, c("Slice"), c("Mask"), A_in_sta, A_in_src, c("edge_attr"), A_src_in_prod, c("A_src_src", torch.long),
+                          c("A_edges_p", torch.long), c("A_edges_s", torch.long), c("dt_partition"), c("tlatent"), c("tpick"),
+                          c("ipick", torch.long), c("phase_label"), c("x_grid"), c("x_query"), c("x_query_src"), c("t_query"),
+                          c("tq_sample"), c("trv_out_q"), S)
+    sum((o * c_).sum() for o, c_ in zip(ref, coef)).backward()
+    checked = 0
+    for k, p in net.named_parameters():
+        if w[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        tol = 1e-5 * max(1.0, float(w[k].grad.abs().max()))
+        assert max_abs(p.grad.cpu(), w[k].grad) <= tol, (k, max_abs(p.grad.cpu(), w[k].grad), tol)
+        checked += 1
+    assert checked >= 130
