@@ -123,7 +123,8 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
     hi = np.searchsorted(P[:, 0], t_all + max_t + 2.0 * sig, side="left")
 
     def step(i):
-        Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv)
+        Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv,
+                                      presplit=not os.environ.get("GENIE_NO_PRESPLIT"))
         y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
         with torch.cuda.stream(hp.side_stream):
             Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])

@@ -56,6 +56,8 @@ SYMBOLS = [
     ("genie_embed_ntime", _c.c_int, [_c.c_double, _c.c_double, _c.c_double, _c.c_double]),
     ("genie_embed_window", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P, _P,
                                       _P, _P, _P]),
+    ("genie_embed_window_split", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P, _P,
+                                            _P, _P, _P, _P]),
 ]
 
 

@@ -116,7 +116,8 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     with torch.no_grad():
         for w, t0 in enumerate(times):
             a, b = int(lo[w]), int(hi[w])
-            Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv)
+            Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
+                                          presplit=True)     # the forward below is the only consumer of (Slice, Mask)
             y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
             with torch.cuda.stream(hp.side_stream):           # the read-out lives on the side stream of the pipeline
                 vals = x[:, :-1, 0] if drop_last else x[:, :, 0]

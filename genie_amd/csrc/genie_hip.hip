@@ -2568,6 +2568,7 @@ struct EmbArgs {
     const float* trv;      // [rows, 2] theoretical P / S travel time of every product node
     long long rows;
     float* slice; float* mask;
+    unsigned* xs;          // optional: the 48-B split rows of k_stage1_b3, written together with Slice / Mask
 };
 
 __global__ void k_embed_scatter(EmbArgs a) {
@@ -2614,6 +2615,16 @@ __global__ void k_embed_gather(EmbArgs a) {
     mk.z = fabsf(sl.z) > 0.01f ? 1.f : 0.f; mk.w = fabsf(sl.w) > 0.01f ? 1.f : 0.f;
     *(f32x4*)(a.slice + p * 4) = sl;
     *(f32x4*)(a.mask + p * 4) = mk;
+    if (a.xs != nullptr) {            // same rows as k_split_rows would produce from (sl, mk)
+        const float v[8] = {sl.x, sl.y, sl.z, sl.w, mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
+            *(u32x4*)(a.xs + p * (XROW / 4) + piece * 4) = o;
+        }
+    }
 }
 
 // de-pad rows of a workspace tensor for parity tests
@@ -2750,6 +2761,8 @@ struct genie_ctx {
     // reversed base graphs (out-edges, weights 1 / in-degree of the target): built on the first genie_nbr_mean_bwd
     int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
     float *r_sta_w, *r_src_w;
+    const float *xs_slice, *xs_mask;   // genie_embed_window_split: the (Slice, Mask) buffers whose split rows already sit in the workspace (one-shot)
+    const void* xs_ws;
     float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
@@ -2970,6 +2983,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
+    c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
     c->abs_sta = c->abs_src = nullptr;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->r_sta_w = c->r_src_w = nullptr;
@@ -3248,7 +3262,9 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
     } else if (c->use_b3) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
-        k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
+        const bool presplit = c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws;     // genie_embed_window_split, one-shot
+        c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
+        if (!presplit) k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
         a.xs = xs; a.packed = c->packed_b3;
         const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
@@ -3521,9 +3537,35 @@ int genie_embed_ntime(double t0, double max_t, double kernel_sig_t, double dt) {
     return (int)ceil((stop - start) / dt);
 }
 
+namespace {
+int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
+                      double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
+                      float* slice_out, float* mask_out, unsigned* xs, void* stream);
+}
+
 int genie_embed_window(genie_ctx* c, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
                        double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
                        float* slice_out, float* mask_out, void* stream) {
+    return embed_window_impl(c, pick_t, pick_sta, pick_phase, n_picks, t0, max_t, kernel_sig_t, dt, trv, emb_ws, slice_out, mask_out,
+                             nullptr, stream);
+}
+
+int genie_embed_window_split(genie_ctx* c, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
+                             double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
+                             float* slice_out, float* mask_out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    unsigned* xs = c->use_b3 ? (unsigned*)((float*)ws + c->o_xs) : nullptr;
+    rc = embed_window_impl(c, pick_t, pick_sta, pick_phase, n_picks, t0, max_t, kernel_sig_t, dt, trv, emb_ws, slice_out, mask_out, xs,
+                           stream);
+    if (rc == GENIE_OK && xs) { c->xs_slice = slice_out; c->xs_mask = mask_out; c->xs_ws = ws; }
+    return rc;
+}
+
+namespace {
+int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
+                      double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
+                      float* slice_out, float* mask_out, unsigned* xs, void* stream) {
     if (!c || !trv || !emb_ws || !slice_out || !mask_out) return fail(GENIE_ERR_ARG, "genie_embed_window: null argument");
     if (n_picks > 0 && (!pick_t || !pick_sta || !pick_phase)) return fail(GENIE_ERR_ARG, "genie_embed_window: null pick array");
     if (!(dt > 0.0) || !(kernel_sig_t > 0.0) || !(max_t > 0.0)) return fail(GENIE_ERR_ARG, "genie_embed_window: bad dt / sigma / max_t");
@@ -3535,7 +3577,7 @@ int genie_embed_window(genie_ctx* c, const double* pick_t, const int32_t* pick_s
     a.S = c->S; a.t0 = t0; a.tref0 = t0 - 3.0 * kernel_sig_t; a.dt = dt; a.sigma = kernel_sig_t;
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
     a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
-    a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out;
+    a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs;
     HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
     if (n_picks > 0) {
         const long long n = (long long)n_picks * (2 * a.n_extra + 1);
@@ -3546,6 +3588,7 @@ int genie_embed_window(genie_ctx* c, const double* pick_t, const int32_t* pick_s
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
+}  // namespace
 
 #if GENIE_TUNING
 int genie_debug_xcc_map(int* out_dev, int nblocks, void* stream) {

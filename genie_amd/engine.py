@@ -364,9 +364,11 @@ class HipPath(object):
     def set_scale_t(self, scale_t):
         _lib.check(self.lib.genie_set_scale_t(self.ctx, ctypes.c_float(float(scale_t))), "genie_set_scale_t")
 
-    def embed_window(self, pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv):
+    def embed_window(self, pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv, presplit=False):
         """Slice, Mask [n_grid_ext*n_sta, 4] for the window starting at t0, from picks resident on the GPU
-        (process_utils.py:460-642). pick_t float64, pick_sta / pick_phase int32 GPU tensors; trv [rows, 2] fp32."""
+        (process_utils.py:460-642). pick_t float64, pick_sta / pick_phase int32 GPU tensors; trv [rows, 2] fp32.
+        `presplit`: also leave the split rows of the bf16x3 stage-1 kernel in the workspace, so that the next stage-1 call on
+        exactly these (Slice, Mask) skips its split pass (genie_embed_window_split; do not modify them in between)."""
         rows = self.n_grid_ext * self.n_sta
         trv = _f32(trv, "trv", (rows, 2))
         n = int(pick_t.numel())
@@ -381,10 +383,12 @@ class HipPath(object):
             self._emb = torch.empty(need, dtype=torch.float32, device=self.device)
         Slice = torch.empty((rows, 4), dtype=torch.float32, device=self.device)
         Mask = torch.empty((rows, 4), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.genie_embed_window(self.ctx, _ptr(pick_t) if n else None, _ptr(pick_sta) if n else None,
-                                               _ptr(pick_phase) if n else None, n, float(t0), float(max_t), float(kernel_sig_t),
-                                               float(dt), _ptr(trv), _ptr(self._emb), _ptr(Slice), _ptr(Mask), _stream()),
-                   "genie_embed_window")
+        common = (self.ctx, _ptr(pick_t) if n else None, _ptr(pick_sta) if n else None, _ptr(pick_phase) if n else None, n,
+                  float(t0), float(max_t), float(kernel_sig_t), float(dt), _ptr(trv), _ptr(self._emb), _ptr(Slice), _ptr(Mask))
+        if presplit:
+            _lib.check(self.lib.genie_embed_window_split(*common, self._ws_ptr, _stream()), "genie_embed_window_split")
+        else:
+            _lib.check(self.lib.genie_embed_window(*common, _stream()), "genie_embed_window")
         return Slice, Mask
 
     def export(self, which):

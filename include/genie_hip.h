@@ -208,6 +208,13 @@ int genie_embed_ntime(double t0, double max_t, double kernel_sig_t, double dt);
 int genie_embed_window(genie_ctx* ctx, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
                        double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
                        float* slice_out, float* mask_out, void* stream);
+/* Same, and additionally leaves the split input rows of the bf16x3 stage-1 kernel in `workspace`: the NEXT genie_da_stage1 /
+ * genie_path_fwd call on this context with exactly these slice_out / mask_out pointers and this workspace skips its
+ * k_split_rows pass (one-shot; the caller must not modify Slice / Mask in between, and stage 1 must run on the same stream or
+ * after it). A no-op extension on contexts that do not use the bf16x3 kernel. */
+int genie_embed_window_split(genie_ctx* ctx, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase,
+                             int n_picks, double t0, double max_t, double kernel_sig_t, double dt, const float* trv,
+                             float* emb_ws, float* slice_out, float* mask_out, void* workspace, void* stream);
 
 /* Neighbour means on the implicit product graph for [P, row_floats] fp32 rows (row_floats = 16 or 32, 16-byte aligned):
  *   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))]      (MessagePassing('mean') over A_in_sta)
