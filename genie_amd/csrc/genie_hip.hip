@@ -51,6 +51,11 @@
 #define GENIE_S2_WAVES 3   // minimum waves per SIMD the register allocator of k_stage2_fast is held to
 #endif
 
+// GENIE_PHASES=1 (with GENIE_TUNING=1): s_memtime phase timers inside the stage kernels (GENIE_ABLATE bit 10); they cost registers
+#ifndef GENIE_PHASES
+#define GENIE_PHASES 0
+#endif
+
 #ifndef GENIE_HOIST_WEIGHTS
 #define GENIE_HOIST_WEIGHTS 0
 #endif
@@ -1337,7 +1342,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     int idv = 0, sc = 0, sta_id[KS];
     bool valid = false;
     if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, valid, sta_id);
-#if GENIE_TUNING
+#if GENIE_TUNING && GENIE_PHASES
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define PH1(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 #else
@@ -1551,7 +1556,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
     }
-#if GENIE_TUNING
+#if GENIE_TUNING && GENIE_PHASES
     if (ABL(a, 10) && a.x_latent != nullptr && (threadIdx.x & 63) == 0)      // x_latent is unused by stage 1: timer dump
         for (int k = 0; k < 5; ++k) a.x_latent[(blockIdx.x * 8 + wave) * 8 + k] = (float)tph[k];
 #endif
@@ -1783,7 +1788,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
             }
         }
     };
-#if GENIE_TUNING
+#if GENIE_TUNING && GENIE_PHASES
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define PH(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 #else
@@ -1877,7 +1882,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         nxt = nn;
         w.it += w.stride;
     }
-#if GENIE_TUNING
+#if GENIE_TUNING && GENIE_PHASES
     if (ABL(a, 10) && a.dbg_h0 != nullptr && lane == 0)
         for (int k = 0; k < 5; ++k) a.dbg_h0[(blockIdx.x * 4 + wave) * 8 + k] = (float)tph[k];
 #endif
@@ -3592,7 +3597,8 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
 
 #if GENIE_TUNING
 int genie_debug_xcc_map(int* out_dev, int nblocks, void* stream) {
-    k_xcc_probe<<<nblocks, 64, 0, (hipStream_t)stream>>>(out_dev);
+    const char* e = getenv("GENIE_PROBE_THREADS");
+    k_xcc_probe<<<nblocks, e ? atoi(e) : 64, 0, (hipStream_t)stream>>>(out_dev);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
