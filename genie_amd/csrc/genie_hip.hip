@@ -48,7 +48,8 @@
 #endif
 
 #ifndef GENIE_S2_WAVES
-#define GENIE_S2_WAVES 3   // minimum waves per SIMD the register allocator of k_stage2_fast is held to
+#define GENIE_S2_WAVES 2   // minimum waves per SIMD the register allocator of k_stage2_fast is held to (3 = 168 VGPRs with
+                           // spills and more rows in flight than L2 keeps: 0.313 vs 0.302 ms, fabric reads +50 %)
 #endif
 
 // GENIE_PHASES=1 (with GENIE_TUNING=1): s_memtime phase timers inside the stage kernels (GENIE_ABLATE bit 10); they cost registers
