@@ -2,17 +2,20 @@
 // message-passing hot path (see include/genie_hip.h for the boundary and the reference lines replaced).
 //
 // Design (DESIGN.md has the long form):
-//  * product node p = g*S + s. A wave owns a TILE of 16 product nodes of ONE source node g
-//    (16 consecutive stations), so g, its source-neighbour list and all row bases are wave-uniform (SGPR).
-//  * every per-node Linear is an exact-fp32 MFMA chain: D[ch, node] += W[ch, k] * X[k, node] with
-//    v_mfma_f32_16x16x4_f32. Output channels are MFMA rows, nodes are MFMA columns, so the accumulator of
-//    one layer (lane (j = lane&15, q = lane>>4) holds channels 16t+4q+{0..3} of node j) IS the B operand of
-//    the next layer: k-step r of a 16-channel block consumes channel 4q+r from lane (j,q). Weights are
-//    pre-permuted into that k order ("A fragments") once per weight update and live in LDS.
-//  * the neighbour means gather 128-B rows (32 fp32 channels, 4 lanes x 16 B per node) straight into that
-//    same fragment layout, apply the per-graph PReLU on the fly, and never materialise an edge list.
-//  * Bipartite station sum: wave-level reduction over the 16 nodes of a tile, one partial row per tile,
-//    summed in fixed order by the read-out kernel (bitwise deterministic, no atomics).
+//  * product node p = g*S + s; a TILE is 16 consecutive stations of ONE source node g. Work items (g, tile) are swept by
+//    persistent workgroups, XCD b%8 taking a contiguous chunk of a Morton order of the source grid.
+//  * every per-node Linear is a matrix product D[ch, node] += W[ch, k] * X[k, node]: output channels are MFMA rows, nodes
+//    are MFMA columns, so the accumulator of one layer IS the B operand of the next (weights are pre-permuted into that k
+//    order, "A fragments", once per weight update and live in LDS; activations never leave registers between layers).
+//  * stage 1 (k_stage1_b3, the default on the reference's 8 / 15-degree kNN graphs) runs on the bf16 matrix pipe with every
+//    fp32 operand split EXACTLY into three bf16 pieces and six partial products per product (fp32 results): fp32 MFMAs share
+//    the vector datapath on this hardware and do not overlap with VALU work. Two tiles per wave, v_mfma_f32_32x32x16_bf16.
+//    The exact-fp32 MFMA kernels (k_stage1, k_stage1_fast, k_stage1_pcsr; v_mfma_f32_16x16x4_f32, lane (j = lane&15,
+//    q = lane>>4) holds channels 16t+4q+{0..3} of node j) serve ragged / irregular graphs and use_absolute_pos.
+//  * a neighbour's hidden state is RECOMPUTED from its raw input row instead of gathered (h0 is never stored), u / v are
+//    projected through the neighbour-mean columns before they are averaged (64-B gather rows), and the node-local layer-2
+//    terms are computed where h1 lives; stage 2 gathers, applies PReLU2 and the Bipartite message MLP, and reduces over the
+//    stations of a tile; one partial row per tile, summed in fixed order (bitwise deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
