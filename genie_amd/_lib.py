@@ -29,6 +29,9 @@ SYMBOLS = [
     ("genie_set_absolute_pos", _c.c_int, [_P, _P, _P, _P]),
     ("genie_nbr_mean", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _P]),
     ("genie_nbr_mean_bwd", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _P]),
+    ("genie_prelu_bwd", _c.c_int, [_P, _P, _P, _c.c_int64, _P, _P, _P, _P]),
+    ("genie_linear_bwd_scratch_floats", _c.c_int64, [_c.c_int]),
+    ("genie_linear_bwd_wb", _c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     ("genie_set_slot", _c.c_int, [_P, _c.c_int]),
     ("genie_set_tail_mode", _c.c_int, [_P, _c.c_int]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),

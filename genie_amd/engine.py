@@ -339,6 +339,36 @@ class HipPath(object):
                    "genie_nbr_mean_bwd")
         return tuple(None if o is None else o[0][:, :o[1]] for o in outs)
 
+    def prelu_bwd(self, x, dy, slope):
+        """Backward of a single-slope PReLU over a contiguous fp32 tensor (genie_prelu_bwd): returns (dx, dslope[1])."""
+        x, dy = _f32(x, "x"), _f32(dy, "dy", tuple(x.shape))
+        slope = _f32(slope, "slope", (1,))
+        dx, ds = torch.empty_like(x), torch.empty_like(slope)
+        scratch = torch.empty(2048, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.genie_prelu_bwd(_ptr(x), _ptr(dy), _ptr(slope), x.numel(), _ptr(dx), _ptr(ds), _ptr(scratch), _stream()),
+                   "genie_prelu_bwd")
+        return dx, ds
+
+    def linear_bwd_wb(self, x, dy, bias=True):
+        """Weight / bias gradients of y = x W^T + b over contiguous rows x [N, K], dy [N, M] (genie_linear_bwd_wb)."""
+        x = _f32(x, "x")
+        N, K = x.shape
+        dy = _f32(dy, "dy")
+        M = dy.shape[1]
+        if dy.shape[0] != N:
+            raise ValueError("linear_bwd_wb: x and dy must have the same number of rows")
+        dW = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        db = torch.empty(M, dtype=torch.float32, device=x.device) if bias else None
+        if N == 0:
+            dW.zero_()
+            if bias:
+                db.zero_()
+            return dW, db
+        scratch = torch.empty(int(self.lib.genie_linear_bwd_scratch_floats(K)), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.genie_linear_bwd_wb(_ptr(x), _ptr(dy), N, K, M, _ptr(dW), _ptr(db), _ptr(scratch), _stream()),
+                   "genie_linear_bwd_wb")
+        return dW, db
+
     def set_absolute_pos(self, pos_sta, pos_src):
         """`use_absolute_pos` (config.yaml:92): station [n_sta,3] / source [n_grid_ext,3] positions appended (scaled by
         1 / (3 scale_rel)) to every product node's input; `None, None` = off (genie_set_absolute_pos)."""

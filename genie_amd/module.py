@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 from . import engine as _engine
 from . import graph as _graph
@@ -60,6 +61,50 @@ def _scatter_mean_rows(msg, index, n):
     return out / cnt.clamp(min=1).view(-1, 1)
 
 
+class _PReLU(torch.autograd.Function):
+    """Single-slope PReLU whose backward is one HIP pass (genie_prelu_bwd) instead of PyTorch's full-size slope gradient plus
+    a reduction -- the largest single item of the training step's backward on product-sized tensors."""
+
+    @staticmethod
+    def forward(ctx, x, slope, hip):
+        ctx.hip = hip
+        ctx.save_for_backward(x, slope)
+        return F.prelu(x, slope)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dx, ds = ctx.hip.prelu_bwd(x, dy.contiguous(), slope)
+        return dx, ds, None
+
+
+class _Linear(torch.autograd.Function):
+    """Per-node Linear over product-sized rows: forward and dX on the library GEMM, dW / db by genie_linear_bwd_wb (one pass
+    over x and dy; the library's [M, N] x [N, K] product with N = 2M rows plus the bias reduction is 10x slower)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, hip):
+        ctx.hip = hip
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dW, db = ctx.hip.linear_bwd_wb(x, dy)
+        return dx, dW, db, None
+
+
+def _lin(module, x, hip):
+    return _Linear.apply(x.contiguous(), module.weight, module.bias, hip)
+
+
+def _act(module, x, hip):
+    return _PReLU.apply(x.contiguous(), module.weight, hip)
+
+
 class DataAggregation(nn.Module):
     """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
     applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
@@ -90,13 +135,14 @@ class DataAggregation(nn.Module):
     def forward_train(self, Slice, Mask, hip):
         """Differentiable restatement of module.py:85-98 for training steps (first pass): per-node Linears and
         PReLUs on PyTorch-ROCm autograd, the four neighbour means through `_NbrMean` (HIP forward and adjoint)."""
-        tr = self.activate(self.init_trns(torch.cat((Slice, Mask), dim=-1)))
-        n1, n2 = _NbrMean.apply(self.activate11(tr), self.activate12(tr), hip)
-        tr = self.activate1(torch.cat((self.l1_t1_2(torch.cat((tr, n1, Mask), dim=1)),
-                                       self.l1_t2_2(torch.cat((tr, n2, Mask), dim=1))), dim=1))
-        m1, m2 = _NbrMean.apply(self.activate21(self.l2_t1_1(tr)), self.activate22(self.l2_t2_1(tr)), hip)
-        return self.activate2(torch.cat((self.l2_t1_2(torch.cat((tr, m1, Mask), dim=1)),
-                                         self.l2_t2_2(torch.cat((tr, m2, Mask), dim=1))), dim=1))
+        tr = _act(self.activate, _lin(self.init_trns, torch.cat((Slice, Mask), dim=-1), hip), hip)
+        n1, n2 = _NbrMean.apply(_act(self.activate11, tr, hip), _act(self.activate12, tr, hip), hip)
+        tr = _act(self.activate1, torch.cat((_lin(self.l1_t1_2, torch.cat((tr, n1, Mask), dim=1), hip),
+                                             _lin(self.l1_t2_2, torch.cat((tr, n2, Mask), dim=1), hip)), dim=1), hip)
+        m1, m2 = _NbrMean.apply(_act(self.activate21, _lin(self.l2_t1_1, tr, hip), hip),
+                                _act(self.activate22, _lin(self.l2_t2_1, tr, hip), hip), hip)
+        return _act(self.activate2, torch.cat((_lin(self.l2_t1_2, torch.cat((tr, m1, Mask), dim=1), hip),
+                                               _lin(self.l2_t2_2, torch.cat((tr, m2, Mask), dim=1), hip)), dim=1), hip)
 
 
 class DataAggregationEdges(nn.Module):
@@ -157,10 +203,10 @@ class BipartiteGraphOperator(nn.Module):
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def forward_train(self, x_latent, edge_attr, Mask, n_sta, n_grid):
+    def forward_train(self, x_latent, edge_attr, Mask, n_sta, n_grid, hip):
         """module.py:224-229, differentiable (the station sum is a view-sum on the Cartesian layout p = g * n_sta + s)."""
         m = Mask.max(1, keepdim=True)[0]
-        msg = m * self.activate1(self.fc1(torch.cat((x_latent, edge_attr), dim=-1)))
+        msg = m * _act(self.activate1, _lin(self.fc1, torch.cat((x_latent, edge_attr), dim=-1), hip), hip)
         return self.activate2(self.fc2(msg.view(n_grid, n_sta, -1).sum(dim=1)))
 
 
@@ -683,7 +729,7 @@ class GCN_Detection_Network_extended(nn.Module):
         Slice = _engine._f32(Slice, "Slice", (hp.n_prod, 4))
         Mask = _engine._f32(Mask, "Mask", (hp.n_prod, 4))
         x_latent = self.DataAggregation.forward_train(Slice, Mask, hp)
-        x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid)
+        x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid, hp)
         A_src = torch.as_tensor(self.A_src).long().to(x.device)
         pos = x_temp_cuda_cart.float()
         for sa in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3):

@@ -223,6 +223,17 @@ int genie_embed_window_split(genie_ctx* ctx, const double* pick_t, const int32_t
  * per-node Linears run on PyTorch-ROCm; an empty neighbourhood gives 0. */
 int genie_nbr_mean(genie_ctx* ctx, const float* x_sta, const float* x_src, float* out_sta, float* out_src, int row_floats,
                    void* stream);
+/* Backward of a single-slope PReLU over n contiguous fp32 values (training path): dx = dy * (x >= 0 ? 1 : slope),
+ * dslope[0] = sum over x < 0 of dy * x, summed in a fixed order. `scratch` = 2048 floats; pointers 16-byte aligned. */
+int genie_prelu_bwd(const float* x, const float* dy, const float* slope, int64_t n, float* dx, float* dslope, float* scratch,
+                    void* stream);
+
+/* Weight and bias gradients of a per-node Linear y = x W^T + b over N contiguous rows (training path):
+ * dW[M, K] = dy^T x, db[M] = column sums of dy (db may be NULL), M <= 32, K <= 128, summed in a fixed order.
+ * `scratch` holds genie_linear_bwd_scratch_floats(K) floats. */
+int64_t genie_linear_bwd_scratch_floats(int K);
+int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M, float* dW, float* db, float* scratch, void* stream);
+
 /* Adjoint of genie_nbr_mean (training): dx_sta[(g,j)] = sum_{i : j in N_sta(i)} g_sta[(g,i)] / deg(i), likewise for the source
  * graph. Deterministic (a gather over the reversed graphs, built once per context); unsharded Cartesian contexts only. */
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,

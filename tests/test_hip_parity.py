@@ -339,6 +339,44 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
     assert max_abs(res["generic"], res["default"]) <= 0.2 * rel_tol(res["generic"]), max_abs(res["generic"], res["default"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,M", [(1, 8, 30), (37, 64, 30), (4099, 94, 15), (70001, 33, 30), (50000, 60, 30)])
+def test_linear_bwd_wb_matches_fp64(N, K, M):
+    """genie_linear_bwd_wb (weight / bias gradients of the per-node Linears, training path) against the fp64 products, at the
+    widths the path uses (K = 8, 33, 60, 64, 94; M = 15, 30) and at ragged row counts."""
+    hp = engine.HipPath(3, 4, engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 3),
+                        engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 4), device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    x = torch.randn((N, K), device=DEV, generator=g)
+    dy = torch.randn((N, M), device=DEV, generator=g)
+    dW, db = hp.linear_bwd_wb(x, dy)
+    refW, refb = dy.double().t() @ x.double(), dy.double().sum(0)
+    tol = 2e-6 * max(1.0, N ** 0.5) * 4
+    assert max_abs(dW.double(), refW) <= tol and max_abs(db.double(), refb) <= tol
+    dW2, none = hp.linear_bwd_wb(x, dy, bias=False)
+    assert none is None and torch.equal(dW, dW2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 3, 30 * 1201, 4 * 100003 + 1])
+def test_prelu_bwd_matches_autograd(n):
+    """genie_prelu_bwd (one-pass PReLU backward of the training path) against PyTorch's: dx bit-exact, the slope gradient to
+    fp32 summation error; sizes cover the empty tensor, the sub-float4 tail and an odd length."""
+    hp = engine.HipPath(3, 4, engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 3),
+                        engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 4), device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(n, device=DEV, generator=g, requires_grad=True)
+    a = torch.tensor([0.25], device=DEV, requires_grad=True)
+    dy = torch.randn(n, device=DEV, generator=g)
+    torch.nn.functional.prelu(x, a).backward(dy)
+    dx, da = hp.prelu_bwd(x.detach(), dy, a.detach())
+    assert torch.equal(dx, x.grad)
+    ref = (dy.double() * x.detach().double() * (x.detach() < 0)).sum()
+    assert abs(float(da[0]) - float(ref)) <= 1e-5 * max(1.0, float((dy * x.detach()).abs().sum()) ** 0.5)
+    assert abs(float(a.grad[0]) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))
+
+
+
 @pytest.mark.parametrize("S,G,C", [(12, 60, 30), (21, 40, 15), (50, 300, 32)])
 def test_nbr_mean_matches_torch_gathers(S, G, C):
     """genie_nbr_mean (neighbour means of arbitrary [P, C] rows on the product graph, used by the association heads) against the
