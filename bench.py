@@ -122,12 +122,18 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
     lo = np.searchsorted(P[:, 0], t_all - 2.0 * sig, side="right")
     hi = np.searchsorted(P[:, 0], t_all + max_t + 2.0 * sig, side="left")
 
+    acc = [None]
+
     def step(i):
         Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv,
                                       presplit=not os.environ.get("GENIE_NO_PRESPLIT"))
         y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
         with torch.cuda.stream(hp.side_stream):
+            if acc[0] is not None:
+                hp.side_stream.wait_event(acc[0])             # windows accumulate in order
             Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
+            acc[0] = torch.cuda.Event()
+            acc[0].record(hp.side_stream)
 
     def barrier():
         if dist is not None:

@@ -113,14 +113,19 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     hi = np.searchsorted(Ps[:, 0], times + max_t + 2.0 * kernel_sig_t, side="left")               # strict <
     ipn = np.abs(tsteps_abs.reshape(-1, 1, 1) - (times.reshape(1, -1, 1) + offsets.reshape(1, 1, -1))).argmin(0)
     cols = torch.from_numpy(ipn[:, :-1] if drop_last else ipn).to(dev)
+    acc_done = None
     with torch.no_grad():
         for w, t0 in enumerate(times):
             a, b = int(lo[w]), int(hi[w])
             Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
                                           presplit=True)     # the forward below is the only consumer of (Slice, Mask)
             y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
-            with torch.cuda.stream(hp.side_stream):           # the read-out lives on the side stream of the pipeline
+            with torch.cuda.stream(hp.side_stream):           # the read-out lives on this window's side stream of the pipeline
+                if acc_done is not None:
+                    hp.side_stream.wait_event(acc_done)       # windows accumulate in order (overlapping columns)
                 vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
                 Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
-        torch.cuda.current_stream(dev).wait_stream(hp.side_stream)
+                acc_done = torch.cuda.Event()
+                acc_done.record(hp.side_stream)
+        hp.wait_tails()
     return Out_2, times

@@ -2949,13 +2949,15 @@ struct genie_ctx {
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
     size_t o_xs, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
-    size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist twice; `slot` selects the copy
+    size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
     size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
     int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
     int slot;                  // lets window i+1's stage 1/2 overlap window i's G-sized kernels on another stream
 };
 
 namespace {
+
+constexpr int GENIE_NSLOT = 4;   // copies of the per-window buffers (genie_set_slot)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -2968,7 +2970,7 @@ void layout_ws(genie_ctx* c) {
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
     c->big_stride = o - big0;
-    o += c->big_stride;        // second copy (slot 1): stage 1 of window i+1 may run while stage 2 of window i reads
+    o += (GENIE_NSLOT - 1) * c->big_stride;   // further copies (slots 1..): stage 1 of window i+1 may run while stage 2 of window i reads
     const size_t small0 = o;
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
@@ -2979,7 +2981,7 @@ void layout_ws(genie_ctx* c) {
     c->o_pj1 = take((size_t)c->G * 32);
     c->o_cv = take((size_t)c->G * CVP);
     c->slot_stride = o - small0;
-    o += c->slot_stride;       // second copy (slot 1)
+    o += (GENIE_NSLOT - 1) * c->slot_stride;  // further copies
     c->ws_floats = o;
 }
 
@@ -3344,7 +3346,7 @@ int genie_set_tail_mode(genie_ctx* c, int slim) {
 }
 
 int genie_set_slot(genie_ctx* c, int slot) {
-    if (!c || (slot != 0 && slot != 1)) return fail(GENIE_ERR_ARG, "genie_set_slot: slot must be 0 or 1");
+    if (!c || slot < 0 || slot >= GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_set_slot: slot must be in [0, GENIE_NSLOT)");
     c->slot = slot;
     return GENIE_OK;
 }

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, current stream); every compute call goe
 of `include/genie_hip.h` with raw device pointers.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -222,26 +223,30 @@ class HipPath(object):
 
     # ---- two-stream window pipeline ----------------------------------------------------------------
     def forward_pipelined(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query):
-        """One forward_fixed_source window as a two-stream pipeline over independent windows: the P-sized kernels (stage 1,
-        fp32-MFMA bound; stage 2, HBM bound) on the current stream, the G-sized tail (Bipartite read-out,
-        SpatialAggregation x3, read-out heads: short latency-bound kernels) on `self.side_stream`, where it overlaps the
-        NEXT window's stage 1 (whose single 512-thread workgroup per CU leaves LDS and wave slots free). Every buffer
-        that crosses the stream boundary is double-buffered (`genie_set_slot`). Results are bit-identical to `path_fwd` +
-        read-outs. Returns (y, x, done_event); y / x are produced on `self.side_stream` — consume them there or wait for
-        `done_event`. (Measured alternative, rejected: also moving stage 2 to its own stream so that it overlaps the
+        """One forward_fixed_source window as a stream pipeline over independent windows: the P-sized kernels (stage 1,
+        stage 2) on the current stream, the G-sized tail (Bipartite read-out, SpatialAggregation x3, read-out heads: short
+        latency-bound kernels) on a side stream, where it overlaps the NEXT windows' P-sized kernels. The persistent P-sized
+        kernels fill every CU, so a tail kernel only advances when their workgroups retire and one tail takes about as long as
+        a whole window; consecutive windows therefore alternate between GENIE_TAILS (default 2) side streams, and every
+        buffer that crosses the stream boundary exists once per window in flight (`genie_set_slot`). Results are
+        bit-identical to `path_fwd` + read-outs. Returns (y, x, done_event); y / x are produced on `self.side_stream` (the
+        side stream of THIS window) — consume them there or wait for `done_event`; `wait_tails()` joins all of them. (Measured alternative, rejected: also moving stage 2 to its own stream so that it overlaps the
         next stage 1 — the two P-sized kernels slow each other down more than the overlap gains)"""
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         pos = _f32(pos, "pos", (self.n_grid, 3))
-        if getattr(self, "side_stream", None) is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
-            self._slot = 0
-            self._ev_tail = [None, None]
+        if getattr(self, "side_streams", None) is None:
+            n_tail = max(1, min(3, int(os.environ.get("GENIE_TAILS", "2"))))
+            prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
+            self.side_streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(n_tail)]
+            self._win = 0
+            self._ev_tail = [None] * (n_tail + 1)
         main = torch.cuda.current_stream(self.device)
-        slot = self._slot
-        self._slot ^= 1
+        slot = self._win % len(self._ev_tail)
+        side = self.side_stream = self.side_streams[self._win % len(self.side_streams)]   # where this window's y / x are produced
+        self._win += 1
         _lib.check(self.lib.genie_set_slot(self.ctx, slot), "genie_set_slot")
         if self._ev_tail[slot] is not None:
             main.wait_event(self._ev_tail[slot])          # the tail that last used this slot's scratch has finished
@@ -251,9 +256,9 @@ class HipPath(object):
                    "genie_da_stage2_partials")
         ev = torch.cuda.Event()
         ev.record(main)
-        self.side_stream.wait_event(ev)
-        with torch.cuda.stream(self.side_stream):
-            ss = ctypes.c_void_p(self.side_stream.cuda_stream)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ss = ctypes.c_void_p(side.cuda_stream)
             bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
             x_spatial = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
             _lib.check(self.lib.genie_bipartite_readout(self.ctx, _ptr(bip), self._ws_ptr, ss), "genie_bipartite_readout")
@@ -262,10 +267,16 @@ class HipPath(object):
             y = self.readout_grid(x_spatial, t_query)
             x = self.readout_query(x_spatial, pos, x_query, knn_idx, t_query)
             done = torch.cuda.Event()
-            done.record(self.side_stream)
+            done.record(side)
         self._ev_tail[slot] = done
         _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
         return y, x, done
+
+    def wait_tails(self, stream=None):
+        """Make `stream` (default: the current one) wait for every window tail issued so far by `forward_pipelined`."""
+        stream = stream or torch.cuda.current_stream(self.device)
+        for s in getattr(self, "side_streams", None) or ():
+            stream.wait_stream(s)
 
     def readout_grid(self, x_spatial, t_query):
         """y[n_grid, T, 1] = TemporalAttention(SpatialDirect(x_spatial), t_query) (module.py:1015-1016)."""

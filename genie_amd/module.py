@@ -754,7 +754,7 @@ class GCN_Detection_Network_extended(nn.Module):
                                        x_query_cart, t_query):
         """Throughput variant of `forward_fixed_source` for loops over independent windows (the apply loop,
         process_continuous_days.py:761-810): same arithmetic and results, but the G-sized tail of the window runs on
-        `self._hip.side_stream` so it overlaps the next window's P-sized kernels. Returns (y, x, done_event): consume
+        `self._hip.side_stream` (one of two alternating side streams) so it overlaps the next windows' P-sized kernels. Returns (y, x, done_event): consume
         y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")

@@ -75,10 +75,10 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
                               const int32_t* src_rowptr, const int32_t* src_col, const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
- * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists twice; `slot` (0/1) selects the copy used by
- * the calls issued next. With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
+ * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists four times; `slot` (0..3) selects the copy used
+ * by the calls issued next. With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
  * i (HBM-bound) and the G-sized tail of window i-1 (latency-bound) concurrently: all calls of one window use the same
- * slot, consecutive windows alternate, and the caller orders "stage 1 of window i+2 after stage 2 of window i" etc. with
+ * slot, consecutive windows rotate through the slots, and the caller orders "stage 1 of window i+2 after stage 2 of window i" etc. with
  * events. Default slot 0. */
 int genie_set_slot(genie_ctx* ctx, int slot);
 /* slim != 0: launch the read-out kernels in their small-LDS shape (<= 52 KB, one workgroup per CU) so they co-reside
