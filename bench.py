@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream forward_fixed_source per window")
+    ap.add_argument("--tail-batch", type=int, default=8,
+                    help="windows per batched G-sized tail (push_window / flush_windows); 1 = one tail per window")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded", "stream"],
                     help="N>1: window-parallel replicas (weak scaling, default) or ONE window sharded over source nodes "
                          "with an RCCL halo all-to-all + all-gather per window (strong scaling; use with --config cfg4_2000x50k)")
@@ -123,17 +125,28 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
     hi = np.searchsorted(P[:, 0], t_all + max_t + 2.0 * sig, side="left")
 
     acc = [None]
+    first = [0]
+
+    def flush(upto):
+        y, x, _ = net.flush_windows(xg, xq, tq)
+        with torch.cuda.stream(hp.side_stream):
+            if acc[0] is not None:
+                hp.side_stream.wait_event(acc[0])             # batches accumulate in order
+            for k in range(x.shape[0]):
+                Out_2.index_add_(1, base + int(t_all[first[0] + k]), x[k, :, :, 0])
+            acc[0] = torch.cuda.Event()
+            acc[0].record(hp.side_stream)
+        first[0] = upto
 
     def step(i):
         Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv,
                                       presplit=not os.environ.get("GENIE_NO_PRESPLIT"))
-        y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
-        with torch.cuda.stream(hp.side_stream):
-            if acc[0] is not None:
-                hp.side_stream.wait_event(acc[0])             # windows accumulate in order
-            Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
-            acc[0] = torch.cuda.Event()
-            acc[0].record(hp.side_stream)
+        if net.push_window(Slice, Mask) >= net.window_batch:
+            flush(i + 1)
+
+    def drain(upto):
+        if net.pending_windows:
+            flush(upto)
 
     def barrier():
         if dist is not None:
@@ -143,10 +156,12 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
     with torch.no_grad():
         for i in range(a.warmup):
             step(i)
+        drain(a.warmup)
         barrier()
         t0 = time.perf_counter()
         for i in range(a.warmup, a.warmup + a.steps):
             step(i)
+        drain(a.warmup + a.steps)
         barrier()
         dtm = time.perf_counter() - t0
     if dist is not None:
@@ -267,29 +282,48 @@ def main():
     xq = torch.from_numpy(geom.x_query).float().to(dev)
     tq = torch.from_numpy(geom.t_query).float().to(dev)
 
+    tail_batch = max(1, min(a.tail_batch, net.window_batch))
+
     def step(i):
-        # windows are independent: the two-stream pipelined call overlaps the G-sized tail of window i with the P-sized
-        # kernels of window i+1 (bitwise-identical results, tests/test_hip_parity.py); --no-pipeline = single stream
+        # windows are independent (the apply loop): the P-sized kernels of every window run on the main stream, the G-sized
+        # tails + read-outs of `tail_batch` windows in one set of launches on a side stream, under the P-sized kernels of the
+        # following windows (bitwise-identical results, tests/test_hip_parity.py). --tail-batch 1 = one tail per window,
+        # --no-pipeline = single stream
         k = i % a.windows
         if a.no_pipeline:
             return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
-        return net.forward_fixed_source_pipelined(dS[k], dM[k], None, None, None, locs, xg, xq, tq)[:2]
+        if tail_batch == 1:
+            return net.forward_fixed_source_pipelined(dS[k], dM[k], None, None, None, locs, xg, xq, tq)[:2]
+        if net.push_window(dS[k], dM[k]) >= tail_batch:
+            return net.flush_windows(xg, xq, tq)[:2]
+        return None
+
+    def drain():        # the tails of the windows pushed so far belong to the steps that pushed them
+        if net.pending_windows:
+            return net.flush_windows(xg, xq, tq)[:2]
+        return None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    import contextlib
+    mp = os.environ.get("GENIE_MAIN_PRIO")
+    main_ctx = torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(mp))) if mp else contextlib.nullcontext()
+    with torch.no_grad(), main_ctx:
         for i in range(a.settle):       # set-up (clock settle), not part of the W warm-up or the K timed steps
             step(i)
+        drain()
         torch.cuda.synchronize()
         for i in range(a.warmup):
             step(i)
+        drain()
         barrier()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            y, x = step(i)
+            step(i)
+        drain()
         barrier()
         dt = time.perf_counter() - t0
     if dist is not None:
@@ -359,7 +393,8 @@ def main():
                                "graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
-        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "settle_windows": a.settle,
+        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,
+        "settle_windows": a.settle,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

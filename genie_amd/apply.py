@@ -113,19 +113,29 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     hi = np.searchsorted(Ps[:, 0], times + max_t + 2.0 * kernel_sig_t, side="left")               # strict <
     ipn = np.abs(tsteps_abs.reshape(-1, 1, 1) - (times.reshape(1, -1, 1) + offsets.reshape(1, 1, -1))).argmin(0)
     cols = torch.from_numpy(ipn[:, :-1] if drop_last else ipn).to(dev)
-    acc_done = None
+    acc_done = [None]
+
+    def flush(first):
+        # tail + read-outs of the pushed windows in one set of launches on a side stream; the accumulation into Out_2 follows
+        # on that stream, window by window and batch by batch in order (overlapping columns: a fixed summation order)
+        y, x, _ = net.flush_windows(xg, xq, tq)
+        with torch.cuda.stream(hp.side_stream):
+            if acc_done[0] is not None:
+                hp.side_stream.wait_event(acc_done[0])
+            for k in range(x.shape[0]):
+                vals = x[k, :, :-1, 0] if drop_last else x[k, :, :, 0]
+                Out_2.index_add_(1, cols[first + k], vals / (n_overlap * n_grids))
+            acc_done[0] = torch.cuda.Event()
+            acc_done[0].record(hp.side_stream)
+
     with torch.no_grad():
+        first = 0
         for w, t0 in enumerate(times):
             a, b = int(lo[w]), int(hi[w])
             Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
-                                          presplit=True)     # the forward below is the only consumer of (Slice, Mask)
-            y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
-            with torch.cuda.stream(hp.side_stream):           # the read-out lives on this window's side stream of the pipeline
-                if acc_done is not None:
-                    hp.side_stream.wait_event(acc_done)       # windows accumulate in order (overlapping columns)
-                vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
-                Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
-                acc_done = torch.cuda.Event()
-                acc_done.record(hp.side_stream)
+                                          presplit=True)     # the push below is the only consumer of (Slice, Mask)
+            if net.push_window(Slice, Mask) == net.window_batch or w == len(times) - 1:
+                flush(first)
+                first = w + 1
         hp.wait_tails()
     return Out_2, times

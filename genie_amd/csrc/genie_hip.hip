@@ -2065,12 +2065,15 @@ __device__ __forceinline__ void stage_transposed_cols(float* dst, const float* _
 }
 
 // Bipartite read-out: r_g = sum over tiles in fixed order; out = PReLU_b2(fc2 r_g)              module.py:229
+// blockIdx.y = window of a batched tail (genie_tail_batched): the window's buffers sit `*_ws` floats apart.
 __global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part, int G, int T,
                                                 const float* __restrict__ raw, int off_w, int off_b, int off_a,
-                                                float* __restrict__ out) {
+                                                float* __restrict__ out, long long part_ws, long long out_ws) {
     __shared__ float wt[30 * 32];
     stage_transposed(wt, raw + off_w, 15, 30);
     __syncthreads();
+    part += blockIdx.y * part_ws;
+    out += blockIdx.y * out_ws;
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const float bias = c < 15 ? raw[off_b + c] : 0.f;
     const float act = raw[off_a];
@@ -2130,7 +2133,18 @@ struct SaArgs {
     float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
     float* gpart_out;      // [gridDim][8]
     float* out;            // [G,30]
+    // batched tail: blockIdx.y = window; the window's copy of each buffer sits this many floats further on
+    long long ws_x_in, ws_slot, ws_out;
 };
+__device__ __forceinline__ void sa_select_window(SaArgs& a) {
+    const long long w = blockIdx.y;
+    a.x_in += w * a.ws_x_in;
+    if (a.pj_in) a.pj_in += w * a.ws_slot;
+    if (a.gpart_in) a.gpart_in += w * a.ws_slot;
+    if (a.pj_out) a.pj_out += w * a.ws_slot;
+    if (a.gpart_out) a.gpart_out += w * a.ws_slot;
+    if (a.out) a.out += w * a.ws_out;
+}
 
 // fixed-order block reduction of the per-lane global-term partials (lanes c < 5 of every node group) -> gpart[block]
 __device__ __forceinline__ void sa_store_gpart(float acc, int c, int grp, float* gpart_out) {
@@ -2149,6 +2163,7 @@ __device__ __forceinline__ void sa_store_gpart(float acc, int c, int grp, float*
 // and this block's partial of the edge-mean term  sum_j outdeg(j) PReLU3(fglobal x_j).
 template <int C>
 __global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
+    sa_select_window(a);
     __shared__ float wx[C * 32];
     __shared__ float wg[C * 32];
     stage_transposed_cols(wx, a.raw + a.fc1_w, 30, C + 8, C);
@@ -2182,6 +2197,7 @@ __global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
 // following layer (pj' = fc1'.weight[:, 0:30] out_i and the partial of its edge-mean term) while out_i is in registers.
 template <int C, bool NEXT>
 __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
+    sa_select_window(a);
     __shared__ float w1p[8 * 32];            // fc1 columns C..C+7 (3 position + 5 global), transposed
     __shared__ float w2t[(C + 30) * 32];
     __shared__ float wxn[NEXT ? 30 * 32 : 32];
@@ -2308,6 +2324,8 @@ constexpr int RO_IMGCV = 2 * 30 * 96;                                         //
 
 struct RoArgs {
     int N, G, T;                 // nodes handled (G for MODE 0, Q for MODE 1), grid size, number of time queries (<= 16)
+    int Nw;                      // batched tail: N = nwin * Nw node ids, window w = n / Nw reads x_spatial / cv of window w
+    long long cv_ws;             // floats between the cv buffers of consecutive windows
     const float* x_spatial;      // [G,30]
     const float* x_grid;         // [G,3]   (MODE 1)
     const float* x_query;        // [Q,3]   (MODE 1)
@@ -2328,8 +2346,9 @@ struct RoArgs {
 // [x_j || edge_attr]; the x_j part  C_j = f_context.weight[:, 0:30] x_j,  V_j = f_values.weight[:, 0:30] x_j  is the same
 // for every query that has j as a neighbour, so it is computed once per grid node: cv[j] = [C_j (75, pad 80) | V_j].
 constexpr int CVP = 160;
+// Batched tail: node ids run over nwin windows of Gw nodes (x_spatial [nwin * Gw, 30]); window w writes cv + w * cv_ws.
 __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spatial, int G, const float* __restrict__ imgcv,
-                                                float* __restrict__ cv) {
+                                                float* __restrict__ cv, int Gw, long long cv_ws) {
     __shared__ __attribute__((aligned(16))) float wc[30 * 96];
     __shared__ __attribute__((aligned(16))) float wv[30 * 96];
     for (int i = threadIdx.x; i < 30 * 96 / 4; i += blockDim.x) {
@@ -2350,7 +2369,8 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
             vv[0] += wv[k * 96 + c] * xk; vv[1] += wv[k * 96 + 32 + c] * xk; vv[2] += wv[k * 96 + 64 + c] * xk;
         }
         if (ok) {
-            float* o = cv + (long long)g * CVP;
+            const int w = g / Gw;
+            float* o = cv + w * cv_ws + (long long)(g - w * Gw) * CVP;
             o[c] = cc[0]; o[32 + c] = cc[1]; if (c < 16) o[64 + c] = cc[2];
             o[80 + c] = vv[0]; o[112 + c] = vv[1]; if (c < 16) o[144 + c] = vv[2];
         }
@@ -2446,13 +2466,15 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
             const float bq[3] = {a.raw[a.o_sq_b + c], a.raw[a.o_sq_b + 32 + c], c < 11 ? a.raw[a.o_sq_b + 64 + c] : 0.f};
             const float bc[3] = {a.raw[a.o_sc_b + c], a.raw[a.o_sc_b + 32 + c], c < 11 ? a.raw[a.o_sc_b + 64 + c] : 0.f};
             const float bv[3] = {a.raw[a.o_sv_b + c], a.raw[a.o_sv_b + 32 + c], c < 11 ? a.raw[a.o_sv_b + 64 + c] : 0.f};
+            const int wq = nc / a.Nw, nl = nc - wq * a.Nw;
+            const float* cvw = a.cv + wq * a.cv_ws;
 #pragma unroll 1
             for (int k = 0; k < RO_K; ++k) {
-                const int jn = a.knn[(long long)nc * RO_K + k];
+                const int jn = a.knn[(long long)nl * RO_K + k];
                 float e[3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) e[d] = (a.x_query[nc * 3 + d] - a.x_grid[jn * 3 + d]) / a.scale_rel;           // :283
-                const float* cvj = a.cv + (long long)jn * CVP;
+                for (int d = 0; d < 3; ++d) e[d] = (a.x_query[nl * 3 + d] - a.x_grid[jn * 3 + d]) / a.scale_rel;           // :283
+                const float* cvj = cvw + (long long)jn * CVP;
                 float q3[3] = {bq[0], bq[1], bq[2]};
                 float c3[3] = {bc[0] + cvj[c], bc[1] + cvj[32 + c], bc[2] + (c < 16 ? cvj[64 + c] : 0.f)};
                 float v3[3] = {bv[0] + cvj[80 + c], bv[1] + cvj[112 + c], bv[2] + (c < 16 ? cvj[144 + c] : 0.f)};
@@ -2957,7 +2979,8 @@ struct genie_ctx {
 
 namespace {
 
-constexpr int GENIE_NSLOT = 4;   // copies of the per-window buffers (genie_set_slot)
+constexpr int GENIE_NSLOT = 16;  // copies of the G-sized per-window buffers (genie_set_slot)
+constexpr int GENIE_NBIG = 4;    // copies of the P-sized c / wu / wv rows: slot % GENIE_NBIG
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -2970,7 +2993,7 @@ void layout_ws(genie_ctx* c) {
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
     c->big_stride = o - big0;
-    o += (GENIE_NSLOT - 1) * c->big_stride;   // further copies (slots 1..): stage 1 of window i+1 may run while stage 2 of window i reads
+    o += (GENIE_NBIG - 1) * c->big_stride;    // further copies (slots 1..): stage 1 of window i+1 may run while stage 2 of window i reads
     const size_t small0 = o;
     c->o_part = take((size_t)c->G * c->T * 32);
     c->o_sa0 = take((size_t)c->G * 32);
@@ -3049,7 +3072,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
-    const size_t bo = c->slot * c->big_stride;
+    const size_t bo = (c->slot % GENIE_NBIG) * c->big_stride;
     a.c = ws + c->o_c + bo; a.wu = ws + c->o_wu + bo; a.wv = ws + c->o_wv + bo;
     a.part = ws + c->o_part + c->slot * c->slot_stride;
     return a;
@@ -3463,7 +3486,7 @@ int genie_da_stage1_debug(genie_ctx* c, const float* slice, const float* mask, f
 }
 
 float* genie_ws_v_ptr(const genie_ctx* c, void* ws) {
-    return (c && ws) ? (float*)ws + c->o_wv + c->slot * c->big_stride : nullptr;
+    return (c && ws) ? (float*)ws + c->o_wv + (c->slot % GENIE_NBIG) * c->big_stride : nullptr;
 }
 int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
@@ -3513,11 +3536,11 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
     const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
     const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
     if (c->pcsr)       // the messages sit in the c rows (k_stage2_pcsr)
-        k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + c->slot * c->big_stride, c->G, c->seg_rowptr, c->raw,
+        k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride, c->G, c->seg_rowptr, c->raw,
                                                           g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
     else
     k_bip_out<<<nb, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off,
-                                                  g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
+                                                  g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out, 0, 0);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -3654,7 +3677,7 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 10 required");
     RoArgs a = make_ro_args(c);
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
-    a.N = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
+    a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
     a.img = c->ro_img;
     if (c->tail_slim) {
         const int nb = std::min((a.N + RO_NG0_SLIM - 1) / RO_NG0_SLIM, c->num_cu);
@@ -3678,14 +3701,14 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_query: 1 <= n_t <= 10 required");
     if (n_query < 1) return fail(GENIE_ERR_ARG, "genie_readout_query: n_query < 1");
     RoArgs a = make_ro_args(c);
-    a.N = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
+    a.N = a.Nw = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
     a.t_query = t_query; a.out = x_out;
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.img = c->ro_img + RO_IMG0;
     float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
     k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, (hipStream_t)stream>>>(
-        x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf);
+        x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf, c->G, 0);
     if (c->tail_slim) {
         const int nb = std::min((a.N + RO_NG1_SLIM - 1) / RO_NG1_SLIM, c->num_cu);
         k_readout<1, RO_NG1_SLIM><<<nb, RO_NG1_SLIM * 32, ro_lds(1, RO_NG1_SLIM), (hipStream_t)stream>>>(a);
@@ -3694,6 +3717,85 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ro_lds(1, RO_NG1)));
         k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), (hipStream_t)stream>>>(a);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+// The G-sized tail of `nwin` windows in one set of launches (Bipartite read-out, SpatialAggregation x3, both read-out heads).
+// The tail kernels are latency-bound at G = 10k nodes and, next to the persistent P-sized kernels of later windows, only
+// advance when those retire workgroups -- every launch costs the P-sized kernels about one of its own durations. Batched, the
+// fixed costs (weight images into LDS, launch, drain) are paid once per nwin windows. Window w uses workspace slot
+// slot0 + w (where genie_da_stage2_partials left its partials); results are bit-identical to the per-window calls.
+int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, const float* x_query, const int32_t* knn, int n_query,
+                       int k, const float* t_query, int n_t, float* x_spatial_out, float* y_out, float* x_out, void* ws,
+                       void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!pos || !t_query || !x_spatial_out || !y_out) return fail(GENIE_ERR_ARG, "genie_tail_batched: null argument");
+    if (nwin < 1 || slot0 < 0 || slot0 + nwin > GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_tail_batched: windows must fit slots [0, 16)");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_batched: 1 <= n_t <= 10 required");
+    if (x_out && (!x_query || !knn || n_query < 1 || k != RO_K)) return fail(GENIE_ERR_ARG, "genie_tail_batched: bad query arguments");
+    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_tail_batched: not available with use_subgraph product graphs");
+    if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_tail_batched needs an unsharded source graph");
+    if ((long long)nwin * std::max(c->G, n_query) > 0x7fffffffLL) return fail(GENIE_ERR_ARG, "genie_tail_batched: batch too large");
+    { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
+    hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
+    const long long ss = (long long)c->slot_stride;
+    const size_t so = (size_t)slot0 * c->slot_stride;
+    // Bipartite read-out -> bip[slot]
+    k_bip_out<<<dim3(std::min((c->G + NPB - 1) / NPB, std::max(32, c->num_cu * 8 / nwin)), nwin), 256, 0, st>>>(
+        w + c->o_part + so, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off,
+        w + c->o_bip + so, ss, ss);
+    // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
+    const int nbx = std::min((c->G + NPB - 1) / NPB, std::min(1024, std::max(32, c->num_cu * 8 / nwin)));
+    float* pj[2] = {w + c->o_pj0 + so, w + c->o_pj1 + so};
+    float* gp[2] = {w + c->o_gpart + so, w + c->o_gpart + so + 1024 * 8};
+    const dim3 grid(nbx, nwin);
+    {
+        SaArgs a;
+        memset(&a, 0, sizeof(a));
+        sa_fill_layer(c, 1, a);
+        a.x_in = w + c->o_bip + so; a.ws_x_in = ss; a.ws_slot = ss;
+        a.pj_out = pj[0]; a.gpart_out = gp[0];
+        k_sa_pre<15><<<grid, 256, 0, st>>>(a);
+    }
+    for (int layer = 1; layer <= 3; ++layer) {
+        SaArgs a;
+        memset(&a, 0, sizeof(a));
+        sa_fill_layer(c, layer, a);
+        const int cur = (layer - 1) & 1;
+        a.pos = pos; a.ws_slot = ss;
+        a.x_in = layer == 1 ? w + c->o_bip + so : (layer == 2 ? w + c->o_sa0 + so : w + c->o_sa1 + so);
+        a.ws_x_in = ss;
+        a.out = layer == 1 ? w + c->o_sa0 + so : (layer == 2 ? w + c->o_sa1 + so : x_spatial_out);
+        a.ws_out = layer == 3 ? (long long)c->G * 30 : ss;
+        a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = nbx;
+        a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
+        if (layer == 1) k_sa_layer<15, true><<<grid, 256, 0, st>>>(a);
+        else if (layer == 2) k_sa_layer<30, true><<<grid, 256, 0, st>>>(a);
+        else k_sa_layer<30, false><<<grid, 256, 0, st>>>(a);
+    }
+    // read-out heads over the nwin * G grid nodes / nwin * Q queries
+    RoArgs a = make_ro_args(c);
+    a.T = n_t; a.x_spatial = x_spatial_out; a.t_query = t_query;
+    {
+        RoArgs g = a;
+        g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->ro_img;
+        const int nb = std::min((g.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(0, RO_NG0)));
+        k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), st>>>(g);
+    }
+    if (x_out) {
+        k_ro_pre<<<std::min((nwin * c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, st>>>(
+            x_spatial_out, nwin * c->G, c->ro_img + RO_IMG0 + RO_IMG1, w + c->o_cv + so, c->G, ss);
+        RoArgs q = a;
+        q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
+        q.img = c->ro_img + RO_IMG0; q.cv = w + c->o_cv + so; q.cv_ws = ss;
+        const int nb = std::min((q.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(1, RO_NG1)));
+        k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), st>>>(q);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -3882,9 +3984,9 @@ int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream)
     float* w = (float*)ws;
     const float* src; long long rows; int pitch, ncol;
     switch (which) {
-        case 0: src = w + c->o_c + c->slot * c->big_stride; rows = c->P; pitch = ROWC; ncol = 30; break;
-        case 1: src = w + c->o_wu + c->slot * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
-        case 2: src = w + c->o_wv + c->slot * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 0: src = w + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride; rows = c->P; pitch = ROWC; ncol = 30; break;
+        case 1: src = w + c->o_wu + (c->slot % GENIE_NBIG) * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
+        case 2: src = w + c->o_wv + (c->slot % GENIE_NBIG) * c->big_stride; rows = c->P; pitch = ROWW; ncol = 15; break;
         default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..2");
     }
     const long long n = rows * ncol;

@@ -762,6 +762,31 @@ class GCN_Detection_Network_extended(nn.Module):
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
 
+    def push_window(self, Slice, Mask):
+        """Batched throughput form of `forward_fixed_source` for loops over independent windows (the apply loop,
+        process_continuous_days.py:761-810): `push_window` runs the P-sized part of one window, `flush_windows` the G-sized
+        tail and both read-outs of every pushed window in one set of launches (at most `net.window_batch` windows).
+        Same arithmetic, bit-identical results. Returns the number of pending windows."""
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
+        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        return self._hip.window_push(Slice, Mask, self._edge_attr)
+
+    def flush_windows(self, x_temp_cuda_cart, x_query_cart, t_query):
+        """(y [n, G, T, 1], x [n, Q, T, 1], done_event) of the n pushed windows, in push order, produced on
+        `self._hip.side_stream` (consume them there, or after `done_event.wait()`)."""
+        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+        return self._hip.windows_flush(x_temp_cuda_cart, x_query_cart, knn, t_query)
+
+    @property
+    def window_batch(self):
+        return _engine.HipPath.BATCH
+
+    @property
+    def pending_windows(self):
+        bt = getattr(self._hip, "_bt", None) if self._hip is not None else None
+        return bt["n"] if bt else 0
+
     def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
                       x_query_src_cart, t_query, tq_sample, trv_out_q):
         """module.py:963-997: (y, x, arv_p, arv_s). The shared front (DataAggregation -> Bipartite_ReadIn ->

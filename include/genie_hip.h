@@ -75,12 +75,20 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
                               const int32_t* src_rowptr, const int32_t* src_col, const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
- * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists four times; `slot` (0..3) selects the copy used
- * by the calls issued next. With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
+ * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists several times; `slot` (0..15) selects the copy
+ * used by the calls issued next (16 copies of the G-sized buffers; the P-sized rows have 4, indexed slot % 4). With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
  * i (HBM-bound) and the G-sized tail of window i-1 (latency-bound) concurrently: all calls of one window use the same
  * slot, consecutive windows rotate through the slots, and the caller orders "stage 1 of window i+2 after stage 2 of window i" etc. with
  * events. Default slot 0. */
 int genie_set_slot(genie_ctx* ctx, int slot);
+/* The G-sized tail of `nwin` windows (whose stage-2 partials sit in slots slot0 .. slot0+nwin-1) in one set of launches:
+ * Bipartite read-out, SpatialAggregation x3 -> x_spatial_out [nwin, G, 30], y_out [nwin, G, n_t] (genie_readout_grid) and,
+ * if x_out != NULL, x_out [nwin, n_query, n_t] (genie_readout_query). Bit-identical to the per-window calls; replaces
+ * nwin x (genie_bipartite_readout + genie_spatial_agg3_fwd + genie_readout_grid + genie_readout_query) in the apply
+ * loop (process_continuous_days.py:761-810), whose windows are independent. */
+int genie_tail_batched(genie_ctx* ctx, int slot0, int nwin, const float* pos, const float* x_query, const int32_t* knn,
+                       int n_query, int k, const float* t_query, int n_t, float* x_spatial_out, float* y_out, float* x_out,
+                       void* ws, void* stream);
 /* slim != 0: launch the read-out kernels in their small-LDS shape (<= 52 KB, one workgroup per CU) so they co-reside
  * with the stage-1 workgroups of the next window on another stream; 0 (default): large workgroups, lowest latency. */
 int genie_set_tail_mode(genie_ctx* ctx, int slim);

@@ -714,6 +714,44 @@ def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
         assert torch.equal(y0, y1) and torch.equal(x0, x1)
 
 
+def test_batched_windows_are_bitwise_equal_to_plain_forward():
+    """push_window / flush_windows (stage 1 / 2 per window, ONE G-sized tail per batch of windows through genie_tail_batched):
+    every window's (y, x) bit-identical to the single-stream forward_fixed_source; 19 windows = two full batches in flight
+    on alternating slot halves and side streams plus a partial batch of 3; a plain forward in between (after wait_tails)."""
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    rng = np.random.default_rng(5)
+    wins = []
+    for k in range(19):
+        S_ = torch.from_numpy(rng.random((c.S * c.G, 4)).astype(np.float32)) * (torch.rand(c.S * c.G, 1) < 0.3)
+        wins.append((S_.to(DEV), (S_ > 0.01).float().to(DEV)))
+    xg, xq, tq = c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV)
+    fixed = (None, None, None, c.locs.float().to(DEV), xg, xq, tq)
+    with torch.no_grad():
+        plain = [net.forward_fixed_source(s_, m_, *fixed) for s_, m_ in wins]
+        torch.cuda.synchronize()
+        got = []
+        for k, (s_, m_) in enumerate(wins):
+            if net.push_window(s_, m_) == net.window_batch or k == len(wins) - 1:
+                y, x, ev = net.flush_windows(xg, xq, tq)
+                got.append((y, x, ev))
+            if k == 9:
+                net._hip.wait_tails()                                 # a plain forward uses slot 0's scratch: join the tails first
+                mid = net.forward_fixed_source(*wins[3], *fixed)
+        torch.cuda.synchronize()
+    assert [g[0].shape[0] for g in got] == [8, 8, 3]
+    ys, xs = torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got])
+    for k, (y0, x0) in enumerate(plain):
+        assert torch.equal(y0, ys[k]) and torch.equal(x0, xs[k]), k
+    assert torch.equal(mid[0], plain[3][0]) and torch.equal(mid[1], plain[3][1])
+    with pytest.raises(RuntimeError):
+        net.flush_windows(xg, xq, tq)
+
+
+@pytest.mark.gpu
 def test_forward_fixed_and_forward_four_outputs_match_reference():
     """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) with the HIP front end and the PyTorch-ROCm association heads,
     against the reference's own forward_fixed golden vector."""
