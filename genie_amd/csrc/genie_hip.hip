@@ -2706,19 +2706,21 @@ __global__ void k_edge_bias(const float* __restrict__ raw, int off1, int off2, c
 
 // Neighbour means on the implicit product graph for arbitrary row widths (association heads, module.py:389-403):
 //   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))],   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]
-// rows of C = 4*C4 floats; C4 lanes per node, every lane keeps up to 8 row chunks in flight; sums in edge order.
+// rows of CL * VW floats; CL lanes per node, every lane keeps up to 8 row chunks in flight; sums in edge order.
 // With per-edge weights (w_sta / w_src non-null) the same kernel is the ADJOINT of the mean on the reversed graphs:
 //   dx[j] = sum_{i : j in N(i)} g[i] / deg(i)   (genie_nbr_mean_bwd; edge lists = out-edges of j, weights 1 / in-degree of i)
-template <int C4>
+template <int CL, int VW>       // CL lanes per row, VW floats per lane: rows of CL * VW floats (16 / 32 padded, or 30 unpadded)
 __global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
                                                   const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
                                                   const float* __restrict__ x_sta, const float* __restrict__ x_src,
                                                   float* __restrict__ out_sta, float* __restrict__ out_src,
                                                   const float* __restrict__ w_sta = nullptr, const float* __restrict__ w_src = nullptr) {
-    constexpr int NPB_ = 256 / C4;
-    const int c4 = threadIdx.x % C4;
+    typedef float V __attribute__((ext_vector_type(VW)));
+    constexpr int NPB_ = 256 / CL, RF = CL * VW;
+    if ((int)threadIdx.x >= NPB_ * CL) return;
+    const int cl = threadIdx.x % CL;
     const long long P = (long long)S * G;
-    for (long long p = (long long)blockIdx.x * NPB_ + threadIdx.x / C4; p < P; p += (long long)gridDim.x * NPB_) {
+    for (long long p = (long long)blockIdx.x * NPB_ + threadIdx.x / CL; p < P; p += (long long)gridDim.x * NPB_) {
         const int g = (int)(p / S), s = (int)(p - (long long)g * S);
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
@@ -2728,16 +2730,16 @@ __global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* _
             const int32_t* col = which == 0 ? sta_col : src_col;
             const float* ew = which == 0 ? w_sta : w_src;
             const int eb = which == 0 ? sta_rowptr[s] : src_rowptr[g], ee = which == 0 ? sta_rowptr[s + 1] : src_rowptr[g + 1];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            V acc = 0.f;
             for (int e0 = eb; e0 < ee; e0 += 8) {
-                f32x4 v[8];
+                V v[8];
                 float wk[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = min(e0 + k, ee - 1);
                     const int j = col[e];
                     const long long row = which == 0 ? (long long)g * S + j : (long long)j * S + s;
-                    v[k] = *(const f32x4*)(x + row * (4 * C4) + 4 * c4);
+                    v[k] = *(const V*)(x + row * RF + VW * cl);
                     wk[k] = ew ? ew[e] : 1.f;
                 }
 #pragma unroll
@@ -2745,7 +2747,7 @@ __global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* _
                     if (e0 + k < ee) acc += v[k] * wk[k];
             }
             const float w = ew ? 1.f : (ee > eb ? 1.f / (float)(ee - eb) : 0.f);
-            *(f32x4*)(out + p * (4 * C4) + 4 * c4) = acc * w;
+            *(V*)(out + p * RF + VW * cl) = acc * w;
         }
     }
 }
@@ -2806,7 +2808,7 @@ __global__ __launch_bounds__(256) void k_prelu_bwd_sum(const float* __restrict__
 constexpr int LBW_ROWS = 32, LBW_BLOCKS = 1024;
 template <int KC>
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ dy, long long N, int K, int M,
-                                                      float* __restrict__ partial) {
+                                                      int ldy, float* __restrict__ partial) {
     __shared__ float sdy[LBW_ROWS][32];
     __shared__ float sb[8][32];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2826,12 +2828,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
         const long long n0 = t * LBW_ROWS;
         const int nr = (int)min((long long)LBW_ROWS, N - n0);        // rows beyond N: dy staged as 0, x re-reads the last row
         const float* __restrict__ xt = x + n0 * K;
-        const float* __restrict__ dt = dy + n0 * M;
+        const float* __restrict__ dt = dy + n0 * ldy;            // M <= 32 columns of rows that are ldy floats apart
         float st[LBW_ROWS / 8];
 #pragma unroll
         for (int q = 0; q < LBW_ROWS / 8; ++q) {
             const int r = sr + 8 * q;
-            const float v = dt[min(r, nr - 1) * M + smc];
+            const float v = dt[min(r, nr - 1) * ldy + smc];
             st[q] = (sm < M && r < nr) ? v : 0.f;
         }
         __syncthreads();
@@ -3877,11 +3879,12 @@ int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* 
     if (!x_sta && !x_src) return GENIE_OK;
     const int nb = std::min<long long>((c->P + 31) / 32, (long long)c->num_cu * 16);
     hipStream_t st = (hipStream_t)stream;
-#define GENIE_NM(C4_) k_nbr_mean<C4_><<<nb, 256, 0, st>>>(c->S, c->G, c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, x_sta, x_src, out_sta, out_src)
+#define GENIE_NM(CL_, VW_) k_nbr_mean<CL_, VW_><<<nb, 256, 0, st>>>(c->S, c->G, c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, x_sta, x_src, out_sta, out_src)
     switch (row_floats) {
-        case 16: GENIE_NM(4); break;
-        case 32: GENIE_NM(8); break;
-        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean: row_floats must be 16 or 32");
+        case 16: GENIE_NM(4, 4); break;
+        case 32: GENIE_NM(8, 4); break;
+        case 30: GENIE_NM(15, 2); break;
+        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean: row_floats must be 16, 30 or 32");
     }
 #undef GENIE_NM
     HIP_TRY(hipGetLastError());
@@ -3938,12 +3941,13 @@ int genie_nbr_mean_bwd(genie_ctx* c, const float* g_sta, const float* g_src, flo
     }
     const int nb = std::min<long long>((c->P + 31) / 32, (long long)c->num_cu * 16);
     hipStream_t st = (hipStream_t)stream;
-#define GENIE_NMB(C4_) k_nbr_mean<C4_><<<nb, 256, 0, st>>>(c->S, c->G, c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, \
+#define GENIE_NMB(CL_, VW_) k_nbr_mean<CL_, VW_><<<nb, 256, 0, st>>>(c->S, c->G, c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, \
                                                             g_sta, g_src, dx_sta, dx_src, c->r_sta_w, c->r_src_w)
     switch (row_floats) {
-        case 16: GENIE_NMB(4); break;
-        case 32: GENIE_NMB(8); break;
-        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean_bwd: row_floats must be 16 or 32");
+        case 16: GENIE_NMB(4, 4); break;
+        case 32: GENIE_NMB(8, 4); break;
+        case 30: GENIE_NMB(15, 2); break;
+        default: return fail(GENIE_ERR_ARG, "genie_nbr_mean_bwd: row_floats must be 16, 30 or 32");
     }
 #undef GENIE_NMB
     HIP_TRY(hipGetLastError());
@@ -3965,14 +3969,17 @@ int64_t genie_linear_bwd_scratch_floats(int K) { return (int64_t)LBW_BLOCKS * (3
 
 int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M, float* dW, float* db, float* scratch, void* stream) {
     if (!x || !dy || !dW || !scratch || N <= 0 || K <= 0 || M <= 0) return fail(GENIE_ERR_ARG, "genie_linear_bwd_wb: bad argument");
-    if (M > 32 || K > 128) return fail(GENIE_ERR_ARG, "genie_linear_bwd_wb: supports M <= 32 outputs and K <= 128 inputs");
+    if (M > 128 || K > 128) return fail(GENIE_ERR_ARG, "genie_linear_bwd_wb: supports M <= 128 outputs and K <= 128 inputs");
     hipStream_t st = (hipStream_t)stream;
     const int KC = (K + 63) / 64;
     const int nb = (int)std::min<int64_t>(LBW_BLOCKS, (N + LBW_ROWS - 1) / LBW_ROWS);
-    if (KC == 1) k_linear_bwd_w<1><<<nb, 256, 0, st>>>(x, dy, N, K, M, scratch);
-    else k_linear_bwd_w<2><<<nb, 256, 0, st>>>(x, dy, N, K, M, scratch);
     const int per = 32 * 64 * KC + 32;
-    k_linear_bwd_sum<<<(per + 31) / 32, 256, 0, st>>>(scratch, nb, KC, K, M, dW, db);
+    for (int m0 = 0; m0 < M; m0 += 32) {       // 32 output columns per pass (x is re-read: the wide layers have few rows)
+        const int mc = std::min(32, M - m0);
+        if (KC == 1) k_linear_bwd_w<1><<<nb, 256, 0, st>>>(x, dy + m0, N, K, mc, M, scratch);
+        else k_linear_bwd_w<2><<<nb, 256, 0, st>>>(x, dy + m0, N, K, mc, M, scratch);
+        k_linear_bwd_sum<<<(per + 31) / 32, 256, 0, st>>>(scratch, nb, KC, K, mc, dW + (size_t)m0 * K, db ? db + m0 : nullptr);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

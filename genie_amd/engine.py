@@ -371,7 +371,7 @@ class HipPath(object):
 
     def nbr_mean(self, x_sta=None, x_src=None):
         """Neighbour means over the product graph of [P, C] rows (C <= 32): (mean over station neighbours of x_sta, mean over
-        source neighbours of x_src); genie_nbr_mean on rows padded to 16 / 32 floats."""
+        source neighbours of x_src); genie_nbr_mean on rows padded to 16 / 32 floats ([P, 30] rows as they are)."""
         outs = []
         args = []
         width = None
@@ -382,7 +382,7 @@ class HipPath(object):
                 continue
             x = _f32(x, "x")
             C = x.shape[1]
-            w = 16 if C <= 16 else 32
+            w = 30 if C == 30 else (16 if C <= 16 else 32)        # [P, 30] rows go through unpadded
             if C > 32 or x.shape[0] != self.n_prod or (width is not None and w != width):
                 raise ValueError("nbr_mean: rows must be [n_prod, C <= 32] of one padded width")
             width = w
@@ -404,7 +404,7 @@ class HipPath(object):
                 continue
             g = _f32(g, "grad")
             C = g.shape[1]
-            w = 16 if C <= 16 else 32
+            w = 30 if C == 30 else (16 if C <= 16 else 32)
             if C > 32 or g.shape[0] != self.n_prod or (width is not None and w != width):
                 raise ValueError("nbr_mean_bwd: rows must be [n_prod, C <= 32] of one padded width")
             width = w

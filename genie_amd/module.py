@@ -101,6 +101,18 @@ def _lin(module, x, hip):
     return _Linear.apply(x.contiguous(), module.weight, module.bias, hip)
 
 
+def _dense(module, x, owner):
+    """`module(x)` for an nn.Linear; under autograd on a HIP-backed network (owner._hip set by set_adjacencies) and with enough
+    rows the weight / bias gradients come from genie_linear_bwd_wb (`_Linear`)."""
+    hip = getattr(owner, "_hip", None)
+    rows = x.numel() // max(1, x.shape[-1])
+    if (hip is None or not torch.is_grad_enabled() or not x.is_cuda or rows < 4096 or module.in_features > 128
+            or module.out_features > 128 or module.bias is None):
+        return module(x)
+    y = _Linear.apply(x.reshape(rows, x.shape[-1]).contiguous(), module.weight, module.bias, hip)
+    return y.view(*x.shape[:-1], module.out_features)
+
+
 def _act(module, x, hip):
     return _PReLU.apply(x.contiguous(), module.weight, hip)
 
@@ -228,9 +240,9 @@ class SpatialAggregation(nn.Module):
         j, i = A_src[0], A_src[1]
         p = pos / self.scale_rel
         x_j = tr[j]
-        c = self.activate3(self.fglobal(x_j)).mean(0, keepdim=True)
-        msg = self.activate1(self.fc1(torch.cat((x_j, p[i] - p[j], c.expand(x_j.shape[0], -1)), dim=-1)))
-        return self.activate2(self.fc2(torch.cat((tr, _scatter_mean_rows(msg, i, tr.shape[0])), dim=-1)))
+        c = self.activate3(_dense(self.fglobal, x_j, self)).mean(0, keepdim=True)
+        msg = self.activate1(_dense(self.fc1, torch.cat((x_j, p[i] - p[j], c.expand(x_j.shape[0], -1)), dim=-1), self))
+        return self.activate2(_dense(self.fc2, torch.cat((tr, _scatter_mean_rows(msg, i, tr.shape[0])), dim=-1), self))
 
 
 class SpatialDirect(nn.Module):
@@ -300,9 +312,9 @@ class SpatialAttention(nn.Module):
         edge_attr = (x_query[i] - x_context[j]) / self.scale_rel
         x_j = inpts[j]
         cat = torch.cat((x_j, edge_attr), dim=-1)
-        q = self.f_queries(edge_attr).view(-1, H, L)
-        c = self.f_context(cat).view(-1, H, L)
-        v = self.f_values(cat).view(-1, H, L)
+        q = _dense(self.f_queries, edge_attr, self).view(-1, H, L)
+        c = _dense(self.f_context, cat, self).view(-1, H, L)
+        v = _dense(self.f_values, cat, self).view(-1, H, L)
         alpha = self.activate1((q * c).sum(-1) / self.scale)                       # [E, H]
         # segment softmax over the k edges of each query (edges are grouped by query, k each)
         alpha = alpha.view(-1, kk, H)
@@ -336,12 +348,12 @@ class TemporalAttention(nn.Module):
 
     def forward(self, inpts, t_query):
         H, L = self.n_heads, self.n_latent
-        context = self.f_context_2(self.activate1(self.f_context_1(inpts))).view(-1, H, L)
-        values = self.f_values_2(self.activate2(self.f_values_1(inpts))).view(-1, H, L)
+        context = _dense(self.f_context_2, self.activate1(_dense(self.f_context_1, inpts, self)), self).view(-1, H, L)
+        values = _dense(self.f_values_2, self.activate2(_dense(self.f_values_1, inpts, self)), self).view(-1, H, L)
         query = self.temporal_query_2(self.activate3(self.temporal_query_1(t_query / self.scale_t))).view(-1, H, L)
         score = torch.einsum("nhl,thl->nth", context, query) / self.scale           # [N, T, H]
         z = torch.einsum("nth,nhl->ntl", score, values) / H                         # mean over heads
-        return self.proj_2(self.activate5(self.proj_1(self.activate4(z))))
+        return _dense(self.proj_2, self.activate5(_dense(self.proj_1, self.activate4(z), self)), self)
 
 
 def _mean_over_sta(x, sta_nbr, n_sta, n_grid):
@@ -629,12 +641,19 @@ class GCN_Detection_Network_extended(nn.Module):
         self._path_params = None
         self._edge_attr = None
 
+    def _share_engine(self):
+        # the G- / Q-sized heads take their Linear weight gradients from the HIP library in training steps (`_dense`)
+        for m in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3, self.SpatialAttention,
+                  self.TemporalAttention):
+            m._hip = self._hip
+
     # ---- graphs --------------------------------------------------------------------------------
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         order = _engine.morton_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev)
+        self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         if self.use_updated_model_definition:
@@ -693,6 +712,7 @@ class GCN_Detection_Network_extended(nn.Module):
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))

@@ -224,7 +224,7 @@ int genie_embed_window_split(genie_ctx* ctx, const double* pick_t, const int32_t
                              int n_picks, double t0, double max_t, double kernel_sig_t, double dt, const float* trv,
                              float* emb_ws, float* slice_out, float* mask_out, void* workspace, void* stream);
 
-/* Neighbour means on the implicit product graph for [P, row_floats] fp32 rows (row_floats = 16 or 32, 16-byte aligned):
+/* Neighbour means on the implicit product graph for [P, row_floats] fp32 rows (row_floats = 16 or 32, 16-byte aligned, or 30 = unpadded [P, 30] rows, 8-byte aligned):
  *   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))]      (MessagePassing('mean') over A_in_sta)
  *   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]      (... over A_in_src; x_src has n_grid_ext * n_sta rows)
  * Either pair may be null. Used by the association heads (DataAggregationAssociationPhase, module.py:395-400), whose
@@ -237,7 +237,7 @@ int genie_prelu_bwd(const float* x, const float* dy, const float* slope, int64_t
                     void* stream);
 
 /* Weight and bias gradients of a per-node Linear y = x W^T + b over N contiguous rows (training path):
- * dW[M, K] = dy^T x, db[M] = column sums of dy (db may be NULL), M <= 32, K <= 128, summed in a fixed order.
+ * dW[M, K] = dy^T x, db[M] = column sums of dy (db may be NULL), M <= 128, K <= 128, summed in a fixed order.
  * `scratch` holds genie_linear_bwd_scratch_floats(K) floats. */
 int64_t genie_linear_bwd_scratch_floats(int K);
 int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M, float* dW, float* db, float* scratch, void* stream);

@@ -340,10 +340,10 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,M", [(1, 8, 30), (37, 64, 30), (4099, 94, 15), (70001, 33, 30), (50000, 60, 30)])
+@pytest.mark.parametrize("N,K,M", [(1, 8, 30), (37, 64, 30), (4099, 94, 15), (70001, 33, 30), (50000, 60, 30), (20011, 33, 75), (3001, 38, 5)])
 def test_linear_bwd_wb_matches_fp64(N, K, M):
     """genie_linear_bwd_wb (weight / bias gradients of the per-node Linears, training path) against the fp64 products, at the
-    widths the path uses (K = 8, 33, 60, 64, 94; M = 15, 30) and at ragged row counts."""
+    widths the path uses (K = 8, 33, 38, 60, 64, 94; M = 5, 15, 30, 75) and at ragged row counts."""
     hp = engine.HipPath(3, 4, engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 3),
                         engine.csr_from_edges(torch.zeros((2, 0), dtype=torch.long), 4), device=DEV)
     g = torch.Generator(device=DEV).manual_seed(N + K)

@@ -19,7 +19,11 @@ def step():
     ((y ** 2).mean() + (x ** 2).mean()).backward()
 for _ in range(3): step()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
     for _ in range(3): step()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=18, max_name_column_width=60))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::sum", "aten::mm", "aten::copy_", "aten::cat", "aten::addmm", "aten::mul", "aten::add", "aten::index", "aten::index_add_", "aten::max", "aten::pad", "aten::constant_pad_nd", "aten::slice_backward", "aten::fill_", "aten::zero_")]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:40]:
+    print("%-22s %8.2f ms/step  x%-3d %s" % (e.key, e.self_device_time_total / 3e3, e.count // 3, str(e.input_shapes)[:110]))
