@@ -2044,6 +2044,10 @@ __global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
 // in LDS ([k][32], lane = output channel), inputs broadcast with width-32 shuffles.
 // ------------------------------------------------------------------------------------------------
 constexpr int NPB = 8;  // nodes per 256-thread block
+// wave-level ordering point for data the 32 lanes of a node group (half a wave) exchange through LDS (see k_readout)
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// The per-node matvecs o[c] = sum_k W[k][c] x[k] read x[k] as an LDS broadcast (the compiler merges four k into one
+// ds_read_b128): 3.5 LDS cycles per wave-FMA and CU against 6.5 with __shfl = ds_bpermute (tools/lds_matvec.hip).
 
 // Weight staging: global [rows][ld] row-major (nn.Linear layout) -> LDS [k][ldo] (k = input index, lane = output
 // channel; conflict-free LDS writes and reads, strided but L1-resident global reads)
@@ -2070,6 +2074,7 @@ __global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part,
                                                 const float* __restrict__ raw, int off_w, int off_b, int off_a,
                                                 float* __restrict__ out, long long part_ws, long long out_ws) {
     __shared__ float wt[30 * 32];
+    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
     stage_transposed(wt, raw + off_w, 15, 30);
     __syncthreads();
     part += blockIdx.y * part_ws;
@@ -2081,11 +2086,21 @@ __global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part,
         const int g = g0 + grp;
         const bool ok = g < G;
         float r = 0.f;
-        if (ok)
-            for (int tb = 0; tb < T; ++tb) r += part[((long long)g * T + tb) * 32 + c];
+        if (ok) {
+            const float* pg = part + (long long)g * T * 32 + c;
+            int tb = 0;
+            for (; tb + 4 <= T; tb += 4) {        // four rows in flight, added in tile order
+                const float v0 = pg[tb * 32], v1 = pg[(tb + 1) * 32], v2 = pg[(tb + 2) * 32], v3 = pg[(tb + 3) * 32];
+                r += v0; r += v1; r += v2; r += v3;
+            }
+            for (; tb < T; ++tb) r += pg[tb * 32];
+        }
+        gx[grp][c] = r;
+        GSYNC();
         float o = bias;
 #pragma unroll
-        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * __shfl(r, k, 32);
+        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * gx[grp][k];
+        GSYNC();
         if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
     }
 }
@@ -2094,6 +2109,7 @@ __global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ r
                                                     const float* __restrict__ raw, int off_w, int off_b, int off_a,
                                                     float* __restrict__ out) {
     __shared__ float wt[30 * 32];
+    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
     stage_transposed(wt, raw + off_w, 15, 30);
     __syncthreads();
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -2105,9 +2121,12 @@ __global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ r
         float r = 0.f;
         if (ok)
             for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) r += rows[pr * 32 + c];
+        gx[grp][c] = r;
+        GSYNC();
         float o = bias;
 #pragma unroll
-        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * __shfl(r, k, 32);
+        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * gx[grp][k];
+        GSYNC();
         if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
     }
 }
@@ -2166,6 +2185,7 @@ __global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
     sa_select_window(a);
     __shared__ float wx[C * 32];
     __shared__ float wg[C * 32];
+    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
     stage_transposed_cols(wx, a.raw + a.fc1_w, 30, C + 8, C);
     stage_transposed(wg, a.raw + a.fg_w, 5, C);
     __syncthreads();
@@ -2176,14 +2196,16 @@ __global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
     for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
         const int g = g0 + grp;
         const bool ok = g < a.G;
-        const float x = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
+        gx[grp][c] = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
+        GSYNC();
         float pj = 0.f, gl = bg;
 #pragma unroll
         for (int k = 0; k < C; ++k) {
-            const float xk = __shfl(x, k, 32);
+            const float xk = gx[grp][k];
             pj += wx[k * 32 + c] * xk;
             gl += wg[k * 32 + c] * xk;
         }
+        GSYNC();
         if (ok) {
             a.pj_out[(long long)g * 32 + c] = c < 30 ? pj : 0.f;
             acc += (float)a.outdeg[g] * prelu1(gl, act3);
@@ -2203,6 +2225,7 @@ __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
     __shared__ float wxn[NEXT ? 30 * 32 : 32];
     __shared__ float wgn[NEXT ? 30 * 32 : 32];
     __shared__ float gsum[8];
+    __shared__ __attribute__((aligned(16))) float gx[NPB][96];       // per node group: x_i, the edge mean, the layer output
     for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
         const int k = i >> 5, cc = i & 31;
         w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
@@ -2270,18 +2293,23 @@ __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
             }
         }
         const float av = asum / (float)max(ee - eb, 1);
+        gx[grp][c] = xi;
+        gx[grp][32 + c] = av;
+        GSYNC();
         float o = b2;
 #pragma unroll
-        for (int kk = 0; kk < C; ++kk) o += w2t[kk * 32 + c] * __shfl(xi, kk, 32);
+        for (int kk = 0; kk < C; ++kk) o += w2t[kk * 32 + c] * gx[grp][kk];
 #pragma unroll
-        for (int kk = 0; kk < 30; ++kk) o += w2t[(C + kk) * 32 + c] * __shfl(av, kk, 32);
+        for (int kk = 0; kk < 30; ++kk) o += w2t[(C + kk) * 32 + c] * gx[grp][32 + kk];
         o = c < 30 ? prelu1(o, act2) : 0.f;
         if (ok && c < 30) a.out[(long long)i * 30 + c] = o;
         if (NEXT) {
+            gx[grp][64 + c] = o;
+            GSYNC();
             float pj = 0.f, gl = bgn;
 #pragma unroll
             for (int k = 0; k < 30; ++k) {
-                const float ok_ = __shfl(o, k, 32);
+                const float ok_ = gx[grp][64 + k];
                 pj += wxn[k * 32 + c] * ok_;
                 gl += wgn[k * 32 + c] * ok_;
             }
@@ -2290,6 +2318,7 @@ __global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
                 acc += (float)a.outdeg[i] * prelu1(gl, act3n);
             }
         }
+        GSYNC();
     }
     if (NEXT) sa_store_gpart(acc, c, grp, a.gpart_out);
 }
@@ -2351,6 +2380,7 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
                                                 float* __restrict__ cv, int Gw, long long cv_ws) {
     __shared__ __attribute__((aligned(16))) float wc[30 * 96];
     __shared__ __attribute__((aligned(16))) float wv[30 * 96];
+    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
     for (int i = threadIdx.x; i < 30 * 96 / 4; i += blockDim.x) {
         ((f32x4*)wc)[i] = ((const f32x4*)imgcv)[i];
         ((f32x4*)wv)[i] = ((const f32x4*)(imgcv + 30 * 96))[i];
@@ -2360,14 +2390,16 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
     for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
         const int g = g0 + grp;
         const bool ok = g < G;
-        const float x = (ok && c < 30) ? x_spatial[(long long)g * 30 + c] : 0.f;
+        gx[grp][c] = (ok && c < 30) ? x_spatial[(long long)g * 30 + c] : 0.f;
+        GSYNC();
         float cc[3] = {0.f, 0.f, 0.f}, vv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 30; ++k) {
-            const float xk = __shfl(x, k, 32);
+            const float xk = gx[grp][k];
             cc[0] += wc[k * 96 + c] * xk; cc[1] += wc[k * 96 + 32 + c] * xk; cc[2] += wc[k * 96 + 64 + c] * xk;
             vv[0] += wv[k * 96 + c] * xk; vv[1] += wv[k * 96 + 32 + c] * xk; vv[2] += wv[k * 96 + 64 + c] * xk;
         }
+        GSYNC();
         if (ok) {
             const int w = g / Gw;
             float* o = cv + w * cv_ws + (long long)(g - w * Gw) * CVP;
@@ -2380,7 +2412,6 @@ __global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spat
 // The 32 lanes of a node group live in ONE wave and only exchange data among themselves through their private LDS
 // scratch, so a wave-level ordering point (LDS ops of a wave complete in order) replaces __syncthreads(): waves do
 // not wait for each other between the ~35 short phases of a node batch.
-#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
 constexpr int RO_TMAX = 10;   // time queries per call (the reference uses 9, process_continuous_days.py:359)
