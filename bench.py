@@ -60,8 +60,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream forward_fixed_source per window")
-    ap.add_argument("--tail-batch", type=int, default=8,
-                    help="windows per batched G-sized tail (push_window / flush_windows); 1 = one tail per window")
+    ap.add_argument("--push-flush", action="store_true",
+                    help="with --tail-batch 1: push_window / flush_windows (genie_tail_batched over one window) instead of "
+                         "forward_fixed_source_pipelined (the same tail launched call by call)")
+    ap.add_argument("--tail-batch", type=int, default=None,
+                    help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 1 for "
+                         "resident windows (the headline workload), 8 for --mode stream (measured best for each, DESIGN.md section 5)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded", "stream"],
                     help="N>1: window-parallel replicas (weak scaling, default) or ONE window sharded over source nodes "
                          "with an RCCL halo all-to-all + all-gather per window (strong scaling; use with --config cfg4_2000x50k)")
@@ -126,6 +130,7 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
 
     acc = [None]
     first = [0]
+    net.window_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 8, 8))
 
     def flush(upto):
         y, x, _ = net.flush_windows(xg, xq, tq)
@@ -141,7 +146,15 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
     def step(i):
         Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv,
                                       presplit=not os.environ.get("GENIE_NO_PRESPLIT"))
-        if net.push_window(Slice, Mask) >= net.window_batch:
+        if net.window_batch == 1:         # one tail per window, launched call by call on alternating side streams
+            y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+            with torch.cuda.stream(hp.side_stream):
+                if acc[0] is not None:
+                    hp.side_stream.wait_event(acc[0])         # windows accumulate in order
+                Out_2.index_add_(1, base + int(t_all[i]), x[:, :, 0])
+                acc[0] = torch.cuda.Event()
+                acc[0].record(hp.side_stream)
+        elif net.push_window(Slice, Mask) >= net.window_batch:
             flush(i + 1)
 
     def drain(upto):
@@ -282,17 +295,18 @@ def main():
     xq = torch.from_numpy(geom.x_query).float().to(dev)
     tq = torch.from_numpy(geom.t_query).float().to(dev)
 
-    tail_batch = max(1, min(a.tail_batch, net.window_batch))
+    tail_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 1, 8))
+    net.window_batch = tail_batch
 
     def step(i):
         # windows are independent (the apply loop): the P-sized kernels of every window run on the main stream, the G-sized
-        # tails + read-outs of `tail_batch` windows in one set of launches on a side stream, under the P-sized kernels of the
-        # following windows (bitwise-identical results, tests/test_hip_parity.py). --tail-batch 1 = one tail per window,
+        # tail + read-outs of every window (or of `tail_batch` windows in one set of launches) on alternating side streams,
+        # under the P-sized kernels of the following windows (bitwise-identical results, tests/test_hip_parity.py).
         # --no-pipeline = single stream
         k = i % a.windows
         if a.no_pipeline:
             return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
-        if tail_batch == 1:
+        if tail_batch == 1 and not a.push_flush:
             return net.forward_fixed_source_pipelined(dS[k], dM[k], None, None, None, locs, xg, xq, tq)[:2]
         if net.push_window(dS[k], dM[k]) >= tail_batch:
             return net.flush_windows(xg, xq, tq)[:2]

@@ -84,10 +84,12 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
 
 def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1,
                          n_grids=1.0, day_len=86400.0, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, max_t=None,
-                         times=None):
+                         times=None, tail_batch=8):
     """GPU-only apply loop: `P` [n,5] (t, station index in the model's station order, amp, prob, phase) sorted by time,
-    `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used)."""
+    `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used). `tail_batch`: windows
+    per G-sized tail (1..8; 8 measured best with the device embedding in the loop, bench.py --mode stream)."""
     hp = net._hip
+    net.window_batch = tail_batch
     dev = hp.device
     max_t = float(max_t if max_t is not None else np.ceil(trv_times.max() + 1.0))
     dt_embed = float(dt_embed if dt_embed is not None else np.round(kernel_sig_t / 10.0, 2))      # process_continuous_days.py:608
@@ -134,7 +136,16 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
             a, b = int(lo[w]), int(hi[w])
             Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
                                           presplit=True)     # the push below is the only consumer of (Slice, Mask)
-            if net.push_window(Slice, Mask) == net.window_batch or w == len(times) - 1:
+            if net.window_batch == 1:     # one tail per window (forward_fixed_source_pipelined), accumulated in window order
+                y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+                with torch.cuda.stream(hp.side_stream):
+                    if acc_done[0] is not None:
+                        hp.side_stream.wait_event(acc_done[0])
+                    vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
+                    Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
+                    acc_done[0] = torch.cuda.Event()
+                    acc_done[0].record(hp.side_stream)
+            elif net.push_window(Slice, Mask) == net.window_batch or w == len(times) - 1:
                 flush(first)
                 first = w + 1
         hp.wait_tails()

@@ -272,30 +272,47 @@ class HipPath(object):
         _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
         return y, x, done
 
-    # ---- batched window pipeline: stage 1 / 2 per window, one G-sized tail per BATCH windows ------------------------
-    BATCH = 8     # windows per batched tail (two batches in flight: 16 workspace slots)
+    # ---- window pipeline with batched tails: stage 1 / 2 per window, one G-sized tail per `window_batch` windows -------
+    MAX_BATCH = 8
+    window_batch = 1      # windows per tail (set_window_batch); 1 = every window gets its own tail
+
+    def set_window_batch(self, n):
+        """Windows per batched tail, 1..8. Measured at config 2: the batched tail needs 104 us of GPU time per window against 186
+        us for per-window tails, but its long persistent read-out workgroups hold CUs that the next stage-1 workgroups wait for:
+        for resident windows one tail per window is ~1 % faster end to end, with the device embedding in the loop batches of 8
+        are 3.6 % faster. Default 1 (results arrive per window); `apply_windows_device` uses 8."""
+        n = int(n)
+        if not 1 <= n <= self.MAX_BATCH:
+            raise ValueError("window batch must be in [1, %d]" % self.MAX_BATCH)
+        if getattr(self, "_bt", None) is not None and self._bt["n"]:
+            raise RuntimeError("set_window_batch: windows pending, call windows_flush first")
+        if getattr(self, "_bt", None) is not None:
+            self.wait_tails()
+            self._bt = None
+        self.window_batch = n
 
     def window_push(self, Slice, Mask, edge_attr):
         """Stage 1 + stage 2 of one window on the current stream, into the next workspace slot of the open batch; returns the
-        number of windows now pending (call `windows_flush` when it reaches `BATCH`, or earlier). The plain single-stream
-        calls (`path_fwd`, read-outs) share workspace slot 0 with the first window of a batch: call `wait_tails()` before mixing
-        them with batches in flight."""
+        number of windows now pending (call `windows_flush` when it reaches `window_batch`, or earlier). The plain
+        single-stream calls (`path_fwd`, read-outs) share workspace slot 0 with the first window of a batch: call
+        `wait_tails()` before mixing them with batches in flight."""
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         if getattr(self, "_bt", None) is None:
             prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
-            self._bt = {"half": 0, "n": 0, "ev": [None, None],
+            groups = 3 if self.window_batch == 1 else 2        # batches in flight (16 workspace slots)
+            self._bt = {"group": 0, "n": 0, "ev": [None] * groups, "turn": 0,
                         "streams": [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(2)]}
             self.side_streams = list(getattr(self, "side_streams", None) or []) + self._bt["streams"]
         bt = self._bt
-        if bt["n"] >= self.BATCH:
+        if bt["n"] >= self.window_batch:
             raise RuntimeError("window_push: %d windows pending, call windows_flush first" % bt["n"])
         main = torch.cuda.current_stream(self.device)
-        if bt["n"] == 0 and bt["ev"][bt["half"]] is not None:
-            main.wait_event(bt["ev"][bt["half"]])          # the batched tail that last read these slots has finished
-        _lib.check(self.lib.genie_set_slot(self.ctx, bt["half"] * self.BATCH + bt["n"]), "genie_set_slot")
+        if bt["n"] == 0 and bt["ev"][bt["group"]] is not None:
+            main.wait_event(bt["ev"][bt["group"]])          # the tail that last read these slots has finished
+        _lib.check(self.lib.genie_set_slot(self.ctx, bt["group"] * self.window_batch + bt["n"]), "genie_set_slot")
         st = ctypes.c_void_p(main.cuda_stream)
         _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, st), "genie_da_stage1")
         _lib.check(self.lib.genie_da_stage2_partials(self.ctx, _ptr(Mask), _ptr(edge_attr), None, self._ws_ptr, st),
@@ -307,7 +324,7 @@ class HipPath(object):
     def windows_flush(self, pos, x_query, knn_idx, t_query):
         """The G-sized tail of all pending windows (genie_tail_batched) on a side stream, where it overlaps the P-sized kernels
         of the following windows. Returns (y [n, G, T, 1], x [n, Q, T, 1], done_event), produced on `self.side_stream`: consume
-        them there or after the event. Two batches may be in flight (their tails alternate between two side streams)."""
+        them there or after the event. Consecutive tails alternate between two side streams."""
         bt = getattr(self, "_bt", None)
         if bt is None or bt["n"] == 0:
             raise RuntimeError("windows_flush: no pending window")
@@ -322,19 +339,20 @@ class HipPath(object):
         main = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         ev.record(main)
-        side = self.side_stream = bt["streams"][bt["half"]]
+        side = self.side_stream = bt["streams"][bt["turn"]]
         side.wait_event(ev)
         with torch.cuda.stream(side):
             x_spatial = torch.empty((n, self.n_grid, 30), dtype=torch.float32, device=self.device)
             y = torch.empty((n, self.n_grid, tq.numel(), 1), dtype=torch.float32, device=self.device)
             x = torch.empty((n, nq, tq.numel(), 1), dtype=torch.float32, device=self.device)
-            _lib.check(self.lib.genie_tail_batched(self.ctx, bt["half"] * self.BATCH, n, _ptr(pos), _ptr(x_query), _ptr(knn_idx), nq, 10,
-                                                   _ptr(tq), tq.numel(), _ptr(x_spatial), _ptr(y), _ptr(x), self._ws_ptr,
+            _lib.check(self.lib.genie_tail_batched(self.ctx, bt["group"] * self.window_batch, n, _ptr(pos), _ptr(x_query), _ptr(knn_idx),
+                                                   nq, 10, _ptr(tq), tq.numel(), _ptr(x_spatial), _ptr(y), _ptr(x), self._ws_ptr,
                                                    ctypes.c_void_p(side.cuda_stream)), "genie_tail_batched")
             done = torch.cuda.Event()
             done.record(side)
-        bt["ev"][bt["half"]] = done
-        bt["half"] ^= 1
+        bt["ev"][bt["group"]] = done
+        bt["group"] = (bt["group"] + 1) % len(bt["ev"])
+        bt["turn"] ^= 1
         bt["n"] = 0
         return y, x, done
 

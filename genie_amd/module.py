@@ -800,7 +800,13 @@ class GCN_Detection_Network_extended(nn.Module):
 
     @property
     def window_batch(self):
-        return _engine.HipPath.BATCH
+        return self._hip.window_batch if self._hip is not None else 1
+
+    @window_batch.setter
+    def window_batch(self, n):
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) first")
+        self._hip.set_window_batch(n)
 
     @property
     def pending_windows(self):

@@ -652,9 +652,11 @@ def test_device_embedding_matches_reference_and_oracle(name):
     assert float(S0.abs().max()) == 0.0 and float(M0.abs().max()) == 0.0
 
 
-def test_device_apply_loop_matches_oracle():
-    """GPU-only apply loop (device embedding + forward + Out_2 stacking) vs the oracle chain
-    embed_oracle.extract_input_from_data -> genie_oracle.forward_fixed_source_structured -> same stacking."""
+@pytest.mark.parametrize("batch", [1, 4])
+def test_device_apply_loop_matches_oracle(batch):
+    """GPU-only apply loop (device embedding + forward + Out_2 stacking; one tail per window, or tails batched 4 windows at a
+    time) vs the oracle chain embed_oracle.extract_input_from_data -> genie_oracle.forward_fixed_source_structured -> same
+    stacking."""
     from genie_amd import apply
     from oracle import embed_oracle as E
     from oracle import genie_oracle as O
@@ -672,7 +674,8 @@ def test_device_apply_loop_matches_oracle():
                              torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.locs).float().to(DEV),
                              torch.from_numpy(geom.x_grid).float().to(DEV))
     max_t = float(np.ceil(trv.max() + 1.0))
-    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size="half", min_required_picks=5, max_t=max_t)
+    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size="half", min_required_picks=5, max_t=max_t,
+                                              tail_batch=batch)
     assert 2 <= len(times) <= 40
     tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size="half")
     tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
@@ -714,10 +717,11 @@ def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
         assert torch.equal(y0, y1) and torch.equal(x0, x1)
 
 
-def test_batched_windows_are_bitwise_equal_to_plain_forward():
+@pytest.mark.parametrize("batch", [8, 1, 3])
+def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
     """push_window / flush_windows (stage 1 / 2 per window, ONE G-sized tail per batch of windows through genie_tail_batched):
-    every window's (y, x) bit-identical to the single-stream forward_fixed_source; 19 windows = two full batches in flight
-    on alternating slot halves and side streams plus a partial batch of 3; a plain forward in between (after wait_tails)."""
+    every window's (y, x) bit-identical to the single-stream forward_fixed_source; 19 windows = full batches in flight on
+    rotating slot groups and alternating side streams plus a partial batch; a plain forward in between (after wait_tails)."""
     c = Case("cfg1_20x500")
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
@@ -733,6 +737,8 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward():
     with torch.no_grad():
         plain = [net.forward_fixed_source(s_, m_, *fixed) for s_, m_ in wins]
         torch.cuda.synchronize()
+        net.window_batch = batch
+        assert net.window_batch == batch
         got = []
         for k, (s_, m_) in enumerate(wins):
             if net.push_window(s_, m_) == net.window_batch or k == len(wins) - 1:
@@ -742,7 +748,7 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward():
                 net._hip.wait_tails()                                 # a plain forward uses slot 0's scratch: join the tails first
                 mid = net.forward_fixed_source(*wins[3], *fixed)
         torch.cuda.synchronize()
-    assert [g[0].shape[0] for g in got] == [8, 8, 3]
+    assert [g[0].shape[0] for g in got] == [batch] * (19 // batch) + ([19 % batch] if 19 % batch else [])
     ys, xs = torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got])
     for k, (y0, x0) in enumerate(plain):
         assert torch.equal(y0, ys[k]) and torch.equal(x0, xs[k]), k
