@@ -209,7 +209,7 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
     torch.manual_seed(0)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev).eval()
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
-    sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev)
+    sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs)
     sp.set_weights(module._path_param_dict(net))
     p = sp.plan
     ext = p.ext_global

@@ -520,6 +520,9 @@ struct DaArgs {
     float* part;               // [G*T, 32] bipartite partial sums
     float* x_latent;           // optional [P,30]
     float* dbg_h0; float* dbg_h1;  // optional parity outputs [P,30] / [P,60]
+    const int32_t* sta_user;       // station processing order (genie_set_station_order): internal station -> caller's station, or null
+    const float* ea_int;           // with sta_user: edge_attr in processing order (genie_set_static_edge_attr), or null
+    const float* mm_int;           // with sta_user: max_k Mask[p][k] in processing order, written by the split pass of this window
     const float* packed;       // packed A fragments for the stage
     const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
     long long Pn;              // k_stage?_pcsr: number of product nodes (rowptr / col arrays are product-level there)
@@ -1237,11 +1240,18 @@ __global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restri
 }
 
 // [Slice || Mask] rows (8 fp32) -> 48-B rows of three bf16x8 pieces
+// sta_user (internal station -> caller's station, or null): the rows of a source node are written in the station processing order
 __global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
-                             unsigned* __restrict__ out) {
+                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
-    const f32x4 s = *(const f32x4*)(slice + p * 4), m = *(const f32x4*)(mask + p * 4);
+    long long pu = p;
+    if (sta_user != nullptr) {
+        const long long g = p / S;
+        pu = g * S + sta_user[(int)(p - g * S)];
+    }
+    const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
+    if (sta_user != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));      // the message mask of stage 2 (module.py:226)
     const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
 #pragma unroll
     for (int piece = 0; piece < 3; ++piece) {
@@ -1751,7 +1761,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     const unsigned q16 = 16u * (unsigned)q;          // byte offset of this lane's 4 channels inside a 64-B row
 
     // ids of a tile: idv = row of src_tab (lane j = 0: source node, j = 1..KP: its source neighbours), station-neighbour ids
-    struct Ids { int idv, sc, tb; bool valid; int sta[KS]; };
+    struct Ids { int idv, sc, su, tb; bool valid; int sta[KS]; };     // su = the caller's id of station sc (Mask, edge_attr, x_latent)
     auto fetch_ids = [&](long long item, Ids& t) {
         int gi;
         w.decode(item, gi, t.tb);
@@ -1759,6 +1769,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         const int s = t.tb * 16 + j;
         t.valid = s < S;
         t.sc = t.valid ? s : S - 1;
+        t.su = a.sta_user != nullptr ? a.sta_user[t.sc] : t.sc;
         load_sta_ids<KS>(a.sta_col, t.sc, t.sta);
     };
     struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; };
@@ -1775,8 +1786,16 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
             if (ABL(a, 9)) p &= 4095;     // tuning: streamed rows (c, Mask, edge_attr) from a cache-resident region
             r.o[0] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 4 * q + tk);
             r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
-            r.mq = a.mask[p * 4 + q + tk];
-            r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
+            if (a.sta_user != nullptr) {
+                // the message mask max_k Mask[p][k] as left by the split pass, edge_attr from its processing-order copy when one
+                // is registered: both contiguous over the 16 stations of the tile
+                const long long pu = (long long)g * S + t.su;
+                r.mq = q == 0 ? a.mm_int[p + tk] : -INFINITY;         // the q lanes are max-reduced below
+                r.eq = q < 3 ? (a.ea_int != nullptr ? a.ea_int[p * 3 + q + tk] : a.edge_attr[pu * 3 + q + tk]) : 0.f;
+            } else {
+                r.mq = a.mask[p * 4 + q + tk];
+                r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
+            }
             // wave-uniform 64-bit row-block bases (SGPR pairs) + 32-bit lane offsets: safe for P x 64 B >= 4 GiB (config 4)
             const char* wug = wub + (size_t)g * (size_t)S * 64u;
 #pragma unroll
@@ -1834,7 +1853,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         o[0] = prelu4u(o[0] + n1, a2);
         o[1] = prelu4u(o[1] + n2, a2);
         if (a.x_latent != nullptr && cur.valid) {
-            float* xl = a.x_latent + p * 30;
+            float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (4 * q + r < 15) {
@@ -2631,6 +2650,8 @@ struct EmbArgs {
     long long rows;
     float* slice; float* mask;
     unsigned* xs;          // optional: the 48-B split rows of k_stage1_b3, written together with Slice / Mask
+    const int32_t* sta_inv; // station processing order of the split rows (caller's station -> internal), or null
+    float* mm;              // with sta_inv: max of the Mask row, in processing order
 };
 
 __global__ void k_embed_scatter(EmbArgs a) {
@@ -2679,12 +2700,14 @@ __global__ void k_embed_gather(EmbArgs a) {
     *(f32x4*)(a.mask + p * 4) = mk;
     if (a.xs != nullptr) {            // same rows as k_split_rows would produce from (sl, mk)
         const float v[8] = {sl.x, sl.y, sl.z, sl.w, mk.x, mk.y, mk.z, mk.w};
+        const long long px = a.sta_inv != nullptr ? p - sta + a.sta_inv[sta] : p;
+        if (a.sta_inv != nullptr) a.mm[px] = fmaxf(fmaxf(mk.x, mk.y), fmaxf(mk.z, mk.w));
 #pragma unroll
         for (int piece = 0; piece < 3; ++piece) {
             u32x4 o;
 #pragma unroll
             for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-            *(u32x4*)(a.xs + p * (XROW / 4) + piece * 4) = o;
+            *(u32x4*)(a.xs + px * (XROW / 4) + piece * 4) = o;
         }
     }
 }
@@ -2949,14 +2972,30 @@ __global__ void k_xcc_probe(int* __restrict__ out) {
 }
 #endif
 
-__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst) {
-    // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one)
+__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst,
+                         const int32_t* __restrict__ sta_user, int S) {
+    // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one); rows in station processing order -> caller's order
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * ncol) return;
     const long long r = idx / ncol;
     const int cc = (int)(idx % ncol);
     const int off = ncol == 15 ? cc : (cc / 15) * 16 + cc % 15;   // c = [c1 15,0 | c2 15,0]
-    dst[idx] = src[r * pitch + off];
+    long long ru = r;
+    if (sta_user != nullptr) {
+        const long long g = r / S;
+        ru = g * S + sta_user[(int)(r - g * S)];
+    }
+    dst[ru * ncol + cc] = src[r * pitch + off];
+}
+// rows [G][S][width] from station processing order to the caller's order (debug outputs) or, with `inv`, the other way (tables)
+__global__ void k_permute_sta_rows(const float* __restrict__ src, long long rows, int width, const int32_t* __restrict__ map, int S,
+                                   float* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * width) return;
+    const long long r = idx / width;
+    const int cc = (int)(idx - r * width);
+    const long long g = r / S;
+    dst[(g * S + map[(int)(r - g * S)]) * width + cc] = src[idx];
 }
 
 }  // namespace
@@ -2990,6 +3029,11 @@ struct genie_ctx {
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
     float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
     bool has_edges;
+    // station processing order (genie_set_station_order): internal -> caller's station, its inverse, the station graph in
+    // internal labels, the per-station edge terms in internal order; null = the caller's order
+    int32_t *sta_perm, *sta_inv, *sta_rowptr_p, *sta_col_p;
+    float* ebias_sta_p;
+    float* ea_int; const float* ea_user;   // genie_set_static_edge_attr: processing-order copy of the caller's static edge_attr
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
     float* packed_b3;          // bf16x3 weight image of k_stage1_b3
     int num_cu;
@@ -3003,7 +3047,7 @@ struct genie_ctx {
     int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
-    size_t o_xs, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
+    size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
     size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
     int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
@@ -3011,6 +3055,13 @@ struct genie_ctx {
 };
 
 namespace {
+
+// The station processing order is honoured by k_split_rows / the embedding's split rows, k_stage1_b3 (through the relabelled
+// station graph) and k_stage2_fast: active only while those are the kernels that run (not with use_absolute_pos, which takes
+// the generic stage-1 kernel).
+bool sta_order_on(const genie_ctx* c) {
+    return c->sta_perm != nullptr && !c->pcsr && c->use_b3 && c->use_fast && !c->nofast2 && c->nob3s2 && c->abs_sta == nullptr;
+}
 
 constexpr int GENIE_NSLOT = 16;  // copies of the G-sized per-window buffers (genie_set_slot)
 constexpr int GENIE_NBIG = 4;    // copies of the P-sized c / wu / wv rows: slot % GENIE_NBIG
@@ -3025,6 +3076,7 @@ void layout_ws(genie_ctx* c) {
     c->o_c = take((size_t)c->P * ROWC);
     c->o_wu = take((size_t)c->P * ROWW);
     c->o_wv = take((size_t)c->P_ext * ROWW);
+    c->o_mm = take((size_t)c->P_ext);                // max_k Mask[p][k] in station processing order (split pass -> stage 2)
     c->big_stride = o - big0;
     o += (GENIE_NBIG - 1) * c->big_stride;    // further copies (slots 1..): stage 1 of window i+1 may run while stage 2 of window i reads
     const size_t small0 = o;
@@ -3067,6 +3119,10 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
                                                             c->mpos_sta, c->S, c->ebias_sta);
         k_edge_bias<<<(c->G * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T22_P].off, g_params[W_DA_L2T22_P].off,
                                                             c->mpos_src, c->G, c->ebias_src);
+        if (c->sta_perm) {
+            if (!c->ebias_sta_p) HIP_TRY(hipMalloc((void**)&c->ebias_sta_p, sizeof(float) * 48 * (size_t)c->S));
+            k_permute_sta_rows<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->ebias_sta, c->S, 48, c->sta_inv, c->S, c->ebias_sta_p);
+        }
     }
     HIP_TRY(hipGetLastError());
     c->dirty = false;
@@ -3099,8 +3155,9 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
         a.Pn = c->P;
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
     }
+    if (sta_order_on(c)) { a.sta_rowptr = c->sta_rowptr_p; a.sta_col = c->sta_col_p; a.sta_user = c->sta_perm; }
     a.abs_sta = c->abs_sta; a.abs_src = c->abs_src;
-    a.eb_sta = c->has_edges ? c->ebias_sta : nullptr;
+    a.eb_sta = c->has_edges ? (sta_order_on(c) ? c->ebias_sta_p : c->ebias_sta) : nullptr;
     a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
     { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
@@ -3210,6 +3267,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
     c->abs_sta = c->abs_src = nullptr;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
+    c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
+    c->ea_int = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr;
     c->pcsr = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
@@ -3401,6 +3460,52 @@ int genie_set_tail_mode(genie_ctx* c, int slim) {
     return GENIE_OK;
 }
 
+int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_station_order: null context");
+    void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int};
+    for (void* q : old) (void)hipFree(q);
+    c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr;
+    c->ea_int = nullptr; c->ea_user = nullptr;
+    c->dirty = true;
+    if (!order_host || c->pcsr) return GENIE_OK;
+    const int S = c->S;
+    std::vector<int32_t> perm(order_host, order_host + S), inv((size_t)S, -1);
+    for (int i = 0; i < S; ++i) {
+        if (perm[i] < 0 || perm[i] >= S || inv[perm[i]] >= 0) return fail(GENIE_ERR_ARG, "genie_set_station_order: not a permutation of 0..n_sta-1");
+        inv[perm[i]] = i;
+    }
+    std::vector<int32_t> rp((size_t)S + 1);
+    HIP_TRY(hipMemcpy(rp.data(), c->sta_rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+    const size_t E = (size_t)rp[S];
+    std::vector<int32_t> col(E), rpp((size_t)S + 1, 0), colp(E);
+    if (E) HIP_TRY(hipMemcpy(col.data(), c->sta_col, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
+    for (int i = 0; i < S; ++i) {          // internal station i = the caller's perm[i]: same neighbours, same edge order, new labels
+        const int u = perm[i];
+        rpp[(size_t)i + 1] = rpp[i] + (rp[u + 1] - rp[u]);
+        for (int e = rp[u]; e < rp[u + 1]; ++e) colp[(size_t)rpp[i] + (e - rp[u])] = inv[col[e]];
+    }
+    HIP_TRY(hipMalloc((void**)&c->sta_perm, sizeof(int32_t) * S));
+    HIP_TRY(hipMalloc((void**)&c->sta_inv, sizeof(int32_t) * S));
+    HIP_TRY(hipMalloc((void**)&c->sta_rowptr_p, sizeof(int32_t) * ((size_t)S + 1)));
+    HIP_TRY(hipMalloc((void**)&c->sta_col_p, sizeof(int32_t) * std::max<size_t>(E, 1)));
+    HIP_TRY(hipMemcpy(c->sta_perm, perm.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->sta_inv, inv.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->sta_rowptr_p, rpp.data(), sizeof(int32_t) * rpp.size(), hipMemcpyHostToDevice));
+    if (E) HIP_TRY(hipMemcpy(c->sta_col_p, colp.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
+    return GENIE_OK;
+}
+
+int genie_set_static_edge_attr(genie_ctx* c, const float* edge_attr, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_static_edge_attr: null context");
+    c->ea_user = nullptr;
+    if (!edge_attr || !c->sta_perm || c->pcsr) return GENIE_OK;       // nothing to prepare without a station processing order
+    if (!c->ea_int) HIP_TRY(hipMalloc((void**)&c->ea_int, sizeof(float) * 3 * (size_t)c->P));
+    k_permute_sta_rows<<<(unsigned)((c->P * 3 + 255) / 256), 256, 0, (hipStream_t)stream>>>(edge_attr, c->P, 3, c->sta_inv, c->S, c->ea_int);
+    HIP_TRY(hipGetLastError());
+    c->ea_user = edge_attr;
+    return GENIE_OK;
+}
+
 int genie_set_slot(genie_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_set_slot: slot must be in [0, GENIE_NSLOT)");
     c->slot = slot;
@@ -3414,7 +3519,8 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
-                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w};
+                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
+                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -3463,6 +3569,12 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     DaArgs a = make_da_args(c, (float*)ws);
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
+    float* dbg_tmp = nullptr;
+    if ((dbg_h0 || dbg_h1) && sta_order_on(c)) {
+        HIP_TRY(hipMalloc((void**)&dbg_tmp, sizeof(float) * 90 * (size_t)c->P));
+        if (dbg_h0) a.dbg_h0 = dbg_tmp;
+        if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
+    }
 #if GENIE_TUNING
     static float* tbuf1 = nullptr;
     if (c->use_b3 && a.abl & 1024) {   // per-wave phase timers of k_stage1_b3 (GENIE_ABLATE bit 10), dumped with GENIE_DUMP_PHASES
@@ -3488,7 +3600,8 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         const bool presplit = c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws;     // genie_embed_window_split, one-shot
         c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
-        if (!presplit) k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs);
+        if (!presplit) k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs, sta_order_on(c) ? c->sta_perm : nullptr, c->S,
+                                                                                        (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride);
         a.xs = xs; a.packed = c->packed_b3;
         const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
@@ -3504,6 +3617,12 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     else
         k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
+    if (dbg_tmp) {     // parity outputs were written in station processing order: back to the caller's order
+        if (dbg_h0) k_permute_sta_rows<<<(unsigned)((c->P * 30 + 255) / 256), 256, 0, st>>>(dbg_tmp, c->P, 30, c->sta_perm, c->S, dbg_h0);
+        if (dbg_h1) k_permute_sta_rows<<<(unsigned)((c->P * 60 + 255) / 256), 256, 0, st>>>(dbg_tmp + c->P * 30, c->P, 60, c->sta_perm, c->S, dbg_h1);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipFree(dbg_tmp));
+    }
     return GENIE_OK;
 }
 }  // namespace
@@ -3532,6 +3651,8 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
+    a.ea_int = (sta_order_on(c) && c->ea_int && c->ea_user == edge_attr) ? c->ea_int : nullptr;
+    a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
 #if GENIE_TUNING
     {   // per-wave phase timers of k_stage2_fast (GENIE_ABLATE bit 10): dumped to stderr by the host after a sync
         static float* tbuf = nullptr;
@@ -3881,6 +4002,8 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
     a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
     a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs;
+    a.sta_inv = (xs && sta_order_on(c)) ? c->sta_inv : nullptr;
+    a.mm = xs ? (float*)xs - c->o_xs + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride : nullptr;   // xs = workspace + o_xs
     HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
     if (n_picks > 0) {
         const long long n = (long long)n_picks * (2 * a.n_extra + 1);
@@ -4028,7 +4151,7 @@ int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream)
         default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..2");
     }
     const long long n = rows * ncol;
-    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out);
+    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out, sta_order_on(c) ? c->sta_perm : nullptr, c->S);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

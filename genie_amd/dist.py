@@ -119,9 +119,11 @@ class ShardedPath(object):
     """Sharded DataAggregation + Bipartite on this rank's GPU, replicated SpatialAggregation / read-out.
 
     sta_csr: (rowptr, col) of the station graph; A_src_src: global [2, E]; edge_attr_own: [n_own*S, 3] rows of the
-    owned nodes in local order; pos_global: [G, 3]."""
+    owned nodes in local order; pos_global: [G, 3]; pos_sta: optional [S, 3] station positions -> station processing order
+    (the same on every rank: the halo rows of `wv` travel in that order)."""
 
-    def __init__(self, n_sta, n_grid, sta_csr, A_src_src, pos_global, world, rank, device, group=None, scale_rel=30000.0):
+    def __init__(self, n_sta, n_grid, sta_csr, A_src_src, pos_global, world, rank, device, group=None, scale_rel=30000.0,
+                 pos_sta=None):
         from . import engine
         self.group = group
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
@@ -129,7 +131,8 @@ class ShardedPath(object):
         self.plan = ShardPlan(A_src_src, n_grid, world, rank, order)
         p = self.plan
         self.local = engine.HipPath(n_sta, p.n_own, sta_csr, (torch.from_numpy(p.src_rowptr), torch.from_numpy(p.src_col)),
-                                    n_grid_ext=p.n_ext, grid_order=None, scale_rel=scale_rel, device=device)
+                                    n_grid_ext=p.n_ext, grid_order=None, scale_rel=scale_rel, device=device,
+                                    sta_order=engine.morton_order(np.asarray(pos_sta)) if pos_sta is not None else None)
         self.full = engine.HipPath(1, n_grid, (torch.zeros(2, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)),
                                    engine.csr_from_edges(torch.as_tensor(A_src_src), n_grid), grid_order=None,
                                    scale_rel=scale_rel, device=device)

@@ -82,9 +82,11 @@ class HipPath(object):
     """
 
     def __init__(self, n_sta, n_grid, sta_csr, src_csr, n_grid_ext=None, grid_order=None, scale_rel=30000.0,
-                 device=None, subgraph=None):
+                 device=None, subgraph=None, sta_order=None):
         """`subgraph` = dict(n_prod, sta_csr, src_csr, seg_rowptr): an irregular product graph (`use_subgraph`) given as
-        product-level CSRs + the row range of every source node (genie_ctx_create_subgraph); `sta_csr` is then ignored."""
+        product-level CSRs + the row range of every source node (genie_ctx_create_subgraph); `sta_csr` is then ignored.
+        `grid_order` / `sta_order`: processing orders of the source nodes / stations (e.g. `morton_order(positions)`);
+        internal only, every input and output keeps the caller's order."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GenieHipError("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
@@ -124,6 +126,11 @@ class HipPath(object):
                                                _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
                                                _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
             _lib.check(rc, "genie_ctx_create")
+            if sta_order is not None and os.environ.get("GENIE_STA_ORDER", "1") != "0":
+                so = np.ascontiguousarray(np.asarray(sta_order), dtype=np.int32)
+                if so.shape != (self.n_sta,):
+                    raise ValueError("sta_order must have n_sta entries")
+                _lib.check(self.lib.genie_set_station_order(self.ctx, ctypes.c_void_p(so.ctypes.data)), "genie_set_station_order")
         self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
@@ -355,6 +362,15 @@ class HipPath(object):
         bt["turn"] ^= 1
         bt["n"] = 0
         return y, x, done
+
+    def set_static_edge_attr(self, edge_attr):
+        """Register the static edge_attr [P, 3] tensor (genie_set_static_edge_attr): with a station processing order stage 2 then
+        reads a processing-order copy whenever it is passed this same tensor. The tensor must stay alive and unchanged."""
+        if self._n_prod is not None:
+            return
+        edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
+        self._static_ea = edge_attr
+        _lib.check(self.lib.genie_set_static_edge_attr(self.ctx, _ptr(edge_attr), _stream()), "genie_set_static_edge_attr")
 
     def wait_tails(self, stream=None):
         """Make `stream` (default: the current one) wait for every window tail issued so far by `forward_pipelined`."""

@@ -650,9 +650,10 @@ class GCN_Detection_Network_extended(nn.Module):
     # ---- graphs --------------------------------------------------------------------------------
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         order = _engine.morton_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
+        sta_order = _engine.morton_order(pos_loc.detach().cpu().numpy()) if pos_loc is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
-                                    device=dev)
+                                    device=dev, sta_order=sta_order)
         self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
@@ -691,6 +692,7 @@ class GCN_Detection_Network_extended(nn.Module):
             raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
+        self._hip.set_static_edge_attr(self._edge_attr)
         dev = self._edge_attr.device
         self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
 
@@ -726,6 +728,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self._build_engine(_engine.csr_from_edges(A_sta_sta, n_sta), _engine.csr_from_edges(A_src_src, n_grid),
                            n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
+        self._hip.set_static_edge_attr(self._edge_attr)
 
     # ---- hot path ------------------------------------------------------------------------------
     def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):

@@ -74,6 +74,18 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
                               const int32_t* p_src_rowptr, const int32_t* p_src_col, const int32_t* seg_rowptr,
                               const int32_t* src_rowptr, const int32_t* src_col, const int32_t* grid_order, float scale_rel);
 int genie_ctx_destroy(genie_ctx* ctx);
+/* Optional station processing order: `order` (HOST pointer, n_sta int32, a permutation; typically the stations sorted along a
+ * space-filling curve) = the caller's station id of the i-th station processed. A tile of the P-sized kernels is 16 consecutive
+ * stations of one source node, and a station's neighbours are its nearest stations: with spatially sorted stations the rows a
+ * tile gathers are shared between its lanes and adjacent in memory (config 2: stage 2 -6 %, config 4 with 2000 stations: whole
+ * path -10 %). Purely internal: every input and output keeps the caller's station order (the split rows, c / wu / wv live in
+ * processing order inside the workspace; genie_ws_export un-permutes). Honoured by the bf16x3 stage 1 + pipelined stage 2
+ * pair on Cartesian product graphs, ignored otherwise; NULL = off. All ranks of a sharded run must pass the same order. */
+int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
+/* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
+ * function of the geometry only); the library keeps a processing-order copy and uses it in every stage-2 call that is passed
+ * this same pointer. Call again if the contents change; NULL unregisters. No-op without a station order. */
+int genie_set_static_edge_attr(genie_ctx* ctx, const float* edge_attr, void* stream);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
  * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists several times; `slot` (0..15) selects the copy
  * used by the calls issued next (16 copies of the G-sized buffers; the P-sized rows have 4, indexed slot % 4). With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window

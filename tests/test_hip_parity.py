@@ -548,12 +548,12 @@ def test_sharded_kernels_two_virtual_ranks_match_unsharded():
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
     # unsharded reference run
     hp = engine.HipPath(S, G, sta_csr, engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
-                        grid_order=engine.morton_order(geom.x_grid), device=DEV)
+                        grid_order=engine.morton_order(geom.x_grid), device=DEV, sta_order=engine.morton_order(geom.locs))
     hp.set_weights(wd)
     out_ref, xl_ref, bip_ref = hp.path_fwd(Slice.to(DEV), Mask.to(DEV), ea.to(DEV), pos.to(DEV), True, True)
-    # two virtual ranks
+    # two virtual ranks (same station processing order: the per-tile station sums then add in the same order)
     W = 2
-    ranks = [gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, W, r, DEV) for r in range(W)]
+    ranks = [gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, W, r, DEV, pos_sta=geom.locs) for r in range(W)]
     rows = []
     for sp in ranks:
         sp.set_weights(wd)
@@ -833,3 +833,37 @@ def test_training_mode_four_output_forward_gradients_match_oracle_autograd():
         assert max_abs(p.grad.cpu(), w[k].grad) <= tol, (k, max_abs(p.grad.cpu(), w[k].grad), tol)
         checked += 1
     assert checked >= 130
+
+
+@pytest.mark.parametrize("S,G", [(37, 90), (200, 300)])
+def test_station_processing_order_is_internal_only(S, G):
+    """genie_set_station_order: with the stations processed in a different (space-filling-curve, or random) order every input and
+    output keeps the caller's station order — h0 / h1 / c / wu / wv exports, x_latent, the Bipartite output and the path output
+    agree with the run in the caller's order to fp32 summation error; a registered static edge_attr gives the same result as an
+    unregistered one; bad permutations are rejected."""
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=10, seed=S)
+    win = synthetic.make_window(geom, 30 * S, seed=S + 1)
+    wd = {k: v.to(DEV) for k, v in Case("cfg1_20x500").weights.items()}
+    Slice, Mask = torch.from_numpy(win["Slice"]).to(DEV), torch.from_numpy(win["Mask"]).to(DEV)
+    ea, pos = torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV)
+    sta = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
+    src = engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G)
+
+    def run(order, register):
+        hp = engine.HipPath(S, G, sta, src, grid_order=engine.morton_order(geom.x_grid), device=DEV, sta_order=order)
+        hp.set_weights(wd)
+        if register:
+            hp.set_static_edge_attr(ea)
+        dbg = hp.da_stage1(Slice, Mask, debug=True)[2:]
+        exports = [hp.export(k) for k in (0, 1, 2)]
+        out, xl, bip = hp.path_fwd(Slice, Mask, ea, pos, True, True)
+        return list(dbg) + exports + [out, xl, bip]
+
+    base = run(None, False)
+    rng = np.random.default_rng(S)
+    for order, register in ((engine.morton_order(geom.locs), True), (engine.morton_order(geom.locs), False), (rng.permutation(S), True)):
+        got = run(order, register)
+        for a, b in zip(base, got):
+            assert a.shape == b.shape and max_abs(a, b) <= 2e-6 * max(1.0, float(a.abs().max()))
+    with pytest.raises(Exception):
+        engine.HipPath(S, G, sta, src, device=DEV, sta_order=np.zeros(S, dtype=np.int64))

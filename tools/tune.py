@@ -40,7 +40,8 @@ def main():
     ref = None
     # the clocks take ~1 s of sustained load to settle: the first spec measured cold reads 5-10 % slow (this bit us:
     # SEG=512 looked better than SEG=1 only because SEG=1 was measured first). Warm up, and repeat specs when in doubt.
-    hp0 = engine.HipPath(S, G, sta, src, grid_order=order, device=dev)
+    sta_order = engine.morton_order(geom.locs) if os.environ.get("TUNE_STAORDER") else None   # internal station processing order
+    hp0 = engine.HipPath(S, G, sta, src, grid_order=order, device=dev, sta_order=sta_order)
     hp0.set_weights(w)
     for _ in range(600 if S * G < 10000000 else 12):
         hp0.da_stage1(Slice, Mask)
@@ -51,8 +52,11 @@ def main():
         for kv in spec.split(","):
             k, v = kv.split("=")
             os.environ["GENIE_" + k] = v
-        hp = engine.HipPath(S, G, sta, src, grid_order=order if os.environ.get("GENIE_ORDER", "morton") == "morton" else None, device=dev)
+        hp = engine.HipPath(S, G, sta, src, grid_order=order if os.environ.get("GENIE_ORDER", "morton") == "morton" else None, device=dev,
+                            sta_order=sta_order)
         hp.set_weights(w)
+        if sta_order is not None:
+            hp.set_static_edge_attr(ea)
         ts = {k: [] for k in ("s0", "s1", "s2", "rest")}
         for i in range(32):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
