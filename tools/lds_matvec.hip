@@ -2,7 +2,7 @@
 //   A: w ds_read_b32 + x ds_read_b32 (broadcast)      B: w b32 + x as one broadcast ds_read_b128 per 4 k
 //   C: w b32 + x via __shfl (ds_bpermute)              D: w b32 only (x in registers: lower bound)
 //   E: w b32 + x of the wave's two nodes via v_readlane x 2 + select (no LDS for x)
-// hipcc --offload-arch=gfx950 -O3 tools/lds_matvec.hip -o /tmp/lds_matvec && /tmp/lds_matvec
+// hipcc --offload-arch=gfx950 -O3 tools/lds_matvec.hip -o tools/lds_matvec.bin && ./tools/lds_matvec.bin   (*.bin is git-ignored)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
