@@ -2451,7 +2451,7 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
     float* qry = w_pr + (MODE == 0 ? 0 : 15 * 32);         // [RO_TMAX][96]
     float* scr = qry + RO_TMAX * 96;                       // per-group scratch
-    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96 + (MODE == 1 ? RO_K * 80 : 0);   // floats per group
+    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;   // floats per group
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
     float* h1 = xin + 40;                // [32]
@@ -2462,7 +2462,6 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     float* zs = scs + 48;                // [T][16]
     float* prd = zs + RO_TMAX * 16;      // [96]  q*c products / aggregated values (MODE 1)
     float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
-    float* vst = als + 96;               // [10][80] per-edge value embeddings (MODE 1)
 
     {   // static weights: one linear copy of the pre-transposed image (same layout as the carve above)
         constexpr int NIMG = (MODE == 0 ? RO_IMG0 : RO_IMG1) / 4;
@@ -2495,6 +2494,17 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     const float b_v2[3] = {a.raw[a.o_v2b + c], a.raw[a.o_v2b + 32 + c], c < 11 ? a.raw[a.o_v2b + 64 + c] : 0.f};
     const float b_p1 = c < 30 ? a.raw[a.o_p1b + c] : 0.f, b_p2 = a.raw[a.o_p2b];
     const float inv_sqrt_l = 1.f / sqrtf(15.f);
+    // MODE 1: the edge-attribute columns of f_queries / f_context / f_values (3 inputs -> 3 x 32 outputs per lane) stay in
+    // registers for every neighbour of every query
+    float wqe[3][3], wce[3][3], wve[3][3];
+    if (MODE == 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                wqe[d][m] = w_x0[d * 96 + 32 * m + c]; wce[d][m] = w_fc[d * 96 + 32 * m + c]; wve[d][m] = w_fv[d * 96 + 32 * m + c];
+            }
+    }
 
     for (int n0 = blockIdx.x * NG; n0 < a.N; n0 += gridDim.x * NG) {
         const int n = n0 + grp;
@@ -2518,24 +2528,21 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
             const float bv[3] = {a.raw[a.o_sv_b + c], a.raw[a.o_sv_b + 32 + c], c < 11 ? a.raw[a.o_sv_b + 64 + c] : 0.f};
             const int wq = nc / a.Nw, nl = nc - wq * a.Nw;
             const float* cvw = a.cv + wq * a.cv_ws;
+            const float xq0 = a.x_query[nl * 3 + 0], xq1 = a.x_query[nl * 3 + 1], xq2 = a.x_query[nl * 3 + 2];
 #pragma unroll 1
             for (int k = 0; k < RO_K; ++k) {
                 const int jn = a.knn[(long long)nl * RO_K + k];
-                float e[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) e[d] = (a.x_query[nl * 3 + d] - a.x_grid[jn * 3 + d]) / a.scale_rel;           // :283
+                const float e[3] = {(xq0 - a.x_grid[jn * 3 + 0]) / a.scale_rel, (xq1 - a.x_grid[jn * 3 + 1]) / a.scale_rel,
+                                    (xq2 - a.x_grid[jn * 3 + 2]) / a.scale_rel};                                            // :283
                 const float* cvj = cvw + (long long)jn * CVP;
                 float q3[3] = {bq[0], bq[1], bq[2]};
                 float c3[3] = {bc[0] + cvj[c], bc[1] + cvj[32 + c], bc[2] + (c < 16 ? cvj[64 + c] : 0.f)};
-                float v3[3] = {bv[0] + cvj[80 + c], bv[1] + cvj[112 + c], bv[2] + (c < 16 ? cvj[144 + c] : 0.f)};
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    q3[0] += w_x0[d * 96 + c] * e[d]; q3[1] += w_x0[d * 96 + 32 + c] * e[d]; q3[2] += w_x0[d * 96 + 64 + c] * e[d];
-                    c3[0] += w_fc[d * 96 + c] * e[d]; c3[1] += w_fc[d * 96 + 32 + c] * e[d]; c3[2] += w_fc[d * 96 + 64 + c] * e[d];
-                    v3[0] += w_fv[d * 96 + c] * e[d]; v3[1] += w_fv[d * 96 + 32 + c] * e[d]; v3[2] += w_fv[d * 96 + 64 + c] * e[d];
+                    q3[0] += wqe[d][0] * e[d]; q3[1] += wqe[d][1] * e[d]; q3[2] += wqe[d][2] * e[d];
+                    c3[0] += wce[d][0] * e[d]; c3[1] += wce[d][1] * e[d]; c3[2] += wce[d][2] * e[d];
                 }
                 prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
-                vst[k * 80 + c] = v3[0]; vst[k * 80 + 32 + c] = v3[1]; if (c < 16) vst[k * 80 + 64 + c] = v3[2];
                 GSYNC();
                 if (c < 5) {                                                            // alpha = PReLU1(sum_l q*c / sqrt(L))  :293
                     float sdot = 0.f;
@@ -2557,13 +2564,22 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
             }
             GSYNC();
             {
+                // 'add' aggregation of alpha * v  :264,297. The value embeddings are recomputed here (3 row chunks + 9 FMAs per
+                // edge) instead of being parked in LDS during the logit pass: 3.2 KB less scratch per query = more queries per CU
                 const int hd0 = c / 15, hd1 = (32 + c) / 15, hd2 = min((64 + c) / 15, 4);
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f;                                     // 'add' aggregation of alpha * v  :264,297
-#pragma unroll
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll 2
                 for (int k = 0; k < RO_K; ++k) {
-                    g0 += als[k * 8 + hd0] * vst[k * 80 + c];
-                    g1 += als[k * 8 + hd1] * vst[k * 80 + 32 + c];
-                    g2 += als[k * 8 + hd2] * (c < 16 ? vst[k * 80 + 64 + c] : 0.f);
+                    const int jn = a.knn[(long long)nl * RO_K + k];
+                    const float e[3] = {(xq0 - a.x_grid[jn * 3 + 0]) / a.scale_rel, (xq1 - a.x_grid[jn * 3 + 1]) / a.scale_rel,
+                                        (xq2 - a.x_grid[jn * 3 + 2]) / a.scale_rel};
+                    const float* cvj = cvw + (long long)jn * CVP;
+                    float v3[3] = {bv[0] + cvj[80 + c], bv[1] + cvj[112 + c], bv[2] + (c < 16 ? cvj[144 + c] : 0.f)};
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { v3[0] += wve[d][0] * e[d]; v3[1] += wve[d][1] * e[d]; v3[2] += wve[d][2] * e[d]; }
+                    g0 += als[k * 8 + hd0] * v3[0];
+                    g1 += als[k * 8 + hd1] * v3[1];
+                    g2 += als[k * 8 + hd2] * (c < 16 ? v3[2] : 0.f);
                 }
                 prd[c] = g0; prd[32 + c] = g1; prd[64 + c] = g2;
             }
@@ -3820,9 +3836,9 @@ constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;
 // node groups (of 32 lanes) per workgroup. "fat": many groups share one weight image (best standalone latency);
 // "slim": <= 52 KB of LDS so that a read-out workgroup co-resides with two k_stage1_fast workgroups (2 x 54 KB) when the
 // G-sized tail of window i runs on a side stream under the P-sized kernels of window i+1 (genie_set_tail_mode).
-constexpr int RO_NG0 = 24, RO_NG1 = 16, RO_NG0_SLIM = 4, RO_NG1_SLIM = 2;
+constexpr int RO_NG0 = 24, RO_NG1 = 20, RO_NG0_SLIM = 4, RO_NG1_SLIM = 2;   // NG1 = 20: 10 000 queries = 1.95 rounds of 256 x 20
 constexpr size_t ro_lds(int mode, int ng) {
-    return sizeof(float) * ((mode == 0 ? RO_IMG0 : RO_IMG1) + RO_TMAX * 96 + ng * (RO_SCR + (mode == 1 ? RO_K * 80 : 0)));
+    return sizeof(float) * ((mode == 0 ? RO_IMG0 : RO_IMG1) + RO_TMAX * 96 + ng * RO_SCR);
 }
 }  // namespace
 

@@ -22,6 +22,7 @@ xq, tq = torch.from_numpy(geom.x_query).float().to(dev), torch.from_numpy(geom.t
 hp = net._hip
 NB = int(os.environ.get("NB", "8"))
 with torch.no_grad():
+    net.window_batch = NB
     for _ in range(NB):
         net.push_window(Slice, Mask)
     y, x, ev = net.flush_windows(xg, xq, tq)
