@@ -1262,6 +1262,34 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
     }
 }
 
+// Same with a station processing order, one workgroup per source node: the node's S rows are read in the caller's order
+// (coalesced), staged in LDS, and written in processing order (coalesced); S <= SPLIT_G_MAXS rows fit the 64-KB staging buffer.
+constexpr int SPLIT_G_MAXS = 2048;
+__global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
+                                                      unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
+                                                      float* __restrict__ mm) {
+    extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
+    const long long base = (long long)blockIdx.x * S;
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        *(f32x4*)(stg + r * 8) = *(const f32x4*)(slice + (base + r) * 4);
+        *(f32x4*)(stg + r * 8 + 4) = *(const f32x4*)(mask + (base + r) * 4);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        const int u = sta_user[r];
+        const f32x4 s = *(const f32x4*)(stg + u * 8), m = *(const f32x4*)(stg + u * 8 + 4);
+        mm[base + r] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+        const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
+            *(u32x4*)(out + (base + r) * (XROW / 4) + piece * 4) = o;
+        }
+    }
+}
+
 // registers 8ks..8ks+7 of an accumulator block -> the three bf16x8 pieces of one B operand
 template <int KS_>
 __device__ __forceinline__ void split8(const f32x16& v, u32x4 (&p)[3]) {
@@ -3616,8 +3644,15 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         const bool presplit = c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws;     // genie_embed_window_split, one-shot
         c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
-        if (!presplit) k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs, sta_order_on(c) ? c->sta_perm : nullptr, c->S,
-                                                                                        (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride);
+        if (!presplit) {
+            float* mmw = (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
+            if (sta_order_on(c) && c->S <= SPLIT_G_MAXS) {
+                HIP_TRY(hipFuncSetAttribute((const void*)k_split_rows_g, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_G_MAXS * 32));
+                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw);
+            } else
+                k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs,
+                                                                                sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
+        }
         a.xs = xs; a.packed = c->packed_b3;
         const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
