@@ -127,12 +127,12 @@ class ShardedPath(object):
         from . import engine
         self.group = group
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
-        order = engine.morton_order(np.asarray(pos_global))
+        order = engine.sfc_order(np.asarray(pos_global))
         self.plan = ShardPlan(A_src_src, n_grid, world, rank, order)
         p = self.plan
         self.local = engine.HipPath(n_sta, p.n_own, sta_csr, (torch.from_numpy(p.src_rowptr), torch.from_numpy(p.src_col)),
                                     n_grid_ext=p.n_ext, grid_order=None, scale_rel=scale_rel, device=device,
-                                    sta_order=engine.morton_order(np.asarray(pos_sta)) if pos_sta is not None else None)
+                                    sta_order=engine.sfc_order(np.asarray(pos_sta)) if pos_sta is not None else None)
         self.full = engine.HipPath(1, n_grid, (torch.zeros(2, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)),
                                    engine.csr_from_edges(torch.as_tensor(A_src_src), n_grid), grid_order=None,
                                    scale_rel=scale_rel, device=device)

@@ -57,11 +57,24 @@ def csr_from_table(nbr):
     return rowptr, nbr.reshape(-1).contiguous()
 
 
-def morton_order(points):
-    """Space-filling-curve (Morton, 10 bits/axis) order of a point set: int32 permutation [n]."""
+def _quantise_isotropic(points, bits):
+    """All axes on the SAME scale: stations (elevations of +-1 km over a 300-km network) and source grids (40 km of depth) are
+    nearly flat, and a per-axis scale lets the noise of the short axis decide the order (median index distance of a station to
+    its neighbours 65 instead of 5 of 200; distinct neighbour rows per 16-station tile 61 instead of 39)."""
     x = np.asarray(points, dtype=np.float64)
+    if x.ndim != 2 or x.shape[1] != 3:
+        raise ValueError("positions must be [n, 3]")
     lo, hi = x.min(0), x.max(0)
-    q = np.clip(((x - lo) / np.maximum(hi - lo, 1e-9) * 1023.0).astype(np.int64), 0, 1023)
+    top = float((1 << bits) - 1)
+    scale = top / max(float((hi - lo).max()), 1e-9)
+    if os.environ.get("GENIE_MORTON_PER_AXIS") == "1":      # A/B: the earlier per-axis quantisation
+        scale = top / np.maximum(hi - lo, 1e-9)
+    return np.clip(((x - lo) * scale).astype(np.int64), 0, (1 << bits) - 1)
+
+
+def morton_order(points):
+    """Morton (Z-curve, 10 bits on the longest axis) order of a point set: int32 permutation [n]."""
+    q = _quantise_isotropic(points, 10)
 
     def spread(v):
         v = (v | (v << 16)) & 0x030000FF
@@ -72,6 +85,45 @@ def morton_order(points):
 
     code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
     return np.argsort(code, kind="stable").astype(np.int32)
+
+
+def hilbert_order(points, bits=10):
+    """Hilbert-curve order of a point set (Skilling's axes-to-transpose transform, vectorised over the points): int32 permutation
+    [n]. No long jumps like the Z-curve has at its quadrant boundaries: 9 % fewer distinct neighbour rows per block of 64 source
+    nodes than `morton_order` on the synthetic 10 000-node grid, but no faster end to end (see `sfc_order`)."""
+    X = _quantise_isotropic(points, bits).T.copy()          # [3, n]
+    n = X.shape[0]
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for i in range(n):
+            hit = (X[i] & Q) != 0
+            X[0] = np.where(hit, X[0] ^ P, X[0])
+            t = np.where(hit, 0, (X[0] ^ X[i]) & P)
+            X[0] ^= t
+            X[i] ^= t
+        Q >>= 1
+    for i in range(1, n):
+        X[i] ^= X[i - 1]
+    t = np.zeros_like(X[0])
+    Q = M
+    while Q > 1:
+        t = np.where((X[n - 1] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    for i in range(n):
+        X[i] ^= t
+    code = np.zeros(X.shape[1], dtype=np.int64)
+    for b in range(bits - 1, -1, -1):
+        for i in range(n):
+            code = (code << 1) | ((X[i] >> b) & 1)
+    return np.argsort(code, kind="stable").astype(np.int32)
+
+
+def sfc_order(points):
+    """The processing order used for source nodes and stations: the Z-curve (measured at config 2: 0.781 ms/window against
+    0.785 with the Hilbert curve; config 4: 42.1 against 41.7 ms; GENIE_SFC=hilbert selects the latter)."""
+    return hilbert_order(points) if os.environ.get("GENIE_SFC") == "hilbert" else morton_order(points)
 
 
 class HipPath(object):
@@ -85,7 +137,7 @@ class HipPath(object):
                  device=None, subgraph=None, sta_order=None):
         """`subgraph` = dict(n_prod, sta_csr, src_csr, seg_rowptr): an irregular product graph (`use_subgraph`) given as
         product-level CSRs + the row range of every source node (genie_ctx_create_subgraph); `sta_csr` is then ignored.
-        `grid_order` / `sta_order`: processing orders of the source nodes / stations (e.g. `morton_order(positions)`);
+        `grid_order` / `sta_order`: processing orders of the source nodes / stations (e.g. `sfc_order(positions)`);
         internal only, every input and output keeps the caller's order."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():

@@ -649,8 +649,8 @@ class GCN_Detection_Network_extended(nn.Module):
 
     # ---- graphs --------------------------------------------------------------------------------
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
-        order = _engine.morton_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
-        sta_order = _engine.morton_order(pos_loc.detach().cpu().numpy()) if pos_loc is not None else None
+        order = _engine.sfc_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
+        sta_order = _engine.sfc_order(pos_loc.detach().cpu().numpy()) if pos_loc is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev, sta_order=sta_order)
@@ -710,7 +710,7 @@ class GCN_Detection_Network_extended(nn.Module):
         seg[1:] = torch.cumsum(torch.bincount(src_of, minlength=n_grid), 0).to(torch.int32)
         sub = {"n_prod": n_prod, "sta_csr": _engine.csr_from_edges(A_in_sta, n_prod),
                "src_csr": _engine.csr_from_edges(A_in_src, n_prod), "seg_rowptr": seg}
-        order = _engine.morton_order(pos_src.detach().cpu().numpy())
+        order = _engine.sfc_order(pos_src.detach().cpu().numpy())
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)

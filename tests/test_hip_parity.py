@@ -548,7 +548,7 @@ def test_sharded_kernels_two_virtual_ranks_match_unsharded():
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
     # unsharded reference run
     hp = engine.HipPath(S, G, sta_csr, engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
-                        grid_order=engine.morton_order(geom.x_grid), device=DEV, sta_order=engine.morton_order(geom.locs))
+                        grid_order=engine.sfc_order(geom.x_grid), device=DEV, sta_order=engine.sfc_order(geom.locs))
     hp.set_weights(wd)
     out_ref, xl_ref, bip_ref = hp.path_fwd(Slice.to(DEV), Mask.to(DEV), ea.to(DEV), pos.to(DEV), True, True)
     # two virtual ranks (same station processing order: the per-tile station sums then add in the same order)

@@ -21,7 +21,7 @@ def main():
     dev = "cuda:0"
     hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
                         engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
-                        grid_order=engine.morton_order(geom.x_grid), device=dev, sta_order=engine.morton_order(geom.locs))
+                        grid_order=engine.sfc_order(geom.x_grid), device=dev, sta_order=engine.sfc_order(geom.locs))
     hp.set_weights({k: v.to(dev) for k, v in Case("cfg1_20x500").weights.items()})
     Slice, Mask = torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev)
     ea, pos = torch.from_numpy(geom.edge_attr()).to(dev), torch.from_numpy(geom.x_grid).float().to(dev)

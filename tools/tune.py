@@ -24,7 +24,7 @@ def main():
     w = {k: v.to(dev) for k, v in Case("cfg1_20x500").weights.items()}
     A_sta = geom.A_sta_sta
     if os.environ.get("TUNE_STAPERM"):          # experiment: relabel the stations along a space-filling curve
-        perm = engine.morton_order(geom.locs)
+        perm = engine.sfc_order(geom.locs)
         perm = np.asarray(perm, dtype=np.int64)          # new index -> old station
         inv = np.empty(S, dtype=np.int64); inv[perm] = np.arange(S)
         A_sta = inv[A_sta]
@@ -36,11 +36,11 @@ def main():
         ea = ea.view(G, S, 3)[:, idx].reshape(G * S, 3).contiguous()
     sta = engine.csr_from_edges(torch.from_numpy(A_sta), S)
     src = engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G)
-    order = engine.morton_order(geom.x_grid)
+    order = engine.sfc_order(geom.x_grid)
     ref = None
     # the clocks take ~1 s of sustained load to settle: the first spec measured cold reads 5-10 % slow (this bit us:
     # SEG=512 looked better than SEG=1 only because SEG=1 was measured first). Warm up, and repeat specs when in doubt.
-    sta_order = engine.morton_order(geom.locs) if os.environ.get("TUNE_STAORDER") else None   # internal station processing order
+    sta_order = engine.sfc_order(geom.locs) if os.environ.get("TUNE_STAORDER") else None   # internal station processing order
     hp0 = engine.HipPath(S, G, sta, src, grid_order=order, device=dev, sta_order=sta_order)
     hp0.set_weights(w)
     for _ in range(600 if S * G < 10000000 else 12):
