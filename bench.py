@@ -43,8 +43,8 @@ F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 
 # bf16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
 BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
-# profiles/r01_j_pmc_stage_kernels.txt (k_split_rows + k_stage1_b3): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024
-S1_TRAFFIC_CFG2 = (2.0 * (3.779e5 + 4.969e4) + (5.041e5 + 1.018e5)) * 1024.0
+# profiles/r01_k_pmc_stage_kernels.txt (k_split_rows + k_stage1_b3): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024
+S1_TRAFFIC_CFG2 = (2.0 * (2.481e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -380,10 +380,10 @@ def main():
         # kernel gets past what fp32 MFMAs can deliver by running exact 3-way bf16 splits on the bf16 matrix pipe; the
         # bf16 FLOPs it really executes are reported next to the bf16 peak.
         # traffic: HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> B), measured on this
-        # exact workload and committed as profiles/r01_j_pmc_stage_kernels.txt; null for other workloads
+        # exact workload and committed as profiles/r01_k_pmc_stage_kernels.txt; null for other workloads
         traffic = S1_TRAFFIC_CFG2 if a.config == "cfg2_200x10k" else None
         exec_tf = BF16_EXEC_FLOP_NODE * P / (kms[dom] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_stage1_b3 (+ k_split_rows)", "achieved": round(dom_tf, 2),
+        roofline = {"bound": "mfma", "kernel": "k_stage1_b3 (+ k_split_rows_g)", "achieved": round(dom_tf, 2),
                     "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4),
                     "traffic": traffic,
                     "executed": {"bf16_tflops": round(exec_tf, 1), "bf16_peak": BF16_MFMA_PEAK_TF,
