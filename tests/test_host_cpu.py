@@ -179,3 +179,26 @@ def test_readout_heads_match_oracle_cpu():
         assert float((y - c.ref("y")).abs().max()) < 1e-6
         assert float((xq - c.ref("xq")).abs().max()) < 2e-6
         assert float((x - c.ref("x")).abs().max()) < 1e-6
+
+
+def test_space_filling_curve_orders():
+    """engine.morton_order / hilbert_order / sfc_order: permutations; one common scale for all axes (a nearly flat point set is
+    ordered by its two long axes, not by the noise of the short one); on a full lattice consecutive Hilbert points are lattice
+    neighbours."""
+    import numpy as np
+    from genie_amd import engine
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(0, 300e3, 500), rng.uniform(0, 300e3, 500), rng.uniform(-1e3, 1e3, 500)], axis=1)
+    for f in (engine.morton_order, engine.hilbert_order, engine.sfc_order):
+        p = np.asarray(f(pts))
+        assert p.dtype == np.int32 and sorted(p.tolist()) == list(range(500))
+    flat = pts.copy()
+    flat[:, 2] = 0.0
+    for f in (engine.morton_order, engine.hilbert_order):
+        a, b = np.asarray(f(pts)), np.asarray(f(flat))
+        assert (a == b).mean() > 0.9          # +-1 km of elevation over 300 km moves (almost) nothing
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), axis=-1).reshape(-1, 3).astype(float)
+    h = g[np.asarray(engine.hilbert_order(g, bits=3))]
+    assert np.all(np.abs(np.diff(h, axis=0)).sum(1) == 1)
+    with pytest.raises(ValueError):
+        engine.morton_order(np.zeros((5, 2)))
