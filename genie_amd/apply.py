@@ -6,8 +6,10 @@ Semantics kept from the reference:
 * window starts `tsteps = arange(max(0, min(pick_t) - max_t), min(day_len, max(pick_t)), step)`, `step` and `n_overlap`
   from `step_size` in {'full', 'partial', 'half'} (`:367-381, :571`);
 * windows with fewer than `min_required_picks` picks in `[t0 - t_win, t0 + max_t + t_win]` are skipped (`:725-741`);
-* `Out_2[:, idx(t0 + offsets)] += x[:, :, 0] / n_overlap / n_grids`, dropping the last offset when `step_size == 'half'`
-  (`:802-805`).
+* `Out_2[:, idx(tsteps_abs[idx(t0)] + offsets)] += x[:, :, 0] / n_overlap / n_grids`, dropping the last offset when
+  `step_size == 'half'` (`:766, :797-805`): the window start is snapped to `tsteps_abs` first, and a column listed twice is
+  written once (numpy fancy `+=`), see `window_columns`;
+* windows with no pick in the embedding range are skipped (`:792-793`).
 Differences by design: `Out_2` stays on the GPU and is accumulated with `index_add_` (the reference copies every window's
 output to the host, `:803-805`); nothing in the loop synchronises with the host.
 
@@ -49,6 +51,29 @@ def windows_with_enough_picks(pick_times, tsteps, max_t, t_win, min_required_pic
     return tsteps[n >= max(1, int(min_required_picks))]
 
 
+def window_columns(tsteps_abs, t0, offsets, drop_last):
+    """Columns of `Out_2` one window adds to, as process_continuous_days.py:766,797-805 finds them: the window start is first
+    SNAPPED to its nearest `tsteps_abs` entry (`tree_tsteps.query`, :766), the nine offsets are added to that entry and
+    looked up again (:797), the last one is dropped for step_size 'half' (:802-803). numpy's `Out_2[:, cols] += vals` writes
+    a column that appears twice only once (the LAST occurrence wins), so duplicates are reduced to their last occurrence.
+    Returns (cols int64 [m], keep int64 [m]: offset index feeding each column)."""
+    tsteps_abs = np.asarray(tsteps_abs, dtype=np.float64)
+    i0 = int(np.abs(tsteps_abs - t0).argmin())
+    ip = np.abs(tsteps_abs.reshape(-1, 1) - (tsteps_abs[i0] + np.asarray(offsets)).reshape(1, -1)).argmin(0)
+    if drop_last:
+        ip = ip[:-1]
+    keep = np.array([k for k in range(len(ip)) if ip[k] not in ip[k + 1:]], dtype=np.int64)
+    return ip[keep].astype(np.int64), keep
+
+
+def picks_in_embed_range(pick_times_sorted, t0, max_t, kernel_sig_t):
+    """[lo, hi) of the picks with t0 - 2 sigma < t < t0 + max_t + 2 sigma (process_utils.py:476); the reference skips a window
+    whose range is empty (process_continuous_days.py:792-793)."""
+    lo = int(np.searchsorted(pick_times_sorted, t0 - 2.0 * kernel_sig_t, side="right"))
+    hi = int(np.searchsorted(pick_times_sorted, t0 + max_t + 2.0 * kernel_sig_t, side="left"))
+    return lo, hi
+
+
 def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1, n_grids=1.0,
                   day_len=86400.0, device=None, embed=None):
     """Run `net.forward_fixed_source` over every kept window and stack the query read-out into `Out_2[Q, len(tsteps_abs)]`.
@@ -69,17 +94,19 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
     tq = torch.from_numpy(offsets.reshape(-1, 1)).float().to(dev)
     embed = embed or (lambda picks, t0: synthetic.make_slice_mask(geom, picks, t0))
     drop_last = step_size == "half"
+    used = []
     with torch.no_grad():
         for t0 in times:
             sel = (P[:, 0] > t0 - 2.0 * synthetic.KERNEL_SIG_T) & (P[:, 0] < t0 + max_t + 2.0 * synthetic.KERNEL_SIG_T)  # process_utils.py:476
+            if not sel.any():
+                continue                                                      # process_continuous_days.py:792-793
+            used.append(t0)
             Slice, Mask = embed(P[sel], t0)
             y, x = net.forward_fixed_source(torch.from_numpy(Slice).to(dev), torch.from_numpy(Mask).to(dev), None, None, None,
                                             locs, xg, xq, tq)
-            ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)   # nearest index, tree_tsteps.query
-            cols = torch.from_numpy(ip[:-1] if drop_last else ip).to(dev)
-            vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
-            Out_2.index_add_(1, cols, vals / (n_overlap * n_grids))
-    return Out_2, times
+            cols, keep = window_columns(tsteps_abs, t0, offsets, drop_last)
+            Out_2.index_add_(1, torch.from_numpy(cols).to(dev), x[:, torch.from_numpy(keep).to(dev), 0] / (n_overlap * n_grids))
+    return Out_2, np.asarray(used)
 
 
 def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1,
@@ -98,6 +125,7 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
         tsteps_abs = np.arange(tsteps.min() - t_win / 2.0, tsteps.max() + t_win / 2.0 + dt_win, dt_win)
     if times is None:
         times = windows_with_enough_picks(P[:, 0], tsteps, max_t, t_win, min_required_picks)
+    times = np.asarray(times, dtype=np.float64)
     order = np.argsort(P[:, 0], kind="stable")
     Ps = P[order]
     d_t = torch.from_numpy(Ps[:, 0].copy()).to(dev)
@@ -113,9 +141,22 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     # per-window pick ranges and Out_2 column indices are host arithmetic on tiny arrays, done up front
     lo = np.searchsorted(Ps[:, 0], times - 2.0 * kernel_sig_t, side="right")                      # strict >, process_utils.py:476
     hi = np.searchsorted(Ps[:, 0], times + max_t + 2.0 * kernel_sig_t, side="left")               # strict <
-    ipn = np.abs(tsteps_abs.reshape(-1, 1, 1) - (times.reshape(1, -1, 1) + offsets.reshape(1, 1, -1))).argmin(0)
-    cols = torch.from_numpy(ipn[:, :-1] if drop_last else ipn).to(dev)
+    nonempty = hi > lo                                                                             # process_continuous_days.py:792-793
+    times, lo, hi = times[nonempty], lo[nonempty], hi[nonempty]
+    wc = [window_columns(tsteps_abs, t0, offsets, drop_last) for t0 in times]
+    n_off = len(offsets) - (1 if drop_last else 0)
+    if all(len(k) == n_off for _, k in wc):            # the usual case: no duplicate column inside a window
+        cols = torch.from_numpy(np.stack([c_ for c_, _ in wc]) if wc else np.zeros((0, n_off), dtype=np.int64)).to(dev)
+        keeps = None
+    else:
+        cols = [torch.from_numpy(c_).to(dev) for c_, _ in wc]
+        keeps = [torch.from_numpy(k_).to(dev) for _, k_ in wc]
     acc_done = [None]
+
+    def window_vals(xw, w):             # xw [Q, T, 1] of window w -> the kept offsets
+        if keeps is not None:
+            return xw[:, keeps[w], 0]
+        return xw[:, :-1, 0] if drop_last else xw[:, :, 0]
 
     def flush(first):
         # tail + read-outs of the pushed windows in one set of launches on a side stream; the accumulation into Out_2 follows
@@ -125,8 +166,7 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
             if acc_done[0] is not None:
                 hp.side_stream.wait_event(acc_done[0])
             for k in range(x.shape[0]):
-                vals = x[k, :, :-1, 0] if drop_last else x[k, :, :, 0]
-                Out_2.index_add_(1, cols[first + k], vals / (n_overlap * n_grids))
+                Out_2.index_add_(1, cols[first + k], window_vals(x[k], first + k) / (n_overlap * n_grids))
             acc_done[0] = torch.cuda.Event()
             acc_done[0].record(hp.side_stream)
 
@@ -141,8 +181,7 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
                 with torch.cuda.stream(hp.side_stream):
                     if acc_done[0] is not None:
                         hp.side_stream.wait_event(acc_done[0])
-                    vals = x[:, :-1, 0] if drop_last else x[:, :, 0]
-                    Out_2.index_add_(1, cols[w], vals / (n_overlap * n_grids))
+                    Out_2.index_add_(1, cols[w], window_vals(x, w) / (n_overlap * n_grids))
                     acc_done[0] = torch.cuda.Event()
                     acc_done[0].record(hp.side_stream)
             elif net.push_window(Slice, Mask) == net.window_batch or w == len(times) - 1:

@@ -3067,6 +3067,7 @@ struct genie_ctx {
     float *r_sta_w, *r_src_w;
     const float *xs_slice, *xs_mask;   // genie_embed_window_split: the (Slice, Mask) buffers whose split rows already sit in the workspace (one-shot)
     const void* xs_ws;
+    int xs_mm_copy;            // ... and the copy (slot % GENIE_NBIG at embed time) its message-mask row `mm` was written to
     float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
@@ -3212,6 +3213,11 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     return a;
 }
 
+struct CtxGuard {            // destroys a partially built context on every early return of the create calls
+    genie_ctx* c;
+    ~CtxGuard() { if (c) genie_ctx_destroy(c); }
+};
+
 int check_ws(const genie_ctx* c, const void* ws) {
     if (!c) return fail(GENIE_ERR_ARG, "null context");
     if (!ws) return fail(GENIE_ERR_ARG, "null workspace");
@@ -3238,7 +3244,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     *out = nullptr;
     if (n_sta < 1 || n_grid < 1 || n_grid_ext < n_grid) return fail(GENIE_ERR_ARG, "bad n_sta / n_grid / n_grid_ext");
     if (!sta_rowptr || !src_rowptr) return fail(GENIE_ERR_ARG, "null rowptr");
-    genie_ctx* c = new genie_ctx();
+    genie_ctx* c = new genie_ctx();      // value-initialised: every pointer member starts null
+    CtxGuard guard{c};                   // every early return below destroys the partially built context
     memset((void*)&c->S, 0, sizeof(int) * 4);
     c->S = n_sta; c->G = n_grid; c->G_ext = n_grid_ext; c->T = (n_sta + 15) / 16;
     c->scale_rel = scale_rel;
@@ -3308,7 +3315,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
-    c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
+    c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; c->xs_mm_copy = 0;
     c->abs_sta = c->abs_src = nullptr;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
@@ -3408,6 +3415,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
 #endif
     layout_ws(c);
     HIP_TRY(hipDeviceSynchronize());
+    guard.c = nullptr;
     *out = c;
     return GENIE_OK;
 }
@@ -3422,23 +3430,23 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
     if (!p_sta_rowptr || !p_src_rowptr || !seg_rowptr) return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: null rowptr");
     int32_t* zeros = nullptr;       // empty base station graph: the station edges live in the product-level CSR
     HIP_TRY(hipMalloc((void**)&zeros, sizeof(int32_t) * ((size_t)n_sta + 1)));
-    HIP_TRY(hipMemset(zeros, 0, sizeof(int32_t) * ((size_t)n_sta + 1)));
     genie_ctx* c = nullptr;
-    int rc = genie_ctx_create(&c, n_sta, n_grid, n_grid, zeros, nullptr, src_rowptr, src_col, grid_order, scale_rel);
+    int rc = hipMemset(zeros, 0, sizeof(int32_t) * ((size_t)n_sta + 1)) == hipSuccess
+                 ? genie_ctx_create(&c, n_sta, n_grid, n_grid, zeros, nullptr, src_rowptr, src_col, grid_order, scale_rel)
+                 : fail(GENIE_ERR_HIP, "genie_ctx_create_subgraph: hipMemset failed");
     (void)hipFree(zeros);
     if (rc) return rc;
+    CtxGuard guard{c};
     int32_t e1 = 0, e2 = 0, last = 0;
     HIP_TRY(hipMemcpy(&e1, p_sta_rowptr + n_prod, sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&e2, p_src_rowptr + n_prod, sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&last, seg_rowptr + n_grid, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (e1 < 0 || e2 < 0 || last != (int32_t)n_prod || (e1 > 0 && !p_sta_col) || (e2 > 0 && !p_src_col)) {
-        genie_ctx_destroy(c);
         return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: inconsistent CSR arrays (seg_rowptr[n_grid] must equal n_prod)");
     }
     if ((rc = dev_copy(&c->p_sta_rowptr, p_sta_rowptr, (size_t)n_prod + 1)) || (rc = dev_copy(&c->p_sta_col, p_sta_col, (size_t)e1)) ||
         (rc = dev_copy(&c->p_src_rowptr, p_src_rowptr, (size_t)n_prod + 1)) || (rc = dev_copy(&c->p_src_col, p_src_col, (size_t)e2)) ||
         (rc = dev_copy(&c->seg_rowptr, seg_rowptr, (size_t)n_grid + 1))) {
-        genie_ctx_destroy(c);
         return rc;
     }
     c->pcsr = true;
@@ -3446,6 +3454,7 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
     c->use_fast = c->use_b3 = 0;
     c->ks_uni = c->kp_uni = -1;
     layout_ws(c);
+    guard.c = nullptr;
     *out = c;
     return GENIE_OK;
 }
@@ -3644,8 +3653,15 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         const bool presplit = c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws;     // genie_embed_window_split, one-shot
         c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
+        float* mmw = (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
+        if (presplit && sta_order_on(c) && c->xs_mm_copy != c->slot % GENIE_NBIG) {
+            // the embedding ran under another slot: its message-mask row sits in a different copy than the one stage 2 of THIS
+            // window reads (the split rows `xs` exist once). Bring it over (P_ext floats, same stream); callers avoid the copy by
+            // selecting the window's slot before they embed (engine.embed_window does).
+            HIP_TRY(hipMemcpyAsync(mmw, (const float*)ws + c->o_mm + c->xs_mm_copy * c->big_stride, sizeof(float) * (size_t)c->P_ext,
+                                   hipMemcpyDeviceToDevice, st));
+        }
         if (!presplit) {
-            float* mmw = (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
             if (sta_order_on(c) && c->S <= SPLIT_G_MAXS) {
                 HIP_TRY(hipFuncSetAttribute((const void*)k_split_rows_g, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_G_MAXS * 32));
                 k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw);
@@ -4033,7 +4049,7 @@ int genie_embed_window_split(genie_ctx* c, const double* pick_t, const int32_t* 
     unsigned* xs = c->use_b3 ? (unsigned*)((float*)ws + c->o_xs) : nullptr;
     rc = embed_window_impl(c, pick_t, pick_sta, pick_phase, n_picks, t0, max_t, kernel_sig_t, dt, trv, emb_ws, slice_out, mask_out, xs,
                            stream);
-    if (rc == GENIE_OK && xs) { c->xs_slice = slice_out; c->xs_mask = mask_out; c->xs_ws = ws; }
+    if (rc == GENIE_OK && xs) { c->xs_slice = slice_out; c->xs_mask = mask_out; c->xs_ws = ws; c->xs_mm_copy = c->slot % GENIE_NBIG; }
     return rc;
 }
 

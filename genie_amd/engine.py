@@ -232,6 +232,8 @@ class HipPath(object):
         state_dict-named tensors to the registry's names / layouts when they differ (DataAggregationEdges)."""
         key = tuple((p.data_ptr(), p._version) for p in params.values())
         if key != self._w_key:
+            # tails of earlier windows may still read the weight mirror / packed images on their side streams
+            self.wait_tails()
             self.set_weights(view(params) if view is not None else params)
             self._w_key = key
 
@@ -251,6 +253,7 @@ class HipPath(object):
 
     def da_stage2_bipartite(self, Mask, edge_attr, want_x_latent=False):
         edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
+        self._refresh_static_edge_attr(edge_attr)
         x_latent = torch.empty((self.n_prod, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
         bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_da_stage2_bipartite(self.ctx, _ptr(Mask), _ptr(edge_attr), _ptr(x_latent), _ptr(bip),
@@ -272,6 +275,7 @@ class HipPath(object):
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        self._refresh_static_edge_attr(edge_attr)
         pos = _f32(pos, "pos", (self.n_grid, 3))
         out = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
         x_latent = torch.empty((P, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
@@ -279,6 +283,22 @@ class HipPath(object):
         _lib.check(self.lib.genie_path_fwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(pos), _ptr(out),
                                            _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
         return out, x_latent, bip
+
+    def _next_window_slot(self):
+        """Workspace slot the NEXT window (forward_pipelined / window_push) will run under; 0 for the single-stream calls."""
+        bt = getattr(self, "_bt", None)
+        if bt is not None or self.window_batch > 1:
+            return (bt["group"] * self.window_batch + bt["n"]) if bt is not None else 0
+        if getattr(self, "_ev_tail", None) is not None:
+            return self._win % len(self._ev_tail)
+        return 0
+
+    def _crosses_to(self, stream, *tensors):
+        """Tensors allocated on the current stream and consumed on `stream`: tell the caching allocator (record_stream), so
+        that a temporary freed by the caller is not handed out again before the side stream has read it."""
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(stream)
 
     # ---- two-stream window pipeline ----------------------------------------------------------------
     def forward_pipelined(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query):
@@ -295,6 +315,7 @@ class HipPath(object):
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        self._refresh_static_edge_attr(edge_attr)
         pos = _f32(pos, "pos", (self.n_grid, 3))
         if getattr(self, "side_streams", None) is None:
             n_tail = max(1, min(3, int(os.environ.get("GENIE_TAILS", "2"))))
@@ -316,6 +337,8 @@ class HipPath(object):
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
+        x_query, t_query = _f32(x_query, "x_query"), _f32(t_query, "t_query")
+        self._crosses_to(side, pos, x_query, knn_idx, t_query)
         with torch.cuda.stream(side):
             ss = ctypes.c_void_p(side.cuda_stream)
             bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
@@ -327,6 +350,7 @@ class HipPath(object):
             x = self.readout_query(x_spatial, pos, x_query, knn_idx, t_query)
             done = torch.cuda.Event()
             done.record(side)
+        self._crosses_to(main, y, x)       # produced on the side stream, usually consumed by the caller on the main one
         self._ev_tail[slot] = done
         _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
         return y, x, done
@@ -359,6 +383,7 @@ class HipPath(object):
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        self._refresh_static_edge_attr(edge_attr)
         if getattr(self, "_bt", None) is None:
             prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
             groups = 3 if self.window_batch == 1 else 2        # batches in flight (16 workspace slots)
@@ -400,6 +425,7 @@ class HipPath(object):
         ev.record(main)
         side = self.side_stream = bt["streams"][bt["turn"]]
         side.wait_event(ev)
+        self._crosses_to(side, pos, x_query, knn_idx, tq)
         with torch.cuda.stream(side):
             x_spatial = torch.empty((n, self.n_grid, 30), dtype=torch.float32, device=self.device)
             y = torch.empty((n, self.n_grid, tq.numel(), 1), dtype=torch.float32, device=self.device)
@@ -409,6 +435,7 @@ class HipPath(object):
                                                    ctypes.c_void_p(side.cuda_stream)), "genie_tail_batched")
             done = torch.cuda.Event()
             done.record(side)
+        self._crosses_to(main, y, x)
         bt["ev"][bt["group"]] = done
         bt["group"] = (bt["group"] + 1) % len(bt["ev"])
         bt["turn"] ^= 1
@@ -421,8 +448,16 @@ class HipPath(object):
         if self._n_prod is not None:
             return
         edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
-        self._static_ea = edge_attr
+        self._static_ea = edge_attr               # kept alive: the library recognises it by address
+        self._static_ea_version = edge_attr._version
         _lib.check(self.lib.genie_set_static_edge_attr(self.ctx, _ptr(edge_attr), _stream()), "genie_set_static_edge_attr")
+
+    def _refresh_static_edge_attr(self, edge_attr):
+        """An in-place edit of the registered edge_attr tensor (same address, new `_version`) refreshes the library's copy."""
+        ea = getattr(self, "_static_ea", None)
+        if ea is not None and edge_attr is not None and edge_attr.data_ptr() == ea.data_ptr() and (
+                edge_attr is not ea or edge_attr._version != self._static_ea_version):
+            self.set_static_edge_attr(edge_attr)
 
     def wait_tails(self, stream=None):
         """Make `stream` (default: the current one) wait for every window tail issued so far by `forward_pipelined`."""
@@ -579,7 +614,13 @@ class HipPath(object):
         common = (self.ctx, _ptr(pick_t) if n else None, _ptr(pick_sta) if n else None, _ptr(pick_phase) if n else None, n,
                   float(t0), float(max_t), float(kernel_sig_t), float(dt), _ptr(trv), _ptr(self._emb), _ptr(Slice), _ptr(Mask))
         if presplit:
-            _lib.check(self.lib.genie_embed_window_split(*common, self._ws_ptr, _stream()), "genie_embed_window_split")
+            # the message-mask row goes to the workspace copy of the slot this window will run under (forward_pipelined /
+            # window_push pick the same one next); a mismatch is repaired by a device copy inside genie_da_stage1
+            _lib.check(self.lib.genie_set_slot(self.ctx, self._next_window_slot()), "genie_set_slot")
+            try:
+                _lib.check(self.lib.genie_embed_window_split(*common, self._ws_ptr, _stream()), "genie_embed_window_split")
+            finally:
+                _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
         else:
             _lib.check(self.lib.genie_embed_window(*common, _stream()), "genie_embed_window")
         return Slice, Mask

@@ -290,14 +290,20 @@ class SpatialAttention(nn.Module):
         self._edge_cache = {}
 
     def query_edges(self, x_query, x_context, k):
-        key = (x_query.data_ptr(), x_query._version, tuple(x_query.shape), x_context.data_ptr(), x_context._version,
-               tuple(x_context.shape), k)
+        """kNN edges of a query set, cached for the set last used. The cache entry HOLDS the two position tensors: while it
+        lives their storage cannot be freed and handed to another tensor, so (address, in-place version, shape) identifies
+        the contents (a freed-and-reallocated query set of the same shape would otherwise hit with stale neighbours)."""
+        key = (x_query.data_ptr(), x_query._version, tuple(x_query.shape), x_query.dtype, x_context.data_ptr(),
+               x_context._version, tuple(x_context.shape), x_context.dtype, k)
         hit = self._edge_cache.get("key") == key
         if not hit:
             edges = knn_query_edges(x_context, x_query, k)
-            self._edge_cache = {"key": key, "edges": edges,
+            self._edge_cache = {"key": key, "edges": edges, "refs": (x_query, x_context),
                                 "table": edges[0].view(x_query.shape[0], -1).to(torch.int32).contiguous()}
         return self._edge_cache["edges"]
+
+    def invalidate_query_cache(self):
+        self._edge_cache = {}
 
     def query_table(self, x_query, x_context, k=10):
         """int32 [Q, k] table of the k nearest context nodes of every query (cached per query set)."""
@@ -605,8 +611,9 @@ class GCN_Detection_Network_extended(nn.Module):
 
     `forward_fixed_source` (module.py:999) runs DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3
     as ONE fused call into libgenie_hip (`genie_path_fwd`) on the graphs cached by `set_adjacencies`, then the
-    read-out heads on PyTorch-ROCm. `use_absolute_pos=True` (config.yaml:92, +6 input channels) is not
-    supported by the kernels and raises.
+    read-out heads (`genie_readout_grid` / `genie_readout_query`). `use_absolute_pos=True` (config.yaml:92, +6 input
+    channels) and `use_updated_model_definition=True` (config.yaml:95) are served for `forward_fixed_source`; their
+    4-output `forward` / `forward_fixed` raise.
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
@@ -692,6 +699,7 @@ class GCN_Detection_Network_extended(nn.Module):
             raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
+        self._edge_attr_version = self._edge_attr._version
         self._hip.set_static_edge_attr(self._edge_attr)
         dev = self._edge_attr.device
         self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
@@ -853,6 +861,11 @@ class GCN_Detection_Network_extended(nn.Module):
         arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 
+    def invalidate_graph_cache(self):
+        """Forget the graphs `forward` cached (next call rebuilds the HIP context) and the cached query kNN table."""
+        self._fwd_key = self._fwd_refs = None
+        self.SpatialAttention.invalidate_query_cache()
+
     def _spatial_attention_uncached(self, x_spatial, x_query, x_context):
         cache = self.SpatialAttention._edge_cache
         self.SpatialAttention._edge_cache = {}
@@ -864,11 +877,24 @@ class GCN_Detection_Network_extended(nn.Module):
                 A_edges_s, dt_partition, tlatent, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
                 x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q):
         """module.py:908-939: same as `forward_fixed` with the graphs passed per call (the training call convention,
-        train_GENIE_model.py:1786). The HIP context is rebuilt only when the graph tensors change identity."""
-        key = (A_in_sta.data_ptr(), A_in_src.data_ptr(), A_src.data_ptr(), tuple(A_in_sta.shape), tuple(A_in_src.shape))
+        train_GENIE_model.py:1786). The HIP context is rebuilt when any tensor that defines the graphs (edge lists, product
+        node list, positions) changes address, shape or in-place version; the cache holds those tensors, so an address cannot
+        be recycled while it is the key. The per-call tensors that do not shape the context (edge_attr, time-pointer tables,
+        tlatent) are simply taken from this call. `invalidate_graph_cache()` forces a rebuild."""
+        def tk(t):
+            return (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if torch.is_tensor(t) else id(t)
+        graph_tensors = (A_in_sta, A_in_src, A_src, A_src_in_sta, locs_use_cart, x_temp_cuda_cart)
+        key = tuple(tk(t) for t in graph_tensors)
         if getattr(self, "_fwd_key", None) != key:
             self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
                                  dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart)
-            self._fwd_key = key
+            self._fwd_key, self._fwd_refs = key, graph_tensors
+        else:
+            self.A_src_in_edges, self.A_Lg_in_src = A_src_in_edges, A_Lg_in_src
+            self.A_edges_p, self.A_edges_s, self.dt_partition, self.tlatent = A_edges_p, A_edges_s, dt_partition, tlatent
+            ea = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", tuple(self._edge_attr.shape))
+            if ea.data_ptr() != self._edge_attr.data_ptr() or ea._version != getattr(self, "_edge_attr_version", None):
+                self._edge_attr, self._edge_attr_version = ea, ea._version
+                self._hip.set_static_edge_attr(ea)
         return self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
                                   x_query_src_cart, t_query, tq_sample, trv_out_q)

@@ -50,3 +50,43 @@ def test_out2_stacking_half_step_is_uniform_in_the_interior():
     interior = o[12:-12]
     assert np.all(interior > 0)
     assert np.allclose(Out_2[0], Out_2[-1])
+
+
+def test_window_columns_snap_to_the_output_axis_and_write_duplicates_once():
+    """process_continuous_days.py:766,797-805: the window start is snapped to `tsteps_abs` before the offsets are added, and
+    numpy's fancy `+=` writes a column that two offsets map to only once (last occurrence)."""
+    off = np.arange(-3.0, 3.75, 0.75)
+    # aligned axis: nine distinct consecutive columns, the last dropped for 'half'
+    ts_abs = np.arange(0.0, 60.0, 0.75)
+    cols, keep = apply.window_columns(ts_abs, 30.0, off, drop_last=True)
+    assert np.array_equal(cols, np.arange(36, 44)) and np.array_equal(keep, np.arange(8))
+    # misaligned window start: snapped first (30.3 -> 30.0), so the same columns as above, not a shifted set
+    cols2, _ = apply.window_columns(ts_abs, 30.3, off, drop_last=True)
+    assert np.array_equal(cols2, cols)
+    # a coarser output axis maps two offsets to one column: written once, by the later offset
+    coarse = np.arange(0.0, 60.0, 1.5)
+    cols3, keep3 = apply.window_columns(coarse, 30.0, off, drop_last=False)
+    want = np.zeros(len(coarse))
+    vals = np.arange(1.0, 10.0)
+    ip = np.abs(coarse.reshape(-1, 1) - (30.0 + off).reshape(1, -1)).argmin(0)
+    want[ip] += vals                                           # the reference's statement
+    got = np.zeros(len(coarse))
+    np.add.at(got, cols3, vals[keep3])
+    assert len(np.unique(cols3)) == len(cols3) < 9 and np.array_equal(got, want)
+
+
+def test_windows_without_picks_in_the_embedding_range_are_skipped():
+    geom = synthetic.Geometry(6, 30, L=50e3, n_query=4, seed=3)
+    P = synthetic.make_picks(geom, 40, seed=4)
+    P[:, 0] += 500.0
+    P2 = P.copy()
+    P2[:, 0] += 2000.0                                          # a second burst far away: the windows in between see no pick
+    P = np.concatenate([P, P2])
+    net = _StubNet()
+    tsteps = apply.window_schedule(P[:, 0], geom.max_t)[0]
+    Out_2, used = apply.apply_windows(net, geom, P, step_size="half", min_required_picks=1, device="cpu",
+                                      embed=lambda picks, t0: (np.zeros((180, 4), np.float32), np.zeros((180, 4), np.float32)))
+    assert net.calls == len(used) < len(tsteps)
+    for t0 in used:
+        lo, hi = apply.picks_in_embed_range(np.sort(P[:, 0]), t0, geom.max_t, synthetic.KERNEL_SIG_T)
+        assert hi > lo

@@ -694,6 +694,59 @@ def test_device_apply_loop_matches_oracle(batch):
     assert max_abs(Out_2.cpu(), want) <= 1e-5
 
 
+@pytest.mark.parametrize("batch", [8, 3, 1])
+def test_presplit_embedding_with_poisoned_workspace(batch):
+    """genie_embed_window_split leaves the split rows AND the message-mask row `mm` in the workspace; `mm` exists once per
+    P-sized slot copy, and the window that consumes it runs under a slot chosen later (push_window / the pipelined forward).
+    Sparse picks (most product nodes have an all-zero Mask row, a different set in every window), a workspace filled with
+    NaN bit patterns beforehand, batches of 8 / 3 / 1 windows: a stage 2 that reads an `mm` copy this window never wrote
+    yields NaN or a wrong Bipartite sum."""
+    from genie_amd import apply
+    from oracle import embed_oracle as E
+    from oracle import genie_oracle as O
+    S, G = 18, 90
+    geom = synthetic.Geometry(S, G, L=400e3, n_query=12, seed=81)
+    rng = np.random.default_rng(82)
+    n = 260
+    P = np.stack([np.sort(rng.uniform(5000.0, 5090.0, n)), rng.integers(0, S, n).astype(np.float64), np.ones(n), np.ones(n),
+                  rng.integers(0, 2, n).astype(np.float64)], axis=1)
+    trv = geom.travel_times().astype(np.float32)
+    c = Case("tiny_6x40")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src),
+                             torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.locs).float().to(DEV),
+                             torch.from_numpy(geom.x_grid).float().to(DEV))
+    net._hip.ws.fill_(255)                       # every float of the workspace = NaN
+    max_t = float(np.ceil(trv.max() + 1.0))
+    sig = 0.5                                    # narrow kernel: |residual| > 1.5 s -> Mask 0
+    tsteps = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size="half")[0]
+    times = tsteps[(tsteps > 4990.0) & (tsteps < 5080.0)][:19]
+    Out_2, used = apply.apply_windows_device(net, geom, P, trv, step_size="half", max_t=max_t, kernel_sig_t=sig, dt_embed=0.1,
+                                             times=times, tail_batch=batch)
+    assert len(used) >= 12
+    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size="half")
+    tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
+    A = np.stack([np.tile(np.arange(S), G), np.repeat(np.arange(G), S)], axis=0)
+    sta_nbr = graph.neighbour_table(geom.A_sta_sta, S)
+    src_nbr = graph.neighbour_table(geom.A_src_src, G)
+    want = torch.zeros(Out_2.shape)
+    zero_rows = []
+    for t0 in used:
+        Slice, Mask = E.extract_input_from_data(P, float(t0), np.arange(S), S, trv, A, max_t, sig, 0.1)
+        zero_rows.append(float((Mask.max(1) == 0).mean()))
+        _, x = O.forward_fixed_source_structured(c.weights, torch.from_numpy(Slice), torch.from_numpy(Mask), sta_nbr, src_nbr,
+                                                 torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.A_src_src),
+                                                 torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+                                                 torch.from_numpy(offsets.reshape(-1, 1)).float(), S, G)
+        cols, keep = apply.window_columns(tsteps_abs, t0, offsets, True)
+        want[:, cols] += x[:, keep, 0] / 2.0
+    assert 0.2 < np.mean(zero_rows) < 0.98 and np.std(zero_rows) > 0       # the message mask matters and differs by window
+    assert torch.isfinite(Out_2).all()
+    assert max_abs(Out_2.cpu(), want) <= 1e-5
+
+
 def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
     """Two-stream window pipeline (G-sized tail of window i overlaps stage 1/2 of window i+1, double-buffered scratch):
     every window's (y, x) must be bit-identical to the single-stream forward_fixed_source."""

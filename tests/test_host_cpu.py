@@ -202,3 +202,30 @@ def test_space_filling_curve_orders():
     assert np.all(np.abs(np.diff(h, axis=0)).sum(1) == 1)
     with pytest.raises(ValueError):
         engine.morton_order(np.zeros((5, 2)))
+
+
+def test_query_knn_cache_cannot_return_a_stale_table():
+    """SpatialAttention.query_edges caches the kNN table of the last query set by (address, version, shape) and holds the
+    tensors, so a query set freed and re-allocated at the same address, or edited in place, is never served the old table."""
+    import gc
+    from genie_amd import module
+    sa = module.SpatialAttention(30, 30, 3, 15)
+    g = torch.Generator().manual_seed(3)
+    xc = torch.rand(200, 3, generator=g) * 1e5
+    seen = []
+    for trial in range(4):                       # same shape every time: the allocator tends to hand back the same block
+        xq = torch.rand(50, 3, generator=g) * 1e5
+        tab = sa.query_table(xq, xc, 10).clone()
+        want = module.knn_query_edges(xc, xq, 10)[0].view(50, 10).int()
+        assert torch.equal(tab, want), trial
+        seen.append(xq.data_ptr())
+        del xq
+        gc.collect()
+    xq = torch.rand(50, 3, generator=g) * 1e5
+    t1 = sa.query_table(xq, xc, 10).clone()
+    assert sa.query_table(xq, xc, 10).data_ptr() == sa._edge_cache["table"].data_ptr()      # hit
+    xq.mul_(-1.0).add_(1e5)                       # in-place edit: same address, new version
+    t2 = sa.query_table(xq, xc, 10)
+    assert torch.equal(t2, module.knn_query_edges(xc, xq, 10)[0].view(50, 10).int()) and not torch.equal(t1, t2)
+    sa.invalidate_query_cache()
+    assert sa._edge_cache == {}
