@@ -5,12 +5,18 @@ One "step" = one forward window (`forward_fixed_source`, reference module.py:999
 graphs already set (`set_adjacencies` runs once per day in the reference, process_continuous_days.py:622-649),
 inputs (`Slice`, `Mask`) resident in HBM. picks/sec = N_picks x windows/sec.
 
-N = 1 workload: BASELINE.json configs[1] = 200 stations / 10 000 grid nodes / 50 000 picks.
-N > 1: window-parallel replicas (BASELINE config 5 — every GPU holds the 200-station model and graph and
-processes its own windows; no data-path collective) => weak scaling, value = sum over ranks.
+N = 1 workload: BASELINE.json configs[1] = 200 stations / 10 000 grid nodes / 50 000 picks (cfg2).
+N > 1 (default `--mode sharded --config cfg4_2000x50k`): BASELINE.json configs[3] = 2000 stations / 50 000 grid nodes /
+500 000 picks, ONE window sharded over source nodes across the N ranks (genie_amd/dist.py: halo all-to-all of the
+projected `wv` rows + all-gather of the [G,15] Bipartite output over RCCL/xGMI) => strong scaling.
+`--mode replicas`: window-parallel replicas of cfg2 (no collective, weak scaling); `--mode stream`: config 5.
 
-Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel, HIP-event timed on the launch
-stream) and `cpu_baseline` (the oracle's reference-formulation forward on the host cores, rank 0, N=1).
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1) when it is not already
+running under one (WORLD_SIZE unset); under `torchrun` it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (path-level algorithmic bytes B_alg x windows/s
+against the 8 TB/s HBM peak; per-kernel HIP-event times and counter traffic as extras) and `cpu_baseline` (the oracle's
+reference-formulation forward on the host cores, rank 0, N=1).
 """
 import argparse
 import json
@@ -43,8 +49,13 @@ F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 
 # bf16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
 BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
-# profiles/r01_k_pmc_stage_kernels.txt (k_split_rows + k_stage1_b3): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024
-S1_TRAFFIC_CFG2 = (2.0 * (2.481e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0
+# HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
+# WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
+TRAFFIC_SOURCE = "profiles/r01_k_pmc_stage_kernels.txt"
+TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.481e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
+                "k_stage2": 0.968e9}                                                          # k_stage2_fast
+# one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
+ONE_GPU_CFG4 = {"ms_per_step": 42.4, "source": "DESIGN.md section 5 (round-1 builder run, single stream)"}
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -53,10 +64,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--settle", type=int, default=600,
+    ap.add_argument("--settle", type=int, default=1500,
                     help="untimed windows run during set-up, before the W warm-up steps: the GPU clocks need ~0.5 s of sustained "
                          "load to settle (a cold start reads 5-10 %% slow for the first few hundred windows; DESIGN.md section 5)")
-    ap.add_argument("--config", default="cfg2_200x10k", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(synthetic.CONFIGS),
+                    help="default: cfg2_200x10k (N = 1, replicas, stream), cfg4_2000x50k (sharded with N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="distinct synthetic pick windows cycled through")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream forward_fixed_source per window")
@@ -66,10 +78,31 @@ def parse():
     ap.add_argument("--tail-batch", type=int, default=None,
                     help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 1 for "
                          "resident windows (the headline workload), 8 for --mode stream (measured best for each, DESIGN.md section 5)")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded", "stream"],
-                    help="N>1: window-parallel replicas (weak scaling, default) or ONE window sharded over source nodes "
-                         "with an RCCL halo all-to-all + all-gather per window (strong scaling; use with --config cfg4_2000x50k)")
+    ap.add_argument("--mode", default=None, choices=["replicas", "sharded", "stream"],
+                    help="default: the cfg2 window pipeline at N = 1; at N > 1 ONE cfg4 window sharded over source nodes with an "
+                         "RCCL halo all-to-all + all-gather per window (strong scaling). replicas = window-parallel copies of "
+                         "cfg2 (weak scaling, no collective); stream = config 5")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: launch the ranks, build the sharding plan and run the two collectives of the sharded path on CPU "
+                         "tensors over gloo (checks the launcher / rank plumbing and the exchange; prints a JSON line, no timing)")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded: sequential schedule (stage 1, exchange, stage 2, all-gather)")
+    ap.add_argument("--cpu-windows", type=int, default=3, help="cpu_baseline: timed windows after one warm-up (median)")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start N ranks of this script on this node."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def build_model(geom, dev, seed=0):
@@ -81,9 +114,19 @@ def build_model(geom, dev, seed=0):
     return net
 
 
-def cpu_baseline(net, geom, win):
-    """Oracle ('port' of the reference formulation: explicit product edge lists, gather + scatter-mean) timed on
-    this box's host cores for ONE window of the same workload."""
+def physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(net, geom, win, n_timed=3):
+    """Oracle ('port' of the reference formulation: explicit product edge lists, gather + scatter-mean) timed on this box's
+    host cores on the same workload: one warm-up window, then the median of `n_timed` windows with torch's
+    default thread count; and a single-thread figure on a bounded sample (the first G/10 source nodes of the same window with
+    their own kNN graph, one warm-up + one timed run, scaled linearly in the number of product nodes)."""
     from oracle import genie_oracle as O
     w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     S, G = geom.n_sta, geom.n_grid
@@ -92,11 +135,33 @@ def cpu_baseline(net, geom, win):
             torch.from_numpy(geom.edge_attr()), A_src_in_prod, torch.from_numpy(geom.A_src_src),
             torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
             torch.from_numpy(geom.t_query).float())
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        y, x = O.forward_fixed_source(*args)
-        dt = time.perf_counter() - t0
-    return y, x, dt
+        for k in range(1 + max(1, n_timed)):
+            t0 = time.perf_counter()
+            y, x = O.forward_fixed_source(*args)
+            if k:
+                times.append(time.perf_counter() - t0)
+    del args, A_in_sta, A_in_src, A_src_in_prod
+    # single thread, bounded sample
+    Gs = max(64, G // 10)
+    A_sub = graph.knn_graph(geom.x_grid[:Gs] / 1000.0, min(synthetic.K_SPC, Gs - 1))
+    B_in_sta, B_in_src, B_src_in_prod, _ = graph.cartesian_product_edges(geom.A_sta_sta, A_sub, S, Gs)
+    sub = (w, torch.from_numpy(win["Slice"][: Gs * S]), torch.from_numpy(win["Mask"][: Gs * S]), B_in_sta, B_in_src,
+           torch.from_numpy(geom.edge_attr(slice(0, Gs))), B_src_in_prod, torch.from_numpy(A_sub),
+           torch.from_numpy(geom.x_grid[:Gs]).float(), torch.from_numpy(geom.x_query[: max(10, geom.x_query.shape[0] // 10)]).float(),
+           torch.from_numpy(geom.t_query).float())
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with torch.no_grad():
+            O.forward_fixed_source(*sub)
+            t0 = time.perf_counter()
+            O.forward_fixed_source(*sub)
+            t1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    return y, x, float(np.median(times)), times, t1 * (G / float(Gs)), Gs
 
 
 def main_stream(a, geom, nq, rank, world, dev, dist):
@@ -203,14 +268,19 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
 
 def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
     """ONE window per step, product graph sharded over source nodes across the ranks (genie_amd/dist.py): per window one
-    halo all-to-all (64 B per halo product node) and one all-gather of the [G,15] Bipartite output over RCCL/xGMI."""
+    halo all-to-all (64 B per halo product node; issued as soon as stage 1 has produced the rows other ranks need, under the
+    rest of stage 1 and the halo-free part of stage 2) and one all-gather of the [G,15] Bipartite output over RCCL/xGMI; the
+    replicated G-sized tail + read-outs of window i run on a tail stream under the P-sized kernels of window i+1 (the windows
+    of the apply loop are independent, as in the N = 1 pipeline)."""
     from genie_amd import dist as gdist, engine
     S, G = geom.n_sta, geom.n_grid
     torch.manual_seed(0)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev).eval()
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
-    sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs)
+    sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs,
+                           overlap=not a.no_overlap)
     sp.set_weights(module._path_param_dict(net))
+    sp.full.set_scale_t(net.TemporalAttention.scale_t)
     p = sp.plan
     ext = p.ext_global
     P = synthetic.make_picks(geom, n_picks, seed=2, window=0)
@@ -218,15 +288,18 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
     chunks = [synthetic.make_slice_mask(geom, P, 0.0, g_slice=ext[i:i + 2048]) for i in range(0, ext.size, 2048)]
     dS = torch.from_numpy(np.concatenate([c[0] for c in chunks])).to(dev)
     dM = torch.from_numpy(np.concatenate([c[1] for c in chunks])).to(dev)
+    del chunks
     ea = torch.from_numpy(np.concatenate([geom.edge_attr(p.own_global[i:i + 2048]) for i in range(0, p.n_own, 2048)])).to(dev)
     xg = torch.from_numpy(geom.x_grid).float().to(dev)
     xq = torch.from_numpy(geom.x_query).float().to(dev)
     tq = torch.from_numpy(geom.t_query).float().to(dev)
     knn = net.SpatialAttention.query_table(xq, xg, 10)
 
-    def step():
-        x_spatial = sp.path_fwd(dS, dM, ea, xg)
+    def readouts(x_spatial):
         return sp.full.readout_grid(x_spatial, tq), sp.full.readout_query(x_spatial, xg, xq, knn, tq)
+
+    def step():
+        return sp.path_fwd(dS, dM, ea, xg, tail=readouts, pipelined=not a.no_pipeline)
 
     def barrier():
         if dist is not None:
@@ -246,19 +319,51 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-phase HIP-event times of the sequential schedule on this rank (stage 1, exchange, stage 2, gather + tail)
+    ph = {k: [] for k in ("stage1", "exchange", "stage2", "gather_tail")}
+    with torch.no_grad():
+        lp, wv = sp.local, sp.wv_view()
+        for _ in range(min(a.steps, 5)):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            barrier()
+            e[0].record()
+            lp.da_stage1_range(dS, dM, 0, p.n_own, True)
+            e[1].record()
+            sp._exchange(wv)
+            e[2].record()
+            lp.da_stage2_partials_range(dM[: p.n_own * S], ea, 0, p.n_own)
+            bip_own = lp.bipartite_readout()
+            e[3].record()
+            sp.gather_and_tail(bip_own, xg, readouts)
+            e[4].record()
+            torch.cuda.synchronize()
+            for k, name in enumerate(("stage1", "exchange", "stage2", "gather_tail")):
+                ph[name].append(e[k].elapsed_time(e[k + 1]))
+    phases = {k: round(float(np.median(v)), 4) for k, v in ph.items()}
+    ranks = world if dist is None else int(dist.get_world_size())
     wps = a.steps / dt
     b_alg = 1532.0 * S * G + 816.0 * G
+    halo_bytes = float(p.n_halo) * S * 64.0
     out = {
         "metric": "picks/sec through GCN_Detection_Network_extended.forward_fixed_source (GCS_Network.forward)",
         "value": round(wps * n_picks, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, ONE window sharded over source "
-                               "nodes" % (a.config, S, G, n_picks), "n_stations": S, "n_grid": G, "n_picks": n_picks,
-                   "n_query": nq, "parallelism": "source-node sharding x%d (halo all-to-all + all-gather per window)" % world,
-                   "halo_fraction_rank0": round(p.halo_fraction(), 3)},
+        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source of ONE window sharded "
+                               "over source nodes, graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
+                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
+                   "parallelism": "source-node sharding x%d (halo all-to-all + all-gather per window, %s)"
+                                  % (world, "sequential" if a.no_overlap else "exchange overlapped with compute"),
+                   "backend": "nccl (RCCL)" if dist is not None else "none", "rccl_ranks": ranks,
+                   "tail_pipelined": not a.no_pipeline,
+                   "rank0_plan": {"n_own": p.n_own, "n_halo": p.n_halo, "send_nodes": p.n_send_nodes, "need_nodes": p.n_need_nodes,
+                                  "halo_MB_in_per_window": round(halo_bytes / 1e6, 1)}},
         "windows_per_s": round(wps, 2),
-        "roofline": {"bound": "hbm", "kernel": "path", "achieved": round(b_alg * wps / 1e9, 1), "peak": HBM_PEAK_GBS * world,
+        "rank0_phase_ms_sequential": phases,
+        "one_gpu_same_config": dict(ONE_GPU_CFG4, speedup=round(ONE_GPU_CFG4["ms_per_step"] / (dt / a.steps * 1e3), 2))
+        if a.config == "cfg4_2000x50k" else None,
+        "roofline": {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
+                     "achieved": round(b_alg * wps / 1e9, 1), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(b_alg * wps / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None},
     }
     if rank == 0:
@@ -267,11 +372,53 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def main_dry_run_cpu(a, rank, world):
+    """Launcher / plan / collective check without a GPU (tests/test_bench_cpu.py): every rank builds its ShardPlan, sends the
+    row blocks its peers list and all-gathers a per-node tensor, over gloo on CPU tensors; values encode (node, station)."""
+    from genie_amd import dist as gdist, engine
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    S, G, n_picks, L, nq = synthetic.CONFIGS[a.config or "cfg1_20x500"]
+    geom = synthetic.Geometry(S, G, L=L, n_query=8, seed=1)
+    plan = gdist.ShardPlan(geom.A_src_src, G, world, rank, engine.sfc_order(geom.x_grid))
+    code = (torch.arange(G).view(-1, 1) * 4096 + torch.arange(S).view(1, -1)).float()                 # [G, S]
+    rows_global = torch.stack((code, -code), dim=2)                                                    # [G, S, 2]
+    own = rows_global[torch.from_numpy(plan.own_global)].reshape(-1, 2).contiguous()
+    halo = gdist.exchange_halo_rows(own, plan, S)
+    ok = torch.equal(halo.view(plan.n_halo, S, 2), rows_global[torch.from_numpy(plan.halo_global)])
+    per_node = torch.stack([torch.from_numpy(plan.own_global).float() * k for k in (1.0, 2.0, 3.0)], dim=1)
+    gathered = gdist.allgather_owned(per_node, plan)
+    ok = ok and torch.equal(gathered[:, 0], torch.arange(G).float()) and torch.equal(gathered[:, 2], 3.0 * torch.arange(G).float())
+    flag = torch.tensor([1.0 if ok else 0.0])
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run_cpu": True, "n_gpus": world, "ranks": world if dist is None else dist.get_world_size(),
+                          "backend": "gloo" if dist is not None else "none", "ok": bool(flag.item() == 1.0),
+                          "config": {"workload": "%s sharding plan + collectives only" % (a.config or "cfg1_20x500")},
+                          "rank0_plan": {"n_own": plan.n_own, "n_halo": plan.n_halo}}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0 if flag.item() == 1.0 else 1
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(respawn_under_torchrun(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.dry_run_cpu:
+        sys.exit(main_dry_run_cpu(a, rank, world))
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)" % (a.gpus, world, world), file=sys.stderr)
+    if a.mode is None:
+        a.mode = "sharded" if world > 1 else "replicas"
+    if a.config is None:
+        a.config = "cfg4_2000x50k" if (a.mode == "sharded" and world > 1) else "cfg2_200x10k"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -370,55 +517,57 @@ def main():
             ev["k_stage2"].append(e[1].elapsed_time(e[2]))
             ev["path"].append(e[0].elapsed_time(e[3]))
     kms = {k: float(np.median(v)) for k, v in ev.items()}
-    dom = max(("k_stage1", "k_stage2"), key=lambda k: kms[k])
-    dom_gbs = B_NODE[dom] * P / (kms[dom] * 1e-3) / 1e9
-    dom_tf = F_NODE[dom] * P / (kms[dom] * 1e-3) / 1e12
     b_alg = 1532.0 * P + 816.0 * G
     path_gbs = b_alg * (windows_per_s / world) / 1e9
-    if dom == "k_stage1":   # dense per-node MLP chain: compute roofline
-        # `achieved` = ALGORITHMIC fp32 FLOPs / time against the fp32 matrix peak (the dtype the path computes in). The
-        # kernel gets past what fp32 MFMAs can deliver by running exact 3-way bf16 splits on the bf16 matrix pipe; the
-        # bf16 FLOPs it really executes are reported next to the bf16 peak.
-        # traffic: HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB -> B), measured on this
-        # exact workload and committed as profiles/r01_k_pmc_stage_kernels.txt; null for other workloads
-        traffic = S1_TRAFFIC_CFG2 if a.config == "cfg2_200x10k" else None
-        exec_tf = BF16_EXEC_FLOP_NODE * P / (kms[dom] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_stage1_b3 (+ k_split_rows_g)", "achieved": round(dom_tf, 2),
-                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4),
-                    "traffic": traffic,
-                    "executed": {"bf16_tflops": round(exec_tf, 1), "bf16_peak": BF16_MFMA_PEAK_TF,
-                                 "frac": round(exec_tf / BF16_MFMA_PEAK_TF, 4)},
-                    "hbm_equiv_GBs": round(dom_gbs, 1)}
-    else:
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": None}
-    roofline["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
-    roofline["path"] = {"alg_bytes_per_window": b_alg, "achieved": round(path_gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                        "frac": round(path_gbs / HBM_PEAK_GBS, 4),
-                        "fp32_tflops": round(FLOP_NODE * P * (windows_per_s / world) / 1e12, 2),
-                        "fp32_frac_of_mfma_peak": round(FLOP_NODE * P * (windows_per_s / world) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+    # the path is priced against the HBM roofline on its ALGORITHMIC bytes (reference dataflow at layer
+    # granularity, B_alg per window); the fused kernels move fewer real bytes, so the per-kernel figures (algorithmic bytes of
+    # what each kernel has to touch, HIP-event time on the launch stream, counter traffic from the committed PMC profile) are
+    # reported next to it. Stage 1 additionally reports the bf16 FLOPs it executes against the bf16 matrix peak: it is the
+    # one compute-bound kernel of the path.
+    kern = {}
+    for k in ("k_stage1", "k_stage2"):
+        gbs = B_NODE[k] * P / (kms[k] * 1e-3) / 1e9
+        kern[k] = {"ms": round(kms[k], 4), "alg_bytes_per_launch": B_NODE[k] * P, "achieved_GBs": round(gbs, 1),
+                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                   "traffic": TRAFFIC_CFG2[k] if a.config == "cfg2_200x10k" else None}
+    exec_tf = BF16_EXEC_FLOP_NODE * P / (kms["k_stage1"] * 1e-3) / 1e12
+    kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_b3"
+    kern["k_stage1"]["executed_bf16"] = {"tflops": round(exec_tf, 1), "peak": BF16_MFMA_PEAK_TF, "frac": round(exec_tf / BF16_MFMA_PEAK_TF, 4)}
+    kern["k_stage2"]["kernels"] = "k_stage2_fast"
+    roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
+                "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
+                "traffic": (sum(TRAFFIC_CFG2.values()) if a.config == "cfg2_200x10k" else None),
+                "traffic_source": "constant from %s (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                  "P-sized kernels), not measured in this run" % TRAFFIC_SOURCE,
+                "alg_bytes_per_window": b_alg, "kernels": kern, "single_stream_path_ms": round(kms["path"], 4),
+                "fp32_tflops": round(FLOP_NODE * P * (windows_per_s / world) / 1e12, 2)}
 
     out = {
         "metric": "picks/sec through GCN_Detection_Network_extended.forward_fixed_source (GCS_Network.forward)",
         "value": round(value, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, "
-                               "graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
-                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
+        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, graphs preset, inputs "
+                               "resident in HBM; steady state after %d untimed clock-settle windows" % (a.config, S, G, n_picks, a.settle),
+                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq, "settle_windows": a.settle,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
         "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,
-        "settle_windows": a.settle,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        yc, xc, cdt = cpu_baseline(net, geom, wins[0])
+        yc, xc, cdt, ctimes, c1, gs = cpu_baseline(net, geom, wins[0], a.cpu_windows)
         with torch.no_grad():
             yg, xgq = net.forward_fixed_source(dS[0], dM[0], None, None, None, locs, xg, xq, tq)
         out["cpu_baseline"] = {
             "value": round(n_picks / cdt, 1), "unit": "picks/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "1 window of the same workload (oracle, reference formulation with explicit product edge "
-                      "lists, torch CPU fp32), %.1f s" % cdt,
+            "physical_cores": physical_cores(),
+            "sample": "median of %d windows of the same workload after 1 warm-up (oracle = reference formulation with explicit "
+                      "product edge lists, torch CPU fp32, %d threads): %s s" % (len(ctimes), int(torch.get_num_threads()),
+                                                                                 ", ".join("%.1f" % t for t in ctimes)),
+            "single_thread": {"value": round(n_picks / c1, 1), "unit": "picks/s", "cores": 1,
+                              "sample": "first %d of %d source nodes of the same window with their own kNN graph, 1 warm-up + 1 "
+                                        "timed run, scaled x%.1f (linear in product nodes): %.1f s per full window"
+                                        % (gs, G, G / float(gs), c1)},
             "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xgq.cpu() - xc).abs().max()),
         }
     if rank == 0:

@@ -49,6 +49,8 @@ SYMBOLS = [
     ("genie_weights_commit", _c.c_int, [_P, _P]),
     ("genie_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_da_stage1", _c.c_int, [_P, _P, _P, _P, _P]),
+    ("genie_da_stage1_range", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    ("genie_da_stage2_partials_range", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int, _P, _P]),
     ("genie_da_stage1_debug", _c.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("genie_ws_v_ptr", _P, [_P, _P]),
     ("genie_ws_v_pitch", _c.c_int, [_P]),

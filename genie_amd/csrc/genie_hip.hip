@@ -508,7 +508,8 @@ constexpr int ROWW = 16;   // row pitch of the projected gather operands wu / wv
 constexpr int WAVES = 4;   // waves per workgroup
 
 struct DaArgs {
-    int S, G, T;               // stations, owned source nodes, tiles per source node = ceil(S/16)
+    int S, G, T;               // stations, source nodes this launch processes, tiles per source node = ceil(S/16)
+    int gi0;                   // ... = positions [gi0, gi0 + G) of the processing order (sub-range launches of the sharded path; else 0)
     int seg;                   // source nodes per scheduling segment
     int abl;                   // GENIE_TUNING only: ablation bits
     int nxcd;                  // XCD-chunked sweep (8) or flat (1)
@@ -550,11 +551,11 @@ struct ItemIter {
         return q;
     }
     static __device__ __forceinline__ unsigned recip(unsigned d) { return d <= 1u ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
-    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave) {
+    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0) {
         const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
         const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
-        gbeg = (int)((long long)G * xcd / nx);
-        gend = (int)((long long)G * (xcd + 1) / nx);
+        gbeg = gi0 + (int)((long long)G * xcd / nx);
+        gend = gi0 + (int)((long long)G * (xcd + 1) / nx);
         T = T_;
         seg = seg_;
         nitems = (long long)(gend - gbeg) * T;
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     for (; w.it < w.nitems; w.it += w.stride) {
         int gi, tb;
         w.decode(w.it, gi, tb);
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void stage1_fast_loop(const DaArgs& a, const f32x4* l
     int lane = lane_in;
     const int j = lane & 15, q = lane >> 4;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     if (w.it >= w.nitems) return;
     // 32-bit BYTE offsets from the (uniform) array bases: one VGPR per address (the host only selects this kernel
     // when n_grid_ext * n_sta * 16 B < 4 GiB)
@@ -1358,7 +1359,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
     const bool hi = h != 0;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     const char* xs = (const char*)a.xs;
     const unsigned la = hi ? 16u : 0u, lb = hi ? 0u : 32u;       // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]
     const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XROW);
@@ -1621,7 +1622,7 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     for (; w.it < w.nitems; w.it += w.stride) {
         int gi, tb;
         w.decode(w.it, gi, tb);
@@ -1782,7 +1783,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     if (w.it >= w.nitems) return;
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
@@ -1968,7 +1969,7 @@ __global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
     const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
     const bool hi = h != 0;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
     const unsigned h16 = 16u * (unsigned)h;
@@ -3613,13 +3614,21 @@ int genie_weights_commit(genie_ctx* c, void* stream) {
 size_t genie_workspace_bytes(const genie_ctx* c) { return c ? c->ws_floats * sizeof(float) : 0; }
 
 namespace {
-int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h0, float* dbg_h1, void* ws, void* stream) {
+// gi_begin / gi_end: positions of the processing order this call covers (the whole grid: 0, G); do_split: run the input
+// split pass over ALL rows (owned + halo) first -- the first range call of a window does, later ones reuse its rows
+int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h0, float* dbg_h1, void* ws, void* stream,
+               int gi_begin, int gi_end, bool do_split) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!slice || !mask) return fail(GENIE_ERR_ARG, "genie_da_stage1: null input");
+    if (gi_begin < 0 || gi_end > c->G || gi_begin > gi_end) return fail(GENIE_ERR_ARG, "genie_da_stage1: bad source-node range");
+    const bool whole = gi_begin == 0 && gi_end == c->G;
+    if (!whole && c->pcsr) return fail(GENIE_ERR_STATE, "genie_da_stage1_range: not available on an irregular product graph");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
+    a.gi0 = gi_begin; a.G = gi_end - gi_begin;
+    const long long n_tiles = (long long)a.G * c->T;
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
     float* dbg_tmp = nullptr;
@@ -3645,16 +3654,16 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     }
 #endif
     if (c->abs_sta && !c->pcsr && !(c->use_b3 && B3_ABS_READY)) {      // use_absolute_pos: generic kernel (64-bit safe, any graph)
-        k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
+        if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
     } else if (c->use_b3) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
-        const bool presplit = c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws;     // genie_embed_window_split, one-shot
-        c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
+        const bool presplit = (c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws) || !do_split;   // genie_embed_window_split, one-shot
+        if (do_split) { c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; }
         float* mmw = (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-        if (presplit && sta_order_on(c) && c->xs_mm_copy != c->slot % GENIE_NBIG) {
+        if (presplit && do_split && sta_order_on(c) && c->xs_mm_copy != c->slot % GENIE_NBIG) {
             // the embedding ran under another slot: its message-mask row sits in a different copy than the one stage 2 of THIS
             // window reads (the split rows `xs` exist once). Bring it over (P_ext floats, same stream); callers avoid the copy by
             // selecting the window's slot before they embed (engine.embed_window does).
@@ -3670,19 +3679,20 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
         a.xs = xs; a.packed = c->packed_b3;
-        const int grid = da_grid_w(c, ((long long)c->G * c->T + 1) / 2, c->bpc1b, B3_THREADS / 64);
+        const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
-        if (c->has_edges) {
+        if (!n_tiles) {
+        } else if (c->has_edges) {
             if (big) k_stage1_b3<8, 15, true, true><<<grid, B3_THREADS, 0, st>>>(a);
             else k_stage1_b3<8, 15, true, false><<<grid, B3_THREADS, 0, st>>>(a);
         } else {
             if (big) k_stage1_b3<8, 15, false, true><<<grid, B3_THREADS, 0, st>>>(a);
             else k_stage1_b3<8, 15, false, false><<<grid, B3_THREADS, 0, st>>>(a);
         }
-    } else if (c->use_fast)
-        k_stage1_fast<8, 15><<<da_grid_w(c, (long long)c->G * c->T, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
-    else
-        k_stage1<<<da_grid(c, (long long)c->G * c->T, c->bpc1), 256, 0, st>>>(a);
+    } else if (c->use_fast) {
+        if (n_tiles) k_stage1_fast<8, 15><<<da_grid_w(c, n_tiles, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
+    } else if (n_tiles)
+        k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     if (dbg_tmp) {     // parity outputs were written in station processing order: back to the caller's order
         if (dbg_h0) k_permute_sta_rows<<<(unsigned)((c->P * 30 + 255) / 256), 256, 0, st>>>(dbg_tmp, c->P, 30, c->sta_perm, c->S, dbg_h0);
@@ -3695,13 +3705,20 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
 }  // namespace
 
 int genie_da_stage1(genie_ctx* c, const float* slice, const float* mask, void* ws, void* stream) {
-    return run_stage1(c, slice, mask, nullptr, nullptr, ws, stream);
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    return run_stage1(c, slice, mask, nullptr, nullptr, ws, stream, 0, c->G, true);
+}
+
+int genie_da_stage1_range(genie_ctx* c, const float* slice, const float* mask, int gi_begin, int gi_end, int first, void* ws,
+                          void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    return run_stage1(c, slice, mask, nullptr, nullptr, ws, stream, gi_begin, gi_end, first != 0);
 }
 
 int genie_da_stage1_debug(genie_ctx* c, const float* slice, const float* mask, float* h0_out, float* h1_out, void* ws,
                           void* stream) {
-    if (!h0_out || !h1_out) return fail(GENIE_ERR_ARG, "genie_da_stage1_debug: null output");
-    return run_stage1(c, slice, mask, h0_out, h1_out, ws, stream);
+    if (!c || !h0_out || !h1_out) return fail(GENIE_ERR_ARG, "genie_da_stage1_debug: null argument");
+    return run_stage1(c, slice, mask, h0_out, h1_out, ws, stream, 0, c->G, true);
 }
 
 float* genie_ws_v_ptr(const genie_ctx* c, void* ws) {
@@ -3709,14 +3726,38 @@ float* genie_ws_v_ptr(const genie_ctx* c, void* ws) {
 }
 int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
+namespace {
+int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws, void* stream,
+               int gi_begin, int gi_end);
+}
+
 int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
                              void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    return run_stage2(c, mask, edge_attr, x_latent_out, ws, stream, 0, c->G);
+}
+
+int genie_da_stage2_partials_range(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, int gi_begin,
+                                   int gi_end, void* ws, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "null context");
+    return run_stage2(c, mask, edge_attr, x_latent_out, ws, stream, gi_begin, gi_end);
+}
+
+namespace {
+int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws, void* stream,
+               int gi_begin, int gi_end) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!mask || !edge_attr) return fail(GENIE_ERR_ARG, "genie_da_stage2_partials: null argument");
+    if (gi_begin < 0 || gi_end > c->G || gi_begin > gi_end) return fail(GENIE_ERR_ARG, "genie_da_stage2_partials: bad source-node range");
+    if (!(gi_begin == 0 && gi_end == c->G) && c->pcsr)
+        return fail(GENIE_ERR_STATE, "genie_da_stage2_partials_range: not available on an irregular product graph");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
+    a.gi0 = gi_begin; a.G = gi_end - gi_begin;
+    const long long n_tiles = (long long)a.G * c->T;
+    if (n_tiles == 0) return GENIE_OK;
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     a.ea_int = (sta_order_on(c) && c->ea_int && c->ea_user == edge_attr) ? c->ea_int : nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
@@ -3741,14 +3782,15 @@ int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_
         k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
     } else if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
         a.packed = c->packed_b3s2;
-        k_stage2_b3<8, 15><<<da_grid(c, ((long long)c->G * c->T + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
+        k_stage2_b3<8, 15><<<da_grid(c, (n_tiles + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2)
-        k_stage2_fast<8, 15><<<da_grid(c, (long long)c->G * c->T, c->bpc2f), 256, 0, st>>>(a);
+        k_stage2_fast<8, 15><<<da_grid(c, n_tiles, c->bpc2f), 256, 0, st>>>(a);
     else
-        k_stage2<<<da_grid(c, (long long)c->G * c->T, c->bpc2), 256, 0, st>>>(a);
+        k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
+}  // namespace
 
 int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream) {
     int rc = check_ws(c, ws);

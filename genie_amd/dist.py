@@ -7,11 +7,21 @@ rows of neighbour source nodes owned elsewhere (the HALO):
 
 * layer 1 recomputes every neighbour's hidden state from its raw 8 input floats, so the halo of layer 1 is just the
   halo nodes' `Slice/Mask` rows, which every rank loads/embeds itself (input distribution, no collective);
-* layer 2 gathers the projected operand `wv` (15 channels, 64-B rows): ONE all-to-all of halo rows per window between
-  `genie_da_stage1` and `genie_da_stage2_bipartite`;
-* the `[G, 15]` Bipartite output is all-gathered and the G-sized SpatialAggregation / read-out kernels run replicated.
+* layer 2 gathers the projected operand `wv` (15 channels, 64-B rows): ONE all-to-all of halo rows per window, issued on a
+  communication stream as soon as stage 1 has produced the rows other ranks need, and overlapped with the rest of stage 1 and
+  with stage 2 of the source nodes that have no halo neighbour;
+* the `[G, 15]` Bipartite output is all-gathered (one `all_gather_into_tensor` + one index op) and the G-sized
+  SpatialAggregation / read-out kernels run replicated, on a tail stream under the next window's P-sized kernels.
 
-The reference has no multi-GPU code at all; this is new.
+How the overlap is arranged: a rank's owned source nodes fall into the classes SEND (some other rank lists them as a
+neighbour) and NEED (they have a neighbour owned elsewhere). The local processing order is
+`[SEND only | SEND and NEED | NEED only | interior]`, each class in space-filling-curve order, so that
+  stage 1 = range [0, n_send) -> all-to-all starts -> range [n_send, n_own)
+  stage 2 = the two ranges without NEED nodes -> wait for the halo rows -> the NEED range
+are contiguous sub-ranges of that order (`genie_da_stage1_range`, `genie_da_stage2_partials_range`).
+
+The reference has no multi-GPU code at all (`process_config.yaml:66 parallel_processing: False`); the layout
+sharded here is its product-node numbering `p = g * n_sta + s` (`process_utils.py:720-722`).
 """
 import numpy as np
 import torch
@@ -29,7 +39,7 @@ class ShardPlan(object):
         A = np.asarray(A_src_src)
         G, W = int(n_grid), int(world)
         order = np.arange(G) if order is None else np.asarray(order, dtype=np.int64)
-        assert sorted(order.tolist()) == list(range(G)), "order must be a permutation of the source nodes"
+        assert order.shape == (G,) and np.array_equal(np.sort(order), np.arange(G)), "order must be a permutation of the source nodes"
         self.n_grid, self.world, self.rank = G, W, int(rank)
         bounds = [(G * r) // W for r in range(W + 1)]
         self.bounds = bounds
@@ -40,12 +50,13 @@ class ShardPlan(object):
         self.owned = [order[bounds[r]:bounds[r + 1]].copy() for r in range(W)]          # global ids per rank
         j, i = A[0].astype(np.int64), A[1].astype(np.int64)
         # need[r][q] = sorted global ids owned by q that appear as neighbours of nodes owned by r
-        self.need = [[None] * W for _ in range(W)]
+        cross = owner[i] != owner[j]
+        ci, cj = owner[i[cross]], j[cross]
+        self.need = [[np.zeros(0, dtype=np.int64)] * W for _ in range(W)]
         for r in range(W):
-            mine = owner[i] == r
-            nb = np.unique(j[mine])
-            for q in range(W):
-                self.need[r][q] = nb[owner[nb] == q] if q != r else np.zeros(0, dtype=np.int64)
+            nb = np.unique(cj[ci == r])
+            onb = owner[nb]
+            self.need[r] = [nb[onb == q] if q != r else np.zeros(0, dtype=np.int64) for q in range(W)]
         me = self.rank
         self.own_global = self.owned[me]
         self.n_own = int(self.own_global.size)
@@ -59,24 +70,73 @@ class ShardPlan(object):
         # local CSR of the owned nodes (in-edges in the original edge order), columns in local numbering
         order_e = np.argsort(i, kind="stable")
         js, is_ = j[order_e], i[order_e]
-        start = np.searchsorted(is_, np.arange(G), side="left")
-        stop = np.searchsorted(is_, np.arange(G), side="right")
+        start = np.searchsorted(is_, self.own_global, side="left")
+        stop = np.searchsorted(is_, self.own_global, side="right")
+        deg = stop - start
         rowptr = np.zeros(self.n_own + 1, dtype=np.int64)
-        cols = []
-        for k, g in enumerate(self.own_global):
-            c = g2l[js[start[g]:stop[g]]]
-            assert (c >= 0).all(), "halo is incomplete"
-            cols.append(c)
-            rowptr[k + 1] = rowptr[k] + c.size
+        rowptr[1:] = np.cumsum(deg)
+        take = np.repeat(start - rowptr[:-1], deg) + np.arange(int(rowptr[-1]))        # edge positions, row by row
+        col = g2l[js[take]] if take.size else np.zeros(0, dtype=np.int64)
+        assert (col >= 0).all(), "halo is incomplete"
         self.src_rowptr = rowptr.astype(np.int32)
-        self.src_col = (np.concatenate(cols) if cols else np.zeros(0)).astype(np.int32)
+        self.src_col = col.astype(np.int32)
         # what this rank sends to q = the rows q needs from it, as LOCAL owned indices, in q's halo order
         self.send_local = [g2l[self.need[q][me]] if q != me else np.zeros(0, dtype=np.int64) for q in range(W)]
         self.send_counts = [int(x.size) for x in self.send_local]
         self.recv_counts = [int(self.need[me][q].size) for q in range(W)]
+        # classes of owned nodes and the local processing order [SEND only | SEND and NEED | NEED only | interior]
+        send = np.zeros(self.n_own, dtype=bool)
+        if W > 1:
+            send[np.concatenate(self.send_local).astype(np.int64)] = True
+        need = np.zeros(self.n_own, dtype=bool)
+        if col.size:
+            row_of = np.repeat(np.arange(self.n_own), deg)
+            need[row_of[col >= self.n_own]] = True
+        loc = np.arange(self.n_own)
+        parts = [loc[send & ~need], loc[send & need], loc[~send & need], loc[~send & ~need]]
+        self.proc_order = np.concatenate(parts).astype(np.int32)
+        c = np.cumsum([0] + [p.size for p in parts])
+        self.r_send = (int(c[0]), int(c[2]))          # positions of the SEND nodes in proc_order
+        self.r_need = (int(c[1]), int(c[3]))          # positions of the NEED nodes
+        self.n_send_nodes, self.n_need_nodes = int(send.sum()), int(need.sum())
 
     def halo_fraction(self):
         return self.n_halo / max(1, self.n_own)
+
+
+class Transport(object):
+    """The two collectives of the sharded path. RCCL ("nccl") takes device buffers directly on the current stream; a process
+    group without device collectives (gloo: the CPU tests and the several-processes-on-one-GPU test) is served by staging
+    through host memory, which synchronises the calling stream -- test plumbing, not a data path."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.device_collectives = self.on and dist.get_backend(group) == "nccl"
+
+    def all_to_all_rows(self, recv, send, recv_counts, send_counts):
+        """recv [sum(recv_counts), C] <- send [sum(send_counts), C], row blocks grouped by peer."""
+        if not self.on:
+            return
+        if self.device_collectives or not send.is_cuda:
+            self.dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+            return
+        r = torch.empty(tuple(recv.shape), dtype=recv.dtype)
+        self.dist.all_to_all_single(r, send.cpu(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+        recv.copy_(r)
+
+    def all_gather_rows(self, out, x):
+        """out [world, n, C] <- x [n, C] of every rank."""
+        if not self.on:
+            out[0].copy_(x)
+            return
+        if self.device_collectives:
+            self.dist.all_gather_into_tensor(out.view(-1, x.shape[1]), x, group=self.group)
+            return
+        parts = [torch.empty(tuple(x.shape), dtype=x.dtype) for _ in range(out.shape[0])]
+        self.dist.all_gather(parts, x.cpu(), group=self.group)
+        out.copy_(torch.stack(parts))
 
 
 def exchange_halo_rows(rows_own, plan, n_sta, group=None):
@@ -84,59 +144,76 @@ def exchange_halo_rows(rows_own, plan, n_sta, group=None):
 
     One `all_to_all_single` (RCCL on GPUs; gloo in the CPU tests): rank r sends, to every peer q, the S-row blocks of
     its owned nodes that q lists in `need[q][r]`."""
-    import torch.distributed as dist
     C = rows_own.shape[1]
     S = int(n_sta)
     blocks = rows_own.view(plan.n_own, S * C)
     send_idx = torch.as_tensor(np.concatenate(plan.send_local).astype(np.int64), device=rows_own.device)
     send = blocks.index_select(0, send_idx).contiguous() if send_idx.numel() else blocks.new_zeros((0, S * C))
     recv = blocks.new_empty((plan.n_halo, S * C))
-    if plan.world == 1:
-        return recv.view(-1, C)
-    dist.all_to_all_single(recv, send, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts, group=group)
+    if plan.world > 1:
+        Transport(group).all_to_all_rows(recv, send, plan.recv_counts, plan.send_counts)
     return recv.view(plan.n_halo * S, C)
 
 
-def allgather_owned(x_own, plan, group=None):
-    """All-gather a per-owned-source-node tensor `[n_own, C]` into global order `[G, C]`."""
-    import torch.distributed as dist
-    if plan.world == 1:
-        out = x_own.new_empty((plan.n_grid, x_own.shape[1]))
-        out[torch.as_tensor(plan.own_global, device=x_own.device)] = x_own
-        return out
+def gather_index(plan):
+    """int64 [G]: position of global source node g inside the all-gathered `[world, n_max, C]` buffer."""
     n_max = max(len(o) for o in plan.owned)
-    pad = x_own.new_zeros((n_max, x_own.shape[1]))
-    pad[: plan.n_own] = x_own
-    parts = [torch.empty_like(pad) for _ in range(plan.world)]
-    dist.all_gather(parts, pad, group=group)
-    out = x_own.new_empty((plan.n_grid, x_own.shape[1]))
+    idx = np.empty(plan.n_grid, dtype=np.int64)
     for r in range(plan.world):
-        out[torch.as_tensor(plan.owned[r], device=x_own.device)] = parts[r][: len(plan.owned[r])]
-    return out
+        idx[plan.owned[r]] = r * n_max + np.arange(len(plan.owned[r]))
+    return idx, n_max
+
+
+def allgather_owned(x_own, plan, group=None, index=None):
+    """All-gather a per-owned-source-node tensor `[n_own, C]` into global order `[G, C]`: one collective on rows padded to
+    the largest shard and one `index_select` with the precomputed `gather_index(plan)`."""
+    if index is None:
+        idx, n_max = gather_index(plan)
+        index = (torch.as_tensor(idx, device=x_own.device), n_max)
+    idx_t, n_max = index
+    pad = x_own if plan.n_own == n_max else torch.cat((x_own, x_own.new_zeros((n_max - plan.n_own, x_own.shape[1]))))
+    buf = x_own.new_empty((plan.world, n_max, x_own.shape[1]))
+    Transport(group).all_gather_rows(buf, pad.contiguous())
+    return buf.view(-1, x_own.shape[1]).index_select(0, idx_t)
 
 
 class ShardedPath(object):
     """Sharded DataAggregation + Bipartite on this rank's GPU, replicated SpatialAggregation / read-out.
 
-    sta_csr: (rowptr, col) of the station graph; A_src_src: global [2, E]; edge_attr_own: [n_own*S, 3] rows of the
-    owned nodes in local order; pos_global: [G, 3]; pos_sta: optional [S, 3] station positions -> station processing order
-    (the same on every rank: the halo rows of `wv` travel in that order)."""
+    sta_csr: (rowptr, col) of the station graph; A_src_src: global [2, E]; pos_global: [G, 3]; pos_sta: optional [S, 3]
+    station positions -> station processing order (the same on every rank: the halo rows of `wv` travel in that order).
+    `overlap=False` runs the window as four sequential steps (stage 1, exchange, stage 2, all-gather) on one stream: the
+    A/B reference for the overlapped schedule (bit-identical results)."""
 
     def __init__(self, n_sta, n_grid, sta_csr, A_src_src, pos_global, world, rank, device, group=None, scale_rel=30000.0,
-                 pos_sta=None):
+                 pos_sta=None, overlap=True):
         from . import engine
         self.group = group
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
         order = engine.sfc_order(np.asarray(pos_global))
         self.plan = ShardPlan(A_src_src, n_grid, world, rank, order)
         p = self.plan
+        self.overlap = bool(overlap)
         self.local = engine.HipPath(n_sta, p.n_own, sta_csr, (torch.from_numpy(p.src_rowptr), torch.from_numpy(p.src_col)),
-                                    n_grid_ext=p.n_ext, grid_order=None, scale_rel=scale_rel, device=device,
+                                    n_grid_ext=p.n_ext, grid_order=p.proc_order, scale_rel=scale_rel, device=device,
                                     sta_order=engine.sfc_order(np.asarray(pos_sta)) if pos_sta is not None else None)
         self.full = engine.HipPath(1, n_grid, (torch.zeros(2, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)),
                                    engine.csr_from_edges(torch.as_tensor(A_src_src), n_grid), grid_order=None,
                                    scale_rel=scale_rel, device=device)
-        self.device = self.local.device
+        self.device = dev = self.local.device
+        self.transport = Transport(group)
+        S = self.n_sta
+        pitch = int(self.local.lib.genie_ws_v_pitch(self.local.ctx))
+        self._pitch = pitch
+        # static exchange state: send-row index, send buffer, the halo part of `wv` inside the workspace (received in place)
+        self._send_idx = torch.as_tensor(np.concatenate(p.send_local).astype(np.int64) if world > 1 else np.zeros(0, np.int64), device=dev)
+        self._send_buf = torch.empty((int(self._send_idx.numel()), S * pitch), dtype=torch.float32, device=dev)
+        idx, n_max = gather_index(p)
+        self._gather = (torch.as_tensor(idx, device=dev), n_max)
+        self._bip_pad = torch.zeros((n_max, 15), dtype=torch.float32, device=dev)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.local.device.type == "cuda" else None
+        self.tail_stream = torch.cuda.Stream(device=dev) if self.local.device.type == "cuda" else None
+        self._tail_done = None
 
     def set_weights(self, named):
         self.local.set_weights(named)
@@ -144,26 +221,95 @@ class ShardedPath(object):
 
     def wv_view(self):
         """Float view [n_ext*S, 16] of the projected operand `wv` inside the local workspace."""
-        import ctypes
         lp = self.local
         ptr = lp.lib.genie_ws_v_ptr(lp.ctx, lp._ws_ptr)
         off = int(ptr) - lp.ws.data_ptr()
-        pitch = int(lp.lib.genie_ws_v_pitch(lp.ctx))
-        n = self.plan.n_ext * self.n_sta * pitch
-        return lp.ws[off: off + 4 * n].view(torch.float32).view(self.plan.n_ext * self.n_sta, pitch)
+        n = self.plan.n_ext * self.n_sta * self._pitch
+        return lp.ws[off: off + 4 * n].view(torch.float32).view(self.plan.n_ext * self.n_sta, self._pitch)
 
-    def path_fwd(self, Slice_ext, Mask_ext, edge_attr_own, pos_global):
-        """Slice_ext / Mask_ext: [n_ext*S, 4] rows of owned then halo source nodes (local order). Returns x_spatial [G,30]."""
+    def _exchange(self, wv):
+        """Pack the SEND rows, all-to-all, halo rows received in place (the halo part of `wv` is contiguous, grouped by owner)."""
+        p, S = self.plan, self.n_sta
+        if not p.n_halo and not self._send_idx.numel():
+            return
+        blocks = wv[: p.n_own * S].view(p.n_own, S * self._pitch)
+        if self._send_idx.numel():
+            torch.index_select(blocks, 0, self._send_idx, out=self._send_buf)
+        recv = wv[p.n_own * S:].view(p.n_halo, S * self._pitch)
+        self.transport.all_to_all_rows(recv, self._send_buf, p.recv_counts, p.send_counts)
+
+    def front(self, Slice_ext, Mask_ext, edge_attr_own):
+        """Sharded DataAggregation + Bipartite of one window on the current stream (+ the communication stream): returns the
+        all-gathered Bipartite output `[G, 15]` in global order, produced on the current stream."""
         p, S = self.plan, self.n_sta
         lp = self.local
-        Slice_ext, Mask_ext = lp.da_stage1(Slice_ext, Mask_ext)
-        wv = self.wv_view()
-        if p.n_halo:
-            wv[p.n_own * S:] = exchange_halo_rows(wv[: p.n_own * S], p, S, self.group)
+        P_ext = p.n_ext * S
+        Slice_ext = lp_f32(Slice_ext, "Slice", (P_ext, 4))
+        Mask_ext = lp_f32(Mask_ext, "Mask", (P_ext, 4))
+        edge_attr_own = lp_f32(edge_attr_own, "edge_attr", (p.n_own * S, 3))
         Mask_own = Mask_ext[: p.n_own * S]
-        _, bip_own = lp.da_stage2_bipartite(Mask_own, edge_attr_own)
-        bip = allgather_owned(bip_own, p, self.group)
-        o = bip
-        for layer in (1, 2, 3):
-            o = self.full.spatial_agg(layer, o, pos_global)
-        return o
+        wv = self.wv_view()
+        main = torch.cuda.current_stream(self.device)
+        (s0, s1), (n0, n1), n = p.r_send, p.r_need, p.n_own
+        if not self.overlap or p.world == 1:
+            lp.da_stage1_range(Slice_ext, Mask_ext, 0, n, True)
+            self._exchange(wv)
+            lp.da_stage2_partials_range(Mask_own, edge_attr_own, 0, n)
+        else:
+            comm = self.comm_stream
+            lp.da_stage1_range(Slice_ext, Mask_ext, s0, s1, True)                 # rows other ranks wait for
+            ev = torch.cuda.Event()
+            ev.record(main)
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                self._exchange(wv)
+                halo = torch.cuda.Event()
+                halo.record(comm)
+            lp.da_stage1_range(Slice_ext, Mask_ext, s1, n, False)                 # under the exchange
+            lp.da_stage2_partials_range(Mask_own, edge_attr_own, 0, n0)           # nodes without halo neighbours
+            lp.da_stage2_partials_range(Mask_own, edge_attr_own, n1, n)
+            main.wait_event(halo)
+            lp.da_stage2_partials_range(Mask_own, edge_attr_own, n0, n1)
+        bip_own = lp.bipartite_readout()
+        return bip_own
+
+    def gather_and_tail(self, bip_own, pos_global, tail=None):
+        """All-gather of the Bipartite output, SpatialAggregation x3 (replicated) and `tail(x_spatial)` (the read-outs)."""
+        p = self.plan
+        idx_t, n_max = self._gather
+        pad = self._bip_pad if p.n_own != n_max else None
+        if pad is not None:
+            pad[: p.n_own].copy_(bip_own)
+        buf = bip_own.new_empty((p.world, n_max, 15))
+        self.transport.all_gather_rows(buf, pad if pad is not None else bip_own)
+        o = self.full.spatial_agg3(buf.view(-1, 15).index_select(0, idx_t), pos_global)
+        return o if tail is None else tail(o)
+
+    def path_fwd(self, Slice_ext, Mask_ext, edge_attr_own, pos_global, tail=None, pipelined=False):
+        """Slice_ext / Mask_ext: [n_ext*S, 4] rows of owned then halo source nodes (local order). Returns x_spatial [G,30]
+        (or `tail(x_spatial)`). `pipelined`: the all-gather and the G-sized kernels run on the tail stream, where they overlap
+        the NEXT window's P-sized kernels (windows are independent in the apply loop); the result is then produced on
+        `self.tail_stream` -- consume it there or after `wait_tail()`."""
+        bip_own = self.front(Slice_ext, Mask_ext, edge_attr_own)
+        if not pipelined:
+            return self.gather_and_tail(bip_own, pos_global, tail)
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        ts = self.tail_stream
+        ts.wait_event(ev)
+        bip_own.record_stream(ts)
+        with torch.cuda.stream(ts):
+            out = self.gather_and_tail(bip_own, pos_global, tail)
+            self._tail_done = torch.cuda.Event()
+            self._tail_done.record(ts)
+        return out
+
+    def wait_tail(self):
+        if self._tail_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._tail_done)
+
+
+def lp_f32(t, name, shape):
+    from . import engine
+    return engine._f32(t, name, shape)

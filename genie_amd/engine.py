@@ -251,6 +251,22 @@ class HipPath(object):
                                                   _stream()), "genie_da_stage1_debug")
         return Slice, Mask, h0, h1
 
+    def da_stage1_range(self, Slice, Mask, gi_begin, gi_end, first):
+        """Stage 1 of the owned source nodes at positions [gi_begin, gi_end) of the processing order (genie_da_stage1_range);
+        `first`: the first range call of this window (runs the split pass over all rows)."""
+        _lib.check(self.lib.genie_da_stage1_range(self.ctx, _ptr(Slice), _ptr(Mask), int(gi_begin), int(gi_end), 1 if first else 0,
+                                                  self._ws_ptr, _stream()), "genie_da_stage1_range")
+
+    def da_stage2_partials_range(self, Mask, edge_attr, gi_begin, gi_end):
+        """Stage-2 partials of the owned source nodes at positions [gi_begin, gi_end) (genie_da_stage2_partials_range)."""
+        _lib.check(self.lib.genie_da_stage2_partials_range(self.ctx, _ptr(Mask), _ptr(edge_attr), None, int(gi_begin), int(gi_end),
+                                                           self._ws_ptr, _stream()), "genie_da_stage2_partials_range")
+
+    def bipartite_readout(self):
+        bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_bipartite_readout(self.ctx, _ptr(bip), self._ws_ptr, _stream()), "genie_bipartite_readout")
+        return bip
+
     def da_stage2_bipartite(self, Mask, edge_attr, want_x_latent=False):
         edge_attr = _f32(edge_attr, "edge_attr", (self.n_prod, 3))
         self._refresh_static_edge_attr(edge_attr)
@@ -267,6 +283,15 @@ class HipPath(object):
         out = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_spatial_agg_fwd(self.ctx, layer, _ptr(x_in), _ptr(pos), _ptr(out), self._ws_ptr,
                                                   _stream()), "genie_spatial_agg_fwd")
+        return out
+
+    def spatial_agg3(self, x_in15, pos):
+        """SpatialAggregation1 -> 2 -> 3 chained (genie_spatial_agg3_fwd, module.py:1012-1014): [G, 15] -> [G, 30]."""
+        x_in15 = _f32(x_in15, "x_in15", (self.n_grid, 15))
+        pos = _f32(pos, "pos", (self.n_grid, 3))
+        out = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_spatial_agg3_fwd(self.ctx, _ptr(x_in15), _ptr(pos), _ptr(out), self._ws_ptr, _stream()),
+                   "genie_spatial_agg3_fwd")
         return out
 
     def path_fwd(self, Slice, Mask, edge_attr, pos, want_x_latent=False, want_bip=False):

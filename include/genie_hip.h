@@ -154,6 +154,13 @@ size_t genie_workspace_bytes(const genie_ctx* ctx);
  * c, wu, wv are kept in the workspace; h1, u, v never leave the registers.
  */
 int genie_da_stage1(genie_ctx* ctx, const float* slice, const float* mask, void* ws, void* stream);
+/* Sub-range form for the source-node-sharded case (the halo exchange of `wv` overlaps compute): only the owned
+ * source nodes at positions [gi_begin, gi_end) of the processing order (`grid_order` of genie_ctx_create) are processed.
+ * `first` != 0 on the first range call of a window: it runs the input split pass over ALL rows (owned + halo); later range
+ * calls of the same window (same slice / mask / workspace / slot) pass 0. A caller that puts the nodes other ranks need first
+ * in the processing order can start sending their `wv` rows while the rest of stage 1 runs. */
+int genie_da_stage1_range(genie_ctx* ctx, const float* slice, const float* mask, int gi_begin, int gi_end, int first,
+                          void* ws, void* stream);
 /* Parity/debug variant: additionally writes h0 [n_grid*n_sta, 30] and h1 [n_grid*n_sta, 60]. */
 int genie_da_stage1_debug(genie_ctx* ctx, const float* slice, const float* mask, float* h0_out, float* h1_out,
                           void* ws, void* stream);
@@ -177,6 +184,10 @@ int genie_da_stage2_bipartite(genie_ctx* ctx, const float* mask, const float* ed
  * per-tile station-sum partials (the P-sized kernel), then r_g = sum of partials and out_g = PReLU_b2(fc2 r_g). */
 int genie_da_stage2_partials(genie_ctx* ctx, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
                              void* stream);
+/* ... and the sub-range form of the P-sized half: partials of the owned source nodes at positions [gi_begin, gi_end) of the
+ * processing order only. Nodes without halo neighbours can run before the halo rows of `wv` have arrived. */
+int genie_da_stage2_partials_range(genie_ctx* ctx, const float* mask, const float* edge_attr, float* x_latent_out,
+                                   int gi_begin, int gi_end, void* ws, void* stream);
 int genie_bipartite_readout(genie_ctx* ctx, float* bip_out, void* ws, void* stream);
 /*
  * SpatialAggregation (module.py:243-249; instances :889-891) on the source graph of this context.

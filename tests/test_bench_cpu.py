@@ -1,0 +1,46 @@
+"""CPU: `python bench.py --gpus N` launches its own N ranks (the driver may also start it under torchrun); the dry-run form
+exercises the launcher, the rank environment, the sharding plan and both collectives of the sharded path over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_bench_gpus_n_launches_n_ranks(n):
+    out = _run(["--gpus", str(n), "--dry-run-cpu"])
+    assert out["n_gpus"] == n and out["ranks"] == n and out["ok"] is True
+    assert (out["rank0_plan"]["n_halo"] > 0) == (n > 1)
+
+
+def test_bench_defaults_pick_the_sharded_config_for_several_gpus():
+    sys.path.insert(0, REPO)
+    import importlib
+    bench = importlib.import_module("bench")
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8"]
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.mode is None and a.config is None and a.gpus == 8          # resolved in main(): sharded cfg4 when world > 1
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert 'a.mode = "sharded" if world > 1 else "replicas"' in src
+    assert '"cfg4_2000x50k" if (a.mode == "sharded" and world > 1) else "cfg2_200x10k"' in src

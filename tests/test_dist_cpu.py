@@ -122,5 +122,17 @@ def test_shard_plan_invariants(world):
             if q.rank != p.rank:
                 assert np.array_equal(p.own_global[p.send_local[q.rank]], q.need[q.rank][p.rank])
                 assert p.send_counts[q.rank] == q.recv_counts[p.rank]
+        # processing order = [SEND only | SEND and NEED | NEED only | interior]: the SEND / NEED nodes are exactly the
+        # sub-ranges r_send / r_need of it (what genie_da_stage1_range / genie_da_stage2_partials_range are launched on)
+        assert sorted(p.proc_order.tolist()) == list(range(p.n_own))
+        sent = set(np.concatenate(p.send_local).astype(int).tolist()) if world > 1 else set()
+        needy = {k for k in range(p.n_own) if (p.src_col[p.src_rowptr[k]:p.src_rowptr[k + 1]] >= p.n_own).any()}
+        assert set(p.proc_order[p.r_send[0]:p.r_send[1]].tolist()) == sent
+        assert set(p.proc_order[p.r_need[0]:p.r_need[1]].tolist()) == needy
+        assert p.r_send[0] == 0 and p.r_send[0] <= p.r_need[0] <= p.r_send[1] <= p.r_need[1] <= p.n_own
+        idx, n_max = gdist.gather_index(p)
+        assert n_max == max(q.n_own for q in plans) and len(set(idx.tolist())) == geom.n_grid
+        for q in plans:
+            assert np.array_equal(idx[q.own_global], q.rank * n_max + np.arange(q.n_own))
     if world == 1:
-        assert plans[0].n_halo == 0
+        assert plans[0].n_halo == 0 and plans[0].r_send == (0, 0) and plans[0].r_need == (0, 0)
