@@ -178,3 +178,30 @@ def subgraph_product_edges(A_sta_sta, A_src_src, A_src_in_sta):
     A2 = induced(A_src, src, False)
     A_src_in_prod = torch.stack((torch.arange(N), torch.from_numpy(src.copy())), dim=0)
     return A1, A2, A_src_in_prod
+
+
+def time_pointers(trv_out, max_t=None, dt=1.0, k=10, win=10.0):
+    """Per-station time-bin -> k nearest product nodes tables of the association heads, as
+    `assemble_time_pointers_for_stations` builds them (`/root/reference/Code/utils.py:602-622`, called at
+    `train_GENIE_model.py:1364`, `process_continuous_days.py:620`).
+
+    trv_out [G, S, 2]: theoretical P / S travel time per (source node, station). For every station i and every time step t of
+    `dt_partition = arange(-win, win + max_t + dt, dt)` the k source nodes whose travel time to i is nearest t (nearest
+    first), as product-node ids `g * S + i`. Returns (edges_p, edges_s, dt_partition): int64 [S * len(dt_partition) * k],
+    laid out [station][time step][k] (what `LocalSliceLgCollapse` indexes with `ipick * l_dt * k + t_index * k + arange(k)`,
+    module.py:635-637)."""
+    trv = np.asarray(trv_out)
+    n_src, n_sta = trv.shape[0], trv.shape[1]
+    if max_t is None:
+        max_t = trv.max()
+    dt_partition = np.arange(-win, win + max_t + dt, dt)
+    k = int(min(k, n_src))
+    out = []
+    for ph in (0, 1):
+        e = np.empty((n_sta, len(dt_partition), k), dtype=np.int64)
+        for i in range(n_sta):
+            d = np.abs(trv[:, i, ph].astype(np.float64)[None, :] - dt_partition[:, None])      # [n_t, G]
+            ip = np.argsort(d, axis=1, kind="stable")[:, :k]
+            e[i] = ip * n_sta + i
+        out.append(e.reshape(-1))
+    return out[0], out[1], dt_partition

@@ -142,3 +142,30 @@ def make_window(geom, n_picks, seed=2, window=0, g_slice=None):
     return {"Slice": Slice, "Mask": Mask, "P": P,
             "tpick": P[order, 0].astype(np.float32), "ipick": P[order, 1].astype(np.int64),
             "phase_label": P[order, 4].astype(np.float32).reshape(-1, 1), "n_picks": int(P.shape[0])}
+
+
+def training_sample(geom, n_picks, n_src=4, seed=3, window=0):
+    """Everything one training-mode call `mz(*input_tensors)` consumes (train_GENIE_model.py:1770-1786) for a synthetic window
+    on `geom`, plus seeded random labels of the right shapes: dict of numpy arrays. The association-head tables come from
+    `graph.time_pointers` (utils.py:602-622 as called at train_GENIE_model.py:1364: k = 10, dt = kernel_sig_t / 5, win = 2 x
+    kernel_sig_t)."""
+    win = make_window(geom, n_picks, seed=seed, window=window)
+    trv = geom.travel_times().astype(np.float32)                                   # [G, S, 2]
+    max_t = float(np.ceil(trv.max()))
+    A_edges_p, A_edges_s, dt_partition = _graph.time_pointers(trv, max_t=max_t, dt=KERNEL_SIG_T / 5.0, k=10, win=2.0 * KERNEL_SIG_T)
+    rng = np.random.default_rng([seed, window, 17])
+    nodes = rng.choice(geom.n_grid, n_src, replace=False)
+    x_query_src = geom.x_grid[nodes] + rng.normal(0.0, 500.0, (n_src, 3))
+    tq_sample = rng.uniform(-2.0, 2.0, n_src).astype(np.float32)
+    d = np.linalg.norm(x_query_src[:, None, :] - geom.locs[None, :, :], axis=2)
+    trv_out_q = np.stack([d / VP, d / VS], axis=2).astype(np.float32)
+    keep = (win["tpick"] > dt_partition[0] + 0.5) & (win["tpick"] < dt_partition[-1] - 0.5)    # inside the time-pointer table
+    out = {"Slice": win["Slice"], "Mask": win["Mask"], "tpick": win["tpick"][keep], "ipick": win["ipick"][keep],
+           "phase_label": win["phase_label"][keep], "A_edges_p": A_edges_p, "A_edges_s": A_edges_s,
+           "dt_partition": dt_partition.astype(np.float32), "tlatent": trv.reshape(-1, 2), "x_query_src": x_query_src.astype(np.float32),
+           "tq_sample": tq_sample, "trv_out_q": trv_out_q}
+    T = geom.t_query.shape[0]
+    out["Lbls"] = rng.random((geom.n_grid, T)).astype(np.float32) * (rng.random((geom.n_grid, 1)) < 0.1)
+    out["Lbls_query"] = rng.random((geom.x_query.shape[0], T)).astype(np.float32) * (rng.random((geom.x_query.shape[0], 1)) < 0.1)
+    out["pick_lbls"] = (rng.random((n_src, int(keep.sum()), 2)) < 0.05).astype(np.float32)
+    return out

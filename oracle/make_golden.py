@@ -78,7 +78,7 @@ def _hook_intermediates(mz):
 
 def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, window=None,
              keep=("h0", "h1", "u", "v", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"),
-             row_stride=1, keep64=None, pairs=None):
+             row_stride=1, keep64=None, pairs=None, gain=1.0, write=True):
     """`pairs` [2, N] (station, source), sorted by (source, station): run the reference on the IRREGULAR product graph of
     `use_subgraph: True` (process_utils.py:744-849) whose nodes are those pairs; Slice / Mask then have N rows."""
     import torch
@@ -104,6 +104,10 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
             for n_, p_ in mz.named_parameters():
                 if p_.numel() == 1:
                     p_.data.fill_(float(0.05 + 0.45 * torch.rand(1, generator=g)))
+        if gain != 1.0:            # every Linear weight (not the biases) scaled: activations grow layer by layer, outputs reach O(1)
+            for n_, p_ in mz.named_parameters():
+                if p_.dim() == 2:
+                    p_.data.mul_(gain)
         sd32 = {k: v.detach().clone().numpy() for k, v in mz.state_dict().items()}
         mz = mz.to(dtype).eval()
         store, handles = _hook_intermediates(mz)
@@ -144,6 +148,9 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
     })
     if pairs is not None:
         results["pairs"] = np.asarray(pairs, dtype=np.int64)
+    results["weight_gain"] = np.float64(gain)
+    if not write:
+        return results
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **results)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0),
@@ -295,7 +302,39 @@ def main_subgraph():
     print("wrote subgraph_builder_14x50.npz: %d product nodes" % out[5].shape[1])
 
 
+def main_scaled():
+    """`python oracle/make_golden.py --scaled`: (vi) config-1 shape with every Linear weight multiplied by a common gain chosen
+    so that max|y|, max|x| are O(1) (with default-initialised weights the outputs are ~0.03 and the 1e-5 absolute tolerance of
+    BASELINE.json is a loose relative one); (vii) 2000 stations x 24 source nodes: the station sum of the Bipartite read-in
+    over 2000 terms (the reference's own fp32-vs-fp64 drift there is 2.7e-4 absolute)."""
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(20, 500, L=100e3, n_query=300, seed=1)
+    win = syn.make_window(geom, 2000, seed=2)
+    kw = dict(window=win, row_stride=7, perturb_prelu=True, keep=("x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"),
+              keep64=("bip", "sa3"))
+    chosen = None
+    for gain in (2.0, 2.1, 2.2, 2.3, 2.4, 2.5, 2.6, 2.8, 3.0):
+        r = run_case(ref, "o1_20x500", geom, win["Slice"], win["Mask"], gain=gain, write=False, **kw)
+        my, mx = float(np.abs(r["y"]).max()), float(np.abs(r["x"]).max())
+        print("gain %.2f: max|y| %.3f max|x| %.3f" % (gain, my, mx))
+        if min(my, mx) >= 0.5:
+            chosen = gain
+            break
+    assert chosen is not None
+    run_case(ref, "o1_20x500", geom, win["Slice"], win["Mask"], gain=chosen, **kw)
+
+    geom = syn.Geometry(2000, 24, L=1000e3, n_query=40, seed=111)
+    win = syn.make_window(geom, 24000, seed=112)
+    run_case(ref, "s2000_2000x24", geom, win["Slice"], win["Mask"], window=win, perturb_prelu=True, row_stride=97,
+             keep=("x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
+
+
 def main():
+    if "--scaled" in sys.argv:
+        return main_scaled()
     if "--edges" in sys.argv:
         return main_edges()
     if "--subgraph" in sys.argv:

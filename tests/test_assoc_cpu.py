@@ -58,3 +58,13 @@ def test_product_heads_match_reference_given_oracle_front():
         arv = net.Arrivals(4, t("tq_sample"), x_src, t("trv_out_q"), arv_p, arv_s, t("tpick"), t("ipick", torch.long), t("phase_label"))
     assert max_abs(arv[:, :, 0:1], t("arv_p")) <= 2e-6
     assert max_abs(arv[:, :, 1:2], t("arv_s")) <= 2e-6
+
+
+def test_time_pointers_match_the_reference_tables():
+    """genie_amd.graph.time_pointers restates utils.py:602-622; the fixture's tables came from the reference function itself."""
+    z, w, t = load()
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    trv = np.asarray(z["tlatent"]).reshape(G, S, 2)
+    ep, es, dtp = graph.time_pointers(trv, max_t=float(z["max_t"]), dt=3.0 / 5.0, k=10, win=6.0)
+    assert np.allclose(dtp, z["dt_partition"])
+    assert ep.shape == z["A_edges_p"].shape and np.array_equal(ep, z["A_edges_p"]) and np.array_equal(es, z["A_edges_s"])

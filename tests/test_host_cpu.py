@@ -229,3 +229,23 @@ def test_query_knn_cache_cannot_return_a_stale_table():
     assert torch.equal(t2, module.knn_query_edges(xc, xq, 10)[0].view(50, 10).int()) and not torch.equal(t1, t2)
     sa.invalidate_query_cache()
     assert sa._edge_cache == {}
+
+
+def test_subset_oracle_matches_the_full_structured_oracle():
+    """tests.util.oracle_bipartite_for_nodes (the oracle on the two-hop neighbourhood of a few source nodes, used to check
+    config-4-sized runs) against the full structured oracle on a problem small enough to evaluate whole."""
+    from genie_amd import graph, synthetic
+    from oracle import genie_oracle as O
+    from tests.util import Case, max_abs, oracle_bipartite_for_nodes
+    S, G = 23, 300
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=5, seed=7)
+    P = synthetic.make_picks(geom, 500, seed=8)
+    Slice, Mask = synthetic.make_slice_mask(geom, P, 0.0)
+    w = Case("odd_33x257").weights
+    sta, src = graph.neighbour_table(geom.A_sta_sta, S), graph.neighbour_table(geom.A_src_src, G)
+    xl = O.data_aggregation_structured(w, torch.from_numpy(Slice), torch.from_numpy(Mask), sta, src, S, G)
+    bip = O.bipartite_read_in_structured(w, xl, torch.from_numpy(geom.edge_attr()), torch.from_numpy(Mask), S, G)
+    sample = np.array([5, 17, 299, 120])
+    b, x = oracle_bipartite_for_nodes(w, geom, P, sample)
+    assert max_abs(b, bip[sample]) <= 1e-6 * max(1.0, float(bip.abs().max()))
+    assert max_abs(x.view(4, S, -1), xl.view(G, S, -1)[sample]) <= 1e-6

@@ -22,8 +22,11 @@ def test_oracle_matches_reference_fp32(name, structured):
         tol = 2e-6 * max(1.0, float(ref.abs().max()))
         assert got.shape == ref.shape, k
         assert max_abs(got, ref) <= tol, (k, max_abs(got, ref), tol)
-    assert max_abs(out["y"], c.ref("y")) <= 1e-6
-    assert max_abs(out["x"], c.ref("x")) <= 1e-6
+    # outputs: 1e-6 absolute while they are below 1 in magnitude (default-initialised weights: ~0.03-0.15); 2e-6 relative to
+    # max|ref| for the fixture with O(1) outputs (`o1_20x500`: max|y| 7.2)
+    for k in ("y", "x"):
+        m = float(c.ref(k).abs().max())
+        assert max_abs(out[k], c.ref(k)) <= (1e-6 if m <= 1.0 else 2e-6 * m), (k, max_abs(out[k], c.ref(k)), m)
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -40,11 +43,20 @@ def test_oracle_matches_reference_fp64(name, structured):
 
 
 def test_reference_fp32_vs_fp64_drift_is_small():
-    """Document the reference's own fp32 drift on the outputs."""
+    """Document the reference's own fp32 drift on the outputs: below 1e-6 while the outputs are small,
+    7.6e-6 (1.05e-6 of max|y| = 7.2) on the fixture with O(1) outputs -- there the 1e-5 absolute tolerance of BASELINE.json is
+    a real constraint (about 1.3 times the reference's own fp32 rounding error). The station sum of the Bipartite read-in over
+    2000 stations (`s2000_2000x24`) drifts 1.7e-4 absolute at max|bip| = 313."""
     for name in GOLDEN_CASES:
         c = Case(name)
-        assert max_abs(c.ref("y"), c.ref("y64")) < 1e-6
-        assert max_abs(c.ref("x"), c.ref("x64")) < 1e-6
+        for k in ("y", "x"):
+            m = max(1.0, float(c.ref(k + "64").abs().max()))
+            assert max_abs(c.ref(k), c.ref(k + "64")) < 1.2e-6 * m, (name, k)
+    c = Case("o1_20x500")
+    assert float(c.ref("y").abs().max()) > 5.0 and float(c.ref("x").abs().max()) > 1.0
+    assert 5e-6 < max_abs(c.ref("y"), c.ref("y64")) < 1e-5
+    c = Case("s2000_2000x24")
+    assert c.S == 2000 and 1e-4 < max_abs(c.ref("bip"), c.ref("bip64")) < 3e-4 and float(c.ref("bip").abs().max()) > 300.0
 
 
 @pytest.mark.parametrize("name", EDGES_CASES)
