@@ -1941,6 +1941,172 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
 #undef PH
 }
 
+// Stage 2 with the station-neighbour operand staged in LDS. All T tiles of a source node gather their KS station-neighbour
+// rows from the SAME S rows wu[g] (64 B each): a workgroup takes NB consecutive source nodes of the processing order per
+// PHASE, copies their wu rows into LDS once (coalesced, each row read exactly once from memory), and its 4 waves then sweep
+// the NB * T tiles of the phase reading the station rows with ds_read_b128 instead of KS global gathers per lane; only the KP
+// source-neighbour rows of wv (and the streamed c / mask / edge_attr rows) still come through the texture path, software-
+// pipelined one tile ahead exactly as in k_stage2_fast. LDS image of a node: chunk (row r, part q) sits at chunk position
+// 4 r + (q ^ ((r >> 2) & 3)), so that rows r and r + 4 of one part do not meet on a bank. Same arithmetic and summation
+// order as k_stage2 / k_stage2_fast (bitwise identical results). NB is chosen by the host so that NB * T is a multiple of the
+// 4 waves where possible (S = 200: T = 13, NB = 4 -> 13 tiles per wave and phase) and NB * S * 64 B fits the LDS budget.
+template <int KS, int KP>
+__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, int NB) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    extern __shared__ f32x4 s2_smem[];
+    f32x4* lw = s2_smem;
+    f32x4* wul = s2_smem + NF4;                       // [NB][S * 4] swizzled 16-B chunks
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S, T = a.T;
+    const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+    const int gbeg = a.gi0 + (int)((long long)a.G * xcd / nx), gend = a.gi0 + (int)((long long)a.G * (xcd + 1) / nx);
+    const int nph = (gend - gbeg + NB - 1) / NB;
+    const char* wvb = (const char*)a.wv;
+    const unsigned q16 = 16u * (unsigned)q;
+    const unsigned m_T = ItemIter::recip((unsigned)T);
+    __syncthreads();
+    const float a2 = lscal[0], ab1 = lscal[1];
+
+    struct Ids { int idv, sc, su, tb, nl; bool valid; int sta[KS]; };
+    struct Rows { f32x4 o[2]; float mq, eq; f32x4 rv[KP]; };
+
+    for (int ph = lb; ph < nph; ph += nbx) {
+        const int g_first = gbeg + ph * NB;
+        const int nb = min(NB, gend - g_first);
+        const int ntile = nb * T;
+        __syncthreads();                                              // every wave has finished reading the previous image
+        for (int n = 0; n < nb; ++n) {
+            const int g = a.src_tab[(g_first + n) * 16];
+            const f32x4* src = (const f32x4*)(a.wu + (size_t)g * (size_t)S * ROWW);
+            f32x4* dst = wul + (size_t)n * S * 4;
+            for (int c = threadIdx.x; c < S * 4; c += 256) {
+                const int r = c >> 2, qq = (c & 3) ^ ((r >> 2) & 3);
+                dst[c] = src[r * 4 + qq];
+            }
+        }
+        __syncthreads();
+
+        auto fetch_ids = [&](int i, Ids& t) {
+            unsigned rem;
+            const unsigned nl = T <= 1 ? (rem = 0u, (unsigned)i) : ItemIter::fdiv((unsigned)i, (unsigned)T, m_T, rem);
+            t.nl = (int)nl;
+            t.tb = (int)rem;
+            t.idv = a.src_tab[(g_first + (int)nl) * 16 + j];
+            const int s_ = t.tb * 16 + j;
+            t.valid = s_ < S;
+            t.sc = t.valid ? s_ : S - 1;
+            t.su = a.sta_user != nullptr ? a.sta_user[t.sc] : t.sc;
+            load_sta_ids<KS>(a.sta_col, t.sc, t.sta);
+        };
+        auto issue = [&](const Ids& t, Rows& r, int part, unsigned tk) {
+            const int g = __builtin_amdgcn_readlane(t.idv, 0);
+            if (part == 0) {
+                const long long p = (long long)g * S + t.sc;
+                r.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q + tk);
+                r.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
+                if (a.sta_user != nullptr) {
+                    const long long pu = (long long)g * S + t.su;
+                    r.mq = q == 0 ? a.mm_int[p + tk] : -INFINITY;
+                    r.eq = q < 3 ? (a.ea_int != nullptr ? a.ea_int[p * 3 + q + tk] : a.edge_attr[pu * 3 + q + tk]) : 0.f;
+                } else {
+                    r.mq = a.mask[p * 4 + q + tk];
+                    r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
+                }
+            } else {
+                const unsigned so = (unsigned)t.sc * 64u + q16 + tk;
+                constexpr int KH = (KP + 1) / 2;
+#pragma unroll
+                for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k) {
+                    const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((size_t)S * 64u);
+                    r.rv[k] = *(const f32x4*)(wvk + so);
+                }
+            }
+        };
+        if (wave >= ntile) continue;                 // (uniform per wave; the barriers above are reached by every wave)
+        Ids cur, nxt, nn;
+        Rows rows;
+        fetch_ids(wave, cur);
+        nxt = cur;
+        if (wave + 4 < ntile) fetch_ids(wave + 4, nxt);
+        issue(cur, rows, 0, 0u);
+        issue(cur, rows, 1, 0u);
+        issue(cur, rows, 2, 0u);
+        for (int it = wave;; it += 4) {
+            asm volatile("" : "+v"(lane));
+            const bool has_next = it + 4 < ntile;
+            const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
+            // station-neighbour rows of this tile from the LDS image, in edge order
+            const f32x4* img = wul + (size_t)cur.nl * S * 4;
+            f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int r = cur.sta[k];
+                n1 += img[r * 4 + (q ^ ((r >> 2) & 3))];
+            }
+            f32x4 o[2] = {rows.o[0], rows.o[1]};
+            const float mq = rows.mq, eq = rows.eq;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
+            asm volatile("" : "+v"(n1), "+v"(n2), "+v"(o[0]), "+v"(o[1]));
+            unsigned tk = 0u;
+            asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
+            if (has_next) issue(nxt, rows, 0, tk);
+            n1 *= 1.f / (float)KS;
+            n2 *= 1.f / (float)KP;
+            o[0] = prelu4u(o[0] + n1, a2);
+            o[1] = prelu4u(o[1] + n2, a2);
+            if (a.x_latent != nullptr && cur.valid) {
+                float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (4 * q + r < 15) {
+                        xl[4 * q + r] = o[0][r];
+                        xl[15 + 4 * q + r] = o[1][r];
+                    }
+                }
+            }
+            f32x4 bp[2];
+            bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+            bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+            nn = nxt;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+                bp[t] = prelu4u(bp[t], ab1);
+                asm volatile("" : "+v"(tk), "+v"(bp[t]));
+                if (has_next) issue(nxt, rows, 1 + t, tk);
+            }
+            if (it + 8 < ntile) fetch_ids(it + 8, nn);
+            float mm = fmaxf(mq, __shfl_xor(mq, 16));
+            mm = fmaxf(mm, __shfl_xor(mm, 32));
+            if (!cur.valid) mm = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 v = bp[t] * mm;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    v.x += __shfl_xor(v.x, d);
+                    v.y += __shfl_xor(v.y, d);
+                    v.z += __shfl_xor(v.z, d);
+                    v.w += __shfl_xor(v.w, d);
+                }
+                if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 16 * t + 4 * q) = v;
+            }
+            if (!has_next) break;
+            cur = nxt;
+            nxt = nn;
+        }
+    }
+}
+
 // Stage 2 in the layout of k_stage1_b3: a wave owns two 16-station tiles, lane (j = lane&31, h = lane>>5) holds channels
 // 8*(r>>2) + 4h + (r&3) of x_latent in the 32-slot order of the c rows ([o1 (15), 0 | o2 (15), 0]); a gathered 64-B row is two
 // 16-B chunks per lane. Bipartite fc1 runs as 12 + 3 bf16x3 MFMAs; the station sum over the 16 nodes of a tile is a DPP row
@@ -3089,6 +3255,7 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
+    int s2_nb, s2_bpc;         // k_stage2_lds: source nodes per phase (0 = kernel not used) and workgroups per CU
     int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
     int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
@@ -3391,6 +3558,32 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
+        {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. Three workgroups per CU (the
+            // kernel's 164 VGPRs allow three waves per SIMD) matter more than a perfectly even split of the NB * T tiles over
+            // the 4 waves (measured at S = 200, T = 13: NB = 3 -> 0.216 ms, NB = 2 -> 0.218, NB = 4 with two workgroups per CU
+            // 0.251, k_stage2_fast 0.246): the largest-efficiency NB whose image leaves room for three workgroups, provided
+            // >= 90 % of the wave slots are used; otherwise (large S) k_stage2_fast. GENIE_S2_LDS=0 keeps k_stage2_fast.
+            c->s2_nb = 0; c->s2_bpc = 1;
+            const size_t img = sizeof(float) * (G2_GROUPS * 256 + G2_BIAS * 16 + 16);
+            const long long budget = (e = getenv("GENIE_S2_LDSKB")) ? 1024ll * atoi(e) : (long long)(160 * 1024 / 3 - img - 256);
+            const bool on = !((e = getenv("GENIE_S2_LDS")) && atoi(e) == 0);
+            if (on && c->ks_uni == 8 && c->kp_uni == 15) {
+                int best = 0; double best_eff = 0.0;
+                for (int n = 1; n <= 8 && (long long)n * n_sta * 64 <= budget; ++n) {
+                    const double eff = (double)(n * c->T) / (4.0 * ((n * c->T + 3) / 4));
+                    if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
+                }
+                if ((e = getenv("GENIE_S2_NB"))) { best = atoi(e); best_eff = 1.0; }
+                if (best > 0 && best_eff >= 0.9 && (long long)best * n_sta * 64 <= 150 * 1024) {
+                    c->s2_nb = best;
+                    const size_t lds = img + (size_t)best * n_sta * 64;
+                    HIP_TRY(hipFuncSetAttribute((const void*)k_stage2_lds<8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    int occ = 0;
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stage2_lds<8, 15>, 256, lds));
+                    c->s2_bpc = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ);
+                }
+            }
+        }
         // k_stage1_fast addresses the 16-B Slice / Mask rows with 32-bit byte offsets
         c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * 16 < (1ll << 32) && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
         // bf16x3 stage 1: same graph shape, 24-bit multiplicands (64-bit row offsets are a template variant)
@@ -3783,6 +3976,12 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     } else if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
         a.packed = c->packed_b3s2;
         k_stage2_b3<8, 15><<<da_grid(c, (n_tiles + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
+    } else if (c->use_fast && !c->nofast2 && c->s2_nb > 0) {
+        const size_t lds = sizeof(float) * (G2_GROUPS * 256 + G2_BIAS * 16 + 16) + (size_t)c->s2_nb * c->S * 64;
+        const long long phases = (a.G + c->s2_nb - 1) / c->s2_nb + 8;
+        long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
+        g = std::max<long long>(8, (g + 7) / 8 * 8);
+        k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
     } else if (c->use_fast && !c->nofast2)
         k_stage2_fast<8, 15><<<da_grid(c, n_tiles, c->bpc2f), 256, 0, st>>>(a);
     else

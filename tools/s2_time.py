@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Stage-2 kernel alone (HIP events over repeated launches after one stage 1), for A/B runs of kernel variants selected by
+environment variables (GENIE_S2_LDS=0 -> k_stage2_fast; GENIE_S2_NB / GENIE_S2_LDSKB / GENIE_BPC2 -> k_stage2_lds shapes).
+Usage: python tools/s2_time.py [config] [iters]"""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from genie_amd import engine, synthetic  # noqa: E402
+from tests.util import Case  # noqa: E402
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2_200x10k"
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    S, G, n_picks, L, nq = synthetic.CONFIGS[cfg]
+    geom = synthetic.Geometry(S, G, L=L, n_query=10, seed=1)
+    win = synthetic.make_window(geom, n_picks, seed=2)
+    dev = "cuda:0"
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                        engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
+                        grid_order=engine.sfc_order(geom.x_grid), device=dev, sta_order=engine.sfc_order(geom.locs))
+    hp.set_weights({k: v.to(dev) for k, v in Case("cfg1_20x500").weights.items()})
+    Slice, Mask = torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev)
+    ea = torch.from_numpy(geom.edge_attr()).to(dev)
+    hp.set_static_edge_attr(ea)
+    hp.da_stage1(Slice, Mask)
+    for _ in range(iters):
+        hp.da_stage2_partials_range(Mask, ea, 0, G)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        hp.da_stage2_partials_range(Mask, ea, 0, G)
+    e1.record()
+    torch.cuda.synchronize()
+    bip = hp.bipartite_readout()
+    tag = " ".join("%s=%s" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith("GENIE_"))
+    print("stage 2 %s [%s]: %.4f ms  (checksum %.6f)" % (cfg, tag or "defaults", e0.elapsed_time(e1) / iters, float(bip.double().sum())))
+
+
+if __name__ == "__main__":
+    main()
