@@ -60,6 +60,9 @@ SYMBOLS = [
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    ("genie_row_select_count", _c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_float, _c.c_int, _P, _P]),
+    ("genie_row_select_fill", _c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_float, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_ws_export", _c.c_int, [_P, _c.c_int, _P, _P, _P]),
     ("genie_embed_ntime", _c.c_int, [_c.c_double, _c.c_double, _c.c_double, _c.c_double]),
     ("genie_embed_window", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P, _P,

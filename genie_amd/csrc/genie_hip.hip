@@ -3174,6 +3174,111 @@ __global__ __launch_bounds__(256) void k_linear_bwd_sum(const float* __restrict_
     } else if (db && e - 32 * 64 * KC < M) db[e - 32 * 64 * KC] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact k-nearest-neighbour search on the device: the `knn(x_context / 1000, x_query / 1000, k)` calls of the
+// reference -- SpatialAttention's query edges (module.py:282; a NEW 112 000-point query set per candidate in the refine pass,
+// process_continuous_days.py:926-980) and the base graphs of the product graph (`knn(x/1000, x/1000, k + 1)` +
+// `remove_self_loops`, process_utils.py:718-719). Brute force in fp64 on the fp32 coordinates themselves (the
+// common 1 / 1000 scale does not change the order; coordinate differences of fp32 values are exact in fp64) (3-D, n_context
+// is 10^4..10^5: 10^9 pair distances = a millisecond): one wave per query, lane l scans candidates l, l + 64, ... keeping its K
+// best in registers (sorted, ties by smaller index), then K rounds of a wave-wide lexicographic (distance, index) minimum pop
+// the global K best in order. exclude_self: skip candidate == query id (query set = context set).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ xc, int nc, const float* __restrict__ xq, int nq, int k,
+                                             int exclude_self, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const double q0 = (double)xq[qi * 3 + 0], q1 = (double)xq[qi * 3 + 1], q2 = (double)xq[qi * 3 + 2];
+    double bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
+    for (int c = lane; c < nc; c += 64) {
+        if (exclude_self && c == qi) continue;
+        const double d0 = q0 - (double)xc[c * 3 + 0], d1 = q1 - (double)xc[c * 3 + 1], d2 = q2 - (double)xc[c * 3 + 2];   // exact
+        double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+        int id = c;
+        if (d < bd[K - 1]) {          // candidates arrive in increasing index order: a tie never displaces an earlier entry
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                if (d < bd[t]) {
+                    const double td = bd[t]; const int ti = bi[t];
+                    bd[t] = d; bi[t] = id; d = td; id = ti;
+                }
+            }
+        }
+    }
+    for (int r = 0; r < k; ++r) {
+        double md = bd[0];
+        int mi = bi[0];
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const double od = __shfl_xor(md, s);
+            const int oi = __shfl_xor(mi, s);
+            if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (bi[0] == mi && bd[0] == md) {        // the owner pops its head (indices are unique across lanes)
+#pragma unroll
+            for (int t = 0; t + 1 < K; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+            bd[K - 1] = __builtin_inf(); bi[K - 1] = 0x7fffffff;
+        }
+        if (lane == 0) out[(long long)qi * k + r] = mi == 0x7fffffff ? -1 : mi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Downstream reduction of the apply loop on the device: the stacked query output Out_2 [rows = queries,
+// cols = time steps] never leaves the GPU whole. MODE 0: entries above a threshold, `np.where(Out_2 > 0.01)`
+// (process_continuous_days.py:812-813). MODE 1: the local maxima of every row that reach `height`, i.e. the first two steps
+// of `scipy.signal.find_peaks(Out[i, :], height = thresh, ...)` (:846; scipy's `_local_maxima_1d`: a sample or the midpoint
+// of a flat run that is strictly higher than both neighbours, never the first or last sample; then `x >= height`).
+// One workgroup per row, chunks of 256 columns, selected entries written in column order at `offsets[row]` + rank
+// (two passes: COUNT fills counts[row], the caller scans them; the second pass fills) -> row-major order like np.where.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(256) void k_row_select(const float* __restrict__ x, long long cols, float thr, int32_t* __restrict__ counts,
+                                                    const long long* __restrict__ offsets, int32_t* __restrict__ out_row,
+                                                    int32_t* __restrict__ out_col, float* __restrict__ out_val) {
+    __shared__ int wsum[4];
+    const long long row = blockIdx.x;
+    const float* xr = x + row * cols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long base = COUNT ? 0 : offsets[row];
+    int total = 0;
+    for (long long c0 = 0; c0 < cols; c0 += 256) {
+        const long long i = c0 + threadIdx.x;
+        bool sel = false;
+        long long col = i;
+        float v = 0.f;
+        if (i < cols) {
+            v = xr[i];
+            if (MODE == 0) {
+                sel = v > thr;
+            } else if (i >= 1 && i + 1 < cols && v >= thr && xr[i - 1] < v) {      // rising edge into a candidate (flat) top
+                long long e = i + 1;
+                while (e < cols - 1 && xr[e] == v) ++e;
+                if (xr[e] < v) { sel = true; col = (i + e - 1) / 2; }
+            }
+        }
+        const unsigned long long b = __ballot(sel);
+        const int rank = __popcll(b & ((1ull << lane) - 1ull)), wtot = __popcll(b);
+        if (lane == 0) wsum[wave] = wtot;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (k < wave) before += wsum[k]; all += wsum[k]; }
+        if (!COUNT && sel) {
+            const long long o = base + total + before + rank;
+            out_row[o] = (int32_t)row; out_col[o] = (int32_t)col; out_val[o] = v;
+        }
+        total += all;
+        __syncthreads();
+    }
+    if (COUNT && threadIdx.x == 0) counts[row] = total;
+}
+
 #if GENIE_TUNING
 // which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
 __global__ void k_xcc_probe(int* __restrict__ out) {
@@ -4442,6 +4547,44 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
         else k_linear_bwd_w<2><<<nb, 256, 0, st>>>(x, dy + m0, N, K, mc, M, scratch);
         k_linear_bwd_sum<<<(per + 31) / 32, 256, 0, st>>>(scratch, nb, KC, K, mc, dW + (size_t)m0 * K, db ? db + m0 : nullptr);
     }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
+              int32_t* out_idx, void* stream) {
+    if (!x_context || !x_query || !out_idx || n_context < 1 || n_query < 0 || k < 1 || k > 16)
+        return fail(GENIE_ERR_ARG, "genie_knn: bad argument (1 <= k <= 16)");
+    if (n_query == 0) return GENIE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (n_query + 3) / 4;
+    if (k <= 8) k_knn<8><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+    else if (k <= 10) k_knn<10><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+    else k_knn<16><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_row_select_count(const float* x, int rows, int64_t cols, float threshold, int mode, int32_t* counts, void* stream) {
+    if (!x || !counts || rows < 0 || cols < 0 || cols >= (1ll << 31) || (mode != 0 && mode != 1))
+        return fail(GENIE_ERR_ARG, "genie_row_select_count: bad argument");
+    if (rows == 0) return GENIE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) k_row_select<0, true><<<rows, 256, 0, st>>>(x, cols, threshold, counts, nullptr, nullptr, nullptr, nullptr);
+    else k_row_select<1, true><<<rows, 256, 0, st>>>(x, cols, threshold, counts, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_row_select_fill(const float* x, int rows, int64_t cols, float threshold, int mode, const int64_t* offsets,
+                          int32_t* out_row, int32_t* out_col, float* out_val, void* stream) {
+    if (!x || !offsets || !out_row || !out_col || !out_val || rows < 0 || cols < 0 || cols >= (1ll << 31) || (mode != 0 && mode != 1))
+        return fail(GENIE_ERR_ARG, "genie_row_select_fill: bad argument");
+    if (rows == 0) return GENIE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long* off = (const long long*)offsets;
+    if (mode == 0) k_row_select<0, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
+    else k_row_select<1, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

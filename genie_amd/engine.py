@@ -33,27 +33,55 @@ def _f32(t, name, shape=None):
     return t
 
 
+def knn_device(x_context, x_query, k, exclude_self=False):
+    """int32 GPU table [n_query, k]: indices of the k nearest context points of every query, nearest first (genie_knn: exact
+    brute-force fp64 search on the device; the reference's `knn(x_context / 1000, x_query / 1000, k)`, module.py:282,
+    process_utils.py:718-719). `exclude_self`: query i never lists context i (query set = context set)."""
+    lib = _lib.load()
+    xc, xq = _f32(x_context, "x_context"), _f32(x_query, "x_query")
+    if xc.dim() != 2 or xc.shape[1] != 3 or xq.dim() != 2 or xq.shape[1] != 3:
+        raise ValueError("knn_device: positions must be [n, 3]")
+    k = int(min(k, xc.shape[0] - (1 if exclude_self else 0)))
+    if not 1 <= k <= 16:
+        raise ValueError("knn_device: 1 <= k <= 16")
+    out = torch.empty((xq.shape[0], k), dtype=torch.int32, device=xq.device)
+    with torch.cuda.device(xq.device):
+        _lib.check(lib.genie_knn(_ptr(xc), int(xc.shape[0]), _ptr(xq), int(xq.shape[0]), k, 1 if exclude_self else 0, _ptr(out),
+                                 _stream()), "genie_knn")
+    return out
+
+
+def knn_graph_device(points, k):
+    """Base kNN graph of a point set on the device: the layout of `remove_self_loops(knn(x, x, k + 1).flip(0))`
+    (process_utils.py:718-719) as (table int32 [n, k], edge list int64 [2, n * k] with row 0 = neighbour, row 1 = centre)."""
+    tab = knn_device(points, points, k, exclude_self=True)
+    n, kk = tab.shape
+    centre = torch.arange(n, device=tab.device).repeat_interleave(kk)
+    return tab, torch.stack((tab.reshape(-1).long(), centre), dim=0)
+
+
 def csr_from_edges(edge_index, n_target):
     """[2,E] edge list (row0 = j source, row1 = i target) -> (rowptr int32 [n+1], col int32 [E]);
     in-edges grouped by target in stable edge order."""
-    ei = torch.as_tensor(edge_index).long().cpu()
+    ei = torch.as_tensor(edge_index).long()          # stays on its device: a GPU edge list is sorted / counted on the GPU
+    dev = ei.device
     if ei.numel() == 0:
-        return torch.zeros(n_target + 1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)
+        return torch.zeros(n_target + 1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
     j, i = ei[0], ei[1]
     if int(i.max()) >= n_target or int(i.min()) < 0:
         raise ValueError("edge target out of range")
     order = torch.sort(i, stable=True)[1]
     deg = torch.bincount(i, minlength=n_target)
-    rowptr = torch.zeros(n_target + 1, dtype=torch.int64)
+    rowptr = torch.zeros(n_target + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(deg, 0)
     return rowptr.to(torch.int32), j[order].to(torch.int32).contiguous()
 
 
 def csr_from_table(nbr):
     """Uniform-degree neighbour table [n, k] -> CSR."""
-    nbr = torch.as_tensor(nbr).to(torch.int32).cpu()
+    nbr = torch.as_tensor(nbr).to(torch.int32)
     n, k = nbr.shape
-    rowptr = (torch.arange(n + 1, dtype=torch.int64) * k).to(torch.int32)
+    rowptr = (torch.arange(n + 1, dtype=torch.int64, device=nbr.device) * k).to(torch.int32)
     return rowptr, nbr.reshape(-1).contiguous()
 
 

@@ -260,6 +260,10 @@ class SpatialDirect(nn.Module):
 def knn_query_edges(x_context, x_query, k):
     """Exact kNN of each query in the context set on `x/1000` (module.py:282), evaluated in fp64 on the device.
     Returns LongTensor [2, Q*k]: row 0 = context j, row 1 = query i (the `.flip(0)` layout)."""
+    if x_context.is_cuda:         # exact brute-force search in one HIP kernel (genie_knn); the torch form below serves CPU tests
+        idx = _engine.knn_device(x_context, x_query, k).long()
+        row_q = torch.arange(x_query.shape[0], device=x_query.device).repeat_interleave(idx.shape[1])
+        return torch.stack([idx.reshape(-1), row_q], dim=0)
     xc = (x_context.double() / 1000.0)
     xq = (x_query.double() / 1000.0)
     k = min(k, xc.shape[0])
@@ -695,7 +699,7 @@ class GCN_Detection_Network_extended(nn.Module):
                                                   pos_loc, pos_src)
         src_from_A = _engine.csr_from_edges(A_src, n_grid)
         src_csr = _engine.csr_from_table(src_nbr)
-        if not (torch.equal(src_from_A[0], src_csr[0]) and torch.equal(src_from_A[1], src_csr[1])):
+        if not (torch.equal(src_from_A[0].cpu(), src_csr[0].cpu()) and torch.equal(src_from_A[1].cpu(), src_csr[1].cpu())):
             raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
@@ -727,6 +731,25 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
         self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
+
+    def set_adjacencies_from_positions(self, pos_loc, pos_src, edge_attr, k_sta_edges=8, k_spc_edges=15):
+        """One-time graph setup entirely on the device (process_utils.py:701-742 without its host detours): the two base kNN
+        graphs `remove_self_loops(knn(x / 1000, x / 1000, k + 1).flip(0))` (:718-719, `k_sta_edges = min(k_sta_edges, n_sta - 2)`
+        :712) by `genie_knn`, handed to libgenie_hip as device CSR arrays; the product edge lists of :720-721 are never built.
+        pos_loc [S, 3] / pos_src [G, 3] Cartesian metres (`ftrns1(locs)`, `ftrns1(x_grid)`), edge_attr [S * G, 3]
+        (`A_src_in_edges.x`, process_continuous_days.py:630)."""
+        dev = next(self.parameters()).device
+        pos_loc, pos_src = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
+        n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
+        sta_tab, A_sta = _engine.knn_graph_device(pos_loc, _graph.k_sta_effective(k_sta_edges, n_sta))
+        src_tab, A_src = _engine.knn_graph_device(pos_src, min(k_spc_edges, n_grid - 1))
+        self.A_src = A_src
+        self._build_engine(_engine.csr_from_table(sta_tab), _engine.csr_from_table(src_tab), n_sta, n_grid, pos_src, pos_loc)
+        self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
+        self._edge_attr_version = self._edge_attr._version
+        self._hip.set_static_edge_attr(self._edge_attr)
+        self._sta_tab, self._src_tab = sta_tab.long(), src_tab.long()
+        return A_sta, A_src
 
     def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src):
         """Same effect as `set_adjacencies` from the BASE graphs only (process_utils.py:718-719), for sizes

@@ -270,6 +270,25 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
                        void* stream);
 
+/* Exact k nearest neighbours on the device, replacing the reference's `torch_cluster.knn(x_context / scale, x_query / scale, k)`
+ * calls: out_idx [n_query, k] int32 = indices into x_context of the k nearest context points of every query, nearest first
+ * (ties: smaller index first; -1 when fewer than k candidates exist). fp64 distances on the fp32 coordinates as given: the
+ * reference's common factor 1 / 1000 (module.py:282, process_utils.py:718-719) does not change the order. exclude_self != 0: candidate i is skipped for query
+ * i (x_query = x_context: the `knn(x, x, k + 1)` + `remove_self_loops` idiom of the base graphs). 1 <= k <= 16. */
+int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
+              int32_t* out_idx, void* stream);
+
+/* Downstream reduction of the apply loop on the device (process_continuous_days.py:812-849): select entries of the stacked
+ * output x [rows, cols] (fp32, row-major, e.g. Out_2 [n_query, len(tsteps_abs)]) without copying it to the host.
+ *   mode 0: x > threshold                       = `np.where(Out_2 > 0.01)` (:812-813), row-major order
+ *   mode 1: local maxima of every row with x >= threshold = scipy.signal.find_peaks(row, height = threshold) BEFORE its
+ *           distance filter (:846): strict maxima and midpoints of flat tops, never the first / last sample
+ * Two passes: genie_row_select_count fills counts[rows]; the caller turns them into exclusive offsets[rows] (int64) and
+ * allocates the outputs; genie_row_select_fill writes (row, col, value) triplets in row-major order. */
+int genie_row_select_count(const float* x, int rows, int64_t cols, float threshold, int mode, int32_t* counts, void* stream);
+int genie_row_select_fill(const float* x, int rows, int64_t cols, float threshold, int mode, const int64_t* offsets,
+                          int32_t* out_row, int32_t* out_col, float* out_val, void* stream);
+
 /* Debug/parity access to intermediates kept in the workspace (which: 0 = c [P,30], 1 = wu [P,15], 2 = wv [P,15]);
  * copies de-padded rows into `out` (async). */
 int genie_ws_export(genie_ctx* ctx, int which, void* ws, float* out, void* stream);

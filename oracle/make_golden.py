@@ -332,7 +332,45 @@ def main_scaled():
              keep=("x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
 
 
+def main_postproc():
+    """`python oracle/make_golden.py --postproc`: the reference's own `LocalMarching` (process_utils.py:40-100) on synthetic
+    source candidates (clusters in space-time + isolated points, some exactly tied values), in the call form of the apply script
+    (process_continuous_days.py:879: n_steps_max = 2, use_directed = False, scale_depth = 0.2) and with its defaults (directed
+    edges, up to 100 steps). Rows are stored sorted (the reference returns them grouped by connected component)."""
+    _import_reference()
+    import process_utils as pu
+    rng = np.random.default_rng(301)
+    centres = np.c_[rng.uniform(0, 300e3, (12, 2)), rng.uniform(-30e3, 0, 12), rng.uniform(0, 600.0, 12)]
+    pts = []
+    for c in centres:
+        m = int(rng.integers(2, 14))
+        pts.append(np.c_[c[None, :3] + rng.normal(0, 12e3, (m, 3)) * np.array([1, 1, 0.3]), c[3] + rng.normal(0, 2.5, m)])
+    pts.append(np.c_[rng.uniform(0, 300e3, (25, 2)), rng.uniform(-30e3, 0, 25), rng.uniform(0, 600.0, 25)])
+    X = np.vstack(pts)
+    vals = rng.uniform(0.1, 1.0, X.shape[0])
+    vals[3] = vals[1]                                   # an exact tie inside a cluster
+    srcs = np.c_[X, vals]
+    srcs = srcs[np.argsort(srcs[:, 3])]
+    ident = lambda x: x
+    out = {"srcs": srcs}
+    for tag, kw in (("apply", dict(tc_win=4.05, sp_win=27e3, scale_depth=0.2, n_steps_max=2, use_directed=False)),
+                    ("default", dict(tc_win=5, sp_win=35e3)),
+                    ("wide", dict(tc_win=12.0, sp_win=60e3, scale_depth=0.2, n_steps_max=2, use_directed=False))):
+        mp = pu.LocalMarching(device="cpu")
+        keep = np.asarray(mp(srcs, ident, **kw))
+        keep = keep[np.lexsort(keep.T[::-1])] if len(keep) else np.zeros((0, 5))
+        out["keep_" + tag] = keep
+        for k, v in kw.items():
+            out["kw_%s_%s" % (tag, k)] = np.float64(v)
+        print(tag, "kept", len(keep), "of", len(srcs))
+    path = os.path.join(OUT, "localmarching.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 def main():
+    if "--postproc" in sys.argv:
+        return main_postproc()
     if "--scaled" in sys.argv:
         return main_scaled()
     if "--edges" in sys.argv:

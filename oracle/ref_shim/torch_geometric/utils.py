@@ -55,5 +55,13 @@ def to_undirected(edge_index, *a, **k):
     return torch.unique(ei, dim=1)
 
 
-def to_networkx(*a, **k):
-    raise NotImplementedError("ref_shim: to_networkx is not on the golden-vector path")
+def to_networkx(data, *a, **k):
+    """Directed networkx graph with nodes 0 .. num_nodes-1 (num_nodes inferred from edge_index when the Data object carries no
+    node features, as PyG does) and one edge per column of edge_index. Used by LocalMarching (process_utils.py:59-60)."""
+    import networkx as nx
+    ei = data.edge_index
+    n = int(data.x.shape[0]) if getattr(data, "x", None) is not None else (int(ei.max().item()) + 1 if ei.numel() else 0)
+    g = nx.DiGraph()
+    g.add_nodes_from(range(n))
+    g.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+    return g

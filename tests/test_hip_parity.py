@@ -1078,3 +1078,41 @@ def test_station_processing_order_is_internal_only(S, G):
             assert a.shape == b.shape and max_abs(a, b) <= 2e-6 * max(1.0, float(a.abs().max()))
     with pytest.raises(Exception):
         engine.HipPath(S, G, sta, src, device=DEV, sta_order=np.zeros(S, dtype=np.int64))
+
+
+@pytest.mark.parametrize("nc,nq,k", [(500, 300, 10), (10000, 2500, 10), (37, 50, 10), (5, 7, 10), (3000, 3000, 15), (200, 200, 8)])
+def test_device_knn_matches_exact_search(nc, nq, k):
+    """genie_knn (module.py:282 / process_utils.py:718-719) against an exact fp64 search on the host: same neighbour sets in
+    the same (nearest-first) order; with `exclude_self` the table equals genie_amd.graph.knn_graph (cKDTree, self removed)."""
+    rng = np.random.default_rng(nc + nq)
+    xc = np.stack([rng.uniform(0, 300e3, nc), rng.uniform(0, 300e3, nc), rng.uniform(-40e3, 2e3, nc)], axis=1).astype(np.float32)
+    xq = np.stack([rng.uniform(0, 300e3, nq), rng.uniform(0, 300e3, nq), rng.uniform(-40e3, 2e3, nq)], axis=1).astype(np.float32)
+    got = engine.knn_device(torch.from_numpy(xc).to(DEV), torch.from_numpy(xq).to(DEV), k).cpu().numpy()
+    kk = min(k, nc)
+    d = ((xq.astype(np.float64)[:, None, :] - xc.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    want = np.argsort(d, axis=1, kind="stable")[:, :kk]
+    assert got.shape == (nq, kk) and np.array_equal(got, want)
+    if nc == nq:       # base graph of a point set with itself
+        tab, edges = engine.knn_graph_device(torch.from_numpy(xc).to(DEV), k)
+        ref = graph.knn_graph(xc.astype(np.float64) / 1000.0, k)
+        assert np.array_equal(edges.cpu().numpy(), ref)
+        assert np.array_equal(tab.cpu().numpy().reshape(-1), ref[0])
+
+
+def test_set_adjacencies_from_positions_equals_host_built_graphs():
+    """Graph setup on the device (genie_knn -> device CSR) gives the same forward as the host-built base graphs."""
+    c = Case("cfg1_20x500")
+    fixed = (None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    outs = []
+    for mode in ("host", "device"):
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+        net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+        net.eval()
+        if mode == "host":
+            net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+        else:
+            A_sta, A_src = net.set_adjacencies_from_positions(c.locs.float().to(DEV), c.x_grid.float().to(DEV), c.edge_attr.to(DEV))
+            assert torch.equal(A_sta.cpu(), c.A_sta_sta) and torch.equal(A_src.cpu(), c.A_src_src)
+        with torch.no_grad():
+            outs.append(net.forward_fixed_source(c.Slice.to(DEV), c.Mask.to(DEV), *fixed))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
