@@ -107,6 +107,11 @@ enum {
     W_DA_L1T12_P, W_DA_L1T22_P, W_DA_L2T12_P, W_DA_L2T22_P,
     // use_absolute_pos (config.yaml:92): the 6 absolute-position columns of init_trns (zero otherwise)
     W_DA_INIT_ABS,
+    // association heads (module.py:333-403): BipartiteGraphReadOutOperator + DataAggregationAssociationPhase
+    W_RO_FC1_W, W_RO_FC1_B, W_RO_FC2_W, W_RO_FC2_B, W_RO_ACT1, W_RO_ACT2,
+    W_AS_INIT_W, W_AS_INIT_B, W_AS_L1T11_W, W_AS_L1T11_B, W_AS_L1T21_W, W_AS_L1T21_B, W_AS_L1T12_W, W_AS_L1T12_B,
+    W_AS_L1T22_W, W_AS_L1T22_B, W_AS_L2T11_W, W_AS_L2T11_B, W_AS_L2T21_W, W_AS_L2T21_B, W_AS_L2T12_W, W_AS_L2T12_B,
+    W_AS_L2T22_W, W_AS_L2T22_B, W_AS_ACT, W_AS_ACT11, W_AS_ACT12, W_AS_ACT1, W_AS_ACT21, W_AS_ACT22, W_AS_ACT2,
     W_COUNT
 };
 
@@ -160,6 +165,22 @@ Param g_params[W_COUNT] = {
     {"DataAggregation.l1_t1_2.weight_pos", 30 * 4, 0}, {"DataAggregation.l1_t2_2.weight_pos", 30 * 4, 0},
     {"DataAggregation.l2_t1_2.weight_pos", 15 * 4, 0}, {"DataAggregation.l2_t2_2.weight_pos", 15 * 4, 0},
     {"DataAggregation.init_trns.weight_abs", 30 * 6, 0},
+    {"BipartiteGraphReadOutOperator.fc1.weight", 30 * 33, 0}, {"BipartiteGraphReadOutOperator.fc1.bias", 30, 0},
+    {"BipartiteGraphReadOutOperator.fc2.weight", 15 * 30, 0}, {"BipartiteGraphReadOutOperator.fc2.bias", 15, 0},
+    {"BipartiteGraphReadOutOperator.activate1.weight", 1, 0}, {"BipartiteGraphReadOutOperator.activate2.weight", 1, 0},
+    {"DataAggregationAssociationPhase.init_trns.weight", 30 * 50, 0}, {"DataAggregationAssociationPhase.init_trns.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l1_t1_1.weight", 30 * 30, 0}, {"DataAggregationAssociationPhase.l1_t1_1.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l1_t2_1.weight", 30 * 30, 0}, {"DataAggregationAssociationPhase.l1_t2_1.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l1_t1_2.weight", 30 * 65, 0}, {"DataAggregationAssociationPhase.l1_t1_2.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l1_t2_2.weight", 30 * 65, 0}, {"DataAggregationAssociationPhase.l1_t2_2.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l2_t1_1.weight", 30 * 60, 0}, {"DataAggregationAssociationPhase.l2_t1_1.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l2_t2_1.weight", 30 * 60, 0}, {"DataAggregationAssociationPhase.l2_t2_1.bias", 30, 0},
+    {"DataAggregationAssociationPhase.l2_t1_2.weight", 15 * 95, 0}, {"DataAggregationAssociationPhase.l2_t1_2.bias", 15, 0},
+    {"DataAggregationAssociationPhase.l2_t2_2.weight", 15 * 95, 0}, {"DataAggregationAssociationPhase.l2_t2_2.bias", 15, 0},
+    {"DataAggregationAssociationPhase.activate.weight", 1, 0}, {"DataAggregationAssociationPhase.activate11.weight", 1, 0},
+    {"DataAggregationAssociationPhase.activate12.weight", 1, 0}, {"DataAggregationAssociationPhase.activate1.weight", 1, 0},
+    {"DataAggregationAssociationPhase.activate21.weight", 1, 0}, {"DataAggregationAssociationPhase.activate22.weight", 1, 0},
+    {"DataAggregationAssociationPhase.activate2.weight", 1, 0},
 };
 
 int g_raw_total = 0;
@@ -248,6 +269,32 @@ void add_bias(StagePlan& p, int vec, int o0, int rows) {
 #define G2_BP(t, b) ((t) * 3 + (b))
 #define G2_GROUPS 6
 #define G2_BIAS 2
+
+// ASSOCIATION stage A (k_assoc_a): BipartiteGraphReadOutOperator (module.py:343-352) + the per-node front of
+// DataAggregationAssociationPhase (:389-396). fc1's edge_attr columns (out tile t); fc2 (input block b of the message);
+// init_trns (out tile t; block 0 = s, 1,2 = x_latent, 3 = Mask; the mask1 column is a per-source-node term);
+// l1_t1_1 / l1_t2_1 (w, out tile t, input block b of tr)
+#define GA_FC1E(t) (t)
+#define GA_FC2(b) (2 + (b))
+#define GA_INIT(t, b) (4 + (t) * 4 + (b))
+#define GA_Q(w, t, b) (12 + ((w) * 2 + (t)) * 2 + (b))
+#define GA_GROUPS 20
+//  bias tiles: 0 fc2; 1,2 init_trns; 3,4 l1_t1_1; 5,6 l1_t2_1
+#define GA_BIAS 7
+// ASSOCIATION stage B (k_assoc_b): layers 1-2 of DataAggregationAssociationPhase up to the second pair of neighbour means
+// (:397-400), same structure as stage 1 of DataAggregation with 65- / 95-wide Linears (mask width 5; the mask1 column is a
+// per-source-node term)
+#define GB_L1(h, t, b) (((h) * 2 + (t)) * 5 + (b))
+#define GB_UV(w, t, hb) (20 + ((w) * 2 + (t)) * 4 + (hb))
+#define GB_W(w, b) (36 + (w) * 2 + (b))
+#define GB_C(w, b) (40 + (w) * 5 + (b))
+#define GB_GROUPS 50
+//  bias tiles: 0..3 layer 1 (h,t); 4..7 u/v (w,t); 8,9 c (w)
+#define GB_BIAS 10
+// per-source-node terms of the association stages, AS_PG floats per source node: [0:30] fc1[:, 0:30] y_latent[g] + fc1 bias,
+// [31] mask1[g]; mask1[g] x the mask1 column of init_trns [32:62], l1_t1_2 [64:94], l1_t2_2 [96:126], l2_t1_2 [128:143],
+// l2_t2_2 [144:159]
+constexpr int AS_PG = 160;
 
 // STAGE 1, bf16x3 form (k_stage1_b3): 1-KB A fragments of v_mfma_f32_32x32x16_bf16, lane (i = lane&31, h = lane>>5) holds
 // 8 bf16 = K slots (h, e = 0..7). Fragment ids: init_trns (3 mixed-piece fragments), then [block][K-step][piece].
@@ -433,6 +480,68 @@ void build_plans(StagePlan& p1, StagePlan& p2) {
     p2.scal.push_back(g_params[W_BP_ACT1].off);
 }
 
+void build_assoc_plans(StagePlan& pa, StagePlan& pb) {
+    const int c1[1] = {30}, n3[1] = {3};
+    for (int t = 0; t < 2; ++t) add_scalar_group(pa, W_RO_FC1_W, 33, 16 * t, std::min(16, 30 - 16 * t), c1, n3, 1);   // edge_attr columns
+    add_block_group(pa, W_RO_FC2_W, 30, 0, 15, 0, 16);
+    add_block_group(pa, W_RO_FC2_W, 30, 0, 15, 16, 14);
+    for (int t = 0; t < 2; ++t) {
+        const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
+        add_block_group(pa, W_AS_INIT_W, 50, o0, rows, 0, 15);      // s
+        add_block_group(pa, W_AS_INIT_W, 50, o0, rows, 15, 16);     // x_latent 0..15
+        add_block_group(pa, W_AS_INIT_W, 50, o0, rows, 31, 14);     // x_latent 16..29
+        const int c0[1] = {46}, n4[1] = {4};
+        add_scalar_group(pa, W_AS_INIT_W, 50, o0, rows, c0, n4, 1); // Mask (column 45 = mask1: per-source-node term)
+    }
+    for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 2; ++t) {
+            const int mat = w == 0 ? W_AS_L1T11_W : W_AS_L1T21_W;
+            add_block_group(pa, mat, 30, 16 * t, std::min(16, 30 - 16 * t), 0, 16);
+            add_block_group(pa, mat, 30, 16 * t, std::min(16, 30 - 16 * t), 16, 14);
+        }
+    add_bias(pa, W_RO_FC2_B, 0, 15);
+    for (int t = 0; t < 2; ++t) add_bias(pa, W_AS_INIT_B, 16 * t, std::min(16, 30 - 16 * t));
+    for (int t = 0; t < 2; ++t) add_bias(pa, W_AS_L1T11_B, 16 * t, std::min(16, 30 - 16 * t));
+    for (int t = 0; t < 2; ++t) add_bias(pa, W_AS_L1T21_B, 16 * t, std::min(16, 30 - 16 * t));
+    const int sa[5] = {W_RO_ACT1, W_RO_ACT2, W_AS_ACT, W_AS_ACT11, W_AS_ACT12};
+    for (int k = 0; k < 5; ++k) pa.scal.push_back(g_params[sa[k]].off);
+    // ---- stage B
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 2; ++t) {
+            const int mat = h == 0 ? W_AS_L1T12_W : W_AS_L1T22_W;
+            const int o0 = 16 * t, rows = std::min(16, 30 - 16 * t);
+            add_block_group(pb, mat, 65, o0, rows, 0, 16);
+            add_block_group(pb, mat, 65, o0, rows, 16, 14);
+            add_block_group(pb, mat, 65, o0, rows, 30, 16);
+            add_block_group(pb, mat, 65, o0, rows, 46, 14);
+            const int c0[1] = {61}, n4[1] = {4};
+            add_scalar_group(pb, mat, 65, o0, rows, c0, n4, 1);
+        }
+    for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 2; ++t) {
+            const int mat = w == 0 ? W_AS_L2T11_W : W_AS_L2T21_W;
+            for (int hb = 0; hb < 4; ++hb)
+                add_block_group(pb, mat, 60, 16 * t, std::min(16, 30 - 16 * t), (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
+        }
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < 2; ++b) add_block_group(pb, w == 0 ? W_AS_L2T12_W : W_AS_L2T22_W, 95, 0, 15, 60 + 16 * b, b ? 14 : 16);
+    for (int w = 0; w < 2; ++w) {
+        const int mat = w == 0 ? W_AS_L2T12_W : W_AS_L2T22_W;
+        for (int hb = 0; hb < 4; ++hb) add_block_group(pb, mat, 95, 0, 15, (hb >> 1) * 30 + 16 * (hb & 1), (hb & 1) ? 14 : 16);
+        const int c0[1] = {91}, n4[1] = {4};
+        add_scalar_group(pb, mat, 95, 0, 15, c0, n4, 1);
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 2; ++t) add_bias(pb, h == 0 ? W_AS_L1T12_B : W_AS_L1T22_B, 16 * t, std::min(16, 30 - 16 * t));
+    for (int w = 0; w < 2; ++w)
+        for (int t = 0; t < 2; ++t) add_bias(pb, w == 0 ? W_AS_L2T11_B : W_AS_L2T21_B, 16 * t, std::min(16, 30 - 16 * t));
+    add_bias(pb, W_AS_L2T12_B, 0, 15);
+    add_bias(pb, W_AS_L2T22_B, 0, 15);
+    pb.scal.push_back(g_params[W_AS_ACT1].off);
+    pb.scal.push_back(g_params[W_AS_ACT21].off);
+    pb.scal.push_back(g_params[W_AS_ACT22].off);
+}
+
 __global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict__ steps, int n_groups,
                        const BiasDesc* __restrict__ bias, int n_bias, const int32_t* __restrict__ scal, int n_scal,
                        float* __restrict__ out) {
@@ -532,6 +641,8 @@ struct DaArgs {
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
+    const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
+    int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
@@ -1617,7 +1728,7 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
     const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = lscal[0], ab1 = lscal[1];
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1666,6 +1777,7 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
                 }
             }
         }
+        if (a.no_bip) continue;
         // Bipartite message: m_p * PReLU_b1(fc1 [x_latent || edge_attr])
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
@@ -1778,7 +1890,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
     const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = lscal[0], ab1 = lscal[1];
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1895,7 +2007,10 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
         nn = nxt;
-        if (!ABL(a, 6)) {
+        if (a.no_bip) {
+            if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
+            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+        } else if (!ABL(a, 6)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
@@ -1971,7 +2086,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, in
     const unsigned q16 = 16u * (unsigned)q;
     const unsigned m_T = ItemIter::recip((unsigned)T);
     __syncthreads();
-    const float a2 = lscal[0], ab1 = lscal[1];
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
 
     struct Ids { int idv, sc, su, tb, nl; bool valid; int sta[KS]; };
     struct Rows { f32x4 o[2]; float mq, eq; f32x4 rv[KP]; };
@@ -2075,6 +2190,14 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, in
             bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
             bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
             nn = nxt;
+            if (a.no_bip) {
+                if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
+                if (it + 8 < ntile) fetch_ids(it + 8, nn);
+                if (!has_next) break;
+                cur = nxt;
+                nxt = nn;
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
@@ -2103,6 +2226,272 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, in
             if (!has_next) break;
             cur = nxt;
             nxt = nn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Association heads on the product graph: BipartiteGraphReadOutOperator (module.py:333-352) and
+// DataAggregationAssociationPhase (:356-403) as three P-sized passes in the layout of the DataAggregation kernels
+// (fp32 MFMA, tile = 16 stations of one source node, outputs of one Linear are the B operands of the next):
+//   k_assoc_pre (G-sized): per-source-node terms pg[g] (the y_latent part of fc1, mask1 and the mask1 columns)
+//   k_assoc_a: s = PReLU2(fc2(mask1 PReLU1(fc1[y_latent[g] || e_p])))                       :343-352
+//              tr = PReLU(init_trns[s || x_latent || mask1 || Mask]), q1 = PReLU11(l1_t1_1 tr), q2 = PReLU12(l1_t2_1 tr)   :389-396
+//   k_assoc_b: tr1 = PReLU1([l1_t1_2[tr || mean_sta q1 || mask] || l1_t2_2[tr || mean_src q2 || mask]])             :397-398
+//              r1 = PReLU21(l2_t1_1 tr1), r2 = PReLU22(l2_t2_1 tr1); c / wu / wv exactly as stage 1 leaves them     :399-400
+//   stage-2 kernel with `no_bip` (second pair of means + PReLU2 -> [P, 30])                                          :401
+// Unlike DataAggregation the first-layer gather operand q is not a function of 8 raw floats, so q1 / q2 (32-float rows) are
+// stored and gathered. tr / q1 / q2 and c / wu / wv live in (station) processing order like the stage-1 outputs.
+// ------------------------------------------------------------------------------------------------
+struct AsArgs {
+    int S, G, T, seg, nxcd;
+    const int32_t* order;
+    const int32_t* sta_rowptr; const int32_t* sta_col; const int32_t* src_rowptr; const int32_t* src_col;
+    const int32_t* sta_user;     // internal station -> caller's station (inputs are in the caller's order), or null
+    const float* pg;             // [G][AS_PG]
+    const float* x_latent; const float* mask; const float* edge_attr;   // caller's order: [P,30], [P,4], [P,3]
+    float* tr; float* q1; float* q2;                                    // [P,32]
+    float* c; float* wu; float* wv;
+    const float* packed;
+};
+
+struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as_l2t12_w, as_l2t22_w; };
+
+__global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw, AsPreOffs o, const float* __restrict__ y_latent,
+                                                   const float* __restrict__ mask_src, int G, float* __restrict__ pg) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * AS_PG) return;
+    const int g = idx / AS_PG, k = idx - g * AS_PG;
+    const float m = mask_src[g];
+    float v = 0.f;
+    if (k < 30) {
+        v = raw[o.ro_fc1_b + k];
+        const float* w = raw + o.ro_fc1_w + k * 33;
+        for (int c = 0; c < 30; ++c) v = fmaf(w[c], y_latent[g * 30 + c], v);
+    } else if (k == 31) v = m;
+    else if (k >= 32 && k < 62) v = m * raw[o.as_init_w + (k - 32) * 50 + 45];
+    else if (k >= 64 && k < 94) v = m * raw[o.as_l1t12_w + (k - 64) * 65 + 60];
+    else if (k >= 96 && k < 126) v = m * raw[o.as_l1t22_w + (k - 96) * 65 + 60];
+    else if (k >= 128 && k < 143) v = m * raw[o.as_l2t12_w + (k - 128) * 95 + 90];
+    else if (k >= 144 && k < 159) v = m * raw[o.as_l2t22_w + (k - 144) * 95 + 90];
+    pg[idx] = v;
+}
+
+__device__ __forceinline__ f32x4 ld_row30(const float* row, int b, int q) {     // channels 16b + 4q .. +3 of a 30-float row (8-B aligned)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = *(const f32x2*)(row + 16 * b + 4 * q);
+    f32x2 hi = {0.f, 0.f};
+    if (b == 0 || q < 3) hi = *(const f32x2*)(row + 16 * b + 4 * q + 2);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
+__global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
+    constexpr int NF4 = (GA_GROUPS * 256 + GA_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + GA_GROUPS * 64);
+    const float* lscal = lbias + GA_BIAS * 16;
+    const float r1 = lscal[0], r2 = lscal[1], a0 = lscal[2], a11 = lscal[3], a12 = lscal[4];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
+        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
+        const float* pg = a.pg + (long long)g * AS_PG;
+        const float eq = q < 3 ? a.edge_attr[pu * 3 + q] : 0.f;
+        const float mq = a.mask[pu * 4 + q];
+        const float m1 = pg[31];
+        const f32x4 lat0 = ld_row30(a.x_latent + pu * 30, 0, q), lat1 = ld_row30(a.x_latent + pu * 30, 1, q);
+        // BipartiteGraphReadOutOperator: one edge per product node, so aggr 'add' is the identity (module.py:343-352)
+        f32x4 msg[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 z = *(const f32x4*)(pg + 16 * t + 4 * q);
+            if (t == 1 && q == 3) z.w = 0.f;                                   // slot 31 carries mask1, not a channel
+            z = MFMA16(lw[GA_FC1E(t) * 64 + lane].x, eq, z);
+            msg[t] = prelu4u(z, r1) * m1;
+        }
+        f32x4 sv = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        sv = mma_block(sv, lw[GA_FC2(0) * 64 + lane], msg[0]);
+        sv = mma_block(sv, lw[GA_FC2(1) * 64 + lane], msg[1]);
+        sv = prelu4u(sv, r2);
+        // init_trns [s || x_latent || mask1 || Mask]
+        f32x4 tr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 acc = *(const f32x4*)(lbias + (1 + t) * 16 + 4 * q) + *(const f32x4*)(pg + 32 + 16 * t + 4 * q);
+            acc = mma_block(acc, lw[GA_INIT(t, 0) * 64 + lane], sv);
+            acc = mma_block(acc, lw[GA_INIT(t, 1) * 64 + lane], lat0);
+            acc = mma_block(acc, lw[GA_INIT(t, 2) * 64 + lane], lat1);
+            acc = MFMA16(lw[GA_INIT(t, 3) * 64 + lane].x, mq, acc);
+            tr[t] = prelu4u(acc, a0);
+        }
+        f32x4 qv[2][2];
+#pragma unroll
+        for (int wq = 0; wq < 2; ++wq)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 acc = *(const f32x4*)(lbias + (3 + 2 * wq + t) * 16 + 4 * q);
+                acc = mma_block(acc, lw[GA_Q(wq, t, 0) * 64 + lane], tr[0]);
+                acc = mma_block(acc, lw[GA_Q(wq, t, 1) * 64 + lane], tr[1]);
+                qv[wq][t] = prelu4u(acc, wq == 0 ? a11 : a12);
+            }
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                *(f32x4*)(a.tr + pi * 32 + 16 * t + 4 * q) = tr[t];
+                *(f32x4*)(a.q1 + pi * 32 + 16 * t + 4 * q) = qv[0][t];
+                *(f32x4*)(a.q2 + pi * 32 + 16 * t + 4 * q) = qv[1][t];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
+    constexpr int NF4 = (GB_GROUPS * 256 + GB_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + GB_GROUPS * 64);
+    const float* lscal = lbias + GB_BIAS * 16;
+    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
+        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
+        const float* pg = a.pg + (long long)g * AS_PG;
+        const float mq = a.mask[pu * 4 + q];
+        const f32x4 x0 = *(const f32x4*)(a.tr + pi * 32 + 4 * q), x1 = *(const f32x4*)(a.tr + pi * 32 + 16 + 4 * q);
+        // neighbour means of q1 (stations of the same source node) and q2 (same station, neighbouring source nodes), edge order
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
+        {
+            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
+            const float* base = a.q1 + (long long)g * S * 32 + 4 * q;
+            for (int e = eb; __any(e < ee); e += 4) {
+                f32x4 ra[4], rb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = e + k < ee;
+                    const float* r = base + (long long)a.sta_col[ok ? e + k : max(ee - 1, 0)] * 32;
+                    ra[k] = *(const f32x4*)r; rb[k] = *(const f32x4*)(r + 16);
+                    if (!ok) { ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[k] = ra[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { n1a += ra[k]; n1b += rb[k]; }
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        {
+            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
+            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
+            const float* base = a.q2 + (long long)sc * 32 + 4 * q;
+            int e = eb;
+            for (; e + 4 <= ee; e += 4) {
+                f32x4 ra[4], rb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* r = base + (long long)a.src_col[e + k] * S * 32;
+                    ra[k] = *(const f32x4*)r; rb[k] = *(const f32x4*)(r + 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { n2a += ra[k]; n2b += rb[k]; }
+            }
+            for (; e < ee; ++e) {
+                const float* r = base + (long long)a.src_col[e] * S * 32;
+                n2a += *(const f32x4*)r; n2b += *(const f32x4*)(r + 16);
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        // layer 1
+        f32x4 acc[4], w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc[k] = *(const f32x4*)(lbias + k * 16 + 4 * q) + *(const f32x4*)(pg + 64 + 32 * (k >> 1) + 16 * (k & 1) + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 0) * 64 + lane];
+        mma_blocks<4>(acc, w4, x0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 1) * 64 + lane];
+        mma_blocks<4>(acc, w4, x1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 na = b == 0 ? n1a : n1b, nb = b == 0 ? n2a : n2b;
+            f32x4 wa[2], wb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wa[t] = lw[GB_L1(0, t, 2 + b) * 64 + lane];
+                wb[t] = lw[GB_L1(1, t, 2 + b) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0] = MFMA16(wa[0][r], na[r], acc[0]);
+                acc[2] = MFMA16(wb[0][r], nb[r], acc[2]);
+                acc[1] = MFMA16(wa[1][r], na[r], acc[1]);
+                acc[3] = MFMA16(wb[1][r], nb[r], acc[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[GB_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);
+        // r1 / r2 and the node-local layer-2 terms
+        f32x4 o6[6], w6[6];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
+        o6[4] = *(const f32x4*)(lbias + 8 * 16 + 4 * q) + *(const f32x4*)(pg + 128 + 4 * q);
+        o6[5] = *(const f32x4*)(lbias + 9 * 16 + 4 * q) + *(const f32x4*)(pg + 144 + 4 * q);
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w6[k] = lw[GB_UV(k >> 1, k & 1, hb) * 64 + lane];
+            w6[4] = lw[GB_C(0, hb) * 64 + lane];
+            w6[5] = lw[GB_C(1, hb) * 64 + lane];
+            mma_blocks<6>(o6, w6, acc[hb]);
+        }
+        o6[4] = MFMA16(lw[GB_C(0, 4) * 64 + lane].x, mq, o6[4]);
+        o6[5] = MFMA16(lw[GB_C(1, 4) * 64 + lane].x, mq, o6[5]);
+        o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
+        o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
+        f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            w2[0] = lw[GB_W(0, b) * 64 + lane];
+            w2[1] = lw[GB_W(1, b) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wuv[0] = MFMA16(w2[0][r], o6[b][r], wuv[0]);
+                wuv[1] = MFMA16(w2[1][r], o6[2 + b][r], wuv[1]);
+            }
+        }
+        if (valid) {
+            *(f32x4*)(a.c + pi * ROWC + 4 * q) = o6[4];
+            *(f32x4*)(a.c + pi * ROWC + 16 + 4 * q) = o6[5];
+            *(f32x4*)(a.wu + pi * ROWW + 4 * q) = wuv[0];
+            *(f32x4*)(a.wv + pi * ROWW + 4 * q) = wuv[1];
         }
     }
 }
@@ -3326,11 +3715,12 @@ struct genie_ctx {
     int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
     float* raw;
     bool dirty;
-    StagePlan plan[2];
-    StepDesc* d_steps[2];
-    BiasDesc* d_bias[2];
-    int32_t* d_scal[2];
-    float* packed[2];
+    StagePlan plan[4];         // 0, 1: DataAggregation stage 1 / stage 2; 2, 3: association stages A / B
+    StepDesc* d_steps[4];
+    BiasDesc* d_bias[4];
+    int32_t* d_scal[4];
+    float* packed[4];
+    float* as_pg;              // [G][AS_PG] per-source-node terms of the association stages (allocated on first use)
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
     float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
@@ -3422,7 +3812,7 @@ int dev_copy(T** dst, const T* src_dev, size_t n) {
 
 int ensure_packed(genie_ctx* c, hipStream_t st) {
     if (!c->dirty) return GENIE_OK;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 4; ++s) {
         const StagePlan& p = c->plan[s];
         const int total = p.packed_floats();
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
@@ -3562,10 +3952,13 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     HIP_TRY(hipMalloc((void**)&c->raw, sizeof(float) * g_raw_total));
     HIP_TRY(hipMemset(c->raw, 0, sizeof(float) * g_raw_total));
     build_plans(c->plan[0], c->plan[1]);
+    build_assoc_plans(c->plan[2], c->plan[3]);
     if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
-        (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS)
+        (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS ||
+        c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
+        (int)c->plan[2].bias.size() != GA_BIAS || (int)c->plan[3].bias.size() != GB_BIAS)
         return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 4; ++s) {
         const StagePlan& p = c->plan[s];
         HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
         HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
@@ -3868,7 +4261,9 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
-                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1], c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
+                    c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1],
+                    c->d_steps[2], c->d_steps[3], c->d_bias[2], c->d_bias[3], c->d_scal[2], c->d_scal[3], c->packed[2], c->packed[3],
+                    c->as_pg, c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
@@ -4026,7 +4421,7 @@ int genie_ws_v_pitch(const genie_ctx* c) { (void)c; return ROWW; }
 
 namespace {
 int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws, void* stream,
-               int gi_begin, int gi_end);
+               int gi_begin, int gi_end, const float* slope2 = nullptr, int no_bip = 0);
 }
 
 int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
@@ -4043,7 +4438,7 @@ int genie_da_stage2_partials_range(genie_ctx* c, const float* mask, const float*
 
 namespace {
 int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws, void* stream,
-               int gi_begin, int gi_end) {
+               int gi_begin, int gi_end, const float* slope2, int no_bip) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!mask || !edge_attr) return fail(GENIE_ERR_ARG, "genie_da_stage2_partials: null argument");
@@ -4054,6 +4449,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     if ((rc = ensure_packed(c, st))) return rc;
     DaArgs a = make_da_args(c, (float*)ws);
     a.gi0 = gi_begin; a.G = gi_end - gi_begin;
+    a.slope2 = slope2; a.no_bip = no_bip;
     const long long n_tiles = (long long)a.G * c->T;
     if (n_tiles == 0) return GENIE_OK;
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
@@ -4078,7 +4474,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
-    } else if (c->use_b3 && !c->nob3s2 && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
+    } else if (c->use_b3 && !c->nob3s2 && !no_bip && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
         a.packed = c->packed_b3s2;
         k_stage2_b3<8, 15><<<da_grid(c, (n_tiles + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2 && c->s2_nb > 0) {
@@ -4549,6 +4945,44 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
+}
+
+size_t genie_assoc_workspace_bytes(const genie_ctx* c) { return c ? sizeof(float) * 3 * 32 * (size_t)c->P : 0; }
+
+int genie_assoc_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                    const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!y_latent || !mask_src || !x_latent || !mask || !edge_attr || !out || !assoc_ws)
+        return fail(GENIE_ERR_ARG, "genie_assoc_fwd: null argument");
+    if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_assoc_fwd: needs an unsharded Cartesian product graph");
+    if (((uintptr_t)assoc_ws & 15) != 0) return fail(GENIE_ERR_ARG, "genie_assoc_fwd: assoc_ws must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
+    AsPreOffs o;
+    o.ro_fc1_w = g_params[W_RO_FC1_W].off; o.ro_fc1_b = g_params[W_RO_FC1_B].off; o.as_init_w = g_params[W_AS_INIT_W].off;
+    o.as_l1t12_w = g_params[W_AS_L1T12_W].off; o.as_l1t22_w = g_params[W_AS_L1T22_W].off;
+    o.as_l2t12_w = g_params[W_AS_L2T12_W].off; o.as_l2t22_w = g_params[W_AS_L2T22_W].off;
+    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, c->as_pg);
+    DaArgs d = make_da_args(c, (float*)ws);
+    AsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = c->S; a.G = c->G; a.T = c->T; a.seg = d.seg; a.nxcd = d.nxcd;
+    a.order = c->order;
+    a.sta_rowptr = d.sta_rowptr; a.sta_col = d.sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
+    a.sta_user = d.sta_user;
+    a.pg = c->as_pg; a.x_latent = x_latent; a.mask = mask; a.edge_attr = edge_attr;
+    a.tr = (float*)assoc_ws; a.q1 = a.tr + 32 * (size_t)c->P; a.q2 = a.q1 + 32 * (size_t)c->P;
+    a.c = d.c; a.wu = d.wu; a.wv = d.wv;
+    const int grid = da_grid(c, (long long)c->G * c->T, std::max(1, c->bpc1));
+    a.packed = c->packed[2];
+    k_assoc_a<<<grid, 256, 0, st>>>(a);
+    a.packed = c->packed[3];
+    k_assoc_b<<<grid, 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    // second pair of neighbour means + PReLU2 = the stage-2 kernel of this context without its Bipartite half
+    return run_stage2(c, mask, edge_attr, out, ws, stream, 0, c->G, c->raw + g_params[W_AS_ACT2].off, 1);
 }
 
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,

@@ -154,6 +154,9 @@ def sfc_order(points):
     return hilbert_order(points) if os.environ.get("GENIE_SFC") == "hilbert" else morton_order(points)
 
 
+ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.")
+
+
 class HipPath(object):
     """One libgenie_hip context bound to the current CUDA(HIP) device.
 
@@ -241,15 +244,25 @@ class HipPath(object):
     # ---- weights -------------------------------------------------------------------------------
     def set_weights(self, named_tensors):
         """Upload the path's parameters (dict name -> tensor, the reference's state_dict names)."""
+        self.assoc_ready = True
         with torch.no_grad():
             for name, n, off in zip(self.w_names, self.w_numel, self.w_off):
+                assoc = name.startswith(ASSOC_PREFIXES)
                 if name not in named_tensors:
                     if name.endswith(".weight_pos") or name.endswith(".weight_abs"):   # optional columns: absent = plain DataAggregation
                         self._blob[off:off + n].zero_()
                         continue
+                    if assoc:                       # a context used for forward_fixed_source only needs no association heads
+                        self._blob[off:off + n].zero_()
+                        self.assoc_ready = False
+                        continue
                     raise KeyError("missing parameter %s" % name)
                 t = named_tensors[name]
                 if t.numel() != n:
+                    if assoc:                       # other model definitions (use_absolute_pos, ...) have other head shapes
+                        self._blob[off:off + n].zero_()
+                        self.assoc_ready = False
+                        continue
                     raise ValueError("parameter %s: expected %d elements, got %d" % (name, n, t.numel()))
                 self._blob[off:off + n].copy_(t.detach().reshape(-1))
         _lib.check(self.lib.genie_weights_set_blob(self.ctx, _ptr(self._blob), self._blob.numel(), _stream()),
@@ -541,6 +554,29 @@ class HipPath(object):
         out = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_readout_query(self.ctx, _ptr(x_spatial), _ptr(x_grid), _ptr(x_query), _ptr(knn_idx), nq, 10,
                                                 _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
+        return out
+
+    def assoc_fwd(self, y_latent, mask_src, x_latent, Mask, edge_attr):
+        """BipartiteGraphReadOutOperator + DataAggregationAssociationPhase (module.py:986-990) in HIP (genie_assoc_fwd):
+        y_latent [G,30], mask_src [G] or [G,1], x_latent [P,30], Mask [P,4], edge_attr [P,3] -> [P,30]. Call after the
+        DataAggregation stage 2 of the same window (it reuses the c / wu / wv rows of the current workspace slot)."""
+        if not getattr(self, "assoc_ready", False):
+            raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
+        P = self.n_prod
+        y_latent = _f32(y_latent, "y_latent", (self.n_grid, 30))
+        mask_src = _f32(mask_src, "mask_src").reshape(-1)
+        if mask_src.numel() != self.n_grid:
+            raise ValueError("mask_src must have n_grid entries")
+        x_latent = _f32(x_latent, "x_latent", (P, 30))
+        Mask = _f32(Mask, "Mask", (P, 4))
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        self._refresh_static_edge_attr(edge_attr)
+        need = int(self.lib.genie_assoc_workspace_bytes(self.ctx))
+        if getattr(self, "_assoc_ws", None) is None or self._assoc_ws.numel() * 4 < need:
+            self._assoc_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        out = torch.empty((P, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_assoc_fwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
+                                            _ptr(out), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_fwd")
         return out
 
     def nbr_mean(self, x_sta=None, x_src=None):

@@ -33,7 +33,8 @@ def _path_param_dict(net):
     """state_dict-name -> Parameter for the modules that run in HIP."""
     out = {}
     for mod_name in ("DataAggregation", "Bipartite_ReadIn", "SpatialAggregation1", "SpatialAggregation2",
-                     "SpatialAggregation3", "SpatialDirect", "TemporalAttention", "SpatialAttention"):
+                     "SpatialAggregation3", "SpatialDirect", "TemporalAttention", "SpatialAttention",
+                     "BipartiteGraphReadOutOperator", "DataAggregationAssociationPhase"):
         mod = getattr(net, mod_name)
         for n, p in mod.named_parameters():
             out[mod_name + "." + n] = p
@@ -550,9 +551,27 @@ class LocalSliceLgCollapse(nn.Module):
         return self.activate2(self.fc2(agg / cnt.clamp(min=1).view(-1, 1)))                                    # 'mean' :612
 
 
+def station_pick_pairs(ipick):
+    """Pick x pick edge list of the arrival-association head, built where `ipick` lives (module.py:703-713 does it on the host
+    with cKDTree / itertools per call): for every station u with picks l_u (in pick order) all pairs (a, b), a in l_u,
+    b in l_u + [n_arv] (the null pick), a-major, stations ascending. Returns LongTensor [2, sum n_u (n_u + 1)], rows (b; a)."""
+    n = int(ipick.shape[0])
+    dev = ipick.device
+    order = torch.sort(ipick, stable=True)[1]
+    _, inv, counts = torch.unique_consecutive(ipick[order], return_inverse=True, return_counts=True)
+    seg_len = counts[inv]
+    seg_start = (torch.cumsum(counts, 0) - counts)[inv]
+    cnt = seg_len + 1
+    a_rep = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
+    pos = torch.arange(a_rep.shape[0], device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+    real = pos < seg_len[a_rep]
+    b = torch.where(real, order[(seg_start[a_rep] + pos).clamp(max=max(n - 1, 0))], torch.full_like(pos, n))
+    return torch.stack((b, order[a_rep]), dim=0)
+
+
 class StationSourceAttentionMergedPhases(nn.Module):
     """Association head, module.py:662-775 (use_sparse = True, use_neighbor_assoc_edges = False). The pick x pick edge
-    list per station is built on the host exactly as the reference does (module.py:703-718)."""
+    list per station (module.py:703-718) comes from `station_pick_pairs`, on the device the picks live on."""
 
     def __init__(self, ndim_src_in, ndim_arv_in, ndim_out, n_latent, ndim_extra=1, n_heads=5, n_hidden=30, eps=EPS):
         super().__init__()
@@ -573,10 +592,7 @@ class StationSourceAttentionMergedPhases(nn.Module):
     def forward(self, n_src, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label):
         dev, dt_ = tpick.device, tpick.dtype
         n_sta, n_arv, H, L, eps = trv_src.shape[1], len(tpick), self.n_heads, self.n_latent, self.eps
-        ip = ipick.detach().cpu().numpy()
-        lists = [np.where(ip == u)[0] for u in np.unique(ip)]
-        pairs = [np.stack(np.meshgrid(l, np.concatenate((l, [n_arv])), indexing="ij"), 0).reshape(2, -1) for l in lists]   # (a; b), a-major
-        edges = torch.from_numpy(np.ascontiguousarray(np.hstack(pairs)[::-1])).long().to(dev)                   # rows (b; a)  :713
+        edges = station_pick_pairs(ipick)                                                                       # rows (b; a)  :703-713
         n_edge = edges.shape[1]
         edges = edges.repeat(1, n_src) + torch.cat((torch.zeros(1, n_src * n_edge, dtype=torch.long, device=dev),
                                                     (torch.arange(n_src, device=dev) * n_arv).repeat_interleave(n_edge).view(1, -1)), 0)
@@ -874,10 +890,15 @@ class GCN_Detection_Network_extended(nn.Module):
             x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)     # :980,982
         x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)      # :981
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
-        s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
         Maskf = _engine._f32(Mask, "Mask")
-        s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
-                                                 hip=self._hip)                                      # :990
+        if (not self._differentiable() and getattr(self._hip, "assoc_ready", False)
+                and os.environ.get("GENIE_ASSOC_TORCH") is None):
+            # :986-990 as three P-sized HIP passes (genie_assoc_fwd); the PyTorch-ROCm restatement below serves training steps
+            s = self._hip.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
+        else:
+            s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
+            s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
+                                                     hip=self._hip)                                  # :990
         tl = self.tlatent
         arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
         arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))

@@ -270,6 +270,18 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
                        void* stream);
 
+/* Association heads on the product graph, the P-sized part of `forward_fixed` after the source branch
+ * (module.py:986-990): BipartiteGraphReadOutOperator (:333-352) followed by DataAggregationAssociationPhase (:356-403).
+ *   y_latent [n_grid, 30] (SpatialDirect output), mask_src [n_grid] (`mask_out`, :985), x_latent [P, 30] (DataAggregation
+ *   output, detached at :990), mask [P, 4], edge_attr [P, 3]  ->  out [P, 30]
+ * assoc_ws: genie_assoc_workspace_bytes(ctx) bytes of scratch (16-byte aligned; tr / q1 / q2 rows). The call reuses the c / wu /
+ * wv buffers of the current workspace slot: issue it after the DataAggregation stage 2 of the same window. Parameters under
+ * their state_dict names ("BipartiteGraphReadOutOperator.*", "DataAggregationAssociationPhase.*", default model definition).
+ * Unsharded Cartesian product graphs only. */
+size_t genie_assoc_workspace_bytes(const genie_ctx* ctx);
+int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                    const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream);
+
 /* Exact k nearest neighbours on the device, replacing the reference's `torch_cluster.knn(x_context / scale, x_query / scale, k)`
  * calls: out_idx [n_query, k] int32 = indices into x_context of the k nearest context points of every query, nearest first
  * (ties: smaller index first; -1 when fewer than k candidates exist). fp64 distances on the fp32 coordinates as given: the

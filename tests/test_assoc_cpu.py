@@ -68,3 +68,16 @@ def test_time_pointers_match_the_reference_tables():
     ep, es, dtp = graph.time_pointers(trv, max_t=float(z["max_t"]), dt=3.0 / 5.0, k=10, win=6.0)
     assert np.allclose(dtp, z["dt_partition"])
     assert ep.shape == z["A_edges_p"].shape and np.array_equal(ep, z["A_edges_p"]) and np.array_equal(es, z["A_edges_s"])
+
+
+def test_station_pick_pairs_match_the_reference_construction():
+    """module.station_pick_pairs against the statement of module.py:703-713 (numpy meshgrid per station)."""
+    from genie_amd import module
+    rng = np.random.default_rng(9)
+    for n, n_sta in ((1, 3), (17, 4), (200, 23), (64, 1)):
+        ip = rng.integers(0, n_sta, n)
+        lists = [np.where(ip == u)[0] for u in np.unique(ip)]
+        pairs = [np.stack(np.meshgrid(l, np.concatenate((l, [n])), indexing="ij"), 0).reshape(2, -1) for l in lists]
+        want = np.ascontiguousarray(np.hstack(pairs)[::-1])
+        got = module.station_pick_pairs(torch.from_numpy(ip))
+        assert np.array_equal(got.numpy(), want), n

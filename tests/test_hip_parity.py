@@ -1116,3 +1116,45 @@ def test_set_adjacencies_from_positions_equals_host_built_graphs():
         with torch.no_grad():
             outs.append(net.forward_fixed_source(c.Slice.to(DEV), c.Mask.to(DEV), *fixed))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("S,G", [(7, 45), (17, 33), (40, 300), (200, 120)])
+def test_association_heads_hip_match_oracle(S, G):
+    """genie_assoc_fwd (BipartiteGraphReadOutOperator + DataAggregationAssociationPhase, module.py:333-403) against the oracle's
+    restatement (pinned to the reference's forward_fixed by tests/golden/assoc_7x45.npz, tests/test_assoc_cpu.py): ragged tiles
+    and small graphs (generic stage-2 kernel), 40 / 200 stations (station processing order, k_stage2_lds without its Bipartite
+    half); mask1 both 0 and 1; 1e-5 x max(1, max|ref|)."""
+    from oracle import genie_oracle as O
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=10, seed=S + G)
+    win = synthetic.make_window(geom, 25 * S, seed=S)
+    z = np.load(__import__("os").path.join(__import__("tests.util", fromlist=["GOLDEN_DIR"]).GOLDEN_DIR, "assoc_7x45.npz"))
+    w = O.weights_from_npz(z)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in w.items()}, strict=True)
+    net.eval()
+    ea = torch.from_numpy(geom.edge_attr())
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), ea.to(DEV),
+                             torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV))
+    hp = net._hip
+    hp.sync_weights(net._path_params)
+    assert hp.assoc_ready
+    Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
+    rng = np.random.default_rng(S)
+    y_latent = torch.from_numpy(rng.normal(0, 1, (G, 30)).astype(np.float32))
+    mask_src = torch.from_numpy((rng.random((G, 1)) < 0.6).astype(np.float32))
+    with torch.no_grad():
+        _, x_latent, _ = hp.path_fwd(Slice.to(DEV), Mask.to(DEV), ea.to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV), True, False)
+        got = hp.assoc_fwd(y_latent.to(DEV), mask_src.to(DEV), x_latent, Mask.to(DEV), ea.to(DEV))
+        got2 = hp.assoc_fwd(y_latent.to(DEV), mask_src.to(DEV), x_latent, Mask.to(DEV), ea.to(DEV))
+        A_in_sta, A_in_src, _, _ = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+        s, m1 = O.bipartite_read_out(w, y_latent, ea, mask_src, S)
+        want = O.data_aggregation_association(w, s, x_latent.cpu(), m1, Mask, A_in_sta, A_in_src)
+    assert torch.equal(got, got2)
+    assert got.shape == want.shape and float(want.abs().max()) > 0.05
+    assert max_abs(got.cpu(), want) <= rel_tol(want), max_abs(got.cpu(), want)
+    # the module's eval-mode forward_fixed takes this path; its PyTorch restatement (training steps) agrees
+    with torch.no_grad():
+        s_t, m1_t = net.BipartiteGraphReadOutOperator(y_latent.to(DEV), ea.to(DEV), mask_src.to(DEV), S)
+        ref_t = net.DataAggregationAssociationPhase(s_t, x_latent, m1_t, Mask.to(DEV), graph.neighbour_table(geom.A_sta_sta, S).long().to(DEV),
+                                                    graph.neighbour_table(geom.A_src_src, G).long().to(DEV), S, G, hip=hp)
+    assert max_abs(got, ref_t) <= rel_tol(want)

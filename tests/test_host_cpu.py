@@ -89,7 +89,9 @@ def test_library_exports_every_declared_symbol(repo_root):
             assert module._split_abs_columns(Case("abspos_12x60").weights)[n_].numel() == lib.genie_weights_numel(i)
             continue
         assert n_ in ref, n_
-        assert ref[n_].numel() == lib.genie_weights_numel(i) == edges[n_].numel()
+        assert ref[n_].numel() == lib.genie_weights_numel(i)
+        if not n_.startswith(("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.")):
+            assert lib.genie_weights_numel(i) == edges[n_].numel()     # (the Edges class has wider association heads: not served)
         assert lib.genie_weights_offset(i) % 4 == 0
 
 

@@ -40,8 +40,14 @@ def main():
             for _ in range(5): heads()
             torch.cuda.synchronize()
             print("P-sized association heads, %s: %.2f ms" % (name, (time.perf_counter() - t0) / 5 * 1e3))
+        net._hip.sync_weights(net._path_params)
+        for _ in range(2): outs["genie_assoc_fwd"] = net._hip.assoc_fwd(y_latent, mask_out, x_latent, Mask, net._edge_attr)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): net._hip.assoc_fwd(y_latent, mask_out, x_latent, Mask, net._edge_attr)
+        torch.cuda.synchronize()
+        print("P-sized association heads, genie_assoc_fwd (HIP): %.2f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
         a_ = outs["torch gathers"]
-        for k in ("HIP neighbour means", "HIP means + blocked GEMMs"):
+        for k in ("HIP neighbour means", "HIP means + blocked GEMMs", "genie_assoc_fwd"):
             print("%s: max|diff| %.3e  max|ref| %.3e" % (k, float((a_ - outs[k]).abs().max()), float(a_.abs().max())))
 
 if __name__ == "__main__":
