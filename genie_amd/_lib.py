@@ -60,6 +60,10 @@ SYMBOLS = [
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_train_save_floats", _c.c_size_t, [_P]),
+    ("genie_train_scratch_floats", _c.c_size_t, [_P]),
+    ("genie_da_train_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_da_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_assoc_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_assoc_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),

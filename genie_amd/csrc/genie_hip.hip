@@ -206,6 +206,7 @@ struct StepDesc {
     int32_t o0;       // first output row of this 16-row tile
     int32_t rows;     // valid rows from o0 (<=16)
     int32_t col[4];   // input column supplied by lanes with q = 0..3, <0 = zero
+    int32_t tr;       // 1 = the TRANSPOSE of W is applied (backward passes): A[i][q] = W[col[q]][o0 + i]
 };
 struct BiasDesc {
     int32_t off, o0, rows, pad;
@@ -221,7 +222,7 @@ struct StagePlan {
 
 StepDesc unused_step() {
     StepDesc d;
-    d.mat_off = -1; d.ld = 0; d.o0 = 0; d.rows = 0;
+    d.mat_off = -1; d.ld = 0; d.o0 = 0; d.rows = 0; d.tr = 0;
     d.col[0] = d.col[1] = d.col[2] = d.col[3] = -1;
     return d;
 }
@@ -230,7 +231,17 @@ StepDesc unused_step() {
 void add_block_group(StagePlan& p, int mat, int ld, int o0, int rows, int c0, int nvalid) {
     for (int r = 0; r < 4; ++r) {
         StepDesc d;
-        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows;
+        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows; d.tr = 0;
+        for (int q = 0; q < 4; ++q) d.col[q] = (4 * q + r < nvalid) ? (c0 + 4 * q + r) : -1;
+        p.steps.push_back(d);
+    }
+}
+// the same with W transposed (backward: dX = W^T dY): output element i = COLUMN (o0 + i) of W, i < rows; k-step r consumes
+// ROW (c0 + 4q + r) of W, valid while (4q + r) < nvalid
+void add_block_group_T(StagePlan& p, int mat, int ld, int o0, int rows, int c0, int nvalid) {
+    for (int r = 0; r < 4; ++r) {
+        StepDesc d;
+        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows; d.tr = 1;
         for (int q = 0; q < 4; ++q) d.col[q] = (4 * q + r < nvalid) ? (c0 + 4 * q + r) : -1;
         p.steps.push_back(d);
     }
@@ -240,7 +251,7 @@ void add_scalar_group(StagePlan& p, int mat, int ld, int o0, int rows, const int
     for (int r = 0; r < 4; ++r) {
         if (r >= nsteps) { p.steps.push_back(unused_step()); continue; }
         StepDesc d;
-        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows;
+        d.mat_off = g_params[mat].off; d.ld = ld; d.o0 = o0; d.rows = rows; d.tr = 0;
         for (int q = 0; q < 4; ++q) d.col[q] = (q < nqs[r]) ? (c0s[r] + q) : -1;
         p.steps.push_back(d);
     }
@@ -418,7 +429,7 @@ void build_plans(StagePlan& p1, StagePlan& p2) {
         // steps 2, 3 of the group: station / source absolute-position columns (use_absolute_pos; zero weights otherwise)
         for (int r = 2; r < 4; ++r) {
             StepDesc& d = p1.steps[p1.steps.size() - 4 + r];
-            d.mat_off = g_params[W_DA_INIT_ABS].off; d.ld = 6; d.o0 = 16 * t; d.rows = std::min(16, 30 - 16 * t);
+            d.mat_off = g_params[W_DA_INIT_ABS].off; d.ld = 6; d.o0 = 16 * t; d.rows = std::min(16, 30 - 16 * t); d.tr = 0;
             for (int q = 0; q < 4; ++q) d.col[q] = q < 3 ? 3 * (r - 2) + q : -1;
         }
     }
@@ -542,6 +553,52 @@ void build_assoc_plans(StagePlan& pa, StagePlan& pb) {
     pb.scal.push_back(g_params[W_AS_ACT22].off);
 }
 
+// Backward of DataAggregation + Bipartite_ReadIn (training) as three P-sized passes that mirror the forward
+// stages in reverse (k_train_b2 / k_train_b1 / k_train_b0). Their dX chains are W^T products in the forward's MFMA layout
+// (transposed A fragments); group index maps:
+//  B2: x_latent gradient from the Bipartite message gradient: GT2(b, t) out block b of x_latent, in block t of dz
+#define GT2(b, t) ((b) * 2 + (t))
+#define GT2_GROUPS 4
+//  B1: du / dv from the transposed-mean of do1 / do2; dh1 block hb from {du0, du1, dv0, dv1, do1, do2}; node-local part of
+//      dh0 from dt = [dt1a dt1b dt2a dt2b]
+#define GT_U(b) (b)
+#define GT_V(b) (2 + (b))
+#define GT_H(hb, src) (4 + (hb) * 6 + (src))
+#define GT_D(b, k) (28 + (b) * 4 + (k))
+#define GT1_GROUPS 36
+//  B0: gradient of PReLU11(h0) / PReLU12(h0) from the transposed means of dt1 / dt2 (half h, out block b, in block k)
+#define GT_Q(h, b, k) ((h) * 4 + (b) * 2 + (k))
+#define GT0_GROUPS 8
+
+void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
+    for (int b = 0; b < 2; ++b)
+        for (int t = 0; t < 2; ++t) add_block_group_T(p2, W_BP_FC1_W, 33, 15 * b, 15, 16 * t, t ? 14 : 16);
+    p2.scal.push_back(g_params[W_DA_ACT2].off);
+    p2.scal.push_back(g_params[W_BP_ACT1].off);
+    for (int b = 0; b < 2; ++b) add_block_group_T(p1, W_DA_L2T12_W, 94, 60 + 16 * b, b ? 14 : 16, 0, 15);
+    for (int b = 0; b < 2; ++b) add_block_group_T(p1, W_DA_L2T22_W, 94, 60 + 16 * b, b ? 14 : 16, 0, 15);
+    for (int hb = 0; hb < 4; ++hb) {
+        const int col0 = (hb >> 1) * 30 + 16 * (hb & 1), rows = (hb & 1) ? 14 : 16;
+        for (int src = 0; src < 2; ++src) add_block_group_T(p1, W_DA_L2T11_W, 60, col0, rows, 16 * src, src ? 14 : 16);
+        for (int src = 0; src < 2; ++src) add_block_group_T(p1, W_DA_L2T21_W, 60, col0, rows, 16 * src, src ? 14 : 16);
+        add_block_group_T(p1, W_DA_L2T12_W, 94, col0, rows, 0, 15);
+        add_block_group_T(p1, W_DA_L2T22_W, 94, col0, rows, 0, 15);
+    }
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 4; ++k)
+            add_block_group_T(p1, k < 2 ? W_DA_L1T12_W : W_DA_L1T22_W, 64, 16 * b, b ? 14 : 16, 16 * (k & 1), (k & 1) ? 14 : 16);
+    p1.scal.push_back(g_params[W_DA_ACT1].off);
+    p1.scal.push_back(g_params[W_DA_ACT21].off);
+    p1.scal.push_back(g_params[W_DA_ACT22].off);
+    for (int h = 0; h < 2; ++h)
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 2; ++k)
+                add_block_group_T(p0, h == 0 ? W_DA_L1T12_W : W_DA_L1T22_W, 64, 30 + 16 * b, b ? 14 : 16, 16 * k, k ? 14 : 16);
+    p0.scal.push_back(g_params[W_DA_ACT].off);
+    p0.scal.push_back(g_params[W_DA_ACT11].off);
+    p0.scal.push_back(g_params[W_DA_ACT12].off);
+}
+
 __global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict__ steps, int n_groups,
                        const BiasDesc* __restrict__ bias, int n_bias, const int32_t* __restrict__ scal, int n_scal,
                        float* __restrict__ out) {
@@ -552,7 +609,8 @@ __global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict
         const StepDesc d = steps[grp * 4 + r];
         const int i = lane & 15, q = lane >> 4;
         float v = 0.f;
-        if (d.mat_off >= 0 && i < d.rows && d.col[q] >= 0) v = raw[d.mat_off + (d.o0 + i) * d.ld + d.col[q]];
+        if (d.mat_off >= 0 && i < d.rows && d.col[q] >= 0)
+            v = d.tr ? raw[d.mat_off + d.col[q] * d.ld + (d.o0 + i)] : raw[d.mat_off + (d.o0 + i) * d.ld + d.col[q]];
         out[idx] = v;
     } else if (idx < nw + n_bias * 16) {
         const int k = idx - nw, t = k >> 4, i = k & 15;
@@ -612,6 +670,8 @@ __device__ __forceinline__ f32x4 prelu4s(f32x4 x, float s) {
 // PReLU maps z < 0 to a*z > 0, which the outer one passes through: slope a.
 __device__ __forceinline__ float compose_slopes(float a, float b) { return a >= 0.f ? a * b : a; }
 
+// blocks of the training forward's saved pre-activations (16 channels each): h0, h1 = [t1 | t2], u, v, x_latent, Bipartite message
+constexpr int SV_Z0 = 0, SV_T = 2, SV_UP = 6, SV_VP = 8, SV_O = 10, SV_ZB = 12, SV_BLOCKS = 14;
 constexpr int ROWC = 32;   // row pitch (floats) of c = [c1 0..14,0 | c2 0..14,0]: the node-local layer-2 terms, 128 B
 constexpr int ROWW = 16;   // row pitch of the projected gather operands wu / wv: 15 channels + 1 zero = 64 B
 constexpr int WAVES = 4;   // waves per workgroup
@@ -641,6 +701,8 @@ struct DaArgs {
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
+    float* save;               // training forward (generic kernels): pre-activations kept for the backward passes, 16-float blocks
+                               // [SV_*][P][16] (genie_da_train_fwd), or null
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
     int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
 };
@@ -892,6 +954,10 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+    if (a.save != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_T + k) * a.Pn + p) * 16 + 4 * q) = acc[k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
     if (a.dbg_h1 != nullptr && valid) {
@@ -921,6 +987,10 @@ __device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, c
     }
     o6[4] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, o6[4]);
     o6[5] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, o6[5]);
+    if (a.save != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_UP + k) * a.Pn + p) * 16 + 4 * q) = o6[k];
+    }
     o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
     o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
     // wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v: two accumulators, interleaved
@@ -983,6 +1053,10 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
             gq = a.abs_src[g * 4 + q];
             x0 = MFMA16(wi0.z, lq, x0); x1 = MFMA16(wi1.z, lq, x1);
             x0 = MFMA16(wi0.w, gq, x0); x1 = MFMA16(wi1.w, gq, x1);
+        }
+        if (a.save != nullptr && valid) {
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 0) * a.Pn + p) * 16 + 4 * q) = x0;
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 1) * a.Pn + p) * 16 + 4 * q) = x1;
         }
         x0 = prelu4u(x0, a0);
         x1 = prelu4u(x1, a0);
@@ -1765,6 +1839,10 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
             if (!ABL(a, 1)) gather_sum16<true>(base, (long long)S * ROWW, a.src_col, eb, ee, n2);
             n2 *= 1.f / (float)max(ee - eb, 1);
         }
+        if (a.save != nullptr && valid) {
+            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p) * 16 + 4 * q) = o[0] + n1;
+            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p) * 16 + 4 * q) = o[1] + n2;
+        }
         o[0] = prelu4u(o[0] + n1, a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
         o[1] = prelu4u(o[1] + n2, a2);   // x_latent[15:30]
         if (a.x_latent != nullptr && valid) {
@@ -1787,6 +1865,7 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
             bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + p) * 16 + 4 * q) = bp[t];
             bp[t] = prelu4u(bp[t], ab1);
         }
         float mm = fmaxf(mq, __shfl_xor(mq, 16));
@@ -2494,6 +2573,411 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
             *(f32x4*)(a.wv + pi * ROWW + 4 * q) = wuv[1];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of DataAggregation + Bipartite_ReadIn (training step, train_GENIE_model.py:1843-1861).
+// The training forward is the generic stage kernels with `save` set (pre-activations of h0, h1, u, v, x_latent and the
+// Bipartite message: 14 blocks of 16 floats per product node); the backward mirrors the stages in reverse order:
+//   k_train_b2: d(station sum)[g] -> dz (message) -> dx_latent = fc1[:, 0:30]^T dz -> do = dx_latent PReLU2'(o)      store do
+//   k_train_b1: transposed means of do1 / do2 (reversed base graphs) -> du, dv -> dh1 -> dt = dh1 PReLU1'(t)           store dt, dh0_local
+//   k_train_b0: transposed means of dt1 / dt2 -> dh0 -> dz0
+// Weight gradients are accumulated INSIDE the passes: dW[out, in] = sum over nodes dY[out] X[in] is an MFMA whose contraction
+// runs over the 16 nodes of a tile (operands transposed through a per-wave LDS scratch), into register accumulators that live
+// across all tiles of a wave; the terms that multiply a neighbour mean use the adjoint identity
+//   sum_p dY[p] (x) mean_{k in N(p)} x[k] = sum_k (transposed mean of dY)[k] (x) x[k],
+// so no mean is stored. Bias and PReLU-slope gradients are per-lane running sums. Every wave writes its partials once; a
+// fixed-order reduction over the waves (k_train_reduce) makes the result run-to-run deterministic.
+// ------------------------------------------------------------------------------------------------
+constexpr int GR_DO = 0, GR_DT = 2, GR_DH0 = 6, GR_BLOCKS = 8;      // gradient rows kept between the passes: [GR_*][P][16]
+
+struct AccDesc { int32_t mat_off, ld, row0, nrows, col0, ncols; };   // dW block: D[i][n] -> W[row0 + i][col0 + n]
+struct VecDesc { int32_t off, row0, nrows, pad; };                   // bias block: sum dY[i] -> b[row0 + i]
+
+struct TrArgs {
+    int S, G, T, seg, nxcd;
+    long long P;
+    const int32_t* order;
+    const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
+    const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
+    const float* slice; const float* mask; const float* edge_attr;
+    const float* save; float* gr;
+    const float* dr;             // [G][32] gradient of the per-source-node station sum (Bipartite, before fc2)
+    const float* packed;
+    float* part;                 // per-wave partials: [wave][n_acc * 256 + n_vec * 16 + 16]
+    int n_acc, n_vec;
+};
+
+__device__ __forceinline__ f32x4 ldb(const float* buf, int blk, long long P, long long p, int q) {
+    return *(const f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q);
+}
+__device__ __forceinline__ void stb(float* buf, int blk, long long P, long long p, int q, f32x4 v) {
+    *(f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q) = v;
+}
+__device__ __forceinline__ f32x4 dprelu4(f32x4 x, float s) {     // PReLU'(x): 1 for x > 0, the slope otherwise
+    return f32x4{x.x > 0.f ? 1.f : s, x.y > 0.f ? 1.f : s, x.z > 0.f ? 1.f : s, x.w > 0.f ? 1.f : s};
+}
+__device__ __forceinline__ float negsum4(f32x4 g, f32x4 x) {    // sum of g * min(x, 0): the slope gradient of PReLU
+    return g.x * fminf(x.x, 0.f) + g.y * fminf(x.y, 0.f) + g.z * fminf(x.z, 0.f) + g.w * fminf(x.w, 0.f);
+}
+// V[ch 4q + r][node j] held by lane (j, q) -> vt[s] = V[ch j][node 4s + q]: the operand form of a node-contracting MFMA
+__device__ __forceinline__ f32x4 tr16(f32x4 v, float* sc, int j, int q) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[(4 * q + r) * 17 + j] = v[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 t;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = sc[j * 17 + 4 * s + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+__device__ __forceinline__ f32x4 outer16(f32x4 acc, f32x4 at, f32x4 bt) {       // acc[out][in] += sum over the tile's nodes
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = MFMA16(at[s], bt[s], acc);
+    return acc;
+}
+// transposed mean: sum over the out-edges e of `node` of w_e * rows[col_e], rows of 16 floats addressed by `rowof(col)`
+template <typename F>
+__device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, const float* w, int node, bool uniform, F rowof) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int eb = rp[node], ee = rp[node + 1];
+    if (uniform) { eb = __builtin_amdgcn_readfirstlane(eb); ee = __builtin_amdgcn_readfirstlane(ee); }
+    for (int e = eb; e < ee; ++e) s += rowof(col[e]) * w[e];
+    return s;
+}
+__device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
+                                               const float* scal, int n_scal, int lane, int j, int q) {
+    float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
+    for (int k = 0; k < n_acc; ++k) *(f32x4*)(out + (size_t)k * 256 + lane * 4) = acc[k];
+    out += (size_t)a.n_acc * 256;
+    for (int k = 0; k < n_vec; ++k) {
+        f32x4 v = vec[k];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+        }
+        if (j == 0) *(f32x4*)(out + k * 16 + 4 * q) = v;
+    }
+    out += (size_t)a.n_vec * 16;
+    for (int k = 0; k < n_scal; ++k) {
+        float v = scal[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0) out[k] = v;
+    }
+}
+
+// ---- pass 2': Bipartite message + PReLU2.  accumulators: fc1 (t, {x_latent 0:15, x_latent 15:30, edge_attr}) = 6; vec: fc1 bias (2)
+__global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
+    constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT2_GROUPS * 64);
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[6], vec[2];
+    float scal[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        float mq = a.mask[p * 4 + q];
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (!valid) mm = 0.f;
+        f32x4 eb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) { eb.x = a.edge_attr[p * 3]; eb.y = a.edge_attr[p * 3 + 1]; eb.z = a.edge_attr[p * 3 + 2]; }
+        f32x4 dz[2], o[2], xl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 zb = ldb(a.save, SV_ZB + t, P, p, q);
+            const f32x4 d = *(const f32x4*)(a.dr + (long long)g * 32 + 16 * t + 4 * q) * mm;      // through the mask gate
+            scal[1] += negsum4(d, zb);
+            dz[t] = d * dprelu4(zb, ab1);
+            vec[t] += dz[t];
+            o[t] = ldb(a.save, SV_O + t, P, p, q);
+            xl[t] = prelu4u(o[t], a2);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+            dx = mma_block(dx, lw[GT2(b, 0) * 64 + lane], dz[0]);
+            dx = mma_block(dx, lw[GT2(b, 1) * 64 + lane], dz[1]);
+            if (!valid) dx = f32x4{0.f, 0.f, 0.f, 0.f};
+            scal[0] += negsum4(dx, o[b]);
+            const f32x4 dob = dx * dprelu4(o[b], a2);
+            if (valid) stb(a.gr, GR_DO + b, P, p, q, dob);
+        }
+        const f32x4 x0t = tr16(xl[0], sc, j, q), x1t = tr16(xl[1], sc, j, q), et = tr16(eb, sc, j, q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 dt_ = tr16(dz[t], sc, j, q);
+            acc[t * 3 + 0] = outer16(acc[t * 3 + 0], dt_, x0t);
+            acc[t * 3 + 1] = outer16(acc[t * 3 + 1], dt_, x1t);
+            acc[t * 3 + 2] = outer16(acc[t * 3 + 2], dt_, et);
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 6, vec, 2, scal, 2, threadIdx.x & 63, j, q);
+}
+
+// ---- pass 1': layer 2 and the activation of layer 1.
+// accumulators: l2_t1_2 {h1 x4, Mask, u x2 (adjoint)} = 7, l2_t2_2 = 7, l2_t1_1 (2 x h1 x4) = 8, l2_t2_1 = 8  -> 30
+// vec: b(l2_t1_2), b(l2_t2_2), b(l2_t1_1) x2, b(l2_t2_1) x2 = 6; scal: a1, a21, a22
+__global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
+    constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
+    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[30], vec[6];
+    float scal[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        const float vm = valid ? 1.f : 0.f;
+        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
+        const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
+        const float* gr = a.gr;
+        const f32x4 tm1 = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                                [&](int c) { return ldb(gr, GR_DO + 0, P, (long long)g * S + c, q); }) * vm;
+        const f32x4 tm2 = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                                [&](int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn, q); }) * vm;
+        f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SV_T + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            up[b] = ldb(a.save, SV_UP + b, P, p, q); u[b] = prelu4u(up[b], a21);
+            vp[b] = ldb(a.save, SV_VP + b, P, p, q); v[b] = prelu4u(vp[b], a22);
+        }
+        // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
+        f32x4 du[2], dv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 gu = mma_block(z, lw[GT_U(b) * 64 + lane], tm1), gv = mma_block(z, lw[GT_V(b) * 64 + lane], tm2);
+            scal[1] += negsum4(gu, up[b]);
+            scal[2] += negsum4(gv, vp[b]);
+            du[b] = gu * dprelu4(up[b], a21);
+            dv[b] = gv * dprelu4(vp[b], a22);
+        }
+        // dh1 and dt
+        f32x4 dt[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du[0]);
+            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du[1]);
+            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv[0]);
+            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv[1]);
+            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
+            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
+            scal[0] += negsum4(d, t[hb]);
+            dt[hb] = d * dprelu4(t[hb], a1);
+            if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(b, k) * 64 + lane], dt[k]);
+            if (valid) stb(a.gr, GR_DH0 + b, P, p, q, d);
+        }
+        vec[0] += do1; vec[1] += do2;
+        vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
+        // weight gradients
+        f32x4 h1t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h1t[k] = tr16(h1[k], sc, j, q);
+        const f32x4 mt = tr16(mb, sc, j, q);
+        {
+            const f32x4 d1t = tr16(do1, sc, j, q), d2t = tr16(do2, sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] = outer16(acc[k], d1t, h1t[k]); acc[7 + k] = outer16(acc[7 + k], d2t, h1t[k]); }
+            acc[4] = outer16(acc[4], d1t, mt);
+            acc[11] = outer16(acc[11], d2t, mt);
+            const f32x4 m1t = tr16(tm1, sc, j, q), m2t = tr16(tm2, sc, j, q);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[5 + b] = outer16(acc[5 + b], m1t, tr16(u[b], sc, j, q));
+                acc[12 + b] = outer16(acc[12 + b], m2t, tr16(v[b], sc, j, q));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 dut = tr16(du[b], sc, j, q), dvt = tr16(dv[b], sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[14 + b * 4 + k] = outer16(acc[14 + b * 4 + k], dut, h1t[k]);
+                acc[22 + b * 4 + k] = outer16(acc[22 + b * 4 + k], dvt, h1t[k]);
+            }
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, 6, scal, 3, threadIdx.x & 63, j, q);
+}
+
+// ---- pass 0': layer 1 and init_trns.
+// accumulators: init_trns (2 x [Slice || Mask]) = 2; l1_t1_2 {2 x (h0 x2, Mask), adjoint 2 x 2} = 10; l1_t2_2 = 10  -> 22
+// vec: b(init_trns) x2, b(l1_t1_2) x2, b(l1_t2_2) x2 = 6; scal: a, a11, a12
+__global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
+    constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT0_GROUPS * 64);
+    const float a0 = lscal[0], a11 = lscal[1], a12 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[22], vec[6];
+    float scal[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 22; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        const float vm = valid ? 1.f : 0.f;
+        f32x4 xm = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) { xm = *(const f32x4*)(a.slice + p * 4); mb = *(const f32x4*)(a.mask + p * 4); }
+        if (q == 1) xm = *(const f32x4*)(a.mask + p * 4);
+        const float* gr = a.gr;
+        f32x4 z0[2], h0[2], dt[4], tmd1[2], tmd2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
+            h0[b] = prelu4u(z0[b], a0);
+            tmd1[b] = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                            [&](int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }) * vm;
+            tmd2[b] = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                            [&](int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }) * vm;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
+        f32x4 dz0[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 dq1 = {0.f, 0.f, 0.f, 0.f}, dq2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                dq1 = mma_block(dq1, lw[GT_Q(0, b, k) * 64 + lane], tmd1[k]);
+                dq2 = mma_block(dq2, lw[GT_Q(1, b, k) * 64 + lane], tmd2[k]);
+            }
+            scal[1] += negsum4(dq1, h0[b]);
+            scal[2] += negsum4(dq2, h0[b]);
+            const f32x4 dh0 = ldb(a.gr, GR_DH0 + b, P, p, q) * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
+            scal[0] += negsum4(dh0, z0[b]);
+            dz0[b] = dh0 * dprelu4(z0[b], a0);
+        }
+        vec[0] += dz0[0]; vec[1] += dz0[1];
+        vec[2] += dt[0]; vec[3] += dt[1]; vec[4] += dt[2]; vec[5] += dt[3];
+        const f32x4 xmt = tr16(xm, sc, j, q), mt = tr16(mb, sc, j, q);
+        const f32x4 h0t[2] = {tr16(h0[0], sc, j, q), tr16(h0[1], sc, j, q)};
+        const f32x4 q1t[2] = {tr16(prelu4u(h0[0], a11), sc, j, q), tr16(prelu4u(h0[1], a11), sc, j, q)};
+        const f32x4 q2t[2] = {tr16(prelu4u(h0[0], a12), sc, j, q), tr16(prelu4u(h0[1], a12), sc, j, q)};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[b] = outer16(acc[b], tr16(dz0[b], sc, j, q), xmt);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int base = 2 + 10 * h;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 dtt = tr16(dt[2 * h + b], sc, j, q);
+                acc[base + b * 3 + 0] = outer16(acc[base + b * 3 + 0], dtt, h0t[0]);
+                acc[base + b * 3 + 1] = outer16(acc[base + b * 3 + 1], dtt, h0t[1]);
+                acc[base + b * 3 + 2] = outer16(acc[base + b * 3 + 2], dtt, mt);
+                const f32x4 tmt = tr16(h == 0 ? tmd1[b] : tmd2[b], sc, j, q);
+                acc[base + 6 + b * 2 + 0] = outer16(acc[base + 6 + b * 2 + 0], tmt, h == 0 ? q1t[0] : q2t[0]);
+                acc[base + 6 + b * 2 + 1] = outer16(acc[base + 6 + b * 2 + 1], tmt, h == 0 ? q1t[1] : q2t[1]);
+            }
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 22, vec, 6, scal, 3, threadIdx.x & 63, j, q);
+}
+
+// fixed-order reduction of the per-wave partials into the gradient blob (registry layout of the weight mirror)
+__global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ part, int n_waves, int n_acc, int n_vec, int n_scal,
+                                                      const AccDesc* __restrict__ ad, const VecDesc* __restrict__ vd,
+                                                      const int32_t* __restrict__ sd, float* __restrict__ blob) {
+    const int stride = n_acc * 256 + n_vec * 16 + 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= stride) return;
+    int dst = -1;
+    if (idx < n_acc * 256) {
+        const int k = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
+        const int i = 4 * (lane >> 4) + r, n = lane & 15;
+        const AccDesc d = ad[k];
+        if (i < d.nrows && n < d.ncols) dst = d.mat_off + (d.row0 + i) * d.ld + d.col0 + n;
+    } else if (idx < n_acc * 256 + n_vec * 16) {
+        const int k = (idx - n_acc * 256) >> 4, i = (idx - n_acc * 256) & 15;
+        const VecDesc d = vd[k];
+        if (i < d.nrows) dst = d.off + d.row0 + i;
+    } else {
+        const int k = idx - n_acc * 256 - n_vec * 16;
+        if (k < n_scal) dst = sd[k];
+    }
+    if (dst < 0) return;
+    float s = 0.f;
+    for (int wv = 0; wv < n_waves; ++wv) s += part[(size_t)wv * stride + idx];
+    blob[dst] = s;
+}
+
+__global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * 30) return;
+    const int g = idx / 30, c = idx - g * 30;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += part[((size_t)g * T + t) * 32 + (c < 16 ? c : c)];
+    r_out[idx] = s;
 }
 
 // Stage 2 in the layout of k_stage1_b3: a wave owns two 16-station tiles, lane (j = lane&31, h = lane>>5) holds channels
@@ -3715,11 +4199,16 @@ struct genie_ctx {
     int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
     float* raw;
     bool dirty;
-    StagePlan plan[4];         // 0, 1: DataAggregation stage 1 / stage 2; 2, 3: association stages A / B
-    StepDesc* d_steps[4];
-    BiasDesc* d_bias[4];
-    int32_t* d_scal[4];
-    float* packed[4];
+    StagePlan plan[7];         // 0, 1: DataAggregation stage 1 / 2; 2, 3: association stages A / B; 4, 5, 6: backward passes 2', 1', 0'
+    StepDesc* d_steps[7];
+    BiasDesc* d_bias[7];
+    int32_t* d_scal[7];
+    float* packed[7];
+    AccDesc* d_acc[3]; VecDesc* d_vec[3]; int32_t* d_sc[3];   // gradient maps of the backward passes (k_train_reduce)
+    int n_acc[3], n_vec[3], n_sc[3];
+    float* train_save;         // ... and where those kernels keep the pre-activations (DaArgs.save)
+    int force_generic;         // set for the duration of a training call: the generic fp32 stage kernels (caller's station order,
+                               // pre-activations saved) run whatever the context would normally select
     float* as_pg;              // [G][AS_PG] per-source-node terms of the association stages (allocated on first use)
     int32_t* d_b3tbl;          // k_pack_b3 source table
     int32_t* d_b3tbl2;         // ... of the stage-2 image
@@ -3768,7 +4257,8 @@ namespace {
 // station graph) and k_stage2_fast: active only while those are the kernels that run (not with use_absolute_pos, which takes
 // the generic stage-1 kernel).
 bool sta_order_on(const genie_ctx* c) {
-    return c->sta_perm != nullptr && !c->pcsr && c->use_b3 && c->use_fast && !c->nofast2 && c->nob3s2 && c->abs_sta == nullptr;
+    return c->sta_perm != nullptr && !c->pcsr && c->use_b3 && c->use_fast && !c->nofast2 && c->nob3s2 && c->abs_sta == nullptr &&
+           !c->force_generic;
 }
 
 constexpr int GENIE_NSLOT = 16;  // copies of the G-sized per-window buffers (genie_set_slot)
@@ -3812,7 +4302,7 @@ int dev_copy(T** dst, const T* src_dev, size_t n) {
 
 int ensure_packed(genie_ctx* c, hipStream_t st) {
     if (!c->dirty) return GENIE_OK;
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 7; ++s) {
         const StagePlan& p = c->plan[s];
         const int total = p.packed_floats();
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
@@ -3859,8 +4349,9 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.sta_rowptr = c->sta_rowptr; a.sta_col = c->sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.order = c->order;
     a.src_tab = c->src_tab;
+    a.Pn = c->P;
+    a.save = c->force_generic ? c->train_save : nullptr;
     if (c->pcsr) {
-        a.Pn = c->P;
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
     }
     if (sta_order_on(c)) { a.sta_rowptr = c->sta_rowptr_p; a.sta_col = c->sta_col_p; a.sta_user = c->sta_perm; }
@@ -3874,6 +4365,75 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.c = ws + c->o_c + bo; a.wu = ws + c->o_wu + bo; a.wv = ws + c->o_wv + bo;
     a.part = ws + c->o_part + c->slot * c->slot_stride;
     return a;
+}
+
+// gradient maps of the three backward passes: accumulator / vector / scalar k of pass s -> entries of the gradient blob
+int build_grad_maps(genie_ctx* c) {
+    std::vector<AccDesc> acc[3];
+    std::vector<VecDesc> vec[3];
+    std::vector<int32_t> sc[3];
+    auto A = [&](int s, int mat, int ld, int row0, int nrows, int col0, int ncols) {
+        AccDesc d; d.mat_off = g_params[mat].off; d.ld = ld; d.row0 = row0; d.nrows = nrows; d.col0 = col0; d.ncols = ncols;
+        acc[s].push_back(d);
+    };
+    auto V = [&](int s, int vecid, int row0, int nrows) {
+        VecDesc d; d.off = g_params[vecid].off; d.row0 = row0; d.nrows = nrows; d.pad = 0;
+        vec[s].push_back(d);
+    };
+    auto rows2 = [](int b) { return b ? 14 : 16; };
+    // pass 2': Bipartite fc1 (30 x 33)
+    for (int t = 0; t < 2; ++t) {
+        A(0, W_BP_FC1_W, 33, 16 * t, rows2(t), 0, 15);
+        A(0, W_BP_FC1_W, 33, 16 * t, rows2(t), 15, 15);
+        A(0, W_BP_FC1_W, 33, 16 * t, rows2(t), 30, 3);
+    }
+    for (int t = 0; t < 2; ++t) V(0, W_BP_FC1_B, 16 * t, rows2(t));
+    sc[0] = {g_params[W_DA_ACT2].off, g_params[W_BP_ACT1].off};
+    // pass 1': l2_t1_2 / l2_t2_2 (15 x 94), l2_t1_1 / l2_t2_1 (30 x 60)
+    for (int w = 0; w < 2; ++w) {
+        const int mat = w == 0 ? W_DA_L2T12_W : W_DA_L2T22_W;
+        for (int k = 0; k < 4; ++k) A(1, mat, 94, 0, 15, (k >> 1) * 30 + 16 * (k & 1), rows2(k & 1));
+        A(1, mat, 94, 0, 15, 90, 4);
+        for (int b = 0; b < 2; ++b) A(1, mat, 94, 0, 15, 60 + 16 * b, rows2(b));
+    }
+    for (int w = 0; w < 2; ++w) {
+        const int mat = w == 0 ? W_DA_L2T11_W : W_DA_L2T21_W;
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 4; ++k) A(1, mat, 60, 16 * b, rows2(b), (k >> 1) * 30 + 16 * (k & 1), rows2(k & 1));
+    }
+    V(1, W_DA_L2T12_B, 0, 15); V(1, W_DA_L2T22_B, 0, 15);
+    for (int b = 0; b < 2; ++b) V(1, W_DA_L2T11_B, 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(1, W_DA_L2T21_B, 16 * b, rows2(b));
+    sc[1] = {g_params[W_DA_ACT1].off, g_params[W_DA_ACT21].off, g_params[W_DA_ACT22].off};
+    // pass 0': init_trns (30 x 8), l1_t1_2 / l1_t2_2 (30 x 64)
+    for (int b = 0; b < 2; ++b) A(2, W_DA_INIT_W, 8, 16 * b, rows2(b), 0, 8);
+    for (int h = 0; h < 2; ++h) {
+        const int mat = h == 0 ? W_DA_L1T12_W : W_DA_L1T22_W;
+        for (int b = 0; b < 2; ++b) {
+            A(2, mat, 64, 16 * b, rows2(b), 0, 16);
+            A(2, mat, 64, 16 * b, rows2(b), 16, 14);
+            A(2, mat, 64, 16 * b, rows2(b), 60, 4);
+        }
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 2; ++k) A(2, mat, 64, 16 * b, rows2(b), 30 + 16 * k, rows2(k));
+    }
+    for (int b = 0; b < 2; ++b) V(2, W_DA_INIT_B, 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(2, W_DA_L1T12_B, 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(2, W_DA_L1T22_B, 16 * b, rows2(b));
+    sc[2] = {g_params[W_DA_ACT].off, g_params[W_DA_ACT11].off, g_params[W_DA_ACT12].off};
+    const int want_acc[3] = {6, 30, 22}, want_vec[3] = {2, 6, 6};
+    for (int s = 0; s < 3; ++s) {
+        if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s])
+            return fail(GENIE_ERR_STATE, "internal: gradient maps do not match the backward kernels");
+        c->n_acc[s] = (int)acc[s].size(); c->n_vec[s] = (int)vec[s].size(); c->n_sc[s] = (int)sc[s].size();
+        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * acc[s].size()));
+        HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * vec[s].size()));
+        HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * sc[s].size()));
+        HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
+    }
+    return GENIE_OK;
 }
 
 struct CtxGuard {            // destroys a partially built context on every early return of the create calls
@@ -3932,7 +4492,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->ks_uni = uniform(sta_rowptr, n_sta);
         c->kp_uni = uniform(src_rowptr, n_grid);
     }
-    int rc;
+    int rc, rc_tr = 0;
     if ((rc = dev_copy(&c->sta_rowptr, sta_rowptr, (size_t)n_sta + 1))) return rc;
     if ((rc = dev_copy(&c->sta_col, sta_col, (size_t)e_sta))) return rc;
     if ((rc = dev_copy(&c->src_rowptr, src_rowptr, (size_t)n_grid + 1))) return rc;
@@ -3953,17 +4513,21 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     HIP_TRY(hipMemset(c->raw, 0, sizeof(float) * g_raw_total));
     build_plans(c->plan[0], c->plan[1]);
     build_assoc_plans(c->plan[2], c->plan[3]);
+    build_train_plans(c->plan[4], c->plan[5], c->plan[6]);
+    if (c->plan[4].n_groups() != GT2_GROUPS || c->plan[5].n_groups() != GT1_GROUPS || c->plan[6].n_groups() != GT0_GROUPS)
+        return fail(GENIE_ERR_STATE, "internal: backward plan does not match kernel group maps");
+    if ((rc_tr = build_grad_maps(c))) return rc_tr;
     if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
         (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS ||
         c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
         (int)c->plan[2].bias.size() != GA_BIAS || (int)c->plan[3].bias.size() != GB_BIAS)
         return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 7; ++s) {
         const StagePlan& p = c->plan[s];
         HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
         HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_bias[s], sizeof(BiasDesc) * p.bias.size()));
-        HIP_TRY(hipMemcpy(c->d_bias[s], p.bias.data(), sizeof(BiasDesc) * p.bias.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_bias[s], sizeof(BiasDesc) * std::max<size_t>(1, p.bias.size())));
+        if (!p.bias.empty()) HIP_TRY(hipMemcpy(c->d_bias[s], p.bias.data(), sizeof(BiasDesc) * p.bias.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->d_scal[s], sizeof(int32_t) * 16));
         HIP_TRY(hipMemcpy(c->d_scal[s], p.scal.data(), sizeof(int32_t) * p.scal.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
@@ -4263,6 +4827,9 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1],
                     c->d_steps[2], c->d_steps[3], c->d_bias[2], c->d_bias[3], c->d_scal[2], c->d_scal[3], c->packed[2], c->packed[3],
+                    c->d_steps[4], c->d_steps[5], c->d_steps[6], c->d_bias[4], c->d_bias[5], c->d_bias[6], c->d_scal[4], c->d_scal[5],
+                    c->d_scal[6], c->packed[4], c->packed[5], c->packed[6], c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_vec[0],
+                    c->d_vec[1], c->d_vec[2], c->d_sc[0], c->d_sc[1], c->d_sc[2],
                     c->as_pg, c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
@@ -4346,7 +4913,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         a.x_latent = tbuf1;
     }
 #endif
-    if (c->abs_sta && !c->pcsr && !(c->use_b3 && B3_ABS_READY)) {      // use_absolute_pos: generic kernel (64-bit safe, any graph)
+    if ((c->force_generic || c->abs_sta) && !c->pcsr && !(c->use_b3 && B3_ABS_READY && !c->force_generic)) {   // use_absolute_pos / training: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
@@ -4471,7 +5038,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         }
     }
 #endif
-    if (c->pcsr) {
+    if (c->force_generic && !c->pcsr) {
+        k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
+    } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
     } else if (c->use_b3 && !c->nob3s2 && !no_bip && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
@@ -4942,6 +5511,72 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
         if (KC == 1) k_linear_bwd_w<1><<<nb, 256, 0, st>>>(x, dy + m0, N, K, mc, M, scratch);
         else k_linear_bwd_w<2><<<nb, 256, 0, st>>>(x, dy + m0, N, K, mc, M, scratch);
         k_linear_bwd_sum<<<(per + 31) / 32, 256, 0, st>>>(scratch, nb, KC, K, mc, dW + (size_t)m0 * K, db ? db + m0 : nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+namespace {
+int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }
+size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 6 * 16 + 16); }
+int train_check(const genie_ctx* c, const char* who) {
+    if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
+    if (c->has_edges || c->abs_sta) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
+    return GENIE_OK;
+}
+}  // namespace
+
+size_t genie_train_save_floats(const genie_ctx* c) { return c ? (size_t)SV_BLOCKS * 16 * (size_t)c->P : 0; }
+size_t genie_train_scratch_floats(const genie_ctx* c) { return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) : 0; }
+
+int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, float* save,
+                       float* x_latent_out, float* r_out, void* ws, void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!slice || !mask || !edge_attr || !save || !r_out) return fail(GENIE_ERR_ARG, "genie_da_train_fwd: null argument");
+    if ((rc = train_check(c, "genie_da_train_fwd"))) return rc;
+    c->force_generic = 1; c->train_save = save;
+    rc = run_stage1(c, slice, mask, nullptr, nullptr, ws, stream, 0, c->G, true);
+    if (!rc) rc = run_stage2(c, mask, edge_attr, x_latent_out, ws, stream, 0, c->G);
+    c->force_generic = 0; c->train_save = nullptr;
+    if (rc) return rc;
+    const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
+    k_part_sum<<<(c->G * 30 + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, r_out);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_da_train_bwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save,
+                       const float* d_r, float* scratch, float* grad_blob, void* stream) {
+    if (!c || !slice || !mask || !edge_attr || !save || !d_r || !scratch || !grad_blob)
+        return fail(GENIE_ERR_ARG, "genie_da_train_bwd: null argument");
+    int rc;
+    if ((rc = train_check(c, "genie_da_train_bwd"))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    if (!c->r_sta_rowptr) {
+        if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w))) return rc;
+        if ((rc = build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w))) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * g_raw_total, st));
+    TrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = c->S; a.G = c->G; a.T = c->T; a.seg = std::max(1, c->seg);
+    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
+    a.P = c->P; a.order = c->order;
+    a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
+    a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
+    a.slice = slice; a.mask = mask; a.edge_attr = edge_attr; a.save = save; a.dr = d_r;
+    a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
+    const int grid = train_grid(c), n_waves = grid * 4;
+    for (int s = 0; s < 3; ++s) {
+        a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
+        if (s == 0) k_train_b2<<<grid, 256, 0, st>>>(a);
+        else if (s == 1) k_train_b1<<<grid, 256, 0, st>>>(a);
+        else k_train_b0<<<grid, 256, 0, st>>>(a);
+        const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
+        k_train_reduce<<<(stride + 255) / 256, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
+                                                            c->d_sc[s], grad_blob);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;

@@ -579,6 +579,32 @@ class HipPath(object):
                                             _ptr(out), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_fwd")
         return out
 
+    def train_fwd(self, Slice, Mask, edge_attr, want_x_latent=True):
+        """Training forward of DataAggregation + the P-sized half of Bipartite_ReadIn (genie_da_train_fwd): returns
+        (r [G, 30] = station sums of the gated messages, x_latent [P, 30] or None, save = the pre-activations the backward needs)."""
+        P = self.n_prod
+        Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        save = torch.empty(int(self.lib.genie_train_save_floats(self.ctx)), dtype=torch.float32, device=self.device)
+        r = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        x_latent = torch.empty((P, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
+        _lib.check(self.lib.genie_da_train_fwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(x_latent), _ptr(r),
+                                               self._ws_ptr, _stream()), "genie_da_train_fwd")
+        return r, x_latent, save
+
+    def train_bwd(self, Slice, Mask, edge_attr, save, d_r):
+        """Backward of `train_fwd` (genie_da_train_bwd): d_r [G, 30] -> dict parameter name -> gradient (views into one blob laid
+        out like the weight mirror) for every DataAggregation parameter and Bipartite_ReadIn.fc1 / activate1."""
+        d = torch.zeros((self.n_grid, 32), dtype=torch.float32, device=self.device)
+        d[:, :30] = d_r
+        need = int(self.lib.genie_train_scratch_floats(self.ctx))
+        if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need:
+            self._train_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        blob = torch.empty(self._blob.numel(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_da_train_bwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(d),
+                                               _ptr(self._train_scratch), _ptr(blob), _stream()), "genie_da_train_bwd")
+        return {name: blob[off:off + n] for name, n, off in zip(self.w_names, self.w_numel, self.w_off)}
+
     def nbr_mean(self, x_sta=None, x_src=None):
         """Neighbour means over the product graph of [P, C] rows (C <= 32): (mean over station neighbours of x_sta, mean over
         source neighbours of x_src); genie_nbr_mean on rows padded to 16 / 32 floats ([P, 30] rows as they are)."""

@@ -56,6 +56,35 @@ class _NbrMean(torch.autograd.Function):
         return d_sta, d_src, None
 
 
+TRAIN_FRONT_PARAMS = tuple(
+    ["DataAggregation.%s.%s" % (l, k) for l in ("init_trns", "l1_t1_2", "l1_t2_2", "l2_t1_1", "l2_t2_1", "l2_t1_2", "l2_t2_2")
+     for k in ("weight", "bias")]
+    + ["DataAggregation.%s.weight" % a for a in ("activate", "activate11", "activate12", "activate1", "activate21", "activate22", "activate2")]
+    + ["Bipartite_ReadIn.fc1.weight", "Bipartite_ReadIn.fc1.bias", "Bipartite_ReadIn.activate1.weight"])
+
+
+class _FrontTrain(torch.autograd.Function):
+    """DataAggregation + the P-sized half of Bipartite_ReadIn of a training step as HIP passes in both directions
+    (genie_da_train_fwd / genie_da_train_bwd): forward = the fused stage kernels with their pre-activations kept, backward =
+    three P-sized passes with in-kernel weight gradients. `params` (order TRAIN_FRONT_PARAMS) are listed so that autograd
+    routes their gradients; their values are read from the library's weight mirror (synchronised by the caller)."""
+
+    @staticmethod
+    def forward(ctx, Slice, Mask, edge_attr, hip, *params):
+        r, x_latent, save = hip.train_fwd(Slice, Mask, edge_attr)
+        ctx.hip = hip
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(Slice, Mask, edge_attr, save)
+        ctx.mark_non_differentiable(x_latent)
+        return r, x_latent
+
+    @staticmethod
+    def backward(ctx, d_r, _d_x_latent):
+        Slice, Mask, edge_attr, save = ctx.saved_tensors
+        g = ctx.hip.train_bwd(Slice, Mask, edge_attr, save, d_r.contiguous())
+        return (None, None, None, None) + tuple(g[n].view(s) for n, s in zip(TRAIN_FRONT_PARAMS, ctx.shapes))
+
+
 def _scatter_mean_rows(msg, index, n):
     out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device).index_add_(0, index, msg)
     cnt = torch.zeros(n, dtype=msg.dtype, device=msg.device).index_add_(0, index, torch.ones_like(index, dtype=msg.dtype))
@@ -798,8 +827,14 @@ class GCN_Detection_Network_extended(nn.Module):
         hp = self._hip
         Slice = _engine._f32(Slice, "Slice", (hp.n_prod, 4))
         Mask = _engine._f32(Mask, "Mask", (hp.n_prod, 4))
-        x_latent = self.DataAggregation.forward_train(Slice, Mask, hp)
-        x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid, hp)
+        if os.environ.get("GENIE_TRAIN_AUTOGRAD") is None:
+            # the P-sized front in HIP in both directions; fc2 / PReLU_b2 of Bipartite_ReadIn (G-sized) under autograd
+            hp.sync_weights(self._path_params)
+            r, x_latent = _FrontTrain.apply(Slice, Mask, self._edge_attr, hp, *[self._path_params[n] for n in TRAIN_FRONT_PARAMS])
+            x = self.Bipartite_ReadIn.activate2(self.Bipartite_ReadIn.fc2(r))
+        else:       # A/B: the per-node ops under autograd with HIP neighbour means / PReLU / weight-gradient kernels
+            x_latent = self.DataAggregation.forward_train(Slice, Mask, hp)
+            x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid, hp)
         A_src = torch.as_tensor(self.A_src).long().to(x.device)
         pos = x_temp_cuda_cart.float()
         for sa in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3):

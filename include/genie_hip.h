@@ -270,6 +270,24 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
                        void* stream);
 
+/* Training step of the path (train_GENIE_model.py:1786-1861): DataAggregation + the P-sized half of
+ * Bipartite_ReadIn forward with the pre-activations kept, and their backward as three P-sized HIP passes.
+ *   genie_da_train_fwd: the generic fp32 stage kernels (same arithmetic as genie_da_stage1 / genie_da_stage2_partials) with
+ *     `save` (genie_train_save_floats(ctx) floats) filled; x_latent_out [P, 30] optional; r_out [n_grid, 30] = the per-source-
+ *     node station sum of the gated Bipartite messages (module.py:229, before fc2: out_g = PReLU_b2(fc2 r_g) stays with the
+ *     caller, G-sized).
+ *   genie_da_train_bwd: d_r [n_grid, 32] (gradient of r_out, rows padded to 32 floats) -> grad_blob: gradients of every
+ *     DataAggregation parameter and of Bipartite_ReadIn.fc1 / activate1, laid out like the weight mirror
+ *     (genie_weights_offset(i), genie_weights_blob_floats() floats; entries of other parameters are zero). `scratch`:
+ *     genie_train_scratch_floats(ctx) floats. Deterministic (fixed-order reduction of per-wave partials).
+ * Unsharded Cartesian product graphs, default model definition. */
+size_t genie_train_save_floats(const genie_ctx* ctx);
+size_t genie_train_scratch_floats(const genie_ctx* ctx);
+int genie_da_train_fwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr, float* save,
+                       float* x_latent_out, float* r_out, void* ws, void* stream);
+int genie_da_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr, const float* save,
+                       const float* d_r, float* scratch, float* grad_blob, void* stream);
+
 /* Association heads on the product graph, the P-sized part of `forward_fixed` after the source branch
  * (module.py:986-990): BipartiteGraphReadOutOperator (:333-352) followed by DataAggregationAssociationPhase (:356-403).
  *   y_latent [n_grid, 30] (SpatialDirect output), mask_src [n_grid] (`mask_out`, :985), x_latent [P, 30] (DataAggregation
