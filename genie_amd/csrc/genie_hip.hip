@@ -2944,13 +2944,21 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
     write_partials(a, blockIdx.x * 4 + wave, acc, 22, vec, 6, scal, 3, threadIdx.x & 63, j, q);
 }
 
-// fixed-order reduction of the per-wave partials into the gradient blob (registry layout of the weight mirror)
+// fixed-order reduction of the per-wave partials into the gradient blob (registry layout of the weight mirror): a workgroup
+// owns 32 entries; its 8 groups of 32 threads sum the waves w = group, group + 8, ... and the 8 sums are added in group order
 __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ part, int n_waves, int n_acc, int n_vec, int n_scal,
                                                       const AccDesc* __restrict__ ad, const VecDesc* __restrict__ vd,
                                                       const int32_t* __restrict__ sd, float* __restrict__ blob) {
+    __shared__ float ps[8][32];
     const int stride = n_acc * 256 + n_vec * 16 + 16;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= stride) return;
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (idx < stride)
+        for (int wv = grp; wv < n_waves; wv += 8) s += part[(size_t)wv * stride + idx];
+    ps[grp][o] = s;
+    __syncthreads();
+    if (grp != 0 || idx >= stride) return;
     int dst = -1;
     if (idx < n_acc * 256) {
         const int k = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
@@ -2966,9 +2974,10 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
         if (k < n_scal) dst = sd[k];
     }
     if (dst < 0) return;
-    float s = 0.f;
-    for (int wv = 0; wv < n_waves; ++wv) s += part[(size_t)wv * stride + idx];
-    blob[dst] = s;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += ps[k][o];
+    blob[dst] = t;
 }
 
 __global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles
@@ -5575,7 +5584,7 @@ int genie_da_train_bwd(genie_ctx* c, const float* slice, const float* mask, cons
         else if (s == 1) k_train_b1<<<grid, 256, 0, st>>>(a);
         else k_train_b0<<<grid, 256, 0, st>>>(a);
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 255) / 256, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob);
     }
     HIP_TRY(hipGetLastError());

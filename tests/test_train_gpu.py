@@ -127,3 +127,60 @@ def test_training_step_200_stations_matches_structured_oracle():
         assert max_abs(p.grad.cpu(), w[k].grad) <= tol, (k, max_abs(p.grad.cpu(), w[k].grad), tol)
         checked += 1
     assert checked >= 85
+
+
+def test_hip_training_front_is_used_deterministic_and_equals_the_autograd_formulation(monkeypatch):
+    """The P-sized front of a training step runs as HIP passes in both directions (genie_da_train_fwd / genie_da_train_bwd):
+    it is the path `forward_fixed_source` takes in train() mode, its gradients are bitwise reproducible (fixed-order reduction of
+    per-wave partials) and equal those of the per-node autograd formulation kept for A/B (GENIE_TRAIN_AUTOGRAD=1)."""
+    S, G = 40, 300
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=60, seed=3)
+    win = synthetic.make_window(geom, 900, seed=4)
+    w0 = Case("tiny_6x40").weights
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    rng = np.random.default_rng(9)
+    cy, cx = t(rng.normal(0, 1, (G, 9, 1))), t(rng.normal(0, 1, (60, 9, 1)))
+
+    def run(env):
+        if env:
+            monkeypatch.setenv("GENIE_TRAIN_AUTOGRAD", "1")
+        else:
+            monkeypatch.delenv("GENIE_TRAIN_AUTOGRAD", raising=False)
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+        net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
+        net.train()
+        net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), t(geom.edge_attr()), t(geom.locs),
+                                 t(geom.x_grid))
+        calls = []
+        orig = net._hip.train_bwd
+        net._hip.train_bwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        y, x = net.forward_fixed_source(t(win["Slice"]), t(win["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query),
+                                        t(geom.t_query))
+        ((y * cy).sum() + (x * cx).sum()).backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, len(calls), y.detach(), x.detach()
+
+    g1, n1, y1, x1 = run(False)
+    g2, n2, y2, x2 = run(False)
+    g3, n3, y3, x3 = run(True)
+    assert n1 == 1 and n2 == 1 and n3 == 0
+    assert set(g1) == set(g3) and len(g1) >= 85
+    for k in g1:
+        tol = max(1e-4 * float(g3[k].abs().max()), 1e-6)     # the G- / Q-sized tail under autograd sums with atomics: two runs of
+        assert max_abs(g1[k], g2[k]) <= tol, k                # the SAME path differ by ~1e-6 of a gradient's scale
+        assert max_abs(g1[k], g3[k]) <= tol, (k, max_abs(g1[k], g3[k]), tol)
+    assert max_abs(y1, y3) <= 1e-6 and max_abs(x1, x3) <= 1e-6
+    # the HIP passes themselves are bitwise reproducible for a given upstream gradient
+    from genie_amd import engine
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                        engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), grid_order=engine.sfc_order(geom.x_grid), device=DEV,
+                        sta_order=engine.sfc_order(geom.locs))
+    hp.set_weights({k: v.to(DEV) for k, v in w0.items()})
+    Sl, Mk, ea = t(win["Slice"]), t(win["Mask"]), t(geom.edge_attr())
+    r, xl, save = hp.train_fwd(Sl, Mk, ea)
+    d_r = t(rng.normal(0, 1, (G, 30)))
+    ga = {k: v.clone() for k, v in hp.train_bwd(Sl, Mk, ea, save, d_r).items()}
+    gb = hp.train_bwd(Sl, Mk, ea, save, d_r)
+    assert all(torch.equal(ga[k], gb[k]) for k in ga)
+    # and the training forward equals the inference kernels' x_latent
+    _, xl_inf, _ = hp.path_fwd(Sl, Mk, ea, t(geom.x_grid), True, False)
+    assert max_abs(xl, xl_inf) <= 2e-6
