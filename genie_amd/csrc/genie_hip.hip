@@ -4629,15 +4629,17 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
-        {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. Three workgroups per CU (the
-            // kernel's 164 VGPRs allow three waves per SIMD) matter more than a perfectly even split of the NB * T tiles over
-            // the 4 waves (measured at S = 200, T = 13: NB = 3 -> 0.216 ms, NB = 2 -> 0.218, NB = 4 with two workgroups per CU
-            // 0.251, k_stage2_fast 0.246): the largest-efficiency NB whose image leaves room for three workgroups, provided
-            // >= 90 % of the wave slots are used; otherwise (large S) k_stage2_fast. GENIE_S2_LDS=0 keeps k_stage2_fast.
+        {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. OPT-IN (GENIE_S2_LDS=1). Measured at
+            // S = 200, T = 13 with three workgroups per CU (164 VGPRs): back to back on cache-warm rows it beats k_stage2_fast
+            // (NB = 3: 0.216 ms vs 0.246), but right after stage 1 -- the only order that occurs, c / wu / wv just written, 500 MB --
+            // it is slower (0.299 vs 0.282 ms, bench 0.865 vs 0.856 ms per window on the same box): the staging copy of a phase
+            // is a cold read that all four waves wait for behind a barrier, where k_stage2_fast prefetches a tile ahead. Kept for
+            // the next step (staging the next phase under the current one); NB = the largest-efficiency count that leaves room
+            // for three workgroups per CU, provided >= 90 % of the wave slots are used.
             c->s2_nb = 0; c->s2_bpc = 1;
             const size_t img = sizeof(float) * (G2_GROUPS * 256 + G2_BIAS * 16 + 16);
             const long long budget = (e = getenv("GENIE_S2_LDSKB")) ? 1024ll * atoi(e) : (long long)(160 * 1024 / 3 - img - 256);
-            const bool on = !((e = getenv("GENIE_S2_LDS")) && atoi(e) == 0);
+            const bool on = (e = getenv("GENIE_S2_LDS")) && atoi(e) != 0;
             if (on && c->ks_uni == 8 && c->kp_uni == 15) {
                 int best = 0; double best_eff = 0.0;
                 for (int n = 1; n <= 8 && (long long)n * n_sta * 64 <= budget; ++n) {

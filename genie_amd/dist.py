@@ -230,8 +230,8 @@ class ShardedPath(object):
     def _exchange(self, wv):
         """Pack the SEND rows, all-to-all, halo rows received in place (the halo part of `wv` is contiguous, grouped by owner)."""
         p, S = self.plan, self.n_sta
-        if not p.n_halo and not self._send_idx.numel():
-            return
+        if p.world == 1:
+            return                      # (with several ranks EVERY rank enters the collective, also one with nothing to exchange)
         blocks = wv[: p.n_own * S].view(p.n_own, S * self._pitch)
         if self._send_idx.numel():
             torch.index_select(blocks, 0, self._send_idx, out=self._send_buf)

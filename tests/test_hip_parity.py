@@ -1122,7 +1122,7 @@ def test_set_adjacencies_from_positions_equals_host_built_graphs():
 def test_association_heads_hip_match_oracle(S, G):
     """genie_assoc_fwd (BipartiteGraphReadOutOperator + DataAggregationAssociationPhase, module.py:333-403) against the oracle's
     restatement (pinned to the reference's forward_fixed by tests/golden/assoc_7x45.npz, tests/test_assoc_cpu.py): ragged tiles
-    and small graphs (generic stage-2 kernel), 40 / 200 stations (station processing order, k_stage2_lds without its Bipartite
+    and small graphs (generic stage-2 kernel), 40 / 200 stations (station processing order, k_stage2_fast without its Bipartite
     half); mask1 both 0 and 1; 1e-5 x max(1, max|ref|)."""
     from oracle import genie_oracle as O
     geom = synthetic.Geometry(S, G, L=150e3, n_query=10, seed=S + G)
@@ -1158,3 +1158,31 @@ def test_association_heads_hip_match_oracle(S, G):
         ref_t = net.DataAggregationAssociationPhase(s_t, x_latent, m1_t, Mask.to(DEV), graph.neighbour_table(geom.A_sta_sta, S).long().to(DEV),
                                                     graph.neighbour_table(geom.A_src_src, G).long().to(DEV), S, G, hip=hp)
     assert max_abs(got, ref_t) <= rel_tol(want)
+
+
+@pytest.mark.parametrize("S,G", [(200, 300), (40, 90), (100, 64)])
+def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, monkeypatch):
+    """k_stage2_lds (opt-in, GENIE_S2_LDS=1: station-neighbour rows staged in LDS per phase of NB source nodes) against the
+    default k_stage2_fast: x_latent, Bipartite output and the association pass (stage 2 without its Bipartite half) bit for bit."""
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=10, seed=S)
+    win = synthetic.make_window(geom, 20 * S, seed=S + 1)
+    wd = {k: v.to(DEV) for k, v in Case("cfg1_20x500").weights.items()}
+    Slice, Mask = torch.from_numpy(win["Slice"]).to(DEV), torch.from_numpy(win["Mask"]).to(DEV)
+    ea, pos = torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV)
+    rng = np.random.default_rng(1)
+    yl = torch.from_numpy(rng.normal(0, 1, (G, 30)).astype(np.float32)).to(DEV)
+    ms = torch.from_numpy((rng.random(G) < 0.5).astype(np.float32)).to(DEV)
+
+    def run():
+        hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                            engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), grid_order=engine.sfc_order(geom.x_grid),
+                            device=DEV, sta_order=engine.sfc_order(geom.locs))
+        hp.set_weights(wd)
+        out, xl, bip = hp.path_fwd(Slice, Mask, ea, pos, True, True)
+        return out, xl, bip, hp.assoc_fwd(yl, ms, xl, Mask, ea)
+
+    base = run()
+    monkeypatch.setenv("GENIE_S2_LDS", "1")
+    got = run()
+    for a, b in zip(base, got):
+        assert torch.equal(a, b)

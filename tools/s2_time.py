@@ -15,7 +15,7 @@ from tests.util import Case  # noqa: E402
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2_200x10k"
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     S, G, n_picks, L, nq = synthetic.CONFIGS[cfg]
     geom = synthetic.Geometry(S, G, L=L, n_query=10, seed=1)
     win = synthetic.make_window(geom, n_picks, seed=2)
@@ -27,19 +27,21 @@ def main():
     Slice, Mask = torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev)
     ea = torch.from_numpy(geom.edge_attr()).to(dev)
     hp.set_static_edge_attr(ea)
-    hp.da_stage1(Slice, Mask)
-    for _ in range(iters):
+    # stage 2 is timed where it runs in the path: right after a stage 1 that has just written c / wu / wv (a back-to-back loop
+    # of stage 2 alone re-reads cache-warm rows and ranked k_stage2_lds 12 % ahead of k_stage2_fast; in sequence it is 6 % behind)
+    ms = []
+    for k in range(iters + 10):
+        hp.da_stage1(Slice, Mask)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         hp.da_stage2_partials_range(Mask, ea, 0, G)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        hp.da_stage2_partials_range(Mask, ea, 0, G)
-    e1.record()
-    torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+        if k >= 10:
+            ms.append(e0.elapsed_time(e1))
     bip = hp.bipartite_readout()
     tag = " ".join("%s=%s" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith("GENIE_"))
-    print("stage 2 %s [%s]: %.4f ms  (checksum %.6f)" % (cfg, tag or "defaults", e0.elapsed_time(e1) / iters, float(bip.double().sum())))
+    print("stage 2 %s [%s]: median %.4f ms after stage 1  (checksum %.6f)" % (cfg, tag or "defaults", sorted(ms)[len(ms) // 2], float(bip.double().sum())))
 
 
 if __name__ == "__main__":
