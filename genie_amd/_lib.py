@@ -60,6 +60,11 @@ SYMBOLS = [
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_cu_mask_probe", _c.c_int, [_P, _c.c_int]),
+    ("genie_where_am_i", _c.c_int, [_P, _c.c_int, _P]),
+    ("genie_stream_create_masked", _c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
+    ("genie_stream_destroy", _c.c_int, [_P]),
+    ("genie_set_num_cu", _c.c_int, [_P, _c.c_int]),
     ("genie_train_save_floats", _c.c_size_t, [_P]),
     ("genie_train_scratch_floats", _c.c_size_t, [_P]),
     ("genie_da_train_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),

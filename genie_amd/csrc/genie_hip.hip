@@ -4056,6 +4056,14 @@ __global__ __launch_bounds__(256) void k_linear_bwd_sum(const float* __restrict_
     } else if (db && e - 32 * 64 * KC < M) db[e - 32 * 64 * KC] = v;
 }
 
+// XCC (XCD) id and CU id of the CU a workgroup runs on: maps the bits of a stream CU mask to XCDs (genie_cu_mask_probe)
+__global__ void k_where_am_i(int* __restrict__ out) {
+    int xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));       // HW_REG_XCC_ID
+    asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hwid));      // HW_REG_HW_ID
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hwid; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Exact k-nearest-neighbour search on the device: the `knn(x_context / 1000, x_query / 1000, k)` calls of the
 // reference -- SpatialAttention's query edges (module.py:282; a NEW 112 000-point query set per candidate in the refine pass,
@@ -4256,6 +4264,7 @@ struct genie_ctx {
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
     size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
+    int tail_cu_ro, tail_cu_sa; // grid caps (workgroups) of the read-out / SpatialAggregation kernels of the G-sized tail
     int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
     int slot;                  // lets window i+1's stage 1/2 overlap window i's G-sized kernels on another stream
 };
@@ -4615,6 +4624,11 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     {
         const char* e;
         c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : 1;
+        // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
+        // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
+        // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
+        c->tail_cu_ro = (e = getenv("GENIE_TAIL_RO")) ? std::max(1, atoi(e)) : c->num_cu;
+        c->tail_cu_sa = (e = getenv("GENIE_TAIL_SA")) ? std::max(1, atoi(e)) : c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
         int occ1 = 0, occ2 = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
@@ -5112,7 +5126,7 @@ void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
         a.nx_act3 = g_params[nb + 8].off;
     }
 }
-int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, c->num_cu * 2); }
+int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, c->tail_cu_sa); }
 
 // chain = true: the pre-pass of `layer` was already produced (by k_sa_pre or by the previous layer's NEXT tail) in
 // pj/gpart buffer `cur`; with_next emits the next layer's pre-pass into the other buffer.
@@ -5226,7 +5240,7 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
         const int nb = std::min((a.N + RO_NG0_SLIM - 1) / RO_NG0_SLIM, c->num_cu);
         k_readout<0, RO_NG0_SLIM><<<nb, RO_NG0_SLIM * 32, ro_lds(0, RO_NG0_SLIM), (hipStream_t)stream>>>(a);
     } else {
-        const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
+        const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->tail_cu_ro);
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ro_lds(0, RO_NG0)));
         k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), (hipStream_t)stream>>>(a);
@@ -5250,13 +5264,13 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     a.img = c->ro_img + RO_IMG0;
     float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
-    k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, (hipStream_t)stream>>>(
+    k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, std::min(c->num_cu * 4, c->tail_cu_ro * 4)), 256, 0, (hipStream_t)stream>>>(
         x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf, c->G, 0);
     if (c->tail_slim) {
         const int nb = std::min((a.N + RO_NG1_SLIM - 1) / RO_NG1_SLIM, c->num_cu);
         k_readout<1, RO_NG1_SLIM><<<nb, RO_NG1_SLIM * 32, ro_lds(1, RO_NG1_SLIM), (hipStream_t)stream>>>(a);
     } else {
-        const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
+        const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->tail_cu_ro);
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ro_lds(1, RO_NG1)));
         k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), (hipStream_t)stream>>>(a);
@@ -5326,7 +5340,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     {
         RoArgs g = a;
         g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->ro_img;
-        const int nb = std::min((g.N + RO_NG0 - 1) / RO_NG0, c->num_cu);
+        const int nb = std::min((g.N + RO_NG0 - 1) / RO_NG0, c->tail_cu_ro);
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(0, RO_NG0)));
         k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), st>>>(g);
     }
@@ -5336,7 +5350,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         RoArgs q = a;
         q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
         q.img = c->ro_img + RO_IMG0; q.cv = w + c->o_cv + so; q.cv_ws = ss;
-        const int nb = std::min((q.N + RO_NG1 - 1) / RO_NG1, c->num_cu);
+        const int nb = std::min((q.N + RO_NG1 - 1) / RO_NG1, c->tail_cu_ro);
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(1, RO_NG1)));
         k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), st>>>(q);
     }
@@ -5590,6 +5604,65 @@ int genie_da_train_bwd(genie_ctx* c, const float* slice, const float* mask, cons
                                                             c->d_sc[s], grad_blob);
     }
     HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out) {
+    if (!mask_words || n_words < 1 || !stream_out) return fail(GENIE_ERR_ARG, "genie_stream_create_masked: bad argument");
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+    *stream_out = (void*)st;
+    return GENIE_OK;
+}
+
+int genie_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return GENIE_OK;
+}
+
+int genie_cu_mask_probe(int32_t* xcc_of_bit, int n_bits) {
+    if (!xcc_of_bit || n_bits < 1 || n_bits > 1024) return fail(GENIE_ERR_ARG, "genie_cu_mask_probe: bad argument");
+    int* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(int) * 2 * 64));
+    const int n_words = (n_bits + 31) / 32;
+    std::vector<uint32_t> words((size_t)n_words);
+    std::vector<int> h(2 * 64);
+    for (int b = 0; b < n_bits; ++b) {
+        std::fill(words.begin(), words.end(), 0u);
+        words[b >> 5] = 1u << (b & 31);
+        hipStream_t st = nullptr;
+        xcc_of_bit[b] = -1;
+        if (hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, words.data()) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipMemsetAsync(d, 0xff, sizeof(int) * 2 * 64, st);
+        k_where_am_i<<<64, 64, 0, st>>>(d);
+        const bool ok = hipStreamSynchronize(st) == hipSuccess &&
+                        hipMemcpy(h.data(), d, sizeof(int) * 2 * 64, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipStreamDestroy(st);
+        if (!ok) continue;
+        int x = h[0];
+        for (int k = 1; k < 64; ++k)
+            if (h[2 * k] != x) x = -2;            // the blocks of a one-CU stream must all report the same XCD
+        xcc_of_bit[b] = x;
+    }
+    (void)hipFree(d);
+    return GENIE_OK;
+}
+
+int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream) {
+    if (!out_dev || n_blocks < 1) return fail(GENIE_ERR_ARG, "genie_where_am_i: bad argument");
+    k_where_am_i<<<n_blocks, 64, 0, (hipStream_t)stream>>>(out_dev);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_set_num_cu(genie_ctx* c, int n) {
+    if (!c || n < 0) return fail(GENIE_ERR_ARG, "genie_set_num_cu: bad argument");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const int all = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->num_cu = (n == 0 || n > all) ? all : n;
     return GENIE_OK;
 }
 

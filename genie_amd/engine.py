@@ -350,6 +350,42 @@ class HipPath(object):
                                            _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
         return out, x_latent, bip
 
+    # ---- CU partitioning -----------------------------------------------------------------------------
+    def _masked_stream(self, bits, n_cu_total):
+        n_words = (n_cu_total + 31) // 32
+        words = (ctypes.c_uint32 * n_words)(*[(bits >> (32 * i)) & 0xffffffff for i in range(n_words)])
+        st = ctypes.c_void_p()
+        _lib.check(self.lib.genie_stream_create_masked(words, n_words, ctypes.byref(st)), "genie_stream_create_masked")
+        return torch.cuda.ExternalStream(st.value, device=self.device)
+
+    def enable_cu_partition(self, tail_cus_per_xcd=1, n_xcd=8):
+        """Give the G-sized tails CUs of their own. The persistent P-sized kernels own every register of every CU, so a tail
+        kernel on a side stream only runs when one of their workgroups retires and then holds that CU: ~0.1 ms per window at
+        config 2 for a tail that needs < 4 CU-ms. Streams restricted to disjoint CU sets (hipExtStreamCreateWithCUMask; mask bit
+        b = CU b // 8 of XCD b % 8, measured with tools/cumask_map.py) fix that: `self.main_stream` (all but `tail_cus_per_xcd`
+        CUs of every XCD; the persistent grids are sized for it) and the tail side streams (those CUs). Run the window loop
+        under `with torch.cuda.stream(hp.main_stream)`. Call before the first pipelined window; 0 switches it off."""
+        if getattr(self, "side_streams", None) or getattr(self, "_bt", None) is not None:
+            raise RuntimeError("enable_cu_partition: call before the first pipelined window")
+        total = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        k = int(tail_cus_per_xcd)
+        if k <= 0:
+            self.main_stream, self._tail_bits = None, None
+            _lib.check(self.lib.genie_set_num_cu(self.ctx, 0), "genie_set_num_cu")
+            return None
+        if total % n_xcd or k * n_xcd >= total:
+            raise ValueError("enable_cu_partition: bad partition")
+        tail_bits = (1 << (n_xcd * k)) - 1
+        self._tail_bits, self._cu_total = tail_bits, total
+        self.main_stream = self._masked_stream(((1 << total) - 1) ^ tail_bits, total)
+        _lib.check(self.lib.genie_set_num_cu(self.ctx, total - n_xcd * k), "genie_set_num_cu")
+        return self.main_stream
+
+    def _new_side_stream(self, prio=0):
+        if getattr(self, "_tail_bits", None):
+            return self._masked_stream(self._tail_bits, self._cu_total)
+        return torch.cuda.Stream(device=self.device, priority=prio)
+
     def _next_window_slot(self):
         """Workspace slot the NEXT window (forward_pipelined / window_push) will run under; 0 for the single-stream calls."""
         bt = getattr(self, "_bt", None)
@@ -386,7 +422,7 @@ class HipPath(object):
         if getattr(self, "side_streams", None) is None:
             n_tail = max(1, min(3, int(os.environ.get("GENIE_TAILS", "2"))))
             prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
-            self.side_streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(n_tail)]
+            self.side_streams = [self._new_side_stream(prio) for _ in range(n_tail)]
             self._win = 0
             self._ev_tail = [None] * (n_tail + 1)
         main = torch.cuda.current_stream(self.device)
@@ -454,7 +490,7 @@ class HipPath(object):
             prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
             groups = 3 if self.window_batch == 1 else 2        # batches in flight (16 workspace slots)
             self._bt = {"group": 0, "n": 0, "ev": [None] * groups, "turn": 0,
-                        "streams": [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(2)]}
+                        "streams": [self._new_side_stream(prio) for _ in range(2)]}
             self.side_streams = list(getattr(self, "side_streams", None) or []) + self._bt["streams"]
         bt = self._bt
         if bt["n"] >= self.window_batch:

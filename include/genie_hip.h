@@ -270,6 +270,21 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
                        void* stream);
 
+/* CU partitioning for the window pipeline. The P-sized stage kernels are persistent and own every register of every CU, so a
+ * G-sized tail kernel of the previous window on another stream only runs when one of their workgroups retires and then holds
+ * that CU: the tail costs the main stream ~0.1 ms per window although it needs under 4 CU-milliseconds. With HIP streams
+ * restricted to disjoint CU sets (hipExtStreamCreateWithCUMask) the tail gets a few CUs of its own (one or two per XCD) and
+ * the stage kernels the rest.
+ *   genie_cu_mask_probe: xcc_of_bit[b] = XCD of the CU that bit b of a CU mask enables (-1: none) -- measured, one-CU streams
+ *   genie_stream_create_masked / genie_stream_destroy: a HIP stream limited to the CUs whose mask bits are set
+ *   genie_set_num_cu: size the persistent grids of this context for n CUs (0 = all), to be used with a stream of n CUs */
+int genie_cu_mask_probe(int32_t* xcc_of_bit, int n_bits);
+/* out_dev [n_blocks][2] = (HW_REG_XCC_ID, HW_REG_HW_ID) of the CU every workgroup of a probe launch ran on */
+int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream);
+int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out);
+int genie_stream_destroy(void* stream);
+int genie_set_num_cu(genie_ctx* ctx, int n);
+
 /* Training step of the path (train_GENIE_model.py:1786-1861): DataAggregation + the P-sized half of
  * Bipartite_ReadIn forward with the pre-activations kept, and their backward as three P-sized HIP passes.
  *   genie_da_train_fwd: the generic fp32 stage kernels (same arithmetic as genie_da_stage1 / genie_da_stage2_partials) with
