@@ -666,6 +666,11 @@ __device__ __forceinline__ f32x4 prelu4s(f32x4 x, float s) {
     else     { y.x = fminf(x.x, t.x); y.y = fminf(x.y, t.y); y.z = fminf(x.z, t.z); y.w = fminf(x.w, t.w); }
     return y;
 }
+// mean = sum * (1 / degree) added to the node-local term as ONE fused multiply-add per channel, spelled out so that every
+// stage-2 kernel rounds the same way whatever the compiler would contract (the variants are bitwise equal by test)
+__device__ __forceinline__ f32x4 fma4(f32x4 s, float inv, f32x4 c) {
+    return f32x4{fmaf(s.x, inv, c.x), fmaf(s.y, inv, c.y), fmaf(s.z, inv, c.z), fmaf(s.w, inv, c.w)};
+}
 // PReLU_b(PReLU_a(z)) is again one PReLU: slope a*b on the negative side when a >= 0; when a < 0 the inner
 // PReLU maps z < 0 to a*z > 0, which the outer one passes through: slope a.
 __device__ __forceinline__ float compose_slopes(float a, float b) { return a >= 0.f ? a * b : a; }
@@ -701,6 +706,9 @@ struct DaArgs {
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
+    int* dyn;                  // dynamic work distribution (k_stage1_b3, k_stage2_fast): [8] per-XCD item counters of THIS launch,
+    int* dyn_next;             // ... and the set the next launch of this kind will use (zeroed by this one), or null = static
+    int dyn_batch;             // items a wave claims per atomic
     float* save;               // training forward (generic kernels): pre-activations kept for the backward passes, 16-float blocks
                                // [SV_*][P][16] (genie_da_train_fwd), or null
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
@@ -711,7 +719,7 @@ struct DaArgs {
 // its contiguous chunk of the processing order. Inside the chunk items are ordered in SEGMENTS of `seg` source
 // nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ...
 struct ItemIter {
-    int gbeg, gend, T, seg;
+    int gbeg, gend, T, seg, xcd_;
     unsigned per_seg, m_per_seg, n_full, m_full, n_last, m_last, last_seg;   // divisors and their 2^32 reciprocals
     long long it, stride, nitems;
     // floor(x / d) for x < 2^31 with m = floor(2^32 / d): scalar multiply-high + at most two corrections (a hardware
@@ -727,6 +735,7 @@ struct ItemIter {
     __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0) {
         const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
         const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+        xcd_ = xcd;
         gbeg = gi0 + (int)((long long)G * xcd / nx);
         gend = gi0 + (int)((long long)G * (xcd + 1) / nx);
         T = T_;
@@ -755,6 +764,26 @@ struct ItemIter {
         gi = gbeg + (int)(sidx * (unsigned)seg) + (int)r2;
     }
 };
+
+// Dynamic work distribution of the persistent P-sized kernels. With a static partition (item = first + k * stride) a workgroup
+// that loses its CU for a while to a G-sized tail kernel of the previous window (window pipeline) finishes late and the whole
+// launch waits for it; with per-XCD item counters a delayed wave simply claims fewer batches. One relaxed atomic per batch and
+// wave, on a counter only the workgroups of one XCD touch (it stays in that XCD's L2). The counters of a launch are zeroed by
+// the PREVIOUS launch of the same kind (two alternating sets), so no extra launch and no host round trip.
+__device__ __forceinline__ long long dyn_claim(int* ctr, int batch, int lane) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(ctr, batch);
+    return (long long)__builtin_amdgcn_readfirstlane(v);
+}
+// the same split in two: the atomic is issued where the item will be needed an item later, its result is read (and only
+// then waited for) at the point of use, so a claim costs its issue slot and not the ~1 us round trip. One item per claim keeps
+// the concurrently processed items of an XCD as contiguous as the static round-robin does (neighbour rows shared in L2).
+__device__ __forceinline__ int dyn_claim_issue(int* ctr, int lane) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(ctr, 1);
+    return v;
+}
+__device__ __forceinline__ long long dyn_claim_value(int v) { return (long long)__builtin_amdgcn_readfirstlane(v); }
 
 // Neighbour sum of PReLU_s(init_trns [Slice || Mask]) with the 30-channel hidden state RECOMPUTED from the raw
 // 8 input floats of every neighbour (2 k-steps x 2 out tiles = 4 MFMAs) instead of gathered from memory: a
@@ -1569,17 +1598,24 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     };
     int idv = 0, sc = 0, sta_id[KS];
     bool valid = false;
-    if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, valid, sta_id);
+    // item stream of this wave: static (first + k * stride) or dynamic batches claimed from the XCD's counter
+    const bool dyn = a.dyn != nullptr;
+    const long long npairs = (w.nitems + 1) / 2;
+    int* ctr = dyn ? a.dyn + w.xcd_ : nullptr;
+    if (dyn && blockIdx.x < 8 && threadIdx.x == 0) a.dyn_next[blockIdx.x] = 0;
+    long long pit0 = w.it;
+    if (dyn) pit0 = dyn_claim(ctr, 1, lane);
+    if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
 #if GENIE_TUNING && GENIE_PHASES
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define PH1(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 #else
 #define PH1(k) do { } while (0)
 #endif
-    for (long long pit = w.it; 2 * pit < w.nitems; pit += w.stride) {
+    for (long long pit = pit0, pnext = 0; 2 * pit < w.nitems; pit = pnext) {
         asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park all 75 in VGPRs)
         PH1(0);
-        const bool has_next = 2 * (pit + w.stride) < w.nitems;
+        const int claim = dyn ? dyn_claim_issue(ctr, lane) : 0;          // read after the neighbour phase
         const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
         const int g = half ? g1 : g0;
         const long long p = (long long)g * S + sc;
@@ -1655,7 +1691,9 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         bool valid_n = false;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_n[k] = 0;
-        if (has_next) fetch_ids(pit + w.stride, idv_n, sc_n, valid_n, sta_n);
+        pnext = dyn ? dyn_claim_value(claim) : pit + w.stride;
+        const bool has_next = 2 * pnext < w.nitems;
+        if (has_next) fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
         PH1(1);
         if (a.dbg_h0 != nullptr && valid) {
 #pragma unroll
@@ -1830,21 +1868,21 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
             const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
             const float* base = a.wu + (long long)g * S * ROWW + 4 * q;
             if (!ABL(a, 0)) gather_sum16<false>(base, ROWW, a.sta_col, eb, ee, n1);
-            n1 *= 1.f / (float)max(ee - eb, 1);
+            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
         }
         {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
             const float* base = a.wv + (long long)sc * ROWW + 4 * q;
             if (!ABL(a, 1)) gather_sum16<true>(base, (long long)S * ROWW, a.src_col, eb, ee, n2);
-            n2 *= 1.f / (float)max(ee - eb, 1);
+            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
         }
         if (a.save != nullptr && valid) {
-            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p) * 16 + 4 * q) = o[0] + n1;
-            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p) * 16 + 4 * q) = o[1] + n2;
+            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p) * 16 + 4 * q) = o[0];
+            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p) * 16 + 4 * q) = o[1];
         }
-        o[0] = prelu4u(o[0] + n1, a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
-        o[1] = prelu4u(o[1] + n2, a2);   // x_latent[15:30]
+        o[0] = prelu4u(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
+        o[1] = prelu4u(o[1], a2);   // x_latent[15:30]
         if (a.x_latent != nullptr && valid) {
             float* xl = a.x_latent + p * 30;
 #pragma unroll
@@ -1917,15 +1955,15 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
         {
             const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
             gather_sum16<false>(a.wu + 4 * q, ROWW, a.sta_col, eb, ee, n1);
-            n1 *= 1.f / (float)max(ee - eb, 1);
+            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
         }
         {
             const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
             gather_sum16<false>(a.wv + 4 * q, ROWW, a.src_col, eb, ee, n2);
-            n2 *= 1.f / (float)max(ee - eb, 1);
+            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
         }
-        o[0] = prelu4u(o[0] + n1, a2);
-        o[1] = prelu4u(o[1] + n2, a2);
+        o[0] = prelu4u(o[0], a2);
+        o[1] = prelu4u(o[1], a2);
         if (a.x_latent != nullptr && valid) {
             float* xl = a.x_latent + p * 30;
 #pragma unroll
@@ -1975,7 +2013,15 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    if (w.it >= w.nitems) return;
+    // item stream of this wave: static (first + k * stride) or dynamic batches claimed from the XCD's counter (see dyn_claim)
+    const bool dyn = a.dyn != nullptr;
+    int* ctr = dyn ? a.dyn + w.xcd_ : nullptr;
+    if (dyn && blockIdx.x < 8 && threadIdx.x == 0) a.dyn_next[blockIdx.x] = 0;
+    long long i0 = dyn ? dyn_claim(ctr, 1, lane) : w.it;
+    if (i0 >= w.nitems) return;
+    long long i1 = dyn ? dyn_claim(ctr, 1, lane) : i0 + w.stride, i2 = w.nitems;
+    int claim = 0;                                          // pending claim of the item after next (dynamic mode)
+    bool pending = false;
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
     const unsigned q16 = 16u * (unsigned)q;          // byte offset of this lane's 4 channels inside a 64-B row
@@ -2039,9 +2085,12 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
 #endif
     Ids cur, nxt, nn;
     Rows rows;
-    fetch_ids(w.it, cur);
+    fetch_ids(i0, cur);
     nxt = cur;
-    if (w.it + w.stride < w.nitems) fetch_ids(w.it + w.stride, nxt);
+    if (i1 < w.nitems) {
+        fetch_ids(i1, nxt);
+        if (dyn) { claim = dyn_claim_issue(ctr, lane); pending = true; } else i2 = i1 + w.stride;
+    }
     issue(cur, rows, 0, 0u);
     issue(cur, rows, 1, 0u);
     issue(cur, rows, 2, 0u);
@@ -2049,7 +2098,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
 #endif
-        const bool has_next = w.it + w.stride < w.nitems;
+        const bool has_next = i1 < w.nitems;
         const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
         const long long p = (long long)g_c * S + cur.sc;
         PH(0);
@@ -2068,10 +2117,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
         if (has_next) issue(nxt, rows, 0, tk);
         PH(2);
-        n1 *= 1.f / (float)KS;
-        n2 *= 1.f / (float)KP;
-        o[0] = prelu4u(o[0] + n1, a2);
-        o[1] = prelu4u(o[1] + n2, a2);
+        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, o[0]), a2);
+        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, o[1]), a2);
         if (a.x_latent != nullptr && cur.valid) {
             float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
 #pragma unroll
@@ -2088,7 +2135,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
         nn = nxt;
         if (a.no_bip) {
             if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
-            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
+            if (i2 < w.nitems) fetch_ids(i2, nn);
         } else if (!ABL(a, 6)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -2100,7 +2148,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
                 asm volatile("" : "+v"(tk), "+v"(bp[t]));
                 if (has_next) issue(nxt, rows, 1 + t, tk);
             }
-            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
+            if (i2 < w.nitems) fetch_ids(i2, nn);
             PH(3);
             float mm = fmaxf(mq, __shfl_xor(mq, 16));
             mm = fmaxf(mm, __shfl_xor(mm, 32));
@@ -2119,14 +2168,18 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
             }
         } else {
             if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
-            if (w.it + 2 * w.stride < w.nitems) fetch_ids(w.it + 2 * w.stride, nn);
+            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
+            if (i2 < w.nitems) fetch_ids(i2, nn);
             if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
         }
         PH(4);
         if (!has_next) break;
         cur = nxt;
         nxt = nn;
-        w.it += w.stride;
+        i0 = i1; i1 = i2; i2 = w.nitems;
+        if (i1 < w.nitems) {
+            if (dyn) { claim = dyn_claim_issue(ctr, lane); pending = true; } else i2 = i1 + w.stride;
+        }
     }
 #if GENIE_TUNING && GENIE_PHASES
     if (ABL(a, 10) && a.dbg_h0 != nullptr && lane == 0)
@@ -2251,10 +2304,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, in
             unsigned tk = 0u;
             asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
             if (has_next) issue(nxt, rows, 0, tk);
-            n1 *= 1.f / (float)KS;
-            n2 *= 1.f / (float)KP;
-            o[0] = prelu4u(o[0] + n1, a2);
-            o[1] = prelu4u(o[1] + n2, a2);
+            o[0] = prelu4u(fma4(n1, 1.f / (float)KS, o[0]), a2);
+            o[1] = prelu4u(fma4(n2, 1.f / (float)KP, o[1]), a2);
             if (a.x_latent != nullptr && cur.valid) {
                 float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
 #pragma unroll
@@ -4223,6 +4274,9 @@ struct genie_ctx {
     float* packed[7];
     AccDesc* d_acc[3]; VecDesc* d_vec[3]; int32_t* d_sc[3];   // gradient maps of the backward passes (k_train_reduce)
     int n_acc[3], n_vec[3], n_sc[3];
+    int* dyn_ctr;              // dynamic work distribution: [kind 2][slot % GENIE_NBIG][parity 2][8] per-XCD item counters
+    int dyn_parity[2][4];      // which set the next launch of (kind, slot) uses
+    int dyn_on, dyn_b1, dyn_b2;
     float* train_save;         // ... and where those kernels keep the pre-activations (DaArgs.save)
     int force_generic;         // set for the duration of a training call: the generic fp32 stage kernels (caller's station order,
                                // pre-activations saved) run whatever the context would normally select
@@ -4459,6 +4513,18 @@ struct CtxGuard {            // destroys a partially built context on every earl
     ~CtxGuard() { if (c) genie_ctx_destroy(c); }
 };
 
+// counters of the next launch of `kind` (0 = stage 1, 1 = stage 2) under the current slot; toggles the parity
+void set_dyn(genie_ctx* c, DaArgs& a, int kind, int batch) {
+    a.dyn = a.dyn_next = nullptr; a.dyn_batch = batch;
+    if (!c->dyn_on || !c->dyn_ctr) return;
+    const int s4 = c->slot % 4;
+    int& par = c->dyn_parity[kind][s4];
+    int* base = c->dyn_ctr + ((kind * 4 + s4) * 2) * 8;
+    a.dyn = base + par * 8;
+    a.dyn_next = base + (par ^ 1) * 8;
+    par ^= 1;
+}
+
 int check_ws(const genie_ctx* c, const void* ws) {
     if (!c) return fail(GENIE_ERR_ARG, "null context");
     if (!ws) return fail(GENIE_ERR_ARG, "null workspace");
@@ -4624,6 +4690,14 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     {
         const char* e;
         c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : 1;
+        // opt-in experiment (GENIE_DYN=1), measured SLOWER at config 2: one item per claim saturates the counters (stage 2 1.5 ms),
+        // batches of 8-16 items per wave widen the set of source nodes an XCD works on at once and lose the L2 sharing of the
+        // neighbour rows (stage 2 0.27 -> 0.33 ms, window 0.846 -> 0.857 ms)
+        c->dyn_on = ((e = getenv("GENIE_DYN")) && atoi(e) != 0);
+        c->dyn_b1 = (e = getenv("GENIE_DYN_B1")) ? std::max(1, atoi(e)) : 4;       // tile pairs per claim (k_stage1_b3)
+        c->dyn_b2 = (e = getenv("GENIE_DYN_B2")) ? std::max(1, atoi(e)) : 8;       // tiles per claim (k_stage2_fast)
+        HIP_TRY(hipMalloc((void**)&c->dyn_ctr, sizeof(int) * 2 * 4 * 2 * 8));
+        HIP_TRY(hipMemset(c->dyn_ctr, 0, sizeof(int) * 2 * 4 * 2 * 8));
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
@@ -4855,7 +4929,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[4], c->d_steps[5], c->d_steps[6], c->d_bias[4], c->d_bias[5], c->d_bias[6], c->d_scal[4], c->d_scal[5],
                     c->d_scal[6], c->packed[4], c->packed[5], c->packed[6], c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_vec[0],
                     c->d_vec[1], c->d_vec[2], c->d_sc[0], c->d_sc[1], c->d_sc[2],
-                    c->as_pg, c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
+                    c->as_pg, c->dyn_ctr, c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
@@ -4964,6 +5038,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
         a.xs = xs; a.packed = c->packed_b3;
+        if (n_tiles) set_dyn(c, a, 0, c->dyn_b1);
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
@@ -5077,8 +5152,10 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
         g = std::max<long long>(8, (g + 7) / 8 * 8);
         k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
-    } else if (c->use_fast && !c->nofast2)
+    } else if (c->use_fast && !c->nofast2) {
+        set_dyn(c, a, 1, c->dyn_b2);
         k_stage2_fast<8, 15><<<da_grid(c, n_tiles, c->bpc2f), 256, 0, st>>>(a);
+    }
     else
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
