@@ -51,11 +51,11 @@ BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r01_k_pmc_stage_kernels.txt"
-TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.481e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
-                "k_stage2": 0.968e9}                                                          # k_stage2_fast
+TRAFFIC_SOURCE = "profiles/r02_a_pmc_stage_kernels.txt"
+TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.485e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
+                "k_stage2": (2.0 * 4.638e5 + 1.626e4) * 1024.0}                               # k_stage2_fast
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
-ONE_GPU_CFG4 = {"ms_per_step": 42.4, "source": "DESIGN.md section 5 (round-1 builder run, single stream)"}
+ONE_GPU_CFG4 = {"ms_per_step": 42.69, "source": "profiles/r02_a_bench_cfg4_one_gpu.json (this code path with --gpus 1)"}
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 

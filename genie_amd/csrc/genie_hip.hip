@@ -709,6 +709,7 @@ struct DaArgs {
     int* dyn;                  // dynamic work distribution (k_stage1_b3, k_stage2_fast): [8] per-XCD item counters of THIS launch,
     int* dyn_next;             // ... and the set the next launch of this kind will use (zeroed by this one), or null = static
     int dyn_batch;             // items a wave claims per atomic
+    int dyn_gw;                // workgroups per group sharing one counter (0 = a whole XCD)
     float* save;               // training forward (generic kernels): pre-activations kept for the backward passes, 16-float blocks
                                // [SV_*][P][16] (genie_da_train_fwd), or null
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
@@ -719,7 +720,7 @@ struct DaArgs {
 // its contiguous chunk of the processing order. Inside the chunk items are ordered in SEGMENTS of `seg` source
 // nodes, station-tile major inside a segment: (tile 0 of seg nodes), (tile 1 of seg nodes), ...
 struct ItemIter {
-    int gbeg, gend, T, seg, xcd_;
+    int gbeg, gend, T, seg, xcd_, chunk_, lead_;    // chunk_: id of the (XCD, group) chunk; lead_: first workgroup of the chunk
     unsigned per_seg, m_per_seg, n_full, m_full, n_last, m_last, last_seg;   // divisors and their 2^32 reciprocals
     long long it, stride, nitems;
     // floor(x / d) for x < 2^31 with m = floor(2^32 / d): scalar multiply-high + at most two corrections (a hardware
@@ -732,12 +733,26 @@ struct ItemIter {
         return q;
     }
     static __device__ __forceinline__ unsigned recip(unsigned d) { return d <= 1u ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
-    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0) {
+    // gw > 0: the workgroups of an XCD are split into GROUPS of gw; a group owns a contiguous sub-chunk of the XCD's chunk and
+    // iterates (or, with dynamic claims, shares a counter) only among its own workgroups
+    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0, int gw = 0) {
         const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
-        const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+        const int xcd = blockIdx.x % nx;
+        int lb = blockIdx.x / nx, nbx = gridDim.x / nx;
         xcd_ = xcd;
         gbeg = gi0 + (int)((long long)G * xcd / nx);
         gend = gi0 + (int)((long long)G * (xcd + 1) / nx);
+        chunk_ = xcd; lead_ = lb == 0;
+        if (gw > 0 && nbx > gw) {
+            const int ng = (nbx + gw - 1) / gw, grp = lb / gw;
+            const int n = gend - gbeg, b0 = gbeg;
+            gbeg = b0 + (int)((long long)n * grp / ng);
+            gend = b0 + (int)((long long)n * (grp + 1) / ng);
+            nbx = min(gw, nbx - grp * gw);
+            lb -= grp * gw;
+            chunk_ = xcd + nx * grp;
+            lead_ = lb == 0;
+        }
         T = T_;
         seg = seg_;
         nitems = (long long)(gend - gbeg) * T;
@@ -770,6 +785,7 @@ struct ItemIter {
 // launch waits for it; with per-XCD item counters a delayed wave simply claims fewer batches. One relaxed atomic per batch and
 // wave, on a counter only the workgroups of one XCD touch (it stays in that XCD's L2). The counters of a launch are zeroed by
 // the PREVIOUS launch of the same kind (two alternating sets), so no extra launch and no host round trip.
+constexpr int DYN_NCTR_DEV = 1024;
 __device__ __forceinline__ long long dyn_claim(int* ctr, int batch, int lane) {
     int v = 0;
     if (lane == 0) v = atomicAdd(ctr, batch);
@@ -1573,7 +1589,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
     const bool hi = h != 0;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, a.dyn != nullptr ? a.dyn_gw : 0);
     const char* xs = (const char*)a.xs;
     const unsigned la = hi ? 16u : 0u, lb = hi ? 0u : 32u;       // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]
     const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XROW);
@@ -1601,8 +1617,9 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     // item stream of this wave: static (first + k * stride) or dynamic batches claimed from the XCD's counter
     const bool dyn = a.dyn != nullptr;
     const long long npairs = (w.nitems + 1) / 2;
-    int* ctr = dyn ? a.dyn + w.xcd_ : nullptr;
-    if (dyn && blockIdx.x < 8 && threadIdx.x == 0) a.dyn_next[blockIdx.x] = 0;
+    int* ctr = dyn ? a.dyn + w.chunk_ : nullptr;
+    if (dyn && blockIdx.x == 0)      // the whole set the next launch of this kind will claim from (its chunk count may differ)
+        for (int i = threadIdx.x; i < DYN_NCTR_DEV; i += blockDim.x) a.dyn_next[i] = 0;
     long long pit0 = w.it;
     if (dyn) pit0 = dyn_claim(ctr, 1, lane);
     if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
@@ -2012,11 +2029,12 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    // item stream of this wave: static (first + k * stride) or dynamic batches claimed from the XCD's counter (see dyn_claim)
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, a.dyn != nullptr ? a.dyn_gw : 0);
+    // item stream of this wave: static (first + k * stride) or single items claimed from its group's counter (see dyn_claim)
     const bool dyn = a.dyn != nullptr;
-    int* ctr = dyn ? a.dyn + w.xcd_ : nullptr;
-    if (dyn && blockIdx.x < 8 && threadIdx.x == 0) a.dyn_next[blockIdx.x] = 0;
+    int* ctr = dyn ? a.dyn + w.chunk_ : nullptr;
+    if (dyn && blockIdx.x == 0)      // the whole set the next launch of this kind will claim from (its chunk count may differ)
+        for (int i = threadIdx.x; i < DYN_NCTR_DEV; i += blockDim.x) a.dyn_next[i] = 0;
     long long i0 = dyn ? dyn_claim(ctr, 1, lane) : w.it;
     if (i0 >= w.nitems) return;
     long long i1 = dyn ? dyn_claim(ctr, 1, lane) : i0 + w.stride, i2 = w.nitems;
@@ -4514,14 +4532,16 @@ struct CtxGuard {            // destroys a partially built context on every earl
 };
 
 // counters of the next launch of `kind` (0 = stage 1, 1 = stage 2) under the current slot; toggles the parity
-void set_dyn(genie_ctx* c, DaArgs& a, int kind, int batch) {
-    a.dyn = a.dyn_next = nullptr; a.dyn_batch = batch;
-    if (!c->dyn_on || !c->dyn_ctr) return;
+constexpr int DYN_NCTR = DYN_NCTR_DEV;      // counters per set: one per (XCD, group) chunk of a launch
+
+void set_dyn(genie_ctx* c, DaArgs& a, int kind, int gw, int grid) {
+    a.dyn = a.dyn_next = nullptr; a.dyn_batch = 1; a.dyn_gw = gw;
+    if (!((c->dyn_on >> kind) & 1) || !c->dyn_ctr || gw < 1 || 8 * ((grid / 8 + gw - 1) / gw) > DYN_NCTR) return;
     const int s4 = c->slot % 4;
     int& par = c->dyn_parity[kind][s4];
-    int* base = c->dyn_ctr + ((kind * 4 + s4) * 2) * 8;
-    a.dyn = base + par * 8;
-    a.dyn_next = base + (par ^ 1) * 8;
+    int* base = c->dyn_ctr + ((kind * 4 + s4) * 2) * DYN_NCTR;
+    a.dyn = base + par * DYN_NCTR;
+    a.dyn_next = base + (par ^ 1) * DYN_NCTR;
     par ^= 1;
 }
 
@@ -4693,11 +4713,11 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // opt-in experiment (GENIE_DYN=1), measured SLOWER at config 2: one item per claim saturates the counters (stage 2 1.5 ms),
         // batches of 8-16 items per wave widen the set of source nodes an XCD works on at once and lose the L2 sharing of the
         // neighbour rows (stage 2 0.27 -> 0.33 ms, window 0.846 -> 0.857 ms)
-        c->dyn_on = ((e = getenv("GENIE_DYN")) && atoi(e) != 0);
-        c->dyn_b1 = (e = getenv("GENIE_DYN_B1")) ? std::max(1, atoi(e)) : 4;       // tile pairs per claim (k_stage1_b3)
-        c->dyn_b2 = (e = getenv("GENIE_DYN_B2")) ? std::max(1, atoi(e)) : 8;       // tiles per claim (k_stage2_fast)
-        HIP_TRY(hipMalloc((void**)&c->dyn_ctr, sizeof(int) * 2 * 4 * 2 * 8));
-        HIP_TRY(hipMemset(c->dyn_ctr, 0, sizeof(int) * 2 * 4 * 2 * 8));
+        c->dyn_on = (e = getenv("GENIE_DYN")) ? atoi(e) : 0;       // bit 0: k_stage1_b3, bit 1: k_stage2_fast
+        c->dyn_b1 = (e = getenv("GENIE_DYN_G1")) ? std::max(1, atoi(e)) : 4;       // workgroups per counter group (k_stage1_b3)
+        c->dyn_b2 = (e = getenv("GENIE_DYN_G2")) ? std::max(1, atoi(e)) : 8;       // ... (k_stage2_fast)
+        HIP_TRY(hipMalloc((void**)&c->dyn_ctr, sizeof(int) * 2 * 4 * 2 * DYN_NCTR));
+        HIP_TRY(hipMemset(c->dyn_ctr, 0, sizeof(int) * 2 * 4 * 2 * DYN_NCTR));
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
@@ -5038,8 +5058,8 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
         a.xs = xs; a.packed = c->packed_b3;
-        if (n_tiles) set_dyn(c, a, 0, c->dyn_b1);
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
+        if (n_tiles) set_dyn(c, a, 0, c->dyn_b1, grid);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
         } else if (c->has_edges) {
@@ -5153,8 +5173,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         g = std::max<long long>(8, (g + 7) / 8 * 8);
         k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
     } else if (c->use_fast && !c->nofast2) {
-        set_dyn(c, a, 1, c->dyn_b2);
-        k_stage2_fast<8, 15><<<da_grid(c, n_tiles, c->bpc2f), 256, 0, st>>>(a);
+        const int grid = da_grid(c, n_tiles, c->bpc2f);
+        set_dyn(c, a, 1, c->dyn_b2, grid);
+        k_stage2_fast<8, 15><<<grid, 256, 0, st>>>(a);
     }
     else
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
