@@ -65,6 +65,7 @@ SYMBOLS = [
     ("genie_stream_create_masked", _c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
     ("genie_stream_destroy", _c.c_int, [_P]),
     ("genie_set_num_cu", _c.c_int, [_P, _c.c_int]),
+    ("genie_set_tail_grid", _c.c_int, [_P, _c.c_int, _c.c_int]),
     ("genie_train_save_floats", _c.c_size_t, [_P]),
     ("genie_train_scratch_floats", _c.c_size_t, [_P]),
     ("genie_da_train_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -4721,8 +4721,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
-        c->tail_cu_ro = (e = getenv("GENIE_TAIL_RO")) ? std::max(1, atoi(e)) : c->num_cu;
-        c->tail_cu_sa = (e = getenv("GENIE_TAIL_SA")) ? std::max(1, atoi(e)) : c->num_cu * 2;
+        c->tail_cu_ro = c->num_cu;          // genie_set_tail_grid
+        c->tail_cu_sa = c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
         int occ1 = 0, occ2 = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
@@ -5750,6 +5750,13 @@ int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream) {
     if (!out_dev || n_blocks < 1) return fail(GENIE_ERR_ARG, "genie_where_am_i: bad argument");
     k_where_am_i<<<n_blocks, 64, 0, (hipStream_t)stream>>>(out_dev);
     HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_set_tail_grid(genie_ctx* c, int readout_workgroups, int sa_workgroups) {
+    if (!c || readout_workgroups < 0 || sa_workgroups < 0) return fail(GENIE_ERR_ARG, "genie_set_tail_grid: bad argument");
+    c->tail_cu_ro = readout_workgroups > 0 ? readout_workgroups : c->num_cu;
+    c->tail_cu_sa = sa_workgroups > 0 ? sa_workgroups : c->num_cu * 2;
     return GENIE_OK;
 }
 

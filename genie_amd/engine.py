@@ -441,6 +441,15 @@ class HipPath(object):
         side.wait_event(ev)
         x_query, t_query = _f32(x_query, "x_query"), _f32(t_query, "t_query")
         self._crosses_to(side, pos, x_query, knn_idx, t_query)
+        # per-window tails next to the persistent P-sized kernels: fewer tail workgroups (each has a CU to itself while it lives)
+        # cost the main stream less, as long as the chain of eight kernels still ends within two windows. 3/8 and 1/4 of the CUs
+        # measured best at config 2 (0.852 -> 0.824 ms per window on the same box; 128 / 64: 0.870, 64 / 32: 0.931, 96 / 96: 0.890;
+        # worse without the pipeline and with batched tails, hence set here only). GENIE_TAIL_RO / GENIE_TAIL_SA override.
+        cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        ro = int(os.environ.get("GENIE_TAIL_RO", "0")) or (3 * cus) // 8
+        sa = int(os.environ.get("GENIE_TAIL_SA", "0")) or cus // 4
+        if os.environ.get("GENIE_TAIL_CAPS", "1") != "0":
+            _lib.check(self.lib.genie_set_tail_grid(self.ctx, ro, sa), "genie_set_tail_grid")
         with torch.cuda.stream(side):
             ss = ctypes.c_void_p(side.cuda_stream)
             bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
@@ -452,6 +461,7 @@ class HipPath(object):
             x = self.readout_query(x_spatial, pos, x_query, knn_idx, t_query)
             done = torch.cuda.Event()
             done.record(side)
+        _lib.check(self.lib.genie_set_tail_grid(self.ctx, 0, 0), "genie_set_tail_grid")
         self._crosses_to(main, y, x)       # produced on the side stream, usually consumed by the caller on the main one
         self._ev_tail[slot] = done
         _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")

@@ -284,6 +284,11 @@ int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream);
 int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out);
 int genie_stream_destroy(void* stream);
 int genie_set_num_cu(genie_ctx* ctx, int n);
+/* Grid caps (workgroups) of the read-out (k_readout, k_ro_pre) and SpatialAggregation kernels of the G-sized tail; 0 = default
+ * (one read-out workgroup per CU, two SpatialAggregation workgroups per CU: lowest latency). In the window pipeline, where a
+ * tail workgroup has a CU to itself while it lives, fewer workgroups cost the P-sized kernels less CU-time as long as the
+ * tail chain still ends within two windows: 96 / 64 at config 2 on 256 CUs is 3.4 % faster end to end, 64 / 32 is 9 % slower. */
+int genie_set_tail_grid(genie_ctx* ctx, int readout_workgroups, int sa_workgroups);
 
 /* Training step of the path (train_GENIE_model.py:1786-1861): DataAggregation + the P-sized half of
  * Bipartite_ReadIn forward with the pre-activations kept, and their backward as three P-sized HIP passes.
