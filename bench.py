@@ -76,8 +76,9 @@ def parse():
                     help="with --tail-batch 1: push_window / flush_windows (genie_tail_batched over one window) instead of "
                          "forward_fixed_source_pipelined (the same tail launched call by call)")
     ap.add_argument("--tail-batch", type=int, default=None,
-                    help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 1 for "
-                         "resident windows (the headline workload), 8 for --mode stream (measured best for each, DESIGN.md section 5)")
+                    help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 8 (with the "
+                         "fp32-MFMA tail kernels the batched tail is the faster form for resident windows too: 0.811 -> 0.776 ms per "
+                         "window on the same box, DESIGN.md section 5)")
     ap.add_argument("--mode", default=None, choices=["replicas", "sharded", "stream"],
                     help="default: the cfg2 window pipeline at N = 1; at N > 1 ONE cfg4 window sharded over source nodes with an "
                          "RCCL halo all-to-all + all-gather per window (strong scaling). replicas = window-parallel copies of "
@@ -445,7 +446,7 @@ def main():
     xq = torch.from_numpy(geom.x_query).float().to(dev)
     tq = torch.from_numpy(geom.t_query).float().to(dev)
 
-    tail_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 1, 8))
+    tail_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 8, 8))
     net.window_batch = tail_batch
 
     def step(i):
@@ -558,7 +559,9 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, graphs preset, inputs "
-                               "resident in HBM; steady state after %d untimed clock-settle windows" % (a.config, S, G, n_picks, a.settle),
+                               "resident in HBM; independent windows as in the apply loop (P-sized kernels per window, G-sized tail "
+                               "and read-outs of %d windows per set of launches); steady state after %d untimed clock-settle windows"
+                               % (a.config, S, G, n_picks, 1 if a.no_pipeline else tail_batch, a.settle),
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq, "settle_windows": a.settle,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
         "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,

@@ -37,6 +37,7 @@ SYMBOLS = [
     ("genie_set_static_edge_attr", _c.c_int, [_P, _P, _P]),
     ("genie_tail_batched", _c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_set_tail_mode", _c.c_int, [_P, _c.c_int]),
+    ("genie_set_tail_kernels", _c.c_int, [_P, _c.c_int]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),
     ("genie_readout_query", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P]),
     ("genie_weights_count", _c.c_int, []),

@@ -599,6 +599,133 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
     p0.scal.push_back(g_params[W_DA_ACT12].off);
 }
 
+// G- / Q-sized tail on fp32 MFMA tiles (k_bip_out_m, k_sa_pre_m, k_sa_layer_m, k_ro_pre_m, k_readout_m): a wave owns 16 nodes,
+// lane (j = lane&15, q = lane>>4) holds channels 16t + 4q + {0..3} of node j exactly as in the stage kernels, every per-node
+// Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack image in LDS (one ds_read_b128 per 16 x 16
+// weight block and wave instead of two LDS reads per scalar FMA) and whose result is the B operand of the next Linear.
+// Plans (genie_ctx::plan[PL_*]) and their group index maps:
+enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, NPLAN };
+//  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
+//  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
+//  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
+#define GR_FRONT(t, b) ((t) * 2 + (b))
+#define GR_C1(t, b) (4 + (t) * 2 + (b))
+#define GR_V1(t, b) (8 + (t) * 2 + (b))
+#define GR_C2(h, b) (12 + (h) * 2 + (b))
+#define GR_V2(h, b) (22 + (h) * 2 + (b))
+#define GR_P1(t) (32 + (t))
+#define GR_GROUPS 34
+//  bias tiles: 0,1 front; 2,3 f_context_1; 4,5 f_values_1; 6..10 f_context_2 (head); 11..15 f_values_2 (head); 16,17 proj_1;
+//  18,19 the proj_2 weight row. Scalars: 0 front PReLU, 1 SpatialAttention.activate1, 2..5 TemporalAttention.activate1/2/4/5,
+//  6 proj_2.bias, 7 TemporalAttention.activate3
+#define GR_BIAS 20
+constexpr int GR_IMG_FLOATS = GR_GROUPS * 256 + GR_BIAS * 16 + 16;
+//  k_ro_pre_m: per-grid-node parts of SpatialAttention's f_context (m = 0) / f_values (m = 1), head h, input block b; bias tiles m*5+h
+#define GP(m, h, b) (((m) * 5 + (h)) * 2 + (b))
+#define GP_GROUPS 20
+#define GP_BIAS 10
+constexpr int GP_IMG_FLOATS = GP_GROUPS * 256 + GP_BIAS * 16 + 16;
+//  SpatialAggregation layer L (module.py:243-249): fc2 (out tile t; b = 0,1: x_i blocks, 2,3: edge-mean blocks), the NEXT layer's
+//  fc1[:, 0:30] and fglobal (layers 1, 2), this layer's own fc1[:, 0:C] and fglobal (the pre-pass k_sa_pre_m)
+#define GS_FC2(t, b) ((t) * 4 + (b))
+#define GS_PJN(t, b) (8 + (t) * 2 + (b))
+#define GS_FGN(b) (12 + (b))
+#define GS_PJ(t, b) (14 + (t) * 2 + (b))
+#define GS_FG(b) (18 + (b))
+#define GS_GROUPS 20
+//  bias tiles: 0,1 fc2; 2,3 fc1 (message bias); 4 next fglobal; 5 own fglobal. Scalars: 0 act1, 1 act2, 2 next act3, 3 own act3
+#define GS_BIAS 6
+constexpr int GS_IMG_FLOATS = GS_GROUPS * 256 + GS_BIAS * 16 + 16;
+//  Bipartite read-out fc2 (15 x 30): input block b; bias tile 0; scalar 0 = activate2
+#define GB_GROUPS2 2
+#define GB_BIAS2 1
+constexpr int GB2_IMG_FLOATS = GB_GROUPS2 * 256 + GB_BIAS2 * 16 + 16;
+
+void add_unused_group(StagePlan& p) {
+    for (int r = 0; r < 4; ++r) p.steps.push_back(unused_step());
+}
+
+void build_tail_plans(StagePlan* plan) {
+    auto rows2 = [](int t) { return t ? 14 : 16; };
+    for (int mode = 0; mode < 2; ++mode) {
+        StagePlan& p = plan[mode == 0 ? PL_RO0 : PL_RO1];
+        for (int t = 0; t < 2; ++t) {
+            if (mode == 0) {
+                add_block_group(p, W_SD_W, 30, 16 * t, rows2(t), 0, 16);
+                add_block_group(p, W_SD_W, 30, 16 * t, rows2(t), 16, 14);
+            } else {
+                add_block_group(p, W_SAT_P_W, 15, 16 * t, rows2(t), 0, 15);
+                add_unused_group(p);
+            }
+        }
+        for (int m = 0; m < 2; ++m)
+            for (int t = 0; t < 2; ++t)
+                for (int b = 0; b < 2; ++b) add_block_group(p, m == 0 ? W_TA_C1_W : W_TA_V1_W, 30, 16 * t, rows2(t), 16 * b, rows2(b));
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h)
+                for (int b = 0; b < 2; ++b) add_block_group(p, m == 0 ? W_TA_C2_W : W_TA_V2_W, 30, 15 * h, 15, 16 * b, rows2(b));
+        for (int t = 0; t < 2; ++t) add_block_group(p, W_TA_P1_W, 15, 16 * t, rows2(t), 0, 15);
+        for (int t = 0; t < 2; ++t) add_bias(p, mode == 0 ? W_SD_B : W_SAT_P_B, 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) add_bias(p, W_TA_C1_B, 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) add_bias(p, W_TA_V1_B, 16 * t, rows2(t));
+        for (int h = 0; h < 5; ++h) add_bias(p, W_TA_C2_B, 15 * h, 15);
+        for (int h = 0; h < 5; ++h) add_bias(p, W_TA_V2_B, 15 * h, 15);
+        for (int t = 0; t < 2; ++t) add_bias(p, W_TA_P1_B, 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) add_bias(p, W_TA_P2_W, 16 * t, rows2(t));
+        const int sc[8] = {mode == 0 ? W_SD_ACT : W_SAT_ACT2, W_SAT_ACT1, W_TA_ACT1, W_TA_ACT2, W_TA_ACT4, W_TA_ACT5, W_TA_P2_B, W_TA_ACT3};
+        for (int k = 0; k < 8; ++k) p.scal.push_back(g_params[sc[k]].off);
+    }
+    {
+        StagePlan& p = plan[PL_ROP];
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h)
+                for (int b = 0; b < 2; ++b) add_block_group(p, m == 0 ? W_SAT_C_W : W_SAT_V_W, 33, 15 * h, 15, 16 * b, rows2(b));
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h) add_bias(p, m == 0 ? W_SAT_C_B : W_SAT_V_B, 15 * h, 15);
+        p.scal.push_back(g_params[W_SAT_ACT1].off);      // unused (a plan carries at least one scalar)
+    }
+    for (int layer = 1; layer <= 3; ++layer) {
+        StagePlan& p = plan[PL_SA1 + layer - 1];
+        const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
+        const int C = layer == 1 ? 15 : 30;
+        for (int t = 0; t < 2; ++t) {
+            if (C == 15) { add_block_group(p, base + 2, C + 30, 16 * t, rows2(t), 0, 15); add_unused_group(p); }
+            else { add_block_group(p, base + 2, C + 30, 16 * t, rows2(t), 0, 16); add_block_group(p, base + 2, C + 30, 16 * t, rows2(t), 16, 14); }
+            add_block_group(p, base + 2, C + 30, 16 * t, rows2(t), C, 16);
+            add_block_group(p, base + 2, C + 30, 16 * t, rows2(t), C + 16, 14);
+        }
+        if (layer < 3) {
+            const int nb = layer == 1 ? W_SA2_FC1_W : W_SA3_FC1_W;
+            for (int t = 0; t < 2; ++t)
+                for (int b = 0; b < 2; ++b) add_block_group(p, nb, 38, 16 * t, rows2(t), 16 * b, rows2(b));
+            for (int b = 0; b < 2; ++b) add_block_group(p, nb + 4, 30, 0, 5, 16 * b, rows2(b));
+        } else {
+            for (int k = 0; k < 6; ++k) add_unused_group(p);
+        }
+        for (int t = 0; t < 2; ++t) {
+            if (C == 15) { add_block_group(p, base, C + 8, 16 * t, rows2(t), 0, 15); add_unused_group(p); }
+            else { add_block_group(p, base, C + 8, 16 * t, rows2(t), 0, 16); add_block_group(p, base, C + 8, 16 * t, rows2(t), 16, 14); }
+        }
+        if (C == 15) { add_block_group(p, base + 4, C, 0, 5, 0, 15); add_unused_group(p); }
+        else { add_block_group(p, base + 4, C, 0, 5, 0, 16); add_block_group(p, base + 4, C, 0, 5, 16, 14); }
+        for (int t = 0; t < 2; ++t) add_bias(p, base + 3, 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) add_bias(p, base + 1, 16 * t, rows2(t));
+        if (layer < 3) add_bias(p, (layer == 1 ? W_SA2_FC1_W : W_SA3_FC1_W) + 5, 0, 5);
+        else add_bias(p, base + 5, 0, 0);
+        add_bias(p, base + 5, 0, 5);
+        p.scal.push_back(g_params[base + 6].off);
+        p.scal.push_back(g_params[base + 7].off);
+        p.scal.push_back(g_params[(layer < 3 ? (layer == 1 ? W_SA2_FC1_W : W_SA3_FC1_W) : base) + 8].off);
+        p.scal.push_back(g_params[base + 8].off);
+    }
+    {
+        StagePlan& p = plan[PL_BIP];
+        for (int b = 0; b < 2; ++b) add_block_group(p, W_BP_FC2_W, 30, 0, 15, 16 * b, rows2(b));
+        add_bias(p, W_BP_FC2_B, 0, 15);
+        p.scal.push_back(g_params[W_BP_ACT2].off);
+    }
+}
+
 __global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict__ steps, int n_groups,
                        const BiasDesc* __restrict__ bias, int n_bias, const int32_t* __restrict__ scal, int n_scal,
                        float* __restrict__ out) {
@@ -3317,6 +3444,7 @@ struct SaArgs {
     float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
     float* gpart_out;      // [gridDim][8]
     float* out;            // [G,30]
+    const float* img;      // k_sa_pre_m / k_sa_layer_m: the layer's k_pack image (plan PL_SA1 + layer - 1)
     // batched tail: blockIdx.y = window; the window's copy of each buffer sits this many floats further on
     long long ws_x_in, ws_slot, ws_out;
 };
@@ -3597,15 +3725,15 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
     float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
     float* qry = w_pr + (MODE == 0 ? 0 : 15 * 32);         // [RO_TMAX][96]
     float* scr = qry + RO_TMAX * 96;                       // per-group scratch
-    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;   // floats per group
+    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 52 + RO_TMAX * 16 + 96 + 96;   // floats per group
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
     float* h1 = xin + 40;                // [32]
     float* h2 = h1 + 32;                 // [32]
     float* ctx = h2 + 32;                // [96]
     float* val = ctx + 96;               // [96]
-    float* scs = val + 96;               // [48]  score[t*5+h]
-    float* zs = scs + 48;                // [T][16]
+    float* scs = val + 96;               // [52]  score[t*5+h], t < RO_TMAX (was [48]: with 10 time queries the scores of t = 9 ran into zs)
+    float* zs = scs + 52;                // [T][16]
     float* prd = zs + RO_TMAX * 16;      // [96]  q*c products / aggregated values (MODE 1)
     float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
 
@@ -3792,6 +3920,442 @@ __global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) o += __shfl_xor(o, d, 32);                     // fixed butterfly order
             if (ok && c == 0) a.out[(long long)n * a.T + t] = o + b_p2;
+        }
+        GSYNC();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The G- / Q-sized tail on fp32 MFMA tiles (plans PL_RO0 .. PL_BIP above): same reference lines and the same arithmetic as
+// k_bip_out / k_sa_pre / k_sa_layer / k_ro_pre / k_readout, with the per-node Linears as MFMA chains over 16 nodes per wave
+// (the dot products are summed in MFMA k-order instead of k = 0, 1, 2 ...: rounding-order differences only). The scalar
+// kernels stay as the A/B reference (genie_set_tail_kernels(ctx, 0), env GENIE_TAIL=scalar).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct TlImg {                 // LDS copy of a k_pack image
+    const f32x4* w; const float* bias; const float* scal;
+};
+__device__ __forceinline__ TlImg tl_stage_image(float* sm, const float* __restrict__ img, int n_groups, int n_bias) {
+    const int n4 = (n_groups * 256 + n_bias * 16 + 16) / 4;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) ((f32x4*)sm)[i] = ((const f32x4*)img)[i];
+    TlImg im;
+    im.w = (const f32x4*)sm; im.bias = sm + n_groups * 256; im.scal = im.bias + n_bias * 16;
+    return im;
+}
+#define TLW(im, g) ((im).w[(g) * 64 + lane])
+__device__ __forceinline__ f32x4 tl_bias(const TlImg& im, int tile, int q) { return *(const f32x4*)(im.bias + tile * 16 + 4 * q); }
+// channel block t (channels 16t + 4q + {0..3}) of a 30-float row; the row is only 4-byte aligned and ends at channel 29
+__device__ __forceinline__ f32x4 tl_load30(const float* __restrict__ row, int t, int q) {
+    if (t == 1 && q == 3) { const f32x2u v = *(const f32x2u*)(row + 28); return f32x4{v.x, v.y, 0.f, 0.f}; }
+    const f32x4u v = *(const f32x4u*)(row + 16 * t + 4 * q);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void tl_store30(float* __restrict__ row, int t, int q, f32x4 v) {
+    if (t == 1 && q == 3) { *(f32x2u*)(row + 28) = f32x2u{v.x, v.y}; return; }
+    *(f32x4u*)(row + 16 * t + 4 * q) = f32x4u{v.x, v.y, v.z, v.w};
+}
+// the single channel block of a 15-float row
+__device__ __forceinline__ f32x4 tl_load15(const float* __restrict__ row, int q) {
+    if (q == 3) return f32x4{row[12], row[13], row[14], 0.f};
+    const f32x4u v = *(const f32x4u*)(row + 4 * q);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ f32x4 tl_zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Bipartite read-out (module.py:229): r_g = sum over the tiles' partial rows in tile order, out = PReLU_b2(fc2 r_g).
+__global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ part, int G, int T, const float* __restrict__ img,
+                                                  float* __restrict__ out, long long part_ws, long long out_ws) {
+    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS];
+    const TlImg im = tl_stage_image(sm, img, GB_GROUPS2, GB_BIAS2);
+    __syncthreads();
+    part += blockIdx.y * part_ws;
+    out += blockIdx.y * out_ws;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float act = im.scal[0];
+    const int ntiles = (G + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int g = tile * 16 + j;
+        const bool ok = g < G;
+        const float* pg = part + (long long)(ok ? g : G - 1) * T * 32 + 4 * q;
+        f32x4 r0 = tl_zero(), r1 = tl_zero();
+        int tb = 0;
+        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
+            f32x4 v0[4], v1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
+        }
+        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
+        f32x4 o = tl_bias(im, 0, q);
+        o = mma_block(o, TLW(im, 0), r0);
+        o = mma_block(o, TLW(im, 1), r1);
+        o = prelu4(o, act);
+        if (ok) {
+            float* og = out + (long long)g * 15 + 4 * q;
+            og[0] = o.x; og[1] = o.y; og[2] = o.z;
+            if (q < 3) og[3] = o.w;
+        }
+    }
+}
+
+// fixed-order reduction of the per-lane global-term partials (rows m = 4q + r < 5 of the fglobal tile) -> gpart[block][m]
+__device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, float* red, float* __restrict__ gpart_out) {
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d); acc.z += __shfl_xor(acc.z, d); acc.w += __shfl_xor(acc.w, d);
+    }
+    const int j = lane & 15, q = lane >> 4;
+    if (j == 0 && q < 2) *(f32x4*)(red + wave * 8 + 4 * q) = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k * 8 + threadIdx.x];
+        gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
+    }
+}
+
+// Pre-pass of a SpatialAggregation layer (see k_sa_pre): pj[j] = fc1.weight[:, 0:C] x_j and the block partial of
+// sum_j outdeg(j) PReLU3(fglobal x_j).
+template <int C>
+__global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
+    sa_select_window(a);
+    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 32];
+    const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
+    float* red = sm + GS_IMG_FLOATS;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float act3 = im.scal[3];
+    f32x4 acc = tl_zero();
+    const int ntiles = (a.G + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int g = tile * 16 + j;
+        const bool ok = g < a.G;
+        const float* row = a.x_in + (long long)(ok ? g : a.G - 1) * C;
+        f32x4 xb[2];
+        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
+        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJ(t, 0)), xb[0]);
+            if (C == 30) pj = mma_block(pj, TLW(im, GS_PJ(t, 1)), xb[1]);
+            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
+        }
+        f32x4 gl = mma_block(tl_bias(im, 5, q), TLW(im, GS_FG(0)), xb[0]);
+        if (C == 30) gl = mma_block(gl, TLW(im, GS_FG(1)), xb[1]);
+        if (ok) acc += prelu4(gl, act3) * (float)a.outdeg[g];
+    }
+    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+}
+
+// One SpatialAggregation layer (see k_sa_layer): per-edge messages on the VALU (8 channels per lane), fc2 and the next layer's
+// pre-pass as MFMA chains on the 16 nodes of the wave.
+template <int C, bool NEXT>
+__global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
+    sa_select_window(a);
+    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 8 * 32 + 8 + 32 * 8 + 32];
+    const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
+    float* w1p = sm + GS_IMG_FLOATS;         // fc1 columns C..C+7 (3 position + 5 global), [k][32]
+    float* gsum = w1p + 8 * 32;
+    float* gred = gsum + 8;                  // [32][8]
+    float* red = gred + 32 * 8;
+    for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
+        const int k = i >> 5, cc = i & 31;
+        w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
+    }
+    {   // global term: the producer's per-block partials in the same fixed two-level order as k_sa_layer
+        const int m = threadIdx.x & 7, chunk = threadIdx.x >> 3;
+        float sgl = 0.f;
+        for (int b = chunk; b < a.n_gpart_in; b += 32) sgl += a.gpart_in[b * 8 + m];
+        gred[chunk * 8 + m] = sgl;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float t = 0.f;
+            for (int k = 0; k < 32; ++k) t += gred[k * 8 + threadIdx.x];
+            gsum[threadIdx.x] = t;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float act1 = im.scal[0], act2 = im.scal[1], act3n = im.scal[2];
+    f32x4 base[2], wp[3][2];
+    {
+        const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            base[t] = tl_bias(im, 2 + t, q);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) base[t] += *(const f32x4*)(w1p + (3 + m) * 32 + 16 * t + 4 * q) * (gsum[m] * invE);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * q);
+        }
+    }
+    f32x4 acc = tl_zero();
+    const int ntiles = (a.G + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int i = tile * 16 + j;
+        const bool ok = i < a.G;
+        const int ic = ok ? i : a.G - 1;
+        const float* row = a.x_in + (long long)ic * C;
+        f32x4 xb[2];
+        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
+        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
+        const float pi0 = a.pos[ic * 3 + 0] / a.scale_rel, pi1 = a.pos[ic * 3 + 1] / a.scale_rel, pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
+        const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
+        f32x4 as[2] = {tl_zero(), tl_zero()};
+        // edges in chunks of 4: ids, the gathered rows / positions in flight, then the arithmetic in edge order (no cross-lane
+        // operation inside: the nodes of a wave may differ in trip count)
+        for (int e0 = eb; e0 < ee; e0 += 4) {
+            int jn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) jn[k] = a.col[min(e0 + k, ee - 1)];
+            f32x4 pjv[4][2];
+            float q0[4], q1[4], q2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pjv[k][0] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 4 * q);
+                pjv[k][1] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 16 + 4 * q);
+                q0[k] = a.pos[jn[k] * 3 + 0]; q1[k] = a.pos[jn[k] * 3 + 1]; q2[k] = a.pos[jn[k] * 3 + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d0 = pi0 - q0[k] / a.scale_rel, d1 = pi1 - q1[k] / a.scale_rel, d2 = pi2 - q2[k] / a.scale_rel;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 m = pjv[k][t] + base[t];
+                    m += wp[0][t] * d0;
+                    m += wp[1][t] * d1;
+                    m += wp[2][t] * d2;
+                    if (e0 + k < ee) as[t] += prelu4(m, act1);
+                }
+            }
+        }
+        const float deg = (float)max(ee - eb, 1);
+        const f32x4 av[2] = {as[0] / deg, as[1] / deg};
+        f32x4 o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = mma_block(tl_bias(im, t, q), TLW(im, GS_FC2(t, 0)), xb[0]);
+            if (C == 30) v = mma_block(v, TLW(im, GS_FC2(t, 1)), xb[1]);
+            v = mma_block(v, TLW(im, GS_FC2(t, 2)), av[0]);
+            v = mma_block(v, TLW(im, GS_FC2(t, 3)), av[1]);
+            o[t] = prelu4(v, act2);
+            if (ok) tl_store30(a.out + (long long)i * 30, t, q, o[t]);
+        }
+        if (NEXT) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJN(t, 0)), o[0]);
+                pj = mma_block(pj, TLW(im, GS_PJN(t, 1)), o[1]);
+                if (ok) *(f32x4*)(a.pj_out + (long long)i * 32 + 16 * t + 4 * q) = pj;
+            }
+            f32x4 gl = mma_block(tl_bias(im, 4, q), TLW(im, GS_FGN(0)), o[0]);
+            gl = mma_block(gl, TLW(im, GS_FGN(1)), o[1]);
+            if (ok) acc += prelu4(gl, act3n) * (float)a.outdeg[i];
+        }
+    }
+    if (NEXT) tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+}
+
+// Per-grid-node part of SpatialAttention's edge Linears (see k_ro_pre), biases included, in a head-padded layout:
+// cv[j] = [f_context: head h at 16h + l (l < 15, slot 15 zero) | f_values: 80 + 16h + l], CVP floats per node.
+__global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_spatial, int G, const float* __restrict__ img,
+                                                 float* __restrict__ cv, int Gw, long long cv_ws) {
+    __shared__ __attribute__((aligned(16))) float sm[GP_IMG_FLOATS];
+    const TlImg im = tl_stage_image(sm, img, GP_GROUPS, GP_BIAS);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int ntiles = (G + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int g = tile * 16 + j;
+        const bool ok = g < G;
+        const int gc = ok ? g : G - 1;
+        const float* row = x_spatial + (long long)gc * 30;
+        const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+        const int w = gc / Gw;
+        float* o = cv + w * cv_ws + (long long)(gc - w * Gw) * CVP + 4 * q;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                f32x4 v = mma_block(tl_bias(im, m * 5 + h, q), TLW(im, GP(m, h, 0)), xb0);
+                v = mma_block(v, TLW(im, GP(m, h, 1)), xb1);
+                if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
+            }
+    }
+}
+
+// Read-out heads (see k_readout). MODE 0: y = TemporalAttention(SpatialDirect(x_spatial)) per grid node; MODE 1:
+// x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query. SpatialAttention's per-edge arithmetic runs on
+// the VALU head by head (a lane holds 4 of a head's 16 slots for its query; the head dot product is a 4-lane butterfly); the
+// attention scores of TemporalAttention are an MFMA against the time-query fragments (score[t] = Q_h[t, :] . ctx_h), and the
+// score x value products, per node, go through a per-wave LDS scratch (a lane needs all T x 5 scores of its node).
+constexpr int RO_SCS = 68;      // floats per node in the score scratch: [5 heads][12 time slots] + pad
+constexpr int ROM_LDS_FLOATS = GR_IMG_FLOATS + 5 * 256 + 10 * 80 + 4 * 16 * RO_SCS;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const TlImg im = tl_stage_image(sm, a.img, GR_GROUPS, GR_BIAS);
+    float* qf = sm + GR_IMG_FLOATS;          // [5][64][4]: A fragments of the temporal queries, head h
+    float* et = qf + 5 * 256;                // [10][80] (MODE 1): f_queries columns 0..2, f_context / f_values edge columns, f_queries bias
+    float* scr = et + 10 * 80;
+    {   // qf[h][lane][r] = query[t = lane & 15][head h][l = 4 (lane >> 4) + r], query = temporal_query_2(PReLU3(temporal_query_1(t / scale_t)))  :329
+        const float act3 = a.raw[a.o_a3];
+        for (int i = threadIdx.x; i < 5 * 256; i += blockDim.x) {
+            const int h = i >> 8, ln = (i & 255) >> 2, r = i & 3, t = ln & 15, l = 4 * (ln >> 4) + r;
+            float v = 0.f;
+            if (t < a.T && l < 15) {
+                const int ch = 15 * h + l;
+                const float tq = a.t_query[t] / a.scale_t;
+                v = a.raw[a.o_q2b + ch];
+                for (int k = 0; k < 30; ++k) {
+                    const float hq = prelu1(a.raw[a.o_q1w + k] * tq + a.raw[a.o_q1b + k], act3);
+                    v += a.raw[a.o_q2w + ch * 30 + k] * hq;
+                }
+            }
+            qf[i] = v;
+        }
+        if (MODE == 1) {
+            for (int i = threadIdx.x; i < 10 * 80; i += blockDim.x) {
+                const int m = i / 80, rem = i - m * 80, h = rem >> 4, l = rem & 15, ch = 15 * h + l;
+                float v = 0.f;
+                if (l < 15) {
+                    if (m < 3) v = a.raw[a.o_sq_w + ch * 3 + m];
+                    else if (m < 6) v = a.raw[a.o_sc_w + ch * 33 + 30 + (m - 3)];
+                    else if (m < 9) v = a.raw[a.o_sv_w + ch * 33 + 30 + (m - 6)];
+                    else v = a.raw[a.o_sq_b + ch];
+                }
+                et[i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float fa = im.scal[0], sa1 = im.scal[1], act1 = im.scal[2], act2 = im.scal[3], act4 = im.scal[4], act5 = im.scal[5];
+    const float b_p2 = im.scal[6];
+    const float inv_sqrt_l = 1.f / sqrtf(15.f);
+    float* ws = scr + (wave * 16 + j) * RO_SCS;
+    const int ntiles = (a.N + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int n = tile * 16 + j;
+        const bool ok = n < a.N;
+        const int nc = ok ? n : a.N - 1;
+        f32x4 xin[2];
+        if (MODE == 0) {
+            const float* row = a.x_spatial + (long long)nc * 30;
+            const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                                               // SpatialDirect  :258-260
+                f32x4 y = mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xb0);
+                y = mma_block(y, TLW(im, GR_FRONT(t, 1)), xb1);
+                xin[t] = prelu4(y, fa);
+            }
+        } else {
+            const int wq = nc / a.Nw, nl = nc - wq * a.Nw;
+            const float* cvw = a.cv + wq * a.cv_ws + 4 * q;
+            const float xq0 = a.x_query[nl * 3 + 0], xq1 = a.x_query[nl * 3 + 1], xq2 = a.x_query[nl * 3 + 2];
+            int jn[RO_K];
+            float e[RO_K][3];
+#pragma unroll
+            for (int k = 0; k < RO_K; ++k) jn[k] = a.knn[(long long)nl * RO_K + k];
+#pragma unroll
+            for (int k = 0; k < RO_K; ++k) {                                            // edge_attr  :283
+                e[k][0] = (xq0 - a.x_grid[jn[k] * 3 + 0]) / a.scale_rel;
+                e[k][1] = (xq1 - a.x_grid[jn[k] * 3 + 1]) / a.scale_rel;
+                e[k][2] = (xq2 - a.x_grid[jn[k] * 3 + 2]) / a.scale_rel;
+            }
+            f32x4 xm = tl_zero();
+#pragma unroll
+            for (int h = 0; h < 5; ++h) {
+                const float* eh = et + h * 16 + 4 * q;
+                const f32x4 bq = *(const f32x4*)(eh + 9 * 80);
+                f32x4 wq_[3], wc_[3], wv_[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    wq_[d] = *(const f32x4*)(eh + d * 80); wc_[d] = *(const f32x4*)(eh + (3 + d) * 80); wv_[d] = *(const f32x4*)(eh + (6 + d) * 80);
+                }
+                f32x4 cvk[RO_K];
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + h * 16);
+                float al[RO_K];
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) {                                        // alpha = PReLU1(sum_l q c / sqrt(L))  :293
+                    f32x4 q4 = bq, c4 = cvk[k];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { q4 += wq_[d] * e[k][d]; c4 += wc_[d] * e[k][d]; }
+                    const f32x4 pr = q4 * c4;
+                    al[k] = ((pr.x + pr.y) + pr.z) + pr.w;
+                }
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + 80 + h * 16);
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) {
+                    al[k] += __shfl_xor(al[k], 16);
+                    al[k] += __shfl_xor(al[k], 32);
+                    al[k] = prelu1(al[k] * inv_sqrt_l, sa1);
+                }
+                float mx = al[0];                                                       // segment softmax over the K edges  :295
+#pragma unroll
+                for (int k = 1; k < RO_K; ++k) mx = fmaxf(mx, al[k]);
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) { al[k] = expf(al[k] - mx); ssum += al[k]; }
+                const float den = ssum + 1e-16f;
+                f32x4 gh = tl_zero();
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) {                                        // 'add' aggregation of alpha * v  :264,297
+                    f32x4 v4 = cvk[k];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) v4 += wv_[d] * e[k][d];
+                    gh += v4 * (al[k] / den);
+                }
+                xm += gh;
+            }
+            xm *= 0.2f;                                                                 // mean over heads  :285
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                                                 // PReLU2(proj(.))  :285
+                xin[t] = prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa);
+        }
+        // ------------------------------------------------------------------ TemporalAttention on xin  :325-331
+        f32x4 h1[2], h2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 c1 = mma_block(tl_bias(im, 2 + t, q), TLW(im, GR_C1(t, 0)), xin[0]);
+            c1 = mma_block(c1, TLW(im, GR_C1(t, 1)), xin[1]);
+            h1[t] = prelu4(c1, act1);
+            f32x4 v1 = mma_block(tl_bias(im, 4 + t, q), TLW(im, GR_V1(t, 0)), xin[0]);
+            v1 = mma_block(v1, TLW(im, GR_V1(t, 1)), xin[1]);
+            h2[t] = prelu4(v1, act2);
+        }
+        f32x4 val[5];
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+            f32x4 cx = mma_block(tl_bias(im, 6 + h, q), TLW(im, GR_C2(h, 0)), h1[0]);
+            cx = mma_block(cx, TLW(im, GR_C2(h, 1)), h1[1]);
+            // score[t, h] = ctx[h, :] . query[t, h, :] / sqrt(L): rows t = 4q + r of the result
+            const f32x4 sc = mma_block(tl_zero(), ((const f32x4*)qf)[h * 64 + lane], cx) * inv_sqrt_l;
+            if (q < 3) *(f32x4*)(ws + h * 12 + 4 * q) = sc;
+            f32x4 vx = mma_block(tl_bias(im, 11 + h, q), TLW(im, GR_V2(h, 0)), h2[0]);
+            val[h] = mma_block(vx, TLW(im, GR_V2(h, 1)), h2[1]);
+        }
+        GSYNC();
+        const f32x4 w2a = tl_bias(im, 18, q), w2b = tl_bias(im, 19, q);
+#pragma unroll 2
+        for (int t = 0; t < a.T; ++t) {
+            f32x4 z = tl_zero();                                                        // z[t, l] = mean_h score[t, h] val[h, l]
+#pragma unroll
+            for (int h = 0; h < 5; ++h) z += val[h] * ws[h * 12 + t];
+            z = prelu4(z * 0.2f, act4);
+            f32x4 pa = prelu4(mma_block(tl_bias(im, 16, q), TLW(im, GR_P1(0)), z), act5);        // proj_2(PReLU5(proj_1(.)))
+            f32x4 pb = prelu4(mma_block(tl_bias(im, 17, q), TLW(im, GR_P1(1)), z), act5);
+            float o = w2a.x * pa.x;
+            o += w2a.y * pa.y; o += w2a.z * pa.z; o += w2a.w * pa.w;
+            o += w2b.x * pb.x; o += w2b.y * pb.y; o += w2b.z * pb.z; o += w2b.w * pb.w;
+            o += __shfl_xor(o, 16);
+            o += __shfl_xor(o, 32);
+            if (ok && q == 0) a.out[(long long)n * a.T + t] = o + b_p2;
         }
         GSYNC();
     }
@@ -4285,11 +4849,13 @@ struct genie_ctx {
     int32_t *sta_rowptr, *sta_col, *src_rowptr, *src_col, *order, *outdeg;
     float* raw;
     bool dirty;
-    StagePlan plan[7];         // 0, 1: DataAggregation stage 1 / 2; 2, 3: association stages A / B; 4, 5, 6: backward passes 2', 1', 0'
-    StepDesc* d_steps[7];
-    BiasDesc* d_bias[7];
-    int32_t* d_scal[7];
-    float* packed[7];
+    StagePlan plan[NPLAN];     // 0, 1: DataAggregation stage 1 / 2; 2, 3: association stages A / B; 4, 5, 6: backward passes 2', 1', 0';
+                               // PL_RO0 ...: the MFMA kernels of the G- / Q-sized tail
+    StepDesc* d_steps[NPLAN];
+    BiasDesc* d_bias[NPLAN];
+    int32_t* d_scal[NPLAN];
+    float* packed[NPLAN];
+    int tail_mfma;             // G- / Q-sized tail on the fp32-MFMA tile kernels (default) or the scalar 32-lanes-per-node ones (A/B)
     AccDesc* d_acc[3]; VecDesc* d_vec[3]; int32_t* d_sc[3];   // gradient maps of the backward passes (k_train_reduce)
     int n_acc[3], n_vec[3], n_sc[3];
     int* dyn_ctr;              // dynamic work distribution: [kind 2][slot % GENIE_NBIG][parity 2][8] per-XCD item counters
@@ -4392,7 +4958,7 @@ int dev_copy(T** dst, const T* src_dev, size_t n) {
 
 int ensure_packed(genie_ctx* c, hipStream_t st) {
     if (!c->dirty) return GENIE_OK;
-    for (int s = 0; s < 7; ++s) {
+    for (int s = 0; s < NPLAN; ++s) {
         const StagePlan& p = c->plan[s];
         const int total = p.packed_floats();
         k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
@@ -4545,6 +5111,9 @@ void set_dyn(genie_ctx* c, DaArgs& a, int kind, int gw, int grid) {
     par ^= 1;
 }
 
+// workgroups (4 waves x 16 nodes) of an MFMA tail kernel over n nodes, at most `cap`
+int tl_blocks(long long n, int cap) { return (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, cap)); }
+
 int check_ws(const genie_ctx* c, const void* ws) {
     if (!c) return fail(GENIE_ERR_ARG, "null context");
     if (!ws) return fail(GENIE_ERR_ARG, "null workspace");
@@ -4618,6 +5187,12 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     build_plans(c->plan[0], c->plan[1]);
     build_assoc_plans(c->plan[2], c->plan[3]);
     build_train_plans(c->plan[4], c->plan[5], c->plan[6]);
+    build_tail_plans(c->plan);
+    if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
+        (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
+        c->plan[PL_SA1].n_groups() != GS_GROUPS || c->plan[PL_SA2].n_groups() != GS_GROUPS || c->plan[PL_SA3].n_groups() != GS_GROUPS ||
+        (int)c->plan[PL_SA1].bias.size() != GS_BIAS || (int)c->plan[PL_SA3].bias.size() != GS_BIAS || c->plan[PL_BIP].n_groups() != GB_GROUPS2)
+        return fail(GENIE_ERR_STATE, "internal: tail plan does not match kernel group maps");
     if (c->plan[4].n_groups() != GT2_GROUPS || c->plan[5].n_groups() != GT1_GROUPS || c->plan[6].n_groups() != GT0_GROUPS)
         return fail(GENIE_ERR_STATE, "internal: backward plan does not match kernel group maps");
     if ((rc_tr = build_grad_maps(c))) return rc_tr;
@@ -4626,7 +5201,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
         (int)c->plan[2].bias.size() != GA_BIAS || (int)c->plan[3].bias.size() != GB_BIAS)
         return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
-    for (int s = 0; s < 7; ++s) {
+    for (int s = 0; s < NPLAN; ++s) {
         const StagePlan& p = c->plan[s];
         HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
         HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
@@ -4721,6 +5296,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
+        c->tail_mfma = ((e = getenv("GENIE_TAIL")) && strcmp(e, "scalar") == 0) ? 0 : 1;   // genie_set_tail_kernels
         c->tail_cu_ro = c->num_cu;          // genie_set_tail_grid
         c->tail_cu_sa = c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
@@ -4888,6 +5464,12 @@ int genie_set_tail_mode(genie_ctx* c, int slim) {
     return GENIE_OK;
 }
 
+int genie_set_tail_kernels(genie_ctx* c, int mfma) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_tail_kernels: null context");
+    c->tail_mfma = mfma ? 1 : 0;
+    return GENIE_OK;
+}
+
 int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_station_order: null context");
     void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int};
@@ -4942,6 +5524,7 @@ int genie_set_slot(genie_ctx* c, int slot) {
 
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
+    for (int s = 7; s < NPLAN; ++s) { (void)hipFree(c->d_steps[s]); (void)hipFree(c->d_bias[s]); (void)hipFree(c->d_scal[s]); (void)hipFree(c->packed[s]); }
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1],
@@ -5193,7 +5776,10 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
     if (c->pcsr)       // the messages sit in the c rows (k_stage2_pcsr)
         k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride, c->G, c->seg_rowptr, c->raw,
                                                           g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
-    else
+    else if (c->tail_mfma) {
+        { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
+        k_bip_out_m<<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
+    } else
     k_bip_out<<<nb, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off,
                                                   g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out, 0, 0);
     HIP_TRY(hipGetLastError());
@@ -5224,7 +5810,10 @@ void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
         a.nx_act3 = g_params[nb + 8].off;
     }
 }
-int sa_blocks(const genie_ctx* c) { return std::min((c->G + NPB - 1) / NPB, c->tail_cu_sa); }
+int sa_blocks(const genie_ctx* c) {
+    if (c->tail_mfma) return tl_blocks(c->G, std::min(1024, c->tail_cu_sa));
+    return std::min((c->G + NPB - 1) / NPB, c->tail_cu_sa);
+}
 
 // chain = true: the pre-pass of `layer` was already produced (by k_sa_pre or by the previous layer's NEXT tail) in
 // pj/gpart buffer `cur`; with_next emits the next layer's pre-pass into the other buffer.
@@ -5240,7 +5829,15 @@ int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos
     a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_blocks(c);
     a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
     const int nb = sa_blocks(c);
-    if (layer == 1) {
+    if (c->tail_mfma) {
+        { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+        a.img = c->packed[PL_SA1 + layer - 1];
+        if (layer == 1) {
+            if (with_next) k_sa_layer_m<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false><<<nb, 256, 0, st>>>(a);
+        } else {
+            if (with_next) k_sa_layer_m<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false><<<nb, 256, 0, st>>>(a);
+        }
+    } else if (layer == 1) {
         if (with_next) k_sa_layer<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<15, false><<<nb, 256, 0, st>>>(a);
     } else {
         if (with_next) k_sa_layer<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<30, false><<<nb, 256, 0, st>>>(a);
@@ -5256,7 +5853,11 @@ int sa_launch_pre(genie_ctx* c, int layer, const float* x_in, float* ws, int cur
     a.pj_out = ws + (cur ? c->o_pj1 : c->o_pj0) + c->slot * c->slot_stride;
     a.gpart_out = ws + c->o_gpart + c->slot * c->slot_stride + (cur ? 1024 * 8 : 0);
     const int nb = sa_blocks(c);
-    if (layer == 1) k_sa_pre<15><<<nb, 256, 0, st>>>(a); else k_sa_pre<30><<<nb, 256, 0, st>>>(a);
+    if (c->tail_mfma) {
+        { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+        a.img = c->packed[PL_SA1 + layer - 1];
+        if (layer == 1) k_sa_pre_m<15><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30><<<nb, 256, 0, st>>>(a);
+    } else if (layer == 1) k_sa_pre<15><<<nb, 256, 0, st>>>(a); else k_sa_pre<30><<<nb, 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -5317,7 +5918,7 @@ RoArgs make_ro_args(const genie_ctx* c) {
     a.o_sa1 = g_params[W_SAT_ACT1].off; a.o_sa2 = g_params[W_SAT_ACT2].off;
     return a;
 }
-constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 48 + RO_TMAX * 16 + 96 + 96;
+constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 52 + RO_TMAX * 16 + 96 + 96;
 // node groups (of 32 lanes) per workgroup. "fat": many groups share one weight image (best standalone latency);
 // "slim": <= 52 KB of LDS so that a read-out workgroup co-resides with two k_stage1_fast workgroups (2 x 54 KB) when the
 // G-sized tail of window i runs on a side stream under the P-sized kernels of window i+1 (genie_set_tail_mode).
@@ -5334,7 +5935,11 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
     a.img = c->ro_img;
-    if (c->tail_slim) {
+    if (c->tail_mfma) {
+        a.img = c->packed[PL_RO0];
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    } else if (c->tail_slim) {
         const int nb = std::min((a.N + RO_NG0_SLIM - 1) / RO_NG0_SLIM, c->num_cu);
         k_readout<0, RO_NG0_SLIM><<<nb, RO_NG0_SLIM * 32, ro_lds(0, RO_NG0_SLIM), (hipStream_t)stream>>>(a);
     } else {
@@ -5362,6 +5967,14 @@ int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_gri
     a.img = c->ro_img + RO_IMG0;
     float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
+    if (c->tail_mfma) {
+        k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+        a.img = c->packed[PL_RO1];
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+        HIP_TRY(hipGetLastError());
+        return GENIE_OK;
+    }
     k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, std::min(c->num_cu * 4, c->tail_cu_ro * 4)), 256, 0, (hipStream_t)stream>>>(
         x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf, c->G, 0);
     if (c->tail_slim) {
@@ -5399,12 +6012,18 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     float* w = (float*)ws;
     const long long ss = (long long)c->slot_stride;
     const size_t so = (size_t)slot0 * c->slot_stride;
+    const bool mf = c->tail_mfma != 0;
     // Bipartite read-out -> bip[slot]
+    if (mf)
+        k_bip_out_m<<<dim3(tl_blocks(c->G, std::max(32, c->num_cu * 2 / nwin)), nwin), 256, 0, st>>>(
+            w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], w + c->o_bip + so, ss, ss);
+    else
     k_bip_out<<<dim3(std::min((c->G + NPB - 1) / NPB, std::max(32, c->num_cu * 8 / nwin)), nwin), 256, 0, st>>>(
         w + c->o_part + so, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off,
         w + c->o_bip + so, ss, ss);
     // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
-    const int nbx = std::min((c->G + NPB - 1) / NPB, std::min(1024, std::max(32, c->num_cu * 8 / nwin)));
+    const int nbx = mf ? tl_blocks(c->G, std::min(1024, std::max(32, c->num_cu * 2 / nwin)))
+                       : std::min((c->G + NPB - 1) / NPB, std::min(1024, std::max(32, c->num_cu * 8 / nwin)));
     float* pj[2] = {w + c->o_pj0 + so, w + c->o_pj1 + so};
     float* gp[2] = {w + c->o_gpart + so, w + c->o_gpart + so + 1024 * 8};
     const dim3 grid(nbx, nwin);
@@ -5414,7 +6033,8 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         sa_fill_layer(c, 1, a);
         a.x_in = w + c->o_bip + so; a.ws_x_in = ss; a.ws_slot = ss;
         a.pj_out = pj[0]; a.gpart_out = gp[0];
-        k_sa_pre<15><<<grid, 256, 0, st>>>(a);
+        a.img = c->packed[PL_SA1];
+        if (mf) k_sa_pre_m<15><<<grid, 256, 0, st>>>(a); else k_sa_pre<15><<<grid, 256, 0, st>>>(a);
     }
     for (int layer = 1; layer <= 3; ++layer) {
         SaArgs a;
@@ -5428,7 +6048,12 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.ws_out = layer == 3 ? (long long)c->G * 30 : ss;
         a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = nbx;
         a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
-        if (layer == 1) k_sa_layer<15, true><<<grid, 256, 0, st>>>(a);
+        a.img = c->packed[PL_SA1 + layer - 1];
+        if (mf) {
+            if (layer == 1) k_sa_layer_m<15, true><<<grid, 256, 0, st>>>(a);
+            else if (layer == 2) k_sa_layer_m<30, true><<<grid, 256, 0, st>>>(a);
+            else k_sa_layer_m<30, false><<<grid, 256, 0, st>>>(a);
+        } else if (layer == 1) k_sa_layer<15, true><<<grid, 256, 0, st>>>(a);
         else if (layer == 2) k_sa_layer<30, true><<<grid, 256, 0, st>>>(a);
         else k_sa_layer<30, false><<<grid, 256, 0, st>>>(a);
     }
@@ -5439,10 +6064,23 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         RoArgs g = a;
         g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->ro_img;
         const int nb = std::min((g.N + RO_NG0 - 1) / RO_NG0, c->tail_cu_ro);
+        if (mf) {
+            g.img = c->packed[PL_RO0];
+            HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+            k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
+        } else {
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(0, RO_NG0)));
         k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), st>>>(g);
+        }
     }
-    if (x_out) {
+    if (x_out && mf) {
+        k_ro_pre_m<<<tl_blocks((long long)nwin * c->G, c->tail_cu_ro), 256, 0, st>>>(x_spatial_out, nwin * c->G, c->packed[PL_ROP], w + c->o_cv + so, c->G, ss);
+        RoArgs q = a;
+        q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
+        q.img = c->packed[PL_RO1]; q.cv = w + c->o_cv + so; q.cv_ws = ss;
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<1><<<tl_blocks(q.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(q);
+    } else if (x_out) {
         k_ro_pre<<<std::min((nwin * c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, st>>>(
             x_spatial_out, nwin * c->G, c->ro_img + RO_IMG0 + RO_IMG1, w + c->o_cv + so, c->G, ss);
         RoArgs q = a;

@@ -104,6 +104,11 @@ int genie_tail_batched(genie_ctx* ctx, int slot0, int nwin, const float* pos, co
 /* slim != 0: launch the read-out kernels in their small-LDS shape (<= 52 KB, one workgroup per CU) so they co-reside
  * with the stage-1 workgroups of the next window on another stream; 0 (default): large workgroups, lowest latency. */
 int genie_set_tail_mode(genie_ctx* ctx, int slim);
+/* Kernels of the G- / Q-sized tail (Bipartite read-out module.py:229, SpatialAggregation x3 :243-249, read-out heads
+ * :251-331): mfma != 0 (default) = fp32-MFMA tiles of 16 nodes per wave (weights as A fragments, every Linear's result is the
+ * next one's B operand); 0 = the scalar kernels with 32 lanes per node (A/B reference; also env GENIE_TAIL=scalar at context
+ * creation). Same arithmetic, different summation order inside the dot products. */
+int genie_set_tail_kernels(genie_ctx* ctx, int mfma);
 /* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
 int genie_set_scale_t(genie_ctx* ctx, float scale_t);
 /* `use_absolute_pos: True` (config.yaml:92; module.py:916, :971, :1007): every product node's input gets its station position and

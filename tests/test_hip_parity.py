@@ -1186,3 +1186,35 @@ def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, monkeypatch):
     got = run()
     for a, b in zip(base, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,T", [("cfg1_20x500", 9), ("odd_33x257", 1), ("o1_20x500", 10), ("tiny_6x40", 4)])
+def test_tail_mfma_kernels_agree_with_scalar_kernels(name, T):
+    """The G- / Q-sized tail (Bipartite read-out, SpatialAggregation x3, both read-out heads) on fp32-MFMA tiles of 16 nodes
+    (default) against the scalar 32-lanes-per-node kernels (genie_set_tail_kernels(ctx, 0)): same arithmetic, another
+    summation order inside the dot products -> 2e-6 of the scale of every output; G and Q that are not multiples of 16,
+    1 / 4 / 9 / 10 time queries; the MFMA kernels run twice are bitwise equal."""
+    c = Case(name)
+    hp = make_engine(c)
+    Slice, Mask, ea = c.Slice.to(DEV), c.Mask.to(DEV), c.edge_attr.to(DEV)
+    xg, xq = c.x_grid.float().to(DEV), c.x_query.float().to(DEV)
+    tq = (torch.arange(T, dtype=torch.float32) * 1.7 - 3.0).to(DEV)
+    from genie_amd.module import knn_query_edges
+    table = knn_query_edges(xg, xq, 10)[0].view(xq.shape[0], -1).to(torch.int32).contiguous()
+
+    def run():
+        out, _, bip = hp.path_fwd(Slice, Mask, ea, xg, want_x_latent=True, want_bip=True)
+        y = hp.readout_grid(out, tq)
+        x = hp.readout_query(out, xg, xq, table, tq)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (bip, out, y, x)]
+
+    got = run()
+    again = run()
+    hp.lib.genie_set_tail_kernels(hp.ctx, 0)
+    ref = run()
+    hp.lib.genie_set_tail_kernels(hp.ctx, 1)
+    for a, b, r, k in zip(got, again, ref, ("bip", "sa3", "y", "x")):
+        assert torch.equal(a, b), k
+        assert a.shape == r.shape and torch.isfinite(a).all(), k
+        assert max_abs(a.cpu(), r.cpu()) <= 2e-6 * max(1.0, float(r.abs().max())), k
