@@ -841,6 +841,7 @@ struct DaArgs {
                                // [SV_*][P][16] (genie_da_train_fwd), or null
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
     int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
+    int rev;                   // k_stage2_fast: sweep every XCD's chunk backwards (the rows stage 1 wrote last are read first)
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
@@ -2175,7 +2176,7 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
     struct Ids { int idv, sc, su, tb; bool valid; int sta[KS]; };     // su = the caller's id of station sc (Mask, edge_attr, x_latent)
     auto fetch_ids = [&](long long item, Ids& t) {
         int gi;
-        w.decode(item, gi, t.tb);
+        w.decode(a.rev ? w.nitems - 1 - item : item, gi, t.tb);
         t.idv = a.src_tab[gi * 16 + j];
         const int s = t.tb * 16 + j;
         t.valid = s < S;
@@ -4802,6 +4803,46 @@ __global__ __launch_bounds__(256) void k_row_select(const float* __restrict__ x,
     if (COUNT && threadIdx.x == 0) counts[row] = total;
 }
 
+// Product-level CSRs of the IRREGULAR product graph of `use_subgraph` (process_utils.py:744-849) on the device. The product
+// nodes are the (station, source) pairs sorted by (source, station): node n = (pair_sta[n], pair_src[n]), source node g owns
+// nodes [seg[g], seg[g + 1]). In-edges of node n (the reference's `subgraph(...)` calls, :824-839):
+//   station graph: m -> n for every base edge j -> pair_sta[n] whose pair (j, pair_src[n]) exists, in base edge order;
+//   source graph:  m -> n for every base edge g' -> pair_src[n] whose pair (pair_sta[n], g') exists, in base edge order.
+// One thread per product node; a pair is looked up by binary search in the station list of its source node. FILL = false
+// counts the in-edges, FILL = true writes them behind the node's row pointer.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_subgraph_csr(const int32_t* __restrict__ pair_sta, const int32_t* __restrict__ pair_src,
+                                                     long long N, const int32_t* __restrict__ seg,
+                                                     const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
+                                                     const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
+                                                     int32_t* __restrict__ cnt_sta, int32_t* __restrict__ cnt_src,
+                                                     const int32_t* __restrict__ p_sta_rowptr, const int32_t* __restrict__ p_src_rowptr,
+                                                     int32_t* __restrict__ p_sta_col, int32_t* __restrict__ p_src_col) {
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int s = pair_sta[n], g = pair_src[n];
+    auto find = [&](int sta, int src) -> int {          // product node of the pair (sta, src), or -1
+        int lo = seg[src], hi = seg[src + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pair_sta[mid] < sta) lo = mid + 1; else hi = mid;
+        }
+        return (lo < seg[src + 1] && pair_sta[lo] == sta) ? lo : -1;
+    };
+    int c1 = 0, c2 = 0;
+    int32_t* o1 = FILL ? p_sta_col + p_sta_rowptr[n] : nullptr;
+    int32_t* o2 = FILL ? p_src_col + p_src_rowptr[n] : nullptr;
+    for (int e = sta_rowptr[s]; e < sta_rowptr[s + 1]; ++e) {
+        const int m = find(sta_col[e], g);
+        if (m >= 0) { if (FILL) o1[c1] = m; ++c1; }
+    }
+    for (int e = src_rowptr[g]; e < src_rowptr[g + 1]; ++e) {
+        const int m = find(s, src_col[e]);
+        if (m >= 0) { if (FILL) o2[c2] = m; ++c2; }
+    }
+    if (!FILL) { cnt_sta[n] = c1; cnt_src[n] = c2; }
+}
+
 #if GENIE_TUNING
 // which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
 __global__ void k_xcc_probe(int* __restrict__ out) {
@@ -5297,7 +5338,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
         c->tail_mfma = ((e = getenv("GENIE_TAIL")) && strcmp(e, "scalar") == 0) ? 0 : 1;   // genie_set_tail_kernels
-        c->tail_cu_ro = c->num_cu;          // genie_set_tail_grid
+        c->tail_cu_ro = c->num_cu * ((e = getenv("GENIE_TAIL_ROX")) ? std::max(1, atoi(e)) : 2);          // genie_set_tail_grid: two 62-KB
+                                            // read-out workgroups per CU hide the gather latency of k_readout_m<1> (window 0.769 -> 0.765 ms)
         c->tail_cu_sa = c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
         int occ1 = 0, occ2 = 0;
@@ -5758,6 +5800,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     } else if (c->use_fast && !c->nofast2) {
         const int grid = da_grid(c, n_tiles, c->bpc2f);
         set_dyn(c, a, 1, c->dyn_b2, grid);
+        // backwards sweep: the c / wu / wv rows stage 1 wrote last (still in the Infinity Cache) are read first; stage 2
+        // 0.278 -> 0.276 ms, same-box A/B (GENIE_S2_REV=0 = forwards); per-tile results do not depend on the order
+        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
         k_stage2_fast<8, 15><<<grid, 256, 0, st>>>(a);
     }
     else
@@ -6393,7 +6438,8 @@ int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream) {
 
 int genie_set_tail_grid(genie_ctx* c, int readout_workgroups, int sa_workgroups) {
     if (!c || readout_workgroups < 0 || sa_workgroups < 0) return fail(GENIE_ERR_ARG, "genie_set_tail_grid: bad argument");
-    c->tail_cu_ro = readout_workgroups > 0 ? readout_workgroups : c->num_cu;
+    const char* e = getenv("GENIE_TAIL_ROX");      // tuning: default read-out grid cap in workgroups per CU
+    c->tail_cu_ro = readout_workgroups > 0 ? readout_workgroups : c->num_cu * (e ? std::max(1, atoi(e)) : 2);
     c->tail_cu_sa = sa_workgroups > 0 ? sa_workgroups : c->num_cu * 2;
     return GENIE_OK;
 }
@@ -6481,6 +6527,33 @@ int genie_row_select_fill(const float* x, int rows, int64_t cols, float threshol
     const long long* off = (const long long*)offsets;
     if (mode == 0) k_row_select<0, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
     else k_row_select<1, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_subgraph_csr_count(const int32_t* pair_sta, const int32_t* pair_src, int64_t n_prod, const int32_t* seg_rowptr,
+                             const int32_t* sta_rowptr, const int32_t* sta_col, const int32_t* src_rowptr, const int32_t* src_col,
+                             int32_t* count_sta, int32_t* count_src, void* stream) {
+    if (!pair_sta || !pair_src || !seg_rowptr || !sta_rowptr || !src_rowptr || !count_sta || !count_src || n_prod < 0 || n_prod >= (1ll << 31))
+        return fail(GENIE_ERR_ARG, "genie_subgraph_csr_count: bad argument");
+    if (n_prod == 0) return GENIE_OK;
+    k_subgraph_csr<false><<<(unsigned)((n_prod + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        pair_sta, pair_src, n_prod, seg_rowptr, sta_rowptr, sta_col, src_rowptr, src_col, count_sta, count_src, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, int64_t n_prod, const int32_t* seg_rowptr,
+                            const int32_t* sta_rowptr, const int32_t* sta_col, const int32_t* src_rowptr, const int32_t* src_col,
+                            const int32_t* p_sta_rowptr, const int32_t* p_src_rowptr, int32_t* p_sta_col, int32_t* p_src_col,
+                            void* stream) {
+    if (!pair_sta || !pair_src || !seg_rowptr || !sta_rowptr || !src_rowptr || !p_sta_rowptr || !p_src_rowptr || !p_sta_col || !p_src_col ||
+        n_prod < 0 || n_prod >= (1ll << 31))
+        return fail(GENIE_ERR_ARG, "genie_subgraph_csr_fill: bad argument");
+    if (n_prod == 0) return GENIE_OK;
+    k_subgraph_csr<true><<<(unsigned)((n_prod + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        pair_sta, pair_src, n_prod, seg_rowptr, sta_rowptr, sta_col, src_rowptr, src_col, nullptr, nullptr, p_sta_rowptr, p_src_rowptr,
+        p_sta_col, p_src_col);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

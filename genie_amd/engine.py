@@ -60,6 +60,67 @@ def knn_graph_device(points, k):
     return tab, torch.stack((tab.reshape(-1).long(), centre), dim=0)
 
 
+def subgraph_pairs_device(pos_loc, pos_src, max_deg_offset=5.0, k_nearest_pairs=30, scale_deg=110e3):
+    """Product nodes of `use_subgraph: True` on the device (process_utils.py:774-794): every source node is paired with the
+    stations within `scale_deg * max_deg_offset` metres (:775-778, float64 as the reference's numpy) and with its
+    `k_nearest_pairs` nearest stations (:781, float32 coordinates in km as the reference's `knn`); the union, sorted by
+    (source, station) (:784-794). pos_loc [S, 3] / pos_src [G, 3] = `ftrns1(locs)`, `ftrns1(x_grid)` in metres.
+    Returns int64 [2, N] (row 0 = station, row 1 = source) on the device of `pos_src`."""
+    pl, ps = torch.as_tensor(pos_loc), torch.as_tensor(pos_src)
+    dev = ps.device
+    pl = pl.to(dev)
+    d = (ps.double()[:, None, :] - pl.double()[None, :, :]).pow(2).sum(-1).sqrt()            # [G, S]
+    member = d < float(scale_deg) * float(max_deg_offset)
+    k = int(min(k_nearest_pairs, pl.shape[0]))
+    if k > 0:
+        pk, sk = (pl.float() / 1000.0).double(), (ps.float() / 1000.0).double()
+        d2 = (sk[:, None, :] - pk[None, :, :]).pow(2).sum(-1)
+        near = torch.topk(d2, k, dim=1, largest=False).indices
+        member.scatter_(1, near, True)
+    src, sta = torch.nonzero(member, as_tuple=True)             # row-major: sorted by (source, station)
+    return torch.stack((sta, src), dim=0)
+
+
+def subgraph_csr_device(pairs, n_grid, sta_csr, src_csr):
+    """Product-level CSRs of the irregular product graph (the `subgraph(...)` loops of process_utils.py:824-839) built by
+    libgenie_hip on the device: pairs int64 [2, N] sorted by (source, station) on the GPU, (rowptr, col) int32 in-edge CSRs of
+    the two base graphs. Returns dict(n_prod, sta_csr, src_csr, seg_rowptr) as `HipPath(subgraph=...)` takes it."""
+    lib = _lib.load()
+    if not pairs.is_cuda:
+        raise ValueError("subgraph_csr_device: pairs must be a GPU tensor")
+    dev = pairs.device
+    sta = pairs[0].to(torch.int32).contiguous()
+    src = pairs[1].to(torch.int32).contiguous()
+    n = int(sta.numel())
+    if n == 0:
+        raise ValueError("subgraph_csr_device: no product nodes")
+    key = pairs[1] * (int(pairs[0].max()) + 1) + pairs[0]
+    if bool((key[1:] <= key[:-1]).any()):
+        raise ValueError("pairs must be sorted by (source, station) without duplicates (process_utils.py:790-794)")
+    seg = torch.zeros(n_grid + 1, dtype=torch.int64, device=dev)
+    seg[1:] = torch.cumsum(torch.bincount(pairs[1], minlength=n_grid), 0)
+    seg = seg.to(torch.int32)
+    csr = [t.to(dev).to(torch.int32).contiguous() for t in (sta_csr[0], sta_csr[1], src_csr[0], src_csr[1])]
+    c1 = torch.empty(n, dtype=torch.int32, device=dev)
+    c2 = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.genie_subgraph_csr_count(_ptr(sta), _ptr(src), n, _ptr(seg), _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]),
+                                                _ptr(csr[3]), _ptr(c1), _ptr(c2), _stream()), "genie_subgraph_csr_count")
+        rp = []
+        for c in (c1, c2):
+            r = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            r[1:] = torch.cumsum(c, 0)
+            if int(r[-1]) >= 2 ** 31:
+                raise ValueError("subgraph_csr_device: more than 2^31 product edges")
+            rp.append(r.to(torch.int32))
+        col1 = torch.empty(max(int(rp[0][-1]), 1), dtype=torch.int32, device=dev)
+        col2 = torch.empty(max(int(rp[1][-1]), 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.genie_subgraph_csr_fill(_ptr(sta), _ptr(src), n, _ptr(seg), _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]),
+                                               _ptr(csr[3]), _ptr(rp[0]), _ptr(rp[1]), _ptr(col1), _ptr(col2), _stream()),
+                   "genie_subgraph_csr_fill")
+    return {"n_prod": n, "sta_csr": (rp[0], col1[:int(rp[0][-1])]), "src_csr": (rp[1], col2[:int(rp[1][-1])]), "seg_rowptr": seg}
+
+
 def csr_from_edges(edge_index, n_target):
     """[2,E] edge list (row0 = j source, row1 = i target) -> (rowptr int32 [n+1], col int32 [E]);
     in-edges grouped by target in stable edge order."""

@@ -777,6 +777,41 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
         self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
 
+    def set_adjacencies_subgraph_from_positions(self, pos_loc, pos_src, edge_attr=None, k_sta_edges=10, k_spc_edges=15,
+                                                max_deg_offset=5.0, k_nearest_pairs=30, scale_deg=110e3,
+                                                scale_pairwise_sta_in_src_distances=100e3):
+        """`use_subgraph: True` set up entirely on the device: `extract_inputs_adjacencies_subgraph` (process_utils.py:744-849,
+        its defaults) without the host loops. Base kNN graphs by `genie_knn` (:782-783), the product nodes = every source node
+        paired with the stations within `scale_deg * max_deg_offset` and its `k_nearest_pairs` nearest stations (:775-794),
+        the product-level CSRs of the two induced graphs (:824-839) by `genie_subgraph_csr_count / _fill`.
+        pos_loc [S, 3] / pos_src [G, 3] Cartesian metres; edge_attr [N, 3] for the N product nodes, a callable
+        `edge_attr(pairs) -> [N, 3]`, or None = `(pos_src[source] - pos_loc[station]) / scale_pairwise_sta_in_src_distances`
+        (:811). Returns (A_sta_sta, A_src_src, A_src_in_sta) with A_src_in_sta int64 [2, N] = the product nodes as
+        (station, source) pairs in node order; Slice / Mask / edge_attr rows follow that order."""
+        if self.use_updated_model_definition or self.use_absolute_pos:
+            raise NotImplementedError("use_updated_model_definition / use_absolute_pos with use_subgraph")
+        dev = next(self.parameters()).device
+        pos_loc, pos_src = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
+        n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
+        sta_tab, A_sta = _engine.knn_graph_device(pos_loc, _graph.k_sta_effective(k_sta_edges, n_sta))
+        src_tab, A_src = _engine.knn_graph_device(pos_src, min(k_spc_edges, n_grid - 1))
+        pairs = _engine.subgraph_pairs_device(pos_loc, pos_src, max_deg_offset, k_nearest_pairs, scale_deg)
+        src_csr = _engine.csr_from_table(src_tab)
+        sub = _engine.subgraph_csr_device(pairs, n_grid, _engine.csr_from_table(sta_tab), src_csr)
+        order = _engine.sfc_order(pos_src.detach().cpu().numpy())
+        self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._share_engine()
+        self._path_params = _path_param_dict(self)
+        self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        if edge_attr is None:
+            edge_attr = (pos_src[pairs[1]] - pos_loc[pairs[0]]) / float(scale_pairwise_sta_in_src_distances)
+        elif callable(edge_attr):
+            edge_attr = edge_attr(pairs)
+        self._edge_attr = _engine._f32(edge_attr, "edge_attr", (sub["n_prod"], 3))
+        self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
+        self.A_src = A_src
+        return A_sta, A_src, pairs
+
     def set_adjacencies_from_positions(self, pos_loc, pos_src, edge_attr, k_sta_edges=8, k_spc_edges=15):
         """One-time graph setup entirely on the device (process_utils.py:701-742 without its host detours): the two base kNN
         graphs `remove_self_loops(knn(x / 1000, x / 1000, k + 1).flip(0))` (:718-719, `k_sta_edges = min(k_sta_edges, n_sta - 2)`

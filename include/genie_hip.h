@@ -333,6 +333,20 @@ int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
               int32_t* out_idx, void* stream);
 
+/* Product-level CSRs of the irregular product graph of `use_subgraph: True` on the device (the two `subgraph(...)` loops of
+ * extract_inputs_adjacencies_subgraph, process_utils.py:824-839). Product node n = the pair (pair_sta[n], pair_src[n]), pairs
+ * sorted by (source, station) (:790-794); seg_rowptr[g] .. seg_rowptr[g+1] = the nodes of source node g; (sta_rowptr, sta_col) /
+ * (src_rowptr, src_col) = in-edge CSRs of the base kNN graphs (:782-783). Two passes: _count fills the in-degrees
+ * count_sta[n_prod] / count_src[n_prod]; the caller scans them into p_*_rowptr[n_prod + 1] (int32) and allocates the column
+ * arrays; _fill writes the neighbours in base edge order. The results feed genie_ctx_create_subgraph directly. */
+int genie_subgraph_csr_count(const int32_t* pair_sta, const int32_t* pair_src, int64_t n_prod, const int32_t* seg_rowptr,
+                             const int32_t* sta_rowptr, const int32_t* sta_col, const int32_t* src_rowptr, const int32_t* src_col,
+                             int32_t* count_sta, int32_t* count_src, void* stream);
+int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, int64_t n_prod, const int32_t* seg_rowptr,
+                            const int32_t* sta_rowptr, const int32_t* sta_col, const int32_t* src_rowptr, const int32_t* src_col,
+                            const int32_t* p_sta_rowptr, const int32_t* p_src_rowptr, int32_t* p_sta_col, int32_t* p_src_col,
+                            void* stream);
+
 /* Downstream reduction of the apply loop on the device (process_continuous_days.py:812-849): select entries of the stacked
  * output x [rows, cols] (fp32, row-major, e.g. Out_2 [n_query, len(tsteps_abs)]) without copying it to the host.
  *   mode 0: x > threshold                       = `np.where(Out_2 > 0.01)` (:812-813), row-major order

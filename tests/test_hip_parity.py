@@ -1218,3 +1218,63 @@ def test_tail_mfma_kernels_agree_with_scalar_kernels(name, T):
         assert torch.equal(a, b), k
         assert a.shape == r.shape and torch.isfinite(a).all(), k
         assert max_abs(a.cpu(), r.cpu()) <= 2e-6 * max(1.0, float(r.abs().max())), k
+
+
+def test_device_subgraph_builder_matches_reference_builder():
+    """f-4: the irregular product graph of `use_subgraph` built on the device (genie_knn + subgraph_pairs_device +
+    genie_subgraph_csr_count / _fill) against the output of the reference's own extract_inputs_adjacencies_subgraph on the same
+    geometry (tests/golden/subgraph_builder_14x50.npz, oracle/make_golden.py --subgraph): the same product nodes in the same
+    order, the same edge sets; then against the host builder on a larger random geometry (exact CSR equality), and the module
+    entry point runs the path on the device-built graph and agrees with the host-built one bit for bit."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subgraph_builder_14x50.npz"))
+    geom = synthetic.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    locs, xg = torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV)
+    pairs = engine.subgraph_pairs_device(torch.from_numpy(geom.locs).to(DEV), torch.from_numpy(geom.x_grid).to(DEV),
+                                         max_deg_offset=0.15, k_nearest_pairs=6, scale_deg=110e3)
+    assert np.array_equal(pairs.cpu().numpy(), z["A_src_in_sta"])
+    sta_tab, A_sta = engine.knn_graph_device(locs, 8)
+    src_tab, A_src = engine.knn_graph_device(xg, 15)
+    as_set = lambda a: set(map(tuple, np.asarray(a).T.tolist()))
+    assert as_set(A_sta.cpu().numpy()) == as_set(z["A_sta_sta"]) and as_set(A_src.cpu().numpy()) == as_set(z["A_src_src"])
+    sub = engine.subgraph_csr_device(pairs, 50, engine.csr_from_table(sta_tab), engine.csr_from_table(src_tab))
+
+    def edges_of(csr):
+        rp, col = csr[0].cpu().numpy(), csr[1].cpu().numpy()
+        tgt = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+        return np.stack((col, tgt))
+    assert as_set(edges_of(sub["sta_csr"])) == as_set(z["A_prod_sta_sta"])
+    assert as_set(edges_of(sub["src_csr"])) == as_set(z["A_prod_src_src"])
+    assert np.array_equal(np.diff(sub["seg_rowptr"].cpu().numpy()), np.bincount(z["A_src_in_sta"][1], minlength=50))
+
+    # larger random geometry: exact equality (edge order included) with the host builder, then the path on both graphs
+    S, G = 40, 300
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=30, seed=5)
+    locs, xg = torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV)
+    c = Case("odd_33x257")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    A_sta, A_src, pairs = net.set_adjacencies_subgraph_from_positions(locs, xg, None, k_sta_edges=8, k_spc_edges=15,
+                                                                      max_deg_offset=0.3, k_nearest_pairs=12)
+    N = pairs.shape[1]
+    assert S * 12 <= N < S * G
+    A1, A2, Ap = graph.subgraph_product_edges(A_sta.cpu().numpy(), A_src.cpu().numpy(), pairs.cpu().numpy())
+    sub = engine.subgraph_csr_device(pairs, G, engine.csr_from_edges(A_sta, S), engine.csr_from_edges(A_src, G))
+    for got, host in ((sub["sta_csr"], engine.csr_from_edges(A1, N)), (sub["src_csr"], engine.csr_from_edges(A2, N))):
+        assert torch.equal(got[0].cpu(), host[0]) and torch.equal(got[1].cpu(), host[1])
+    rng = np.random.default_rng(11)
+    Slice = torch.from_numpy(rng.random((N, 4)).astype(np.float32)).to(DEV)
+    Mask = torch.from_numpy((rng.random((N, 4)) < 0.4).astype(np.float32)).to(DEV)
+    xq, tq = torch.from_numpy(geom.x_query).float().to(DEV), torch.from_numpy(geom.t_query).float().to(DEV)
+    with torch.no_grad():
+        y1, x1 = net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
+    ea_x = net._edge_attr.clone()
+    net2 = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net2.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net2.eval()
+    ea = graph.GraphEdges(x=ea_x, edge_index=Ap.to(DEV))
+    net2.set_adjacencies(A1.to(DEV), A2.to(DEV), ea, ea, pairs, A_src, None, None, None, None, locs, xg)
+    with torch.no_grad():
+        y2, x2 = net2.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
+    assert torch.equal(y1, y2) and torch.equal(x1, x2) and torch.isfinite(y1).all()
