@@ -2334,6 +2334,156 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
 #undef PH
 }
 
+// k_stage2_fast for the production configuration (uniform-degree graphs, station processing order with a registered static
+// edge_attr, static item stream, Bipartite half on), straight-line: the ISA of k_stage2_fast spends a fifth of its vector
+// instructions on register copies at the joins of its option branches (the 15 source rows were copied out and back every tile),
+// 34 ds_bpermute per tile on the station sum and a dozen uniform branches. Here
+//  * the item after the last one is clamped to the last one, so every load of the software pipeline is unconditional and no
+//    value has two definitions at a join;
+//  * a tile's ids are its (wave-uniform) item number, one src_tab row and the 8 station-neighbour ids, which are loaded into the
+//    registers the previous tile's ids have just left: nothing rotates but one register;
+//  * the station sum over the 16 nodes of a tile is a DPP row reduction (row_shl:1, 2, 4, 8): lane 0 of every row adds the same
+//    operands in the same tree as the xor butterfly of k_stage2 (bitwise identical), without the LDS round trips;
+//  * the message mask is read by all four lanes of a node (one address) instead of max-reduced across them.
+// Same arithmetic and summation order as k_stage2 / k_stage2_fast (bitwise identical results; tests).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of every row of 16: the butterfly's sum tree
+    v = dpp_add<0x101>(v);      // row_shl:1
+    v = dpp_add<0x102>(v);
+    v = dpp_add<0x104>(v);
+    v = dpp_add<0x108>(v);
+    return v;
+}
+template <int KS, int KP, bool XL>
+__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, 0);
+    if (w.it >= w.nitems) return;
+    const char* wub = (const char*)a.wu;
+    const char* wvb = (const char*)a.wv;
+    const unsigned q16 = 16u * (unsigned)q;
+    const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
+
+    // item -> wave-uniform (processing position gi, station tile tb); per lane the clamped station and its validity
+    auto item_of = [&](long long it, int& gi, int& tb) {
+        w.decode(a.rev ? w.nitems - 1 - it : it, gi, tb);
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        tb = __builtin_amdgcn_readfirstlane(tb);
+    };
+    struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; } rows;
+    int sta[KS];
+    auto load_ids = [&](int gi, int tb, int& idv) {
+        idv = a.src_tab[gi * 16 + j];
+        const int s = tb * 16 + j;
+        load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
+    };
+    auto issue0 = [&](int idv, int tb) {
+        const int g = __builtin_amdgcn_readlane(idv, 0);
+        const int s = tb * 16 + j, sc = s < S ? s : S - 1;
+        const long long p = (long long)g * S + sc;
+        rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        rows.mq = a.mm_int[p];
+        rows.eq = q < 3 ? a.ea_int[p * 3 + q] : 0.f;
+        const char* wug = wub + (size_t)g * gpitch;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) rows.ru[k] = *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
+    };
+    auto issue_v = [&](int idv, int tb, int k0, int k1) {
+        const int s = tb * 16 + j, sc = s < S ? s : S - 1;
+        const unsigned so = (unsigned)sc * 64u + q16;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            if (k >= k0 && k < k1) {
+                const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(idv, 1 + k) * gpitch;
+                rows.rv[k] = *(const f32x4*)(wvk + so);
+            }
+    };
+    constexpr int KH = (KP + 1) / 2;
+
+    long long it = w.it;
+    int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
+    item_of(it, gi_c, tb_c);
+    load_ids(gi_c, tb_c, idv_c);
+    issue0(idv_c, tb_c);
+    issue_v(idv_c, tb_c, 0, KP);
+    {
+        const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
+        item_of(itn, gi_n, tb_n);
+        load_ids(gi_n, tb_n, idv_n);
+    }
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
+        const int s_c = tb_c * 16 + j;
+        const bool valid = s_c < S;
+        // (1) consume the rows of this tile: neighbour means of the projected operands in edge order, PReLU2 -> x_latent
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) n1 += rows.ru[k];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
+        f32x4 o[2];
+        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, rows.o[0]), a2);
+        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, rows.o[1]), a2);
+        const float mq = rows.mq, eq = rows.eq;
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
+        // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
+        issue0(idv_n, tb_n);
+        if (XL && valid) {
+            const int su = a.sta_user[s_c];
+            float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < 15) { xl[4 * q + r] = o[0][r]; xl[15 + 4 * q + r] = o[1][r]; }
+        }
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            bp[t] = prelu4u(bp[t], ab1);
+            // (3) second / third burst, behind the first / second output tile of fc1
+            asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
+            if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP);
+        }
+        // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
+        const bool has_next = it + w.stride < w.nitems;
+        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
+        int gi_2, tb_2, idv_2;
+        item_of(it2, gi_2, tb_2);
+        load_ids(gi_2, tb_2, idv_2);
+        // (5) mask gate and station sum of this tile
+        const float mm = valid ? mq : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = bp[t] * mm;
+            v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
+            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
+        }
+        if (!has_next) break;
+        it += w.stride;
+        idv_c = idv_n; tb_c = tb_n;
+        idv_n = idv_2; tb_n = tb_2;
+    }
+}
+
 // Stage 2 with the station-neighbour operand staged in LDS. All T tiles of a source node gather their KS station-neighbour
 // rows from the SAME S rows wu[g] (64 B each): a workgroup takes NB consecutive source nodes of the processing order per
 // PHASE, copies their wu rows into LDS once (coalesced, each row read exactly once from memory), and its 4 waves then sweep
@@ -4935,6 +5085,8 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
+    int s2_plain;              // A/B: k_stage2_fast where k_stage2_ord would run (env GENIE_S2_ORD=0)
+    int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: 144 VGPRs = three per CU)
     int s2_nb, s2_bpc;         // k_stage2_lds: source nodes per phase (0 = kernel not used) and workgroups per CU
     int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
     int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
@@ -5355,6 +5507,12 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
         c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
         c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
+        c->s2_plain = ((e = getenv("GENIE_S2_ORD")) && atoi(e) == 0) ? 1 : 0;
+        {
+            int occo = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false>, 256, 0));
+            c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occo);
+        }
         {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. OPT-IN (GENIE_S2_LDS=1). Measured at
             // S = 200, T = 13 with three workgroups per CU (164 VGPRs): back to back on cache-warm rows it beats k_stage2_fast
             // (NB = 3: 0.216 ms vs 0.246), but right after stage 1 -- the only order that occurs, c / wu / wv just written, 500 MB --
@@ -5797,6 +5955,12 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
         g = std::max<long long>(8, (g + 7) / 8 * 8);
         k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
+    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && a.ea_int != nullptr && !no_bip && a.abl == 0 &&
+               !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
+        const int grid = da_grid(c, n_tiles, c->bpc2o);
+        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
+        if (x_latent_out) k_stage2_ord<8, 15, true><<<grid, 256, 0, st>>>(a);
+        else k_stage2_ord<8, 15, false><<<grid, 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2) {
         const int grid = da_grid(c, n_tiles, c->bpc2f);
         set_dyn(c, a, 1, c->dyn_b2, grid);

@@ -1161,9 +1161,12 @@ def test_association_heads_hip_match_oracle(S, G):
 
 
 @pytest.mark.parametrize("S,G", [(200, 300), (40, 90), (100, 64)])
-def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, monkeypatch):
-    """k_stage2_lds (opt-in, GENIE_S2_LDS=1: station-neighbour rows staged in LDS per phase of NB source nodes) against the
-    default k_stage2_fast: x_latent, Bipartite output and the association pass (stage 2 without its Bipartite half) bit for bit."""
+@pytest.mark.parametrize("env", [("GENIE_S2_LDS", "1"), ("GENIE_S2_ORD", "0")])
+def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, env, monkeypatch):
+    """Stage-2 kernel variants against the default (k_stage2_ord: straight-line software pipeline, DPP station sum):
+    k_stage2_lds (opt-in, GENIE_S2_LDS=1: station-neighbour rows staged in LDS per phase of NB source nodes) and k_stage2_fast
+    (GENIE_S2_ORD=0: the round-1 kernel with its option branches and xor-butterfly station sum): x_latent, Bipartite output
+    and the association pass (stage 2 without its Bipartite half) bit for bit."""
     geom = synthetic.Geometry(S, G, L=200e3, n_query=10, seed=S)
     win = synthetic.make_window(geom, 20 * S, seed=S + 1)
     wd = {k: v.to(DEV) for k, v in Case("cfg1_20x500").weights.items()}
@@ -1182,7 +1185,7 @@ def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, monkeypatch):
         return out, xl, bip, hp.assoc_fwd(yl, ms, xl, Mask, ea)
 
     base = run()
-    monkeypatch.setenv("GENIE_S2_LDS", "1")
+    monkeypatch.setenv(*env)
     got = run()
     for a, b in zip(base, got):
         assert torch.equal(a, b)
