@@ -40,7 +40,7 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
 # granularity). The HIP path moves fewer real bytes than that because h0/h1/u/v never leave the registers; per
 # product node and per kernel group (gathers counted once per row = perfect cache):
 #   stage 1 = k_split_rows + k_stage1_b3: Slice+Mask 32 R, split rows 48 W + 48 R, c 120 W, wu+wv 120 W = 368 B
-#   stage 2 = k_stage2_fast             : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R               = 268 B
+#   stage 2 = k_stage2_ord              : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R               = 268 B
 B_NODE = {"k_stage1": 368.0, "k_stage2": 268.0}
 # ALGORITHMIC FLOPs per product node (SURVEY.md 8d split by kernel; 2 per MAC): stage 1 = init_trns 240 + layer-1 3840
 # + l2_t*_1 3600 + l2_t*_2 2820 MACs + 690 layer-1 gather adds; stage 2 = Bipartite fc1 990 MACs + 690 gather adds.
@@ -51,9 +51,9 @@ BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r02_a_pmc_stage_kernels.txt"
-TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.485e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
-                "k_stage2": (2.0 * 4.638e5 + 1.626e4) * 1024.0}                               # k_stage2_fast
+TRAFFIC_SOURCE = "profiles/r02_f_pmc_stage_kernels.txt"
+TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.480e5 + 3.126e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
+                "k_stage2": (2.0 * 5.373e5 + 1.630e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
 ONE_GPU_CFG4 = {"ms_per_step": 42.69, "source": "profiles/r02_a_bench_cfg4_one_gpu.json (this code path with --gpus 1)"}
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
@@ -544,7 +544,7 @@ def main():
     exec_tf = BF16_EXEC_FLOP_NODE * P / (kms["k_stage1"] * 1e-3) / 1e12
     kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_b3"
     kern["k_stage1"]["executed_bf16"] = {"tflops": round(exec_tf, 1), "peak": BF16_MFMA_PEAK_TF, "frac": round(exec_tf / BF16_MFMA_PEAK_TF, 4)}
-    kern["k_stage2"]["kernels"] = "k_stage2_fast"
+    kern["k_stage2"]["kernels"] = "k_stage2_ord"
     roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                 "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
                 "traffic": (sum(TRAFFIC_CFG2.values()) if a.config == "cfg2_200x10k" else None),

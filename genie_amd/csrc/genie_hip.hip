@@ -842,6 +842,7 @@ struct DaArgs {
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
     int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
     int rev;                   // k_stage2_fast: sweep every XCD's chunk backwards (the rows stage 1 wrote last are read first)
+    int wgmap;                 // k_stage2_ord: blocks of 4 source nodes per workgroup, one node per wave (see the kernel)
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
@@ -2357,11 +2358,21 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
     v = dpp_add<0x108>(v);
     return v;
 }
-template <int KS, int KP, bool XL>
-__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
+// SCHED: where the three load bursts of the next tile sit among the compute chunks of this one. 0: after the neighbour sums /
+// the first / the second fc1 output tile; 1: the first two bursts after the sums, the third after the first fc1 tile; 2: all
+// three after the sums
+// SCHED 3 (workgroups of 8 waves): PHASED. Identical persistent waves fall into lockstep -- all of them issue their loads at
+// once (the texture path works, the SIMDs idle), then all compute (the reverse); measured time = the SUM of the two. Here
+// the waves of a workgroup are two groups half an iteration apart, held there by two workgroup barriers per tile: while waves
+// 0-3 (one per SIMD) consume their rows and issue the next tile's loads, waves 4-7 run their MFMA / reduction phase, and
+// vice versa, so the texture path always has one group's loads to work on. Every wave runs the same number of iterations
+// (a wave that has run out of items repeats its last one: identical stores).
+template <int KS, int KP, bool XL, int SCHED>
+__global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    constexpr bool PH = SCHED == 3;
     __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
     const float* lscal = lbias + G2_BIAS * 16;
@@ -2371,15 +2382,41 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, 0);
-    if (w.it >= w.nitems) return;
+    // a.wgmap: a workgroup takes BLOCKS of 4 consecutive source nodes of its XCD's chunk, wave k sweeps the tiles of the k-th
+    // node of the block: the four waves of a CU then read the source-neighbour rows of four adjacent source nodes (half of
+    // them shared) for the same station tile at about the same time, and every station row wu[g] is gathered on one CU only
+    if (a.wgmap) {
+        const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+        const int lb = blockIdx.x / nx, nbx = gridDim.x / nx, n = w.gend - w.gbeg, n_blk = (n + 3) / 4;
+        int n_my = lb < n_blk ? (n_blk - lb + nbx - 1) / nbx : 0;
+        if (n_my > 0 && 4 * (lb + (n_my - 1) * nbx) + wave >= n) --n_my;
+        w.it = 0; w.stride = 1; w.nitems = (long long)n_my * a.T;
+        w.lead_ = lb; w.chunk_ = nbx;                     // (reused as: first block, block stride)
+    }
+    long long nmax = 0;                                    // PHASED: iterations of every wave of this workgroup
+    if (PH) {
+        const long long it0 = w.it - wave;                 // first item of the workgroup's wave 0
+        if (it0 >= w.nitems) return;                       // (uniform over the workgroup)
+        nmax = (w.nitems - it0 + w.stride - 1) / w.stride;
+    } else if (w.it >= w.nitems) return;
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
     const unsigned q16 = 16u * (unsigned)q;
     const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
+    const unsigned m_T = ItemIter::recip((unsigned)a.T);
 
     // item -> wave-uniform (processing position gi, station tile tb); per lane the clamped station and its validity
     auto item_of = [&](long long it, int& gi, int& tb) {
-        w.decode(a.rev ? w.nitems - 1 - it : it, gi, tb);
+        if (PH && it >= w.nitems) it = w.nitems - 1;
+        const long long itr = a.rev ? w.nitems - 1 - it : it;
+        if (a.wgmap) {
+            unsigned rem;
+            const unsigned kb = a.T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)a.T, m_T, rem);
+            tb = (int)rem;
+            gi = w.gbeg + 4 * (w.lead_ + (int)kb * w.chunk_) + wave;
+        } else {
+            w.decode(itr, gi, tb);
+        }
         gi = __builtin_amdgcn_readfirstlane(gi);
         tb = __builtin_amdgcn_readfirstlane(tb);
     };
@@ -2393,14 +2430,15 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     auto issue0 = [&](int idv, int tb) {
         const int g = __builtin_amdgcn_readlane(idv, 0);
         const int s = tb * 16 + j, sc = s < S ? s : S - 1;
-        const long long p = (long long)g * S + sc;
+        long long p = (long long)g * S + sc;
+        if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
         rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
         rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
         rows.mq = a.mm_int[p];
         rows.eq = q < 3 ? a.ea_int[p * 3 + q] : 0.f;
-        const char* wug = wub + (size_t)g * gpitch;
+        const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
 #pragma unroll
-        for (int k = 0; k < KS; ++k) rows.ru[k] = *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
+        for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? rows.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
     };
     auto issue_v = [&](int idv, int tb, int k0, int k1) {
         const int s = tb * 16 + j, sc = s < S ? s : S - 1;
@@ -2408,8 +2446,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KP; ++k)
             if (k >= k0 && k < k1) {
-                const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(idv, 1 + k) * gpitch;
-                rows.rv[k] = *(const f32x4*)(wvk + so);
+                const char* wvk = wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
+                rows.rv[k] = ABL(a, 1) ? rows.o[1] : *(const f32x4*)(wvk + so);
             }
     };
     constexpr int KH = (KP + 1) / 2;
@@ -2425,7 +2463,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
         item_of(itn, gi_n, tb_n);
         load_ids(gi_n, tb_n, idv_n);
     }
-    for (;;) {
+    if (PH && wave >= 4) __syncthreads();                 // the second group runs half an iteration behind
+    for (long long iter = 0;; ++iter) {
         asm volatile("" : "+v"(lane));
         const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
         const int s_c = tb_c * 16 + j;
@@ -2443,6 +2482,9 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
         // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
         issue0(idv_n, tb_n);
+        if (SCHED >= 1) issue_v(idv_n, tb_n, 0, KH);
+        if (SCHED >= 2) issue_v(idv_n, tb_n, KH, KP);
+        if (PH) __syncthreads();
         if (XL && valid) {
             const int su = a.sta_user[s_c];
             float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
@@ -2461,7 +2503,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
             bp[t] = prelu4u(bp[t], ab1);
             // (3) second / third burst, behind the first / second output tile of fc1
             asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
-            if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP);
+            if (SCHED == 0) { if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP); }
+            if (SCHED == 1 && t == 0) issue_v(idv_n, tb_n, KH, KP);
         }
         // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
         const bool has_next = it + w.stride < w.nitems;
@@ -2477,11 +2520,15 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
             v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
             if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
         }
-        if (!has_next) break;
+        if (PH) {
+            __syncthreads();
+            if (iter + 1 >= nmax) break;
+        } else if (!has_next) break;
         it += w.stride;
         idv_c = idv_n; tb_c = tb_n;
         idv_n = idv_2; tb_n = tb_2;
     }
+    if (PH && wave < 4) __syncthreads();
 }
 
 // Stage 2 with the station-neighbour operand staged in LDS. All T tiles of a source node gather their KS station-neighbour
@@ -5510,7 +5557,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->s2_plain = ((e = getenv("GENIE_S2_ORD")) && atoi(e) == 0) ? 1 : 0;
         {
             int occo = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false>, 256, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false, 0>, 256, 0));
             c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occo);
         }
         {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. OPT-IN (GENIE_S2_LDS=1). Measured at
@@ -5955,12 +6002,18 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
         g = std::max<long long>(8, (g + 7) / 8 * 8);
         k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
-    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && a.ea_int != nullptr && !no_bip && a.abl == 0 &&
+    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && a.ea_int != nullptr && !no_bip &&
                !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
         const int grid = da_grid(c, n_tiles, c->bpc2o);
         { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
-        if (x_latent_out) k_stage2_ord<8, 15, true><<<grid, 256, 0, st>>>(a);
-        else k_stage2_ord<8, 15, false><<<grid, 256, 0, st>>>(a);
+        { const char* e = getenv("GENIE_S2_WGMAP"); a.wgmap = (e && atoi(e)) ? 1 : 0; }
+        const char* es = getenv("GENIE_S2_SCHED");
+        const int sched = es ? atoi(es) : 0;
+        if (x_latent_out) k_stage2_ord<8, 15, true, 0><<<grid, 256, 0, st>>>(a);
+        else if (sched == 3) k_stage2_ord<8, 15, false, 3><<<da_grid_w(c, n_tiles, 1, 8), 512, 0, st>>>(a);
+        else if (sched == 1) k_stage2_ord<8, 15, false, 1><<<grid, 256, 0, st>>>(a);
+        else if (sched == 2) k_stage2_ord<8, 15, false, 2><<<grid, 256, 0, st>>>(a);
+        else k_stage2_ord<8, 15, false, 0><<<grid, 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2) {
         const int grid = da_grid(c, n_tiles, c->bpc2f);
         set_dyn(c, a, 1, c->dyn_b2, grid);
