@@ -74,6 +74,8 @@ SYMBOLS = [
     ("genie_assoc_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_assoc_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    ("genie_lslc_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
+                                  _P, _P, _P, _c.c_int, _P, _P]),
     ("genie_subgraph_csr_count", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_subgraph_csr_fill", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_row_select_count", _c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_float, _c.c_int, _P, _P]),

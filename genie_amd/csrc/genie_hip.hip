@@ -112,6 +112,9 @@ enum {
     W_AS_INIT_W, W_AS_INIT_B, W_AS_L1T11_W, W_AS_L1T11_B, W_AS_L1T21_W, W_AS_L1T21_B, W_AS_L1T12_W, W_AS_L1T12_B,
     W_AS_L1T22_W, W_AS_L1T22_B, W_AS_L2T11_W, W_AS_L2T11_B, W_AS_L2T21_W, W_AS_L2T21_B, W_AS_L2T12_W, W_AS_L2T12_B,
     W_AS_L2T22_W, W_AS_L2T22_B, W_AS_ACT, W_AS_ACT11, W_AS_ACT12, W_AS_ACT1, W_AS_ACT21, W_AS_ACT22, W_AS_ACT2,
+    // pick-sized association heads (module.py:610-659): LocalSliceLgCollapse P / S
+    W_LP_FC1_W, W_LP_FC1_B, W_LP_FC2_W, W_LP_FC2_B, W_LP_ACT1, W_LP_ACT2,
+    W_LS_FC1_W, W_LS_FC1_B, W_LS_FC2_W, W_LS_FC2_B, W_LS_ACT1, W_LS_ACT2,
     W_COUNT
 };
 
@@ -181,6 +184,12 @@ Param g_params[W_COUNT] = {
     {"DataAggregationAssociationPhase.activate12.weight", 1, 0}, {"DataAggregationAssociationPhase.activate1.weight", 1, 0},
     {"DataAggregationAssociationPhase.activate21.weight", 1, 0}, {"DataAggregationAssociationPhase.activate22.weight", 1, 0},
     {"DataAggregationAssociationPhase.activate2.weight", 1, 0},
+    {"LocalSliceLgCollapseP.fc1.weight", 30 * 32, 0}, {"LocalSliceLgCollapseP.fc1.bias", 30, 0},
+    {"LocalSliceLgCollapseP.fc2.weight", 15 * 30, 0}, {"LocalSliceLgCollapseP.fc2.bias", 15, 0},
+    {"LocalSliceLgCollapseP.activate1.weight", 1, 0}, {"LocalSliceLgCollapseP.activate2.weight", 1, 0},
+    {"LocalSliceLgCollapseS.fc1.weight", 30 * 32, 0}, {"LocalSliceLgCollapseS.fc1.bias", 30, 0},
+    {"LocalSliceLgCollapseS.fc2.weight", 15 * 30, 0}, {"LocalSliceLgCollapseS.fc2.bias", 15, 0},
+    {"LocalSliceLgCollapseS.activate1.weight", 1, 0}, {"LocalSliceLgCollapseS.activate2.weight", 1, 0},
 };
 
 int g_raw_total = 0;
@@ -604,7 +613,7 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
 // Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack image in LDS (one ds_read_b128 per 16 x 16
 // weight block and wave instead of two LDS reads per scalar FMA) and whose result is the B operand of the next Linear.
 // Plans (genie_ctx::plan[PL_*]) and their group index maps:
-enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, NPLAN };
+enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, NPLAN };
 //  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
 //  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
 //  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
@@ -640,6 +649,14 @@ constexpr int GS_IMG_FLOATS = GS_GROUPS * 256 + GS_BIAS * 16 + 16;
 #define GB_GROUPS2 2
 #define GB_BIAS2 1
 constexpr int GB2_IMG_FLOATS = GB_GROUPS2 * 256 + GB_BIAS2 * 16 + 16;
+
+//  LocalSliceLgCollapse P / S (module.py:610-659): fc1 (out tile t; b = 0,1: the gathered s row, 2: [relative time, phase]),
+//  fc2 (input block b); bias tiles 0,1 fc1, 2 fc2; scalars activate1, activate2
+#define GL_FC1(t, b) ((t) * 3 + (b))
+#define GL_FC2(b) (6 + (b))
+#define GL_GROUPS 8
+#define GL_BIAS 3
+constexpr int GL_IMG_FLOATS = GL_GROUPS * 256 + GL_BIAS * 16 + 16;
 
 void add_unused_group(StagePlan& p) {
     for (int r = 0; r < 4; ++r) p.steps.push_back(unused_step());
@@ -717,6 +734,21 @@ void build_tail_plans(StagePlan* plan) {
         p.scal.push_back(g_params[base + 7].off);
         p.scal.push_back(g_params[(layer < 3 ? (layer == 1 ? W_SA2_FC1_W : W_SA3_FC1_W) : base) + 8].off);
         p.scal.push_back(g_params[base + 8].off);
+    }
+    for (int ph = 0; ph < 2; ++ph) {
+        StagePlan& p = plan[ph == 0 ? PL_LSP : PL_LSS];
+        const int base = ph == 0 ? W_LP_FC1_W : W_LS_FC1_W;
+        for (int t = 0; t < 2; ++t) {
+            add_block_group(p, base, 32, 16 * t, rows2(t), 0, 16);
+            add_block_group(p, base, 32, 16 * t, rows2(t), 16, 14);
+            const int c0[1] = {30}, n2[1] = {2};
+            add_scalar_group(p, base, 32, 16 * t, rows2(t), c0, n2, 1);
+        }
+        for (int b = 0; b < 2; ++b) add_block_group(p, base + 2, 30, 0, 15, 16 * b, rows2(b));
+        for (int t = 0; t < 2; ++t) add_bias(p, base + 1, 16 * t, rows2(t));
+        add_bias(p, base + 3, 0, 15);
+        p.scal.push_back(g_params[base + 4].off);
+        p.scal.push_back(g_params[base + 5].off);
     }
     {
         StagePlan& p = plan[PL_BIP];
@@ -4559,6 +4591,69 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
     }
 }
 
+// LocalSliceLgCollapse (module.py:610-659), pick-sized: per pick a the K = 10 product nodes of its station whose theoretical
+// arrival is nearest the pick time (time-pointer table A_edges[(ipick * l_dt + t_index) * K + k], :635-640), those within
+// 2 eps of the pick time kept (:642-647), message PReLU1(fc1[s[e] || (tpick - tlatent[e]) / eps || phase]) (:657-659), 'mean'
+// over the kept edges (:612), PReLU2(fc2 .) (:651). A wave owns 16 picks (fp32-MFMA tile layout of the tail kernels).
+constexpr int LS_K = 10;
+struct LsArgs {
+    int n_picks, l_dt;
+    long long n_edges;            // entries of the time-pointer table (indices are clamped into it)
+    float t0, dt, eps;
+    const float* s;               // [P, 30] association embedding (genie_assoc_fwd)
+    const int32_t* A_edges;       // [n_sta * l_dt * K] product-node ids
+    const float* tlatent; int tl_stride, tl_col;     // theoretical arrival of product node e: tlatent[e * tl_stride + tl_col]
+    const float* tpick; const int32_t* ipick; const float* phase;
+    const float* img;
+    float* out;                   // [n_picks, 15]
+};
+__global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[GL_IMG_FLOATS];
+    const TlImg im = tl_stage_image(sm, a.img, GL_GROUPS, GL_BIAS);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float act1 = im.scal[0], act2 = im.scal[1];
+    const int ntiles = (a.n_picks + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int p = tile * 16 + j;
+        const bool ok = p < a.n_picks;
+        const int pc = ok ? p : a.n_picks - 1;
+        const float tp = a.tpick[pc], ph = a.phase[pc];
+        const int ti = (int)floorf((tp - a.t0) / a.dt);                                   // :635
+        long long base = ((long long)a.ipick[pc] * a.l_dt + ti) * LS_K;
+        base = base < 0 ? 0 : (base > a.n_edges - LS_K ? a.n_edges - LS_K : base);
+        f32x4 acc[2] = {tl_zero(), tl_zero()};
+        float cnt = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < LS_K; ++k) {
+            const int e = a.A_edges[base + k];
+            const float rt = tp - a.tlatent[(long long)e * a.tl_stride + a.tl_col];
+            const bool keep = ok && fabsf(rt) < 2.0f * a.eps;                             // :642-645
+            const float* row = a.s + (long long)e * 30;
+            const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+            const float xs = q == 0 ? rt / a.eps : (q == 1 ? ph : 0.f);                   // columns 30, 31 of fc1
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 m = mma_block(tl_bias(im, t, q), TLW(im, GL_FC1(t, 0)), xb0);
+                m = mma_block(m, TLW(im, GL_FC1(t, 1)), xb1);
+                m = MFMA16(TLW(im, GL_FC1(t, 2)).x, xs, m);
+                m = prelu4(m, act1);
+                if (keep) acc[t] += m;
+            }
+            cnt += keep ? 1.f : 0.f;
+        }
+        const float den = fmaxf(cnt, 1.f);
+        f32x4 o = mma_block(tl_bias(im, 2, q), TLW(im, GL_FC2(0)), acc[0] / den);
+        o = mma_block(o, TLW(im, GL_FC2(1)), acc[1] / den);
+        o = prelu4(o, act2);
+        if (ok) {
+            float* og = a.out + (long long)p * 15 + 4 * q;
+            og[0] = o.x; og[1] = o.y; og[2] = o.z;
+            if (q < 3) og[3] = o.w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pick -> Slice/Mask embedding on device: `extract_input_from_data`,
 // /root/reference/Code/process_utils.py:460-642 (use_sign_input = False). Step 1: per-station Gaussian-kernel time
@@ -6744,6 +6839,25 @@ int genie_row_select_fill(const float* x, int rows, int64_t cols, float threshol
     const long long* off = (const long long*)offsets;
     if (mode == 0) k_row_select<0, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
     else k_row_select<1, false><<<rows, 256, 0, st>>>(x, cols, threshold, nullptr, off, out_row, out_col, out_val);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
+                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
+                   const float* phase_label, int n_picks, float* out, void* stream) {
+    if (!c || !s_rows || !a_edges || !tlatent || !tpick || !ipick || !phase_label || !out) return fail(GENIE_ERR_ARG, "genie_lslc_fwd: null argument");
+    if (phase_head < 0 || phase_head > 1 || l_dt < 1 || n_edges < LS_K || !(dt > 0.f) || !(eps > 0.f) || tl_stride < 1 || tl_col < 0 || tl_col >= tl_stride)
+        return fail(GENIE_ERR_ARG, "genie_lslc_fwd: bad argument");
+    if (n_picks < 1) return GENIE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+    LsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_picks = n_picks; a.l_dt = l_dt; a.n_edges = n_edges; a.t0 = t0; a.dt = dt; a.eps = eps;
+    a.s = s_rows; a.A_edges = a_edges; a.tlatent = tlatent; a.tl_stride = tl_stride; a.tl_col = tl_col;
+    a.tpick = tpick; a.ipick = ipick; a.phase = phase_label; a.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS]; a.out = out;
+    k_lslc<<<tl_blocks(n_picks, c->num_cu * 4), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

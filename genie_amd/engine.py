@@ -215,7 +215,8 @@ def sfc_order(points):
     return hilbert_order(points) if os.environ.get("GENIE_SFC") == "hilbert" else morton_order(points)
 
 
-ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.")
+ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.", "LocalSliceLgCollapseP.",
+                  "LocalSliceLgCollapseS.")
 
 
 class HipPath(object):
@@ -684,6 +685,28 @@ class HipPath(object):
         out = torch.empty((P, 30), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_assoc_fwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
                                             _ptr(out), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_fwd")
+        return out
+
+    def lslc_fwd(self, head, s_rows, a_edges, dt_partition, tpick, ipick, phase_label, tlatent, col, eps):
+        """LocalSliceLgCollapse P (head 0) / S (head 1), module.py:610-659, in HIP (genie_lslc_fwd): s_rows [P, 30], a_edges int32
+        [n_sta * l_dt * 10] time-pointer table, dt_partition [l_dt], tpick / phase_label fp32 [n], ipick int32 [n], tlatent
+        [P, C] fp32 with the phase's theoretical arrival in column `col` -> [n, 15]."""
+        if not getattr(self, "assoc_ready", False):
+            raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
+        s_rows = _f32(s_rows, "s_rows", (self.n_prod, 30))
+        tpick = _f32(tpick, "tpick").reshape(-1)
+        n = int(tpick.numel())
+        phase_label = _f32(phase_label, "phase_label").reshape(-1)
+        tlatent = _f32(tlatent, "tlatent")
+        if (a_edges.dtype != torch.int32 or not a_edges.is_cuda or ipick.dtype != torch.int32 or ipick.numel() != n
+                or phase_label.numel() != n or tlatent.dim() != 2 or tlatent.shape[0] != self.n_prod):
+            raise ValueError("lslc_fwd: a_edges / ipick must be int32 GPU tensors, one ipick / phase_label per pick, tlatent [P, C]")
+        a_edges, ipick = a_edges.contiguous(), ipick.contiguous()
+        t0, dt = float(dt_partition[0]), float(dt_partition[1] - dt_partition[0])
+        out = torch.empty((n, 15), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)),
+                                           t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
+                                           _ptr(phase_label), n, _ptr(out), _stream()), "genie_lslc_fwd")
         return out
 
     def train_fwd(self, Slice, Mask, edge_attr, want_x_latent=True):

@@ -34,7 +34,8 @@ def _path_param_dict(net):
     out = {}
     for mod_name in ("DataAggregation", "Bipartite_ReadIn", "SpatialAggregation1", "SpatialAggregation2",
                      "SpatialAggregation3", "SpatialDirect", "TemporalAttention", "SpatialAttention",
-                     "BipartiteGraphReadOutOperator", "DataAggregationAssociationPhase"):
+                     "BipartiteGraphReadOutOperator", "DataAggregationAssociationPhase", "LocalSliceLgCollapseP",
+                     "LocalSliceLgCollapseS"):
         mod = getattr(net, mod_name)
         for n, p in mod.named_parameters():
             out[mod_name + "." + n] = p
@@ -970,8 +971,21 @@ class GCN_Detection_Network_extended(nn.Module):
             s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
                                                      hip=self._hip)                                  # :990
         tl = self.tlatent
-        arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
-        arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
+        if (not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0
+                and os.environ.get("GENIE_ASSOC_TORCH") is None):
+            # :991-992 in HIP (genie_lslc_fwd); the int32 copies of the static time-pointer tables are cached with the tables
+            key = (self.A_edges_p.data_ptr(), self.A_edges_s.data_ptr(), self.A_edges_p._version, self.A_edges_s._version)
+            if getattr(self, "_a_edges_key", None) != key:
+                self._a_edges_i32 = (self.A_edges_p.to(s.device).to(torch.int32).contiguous(),
+                                     self.A_edges_s.to(s.device).to(torch.int32).contiguous())
+                self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
+            ip32 = ipick.to(torch.int32)
+            eps = self.LocalSliceLgCollapseP.eps
+            arv_p = self._hip.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
+            arv_s = self._hip.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
+        else:
+            arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
+            arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
         arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 

@@ -333,6 +333,15 @@ int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
               int32_t* out_idx, void* stream);
 
+/* LocalSliceLgCollapse P (phase_head 0) / S (1), module.py:610-659, on the device: for every pick the 10 product nodes listed in the
+ * time-pointer table a_edges [n_sta * l_dt * 10] (int32 product-node ids, `assemble_time_pointers_for_stations`, utils.py:602-622)
+ * at (ipick, floor((tpick - t0) / dt)), those with |tpick - tlatent[e * tl_stride + tl_col]| < 2 eps kept, edge MLP on the rows of
+ * s_rows [P, 30] (genie_assoc_fwd), mean, fc2: out [n_picks, 15]. t0 = dt_partition[0], dt = dt_partition[1] - dt_partition[0];
+ * tpick / phase_label fp32 [n_picks], ipick int32. */
+int genie_lslc_fwd(genie_ctx* ctx, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
+                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
+                   const float* phase_label, int n_picks, float* out, void* stream);
+
 /* Product-level CSRs of the irregular product graph of `use_subgraph: True` on the device (the two `subgraph(...)` loops of
  * extract_inputs_adjacencies_subgraph, process_utils.py:824-839). Product node n = the pair (pair_sta[n], pair_src[n]), pairs
  * sorted by (source, station) (:790-794); seg_rowptr[g] .. seg_rowptr[g+1] = the nodes of source node g; (sta_rowptr, sta_col) /

@@ -1281,3 +1281,36 @@ def test_device_subgraph_builder_matches_reference_builder():
     with torch.no_grad():
         y2, x2 = net2.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
     assert torch.equal(y1, y2) and torch.equal(x1, x2) and torch.isfinite(y1).all()
+
+
+@pytest.mark.parametrize("S,G,n_picks", [(7, 45, 23), (40, 300, 1000), (21, 64, 1)])
+def test_local_slice_collapse_hip_matches_module(S, G, n_picks):
+    """f-2: LocalSliceLgCollapse P / S (module.py:610-659) in HIP (genie_lslc_fwd) against the PyTorch restatement in
+    genie_amd/module.py (itself pinned to the reference by tests/test_assoc_cpu.py): time-pointer tables of
+    graph.time_pointers, picks scattered over the stations, some with no product node inside 2 eps (empty mean = 0)."""
+    rng = np.random.default_rng(S * 1000 + n_picks)
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=10, seed=S)
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), torch.from_numpy(geom.edge_attr()).to(DEV),
+                             torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV))
+    d = np.linalg.norm(geom.x_grid[:, None, :] - geom.locs[None, :, :], axis=2)              # [G, S]
+    trv = np.stack((d / 6000.0, d / 3500.0), axis=2).astype(np.float32)                        # P / S travel times
+    ep, es, dtp = graph.time_pointers(trv, max_t=float(trv.max()), dt=0.6, k=10, win=6.0)
+    tlatent = torch.from_numpy(trv.reshape(G * S, 2)).to(DEV)
+    ipick = torch.from_numpy(rng.integers(0, S, n_picks)).to(DEV)
+    tpick = torch.from_numpy(rng.uniform(-5.0, float(trv.max()) + 5.0, n_picks).astype(np.float32)).to(DEV)
+    tpick[0] = float(dtp[0]) + 0.01                                                            # first time bin
+    phase = torch.from_numpy(rng.integers(0, 2, (n_picks, 1)).astype(np.float32)).to(DEV)
+    s = torch.from_numpy(rng.normal(0, 1, (G * S, 30)).astype(np.float32)).to(DEV)
+    dtp_t = torch.from_numpy(dtp.astype(np.float32)).to(DEV)
+    net._hip.sync_weights(net._path_params)
+    for head, (mod, tab, col) in enumerate(((net.LocalSliceLgCollapseP, ep, 0), (net.LocalSliceLgCollapseS, es, 1))):
+        tab_t = torch.from_numpy(tab).to(DEV)
+        with torch.no_grad():
+            ref = mod(tab_t, dtp_t, tpick, ipick, phase, s, tlatent[:, col].reshape(-1, 1))
+        got = net._hip.lslc_fwd(head, s, tab_t.to(torch.int32), dtp_t, tpick, ipick.to(torch.int32), phase, tlatent, col, mod.eps)
+        assert got.shape == ref.shape and torch.isfinite(got).all()
+        assert max_abs(got.cpu(), ref.cpu()) <= 2e-6 * max(1.0, float(ref.abs().max())), head
