@@ -76,6 +76,8 @@ SYMBOLS = [
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     ("genie_lslc_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
                                   _P, _P, _P, _c.c_int, _P, _P]),
+    ("genie_arrivals_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_float,
+                                      _P, _P, _P, _P]),
     ("genie_subgraph_csr_count", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_subgraph_csr_fill", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_row_select_count", _c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_float, _c.c_int, _P, _P]),

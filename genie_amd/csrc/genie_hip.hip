@@ -115,6 +115,9 @@ enum {
     // pick-sized association heads (module.py:610-659): LocalSliceLgCollapse P / S
     W_LP_FC1_W, W_LP_FC1_B, W_LP_FC2_W, W_LP_FC2_B, W_LP_ACT1, W_LP_ACT2,
     W_LS_FC1_W, W_LS_FC1_B, W_LS_FC2_W, W_LS_FC2_B, W_LS_ACT1, W_LS_ACT2,
+    // StationSourceAttentionMergedPhases (module.py:662-775, `Arrivals`)
+    W_AR_Q1_W, W_AR_Q1_B, W_AR_Q2_W, W_AR_Q2_B, W_AR_C1_W, W_AR_C1_B, W_AR_C2_W, W_AR_C2_B, W_AR_V1_W, W_AR_V1_B, W_AR_V2_W, W_AR_V2_B,
+    W_AR_P1_W, W_AR_P1_B, W_AR_P2_W, W_AR_P2_B, W_AR_ACT1, W_AR_ACT2, W_AR_ACT3, W_AR_ACT4,
     W_COUNT
 };
 
@@ -190,6 +193,16 @@ Param g_params[W_COUNT] = {
     {"LocalSliceLgCollapseS.fc1.weight", 30 * 32, 0}, {"LocalSliceLgCollapseS.fc1.bias", 30, 0},
     {"LocalSliceLgCollapseS.fc2.weight", 15 * 30, 0}, {"LocalSliceLgCollapseS.fc2.bias", 15, 0},
     {"LocalSliceLgCollapseS.activate1.weight", 1, 0}, {"LocalSliceLgCollapseS.activate2.weight", 1, 0},
+    {"Arrivals.f_arrival_query_1.weight", 30 * 36, 0}, {"Arrivals.f_arrival_query_1.bias", 30, 0},
+    {"Arrivals.f_arrival_query_2.weight", 45 * 30, 0}, {"Arrivals.f_arrival_query_2.bias", 45, 0},
+    {"Arrivals.f_src_context_1.weight", 30 * 33, 0}, {"Arrivals.f_src_context_1.bias", 30, 0},
+    {"Arrivals.f_src_context_2.weight", 45 * 30, 0}, {"Arrivals.f_src_context_2.bias", 45, 0},
+    {"Arrivals.f_values_1.weight", 30 * 38, 0}, {"Arrivals.f_values_1.bias", 30, 0},
+    {"Arrivals.f_values_2.weight", 45 * 30, 0}, {"Arrivals.f_values_2.bias", 45, 0},
+    {"Arrivals.proj_1.weight", 30 * 15, 0}, {"Arrivals.proj_1.bias", 30, 0},
+    {"Arrivals.proj_2.weight", 2 * 30, 0}, {"Arrivals.proj_2.bias", 2, 0},
+    {"Arrivals.activate1.weight", 1, 0}, {"Arrivals.activate2.weight", 1, 0},
+    {"Arrivals.activate3.weight", 1, 0}, {"Arrivals.activate4.weight", 1, 0},
 };
 
 int g_raw_total = 0;
@@ -613,7 +626,7 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
 // Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack image in LDS (one ds_read_b128 per 16 x 16
 // weight block and wave instead of two LDS reads per scalar FMA) and whose result is the B operand of the next Linear.
 // Plans (genie_ctx::plan[PL_*]) and their group index maps:
-enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, NPLAN };
+enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, PL_ARR, NPLAN };
 //  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
 //  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
 //  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
@@ -657,6 +670,20 @@ constexpr int GB2_IMG_FLOATS = GB_GROUPS2 * 256 + GB_BIAS2 * 16 + 16;
 #define GL_GROUPS 8
 #define GL_BIAS 3
 constexpr int GL_IMG_FLOATS = GL_GROUPS * 256 + GL_BIAS * 16 + 16;
+
+//  StationSourceAttentionMergedPhases (module.py:662-775): f_arrival_query_1 / f_values_1 (out tile t; b = 0: arrival_p row, 1:
+//  arrival_s row, 2: the six relative-time features, two k-steps; f_values_1 b = 3: [self_link, null_link]), f_arrival_query_2 /
+//  f_values_2 (one out tile per head h, input block b), proj_1 (t)
+#define GA_Q1(t, b) ((t) * 3 + (b))
+#define GA_V1(t, b) (6 + (t) * 4 + (b))
+#define GA_Q2(h, b) (14 + (h) * 2 + (b))
+#define GA_V2(h, b) (20 + (h) * 2 + (b))
+#define GA_P1(t) (26 + (t))
+#define GA_GROUPS2 28
+//  bias tiles: 0,1 query_1; 2,3 values_1; 4..6 query_2 (head); 7..9 values_2 (head); 10,11 proj_1; 12..15 proj_2 weight rows
+//  (output m, tile t: 12 + 2m + t). Scalars: 0 activate2 (query), 1 activate3 (values), 2 activate4, 3,4 proj_2.bias
+#define GA_BIAS2 16
+constexpr int GA2_IMG_FLOATS = GA_GROUPS2 * 256 + GA_BIAS2 * 16 + 16;
 
 void add_unused_group(StagePlan& p) {
     for (int r = 0; r < 4; ++r) p.steps.push_back(unused_step());
@@ -749,6 +776,35 @@ void build_tail_plans(StagePlan* plan) {
         add_bias(p, base + 3, 0, 15);
         p.scal.push_back(g_params[base + 4].off);
         p.scal.push_back(g_params[base + 5].off);
+    }
+    {
+        StagePlan& p = plan[PL_ARR];
+        for (int m = 0; m < 2; ++m) {            // f_arrival_query_1 (36 inputs), f_values_1 (38 inputs)
+            const int mat = m == 0 ? W_AR_Q1_W : W_AR_V1_W, ld = m == 0 ? 36 : 38;
+            for (int t = 0; t < 2; ++t) {
+                add_block_group(p, mat, ld, 16 * t, rows2(t), 0, 15);
+                add_block_group(p, mat, ld, 16 * t, rows2(t), 15, 15);
+                const int c6[2] = {30, 34}, n6[2] = {4, 2};
+                add_scalar_group(p, mat, ld, 16 * t, rows2(t), c6, n6, 2);
+                if (m == 1) { const int c2[1] = {36}, n2[1] = {2}; add_scalar_group(p, mat, ld, 16 * t, rows2(t), c2, n2, 1); }
+            }
+        }
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 3; ++h)
+                for (int b = 0; b < 2; ++b) add_block_group(p, m == 0 ? W_AR_Q2_W : W_AR_V2_W, 30, 15 * h, 15, 16 * b, rows2(b));
+        for (int t = 0; t < 2; ++t) add_block_group(p, W_AR_P1_W, 15, 16 * t, rows2(t), 0, 15);
+        for (int t = 0; t < 2; ++t) add_bias(p, W_AR_Q1_B, 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) add_bias(p, W_AR_V1_B, 16 * t, rows2(t));
+        for (int h = 0; h < 3; ++h) add_bias(p, W_AR_Q2_B, 15 * h, 15);
+        for (int h = 0; h < 3; ++h) add_bias(p, W_AR_V2_B, 15 * h, 15);
+        for (int t = 0; t < 2; ++t) add_bias(p, W_AR_P1_B, 16 * t, rows2(t));
+        for (int m = 0; m < 2; ++m)
+            for (int t = 0; t < 2; ++t) add_bias(p, W_AR_P2_W, 30 * m + 16 * t, rows2(t));
+        p.scal.push_back(g_params[W_AR_ACT2].off);
+        p.scal.push_back(g_params[W_AR_ACT3].off);
+        p.scal.push_back(g_params[W_AR_ACT4].off);
+        p.scal.push_back(g_params[W_AR_P2_B].off);
+        p.scal.push_back(g_params[W_AR_P2_B].off + 1);
     }
     {
         StagePlan& p = plan[PL_BIP];
@@ -4654,6 +4710,222 @@ __global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
     }
 }
 
+// StationSourceAttentionMergedPhases (module.py:662-775, use_sparse = True, use_neighbor_assoc_edges = False), pick-sized. For
+// every source i and pick a the reference attends over the picks b of a's station plus a null pick (:703-718), keeps the edges
+// whose observed - theoretical arrival time (P or S) is inside 2 eps (:722-729) -- a property of (b, i) alone --, and runs three
+// edge MLPs; queries and the relative-time features depend on (b, i) only, the context on (i, self_link, null_link), the values
+// on (b, i, self_link, null_link). One workgroup per (source i, station u with picks):
+//   A1  keep flags of the station's picks + the null pick, compacted in order into an LDS list;
+//   A2  per kept b (16 per wave, fp32-MFMA tiles): query -> the three head scores against the context of a plain edge and of a
+//       self edge (the null pick: of a null edge), values of a plain edge and of a self edge (null pick: of a null edge) -> LDS;
+//   B   per target a of the station (16 per wave): segment softmax over the kept list (the entry b == a takes its self variant),
+//       'add' aggregation, mean over heads, proj_2(PReLU4(proj_1(.))).
+// k_arr_ctx prepares the three context vectors of every source. Needs at least one source with |stime| < 2 eps (then the
+// reference's `edge_index[0].max()` (:762-763) is the null pick, as assumed here); the host checks it and otherwise keeps the
+// PyTorch restatement. The softmax runs in its streaming form over chunks of AR_CAP picks (running maximum, denominator and
+// weighted value sum per target; the sum is divided by (denominator + 1e-16) at the end instead of every weight being divided
+// first: rounding-order difference only), so a station may hold any number of picks.
+constexpr int AR_CAP = 192;       // picks of a station (null included) per LDS chunk
+constexpr int AR_ENT = 104;       // floats per kept entry: scores plain [3], self [3], pad 2, values plain [3][16], self [3][16]
+struct ArArgs {
+    int n_src, n_sta, n_arv, n_useg;
+    float eps;
+    const float* stime;           // [n_src]
+    const float* trv_src;         // [n_src, n_sta, 2]
+    const float* ctx;             // [n_src][3][48] (k_arr_ctx): plain, self, null edge; head h at 16h
+    const float* arv_p; const float* arv_s;          // [n_arv, 15]
+    const float* tpick; const float* phase;          // [n_arv]
+    const int32_t* order;         // picks sorted by station (stable)
+    const int32_t* seg_sta; const int32_t* seg_start; const int32_t* seg_len;     // [n_useg] stations with picks
+    const float* img;
+    float* out;                   // [n_src, n_arv, 2]
+    int* overflow;                // (unused: the chunked softmax has no capacity limit)
+};
+
+__global__ __launch_bounds__(128) void k_arr_ctx(const float* __restrict__ raw, int o_c1w, int o_c1b, int o_c2w, int o_c2b, int o_a1,
+                                                const float* __restrict__ src_embed, const float* __restrict__ stime, int n_src,
+                                                float* __restrict__ ctx) {
+    __shared__ float hid[3][32];
+    const int i = blockIdx.x;
+    if (i >= n_src) return;
+    const float act1 = raw[o_a1];
+    for (int idx = threadIdx.x; idx < 3 * 30; idx += blockDim.x) {
+        const int v = idx / 30, c = idx - v * 30;
+        float t = raw[o_c1b + c];
+        for (int k = 0; k < 30; ++k) t += raw[o_c1w + c * 33 + k] * src_embed[(long long)i * 30 + k];
+        t += raw[o_c1w + c * 33 + 30] * stime[i];
+        if (v == 1) t += raw[o_c1w + c * 33 + 31];
+        if (v == 2) t += raw[o_c1w + c * 33 + 32];
+        hid[v][c] = prelu1(t, act1);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * 48; idx += blockDim.x) {
+        const int v = idx / 48, r = idx - v * 48, h = r >> 4, l = r & 15;
+        float t = 0.f;
+        if (l < 15) {
+            const int ch = 15 * h + l;
+            t = raw[o_c2b + ch];
+            for (int k = 0; k < 30; ++k) t += raw[o_c2w + ch * 30 + k] * hid[v][k];
+        }
+        ctx[((long long)i * 3 + v) * 48 + r] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const TlImg im = tl_stage_image(sm, a.img, GA_GROUPS2, GA_BIAS2);
+    float* ent = sm + GA2_IMG_FLOATS;                 // [AR_CAP][AR_ENT]
+    int* kept = (int*)(ent + AR_CAP * AR_ENT);        // [AR_CAP] position r in the station's pick list (L = the null pick)
+    float* cx = (float*)(kept + AR_CAP);              // [3][48] context vectors of this source
+    int* wcnt = (int*)(cx + 144);                     // [4] per-wave counts of the compaction, [4] = total
+    const int i = blockIdx.x / a.n_useg, ug = blockIdx.x - i * a.n_useg;
+    const int u = a.seg_sta[ug], r0 = a.seg_start[ug], L = a.seg_len[ug];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const float eps = a.eps, st = a.stime[i];
+    const float tp_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 0] + st, ts_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 1] + st;
+    const float rel_null = -eps - (-eps + st);        // null pick: atime = -eps, theoretical time = -eps (:722-725)
+    for (int k = threadIdx.x; k < 144; k += blockDim.x) cx[k] = a.ctx[(long long)i * 144 + k];
+    const float act2 = im.scal[0], act3 = im.scal[1], act4 = im.scal[2];
+    const float e2 = eps * eps, sq = sqrtf(15.f);
+    const f32x4 w2[2][2] = {{tl_bias(im, 12, q), tl_bias(im, 13, q)}, {tl_bias(im, 14, q), tl_bias(im, 15, q)}};
+    // Targets in blocks of 256 (4 tiles of 16 per wave, their softmax state in registers); the station's picks + the null pick
+    // (r = 0 .. L) in chunks of AR_CAP: A1 / A2 fill the LDS list with the kept picks of the chunk, B folds them into the running
+    // (max, denominator, weighted value sum) of every target (one chunk = the plain two-pass segment softmax).
+    for (int tb0 = 0; tb0 < L; tb0 += 256) {
+        float mx[4][3], den[4][3];
+        f32x4 agg[4][3];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int h = 0; h < 3; ++h) { mx[tt][h] = -INFINITY; den[tt][h] = 0.f; agg[tt][h] = tl_zero(); }
+        for (int cb = 0; cb <= L; cb += AR_CAP) {
+            __syncthreads();                          // the previous chunk's list is no longer read
+            // ---- A1: ordered compaction of the kept picks of the chunk
+            {
+                const int r = cb + (int)threadIdx.x;
+                bool keep = false;
+                if ((int)threadIdx.x < AR_CAP) {
+                    if (r < L) {
+                        const float tp = a.tpick[a.order[r0 + r]];
+                        keep = fabsf(tp - tp_src) < 2.f * eps || fabsf(tp - ts_src) < 2.f * eps;
+                    } else if (r == L) keep = fabsf(rel_null) < 2.f * eps;
+                }
+                const unsigned long long bal = __ballot(keep);
+                if (lane == 0) wcnt[wave] = __popcll(bal);
+                __syncthreads();
+                int off = 0;
+                for (int k = 0; k < wave; ++k) off += wcnt[k];
+                if (keep) kept[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+                if (threadIdx.x == 0) wcnt[4] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                __syncthreads();
+            }
+            const int K = wcnt[4];
+            // ---- A2: queries / scores / values of the kept picks
+            for (int tile = wave; tile * 16 < K; tile += 4) {
+                const int kk = tile * 16 + j;
+                const bool ok = kk < K;
+                const int r = kept[ok ? kk : K - 1];
+                const bool nul = r == L;
+                const int b = nul ? 0 : a.order[r0 + r];
+                const float tp = nul ? 0.f : a.tpick[b];
+                const float rp = nul ? rel_null : tp - tp_src, rs = nul ? rel_null : tp - ts_src;
+                const float ph = nul ? -1.f : a.phase[b];
+                const float f6[6] = {expf(-0.5f * (rp * rp) / e2), (rp > 0.f) - (rp < 0.f) + 0.f, ph,
+                                     expf(-0.5f * (rs * rs) / e2), (rs > 0.f) - (rs < 0.f) + 0.f, ph};
+                const float x0 = q == 0 ? f6[0] : (q == 1 ? f6[1] : (q == 2 ? f6[2] : f6[3]));     // columns 30 + q
+                const float x1 = q == 0 ? f6[4] : (q == 1 ? f6[5] : 0.f);                          // columns 34 + q
+                const f32x4 xp = nul ? tl_zero() : tl_load15(a.arv_p + (long long)b * 15, q);
+                const f32x4 xs = nul ? tl_zero() : tl_load15(a.arv_s + (long long)b * 15, q);
+                f32x4 hq[2], hv[2], hw[2];   // hidden layers: query, values of a plain edge, values of a self (null pick: null) edge
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 z = mma_block(tl_bias(im, t, q), TLW(im, GA_Q1(t, 0)), xp);
+                    z = mma_block(z, TLW(im, GA_Q1(t, 1)), xs);
+                    z = MFMA16(TLW(im, GA_Q1(t, 2)).x, x0, z);
+                    z = MFMA16(TLW(im, GA_Q1(t, 2)).y, x1, z);
+                    hq[t] = prelu4(z, act2);
+                    f32x4 v = mma_block(tl_bias(im, 2 + t, q), TLW(im, GA_V1(t, 0)), xp);
+                    v = mma_block(v, TLW(im, GA_V1(t, 1)), xs);
+                    v = MFMA16(TLW(im, GA_V1(t, 2)).x, x0, v);
+                    v = MFMA16(TLW(im, GA_V1(t, 2)).y, x1, v);
+                    const f32x4 w = MFMA16(TLW(im, GA_V1(t, 3)).x, nul ? (q == 1 ? 1.f : 0.f) : (q == 0 ? 1.f : 0.f), v);
+                    hv[t] = prelu4(v, act3);
+                    hw[t] = prelu4(w, act3);
+                }
+                float* eo = ent + (long long)(ok ? kk : K - 1) * AR_ENT;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    f32x4 qh = mma_block(tl_bias(im, 4 + h, q), TLW(im, GA_Q2(h, 0)), hq[0]);
+                    qh = mma_block(qh, TLW(im, GA_Q2(h, 1)), hq[1]);
+                    // plain-edge context (null pick: null-edge context) and self-edge context
+                    const f32x4 c0 = *(const f32x4*)(cx + (nul ? 96 : 0) + h * 16 + 4 * q), c1 = *(const f32x4*)(cx + 48 + h * 16 + 4 * q);
+                    const f32x4 p0 = qh * c0, p1 = qh * c1;
+                    float s0 = ((p0.x + p0.y) + p0.z) + p0.w, s1 = ((p1.x + p1.y) + p1.z) + p1.w;
+                    s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+                    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                    f32x4 vh = mma_block(tl_bias(im, 7 + h, q), TLW(im, GA_V2(h, 0)), hv[0]);
+                    vh = mma_block(vh, TLW(im, GA_V2(h, 1)), hv[1]);
+                    f32x4 wh = mma_block(tl_bias(im, 7 + h, q), TLW(im, GA_V2(h, 0)), hw[0]);
+                    wh = mma_block(wh, TLW(im, GA_V2(h, 1)), hw[1]);
+                    if (ok) {
+                        if (q == 0) { eo[h] = s0 / sq; eo[3 + h] = s1 / sq; }
+                        *(f32x4*)(eo + 8 + h * 16 + 4 * q) = nul ? wh : vh;      // the null pick has one variant (null edge)
+                        *(f32x4*)(eo + 56 + h * 16 + 4 * q) = wh;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- B: fold the chunk into the targets' softmax state
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int r = tb0 + (tt * 4 + wave) * 16 + j;
+                if (tb0 + (tt * 4 + wave) * 16 >= L || K == 0) continue;          // (uniform per wave)
+                float cm[3] = {mx[tt][0], mx[tt][1], mx[tt][2]};
+                for (int k = 0; k < K; ++k) {
+                    const float* e = ent + k * AR_ENT + (kept[k] == r ? 3 : 0);
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) cm[h] = fmaxf(cm[h], e[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const float sc = mx[tt][h] == -INFINITY ? 0.f : expf(mx[tt][h] - cm[h]);
+                    den[tt][h] *= sc; agg[tt][h] *= sc; mx[tt][h] = cm[h];
+                }
+                for (int k = 0; k < K; ++k) {
+                    const bool self = kept[k] == r;
+                    const float* e = ent + k * AR_ENT;
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const float ex = expf(e[(self ? 3 : 0) + h] - cm[h]);
+                        den[tt][h] += ex;
+                        agg[tt][h] += *(const f32x4*)(e + (self ? 56 : 8) + h * 16 + 4 * q) * ex;
+                    }
+                }
+            }
+        }
+        // ---- every pick of the block: normalise, mean over heads (:760), proj_2(PReLU4(proj_1(.)))
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int rb = tb0 + (tt * 4 + wave) * 16;
+            if (rb >= L) continue;
+            const int r = rb + j;
+            const bool ok = r < L;
+            const f32x4 z = ((agg[tt][0] / (den[tt][0] + 1e-16f) + agg[tt][1] / (den[tt][1] + 1e-16f)) + agg[tt][2] / (den[tt][2] + 1e-16f)) / 3.f;
+            f32x4 pa = prelu4(mma_block(tl_bias(im, 10, q), TLW(im, GA_P1(0)), z), act4);
+            f32x4 pb = prelu4(mma_block(tl_bias(im, 11, q), TLW(im, GA_P1(1)), z), act4);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float o = w2[m][0].x * pa.x;
+                o += w2[m][0].y * pa.y; o += w2[m][0].z * pa.z; o += w2[m][0].w * pa.w;
+                o += w2[m][1].x * pb.x; o += w2[m][1].y * pb.y; o += w2[m][1].z * pb.z; o += w2[m][1].w * pb.w;
+                o += __shfl_xor(o, 16);
+                o += __shfl_xor(o, 32);
+                if (ok && q == 0) a.out[((long long)i * a.n_arv + a.order[r0 + r]) * 2 + m] = o + im.scal[3 + m];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pick -> Slice/Mask embedding on device: `extract_input_from_data`,
 // /root/reference/Code/process_utils.py:460-642 (use_sign_input = False). Step 1: per-station Gaussian-kernel time
@@ -6858,6 +7130,31 @@ int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int3
     a.s = s_rows; a.A_edges = a_edges; a.tlatent = tlatent; a.tl_stride = tl_stride; a.tl_col = tl_col;
     a.tpick = tpick; a.ipick = ipick; a.phase = phase_label; a.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS]; a.out = out;
     k_lslc<<<tl_blocks(n_picks, c->num_cu * 4), 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_arrivals_fwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                       const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                       const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                       float eps, float* ctx_scratch, int32_t* overflow, float* out, void* stream) {
+    if (!c || !stime || !src_embed || !trv_src || !arrival_p || !arrival_s || !tpick || !phase_label || !order || !seg_sta || !seg_start ||
+        !seg_len || !ctx_scratch || !overflow || !out)
+        return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: null argument");
+    if (n_src < 1 || n_sta < 1 || n_arv < 1 || n_useg < 1 || !(eps > 0.f)) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: bad argument");
+    if ((long long)n_src * n_useg > 0x7fffffffLL) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: too many (source, station) pairs");
+    hipStream_t st = (hipStream_t)stream;
+    { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+    k_arr_ctx<<<n_src, 128, 0, st>>>(c->raw, g_params[W_AR_C1_W].off, g_params[W_AR_C1_B].off, g_params[W_AR_C2_W].off, g_params[W_AR_C2_B].off,
+                                     g_params[W_AR_ACT1].off, src_embed, stime, n_src, ctx_scratch);
+    ArArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_src = n_src; a.n_sta = n_sta; a.n_arv = n_arv; a.n_useg = n_useg; a.eps = eps;
+    a.stime = stime; a.trv_src = trv_src; a.ctx = ctx_scratch; a.arv_p = arrival_p; a.arv_s = arrival_s; a.tpick = tpick; a.phase = phase_label;
+    a.order = order; a.seg_sta = seg_sta; a.seg_start = seg_start; a.seg_len = seg_len; a.img = c->packed[PL_ARR]; a.out = out; a.overflow = overflow;
+    const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + AR_CAP * AR_ENT + AR_CAP + 144 + 8);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_arrivals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_arrivals<<<n_src * n_useg, 256, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -216,7 +216,7 @@ def sfc_order(points):
 
 
 ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.", "LocalSliceLgCollapseP.",
-                  "LocalSliceLgCollapseS.")
+                  "LocalSliceLgCollapseS.", "Arrivals.")
 
 
 class HipPath(object):
@@ -707,6 +707,43 @@ class HipPath(object):
         _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)),
                                            t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
                                            _ptr(phase_label), n, _ptr(out), _stream()), "genie_lslc_fwd")
+        return out
+
+    def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps):
+        """StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd): stime [n_src], src_embed
+        [n_src, 30], trv_src [n_src, n_sta, 2], arrival_p / arrival_s [n, 15], tpick / phase_label [n], ipick integer [n] ->
+        [n_src, n, 2], or None when the kernel's precondition does not hold (no source with |stime| < 2 eps: the reference's
+        `edge_index[0].max()` is then not the null pick): the caller then takes the PyTorch restatement."""
+        if not getattr(self, "assoc_ready", False):
+            raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
+        stime = _f32(stime, "stime").reshape(-1)
+        n_src = int(stime.numel())
+        src_embed = _f32(src_embed, "src_embed", (n_src, 30))
+        trv_src = _f32(trv_src, "trv_src")
+        if trv_src.dim() != 3 or trv_src.shape[0] != n_src or trv_src.shape[2] != 2:
+            raise ValueError("arrivals_fwd: trv_src must be [n_src, n_sta, 2]")
+        n_sta = int(trv_src.shape[1])
+        tpick = _f32(tpick, "tpick").reshape(-1)
+        n = int(tpick.numel())
+        arrival_p, arrival_s = _f32(arrival_p, "arrival_p", (n, 15)), _f32(arrival_s, "arrival_s", (n, 15))
+        phase_label = _f32(phase_label, "phase_label").reshape(-1)
+        if n == 0 or n_src == 0 or not bool((stime.abs() < 2.0 * float(eps)).any()):
+            return None
+        ip = ipick.reshape(-1).long()
+        if ip.numel() != n or phase_label.numel() != n or int(ip.max()) >= n_sta or int(ip.min()) < 0:
+            raise ValueError("arrivals_fwd: one station index in [0, n_sta) and one phase label per pick")
+        order = torch.sort(ip, stable=True)[1]
+        seg_sta, counts = torch.unique_consecutive(ip[order], return_counts=True)
+        seg_start = torch.cumsum(counts, 0) - counts
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        order, seg_sta, seg_start, counts = i32(order), i32(seg_sta), i32(seg_start), i32(counts)
+        ctx = torch.empty(n_src * 144, dtype=torch.float32, device=self.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        out = torch.empty((n_src, n, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_arrivals_fwd(self.ctx, n_src, _ptr(stime), _ptr(src_embed), _ptr(trv_src), n_sta, _ptr(arrival_p),
+                                               _ptr(arrival_s), _ptr(tpick), _ptr(phase_label), n, _ptr(order), _ptr(seg_sta),
+                                               _ptr(seg_start), _ptr(counts), int(seg_sta.numel()), float(eps), _ptr(ctx), _ptr(flag),
+                                               _ptr(out), _stream()), "genie_arrivals_fwd")
         return out
 
     def train_fwd(self, Slice, Mask, edge_attr, want_x_latent=True):

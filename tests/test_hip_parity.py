@@ -1314,3 +1314,44 @@ def test_local_slice_collapse_hip_matches_module(S, G, n_picks):
         got = net._hip.lslc_fwd(head, s, tab_t.to(torch.int32), dtp_t, tpick, ipick.to(torch.int32), phase, tlatent, col, mod.eps)
         assert got.shape == ref.shape and torch.isfinite(got).all()
         assert max_abs(got.cpu(), ref.cpu()) <= 2e-6 * max(1.0, float(ref.abs().max())), head
+
+
+@pytest.mark.parametrize("S,n_src,n_picks", [(7, 4, 23), (40, 9, 1500), (12, 1, 1), (30, 3, 600), (3, 2, 1300)])
+def test_arrivals_head_hip_matches_module(S, n_src, n_picks):
+    """f-2: StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd) against the PyTorch
+    restatement in genie_amd/module.py (pinned to the reference's forward_fixed by tests/test_assoc_cpu.py): picks clustered
+    around the theoretical arrivals of the sources (so that the 2-eps windows hold several picks per station, some stations
+    none), picks outside every window (targets without edges), one source whose null pick is filtered (|stime| >= 2 eps);
+    3 stations x 1300 picks: several LDS chunks and two target blocks per station (streaming softmax)."""
+    rng = np.random.default_rng(S * 100 + n_picks)
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    geom = synthetic.Geometry(S, 40, L=100e3, n_query=5, seed=S)
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), torch.from_numpy(geom.edge_attr()).to(DEV),
+                             torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV))
+    net._hip.sync_weights(net._path_params)
+    eps = net.Arrivals.eps
+    trv = rng.uniform(5.0, 60.0, (n_src, S, 1)).astype(np.float32)
+    trv = np.concatenate((trv, trv * 1.7), axis=2)
+    stime = rng.uniform(-10.0, 10.0, n_src).astype(np.float32)
+    if n_src > 2:
+        stime[-1] = 2.5 * eps                                      # this source's null pick is filtered
+    ipick = rng.integers(0, S, n_picks)
+    src_of = rng.integers(0, n_src, n_picks)
+    tpick = (trv[src_of, ipick, rng.integers(0, 2, n_picks)] + stime[src_of] + rng.normal(0, 0.7 * eps, n_picks)).astype(np.float32)
+    far = rng.random(n_picks) < 0.1
+    tpick[far] += 500.0                                            # picks no source explains
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    arv_p = t(rng.normal(0, 1, (n_picks, 15)).astype(np.float32))
+    arv_s = t(rng.normal(0, 1, (n_picks, 15)).astype(np.float32))
+    phase = t(rng.integers(0, 2, (n_picks, 1)).astype(np.float32))
+    x_src = t(rng.normal(0, 1, (n_src, 30)).astype(np.float32))
+    with torch.no_grad():
+        ref = net.Arrivals(n_src, t(stime), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase)
+    got = net._hip.arrivals_fwd(t(stime), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase, eps)
+    assert got is not None and got.shape == ref.shape and torch.isfinite(got).all()
+    assert max_abs(got.cpu(), ref.cpu()) <= 5e-6 * max(1.0, float(ref.abs().max()))
+    # no source inside 2 eps of the origin time: the kernel's precondition fails and the caller keeps the PyTorch path
+    assert net._hip.arrivals_fwd(t(np.full(n_src, 3.0 * eps, np.float32)), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase, eps) is None
