@@ -55,7 +55,8 @@ TRAFFIC_SOURCE = "profiles/r02_f_pmc_stage_kernels.txt"
 TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.480e5 + 3.126e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
                 "k_stage2": (2.0 * 5.373e5 + 1.630e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
-ONE_GPU_CFG4 = {"ms_per_step": 42.69, "source": "profiles/r02_a_bench_cfg4_one_gpu.json (this code path with --gpus 1)"}
+ONE_GPU_CFG4 = {"ms_per_step": 43.22, "source": "profiles/r02_f_bench_cfg4_one_gpu.json (this code path with --gpus 1; the N = 1 line of this bench "
+                                                 "measures it live as sharded_workload_on_one_gpu)"}
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -91,6 +92,9 @@ def parse():
                          "pipeline through CU-masked streams; 0 = shared CUs (default)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded: sequential schedule (stage 1, exchange, stage 2, all-gather)")
     ap.add_argument("--cpu-windows", type=int, default=3, help="cpu_baseline: timed windows after one warm-up (median)")
+    ap.add_argument("--no-cfg4-one-gpu", action="store_true",
+                    help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
+                         "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
     return ap.parse_args()
 
 
@@ -270,7 +274,7 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
-def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
+def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     """ONE window per step, product graph sharded over source nodes across the ranks (genie_amd/dist.py): per window one
     halo all-to-all (64 B per halo product node; issued as soon as stage 1 has produced the rows other ranks need, under the
     rest of stage 1 and the halo-free part of stage 2) and one all-gather of the [G,15] Bipartite output over RCCL/xGMI; the
@@ -370,10 +374,11 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist):
                      "achieved": round(b_alg * wps / 1e9, 1), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(b_alg * wps / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None},
     }
-    if rank == 0:
+    if rank == 0 and emit:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out
 
 
 def main_dry_run_cpu(a, rank, world):
@@ -568,6 +573,23 @@ def main():
         "tail_cus_per_xcd": 0 if a.no_pipeline else a.tail_cus,
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_cfg4_one_gpu \
+            and torch.cuda.get_device_properties(dev).total_memory > 160e9:
+        # The N > 1 lines of this bench run ANOTHER workload (config 4: 2000 stations / 50 000 grid nodes / 500 000 picks, ONE
+        # window sharded over source nodes, strong scaling). Its one-GPU figure belongs next to them: measured here through the
+        # same code path (a few windows), so that a scaling curve over N = 1, 2, 4, 8 has its own N = 1 point.
+        import copy
+        a4 = copy.copy(a)
+        a4.config, a4.steps, a4.warmup, a4.no_overlap = "cfg4_2000x50k", 5, 2, False
+        S4, G4, np4, L4, nq4 = synthetic.CONFIGS[a4.config]
+        try:
+            o4 = main_sharded(a4, synthetic.Geometry(S4, G4, L=L4, n_query=nq4, seed=1), np4, nq4, 0, 1, dev, None, emit=False)
+            out["sharded_workload_on_one_gpu"] = {"config": o4["config"]["workload"], "steps": a4.steps, "ms_per_step": o4["ms_per_step"],
+                                                  "value": o4["value"], "unit": "picks/s", "rank0_phase_ms_sequential": o4["rank0_phase_ms_sequential"],
+                                                  "roofline_frac": o4["roofline"]["frac"]}
+        except Exception as e:       # (the headline line must not depend on it)
+            out["sharded_workload_on_one_gpu"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         yc, xc, cdt, ctimes, c1, gs = cpu_baseline(net, geom, wins[0], a.cpu_windows)
         with torch.no_grad():
