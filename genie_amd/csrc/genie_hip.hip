@@ -847,6 +847,8 @@ __device__ int g_abl_mfma;  // set from the host in tuning builds
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #endif
 
+// wave-level ordering point for data the lanes of one wave exchange through LDS (LDS operations of a wave complete in order)
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 __device__ __forceinline__ float prelu1(float x, float a) { return x >= 0.f ? x : a * x; }
 __device__ __forceinline__ f32x4 prelu4(f32x4 x, float a) {
     f32x4 y;
@@ -2455,11 +2457,19 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
 // 0-3 (one per SIMD) consume their rows and issue the next tile's loads, waves 4-7 run their MFMA / reduction phase, and
 // vice versa, so the texture path always has one group's loads to work on. Every wave runs the same number of iterations
 // (a wave that has run out of items repeats its last one: identical stores).
-template <int KS, int KP, bool XL, int SCHED>
+// RL (row-layout loads): in the MFMA layout lane (j = lane & 15, q = lane >> 4) reads the 16-B chunk q of node j's row, so four
+// CONSECUTIVE lanes touch four different rows and the texture path works on 16 useful bytes per 64-B request (measured: the kernel
+// moved 24 B per clock and CU where contiguous row gathers reach 57). With RL every row is loaded in the layout lane = 4 r + cq
+// (node r = lane >> 2, chunk cq = lane & 3): four consecutive lanes read one 64-B row, sixteen consecutive source rows one
+// contiguous KB. Everything up to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the
+// gated mask then go through a 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1. Same arithmetic in
+// the same order: bitwise identical results.
+template <int KS, int KP, bool XL, int SCHED, bool RL = false>
 __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     constexpr bool PH = SCHED == 3;
     __shared__ f32x4 lw[NF4];
+    __shared__ __attribute__((aligned(16))) float tsc[RL ? 4 * 16 * 36 : 4];
     for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
@@ -2468,6 +2478,8 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jl = RL ? lane >> 2 : j, ql = RL ? lane & 3 : q;      // (node, chunk) this lane LOADS
+    float* ts = tsc + (RL ? wave * 16 * 36 : 0);
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, 0);
     // a.wgmap: a workgroup takes BLOCKS of 4 consecutive source nodes of its XCD's chunk, wave k sweeps the tiles of the k-th
@@ -2489,7 +2501,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     } else if (w.it >= w.nitems) return;
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
-    const unsigned q16 = 16u * (unsigned)q;
+    const unsigned q16 = 16u * (unsigned)ql;
     const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
     const unsigned m_T = ItemIter::recip((unsigned)a.T);
 
@@ -2512,24 +2524,24 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     int sta[KS];
     auto load_ids = [&](int gi, int tb, int& idv) {
         idv = a.src_tab[gi * 16 + j];
-        const int s = tb * 16 + j;
+        const int s = tb * 16 + jl;
         load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
     };
     auto issue0 = [&](int idv, int tb) {
         const int g = __builtin_amdgcn_readlane(idv, 0);
-        const int s = tb * 16 + j, sc = s < S ? s : S - 1;
+        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
         long long p = (long long)g * S + sc;
         if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
-        rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
+        rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
         rows.mq = a.mm_int[p];
-        rows.eq = q < 3 ? a.ea_int[p * 3 + q] : 0.f;
+        rows.eq = ql < 3 ? a.ea_int[p * 3 + ql] : 0.f;
         const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
 #pragma unroll
         for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? rows.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
     };
     auto issue_v = [&](int idv, int tb, int k0, int k1) {
-        const int s = tb * 16 + j, sc = s < S ? s : S - 1;
+        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
         const unsigned so = (unsigned)sc * 64u + q16;
 #pragma unroll
         for (int k = 0; k < KP; ++k)
@@ -2566,28 +2578,43 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         f32x4 o[2];
         o[0] = prelu4u(fma4(n1, 1.f / (float)KS, rows.o[0]), a2);
         o[1] = prelu4u(fma4(n2, 1.f / (float)KP, rows.o[1]), a2);
-        const float mq = rows.mq, eq = rows.eq;
+        float mq = rows.mq, eq = rows.eq;
+        const int s_l = tb_c * 16 + jl;              // the node this lane loaded (RL: not the node it holds in the MFMA layout)
+        const bool valid_l = s_l < S;
+        const f32x4 ol0 = o[0], ol1 = o[1];
+        if (RL) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
+            *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
+            *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
+            ts[jl * 36 + 32 + ql] = ql < 3 ? eq : (valid_l ? mq : 0.f);
+            GSYNC();
+            o[0] = *(const f32x4*)(ts + j * 36 + 4 * q);
+            o[1] = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+            eq = q < 3 ? ts[j * 36 + 32 + q] : 0.f;
+            mq = ts[j * 36 + 35];
+        }
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
         // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
         issue0(idv_n, tb_n);
         if (SCHED >= 1) issue_v(idv_n, tb_n, 0, KH);
         if (SCHED >= 2) issue_v(idv_n, tb_n, KH, KP);
         if (PH) __syncthreads();
-        if (XL && valid) {
-            const int su = a.sta_user[s_c];
+        if (XL && valid_l) {
+            const int su = a.sta_user[s_l];
             float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * q + r < 15) { xl[4 * q + r] = o[0][r]; xl[15 + 4 * q + r] = o[1][r]; }
+                if (4 * ql + r < 15) { xl[4 * ql + r] = ol0[r]; xl[15 + 4 * ql + r] = ol1[r]; }
         }
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            if (!ABL(a, 6)) {      // (tuning bit 6: no fc1 MFMAs)
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            } else bp[t] += o[0] + o[1] + eq;
             bp[t] = prelu4u(bp[t], ab1);
             // (3) second / third burst, behind the first / second output tile of fc1
             asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
@@ -2601,7 +2628,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         item_of(it2, gi_2, tb_2);
         load_ids(gi_2, tb_2, idv_2);
         // (5) mask gate and station sum of this tile
-        const float mm = valid ? mq : 0.f;
+        const float mm = RL ? mq : (valid ? mq : 0.f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 v = bp[t] * mm;
@@ -3622,8 +3649,6 @@ __global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
 // in LDS ([k][32], lane = output channel), inputs broadcast with width-32 shuffles.
 // ------------------------------------------------------------------------------------------------
 constexpr int NPB = 8;  // nodes per 256-thread block
-// wave-level ordering point for data the 32 lanes of a node group (half a wave) exchange through LDS (see k_readout)
-#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 // The per-node matvecs o[c] = sum_k W[k][c] x[k] read x[k] as an LDS broadcast (the compiler merges four k into one
 // ds_read_b128): 3.5 LDS cycles per wave-FMA and CU against 6.5 with __shfl = ds_bpermute (tools/lds_matvec.hip).
 
@@ -6376,7 +6401,11 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         { const char* e = getenv("GENIE_S2_WGMAP"); a.wgmap = (e && atoi(e)) ? 1 : 0; }
         const char* es = getenv("GENIE_S2_SCHED");
         const int sched = es ? atoi(es) : 0;
-        if (x_latent_out) k_stage2_ord<8, 15, true, 0><<<grid, 256, 0, st>>>(a);
+        const char* erl = getenv("GENIE_S2_RL");
+        const bool rl = !(erl && atoi(erl) == 0);
+        if (x_latent_out && rl) k_stage2_ord<8, 15, true, 0, true><<<grid, 256, 0, st>>>(a);
+        else if (x_latent_out) k_stage2_ord<8, 15, true, 0><<<grid, 256, 0, st>>>(a);
+        else if (rl && sched == 0) k_stage2_ord<8, 15, false, 0, true><<<grid, 256, 0, st>>>(a);
         else if (sched == 3) k_stage2_ord<8, 15, false, 3><<<da_grid_w(c, n_tiles, 1, 8), 512, 0, st>>>(a);
         else if (sched == 1) k_stage2_ord<8, 15, false, 1><<<grid, 256, 0, st>>>(a);
         else if (sched == 2) k_stage2_ord<8, 15, false, 2><<<grid, 256, 0, st>>>(a);
