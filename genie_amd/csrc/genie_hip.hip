@@ -916,7 +916,8 @@ struct DaArgs {
     const float* ea_int;           // with sta_user: edge_attr in processing order (genie_set_static_edge_attr), or null
     const float* mm_int;           // with sta_user: max_k Mask[p][k] in processing order, written by the split pass of this window
     const float* packed;       // packed A fragments for the stage
-    const void* xs;            // k_stage1_b3: 48-B rows of bf16 pieces of [Slice || Mask]
+    const void* xs;            // k_stage1_b3: the three 16-B bf16 pieces of every [Slice || Mask] row, planar
+    long long xs_plane;        // ... bytes per plane (= rows x 16)
     long long Pn;              // k_stage?_pcsr: number of product nodes (rowptr / col arrays are product-level there)
     const float* abs_sta;      // use_absolute_pos: [S][4] = {loc / (3 scale_rel), 0}, or null
     const float* abs_src;      // ... [G_ext][4] = {x_grid / (3 scale_rel), 0}
@@ -1649,7 +1650,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-constexpr int XROW = 48;                 // bytes per split input row
+constexpr int XROW = 48;                 // bytes per split input row: three 16-B pieces, stored PLANAR (piece q of row p at
+                                         // q * rows * 16 + p * 16): the 32 lanes of a half-wave then read the same piece of 32
+                                         // consecutive rows as one contiguous 512 B instead of 16-B chunks 48 B apart
+constexpr int XPC = 16;                  // bytes per piece
 constexpr bool B3_ABS_READY = false;      // the bf16x3 kernel has no absolute-position form yet: use_absolute_pos runs k_stage1
 constexpr int B3_THREADS = 512;
 
@@ -1708,7 +1712,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
         u32x4 o;
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-        *(u32x4*)(out + p * (XROW / 4) + piece * 4) = o;
+        *(u32x4*)(out + ((long long)piece * rows + p) * 4) = o;
     }
 }
 
@@ -1717,7 +1721,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
 constexpr int SPLIT_G_MAXS = 2048;
 __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
                                                       unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
-                                                      float* __restrict__ mm) {
+                                                      float* __restrict__ mm, long long rows) {
     extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
     const long long base = (long long)blockIdx.x * S;
     for (int r = threadIdx.x; r < S; r += blockDim.x) {
@@ -1735,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ 
             u32x4 o;
 #pragma unroll
             for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-            *(u32x4*)(out + (base + r) * (XROW / 4) + piece * 4) = o;
+            *(u32x4*)(out + ((long long)piece * rows + base + r) * 4) = o;
         }
     }
 }
@@ -1810,8 +1814,9 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, a.dyn != nullptr ? a.dyn_gw : 0);
     const char* xs = (const char*)a.xs;
-    const unsigned la = hi ? 16u : 0u, lb = hi ? 0u : 32u;       // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]
-    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XROW);
+    // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]: plane offsets of its two pieces
+    const off_t_ la = hi ? (off_t_)a.xs_plane : (off_t_)0, lb = hi ? (off_t_)0 : (off_t_)(2 * a.xs_plane);
+    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XPC);
 
     const f32x4 fa0 = lw[(B3_FA + 0) * 64 + lane], fa1 = lw[(B3_FA + 1) * 64 + lane], fa2 = lw[(B3_FA + 2) * 64 + lane];
     const f32x16 biasA = bias16(lbias, 0, h);
@@ -1856,7 +1861,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         const int g = half ? g1 : g0;
         const long long p = (long long)g * S + sc;
         off_t_ gbase = (off_t_)(unsigned)g * gstride;                   // byte offset of source node g in xs
-        unsigned sbase = (unsigned)sc * (unsigned)XROW;
+        unsigned sbase = (unsigned)sc * (unsigned)XPC;
         const int srcv = idv;
 
         // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
@@ -1867,16 +1872,17 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         auto issue = [&](int u) {
             off_t_ off;
             if (u == 0) off = gbase + sbase;
-            else if (u <= KS) off = gbase + __umul24((unsigned)sta_id[u - 1], (unsigned)XROW);
+            else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
             else {
                 const int n0 = __builtin_amdgcn_readlane(srcv, u - KS), n1 = __builtin_amdgcn_readlane(srcv, 16 + u - KS);
                 off = (BIG ? (off_t_)(unsigned)(half ? n1 : n0) * gstride : (off_t_)__umul24((unsigned)(half ? n1 : n0), (unsigned)gstride)) + sbase;
             }
             const off_t_ oa = off + la, ob = off + lb;        // offsets from the uniform base (saddr addressing when 32-bit)
+            if (ABL(a, 12) && u > 0) { bufa[u] = bufa[0]; bufb[u] = bufb[0]; return; }     // tuning: no neighbour-row loads
             bufa[u] = *(const u32x4*)(xs + oa);
             bufb[u] = *(const u32x4*)(xs + ob);
         };
-        const u32x4 own3 = *(const u32x4*)(xs + (gbase + sbase + 32u));         // piece 3 of the own row (Mask pads)
+        const u32x4 own3 = *(const u32x4*)(xs + (gbase + sbase + (off_t_)(2 * a.xs_plane)));         // piece 3 of the own row (Mask pads)
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) issue(u);
 
@@ -5023,7 +5029,7 @@ __global__ void k_embed_gather(EmbArgs a) {
             u32x4 o;
 #pragma unroll
             for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-            *(u32x4*)(a.xs + px * (XROW / 4) + piece * 4) = o;
+            *(u32x4*)(a.xs + ((long long)piece * a.rows + px) * 4) = o;
         }
     }
 }
@@ -6274,12 +6280,12 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (!presplit) {
             if (sta_order_on(c) && c->S <= SPLIT_G_MAXS) {
                 HIP_TRY(hipFuncSetAttribute((const void*)k_split_rows_g, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_G_MAXS * 32));
-                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw);
+                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw, c->P_ext);
             } else
                 k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs,
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
-        a.xs = xs; a.packed = c->packed_b3;
+        a.xs = xs; a.packed = c->packed_b3; a.xs_plane = c->P_ext * (long long)XPC;
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
         if (n_tiles) set_dyn(c, a, 0, c->dyn_b1, grid);
         const bool big = c->P_ext * XROW >= (1ll << 32);
