@@ -2470,7 +2470,8 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
 // contiguous KB. Everything up to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the
 // gated mask then go through a 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1. Same arithmetic in
 // the same order: bitwise identical results.
-template <int KS, int KP, bool XL, int SCHED, bool RL = false>
+// NB: stop after x_latent (no Bipartite message / station sum): the last pass of the association heads (genie_assoc_fwd).
+template <int KS, int KP, bool XL, int SCHED, bool RL = false, bool NB = false>
 __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     constexpr bool PH = SCHED == 3;
@@ -2540,8 +2541,8 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
         rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
         rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
-        rows.mq = a.mm_int[p];
-        rows.eq = ql < 3 ? a.ea_int[p * 3 + ql] : 0.f;
+        rows.mq = NB ? 0.f : a.mm_int[p];
+        rows.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
         const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
 #pragma unroll
         for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? rows.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
@@ -2588,7 +2589,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         const int s_l = tb_c * 16 + jl;              // the node this lane loaded (RL: not the node it holds in the MFMA layout)
         const bool valid_l = s_l < S;
         const f32x4 ol0 = o[0], ol1 = o[1];
-        if (RL) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
+        if (RL && !NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
             *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
             *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
             ts[jl * 36 + 32 + ql] = ql < 3 ? eq : (valid_l ? mq : 0.f);
@@ -2601,8 +2602,8 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
         // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
         issue0(idv_n, tb_n);
-        if (SCHED >= 1) issue_v(idv_n, tb_n, 0, KH);
-        if (SCHED >= 2) issue_v(idv_n, tb_n, KH, KP);
+        if (SCHED >= 1 || NB) issue_v(idv_n, tb_n, 0, KH);
+        if (SCHED >= 2 || NB) issue_v(idv_n, tb_n, KH, KP);
         if (PH) __syncthreads();
         if (XL && valid_l) {
             const int su = a.sta_user[s_l];
@@ -2616,6 +2617,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if (NB) break;
             if (!ABL(a, 6)) {      // (tuning bit 6: no fc1 MFMAs)
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
@@ -2637,6 +2639,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         const float mm = RL ? mq : (valid ? mq : 0.f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if (NB) break;
             f32x4 v = bp[t] * mm;
             v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
             if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
@@ -6400,6 +6403,10 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
         g = std::max<long long>(8, (g + 7) / 8 * 8);
         k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
+    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && no_bip && x_latent_out && !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
+        const int grid = da_grid(c, n_tiles, c->bpc2o);
+        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
+        k_stage2_ord<8, 15, true, 0, true, true><<<grid, 256, 0, st>>>(a);
     } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && a.ea_int != nullptr && !no_bip &&
                !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
         const int grid = da_grid(c, n_tiles, c->bpc2o);
