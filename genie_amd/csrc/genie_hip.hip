@@ -2471,7 +2471,11 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
 // gated mask then go through a 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1. Same arithmetic in
 // the same order: bitwise identical results.
 // NB: stop after x_latent (no Bipartite message / station sum): the last pass of the association heads (genie_assoc_fwd).
-template <int KS, int KP, bool XL, int SCHED, bool RL = false, bool NB = false>
+// SD (stream depth 2, opt-in GENIE_S2_SD=1): the streamed rows (c, message mask, edge_attr: never in a cache, 7 % of the kernel in
+// the ablation) are loaded TWO tiles ahead into two alternating register sets (the loop is unrolled twice); the source node of the
+// tile after next comes from a wave-uniform load at the top of the tile. Measured SLOWER: the unrolled loop needs 246 VGPRs (150),
+// two workgroups per CU instead of three, 0.226 -> 0.240 ms.
+template <int KS, int KP, bool XL, int SCHED, bool RL = false, bool NB = false, bool SD = false>
 __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     constexpr bool PH = SCHED == 3;
@@ -2527,25 +2531,30 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         gi = __builtin_amdgcn_readfirstlane(gi);
         tb = __builtin_amdgcn_readfirstlane(tb);
     };
-    struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; } rows;
+    struct Stream { f32x4 o[2]; float mq, eq; };                  // streamed rows of a tile: c, message mask, edge_attr
+    struct Rows { f32x4 ru[KS], rv[KP]; } rows;                    // gathered rows
+    Stream sA, sB;
     int sta[KS];
     auto load_ids = [&](int gi, int tb, int& idv) {
         idv = a.src_tab[gi * 16 + j];
         const int s = tb * 16 + jl;
         load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
     };
-    auto issue0 = [&](int idv, int tb) {
-        const int g = __builtin_amdgcn_readlane(idv, 0);
+    auto issue_s = [&](Stream& st, int g, int tb) {
         const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
         long long p = (long long)g * S + sc;
         if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
-        rows.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
-        rows.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
-        rows.mq = NB ? 0.f : a.mm_int[p];
-        rows.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
+        st.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
+        st.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
+        st.mq = NB ? 0.f : a.mm_int[p];
+        st.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
+    };
+    auto issue0 = [&](Stream& st, int idv, int tb) {
+        const int g = __builtin_amdgcn_readlane(idv, 0);
+        if (!SD) issue_s(st, g, tb);
         const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
 #pragma unroll
-        for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? rows.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
+        for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? st.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
     };
     auto issue_v = [&](int idv, int tb, int k0, int k1) {
         const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
@@ -2554,7 +2563,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         for (int k = 0; k < KP; ++k)
             if (k >= k0 && k < k1) {
                 const char* wvk = wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
-                rows.rv[k] = ABL(a, 1) ? rows.o[1] : *(const f32x4*)(wvk + so);
+                rows.rv[k] = ABL(a, 1) ? rows.ru[0] : *(const f32x4*)(wvk + so);
             }
     };
     constexpr int KH = (KP + 1) / 2;
@@ -2563,19 +2572,30 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
     item_of(it, gi_c, tb_c);
     load_ids(gi_c, tb_c, idv_c);
-    issue0(idv_c, tb_c);
+    if (SD) issue_s(sA, __builtin_amdgcn_readlane(idv_c, 0), tb_c);
+    issue0(sA, idv_c, tb_c);
     issue_v(idv_c, tb_c, 0, KP);
     {
         const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
         item_of(itn, gi_n, tb_n);
         load_ids(gi_n, tb_n, idv_n);
+        if (SD) issue_s(sB, __builtin_amdgcn_readfirstlane(a.src_tab[gi_n * 16]), tb_n);
     }
     if (PH && wave >= 4) __syncthreads();                 // the second group runs half an iteration behind
-    for (long long iter = 0;; ++iter) {
+    long long iter = 0;
+    // one tile: `sx` holds its streamed rows (SD: loaded two tiles ago and refilled here for the tile after next; else loaded one
+    // tile ago like the gathers), `sn` receives the next tile's streamed rows when they travel with its gathers (!SD)
+    auto tile = [&](Stream& sx, Stream& sn) -> bool {
         asm volatile("" : "+v"(lane));
         const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
         const int s_c = tb_c * 16 + j;
         const bool valid = s_c < S;
+        const bool has_next = it + w.stride < w.nitems;
+        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
+        int gi_2, tb_2, idv_2;
+        item_of(it2, gi_2, tb_2);
+        int g_2 = 0;
+        if (SD) g_2 = __builtin_amdgcn_readfirstlane(a.src_tab[gi_2 * 16]);        // (in flight until the end of this tile)
         // (1) consume the rows of this tile: neighbour means of the projected operands in edge order, PReLU2 -> x_latent
         f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2583,9 +2603,9 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
 #pragma unroll
         for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
         f32x4 o[2];
-        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, rows.o[0]), a2);
-        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, rows.o[1]), a2);
-        float mq = rows.mq, eq = rows.eq;
+        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sx.o[0]), a2);
+        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sx.o[1]), a2);
+        float mq = sx.mq, eq = sx.eq;
         const int s_l = tb_c * 16 + jl;              // the node this lane loaded (RL: not the node it holds in the MFMA layout)
         const bool valid_l = s_l < S;
         const f32x4 ol0 = o[0], ol1 = o[1];
@@ -2601,7 +2621,7 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         }
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
         // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
-        issue0(idv_n, tb_n);
+        issue0(sn, idv_n, tb_n);
         if (SCHED >= 1 || NB) issue_v(idv_n, tb_n, 0, KH);
         if (SCHED >= 2 || NB) issue_v(idv_n, tb_n, KH, KP);
         if (PH) __syncthreads();
@@ -2630,10 +2650,6 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
             if (SCHED == 1 && t == 0) issue_v(idv_n, tb_n, KH, KP);
         }
         // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
-        const bool has_next = it + w.stride < w.nitems;
-        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
-        int gi_2, tb_2, idv_2;
-        item_of(it2, gi_2, tb_2);
         load_ids(gi_2, tb_2, idv_2);
         // (5) mask gate and station sum of this tile
         const float mm = RL ? mq : (valid ? mq : 0.f);
@@ -2644,14 +2660,20 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
             v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
             if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
         }
+        // (6) SD: the streamed rows of the tile after next, into the registers this tile has just consumed
+        if (SD) issue_s(sx, g_2, tb_2);
         if (PH) {
             __syncthreads();
-            if (iter + 1 >= nmax) break;
-        } else if (!has_next) break;
+            if (iter + 1 >= nmax) return false;
+        } else if (!has_next) return false;
+        ++iter;
         it += w.stride;
         idv_c = idv_n; tb_c = tb_n;
         idv_n = idv_2; tb_n = tb_2;
-    }
+        return true;
+    };
+    if (SD) { for (;;) { if (!tile(sA, sA)) break; if (!tile(sB, sB)) break; } }
+    else { while (tile(sA, sA)) {} }
     if (PH && wave < 4) __syncthreads();
 }
 
@@ -6418,6 +6440,8 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         const bool rl = !(erl && atoi(erl) == 0);
         if (x_latent_out && rl) k_stage2_ord<8, 15, true, 0, true><<<grid, 256, 0, st>>>(a);
         else if (x_latent_out) k_stage2_ord<8, 15, true, 0><<<grid, 256, 0, st>>>(a);
+        else if (rl && sched == 0 && getenv("GENIE_S2_SD") && atoi(getenv("GENIE_S2_SD")) != 0)      // opt-in: 246 VGPRs, 0.226 -> 0.240 ms
+            k_stage2_ord<8, 15, false, 0, true, false, true><<<grid, 256, 0, st>>>(a);
         else if (rl && sched == 0) k_stage2_ord<8, 15, false, 0, true><<<grid, 256, 0, st>>>(a);
         else if (sched == 3) k_stage2_ord<8, 15, false, 3><<<da_grid_w(c, n_tiles, 1, 8), 512, 0, st>>>(a);
         else if (sched == 1) k_stage2_ord<8, 15, false, 1><<<grid, 256, 0, st>>>(a);

@@ -1161,7 +1161,7 @@ def test_association_heads_hip_match_oracle(S, G):
 
 
 @pytest.mark.parametrize("S,G", [(200, 300), (40, 90), (100, 64)])
-@pytest.mark.parametrize("env", [("GENIE_S2_LDS", "1"), ("GENIE_S2_ORD", "0"), ("GENIE_S2_WGMAP", "1"), ("GENIE_S2_SCHED", "3"), ("GENIE_S2_RL", "0")])
+@pytest.mark.parametrize("env", [("GENIE_S2_LDS", "1"), ("GENIE_S2_ORD", "0"), ("GENIE_S2_WGMAP", "1"), ("GENIE_S2_SCHED", "3"), ("GENIE_S2_RL", "0"), ("GENIE_S2_SD", "1")])
 def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, env, monkeypatch):
     """Stage-2 kernel variants against the default (k_stage2_ord: straight-line software pipeline, DPP station sum):
     k_stage2_lds (opt-in, GENIE_S2_LDS=1: station-neighbour rows staged in LDS per phase of NB source nodes) and k_stage2_fast
