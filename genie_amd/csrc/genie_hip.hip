@@ -5557,6 +5557,7 @@ struct genie_ctx {
     int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
     int s2_plain;              // A/B: k_stage2_fast where k_stage2_ord would run (env GENIE_S2_ORD=0)
     int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: 144 VGPRs = three per CU)
+    int s2_wgmap;              // k_stage2_ord: blocks of 4 source nodes per workgroup (large station counts)
     int s2_nb, s2_bpc;         // k_stage2_lds: source nodes per phase (0 = kernel not used) and workgroups per CU
     int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
     int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
@@ -5947,7 +5948,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
         const char* e;
-        c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : 1;
+        // scheduling segments: node-major sweeps (1) at config 2; at 2000 stations station-tile-major sweeps over segments of 16
+        // source nodes keep the source-neighbour rows of stage 1 in L2 (config 4 on one GPU: stage 1 25.8 -> 24.8 ms)
+        c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : (n_sta >= 1024 ? 16 : 1);
         // opt-in experiment (GENIE_DYN=1), measured SLOWER at config 2: one item per claim saturates the counters (stage 2 1.5 ms),
         // batches of 8-16 items per wave widen the set of source nodes an XCD works on at once and lose the L2 sharing of the
         // neighbour rows (stage 2 0.27 -> 0.33 ms, window 0.846 -> 0.857 ms)
@@ -5981,7 +5984,13 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         {
             int occo = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false, 0>, 256, 0));
-            c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occo);
+            // Large station counts (config 4: 2000 stations, 128 KB of wu / wv rows per source node): the gathers leave L2, and what
+            // pays is locality, not concurrency: blocks of 4 adjacent source nodes per workgroup (one node per wave: the four waves
+            // share half of their source rows, every wu block is gathered on one CU) and two workgroups per CU. Config 4 on one
+            // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
+            // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
+            c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
+            c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : (c->s2_wgmap ? std::min(2, std::max(1, occo)) : std::max(1, occo));
         }
         {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. OPT-IN (GENIE_S2_LDS=1). Measured at
             // S = 200, T = 13 with three workgroups per CU (164 VGPRs): back to back on cache-warm rows it beats k_stage2_fast
@@ -6433,7 +6442,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
         const int grid = da_grid(c, n_tiles, c->bpc2o);
         { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
-        { const char* e = getenv("GENIE_S2_WGMAP"); a.wgmap = (e && atoi(e)) ? 1 : 0; }
+        a.wgmap = c->s2_wgmap;
         const char* es = getenv("GENIE_S2_SCHED");
         const int sched = es ? atoi(es) : 0;
         const char* erl = getenv("GENIE_S2_RL");

@@ -247,6 +247,11 @@ class ShardedPath(object):
         Slice_ext = lp_f32(Slice_ext, "Slice", (P_ext, 4))
         Mask_ext = lp_f32(Mask_ext, "Mask", (P_ext, 4))
         edge_attr_own = lp_f32(edge_attr_own, "edge_attr", (p.n_own * S, 3))
+        ea = getattr(lp, "_static_ea", None)
+        if ea is None or ea.data_ptr() != edge_attr_own.data_ptr() or edge_attr_own._version != lp._static_ea_version:
+            # the static edge_attr of the owned rows: registered once, so that stage 2 reads its processing-order copy and runs
+            # the straight-line row-layout kernel (k_stage2_ord) as the unsharded path does
+            lp.set_static_edge_attr(edge_attr_own)
         Mask_own = Mask_ext[: p.n_own * S]
         wv = self.wv_view()
         main = torch.cuda.current_stream(self.device)
