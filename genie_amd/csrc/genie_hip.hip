@@ -4309,18 +4309,21 @@ __device__ __forceinline__ f32x4 tl_zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // Bipartite read-out (module.py:229): r_g = sum over the tiles' partial rows in tile order, out = PReLU_b2(fc2 r_g).
 __global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ part, int G, int T, const float* __restrict__ img,
                                                   float* __restrict__ out, long long part_ws, long long out_ws) {
-    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36];
     const TlImg im = tl_stage_image(sm, img, GB_GROUPS2, GB_BIAS2);
     __syncthreads();
     part += blockIdx.y * part_ws;
     out += blockIdx.y * out_ws;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int jl = lane >> 2, ql = lane & 3;          // row layout of the partial-row loads: four consecutive lanes read 64 contiguous bytes
+    float* ts = sm + GB2_IMG_FLOATS + wave * 16 * 36;
     const float act = im.scal[0];
     const int ntiles = (G + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int g = tile * 16 + j;
         const bool ok = g < G;
-        const float* pg = part + (long long)(ok ? g : G - 1) * T * 32 + 4 * q;
+        const int gl = tile * 16 + jl;
+        const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
         f32x4 r0 = tl_zero(), r1 = tl_zero();
         int tb = 0;
         for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
@@ -4331,6 +4334,12 @@ __global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ par
             for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
         }
         for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
+        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
+        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
+        GSYNC();
+        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
+        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+        GSYNC();
         f32x4 o = tl_bias(im, 0, q);
         o = mma_block(o, TLW(im, 0), r0);
         o = mma_block(o, TLW(im, 1), r1);
@@ -4397,12 +4406,13 @@ __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
 template <int C, bool NEXT>
 __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
     sa_select_window(a);
-    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 8 * 32 + 8 + 32 * 8 + 32];
+    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 8 * 32 + 8 + 32 * 8 + 32 + 4 * 16 * 36];
     const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
     float* w1p = sm + GS_IMG_FLOATS;         // fc1 columns C..C+7 (3 position + 5 global), [k][32]
     float* gsum = w1p + 8 * 32;
     float* gred = gsum + 8;                  // [32][8]
     float* red = gred + 32 * 8;
+    float* tsc = red + 32;                   // per wave [16][36]: edge means, row layout -> MFMA layout
     for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
         const int k = i >> 5, cc = i & 31;
         w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
@@ -4421,17 +4431,22 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    // The per-edge phase is elementwise per (node, channel) and runs in the ROW layout lane = 4 r + cq (node r, chunk cq): four
+    // consecutive lanes read one 64-B half of a gathered pj row (in the MFMA layout they read 16-B chunks of four different
+    // rows: a quarter of the texture path's rate); the edge means cross a per-wave LDS scratch into the MFMA layout for fc2.
+    const int jl = lane >> 2, ql = lane & 3;
+    float* ts = tsc + wave * 16 * 36;
     const float act1 = im.scal[0], act2 = im.scal[1], act3n = im.scal[2];
     f32x4 base[2], wp[3][2];
     {
         const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            base[t] = tl_bias(im, 2 + t, q);
+            base[t] = tl_bias(im, 2 + t, ql);
 #pragma unroll
-            for (int m = 0; m < 5; ++m) base[t] += *(const f32x4*)(w1p + (3 + m) * 32 + 16 * t + 4 * q) * (gsum[m] * invE);
+            for (int m = 0; m < 5; ++m) base[t] += *(const f32x4*)(w1p + (3 + m) * 32 + 16 * t + 4 * ql) * (gsum[m] * invE);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * q);
+            for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * ql);
         }
     }
     f32x4 acc = tl_zero();
@@ -4444,8 +4459,12 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
         f32x4 xb[2];
         if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
         else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
-        const float pi0 = a.pos[ic * 3 + 0] / a.scale_rel, pi1 = a.pos[ic * 3 + 1] / a.scale_rel, pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
-        const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
+        // ---- edges of node il (row layout)
+        const int il = tile * 16 + jl;
+        const bool okl = il < a.G;
+        const int icl = okl ? il : a.G - 1;
+        const float pi0 = a.pos[icl * 3 + 0] / a.scale_rel, pi1 = a.pos[icl * 3 + 1] / a.scale_rel, pi2 = a.pos[icl * 3 + 2] / a.scale_rel;
+        const int eb = a.rowptr[icl], ee = okl ? a.rowptr[icl + 1] : eb;
         f32x4 as[2] = {tl_zero(), tl_zero()};
         // edges in chunks of 4: ids, the gathered rows / positions in flight, then the arithmetic in edge order (no cross-lane
         // operation inside: the nodes of a wave may differ in trip count)
@@ -4457,8 +4476,8 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
             float q0[4], q1[4], q2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                pjv[k][0] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 4 * q);
-                pjv[k][1] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 16 + 4 * q);
+                pjv[k][0] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 4 * ql);
+                pjv[k][1] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 16 + 4 * ql);
                 q0[k] = a.pos[jn[k] * 3 + 0]; q1[k] = a.pos[jn[k] * 3 + 1]; q2[k] = a.pos[jn[k] * 3 + 2];
             }
 #pragma unroll
@@ -4475,7 +4494,11 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
             }
         }
         const float deg = (float)max(ee - eb, 1);
-        const f32x4 av[2] = {as[0] / deg, as[1] / deg};
+        *(f32x4*)(ts + jl * 36 + 4 * ql) = as[0] / deg;
+        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = as[1] / deg;
+        GSYNC();
+        const f32x4 av[2] = {*(const f32x4*)(ts + j * 36 + 4 * q), *(const f32x4*)(ts + j * 36 + 16 + 4 * q)};
+        GSYNC();
         f32x4 o[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -4595,8 +4618,15 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                 xin[t] = prelu4(y, fa);
             }
         } else {
-            const int wq = nc / a.Nw, nl = nc - wq * a.Nw;
-            const float* cvw = a.cv + wq * a.cv_ws + 4 * q;
+            // SpatialAttention in the ROW layout lane = 4 r + cq (query r = lane >> 2, chunk cq = lane & 3): four consecutive lanes
+            // read one 64-B head block of a gathered cv row (the MFMA layout reads 16-B chunks of four rows per quad: a quarter of
+            // the texture path's rate on the 6.4 KB a query gathers), the head sums are butterflies inside a quad; the aggregated
+            // vector crosses the wave's LDS scratch into the MFMA layout for proj.
+            const int jl = lane >> 2, ql = lane & 3;
+            const int n_l = tile * 16 + jl;
+            const int ncl = n_l < a.N ? n_l : a.N - 1;
+            const int wq = ncl / a.Nw, nl = ncl - wq * a.Nw;
+            const float* cvw = a.cv + wq * a.cv_ws + 4 * ql;
             const float xq0 = a.x_query[nl * 3 + 0], xq1 = a.x_query[nl * 3 + 1], xq2 = a.x_query[nl * 3 + 2];
             int jn[RO_K];
             float e[RO_K][3];
@@ -4611,7 +4641,7 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
             f32x4 xm = tl_zero();
 #pragma unroll
             for (int h = 0; h < 5; ++h) {
-                const float* eh = et + h * 16 + 4 * q;
+                const float* eh = et + h * 16 + 4 * ql;
                 const f32x4 bq = *(const f32x4*)(eh + 9 * 80);
                 f32x4 wq_[3], wc_[3], wv_[3];
 #pragma unroll
@@ -4634,8 +4664,8 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                 for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + 80 + h * 16);
 #pragma unroll
                 for (int k = 0; k < RO_K; ++k) {
-                    al[k] += __shfl_xor(al[k], 16);
-                    al[k] += __shfl_xor(al[k], 32);
+                    al[k] += __shfl_xor(al[k], 1);
+                    al[k] += __shfl_xor(al[k], 2);
                     al[k] = prelu1(al[k] * inv_sqrt_l, sa1);
                 }
                 float mx = al[0];                                                       // segment softmax over the K edges  :295
@@ -4656,6 +4686,11 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                 xm += gh;
             }
             xm *= 0.2f;                                                                 // mean over heads  :285
+            float* wsb = scr + wave * 16 * RO_SCS;
+            *(f32x4*)(wsb + jl * RO_SCS + 4 * ql) = xm;                                 // row layout -> MFMA layout
+            GSYNC();
+            xm = *(const f32x4*)(wsb + j * RO_SCS + 4 * q);
+            GSYNC();
 #pragma unroll
             for (int t = 0; t < 2; ++t)                                                 // PReLU2(proj(.))  :285
                 xin[t] = prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa);
