@@ -51,9 +51,9 @@ BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r02_h_pmc_stage_kernels.txt"
-TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.466e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
-                "k_stage2": (2.0 * 5.423e5 + 1.630e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
+TRAFFIC_SOURCE = "profiles/r02_j_pmc_stage_kernels.txt"
+TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.469e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
+                "k_stage2": (2.0 * 5.390e5 + 1.629e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
 ONE_GPU_CFG4 = {"ms_per_step": 37.80, "source": "profiles/r02_i_bench_cfg4_one_gpu.json (this code path with --gpus 1; the N = 1 line of this bench "
                                                  "measures it live as sharded_workload_on_one_gpu)"}
