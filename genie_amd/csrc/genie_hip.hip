@@ -2980,6 +2980,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
 __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
     constexpr int NF4 = (GB_GROUPS * 256 + GB_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
+    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 68];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + GB_GROUPS * 64);
@@ -2988,6 +2989,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the 23 gathered 128-B rows of a node are read in the row layout lane = 4 r + cq (four consecutive lanes: one 64-B half of a
+    // row); the four neighbour means then cross a per-wave LDS scratch into the MFMA layout (see k_stage2_ord, RL)
+    const int jl = lane >> 2, ql = lane & 3;
+    float* ts = tsc + wave * 16 * 68;
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
@@ -3005,9 +3010,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         const f32x4 x0 = *(const f32x4*)(a.tr + pi * 32 + 4 * q), x1 = *(const f32x4*)(a.tr + pi * 32 + 16 + 4 * q);
         // neighbour means of q1 (stations of the same source node) and q2 (same station, neighbouring source nodes), edge order
         f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
+        const int s_l = tb * 16 + jl, scl = s_l < S ? s_l : S - 1;        // the node whose rows this lane gathers
         {
-            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            const float* base = a.q1 + (long long)g * S * 32 + 4 * q;
+            const int eb = a.sta_rowptr[scl], ee = a.sta_rowptr[scl + 1];
+            const float* base = a.q1 + (long long)g * S * 32 + 4 * ql;
             for (int e = eb; __any(e < ee); e += 4) {
                 f32x4 ra[4], rb[4];
 #pragma unroll
@@ -3026,7 +3032,7 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         {
             const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
             const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.q2 + (long long)sc * 32 + 4 * q;
+            const float* base = a.q2 + (long long)scl * 32 + 4 * ql;
             int e = eb;
             for (; e + 4 <= ee; e += 4) {
                 f32x4 ra[4], rb[4];
@@ -3045,6 +3051,12 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }
+        *(f32x4*)(ts + jl * 68 + 4 * ql) = n1a; *(f32x4*)(ts + jl * 68 + 16 + 4 * ql) = n1b;
+        *(f32x4*)(ts + jl * 68 + 32 + 4 * ql) = n2a; *(f32x4*)(ts + jl * 68 + 48 + 4 * ql) = n2b;
+        GSYNC();
+        n1a = *(const f32x4*)(ts + j * 68 + 4 * q); n1b = *(const f32x4*)(ts + j * 68 + 16 + 4 * q);
+        n2a = *(const f32x4*)(ts + j * 68 + 32 + 4 * q); n2b = *(const f32x4*)(ts + j * 68 + 48 + 4 * q);
+        GSYNC();
         // layer 1
         f32x4 acc[4], w4[4];
 #pragma unroll
