@@ -253,3 +253,16 @@ def test_subset_oracle_matches_the_full_structured_oracle():
     b, x = oracle_bipartite_for_nodes(w, geom, P, sample)
     assert max_abs(b, bip[sample]) <= 1e-6 * max(1.0, float(bip.abs().max()))
     assert max_abs(x.view(4, S, -1), xl.view(G, S, -1)[sample]) <= 1e-6
+
+
+def test_subgraph_pairs_match_the_reference_builder_on_cpu():
+    """engine.subgraph_pairs_device (torch ops, any device): the product nodes of `use_subgraph` for the geometry of
+    tests/golden/subgraph_builder_14x50.npz equal the reference builder's A_src_in_sta (process_utils.py:775-794)."""
+    import numpy as np
+    import torch
+    from genie_amd import engine, synthetic
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subgraph_builder_14x50.npz"))
+    geom = synthetic.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    pairs = engine.subgraph_pairs_device(torch.from_numpy(geom.locs), torch.from_numpy(geom.x_grid), max_deg_offset=0.15,
+                                         k_nearest_pairs=6, scale_deg=110e3)
+    assert np.array_equal(pairs.numpy(), z["A_src_in_sta"])
