@@ -60,6 +60,10 @@
 #define GENIE_PHASES 0
 #endif
 
+#ifndef GENIE_S1_PK
+#define GENIE_S1_PK 0      // k_stage1_b3: packed fp32 adds in the neighbour accumulate (measured: see DESIGN.md section 5)
+#endif
+
 #ifndef GENIE_HOIST_WEIGHTS
 #define GENIE_HOIST_WEIGHTS 0
 #endif
@@ -1916,7 +1920,18 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
                     m01[2] = own3.z;    m23[2] = own3.w;
                 } else {
 #pragma unroll
+#if GENIE_S1_PK
+                    for (int r = 0; r < 16; r += 2) {      // experiment: packed adds, |z| = max(z, -z) as one packed op
+                        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                        const f32x2_ zz = {z[r], z[r + 1]};
+                        f32x2_ a_ = {sz[r], sz[r + 1]}, b_ = {sa[r], sa[r + 1]};
+                        a_ += zz;
+                        b_ += __builtin_elementwise_max(zz, -zz);
+                        sz[r] = a_.x; sz[r + 1] = a_.y; sa[r] = b_.x; sa[r + 1] = b_.y;
+                    }
+#else
                     for (int r = 0; r < 16; ++r) { sz[r] += z[r]; sa[r] += __builtin_fabsf(z[r]); }
+#endif
                 }
                 if (uu == KS || uu == NU - 1) {
                     const float al = uu == KS ? al1 : al2, be = uu == KS ? be1 : be2;
