@@ -92,6 +92,9 @@ def parse():
                          "pipeline through CU-masked streams; 0 = shared CUs (default)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded: sequential schedule (stage 1, exchange, stage 2, all-gather)")
     ap.add_argument("--cpu-windows", type=int, default=3, help="cpu_baseline: timed windows after one warm-up (median)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1 default run: skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the line "
+                         "then carries the constants of the committed profile)")
     ap.add_argument("--no-cfg4-one-gpu", action="store_true",
                     help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
                          "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
@@ -128,6 +131,55 @@ def physical_cores():
         return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
     except Exception:
         return int(os.cpu_count() or 1)
+
+
+def measure_traffic(timeout_s=150):
+    """HBM-side bytes per launch of the P-sized kernels, measured now: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE:
+    the two do not fit one pass) over tools/stage_profile.py (the same kernels on the same config-2 workload, 5 windows), averaged
+    per kernel; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at
+    64 B). Returns {"k_stage1": bytes, "k_stage2": bytes} or None when rocprofv3 is unavailable / fails (the line then carries the
+    constants of the committed profile, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) or k == "HSA_TOOLS_LIB" for k in os.environ):
+        return None          # this process is being profiled itself: no nested profiler
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="genie_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(REPO, "tools", "stage_profile.py"), "cfg2_200x10k", "5"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                disp = {}
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    key = (row["Kernel_Name"], row["Dispatch_Id"])
+                    disp[key] = disp.get(key, 0.0) + float(row["Counter_Value"])
+                for (kname, _), v in disp.items():
+                    for tag in ("k_split_rows", "k_stage1_b3", "k_stage2_ord"):
+                        if tag in kname:
+                            acc.setdefault(tag, []).append(v)
+            if not all(t in acc for t in ("k_split_rows", "k_stage1_b3", "k_stage2_ord")):
+                return None
+            per[counter] = {t: float(np.mean(v)) for t, v in acc.items()}
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    byts = lambda t: (2.0 * per["FETCH_SIZE"][t] + per["WRITE_SIZE"][t]) * 1024.0
+    return {"k_stage1": byts("k_split_rows") + byts("k_stage1_b3"), "k_stage2": byts("k_stage2_ord")}
 
 
 def cpu_baseline(net, geom, win, n_timed=3):
@@ -573,6 +625,15 @@ def main():
         "tail_cus_per_xcd": 0 if a.no_pipeline else a.tail_cus,
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_live_traffic:
+        tr = measure_traffic()
+        if tr is not None:
+            roofline["traffic"] = tr["k_stage1"] + tr["k_stage2"]
+            roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/stage_profile.py "
+                                          "(same kernels, same workload), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch of the P-sized kernels; "
+                                          "committed profile of the same passes: %s" % TRAFFIC_SOURCE)
+            for k in ("k_stage1", "k_stage2"):
+                kern[k]["traffic"] = tr[k]
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_cfg4_one_gpu \
             and torch.cuda.get_device_properties(dev).total_memory > 160e9:
         # The N > 1 lines of this bench run ANOTHER workload (config 4: 2000 stations / 50 000 grid nodes / 500 000 picks, ONE
