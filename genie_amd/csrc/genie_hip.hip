@@ -1635,8 +1635,9 @@ __device__ __forceinline__ void load_sta_ids(const int32_t* __restrict__ sta_col
 // rate and does NOT overlap with VALU work (time = 32 cyc x MFMAs + ~3.3 cyc x VALU ops), so the fp32-MFMA kernel
 // above is bound by the sum of both. The bf16 matrix pipe is 16x faster. Every fp32 value is split EXACTLY into three
 // bf16 pieces by truncation (8 + 8 + 8 mantissa bits: x = x1 + x2 + x3) and a product keeps the six partial products
-// above 2^-24: W1x1 + W1x2 + W2x1 + W1x3 + W2x2 + W3x1, accumulated in fp32 by the MFMA. Error is that of an fp32 dot
-// product (oracle/genie_oracle.py parity stays ~1e-7; tests/test_hip_parity.py).
+// above 2^-24: W1x1 + W1x2 + W2x1 + W1x3 + W2x2 + W3x1, accumulated in fp32 by the MFMA. The dropped terms (W2x3, W3x2,
+// W3x3) are about one fp32 ulp of a product: fp32-class results (an fp32 dot product in another summation order plus that
+// ulp), not bit-for-bit fp32 (oracle/genie_oracle.py parity stays ~1e-7; tests/test_hip_parity.py).
 //
 //  * v_mfma_f32_32x32x16_bf16: D[ch, node] for 32 channels x 32 nodes. A wave owns TWO 16-station tiles (lanes
 //    0-15/32-47 and 16-31/48-63). Lane (j = lane&31, h = lane>>5) holds D channels 8*(r>>2) + 4h + (r&3), r = 0..15,

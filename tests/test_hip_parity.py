@@ -1355,3 +1355,30 @@ def test_arrivals_head_hip_matches_module(S, n_src, n_picks):
     assert max_abs(got.cpu(), ref.cpu()) <= 5e-6 * max(1.0, float(ref.abs().max()))
     # no source inside 2 eps of the origin time: the kernel's precondition fails and the caller keeps the PyTorch path
     assert net._hip.arrivals_fwd(t(np.full(n_src, 3.0 * eps, np.float32)), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase, eps) is None
+
+
+def test_bench_line_contract_on_the_gpu():
+    """`python bench.py` (short run, the optional extras off): ONE JSON line with the fields the driver reads, the headline
+    workload named, a roofline object priced on algorithmic bytes against the HBM peak and per-kernel HIP-event times."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "16", "--warmup", "8", "--settle", "16", "--no-cpu-baseline",
+                        "--no-cfg4-one-gpu", "--no-live-traffic"], cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 8 and d["unit"] == "picks/s" and d["dtype"] == "f32"
+    assert d["config"]["workload"].startswith("cfg2_200x10k") and d["config"]["n_picks"] == 50000
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(d["value"] - 50000.0 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
+    assert abs(rf["achieved"] - 3.07216 / d["ms_per_step"] * 1e3) <= 2e-3 * rf["achieved"]          # B_alg = 3.072 GB per window
+    assert 0.1 < d["ms_per_step"] < 5.0 and set(rf["kernels"]) == {"k_stage1", "k_stage2"}
