@@ -80,7 +80,7 @@ def parse():
                     help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 8 (with the "
                          "fp32-MFMA tail kernels the batched tail is the faster form for resident windows too: 0.811 -> 0.776 ms per "
                          "window on the same box, DESIGN.md section 5)")
-    ap.add_argument("--mode", default=None, choices=["replicas", "sharded", "stream"],
+    ap.add_argument("--mode", default=None, choices=["replicas", "sharded", "stream", "train"],
                     help="default: the cfg2 window pipeline at N = 1; at N > 1 ONE cfg4 window sharded over source nodes with an "
                          "RCCL halo all-to-all + all-gather per window (strong scaling). replicas = window-parallel copies of "
                          "cfg2 (weak scaling, no collective); stream = config 5")
@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1 default run: skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the line "
                          "then carries the constants of the committed profile)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the live config-3 training-step figure of the default line")
     ap.add_argument("--no-cfg4-one-gpu", action="store_true",
                     help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
                          "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
@@ -433,6 +434,178 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     return out
 
 
+TRAIN_FLOP_FACTOR = 3.0     # a training step = forward + two backward products per Linear = 3 x the forward FLOPs
+
+
+def cpu_train_baseline(geom, win, lbl, lbl_q, frac=10):
+    """Oracle training step (reference formulation with explicit product edge lists, autograd, Adam) timed on this box's host
+    cores on a BOUNDED sample: the first G / frac source nodes of the same window with their own kNN graph, 1 warm-up + 1 timed
+    step, scaled linearly in the number of product nodes."""
+    from oracle import genie_oracle as O
+    S, G = geom.n_sta, geom.n_grid
+    Gs = max(64, G // frac)
+    nq = max(10, geom.x_query.shape[0] // frac)
+    torch.manual_seed(0)
+    ref = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
+    w = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in ref.state_dict().items()}
+    opt = torch.optim.Adam([v for v in w.values() if v.requires_grad], lr=1e-3)
+    A_sub = graph.knn_graph(geom.x_grid[:Gs] / 1000.0, min(synthetic.K_SPC, Gs - 1))
+    B_in_sta, B_in_src, B_src_in_prod, _ = graph.cartesian_product_edges(geom.A_sta_sta, A_sub, S, Gs)
+    sub = (torch.from_numpy(win["Slice"][: Gs * S]), torch.from_numpy(win["Mask"][: Gs * S]), B_in_sta, B_in_src,
+           torch.from_numpy(geom.edge_attr(slice(0, Gs))), B_src_in_prod, torch.from_numpy(A_sub),
+           torch.from_numpy(geom.x_grid[:Gs]).float(), torch.from_numpy(geom.x_query[:nq]).float(), torch.from_numpy(geom.t_query).float())
+    mse = torch.nn.functional.mse_loss
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        y, x = O.forward_fixed_source(w, *sub)
+        loss = 0.1 * mse(y[:, :, 0], lbl[:Gs].cpu()) + 0.4 * mse(x[:, :, 0], lbl_q[:nq].cpu())
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    return times[-1] * (G / float(Gs)), Gs, times[-1]
+
+
+def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
+    """BASELINE config 3: the training step on the config-2 shape. One step = forward_fixed_source in train() mode (the whole
+    path in HIP in both directions, module._PathTrain) + the y / x terms of the reference's weighted MSE (train_GENIE_model.py:1789)
+    + backward + one Adam(1e-3) step (:1861), on a synthetic window resident in HBM. N > 1: independent replicas (the reference has
+    no multi-GPU training). The reference's own 4-output step `mz(*input_tensors)` (association heads included, their backward
+    still under PyTorch-ROCm autograd) is timed next to it."""
+    S, G = geom.n_sta, geom.n_grid
+    P = S * G
+    torch.manual_seed(0)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev)
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).float().to(dev)
+    locs, xg, xq, tq = t(geom.locs), t(geom.x_grid), t(geom.x_query), t(geom.t_query)
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), t(geom.edge_attr()), locs, xg)
+    wins = [synthetic.make_window(geom, n_picks, seed=2, window=rank * 1000 + i) for i in range(max(1, min(a.windows, 2)))]
+    dS, dM = [t(w["Slice"]) for w in wins], [t(w["Mask"]) for w in wins]
+    rng = np.random.default_rng(7)
+    lbl = t(rng.random((G, 9)) * (rng.random((G, 1)) < 0.1))
+    lbl_q = t(rng.random((nq, 9)) * (rng.random((nq, 1)) < 0.1))
+    mse = torch.nn.functional.mse_loss
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+
+    def step(i):
+        k = i % len(dS)
+        opt.zero_grad(set_to_none=True)
+        y, x = net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
+        loss = 0.1 * mse(y[:, :, 0], lbl) + 0.4 * mse(x[:, :, 0], lbl_q)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    losses.clear()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / a.steps * 1e3
+    loss_vals = [float(v) for v in losses]
+    # ---- phases with HIP events on the launch stream (the same entry points, called directly)
+    hp = net._hip
+    knn = net.SpatialAttention.query_table(xq, xg, 10)
+    ph = {k: [] for k in ("fwd_front", "fwd_total", "bwd_tail", "bwd_front")}
+    for i in range(min(a.steps, 10)):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e[0].record()
+        r_, xl_, save = hp.train_fwd(dS[0], dM[0], net._edge_attr, want_x_latent=False)
+        e[1].record()
+        del r_, xl_, save
+        e[2].record()
+        y, x, xs, _, _, save, tsave = hp.path_train_fwd(dS[0], dM[0], net._edge_attr, xg, xq, knn, tq)
+        e[3].record()
+        d_r, blob = hp.tail_train_bwd(xg, xq, knn, tq, tsave, y[:, :, 0].contiguous(), x[:, :, 0].contiguous())
+        e[4].record()
+        hp.train_bwd(dS[0], dM[0], net._edge_attr, save, d_r[:, :30])
+        e[5].record()
+        torch.cuda.synchronize()
+        ph["fwd_front"].append(e[0].elapsed_time(e[1])); ph["fwd_total"].append(e[2].elapsed_time(e[3]))
+        ph["bwd_tail"].append(e[3].elapsed_time(e[4])); ph["bwd_front"].append(e[4].elapsed_time(e[5]))
+        del y, x, xs, save, tsave, d_r, blob
+    pms = {k: round(float(np.median(v)), 4) for k, v in ph.items()}
+    pms["fwd_tail"] = round(pms["fwd_total"] - pms["fwd_front"], 4)
+    pms["adam_loss_and_host"] = round(ms - pms["fwd_total"] - pms["bwd_tail"] - pms["bwd_front"], 4)
+    # ---- the reference's 4-output step (association heads' backward under autograd), a few steps
+    four = None
+    try:
+        smp = synthetic.training_sample(geom, min(n_picks, 4000), n_src=4, seed=3, window=0)
+        net._sta_tab = graph.neighbour_table(geom.A_sta_sta, S).long().to(dev)
+        net._src_tab = graph.neighbour_table(geom.A_src_src, G).long().to(dev)
+        net.A_edges_p, net.A_edges_s = t(smp["A_edges_p"]).long(), t(smp["A_edges_s"]).long()
+        net.dt_partition, net.tlatent = t(smp["dt_partition"]), t(smp["tlatent"])
+        from genie_amd import train as gtrain
+        args4 = (t(smp["Slice"]), t(smp["Mask"]), t(smp["tpick"]), t(smp["ipick"]).long(), t(smp["phase_label"]), locs, xg, xq,
+                 t(smp["x_query_src"]), tq, t(smp["tq_sample"]), t(smp["trv_out_q"]))
+        lab4 = (t(smp["Lbls"]), t(smp["Lbls_query"]), t(smp["pick_lbls"]))
+
+        def step4():
+            opt.zero_grad(set_to_none=True)
+            loss = gtrain.reference_loss(net.forward_fixed(*args4), lab4, 1)
+            loss.backward()
+            opt.step()
+        for _ in range(2):
+            step4()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step4()
+        torch.cuda.synchronize()
+        four = {"ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 3), "n_picks": int(len(smp["tpick"])), "n_src": 4,
+                "note": "mz(*input_tensors) + 4-term loss + backward + Adam; shared path in HIP in both directions, association heads' "
+                        "forward / backward under PyTorch-ROCm autograd"}
+    except Exception as e:
+        four = {"error": repr(e)[:200]}
+    flops = TRAIN_FLOP_FACTOR * (FLOP_NODE * P)
+    tf = flops / (ms * 1e-3) / 1e12 * 1.0
+    out = {
+        "metric": "picks/sec through the training step of GCN_Detection_Network_extended (forward + loss + backward + Adam)",
+        "value": round(world * n_picks / (ms * 1e-3), 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config 3 = %s training step: %d stations / %d grid nodes / %d picks per window, forward_fixed_source in "
+                               "train() mode (whole path in HIP in both directions) + 0.1 MSE(y) + 0.4 MSE(x) + backward + Adam(1e-3), "
+                               "graphs preset, window resident in HBM" % (a.config, S, G, n_picks),
+                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
+                   "parallelism": "independent replicas x%d" % world if world > 1 else "single GPU"},
+        "steps_per_s": round(world * 1e3 / ms, 2), "loss_first_last": [loss_vals[0], loss_vals[-1]],
+        "roofline": {"bound": "mfma", "kernel": "training step (3 x the path's forward FLOPs, SURVEY.md 8d; fp32 MFMA kernels)",
+                     "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+                     "traffic": None, "alg_flops_per_step": flops, "phase_ms": pms,
+                     "hbm_view": {"alg_bytes_per_step": 3.0 * (1532.0 * P + 816.0 * G),
+                                  "frac_of_hbm_peak": round(3.0 * (1532.0 * P + 816.0 * G) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+        "four_output_step": four,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and emit:
+        c_full, gs, c_s = cpu_train_baseline(geom, wins[0], lbl, lbl_q)
+        out["cpu_baseline"] = {"value": round(n_picks / c_full, 1), "unit": "picks/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                               "physical_cores": physical_cores(),
+                               "sample": "oracle training step (reference formulation, autograd, Adam) on the first %d of %d source nodes of the "
+                                         "same window with their own kNN graph, 1 warm-up + 1 timed step (%.1f s), scaled x%.1f (linear in "
+                                         "product nodes): %.1f s per full step" % (gs, G, c_s, G / float(gs), c_full)}
+    if rank == 0 and emit:
+        print(json.dumps(out))
+    if dist is not None and emit:
+        dist.destroy_process_group()
+    return out
+
+
 def main_dry_run_cpu(a, rank, world):
     """Launcher / plan / collective check without a GPU (tests/test_bench_cpu.py): every rank builds its ShardPlan, sends the
     row blocks its peers list and all-gathers a per-node tensor, over gloo on CPU tensors; values encode (node, station)."""
@@ -493,6 +666,10 @@ def main():
         return main_sharded(a, geom, n_picks, nq, rank, world, dev, dist)
     if a.mode == "stream":
         return main_stream(a, geom, nq, rank, world, dev, dist)
+    if a.mode == "train":
+        if a.steps == 300 and a.warmup == 30:       # the window defaults are too many for a training step
+            a.steps, a.warmup = 50, 5
+        return main_train(a, geom, n_picks, nq, rank, world, dev, dist)
     net = build_model(geom, dev)
     # synthetic pick windows of the fixed shape, resident in HBM (each rank its own windows)
     wins = [synthetic.make_window(geom, n_picks, seed=2, window=rank * 1000 + i) for i in range(a.windows)]
@@ -650,6 +827,19 @@ def main():
                                                   "roofline_frac": o4["roofline"]["frac"]}
         except Exception as e:       # (the headline line must not depend on it)
             out["sharded_workload_on_one_gpu"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_train_step:
+        # BASELINE config 3 (the training step on this same shape), measured live through `--mode train`'s code path
+        import copy
+        a3 = copy.copy(a)
+        a3.steps, a3.warmup, a3.no_cpu_baseline = 10, 3, True
+        try:
+            o3 = main_train(a3, geom, n_picks, nq, 0, 1, dev, None, emit=False)
+            out["training_step_config3"] = {"config": o3["config"]["workload"], "steps": a3.steps, "ms_per_step": o3["ms_per_step"],
+                                            "value": o3["value"], "unit": "picks/s", "roofline_frac_fp32_mfma": o3["roofline"]["frac"],
+                                            "phase_ms": o3["roofline"]["phase_ms"], "four_output_step": o3["four_output_step"]}
+        except Exception as e:
+            out["training_step_config3"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         yc, xc, cdt, ctimes, c1, gs = cpu_baseline(net, geom, wins[0], a.cpu_windows)

@@ -71,6 +71,13 @@ SYMBOLS = [
     ("genie_train_scratch_floats", _c.c_size_t, [_P]),
     ("genie_da_train_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_da_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_tail_train_save_floats", _c.c_size_t, [_P]),
+    ("genie_tail_train_scratch_floats", _c.c_size_t, [_P, _c.c_int]),
+    ("genie_train_grad_floats", _c.c_size_t, []),
+    ("genie_tail_train_fwd", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P]),
+    ("genie_tail_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P]),
     ("genie_assoc_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_assoc_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),

@@ -630,7 +630,11 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
 // Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack image in LDS (one ds_read_b128 per 16 x 16
 // weight block and wave instead of two LDS reads per scalar FMA) and whose result is the B operand of the next Linear.
 // Plans (genie_ctx::plan[PL_*]) and their group index maps:
-enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, PL_ARR, NPLAN };
+enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, PL_ARR,
+       // transposed weights of the tail's backward passes (train_tail_kernels.hpp)
+       PL_TRO0, PL_TRO1, PL_TSN, PL_TSA1, PL_TSA2, PL_TSA3, PL_TBIP, NPLAN };
+// gradient maps (k_train_reduce): the three P-sized passes, then the tail's backward kernels
+enum { TM_B2 = 0, TM_B1, TM_B0, TM_RO0, TM_RO1, TM_SN, TM_SAA1, TM_SAA2, TM_SAA3, TM_SAB1, TM_SAB2, TM_SAB3, TM_BIP, NTM };
 //  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
 //  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
 //  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
@@ -3159,8 +3163,8 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int GR_DO = 0, GR_DT = 2, GR_DH0 = 6, GR_BLOCKS = 8;      // gradient rows kept between the passes: [GR_*][P][16]
 
-struct AccDesc { int32_t mat_off, ld, row0, nrows, col0, ncols; };   // dW block: D[i][n] -> W[row0 + i][col0 + n]
-struct VecDesc { int32_t off, row0, nrows, pad; };                   // bias block: sum dY[i] -> b[row0 + i]
+struct AccDesc { int32_t mat_off, ld, row0, nrows, col0, ncols, n0, pad; };   // dW block: D[i][n] -> W[row0 + i][col0 + n], n0 <= n < ncols
+struct VecDesc { int32_t off, row0, nrows, stride; };                // bias block: sum dY[i] -> b[(row0 + i) * stride]
 
 struct TrArgs {
     int S, G, T, seg, nxcd;
@@ -3516,7 +3520,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
 // owns 32 entries; its 8 groups of 32 threads sum the waves w = group, group + 8, ... and the 8 sums are added in group order
 __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ part, int n_waves, int n_acc, int n_vec, int n_scal,
                                                       const AccDesc* __restrict__ ad, const VecDesc* __restrict__ vd,
-                                                      const int32_t* __restrict__ sd, float* __restrict__ blob) {
+                                                      const int32_t* __restrict__ sd, float* __restrict__ blob, int accumulate) {
     __shared__ float ps[8][32];
     const int stride = n_acc * 256 + n_vec * 16 + 16;
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -3532,11 +3536,11 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
         const int k = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
         const int i = 4 * (lane >> 4) + r, n = lane & 15;
         const AccDesc d = ad[k];
-        if (i < d.nrows && n < d.ncols) dst = d.mat_off + (d.row0 + i) * d.ld + d.col0 + n;
+        if (i < d.nrows && n < d.ncols && n >= d.n0) dst = d.mat_off + (d.row0 + i) * d.ld + d.col0 + n;
     } else if (idx < n_acc * 256 + n_vec * 16) {
         const int k = (idx - n_acc * 256) >> 4, i = (idx - n_acc * 256) & 15;
         const VecDesc d = vd[k];
-        if (i < d.nrows) dst = d.off + d.row0 + i;
+        if (i < d.nrows) dst = d.off + (d.row0 + i) * d.stride;
     } else {
         const int k = idx - n_acc * 256 - n_vec * 16;
         if (k < n_scal) dst = sd[k];
@@ -3545,7 +3549,7 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += ps[k][o];
-    blob[dst] = t;
+    blob[dst] = accumulate ? blob[dst] + t : t;      // accumulate: parameters that several passes contribute to (each pass in stream order)
 }
 
 __global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles
@@ -4028,6 +4032,8 @@ struct RoArgs {
     const float* raw;
     float scale_rel, scale_t;
     float* out;                  // [N,T]
+    float* lat_out;              // optional [N,30]: the head's latent input of TemporalAttention (MODE 0: SpatialDirect(x_spatial) = y_latent,
+                                 // MODE 1: SpatialAttention(x_spatial, x_query)); k_readout_m only
     int o_sd_w, o_sd_b, o_sd_a;
     int o_q1w, o_q1b, o_q2w, o_q2b, o_c1w, o_c1b, o_c2w, o_c2b, o_v1w, o_v1b, o_v2w, o_v2b, o_p1w, o_p1b, o_p2w, o_p2b;
     int o_a1, o_a2, o_a3, o_a4, o_a5;
@@ -4722,6 +4728,10 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)                                                 // PReLU2(proj(.))  :285
                 xin[t] = prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa);
+        }
+        if (a.lat_out != nullptr && ok) {
+            tl_store30(a.lat_out + (long long)n * 30, 0, q, xin[0]);
+            tl_store30(a.lat_out + (long long)n * 30, 1, q, xin[1]);
         }
         // ------------------------------------------------------------------ TemporalAttention on xin  :325-331
         f32x4 h1[2], h2[2];
@@ -5561,6 +5571,8 @@ __global__ void k_permute_sta_rows(const float* __restrict__ src, long long rows
     dst[(g * S + map[(int)(r - g * S)]) * width + cc] = src[idx];
 }
 
+#include "train_tail_kernels.hpp"
+
 }  // namespace
 
 // ================================================================================================
@@ -5580,8 +5592,8 @@ struct genie_ctx {
     int32_t* d_scal[NPLAN];
     float* packed[NPLAN];
     int tail_mfma;             // G- / Q-sized tail on the fp32-MFMA tile kernels (default) or the scalar 32-lanes-per-node ones (A/B)
-    AccDesc* d_acc[3]; VecDesc* d_vec[3]; int32_t* d_sc[3];   // gradient maps of the backward passes (k_train_reduce)
-    int n_acc[3], n_vec[3], n_sc[3];
+    AccDesc* d_acc[NTM]; VecDesc* d_vec[NTM]; int32_t* d_sc[NTM];   // gradient maps of the backward passes (k_train_reduce)
+    int n_acc[NTM], n_vec[NTM], n_sc[NTM];
     int* dyn_ctr;              // dynamic work distribution: [kind 2][slot % GENIE_NBIG][parity 2][8] per-XCD item counters
     int dyn_parity[2][4];      // which set the next launch of (kind, slot) uses
     int dyn_on, dyn_b1, dyn_b2;
@@ -5756,11 +5768,11 @@ int build_grad_maps(genie_ctx* c) {
     std::vector<VecDesc> vec[3];
     std::vector<int32_t> sc[3];
     auto A = [&](int s, int mat, int ld, int row0, int nrows, int col0, int ncols) {
-        AccDesc d; d.mat_off = g_params[mat].off; d.ld = ld; d.row0 = row0; d.nrows = nrows; d.col0 = col0; d.ncols = ncols;
+        AccDesc d; d.mat_off = g_params[mat].off; d.ld = ld; d.row0 = row0; d.nrows = nrows; d.col0 = col0; d.ncols = ncols; d.n0 = 0; d.pad = 0;
         acc[s].push_back(d);
     };
     auto V = [&](int s, int vecid, int row0, int nrows) {
-        VecDesc d; d.off = g_params[vecid].off; d.row0 = row0; d.nrows = nrows; d.pad = 0;
+        VecDesc d; d.off = g_params[vecid].off; d.row0 = row0; d.nrows = nrows; d.stride = 1;
         vec[s].push_back(d);
     };
     auto rows2 = [](int b) { return b ? 14 : 16; };
@@ -5815,6 +5827,161 @@ int build_grad_maps(genie_ctx* c) {
         HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * sc[s].size()));
         HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
+    }
+    return GENIE_OK;
+}
+
+
+// Transposed-weight plans of the tail's backward kernels (group maps GTR_* / GTN / GTS_* / GTB of train_tail_kernels.hpp)
+void build_tail_train_plans(StagePlan* plan) {
+    auto rows2 = [](int t) { return t ? 14 : 16; };
+    for (int mode = 0; mode < 2; ++mode) {
+        StagePlan& p = plan[mode == 0 ? PL_TRO0 : PL_TRO1];
+        for (int k = 0; k < 2; ++k) add_block_group_T(p, W_TA_P1_W, 15, 0, 15, 16 * k, rows2(k));
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h)
+                for (int b = 0; b < 2; ++b) add_block_group_T(p, m == 0 ? W_TA_V2_W : W_TA_C2_W, 30, 16 * b, rows2(b), 15 * h, 15);
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < 2; ++b)
+                for (int k = 0; k < 2; ++k) add_block_group_T(p, m == 0 ? W_TA_V1_W : W_TA_C1_W, 30, 16 * b, rows2(b), 16 * k, rows2(k));
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 2; ++k) {
+                if (mode == 0) add_block_group_T(p, W_SD_W, 30, 16 * b, rows2(b), 16 * k, rows2(k));
+                else if (b == 0) add_block_group_T(p, W_SAT_P_W, 15, 0, 15, 16 * k, rows2(k));
+                else add_unused_group(p);
+            }
+        p.scal.push_back(g_params[W_TA_ACT1].off);          // unused (a plan carries at least one scalar)
+    }
+    {
+        StagePlan& p = plan[PL_TSN];
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h)
+                for (int b = 0; b < 2; ++b) add_block_group_T(p, m == 0 ? W_SAT_C_W : W_SAT_V_W, 33, 16 * b, rows2(b), 15 * h, 15);
+        p.scal.push_back(g_params[W_SAT_ACT1].off);
+    }
+    for (int layer = 1; layer <= 3; ++layer) {
+        StagePlan& p = plan[PL_TSA1 + layer - 1];
+        const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
+        const int C = layer == 1 ? 15 : 30;
+        auto xrows = [&](int b) { return C == 15 ? 15 : rows2(b); };
+        for (int b = 0; b < 2; ++b)                       // fc2^T, x_i part
+            for (int t = 0; t < 2; ++t) {
+                if (C == 30 || b == 0) add_block_group_T(p, base + 2, C + 30, 16 * b, xrows(b), 16 * t, rows2(t));
+                else add_unused_group(p);
+            }
+        for (int b = 0; b < 2; ++b)                       // fc2^T, edge-mean part
+            for (int t = 0; t < 2; ++t) add_block_group_T(p, base + 2, C + 30, C + 16 * b, rows2(b), 16 * t, rows2(t));
+        for (int b = 0; b < 2; ++b)                       // fc1[:, 0:C]^T
+            for (int t = 0; t < 2; ++t) {
+                if (C == 30 || b == 0) add_block_group_T(p, base, C + 8, 16 * b, xrows(b), 16 * t, rows2(t));
+                else add_unused_group(p);
+            }
+        for (int b = 0; b < 2; ++b) {                     // fglobal^T
+            if (C == 30 || b == 0) add_block_group_T(p, base + 4, C, 16 * b, xrows(b), 0, 5);
+            else add_unused_group(p);
+        }
+        p.scal.push_back(g_params[base + 6].off);
+    }
+    {
+        StagePlan& p = plan[PL_TBIP];
+        for (int b = 0; b < 2; ++b) add_block_group_T(p, W_BP_FC2_W, 30, 16 * b, rows2(b), 0, 15);
+        p.scal.push_back(g_params[W_BP_ACT2].off);
+    }
+}
+
+// gradient maps of the tail's backward kernels (accumulator / vector / scalar k of kernel TM_* -> entries of the gradient blob;
+// the d(temporal query) blocks land behind the blob, at g_raw_total)
+int build_tail_grad_maps(genie_ctx* c) {
+    std::vector<AccDesc> acc[NTM];
+    std::vector<VecDesc> vec[NTM];
+    std::vector<int32_t> sc[NTM];
+    auto A = [&](int s, int mat_off, int ld, int row0, int nrows, int col0, int ncols, int n0 = 0) {
+        AccDesc d; d.mat_off = mat_off; d.ld = ld; d.row0 = row0; d.nrows = nrows; d.col0 = col0; d.ncols = ncols; d.n0 = n0; d.pad = 0;
+        acc[s].push_back(d);
+    };
+    auto V = [&](int s, int off, int row0, int nrows, int stride = 1) {
+        VecDesc d; d.off = off; d.row0 = row0; d.nrows = nrows; d.stride = stride;
+        vec[s].push_back(d);
+    };
+    auto O = [](int w) { return g_params[w].off; };
+    auto rows2 = [](int b) { return b ? 14 : 16; };
+    for (int mode = 0; mode < 2; ++mode) {
+        const int s = mode == 0 ? TM_RO0 : TM_RO1;
+        for (int t = 0; t < 2; ++t) A(s, O(W_TA_P1_W), 15, 16 * t, rows2(t), 0, 15);
+        for (int m = 0; m < 2; ++m)
+            for (int t = 0; t < 2; ++t)
+                for (int k = 0; k < 2; ++k) A(s, O(m == 0 ? W_TA_C1_W : W_TA_V1_W), 30, 16 * t, rows2(t), 16 * k, rows2(k));
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 5; ++h)
+                for (int k = 0; k < 2; ++k) A(s, O(m == 0 ? W_TA_C2_W : W_TA_V2_W), 30, 15 * h, 15, 16 * k, rows2(k));
+        for (int h = 0; h < 5; ++h) A(s, g_raw_total, 75, 0, TQ_ROWS, 15 * h, 15);
+        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < 2; ++k) {
+                if (mode == 0) A(s, O(W_SD_W), 30, 16 * t, rows2(t), 16 * k, rows2(k));
+                else A(s, O(W_SAT_P_W), 15, 16 * t, k == 0 ? rows2(t) : 0, 0, 15);
+            }
+        if (mode == 1) {
+            for (int m = 0; m < 3; ++m)
+                for (int h = 0; h < 5; ++h) {
+                    if (m == 0) A(s, O(W_SAT_Q_W), 3, 15 * h, 15, 0, 3);
+                    else A(s, O(m == 1 ? W_SAT_C_W : W_SAT_V_W), 33, 15 * h, 15, 30, 3);
+                }
+            for (int h = 0; h < 5; ++h) A(s, O(W_SAT_Q_B) - 3, 1, 15 * h, 15, 0, 4, 3);      // column 3 of the f_queries blocks = bias gradient
+        }
+        for (int t = 0; t < 2; ++t) V(s, O(W_TA_P1_B), 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) V(s, O(W_TA_P2_W), 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) V(s, O(W_TA_C1_B), 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) V(s, O(W_TA_V1_B), 16 * t, rows2(t));
+        for (int h = 0; h < 5; ++h) V(s, O(W_TA_C2_B), 15 * h, 15);
+        for (int h = 0; h < 5; ++h) V(s, O(W_TA_V2_B), 15 * h, 15);
+        for (int t = 0; t < 2; ++t) V(s, O(mode == 0 ? W_SD_B : W_SAT_P_B), 16 * t, rows2(t));
+        sc[s] = {O(mode == 0 ? W_SD_ACT : W_SAT_ACT2), O(W_TA_ACT1), O(W_TA_ACT2), O(W_TA_ACT4), O(W_TA_ACT5), O(W_TA_P2_B)};
+        if (mode == 1) sc[s].push_back(O(W_SAT_ACT1));
+    }
+    for (int m = 0; m < 2; ++m)
+        for (int h = 0; h < 5; ++h)
+            for (int k = 0; k < 2; ++k) A(TM_SN, O(m == 0 ? W_SAT_C_W : W_SAT_V_W), 33, 15 * h, 15, 16 * k, rows2(k));
+    for (int m = 0; m < 2; ++m)
+        for (int h = 0; h < 5; ++h) V(TM_SN, O(m == 0 ? W_SAT_C_B : W_SAT_V_B), 15 * h, 15);
+    for (int layer = 1; layer <= 3; ++layer) {
+        const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
+        const int C = layer == 1 ? 15 : 30;
+        const int sa = TM_SAA1 + layer - 1, sb = TM_SAB1 + layer - 1;
+        for (int t = 0; t < 2; ++t) {
+            A(sa, O(base + 2), C + 30, 16 * t, rows2(t), 0, C == 15 ? 15 : 16);
+            A(sa, O(base + 2), C + 30, 16 * t, C == 15 ? 0 : rows2(t), 16, 14);
+            A(sa, O(base + 2), C + 30, 16 * t, rows2(t), C, 16);
+            A(sa, O(base + 2), C + 30, 16 * t, rows2(t), C + 16, 14);
+        }
+        for (int t = 0; t < 2; ++t) V(sa, O(base + 3), 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) V(sa, O(base + 1), 16 * t, rows2(t));                     // d base = gradient of fc1's bias
+        for (int d = 0; d < 3; ++d)
+            for (int t = 0; t < 2; ++t) V(sa, O(base) + C + d, 16 * t, rows2(t), C + 8);      // fc1's position columns
+        sc[sa] = {O(base + 7), O(base + 6)};
+        for (int t = 0; t < 2; ++t) {
+            A(sb, O(base), C + 8, 16 * t, rows2(t), 0, C == 15 ? 15 : 16);
+            A(sb, O(base), C + 8, 16 * t, C == 15 ? 0 : rows2(t), 16, 14);
+        }
+        A(sb, O(base + 4), C, 0, 5, 0, C == 15 ? 15 : 16);
+        A(sb, O(base + 4), C, 0, C == 15 ? 0 : 5, 16, 14);
+        V(sb, O(base + 5), 0, 5);
+        sc[sb] = {O(base + 8)};
+    }
+    for (int k = 0; k < 2; ++k) A(TM_BIP, O(W_BP_FC2_W), 30, 0, 15, 16 * k, rows2(k));
+    V(TM_BIP, O(W_BP_FC2_B), 0, 15);
+    sc[TM_BIP] = {O(W_BP_ACT2)};
+    const int want_acc[NTM] = {0, 0, 0, RB_NACC0, RB_NACC1, GTN_GROUPS, SBA_NACC, SBA_NACC, SBA_NACC, SBB_NACC, SBB_NACC, SBB_NACC, 2};
+    const int want_vec[NTM] = {0, 0, 0, RB_NVEC, RB_NVEC, 10, SBA_NVEC, SBA_NVEC, SBA_NVEC, SBB_NVEC, SBB_NVEC, SBB_NVEC, 1};
+    for (int s = TM_RO0; s < NTM; ++s) {
+        if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s] || sc[s].size() > 16)
+            return fail(GENIE_ERR_STATE, "internal: tail gradient maps do not match the backward kernels");
+        c->n_acc[s] = (int)acc[s].size(); c->n_vec[s] = (int)vec[s].size(); c->n_sc[s] = (int)sc[s].size();
+        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * acc[s].size()));
+        HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * vec[s].size()));
+        HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * std::max<size_t>(1, sc[s].size())));
+        if (!sc[s].empty()) HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
     }
     return GENIE_OK;
 }
@@ -5915,6 +6082,10 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     build_assoc_plans(c->plan[2], c->plan[3]);
     build_train_plans(c->plan[4], c->plan[5], c->plan[6]);
     build_tail_plans(c->plan);
+    build_tail_train_plans(c->plan);
+    if (c->plan[PL_TRO0].n_groups() != GTR_GROUPS || c->plan[PL_TRO1].n_groups() != GTR_GROUPS || c->plan[PL_TSN].n_groups() != GTN_GROUPS ||
+        c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS)
+        return fail(GENIE_ERR_STATE, "internal: transposed tail plan does not match kernel group maps");
     if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
         (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
         c->plan[PL_SA1].n_groups() != GS_GROUPS || c->plan[PL_SA2].n_groups() != GS_GROUPS || c->plan[PL_SA3].n_groups() != GS_GROUPS ||
@@ -5923,6 +6094,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     if (c->plan[4].n_groups() != GT2_GROUPS || c->plan[5].n_groups() != GT1_GROUPS || c->plan[6].n_groups() != GT0_GROUPS)
         return fail(GENIE_ERR_STATE, "internal: backward plan does not match kernel group maps");
     if ((rc_tr = build_grad_maps(c))) return rc_tr;
+    if ((rc_tr = build_tail_grad_maps(c))) return rc_tr;
     if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
         (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS ||
         c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
@@ -6267,6 +6439,7 @@ int genie_set_slot(genie_ctx* c, int slot) {
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
     for (int s = 7; s < NPLAN; ++s) { (void)hipFree(c->d_steps[s]); (void)hipFree(c->d_bias[s]); (void)hipFree(c->d_scal[s]); (void)hipFree(c->packed[s]); }
+    for (int s = 3; s < NTM; ++s) { (void)hipFree(c->d_acc[s]); (void)hipFree(c->d_vec[s]); (void)hipFree(c->d_sc[s]); }
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1],
@@ -7074,19 +7247,33 @@ int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, cons
     return GENIE_OK;
 }
 
+namespace {
+int ensure_reversed(genie_ctx* c) {
+    if (c->r_sta_rowptr) return GENIE_OK;
+    int rc;
+    if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w))) return rc;
+    return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w);
+}
+int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save,
+                      const float* d_r, float* scratch, float* grad_blob, void* stream, bool zero_blob);
+}  // namespace
+
 int genie_da_train_bwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save,
                        const float* d_r, float* scratch, float* grad_blob, void* stream) {
+    return da_train_bwd_impl(c, slice, mask, edge_attr, save, d_r, scratch, grad_blob, stream, true);
+}
+
+namespace {
+int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save,
+                      const float* d_r, float* scratch, float* grad_blob, void* stream, bool zero_blob) {
     if (!c || !slice || !mask || !edge_attr || !save || !d_r || !scratch || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_da_train_bwd: null argument");
     int rc;
     if ((rc = train_check(c, "genie_da_train_bwd"))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
-    if (!c->r_sta_rowptr) {
-        if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w))) return rc;
-        if ((rc = build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w))) return rc;
-    }
-    HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * g_raw_total, st));
+    if ((rc = ensure_reversed(c))) return rc;
+    if (zero_blob) HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * g_raw_total, st));
     TrArgs a;
     memset(&a, 0, sizeof(a));
     a.S = c->S; a.G = c->G; a.T = c->T; a.seg = std::max(1, c->seg);
@@ -7104,10 +7291,200 @@ int genie_da_train_bwd(genie_ctx* c, const float* slice, const float* mask, cons
         else k_train_b0<<<grid, 256, 0, st>>>(a);
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
-                                                            c->d_sc[s], grad_blob);
+                                                            c->d_sc[s], grad_blob, 0);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
+}
+}  // namespace
+
+// ---- training step: the G- / Q-sized tail (train_tail_kernels.hpp) -------------------------------------------------------
+namespace {
+constexpr int TT_R = 0, TT_BIP = 32, TT_SA1 = 48, TT_SA2 = 80, TT_XS = 112, TT_ROW = 144;     // floats per source node in `tsave`
+int tt_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, 160)); }
+size_t tt_part_floats(int n_acc, int n_vec, int grid) { return (size_t)grid * 4 * ((size_t)n_acc * 256 + (size_t)n_vec * 16 + 16); }
+struct TtScratch {           // offsets (floats) into the backward's scratch
+    size_t dxs_a, dxs_b, eb, dxm, cv, pj, gpart, dxd, dan, dx0, dx1, part_ro, part_a, part_b, total;
+};
+TtScratch tt_layout(const genie_ctx* c, int n_query) {
+    TtScratch t;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 64); return r; };
+    const size_t G = (size_t)c->G, Q = (size_t)std::max(1, n_query);
+    t.dxs_a = take(G * 32); t.dxs_b = take(G * 32);
+    t.eb = take(Q * RO_K * 12); t.dxm = take(Q * 16);
+    t.cv = take(G * CVP);
+    t.pj = take(G * 32); t.gpart = take(1024 * 8);
+    t.dxd = take(G * 32); t.dan = take(G * 32); t.dx0 = take(G * 32); t.dx1 = take(G * 32);
+    t.part_ro = take(tt_part_floats(RB_NACC1, RB_NVEC, tt_grid(std::max(G, Q))));
+    t.part_a = take(tt_part_floats(GTN_GROUPS, 10, tt_grid(G)));      // also k_sat_node_bwd / k_bip_bwd (largest of the G-sized maps)
+    t.part_b = take(tt_part_floats(SBA_NACC, SBA_NVEC, tt_grid(G)));
+    t.total = o;
+    return t;
+}
+int tt_reduce(genie_ctx* c, int tm, const float* part, int n_waves, float* blob, hipStream_t st) {
+    const int stride = c->n_acc[tm] * 256 + c->n_vec[tm] * 16 + 16;
+    k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(part, n_waves, c->n_acc[tm], c->n_vec[tm], c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
+                                                        c->d_sc[tm], blob, 1);
+    return GENIE_OK;
+}
+}  // namespace
+
+size_t genie_tail_train_save_floats(const genie_ctx* c) { return c ? (size_t)TT_ROW * (size_t)c->G : 0; }
+size_t genie_tail_train_scratch_floats(const genie_ctx* c, int n_query) { return c ? tt_layout(c, n_query).total : 0; }
+size_t genie_train_grad_floats(void) { init_registry(); return (size_t)g_raw_total + (size_t)TQ_ROWS * 75 + 16; }
+
+int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, const int32_t* knn, int n_query, int k,
+                         const float* t_query, int n_t, float* tsave, float* y_latent_out, float* y_out, float* x_out, void* ws,
+                         void* stream) {
+    int rc = check_ws(c, ws);
+    if (rc) return rc;
+    if (!pos || !x_query || !knn || !t_query || !tsave || !y_out || !x_out) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: null argument");
+    if ((rc = train_check(c, "genie_tail_train_fwd"))) return rc;
+    if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
+    if (!c->tail_mfma) return fail(GENIE_ERR_STATE, "genie_tail_train_fwd: needs the MFMA tail kernels");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    float* w = (float*)ws;
+    const size_t so = c->slot * c->slot_stride;
+    const size_t G = (size_t)c->G;
+    float* r = tsave + TT_R * G; float* bip = tsave + TT_BIP * G; float* sa1 = tsave + TT_SA1 * G; float* sa2 = tsave + TT_SA2 * G;
+    float* xs = tsave + TT_XS * G;
+    // the same kernels, in the same order, as the inference tail (genie_bipartite_readout, genie_spatial_agg3_fwd, read-outs); the layer
+    // inputs land in `tsave` instead of the workspace slot
+    k_part_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(w + c->o_part + so, c->G, c->T, r);
+    k_bip_out_m<<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], bip, 0, 0);
+    if ((rc = sa_launch_pre(c, 1, bip, w, 0, st))) return rc;
+    if ((rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st))) return rc;
+    if ((rc = sa_launch_layer(c, 2, sa1, pos, sa2, w, 1, true, st))) return rc;
+    if ((rc = sa_launch_layer(c, 3, sa2, pos, xs, w, 0, false, st))) return rc;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    RoArgs a = make_ro_args(c);
+    a.T = n_t; a.x_spatial = xs; a.t_query = t_query;
+    {
+        RoArgs g = a;
+        g.N = g.Nw = c->G; g.out = y_out; g.lat_out = y_latent_out; g.img = c->packed[PL_RO0];
+        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
+    }
+    float* cvbuf = w + c->o_cv + so;
+    k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+    {
+        RoArgs q = a;
+        q.N = q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out; q.img = c->packed[PL_RO1]; q.cv = cvbuf;
+        k_readout_m<1><<<tl_blocks(q.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(q);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr,
+                         const int32_t* rknn_edge, int n_query, int k, const float* t_query, int n_t, const float* tsave,
+                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, float* scratch,
+                         float* d_r_out, float* grad_blob, void* stream) {
+    if (!c || !pos || !x_query || !knn || !rknn_rowptr || !rknn_edge || !t_query || !tsave || !d_y || !d_x || !scratch || !d_r_out || !grad_blob)
+        return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: null argument");
+    int rc;
+    if ((rc = train_check(c, "genie_tail_train_bwd"))) return rc;
+    if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    if ((rc = ensure_reversed(c))) return rc;
+    const size_t G = (size_t)c->G;
+    const float* r = tsave + TT_R * G; const float* bip = tsave + TT_BIP * G; const float* sa1 = tsave + TT_SA1 * G;
+    const float* sa2 = tsave + TT_SA2 * G; const float* xs = tsave + TT_XS * G;
+    const TtScratch L = tt_layout(c, n_query);
+    float* S = scratch;
+    HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * genie_train_grad_floats(), st));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ro_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ro_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS)));
+    RoArgs ro = make_ro_args(c);
+    ro.T = n_t; ro.x_spatial = xs; ro.t_query = t_query;
+    {   // y branch: TemporalAttention + SpatialDirect
+        RbArgs b;
+        memset(&b, 0, sizeof(b));
+        b.ro = ro; b.ro.N = b.ro.Nw = c->G; b.ro.img = c->packed[PL_RO0];
+        b.timg = c->packed[PL_TRO0]; b.d_out = d_y; b.d_lat = d_ylat_extra; b.dxs = S + L.dxs_a;
+        b.part = S + L.part_ro; b.n_acc = c->n_acc[TM_RO0]; b.n_vec = c->n_vec[TM_RO0];
+        const int grid = tt_grid(c->G);
+        k_ro_bwd<0><<<grid, 256, sizeof(float) * RB_LDS_FLOATS, st>>>(b);
+        tt_reduce(c, TM_RO0, b.part, grid * 4, grad_blob, st);
+    }
+    {   // x branch: TemporalAttention + SpatialAttention (query side), then its grid-node side
+        k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], S + L.cv, c->G, 0);
+        RbArgs b;
+        memset(&b, 0, sizeof(b));
+        b.ro = ro; b.ro.N = b.ro.Nw = n_query; b.ro.x_grid = pos; b.ro.x_query = x_query; b.ro.knn = knn; b.ro.cv = S + L.cv;
+        b.ro.img = c->packed[PL_RO1];
+        b.timg = c->packed[PL_TRO1]; b.d_out = d_x; b.eb = S + L.eb; b.dxm = S + L.dxm;
+        b.part = S + L.part_ro; b.n_acc = c->n_acc[TM_RO1]; b.n_vec = c->n_vec[TM_RO1];
+        const int grid = tt_grid(n_query);
+        k_ro_bwd<1><<<grid, 256, sizeof(float) * RB_LDS_FLOATS, st>>>(b);
+        tt_reduce(c, TM_RO1, b.part, grid * 4, grad_blob, st);
+        k_tq_bwd<<<1, 256, 0, st>>>(c->raw, grad_blob + g_raw_total, t_query, n_t, c->scale_t, g_params[W_TA_Q1_W].off, g_params[W_TA_Q1_B].off,
+                                    g_params[W_TA_Q2_W].off, g_params[W_TA_Q2_B].off, g_params[W_TA_ACT3].off, grad_blob);
+        SnArgs n;
+        memset(&n, 0, sizeof(n));
+        n.G = c->G; n.nq = n_query; n.x_spatial = xs; n.x_grid = pos; n.x_query = x_query; n.r_rowptr = rknn_rowptr; n.r_edge = rknn_edge;
+        n.eb = S + L.eb; n.dxm = S + L.dxm; n.raw = c->raw; n.o_sq_w = g_params[W_SAT_Q_W].off; n.o_sq_b = g_params[W_SAT_Q_B].off;
+        n.scale_rel = c->scale_rel; n.timg = c->packed[PL_TSN]; n.dxs = S + L.dxs_b;
+        n.part = S + L.part_a; n.n_acc = c->n_acc[TM_SN]; n.n_vec = c->n_vec[TM_SN];
+        const int gn = tt_grid(c->G);
+        k_sat_node_bwd<<<gn, 256, 0, st>>>(n);
+        tt_reduce(c, TM_SN, n.part, gn * 4, grad_blob, st);
+    }
+    // SpatialAggregation 3, 2, 1
+    const float* x_in[3] = {bip, sa1, sa2};
+    float* dxl[2] = {S + L.dx0, S + L.dx1};
+    const int gs = tt_grid(c->G);
+    for (int layer = 3; layer >= 1; --layer) {
+        SaArgs pre;
+        memset(&pre, 0, sizeof(pre));
+        sa_fill_layer(c, layer, pre);
+        pre.x_in = x_in[layer - 1]; pre.pj_out = S + L.pj; pre.gpart_out = S + L.gpart; pre.img = c->packed[PL_SA1 + layer - 1];
+        const int nbp = sa_blocks(c);
+        if (layer == 1) k_sa_pre_m<15><<<nbp, 256, 0, st>>>(pre); else k_sa_pre_m<30><<<nbp, 256, 0, st>>>(pre);
+        SbArgs a;
+        memset(&a, 0, sizeof(a));
+        a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src; a.x_in = x_in[layer - 1]; a.pos = pos;
+        a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg; a.r_rowptr = c->r_src_rowptr; a.r_col = c->r_src_col;
+        a.raw = c->raw; a.fc1_w = g_params[(layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W))].off;
+        a.scale_rel = c->scale_rel; a.pj = S + L.pj; a.gpart = S + L.gpart; a.n_gpart = nbp;
+        a.img = c->packed[PL_SA1 + layer - 1]; a.timg = c->packed[PL_TSA1 + layer - 1];
+        if (layer == 3) { a.dout_a = S + L.dxs_a; a.dout_b = S + L.dxs_b; a.dout_x30 = d_xs_extra; }
+        else a.dout_a = dxl[layer & 1];
+        a.dxd = S + L.dxd; a.dan = S + L.dan; a.dx = dxl[(layer - 1) & 1];
+        const int tma = TM_SAA1 + layer - 1, tmb = TM_SAB1 + layer - 1;
+        a.part = S + L.part_b; a.n_acc = c->n_acc[tma]; a.n_vec = c->n_vec[tma];
+        if (layer == 1) k_sa_bwd_a<15><<<gs, 256, 0, st>>>(a); else k_sa_bwd_a<30><<<gs, 256, 0, st>>>(a);
+        tt_reduce(c, tma, a.part, gs * 4, grad_blob, st);
+        a.part_a = S + L.part_b; a.n_waves_a = gs * 4; a.n_acc_a = c->n_acc[tma]; a.n_vec_a = c->n_vec[tma];
+        a.part = S + L.part_a; a.n_acc = c->n_acc[tmb]; a.n_vec = c->n_vec[tmb]; a.blob = grad_blob;
+        if (layer == 1) k_sa_bwd_b<15><<<gs, 256, 0, st>>>(a); else k_sa_bwd_b<30><<<gs, 256, 0, st>>>(a);
+        tt_reduce(c, tmb, a.part, gs * 4, grad_blob, st);
+    }
+    {   // Bipartite_ReadIn.fc2: d bip (= the gradient of SpatialAggregation1's input) -> d r
+        BbArgs b;
+        memset(&b, 0, sizeof(b));
+        b.G = c->G; b.r = r; b.dbip = dxl[0]; b.img = c->packed[PL_BIP]; b.timg = c->packed[PL_TBIP]; b.dr = d_r_out;
+        b.part = S + L.part_a; b.n_acc = c->n_acc[TM_BIP]; b.n_vec = c->n_vec[TM_BIP];
+        k_bip_bwd<<<gs, 256, 0, st>>>(b);
+        tt_reduce(c, TM_BIP, b.part, gs * 4, grad_blob, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+// Whole backward of a training step of `forward_fixed_source`: the tail (genie_tail_train_bwd) and then the P-sized front
+// (genie_da_train_bwd) driven by the tail's d r, into one gradient blob.
+int genie_train_bwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save, const float* pos,
+                    const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr, const int32_t* rknn_edge, int n_query, int k,
+                    const float* t_query, int n_t, const float* tsave, const float* d_y, const float* d_x, const float* d_xs_extra,
+                    const float* d_ylat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch, float* grad_blob, void* stream) {
+    int rc = genie_tail_train_bwd(c, pos, x_query, knn, rknn_rowptr, rknn_edge, n_query, k, t_query, n_t, tsave, d_y, d_x, d_xs_extra,
+                                  d_ylat_extra, tail_scratch, d_r_scratch, grad_blob, stream);
+    if (rc) return rc;
+    return da_train_bwd_impl(c, slice, mask, edge_attr, save, d_r_scratch, front_scratch, grad_blob, stream, false);
 }
 
 int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out) {

@@ -772,6 +772,98 @@ class HipPath(object):
                                                _ptr(self._train_scratch), _ptr(blob), _stream()), "genie_da_train_bwd")
         return {name: blob[off:off + n] for name, n, off in zip(self.w_names, self.w_numel, self.w_off)}
 
+    # ---- training step of forward_fixed_source: the whole path in HIP, both directions ----------------------------------
+    def reverse_query_table(self, knn_idx):
+        """The query kNN table [Q, 10] reversed (index plumbing for genie_tail_train_bwd): (rowptr int32 [n_grid + 1], edge ids
+        int32 [Q * 10]) = for every grid node the attention edges `i * 10 + k` that end in it, ascending. Cached per table."""
+        key = (knn_idx.data_ptr(), knn_idx._version, tuple(knn_idx.shape))
+        if getattr(self, "_rknn_key", None) != key:
+            flat = knn_idx.reshape(-1).long()
+            order = torch.sort(flat, stable=True)[1]
+            rowptr = torch.zeros(self.n_grid + 1, dtype=torch.int64, device=knn_idx.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=self.n_grid), 0)
+            self._rknn = (rowptr.to(torch.int32), order.to(torch.int32).contiguous())
+            self._rknn_key, self._rknn_ref = key, knn_idx
+        return self._rknn
+
+    def path_train_fwd(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query, want_x_latent=False, want_y_latent=False):
+        """Training forward of `forward_fixed_source` (genie_da_train_fwd + genie_tail_train_fwd): returns (y [G, T, 1], x [Q, T, 1],
+        x_spatial [G, 30] (a view into tsave), y_latent [G, 30] or None, x_latent [P, 30] or None, save, tsave)."""
+        P = self.n_prod
+        Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
+        pos = _f32(pos, "pos", (self.n_grid, 3))
+        x_query = _f32(x_query, "x_query")
+        nq = int(x_query.shape[0])
+        if tuple(knn_idx.shape) != (nq, 10) or knn_idx.dtype != torch.int32 or not knn_idx.is_cuda:
+            raise ValueError("knn_idx must be an int32 GPU tensor of shape [n_query, 10]")
+        knn_idx = knn_idx.contiguous()
+        tq = _f32(t_query, "t_query").reshape(-1)
+        dev, G = self.device, self.n_grid
+        save = torch.empty(int(self.lib.genie_train_save_floats(self.ctx)), dtype=torch.float32, device=dev)
+        tsave = torch.empty(int(self.lib.genie_tail_train_save_floats(self.ctx)), dtype=torch.float32, device=dev)
+        r = torch.empty((G, 30), dtype=torch.float32, device=dev)
+        x_latent = torch.empty((P, 30), dtype=torch.float32, device=dev) if want_x_latent else None
+        y_latent = torch.empty((G, 30), dtype=torch.float32, device=dev) if want_y_latent else None
+        y = torch.empty((G, tq.numel(), 1), dtype=torch.float32, device=dev)
+        x = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.genie_da_train_fwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(x_latent), _ptr(r),
+                                               self._ws_ptr, _stream()), "genie_da_train_fwd")
+        _lib.check(self.lib.genie_tail_train_fwd(self.ctx, _ptr(pos), _ptr(x_query), _ptr(knn_idx), nq, 10, _ptr(tq), tq.numel(),
+                                                 _ptr(tsave), _ptr(y_latent), _ptr(y), _ptr(x), self._ws_ptr, _stream()),
+                   "genie_tail_train_fwd")
+        x_spatial = tsave[112 * G:142 * G].view(G, 30)
+        return y, x, x_spatial, y_latent, x_latent, save, tsave
+
+    def path_train_bwd(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query, save, tsave, d_y, d_x, d_xs=None, d_ylat=None):
+        """Backward of `path_train_fwd` (genie_train_bwd): upstream gradients d_y [G, T], d_x [Q, T] (+ optional d_xs [G, 30] on
+        x_spatial and d_ylat [G, 30] on y_latent from consumers outside the path) -> dict parameter name -> gradient (views
+        into one blob laid out like the weight mirror), every parameter of the path."""
+        dev, G = self.device, self.n_grid
+        pos = _f32(pos, "pos", (G, 3))
+        x_query = _f32(x_query, "x_query")
+        nq = int(x_query.shape[0])
+        tq = _f32(t_query, "t_query").reshape(-1)
+        T = tq.numel()
+        d_y = _f32(d_y, "d_y").reshape(G, T)
+        d_x = _f32(d_x, "d_x").reshape(nq, T)
+        d_xs = _f32(d_xs, "d_xs", (G, 30)) if d_xs is not None else None
+        d_ylat = _f32(d_ylat, "d_ylat", (G, 30)) if d_ylat is not None else None
+        rp, re = self.reverse_query_table(knn_idx)
+        need_t = int(self.lib.genie_tail_train_scratch_floats(self.ctx, nq))
+        need_f = int(self.lib.genie_train_scratch_floats(self.ctx))
+        if getattr(self, "_tail_scratch", None) is None or self._tail_scratch.numel() < need_t:
+            self._tail_scratch = torch.empty(need_t, dtype=torch.float32, device=dev)
+        if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need_f:
+            self._train_scratch = torch.empty(need_f, dtype=torch.float32, device=dev)
+        d_r = torch.empty((G, 32), dtype=torch.float32, device=dev)
+        blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.genie_train_bwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(pos), _ptr(x_query),
+                                            _ptr(knn_idx), _ptr(rp), _ptr(re), nq, 10, _ptr(tq), T, _ptr(tsave), _ptr(d_y), _ptr(d_x),
+                                            _ptr(d_xs), _ptr(d_ylat), _ptr(self._tail_scratch), _ptr(self._train_scratch), _ptr(d_r),
+                                            _ptr(blob), _stream()), "genie_train_bwd")
+        return {name: blob[off:off + n] for name, n, off in zip(self.w_names, self.w_numel, self.w_off)}
+
+    def tail_train_bwd(self, pos, x_query, knn_idx, t_query, tsave, d_y, d_x, d_xs=None, d_ylat=None):
+        """The tail half of `path_train_bwd` alone (genie_tail_train_bwd): returns (d_r [G, 32], gradient blob). Phase timing
+        (bench.py --mode train) and tests; `train_bwd(Slice, Mask, edge_attr, save, d_r[:, :30])` is the other half."""
+        dev, G = self.device, self.n_grid
+        x_query = _f32(x_query, "x_query")
+        nq = int(x_query.shape[0])
+        tq = _f32(t_query, "t_query").reshape(-1)
+        T = tq.numel()
+        d_y, d_x = _f32(d_y, "d_y").reshape(G, T), _f32(d_x, "d_x").reshape(nq, T)
+        rp, re = self.reverse_query_table(knn_idx)
+        need_t = int(self.lib.genie_tail_train_scratch_floats(self.ctx, nq))
+        if getattr(self, "_tail_scratch", None) is None or self._tail_scratch.numel() < need_t:
+            self._tail_scratch = torch.empty(need_t, dtype=torch.float32, device=dev)
+        d_r = torch.empty((G, 32), dtype=torch.float32, device=dev)
+        blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.genie_tail_train_bwd(self.ctx, _ptr(_f32(pos, "pos", (G, 3))), _ptr(x_query), _ptr(knn_idx), _ptr(rp), _ptr(re), nq, 10,
+                                                 _ptr(tq), T, _ptr(tsave), _ptr(d_y), _ptr(d_x), _ptr(d_xs), _ptr(d_ylat),
+                                                 _ptr(self._tail_scratch), _ptr(d_r), _ptr(blob), _stream()), "genie_tail_train_bwd")
+        return d_r, blob
+
     def nbr_mean(self, x_sta=None, x_src=None):
         """Neighbour means over the product graph of [P, C] rows (C <= 32): (mean over station neighbours of x_sta, mean over
         source neighbours of x_src); genie_nbr_mean on rows padded to 16 / 32 floats ([P, 30] rows as they are)."""

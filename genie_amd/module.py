@@ -57,56 +57,66 @@ class _NbrMean(torch.autograd.Function):
         return d_sta, d_src, None
 
 
-TRAIN_FRONT_PARAMS = tuple(
-    ["DataAggregation.%s.%s" % (l, k) for l in ("init_trns", "l1_t1_2", "l1_t2_2", "l2_t1_1", "l2_t2_1", "l2_t1_2", "l2_t2_2")
-     for k in ("weight", "bias")]
-    + ["DataAggregation.%s.weight" % a for a in ("activate", "activate11", "activate12", "activate1", "activate21", "activate22", "activate2")]
-    + ["Bipartite_ReadIn.fc1.weight", "Bipartite_ReadIn.fc1.bias", "Bipartite_ReadIn.activate1.weight"])
+def _train_path_params():
+    """state_dict names of every parameter the HIP training step differentiates (the whole `forward_fixed_source` path): the
+    dead layers of the reference (DataAggregation.l1_t1_1 / l1_t2_1, SpatialAttention.param_vector / f_direct) get no gradient
+    there either."""
+    names = ["DataAggregation.%s.%s" % (l, k) for l in ("init_trns", "l1_t1_2", "l1_t2_2", "l2_t1_1", "l2_t2_1", "l2_t1_2", "l2_t2_2")
+             for k in ("weight", "bias")]
+    names += ["DataAggregation.%s.weight" % a for a in ("activate", "activate11", "activate12", "activate1", "activate21", "activate22", "activate2")]
+    names += ["Bipartite_ReadIn.%s" % n for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "activate1.weight", "activate2.weight")]
+    for k in (1, 2, 3):
+        names += ["SpatialAggregation%d.%s" % (k, n) for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fglobal.weight",
+                                                               "fglobal.bias", "activate1.weight", "activate2.weight", "activate3.weight")]
+    names += ["SpatialDirect.f_direct.weight", "SpatialDirect.f_direct.bias", "SpatialDirect.activate.weight"]
+    names += ["TemporalAttention.%s.%s" % (l, k) for l in ("temporal_query_1", "temporal_query_2", "f_context_1", "f_context_2",
+                                                             "f_values_1", "f_values_2", "proj_1", "proj_2") for k in ("weight", "bias")]
+    names += ["TemporalAttention.activate%d.weight" % k for k in (1, 2, 3, 4, 5)]
+    names += ["SpatialAttention.%s.%s" % (l, k) for l in ("f_queries", "f_context", "f_values", "proj") for k in ("weight", "bias")]
+    names += ["SpatialAttention.activate1.weight", "SpatialAttention.activate2.weight"]
+    return tuple(names)
 
 
-class _FrontTrain(torch.autograd.Function):
-    """DataAggregation + the P-sized half of Bipartite_ReadIn of a training step as HIP passes in both directions
-    (genie_da_train_fwd / genie_da_train_bwd): forward = the fused stage kernels with their pre-activations kept, backward =
-    three P-sized passes with in-kernel weight gradients. `params` (order TRAIN_FRONT_PARAMS) are listed so that autograd
-    routes their gradients; their values are read from the library's weight mirror (synchronised by the caller)."""
+TRAIN_PATH_PARAMS = _train_path_params()
+
+
+class _PathTrain(torch.autograd.Function):
+    """A training step of the whole `forward_fixed_source` path in HIP, both directions: forward =
+    genie_da_train_fwd (stage kernels, pre-activations kept) + genie_tail_train_fwd (the inference tail); backward =
+    genie_train_bwd (tail passes, then the three P-sized passes, weight gradients reduced in a fixed order). Outputs
+    (y, x, x_spatial, y_latent, x_latent): x_spatial / y_latent are differentiable too, for the association heads of the 4-output
+    `forward` that consume them. `params` (order TRAIN_PATH_PARAMS) are listed so that autograd routes their gradients; their
+    values are read from the library's weight mirror (synchronised by the caller)."""
 
     @staticmethod
-    def forward(ctx, Slice, Mask, edge_attr, hip, *params):
-        r, x_latent, save = hip.train_fwd(Slice, Mask, edge_attr)
+    def forward(ctx, Slice, Mask, edge_attr, pos, x_query, knn, t_query, hip, want_latents, *params):
+        y, x, xs, ylat, xl, save, tsave = hip.path_train_fwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query,
+                                                              want_x_latent=want_latents, want_y_latent=want_latents)
         ctx.hip = hip
         ctx.shapes = [tuple(p.shape) for p in params]
-        ctx.save_for_backward(Slice, Mask, edge_attr, save)
-        ctx.mark_non_differentiable(x_latent)
-        return r, x_latent
+        ctx.save_for_backward(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave)
+        ctx.set_materialize_grads(False)
+        xs = xs.clone()
+        if not want_latents:
+            ylat, xl = xs.new_zeros(0), xs.new_zeros(0)
+        ctx.mark_non_differentiable(xl)
+        return y, x, xs, ylat, xl
 
     @staticmethod
-    def backward(ctx, d_r, _d_x_latent):
-        Slice, Mask, edge_attr, save = ctx.saved_tensors
-        g = ctx.hip.train_bwd(Slice, Mask, edge_attr, save, d_r.contiguous())
-        return (None, None, None, None) + tuple(g[n].view(s) for n, s in zip(TRAIN_FRONT_PARAMS, ctx.shapes))
+    def backward(ctx, d_y, d_x, d_xs, d_ylat, _d_xl):
+        Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave = ctx.saved_tensors
+        hp = ctx.hip
+        T = t_query.numel()
+        d_y = d_y if d_y is not None else torch.zeros((hp.n_grid, T), dtype=torch.float32, device=Slice.device)
+        d_x = d_x if d_x is not None else torch.zeros((x_query.shape[0], T), dtype=torch.float32, device=Slice.device)
+        g = hp.path_train_bwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave, d_y, d_x, d_xs, d_ylat)
+        return (None,) * 9 + tuple(g[n].view(s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
 
 
 def _scatter_mean_rows(msg, index, n):
     out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device).index_add_(0, index, msg)
     cnt = torch.zeros(n, dtype=msg.dtype, device=msg.device).index_add_(0, index, torch.ones_like(index, dtype=msg.dtype))
     return out / cnt.clamp(min=1).view(-1, 1)
-
-
-class _PReLU(torch.autograd.Function):
-    """Single-slope PReLU whose backward is one HIP pass (genie_prelu_bwd) instead of PyTorch's full-size slope gradient plus
-    a reduction -- the largest single item of the training step's backward on product-sized tensors."""
-
-    @staticmethod
-    def forward(ctx, x, slope, hip):
-        ctx.hip = hip
-        ctx.save_for_backward(x, slope)
-        return F.prelu(x, slope)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, slope = ctx.saved_tensors
-        dx, ds = ctx.hip.prelu_bwd(x, dy.contiguous(), slope)
-        return dx, ds, None
 
 
 class _Linear(torch.autograd.Function):
@@ -128,10 +138,6 @@ class _Linear(torch.autograd.Function):
         return dx, dW, db, None
 
 
-def _lin(module, x, hip):
-    return _Linear.apply(x.contiguous(), module.weight, module.bias, hip)
-
-
 def _dense(module, x, owner):
     """`module(x)` for an nn.Linear; under autograd on a HIP-backed network (owner._hip set by set_adjacencies) and with enough
     rows the weight / bias gradients come from genie_linear_bwd_wb (`_Linear`)."""
@@ -142,10 +148,6 @@ def _dense(module, x, owner):
         return module(x)
     y = _Linear.apply(x.reshape(rows, x.shape[-1]).contiguous(), module.weight, module.bias, hip)
     return y.view(*x.shape[:-1], module.out_features)
-
-
-def _act(module, x, hip):
-    return _PReLU.apply(x.contiguous(), module.weight, hip)
 
 
 class DataAggregation(nn.Module):
@@ -174,18 +176,6 @@ class DataAggregation(nn.Module):
         self.activate21 = nn.PReLU()
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
-
-    def forward_train(self, Slice, Mask, hip):
-        """Differentiable restatement of module.py:85-98 for training steps (first pass): per-node Linears and
-        PReLUs on PyTorch-ROCm autograd, the four neighbour means through `_NbrMean` (HIP forward and adjoint)."""
-        tr = _act(self.activate, _lin(self.init_trns, torch.cat((Slice, Mask), dim=-1), hip), hip)
-        n1, n2 = _NbrMean.apply(_act(self.activate11, tr, hip), _act(self.activate12, tr, hip), hip)
-        tr = _act(self.activate1, torch.cat((_lin(self.l1_t1_2, torch.cat((tr, n1, Mask), dim=1), hip),
-                                             _lin(self.l1_t2_2, torch.cat((tr, n2, Mask), dim=1), hip)), dim=1), hip)
-        m1, m2 = _NbrMean.apply(_act(self.activate21, _lin(self.l2_t1_1, tr, hip), hip),
-                                _act(self.activate22, _lin(self.l2_t2_1, tr, hip), hip), hip)
-        return _act(self.activate2, torch.cat((_lin(self.l2_t1_2, torch.cat((tr, m1, Mask), dim=1), hip),
-                                               _lin(self.l2_t2_2, torch.cat((tr, m2, Mask), dim=1), hip)), dim=1), hip)
 
 
 class DataAggregationEdges(nn.Module):
@@ -246,12 +236,6 @@ class BipartiteGraphOperator(nn.Module):
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def forward_train(self, x_latent, edge_attr, Mask, n_sta, n_grid, hip):
-        """module.py:224-229, differentiable (the station sum is a view-sum on the Cartesian layout p = g * n_sta + s)."""
-        m = Mask.max(1, keepdim=True)[0]
-        msg = m * _act(self.activate1, _lin(self.fc1, torch.cat((x_latent, edge_attr), dim=-1), hip), hip)
-        return self.activate2(self.fc2(msg.view(n_grid, n_sta, -1).sum(dim=1)))
-
 
 class SpatialAggregation(nn.Module):
     """Parameters of reference `SpatialAggregation` (module.py:232-241)."""
@@ -265,15 +249,6 @@ class SpatialAggregation(nn.Module):
         self.activate2 = nn.PReLU()
         self.activate3 = nn.PReLU()
         self.scale_rel = scale_rel
-
-    def forward_train(self, tr, A_src, pos):
-        """module.py:243-249, differentiable (G-sized: plain index gathers / index_add)."""
-        j, i = A_src[0], A_src[1]
-        p = pos / self.scale_rel
-        x_j = tr[j]
-        c = self.activate3(_dense(self.fglobal, x_j, self)).mean(0, keepdim=True)
-        msg = self.activate1(_dense(self.fc1, torch.cat((x_j, p[i] - p[j], c.expand(x_j.shape[0], -1)), dim=-1), self))
-        return self.activate2(_dense(self.fc2, torch.cat((tr, _scatter_mean_rows(msg, i, tr.shape[0])), dim=-1), self))
 
 
 class SpatialDirect(nn.Module):
@@ -852,38 +827,25 @@ class GCN_Detection_Network_extended(nn.Module):
     def _differentiable(self):
         return self.training and torch.is_grad_enabled()
 
-    def _path_train(self, Slice, Mask, x_temp_cuda_cart):
-        """Training-mode forward of the path (first pass): same arithmetic with autograd. The P-sized
-        neighbour means run in HIP in both directions (`_NbrMean`); the per-node Linears are rocBLAS GEMMs under autograd.
-        Used when the module is in train() mode with gradients enabled; eval / no_grad calls take the fused HIP path."""
+    def _path_train(self, Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=False):
+        """Training-mode `forward_fixed_source`: the whole path in HIP in both directions (`_PathTrain`). Used
+        when the module is in train() mode with gradients enabled; eval / no_grad calls take the fused inference kernels.
+        Returns (y, x, x_spatial, y_latent, x_latent); the latents only with `want_latents` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
         if self.use_updated_model_definition or self.use_absolute_pos or self._hip._n_prod is not None:
             raise NotImplementedError("training-mode forward: default model definition on a Cartesian product graph only")
         hp = self._hip
-        Slice = _engine._f32(Slice, "Slice", (hp.n_prod, 4))
-        Mask = _engine._f32(Mask, "Mask", (hp.n_prod, 4))
-        if os.environ.get("GENIE_TRAIN_AUTOGRAD") is None:
-            # the P-sized front in HIP in both directions; fc2 / PReLU_b2 of Bipartite_ReadIn (G-sized) under autograd
-            hp.sync_weights(self._path_params)
-            r, x_latent = _FrontTrain.apply(Slice, Mask, self._edge_attr, hp, *[self._path_params[n] for n in TRAIN_FRONT_PARAMS])
-            x = self.Bipartite_ReadIn.activate2(self.Bipartite_ReadIn.fc2(r))
-        else:       # A/B: the per-node ops under autograd with HIP neighbour means / PReLU / weight-gradient kernels
-            x_latent = self.DataAggregation.forward_train(Slice, Mask, hp)
-            x = self.Bipartite_ReadIn.forward_train(x_latent, self._edge_attr, Mask, hp.n_sta, hp.n_grid, hp)
-        A_src = torch.as_tensor(self.A_src).long().to(x.device)
-        pos = x_temp_cuda_cart.float()
-        for sa in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3):
-            x = sa.forward_train(x, A_src, pos)
-        return x, x_latent
+        hp.sync_weights(self._path_params)
+        knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+        return _PathTrain.apply(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query, hp, bool(want_latents),
+                                *[self._path_params[n] for n in TRAIN_PATH_PARAMS])
 
     def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
                              x_query_cart, t_query):
         """module.py:999-1020. `tpick`, `ipick`, `phase_label` are accepted and ignored, as in the reference."""
         if self._differentiable():
-            x_spatial, _ = self._path_train(Slice, Mask, x_temp_cuda_cart)
-            y = self.TemporalAttention(self.SpatialDirect(x_spatial), t_query)
-            x = self.TemporalAttention(self._spatial_attention_uncached(x_spatial, x_query_cart, x_temp_cuda_cart), t_query)
+            y, x = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query)[:2]
             return y, x
         x_spatial, _, _ = self._path(Slice, Mask, x_temp_cuda_cart)                       # :1010-1014
         y = self._hip.readout_grid(x_spatial, t_query)                                     # :1015-1016
@@ -948,11 +910,8 @@ class GCN_Detection_Network_extended(nn.Module):
             raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
                                       "set_adjacencies_base): only forward_fixed_source is available here")
         S, G = self._hip.n_sta, self._hip.n_grid
-        if self._differentiable():       # training step (train_GENIE_model.py:1786): same arithmetic under autograd
-            x_spatial, x_latent = self._path_train(Slice, Mask, x_temp_cuda_cart)
-            y_latent = self.SpatialDirect(x_spatial)
-            y = self.TemporalAttention(y_latent, t_query)
-            x = self.TemporalAttention(self._spatial_attention_uncached(x_spatial, x_query_cart, x_temp_cuda_cart), t_query)
+        if self._differentiable():       # training step (train_GENIE_model.py:1786): the shared path in HIP in both directions
+            y, x, x_spatial, y_latent, x_latent = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True)
         else:
             x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)  # :973-977
             y_latent = self.SpatialDirect(x_spatial)                                                 # :978

@@ -313,6 +313,39 @@ int genie_da_train_fwd(genie_ctx* ctx, const float* slice, const float* mask, co
 int genie_da_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr, const float* save,
                        const float* d_r, float* scratch, float* grad_blob, void* stream);
 
+/* Training step, the G- / Q-sized tail (round 3): Bipartite_ReadIn.fc2 (module.py:229), SpatialAggregation1..3 (:243-249, the
+ * grid-wide edge-mean term included), SpatialDirect (:251-260), SpatialAttention (:262-297) and TemporalAttention (:299-331,
+ * applied to both read-outs), i.e. everything of `forward_fixed_source` (:1011-1018) after the station sum, in both directions.
+ *   genie_tail_train_fwd: call right after genie_da_train_fwd on the same workspace slot (it consumes the per-tile partials).
+ *     It IS the inference tail (k_bip_out_m, k_sa_pre_m / k_sa_layer_m, k_ro_pre_m, k_readout_m); the layer inputs the backward
+ *     recomputes from (r, bip, sa1, sa2, x_spatial) go to `tsave` (genie_tail_train_save_floats(ctx) floats; x_spatial [n_grid, 30]
+ *     starts at float 112 * n_grid). y_out [n_grid, n_t], x_out [n_query, n_t]; y_latent_out [n_grid, 30] optional
+ *     (SpatialDirect output, the input of the association heads).
+ *   genie_tail_train_bwd: d_y [n_grid, n_t], d_x [n_query, n_t]; optional extra upstream gradients d_xs_extra [n_grid, 30]
+ *     (other consumers of x_spatial) and d_ylat_extra [n_grid, 30] (other consumers of y_latent) -> d_r_out [n_grid, 32] (the
+ *     input of genie_da_train_bwd) and grad_blob (genie_train_grad_floats() floats, zeroed by the call; weight-mirror layout):
+ *     gradients of every tail parameter. rknn_rowptr [n_grid + 1] / rknn_edge [n_query * 10]: the query kNN table reversed =
+ *     for every grid node the attention edges i * 10 + k that end in it, ascending. `scratch`:
+ *     genie_tail_train_scratch_floats(ctx, n_query) floats. Deterministic: per-wave partial sums reduced in a fixed order,
+ *     scatter-shaped gradients gathered over reversed graphs, no atomics.
+ *   genie_train_bwd: genie_tail_train_bwd followed by genie_da_train_bwd (driven by the tail's d r) into ONE gradient blob:
+ *     the whole backward of a `forward_fixed_source` training step (train_GENIE_model.py:1843-1846). */
+size_t genie_tail_train_save_floats(const genie_ctx* ctx);
+size_t genie_tail_train_scratch_floats(const genie_ctx* ctx, int n_query);
+size_t genie_train_grad_floats(void);
+int genie_tail_train_fwd(genie_ctx* ctx, const float* pos, const float* x_query, const int32_t* knn, int n_query, int k,
+                         const float* t_query, int n_t, float* tsave, float* y_latent_out, float* y_out, float* x_out, void* ws,
+                         void* stream);
+int genie_tail_train_bwd(genie_ctx* ctx, const float* pos, const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr,
+                         const int32_t* rknn_edge, int n_query, int k, const float* t_query, int n_t, const float* tsave,
+                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, float* scratch,
+                         float* d_r_out, float* grad_blob, void* stream);
+int genie_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr, const float* save, const float* pos,
+                    const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr, const int32_t* rknn_edge, int n_query, int k,
+                    const float* t_query, int n_t, const float* tsave, const float* d_y, const float* d_x, const float* d_xs_extra,
+                    const float* d_ylat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch, float* grad_blob,
+                    void* stream);
+
 /* Association heads on the product graph, the P-sized part of `forward_fixed` after the source branch
  * (module.py:986-990): BipartiteGraphReadOutOperator (:333-352) followed by DataAggregationAssociationPhase (:356-403).
  *   y_latent [n_grid, 30] (SpatialDirect output), mask_src [n_grid] (`mask_out`, :985), x_latent [P, 30] (DataAggregation
