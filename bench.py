@@ -87,9 +87,6 @@ def parse():
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: launch the ranks, build the sharding plan and run the two collectives of the sharded path on CPU "
                          "tensors over gloo (checks the launcher / rank plumbing and the exchange; prints a JSON line, no timing)")
-    ap.add_argument("--tail-cus", type=int, default=int(os.environ.get("GENIE_TAIL_CUS", "0")),
-                    help="experiment (measured 2.4-4.4x SLOWER, DESIGN.md section 5): CUs per XCD reserved for the G-sized tails of the window "
-                         "pipeline through CU-masked streams; 0 = shared CUs (default)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded: sequential schedule (stage 1, exchange, stage 2, all-gather)")
     ap.add_argument("--cpu-windows", type=int, default=3, help="cpu_baseline: timed windows after one warm-up (median)")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -271,7 +268,7 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
 
     def step(i):
         Slice, Mask = hp.embed_window(d_t[lo[i]:hi[i]], d_sta[lo[i]:hi[i]], d_ph[lo[i]:hi[i]], float(t_all[i]), max_t, sig, dt, d_trv,
-                                      presplit=not os.environ.get("GENIE_NO_PRESPLIT"))
+                                      presplit=True)
         if net.window_batch == 1:         # one tail per window, launched call by call on alternating side streams
             y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
             with torch.cuda.stream(hp.side_stream):
@@ -708,14 +705,7 @@ def main():
         torch.cuda.synchronize()
 
     import contextlib
-    mp = os.environ.get("GENIE_MAIN_PRIO")
-    main_ctx = torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(mp))) if mp else contextlib.nullcontext()
-    if a.tail_cus > 0 and not a.no_pipeline:
-        # CU partition: P-sized kernels on all but `tail_cus` CUs per XCD, the G-sized tails on those (engine.enable_cu_partition)
-        torch.cuda.synchronize()
-        part_stream = net._hip.enable_cu_partition(a.tail_cus)
-        main_ctx = torch.cuda.stream(part_stream)
-    with torch.no_grad(), main_ctx:
+    with torch.no_grad():
         for i in range(a.settle):       # set-up (clock settle), not part of the W warm-up or the K timed steps
             step(i)
         drain()
@@ -743,8 +733,7 @@ def main():
     P = S * G
     ev = {k: [] for k in ("k_stage1", "k_stage2", "path")}
     torch.cuda.synchronize()
-    ev_ctx = torch.cuda.stream(part_stream) if (a.tail_cus > 0 and not a.no_pipeline) else contextlib.nullcontext()
-    with torch.no_grad(), ev_ctx:
+    with torch.no_grad():
         for i in range(min(a.steps, 20)):
             k = i % a.windows
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -799,7 +788,6 @@ def main():
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq, "settle_windows": a.settle,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
         "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,
-        "tail_cus_per_xcd": 0 if a.no_pipeline else a.tail_cus,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_live_traffic:

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "genie_hip.hip")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.environ.get("GENIE_LIB_PATH", os.path.join(LIB_DIR, "libgenie_hip.so"))  # override: tuning builds only
+LIB_PATH = os.environ.get("GENIE_LIB_PATH", os.path.join(LIB_DIR, "libgenie_hip.so"))  # override: tuning builds (tools/tune.py) only
 INCLUDE = os.path.join(REPO, "include")
 
 # every symbol include/genie_hip.h declares: (name, restype, argtypes)
@@ -36,10 +36,10 @@ SYMBOLS = [
     ("genie_set_station_order", _c.c_int, [_P, _P]),
     ("genie_set_static_edge_attr", _c.c_int, [_P, _P, _P]),
     ("genie_tail_batched", _c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P]),
-    ("genie_set_tail_mode", _c.c_int, [_P, _c.c_int]),
-    ("genie_set_tail_kernels", _c.c_int, [_P, _c.c_int]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),
     ("genie_readout_query", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P]),
+    ("genie_readout_grid_latent", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P, _P]),
+    ("genie_readout_query_latent", _c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     ("genie_weights_count", _c.c_int, []),
     ("genie_weights_name", _c.c_char_p, [_c.c_int]),
     ("genie_weights_numel", _c.c_int64, [_c.c_int]),
@@ -61,11 +61,7 @@ SYMBOLS = [
     ("genie_spatial_agg_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_spatial_agg3_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P]),
     ("genie_path_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    ("genie_cu_mask_probe", _c.c_int, [_P, _c.c_int]),
     ("genie_where_am_i", _c.c_int, [_P, _c.c_int, _P]),
-    ("genie_stream_create_masked", _c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
-    ("genie_stream_destroy", _c.c_int, [_P]),
-    ("genie_set_num_cu", _c.c_int, [_P, _c.c_int]),
     ("genie_set_tail_grid", _c.c_int, [_P, _c.c_int, _c.c_int]),
     ("genie_train_save_floats", _c.c_size_t, [_P]),
     ("genie_train_scratch_floats", _c.c_size_t, [_P]),

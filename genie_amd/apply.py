@@ -51,15 +51,43 @@ def windows_with_enough_picks(pick_times, tsteps, max_t, t_win, min_required_pic
     return tsteps[n >= max(1, int(min_required_picks))]
 
 
-def window_columns(tsteps_abs, t0, offsets, drop_last):
+def is_ascending(grid):
+    grid = np.asarray(grid)
+    return bool(grid.shape[0] < 2 or np.all(grid[1:] >= grid[:-1]))
+
+
+def nearest_index(grid, values, ascending=None):
+    """Index of the `grid` entry nearest to every value (ties -> the lower index, as `np.abs(grid - v).argmin()` gives): a
+    binary search + a choice between the two bracketing entries when `grid` is ascending (the reference's `tsteps_abs`,
+    process_continuous_days.py:374-381, queried through a cKDTree at :766 / :797) -- O(log n) per value instead of a dense scan
+    of a day-long grid per window; any other grid takes the dense scan."""
+    grid = np.asarray(grid, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    n = grid.shape[0]
+    if ascending is None:
+        ascending = is_ascending(grid)
+    if n < 2 or not ascending:
+        return np.abs(grid.reshape(-1, 1) - values.reshape(1, -1)).argmin(0)
+    hi = np.clip(np.searchsorted(grid, values, side="left"), 0, n - 1)
+    lo = np.clip(hi - 1, 0, n - 1)
+    take_lo = np.abs(grid[lo] - values) <= np.abs(grid[hi] - values)
+    idx = np.where(take_lo, lo, hi)
+    # equal grid entries: argmin returns the first of them
+    first = np.searchsorted(grid, grid[idx], side="left")
+    return first.astype(np.int64)
+
+
+def window_columns(tsteps_abs, t0, offsets, drop_last, ascending=None):
     """Columns of `Out_2` one window adds to, as process_continuous_days.py:766,797-805 finds them: the window start is first
     SNAPPED to its nearest `tsteps_abs` entry (`tree_tsteps.query`, :766), the nine offsets are added to that entry and
     looked up again (:797), the last one is dropped for step_size 'half' (:802-803). numpy's `Out_2[:, cols] += vals` writes
     a column that appears twice only once (the LAST occurrence wins), so duplicates are reduced to their last occurrence.
     Returns (cols int64 [m], keep int64 [m]: offset index feeding each column)."""
     tsteps_abs = np.asarray(tsteps_abs, dtype=np.float64)
-    i0 = int(np.abs(tsteps_abs - t0).argmin())
-    ip = np.abs(tsteps_abs.reshape(-1, 1) - (tsteps_abs[i0] + np.asarray(offsets)).reshape(1, -1)).argmin(0)
+    if ascending is None:
+        ascending = is_ascending(tsteps_abs)          # (loops over many windows pass it: one O(n) check per grid, not per window)
+    i0 = int(nearest_index(tsteps_abs, np.asarray([t0], dtype=np.float64), ascending)[0])
+    ip = nearest_index(tsteps_abs, tsteps_abs[i0] + np.asarray(offsets, dtype=np.float64), ascending)
     if drop_last:
         ip = ip[:-1]
     keep = np.array([k for k in range(len(ip)) if ip[k] not in ip[k + 1:]], dtype=np.int64)
@@ -94,6 +122,7 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
     tq = torch.from_numpy(offsets.reshape(-1, 1)).float().to(dev)
     embed = embed or (lambda picks, t0: synthetic.make_slice_mask(geom, picks, t0))
     drop_last = step_size == "half"
+    asc = is_ascending(tsteps_abs)
     used = []
     with torch.no_grad():
         for t0 in times:
@@ -104,7 +133,7 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
             Slice, Mask = embed(P[sel], t0)
             y, x = net.forward_fixed_source(torch.from_numpy(Slice).to(dev), torch.from_numpy(Mask).to(dev), None, None, None,
                                             locs, xg, xq, tq)
-            cols, keep = window_columns(tsteps_abs, t0, offsets, drop_last)
+            cols, keep = window_columns(tsteps_abs, t0, offsets, drop_last, asc)
             Out_2.index_add_(1, torch.from_numpy(cols).to(dev), x[:, torch.from_numpy(keep).to(dev), 0] / (n_overlap * n_grids))
     return Out_2, np.asarray(used)
 
@@ -143,7 +172,8 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     hi = np.searchsorted(Ps[:, 0], times + max_t + 2.0 * kernel_sig_t, side="left")               # strict <
     nonempty = hi > lo                                                                             # process_continuous_days.py:792-793
     times, lo, hi = times[nonempty], lo[nonempty], hi[nonempty]
-    wc = [window_columns(tsteps_abs, t0, offsets, drop_last) for t0 in times]
+    asc = is_ascending(tsteps_abs)
+    wc = [window_columns(tsteps_abs, t0, offsets, drop_last, asc) for t0 in times]
     n_off = len(offsets) - (1 if drop_last else 0)
     if all(len(k) == n_off for _, k in wc):            # the usual case: no duplicate column inside a window
         cols = torch.from_numpy(np.stack([c_ for c_, _ in wc]) if wc else np.zeros((0, n_off), dtype=np.int64)).to(dev)

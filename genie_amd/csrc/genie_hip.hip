@@ -55,11 +55,6 @@
                            // spills and more rows in flight than L2 keeps: 0.313 vs 0.302 ms, fabric reads +50 %)
 #endif
 
-// GENIE_PHASES=1 (with GENIE_TUNING=1): s_memtime phase timers inside the stage kernels (GENIE_ABLATE bit 10); they cost registers
-#ifndef GENIE_PHASES
-#define GENIE_PHASES 0
-#endif
-
 #ifndef GENIE_S1_PK
 #define GENIE_S1_PK 0      // k_stage1_b3: packed fp32 adds in the neighbour accumulate (measured: see DESIGN.md section 5)
 #endif
@@ -411,40 +406,6 @@ void build_b3_table(std::vector<int32_t>& tbl) {
     int32_t* scal = bias + B3_NBIAS * 32;
     const int sv[6] = {W_DA_ACT, W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22};
     for (int k = 0; k < 6; ++k) scal[k] = g_params[sv[k]].off;
-}
-
-// STAGE 2, bf16x3 form (k_stage2_b3): Bipartite fc1 on x_latent in the 32-slot layout [o1 (15), 0, o2 (15), 0] of the c rows.
-// Fragments: ks*3 + piece (K-steps 0,1 of that block), then 6 + m: [W1|W1], [W2|W2], [W1|W3] of the 3 edge_attr columns.
-constexpr int B3S2_FRAGS = 9;
-constexpr int B3S2_IMG_FLOATS = B3S2_FRAGS * 256 + 32 + 16;
-constexpr int B3S2_TBL = B3S2_FRAGS * 512 + 32 + 16;
-
-void build_b3_table_stage2(std::vector<int32_t>& tbl) {
-    tbl.assign(B3S2_TBL, -1);
-    auto put = [&](int f, int i, int h, int e, int piece, int off) {
-        tbl[((size_t)f * 64 + (h * 32 + i)) * 8 + e] = off < 0 ? -1 : (off | (piece << 28));
-    };
-    const int W = g_params[W_BP_FC1_W].off;
-    for (int i = 0; i < 32; ++i)
-        for (int h = 0; h < 2; ++h)
-            for (int e = 0; e < 8; ++e) {
-                for (int kb = 0; kb < 2; ++kb) {
-                    const int ch = 16 * kb + 8 * (e >> 2) + 4 * h + (e & 3);
-                    int col = -1;
-                    if (ch < 15) col = ch;
-                    else if (ch >= 16 && ch < 31) col = 15 + (ch - 16);
-                    const int off = (i < 30 && col >= 0) ? W + i * 33 + col : -1;
-                    for (int piece = 0; piece < 3; ++piece) put(kb * 3 + piece, i, h, e, piece, off);
-                }
-                const int offe = (i < 30 && e < 3) ? W + i * 33 + 30 + e : -1;
-                put(6, i, h, e, 0, offe);
-                put(7, i, h, e, 1, offe);
-                put(8, i, h, e, h == 0 ? 0 : 2, offe);
-            }
-    int32_t* tail = tbl.data() + (size_t)B3S2_FRAGS * 512;
-    for (int i = 0; i < 30; ++i) tail[i] = g_params[W_BP_FC1_B].off + i;
-    tail[32] = g_params[W_DA_ACT2].off;
-    tail[33] = g_params[W_BP_ACT1].off;
 }
 
 void build_plans(StagePlan& p1, StagePlan& p2) {
@@ -932,10 +893,6 @@ struct DaArgs {
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_b3: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
-    int* dyn;                  // dynamic work distribution (k_stage1_b3, k_stage2_fast): [8] per-XCD item counters of THIS launch,
-    int* dyn_next;             // ... and the set the next launch of this kind will use (zeroed by this one), or null = static
-    int dyn_batch;             // items a wave claims per atomic
-    int dyn_gw;                // workgroups per group sharing one counter (0 = a whole XCD)
     float* save;               // training forward (generic kernels): pre-activations kept for the backward passes, 16-float blocks
                                // [SV_*][P][16] (genie_da_train_fwd), or null
     const float* slope2;       // stage 2: PReLU slope to use instead of the image's (association heads), or null
@@ -961,9 +918,7 @@ struct ItemIter {
         return q;
     }
     static __device__ __forceinline__ unsigned recip(unsigned d) { return d <= 1u ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
-    // gw > 0: the workgroups of an XCD are split into GROUPS of gw; a group owns a contiguous sub-chunk of the XCD's chunk and
-    // iterates (or, with dynamic claims, shares a counter) only among its own workgroups
-    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0, int gw = 0) {
+    __device__ ItemIter(int G, int T_, int seg_, int nxcd, int wave, int gi0 = 0) {
         const int nx = (nxcd > 1 && gridDim.x >= nxcd && (gridDim.x % nxcd) == 0) ? nxcd : 1;
         const int xcd = blockIdx.x % nx;
         int lb = blockIdx.x / nx, nbx = gridDim.x / nx;
@@ -971,16 +926,6 @@ struct ItemIter {
         gbeg = gi0 + (int)((long long)G * xcd / nx);
         gend = gi0 + (int)((long long)G * (xcd + 1) / nx);
         chunk_ = xcd; lead_ = lb == 0;
-        if (gw > 0 && nbx > gw) {
-            const int ng = (nbx + gw - 1) / gw, grp = lb / gw;
-            const int n = gend - gbeg, b0 = gbeg;
-            gbeg = b0 + (int)((long long)n * grp / ng);
-            gend = b0 + (int)((long long)n * (grp + 1) / ng);
-            nbx = min(gw, nbx - grp * gw);
-            lb -= grp * gw;
-            chunk_ = xcd + nx * grp;
-            lead_ = lb == 0;
-        }
         T = T_;
         seg = seg_;
         nitems = (long long)(gend - gbeg) * T;
@@ -1007,27 +952,6 @@ struct ItemIter {
         gi = gbeg + (int)(sidx * (unsigned)seg) + (int)r2;
     }
 };
-
-// Dynamic work distribution of the persistent P-sized kernels. With a static partition (item = first + k * stride) a workgroup
-// that loses its CU for a while to a G-sized tail kernel of the previous window (window pipeline) finishes late and the whole
-// launch waits for it; with per-XCD item counters a delayed wave simply claims fewer batches. One relaxed atomic per batch and
-// wave, on a counter only the workgroups of one XCD touch (it stays in that XCD's L2). The counters of a launch are zeroed by
-// the PREVIOUS launch of the same kind (two alternating sets), so no extra launch and no host round trip.
-constexpr int DYN_NCTR_DEV = 1024;
-__device__ __forceinline__ long long dyn_claim(int* ctr, int batch, int lane) {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(ctr, batch);
-    return (long long)__builtin_amdgcn_readfirstlane(v);
-}
-// the same split in two: the atomic is issued where the item will be needed an item later, its result is read (and only
-// then waited for) at the point of use, so a claim costs its issue slot and not the ~1 us round trip. One item per claim keeps
-// the concurrently processed items of an XCD as contiguous as the static round-robin does (neighbour rows shared in L2).
-__device__ __forceinline__ int dyn_claim_issue(int* ctr, int lane) {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(ctr, 1);
-    return v;
-}
-__device__ __forceinline__ long long dyn_claim_value(int v) { return (long long)__builtin_amdgcn_readfirstlane(v); }
 
 // Neighbour sum of PReLU_s(init_trns [Slice || Mask]) with the 30-channel hidden state RECOMPUTED from the raw
 // 8 input floats of every neighbour (2 k-steps x 2 out tiles = 4 MFMAs) instead of gathered from memory: a
@@ -1419,205 +1343,6 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
     }
 }
 
-// Fast stage 1 for UNIFORM-degree graphs with exactly KS station and KP source neighbours per node (the
-// reference's kNN graphs: k_sta_edges = 8, k_spc_edges = 15, config.yaml:79-80). Same arithmetic in the same
-// order as k_stage1 (bitwise identical results), software-pipelined across tiles: while tile i runs its ~180
-// dense MFMAs the 2*(1+KS+KP) raw dwords of tile i+1 are already in flight, and the neighbour ids of tile i+2
-// are fetched one tile ahead, so no memory round trip sits on the critical path.
-template <bool LE1>
-__device__ __forceinline__ void nbr_pipe_step(f32x4& h_a, f32x4& h_b, bool has_next, float xs, float xm, f32x4 wi0, f32x4 wi1,
-                                              f32x4 bi0, f32x4 bi1, float slope, f32x4& s0, f32x4& s1) {
-    // one step of the 1-deep MFMA/VALU software pipeline over neighbours: issue the 4 MFMAs of the NEXT neighbour,
-    // then PReLU + accumulate the CURRENT one while they run; fences keep the compiler from hoisting every MFMA first
-    // (empty asm statements are ordered among themselves and pin the operands they touch: the next neighbour's
-    // MFMAs cannot be hoisted above the previous accumulate, so at most two neighbours' results are ever alive;
-    // __builtin_amdgcn_sched_barrier alone did not stop hipcc from issuing all 4*(KS+KP) MFMAs up front)
-    // The PReLU + accumulate of the current neighbour is cut into four 2-channel chunks and one chunk is pinned behind
-    // each MFMA, so a single wave keeps the matrix pipe busy (an in-order wave that issues its 4 MFMAs back to back
-    // sits in the issue queue for 3 x 32 cycles and only then starts its ~20 VALU ops: 65 % pipe utilisation).
-    f32x4 g_a = h_a, g_b = h_b;
-#define GENIE_CHUNK(S, H, c0, c1)                                                    \
-    {                                                                                \
-        const float t0 = H[c0] * slope, t1 = H[c1] * slope;                          \
-        S[c0] += LE1 ? fmaxf(H[c0], t0) : fminf(H[c0], t0);                          \
-        S[c1] += LE1 ? fmaxf(H[c1], t1) : fminf(H[c1], t1);                          \
-    }
-    if (has_next) {
-        asm volatile("" : "+v"(xs), "+v"(xm));
-        g_a = MFMA16(wi0.x, xs, bi0);
-        GENIE_CHUNK(s0, h_a, 0, 1)
-        asm volatile("" : "+v"(s0), "+v"(xs));
-        g_b = MFMA16(wi1.x, xs, bi1);
-        GENIE_CHUNK(s0, h_a, 2, 3)
-        asm volatile("" : "+v"(s0), "+v"(xm));
-        g_a = MFMA16(wi0.y, xm, g_a);
-        GENIE_CHUNK(s1, h_b, 0, 1)
-        asm volatile("" : "+v"(s1), "+v"(xm));
-        g_b = MFMA16(wi1.y, xm, g_b);
-        GENIE_CHUNK(s1, h_b, 2, 3)
-    } else {
-        GENIE_CHUNK(s0, h_a, 0, 1)
-        GENIE_CHUNK(s0, h_a, 2, 3)
-        GENIE_CHUNK(s1, h_b, 0, 1)
-        GENIE_CHUNK(s1, h_b, 2, 3)
-    }
-#undef GENIE_CHUNK
-    asm volatile("" : "+v"(s0), "+v"(s1));
-    h_a = g_a; h_b = g_b;
-}
-
-template <int KS, int KP, bool LE11, bool LE12>
-__device__ __forceinline__ void stage1_fast_loop(const DaArgs& a, const f32x4* lw, const float* lbias, int lane_in,
-                                                 int wave, float a0, float a1, float a21, float a22, float s11, float s12) {
-    static_assert(KP > 8 && KP <= 16, "source-neighbour count handled as chunks of 8 and KP-8");
-    int lane = lane_in;
-    const int j = lane & 15, q = lane >> 4;
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    if (w.it >= w.nitems) return;
-    // 32-bit BYTE offsets from the (uniform) array bases: one VGPR per address (the host only selects this kernel
-    // when n_grid_ext * n_sta * 16 B < 4 GiB)
-    const char* sl = (const char*)a.slice;
-    const char* mk = (const char*)a.mask;
-    const unsigned q4 = 4u * (unsigned)q;
-
-    // tile descriptor of the tile being computed (c) and of the next one (n)
-    int g_c, sc_c, g_n = 0, sc_n = 0;
-    bool valid_c, valid_n = false;
-    int sta_n[KS];          // station-neighbour ids of the next tile
-    int srcv_c, srcv_n = 0; // lane k holds source-neighbour id k
-    float os_c, om_c, ss_c[KS], sm_c[KS];   // own + station-neighbour raw inputs of the current tile (prefetched)
-    float os_n = 0.f, om_n = 0.f, ss_n[KS], sm_n[KS];
-
-    auto decode = [&](long long item, int& g, int& sc, bool& valid) {
-        int gi, tb;
-        w.decode(item, gi, tb);
-        g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        const int s = tb * 16 + j;
-        valid = s < S;
-        sc = valid ? s : S - 1;
-    };
-    // prologue: everything of tile 0 that later tiles get prefetched
-    decode(w.it, g_c, sc_c, valid_c);
-    {
-        const unsigned gS = (unsigned)g_c * (unsigned)S;
-        const unsigned oo = (gS + (unsigned)sc_c) * 16u + q4;
-        os_c = *(const float*)(sl + oo);
-        om_c = *(const float*)(mk + oo);
-        srcv_c = a.src_col[(long long)g_c * KP + min(lane_in & 15, KP - 1)];
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const unsigned o = (gS + (unsigned)a.sta_col[sc_c * KS + k]) * 16u + q4;
-            ss_c[k] = *(const float*)(sl + o);
-            sm_c[k] = *(const float*)(mk + o);
-        }
-    }
-    for (;;) {
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));
-#endif
-        const bool has_next = w.it + w.stride < w.nitems;
-        // (1) ids of the NEXT tile (consumed before the dense phase of this one)
-        if (has_next) {
-            decode(w.it + w.stride, g_n, sc_n, valid_n);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) sta_n[k] = a.sta_col[sc_n * KS + k];
-            srcv_n = a.src_col[(long long)g_n * KP + min(lane_in & 15, KP - 1)];
-        }
-        // (2) first 8 source neighbours of THIS tile: in flight while own + station neighbours are computed
-        const unsigned so = (unsigned)sc_c * 16u + q4;
-        const unsigned gstride = (unsigned)S * 16u;
-        float rs1[8], rm1[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned o = (unsigned)__builtin_amdgcn_readlane(srcv_c, k) * gstride + so;
-            rs1[k] = *(const float*)(sl + o);
-            rm1[k] = *(const float*)(mk + o);
-        }
-        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
-        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-        // own hidden state
-        f32x4 x0 = MFMA16(wi0.x, os_c, bi0), x1 = MFMA16(wi1.x, os_c, bi1);
-        x0 = MFMA16(wi0.y, om_c, x0);
-        x1 = MFMA16(wi1.y, om_c, x1);
-        x0 = prelu4u(x0, a0);
-        x1 = prelu4u(x1, a0);
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f}, n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
-        // station neighbours (raw inputs prefetched one tile ago)
-        f32x4 h_a = MFMA16(wi0.x, ss_c[0], bi0), h_b = MFMA16(wi1.x, ss_c[0], bi1);
-        h_a = MFMA16(wi0.y, sm_c[0], h_a);
-        h_b = MFMA16(wi1.y, sm_c[0], h_b);
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-            nbr_pipe_step<LE11>(h_a, h_b, true, k + 1 < KS ? ss_c[k + 1 < KS ? k + 1 : 0] : rs1[0],
-                                k + 1 < KS ? sm_c[k + 1 < KS ? k + 1 : 0] : rm1[0], wi0, wi1, bi0, bi1, s11, n1a, n1b);
-        // (3) remaining source neighbours: in flight while the first 8 are computed
-        float rs2[KP - 8], rm2[KP - 8];
-#pragma unroll
-        for (int k = 0; k < KP - 8; ++k) {
-            const unsigned o = (unsigned)__builtin_amdgcn_readlane(srcv_c, 8 + k) * gstride + so;
-            rs2[k] = *(const float*)(sl + o);
-            rm2[k] = *(const float*)(mk + o);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            nbr_pipe_step<LE12>(h_a, h_b, true, k + 1 < 8 ? rs1[k + 1 < 8 ? k + 1 : 0] : rs2[0],
-                                k + 1 < 8 ? rm1[k + 1 < 8 ? k + 1 : 0] : rm2[0], wi0, wi1, bi0, bi1, s12, n2a, n2b);
-#pragma unroll
-        for (int k = 0; k < KP - 8; ++k)
-            nbr_pipe_step<LE12>(h_a, h_b, k + 1 < KP - 8, rs2[k + 1 < KP - 8 ? k + 1 : 0], rm2[k + 1 < KP - 8 ? k + 1 : 0], wi0,
-                                wi1, bi0, bi1, s12, n2a, n2b);
-        {
-            const float i1 = 1.f / (float)KS, i2 = 1.f / (float)KP;
-            n1a *= i1; n1b *= i1; n2a *= i2; n2b *= i2;
-        }
-        // (4) own + station-neighbour raw inputs of the NEXT tile: in flight during the dense phase
-        if (has_next) {
-            const unsigned gS = (unsigned)g_n * (unsigned)S;
-            const unsigned oo = (gS + (unsigned)sc_n) * 16u + q4;
-            os_n = *(const float*)(sl + oo);
-            om_n = *(const float*)(mk + oo);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const unsigned o = (gS + (unsigned)sta_n[k]) * 16u + q4;
-                ss_n[k] = *(const float*)(sl + o);
-                sm_n[k] = *(const float*)(mk + o);
-            }
-        }
-        // (5) dense tail + stores of this tile
-        stage1_dense(a, lw, lbias, lane, q, valid_c, (long long)g_c * S + sc_c, g_c, sc_c, om_c, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
-        if (!has_next) break;
-        g_c = g_n; sc_c = sc_n; valid_c = valid_n; srcv_c = srcv_n; os_c = os_n; om_c = om_n;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) { ss_c[k] = ss_n[k]; sm_c[k] = sm_n[k]; }
-        w.it += w.stride;
-    }
-}
-
-constexpr int S1F_THREADS = 512;   // 8 waves share one 54-KB weight image: ONE workgroup per CU gives the same 8 waves / CU
-                                   // as two 256-thread ones but leaves 106 KB of LDS free for the tail kernels of the
-                                   // previous window running on a second stream
-template <int KS, int KP>
-__global__ __launch_bounds__(S1F_THREADS) void k_stage1_fast(DaArgs a) {
-    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += S1F_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
-    const float* lscal = lbias + G1_BIAS * 16;
-    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
-    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (s11 <= 1.f) {
-        if (s12 <= 1.f) stage1_fast_loop<KS, KP, true, true>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
-        else stage1_fast_loop<KS, KP, true, false>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
-    } else {
-        if (s12 <= 1.f) stage1_fast_loop<KS, KP, false, true>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
-        else stage1_fast_loop<KS, KP, false, false>(a, lw, lbias, lane, wave, a0, a1, a21, a22, s11, s12);
-    }
-}
-
 // the KS station-neighbour ids of one station as wide loads: a dword load whose lanes hit 16 different 32-B segments costs the
 // texture path about as much as two and a half full 1-KB row loads (tools/: skeleton ablations of k_stage2_fast), and a tile
 // issued KS of them
@@ -1821,7 +1546,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
     const bool hi = h != 0;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, a.dyn != nullptr ? a.dyn_gw : 0);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     const char* xs = (const char*)a.xs;
     // lane h = 0 loads [x1 ; x3], lane h = 1 loads [x2 ; x1]: plane offsets of its two pieces
     const off_t_ la = hi ? (off_t_)a.xs_plane : (off_t_)0, lb = hi ? (off_t_)0 : (off_t_)(2 * a.xs_plane);
@@ -1847,25 +1572,12 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     };
     int idv = 0, sc = 0, sta_id[KS];
     bool valid = false;
-    // item stream of this wave: static (first + k * stride) or dynamic batches claimed from the XCD's counter
-    const bool dyn = a.dyn != nullptr;
-    const long long npairs = (w.nitems + 1) / 2;
-    int* ctr = dyn ? a.dyn + w.chunk_ : nullptr;
-    if (dyn && blockIdx.x == 0)      // the whole set the next launch of this kind will claim from (its chunk count may differ)
-        for (int i = threadIdx.x; i < DYN_NCTR_DEV; i += blockDim.x) a.dyn_next[i] = 0;
-    long long pit0 = w.it;
-    if (dyn) pit0 = dyn_claim(ctr, 1, lane);
+    // item stream of this wave: static (first + k * stride). Dynamic claims from per-XCD / per-group counters were measured and
+    // dropped (counters saturate, or batches destroy the L2 sharing of neighbour rows)
+    const long long pit0 = w.it;
     if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
-#if GENIE_TUNING && GENIE_PHASES
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define PH1(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
-#else
-#define PH1(k) do { } while (0)
-#endif
     for (long long pit = pit0, pnext = 0; 2 * pit < w.nitems; pit = pnext) {
         asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park all 75 in VGPRs)
-        PH1(0);
-        const int claim = dyn ? dyn_claim_issue(ctr, lane) : 0;          // read after the neighbour phase
         const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
         const int g = half ? g1 : g0;
         const long long p = (long long)g * S + sc;
@@ -1953,10 +1665,9 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         bool valid_n = false;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_n[k] = 0;
-        pnext = dyn ? dyn_claim_value(claim) : pit + w.stride;
+        pnext = pit + w.stride;
         const bool has_next = 2 * pnext < w.nitems;
         if (has_next) fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
-        PH1(1);
         if (a.dbg_h0 != nullptr && valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -2004,7 +1715,6 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         acc[0] = prelu16(acc[0], a1, sel1);
         acc[1] = prelu16(acc[1], a1, sel1);
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
-        PH1(2);
         if (a.dbg_h1 != nullptr && valid) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -2047,7 +1757,6 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
         o3[0] = prelu16(o3[0], a21, sel21);
         o3[1] = prelu16(o3[1], a22, sel22);
         asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
-        PH1(3);
         // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
         //      (the u K-steps only reach rows 0..14, the v K-steps rows 16..30: two independent accumulator chains)
         f32x16 ow[2];
@@ -2079,16 +1788,10 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
                     f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
             }
         }
-        PH1(4);
         idv = idv_n; sc = sc_n; valid = valid_n;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
     }
-#if GENIE_TUNING && GENIE_PHASES
-    if (ABL(a, 10) && a.x_latent != nullptr && (threadIdx.x & 63) == 0)      // x_latent is unused by stage 1: timer dump
-        for (int k = 0; k < 5; ++k) a.x_latent[(blockIdx.x * 8 + wave) * 8 + k] = (float)tph[k];
-#endif
-#undef PH1
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2255,202 +1958,6 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     }
 }
 
-// Fast stage 2 for uniform-degree graphs (KS station / KP source neighbours), software-pipelined across tiles: the
-// 1 + KS + KP row loads of tile i+1 are issued BEFORE the MFMA / shuffle phase of tile i, and the ids of tile i+2 are
-// fetched one iteration earlier still, so no memory round trip sits on a wave's critical path. (Without this every wave
-// of a CU moves through "load, wait, compute" in lockstep: the texture path and the VALU take turns instead of
-// overlapping, and the kernel ran 0.33 ms regardless of occupancy or cache hit rate.) Same arithmetic and summation order
-// as k_stage2 (bitwise identical).
-template <int KS, int KP>
-__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_fast(DaArgs a) {
-    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
-    const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, a.dyn != nullptr ? a.dyn_gw : 0);
-    // item stream of this wave: static (first + k * stride) or single items claimed from its group's counter (see dyn_claim)
-    const bool dyn = a.dyn != nullptr;
-    int* ctr = dyn ? a.dyn + w.chunk_ : nullptr;
-    if (dyn && blockIdx.x == 0)      // the whole set the next launch of this kind will claim from (its chunk count may differ)
-        for (int i = threadIdx.x; i < DYN_NCTR_DEV; i += blockDim.x) a.dyn_next[i] = 0;
-    long long i0 = dyn ? dyn_claim(ctr, 1, lane) : w.it;
-    if (i0 >= w.nitems) return;
-    long long i1 = dyn ? dyn_claim(ctr, 1, lane) : i0 + w.stride, i2 = w.nitems;
-    int claim = 0;                                          // pending claim of the item after next (dynamic mode)
-    bool pending = false;
-    const char* wub = (const char*)a.wu;
-    const char* wvb = (const char*)a.wv;
-    const unsigned q16 = 16u * (unsigned)q;          // byte offset of this lane's 4 channels inside a 64-B row
-
-    // ids of a tile: idv = row of src_tab (lane j = 0: source node, j = 1..KP: its source neighbours), station-neighbour ids
-    struct Ids { int idv, sc, su, tb; bool valid; int sta[KS]; };     // su = the caller's id of station sc (Mask, edge_attr, x_latent)
-    auto fetch_ids = [&](long long item, Ids& t) {
-        int gi;
-        w.decode(a.rev ? w.nitems - 1 - item : item, gi, t.tb);
-        t.idv = a.src_tab[gi * 16 + j];
-        const int s = t.tb * 16 + j;
-        t.valid = s < S;
-        t.sc = t.valid ? s : S - 1;
-        t.su = a.sta_user != nullptr ? a.sta_user[t.sc] : t.sc;
-        load_sta_ids<KS>(a.sta_col, t.sc, t.sta);
-    };
-    struct Rows { f32x4 o[2]; float mq, eq; f32x4 ru[KS], rv[KP]; };
-    // The row loads of a tile are issued in three bursts (part 0: c, Mask, edge_attr and the KS station rows; parts 1, 2: the
-    // source rows) placed BETWEEN the compute chunks of the previous tile. Every wave of a CU runs the same loop, so a single
-    // 38-load burst makes all of them queue on the texture path at once and then all compute at once (measured: half of a
-    // wave's time went into issuing loads); short bursts let the texture path and the VALU / MFMA work overlap.
-    // `tk` is an ordering token: it passes through an empty asm statement after the preceding compute chunk, so the loads
-    // that add it to their address cannot be hoisted above that chunk.
-    auto issue = [&](const Ids& t, Rows& r, int part, unsigned tk) {
-        const int g = __builtin_amdgcn_readlane(t.idv, 0);
-        if (part == 0) {
-            long long p = (long long)g * S + t.sc;
-            if (ABL(a, 9)) p &= 4095;     // tuning: streamed rows (c, Mask, edge_attr) from a cache-resident region
-            r.o[0] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 4 * q + tk);
-            r.o[1] = ABL(a, 5) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
-            if (a.sta_user != nullptr) {
-                // the message mask max_k Mask[p][k] as left by the split pass, edge_attr from its processing-order copy when one
-                // is registered: both contiguous over the 16 stations of the tile
-                const long long pu = (long long)g * S + t.su;
-                r.mq = q == 0 ? a.mm_int[p + tk] : -INFINITY;         // the q lanes are max-reduced below
-                r.eq = q < 3 ? (a.ea_int != nullptr ? a.ea_int[p * 3 + q + tk] : a.edge_attr[pu * 3 + q + tk]) : 0.f;
-            } else {
-                r.mq = a.mask[p * 4 + q + tk];
-                r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
-            }
-            // wave-uniform 64-bit row-block bases (SGPR pairs) + 32-bit lane offsets: safe for P x 64 B >= 4 GiB (config 4)
-            const char* wug = wub + (size_t)g * (size_t)S * 64u;
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-                r.ru[k] = ABL(a, 0) ? r.o[0] : *(const f32x4*)(wug + ((unsigned)t.sta[k] * 64u + q16 + tk));
-        } else {
-            const unsigned so = (unsigned)t.sc * 64u + q16 + tk;
-            constexpr int KH = (KP + 1) / 2;
-#pragma unroll
-            for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k) {
-                const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((size_t)S * 64u);
-                r.rv[k] = ABL(a, 1) ? r.o[1] : *(const f32x4*)(wvk + so);
-            }
-        }
-    };
-#if GENIE_TUNING && GENIE_PHASES
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define PH(k) do { if (ABL(a, 10)) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
-#else
-#define PH(k) do { } while (0)
-#endif
-    Ids cur, nxt, nn;
-    Rows rows;
-    fetch_ids(i0, cur);
-    nxt = cur;
-    if (i1 < w.nitems) {
-        fetch_ids(i1, nxt);
-        if (dyn) { claim = dyn_claim_issue(ctr, lane); pending = true; } else i2 = i1 + w.stride;
-    }
-    issue(cur, rows, 0, 0u);
-    issue(cur, rows, 1, 0u);
-    issue(cur, rows, 2, 0u);
-    for (;;) {
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));
-#endif
-        const bool has_next = i1 < w.nitems;
-        const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
-        const long long p = (long long)g_c * S + cur.sc;
-        PH(0);
-        // (1) consume the rows of this tile: neighbour means of the projected operands, in edge order
-        f32x4 o[2] = {rows.o[0], rows.o[1]};
-        const float mq = rows.mq, eq = rows.eq;
-        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KS; ++k) n1 += rows.ru[k];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
-        asm volatile("" : "+v"(n1), "+v"(n2), "+v"(o[0]), "+v"(o[1]));
-        PH(1);
-        // (2) first burst of the next tile's rows
-        unsigned tk = 0u;
-        asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
-        if (has_next) issue(nxt, rows, 0, tk);
-        PH(2);
-        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, o[0]), a2);
-        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, o[1]), a2);
-        if (a.x_latent != nullptr && cur.valid) {
-            float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (4 * q + r < 15) {
-                    xl[4 * q + r] = o[0][r];
-                    xl[15 + 4 * q + r] = o[1][r];
-                }
-            }
-        }
-        f32x4 bp[2];
-        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-        nn = nxt;
-        if (a.no_bip) {
-            if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
-            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
-            if (i2 < w.nitems) fetch_ids(i2, nn);
-        } else if (!ABL(a, 6)) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-                bp[t] = prelu4u(bp[t], ab1);
-                // (3) second / third burst, behind the first / second output tile of fc1
-                asm volatile("" : "+v"(tk), "+v"(bp[t]));
-                if (has_next) issue(nxt, rows, 1 + t, tk);
-            }
-            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
-            if (i2 < w.nitems) fetch_ids(i2, nn);
-            PH(3);
-            float mm = fmaxf(mq, __shfl_xor(mq, 16));
-            mm = fmaxf(mm, __shfl_xor(mm, 32));
-            if (!cur.valid) mm = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 v = bp[t] * mm;
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    v.x += __shfl_xor(v.x, d);
-                    v.y += __shfl_xor(v.y, d);
-                    v.z += __shfl_xor(v.z, d);
-                    v.w += __shfl_xor(v.w, d);
-                }
-                if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 16 * t + 4 * q) = v;
-            }
-        } else {
-            if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
-            if (pending) { i2 = dyn_claim_value(claim); pending = false; }
-            if (i2 < w.nitems) fetch_ids(i2, nn);
-            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 4 * q) = o[0] + o[1] + mq + eq;
-        }
-        PH(4);
-        if (!has_next) break;
-        cur = nxt;
-        nxt = nn;
-        i0 = i1; i1 = i2; i2 = w.nitems;
-        if (i1 < w.nitems) {
-            if (dyn) { claim = dyn_claim_issue(ctr, lane); pending = true; } else i2 = i1 + w.stride;
-        }
-    }
-#if GENIE_TUNING && GENIE_PHASES
-    if (ABL(a, 10) && a.dbg_h0 != nullptr && lane == 0)
-        for (int k = 0; k < 5; ++k) a.dbg_h0[(blockIdx.x * 4 + wave) * 8 + k] = (float)tph[k];
-#endif
-#undef PH
-}
-
 // k_stage2_fast for the production configuration (uniform-degree graphs, station processing order with a registered static
 // edge_attr, static item stream, Bipartite half on), straight-line: the ISA of k_stage2_fast spends a fifth of its vector
 // instructions on register copies at the joins of its option branches (the 15 source rows were copied out and back every tile),
@@ -2474,33 +1981,22 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
     v = dpp_add<0x108>(v);
     return v;
 }
-// SCHED: where the three load bursts of the next tile sit among the compute chunks of this one. 0: after the neighbour sums /
-// the first / the second fc1 output tile; 1: the first two bursts after the sums, the third after the first fc1 tile; 2: all
-// three after the sums
-// SCHED 3 (workgroups of 8 waves): PHASED. Identical persistent waves fall into lockstep -- all of them issue their loads at
-// once (the texture path works, the SIMDs idle), then all compute (the reverse); measured time = the SUM of the two. Here
-// the waves of a workgroup are two groups half an iteration apart, held there by two workgroup barriers per tile: while waves
-// 0-3 (one per SIMD) consume their rows and issue the next tile's loads, waves 4-7 run their MFMA / reduction phase, and
-// vice versa, so the texture path always has one group's loads to work on. Every wave runs the same number of iterations
-// (a wave that has run out of items repeats its last one: identical stores).
-// RL (row-layout loads): in the MFMA layout lane (j = lane & 15, q = lane >> 4) reads the 16-B chunk q of node j's row, so four
-// CONSECUTIVE lanes touch four different rows and the texture path works on 16 useful bytes per 64-B request (measured: the kernel
-// moved 24 B per clock and CU where contiguous row gathers reach 57). With RL every row is loaded in the layout lane = 4 r + cq
-// (node r = lane >> 2, chunk cq = lane & 3): four consecutive lanes read one 64-B row, sixteen consecutive source rows one
-// contiguous KB. Everything up to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the
-// gated mask then go through a 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1. Same arithmetic in
-// the same order: bitwise identical results.
-// NB: stop after x_latent (no Bipartite message / station sum): the last pass of the association heads (genie_assoc_fwd).
-// SD (stream depth 2, opt-in GENIE_S2_SD=1): the streamed rows (c, message mask, edge_attr: never in a cache, 7 % of the kernel in
-// the ablation) are loaded TWO tiles ahead into two alternating register sets (the loop is unrolled twice); the source node of the
-// tile after next comes from a wave-uniform load at the top of the tile. Measured SLOWER: the unrolled loop needs 246 VGPRs (150),
-// two workgroups per CU instead of three, 0.226 -> 0.240 ms.
-template <int KS, int KP, bool XL, int SCHED, bool RL = false, bool NB = false, bool SD = false>
-__global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
+// Row-layout loads: in the MFMA layout lane (j = lane & 15, q = lane >> 4) reads the 16-B chunk q of node j's row, so four
+// CONSECUTIVE lanes touch four different rows and the texture path works on 16 useful bytes per 64-B request (measured: 24 B per
+// clock and CU where contiguous row gathers reach 57). Every row is therefore loaded in the layout lane = 4 r + cq (node r = lane >> 2,
+// chunk cq = lane & 3): four consecutive lanes read one 64-B row, sixteen consecutive source rows one contiguous KB. Everything up
+// to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the gated mask then go through a
+// 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1.
+// XL: also store x_latent [P, 30] (caller's station order). NB: stop after x_latent (no Bipartite message / station sum): the
+// last pass of the association heads (genie_assoc_fwd).
+// Measured and dropped: other positions of the three load bursts (0.2627 / 0.2650 / 0.2649 ms), waves of a
+// workgroup phased half an iteration apart by barriers (0.262 -> 0.290), streamed rows two tiles ahead (246 VGPRs, 0.226 -> 0.240),
+// MFMA-layout loads (0.262 vs 0.226), station rows staged in LDS behind a barrier (0.282 -> 0.299 after a cold stage 1).
+template <int KS, int KP, bool XL, bool NB = false>
+__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    constexpr bool PH = SCHED == 3;
     __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[RL ? 4 * 16 * 36 : 4];
+    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
     for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
@@ -2509,10 +2005,10 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int jl = RL ? lane >> 2 : j, ql = RL ? lane & 3 : q;      // (node, chunk) this lane LOADS
-    float* ts = tsc + (RL ? wave * 16 * 36 : 0);
+    const int jl = lane >> 2, ql = lane & 3;      // (node, chunk) this lane LOADS
+    float* ts = tsc + wave * 16 * 36;
     const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0, 0);
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
     // a.wgmap: a workgroup takes BLOCKS of 4 consecutive source nodes of its XCD's chunk, wave k sweeps the tiles of the k-th
     // node of the block: the four waves of a CU then read the source-neighbour rows of four adjacent source nodes (half of
     // them shared) for the same station tile at about the same time, and every station row wu[g] is gathered on one CU only
@@ -2524,22 +2020,17 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         w.it = 0; w.stride = 1; w.nitems = (long long)n_my * a.T;
         w.lead_ = lb; w.chunk_ = nbx;                     // (reused as: first block, block stride)
     }
-    long long nmax = 0;                                    // PHASED: iterations of every wave of this workgroup
-    if (PH) {
-        const long long it0 = w.it - wave;                 // first item of the workgroup's wave 0
-        if (it0 >= w.nitems) return;                       // (uniform over the workgroup)
-        nmax = (w.nitems - it0 + w.stride - 1) / w.stride;
-    } else if (w.it >= w.nitems) return;
+    if (w.it >= w.nitems) return;
     const char* wub = (const char*)a.wu;
     const char* wvb = (const char*)a.wv;
     const unsigned q16 = 16u * (unsigned)ql;
     const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
     const unsigned m_T = ItemIter::recip((unsigned)a.T);
 
-    // item -> wave-uniform (processing position gi, station tile tb); per lane the clamped station and its validity
+    // item -> wave-uniform (processing position gi, station tile tb); every XCD's chunk is swept BACKWARDS: the c / wu / wv rows
+    // stage 1 wrote last (still in the Infinity Cache) are read first (0.278 -> 0.276 ms)
     auto item_of = [&](long long it, int& gi, int& tb) {
-        if (PH && it >= w.nitems) it = w.nitems - 1;
-        const long long itr = a.rev ? w.nitems - 1 - it : it;
+        const long long itr = w.nitems - 1 - it;
         if (a.wgmap) {
             unsigned rem;
             const unsigned kb = a.T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)a.T, m_T, rem);
@@ -2553,14 +2044,15 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     };
     struct Stream { f32x4 o[2]; float mq, eq; };                  // streamed rows of a tile: c, message mask, edge_attr
     struct Rows { f32x4 ru[KS], rv[KP]; } rows;                    // gathered rows
-    Stream sA, sB;
+    Stream sA;
     int sta[KS];
     auto load_ids = [&](int gi, int tb, int& idv) {
         idv = a.src_tab[gi * 16 + j];
         const int s = tb * 16 + jl;
         load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
     };
-    auto issue_s = [&](Stream& st, int g, int tb) {
+    auto issue0 = [&](Stream& st, int idv, int tb) {
+        const int g = __builtin_amdgcn_readlane(idv, 0);
         const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
         long long p = (long long)g * S + sc;
         if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
@@ -2568,10 +2060,6 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         st.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
         st.mq = NB ? 0.f : a.mm_int[p];
         st.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
-    };
-    auto issue0 = [&](Stream& st, int idv, int tb) {
-        const int g = __builtin_amdgcn_readlane(idv, 0);
-        if (!SD) issue_s(st, g, tb);
         const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
 #pragma unroll
         for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? st.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
@@ -2592,30 +2080,20 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
     int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
     item_of(it, gi_c, tb_c);
     load_ids(gi_c, tb_c, idv_c);
-    if (SD) issue_s(sA, __builtin_amdgcn_readlane(idv_c, 0), tb_c);
     issue0(sA, idv_c, tb_c);
     issue_v(idv_c, tb_c, 0, KP);
     {
         const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
         item_of(itn, gi_n, tb_n);
         load_ids(gi_n, tb_n, idv_n);
-        if (SD) issue_s(sB, __builtin_amdgcn_readfirstlane(a.src_tab[gi_n * 16]), tb_n);
     }
-    if (PH && wave >= 4) __syncthreads();                 // the second group runs half an iteration behind
-    long long iter = 0;
-    // one tile: `sx` holds its streamed rows (SD: loaded two tiles ago and refilled here for the tile after next; else loaded one
-    // tile ago like the gathers), `sn` receives the next tile's streamed rows when they travel with its gathers (!SD)
-    auto tile = [&](Stream& sx, Stream& sn) -> bool {
+    for (;;) {
         asm volatile("" : "+v"(lane));
         const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
-        const int s_c = tb_c * 16 + j;
-        const bool valid = s_c < S;
         const bool has_next = it + w.stride < w.nitems;
         const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
         int gi_2, tb_2, idv_2;
         item_of(it2, gi_2, tb_2);
-        int g_2 = 0;
-        if (SD) g_2 = __builtin_amdgcn_readfirstlane(a.src_tab[gi_2 * 16]);        // (in flight until the end of this tile)
         // (1) consume the rows of this tile: neighbour means of the projected operands in edge order, PReLU2 -> x_latent
         f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2623,13 +2101,13 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
 #pragma unroll
         for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
         f32x4 o[2];
-        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sx.o[0]), a2);
-        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sx.o[1]), a2);
-        float mq = sx.mq, eq = sx.eq;
-        const int s_l = tb_c * 16 + jl;              // the node this lane loaded (RL: not the node it holds in the MFMA layout)
+        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sA.o[0]), a2);
+        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sA.o[1]), a2);
+        float mq = sA.mq, eq = sA.eq;
+        const int s_l = tb_c * 16 + jl;              // the node this lane loaded (not the node it holds in the MFMA layout)
         const bool valid_l = s_l < S;
         const f32x4 ol0 = o[0], ol1 = o[1];
-        if (RL && !NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
+        if (!NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
             *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
             *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
             ts[jl * 36 + 32 + ql] = ql < 3 ? eq : (valid_l ? mq : 0.f);
@@ -2641,10 +2119,8 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
         }
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
         // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
-        issue0(sn, idv_n, tb_n);
-        if (SCHED >= 1 || NB) issue_v(idv_n, tb_n, 0, KH);
-        if (SCHED >= 2 || NB) issue_v(idv_n, tb_n, KH, KP);
-        if (PH) __syncthreads();
+        issue0(sA, idv_n, tb_n);
+        if (NB) issue_v(idv_n, tb_n, 0, KP);
         if (XL && valid_l) {
             const int su = a.sta_user[s_l];
             float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
@@ -2666,206 +2142,22 @@ __global__ __launch_bounds__(SCHED == 3 ? 512 : 256, SCHED == 3 ? 1 : GENIE_S2_W
             bp[t] = prelu4u(bp[t], ab1);
             // (3) second / third burst, behind the first / second output tile of fc1
             asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
-            if (SCHED == 0) { if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP); }
-            if (SCHED == 1 && t == 0) issue_v(idv_n, tb_n, KH, KP);
+            if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP);
         }
         // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
         load_ids(gi_2, tb_2, idv_2);
         // (5) mask gate and station sum of this tile
-        const float mm = RL ? mq : (valid ? mq : 0.f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (NB) break;
-            f32x4 v = bp[t] * mm;
+            f32x4 v = bp[t] * mq;
             v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
             if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
         }
-        // (6) SD: the streamed rows of the tile after next, into the registers this tile has just consumed
-        if (SD) issue_s(sx, g_2, tb_2);
-        if (PH) {
-            __syncthreads();
-            if (iter + 1 >= nmax) return false;
-        } else if (!has_next) return false;
-        ++iter;
+        if (!has_next) break;
         it += w.stride;
         idv_c = idv_n; tb_c = tb_n;
         idv_n = idv_2; tb_n = tb_2;
-        return true;
-    };
-    if (SD) { for (;;) { if (!tile(sA, sA)) break; if (!tile(sB, sB)) break; } }
-    else { while (tile(sA, sA)) {} }
-    if (PH && wave < 4) __syncthreads();
-}
-
-// Stage 2 with the station-neighbour operand staged in LDS. All T tiles of a source node gather their KS station-neighbour
-// rows from the SAME S rows wu[g] (64 B each): a workgroup takes NB consecutive source nodes of the processing order per
-// PHASE, copies their wu rows into LDS once (coalesced, each row read exactly once from memory), and its 4 waves then sweep
-// the NB * T tiles of the phase reading the station rows with ds_read_b128 instead of KS global gathers per lane; only the KP
-// source-neighbour rows of wv (and the streamed c / mask / edge_attr rows) still come through the texture path, software-
-// pipelined one tile ahead exactly as in k_stage2_fast. LDS image of a node: chunk (row r, part q) sits at chunk position
-// 4 r + (q ^ ((r >> 2) & 3)), so that rows r and r + 4 of one part do not meet on a bank. Same arithmetic and summation
-// order as k_stage2 / k_stage2_fast (bitwise identical results). NB is chosen by the host so that NB * T is a multiple of the
-// 4 waves where possible (S = 200: T = 13, NB = 4 -> 13 tiles per wave and phase) and NB * S * 64 B fits the LDS budget.
-template <int KS, int KP>
-__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_lds(DaArgs a, int NB) {
-    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    extern __shared__ f32x4 s2_smem[];
-    f32x4* lw = s2_smem;
-    f32x4* wul = s2_smem + NF4;                       // [NB][S * 4] swizzled 16-B chunks
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
-    const float* lscal = lbias + G2_BIAS * 16;
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = a.S, T = a.T;
-    const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
-    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
-    const int gbeg = a.gi0 + (int)((long long)a.G * xcd / nx), gend = a.gi0 + (int)((long long)a.G * (xcd + 1) / nx);
-    const int nph = (gend - gbeg + NB - 1) / NB;
-    const char* wvb = (const char*)a.wv;
-    const unsigned q16 = 16u * (unsigned)q;
-    const unsigned m_T = ItemIter::recip((unsigned)T);
-    __syncthreads();
-    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
-
-    struct Ids { int idv, sc, su, tb, nl; bool valid; int sta[KS]; };
-    struct Rows { f32x4 o[2]; float mq, eq; f32x4 rv[KP]; };
-
-    for (int ph = lb; ph < nph; ph += nbx) {
-        const int g_first = gbeg + ph * NB;
-        const int nb = min(NB, gend - g_first);
-        const int ntile = nb * T;
-        __syncthreads();                                              // every wave has finished reading the previous image
-        for (int n = 0; n < nb; ++n) {
-            const int g = a.src_tab[(g_first + n) * 16];
-            const f32x4* src = (const f32x4*)(a.wu + (size_t)g * (size_t)S * ROWW);
-            f32x4* dst = wul + (size_t)n * S * 4;
-            for (int c = threadIdx.x; c < S * 4; c += 256) {
-                const int r = c >> 2, qq = (c & 3) ^ ((r >> 2) & 3);
-                dst[c] = src[r * 4 + qq];
-            }
-        }
-        __syncthreads();
-
-        auto fetch_ids = [&](int i, Ids& t) {
-            unsigned rem;
-            const unsigned nl = T <= 1 ? (rem = 0u, (unsigned)i) : ItemIter::fdiv((unsigned)i, (unsigned)T, m_T, rem);
-            t.nl = (int)nl;
-            t.tb = (int)rem;
-            t.idv = a.src_tab[(g_first + (int)nl) * 16 + j];
-            const int s_ = t.tb * 16 + j;
-            t.valid = s_ < S;
-            t.sc = t.valid ? s_ : S - 1;
-            t.su = a.sta_user != nullptr ? a.sta_user[t.sc] : t.sc;
-            load_sta_ids<KS>(a.sta_col, t.sc, t.sta);
-        };
-        auto issue = [&](const Ids& t, Rows& r, int part, unsigned tk) {
-            const int g = __builtin_amdgcn_readlane(t.idv, 0);
-            if (part == 0) {
-                const long long p = (long long)g * S + t.sc;
-                r.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q + tk);
-                r.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q + tk);
-                if (a.sta_user != nullptr) {
-                    const long long pu = (long long)g * S + t.su;
-                    r.mq = q == 0 ? a.mm_int[p + tk] : -INFINITY;
-                    r.eq = q < 3 ? (a.ea_int != nullptr ? a.ea_int[p * 3 + q + tk] : a.edge_attr[pu * 3 + q + tk]) : 0.f;
-                } else {
-                    r.mq = a.mask[p * 4 + q + tk];
-                    r.eq = q < 3 ? a.edge_attr[p * 3 + q + tk] : 0.f;
-                }
-            } else {
-                const unsigned so = (unsigned)t.sc * 64u + q16 + tk;
-                constexpr int KH = (KP + 1) / 2;
-#pragma unroll
-                for (int k = (part == 1 ? 0 : KH); k < (part == 1 ? KH : KP); ++k) {
-                    const char* wvk = wvb + (size_t)__builtin_amdgcn_readlane(t.idv, 1 + k) * ((size_t)S * 64u);
-                    r.rv[k] = *(const f32x4*)(wvk + so);
-                }
-            }
-        };
-        if (wave >= ntile) continue;                 // (uniform per wave; the barriers above are reached by every wave)
-        Ids cur, nxt, nn;
-        Rows rows;
-        fetch_ids(wave, cur);
-        nxt = cur;
-        if (wave + 4 < ntile) fetch_ids(wave + 4, nxt);
-        issue(cur, rows, 0, 0u);
-        issue(cur, rows, 1, 0u);
-        issue(cur, rows, 2, 0u);
-        for (int it = wave;; it += 4) {
-            asm volatile("" : "+v"(lane));
-            const bool has_next = it + 4 < ntile;
-            const int g_c = __builtin_amdgcn_readlane(cur.idv, 0);
-            // station-neighbour rows of this tile from the LDS image, in edge order
-            const f32x4* img = wul + (size_t)cur.nl * S * 4;
-            f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const int r = cur.sta[k];
-                n1 += img[r * 4 + (q ^ ((r >> 2) & 3))];
-            }
-            f32x4 o[2] = {rows.o[0], rows.o[1]};
-            const float mq = rows.mq, eq = rows.eq;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
-            asm volatile("" : "+v"(n1), "+v"(n2), "+v"(o[0]), "+v"(o[1]));
-            unsigned tk = 0u;
-            asm volatile("" : "+v"(tk), "+v"(n1), "+v"(n2));
-            if (has_next) issue(nxt, rows, 0, tk);
-            o[0] = prelu4u(fma4(n1, 1.f / (float)KS, o[0]), a2);
-            o[1] = prelu4u(fma4(n2, 1.f / (float)KP, o[1]), a2);
-            if (a.x_latent != nullptr && cur.valid) {
-                float* xl = a.x_latent + ((long long)g_c * S + cur.su) * 30;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (4 * q + r < 15) {
-                        xl[4 * q + r] = o[0][r];
-                        xl[15 + 4 * q + r] = o[1][r];
-                    }
-                }
-            }
-            f32x4 bp[2];
-            bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-            bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-            nn = nxt;
-            if (a.no_bip) {
-                if (has_next) { issue(nxt, rows, 1, tk); issue(nxt, rows, 2, tk); }
-                if (it + 8 < ntile) fetch_ids(it + 8, nn);
-                if (!has_next) break;
-                cur = nxt;
-                nxt = nn;
-                continue;
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-                bp[t] = prelu4u(bp[t], ab1);
-                asm volatile("" : "+v"(tk), "+v"(bp[t]));
-                if (has_next) issue(nxt, rows, 1 + t, tk);
-            }
-            if (it + 8 < ntile) fetch_ids(it + 8, nn);
-            float mm = fmaxf(mq, __shfl_xor(mq, 16));
-            mm = fmaxf(mm, __shfl_xor(mm, 32));
-            if (!cur.valid) mm = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 v = bp[t] * mm;
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    v.x += __shfl_xor(v.x, d);
-                    v.y += __shfl_xor(v.y, d);
-                    v.z += __shfl_xor(v.z, d);
-                    v.w += __shfl_xor(v.w, d);
-                }
-                if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + cur.tb) * 32 + 16 * t + 4 * q) = v;
-            }
-            if (!has_next) break;
-            cur = nxt;
-            nxt = nn;
-        }
     }
 }
 
@@ -3561,10 +2853,7 @@ __global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* 
     r_out[idx] = s;
 }
 
-// Stage 2 in the layout of k_stage1_b3: a wave owns two 16-station tiles, lane (j = lane&31, h = lane>>5) holds channels
-// 8*(r>>2) + 4h + (r&3) of x_latent in the 32-slot order of the c rows ([o1 (15), 0 | o2 (15), 0]); a gathered 64-B row is two
-// 16-B chunks per lane. Bipartite fc1 runs as 12 + 3 bf16x3 MFMAs; the station sum over the 16 nodes of a tile is a DPP row
-// reduction (a DPP row = 16 lanes = one tile), no LDS traffic. Summation orders differ from k_stage2 / k_stage2_fast.
+// sum over the 16 lanes of a DPP row (all lanes end with the total)
 __device__ __forceinline__ float row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
@@ -3573,147 +2862,12 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-template <int KS, int KP>
-__global__ __launch_bounds__(256) void k_stage2_b3(DaArgs a) {
-    constexpr int NF4 = B3S2_IMG_FLOATS / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + B3S2_FRAGS * 64);
-    const float* lscal = lbias + 32;
-    const float a2 = lscal[0], ab1 = lscal[1];
-    const float inf = __builtin_inff();
-    const float sel2 = a2 <= 1.f ? inf : -inf, selb = ab1 <= 1.f ? inf : -inf;
-    int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
-    const bool hi = h != 0;
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    const char* wub = (const char*)a.wu;
-    const char* wvb = (const char*)a.wv;
-    const unsigned h16 = 16u * (unsigned)h;
-    const unsigned gstride = (unsigned)S * 64u;
-
-    int jt = jj;
-    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, int& tb_, bool& valid_, bool& tile_, int (&sta_)[KS]) {
-        int gi0, tb0, gi1, tb1;
-        w.decode(2 * pit_, gi0, tb0);
-        const bool second = 2 * pit_ + 1 < w.nitems;
-        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
-        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
-        tb_ = half ? tb1 : tb0;
-        const int s = tb_ * 16 + jt;
-        tile_ = second || !half;
-        valid_ = s < S && tile_;
-        sc_ = s < S ? s : S - 1;
-        load_sta_ids<KS>(a.sta_col, sc_, sta_);
-    };
-    int idv = 0, sc = 0, tb = 0, sta_id[KS];
-    bool valid = false, tile = false;
-    if (2 * w.it < w.nitems) fetch_ids(w.it, idv, sc, tb, valid, tile, sta_id);
-    for (long long pit = w.it; 2 * pit < w.nitems; pit += w.stride) {
-        asm volatile("" : "+v"(lane));
-        const bool has_next = 2 * (pit + w.stride) < w.nitems;
-        const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
-        const int g = half ? g1 : g0;
-        const long long p = (long long)g * S + sc;
-        // (1) every load of this tile pair
-        f32x4 cc[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) cc[b] = GENIE_LD_STREAM((const f32x4*)(a.c + p * ROWC + 8 * b + 4 * h));
-        const f32x4 m4 = GENIE_LD_STREAM((const f32x4*)(a.mask + p * 4));
-        const float e0 = GENIE_LD_STREAM(a.edge_attr + p * 3), e1 = GENIE_LD_STREAM(a.edge_attr + p * 3 + 1),
-                    e2 = GENIE_LD_STREAM(a.edge_attr + p * 3 + 2);
-        f32x4 ru[KS][2], rv[KP][2];
-        const unsigned gS = (unsigned)g * (unsigned)S;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const unsigned o = (gS + (unsigned)sta_id[k]) * 64u + h16;
-            ru[k][0] = *(const f32x4*)(wub + o);
-            ru[k][1] = *(const f32x4*)(wub + (o + 32u));
-        }
-        const unsigned so = (unsigned)sc * 64u + h16;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int n0 = __builtin_amdgcn_readlane(idv, 1 + k), n1 = __builtin_amdgcn_readlane(idv, 17 + k);
-            const unsigned o = __umul24((unsigned)(half ? n1 : n0), gstride) + so;
-            rv[k][0] = *(const f32x4*)(wvb + o);
-            rv[k][1] = *(const f32x4*)(wvb + (o + 32u));
-        }
-        // (2) ids of the next tile pair
-        int idv_n = 0, sc_n = 0, tb_n = 0, sta_n[KS];
-        bool valid_n = false, tile_n = false;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
-        if (has_next) fetch_ids(pit + w.stride, idv_n, sc_n, tb_n, valid_n, tile_n, sta_n);
-        // (3) neighbour means of the projected operands + node-local terms, PReLU2 -> x_latent (32-slot order)
-        f32x4 su[2] = {ru[0][0], ru[0][1]}, sv[2] = {rv[0][0], rv[0][1]};
-#pragma unroll
-        for (int k = 1; k < KS; ++k) { su[0] += ru[k][0]; su[1] += ru[k][1]; }
-#pragma unroll
-        for (int k = 1; k < KP; ++k) { sv[0] += rv[k][0]; sv[1] += rv[k][1]; }
-        f32x16 x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            x[r] = fmaf(su[0][r], 1.f / (float)KS, cc[0][r]);
-            x[4 + r] = fmaf(su[1][r], 1.f / (float)KS, cc[1][r]);
-            x[8 + r] = fmaf(sv[0][r], 1.f / (float)KP, cc[2][r]);
-            x[12 + r] = fmaf(sv[1][r], 1.f / (float)KP, cc[3][r]);
-        }
-        x = prelu16(x, a2, sel2);
-        if (a.x_latent != nullptr && valid) {
-            float* xl = a.x_latent + p * 30;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
-                if (ch < 15) xl[ch] = x[r];
-                else if (ch >= 16 && ch < 31) xl[ch - 1] = x[r];
-            }
-        }
-        // (4) Bipartite fc1 [x_latent || edge_attr] + PReLU, mask gate
-        u32x4 xp[2][3];
-        split8<0>(x, xp[0]);
-        split8<1>(x, xp[1]);
-        u32x4 ea, eb;      // edge_attr slices: lane h = 0 supplies [e1 ; e3], lane h = 1 [e2 ; e1] (as the raw rows of stage 1)
-        {
-            const float r0 = e0 - bf_hi(e0), r1 = e1 - bf_hi(e1), r2 = e2 - bf_hi(e2);
-            const unsigned p1a = pk_hi(e0, e1), p1b = __float_as_uint(e2) >> 16;
-            const unsigned p2a = pk_hi(r0, r1), p2b = __float_as_uint(r2) >> 16;
-            const unsigned p3a = pk_hi(r0 - bf_hi(r0), r1 - bf_hi(r1)), p3b = __float_as_uint(r2 - bf_hi(r2)) >> 16;
-            ea = u32x4{hi ? p2a : p1a, hi ? p2b : p1b, 0u, 0u};
-            eb = u32x4{hi ? p1a : p3a, hi ? p1b : p3b, 0u, 0u};
-        }
-        f32x16 acc[1] = {bias16(lbias, 0, h)};
-        acc[0] = MFMA32(lw[6 * 64 + lane], ea, acc[0]);
-        acc[0] = MFMA32(lw[7 * 64 + lane], ea, acc[0]);
-        acc[0] = MFMA32(lw[8 * 64 + lane], eb, acc[0]);
-        { const int f0[1] = {0}; mma6<1>(acc, lw, f0, lane, xp[0]); }
-        { const int f0[1] = {3}; mma6<1>(acc, lw, f0, lane, xp[1]); }
-        acc[0] = prelu16(acc[0], ab1, selb);
-        const float mm = valid ? fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w)) : 0.f;
-        // (5) station sum over the 16 nodes of each tile
-        f32x16 rs;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = row_sum16(acc[0][r] * mm);
-        if (jj == 0 && tile) {
-            float* dst = a.part + ((long long)g * a.T + tb) * 32 + 4 * h;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) *(f32x4*)(dst + 8 * b) = f32x4{rs[4 * b], rs[4 * b + 1], rs[4 * b + 2], rs[4 * b + 3]};
-        }
-        idv = idv_n; sc = sc_n; tb = tb_n; valid = valid_n; tile = tile_n;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// small G-sized kernels: 32 lanes per source node (2 nodes per wave, 8 per workgroup), weights transposed
-// in LDS ([k][32], lane = output channel), inputs broadcast with width-32 shuffles.
+// Bipartite read-out of an irregular product graph (32 lanes per source node, weights transposed in LDS). The scalar form of
+// the whole G-sized tail (32 lanes per node, both matvec operands from LDS: 3.5 LDS cycles per wave-FMA, tools/lds_matvec.hip)
+// was replaced by the fp32-MFMA tile kernels below in round 2 (103.5 -> 45.4 us per window).
 // ------------------------------------------------------------------------------------------------
 constexpr int NPB = 8;  // nodes per 256-thread block
-// The per-node matvecs o[c] = sum_k W[k][c] x[k] read x[k] as an LDS broadcast (the compiler merges four k into one
-// ds_read_b128): 3.5 LDS cycles per wave-FMA and CU against 6.5 with __shfl = ds_bpermute (tools/lds_matvec.hip).
 
 // Weight staging: global [rows][ld] row-major (nn.Linear layout) -> LDS [k][ldo] (k = input index, lane = output
 // channel; conflict-free LDS writes and reads, strided but L1-resident global reads)
@@ -3726,51 +2880,8 @@ __device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __r
 __device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
     stage_transposed_ld(dst, W, rows, ld, 32);
 }
-// first kcols input columns only: dst[k*32 + c] = W[c][k], k < kcols
-__device__ __forceinline__ void stage_transposed_cols(float* dst, const float* __restrict__ W, int rows, int ld, int kcols) {
-    for (int i = threadIdx.x; i < kcols * 32; i += blockDim.x) {
-        const int k = i >> 5, c = i & 31;
-        dst[i] = c < rows ? W[c * ld + k] : 0.f;
-    }
-}
 
-// Bipartite read-out: r_g = sum over tiles in fixed order; out = PReLU_b2(fc2 r_g)              module.py:229
-// blockIdx.y = window of a batched tail (genie_tail_batched): the window's buffers sit `*_ws` floats apart.
-__global__ __launch_bounds__(256) void k_bip_out(const float* __restrict__ part, int G, int T,
-                                                const float* __restrict__ raw, int off_w, int off_b, int off_a,
-                                                float* __restrict__ out, long long part_ws, long long out_ws) {
-    __shared__ float wt[30 * 32];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
-    stage_transposed(wt, raw + off_w, 15, 30);
-    __syncthreads();
-    part += blockIdx.y * part_ws;
-    out += blockIdx.y * out_ws;
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float bias = c < 15 ? raw[off_b + c] : 0.f;
-    const float act = raw[off_a];
-    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < G;
-        float r = 0.f;
-        if (ok) {
-            const float* pg = part + (long long)g * T * 32 + c;
-            int tb = 0;
-            for (; tb + 4 <= T; tb += 4) {        // four rows in flight, added in tile order
-                const float v0 = pg[tb * 32], v1 = pg[(tb + 1) * 32], v2 = pg[(tb + 2) * 32], v3 = pg[(tb + 3) * 32];
-                r += v0; r += v1; r += v2; r += v3;
-            }
-            for (; tb < T; ++tb) r += pg[tb * 32];
-        }
-        gx[grp][c] = r;
-        GSYNC();
-        float o = bias;
-#pragma unroll
-        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * gx[grp][k];
-        GSYNC();
-        if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
-    }
-}
-// same for an irregular product graph: source node g owns the message rows [seg[g], seg[g+1]) of a [P, 32] buffer
+// r_g = sum of the message rows [seg[g], seg[g+1]) of a [P, 32] buffer (k_stage2_pcsr) in row order, out = PReLU_b2(fc2 r_g)  module.py:229
 __global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ rows, int G, const int32_t* __restrict__ seg,
                                                     const float* __restrict__ raw, int off_w, int off_b, int off_a,
                                                     float* __restrict__ out) {
@@ -3832,191 +2943,10 @@ __device__ __forceinline__ void sa_select_window(SaArgs& a) {
     if (a.out) a.out += w * a.ws_out;
 }
 
-// fixed-order block reduction of the per-lane global-term partials (lanes c < 5 of every node group) -> gpart[block]
-__device__ __forceinline__ void sa_store_gpart(float acc, int c, int grp, float* gpart_out) {
-    __shared__ float red[NPB][8];
-    if (c < 8) red[grp][c] = c < 5 ? acc : 0.f;
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        float s = 0.f;
-        for (int k = 0; k < NPB; ++k) s += red[k][threadIdx.x];
-        gpart_out[blockIdx.x * 8 + threadIdx.x] = s;
-    }
-}
 
-// Per-node pre-pass of a SpatialAggregation layer (module.py:249): the x_j part of the message Linear
-//   pj[j] = fc1.weight[:, 0:C] x_j                      (shared by every edge leaving j)
-// and this block's partial of the edge-mean term  sum_j outdeg(j) PReLU3(fglobal x_j).
-template <int C>
-__global__ __launch_bounds__(256) void k_sa_pre(SaArgs a) {
-    sa_select_window(a);
-    __shared__ float wx[C * 32];
-    __shared__ float wg[C * 32];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
-    stage_transposed_cols(wx, a.raw + a.fc1_w, 30, C + 8, C);
-    stage_transposed(wg, a.raw + a.fg_w, 5, C);
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float bg = c < 5 ? a.raw[a.fg_b + c] : 0.f;
-    const float act3 = a.raw[a.act3];
-    float acc = 0.f;
-    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < a.G;
-        gx[grp][c] = (ok && c < C) ? a.x_in[(long long)g * C + c] : 0.f;
-        GSYNC();
-        float pj = 0.f, gl = bg;
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const float xk = gx[grp][k];
-            pj += wx[k * 32 + c] * xk;
-            gl += wg[k * 32 + c] * xk;
-        }
-        GSYNC();
-        if (ok) {
-            a.pj_out[(long long)g * 32 + c] = c < 30 ? pj : 0.f;
-            acc += (float)a.outdeg[g] * prelu1(gl, act3);
-        }
-    }
-    sa_store_gpart(acc, c, grp, a.gpart_out);
-}
 
-// One SpatialAggregation layer (module.py:245,249): message = PReLU1(pj[j] + fc1_pos (p_i - p_j) + fc1_glob c + b1),
-// mean over in-edges, update out_i = PReLU2(fc2 [x_i || mean]). With NEXT the kernel also emits the pre-pass of the
-// following layer (pj' = fc1'.weight[:, 0:30] out_i and the partial of its edge-mean term) while out_i is in registers.
-template <int C, bool NEXT>
-__global__ __launch_bounds__(256) void k_sa_layer(SaArgs a) {
-    sa_select_window(a);
-    __shared__ float w1p[8 * 32];            // fc1 columns C..C+7 (3 position + 5 global), transposed
-    __shared__ float w2t[(C + 30) * 32];
-    __shared__ float wxn[NEXT ? 30 * 32 : 32];
-    __shared__ float wgn[NEXT ? 30 * 32 : 32];
-    __shared__ float gsum[8];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][96];       // per node group: x_i, the edge mean, the layer output
-    for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
-        const int k = i >> 5, cc = i & 31;
-        w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
-    }
-    stage_transposed(w2t, a.raw + a.fc2_w, 30, C + 30);
-    if (NEXT) {
-        stage_transposed_cols(wxn, a.raw + a.nx_fc1_w, 30, 30 + 8, 30);
-        stage_transposed(wgn, a.raw + a.nx_fg_w, 5, 30);
-    }
-    {   // global term: sum of the producer's per-block partials in a FIXED two-level order (deterministic, parallel)
-        __shared__ float gred[32][8];
-        const int m = threadIdx.x & 7, chunk = threadIdx.x >> 3;
-        float sgl = 0.f;
-        for (int b = chunk; b < a.n_gpart_in; b += 32) sgl += a.gpart_in[b * 8 + m];
-        gred[chunk][m] = sgl;
-        __syncthreads();
-        if (threadIdx.x < 8) {
-            float t = 0.f;
-            for (int k = 0; k < 32; ++k) t += gred[k][threadIdx.x];
-            gsum[threadIdx.x] = t;
-        }
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float act1 = a.raw[a.act1], act2 = a.raw[a.act2];
-    const float b2 = c < 30 ? a.raw[a.fc2_b + c] : 0.f;
-    float base = c < 30 ? a.raw[a.fc1_b + c] : 0.f;       // message bias + global-term contribution (same for every edge)
-    {
-        const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
-#pragma unroll
-        for (int m = 0; m < 5; ++m) base += w1p[(3 + m) * 32 + c] * (gsum[m] * invE);
-    }
-    const float wp0 = w1p[0 * 32 + c], wp1 = w1p[1 * 32 + c], wp2 = w1p[2 * 32 + c];
-    const float bgn = (NEXT && c < 5) ? a.raw[a.nx_fg_b + c] : 0.f;
-    const float act3n = NEXT ? a.raw[a.nx_act3] : 0.f;
-    float acc = 0.f;
-    for (int g0 = blockIdx.x * NPB; g0 < a.G; g0 += gridDim.x * NPB) {
-        const int i = g0 + grp;
-        const bool ok = i < a.G;
-        const int ic = ok ? i : a.G - 1;
-        const float xi = c < C ? a.x_in[(long long)ic * C + c] : 0.f;
-        const float pi0 = a.pos[ic * 3 + 0] / a.scale_rel, pi1 = a.pos[ic * 3 + 1] / a.scale_rel,
-                    pi2 = a.pos[ic * 3 + 2] / a.scale_rel;
-        const int eb = a.rowptr[ic], ee = ok ? a.rowptr[ic + 1] : eb;
-        float asum = 0.f;
-        // edges in chunks of 8: ids, then all gathered rows / positions in flight, then the arithmetic in edge order
-        // (no cross-lane op inside: the two half-waves of a wave may differ in trip count)
-        for (int e0 = eb; e0 < ee; e0 += 8) {
-            int jn[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) jn[k] = a.col[min(e0 + k, ee - 1)];
-            float pjv[8], q0[8], q1[8], q2[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                pjv[k] = a.pj_in[(long long)jn[k] * 32 + c];
-                q0[k] = a.pos[jn[k] * 3 + 0]; q1[k] = a.pos[jn[k] * 3 + 1]; q2[k] = a.pos[jn[k] * 3 + 2];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float m = pjv[k] + base;
-                m += wp0 * (pi0 - q0[k] / a.scale_rel);
-                m += wp1 * (pi1 - q1[k] / a.scale_rel);
-                m += wp2 * (pi2 - q2[k] / a.scale_rel);
-                if (e0 + k < ee) asum += prelu1(m, act1);
-            }
-        }
-        const float av = asum / (float)max(ee - eb, 1);
-        gx[grp][c] = xi;
-        gx[grp][32 + c] = av;
-        GSYNC();
-        float o = b2;
-#pragma unroll
-        for (int kk = 0; kk < C; ++kk) o += w2t[kk * 32 + c] * gx[grp][kk];
-#pragma unroll
-        for (int kk = 0; kk < 30; ++kk) o += w2t[(C + kk) * 32 + c] * gx[grp][32 + kk];
-        o = c < 30 ? prelu1(o, act2) : 0.f;
-        if (ok && c < 30) a.out[(long long)i * 30 + c] = o;
-        if (NEXT) {
-            gx[grp][64 + c] = o;
-            GSYNC();
-            float pj = 0.f, gl = bgn;
-#pragma unroll
-            for (int k = 0; k < 30; ++k) {
-                const float ok_ = gx[grp][64 + k];
-                pj += wxn[k * 32 + c] * ok_;
-                gl += wgn[k * 32 + c] * ok_;
-            }
-            if (ok) {
-                a.pj_out[(long long)i * 32 + c] = c < 30 ? pj : 0.f;
-                acc += (float)a.outdeg[i] * prelu1(gl, act3n);
-            }
-        }
-        GSYNC();
-    }
-    if (NEXT) sa_store_gpart(acc, c, grp, a.gpart_out);
-}
 
-// ------------------------------------------------------------------------------------------------
-// Read-out heads (module.py:251-331), G- / Q-sized: 32 lanes per node, 8 nodes per workgroup, weights transposed in
-// LDS, per-node vectors exchanged through LDS. MODE 0: y = TemporalAttention(SpatialDirect(x_spatial)) per grid
-// node (module.py:1015-1016); MODE 1: x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query
-// (module.py:1017-1018), the K = 10 nearest grid nodes of every query given as an index table.
-// ------------------------------------------------------------------------------------------------
-// Pre-transposed weight images for the G-/Q-sized kernels: built once per weight update (ensure_packed) so that a
-// workgroup fills its LDS with ONE linear, coalesced copy instead of a strided transpose of ~20k floats.
-// image element (k, c) of one matrix = W[c][col0 + k] (c < rows, k < ncols) at dst + k*ldo + c, zero padded.
-struct TDesc {
-    int32_t dst, raw, rows, ld, ldo, col0, ncols, pad;
-};
-__global__ void k_pack_t(const float* __restrict__ raw, const TDesc* __restrict__ d, int nd, float* __restrict__ img) {
-    for (int m = 0; m < nd; ++m) {
-        const TDesc t = d[m];
-        const int n = t.ncols * t.ldo;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            const int k = i / t.ldo, c = i - k * t.ldo;
-            img[t.dst + i] = c < t.rows ? raw[t.raw + c * t.ld + t.col0 + k] : 0.f;
-        }
-    }
-}
-// read-out images (floats): common part, then MODE-specific part
-constexpr int RO_IMG_COMMON = 30 * 32 * 2 + 30 * 96 * 2 + 15 * 32 + 32;     // w_c1 w_v1 w_c2 w_v2 w_p1 w_p2
-constexpr int RO_IMG0 = RO_IMG_COMMON + 30 * 32;                              // + f_direct
-constexpr int RO_IMG1 = RO_IMG_COMMON + 3 * 96 * 3 + 15 * 32;                 // + f_queries, f_context[e], f_values[e], proj
-constexpr int RO_IMGCV = 2 * 30 * 96;                                         // f_context / f_values x-columns (k_ro_pre)
+// read-out heads (module.py:251-331): arguments shared by k_ro_pre_m / k_readout_m and their backward passes
 
 struct RoArgs {
     int N, G, T;                 // nodes handled (G for MODE 0, Q for MODE 1), grid size, number of time queries (<= 16)
@@ -4044,268 +2974,15 @@ struct RoArgs {
 // [x_j || edge_attr]; the x_j part  C_j = f_context.weight[:, 0:30] x_j,  V_j = f_values.weight[:, 0:30] x_j  is the same
 // for every query that has j as a neighbour, so it is computed once per grid node: cv[j] = [C_j (75, pad 80) | V_j].
 constexpr int CVP = 160;
-// Batched tail: node ids run over nwin windows of Gw nodes (x_spatial [nwin * Gw, 30]); window w writes cv + w * cv_ws.
-__global__ __launch_bounds__(256) void k_ro_pre(const float* __restrict__ x_spatial, int G, const float* __restrict__ imgcv,
-                                                float* __restrict__ cv, int Gw, long long cv_ws) {
-    __shared__ __attribute__((aligned(16))) float wc[30 * 96];
-    __shared__ __attribute__((aligned(16))) float wv[30 * 96];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
-    for (int i = threadIdx.x; i < 30 * 96 / 4; i += blockDim.x) {
-        ((f32x4*)wc)[i] = ((const f32x4*)imgcv)[i];
-        ((f32x4*)wv)[i] = ((const f32x4*)(imgcv + 30 * 96))[i];
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < G;
-        gx[grp][c] = (ok && c < 30) ? x_spatial[(long long)g * 30 + c] : 0.f;
-        GSYNC();
-        float cc[3] = {0.f, 0.f, 0.f}, vv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 30; ++k) {
-            const float xk = gx[grp][k];
-            cc[0] += wc[k * 96 + c] * xk; cc[1] += wc[k * 96 + 32 + c] * xk; cc[2] += wc[k * 96 + 64 + c] * xk;
-            vv[0] += wv[k * 96 + c] * xk; vv[1] += wv[k * 96 + 32 + c] * xk; vv[2] += wv[k * 96 + 64 + c] * xk;
-        }
-        GSYNC();
-        if (ok) {
-            const int w = g / Gw;
-            float* o = cv + w * cv_ws + (long long)(g - w * Gw) * CVP;
-            o[c] = cc[0]; o[32 + c] = cc[1]; if (c < 16) o[64 + c] = cc[2];
-            o[80 + c] = vv[0]; o[112 + c] = vv[1]; if (c < 16) o[144 + c] = vv[2];
-        }
-    }
-}
-
-// The 32 lanes of a node group live in ONE wave and only exchange data among themselves through their private LDS
-// scratch, so a wave-level ordering point (LDS ops of a wave complete in order) replaces __syncthreads(): waves do
-// not wait for each other between the ~35 short phases of a node batch.
 
 constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
 constexpr int RO_TMAX = 10;   // time queries per call (the reference uses 9, process_continuous_days.py:359)
 
-template <int MODE, int NG>
-__global__ __launch_bounds__(NG * 32) void k_readout(RoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    // ---- LDS carve (floats)
-    float* w_c1 = sm;                    // [30][32]
-    float* w_v1 = w_c1 + 30 * 32;        // [30][32]
-    float* w_c2 = w_v1 + 30 * 32;        // [30][96]
-    float* w_v2 = w_c2 + 30 * 96;        // [30][96]
-    float* w_p1 = w_v2 + 30 * 96;        // [15][32]
-    float* w_p2 = w_p1 + 15 * 32;        // [32]
-    float* w_x0 = w_p2 + 32;             // MODE 0: f_direct [30][32];  MODE 1: f_queries [3][96]
-    float* w_fc = w_x0 + (MODE == 0 ? 30 * 32 : 3 * 96);   // MODE 1: f_context, edge-attr columns [3][96]
-    float* w_fv = w_fc + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: f_values, edge-attr columns [3][96]
-    float* w_pr = w_fv + (MODE == 0 ? 0 : 3 * 96);         // MODE 1: proj [15][32]
-    float* qry = w_pr + (MODE == 0 ? 0 : 15 * 32);         // [RO_TMAX][96]
-    float* scr = qry + RO_TMAX * 96;                       // per-group scratch
-    constexpr int SCR = 40 + 32 + 32 + 96 + 96 + 52 + RO_TMAX * 16 + 96 + 96;   // floats per group
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    float* xin = scr + grp * SCR;        // [40]  input vector of the current sub-layer
-    float* h1 = xin + 40;                // [32]
-    float* h2 = h1 + 32;                 // [32]
-    float* ctx = h2 + 32;                // [96]
-    float* val = ctx + 96;               // [96]
-    float* scs = val + 96;               // [52]  score[t*5+h], t < RO_TMAX (was [48]: with 10 time queries the scores of t = 9 ran into zs)
-    float* zs = scs + 52;                // [T][16]
-    float* prd = zs + RO_TMAX * 16;      // [96]  q*c products / aggregated values (MODE 1)
-    float* als = prd + 96;               // [10][8] attention logits / weights (MODE 1)
-
-    {   // static weights: one linear copy of the pre-transposed image (same layout as the carve above)
-        constexpr int NIMG = (MODE == 0 ? RO_IMG0 : RO_IMG1) / 4;
-        const f32x4* src = (const f32x4*)a.img;
-        f32x4* dst = (f32x4*)sm;
-        for (int i = threadIdx.x; i < NIMG; i += blockDim.x) dst[i] = src[i];
-    }
-    // temporal queries: qry[t][ch] = temporal_query_2(PReLU3(temporal_query_1(t_query/scale_t)))   module.py:329
-    {
-        const float act3 = a.raw[a.o_a3];
-        for (int i = threadIdx.x; i < RO_TMAX * 96; i += blockDim.x) {
-            const int t = i / 96, ch = i - t * 96;
-            float v = 0.f;
-            if (t < a.T && ch < 75) {
-                const float tq = a.t_query[t] / a.scale_t;
-                v = a.raw[a.o_q2b + ch];
-                for (int k = 0; k < 30; ++k) {
-                    const float hq = prelu1(a.raw[a.o_q1w + k] * tq + a.raw[a.o_q1b + k], act3);
-                    v += a.raw[a.o_q2w + ch * 30 + k] * hq;
-                }
-            }
-            qry[i] = v;
-        }
-    }
-    __syncthreads();
-
-    const float act1 = a.raw[a.o_a1], act2 = a.raw[a.o_a2], act4 = a.raw[a.o_a4], act5 = a.raw[a.o_a5];
-    const float b_c1 = c < 30 ? a.raw[a.o_c1b + c] : 0.f, b_v1 = c < 30 ? a.raw[a.o_v1b + c] : 0.f;
-    const float b_c2[3] = {a.raw[a.o_c2b + c], a.raw[a.o_c2b + 32 + c], c < 11 ? a.raw[a.o_c2b + 64 + c] : 0.f};
-    const float b_v2[3] = {a.raw[a.o_v2b + c], a.raw[a.o_v2b + 32 + c], c < 11 ? a.raw[a.o_v2b + 64 + c] : 0.f};
-    const float b_p1 = c < 30 ? a.raw[a.o_p1b + c] : 0.f, b_p2 = a.raw[a.o_p2b];
-    const float inv_sqrt_l = 1.f / sqrtf(15.f);
-    // MODE 1: the edge-attribute columns of f_queries / f_context / f_values (3 inputs -> 3 x 32 outputs per lane) stay in
-    // registers for every neighbour of every query
-    float wqe[3][3], wce[3][3], wve[3][3];
-    if (MODE == 1) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                wqe[d][m] = w_x0[d * 96 + 32 * m + c]; wce[d][m] = w_fc[d * 96 + 32 * m + c]; wve[d][m] = w_fv[d * 96 + 32 * m + c];
-            }
-    }
-
-    for (int n0 = blockIdx.x * NG; n0 < a.N; n0 += gridDim.x * NG) {
-        const int n = n0 + grp;
-        const bool ok = n < a.N;
-        const int nc = ok ? n : a.N - 1;
-        // ------------------------------------------------------------------ front end -> 30-vector in xin
-        if (MODE == 0) {
-            xin[c] = c < 30 ? a.x_spatial[(long long)nc * 30 + c] : 0.f;
-            GSYNC();
-            float y = c < 30 ? a.raw[a.o_sd_b + c] : 0.f;                               // SpatialDirect, module.py:258-260
-#pragma unroll
-            for (int k = 0; k < 30; ++k) y += w_x0[k * 32 + c] * xin[k];
-            y = prelu1(y, a.raw[a.o_sd_a]);
-            GSYNC();
-            xin[c] = c < 30 ? y : 0.f;
-            GSYNC();
-        } else {
-            const float sa1 = a.raw[a.o_sa1], sa2 = a.raw[a.o_sa2];
-            const float bq[3] = {a.raw[a.o_sq_b + c], a.raw[a.o_sq_b + 32 + c], c < 11 ? a.raw[a.o_sq_b + 64 + c] : 0.f};
-            const float bc[3] = {a.raw[a.o_sc_b + c], a.raw[a.o_sc_b + 32 + c], c < 11 ? a.raw[a.o_sc_b + 64 + c] : 0.f};
-            const float bv[3] = {a.raw[a.o_sv_b + c], a.raw[a.o_sv_b + 32 + c], c < 11 ? a.raw[a.o_sv_b + 64 + c] : 0.f};
-            const int wq = nc / a.Nw, nl = nc - wq * a.Nw;
-            const float* cvw = a.cv + wq * a.cv_ws;
-            const float xq0 = a.x_query[nl * 3 + 0], xq1 = a.x_query[nl * 3 + 1], xq2 = a.x_query[nl * 3 + 2];
-#pragma unroll 1
-            for (int k = 0; k < RO_K; ++k) {
-                const int jn = a.knn[(long long)nl * RO_K + k];
-                const float e[3] = {(xq0 - a.x_grid[jn * 3 + 0]) / a.scale_rel, (xq1 - a.x_grid[jn * 3 + 1]) / a.scale_rel,
-                                    (xq2 - a.x_grid[jn * 3 + 2]) / a.scale_rel};                                            // :283
-                const float* cvj = cvw + (long long)jn * CVP;
-                float q3[3] = {bq[0], bq[1], bq[2]};
-                float c3[3] = {bc[0] + cvj[c], bc[1] + cvj[32 + c], bc[2] + (c < 16 ? cvj[64 + c] : 0.f)};
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    q3[0] += wqe[d][0] * e[d]; q3[1] += wqe[d][1] * e[d]; q3[2] += wqe[d][2] * e[d];
-                    c3[0] += wce[d][0] * e[d]; c3[1] += wce[d][1] * e[d]; c3[2] += wce[d][2] * e[d];
-                }
-                prd[c] = q3[0] * c3[0]; prd[32 + c] = q3[1] * c3[1]; prd[64 + c] = q3[2] * c3[2];
-                GSYNC();
-                if (c < 5) {                                                            // alpha = PReLU1(sum_l q*c / sqrt(L))  :293
-                    float sdot = 0.f;
-#pragma unroll
-                    for (int l = 0; l < 15; ++l) sdot += prd[c * 15 + l];
-                    als[k * 8 + c] = prelu1(sdot * inv_sqrt_l, sa1);
-                }
-                GSYNC();
-            }
-            if (c < 5) {                                                                // segment softmax over the K edges  :295
-                float m = als[c];
-#pragma unroll
-                for (int k = 1; k < RO_K; ++k) m = fmaxf(m, als[k * 8 + c]);
-                float ssum = 0.f, ek[RO_K];
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) { ek[k] = expf(als[k * 8 + c] - m); ssum += ek[k]; }
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) als[k * 8 + c] = ek[k] / (ssum + 1e-16f);
-            }
-            GSYNC();
-            {
-                // 'add' aggregation of alpha * v  :264,297. The value embeddings are recomputed here (3 row chunks + 9 FMAs per
-                // edge) instead of being parked in LDS during the logit pass: 3.2 KB less scratch per query = more queries per CU
-                const int hd0 = c / 15, hd1 = (32 + c) / 15, hd2 = min((64 + c) / 15, 4);
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-#pragma unroll 2
-                for (int k = 0; k < RO_K; ++k) {
-                    const int jn = a.knn[(long long)nl * RO_K + k];
-                    const float e[3] = {(xq0 - a.x_grid[jn * 3 + 0]) / a.scale_rel, (xq1 - a.x_grid[jn * 3 + 1]) / a.scale_rel,
-                                        (xq2 - a.x_grid[jn * 3 + 2]) / a.scale_rel};
-                    const float* cvj = cvw + (long long)jn * CVP;
-                    float v3[3] = {bv[0] + cvj[80 + c], bv[1] + cvj[112 + c], bv[2] + (c < 16 ? cvj[144 + c] : 0.f)};
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { v3[0] += wve[d][0] * e[d]; v3[1] += wve[d][1] * e[d]; v3[2] += wve[d][2] * e[d]; }
-                    g0 += als[k * 8 + hd0] * v3[0];
-                    g1 += als[k * 8 + hd1] * v3[1];
-                    g2 += als[k * 8 + hd2] * (c < 16 ? v3[2] : 0.f);
-                }
-                prd[c] = g0; prd[32 + c] = g1; prd[64 + c] = g2;
-            }
-            GSYNC();
-            float xm = 0.f;                                                             // mean over heads  :285
-            if (c < 15) {
-#pragma unroll
-                for (int hh = 0; hh < 5; ++hh) xm += prd[hh * 15 + c];
-                xm *= 0.2f;
-            }
-            GSYNC();
-            xin[c] = xm;
-            GSYNC();
-            float xo = c < 30 ? a.raw[a.o_sp_b + c] : 0.f;                              // PReLU2(proj(.))  :285
-#pragma unroll
-            for (int l = 0; l < 15; ++l) xo += w_pr[l * 32 + c] * xin[l];
-            xo = prelu1(xo, sa2);
-            GSYNC();
-            xin[c] = c < 30 ? xo : 0.f;
-            GSYNC();
-        }
-        // ------------------------------------------------------------------ TemporalAttention on xin[0..29]  :325-331
-        {
-            float t1 = b_c1, t2 = b_v1;
-#pragma unroll
-            for (int k = 0; k < 30; ++k) { const float xv = xin[k]; t1 += w_c1[k * 32 + c] * xv; t2 += w_v1[k * 32 + c] * xv; }
-            h1[c] = c < 30 ? prelu1(t1, act1) : 0.f;
-            h2[c] = c < 30 ? prelu1(t2, act2) : 0.f;
-        }
-        GSYNC();
-        {
-            float cx[3] = {b_c2[0], b_c2[1], b_c2[2]}, vx[3] = {b_v2[0], b_v2[1], b_v2[2]};
-#pragma unroll
-            for (int k = 0; k < 30; ++k) {
-                const float u1 = h1[k], u2 = h2[k];
-                cx[0] += w_c2[k * 96 + c] * u1; cx[1] += w_c2[k * 96 + 32 + c] * u1; cx[2] += w_c2[k * 96 + 64 + c] * u1;
-                vx[0] += w_v2[k * 96 + c] * u2; vx[1] += w_v2[k * 96 + 32 + c] * u2; vx[2] += w_v2[k * 96 + 64 + c] * u2;
-            }
-            ctx[c] = cx[0]; ctx[32 + c] = cx[1]; ctx[64 + c] = cx[2];
-            val[c] = vx[0]; val[32 + c] = vx[1]; val[64 + c] = vx[2];
-        }
-        GSYNC();
-        for (int idx = c; idx < a.T * 5; idx += 32) {                                    // score[t,h] = ctx[h,:].qry[t,h,:]/sqrt(L)
-            const int t = idx / 5, hh = idx - t * 5;
-            float sdot = 0.f;
-#pragma unroll
-            for (int l = 0; l < 15; ++l) sdot += ctx[hh * 15 + l] * qry[t * 96 + hh * 15 + l];
-            scs[idx] = sdot * inv_sqrt_l;
-        }
-        GSYNC();
-        for (int idx = c; idx < a.T * 15; idx += 32) {                                   // z[t,l] = mean_h score[t,h] * val[h,l]
-            const int t = idx / 15, l = idx - t * 15;
-            float z = 0.f;
-#pragma unroll
-            for (int hh = 0; hh < 5; ++hh) z += scs[t * 5 + hh] * val[hh * 15 + l];
-            zs[t * 16 + l] = prelu1(z * 0.2f, act4);
-        }
-        GSYNC();
-        for (int t = 0; t < a.T; ++t) {                                                  // proj_2(PReLU5(proj_1(.))): 15 -> 30 -> 1
-            float pv = b_p1;
-#pragma unroll
-            for (int l = 0; l < 15; ++l) pv += w_p1[l * 32 + c] * zs[t * 16 + l];
-            float o = c < 30 ? w_p2[c] * prelu1(pv, act5) : 0.f;
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) o += __shfl_xor(o, d, 32);                     // fixed butterfly order
-            if (ok && c == 0) a.out[(long long)n * a.T + t] = o + b_p2;
-        }
-        GSYNC();
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// The G- / Q-sized tail on fp32 MFMA tiles (plans PL_RO0 .. PL_BIP above): same reference lines and the same arithmetic as
-// k_bip_out / k_sa_pre / k_sa_layer / k_ro_pre / k_readout, with the per-node Linears as MFMA chains over 16 nodes per wave
-// (the dot products are summed in MFMA k-order instead of k = 0, 1, 2 ...: rounding-order differences only). The scalar
-// kernels stay as the A/B reference (genie_set_tail_kernels(ctx, 0), env GENIE_TAIL=scalar).
+// The G- / Q-sized tail on fp32 MFMA tiles (plans PL_RO0 .. PL_BIP above): Bipartite read-out (module.py:229), SpatialAggregation
+// (:243-249), SpatialDirect / SpatialAttention / TemporalAttention (:251-331) with the per-node Linears as MFMA chains over 16
+// nodes per wave.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -5383,7 +4060,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_sum(const float* __restrict_
     } else if (db && e - 32 * 64 * KC < M) db[e - 32 * 64 * KC] = v;
 }
 
-// XCC (XCD) id and CU id of the CU a workgroup runs on: maps the bits of a stream CU mask to XCDs (genie_cu_mask_probe)
+// XCC (XCD) id and CU id of the CU a workgroup runs on (genie_where_am_i): workgroup b of a launch lands on XCD b % 8
 __global__ void k_where_am_i(int* __restrict__ out) {
     int xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));       // HW_REG_XCC_ID
@@ -5420,7 +4097,8 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ xc, int n
         if (d < bd[K - 1]) {          // candidates arrive in increasing index order: a tie never displaces an earlier entry
 #pragma unroll
             for (int t = 0; t < K; ++t) {
-                if (d < bd[t]) {
+                if (d < bd[t] || (d == bd[t] && id < bi[t])) {       // lexicographic (distance, index): a displaced entry that ties with
+                                                                      // the next slot goes in front of it (it has the smaller index)
                     const double td = bd[t]; const int ti = bi[t];
                     bd[t] = d; bi[t] = id; d = td; id = ti;
                 }
@@ -5536,15 +4214,6 @@ __global__ __launch_bounds__(256) void k_subgraph_csr(const int32_t* __restrict_
     if (!FILL) { cnt_sta[n] = c1; cnt_src[n] = c2; }
 }
 
-#if GENIE_TUNING
-// which XCD a workgroup landed on (HW_REG_XCC_ID = hardware register 20, bits 3:0): tools/xcc_probe.py
-__global__ void k_xcc_probe(int* __restrict__ out) {
-    int v;
-    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(v));
-    if (threadIdx.x == 0) out[blockIdx.x] = v;
-}
-#endif
-
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst,
                          const int32_t* __restrict__ sta_user, int S) {
     // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one); rows in station processing order -> caller's order
@@ -5591,19 +4260,13 @@ struct genie_ctx {
     BiasDesc* d_bias[NPLAN];
     int32_t* d_scal[NPLAN];
     float* packed[NPLAN];
-    int tail_mfma;             // G- / Q-sized tail on the fp32-MFMA tile kernels (default) or the scalar 32-lanes-per-node ones (A/B)
     AccDesc* d_acc[NTM]; VecDesc* d_vec[NTM]; int32_t* d_sc[NTM];   // gradient maps of the backward passes (k_train_reduce)
     int n_acc[NTM], n_vec[NTM], n_sc[NTM];
-    int* dyn_ctr;              // dynamic work distribution: [kind 2][slot % GENIE_NBIG][parity 2][8] per-XCD item counters
-    int dyn_parity[2][4];      // which set the next launch of (kind, slot) uses
-    int dyn_on, dyn_b1, dyn_b2;
     float* train_save;         // ... and where those kernels keep the pre-activations (DaArgs.save)
     int force_generic;         // set for the duration of a training call: the generic fp32 stage kernels (caller's station order,
                                // pre-activations saved) run whatever the context would normally select
     float* as_pg;              // [G][AS_PG] per-source-node terms of the association stages (allocated on first use)
     int32_t* d_b3tbl;          // k_pack_b3 source table
-    int32_t* d_b3tbl2;         // ... of the stage-2 image
-    float* packed_b3s2;        // bf16x3 weight image of k_stage2_b3
     // reversed base graphs (out-edges, weights 1 / in-degree of the target): built on the first genie_nbr_mean_bwd
     int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
     float *r_sta_w, *r_src_w;
@@ -5621,39 +4284,32 @@ struct genie_ctx {
     int32_t *sta_perm, *sta_inv, *sta_rowptr_p, *sta_col_p;
     float* ebias_sta_p;
     float* ea_int; const float* ea_user;   // genie_set_static_edge_attr: processing-order copy of the caller's static edge_attr
+    float* ea_tmp;             // ... of an edge_attr that is not the registered one (permuted per call)
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_b3 (null unless kp_uni == 15)
     float* packed_b3;          // bf16x3 weight image of k_stage1_b3
     int num_cu;
-    float* ro_img;             // [RO_IMG0 | RO_IMG1 | RO_IMGCV] pre-transposed read-out weight images
-    TDesc* d_tdesc; int n_tdesc;
-    int seg, bpc1, bpc1f, bpc2, bpc2f;  // tuning knobs (env GENIE_SEG / GENIE_BPC1 / GENIE_BPC2)
+    int seg, bpc1, bpc2;       // sweep segments (env GENIE_SEG), workgroups per CU of the generic stage kernels
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
-    int use_fast;              // the software-pipelined stage-1 kernel applies (ks_uni == 8 && kp_uni == 15)
-    int nofast2;               // tuning: use the generic (leaner, 104-VGPR) stage-2 kernel
-    int s2_plain;              // A/B: k_stage2_fast where k_stage2_ord would run (env GENIE_S2_ORD=0)
-    int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: 144 VGPRs = three per CU)
+    int use_fast;              // the reference's kNN graphs (ks_uni == 8 && kp_uni == 15): the pipelined kernels k_stage1_b3 / k_stage2_ord apply
+    int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: three per CU)
     int s2_wgmap;              // k_stage2_ord: blocks of 4 source nodes per workgroup (large station counts)
-    int s2_nb, s2_bpc;         // k_stage2_lds: source nodes per phase (0 = kernel not used) and workgroups per CU
     int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
-    int nob3s2, bpc2b;         // tuning: GENIE_S2=f32 keeps the fp32 stage-2 kernels; workgroups per CU of k_stage2_b3
     int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
     // workspace offsets (floats)
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
     size_t big_stride;         // so do the P-sized stage-1 -> stage-2 buffers (c, wu, wv)
     int tail_cu_ro, tail_cu_sa; // grid caps (workgroups) of the read-out / SpatialAggregation kernels of the G-sized tail
-    int tail_slim;             // read-out kernels launched in their small-LDS shape (co-residency with stage 1)
     int slot;                  // lets window i+1's stage 1/2 overlap window i's G-sized kernels on another stream
 };
 
 namespace {
 
 // The station processing order is honoured by k_split_rows / the embedding's split rows, k_stage1_b3 (through the relabelled
-// station graph) and k_stage2_fast: active only while those are the kernels that run (not with use_absolute_pos, which takes
+// station graph) and k_stage2_ord: active only while those are the kernels that run (not with use_absolute_pos, which takes
 // the generic stage-1 kernel).
 bool sta_order_on(const genie_ctx* c) {
-    return c->sta_perm != nullptr && !c->pcsr && c->use_b3 && c->use_fast && !c->nofast2 && c->nob3s2 && c->abs_sta == nullptr &&
-           !c->force_generic;
+    return c->sta_perm != nullptr && !c->pcsr && c->use_b3 && c->abs_sta == nullptr && !c->force_generic;
 }
 
 constexpr int GENIE_NSLOT = 16;  // copies of the G-sized per-window buffers (genie_set_slot)
@@ -5705,8 +4361,6 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
     }
     k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3, B3_FRAGS,
                                                                                B3_NBIAS * 32 + 16);
-    k_pack_b3<<<(B3S2_FRAGS * 64 + 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl2, c->packed_b3s2, B3S2_FRAGS, 32 + 16);
-    k_pack_t<<<8, 256, 0, st>>>(c->raw, c->d_tdesc, c->n_tdesc, c->ro_img);
     if (c->has_edges) {
         k_edge_bias<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
                                                             c->mpos_sta, c->S, c->ebias_sta);
@@ -5754,7 +4408,9 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
     a.eb_sta = c->has_edges ? (sta_order_on(c) ? c->ebias_sta_p : c->ebias_sta) : nullptr;
     a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
-    { const char* e = getenv("GENIE_ABLATE"); a.abl = (GENIE_TUNING && e) ? atoi(e) : 0; }
+#if GENIE_TUNING
+    { const char* e = getenv("GENIE_ABLATE"); a.abl = e ? atoi(e) : 0; }
+#endif
     { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
     const size_t bo = (c->slot % GENIE_NBIG) * c->big_stride;
     a.c = ws + c->o_c + bo; a.wu = ws + c->o_wu + bo; a.wv = ws + c->o_wv + bo;
@@ -5991,20 +4647,6 @@ struct CtxGuard {            // destroys a partially built context on every earl
     ~CtxGuard() { if (c) genie_ctx_destroy(c); }
 };
 
-// counters of the next launch of `kind` (0 = stage 1, 1 = stage 2) under the current slot; toggles the parity
-constexpr int DYN_NCTR = DYN_NCTR_DEV;      // counters per set: one per (XCD, group) chunk of a launch
-
-void set_dyn(genie_ctx* c, DaArgs& a, int kind, int gw, int grid) {
-    a.dyn = a.dyn_next = nullptr; a.dyn_batch = 1; a.dyn_gw = gw;
-    if (!((c->dyn_on >> kind) & 1) || !c->dyn_ctr || gw < 1 || 8 * ((grid / 8 + gw - 1) / gw) > DYN_NCTR) return;
-    const int s4 = c->slot % 4;
-    int& par = c->dyn_parity[kind][s4];
-    int* base = c->dyn_ctr + ((kind * 4 + s4) * 2) * DYN_NCTR;
-    a.dyn = base + par * DYN_NCTR;
-    a.dyn_next = base + (par ^ 1) * DYN_NCTR;
-    par ^= 1;
-}
-
 // workgroups (4 waves x 16 nodes) of an MFMA tail kernel over n nodes, at most `cap`
 int tl_blocks(long long n, int cap) { return (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, cap)); }
 
@@ -6116,10 +4758,6 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->d_b3tbl, sizeof(int32_t) * tbl.size()));
         HIP_TRY(hipMemcpy(c->d_b3tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_b3, sizeof(float) * B3_IMG_FLOATS));
-        build_b3_table_stage2(tbl);
-        HIP_TRY(hipMalloc((void**)&c->d_b3tbl2, sizeof(int32_t) * tbl.size()));
-        HIP_TRY(hipMemcpy(c->d_b3tbl2, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->packed_b3s2, sizeof(float) * B3S2_IMG_FLOATS));
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
@@ -6127,7 +4765,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->abs_sta = c->abs_src = nullptr;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
-    c->ea_int = nullptr; c->ea_user = nullptr;
+    c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr;
     c->pcsr = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
@@ -6145,36 +4783,6 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->src_tab, sizeof(int32_t) * tab.size()));
         HIP_TRY(hipMemcpy(c->src_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
     }
-    {
-        std::vector<TDesc> td;
-        auto add = [&](int dst, int w, int rows, int ld, int ldo, int col0, int ncols) {
-            TDesc t; t.dst = dst; t.raw = g_params[w].off; t.rows = rows; t.ld = ld; t.ldo = ldo; t.col0 = col0; t.ncols = ncols; t.pad = 0;
-            td.push_back(t);
-        };
-        for (int m = 0; m < 2; ++m) {                       // common part of both images
-            const int b = m == 0 ? 0 : RO_IMG0;
-            add(b + 0, W_TA_C1_W, 30, 30, 32, 0, 30);
-            add(b + 960, W_TA_V1_W, 30, 30, 32, 0, 30);
-            add(b + 1920, W_TA_C2_W, 75, 30, 96, 0, 30);
-            add(b + 4800, W_TA_V2_W, 75, 30, 96, 0, 30);
-            add(b + 7680, W_TA_P1_W, 30, 15, 32, 0, 15);
-            add(b + 8160, W_TA_P2_W, 1, 30, 32, 0, 0);      // placeholder, proj_2 (a [1,30] row) handled below
-        }
-        // proj_2.weight is [1,30]: image element k (k < 30) = W[0][k] -> rows = 30 "channels" read along the row
-        td[5].rows = 30; td[5].ld = 1; td[5].ldo = 32; td[5].col0 = 0; td[5].ncols = 1;
-        td[11] = td[5]; td[11].dst = RO_IMG0 + 8160;
-        add(RO_IMG_COMMON, W_SD_W, 30, 30, 32, 0, 30);                                   // MODE 0: f_direct
-        add(RO_IMG0 + RO_IMG_COMMON, W_SAT_Q_W, 75, 3, 96, 0, 3);                        // MODE 1: f_queries
-        add(RO_IMG0 + RO_IMG_COMMON + 288, W_SAT_C_W, 75, 33, 96, 30, 3);                //          f_context[:, 30:33]
-        add(RO_IMG0 + RO_IMG_COMMON + 576, W_SAT_V_W, 75, 33, 96, 30, 3);                //          f_values[:, 30:33]
-        add(RO_IMG0 + RO_IMG_COMMON + 864, W_SAT_P_W, 30, 15, 32, 0, 15);                //          proj
-        add(RO_IMG0 + RO_IMG1, W_SAT_C_W, 75, 33, 96, 0, 30);                            // k_ro_pre: f_context[:, 0:30]
-        add(RO_IMG0 + RO_IMG1 + 2880, W_SAT_V_W, 75, 33, 96, 0, 30);                     //           f_values[:, 0:30]
-        c->n_tdesc = (int)td.size();
-        HIP_TRY(hipMalloc((void**)&c->d_tdesc, sizeof(TDesc) * td.size()));
-        HIP_TRY(hipMemcpy(c->d_tdesc, td.data(), sizeof(TDesc) * td.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->ro_img, sizeof(float) * (RO_IMG0 + RO_IMG1 + RO_IMGCV)));
-    }
     c->dirty = true;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -6186,90 +4794,35 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // scheduling segments: node-major sweeps (1) at config 2; at 2000 stations station-tile-major sweeps over segments of 16
         // source nodes keep the source-neighbour rows of stage 1 in L2 (config 4 on one GPU: stage 1 25.8 -> 24.8 ms)
         c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : (n_sta >= 1024 ? 16 : 1);
-        // opt-in experiment (GENIE_DYN=1), measured SLOWER at config 2: one item per claim saturates the counters (stage 2 1.5 ms),
-        // batches of 8-16 items per wave widen the set of source nodes an XCD works on at once and lose the L2 sharing of the
-        // neighbour rows (stage 2 0.27 -> 0.33 ms, window 0.846 -> 0.857 ms)
-        c->dyn_on = (e = getenv("GENIE_DYN")) ? atoi(e) : 0;       // bit 0: k_stage1_b3, bit 1: k_stage2_fast
-        c->dyn_b1 = (e = getenv("GENIE_DYN_G1")) ? std::max(1, atoi(e)) : 4;       // workgroups per counter group (k_stage1_b3)
-        c->dyn_b2 = (e = getenv("GENIE_DYN_G2")) ? std::max(1, atoi(e)) : 8;       // ... (k_stage2_fast)
-        HIP_TRY(hipMalloc((void**)&c->dyn_ctr, sizeof(int) * 2 * 4 * 2 * DYN_NCTR));
-        HIP_TRY(hipMemset(c->dyn_ctr, 0, sizeof(int) * 2 * 4 * 2 * DYN_NCTR));
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
-        // duration, and most of a short tail workgroup is fixed cost (its LDS weight image).
-        c->tail_mfma = ((e = getenv("GENIE_TAIL")) && strcmp(e, "scalar") == 0) ? 0 : 1;   // genie_set_tail_kernels
-        c->tail_cu_ro = c->num_cu * ((e = getenv("GENIE_TAIL_ROX")) ? std::max(1, atoi(e)) : 2);          // genie_set_tail_grid: two 62-KB
-                                            // read-out workgroups per CU hide the gather latency of k_readout_m<1> (window 0.769 -> 0.765 ms)
+        // duration, and most of a short tail workgroup is fixed cost (its LDS weight image). Two 62-KB read-out workgroups per CU
+        // hide the gather latency of k_readout_m<1> (window 0.769 -> 0.765 ms).
+        c->tail_cu_ro = c->num_cu * 2;          // genie_set_tail_grid
         c->tail_cu_sa = c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
-        int occ1 = 0, occ2 = 0;
+        int occ1 = 0, occ2 = 0, occo = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
-        int occ1f = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1f, k_stage1_fast<8, 15>, S1F_THREADS, 0));
-        c->bpc1 = (e = getenv("GENIE_BPC1")) ? atoi(e) : std::max(1, occ1);
-        // 2 workgroups per CU run as fast as 3 (the kernel is MFMA-pipe bound) and leave 52 KB of LDS + wave slots for the
-        // G-sized tail kernels of the previous window on a second stream
-        c->bpc1f = (e = getenv("GENIE_BPC1")) ? atoi(e) : 1;
-        int occ2f = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2f, k_stage2_fast<8, 15>, 256, 0));
-        c->bpc2f = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2f);
-        c->nofast2 = ((e = getenv("GENIE_NOFAST2")) && atoi(e)) ? 1 : 0;
-        c->s2_plain = ((e = getenv("GENIE_S2_ORD")) && atoi(e) == 0) ? 1 : 0;
-        {
-            int occo = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false, 0>, 256, 0));
-            // Large station counts (config 4: 2000 stations, 128 KB of wu / wv rows per source node): the gathers leave L2, and what
-            // pays is locality, not concurrency: blocks of 4 adjacent source nodes per workgroup (one node per wave: the four waves
-            // share half of their source rows, every wu block is gathered on one CU) and two workgroups per CU. Config 4 on one
-            // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
-            // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
-            c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
-            c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : (c->s2_wgmap ? std::min(2, std::max(1, occo)) : std::max(1, occo));
-        }
-        {   // k_stage2_lds: NB source nodes per phase, NB * S * 64 B of station rows in LDS. OPT-IN (GENIE_S2_LDS=1). Measured at
-            // S = 200, T = 13 with three workgroups per CU (164 VGPRs): back to back on cache-warm rows it beats k_stage2_fast
-            // (NB = 3: 0.216 ms vs 0.246), but right after stage 1 -- the only order that occurs, c / wu / wv just written, 500 MB --
-            // it is slower (0.299 vs 0.282 ms, bench 0.865 vs 0.856 ms per window on the same box): the staging copy of a phase
-            // is a cold read that all four waves wait for behind a barrier, where k_stage2_fast prefetches a tile ahead. Kept for
-            // the next step (staging the next phase under the current one); NB = the largest-efficiency count that leaves room
-            // for three workgroups per CU, provided >= 90 % of the wave slots are used.
-            c->s2_nb = 0; c->s2_bpc = 1;
-            const size_t img = sizeof(float) * (G2_GROUPS * 256 + G2_BIAS * 16 + 16);
-            const long long budget = (e = getenv("GENIE_S2_LDSKB")) ? 1024ll * atoi(e) : (long long)(160 * 1024 / 3 - img - 256);
-            const bool on = (e = getenv("GENIE_S2_LDS")) && atoi(e) != 0;
-            if (on && c->ks_uni == 8 && c->kp_uni == 15) {
-                int best = 0; double best_eff = 0.0;
-                for (int n = 1; n <= 8 && (long long)n * n_sta * 64 <= budget; ++n) {
-                    const double eff = (double)(n * c->T) / (4.0 * ((n * c->T + 3) / 4));
-                    if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
-                }
-                if ((e = getenv("GENIE_S2_NB"))) { best = atoi(e); best_eff = 1.0; }
-                if (best > 0 && best_eff >= 0.9 && (long long)best * n_sta * 64 <= 150 * 1024) {
-                    c->s2_nb = best;
-                    const size_t lds = img + (size_t)best * n_sta * 64;
-                    HIP_TRY(hipFuncSetAttribute((const void*)k_stage2_lds<8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    int occ = 0;
-                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stage2_lds<8, 15>, 256, lds));
-                    c->s2_bpc = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ);
-                }
-            }
-        }
-        // k_stage1_fast addresses the 16-B Slice / Mask rows with 32-bit byte offsets
-        c->use_fast = (c->ks_uni == 8 && c->kp_uni == 15 && c->P_ext * 16 < (1ll << 32) && !((e = getenv("GENIE_NOFAST")) && atoi(e)));
-        // bf16x3 stage 1: same graph shape, 24-bit multiplicands (64-bit row offsets are a template variant)
-        c->use_b3 = (c->ks_uni == 8 && c->kp_uni == 15 && n_grid_ext < (1 << 24) &&
-                     (long long)n_sta * XROW < (1 << 24) && !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false>, 256, 0));
+        c->bpc1 = std::max(1, occ1);
+        c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
+        // Large station counts (config 4: 2000 stations, 128 KB of wu / wv rows per source node): the gathers leave L2, and what
+        // pays is locality, not concurrency: blocks of 4 adjacent source nodes per workgroup (one node per wave: the four waves
+        // share half of their source rows, every wu block is gathered on one CU) and two workgroups per CU. Config 4 on one
+        // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
+        // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
+        c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
+        c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : (c->s2_wgmap ? std::min(2, std::max(1, occo)) : std::max(1, occo));
+        // the reference's kNN graphs (8 station / 15 source neighbours everywhere): pipelined kernels k_stage1_b3 / k_stage2_ord
+        c->use_fast = c->ks_uni == 8 && c->kp_uni == 15;
+        // bf16x3 stage 1: 24-bit multiplicands (64-bit row offsets are a template variant); GENIE_S1=f32 = the generic fp32-MFMA
+        // kernels, the A/B reference
+        c->use_b3 = (c->use_fast && n_grid_ext < (1 << 24) && (long long)n_sta * XROW < (1 << 24) &&
+                     !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
         // 4 workgroups per CU in the grid, one resident: a workgroup held up by a tail kernel of the previous window then costs a
         // quarter of a share, not a whole one (pipelined window 0.877 -> 0.866 ms; no effect on the kernel alone)
         c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 4;
-        // k_stage2_b3 is no faster than k_stage2_fast (stage 2 is bound by L2-miss traffic, not by its arithmetic) and its 240
-        // VGPRs leave no room for the G-sized tail kernels of the previous window: opt-in only (GENIE_S2=b3)
-        c->nob3s2 = ((e = getenv("GENIE_S2")) && strcmp(e, "b3") == 0) ? 0 : 1;
-        int occ2b = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2b, k_stage2_b3<8, 15>, 256, 0));
-        c->bpc2b = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2b);
-        c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
     }
 #if GENIE_TUNING
     {
@@ -6372,24 +4925,12 @@ int genie_set_scale_t(genie_ctx* c, float scale_t) {
     return GENIE_OK;
 }
 
-int genie_set_tail_mode(genie_ctx* c, int slim) {
-    if (!c) return fail(GENIE_ERR_ARG, "genie_set_tail_mode: null context");
-    c->tail_slim = slim ? 1 : 0;
-    return GENIE_OK;
-}
-
-int genie_set_tail_kernels(genie_ctx* c, int mfma) {
-    if (!c) return fail(GENIE_ERR_ARG, "genie_set_tail_kernels: null context");
-    c->tail_mfma = mfma ? 1 : 0;
-    return GENIE_OK;
-}
-
 int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_station_order: null context");
     void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int};
     for (void* q : old) (void)hipFree(q);
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr;
-    c->ea_int = nullptr; c->ea_user = nullptr;
+    c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->dirty = true;
     if (!order_host || c->pcsr) return GENIE_OK;
     const int S = c->S;
@@ -6447,11 +4988,11 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[4], c->d_steps[5], c->d_steps[6], c->d_bias[4], c->d_bias[5], c->d_bias[6], c->d_scal[4], c->d_scal[5],
                     c->d_scal[6], c->packed[4], c->packed[5], c->packed[6], c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_vec[0],
                     c->d_vec[1], c->d_vec[2], c->d_sc[0], c->d_sc[1], c->d_sc[2],
-                    c->as_pg, c->dyn_ctr, c->ro_img, c->d_tdesc, c->d_b3tbl, c->packed_b3, c->src_tab, c->d_b3tbl2, c->packed_b3s2,
+                    c->as_pg, c->d_b3tbl, c->packed_b3, c->src_tab,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
-                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int};
+                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -6514,22 +5055,6 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (dbg_h0) a.dbg_h0 = dbg_tmp;
         if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
     }
-#if GENIE_TUNING
-    static float* tbuf1 = nullptr;
-    if (c->use_b3 && a.abl & 1024) {   // per-wave phase timers of k_stage1_b3 (GENIE_ABLATE bit 10), dumped with GENIE_DUMP_PHASES
-        if (!tbuf1) { HIP_TRY(hipMalloc((void**)&tbuf1, sizeof(float) * 8 * 8 * 4096)); HIP_TRY(hipMemset(tbuf1, 0, sizeof(float) * 8 * 8 * 4096)); }
-        if (getenv("GENIE_DUMP_PHASES")) {
-            HIP_TRY(hipDeviceSynchronize());
-            std::vector<float> hbuf(8 * 8 * 4096);
-            HIP_TRY(hipMemcpy(hbuf.data(), tbuf1, sizeof(float) * hbuf.size(), hipMemcpyDeviceToHost));
-            double sum[5] = {0, 0, 0, 0, 0}; int n = 0;
-            for (int wv = 0; wv < 8 * 4096; ++wv) if (hbuf[wv * 8 + 1] > 0) { for (int k = 0; k < 5; ++k) sum[k] += hbuf[wv * 8 + k]; ++n; }
-            if (n) fprintf(stderr, "[stage1_b3 phases, avg memtime ticks per wave over %d waves] loop+ids %.0f neighbours %.0f layer1 %.0f uvc %.0f w+stores+fetch %.0f\n",
-                           n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
-        }
-        a.x_latent = tbuf1;
-    }
-#endif
     if ((c->force_generic || c->abs_sta) && !c->pcsr && !(c->use_b3 && B3_ABS_READY && !c->force_generic)) {   // use_absolute_pos / training: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr) {
@@ -6557,7 +5082,6 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         }
         a.xs = xs; a.packed = c->packed_b3; a.xs_plane = c->P_ext * (long long)XPC;
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
-        if (n_tiles) set_dyn(c, a, 0, c->dyn_b1, grid);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
         } else if (c->has_edges) {
@@ -6567,8 +5091,6 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
             if (big) k_stage1_b3<8, 15, false, true><<<grid, B3_THREADS, 0, st>>>(a);
             else k_stage1_b3<8, 15, false, false><<<grid, B3_THREADS, 0, st>>>(a);
         }
-    } else if (c->use_fast) {
-        if (n_tiles) k_stage1_fast<8, 15><<<da_grid_w(c, n_tiles, c->bpc1f, S1F_THREADS / 64), S1F_THREADS, 0, st>>>(a);
     } else if (n_tiles)
         k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
@@ -6640,65 +5162,24 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     a.ea_int = (sta_order_on(c) && c->ea_int && c->ea_user == edge_attr) ? c->ea_int : nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-#if GENIE_TUNING
-    {   // per-wave phase timers of k_stage2_fast (GENIE_ABLATE bit 10): dumped to stderr by the host after a sync
-        static float* tbuf = nullptr;
-        if (!tbuf) { HIP_TRY(hipMalloc((void**)&tbuf, sizeof(float) * 8 * 4 * 4096)); HIP_TRY(hipMemset(tbuf, 0, sizeof(float) * 8 * 4 * 4096)); }
-        a.dbg_h0 = tbuf;
-        if (getenv("GENIE_DUMP_PHASES")) {
-            HIP_TRY(hipDeviceSynchronize());
-            std::vector<float> hbuf(8 * 4 * 4096);
-            HIP_TRY(hipMemcpy(hbuf.data(), tbuf, sizeof(float) * hbuf.size(), hipMemcpyDeviceToHost));
-            double sum[5] = {0, 0, 0, 0, 0}; int n = 0;
-            for (int wv = 0; wv < 4 * 4096; ++wv) if (hbuf[wv * 8] > 0) { for (int k = 0; k < 5; ++k) sum[k] += hbuf[wv * 8 + k]; ++n; }
-            if (n) fprintf(stderr, "[stage2 phases, avg memtime ticks per wave over %d waves] wait+loop %.0f sums %.0f issue+ids %.0f prelu+mfma %.0f reduce+store %.0f\n",
-                           n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
-        }
-    }
-#endif
     if (c->force_generic && !c->pcsr) {
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
-    } else if (c->use_b3 && !c->nob3s2 && !no_bip && c->P_ext * 64 < (1ll << 32)) {     // k_stage2_b3 keeps 32-bit row offsets
-        a.packed = c->packed_b3s2;
-        k_stage2_b3<8, 15><<<da_grid(c, (n_tiles + 1) / 2, c->bpc2b), 256, 0, st>>>(a);
-    } else if (c->use_fast && !c->nofast2 && c->s2_nb > 0) {
-        const size_t lds = sizeof(float) * (G2_GROUPS * 256 + G2_BIAS * 16 + 16) + (size_t)c->s2_nb * c->S * 64;
-        const long long phases = (a.G + c->s2_nb - 1) / c->s2_nb + 8;
-        long long g = std::min<long long>(phases, (long long)c->num_cu * c->s2_bpc);
-        g = std::max<long long>(8, (g + 7) / 8 * 8);
-        k_stage2_lds<8, 15><<<(int)g, 256, lds, st>>>(a, c->s2_nb);
-    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && no_bip && x_latent_out && !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
+    } else if (c->use_fast && a.sta_user != nullptr && (!no_bip || x_latent_out != nullptr)) {
+        // the production configuration: uniform 8 / 15-degree graphs, station processing order; the static edge_attr is registered
+        // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])
+        if (!no_bip && a.ea_int == nullptr) {
+            if (!c->ea_tmp) HIP_TRY(hipMalloc((void**)&c->ea_tmp, sizeof(float) * 3 * (size_t)c->P));
+            k_permute_sta_rows<<<(unsigned)((c->P * 3 + 255) / 256), 256, 0, st>>>(edge_attr, c->P, 3, c->sta_inv, c->S, c->ea_tmp);
+            a.ea_int = c->ea_tmp;
+        }
         const int grid = da_grid(c, n_tiles, c->bpc2o);
-        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
-        k_stage2_ord<8, 15, true, 0, true, true><<<grid, 256, 0, st>>>(a);
-    } else if (c->use_fast && !c->nofast2 && a.sta_user != nullptr && a.ea_int != nullptr && !no_bip &&
-               !((c->dyn_on >> 1) & 1) && !c->s2_plain) {
-        const int grid = da_grid(c, n_tiles, c->bpc2o);
-        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
-        a.wgmap = c->s2_wgmap;
-        const char* es = getenv("GENIE_S2_SCHED");
-        const int sched = es ? atoi(es) : 0;
-        const char* erl = getenv("GENIE_S2_RL");
-        const bool rl = !(erl && atoi(erl) == 0);
-        if (x_latent_out && rl) k_stage2_ord<8, 15, true, 0, true><<<grid, 256, 0, st>>>(a);
-        else if (x_latent_out) k_stage2_ord<8, 15, true, 0><<<grid, 256, 0, st>>>(a);
-        else if (rl && sched == 0 && getenv("GENIE_S2_SD") && atoi(getenv("GENIE_S2_SD")) != 0)      // opt-in: 246 VGPRs, 0.226 -> 0.240 ms
-            k_stage2_ord<8, 15, false, 0, true, false, true><<<grid, 256, 0, st>>>(a);
-        else if (rl && sched == 0) k_stage2_ord<8, 15, false, 0, true><<<grid, 256, 0, st>>>(a);
-        else if (sched == 3) k_stage2_ord<8, 15, false, 3><<<da_grid_w(c, n_tiles, 1, 8), 512, 0, st>>>(a);
-        else if (sched == 1) k_stage2_ord<8, 15, false, 1><<<grid, 256, 0, st>>>(a);
-        else if (sched == 2) k_stage2_ord<8, 15, false, 2><<<grid, 256, 0, st>>>(a);
-        else k_stage2_ord<8, 15, false, 0><<<grid, 256, 0, st>>>(a);
-    } else if (c->use_fast && !c->nofast2) {
-        const int grid = da_grid(c, n_tiles, c->bpc2f);
-        set_dyn(c, a, 1, c->dyn_b2, grid);
-        // backwards sweep: the c / wu / wv rows stage 1 wrote last (still in the Infinity Cache) are read first; stage 2
-        // 0.278 -> 0.276 ms, same-box A/B (GENIE_S2_REV=0 = forwards); per-tile results do not depend on the order
-        { const char* e = getenv("GENIE_S2_REV"); a.rev = (e && atoi(e) == 0) ? 0 : 1; }
-        k_stage2_fast<8, 15><<<grid, 256, 0, st>>>(a);
+        a.wgmap = no_bip ? 0 : c->s2_wgmap;
+        if (no_bip) k_stage2_ord<8, 15, true, true><<<grid, 256, 0, st>>>(a);
+        else if (x_latent_out) k_stage2_ord<8, 15, true><<<grid, 256, 0, st>>>(a);
+        else k_stage2_ord<8, 15, false><<<grid, 256, 0, st>>>(a);
     }
     else
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
@@ -6712,16 +5193,14 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
     if (rc) return rc;
     if (!bip_out) return fail(GENIE_ERR_ARG, "genie_bipartite_readout: null output");
     const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
-    const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
-    if (c->pcsr)       // the messages sit in the c rows (k_stage2_pcsr)
+    if (c->pcsr) {     // the messages sit in the c rows (k_stage2_pcsr)
+        const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
         k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride, c->G, c->seg_rowptr, c->raw,
                                                           g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
-    else if (c->tail_mfma) {
+    } else {
         { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
         k_bip_out_m<<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
-    } else
-    k_bip_out<<<nb, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off,
-                                                  g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out, 0, 0);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -6750,13 +5229,10 @@ void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
         a.nx_act3 = g_params[nb + 8].off;
     }
 }
-int sa_blocks(const genie_ctx* c) {
-    if (c->tail_mfma) return tl_blocks(c->G, std::min(1024, c->tail_cu_sa));
-    return std::min((c->G + NPB - 1) / NPB, c->tail_cu_sa);
-}
+int sa_blocks(const genie_ctx* c) { return tl_blocks(c->G, std::min(1024, c->tail_cu_sa)); }
 
-// chain = true: the pre-pass of `layer` was already produced (by k_sa_pre or by the previous layer's NEXT tail) in
-// pj/gpart buffer `cur`; with_next emits the next layer's pre-pass into the other buffer.
+// The pre-pass of `layer` was already produced (by k_sa_pre_m or by the previous layer's NEXT tail) in pj / gpart buffer `cur`;
+// with_next emits the next layer's pre-pass into the other buffer.
 int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos, float* out, float* ws, int cur,
                     bool with_next, hipStream_t st) {
     SaArgs a;
@@ -6769,18 +5245,12 @@ int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos
     a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_blocks(c);
     a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
     const int nb = sa_blocks(c);
-    if (c->tail_mfma) {
-        { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
-        a.img = c->packed[PL_SA1 + layer - 1];
-        if (layer == 1) {
-            if (with_next) k_sa_layer_m<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false><<<nb, 256, 0, st>>>(a);
-        } else {
-            if (with_next) k_sa_layer_m<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false><<<nb, 256, 0, st>>>(a);
-        }
-    } else if (layer == 1) {
-        if (with_next) k_sa_layer<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<15, false><<<nb, 256, 0, st>>>(a);
+    { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+    a.img = c->packed[PL_SA1 + layer - 1];
+    if (layer == 1) {
+        if (with_next) k_sa_layer_m<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false><<<nb, 256, 0, st>>>(a);
     } else {
-        if (with_next) k_sa_layer<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer<30, false><<<nb, 256, 0, st>>>(a);
+        if (with_next) k_sa_layer_m<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false><<<nb, 256, 0, st>>>(a);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -6793,11 +5263,9 @@ int sa_launch_pre(genie_ctx* c, int layer, const float* x_in, float* ws, int cur
     a.pj_out = ws + (cur ? c->o_pj1 : c->o_pj0) + c->slot * c->slot_stride;
     a.gpart_out = ws + c->o_gpart + c->slot * c->slot_stride + (cur ? 1024 * 8 : 0);
     const int nb = sa_blocks(c);
-    if (c->tail_mfma) {
-        { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
-        a.img = c->packed[PL_SA1 + layer - 1];
-        if (layer == 1) k_sa_pre_m<15><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30><<<nb, 256, 0, st>>>(a);
-    } else if (layer == 1) k_sa_pre<15><<<nb, 256, 0, st>>>(a); else k_sa_pre<30><<<nb, 256, 0, st>>>(a);
+    { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+    a.img = c->packed[PL_SA1 + layer - 1];
+    if (layer == 1) k_sa_pre_m<15><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30><<<nb, 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -6858,14 +5326,6 @@ RoArgs make_ro_args(const genie_ctx* c) {
     a.o_sa1 = g_params[W_SAT_ACT1].off; a.o_sa2 = g_params[W_SAT_ACT2].off;
     return a;
 }
-constexpr int RO_SCR = 40 + 32 + 32 + 96 + 96 + 52 + RO_TMAX * 16 + 96 + 96;
-// node groups (of 32 lanes) per workgroup. "fat": many groups share one weight image (best standalone latency);
-// "slim": <= 52 KB of LDS so that a read-out workgroup co-resides with two k_stage1_fast workgroups (2 x 54 KB) when the
-// G-sized tail of window i runs on a side stream under the P-sized kernels of window i+1 (genie_set_tail_mode).
-constexpr int RO_NG0 = 24, RO_NG1 = 20, RO_NG0_SLIM = 4, RO_NG1_SLIM = 2;   // NG1 = 20: 10 000 queries = 1.95 rounds of 256 x 20
-constexpr size_t ro_lds(int mode, int ng) {
-    return sizeof(float) * ((mode == 0 ? RO_IMG0 : RO_IMG1) + RO_TMAX * 96 + ng * RO_SCR);
-}
 }  // namespace
 
 int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
@@ -6874,60 +5334,61 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
     RoArgs a = make_ro_args(c);
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
-    a.img = c->ro_img;
-    if (c->tail_mfma) {
-        a.img = c->packed[PL_RO0];
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
-        k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
-    } else if (c->tail_slim) {
-        const int nb = std::min((a.N + RO_NG0_SLIM - 1) / RO_NG0_SLIM, c->num_cu);
-        k_readout<0, RO_NG0_SLIM><<<nb, RO_NG0_SLIM * 32, ro_lds(0, RO_NG0_SLIM), (hipStream_t)stream>>>(a);
-    } else {
-        const int nb = std::min((a.N + RO_NG0 - 1) / RO_NG0, c->tail_cu_ro);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ro_lds(0, RO_NG0)));
-        k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), (hipStream_t)stream>>>(a);
-    }
+    a.img = c->packed[PL_RO0];
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 
-int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
-                        int n_query, int k, const float* t_query, int n_t, float* x_out, void* ws, void* stream) {
+namespace {
+// x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query, and / or the SpatialAttention output itself
+int readout_query_impl(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
+                       int n_query, int k, const float* t_query, int n_t, float* x_out, float* lat_out, void* ws, void* stream) {
     { int rcw = check_ws(c, ws); if (rcw) return rcw; }
-    if (!c || !x_spatial || !x_grid || !x_query || !knn || !t_query || !x_out)
-        return fail(GENIE_ERR_ARG, "genie_readout_query: null argument");
+    if (!x_spatial || !x_grid || !x_query || !knn || !t_query || !x_out) return fail(GENIE_ERR_ARG, "genie_readout_query: null argument");
     if (k != RO_K) return fail(GENIE_ERR_ARG, "genie_readout_query: k must be 10 (module.py:280)");
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_query: 1 <= n_t <= 10 required");
     if (n_query < 1) return fail(GENIE_ERR_ARG, "genie_readout_query: n_query < 1");
     RoArgs a = make_ro_args(c);
     a.N = a.Nw = n_query; a.T = n_t; a.x_spatial = x_spatial; a.x_grid = x_grid; a.x_query = x_query; a.knn = knn;
-    a.t_query = t_query; a.out = x_out;
+    a.t_query = t_query; a.out = x_out; a.lat_out = lat_out;
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
-    a.img = c->ro_img + RO_IMG0;
     float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
-    if (c->tail_mfma) {
-        k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
-        a.img = c->packed[PL_RO1];
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
-        k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
-        HIP_TRY(hipGetLastError());
-        return GENIE_OK;
-    }
-    k_ro_pre<<<std::min((c->G + NPB - 1) / NPB, std::min(c->num_cu * 4, c->tail_cu_ro * 4)), 256, 0, (hipStream_t)stream>>>(
-        x_spatial, c->G, c->ro_img + RO_IMG0 + RO_IMG1, cvbuf, c->G, 0);
-    if (c->tail_slim) {
-        const int nb = std::min((a.N + RO_NG1_SLIM - 1) / RO_NG1_SLIM, c->num_cu);
-        k_readout<1, RO_NG1_SLIM><<<nb, RO_NG1_SLIM * 32, ro_lds(1, RO_NG1_SLIM), (hipStream_t)stream>>>(a);
-    } else {
-        const int nb = std::min((a.N + RO_NG1 - 1) / RO_NG1, c->tail_cu_ro);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ro_lds(1, RO_NG1)));
-        k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), (hipStream_t)stream>>>(a);
-    }
+    k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+    a.img = c->packed[PL_RO1];
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
+}
+}  // namespace
+
+int genie_readout_query(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
+                        int n_query, int k, const float* t_query, int n_t, float* x_out, void* ws, void* stream) {
+    return readout_query_impl(c, x_spatial, x_grid, x_query, knn, n_query, k, t_query, n_t, x_out, nullptr, ws, stream);
+}
+
+// The latent inputs of TemporalAttention next to the read-outs (the 4-output forward needs them, module.py:978-981):
+// y_latent = SpatialDirect(x_spatial) [n_grid, 30] and / or SpatialAttention(x_spatial, x_query, x_grid) [n_query, 30].
+int genie_readout_grid_latent(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, float* y_latent_out,
+                              void* stream) {
+    if (!c || !x_spatial || !t_query || !y_out || !y_latent_out) return fail(GENIE_ERR_ARG, "genie_readout_grid_latent: null argument");
+    if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid_latent: 1 <= n_t <= 10 required");
+    RoArgs a = make_ro_args(c);
+    { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
+    a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out; a.lat_out = y_latent_out;
+    a.img = c->packed[PL_RO0];
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+int genie_readout_query_latent(genie_ctx* c, const float* x_spatial, const float* x_grid, const float* x_query, const int32_t* knn,
+                               int n_query, int k, const float* t_query, int n_t, float* x_out, float* latent_out, void* ws, void* stream) {
+    if (!latent_out) return fail(GENIE_ERR_ARG, "genie_readout_query_latent: null argument");
+    return readout_query_impl(c, x_spatial, x_grid, x_query, knn, n_query, k, t_query, n_t, x_out, latent_out, ws, stream);
 }
 
 // The G-sized tail of `nwin` windows in one set of launches (Bipartite read-out, SpatialAggregation x3, both read-out heads).
@@ -6952,18 +5413,11 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     float* w = (float*)ws;
     const long long ss = (long long)c->slot_stride;
     const size_t so = (size_t)slot0 * c->slot_stride;
-    const bool mf = c->tail_mfma != 0;
     // Bipartite read-out -> bip[slot]
-    if (mf)
-        k_bip_out_m<<<dim3(tl_blocks(c->G, std::max(32, c->num_cu * 2 / nwin)), nwin), 256, 0, st>>>(
-            w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], w + c->o_bip + so, ss, ss);
-    else
-    k_bip_out<<<dim3(std::min((c->G + NPB - 1) / NPB, std::max(32, c->num_cu * 8 / nwin)), nwin), 256, 0, st>>>(
-        w + c->o_part + so, c->G, c->T, c->raw, g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off,
-        w + c->o_bip + so, ss, ss);
+    k_bip_out_m<<<dim3(tl_blocks(c->G, std::max(32, c->num_cu * 2 / nwin)), nwin), 256, 0, st>>>(
+        w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], w + c->o_bip + so, ss, ss);
     // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
-    const int nbx = mf ? tl_blocks(c->G, std::min(1024, std::max(32, c->num_cu * 2 / nwin)))
-                       : std::min((c->G + NPB - 1) / NPB, std::min(1024, std::max(32, c->num_cu * 8 / nwin)));
+    const int nbx = tl_blocks(c->G, std::min(1024, std::max(32, c->num_cu * 2 / nwin)));
     float* pj[2] = {w + c->o_pj0 + so, w + c->o_pj1 + so};
     float* gp[2] = {w + c->o_gpart + so, w + c->o_gpart + so + 1024 * 8};
     const dim3 grid(nbx, nwin);
@@ -6974,7 +5428,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.x_in = w + c->o_bip + so; a.ws_x_in = ss; a.ws_slot = ss;
         a.pj_out = pj[0]; a.gpart_out = gp[0];
         a.img = c->packed[PL_SA1];
-        if (mf) k_sa_pre_m<15><<<grid, 256, 0, st>>>(a); else k_sa_pre<15><<<grid, 256, 0, st>>>(a);
+        k_sa_pre_m<15><<<grid, 256, 0, st>>>(a);
     }
     for (int layer = 1; layer <= 3; ++layer) {
         SaArgs a;
@@ -6989,46 +5443,26 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = nbx;
         a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
         a.img = c->packed[PL_SA1 + layer - 1];
-        if (mf) {
-            if (layer == 1) k_sa_layer_m<15, true><<<grid, 256, 0, st>>>(a);
-            else if (layer == 2) k_sa_layer_m<30, true><<<grid, 256, 0, st>>>(a);
-            else k_sa_layer_m<30, false><<<grid, 256, 0, st>>>(a);
-        } else if (layer == 1) k_sa_layer<15, true><<<grid, 256, 0, st>>>(a);
-        else if (layer == 2) k_sa_layer<30, true><<<grid, 256, 0, st>>>(a);
-        else k_sa_layer<30, false><<<grid, 256, 0, st>>>(a);
+        if (layer == 1) k_sa_layer_m<15, true><<<grid, 256, 0, st>>>(a);
+        else if (layer == 2) k_sa_layer_m<30, true><<<grid, 256, 0, st>>>(a);
+        else k_sa_layer_m<30, false><<<grid, 256, 0, st>>>(a);
     }
     // read-out heads over the nwin * G grid nodes / nwin * Q queries
     RoArgs a = make_ro_args(c);
     a.T = n_t; a.x_spatial = x_spatial_out; a.t_query = t_query;
     {
         RoArgs g = a;
-        g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->ro_img;
-        const int nb = std::min((g.N + RO_NG0 - 1) / RO_NG0, c->tail_cu_ro);
-        if (mf) {
-            g.img = c->packed[PL_RO0];
-            HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
-            k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
-        } else {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<0, RO_NG0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(0, RO_NG0)));
-        k_readout<0, RO_NG0><<<nb, RO_NG0 * 32, ro_lds(0, RO_NG0), st>>>(g);
-        }
+        g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->packed[PL_RO0];
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
     }
-    if (x_out && mf) {
+    if (x_out) {
         k_ro_pre_m<<<tl_blocks((long long)nwin * c->G, c->tail_cu_ro), 256, 0, st>>>(x_spatial_out, nwin * c->G, c->packed[PL_ROP], w + c->o_cv + so, c->G, ss);
         RoArgs q = a;
         q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
         q.img = c->packed[PL_RO1]; q.cv = w + c->o_cv + so; q.cv_ws = ss;
         HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
         k_readout_m<1><<<tl_blocks(q.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(q);
-    } else if (x_out) {
-        k_ro_pre<<<std::min((nwin * c->G + NPB - 1) / NPB, c->num_cu * 4), 256, 0, st>>>(
-            x_spatial_out, nwin * c->G, c->ro_img + RO_IMG0 + RO_IMG1, w + c->o_cv + so, c->G, ss);
-        RoArgs q = a;
-        q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
-        q.img = c->ro_img + RO_IMG0; q.cv = w + c->o_cv + so; q.cv_ws = ss;
-        const int nb = std::min((q.N + RO_NG1 - 1) / RO_NG1, c->tail_cu_ro);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout<1, RO_NG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ro_lds(1, RO_NG1)));
-        k_readout<1, RO_NG1><<<nb, RO_NG1 * 32, ro_lds(1, RO_NG1), st>>>(q);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -7095,14 +5529,6 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
 }
 }  // namespace
 
-#if GENIE_TUNING
-int genie_debug_xcc_map(int* out_dev, int nblocks, void* stream) {
-    const char* e = getenv("GENIE_PROBE_THREADS");
-    k_xcc_probe<<<nblocks, e ? atoi(e) : 64, 0, (hipStream_t)stream>>>(out_dev);
-    HIP_TRY(hipGetLastError());
-    return GENIE_OK;
-}
-#endif
 
 int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* out_sta, float* out_src, int row_floats,
                    void* stream) {
@@ -7342,7 +5768,6 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     if (!pos || !x_query || !knn || !t_query || !tsave || !y_out || !x_out) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: null argument");
     if ((rc = train_check(c, "genie_tail_train_fwd"))) return rc;
     if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
-    if (!c->tail_mfma) return fail(GENIE_ERR_STATE, "genie_tail_train_fwd: needs the MFMA tail kernels");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     float* w = (float*)ws;
@@ -7487,46 +5912,8 @@ int genie_train_bwd(genie_ctx* c, const float* slice, const float* mask, const f
     return da_train_bwd_impl(c, slice, mask, edge_attr, save, d_r_scratch, front_scratch, grad_blob, stream, false);
 }
 
-int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out) {
-    if (!mask_words || n_words < 1 || !stream_out) return fail(GENIE_ERR_ARG, "genie_stream_create_masked: bad argument");
-    hipStream_t st = nullptr;
-    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
-    *stream_out = (void*)st;
-    return GENIE_OK;
-}
 
-int genie_stream_destroy(void* stream) {
-    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
-    return GENIE_OK;
-}
 
-int genie_cu_mask_probe(int32_t* xcc_of_bit, int n_bits) {
-    if (!xcc_of_bit || n_bits < 1 || n_bits > 1024) return fail(GENIE_ERR_ARG, "genie_cu_mask_probe: bad argument");
-    int* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, sizeof(int) * 2 * 64));
-    const int n_words = (n_bits + 31) / 32;
-    std::vector<uint32_t> words((size_t)n_words);
-    std::vector<int> h(2 * 64);
-    for (int b = 0; b < n_bits; ++b) {
-        std::fill(words.begin(), words.end(), 0u);
-        words[b >> 5] = 1u << (b & 31);
-        hipStream_t st = nullptr;
-        xcc_of_bit[b] = -1;
-        if (hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, words.data()) != hipSuccess) { (void)hipGetLastError(); continue; }
-        (void)hipMemsetAsync(d, 0xff, sizeof(int) * 2 * 64, st);
-        k_where_am_i<<<64, 64, 0, st>>>(d);
-        const bool ok = hipStreamSynchronize(st) == hipSuccess &&
-                        hipMemcpy(h.data(), d, sizeof(int) * 2 * 64, hipMemcpyDeviceToHost) == hipSuccess;
-        (void)hipStreamDestroy(st);
-        if (!ok) continue;
-        int x = h[0];
-        for (int k = 1; k < 64; ++k)
-            if (h[2 * k] != x) x = -2;            // the blocks of a one-CU stream must all report the same XCD
-        xcc_of_bit[b] = x;
-    }
-    (void)hipFree(d);
-    return GENIE_OK;
-}
 
 int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream) {
     if (!out_dev || n_blocks < 1) return fail(GENIE_ERR_ARG, "genie_where_am_i: bad argument");
@@ -7537,22 +5924,11 @@ int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream) {
 
 int genie_set_tail_grid(genie_ctx* c, int readout_workgroups, int sa_workgroups) {
     if (!c || readout_workgroups < 0 || sa_workgroups < 0) return fail(GENIE_ERR_ARG, "genie_set_tail_grid: bad argument");
-    const char* e = getenv("GENIE_TAIL_ROX");      // tuning: default read-out grid cap in workgroups per CU
-    c->tail_cu_ro = readout_workgroups > 0 ? readout_workgroups : c->num_cu * (e ? std::max(1, atoi(e)) : 2);
+    c->tail_cu_ro = readout_workgroups > 0 ? readout_workgroups : c->num_cu * 2;
     c->tail_cu_sa = sa_workgroups > 0 ? sa_workgroups : c->num_cu * 2;
     return GENIE_OK;
 }
 
-int genie_set_num_cu(genie_ctx* c, int n) {
-    if (!c || n < 0) return fail(GENIE_ERR_ARG, "genie_set_num_cu: bad argument");
-    int dev = 0;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    const int all = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->num_cu = (n == 0 || n > all) ? all : n;
-    return GENIE_OK;
-}
 
 size_t genie_assoc_workspace_bytes(const genie_ctx* c) { return c ? sizeof(float) * 3 * 32 * (size_t)c->P : 0; }
 

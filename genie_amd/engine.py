@@ -156,8 +156,6 @@ def _quantise_isotropic(points, bits):
     lo, hi = x.min(0), x.max(0)
     top = float((1 << bits) - 1)
     scale = top / max(float((hi - lo).max()), 1e-9)
-    if os.environ.get("GENIE_MORTON_PER_AXIS") == "1":      # A/B: the earlier per-axis quantisation
-        scale = top / np.maximum(hi - lo, 1e-9)
     return np.clip(((x - lo) * scale).astype(np.int64), 0, (1 << bits) - 1)
 
 
@@ -211,8 +209,8 @@ def hilbert_order(points, bits=10):
 
 def sfc_order(points):
     """The processing order used for source nodes and stations: the Z-curve (measured at config 2: 0.781 ms/window against
-    0.785 with the Hilbert curve; config 4: 42.1 against 41.7 ms; GENIE_SFC=hilbert selects the latter)."""
-    return hilbert_order(points) if os.environ.get("GENIE_SFC") == "hilbert" else morton_order(points)
+    0.785 with the Hilbert curve `hilbert_order`; config 4: 42.1 against 41.7 ms)."""
+    return morton_order(points)
 
 
 ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.", "LocalSliceLgCollapseP.",
@@ -271,8 +269,8 @@ class HipPath(object):
                                                _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
                                                _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
             _lib.check(rc, "genie_ctx_create")
-            if sta_order is not None and os.environ.get("GENIE_STA_ORDER", "1") != "0":
-                so = np.ascontiguousarray(np.asarray(sta_order), dtype=np.int32)
+            if True:      # without a station order the identity: stage 2's production kernel reads its rows in processing order
+                so = np.ascontiguousarray(np.asarray(sta_order if sta_order is not None else np.arange(self.n_sta)), dtype=np.int32)
                 if so.shape != (self.n_sta,):
                     raise ValueError("sta_order must have n_sta entries")
                 _lib.check(self.lib.genie_set_station_order(self.ctx, ctypes.c_void_p(so.ctypes.data)), "genie_set_station_order")
@@ -412,40 +410,7 @@ class HipPath(object):
                                            _ptr(x_latent), _ptr(bip), self._ws_ptr, _stream()), "genie_path_fwd")
         return out, x_latent, bip
 
-    # ---- CU partitioning -----------------------------------------------------------------------------
-    def _masked_stream(self, bits, n_cu_total):
-        n_words = (n_cu_total + 31) // 32
-        words = (ctypes.c_uint32 * n_words)(*[(bits >> (32 * i)) & 0xffffffff for i in range(n_words)])
-        st = ctypes.c_void_p()
-        _lib.check(self.lib.genie_stream_create_masked(words, n_words, ctypes.byref(st)), "genie_stream_create_masked")
-        return torch.cuda.ExternalStream(st.value, device=self.device)
-
-    def enable_cu_partition(self, tail_cus_per_xcd=1, n_xcd=8):
-        """Give the G-sized tails CUs of their own. The persistent P-sized kernels own every register of every CU, so a tail
-        kernel on a side stream only runs when one of their workgroups retires and then holds that CU: ~0.1 ms per window at
-        config 2 for a tail that needs < 4 CU-ms. Streams restricted to disjoint CU sets (hipExtStreamCreateWithCUMask; mask bit
-        b = CU b // 8 of XCD b % 8, measured with tools/cumask_map.py) fix that: `self.main_stream` (all but `tail_cus_per_xcd`
-        CUs of every XCD; the persistent grids are sized for it) and the tail side streams (those CUs). Run the window loop
-        under `with torch.cuda.stream(hp.main_stream)`. Call before the first pipelined window; 0 switches it off."""
-        if getattr(self, "side_streams", None) or getattr(self, "_bt", None) is not None:
-            raise RuntimeError("enable_cu_partition: call before the first pipelined window")
-        total = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        k = int(tail_cus_per_xcd)
-        if k <= 0:
-            self.main_stream, self._tail_bits = None, None
-            _lib.check(self.lib.genie_set_num_cu(self.ctx, 0), "genie_set_num_cu")
-            return None
-        if total % n_xcd or k * n_xcd >= total:
-            raise ValueError("enable_cu_partition: bad partition")
-        tail_bits = (1 << (n_xcd * k)) - 1
-        self._tail_bits, self._cu_total = tail_bits, total
-        self.main_stream = self._masked_stream(((1 << total) - 1) ^ tail_bits, total)
-        _lib.check(self.lib.genie_set_num_cu(self.ctx, total - n_xcd * k), "genie_set_num_cu")
-        return self.main_stream
-
     def _new_side_stream(self, prio=0):
-        if getattr(self, "_tail_bits", None):
-            return self._masked_stream(self._tail_bits, self._cu_total)
         return torch.cuda.Stream(device=self.device, priority=prio)
 
     def _next_window_slot(self):
@@ -470,7 +435,7 @@ class HipPath(object):
         stage 2) on the current stream, the G-sized tail (Bipartite read-out, SpatialAggregation x3, read-out heads: short
         latency-bound kernels) on a side stream, where it overlaps the NEXT windows' P-sized kernels. The persistent P-sized
         kernels fill every CU, so a tail kernel only advances when their workgroups retire and one tail takes about as long as
-        a whole window; consecutive windows therefore alternate between GENIE_TAILS (default 2) side streams, and every
+        a whole window; consecutive windows therefore alternate between two side streams, and every
         buffer that crosses the stream boundary exists once per window in flight (`genie_set_slot`). Results are
         bit-identical to `path_fwd` + read-outs. Returns (y, x, done_event); y / x are produced on `self.side_stream` (the
         side stream of THIS window) — consume them there or wait for `done_event`; `wait_tails()` joins all of them. (Measured alternative, rejected: also moving stage 2 to its own stream so that it overlaps the
@@ -482,9 +447,8 @@ class HipPath(object):
         self._refresh_static_edge_attr(edge_attr)
         pos = _f32(pos, "pos", (self.n_grid, 3))
         if getattr(self, "side_streams", None) is None:
-            n_tail = max(1, min(3, int(os.environ.get("GENIE_TAILS", "2"))))
-            prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
-            self.side_streams = [self._new_side_stream(prio) for _ in range(n_tail)]
+            n_tail = 2
+            self.side_streams = [self._new_side_stream() for _ in range(n_tail)]
             self._win = 0
             self._ev_tail = [None] * (n_tail + 1)
         main = torch.cuda.current_stream(self.device)
@@ -506,12 +470,9 @@ class HipPath(object):
         # per-window tails next to the persistent P-sized kernels: fewer tail workgroups (each has a CU to itself while it lives)
         # cost the main stream less, as long as the chain of eight kernels still ends within two windows. 3/8 and 1/4 of the CUs
         # measured best at config 2 (0.852 -> 0.824 ms per window on the same box; 128 / 64: 0.870, 64 / 32: 0.931, 96 / 96: 0.890;
-        # worse without the pipeline and with batched tails, hence set here only). GENIE_TAIL_RO / GENIE_TAIL_SA override.
+        # worse without the pipeline and with batched tails, hence set here only).
         cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        ro = int(os.environ.get("GENIE_TAIL_RO", "0")) or (3 * cus) // 8
-        sa = int(os.environ.get("GENIE_TAIL_SA", "0")) or cus // 4
-        if os.environ.get("GENIE_TAIL_CAPS", "1") != "0":
-            _lib.check(self.lib.genie_set_tail_grid(self.ctx, ro, sa), "genie_set_tail_grid")
+        _lib.check(self.lib.genie_set_tail_grid(self.ctx, (3 * cus) // 8, cus // 4), "genie_set_tail_grid")
         with torch.cuda.stream(side):
             ss = ctypes.c_void_p(side.cuda_stream)
             bip = torch.empty((self.n_grid, 15), dtype=torch.float32, device=self.device)
@@ -559,10 +520,9 @@ class HipPath(object):
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         self._refresh_static_edge_attr(edge_attr)
         if getattr(self, "_bt", None) is None:
-            prio = int(os.environ.get("GENIE_SIDE_PRIO", "0"))
             groups = 3 if self.window_batch == 1 else 2        # batches in flight (16 workspace slots)
             self._bt = {"group": 0, "n": 0, "ev": [None] * groups, "turn": 0,
-                        "streams": [self._new_side_stream(prio) for _ in range(2)]}
+                        "streams": [self._new_side_stream() for _ in range(2)]}
             self.side_streams = list(getattr(self, "side_streams", None) or []) + self._bt["streams"]
         bt = self._bt
         if bt["n"] >= self.window_batch:
@@ -664,6 +624,33 @@ class HipPath(object):
                                                 _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
         return out
 
+    def readout_grid_latent(self, x_spatial, t_query):
+        """(y [n_grid, T, 1], y_latent [n_grid, 30] = SpatialDirect(x_spatial)) (module.py:978-979; genie_readout_grid_latent)."""
+        x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))
+        tq = _f32(t_query, "t_query").reshape(-1)
+        out = torch.empty((self.n_grid, tq.numel(), 1), dtype=torch.float32, device=self.device)
+        lat = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_readout_grid_latent(self.ctx, _ptr(x_spatial), _ptr(tq), tq.numel(), _ptr(out), _ptr(lat), _stream()),
+                   "genie_readout_grid_latent")
+        return out, lat
+
+    def spatial_attention(self, x_spatial, x_grid, x_query, knn_idx, t_query):
+        """SpatialAttention(x_spatial, x_query, x_grid) [Q, 30] (module.py:981, `x_src` of the candidate sources) by the read-out
+        kernel (genie_readout_query_latent; its TemporalAttention output is discarded: Q is a handful of sources)."""
+        x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))
+        x_grid = _f32(x_grid, "x_grid", (self.n_grid, 3))
+        x_query = _f32(x_query, "x_query")
+        nq = x_query.shape[0]
+        if tuple(knn_idx.shape) != (nq, 10) or knn_idx.dtype != torch.int32 or not knn_idx.is_cuda:
+            raise ValueError("knn_idx must be an int32 GPU tensor of shape [n_query, 10]")
+        tq = _f32(t_query, "t_query").reshape(-1)
+        out = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=self.device)
+        lat = torch.empty((nq, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_readout_query_latent(self.ctx, _ptr(x_spatial), _ptr(x_grid), _ptr(x_query), _ptr(knn_idx.contiguous()), nq, 10,
+                                                       _ptr(tq), tq.numel(), _ptr(out), _ptr(lat), self._ws_ptr, _stream()),
+                   "genie_readout_query_latent")
+        return lat
+
     def assoc_fwd(self, y_latent, mask_src, x_latent, Mask, edge_attr):
         """BipartiteGraphReadOutOperator + DataAggregationAssociationPhase (module.py:986-990) in HIP (genie_assoc_fwd):
         y_latent [G,30], mask_src [G] or [G,1], x_latent [P,30], Mask [P,4], edge_attr [P,3] -> [P,30]. Call after the
@@ -703,6 +690,14 @@ class HipPath(object):
             raise ValueError("lslc_fwd: a_edges / ipick must be int32 GPU tensors, one ipick / phase_label per pick, tlatent [P, C]")
         a_edges, ipick = a_edges.contiguous(), ipick.contiguous()
         t0, dt = float(dt_partition[0]), float(dt_partition[1] - dt_partition[0])
+        if n:
+            # the reference indexes the time-pointer table with these and raises on an index outside it (module.py:635-640); the
+            # kernel would clamp silently, so a pick outside `dt_partition` / the station range is refused here
+            ti = torch.floor((tpick - t0) / dt)
+            lim = torch.stack((ti.min(), ti.max(), ipick.min().float(), ipick.max().float())).tolist()
+            if lim[0] < 0 or lim[1] >= len(dt_partition) or lim[2] < 0 or (lim[3] * len(dt_partition) + lim[1]) * 10 + 9 >= a_edges.numel():
+                raise IndexError("lslc_fwd: a pick lies outside the time-pointer table (tpick outside dt_partition, or ipick outside "
+                                 "the stations of A_edges)")
         out = torch.empty((n, 15), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)),
                                            t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),

@@ -499,8 +499,7 @@ class DataAggregationAssociationPhase(nn.Module):
         """`hip`: an engine.HipPath on the same graphs -> the four neighbour means run as genie_nbr_mean (HIP) instead of
         materialised index gathers (21 -> ~6 ms at config 2); the Linears stay on PyTorch-ROCm."""
         grad = torch.is_grad_enabled() and tr.requires_grad
-        if (hip is not None and tr.is_cuda and not grad and self.l1_t1_2.weight.shape[1] == 65
-                and os.environ.get("GENIE_ASSOC_PLAIN") is None):
+        if hip is not None and tr.is_cuda and not grad and self.l1_t1_2.weight.shape[1] == 65:
             return self._forward_blocked(tr, latent, mask1, mask2, n_sta, n_grid, hip)
 
         def means(x1, x2):
@@ -914,15 +913,17 @@ class GCN_Detection_Network_extended(nn.Module):
             y, x, x_spatial, y_latent, x_latent = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True)
         else:
             x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)  # :973-977
-            y_latent = self.SpatialDirect(x_spatial)                                                 # :978
-            y = self._hip.readout_grid(x_spatial, t_query)                                           # :979
+            y, y_latent = self._hip.readout_grid_latent(x_spatial, t_query)                          # :978-979
             knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
             x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)     # :980,982
-        x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)      # :981
+        if self._differentiable():
+            x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)  # :981 (autograd: training steps)
+        else:
+            knn_src = _engine.knn_device(x_temp_cuda_cart, x_query_src_cart, 10)
+            x_src = self._hip.spatial_attention(x_spatial, x_temp_cuda_cart, x_query_src_cart, knn_src, t_query)   # :981
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
         Maskf = _engine._f32(Mask, "Mask")
-        if (not self._differentiable() and getattr(self._hip, "assoc_ready", False)
-                and os.environ.get("GENIE_ASSOC_TORCH") is None):
+        if not self._differentiable() and getattr(self._hip, "assoc_ready", False):
             # :986-990 as three P-sized HIP passes (genie_assoc_fwd); the PyTorch-ROCm restatement below serves training steps
             s = self._hip.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
         else:
@@ -930,8 +931,7 @@ class GCN_Detection_Network_extended(nn.Module):
             s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
                                                      hip=self._hip)                                  # :990
         tl = self.tlatent
-        if (not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0
-                and os.environ.get("GENIE_ASSOC_TORCH") is None):
+        if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
             # :991-992 in HIP (genie_lslc_fwd); the int32 copies of the static time-pointer tables are cached with the tables
             key = (self.A_edges_p.data_ptr(), self.A_edges_s.data_ptr(), self.A_edges_p._version, self.A_edges_s._version)
             if getattr(self, "_a_edges_key", None) != key:
@@ -946,8 +946,7 @@ class GCN_Detection_Network_extended(nn.Module):
             arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
             arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
         arv = None
-        if (not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0
-                and os.environ.get("GENIE_ASSOC_TORCH") is None):
+        if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
             # :993 in HIP (genie_arrivals_fwd); None = its preconditions do not hold for this call
             arv = self._hip.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)
         if arv is None:

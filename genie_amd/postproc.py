@@ -30,22 +30,31 @@ def row_select(x, threshold, mode):
     value fp32) GPU tensors in row-major order. The only host round trip is the total count (one integer)."""
     if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
         raise ValueError("row_select: x must be a 2-D fp32 GPU tensor")
-    x = x.contiguous()
+    if not x.is_contiguous():
+        raise ValueError("row_select: x must be contiguous (a silent copy of a multi-GB Out_2 is not what the caller wants)")
     lib = _lib.load()
     rows, cols = int(x.shape[0]), int(x.shape[1])
-    st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    counts = torch.empty(rows, dtype=torch.int32, device=x.device)
-    _lib.check(lib.genie_row_select_count(_ptr(x), rows, cols, ctypes.c_float(float(threshold)), int(mode), _ptr(counts), st),
-               "genie_row_select_count")
-    ends = torch.cumsum(counts.long(), 0)
-    offsets = (ends - counts.long()).contiguous()
-    n = int(ends[-1].item()) if rows else 0
-    out_row = torch.empty(n, dtype=torch.int32, device=x.device)
-    out_col = torch.empty(n, dtype=torch.int32, device=x.device)
-    out_val = torch.empty(n, dtype=torch.float32, device=x.device)
-    if n:
-        _lib.check(lib.genie_row_select_fill(_ptr(x), rows, cols, ctypes.c_float(float(threshold)), int(mode), _ptr(offsets),
-                                             _ptr(out_row), _ptr(out_col), _ptr(out_val), st), "genie_row_select_fill")
+    # the device compares in fp32 where numpy / scipy compare the fp32 entries with a float64 threshold: round the threshold to
+    # the fp32 value that gives the same decisions (`>`: the largest fp32 <= threshold; `>=`: the smallest fp32 >= threshold)
+    th = np.float32(threshold)
+    if mode == 0 and float(th) > float(threshold):
+        th = np.nextafter(th, np.float32(-np.inf))
+    if mode == 1 and float(th) < float(threshold):
+        th = np.nextafter(th, np.float32(np.inf))
+    with torch.cuda.device(x.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        counts = torch.empty(rows, dtype=torch.int32, device=x.device)
+        _lib.check(lib.genie_row_select_count(_ptr(x), rows, cols, ctypes.c_float(float(th)), int(mode), _ptr(counts), st),
+                   "genie_row_select_count")
+        ends = torch.cumsum(counts.long(), 0)
+        offsets = (ends - counts.long()).contiguous()
+        n = int(ends[-1].item()) if rows else 0
+        out_row = torch.empty(n, dtype=torch.int32, device=x.device)
+        out_col = torch.empty(n, dtype=torch.int32, device=x.device)
+        out_val = torch.empty(n, dtype=torch.float32, device=x.device)
+        if n:
+            _lib.check(lib.genie_row_select_fill(_ptr(x), rows, cols, ctypes.c_float(float(th)), int(mode), _ptr(offsets),
+                                                 _ptr(out_row), _ptr(out_col), _ptr(out_val), st), "genie_row_select_fill")
     return out_row, out_col, out_val
 
 
@@ -85,6 +94,10 @@ def find_peaks_rows(Out_2, height, distance):
     rows ascending, columns ascending within a row."""
     if distance is not None and distance < 1:
         raise ValueError("`distance` must be greater or equal to 1")          # scipy's own check
+    if not height > 0.01:
+        # the reference runs find_peaks on the array REBUILT from `Out_2 > 0.01` (everything else zero, process_continuous_days.py:812-846);
+        # that equals find_peaks on Out_2 itself only for thresholds above the sparsification level
+        raise ValueError("find_peaks_rows: height must be > 0.01 (the reference's sparsification threshold)")
     r, c, v = row_select(Out_2, height, 1)
     r, c, v = r.cpu().numpy().astype(np.int64), c.cpu().numpy().astype(np.int64), v.cpu().numpy()
     if distance is None or r.size == 0:

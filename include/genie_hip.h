@@ -101,14 +101,6 @@ int genie_set_slot(genie_ctx* ctx, int slot);
 int genie_tail_batched(genie_ctx* ctx, int slot0, int nwin, const float* pos, const float* x_query, const int32_t* knn,
                        int n_query, int k, const float* t_query, int n_t, float* x_spatial_out, float* y_out, float* x_out,
                        void* ws, void* stream);
-/* slim != 0: launch the read-out kernels in their small-LDS shape (<= 52 KB, one workgroup per CU) so they co-reside
- * with the stage-1 workgroups of the next window on another stream; 0 (default): large workgroups, lowest latency. */
-int genie_set_tail_mode(genie_ctx* ctx, int slim);
-/* Kernels of the G- / Q-sized tail (Bipartite read-out module.py:229, SpatialAggregation x3 :243-249, read-out heads
- * :251-331): mfma != 0 (default) = fp32-MFMA tiles of 16 nodes per wave (weights as A fragments, every Linear's result is the
- * next one's B operand); 0 = the scalar kernels with 32 lanes per node (A/B reference; also env GENIE_TAIL=scalar at context
- * creation). Same arithmetic, different summation order inside the dot products. */
-int genie_set_tail_kernels(genie_ctx* ctx, int mfma);
 /* Temporal scale of TemporalAttention: `scale_t = 3 * kernel_sig_t` (module.py:40); default 9.0. */
 int genie_set_scale_t(genie_ctx* ctx, float scale_t);
 /* `use_absolute_pos: True` (config.yaml:92; module.py:916, :971, :1007): every product node's input gets its station position and
@@ -231,6 +223,14 @@ int genie_readout_grid(genie_ctx* ctx, const float* x_spatial, const float* t_qu
 int genie_readout_query(genie_ctx* ctx, const float* x_spatial, const float* x_grid, const float* x_query,
                         const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out,
                         void* ws, void* stream);
+/* The same read-outs with the latent input of TemporalAttention exported next to them, as the 4-output forward needs it
+ * (module.py:978-981): y_latent_out [n_grid, 30] = SpatialDirect(x_spatial) (:978), latent_out [n_query, 30] =
+ * SpatialAttention(x_spatial, x_query, x_grid) (:981, `x_src` for the candidate sources). */
+int genie_readout_grid_latent(genie_ctx* ctx, const float* x_spatial, const float* t_query, int n_t, float* y_out,
+                              float* y_latent_out, void* stream);
+int genie_readout_query_latent(genie_ctx* ctx, const float* x_spatial, const float* x_grid, const float* x_query,
+                               const int32_t* knn, int n_query, int k, const float* t_query, int n_t, float* x_out,
+                               float* latent_out, void* ws, void* stream);
 
 /*
  * Pick -> Slice/Mask embedding on device = `extract_input_from_data` (process_utils.py:460-642, use_sign_input False),
@@ -275,20 +275,9 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 int genie_nbr_mean_bwd(genie_ctx* ctx, const float* g_sta, const float* g_src, float* dx_sta, float* dx_src, int row_floats,
                        void* stream);
 
-/* CU partitioning for the window pipeline. The P-sized stage kernels are persistent and own every register of every CU, so a
- * G-sized tail kernel of the previous window on another stream only runs when one of their workgroups retires and then holds
- * that CU: the tail costs the main stream ~0.1 ms per window although it needs under 4 CU-milliseconds. With HIP streams
- * restricted to disjoint CU sets (hipExtStreamCreateWithCUMask) the tail gets a few CUs of its own (one or two per XCD) and
- * the stage kernels the rest.
- *   genie_cu_mask_probe: xcc_of_bit[b] = XCD of the CU that bit b of a CU mask enables (-1: none) -- measured, one-CU streams
- *   genie_stream_create_masked / genie_stream_destroy: a HIP stream limited to the CUs whose mask bits are set
- *   genie_set_num_cu: size the persistent grids of this context for n CUs (0 = all), to be used with a stream of n CUs */
-int genie_cu_mask_probe(int32_t* xcc_of_bit, int n_bits);
-/* out_dev [n_blocks][2] = (HW_REG_XCC_ID, HW_REG_HW_ID) of the CU every workgroup of a probe launch ran on */
+/* out_dev [n_blocks][2] = (HW_REG_XCC_ID, HW_REG_HW_ID) of the CU every workgroup of a probe launch ran on: workgroup b of a
+ * launch lands on XCD b % 8, which the XCD-chunked sweeps of the stage kernels rely on (for speed only). */
 int genie_where_am_i(int32_t* out_dev, int n_blocks, void* stream);
-int genie_stream_create_masked(const uint32_t* mask_words, int n_words, void** stream_out);
-int genie_stream_destroy(void* stream);
-int genie_set_num_cu(genie_ctx* ctx, int n);
 /* Grid caps (workgroups) of the read-out (k_readout, k_ro_pre) and SpatialAggregation kernels of the G-sized tail; 0 = default
  * (one read-out workgroup per CU, two SpatialAggregation workgroups per CU: lowest latency). In the window pipeline, where a
  * tail workgroup has a CU to itself while it lives, fewer workgroups cost the P-sized kernels less CU-time as long as the

@@ -275,9 +275,9 @@ def test_bitwise_deterministic_and_order_independent():
 
 @pytest.mark.parametrize("case", ["cfg1_20x500", "random_50x700"])
 def test_kernel_variants_agree(case, monkeypatch):
-    """The stage kernels exist in three forms: generic CSR fp32-MFMA (any graph), software-pipelined fp32-MFMA (uniform
-    8 / 15 degrees; same arithmetic order as the generic one: bitwise equal) and the exact-split bf16 matrix-pipe form
-    (k_stage1_b3 default, k_stage2_b3 opt-in; different summation order: fp32 tolerance)."""
+    """The stage kernels exist in two forms: generic CSR fp32-MFMA (any graph; GENIE_S1=f32 selects them on the reference's kNN
+    graphs too: the A/B reference) and the production pair k_stage1_b3 (exact-split bf16 matrix pipe) + k_stage2_ord (pipelined,
+    row-layout loads): another summation order, fp32 tolerance."""
     if case == "cfg1_20x500":
         c = Case(case)
         S, G, w = c.S, c.G, c.weights
@@ -291,10 +291,8 @@ def test_kernel_variants_agree(case, monkeypatch):
         Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
         ea, pos, xg = torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.x_grid).float(), geom.x_grid
     res = {}
-    for name, env in (("generic", {"GENIE_S1": "f32", "GENIE_NOFAST": "1", "GENIE_NOFAST2": "1"}), ("fast", {"GENIE_S1": "f32"}),
-                      ("b3", {}), ("b3_s2", {"GENIE_S2": "b3"})):
-        for k in ("GENIE_S1", "GENIE_S2", "GENIE_NOFAST", "GENIE_NOFAST2"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("generic", {"GENIE_S1": "f32"}), ("b3", {})):
+        monkeypatch.delenv("GENIE_S1", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         hp = engine.HipPath(S, G, engine.csr_from_table(sta_nbr), engine.csr_from_table(src_nbr),
@@ -303,17 +301,14 @@ def test_kernel_variants_agree(case, monkeypatch):
         _, _, h0, h1 = hp.da_stage1(Slice.to(DEV), Mask.to(DEV), debug=True)
         xl, bip = hp.da_stage2_bipartite(Mask.to(DEV), ea.to(DEV), want_x_latent=True)
         res[name] = [t.cpu() for t in (h0, h1, xl, bip)]
-    for a_, b_ in zip(res["generic"], res["fast"]):
-        assert torch.equal(a_, b_)
-    for other in ("b3", "b3_s2"):
-        for a_, b_ in zip(res["fast"], res[other]):
-            assert max_abs(a_, b_) <= 0.2 * rel_tol(a_), (other, max_abs(a_, b_))     # 2e-6 x max(1, max|ref|)
+    for a_, b_ in zip(res["generic"], res["b3"]):
+        assert max_abs(a_, b_) <= 0.2 * rel_tol(a_), max_abs(a_, b_)     # 2e-6 x max(1, max|ref|)
 
 
 def test_rows_beyond_4gib_offsets(monkeypatch):
     """Config-4 scale on one GPU: P x 48 B (split rows) and P x 64 B (wu / wv rows) both exceed 4 GiB, so the kernels that
     address rows with 32-bit byte offsets must switch to their 64-bit forms (k_stage1_b3<.., BIG>, wave-uniform 64-bit row
-    bases in k_stage2_fast). Property: same result as the generic CSR kernels (64-bit arithmetic throughout)."""
+    bases in k_stage2_ord). Property: same result as the generic CSR kernels (64-bit arithmetic throughout)."""
     S, G = 2000, 46000
     assert S * G * 48 > 2 ** 32
     geom = synthetic.Geometry(S, G, L=2000e3, n_query=5, seed=301)
@@ -326,10 +321,8 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
     Mask = (torch.rand((P, 4), device=DEV, generator=g) < 0.3).float()
     ea = torch.rand((P, 3), device=DEV, generator=g) - 0.5
     res = {}
-    for name, env in (("generic", {"GENIE_S1": "f32", "GENIE_NOFAST": "1", "GENIE_NOFAST2": "1"}), ("fast_f32", {"GENIE_S1": "f32"}),
-                      ("default", {})):
-        for k in ("GENIE_S1", "GENIE_S2", "GENIE_NOFAST", "GENIE_NOFAST2"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("generic", {"GENIE_S1": "f32"}), ("default", {})):
+        monkeypatch.delenv("GENIE_S1", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         hp = engine.HipPath(S, G, sta, src, grid_order=engine.morton_order(geom.x_grid), device=DEV)
@@ -339,7 +332,6 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
         res[name] = bip.cpu()
         del hp
         torch.cuda.empty_cache()
-    assert torch.equal(res["generic"], res["fast_f32"])
     assert max_abs(res["generic"], res["default"]) <= 0.2 * rel_tol(res["generic"]), max_abs(res["generic"], res["default"])
 
 
@@ -646,11 +638,9 @@ def test_config4_shape_two_virtual_ranks_vs_unsharded_generic_kernels_and_oracle
     out_ref, bip_ref = unsharded()
     assert torch.isfinite(out_ref).all() and torch.isfinite(bip_ref).all()
     # (2) generic kernels
-    for k in ("GENIE_S1", "GENIE_NOFAST", "GENIE_NOFAST2"):
-        monkeypatch.setenv(k, "f32" if k == "GENIE_S1" else "1")
+    monkeypatch.setenv("GENIE_S1", "f32")
     out_gen, bip_gen = unsharded()
-    for k in ("GENIE_S1", "GENIE_NOFAST", "GENIE_NOFAST2"):
-        monkeypatch.delenv(k)
+    monkeypatch.delenv("GENIE_S1")
     scale = float(bip_ref.abs().max())
     print("config 4 shape: max|bip| %.4g, fast vs generic kernels %.3g" % (scale, max_abs(bip_ref, bip_gen)))
     assert max_abs(bip_ref, bip_gen) <= 1e-5 * max(1.0, scale)
@@ -1161,12 +1151,11 @@ def test_association_heads_hip_match_oracle(S, G):
 
 
 @pytest.mark.parametrize("S,G", [(200, 300), (40, 90), (100, 64)])
-@pytest.mark.parametrize("env", [("GENIE_S2_LDS", "1"), ("GENIE_S2_ORD", "0"), ("GENIE_S2_WGMAP", "1"), ("GENIE_S2_SCHED", "3"), ("GENIE_S2_RL", "0"), ("GENIE_S2_SD", "1")])
-def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, env, monkeypatch):
-    """Stage-2 kernel variants against the default (k_stage2_ord: straight-line software pipeline, DPP station sum):
-    k_stage2_lds (opt-in, GENIE_S2_LDS=1: station-neighbour rows staged in LDS per phase of NB source nodes) and k_stage2_fast
-    (GENIE_S2_ORD=0: the round-1 kernel with its option branches and xor-butterfly station sum): x_latent, Bipartite output
-    and the association pass (stage 2 without its Bipartite half) bit for bit."""
+@pytest.mark.parametrize("env", [("GENIE_S2_WGMAP", "1")])
+def test_stage2_work_maps_are_bitwise_equal(S, G, env, monkeypatch):
+    """k_stage2_ord with its large-station-count work map (blocks of 4 source nodes per workgroup, one node per wave; the default
+    from 1024 stations up) against the interleaved map: x_latent, Bipartite output and the association pass (stage 2 without its
+    Bipartite half) bit for bit -- per-tile results do not depend on which wave computes them."""
     geom = synthetic.Geometry(S, G, L=200e3, n_query=10, seed=S)
     win = synthetic.make_window(geom, 20 * S, seed=S + 1)
     wd = {k: v.to(DEV) for k, v in Case("cfg1_20x500").weights.items()}
@@ -1192,18 +1181,19 @@ def test_stage2_lds_kernel_is_bitwise_equal_to_the_default(S, G, env, monkeypatc
 
 
 @pytest.mark.parametrize("name,T", [("cfg1_20x500", 9), ("odd_33x257", 1), ("o1_20x500", 10), ("tiny_6x40", 4)])
-def test_tail_mfma_kernels_agree_with_scalar_kernels(name, T):
-    """The G- / Q-sized tail (Bipartite read-out, SpatialAggregation x3, both read-out heads) on fp32-MFMA tiles of 16 nodes
-    (default) against the scalar 32-lanes-per-node kernels (genie_set_tail_kernels(ctx, 0)): same arithmetic, another
-    summation order inside the dot products -> 2e-6 of the scale of every output; G and Q that are not multiples of 16,
-    1 / 4 / 9 / 10 time queries; the MFMA kernels run twice are bitwise equal."""
+def test_tail_kernels_other_time_query_counts_vs_oracle(name, T):
+    """The G- / Q-sized tail (Bipartite read-out, SpatialAggregation x3, both read-out heads) with 1 / 4 / 9 / 10 time queries, G and
+    Q that are not multiples of 16: y / x against the oracle's read-out heads on the HIP x_spatial (1e-5 absolute, 2e-6 of the
+    scale), every output bitwise equal when run twice."""
+    from oracle import genie_oracle as O
     c = Case(name)
     hp = make_engine(c)
     Slice, Mask, ea = c.Slice.to(DEV), c.Mask.to(DEV), c.edge_attr.to(DEV)
     xg, xq = c.x_grid.float().to(DEV), c.x_query.float().to(DEV)
     tq = (torch.arange(T, dtype=torch.float32) * 1.7 - 3.0).to(DEV)
     from genie_amd.module import knn_query_edges
-    table = knn_query_edges(xg, xq, 10)[0].view(xq.shape[0], -1).to(torch.int32).contiguous()
+    edges = knn_query_edges(xg, xq, 10)
+    table = edges[0].view(xq.shape[0], -1).to(torch.int32).contiguous()
 
     def run():
         out, _, bip = hp.path_fwd(Slice, Mask, ea, xg, want_x_latent=True, want_bip=True)
@@ -1214,13 +1204,17 @@ def test_tail_mfma_kernels_agree_with_scalar_kernels(name, T):
 
     got = run()
     again = run()
-    hp.lib.genie_set_tail_kernels(hp.ctx, 0)
-    ref = run()
-    hp.lib.genie_set_tail_kernels(hp.ctx, 1)
-    for a, b, r, k in zip(got, again, ref, ("bip", "sa3", "y", "x")):
+    for a, b, k in zip(got, again, ("bip", "sa3", "y", "x")):
         assert torch.equal(a, b), k
-        assert a.shape == r.shape and torch.isfinite(a).all(), k
-        assert max_abs(a.cpu(), r.cpu()) <= 2e-6 * max(1.0, float(r.abs().max())), k
+        assert torch.isfinite(a).all(), k
+    w = c.weights
+    sa3 = got[1].cpu()
+    tqc = tq.cpu().view(-1, 1)
+    y_o = O.temporal_attention(w, O.spatial_direct(w, sa3), tqc)
+    x_o = O.temporal_attention(w, O.spatial_attention(w, sa3, c.x_query.float(), c.x_grid.float(), edge_index=edges.cpu()), tqc)
+    for a, r, k in ((got[2].cpu(), y_o, "y"), (got[3].cpu(), x_o, "x")):
+        assert a.shape == r.shape, k
+        assert max_abs(a, r) <= 2e-6 * max(5.0, float(r.abs().max())), (k, max_abs(a, r))
 
 
 def test_device_subgraph_builder_matches_reference_builder():

@@ -54,10 +54,11 @@ def _oracle_curve(w0, geom, samples, n_steps):
     return losses, w
 
 
-@pytest.mark.parametrize("shape", ["7x45", "20x500"])
+@pytest.mark.parametrize("shape", ["7x45"])
 def test_training_loss_curve_matches_oracle_adam(shape):
     """24 Adam steps over a batch of two samples (same station set and grid, different pick windows): the loss of every step
-    within 1e-4 relative of the oracle's, the loss goes down, and the trained weights agree."""
+    within 1e-4 relative of the oracle's, the loss goes down, and the trained weights agree. (The 200-station curve is
+    test_config3_station_count_loss_curve_matches_oracle_adam; a 20 x 500 curve was part of this test until round 3: 9e-8.)"""
     S, G, n_picks, nq = {"7x45": (7, 45, 90, 20), "20x500": (20, 500, 500, 300)}[shape]
     geom = synthetic.Geometry(S, G, L=100e3, n_query=nq, seed=1)
     samples = [synthetic.training_sample(geom, n_picks, seed=3, window=k) for k in range(2)]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Stage-2 kernel alone (HIP events over repeated launches after one stage 1), for A/B runs of kernel variants selected by
-environment variables (GENIE_S2_LDS=0 -> k_stage2_fast; GENIE_S2_NB / GENIE_S2_LDSKB / GENIE_BPC2 -> k_stage2_lds shapes).
+environment variables (GENIE_BPC2 = workgroups per CU, GENIE_S2_WGMAP = work map).
 Usage: python tools/s2_time.py [config] [iters]"""
 import os
 import sys

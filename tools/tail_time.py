@@ -40,8 +40,7 @@ with torch.no_grad():
         _lib.check(hp.lib.genie_bipartite_readout(hp.ctx, _ptr(bip), hp._ws_ptr, st), "bip")
         _lib.check(hp.lib.genie_spatial_agg3_fwd(hp.ctx, _ptr(bip), _ptr(xg), _ptr(xs1), hp._ws_ptr, st), "sa")
         hp.readout_grid(xs1, tq); hp.readout_query(xs1, xg, xq, knn, tq)
-    for mf, label in ((1, "MFMA tiles"), (0, "scalar kernels")):
-        hp.lib.genie_set_tail_kernels(hp.ctx, mf)
+    for label in ("MFMA tiles",):
         for name, f, per in (("per-window tail", single, 1), ("batched tail x%d" % NB, batched, NB)):
             for _ in range(5): f()
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -49,5 +48,4 @@ with torch.no_grad():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 30
             print("%-14s %-18s %.1f us per call, %.1f us per window" % (label, name, dt * 1e6, dt / per * 1e6))
-    hp.lib.genie_set_tail_kernels(hp.ctx, 1)
     print("n_query", xq.shape[0], "T", tqf.numel())
