@@ -2962,6 +2962,8 @@ struct RoArgs {
     const float* raw;
     float scale_rel, scale_t;
     float* out;                  // [N,T]
+    float* cv_out;               // MODE 0, optional: also write the per-grid-node table cv of MODE 1 (the work of k_ro_pre_m: one
+    const float* pimg;           // pass over x_spatial and one launch less), with the PL_ROP image `pimg`; cv_ws as for `cv`
     float* lat_out;              // optional [N,30]: the head's latent input of TemporalAttention (MODE 0: SpatialDirect(x_spatial) = y_latent,
                                  // MODE 1: SpatialAttention(x_spatial, x_query)); k_readout_m only
     int o_sd_w, o_sd_b, o_sd_a;
@@ -3108,6 +3110,67 @@ __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
         f32x4 gl = mma_block(tl_bias(im, 5, q), TLW(im, GS_FG(0)), xb[0]);
         if (C == 30) gl = mma_block(gl, TLW(im, GS_FG(1)), xb[1]);
         if (ok) acc += prelu4(gl, act3) * (float)a.outdeg[g];
+    }
+    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+}
+
+// k_bip_out_m + k_sa_pre_m<15> in one launch (the batched tail): the Bipartite output of a node is the input of
+// SpatialAggregation1's pre-pass of the same node. Same MFMA chains as the two kernels (bitwise equal results).
+__global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ part, int T, const float* __restrict__ img_bip, long long part_ws,
+                                                  SaArgs a) {
+    sa_select_window(a);
+    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36 + GS_IMG_FLOATS + 32];
+    const TlImg im = tl_stage_image(sm, img_bip, GB_GROUPS2, GB_BIAS2);
+    float* tsc = sm + GB2_IMG_FLOATS;
+    const TlImg is = tl_stage_image(tsc + 4 * 16 * 36, a.img, GS_GROUPS, GS_BIAS);
+    float* red = tsc + 4 * 16 * 36 + GS_IMG_FLOATS;
+    __syncthreads();
+    part += blockIdx.y * part_ws;
+    const int G = a.G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int jl = lane >> 2, ql = lane & 3;
+    float* ts = tsc + wave * 16 * 36;
+    const float act = im.scal[0], act3 = is.scal[3];
+    f32x4 acc = tl_zero();
+    const int ntiles = (G + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int g = tile * 16 + j;
+        const bool ok = g < G;
+        const int gl = tile * 16 + jl;
+        const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
+        f32x4 r0 = tl_zero(), r1 = tl_zero();
+        int tb = 0;
+        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
+            f32x4 v0[4], v1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
+        }
+        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
+        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
+        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
+        GSYNC();
+        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
+        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+        GSYNC();
+        f32x4 o = tl_bias(im, 0, q);
+        o = mma_block(o, TLW(im, 0), r0);
+        o = mma_block(o, TLW(im, 1), r1);
+        o = prelu4(o, act);
+        if (q == 3) o.w = 0.f;                    // channel 15 does not exist (tl_load15 of the stored row reads it as zero)
+        if (ok) {
+            float* og = a.out + (long long)g * 15 + 4 * q;
+            og[0] = o.x; og[1] = o.y; og[2] = o.z;
+            if (q < 3) og[3] = o.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 pj = mma_block(tl_zero(), TLW(is, GS_PJ(t, 0)), o);
+            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
+        }
+        const f32x4 glb = mma_block(tl_bias(is, 5, q), TLW(is, GS_FG(0)), o);
+        if (ok) acc += prelu4(glb, act3) * (float)a.outdeg[g];
     }
     tl_store_gpart(acc, lane, wave, red, a.gpart_out);
 }
@@ -3277,6 +3340,8 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
     float* qf = sm + GR_IMG_FLOATS;          // [5][64][4]: A fragments of the temporal queries, head h
     float* et = qf + 5 * 256;                // [10][80] (MODE 1): f_queries columns 0..2, f_context / f_values edge columns, f_queries bias
     float* scr = et + 10 * 80;
+    TlImg imp = im;                          // MODE 0 with cv_out: the PL_ROP image behind the score scratch
+    if (MODE == 0 && a.cv_out != nullptr) imp = tl_stage_image(scr + 4 * 16 * RO_SCS, a.pimg, GP_GROUPS, GP_BIAS);
     {   // qf[h][lane][r] = query[t = lane & 15][head h][l = 4 (lane >> 4) + r], query = temporal_query_2(PReLU3(temporal_query_1(t / scale_t)))  :329
         const float act3 = a.raw[a.o_a3];
         for (int i = threadIdx.x; i < 5 * 256; i += blockDim.x) {
@@ -3322,6 +3387,18 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
         if (MODE == 0) {
             const float* row = a.x_spatial + (long long)nc * 30;
             const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+            if (a.cv_out != nullptr) {                                                  // k_ro_pre_m's work for this node (same MFMA chains)
+                const int w = nc / a.Nw;
+                float* o = a.cv_out + w * a.cv_ws + (long long)(nc - w * a.Nw) * CVP + 4 * q;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int h = 0; h < 5; ++h) {
+                        f32x4 v = mma_block(tl_bias(imp, m * 5 + h, q), TLW(imp, GP(m, h, 0)), xb0);
+                        v = mma_block(v, TLW(imp, GP(m, h, 1)), xb1);
+                        if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {                                               // SpatialDirect  :258-260
                 f32x4 y = mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xb0);
@@ -3538,34 +3615,54 @@ struct ArArgs {
     float eps;
     const float* stime;           // [n_src]
     const float* trv_src;         // [n_src, n_sta, 2]
-    const float* ctx;             // [n_src][3][48] (k_arr_ctx): plain, self, null edge; head h at 16h
+    const float* ctx;             // [n_src][4][48] (k_arr_ctx): plain, self, null, self + null edge; head h at 16h
     const float* arv_p; const float* arv_s;          // [n_arv, 15]
     const float* tpick; const float* phase;          // [n_arv]
     const int32_t* order;         // picks sorted by station (stable)
     const int32_t* seg_sta; const int32_t* seg_start; const int32_t* seg_len;     // [n_useg] stations with picks
     const float* img;
     float* out;                   // [n_src, n_arv, 2]
-    int* overflow;                // (unused: the chunked softmax has no capacity limit)
+    int* e0max;                   // [1] `edge_index[0].max()` over the kept edges (module.py:762-763), by k_arr_e0max: the pick the
+                                  // reference treats as "the null pick"; = n_arv (the real null pick) whenever some source has
+                                  // |stime| < 2 eps, i.e. always in practice
 };
+
+// e0max = max over the kept (pick b, source i) pairs of b, the null pick (index n_arv) included (module.py:740-763). A pick's
+// edges towards source i survive the 2-eps filter or not as a whole (the test involves only b and i), and every pick has at
+// least its self pair, so "b has a kept edge towards i" = "its test passes".
+__global__ __launch_bounds__(256) void k_arr_e0max(ArArgs a) {
+    const int i = blockIdx.x / a.n_useg, ug = blockIdx.x - i * a.n_useg;
+    const int u = a.seg_sta[ug], r0 = a.seg_start[ug], L = a.seg_len[ug];
+    const float eps = a.eps, st = a.stime[i];
+    const float tp_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 0] + st, ts_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 1] + st;
+    int best = -1;
+    if (threadIdx.x == 0 && ug == 0 && fabsf(st) < 2.f * eps) best = a.n_arv;
+    for (int r = threadIdx.x; r < L; r += blockDim.x) {
+        const int b = a.order[r0 + r];
+        const float tp = a.tpick[b];
+        if (fabsf(tp - tp_src) < 2.f * eps || fabsf(tp - ts_src) < 2.f * eps) best = max(best, b);
+    }
+    if (best >= 0) atomicMax(a.e0max, best);
+}
 
 __global__ __launch_bounds__(128) void k_arr_ctx(const float* __restrict__ raw, int o_c1w, int o_c1b, int o_c2w, int o_c2b, int o_a1,
                                                 const float* __restrict__ src_embed, const float* __restrict__ stime, int n_src,
                                                 float* __restrict__ ctx) {
-    __shared__ float hid[3][32];
+    __shared__ float hid[4][32];
     const int i = blockIdx.x;
     if (i >= n_src) return;
     const float act1 = raw[o_a1];
-    for (int idx = threadIdx.x; idx < 3 * 30; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < 4 * 30; idx += blockDim.x) {
         const int v = idx / 30, c = idx - v * 30;
         float t = raw[o_c1b + c];
         for (int k = 0; k < 30; ++k) t += raw[o_c1w + c * 33 + k] * src_embed[(long long)i * 30 + k];
         t += raw[o_c1w + c * 33 + 30] * stime[i];
-        if (v == 1) t += raw[o_c1w + c * 33 + 31];
-        if (v == 2) t += raw[o_c1w + c * 33 + 32];
+        if (v & 1) t += raw[o_c1w + c * 33 + 31];      // self_link
+        if (v & 2) t += raw[o_c1w + c * 33 + 32];      // null_link
         hid[v][c] = prelu1(t, act1);
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 3 * 48; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < 4 * 48; idx += blockDim.x) {
         const int v = idx / 48, r = idx - v * 48, h = r >> 4, l = r & 15;
         float t = 0.f;
         if (l < 15) {
@@ -3573,7 +3670,7 @@ __global__ __launch_bounds__(128) void k_arr_ctx(const float* __restrict__ raw, 
             t = raw[o_c2b + ch];
             for (int k = 0; k < 30; ++k) t += raw[o_c2w + ch * 30 + k] * hid[v][k];
         }
-        ctx[((long long)i * 3 + v) * 48 + r] = t;
+        ctx[((long long)i * 4 + v) * 48 + r] = t;
     }
 }
 
@@ -3582,15 +3679,19 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
     const TlImg im = tl_stage_image(sm, a.img, GA_GROUPS2, GA_BIAS2);
     float* ent = sm + GA2_IMG_FLOATS;                 // [AR_CAP][AR_ENT]
     int* kept = (int*)(ent + AR_CAP * AR_ENT);        // [AR_CAP] position r in the station's pick list (L = the null pick)
-    float* cx = (float*)(kept + AR_CAP);              // [3][48] context vectors of this source
-    int* wcnt = (int*)(cx + 144);                     // [4] per-wave counts of the compaction, [4] = total
+    int* kbi = kept + AR_CAP;                         // [AR_CAP] its pick index (n_arv = the null pick)
+    float* cx = (float*)(kbi + AR_CAP);               // [4][48] context vectors of this source
+    int* wcnt = (int*)(cx + 192);                     // [4] per-wave counts of the compaction, [4] = total
     const int i = blockIdx.x / a.n_useg, ug = blockIdx.x - i * a.n_useg;
     const int u = a.seg_sta[ug], r0 = a.seg_start[ug], L = a.seg_len[ug];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const float eps = a.eps, st = a.stime[i];
     const float tp_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 0] + st, ts_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 1] + st;
     const float rel_null = -eps - (-eps + st);        // null pick: atime = -eps, theoretical time = -eps (:722-725)
-    for (int k = threadIdx.x; k < 144; k += blockDim.x) cx[k] = a.ctx[(long long)i * 144 + k];
+    for (int k = threadIdx.x; k < 192; k += blockDim.x) cx[k] = a.ctx[(long long)i * 192 + k];
+    // the pick index the reference takes for the null pick (:762-765): n_arv unless NO source keeps the real null pick
+    const int E = *a.e0max;
+    __syncthreads();      // the weight image and cx are complete before any wave reads them (the slopes and proj_2 rows below!)
     const float act2 = im.scal[0], act3 = im.scal[1], act4 = im.scal[2];
     const float e2 = eps * eps, sq = sqrtf(15.f);
     const f32x4 w2[2][2] = {{tl_bias(im, 12, q), tl_bias(im, 13, q)}, {tl_bias(im, 14, q), tl_bias(im, 15, q)}};
@@ -3621,7 +3722,11 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                 __syncthreads();
                 int off = 0;
                 for (int k = 0; k < wave; ++k) off += wcnt[k];
-                if (keep) kept[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+                if (keep) {
+                    const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+                    kept[pos] = r;
+                    kbi[pos] = r == L ? a.n_arv : a.order[r0 + r];
+                }
                 if (threadIdx.x == 0) wcnt[4] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
                 __syncthreads();
             }
@@ -3633,6 +3738,7 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                 const int r = kept[ok ? kk : K - 1];
                 const bool nul = r == L;
                 const int b = nul ? 0 : a.order[r0 + r];
+                const bool nl = (nul ? a.n_arv : b) == E;          // null_link of this pick's edges (:765)
                 const float tp = nul ? 0.f : a.tpick[b];
                 const float rp = nul ? rel_null : tp - tp_src, rs = nul ? rel_null : tp - ts_src;
                 const float ph = nul ? -1.f : a.phase[b];
@@ -3642,7 +3748,7 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                 const float x1 = q == 0 ? f6[4] : (q == 1 ? f6[5] : 0.f);                          // columns 34 + q
                 const f32x4 xp = nul ? tl_zero() : tl_load15(a.arv_p + (long long)b * 15, q);
                 const f32x4 xs = nul ? tl_zero() : tl_load15(a.arv_s + (long long)b * 15, q);
-                f32x4 hq[2], hv[2], hw[2];   // hidden layers: query, values of a plain edge, values of a self (null pick: null) edge
+                f32x4 hq[2], hv[2], hw[2];   // hidden layers: query, values of an edge without / with self_link (null_link = nl in both)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f32x4 z = mma_block(tl_bias(im, t, q), TLW(im, GA_Q1(t, 0)), xp);
@@ -3654,8 +3760,10 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                     v = mma_block(v, TLW(im, GA_V1(t, 1)), xs);
                     v = MFMA16(TLW(im, GA_V1(t, 2)).x, x0, v);
                     v = MFMA16(TLW(im, GA_V1(t, 2)).y, x1, v);
-                    const f32x4 w = MFMA16(TLW(im, GA_V1(t, 3)).x, nul ? (q == 1 ? 1.f : 0.f) : (q == 0 ? 1.f : 0.f), v);
-                    hv[t] = prelu4(v, act3);
+                    const float lnk = (q == 1 && nl) ? 1.f : 0.f;          // k-step [self_link, null_link]: lane q = 0 / 1 supplies it
+                    const f32x4 vb = MFMA16(TLW(im, GA_V1(t, 3)).x, lnk, v);
+                    const f32x4 w = MFMA16(TLW(im, GA_V1(t, 3)).x, q == 0 ? 1.f : lnk, v);
+                    hv[t] = prelu4(vb, act3);
                     hw[t] = prelu4(w, act3);
                 }
                 float* eo = ent + (long long)(ok ? kk : K - 1) * AR_ENT;
@@ -3663,8 +3771,8 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                 for (int h = 0; h < 3; ++h) {
                     f32x4 qh = mma_block(tl_bias(im, 4 + h, q), TLW(im, GA_Q2(h, 0)), hq[0]);
                     qh = mma_block(qh, TLW(im, GA_Q2(h, 1)), hq[1]);
-                    // plain-edge context (null pick: null-edge context) and self-edge context
-                    const f32x4 c0 = *(const f32x4*)(cx + (nul ? 96 : 0) + h * 16 + 4 * q), c1 = *(const f32x4*)(cx + 48 + h * 16 + 4 * q);
+                    // context of an edge without / with self_link (variants: bit 0 self_link, bit 1 null_link)
+                    const f32x4 c0 = *(const f32x4*)(cx + (nl ? 96 : 0) + h * 16 + 4 * q), c1 = *(const f32x4*)(cx + (nl ? 144 : 48) + h * 16 + 4 * q);
                     const f32x4 p0 = qh * c0, p1 = qh * c1;
                     float s0 = ((p0.x + p0.y) + p0.z) + p0.w, s1 = ((p1.x + p1.y) + p1.z) + p1.w;
                     s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
@@ -3675,7 +3783,7 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                     wh = mma_block(wh, TLW(im, GA_V2(h, 1)), hw[1]);
                     if (ok) {
                         if (q == 0) { eo[h] = s0 / sq; eo[3 + h] = s1 / sq; }
-                        *(f32x4*)(eo + 8 + h * 16 + 4 * q) = nul ? wh : vh;      // the null pick has one variant (null edge)
+                        *(f32x4*)(eo + 8 + h * 16 + 4 * q) = vh;
                         *(f32x4*)(eo + 56 + h * 16 + 4 * q) = wh;
                     }
                 }
@@ -3686,9 +3794,11 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
             for (int tt = 0; tt < 4; ++tt) {
                 const int r = tb0 + (tt * 4 + wave) * 16 + j;
                 if (tb0 + (tt * 4 + wave) * 16 >= L || K == 0) continue;          // (uniform per wave)
+                // self_link = (e0 == e1 mod e0max), e1 = a + i n_arv (:764): the target pick itself when e0max = n_arv
+                const int tsel = (r < L && E > 0) ? (int)(((long long)a.order[r0 + r] + (long long)i * a.n_arv) % E) : -1;
                 float cm[3] = {mx[tt][0], mx[tt][1], mx[tt][2]};
                 for (int k = 0; k < K; ++k) {
-                    const float* e = ent + k * AR_ENT + (kept[k] == r ? 3 : 0);
+                    const float* e = ent + k * AR_ENT + (kbi[k] == tsel ? 3 : 0);
 #pragma unroll
                     for (int h = 0; h < 3; ++h) cm[h] = fmaxf(cm[h], e[h]);
                 }
@@ -3698,7 +3808,7 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
                     den[tt][h] *= sc; agg[tt][h] *= sc; mx[tt][h] = cm[h];
                 }
                 for (int k = 0; k < K; ++k) {
-                    const bool self = kept[k] == r;
+                    const bool self = kbi[k] == tsel;
                     const float* e = ent + k * AR_ENT;
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
@@ -5335,7 +5445,7 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
     a.img = c->packed[PL_RO0];
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
     k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -5380,7 +5490,7 @@ int genie_readout_grid_latent(genie_ctx* c, const float* x_spatial, const float*
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out; a.lat_out = y_latent_out;
     a.img = c->packed[PL_RO0];
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
     k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -5413,10 +5523,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     float* w = (float*)ws;
     const long long ss = (long long)c->slot_stride;
     const size_t so = (size_t)slot0 * c->slot_stride;
-    // Bipartite read-out -> bip[slot]
-    k_bip_out_m<<<dim3(tl_blocks(c->G, std::max(32, c->num_cu * 2 / nwin)), nwin), 256, 0, st>>>(
-        w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], w + c->o_bip + so, ss, ss);
-    // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
+    // Bipartite read-out -> bip[slot] and the pre-pass of SpatialAggregation1, one launch
     const int nbx = tl_blocks(c->G, std::min(1024, std::max(32, c->num_cu * 2 / nwin)));
     float* pj[2] = {w + c->o_pj0 + so, w + c->o_pj1 + so};
     float* gp[2] = {w + c->o_gpart + so, w + c->o_gpart + so + 1024 * 8};
@@ -5425,11 +5532,12 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         SaArgs a;
         memset(&a, 0, sizeof(a));
         sa_fill_layer(c, 1, a);
-        a.x_in = w + c->o_bip + so; a.ws_x_in = ss; a.ws_slot = ss;
+        a.out = w + c->o_bip + so; a.ws_out = ss; a.ws_slot = ss;
         a.pj_out = pj[0]; a.gpart_out = gp[0];
         a.img = c->packed[PL_SA1];
-        k_sa_pre_m<15><<<grid, 256, 0, st>>>(a);
+        k_bip_pre_m<<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
     }
+    // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
     for (int layer = 1; layer <= 3; ++layer) {
         SaArgs a;
         memset(&a, 0, sizeof(a));
@@ -5450,14 +5558,15 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     // read-out heads over the nwin * G grid nodes / nwin * Q queries
     RoArgs a = make_ro_args(c);
     a.T = n_t; a.x_spatial = x_spatial_out; a.t_query = t_query;
-    {
+    {   // the grid read-out also leaves the per-grid-node table cv of the query read-out (k_ro_pre_m's work)
         RoArgs g = a;
         g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->packed[PL_RO0];
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
-        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
+        size_t lds = sizeof(float) * ROM_LDS_FLOATS;
+        if (x_out) { g.cv_out = w + c->o_cv + so; g.cv_ws = ss; g.pimg = c->packed[PL_ROP]; lds += sizeof(float) * GP_IMG_FLOATS; }
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
+        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, lds, st>>>(g);
     }
     if (x_out) {
-        k_ro_pre_m<<<tl_blocks((long long)nwin * c->G, c->tail_cu_ro), 256, 0, st>>>(x_spatial_out, nwin * c->G, c->packed[PL_ROP], w + c->o_cv + so, c->G, ss);
         RoArgs q = a;
         q.N = nwin * n_query; q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out;
         q.img = c->packed[PL_RO1]; q.cv = w + c->o_cv + so; q.cv_ws = ss;
@@ -5783,7 +5892,7 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     if ((rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st))) return rc;
     if ((rc = sa_launch_layer(c, 2, sa1, pos, sa2, w, 1, true, st))) return rc;
     if ((rc = sa_launch_layer(c, 3, sa2, pos, xs, w, 0, false, st))) return rc;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
     HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
     RoArgs a = make_ro_args(c);
     a.T = n_t; a.x_spatial = xs; a.t_query = t_query;
@@ -6028,9 +6137,9 @@ int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int3
 int genie_arrivals_fwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
                        const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
                        const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
-                       float eps, float* ctx_scratch, int32_t* overflow, float* out, void* stream) {
+                       float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, void* stream) {
     if (!c || !stime || !src_embed || !trv_src || !arrival_p || !arrival_s || !tpick || !phase_label || !order || !seg_sta || !seg_start ||
-        !seg_len || !ctx_scratch || !overflow || !out)
+        !seg_len || !ctx_scratch || !e0max_scratch || !out)
         return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: null argument");
     if (n_src < 1 || n_sta < 1 || n_arv < 1 || n_useg < 1 || !(eps > 0.f)) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: bad argument");
     if ((long long)n_src * n_useg > 0x7fffffffLL) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: too many (source, station) pairs");
@@ -6042,8 +6151,10 @@ int genie_arrivals_fwd(genie_ctx* c, int n_src, const float* stime, const float*
     memset(&a, 0, sizeof(a));
     a.n_src = n_src; a.n_sta = n_sta; a.n_arv = n_arv; a.n_useg = n_useg; a.eps = eps;
     a.stime = stime; a.trv_src = trv_src; a.ctx = ctx_scratch; a.arv_p = arrival_p; a.arv_s = arrival_s; a.tpick = tpick; a.phase = phase_label;
-    a.order = order; a.seg_sta = seg_sta; a.seg_start = seg_start; a.seg_len = seg_len; a.img = c->packed[PL_ARR]; a.out = out; a.overflow = overflow;
-    const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + AR_CAP * AR_ENT + AR_CAP + 144 + 8);
+    a.order = order; a.seg_sta = seg_sta; a.seg_start = seg_start; a.seg_len = seg_len; a.img = c->packed[PL_ARR]; a.out = out; a.e0max = e0max_scratch;
+    HIP_TRY(hipMemsetAsync(e0max_scratch, 0xff, sizeof(int32_t), st));       // -1
+    k_arr_e0max<<<n_src * n_useg, 256, 0, st>>>(a);
+    const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + AR_CAP * AR_ENT + 2 * AR_CAP + 192 + 8);
     HIP_TRY(hipFuncSetAttribute((const void*)k_arrivals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_arrivals<<<n_src * n_useg, 256, lds, st>>>(a);
     HIP_TRY(hipGetLastError());

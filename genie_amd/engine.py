@@ -707,8 +707,8 @@ class HipPath(object):
     def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps):
         """StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd): stime [n_src], src_embed
         [n_src, 30], trv_src [n_src, n_sta, 2], arrival_p / arrival_s [n, 15], tpick / phase_label [n], ipick integer [n] ->
-        [n_src, n, 2], or None when the kernel's precondition does not hold (no source with |stime| < 2 eps: the reference's
-        `edge_index[0].max()` is then not the null pick): the caller then takes the PyTorch restatement."""
+        [n_src, n, 2]. `edge_index[0].max()` (module.py:762-763: the pick the reference treats as the null pick; the real null pick
+        whenever some source has |stime| < 2 eps) is found on the device (k_arr_e0max)."""
         if not getattr(self, "assoc_ready", False):
             raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
         stime = _f32(stime, "stime").reshape(-1)
@@ -722,8 +722,8 @@ class HipPath(object):
         n = int(tpick.numel())
         arrival_p, arrival_s = _f32(arrival_p, "arrival_p", (n, 15)), _f32(arrival_s, "arrival_s", (n, 15))
         phase_label = _f32(phase_label, "phase_label").reshape(-1)
-        if n == 0 or n_src == 0 or not bool((stime.abs() < 2.0 * float(eps)).any()):
-            return None
+        if n == 0 or n_src == 0:
+            raise ValueError("arrivals_fwd: needs at least one pick and one source")
         ip = ipick.reshape(-1).long()
         if ip.numel() != n or phase_label.numel() != n or int(ip.max()) >= n_sta or int(ip.min()) < 0:
             raise ValueError("arrivals_fwd: one station index in [0, n_sta) and one phase label per pick")
@@ -732,8 +732,8 @@ class HipPath(object):
         seg_start = torch.cumsum(counts, 0) - counts
         i32 = lambda t: t.to(torch.int32).contiguous()
         order, seg_sta, seg_start, counts = i32(order), i32(seg_sta), i32(seg_start), i32(counts)
-        ctx = torch.empty(n_src * 144, dtype=torch.float32, device=self.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ctx = torch.empty(n_src * 192, dtype=torch.float32, device=self.device)
+        flag = torch.empty(1, dtype=torch.int32, device=self.device)
         out = torch.empty((n_src, n, 2), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_arrivals_fwd(self.ctx, n_src, _ptr(stime), _ptr(src_embed), _ptr(trv_src), n_sta, _ptr(arrival_p),
                                                _ptr(arrival_s), _ptr(tpick), _ptr(phase_label), n, _ptr(order), _ptr(seg_sta),

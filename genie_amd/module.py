@@ -945,11 +945,9 @@ class GCN_Detection_Network_extended(nn.Module):
         else:
             arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
             arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
-        arv = None
         if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
-            # :993 in HIP (genie_arrivals_fwd); None = its preconditions do not hold for this call
-            arv = self._hip.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)
-        if arv is None:
+            arv = self._hip.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)   # :993 in HIP
+        else:       # training steps (autograd), or a context without association-head weights
             arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 

@@ -368,14 +368,15 @@ int genie_lslc_fwd(genie_ctx* ctx, int phase_head, const float* s_rows, const in
  * the device: out [n_src, n_arv, 2]. stime [n_src] (`tq_sample`), src_embed [n_src, 30] (`x_src`), trv_src [n_src, n_sta, 2]
  * (`trv_out_q`), arrival_p / arrival_s [n_arv, 15] (genie_lslc_fwd), tpick / phase_label fp32 [n_arv]. The picks grouped by station:
  * order [n_arv] = pick ids sorted by station (stable), and for each of the n_useg stations that have picks its id, the start of
- * its picks in `order` and their count. ctx_scratch: n_src * 144 floats; overflow: one int32, reserved (never set). Precondition
- * (checked by the caller): some source has |stime| < 2 eps, i.e. the null pick of module.py:715-718 survives the time filter, so
- * that `edge_index[0].max()` at :762-763 is the null pick. The segment softmax (:773) runs in streaming form over chunks of 192
- * picks of a station, so a station may hold any number of picks. */
+ * its picks in `order` and their count. ctx_scratch: n_src * 192 floats; e0max_scratch: one int32 where the call leaves
+ * `edge_index[0].max()` over the kept edges (:762-763), the pick index the reference uses for `self_link` / `null_link` (:764-765):
+ * the null pick n_arv whenever some source has |stime| < 2 eps (the null pick of :715-718 then survives the time filter), otherwise
+ * the largest pick index with a kept edge -- reproduced as the reference computes it. The segment softmax (:773) runs in streaming
+ * form over chunks of 192 picks of a station, so a station may hold any number of picks. */
 int genie_arrivals_fwd(genie_ctx* ctx, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
                        const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
                        const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
-                       float eps, float* ctx_scratch, int32_t* overflow, float* out, void* stream);
+                       float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, void* stream);
 
 /* Product-level CSRs of the irregular product graph of `use_subgraph: True` on the device (the two `subgraph(...)` loops of
  * extract_inputs_adjacencies_subgraph, process_utils.py:824-839). Product node n = the pair (pair_sta[n], pair_src[n]), pairs

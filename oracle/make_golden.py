@@ -178,7 +178,7 @@ def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "nonzero rows", int((Inpts[0].abs().sum(1) > 0).sum()))
 
 
-def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0):
+def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
     """Golden vector for the 4-output `forward_fixed` (module.py:963-997): source branch + association heads
     (BipartiteGraphReadOutOperator, DataAggregationAssociationPhase, LocalSliceLgCollapse P/S,
     StationSourceAttentionMergedPhases), with the time-pointer tables built by the reference's own
@@ -212,7 +212,7 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0):
     rng = np.random.default_rng(77)
     src_nodes = rng.choice(Gn, n_src, replace=False)
     x_query_src = geom.x_grid[src_nodes] + rng.normal(0, 500.0, (n_src, 3))
-    tq_sample = rng.uniform(-2.0, 2.0, n_src).astype(np.float32)
+    tq_sample = rng.uniform(-2.0, 2.0, n_src).astype(np.float32) if stime is None else np.asarray(stime, dtype=np.float32)
     d = np.linalg.norm(x_query_src[:, None, :] - geom.locs[None, :, :], axis=2)
     trv_out_q = np.stack([d / syn_VP, d / syn_VS], axis=2).astype(np.float32)    # [n_src, S, 2]
     # picks inside the embedding range of the time-pointer table (tpick - dt_partition[0] >= 0)
@@ -238,6 +238,29 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0):
 
 
 syn_VP, syn_VS = 6000.0, 3400.0
+
+
+def main_assoc():
+    """Round 3: the pick-sized association heads pinned where the HIP kernels branch: >= 17 stations with uniform degree (pipelined
+    kernels, station processing order), one station with > 250 picks (two 192-pick chunks of k_arrivals' streaming softmax), a
+    station without any pick, and a call where NO candidate source has |stime| < 2 eps, so that the reference's
+    `edge_index[0].max()` (module.py:762-763) is not the null pick."""
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+    geom = syn.Geometry(20, 60, L=80e3, n_query=30, seed=91)
+    P = syn.make_picks(geom, 420, seed=92)
+    rng = np.random.default_rng(93)
+    extra = np.stack([rng.uniform(-5.0, geom.max_t + 5.0, 270), np.full(270, 3.0), np.ones(270), np.ones(270),
+                      rng.integers(0, 2, 270).astype(np.float64)], axis=1)                  # 270 more picks on station 3
+    P = np.concatenate([P[P[:, 1] != 7], extra], axis=0)                                      # station 7 has no pick at all
+    P = P[np.argsort(P[:, 0], kind="stable")]
+    Slice, Mask = syn.make_slice_mask(geom, P, 0.0)
+    order = np.lexsort((P[:, 0], P[:, 1]))
+    win = {"Slice": Slice, "Mask": Mask, "P": P, "tpick": P[order, 0].astype(np.float32), "ipick": P[order, 1].astype(np.int64),
+           "phase_label": P[order, 4].astype(np.float32).reshape(-1, 1), "n_picks": int(P.shape[0])}
+    assert int((win["ipick"] == 3).sum()) > 250 and int((win["ipick"] == 7).sum()) == 0
+    run_assoc_case(ref, "assoc_20x60", geom, win, n_src=5)
+    run_assoc_case(ref, "assoc_20x60_nonull", geom, win, n_src=3, stime=[33.0, -31.5, 36.0])
 
 
 def main_edges():
@@ -379,6 +402,8 @@ def main():
         return main_subgraph()
     if "--abspos" in sys.argv:
         return main_abspos()
+    if "--assoc" in sys.argv:
+        return main_assoc()
     ref = _import_reference()
     from genie_amd import synthetic as syn
 

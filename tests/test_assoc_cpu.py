@@ -3,6 +3,7 @@ vector produced by the reference's own forward_fixed (tests/golden/assoc_7x45.np
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from genie_amd import graph
@@ -10,15 +11,21 @@ from oracle import genie_oracle as O
 from tests.util import GOLDEN_DIR, max_abs
 
 
-def load():
-    z = np.load(os.path.join(GOLDEN_DIR, "assoc_7x45.npz"))
+# round 3: 20 stations (uniform degree 8: the pipelined kernels), 270 picks on one station, one station without picks; `_nonull`:
+# no candidate source with |stime| < 2 eps, so `edge_index[0].max()` (module.py:762-763) is a real pick, not the null pick
+ASSOC_CASES = ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull"]
+
+
+def load(name="assoc_7x45"):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     w = O.weights_from_npz(z)
     t = lambda k, dt=torch.float32: torch.from_numpy(np.asarray(z[k])).to(dt)
     return z, w, t
 
 
-def test_oracle_forward_fixed_matches_reference():
-    z, w, t = load()
+@pytest.mark.parametrize("name", ASSOC_CASES)
+def test_oracle_forward_fixed_matches_reference(name):
+    z, w, t = load(name)
     S, G = int(z["n_sta"]), int(z["n_grid"])
     A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
     y, x, arv_p, arv_s = O.forward_fixed(
@@ -32,11 +39,12 @@ def test_oracle_forward_fixed_matches_reference():
     assert float(t("arv_p").abs().max()) > 1e-2          # non-trivial fixture
 
 
-def test_product_heads_match_reference_given_oracle_front():
-    """The PyTorch association heads shipped in genie_amd/module.py (CPU run), fed with the oracle's front-end
-    intermediates, reproduce the reference's arv_p / arv_s."""
+@pytest.mark.parametrize("name", ASSOC_CASES)
+def test_product_heads_match_reference_given_oracle_front(name):
+    """The PyTorch association heads shipped in genie_amd/module.py (CPU run: what training steps differentiate), fed with the
+    oracle's front-end intermediates, reproduce the reference's arv_p / arv_s."""
     from genie_amd import module
-    z, w, t = load()
+    z, w, t = load(name)
     S, G = int(z["n_sta"]), int(z["n_grid"])
     A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
     o = O.forward_fixed_source(w, t("Slice"), t("Mask"), A_in_sta, A_in_src, t("edge_attr"), A_src_in_prod,
@@ -55,7 +63,7 @@ def test_product_heads_match_reference_given_oracle_front():
                                           t("phase_label"), s, tl[:, 0:1])
         arv_s = net.LocalSliceLgCollapseS(t("A_edges_s", torch.long), t("dt_partition"), t("tpick"), t("ipick", torch.long),
                                           t("phase_label"), s, tl[:, 1:2])
-        arv = net.Arrivals(4, t("tq_sample"), x_src, t("trv_out_q"), arv_p, arv_s, t("tpick"), t("ipick", torch.long), t("phase_label"))
+        arv = net.Arrivals(int(z["tq_sample"].shape[0]), t("tq_sample"), x_src, t("trv_out_q"), arv_p, arv_s, t("tpick"), t("ipick", torch.long), t("phase_label"))
     assert max_abs(arv[:, :, 0:1], t("arv_p")) <= 2e-6
     assert max_abs(arv[:, :, 1:2], t("arv_s")) <= 2e-6
 
