@@ -76,9 +76,17 @@ SYMBOLS = [
                                    _P, _P, _P, _P]),
     ("genie_assoc_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_assoc_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_assoc_train_save_floats", _c.c_size_t, [_P]),
+    ("genie_assoc_train_scratch_floats", _c.c_size_t, [_P]),
+    ("genie_assoc_train_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_assoc_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     ("genie_lslc_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
                                   _P, _P, _P, _c.c_int, _P, _P]),
+    ("genie_lslc_bwd_part_floats", _c.c_size_t, [_c.c_int]),
+    ("genie_lslc_bwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
+                                  _P, _P, _P, _c.c_int, _P, _P, _P, _P, _P, _P]),
+    ("genie_seg_rows", _c.c_int, [_P, _P, _P, _c.c_int64, _P, _P]),
     ("genie_arrivals_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_float,
                                       _P, _P, _P, _P]),
     ("genie_subgraph_csr_count", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -593,9 +593,12 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
 // Plans (genie_ctx::plan[PL_*]) and their group index maps:
 enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, PL_ARR,
        // transposed weights of the tail's backward passes (train_tail_kernels.hpp)
-       PL_TRO0, PL_TRO1, PL_TSN, PL_TSA1, PL_TSA2, PL_TSA3, PL_TBIP, NPLAN };
+       PL_TRO0, PL_TRO1, PL_TSN, PL_TSA1, PL_TSA2, PL_TSA3, PL_TBIP,
+       // ... and of the association heads' backward passes (train_assoc_kernels.hpp)
+       PL_TAB2, PL_TAB1, PL_TAB0, PL_TAG, PL_TLSP, PL_TLSS, NPLAN };
 // gradient maps (k_train_reduce): the three P-sized passes, then the tail's backward kernels
-enum { TM_B2 = 0, TM_B1, TM_B0, TM_RO0, TM_RO1, TM_SN, TM_SAA1, TM_SAA2, TM_SAA3, TM_SAB1, TM_SAB2, TM_SAB3, TM_BIP, NTM };
+enum { TM_B2 = 0, TM_B1, TM_B0, TM_RO0, TM_RO1, TM_SN, TM_SAA1, TM_SAA2, TM_SAA3, TM_SAB1, TM_SAB2, TM_SAB3, TM_BIP,
+       TM_AB3, TM_AB2, TM_AB1, TM_AB0, TM_AG, TM_LSP, TM_LSS, NTM };
 //  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
 //  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
 //  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
@@ -2184,7 +2187,13 @@ struct AsArgs {
     float* tr; float* q1; float* q2;                                    // [P,32]
     float* c; float* wu; float* wv;
     const float* packed;
+    float* save; long long Pn;   // training forward: pre-activations kept for the backward passes, [AV_*][Pn][16], or null
 };
+// blocks of the association phase's saved pre-activations: BipartiteGraphReadOutOperator fc1 (before PReLU and the mask gate) and
+// fc2, init_trns, l1_t1_1 / l1_t2_1 (w, tile), [10, 11] = the output layer (written by the stage-2 kernel as its SV_O), layer 1
+// (half, tile), l2_t1_1 / l2_t2_1 (w, tile)
+constexpr int AV_Z1 = 0, AV_SV = 2, AV_TR = 3, AV_Q = 5, AV_O = 10, AV_T = 12, AV_UV = 16, AV_BLOCKS = 20;
+static_assert(AV_O == SV_O, "the stage-2 kernel stores the output layer's pre-activations at SV_O");
 
 struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as_l2t12_w, as_l2t22_w; };
 
@@ -2251,11 +2260,13 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
             f32x4 z = *(const f32x4*)(pg + 16 * t + 4 * q);
             if (t == 1 && q == 3) z.w = 0.f;                                   // slot 31 carries mask1, not a channel
             z = MFMA16(lw[GA_FC1E(t) * 64 + lane].x, eq, z);
+            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_Z1 + t) * a.Pn + pi) * 16 + 4 * q) = z;
             msg[t] = prelu4u(z, r1) * m1;
         }
         f32x4 sv = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         sv = mma_block(sv, lw[GA_FC2(0) * 64 + lane], msg[0]);
         sv = mma_block(sv, lw[GA_FC2(1) * 64 + lane], msg[1]);
+        if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)AV_SV * a.Pn + pi) * 16 + 4 * q) = sv;
         sv = prelu4u(sv, r2);
         // init_trns [s || x_latent || mask1 || Mask]
         f32x4 tr[2];
@@ -2266,6 +2277,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
             acc = mma_block(acc, lw[GA_INIT(t, 1) * 64 + lane], lat0);
             acc = mma_block(acc, lw[GA_INIT(t, 2) * 64 + lane], lat1);
             acc = MFMA16(lw[GA_INIT(t, 3) * 64 + lane].x, mq, acc);
+            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_TR + t) * a.Pn + pi) * 16 + 4 * q) = acc;
             tr[t] = prelu4u(acc, a0);
         }
         f32x4 qv[2][2];
@@ -2276,6 +2288,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
                 f32x4 acc = *(const f32x4*)(lbias + (3 + 2 * wq + t) * 16 + 4 * q);
                 acc = mma_block(acc, lw[GA_Q(wq, t, 0) * 64 + lane], tr[0]);
                 acc = mma_block(acc, lw[GA_Q(wq, t, 1) * 64 + lane], tr[1]);
+                if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_Q + 2 * wq + t) * a.Pn + pi) * 16 + 4 * q) = acc;
                 qv[wq][t] = prelu4u(acc, wq == 0 ? a11 : a12);
             }
         if (valid) {
@@ -2399,6 +2412,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[GB_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+        if (a.save != nullptr && valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(AV_T + k) * a.Pn + pi) * 16 + 4 * q) = acc[k];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);
         // r1 / r2 and the node-local layer-2 terms
@@ -2417,6 +2434,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         }
         o6[4] = MFMA16(lw[GB_C(0, 4) * 64 + lane].x, mq, o6[4]);
         o6[5] = MFMA16(lw[GB_C(1, 4) * 64 + lane].x, mq, o6[5]);
+        if (a.save != nullptr && valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(AV_UV + k) * a.Pn + pi) * 16 + 4 * q) = o6[k];
+        }
         o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
         o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
         f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
@@ -2470,6 +2491,11 @@ struct TrArgs {
     const float* packed;
     float* part;                 // per-wave partials: [wave][n_acc * 256 + n_vec * 16 + 16]
     int n_acc, n_vec;
+    int sv_t, sv_up, sv_vp;      // k_train_b1: blocks of `save` holding the pre-activations of h1 / u / v (SV_T, SV_UP, SV_VP, or the
+                                 // association phase's AV_T, AV_UV, AV_UV + 2)
+    const float* pg;             // association phase (k_train_b1<true>, k_as_*): [G][AS_PG] per-source-node terms, pg[31] = mask1[g]
+    const float* x_latent;       // association phase: [P, 30] DataAggregation output (an input of init_trns there)
+    float* zsum;                 // k_as_b0: [G * T][32] per-tile station sums of d z1 (-> d y_latent, fc1's y_latent columns)
 };
 
 __device__ __forceinline__ f32x4 ldb(const float* buf, int blk, long long P, long long p, int q) {
@@ -2604,6 +2630,9 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
 // ---- pass 1': layer 2 and the activation of layer 1.
 // accumulators: l2_t1_2 {h1 x4, Mask, u x2 (adjoint)} = 7, l2_t2_2 = 7, l2_t1_1 (2 x h1 x4) = 8, l2_t2_1 = 8  -> 30
 // vec: b(l2_t1_2), b(l2_t2_2), b(l2_t1_1) x2, b(l2_t2_1) x2 = 6; scal: a1, a21, a22
+// AS: the same pass for DataAggregationAssociationPhase (module.py:397-401; 95-wide l2_t?_2 with mask width 5): the column of mask1
+// (one value per source node) gets its gradient as two extra vectors.
+template <bool AS>
 __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -2618,12 +2647,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     float* sc = tsc[wave];
     const int S = a.S;
     const long long P = a.P;
-    f32x4 acc[30], vec[6];
+    constexpr int NV = AS ? 8 : 6;
+    f32x4 acc[30], vec[NV];
     float scal[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 30; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NV; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     for (; w.it < w.nitems; w.it += w.stride) {
         int gi, tb;
@@ -2638,6 +2669,10 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
         f32x4 mb = {0.f, 0.f, 0.f, 0.f};
         if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
         const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
+        if (AS) {
+            const float m1 = a.pg[(long long)g * AS_PG + 31];
+            vec[6] += do1 * m1; vec[7] += do2 * m1;
+        }
         const float* gr = a.gr;
         const f32x4 tm1 = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
                                 [&](int c) { return ldb(gr, GR_DO + 0, P, (long long)g * S + c, q); }) * vm;
@@ -2645,11 +2680,11 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
                                 [&](int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn, q); }) * vm;
         f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SV_T + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
+        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SVT + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            up[b] = ldb(a.save, SV_UP + b, P, p, q); u[b] = prelu4u(up[b], a21);
-            vp[b] = ldb(a.save, SV_VP + b, P, p, q); v[b] = prelu4u(vp[b], a22);
+            up[b] = ldb(a.save, SVU + b, P, p, q); u[b] = prelu4u(up[b], a21);
+            vp[b] = ldb(a.save, SVV + b, P, p, q); v[b] = prelu4u(vp[b], a22);
         }
         // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
         f32x4 du[2], dv[2];
@@ -2714,7 +2749,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
             }
         }
     }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, 6, scal, 3, threadIdx.x & 63, j, q);
+    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
 }
 
 // ---- pass 0': layer 1 and init_trns.
@@ -4351,6 +4386,7 @@ __global__ void k_permute_sta_rows(const float* __restrict__ src, long long rows
 }
 
 #include "train_tail_kernels.hpp"
+#include "train_assoc_kernels.hpp"
 
 }  // namespace
 
@@ -4653,6 +4689,57 @@ void build_tail_train_plans(StagePlan* plan) {
         for (int b = 0; b < 2; ++b) add_block_group_T(p, W_BP_FC2_W, 30, 16 * b, rows2(b), 0, 15);
         p.scal.push_back(g_params[W_BP_ACT2].off);
     }
+    {   // association phase, pass 2' = k_train_b1<true>: the group map of build_train_plans' p1 with this head's weights
+        StagePlan& p1 = plan[PL_TAB2];
+        for (int b = 0; b < 2; ++b) add_block_group_T(p1, W_AS_L2T12_W, 95, 60 + 16 * b, rows2(b), 0, 15);
+        for (int b = 0; b < 2; ++b) add_block_group_T(p1, W_AS_L2T22_W, 95, 60 + 16 * b, rows2(b), 0, 15);
+        for (int hb = 0; hb < 4; ++hb) {
+            const int col0 = (hb >> 1) * 30 + 16 * (hb & 1), rows = (hb & 1) ? 14 : 16;
+            for (int src = 0; src < 2; ++src) add_block_group_T(p1, W_AS_L2T11_W, 60, col0, rows, 16 * src, src ? 14 : 16);
+            for (int src = 0; src < 2; ++src) add_block_group_T(p1, W_AS_L2T21_W, 60, col0, rows, 16 * src, src ? 14 : 16);
+            add_block_group_T(p1, W_AS_L2T12_W, 95, col0, rows, 0, 15);
+            add_block_group_T(p1, W_AS_L2T22_W, 95, col0, rows, 0, 15);
+        }
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 4; ++k)
+                add_block_group_T(p1, k < 2 ? W_AS_L1T12_W : W_AS_L1T22_W, 65, 16 * b, rows2(b), 16 * (k & 1), rows2(k & 1));
+        p1.scal.push_back(g_params[W_AS_ACT1].off);
+        p1.scal.push_back(g_params[W_AS_ACT21].off);
+        p1.scal.push_back(g_params[W_AS_ACT22].off);
+    }
+    {
+        StagePlan& p = plan[PL_TAB1];
+        for (int h = 0; h < 2; ++h)
+            for (int b = 0; b < 2; ++b)
+                for (int k = 0; k < 2; ++k) add_block_group_T(p, h == 0 ? W_AS_L1T12_W : W_AS_L1T22_W, 65, 30 + 16 * b, rows2(b), 16 * k, rows2(k));
+        for (int w = 0; w < 2; ++w)
+            for (int b = 0; b < 2; ++b)
+                for (int k = 0; k < 2; ++k) add_block_group_T(p, w == 0 ? W_AS_L1T11_W : W_AS_L1T21_W, 30, 16 * b, rows2(b), 16 * k, rows2(k));
+        p.scal.push_back(g_params[W_AS_ACT].off);
+        p.scal.push_back(g_params[W_AS_ACT11].off);
+        p.scal.push_back(g_params[W_AS_ACT12].off);
+    }
+    {
+        StagePlan& p = plan[PL_TAB0];
+        for (int t = 0; t < 2; ++t) add_block_group_T(p, W_AS_INIT_W, 50, 0, 15, 16 * t, rows2(t));
+        for (int b = 0; b < 2; ++b) add_block_group_T(p, W_RO_FC2_W, 30, 16 * b, rows2(b), 0, 15);
+        p.scal.push_back(g_params[W_RO_ACT1].off);
+        p.scal.push_back(g_params[W_RO_ACT2].off);
+    }
+    for (int ph = 0; ph < 2; ++ph) {
+        StagePlan& p = plan[ph == 0 ? PL_TLSP : PL_TLSS];
+        const int base = ph == 0 ? W_LP_FC1_W : W_LS_FC1_W;
+        for (int b = 0; b < 2; ++b) add_block_group_T(p, base + 2, 30, 16 * b, rows2(b), 0, 15);
+        for (int b = 0; b < 2; ++b)
+            for (int t = 0; t < 2; ++t) add_block_group_T(p, base, 32, 16 * b, rows2(b), 16 * t, rows2(t));
+        p.scal.push_back(g_params[base + 4].off);
+    }
+    {
+        StagePlan& p = plan[PL_TAG];
+        for (int b = 0; b < 2; ++b)
+            for (int t = 0; t < 2; ++t) add_block_group_T(p, W_RO_FC1_W, 33, 16 * b, rows2(b), 16 * t, rows2(t));
+        p.scal.push_back(g_params[W_RO_ACT1].off);
+    }
 }
 
 // gradient maps of the tail's backward kernels (accumulator / vector / scalar k of kernel TM_* -> entries of the gradient blob;
@@ -4736,16 +4823,81 @@ int build_tail_grad_maps(genie_ctx* c) {
     for (int k = 0; k < 2; ++k) A(TM_BIP, O(W_BP_FC2_W), 30, 0, 15, 16 * k, rows2(k));
     V(TM_BIP, O(W_BP_FC2_B), 0, 15);
     sc[TM_BIP] = {O(W_BP_ACT2)};
-    const int want_acc[NTM] = {0, 0, 0, RB_NACC0, RB_NACC1, GTN_GROUPS, SBA_NACC, SBA_NACC, SBA_NACC, SBB_NACC, SBB_NACC, SBB_NACC, 2};
-    const int want_vec[NTM] = {0, 0, 0, RB_NVEC, RB_NVEC, 10, SBA_NVEC, SBA_NVEC, SBA_NVEC, SBB_NVEC, SBB_NVEC, SBB_NVEC, 1};
+    // ---- association phase
+    sc[TM_AB3] = {O(W_AS_ACT2)};
+    for (int w = 0; w < 2; ++w) {       // pass 2' (k_train_b1<true>): l2_t1_2 / l2_t2_2 (15 x 95), l2_t1_1 / l2_t2_1 (30 x 60)
+        const int mat = O(w == 0 ? W_AS_L2T12_W : W_AS_L2T22_W);
+        for (int k = 0; k < 4; ++k) A(TM_AB2, mat, 95, 0, 15, (k >> 1) * 30 + 16 * (k & 1), rows2(k & 1));
+        A(TM_AB2, mat, 95, 0, 15, 91, 4);
+        for (int b = 0; b < 2; ++b) A(TM_AB2, mat, 95, 0, 15, 60 + 16 * b, rows2(b));
+    }
+    for (int w = 0; w < 2; ++w) {
+        const int mat = O(w == 0 ? W_AS_L2T11_W : W_AS_L2T21_W);
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 4; ++k) A(TM_AB2, mat, 60, 16 * b, rows2(b), (k >> 1) * 30 + 16 * (k & 1), rows2(k & 1));
+    }
+    V(TM_AB2, O(W_AS_L2T12_B), 0, 15); V(TM_AB2, O(W_AS_L2T22_B), 0, 15);
+    for (int b = 0; b < 2; ++b) V(TM_AB2, O(W_AS_L2T11_B), 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(TM_AB2, O(W_AS_L2T21_B), 16 * b, rows2(b));
+    V(TM_AB2, O(W_AS_L2T12_W) + 90, 0, 15, 95); V(TM_AB2, O(W_AS_L2T22_W) + 90, 0, 15, 95);      // the mask1 columns
+    sc[TM_AB2] = {O(W_AS_ACT1), O(W_AS_ACT21), O(W_AS_ACT22)};
+    for (int h = 0; h < 2; ++h) {       // pass 1' (k_as_b1): l1_t1_2 / l1_t2_2 (30 x 65)
+        const int mat = O(h == 0 ? W_AS_L1T12_W : W_AS_L1T22_W);
+        for (int b = 0; b < 2; ++b) {
+            A(TM_AB1, mat, 65, 16 * b, rows2(b), 0, 16);
+            A(TM_AB1, mat, 65, 16 * b, rows2(b), 16, 14);
+            A(TM_AB1, mat, 65, 16 * b, rows2(b), 61, 4);
+        }
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 2; ++k) A(TM_AB1, mat, 65, 16 * b, rows2(b), 30 + 16 * k, rows2(k));
+    }
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 2; ++k) A(TM_AB1, O(w == 0 ? W_AS_L1T11_W : W_AS_L1T21_W), 30, 16 * b, rows2(b), 16 * k, rows2(k));
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T12_B), 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T22_B), 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T12_W) + 60, 16 * b, rows2(b), 65);
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T22_W) + 60, 16 * b, rows2(b), 65);
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T11_B), 16 * b, rows2(b));
+    for (int b = 0; b < 2; ++b) V(TM_AB1, O(W_AS_L1T21_B), 16 * b, rows2(b));
+    sc[TM_AB1] = {O(W_AS_ACT), O(W_AS_ACT11), O(W_AS_ACT12)};
+    for (int t = 0; t < 2; ++t) {       // pass 0' (k_as_b0): init_trns (30 x 50), the read-out operator's fc2 (15 x 30), fc1's edge columns
+        A(TM_AB0, O(W_AS_INIT_W), 50, 16 * t, rows2(t), 0, 15);
+        A(TM_AB0, O(W_AS_INIT_W), 50, 16 * t, rows2(t), 15, 16);
+        A(TM_AB0, O(W_AS_INIT_W), 50, 16 * t, rows2(t), 31, 14);
+        A(TM_AB0, O(W_AS_INIT_W), 50, 16 * t, rows2(t), 46, 4);
+    }
+    for (int k = 0; k < 2; ++k) A(TM_AB0, O(W_RO_FC2_W), 30, 0, 15, 16 * k, rows2(k));
+    for (int t = 0; t < 2; ++t) A(TM_AB0, O(W_RO_FC1_W), 33, 16 * t, rows2(t), 30, 3);
+    for (int t = 0; t < 2; ++t) V(TM_AB0, O(W_AS_INIT_B), 16 * t, rows2(t));
+    for (int t = 0; t < 2; ++t) V(TM_AB0, O(W_AS_INIT_W) + 45, 16 * t, rows2(t), 50);
+    V(TM_AB0, O(W_RO_FC2_B), 0, 15);
+    for (int t = 0; t < 2; ++t) V(TM_AB0, O(W_RO_FC1_B), 16 * t, rows2(t));
+    sc[TM_AB0] = {O(W_RO_ACT1), O(W_RO_ACT2)};
+    for (int t = 0; t < 2; ++t)
+        for (int k = 0; k < 2; ++k) A(TM_AG, O(W_RO_FC1_W), 33, 16 * t, rows2(t), 16 * k, rows2(k));
+    for (int ph = 0; ph < 2; ++ph) {     // LocalSliceLgCollapse P / S (k_lslc_bwd): fc1 (30 x 32), fc2 (15 x 30)
+        const int tm = ph == 0 ? TM_LSP : TM_LSS, base = ph == 0 ? W_LP_FC1_W : W_LS_FC1_W;
+        for (int t = 0; t < 2; ++t) {
+            A(tm, O(base), 32, 16 * t, rows2(t), 0, 16);
+            A(tm, O(base), 32, 16 * t, rows2(t), 16, 14);
+            A(tm, O(base), 32, 16 * t, rows2(t), 30, 2);
+        }
+        for (int k = 0; k < 2; ++k) A(tm, O(base + 2), 30, 0, 15, 16 * k, rows2(k));
+        for (int t = 0; t < 2; ++t) V(tm, O(base + 1), 16 * t, rows2(t));
+        V(tm, O(base + 3), 0, 15);
+        sc[tm] = {O(base + 4), O(base + 5)};
+    }
+    const int want_acc[NTM] = {0, 0, 0, RB_NACC0, RB_NACC1, GTN_GROUPS, SBA_NACC, SBA_NACC, SBA_NACC, SBB_NACC, SBB_NACC, SBB_NACC, 2, 0, 30, 28, 12, 4, 8, 8};
+    const int want_vec[NTM] = {0, 0, 0, RB_NVEC, RB_NVEC, 10, SBA_NVEC, SBA_NVEC, SBA_NVEC, SBB_NVEC, SBB_NVEC, SBB_NVEC, 1, 0, 8, 12, 7, 0, 3, 3};
     for (int s = TM_RO0; s < NTM; ++s) {
         if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s] || sc[s].size() > 16)
             return fail(GENIE_ERR_STATE, "internal: tail gradient maps do not match the backward kernels");
         c->n_acc[s] = (int)acc[s].size(); c->n_vec[s] = (int)vec[s].size(); c->n_sc[s] = (int)sc[s].size();
-        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * acc[s].size()));
-        HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * vec[s].size()));
-        HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * std::max<size_t>(1, acc[s].size())));
+        if (!acc[s].empty()) HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * std::max<size_t>(1, vec[s].size())));
+        if (!vec[s].empty()) HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * std::max<size_t>(1, sc[s].size())));
         if (!sc[s].empty()) HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
     }
@@ -4836,7 +4988,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     build_tail_plans(c->plan);
     build_tail_train_plans(c->plan);
     if (c->plan[PL_TRO0].n_groups() != GTR_GROUPS || c->plan[PL_TRO1].n_groups() != GTR_GROUPS || c->plan[PL_TSN].n_groups() != GTN_GROUPS ||
-        c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS)
+        c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS ||
+        c->plan[PL_TAB2].n_groups() != GT1_GROUPS || c->plan[PL_TAB1].n_groups() != GA1_GROUPS || c->plan[PL_TAB0].n_groups() != GA0_GROUPS ||
+        c->plan[PL_TAG].n_groups() != GAG_GROUPS || c->plan[PL_TLSP].n_groups() != GLT_GROUPS || c->plan[PL_TLSS].n_groups() != GLT_GROUPS)
         return fail(GENIE_ERR_STATE, "internal: transposed tail plan does not match kernel group maps");
     if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
         (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
@@ -5754,7 +5908,7 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 
 namespace {
 int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }
-size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 6 * 16 + 16); }
+size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 12 * 16 + 16); }
 int train_check(const genie_ctx* c, const char* who) {
     if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
     if (c->has_edges || c->abs_sta) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
@@ -5818,11 +5972,12 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
     a.slice = slice; a.mask = mask; a.edge_attr = edge_attr; a.save = save; a.dr = d_r;
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
+    a.sv_t = SV_T; a.sv_up = SV_UP; a.sv_vp = SV_VP;
     const int grid = train_grid(c), n_waves = grid * 4;
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
         if (s == 0) k_train_b2<<<grid, 256, 0, st>>>(a);
-        else if (s == 1) k_train_b1<<<grid, 256, 0, st>>>(a);
+        else if (s == 1) k_train_b1<false><<<grid, 256, 0, st>>>(a);
         else k_train_b0<<<grid, 256, 0, st>>>(a);
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
@@ -6041,8 +6196,26 @@ int genie_set_tail_grid(genie_ctx* c, int readout_workgroups, int sa_workgroups)
 
 size_t genie_assoc_workspace_bytes(const genie_ctx* c) { return c ? sizeof(float) * 3 * 32 * (size_t)c->P : 0; }
 
+namespace {
+int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                   const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream, float* save);
+void assoc_pre_launch(genie_ctx* c, const float* y_latent, const float* mask_src, hipStream_t st) {
+    AsPreOffs o;
+    o.ro_fc1_w = g_params[W_RO_FC1_W].off; o.ro_fc1_b = g_params[W_RO_FC1_B].off; o.as_init_w = g_params[W_AS_INIT_W].off;
+    o.as_l1t12_w = g_params[W_AS_L1T12_W].off; o.as_l1t22_w = g_params[W_AS_L1T22_W].off;
+    o.as_l2t12_w = g_params[W_AS_L2T12_W].off; o.as_l2t22_w = g_params[W_AS_L2T22_W].off;
+    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, c->as_pg);
+}
+}  // namespace
+
 int genie_assoc_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
                     const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream) {
+    return assoc_fwd_impl(c, y_latent, mask_src, x_latent, mask, edge_attr, out, assoc_ws, ws, stream, nullptr);
+}
+
+namespace {
+int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                   const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream, float* save) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!y_latent || !mask_src || !x_latent || !mask || !edge_attr || !out || !assoc_ws)
@@ -6052,11 +6225,8 @@ int genie_assoc_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, 
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
-    AsPreOffs o;
-    o.ro_fc1_w = g_params[W_RO_FC1_W].off; o.ro_fc1_b = g_params[W_RO_FC1_B].off; o.as_init_w = g_params[W_AS_INIT_W].off;
-    o.as_l1t12_w = g_params[W_AS_L1T12_W].off; o.as_l1t22_w = g_params[W_AS_L1T22_W].off;
-    o.as_l2t12_w = g_params[W_AS_L2T12_W].off; o.as_l2t22_w = g_params[W_AS_L2T22_W].off;
-    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, c->as_pg);
+    assoc_pre_launch(c, y_latent, mask_src, st);
+    if (save) { c->force_generic = 1; c->train_save = save; }      // training forward: caller's station order, pre-activations kept
     DaArgs d = make_da_args(c, (float*)ws);
     AsArgs a;
     memset(&a, 0, sizeof(a));
@@ -6067,14 +6237,84 @@ int genie_assoc_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, 
     a.pg = c->as_pg; a.x_latent = x_latent; a.mask = mask; a.edge_attr = edge_attr;
     a.tr = (float*)assoc_ws; a.q1 = a.tr + 32 * (size_t)c->P; a.q2 = a.q1 + 32 * (size_t)c->P;
     a.c = d.c; a.wu = d.wu; a.wv = d.wv;
+    a.save = save; a.Pn = c->P;
     const int grid = da_grid(c, (long long)c->G * c->T, std::max(1, c->bpc1));
     a.packed = c->packed[2];
     k_assoc_a<<<grid, 256, 0, st>>>(a);
     a.packed = c->packed[3];
     k_assoc_b<<<grid, 256, 0, st>>>(a);
-    HIP_TRY(hipGetLastError());
     // second pair of neighbour means + PReLU2 = the stage-2 kernel of this context without its Bipartite half
-    return run_stage2(c, mask, edge_attr, out, ws, stream, 0, c->G, c->raw + g_params[W_AS_ACT2].off, 1);
+    rc = run_stage2(c, mask, edge_attr, out, ws, stream, 0, c->G, c->raw + g_params[W_AS_ACT2].off, 1);
+    if (save) { c->force_generic = 0; c->train_save = nullptr; }
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+}  // namespace
+
+// Training step of the P-sized association heads (train_assoc_kernels.hpp).
+size_t genie_assoc_train_save_floats(const genie_ctx* c) { return c ? (size_t)AV_BLOCKS * 16 * (size_t)c->P : 0; }
+size_t genie_assoc_train_scratch_floats(const genie_ctx* c) {
+    return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) + (size_t)c->G * c->T * 32 + 64 : 0;
+}
+
+int genie_assoc_train_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                          const float* edge_attr, float* out, float* asave, void* assoc_ws, void* ws, void* stream) {
+    if (!c || !asave) return fail(GENIE_ERR_ARG, "genie_assoc_train_fwd: null argument");
+    int rc = train_check(c, "genie_assoc_train_fwd");
+    if (rc) return rc;
+    return assoc_fwd_impl(c, y_latent, mask_src, x_latent, mask, edge_attr, out, assoc_ws, ws, stream, asave);
+}
+
+int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                          const float* edge_attr, const float* asave, const float* d_s, float* scratch, float* d_ylat_out,
+                          float* grad_blob, void* stream) {
+    if (!c || !y_latent || !mask_src || !x_latent || !mask || !edge_attr || !asave || !d_s || !scratch || !d_ylat_out || !grad_blob)
+        return fail(GENIE_ERR_ARG, "genie_assoc_train_bwd: null argument");
+    int rc;
+    if ((rc = train_check(c, "genie_assoc_train_bwd"))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    if ((rc = ensure_reversed(c))) return rc;
+    if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
+    assoc_pre_launch(c, y_latent, mask_src, st);          // pg[31] = mask1[g] (another forward may have overwritten the table)
+    HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * g_raw_total, st));
+    TrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = c->S; a.G = c->G; a.T = c->T; a.seg = std::max(1, c->seg);
+    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
+    a.P = c->P; a.order = c->order;
+    a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
+    a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
+    a.mask = mask; a.edge_attr = edge_attr; a.save = asave; a.x_latent = x_latent; a.pg = c->as_pg;
+    a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
+    a.zsum = a.part + train_part_floats(c);
+    a.sv_t = AV_T; a.sv_up = AV_UV; a.sv_vp = AV_UV + 2;
+    const int grid = train_grid(c), n_waves = grid * 4;
+    const int tms[4] = {TM_AB3, TM_AB2, TM_AB1, TM_AB0};
+    const int pls[4] = {-1, PL_TAB2, PL_TAB1, PL_TAB0};
+    for (int s = 0; s < 4; ++s) {
+        const int tm = tms[s];
+        a.packed = pls[s] >= 0 ? c->packed[pls[s]] : nullptr; a.n_acc = c->n_acc[tm]; a.n_vec = c->n_vec[tm];
+        if (s == 0) k_as_b3<<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
+        else if (s == 1) k_train_b1<true><<<grid, 256, 0, st>>>(a);
+        else if (s == 2) k_as_b1<<<grid, 256, 0, st>>>(a);
+        else k_as_b0<<<grid, 256, 0, st>>>(a);
+        const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
+                                                            c->d_sc[tm], grad_blob, 0);
+    }
+    {
+        AgArgs g;
+        memset(&g, 0, sizeof(g));
+        g.G = c->G; g.T = c->T; g.zsum = a.zsum; g.y_latent = y_latent; g.timg = c->packed[PL_TAG]; g.d_ylat = d_ylat_out;
+        g.part = a.part; g.n_acc = c->n_acc[TM_AG]; g.n_vec = c->n_vec[TM_AG];
+        const int gg = tt_grid(c->G);
+        k_as_g<<<gg, 256, 0, st>>>(g);
+        tt_reduce(c, TM_AG, g.part, gg * 4, grad_blob, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
 }
 
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
@@ -6130,6 +6370,47 @@ int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int3
     a.s = s_rows; a.A_edges = a_edges; a.tlatent = tlatent; a.tl_stride = tl_stride; a.tl_col = tl_col;
     a.tpick = tpick; a.ipick = ipick; a.phase = phase_label; a.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS]; a.out = out;
     k_lslc<<<tl_blocks(n_picks, c->num_cu * 4), 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+// Backward of genie_lslc_fwd (training; k_lslc_bwd): d_out [n_picks, 15] -> gradients of the head's fc1 / fc2 / PReLU slopes ADDED into
+// grad_blob (weight-mirror layout; the caller zeroes it once for both heads), the gradient of every gathered s row in erow
+// [n_picks * 10][32] and its product node in etgt [n_picks * 10] (-1: edge dropped by the 2-eps filter). genie_seg_rows then adds the
+// rows to d s [P, 30] per product node in the order of `order` (edges sorted by etgt, stable): deterministic.
+size_t genie_lslc_bwd_part_floats(int n_picks) { return tt_part_floats(8, 3, tt_grid(std::max(1, n_picks))); }
+
+int genie_lslc_bwd(genie_ctx* c, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
+                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
+                   const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt, float* part_scratch,
+                   float* grad_blob, void* stream) {
+    if (!c || !s_rows || !a_edges || !tlatent || !tpick || !ipick || !phase_label || !d_out || !erow || !etgt || !part_scratch || !grad_blob)
+        return fail(GENIE_ERR_ARG, "genie_lslc_bwd: null argument");
+    if (phase_head < 0 || phase_head > 1 || l_dt < 1 || n_edges < LS_K || !(dt > 0.f) || !(eps > 0.f) || tl_stride < 1 || tl_col < 0 || tl_col >= tl_stride ||
+        n_picks < 1)
+        return fail(GENIE_ERR_ARG, "genie_lslc_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
+    LbArgs b;
+    memset(&b, 0, sizeof(b));
+    b.f.n_picks = n_picks; b.f.l_dt = l_dt; b.f.n_edges = n_edges; b.f.t0 = t0; b.f.dt = dt; b.f.eps = eps;
+    b.f.s = s_rows; b.f.A_edges = a_edges; b.f.tlatent = tlatent; b.f.tl_stride = tl_stride; b.f.tl_col = tl_col;
+    b.f.tpick = tpick; b.f.ipick = ipick; b.f.phase = phase_label; b.f.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS];
+    b.timg = c->packed[phase_head == 0 ? PL_TLSP : PL_TLSS];
+    b.d_out = d_out; b.erow = erow; b.etgt = etgt;
+    const int tm = phase_head == 0 ? TM_LSP : TM_LSS;
+    b.part = part_scratch; b.n_acc = c->n_acc[tm]; b.n_vec = c->n_vec[tm];
+    const int grid = tt_grid(n_picks);
+    k_lslc_bwd<<<grid, 256, 0, st>>>(b);
+    tt_reduce(c, tm, b.part, grid * 4, grad_blob, st);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_seg_rows(const float* erow, const int32_t* etgt, const int32_t* order, int64_t n_edges, float* ds, void* stream) {
+    if (!erow || !etgt || !order || !ds || n_edges < 0) return fail(GENIE_ERR_ARG, "genie_seg_rows: bad argument");
+    if (n_edges == 0) return GENIE_OK;
+    k_seg_rows<<<(unsigned)((n_edges * 8 + 255) / 256), 256, 0, (hipStream_t)stream>>>(erow, etgt, order, n_edges, ds);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

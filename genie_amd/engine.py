@@ -674,6 +674,38 @@ class HipPath(object):
                                             _ptr(out), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_fwd")
         return out
 
+    def assoc_train_fwd(self, y_latent, mask_src, x_latent, Mask, edge_attr):
+        """Training forward of the P-sized association heads (genie_assoc_train_fwd): as `assoc_fwd`, returns (s [P, 30], asave)."""
+        if not getattr(self, "assoc_ready", False):
+            raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
+        P = self.n_prod
+        y_latent = _f32(y_latent, "y_latent", (self.n_grid, 30))
+        mask_src = _f32(mask_src, "mask_src").reshape(-1)
+        x_latent, Mask, edge_attr = _f32(x_latent, "x_latent", (P, 30)), _f32(Mask, "Mask", (P, 4)), _f32(edge_attr, "edge_attr", (P, 3))
+        need = int(self.lib.genie_assoc_workspace_bytes(self.ctx))
+        if getattr(self, "_assoc_ws", None) is None or self._assoc_ws.numel() * 4 < need:
+            self._assoc_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        asave = torch.empty(int(self.lib.genie_assoc_train_save_floats(self.ctx)), dtype=torch.float32, device=self.device)
+        out = torch.empty((P, 30), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_assoc_train_fwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
+                                                  _ptr(out), _ptr(asave), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_train_fwd")
+        return out, asave
+
+    def assoc_train_bwd(self, y_latent, mask_src, x_latent, Mask, edge_attr, asave, d_s):
+        """Backward of `assoc_train_fwd` (genie_assoc_train_bwd): d_s [P, 30] -> (d_y_latent [G, 30], dict parameter name -> gradient)."""
+        P, G = self.n_prod, self.n_grid
+        d_s = _f32(d_s, "d_s", (P, 30))
+        mask_src = _f32(mask_src, "mask_src").reshape(-1)
+        need = int(self.lib.genie_assoc_train_scratch_floats(self.ctx))
+        if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need:
+            self._train_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        d_ylat = torch.empty((G, 30), dtype=torch.float32, device=self.device)
+        blob = torch.empty(self._blob.numel(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_assoc_train_bwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
+                                                  _ptr(asave), _ptr(d_s), _ptr(self._train_scratch), _ptr(d_ylat), _ptr(blob), _stream()),
+                   "genie_assoc_train_bwd")
+        return d_ylat, {name: blob[off:off + n] for name, n, off in zip(self.w_names, self.w_numel, self.w_off)}
+
     def lslc_fwd(self, head, s_rows, a_edges, dt_partition, tpick, ipick, phase_label, tlatent, col, eps):
         """LocalSliceLgCollapse P (head 0) / S (head 1), module.py:610-659, in HIP (genie_lslc_fwd): s_rows [P, 30], a_edges int32
         [n_sta * l_dt * 10] time-pointer table, dt_partition [l_dt], tpick / phase_label fp32 [n], ipick int32 [n], tlatent
@@ -703,6 +735,33 @@ class HipPath(object):
                                            t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
                                            _ptr(phase_label), n, _ptr(out), _stream()), "genie_lslc_fwd")
         return out
+
+    def lslc_bwd(self, s_rows, a_edges_ps, dt_partition, tpick, ipick, phase_label, tlatent, eps, d_p, d_s):
+        """Backward of the two `lslc_fwd` heads of a training step (genie_lslc_bwd + genie_seg_rows): d_p / d_s [n, 15] (None = zero) ->
+        (d_s_rows [P, 30], dict parameter name -> gradient). The edge sort by product node is index plumbing (torch.sort, stable)."""
+        s_rows = _f32(s_rows, "s_rows", (self.n_prod, 30))
+        tpick = _f32(tpick, "tpick").reshape(-1)
+        n = int(tpick.numel())
+        phase_label = _f32(phase_label, "phase_label").reshape(-1)
+        tlatent = _f32(tlatent, "tlatent")
+        t0, dt = float(dt_partition[0]), float(dt_partition[1] - dt_partition[0])
+        dev = self.device
+        ds = torch.zeros((self.n_prod, 30), dtype=torch.float32, device=dev)
+        blob = torch.zeros(self._blob.numel(), dtype=torch.float32, device=dev)
+        part = torch.empty(int(self.lib.genie_lslc_bwd_part_floats(n)), dtype=torch.float32, device=dev)
+        for head, d_out in ((0, d_p), (1, d_s)):
+            if d_out is None or n == 0:
+                continue
+            d_out = _f32(d_out, "d_out", (n, 15))
+            a_edges = a_edges_ps[head]
+            erow = torch.empty((n * 10, 32), dtype=torch.float32, device=dev)
+            etgt = torch.empty(n * 10, dtype=torch.int32, device=dev)
+            _lib.check(self.lib.genie_lslc_bwd(self.ctx, head, _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)), t0, dt,
+                                               float(eps), _ptr(tlatent), int(tlatent.shape[1]), head, _ptr(tpick), _ptr(ipick), _ptr(phase_label),
+                                               n, _ptr(d_out), _ptr(erow), _ptr(etgt), _ptr(part), _ptr(blob), _stream()), "genie_lslc_bwd")
+            order = torch.sort(etgt, stable=True)[1].to(torch.int32)
+            _lib.check(self.lib.genie_seg_rows(_ptr(erow), _ptr(etgt), _ptr(order), n * 10, _ptr(ds), _stream()), "genie_seg_rows")
+        return ds, {name: blob[off:off + k] for name, k, off in zip(self.w_names, self.w_numel, self.w_off)}
 
     def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps):
         """StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd): stime [n_src], src_embed

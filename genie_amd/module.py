@@ -113,6 +113,63 @@ class _PathTrain(torch.autograd.Function):
         return (None,) * 9 + tuple(g[n].view(s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
 
 
+TRAIN_ASSOC_PARAMS = tuple(
+    ["BipartiteGraphReadOutOperator.%s" % n for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "activate1.weight", "activate2.weight")]
+    + ["DataAggregationAssociationPhase.%s.%s" % (l, k) for l in ("init_trns", "l1_t1_1", "l1_t2_1", "l1_t1_2", "l1_t2_2", "l2_t1_1", "l2_t2_1",
+                                                                 "l2_t1_2", "l2_t2_2") for k in ("weight", "bias")]
+    + ["DataAggregationAssociationPhase.%s.weight" % a for a in ("activate", "activate11", "activate12", "activate1", "activate21", "activate22",
+                                                                "activate2")])
+
+
+class _AssocTrain(torch.autograd.Function):
+    """The P-sized association heads of a training step (BipartiteGraphReadOutOperator + DataAggregationAssociationPhase,
+    module.py:986-990) in HIP in both directions: forward = genie_assoc_train_fwd (the inference kernels, pre-activations kept),
+    backward = genie_assoc_train_bwd. Differentiable inputs: y_latent and the parameters (order TRAIN_ASSOC_PARAMS; values read from
+    the library's weight mirror); x_latent arrives detached (module.py:990), the masks carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, y_latent, mask_src, x_latent, Mask, edge_attr, hip, *params):
+        s, asave = hip.assoc_train_fwd(y_latent, mask_src, x_latent, Mask, edge_attr)
+        ctx.hip = hip
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(y_latent, mask_src, x_latent, Mask, edge_attr, asave)
+        return s
+
+    @staticmethod
+    def backward(ctx, d_s):
+        y_latent, mask_src, x_latent, Mask, edge_attr, asave = ctx.saved_tensors
+        d_ylat, g = ctx.hip.assoc_train_bwd(y_latent, mask_src, x_latent, Mask, edge_attr, asave, d_s.contiguous())
+        return (d_ylat, None, None, None, None, None) + tuple(g[n].view(sh) for n, sh in zip(TRAIN_ASSOC_PARAMS, ctx.shapes))
+
+
+TRAIN_LSLC_PARAMS = tuple("LocalSliceLgCollapse%s.%s" % (h, n) for h in ("P", "S")
+                           for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "activate1.weight", "activate2.weight"))
+
+
+class _LslcTrain(torch.autograd.Function):
+    """LocalSliceLgCollapse P and S (module.py:610-659, :991-992) of a training step in HIP in both directions: forward = the
+    inference kernel (genie_lslc_fwd), backward = genie_lslc_bwd (forward recomputed per tile) + genie_seg_rows (the gathered rows'
+    gradients summed per product node in a fixed order). Differentiable inputs: the association embedding s [P, 30] and the two
+    heads' parameters (order TRAIN_LSLC_PARAMS)."""
+
+    @staticmethod
+    def forward(ctx, s, a_edges_p, a_edges_s, dt_partition, tpick, ipick32, phase_label, tlatent, eps, hip, *params):
+        arv_p = hip.lslc_fwd(0, s, a_edges_p, dt_partition, tpick, ipick32, phase_label, tlatent, 0, eps)
+        arv_s = hip.lslc_fwd(1, s, a_edges_s, dt_partition, tpick, ipick32, phase_label, tlatent, 1, eps)
+        ctx.hip, ctx.eps, ctx.dt_partition = hip, eps, dt_partition
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(s, a_edges_p, a_edges_s, tpick, ipick32, phase_label, tlatent)
+        ctx.set_materialize_grads(False)
+        return arv_p, arv_s
+
+    @staticmethod
+    def backward(ctx, d_p, d_s):
+        s, a_edges_p, a_edges_s, tpick, ipick32, phase_label, tlatent = ctx.saved_tensors
+        ds_rows, g = ctx.hip.lslc_bwd(s, (a_edges_p, a_edges_s), ctx.dt_partition, tpick, ipick32, phase_label, tlatent, ctx.eps,
+                                      d_p.contiguous() if d_p is not None else None, d_s.contiguous() if d_s is not None else None)
+        return (ds_rows,) + (None,) * 9 + tuple(g[n].view(sh) for n, sh in zip(TRAIN_LSLC_PARAMS, ctx.shapes))
+
+
 def _scatter_mean_rows(msg, index, n):
     out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device).index_add_(0, index, msg)
     cnt = torch.zeros(n, dtype=msg.dtype, device=msg.device).index_add_(0, index, torch.ones_like(index, dtype=msg.dtype))
@@ -517,14 +574,35 @@ class DataAggregationAssociationPhase(nn.Module):
                                          self.l2_t2_2(torch.cat((tr, b2, mask), dim=1))), dim=1))
 
 
+class _Gather(torch.autograd.Function):
+    """x[idx] whose backward is one index_add_ (atomic adds) instead of PyTorch's sort-based index_put: the arrival-association head
+    gathers every pick's rows ~80 times over (pick pairs x sources), where the sort-based kernel took 38 of the 70 ms of a config-3
+    training step. Used only by the one head whose backward still runs under autograd (StationSourceAttentionMergedPhases)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.n = x.shape[0]
+        ctx.save_for_backward(idx)
+        return x[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device).index_add_(0, idx, g.contiguous()), None
+
+
+def _gather(x, idx):
+    return _Gather.apply(x, idx) if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else x[idx]
+
+
 def _segment_softmax(src, index, n):
     """torch_geometric.utils.softmax semantics: per-segment max subtraction, exp, / (sum + 1e-16)."""
     idx = index.view(-1, 1).expand_as(src)
     mx = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype, device=src.device).scatter_reduce(
         0, idx, src, reduce="amax", include_self=True)
-    out = (src - mx[index]).exp()
+    out = (src - _gather(mx, index)).exp()
     den = torch.zeros((n, src.shape[1]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
-    return out / (den[index] + 1e-16)
+    return out / (_gather(den, index) + 1e-16)
 
 
 class LocalSliceLgCollapse(nn.Module):
@@ -620,11 +698,12 @@ class StationSourceAttentionMergedPhases(nn.Module):
         fs = torch.cat((torch.exp(-0.5 * rs ** 2 / eps ** 2), torch.sign(rs), phase[e0]), dim=1)
         self_link = (e0 == torch.remainder(e1, e0max)).view(-1, 1).to(dt_)
         null_link = (e0 == e0max).view(-1, 1).to(dt_)
-        x_j = arrival[e0]
-        ctx = self.f_src_context_2(self.activate1(self.f_src_context_1(
-            torch.cat((src_embed[sidx], stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
-        qry = self.f_arrival_query_2(self.activate2(self.f_arrival_query_1(torch.cat((x_j, fp, fs), dim=1)))).view(-1, H, L)
-        val = self.f_values_2(self.activate3(self.f_values_1(torch.cat((x_j, fp, fs, self_link, null_link), dim=1)))).view(-1, H, L)
+        x_j = _gather(arrival, e0)
+        d = lambda lin, x: _dense(lin, x, self)       # (weight gradients of the edge-sized Linears by genie_linear_bwd_wb under autograd)
+        ctx = d(self.f_src_context_2, self.activate1(d(self.f_src_context_1,
+            torch.cat((_gather(src_embed, sidx), stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
+        qry = d(self.f_arrival_query_2, self.activate2(d(self.f_arrival_query_1, torch.cat((x_j, fp, fs), dim=1)))).view(-1, H, L)
+        val = d(self.f_values_2, self.activate3(d(self.f_values_1, torch.cat((x_j, fp, fs, self_link, null_link), dim=1)))).view(-1, H, L)
         alpha = _segment_softmax((qry * ctx).sum(-1) / math.sqrt(L), e1, n_arv * n_src)
         agg = torch.zeros((n_arv * n_src, H, L), dtype=dt_, device=dev).index_add_(0, e1, alpha.unsqueeze(-1) * val)
         return self.proj_2(self.activate4(self.proj_1(agg.mean(1)))).view(n_src, n_arv, -1)
@@ -674,8 +753,7 @@ class GCN_Detection_Network_extended(nn.Module):
 
     def _share_engine(self):
         # the G- / Q-sized heads take their Linear weight gradients from the HIP library in training steps (`_dense`)
-        for m in (self.SpatialAggregation1, self.SpatialAggregation2, self.SpatialAggregation3, self.SpatialAttention,
-                  self.TemporalAttention):
+        for m in (self.SpatialAttention, self.TemporalAttention, self.Arrivals):
             m._hip = self._hip
 
     # ---- graphs --------------------------------------------------------------------------------
@@ -924,14 +1002,18 @@ class GCN_Detection_Network_extended(nn.Module):
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
         Maskf = _engine._f32(Mask, "Mask")
         if not self._differentiable() and getattr(self._hip, "assoc_ready", False):
-            # :986-990 as three P-sized HIP passes (genie_assoc_fwd); the PyTorch-ROCm restatement below serves training steps
+            # :986-990 as three P-sized HIP passes (genie_assoc_fwd)
             s = self._hip.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
-        else:
+        elif self._differentiable() and getattr(self._hip, "assoc_ready", False) and y_latent.is_cuda:
+            # training step: the same kernels with their pre-activations kept, backward in HIP (`_AssocTrain`)
+            s = _AssocTrain.apply(y_latent, mask_out, x_latent.detach(), Maskf, self._edge_attr, self._hip,
+                                  *[self._path_params[n] for n in TRAIN_ASSOC_PARAMS])
+        else:       # CPU restatement (tests) / contexts without association-head weights
             s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
             s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
                                                      hip=self._hip)                                  # :990
         tl = self.tlatent
-        if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
+        if getattr(self._hip, "assoc_ready", False) and len(tpick) > 0 and s.is_cuda:
             # :991-992 in HIP (genie_lslc_fwd); the int32 copies of the static time-pointer tables are cached with the tables
             key = (self.A_edges_p.data_ptr(), self.A_edges_s.data_ptr(), self.A_edges_p._version, self.A_edges_s._version)
             if getattr(self, "_a_edges_key", None) != key:
@@ -940,8 +1022,13 @@ class GCN_Detection_Network_extended(nn.Module):
                 self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
             ip32 = ipick.to(torch.int32)
             eps = self.LocalSliceLgCollapseP.eps
-            arv_p = self._hip.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
-            arv_s = self._hip.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
+            if self._differentiable():      # training step: the same kernels, backward in HIP (`_LslcTrain`)
+                arv_p, arv_s = _LslcTrain.apply(s, self._a_edges_i32[0], self._a_edges_i32[1], self.dt_partition, _engine._f32(tpick, "tpick"),
+                                                ip32, _engine._f32(phase_label, "phase_label"), _engine._f32(tl, "tlatent"), eps, self._hip,
+                                                *[self._path_params[n] for n in TRAIN_LSLC_PARAMS])
+            else:
+                arv_p = self._hip.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
+                arv_s = self._hip.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
         else:
             arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
             arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))

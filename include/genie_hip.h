@@ -355,6 +355,22 @@ int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
               int32_t* out_idx, void* stream);
 
+/* Training step of the P-sized association heads (round 3; module.py:986-990 inside train_GENIE_model.py:1786-1861):
+ *   genie_assoc_train_fwd = genie_assoc_fwd in the caller's station order with the pre-activations of every layer kept in `asave`
+ *     (genie_assoc_train_save_floats(ctx) floats: 20 blocks of 16 floats per product node);
+ *   genie_assoc_train_bwd: d_s [P, 30] (gradient of the head's output) -> d_ylat_out [n_grid, 30] (gradient of y_latent; x_latent is
+ *     detached at module.py:990) and grad_blob (genie_weights_blob_floats() floats, zeroed by the call, weight-mirror layout): gradients of
+ *     every BipartiteGraphReadOutOperator / DataAggregationAssociationPhase parameter. Four P-sized passes (k_as_b3, k_train_b1<true>,
+ *     k_as_b1, k_as_b0: the structure of DataAggregation's backward) + one G-sized (k_as_g); `scratch`:
+ *     genie_assoc_train_scratch_floats(ctx) floats. Deterministic. Unsharded Cartesian product graphs, default model definition. */
+size_t genie_assoc_train_save_floats(const genie_ctx* ctx);
+size_t genie_assoc_train_scratch_floats(const genie_ctx* ctx);
+int genie_assoc_train_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                          const float* edge_attr, float* out, float* asave, void* assoc_ws, void* ws, void* stream);
+int genie_assoc_train_bwd(genie_ctx* ctx, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
+                          const float* edge_attr, const float* asave, const float* d_s, float* scratch, float* d_ylat_out,
+                          float* grad_blob, void* stream);
+
 /* LocalSliceLgCollapse P (phase_head 0) / S (1), module.py:610-659, on the device: for every pick the 10 product nodes listed in the
  * time-pointer table a_edges [n_sta * l_dt * 10] (int32 product-node ids, `assemble_time_pointers_for_stations`, utils.py:602-622)
  * at (ipick, floor((tpick - t0) / dt)), those with |tpick - tlatent[e * tl_stride + tl_col]| < 2 eps kept, edge MLP on the rows of
@@ -363,6 +379,18 @@ int genie_knn(const float* x_context, int n_context, const float* x_query, int n
 int genie_lslc_fwd(genie_ctx* ctx, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
                    float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
                    const float* phase_label, int n_picks, float* out, void* stream);
+
+/* Backward of genie_lslc_fwd for training steps (round 3; k_lslc_bwd, forward recomputed per tile): d_out [n_picks, 15] -> the head's
+ * fc1 / fc2 / PReLU-slope gradients ADDED into grad_blob (weight-mirror layout; zero it once before the two heads), the gradient of every
+ * gathered s row in erow [n_picks * 10][32] and its product node in etgt [n_picks * 10] (-1 = dropped by the 2-eps filter, module.py:642-647).
+ * genie_seg_rows adds those rows into d_s [P, 30] per product node, in the order of `order` (the edges sorted by etgt, stable): several
+ * picks may gather the same node, and the sum must not depend on scheduling. part_scratch: genie_lslc_bwd_part_floats(n_picks) floats. */
+size_t genie_lslc_bwd_part_floats(int n_picks);
+int genie_lslc_bwd(genie_ctx* ctx, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
+                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
+                   const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt, float* part_scratch,
+                   float* grad_blob, void* stream);
+int genie_seg_rows(const float* erow, const int32_t* etgt, const int32_t* order, int64_t n_edges, float* d_s, void* stream);
 
 /* StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775; use_sparse = True, use_neighbor_assoc_edges = False) on
  * the device: out [n_src, n_arv, 2]. stime [n_src] (`tq_sample`), src_embed [n_src, 30] (`x_src`), trv_src [n_src, n_sta, 2]
