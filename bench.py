@@ -103,6 +103,10 @@ def respawn_under_torchrun(a):
     """`python bench.py --gpus N` with N > 1 outside a launcher: start N ranks of this script on this node."""
     import socket
     import subprocess
+    n_vis = torch.cuda.device_count()
+    if a.gpus > n_vis and not a.dry_run_cpu:
+        print("bench.py: --gpus %d needs %d visible GPUs, this node shows %d; nothing was launched" % (a.gpus, a.gpus, n_vis), file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -418,8 +422,7 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                                   "halo_MB_in_per_window": round(halo_bytes / 1e6, 1)}},
         "windows_per_s": round(wps, 2),
         "rank0_phase_ms_sequential": phases,
-        "one_gpu_same_config": dict(ONE_GPU_CFG4, speedup=round(ONE_GPU_CFG4["ms_per_step"] / (dt / a.steps * 1e3), 2))
-        if a.config == "cfg4_2000x50k" else None,
+        "one_gpu_same_config": None,       # N > 1: filled by main() with a live one-rank run of the same workload
         "roofline": {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                      "achieved": round(b_alg * wps / 1e9, 1), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(b_alg * wps / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None},
@@ -653,6 +656,10 @@ def main():
         a.config = "cfg4_2000x50k" if (a.mode == "sharded" and world > 1) else "cfg2_200x10k"
     dist = None
     if world > 1:
+        if local_rank >= torch.cuda.device_count():      # (under an external launcher: fail before any rendezvous can hang)
+            print("bench.py: rank %d has no GPU (WORLD_SIZE %d, %d visible GPUs): one GPU per rank is required"
+                  % (rank, world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -661,7 +668,24 @@ def main():
     S, G, n_picks, L, nq = synthetic.CONFIGS[a.config]
     geom = synthetic.Geometry(S, G, L=L, n_query=nq, seed=1)
     if a.mode == "sharded":
-        return main_sharded(a, geom, n_picks, nq, rank, world, dev, dist)
+        if world == 1:
+            return main_sharded(a, geom, n_picks, nq, rank, world, dev, dist)
+        out = main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=False)       # (destroys the process group)
+        if rank == 0:
+            # the one-GPU figure of the SAME workload, measured live on this rank after the sharded run (not a constant)
+            import copy
+            a1 = copy.copy(a)
+            a1.steps, a1.warmup, a1.no_overlap = 5, 2, False
+            torch.cuda.empty_cache()
+            try:
+                o1 = main_sharded(a1, geom, n_picks, nq, 0, 1, dev, None, emit=False)
+                out["one_gpu_same_config"] = {"ms_per_step": o1["ms_per_step"], "steps": a1.steps, "speedup": round(o1["ms_per_step"] / out["ms_per_step"], 2),
+                                              "rank0_phase_ms_sequential": o1["rank0_phase_ms_sequential"],
+                                              "source": "measured live on rank 0 after the sharded run, same code path with one rank"}
+            except Exception as e:
+                out["one_gpu_same_config"] = {"error": repr(e)[:200], "fallback": ONE_GPU_CFG4}
+            print(json.dumps(out))
+        return out
     if a.mode == "stream":
         return main_stream(a, geom, nq, rank, world, dev, dist)
     if a.mode == "train":

@@ -5421,6 +5421,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     DaArgs a = make_da_args(c, (float*)ws);
     a.gi0 = gi_begin; a.G = gi_end - gi_begin;
     a.slope2 = slope2; a.no_bip = no_bip;
+    { const char* e = getenv("GENIE_SEG2"); if (e) a.seg = std::max(1, atoi(e)); }      // EXPERIMENT (round 3): stage-2 sweep segments
     const long long n_tiles = (long long)a.G * c->T;
     if (n_tiles == 0) return GENIE_OK;
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];

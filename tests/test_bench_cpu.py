@@ -44,3 +44,17 @@ def test_bench_defaults_pick_the_sharded_config_for_several_gpus():
     src = open(os.path.join(REPO, "bench.py")).read()
     assert 'a.mode = "sharded" if world > 1 else "replicas"' in src
     assert '"cfg4_2000x50k" if (a.mode == "sharded" and world > 1) else "cfg2_200x10k"' in src
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus_instead_of_hanging():
+    """`python bench.py --gpus 8` on a node that shows fewer GPUs: a clear message and exit code 2 before anything is launched (no
+    rendezvous that could hang)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight GPUs visible")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 2 and "needs 8 visible GPUs" in r.stderr and not r.stdout.strip()
