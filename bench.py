@@ -471,8 +471,8 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     """BASELINE config 3: the training step on the config-2 shape. One step = forward_fixed_source in train() mode (the whole
     path in HIP in both directions, module._PathTrain) + the y / x terms of the reference's weighted MSE (train_GENIE_model.py:1789)
     + backward + one Adam(1e-3) step (:1861), on a synthetic window resident in HBM. N > 1: independent replicas (the reference has
-    no multi-GPU training). The reference's own 4-output step `mz(*input_tensors)` (association heads included; of them only the
-    pick-pair sized arrival head still differentiates under PyTorch-ROCm autograd) is timed next to it."""
+    no multi-GPU training). The reference's own 4-output step `mz(*input_tensors)` (association heads included, every module in HIP in
+    both directions) is timed next to it."""
     S, G = geom.n_sta, geom.n_grid
     P = S * G
     torch.manual_seed(0)
@@ -543,7 +543,7 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     pms = {k: round(float(np.median(v)), 4) for k, v in ph.items()}
     pms["fwd_tail"] = round(pms["fwd_total"] - pms["fwd_front"], 4)
     pms["adam_loss_and_host"] = round(ms - pms["fwd_total"] - pms["bwd_tail"] - pms["bwd_front"], 4)
-    # ---- the reference's 4-output step (association heads' backward under autograd), a few steps
+    # ---- the reference's 4-output step (association heads included), a few steps
     four = None
     try:
         smp = synthetic.training_sample(geom, min(n_picks, 4000), n_src=4, seed=3, window=0)
@@ -569,9 +569,9 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
             step4()
         torch.cuda.synchronize()
         four = {"ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 3), "n_picks": int(len(smp["tpick"])), "n_src": 4,
-                "note": "mz(*input_tensors) + 4-term loss + backward + Adam; shared path, BipartiteGraphReadOutOperator + "
-                        "DataAggregationAssociationPhase and LocalSliceLgCollapse P / S in HIP in both directions; the arrival-association "
-                        "head (StationSourceAttentionMergedPhases, pick-pair sized) under PyTorch-ROCm autograd"}
+                "note": "mz(*input_tensors) + 4-term loss + backward + Adam; every module in HIP in both directions: shared path (source "
+                        "queries riding along), BipartiteGraphReadOutOperator + DataAggregationAssociationPhase, LocalSliceLgCollapse P / S, "
+                        "StationSourceAttentionMergedPhases; PyTorch: the loss, Adam, index plumbing"}
     except Exception as e:
         four = {"error": repr(e)[:200]}
     flops = TRAIN_FLOP_FACTOR * (FLOP_NODE * P)

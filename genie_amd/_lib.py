@@ -71,8 +71,8 @@ SYMBOLS = [
     ("genie_tail_train_scratch_floats", _c.c_size_t, [_P, _c.c_int]),
     ("genie_train_grad_floats", _c.c_size_t, []),
     ("genie_tail_train_fwd", _c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P]),
-    ("genie_tail_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    ("genie_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P,
+    ("genie_tail_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("genie_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P]),
     ("genie_assoc_workspace_bytes", _c.c_size_t, [_P]),
     ("genie_assoc_fwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -89,6 +89,12 @@ SYMBOLS = [
     ("genie_seg_rows", _c.c_int, [_P, _P, _P, _c.c_int64, _P, _P]),
     ("genie_arrivals_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_float,
                                       _P, _P, _P, _P]),
+    ("genie_arrivals_train_save_floats", _c.c_int64, [_c.c_int, _c.c_int]),
+    ("genie_arrivals_train_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int,
+                                            _c.c_float, _P, _P, _P, _P, _P]),
+    ("genie_arrivals_bwd_scratch_floats", _c.c_int64, [_c.c_int, _c.c_int, _c.c_int]),
+    ("genie_arrivals_bwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_float,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_subgraph_csr_count", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_subgraph_csr_fill", _c.c_int, [_P, _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_row_select_count", _c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_float, _c.c_int, _P, _P]),

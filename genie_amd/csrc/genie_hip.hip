@@ -595,10 +595,10 @@ enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LS
        // transposed weights of the tail's backward passes (train_tail_kernels.hpp)
        PL_TRO0, PL_TRO1, PL_TSN, PL_TSA1, PL_TSA2, PL_TSA3, PL_TBIP,
        // ... and of the association heads' backward passes (train_assoc_kernels.hpp)
-       PL_TAB2, PL_TAB1, PL_TAB0, PL_TAG, PL_TLSP, PL_TLSS, NPLAN };
+       PL_TAB2, PL_TAB1, PL_TAB0, PL_TAG, PL_TLSP, PL_TLSS, PL_TARR, NPLAN };
 // gradient maps (k_train_reduce): the three P-sized passes, then the tail's backward kernels
 enum { TM_B2 = 0, TM_B1, TM_B0, TM_RO0, TM_RO1, TM_SN, TM_SAA1, TM_SAA2, TM_SAA3, TM_SAB1, TM_SAB2, TM_SAB3, TM_BIP,
-       TM_AB3, TM_AB2, TM_AB1, TM_AB0, TM_AG, TM_LSP, TM_LSS, NTM };
+       TM_AB3, TM_AB2, TM_AB1, TM_AB0, TM_AG, TM_LSP, TM_LSS, TM_ART, TM_ARE, NTM };
 //  read-out heads (module.py:251-331), one image per MODE with the same map. FRONT: MODE 0 = SpatialDirect.f_direct (out tile t,
 //  in block b), MODE 1 = SpatialAttention.proj (out tile t, b = 0; b = 1 unused). TemporalAttention: f_context_1 / f_values_1
 //  (t, b), f_context_2 / f_values_2 with one out tile per HEAD h (rows 15h .. 15h+14, row 15 of the tile zero), proj_1 (t)
@@ -3645,6 +3645,7 @@ __global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
 // first: rounding-order difference only), so a station may hold any number of picks.
 constexpr int AR_CAP = 192;       // picks of a station (null included) per LDS chunk
 constexpr int AR_ENT = 104;       // floats per kept entry: scores plain [3], self [3], pad 2, values plain [3][16], self [3][16]
+constexpr int AT_STAT = 64;       // training forward, per (source, pick): normalised head aggregates [3][16], running max [3], denominator [3]
 struct ArArgs {
     int n_src, n_sta, n_arv, n_useg;
     float eps;
@@ -3660,6 +3661,7 @@ struct ArArgs {
     int* e0max;                   // [1] `edge_index[0].max()` over the kept edges (module.py:762-763), by k_arr_e0max: the pick the
                                   // reference treats as "the null pick"; = n_arv (the real null pick) whenever some source has
                                   // |stime| < 2 eps, i.e. always in practice
+    float* save;                  // training forward: [n_src * n_arv][AT_STAT] (else null)
 };
 
 // e0max = max over the kept (pick b, source i) pairs of b, the null pick (index n_arv) included (module.py:740-763). A pick's
@@ -3862,6 +3864,14 @@ __global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
             const int r = rb + j;
             const bool ok = r < L;
             const f32x4 z = ((agg[tt][0] / (den[tt][0] + 1e-16f) + agg[tt][1] / (den[tt][1] + 1e-16f)) + agg[tt][2] / (den[tt][2] + 1e-16f)) / 3.f;
+            if (a.save && ok) {
+                float* sv = a.save + ((long long)i * a.n_arv + a.order[r0 + r]) * AT_STAT;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    *(f32x4*)(sv + 16 * h + 4 * q) = agg[tt][h] / (den[tt][h] + 1e-16f);
+                    if (q == 0) { sv[48 + h] = mx[tt][h]; sv[51 + h] = den[tt][h]; }
+                }
+            }
             f32x4 pa = prelu4(mma_block(tl_bias(im, 10, q), TLW(im, GA_P1(0)), z), act4);
             f32x4 pb = prelu4(mma_block(tl_bias(im, 11, q), TLW(im, GA_P1(1)), z), act4);
 #pragma unroll
@@ -4387,6 +4397,7 @@ __global__ void k_permute_sta_rows(const float* __restrict__ src, long long rows
 
 #include "train_tail_kernels.hpp"
 #include "train_assoc_kernels.hpp"
+#include "train_arrival_kernels.hpp"
 
 }  // namespace
 
@@ -4740,6 +4751,17 @@ void build_tail_train_plans(StagePlan* plan) {
             for (int t = 0; t < 2; ++t) add_block_group_T(p, W_RO_FC1_W, 33, 16 * b, rows2(b), 16 * t, rows2(t));
         p.scal.push_back(g_params[W_RO_ACT1].off);
     }
+    {
+        StagePlan& p = plan[PL_TARR];             // the arrival head's transposed blocks (GTA_*)
+        for (int t = 0; t < 2; ++t) add_block_group_T(p, W_AR_P1_W, 15, 0, 15, 16 * t, rows2(t));
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < 2; ++b)
+                for (int h = 0; h < 3; ++h) add_block_group_T(p, m == 0 ? W_AR_V2_W : W_AR_Q2_W, 30, 16 * b, rows2(b), 15 * h, 15);
+        for (int m = 0; m < 2; ++m)
+            for (int s = 0; s < 2; ++s)
+                for (int t = 0; t < 2; ++t) add_block_group_T(p, m == 0 ? W_AR_V1_W : W_AR_Q1_W, m == 0 ? 38 : 36, 15 * s, 15, 16 * t, rows2(t));
+        p.scal.push_back(g_params[W_AR_ACT4].off);
+    }
 }
 
 // gradient maps of the tail's backward kernels (accumulator / vector / scalar k of kernel TM_* -> entries of the gradient blob;
@@ -4888,8 +4910,33 @@ int build_tail_grad_maps(genie_ctx* c) {
         V(tm, O(base + 3), 0, 15);
         sc[tm] = {O(base + 4), O(base + 5)};
     }
-    const int want_acc[NTM] = {0, 0, 0, RB_NACC0, RB_NACC1, GTN_GROUPS, SBA_NACC, SBA_NACC, SBA_NACC, SBB_NACC, SBB_NACC, SBB_NACC, 2, 0, 30, 28, 12, 4, 8, 8};
-    const int want_vec[NTM] = {0, 0, 0, RB_NVEC, RB_NVEC, 10, SBA_NVEC, SBA_NVEC, SBA_NVEC, SBB_NVEC, SBB_NVEC, SBB_NVEC, 1, 0, 8, 12, 7, 0, 3, 3};
+    {   // the arrival head: k_arrt_tgt_bwd (proj_1, proj_2), k_arrt_ent_bwd (the query / value edge MLPs; 3 context tiles it sums itself)
+        for (int t = 0; t < 2; ++t) A(TM_ART, O(W_AR_P1_W), 15, 16 * t, rows2(t), 0, 15);
+        for (int t = 0; t < 2; ++t) V(TM_ART, O(W_AR_P1_B), 16 * t, rows2(t));
+        for (int m = 0; m < 2; ++m)
+            for (int t = 0; t < 2; ++t) V(TM_ART, O(W_AR_P2_W), 30 * m + 16 * t, rows2(t));
+        sc[TM_ART] = {O(W_AR_ACT4), O(W_AR_P2_B), O(W_AR_P2_B) + 1};
+        for (int m = 0; m < 2; ++m) {
+            const int mat = m == 0 ? W_AR_Q1_W : W_AR_V1_W, ld = m == 0 ? 36 : 38;
+            for (int t = 0; t < 2; ++t) {
+                A(TM_ARE, O(mat), ld, 16 * t, rows2(t), 0, 15);
+                A(TM_ARE, O(mat), ld, 16 * t, rows2(t), 15, 15);
+                A(TM_ARE, O(mat), ld, 16 * t, rows2(t), 30, m == 0 ? 6 : 8);
+            }
+        }
+        for (int m = 0; m < 2; ++m)
+            for (int h = 0; h < 3; ++h)
+                for (int b = 0; b < 2; ++b) A(TM_ARE, O(m == 0 ? W_AR_Q2_W : W_AR_V2_W), 30, 15 * h, 15, 16 * b, rows2(b));
+        for (int t = 0; t < 2; ++t) V(TM_ARE, O(W_AR_Q1_B), 16 * t, rows2(t));
+        for (int t = 0; t < 2; ++t) V(TM_ARE, O(W_AR_V1_B), 16 * t, rows2(t));
+        for (int h = 0; h < 3; ++h) V(TM_ARE, O(W_AR_Q2_B), 15 * h, 15);
+        for (int h = 0; h < 3; ++h) V(TM_ARE, O(W_AR_V2_B), 15 * h, 15);
+        sc[TM_ARE] = {O(W_AR_ACT2), O(W_AR_ACT3)};
+    }
+    const int want_acc[NTM] = {0, 0, 0, RB_NACC0, RB_NACC1, GTN_GROUPS, SBA_NACC, SBA_NACC, SBA_NACC, SBB_NACC, SBB_NACC, SBB_NACC, 2, 0, 30, 28, 12, 4, 8, 8,
+                               AT_NACC, AE_NACC};
+    const int want_vec[NTM] = {0, 0, 0, RB_NVEC, RB_NVEC, 10, SBA_NVEC, SBA_NVEC, SBA_NVEC, SBB_NVEC, SBB_NVEC, SBB_NVEC, 1, 0, 8, 12, 7, 0, 3, 3,
+                               AT_NVEC, AE_NVEC};
     for (int s = TM_RO0; s < NTM; ++s) {
         if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s] || sc[s].size() > 16)
             return fail(GENIE_ERR_STATE, "internal: tail gradient maps do not match the backward kernels");
@@ -4990,7 +5037,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     if (c->plan[PL_TRO0].n_groups() != GTR_GROUPS || c->plan[PL_TRO1].n_groups() != GTR_GROUPS || c->plan[PL_TSN].n_groups() != GTN_GROUPS ||
         c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS ||
         c->plan[PL_TAB2].n_groups() != GT1_GROUPS || c->plan[PL_TAB1].n_groups() != GA1_GROUPS || c->plan[PL_TAB0].n_groups() != GA0_GROUPS ||
-        c->plan[PL_TAG].n_groups() != GAG_GROUPS || c->plan[PL_TLSP].n_groups() != GLT_GROUPS || c->plan[PL_TLSS].n_groups() != GLT_GROUPS)
+        c->plan[PL_TAG].n_groups() != GAG_GROUPS || c->plan[PL_TLSP].n_groups() != GLT_GROUPS || c->plan[PL_TLSS].n_groups() != GLT_GROUPS ||
+        c->plan[PL_TARR].n_groups() != GTA_GROUPS)
         return fail(GENIE_ERR_STATE, "internal: transposed tail plan does not match kernel group maps");
     if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
         (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
@@ -6070,8 +6118,8 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
 
 int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr,
                          const int32_t* rknn_edge, int n_query, int k, const float* t_query, int n_t, const float* tsave,
-                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, float* scratch,
-                         float* d_r_out, float* grad_blob, void* stream) {
+                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, const float* d_qlat_extra,
+                         float* scratch, float* d_r_out, float* grad_blob, void* stream) {
     if (!c || !pos || !x_query || !knn || !rknn_rowptr || !rknn_edge || !t_query || !tsave || !d_y || !d_x || !scratch || !d_r_out || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: null argument");
     int rc;
@@ -6106,7 +6154,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         memset(&b, 0, sizeof(b));
         b.ro = ro; b.ro.N = b.ro.Nw = n_query; b.ro.x_grid = pos; b.ro.x_query = x_query; b.ro.knn = knn; b.ro.cv = S + L.cv;
         b.ro.img = c->packed[PL_RO1];
-        b.timg = c->packed[PL_TRO1]; b.d_out = d_x; b.eb = S + L.eb; b.dxm = S + L.dxm;
+        b.timg = c->packed[PL_TRO1]; b.d_out = d_x; b.d_lat = d_qlat_extra; b.eb = S + L.eb; b.dxm = S + L.dxm;
         b.part = S + L.part_ro; b.n_acc = c->n_acc[TM_RO1]; b.n_vec = c->n_vec[TM_RO1];
         const int grid = tt_grid(n_query);
         k_ro_bwd<1><<<grid, 256, sizeof(float) * RB_LDS_FLOATS, st>>>(b);
@@ -6170,9 +6218,10 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
 int genie_train_bwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save, const float* pos,
                     const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr, const int32_t* rknn_edge, int n_query, int k,
                     const float* t_query, int n_t, const float* tsave, const float* d_y, const float* d_x, const float* d_xs_extra,
-                    const float* d_ylat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch, float* grad_blob, void* stream) {
+                    const float* d_ylat_extra, const float* d_qlat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch,
+                    float* grad_blob, void* stream) {
     int rc = genie_tail_train_bwd(c, pos, x_query, knn, rknn_rowptr, rknn_edge, n_query, k, t_query, n_t, tsave, d_y, d_x, d_xs_extra,
-                                  d_ylat_extra, tail_scratch, d_r_scratch, grad_blob, stream);
+                                  d_ylat_extra, d_qlat_extra, tail_scratch, d_r_scratch, grad_blob, stream);
     if (rc) return rc;
     return da_train_bwd_impl(c, slice, mask, edge_attr, save, d_r_scratch, front_scratch, grad_blob, stream, false);
 }
@@ -6416,29 +6465,113 @@ int genie_seg_rows(const float* erow, const int32_t* etgt, const int32_t* order,
     return GENIE_OK;
 }
 
-int genie_arrivals_fwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
-                       const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
-                       const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
-                       float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, void* stream) {
+namespace {
+static int arrivals_fwd_impl(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                      const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                      const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                      float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, float* save, hipStream_t st, ArArgs* a_out) {
     if (!c || !stime || !src_embed || !trv_src || !arrival_p || !arrival_s || !tpick || !phase_label || !order || !seg_sta || !seg_start ||
-        !seg_len || !ctx_scratch || !e0max_scratch || !out)
-        return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: null argument");
-    if (n_src < 1 || n_sta < 1 || n_arv < 1 || n_useg < 1 || !(eps > 0.f)) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: bad argument");
-    if ((long long)n_src * n_useg > 0x7fffffffLL) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: too many (source, station) pairs");
-    hipStream_t st = (hipStream_t)stream;
+        !seg_len || !ctx_scratch || !e0max_scratch)
+        return fail(GENIE_ERR_ARG, "genie_arrivals: null argument");
+    if (n_src < 1 || n_sta < 1 || n_arv < 1 || n_useg < 1 || !(eps > 0.f)) return fail(GENIE_ERR_ARG, "genie_arrivals: bad argument");
+    if ((long long)n_src * n_useg > 0x7fffffffLL || (long long)n_src * n_arv > 0x7fffffffLL)
+        return fail(GENIE_ERR_ARG, "genie_arrivals: too many (source, station) or (source, pick) pairs");
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
-    k_arr_ctx<<<n_src, 128, 0, st>>>(c->raw, g_params[W_AR_C1_W].off, g_params[W_AR_C1_B].off, g_params[W_AR_C2_W].off, g_params[W_AR_C2_B].off,
-                                     g_params[W_AR_ACT1].off, src_embed, stime, n_src, ctx_scratch);
     ArArgs a;
     memset(&a, 0, sizeof(a));
     a.n_src = n_src; a.n_sta = n_sta; a.n_arv = n_arv; a.n_useg = n_useg; a.eps = eps;
     a.stime = stime; a.trv_src = trv_src; a.ctx = ctx_scratch; a.arv_p = arrival_p; a.arv_s = arrival_s; a.tpick = tpick; a.phase = phase_label;
     a.order = order; a.seg_sta = seg_sta; a.seg_start = seg_start; a.seg_len = seg_len; a.img = c->packed[PL_ARR]; a.out = out; a.e0max = e0max_scratch;
+    a.save = save;
+    if (a_out) { *a_out = a; return GENIE_OK; }        // the backward: ctx / e0max of the forward are still in the caller's scratch
+    k_arr_ctx<<<n_src, 128, 0, st>>>(c->raw, g_params[W_AR_C1_W].off, g_params[W_AR_C1_B].off, g_params[W_AR_C2_W].off, g_params[W_AR_C2_B].off,
+                                     g_params[W_AR_ACT1].off, src_embed, stime, n_src, ctx_scratch);
     HIP_TRY(hipMemsetAsync(e0max_scratch, 0xff, sizeof(int32_t), st));       // -1
     k_arr_e0max<<<n_src * n_useg, 256, 0, st>>>(a);
     const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + AR_CAP * AR_ENT + 2 * AR_CAP + 192 + 8);
     HIP_TRY(hipFuncSetAttribute((const void*)k_arrivals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_arrivals<<<n_src * n_useg, 256, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+constexpr int ARRT_GRID = 512;        // workgroups of the two backward passes (each wave owns one partial slot)
+inline size_t arrt_stride(int n_acc, int n_vec) { return (size_t)n_acc * 256 + (size_t)n_vec * 16 + 16; }
+}  // namespace
+
+int genie_arrivals_fwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                       const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                       const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                       float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, void* stream) {
+    if (!out) return fail(GENIE_ERR_ARG, "genie_arrivals_fwd: null argument");
+    return arrivals_fwd_impl(c, n_src, stime, src_embed, trv_src, n_sta, arrival_p, arrival_s, tpick, phase_label, n_arv, order, seg_sta,
+                             seg_start, seg_len, n_useg, eps, ctx_scratch, e0max_scratch, out, nullptr, (hipStream_t)stream, nullptr);
+}
+
+int64_t genie_arrivals_train_save_floats(int n_src, int n_arv) { return (int64_t)n_src * n_arv * AT_STAT; }
+
+int genie_arrivals_train_fwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                             const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                             const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                             float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, float* save, void* stream) {
+    if (!out || !save) return fail(GENIE_ERR_ARG, "genie_arrivals_train_fwd: null argument");
+    return arrivals_fwd_impl(c, n_src, stime, src_embed, trv_src, n_sta, arrival_p, arrival_s, tpick, phase_label, n_arv, order, seg_sta,
+                             seg_start, seg_len, n_useg, eps, ctx_scratch, e0max_scratch, out, save, (hipStream_t)stream, nullptr);
+}
+
+int64_t genie_arrivals_bwd_scratch_floats(int n_src, int n_arv, int n_useg) {
+    if (n_src < 1 || n_arv < 1 || n_useg < 1) return 0;
+    const int64_t tgt = (int64_t)n_src * n_arv;
+    return tgt * AT_TG + tgt * 32 + (int64_t)n_src * n_useg * 192 + (int64_t)n_src * AC_STRIDE +
+           (int64_t)ARRT_GRID * 4 * (int64_t)std::max(arrt_stride(AT_NACC, AT_NVEC), arrt_stride(AE_NACC, AE_NVEC));
+}
+
+int genie_arrivals_bwd(genie_ctx* c, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                       const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                       const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                       float eps, const float* ctx_scratch, const int32_t* e0max_scratch, const float* save, const float* d_out,
+                       float* scratch, float* d_src_embed, float* d_arrival_p, float* d_arrival_s, float* grad_blob, void* stream) {
+    if (!save || !d_out || !scratch || !d_src_embed || !d_arrival_p || !d_arrival_s || !grad_blob)
+        return fail(GENIE_ERR_ARG, "genie_arrivals_bwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    ArArgs a;
+    { int rc = arrivals_fwd_impl(c, n_src, stime, src_embed, trv_src, n_sta, arrival_p, arrival_s, tpick, phase_label, n_arv, order, seg_sta,
+                                 seg_start, seg_len, n_useg, eps, (float*)ctx_scratch, (int32_t*)e0max_scratch, nullptr, nullptr, st, &a);
+      if (rc) return rc; }
+    const long long n_tgt = (long long)n_src * n_arv;
+    float* tg = scratch;
+    float* darv = tg + n_tgt * AT_TG;
+    float* cpair = darv + n_tgt * 32;
+    float* cpart = cpair + (long long)n_src * n_useg * 192;
+    float* part = cpart + (long long)n_src * AC_STRIDE;
+    {
+        AtArgs b;
+        memset(&b, 0, sizeof(b));
+        b.n_tgt = (int)n_tgt; b.img = c->packed[PL_ARR]; b.timg = c->packed[PL_TARR]; b.tstat = save; b.d_out = d_out; b.tg = tg;
+        b.part = part; b.n_acc = c->n_acc[TM_ART]; b.n_vec = c->n_vec[TM_ART];
+        const int grid = (int)std::min<long long>(ARRT_GRID, (n_tgt + 63) / 64);
+        const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + GTA_IMG_FLOATS + 4 * 16 * 17);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_arrt_tgt_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_arrt_tgt_bwd<<<grid, 256, lds, st>>>(b);
+        int rc = tt_reduce(c, TM_ART, part, grid * 4, grad_blob, st);
+        if (rc) return rc;
+    }
+    {
+        AeArgs b;
+        memset(&b, 0, sizeof(b));
+        b.f = a; b.timg = c->packed[PL_TARR]; b.tg = tg; b.darv = darv; b.cpair = cpair;
+        b.part = part; b.n_acc = c->n_acc[TM_ARE]; b.n_vec = c->n_vec[TM_ARE];
+        const int grid = (int)std::min<long long>(ARRT_GRID, (long long)n_src * n_useg);
+        const size_t lds = sizeof(float) * (GA2_IMG_FLOATS + GTA_IMG_FLOATS + 4 * 16 * 17 + 192 + AE_TCH * AT_TG + AE_TCH + 4 * 3 * 256);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_arrt_ent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_arrt_ent_bwd<<<grid, 256, lds, st>>>(b);
+        int rc = tt_reduce(c, TM_ARE, part, grid * 4, grad_blob, st);
+        if (rc) return rc;
+    }
+    const int o1w = g_params[W_AR_C1_W].off, o1b = g_params[W_AR_C1_B].off, o2w = g_params[W_AR_C2_W].off, o2b = g_params[W_AR_C2_B].off,
+              oa1 = g_params[W_AR_ACT1].off;
+    k_arrt_ctx_bwd<<<n_src, 128, 0, st>>>(c->raw, o1w, o1b, o2w, o2b, oa1, src_embed, stime, n_src, n_useg, cpair, cpart, d_src_embed);
+    k_arrt_ctx_red<<<(AC_PARAMS + 255) / 256, 256, 0, st>>>(cpart, n_src, o1w, o1b, o2w, o2b, oa1, grad_blob);
+    k_arrt_pick_sum<<<(n_arv * 30 + 255) / 256, 256, 0, st>>>(darv, n_src, n_arv, d_arrival_p, d_arrival_s);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -128,7 +128,8 @@ struct RbArgs {
     RoArgs ro;                   // the forward's arguments (img = the MODE's forward image)
     const float* timg;           // transposed image (PL_TRO0 / PL_TRO1)
     const float* d_out;          // [N][T] upstream gradient of y / x
-    const float* d_lat;          // MODE 0: optional extra gradient on y_latent [G][30] (consumers outside this kernel), or null
+    const float* d_lat;          // optional extra gradient on the head's latent (y_latent [G][30] / the SpatialAttention output [Q][30]:
+                                 // consumers outside this kernel), or null
     float* dxs;                  // MODE 0: [G][32] gradient w.r.t. x_spatial through the y branch
     float* eb;                   // MODE 1: [Q * 10][12] per attention edge: alpha (5 heads), d(pre-activation) / sqrt(L) (5 heads)
     float* dxm;                  // MODE 1: [Q][16] gradient w.r.t. the aggregated attention vector (before proj)
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void k_ro_bwd(RbArgs b) {
                 dxin[bb] = d;
             }
         }
-        if (MODE == 0 && b.d_lat != nullptr && ok) {
+        if (b.d_lat != nullptr && ok) {
             dxin[0] += tl_load30(b.d_lat + (long long)n * 30, 0, q);
             dxin[1] += tl_load30(b.d_lat + (long long)n * 30, 1, q);
         }

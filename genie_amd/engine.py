@@ -763,11 +763,7 @@ class HipPath(object):
             _lib.check(self.lib.genie_seg_rows(_ptr(erow), _ptr(etgt), _ptr(order), n * 10, _ptr(ds), _stream()), "genie_seg_rows")
         return ds, {name: blob[off:off + k] for name, k, off in zip(self.w_names, self.w_numel, self.w_off)}
 
-    def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps):
-        """StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd): stime [n_src], src_embed
-        [n_src, 30], trv_src [n_src, n_sta, 2], arrival_p / arrival_s [n, 15], tpick / phase_label [n], ipick integer [n] ->
-        [n_src, n, 2]. `edge_index[0].max()` (module.py:762-763: the pick the reference treats as the null pick; the real null pick
-        whenever some source has |stime| < 2 eps) is found on the device (k_arr_e0max)."""
+    def _arrivals_args(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label):
         if not getattr(self, "assoc_ready", False):
             raise _lib.GenieHipError("association-head parameters were not uploaded (or have another model definition's shapes)")
         stime = _f32(stime, "stime").reshape(-1)
@@ -775,30 +771,60 @@ class HipPath(object):
         src_embed = _f32(src_embed, "src_embed", (n_src, 30))
         trv_src = _f32(trv_src, "trv_src")
         if trv_src.dim() != 3 or trv_src.shape[0] != n_src or trv_src.shape[2] != 2:
-            raise ValueError("arrivals_fwd: trv_src must be [n_src, n_sta, 2]")
+            raise ValueError("arrivals: trv_src must be [n_src, n_sta, 2]")
         n_sta = int(trv_src.shape[1])
         tpick = _f32(tpick, "tpick").reshape(-1)
         n = int(tpick.numel())
         arrival_p, arrival_s = _f32(arrival_p, "arrival_p", (n, 15)), _f32(arrival_s, "arrival_s", (n, 15))
         phase_label = _f32(phase_label, "phase_label").reshape(-1)
         if n == 0 or n_src == 0:
-            raise ValueError("arrivals_fwd: needs at least one pick and one source")
+            raise ValueError("arrivals: needs at least one pick and one source")
         ip = ipick.reshape(-1).long()
         if ip.numel() != n or phase_label.numel() != n or int(ip.max()) >= n_sta or int(ip.min()) < 0:
-            raise ValueError("arrivals_fwd: one station index in [0, n_sta) and one phase label per pick")
+            raise ValueError("arrivals: one station index in [0, n_sta) and one phase label per pick")
         order = torch.sort(ip, stable=True)[1]
         seg_sta, counts = torch.unique_consecutive(ip[order], return_counts=True)
         seg_start = torch.cumsum(counts, 0) - counts
         i32 = lambda t: t.to(torch.int32).contiguous()
-        order, seg_sta, seg_start, counts = i32(order), i32(seg_sta), i32(seg_start), i32(counts)
+        segs = (i32(order), i32(seg_sta), i32(seg_start), i32(counts))
+        return n_src, n_sta, n, (stime, src_embed, trv_src, arrival_p, arrival_s, tpick, phase_label), segs
+
+    def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps, train=False):
+        """StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd): stime [n_src], src_embed
+        [n_src, 30], trv_src [n_src, n_sta, 2], arrival_p / arrival_s [n, 15], tpick / phase_label [n], ipick integer [n] ->
+        [n_src, n, 2]. `edge_index[0].max()` (module.py:762-763: the pick the reference treats as the null pick; the real null pick
+        whenever some source has |stime| < 2 eps) is found on the device (k_arr_e0max). train=True (genie_arrivals_train_fwd): also
+        returns the state `arrivals_bwd` needs."""
+        n_src, n_sta, n, data, segs = self._arrivals_args(stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label)
         ctx = torch.empty(n_src * 192, dtype=torch.float32, device=self.device)
         flag = torch.empty(1, dtype=torch.int32, device=self.device)
         out = torch.empty((n_src, n, 2), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.genie_arrivals_fwd(self.ctx, n_src, _ptr(stime), _ptr(src_embed), _ptr(trv_src), n_sta, _ptr(arrival_p),
-                                               _ptr(arrival_s), _ptr(tpick), _ptr(phase_label), n, _ptr(order), _ptr(seg_sta),
-                                               _ptr(seg_start), _ptr(counts), int(seg_sta.numel()), float(eps), _ptr(ctx), _ptr(flag),
-                                               _ptr(out), _stream()), "genie_arrivals_fwd")
-        return out
+        head = (self.ctx, n_src, _ptr(data[0]), _ptr(data[1]), _ptr(data[2]), n_sta, _ptr(data[3]), _ptr(data[4]), _ptr(data[5]), _ptr(data[6]),
+                n, _ptr(segs[0]), _ptr(segs[1]), _ptr(segs[2]), _ptr(segs[3]), int(segs[1].numel()), float(eps), _ptr(ctx), _ptr(flag))
+        if not train:
+            _lib.check(self.lib.genie_arrivals_fwd(*head, _ptr(out), _stream()), "genie_arrivals_fwd")
+            return out
+        save = torch.empty(int(self.lib.genie_arrivals_train_save_floats(n_src, n)), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.genie_arrivals_train_fwd(*head, _ptr(out), _ptr(save), _stream()), "genie_arrivals_train_fwd")
+        return out, (data, segs, ctx, flag, save, float(eps))
+
+    def arrivals_bwd(self, state, d_out):
+        """Backward of `arrivals_fwd(..., train=True)` (genie_arrivals_bwd): d_out [n_src, n, 2] -> (d_src_embed [n_src, 30],
+        d_arrival_p [n, 15], d_arrival_s [n, 15], dict parameter name -> gradient)."""
+        data, segs, ctx, flag, save, eps = state
+        n_src, n, n_sta, n_useg = int(data[0].numel()), int(data[5].numel()), int(data[2].shape[1]), int(segs[1].numel())
+        d_out = _f32(d_out, "d_out", (n_src, n, 2))
+        dev = self.device
+        scratch = torch.empty(int(self.lib.genie_arrivals_bwd_scratch_floats(n_src, n, n_useg)), dtype=torch.float32, device=dev)
+        blob = torch.zeros(self._blob.numel(), dtype=torch.float32, device=dev)
+        d_src = torch.empty((n_src, 30), dtype=torch.float32, device=dev)
+        d_p = torch.empty((n, 15), dtype=torch.float32, device=dev)
+        d_s = torch.empty((n, 15), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.genie_arrivals_bwd(self.ctx, n_src, _ptr(data[0]), _ptr(data[1]), _ptr(data[2]), n_sta, _ptr(data[3]), _ptr(data[4]),
+                                               _ptr(data[5]), _ptr(data[6]), n, _ptr(segs[0]), _ptr(segs[1]), _ptr(segs[2]), _ptr(segs[3]), n_useg,
+                                               eps, _ptr(ctx), _ptr(flag), _ptr(save), _ptr(d_out), _ptr(scratch), _ptr(d_src), _ptr(d_p),
+                                               _ptr(d_s), _ptr(blob), _stream()), "genie_arrivals_bwd")
+        return d_src, d_p, d_s, {name: blob[off:off + k] for name, k, off in zip(self.w_names, self.w_numel, self.w_off)}
 
     def train_fwd(self, Slice, Mask, edge_attr, want_x_latent=True):
         """Training forward of DataAggregation + the P-sized half of Bipartite_ReadIn (genie_da_train_fwd): returns
@@ -869,10 +895,12 @@ class HipPath(object):
         x_spatial = tsave[112 * G:142 * G].view(G, 30)
         return y, x, x_spatial, y_latent, x_latent, save, tsave
 
-    def path_train_bwd(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query, save, tsave, d_y, d_x, d_xs=None, d_ylat=None):
+    def path_train_bwd(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query, save, tsave, d_y, d_x, d_xs=None, d_ylat=None,
+                       d_qlat=None):
         """Backward of `path_train_fwd` (genie_train_bwd): upstream gradients d_y [G, T], d_x [Q, T] (+ optional d_xs [G, 30] on
-        x_spatial and d_ylat [G, 30] on y_latent from consumers outside the path) -> dict parameter name -> gradient (views
-        into one blob laid out like the weight mirror), every parameter of the path."""
+        x_spatial, d_ylat [G, 30] on y_latent and d_qlat [Q, 30] on the SpatialAttention output of the query rows, from consumers
+        outside the path) -> dict parameter name -> gradient (views into one blob laid out like the weight mirror), every
+        parameter of the path."""
         dev, G = self.device, self.n_grid
         pos = _f32(pos, "pos", (G, 3))
         x_query = _f32(x_query, "x_query")
@@ -883,6 +911,7 @@ class HipPath(object):
         d_x = _f32(d_x, "d_x").reshape(nq, T)
         d_xs = _f32(d_xs, "d_xs", (G, 30)) if d_xs is not None else None
         d_ylat = _f32(d_ylat, "d_ylat", (G, 30)) if d_ylat is not None else None
+        d_qlat = _f32(d_qlat, "d_qlat", (nq, 30)) if d_qlat is not None else None
         rp, re = self.reverse_query_table(knn_idx)
         need_t = int(self.lib.genie_tail_train_scratch_floats(self.ctx, nq))
         need_f = int(self.lib.genie_train_scratch_floats(self.ctx))
@@ -894,7 +923,7 @@ class HipPath(object):
         blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
         _lib.check(self.lib.genie_train_bwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(pos), _ptr(x_query),
                                             _ptr(knn_idx), _ptr(rp), _ptr(re), nq, 10, _ptr(tq), T, _ptr(tsave), _ptr(d_y), _ptr(d_x),
-                                            _ptr(d_xs), _ptr(d_ylat), _ptr(self._tail_scratch), _ptr(self._train_scratch), _ptr(d_r),
+                                            _ptr(d_xs), _ptr(d_ylat), _ptr(d_qlat), _ptr(self._tail_scratch), _ptr(self._train_scratch), _ptr(d_r),
                                             _ptr(blob), _stream()), "genie_train_bwd")
         return {name: blob[off:off + n] for name, n, off in zip(self.w_names, self.w_numel, self.w_off)}
 
@@ -914,7 +943,7 @@ class HipPath(object):
         d_r = torch.empty((G, 32), dtype=torch.float32, device=dev)
         blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
         _lib.check(self.lib.genie_tail_train_bwd(self.ctx, _ptr(_f32(pos, "pos", (G, 3))), _ptr(x_query), _ptr(knn_idx), _ptr(rp), _ptr(re), nq, 10,
-                                                 _ptr(tq), T, _ptr(tsave), _ptr(d_y), _ptr(d_x), _ptr(d_xs), _ptr(d_ylat),
+                                                 _ptr(tq), T, _ptr(tsave), _ptr(d_y), _ptr(d_x), _ptr(d_xs), _ptr(d_ylat), None,
                                                  _ptr(self._tail_scratch), _ptr(d_r), _ptr(blob), _stream()), "genie_tail_train_bwd")
         return d_r, blob
 

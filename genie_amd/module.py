@@ -89,28 +89,42 @@ class _PathTrain(torch.autograd.Function):
     values are read from the library's weight mirror (synchronised by the caller)."""
 
     @staticmethod
-    def forward(ctx, Slice, Mask, edge_attr, pos, x_query, knn, t_query, hip, want_latents, *params):
+    def forward(ctx, Slice, Mask, edge_attr, pos, x_query, knn, t_query, hip, want_latents, n_src_rows, *params):
+        # the last n_src_rows query rows are the source queries of the 4-output forward (module.py:981): only their
+        # SpatialAttention output (`x_src`) is used
         y, x, xs, ylat, xl, save, tsave = hip.path_train_fwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query,
                                                               want_x_latent=want_latents, want_y_latent=want_latents)
-        ctx.hip = hip
+        nq = x_query.shape[0] - n_src_rows
+        ctx.hip, ctx.n_src_rows = hip, n_src_rows
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave)
         ctx.set_materialize_grads(False)
         xs = xs.clone()
+        if n_src_rows:
+            x_src = hip.spatial_attention(xs, pos, x_query[nq:], knn[nq:], t_query)
+            x = x[:nq].contiguous()
+        else:
+            x_src = xs.new_zeros(0)
         if not want_latents:
             ylat, xl = xs.new_zeros(0), xs.new_zeros(0)
         ctx.mark_non_differentiable(xl)
-        return y, x, xs, ylat, xl
+        return y, x, xs, ylat, xl, x_src
 
     @staticmethod
-    def backward(ctx, d_y, d_x, d_xs, d_ylat, _d_xl):
+    def backward(ctx, d_y, d_x, d_xs, d_ylat, _d_xl, d_xsrc):
         Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave = ctx.saved_tensors
-        hp = ctx.hip
-        T = t_query.numel()
-        d_y = d_y if d_y is not None else torch.zeros((hp.n_grid, T), dtype=torch.float32, device=Slice.device)
-        d_x = d_x if d_x is not None else torch.zeros((x_query.shape[0], T), dtype=torch.float32, device=Slice.device)
-        g = hp.path_train_bwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave, d_y, d_x, d_xs, d_ylat)
-        return (None,) * 9 + tuple(g[n].view(s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
+        hp, ns = ctx.hip, ctx.n_src_rows
+        T, nq_all, dev = t_query.numel(), x_query.shape[0], Slice.device
+        d_y = d_y if d_y is not None else torch.zeros((hp.n_grid, T), dtype=torch.float32, device=dev)
+        d_xa = torch.zeros((nq_all, T), dtype=torch.float32, device=dev)
+        if d_x is not None:
+            d_xa[:nq_all - ns] = d_x.reshape(nq_all - ns, T)
+        d_qlat = None
+        if ns and d_xsrc is not None:
+            d_qlat = torch.zeros((nq_all, 30), dtype=torch.float32, device=dev)
+            d_qlat[nq_all - ns:] = d_xsrc
+        g = hp.path_train_bwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave, d_y, d_xa, d_xs, d_ylat, d_qlat)
+        return (None,) * 10 + tuple(g[n].view(s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
 
 
 TRAIN_ASSOC_PARAMS = tuple(
@@ -168,6 +182,32 @@ class _LslcTrain(torch.autograd.Function):
         ds_rows, g = ctx.hip.lslc_bwd(s, (a_edges_p, a_edges_s), ctx.dt_partition, tpick, ipick32, phase_label, tlatent, ctx.eps,
                                       d_p.contiguous() if d_p is not None else None, d_s.contiguous() if d_s is not None else None)
         return (ds_rows,) + (None,) * 9 + tuple(g[n].view(sh) for n, sh in zip(TRAIN_LSLC_PARAMS, ctx.shapes))
+
+
+TRAIN_ARR_PARAMS = tuple("Arrivals.%s" % n for n in (
+    "f_arrival_query_1.weight", "f_arrival_query_1.bias", "f_arrival_query_2.weight", "f_arrival_query_2.bias",
+    "f_src_context_1.weight", "f_src_context_1.bias", "f_src_context_2.weight", "f_src_context_2.bias",
+    "f_values_1.weight", "f_values_1.bias", "f_values_2.weight", "f_values_2.bias", "proj_1.weight", "proj_1.bias",
+    "proj_2.weight", "proj_2.bias", "activate1.weight", "activate2.weight", "activate3.weight", "activate4.weight"))
+
+
+class _ArrivalsTrain(torch.autograd.Function):
+    """StationSourceAttentionMergedPhases (module.py:662-775, :993) of a training step in HIP in both directions: forward = the
+    inference kernels keeping the per-target softmax state (genie_arrivals_train_fwd), backward = genie_arrivals_bwd.
+    Differentiable inputs: src_embed (`x_src`), arrival_p, arrival_s and the head's parameters (order TRAIN_ARR_PARAMS)."""
+
+    @staticmethod
+    def forward(ctx, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps, hip, *params):
+        out, state = hip.arrivals_fwd(stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps, train=True)
+        ctx.hip, ctx.state = hip, state
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_src, d_p, d_s, g = ctx.hip.arrivals_bwd(ctx.state, d_out.contiguous())
+        ctx.state = None
+        return (None, d_src, None, d_p, d_s, None, None, None, None, None) + tuple(g[n].view(sh) for n, sh in zip(TRAIN_ARR_PARAMS, ctx.shapes))
 
 
 def _scatter_mean_rows(msg, index, n):
@@ -904,10 +944,11 @@ class GCN_Detection_Network_extended(nn.Module):
     def _differentiable(self):
         return self.training and torch.is_grad_enabled()
 
-    def _path_train(self, Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=False):
+    def _path_train(self, Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=False, x_query_src_cart=None):
         """Training-mode `forward_fixed_source`: the whole path in HIP in both directions (`_PathTrain`). Used
         when the module is in train() mode with gradients enabled; eval / no_grad calls take the fused inference kernels.
-        Returns (y, x, x_spatial, y_latent, x_latent); the latents only with `want_latents` (the 4-output forward)."""
+        Returns (y, x, x_spatial, y_latent, x_latent, x_src); the latents only with `want_latents`, x_src (SpatialAttention at the
+        source queries, module.py:981) only with `x_query_src_cart` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
         if self.use_updated_model_definition or self.use_absolute_pos or self._hip._n_prod is not None:
@@ -915,7 +956,12 @@ class GCN_Detection_Network_extended(nn.Module):
         hp = self._hip
         hp.sync_weights(self._path_params)
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
-        return _PathTrain.apply(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query, hp, bool(want_latents),
+        n_src_rows = 0
+        if x_query_src_cart is not None:          # the source queries ride along as extra query rows (same kernels, same backward)
+            n_src_rows = int(x_query_src_cart.shape[0])
+            knn = torch.cat((knn, _engine.knn_device(x_temp_cuda_cart, x_query_src_cart, 10)), 0)
+            x_query_cart = torch.cat((_engine._f32(x_query_cart, "x_query"), _engine._f32(x_query_src_cart, "x_query_src")), 0)
+        return _PathTrain.apply(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query, hp, bool(want_latents), n_src_rows,
                                 *[self._path_params[n] for n in TRAIN_PATH_PARAMS])
 
     def forward_fixed_source(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
@@ -988,15 +1034,13 @@ class GCN_Detection_Network_extended(nn.Module):
                                       "set_adjacencies_base): only forward_fixed_source is available here")
         S, G = self._hip.n_sta, self._hip.n_grid
         if self._differentiable():       # training step (train_GENIE_model.py:1786): the shared path in HIP in both directions
-            y, x, x_spatial, y_latent, x_latent = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True)
+            y, x, x_spatial, y_latent, x_latent, x_src = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True,
+                                                                          x_query_src_cart=x_query_src_cart)      # :973-982
         else:
             x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)  # :973-977
             y, y_latent = self._hip.readout_grid_latent(x_spatial, t_query)                          # :978-979
             knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
             x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)     # :980,982
-        if self._differentiable():
-            x_src = self._spatial_attention_uncached(x_spatial, x_query_src_cart, x_temp_cuda_cart)  # :981 (autograd: training steps)
-        else:
             knn_src = _engine.knn_device(x_temp_cuda_cart, x_query_src_cart, 10)
             x_src = self._hip.spatial_attention(x_spatial, x_temp_cuda_cart, x_query_src_cart, knn_src, t_query)   # :981
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
@@ -1034,7 +1078,11 @@ class GCN_Detection_Network_extended(nn.Module):
             arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
         if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
             arv = self._hip.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)   # :993 in HIP
-        else:       # training steps (autograd), or a context without association-head weights
+        elif getattr(self._hip, "assoc_ready", False) and len(tpick) > 0 and arv_p.is_cuda:
+            # training step: the same kernels keeping the per-target softmax state, backward in HIP (`_ArrivalsTrain`)
+            arv = _ArrivalsTrain.apply(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps, self._hip,
+                                       *[self._path_params[n] for n in TRAIN_ARR_PARAMS])
+        else:       # CPU restatement (tests), or a context without association-head weights
             arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 
@@ -1042,13 +1090,6 @@ class GCN_Detection_Network_extended(nn.Module):
         """Forget the graphs `forward` cached (next call rebuilds the HIP context) and the cached query kNN table."""
         self._fwd_key = self._fwd_refs = None
         self.SpatialAttention.invalidate_query_cache()
-
-    def _spatial_attention_uncached(self, x_spatial, x_query, x_context):
-        cache = self.SpatialAttention._edge_cache
-        self.SpatialAttention._edge_cache = {}
-        out = self.SpatialAttention(x_spatial, x_query, x_context)
-        self.SpatialAttention._edge_cache = cache
-        return out
 
     def forward(self, Slice, Mask, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                 A_edges_s, dt_partition, tlatent, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,

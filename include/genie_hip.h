@@ -311,7 +311,8 @@ int genie_da_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, co
  *     starts at float 112 * n_grid). y_out [n_grid, n_t], x_out [n_query, n_t]; y_latent_out [n_grid, 30] optional
  *     (SpatialDirect output, the input of the association heads).
  *   genie_tail_train_bwd: d_y [n_grid, n_t], d_x [n_query, n_t]; optional extra upstream gradients d_xs_extra [n_grid, 30]
- *     (other consumers of x_spatial) and d_ylat_extra [n_grid, 30] (other consumers of y_latent) -> d_r_out [n_grid, 32] (the
+ *     (other consumers of x_spatial), d_ylat_extra [n_grid, 30] (other consumers of y_latent) and d_qlat_extra [n_query, 30] (consumers
+ *     of the SpatialAttention output of a query row, :981: the `x_src` rows the arrival head reads) -> d_r_out [n_grid, 32] (the
  *     input of genie_da_train_bwd) and grad_blob (genie_train_grad_floats() floats, zeroed by the call; weight-mirror layout):
  *     gradients of every tail parameter. rknn_rowptr [n_grid + 1] / rknn_edge [n_query * 10]: the query kNN table reversed =
  *     for every grid node the attention edges i * 10 + k that end in it, ascending. `scratch`:
@@ -327,13 +328,13 @@ int genie_tail_train_fwd(genie_ctx* ctx, const float* pos, const float* x_query,
                          void* stream);
 int genie_tail_train_bwd(genie_ctx* ctx, const float* pos, const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr,
                          const int32_t* rknn_edge, int n_query, int k, const float* t_query, int n_t, const float* tsave,
-                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, float* scratch,
-                         float* d_r_out, float* grad_blob, void* stream);
+                         const float* d_y, const float* d_x, const float* d_xs_extra, const float* d_ylat_extra, const float* d_qlat_extra,
+                         float* scratch, float* d_r_out, float* grad_blob, void* stream);
 int genie_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, const float* edge_attr, const float* save, const float* pos,
                     const float* x_query, const int32_t* knn, const int32_t* rknn_rowptr, const int32_t* rknn_edge, int n_query, int k,
                     const float* t_query, int n_t, const float* tsave, const float* d_y, const float* d_x, const float* d_xs_extra,
-                    const float* d_ylat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch, float* grad_blob,
-                    void* stream);
+                    const float* d_ylat_extra, const float* d_qlat_extra, float* tail_scratch, float* front_scratch, float* d_r_scratch,
+                    float* grad_blob, void* stream);
 
 /* Association heads on the product graph, the P-sized part of `forward_fixed` after the source branch
  * (module.py:986-990): BipartiteGraphReadOutOperator (:333-352) followed by DataAggregationAssociationPhase (:356-403).
@@ -405,6 +406,28 @@ int genie_arrivals_fwd(genie_ctx* ctx, int n_src, const float* stime, const floa
                        const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
                        const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
                        float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, void* stream);
+
+/* The same head inside a training step (train_GENIE_model.py:1786-1861 differentiates module.py:662-775). _train_fwd = the forward
+ * above that also keeps, per (source, pick), the three normalised head aggregates and the softmax statistics in `save`
+ * (genie_arrivals_train_save_floats(n_src, n_arv) floats); ctx_scratch / e0max_scratch must be kept for the backward as well.
+ * genie_arrivals_bwd: d_out [n_src, n_arv, 2] -> d_src_embed [n_src, 30], d_arrival_p / d_arrival_s [n_arv, 15], and the gradients of
+ * the head's 24 parameters ADDED into grad_blob (registry layout, genie_train_grad_floats() floats; the f_src_context_* entries are
+ * written). The reference's per-call edge list is never built: queries / values are functions of (pick, source) and the two link
+ * bits, so the backward is one pointwise pass over the (source, pick) targets (proj_1 / proj_2, d aggregate, the softmax's segment
+ * term in closed form), one pass over the (source, station) pairs (forward of every entry recomputed, one sweep over the station's
+ * targets, the edge MLPs backwards), and a per-source pass for the context MLP. No atomics, fixed summation order: bitwise
+ * reproducible. scratch: genie_arrivals_bwd_scratch_floats(n_src, n_arv, n_useg) floats. */
+int64_t genie_arrivals_train_save_floats(int n_src, int n_arv);
+int genie_arrivals_train_fwd(genie_ctx* ctx, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                             const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                             const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                             float eps, float* ctx_scratch, int32_t* e0max_scratch, float* out, float* save, void* stream);
+int64_t genie_arrivals_bwd_scratch_floats(int n_src, int n_arv, int n_useg);
+int genie_arrivals_bwd(genie_ctx* ctx, int n_src, const float* stime, const float* src_embed, const float* trv_src, int n_sta,
+                       const float* arrival_p, const float* arrival_s, const float* tpick, const float* phase_label, int n_arv,
+                       const int32_t* order, const int32_t* seg_sta, const int32_t* seg_start, const int32_t* seg_len, int n_useg,
+                       float eps, const float* ctx_scratch, const int32_t* e0max_scratch, const float* save, const float* d_out,
+                       float* scratch, float* d_src_embed, float* d_arrival_p, float* d_arrival_s, float* grad_blob, void* stream);
 
 /* Product-level CSRs of the irregular product graph of `use_subgraph: True` on the device (the two `subgraph(...)` loops of
  * extract_inputs_adjacencies_subgraph, process_utils.py:824-839). Product node n = the pair (pair_sta[n], pair_src[n]), pairs
