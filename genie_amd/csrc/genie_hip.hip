@@ -4568,7 +4568,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
 #if GENIE_TUNING
     { const char* e = getenv("GENIE_ABLATE"); a.abl = e ? atoi(e) : 0; }
 #endif
-    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
+    a.nxcd = 8;
     const size_t bo = (c->slot % GENIE_NBIG) * c->big_stride;
     a.c = ws + c->o_c + bo; a.wu = ws + c->o_wu + bo; a.wv = ws + c->o_wv + bo;
     a.part = ws + c->o_part + c->slot * c->slot_stride;
@@ -5134,7 +5134,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
                      !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
         // 4 workgroups per CU in the grid, one resident: a workgroup held up by a tail kernel of the previous window then costs a
         // quarter of a share, not a whole one (pipelined window 0.877 -> 0.866 ms; no effect on the kernel alone)
-        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? std::max(1, atoi(e)) : 4;
+        c->bpc1b = 4;
     }
 #if GENIE_TUNING
     {
@@ -5469,7 +5469,6 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     DaArgs a = make_da_args(c, (float*)ws);
     a.gi0 = gi_begin; a.G = gi_end - gi_begin;
     a.slope2 = slope2; a.no_bip = no_bip;
-    { const char* e = getenv("GENIE_SEG2"); if (e) a.seg = std::max(1, atoi(e)); }      // EXPERIMENT (round 3): stage-2 sweep segments
     const long long n_tiles = (long long)a.G * c->T;
     if (n_tiles == 0) return GENIE_OK;
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
@@ -6015,7 +6014,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     TrArgs a;
     memset(&a, 0, sizeof(a));
     a.S = c->S; a.G = c->G; a.T = c->T; a.seg = std::max(1, c->seg);
-    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
+    a.nxcd = 8;
     a.P = c->P; a.order = c->order;
     a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
     a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
@@ -6332,7 +6331,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     TrArgs a;
     memset(&a, 0, sizeof(a));
     a.S = c->S; a.G = c->G; a.T = c->T; a.seg = std::max(1, c->seg);
-    { const char* e = getenv("GENIE_NXCD"); a.nxcd = e ? atoi(e) : 8; }
+    a.nxcd = 8;
     a.P = c->P; a.order = c->order;
     a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
     a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
