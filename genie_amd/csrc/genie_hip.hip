@@ -117,6 +117,9 @@ enum {
     // StationSourceAttentionMergedPhases (module.py:662-775, `Arrivals`)
     W_AR_Q1_W, W_AR_Q1_B, W_AR_Q2_W, W_AR_Q2_B, W_AR_C1_W, W_AR_C1_B, W_AR_C2_W, W_AR_C2_B, W_AR_V1_W, W_AR_V1_B, W_AR_V2_W, W_AR_V2_B,
     W_AR_P1_W, W_AR_P1_B, W_AR_P2_W, W_AR_P2_B, W_AR_ACT1, W_AR_ACT2, W_AR_ACT3, W_AR_ACT4,
+    // DataAggregationAssociationPhaseEdges (module.py:407-480): the 4 edge-feature columns of l1_t?_2 / l2_t?_2, and the 6
+    // absolute-position columns of its init_trns under use_absolute_pos (module.py:987-988); zero otherwise
+    W_AS_L1T12_P, W_AS_L1T22_P, W_AS_L2T12_P, W_AS_L2T22_P, W_AS_INIT_ABS,
     W_COUNT
 };
 
@@ -202,6 +205,9 @@ Param g_params[W_COUNT] = {
     {"Arrivals.proj_2.weight", 2 * 30, 0}, {"Arrivals.proj_2.bias", 2, 0},
     {"Arrivals.activate1.weight", 1, 0}, {"Arrivals.activate2.weight", 1, 0},
     {"Arrivals.activate3.weight", 1, 0}, {"Arrivals.activate4.weight", 1, 0},
+    {"DataAggregationAssociationPhase.l1_t1_2.weight_pos", 30 * 4, 0}, {"DataAggregationAssociationPhase.l1_t2_2.weight_pos", 30 * 4, 0},
+    {"DataAggregationAssociationPhase.l2_t1_2.weight_pos", 15 * 4, 0}, {"DataAggregationAssociationPhase.l2_t2_2.weight_pos", 15 * 4, 0},
+    {"DataAggregationAssociationPhase.init_trns.weight_abs", 30 * 6, 0},
 };
 
 int g_raw_total = 0;
@@ -2183,6 +2189,7 @@ struct AsArgs {
     const int32_t* sta_rowptr; const int32_t* sta_col; const int32_t* src_rowptr; const int32_t* src_col;
     const int32_t* sta_user;     // internal station -> caller's station (inputs are in the caller's order), or null
     const float* pg;             // [G][AS_PG]
+    const float* ps;             // [S][AS_PS] static per-station terms of the two model variants (caller's station order), or null
     const float* x_latent; const float* mask; const float* edge_attr;   // caller's order: [P,30], [P,4], [P,3]
     float* tr; float* q1; float* q2;                                    // [P,32]
     float* c; float* wu; float* wv;
@@ -2195,10 +2202,25 @@ struct AsArgs {
 constexpr int AV_Z1 = 0, AV_SV = 2, AV_TR = 3, AV_Q = 5, AV_O = 10, AV_T = 12, AV_UV = 16, AV_BLOCKS = 20;
 static_assert(AV_O == SV_O, "the stage-2 kernel stores the output layer's pre-activations at SV_O");
 
-struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as_l2t12_w, as_l2t22_w; };
+struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as_l2t12_w, as_l2t22_w;
+                   int as_init_abs, as_l1t12_p, as_l1t22_p, as_l2t12_p, as_l2t22_p; };
+
+// The two model variants in the association phase: under use_updated_model_definition the mean edge feature of a node's
+// in-neighbourhood (static: mpos_sta [S][4] / mpos_src [G][4], genie_set_edge_features) enters l1_t?_2 / l2_t?_2 (module.py:462-467,
+// :472-480); under use_absolute_pos the station / source positions / (3 scale_rel) (abs_sta [S][4] / abs_src [G][4]) are appended to
+// the head's input (module.py:987-988, 6 more columns of init_trns). Both are per-station / per-source-node ADDITIVE terms of a
+// pre-activation: the source-node ones are folded into pg, the station ones are ps [S][AS_PS]: [0:30] init_trns, [32:62]
+// l1_t1_2, [64:79] l2_t1_2.
+constexpr int AS_PS = 80;
+__device__ __forceinline__ float dot4w(const float* __restrict__ w, const float* __restrict__ m, int n) {
+    float v = 0.f;
+    for (int c = 0; c < n; ++c) v = fmaf(w[c], m[c], v);
+    return v;
+}
 
 __global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw, AsPreOffs o, const float* __restrict__ y_latent,
-                                                   const float* __restrict__ mask_src, int G, float* __restrict__ pg) {
+                                                   const float* __restrict__ mask_src, int G, const float* __restrict__ mpos_src,
+                                                   const float* __restrict__ abs_src, float* __restrict__ pg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= G * AS_PG) return;
     const int g = idx / AS_PG, k = idx - g * AS_PG;
@@ -2209,12 +2231,31 @@ __global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw
         const float* w = raw + o.ro_fc1_w + k * 33;
         for (int c = 0; c < 30; ++c) v = fmaf(w[c], y_latent[g * 30 + c], v);
     } else if (k == 31) v = m;
-    else if (k >= 32 && k < 62) v = m * raw[o.as_init_w + (k - 32) * 50 + 45];
-    else if (k >= 64 && k < 94) v = m * raw[o.as_l1t12_w + (k - 64) * 65 + 60];
-    else if (k >= 96 && k < 126) v = m * raw[o.as_l1t22_w + (k - 96) * 65 + 60];
-    else if (k >= 128 && k < 143) v = m * raw[o.as_l2t12_w + (k - 128) * 95 + 90];
-    else if (k >= 144 && k < 159) v = m * raw[o.as_l2t22_w + (k - 144) * 95 + 90];
+    else if (k >= 32 && k < 62) {
+        v = m * raw[o.as_init_w + (k - 32) * 50 + 45];
+        if (abs_src) v += dot4w(raw + o.as_init_abs + (k - 32) * 6 + 3, abs_src + g * 4, 3);
+    } else if (k >= 64 && k < 94) v = m * raw[o.as_l1t12_w + (k - 64) * 65 + 60];
+    else if (k >= 96 && k < 126) {
+        v = m * raw[o.as_l1t22_w + (k - 96) * 65 + 60];
+        if (mpos_src) v += dot4w(raw + o.as_l1t22_p + (k - 96) * 4, mpos_src + g * 4, 4);
+    } else if (k >= 128 && k < 143) v = m * raw[o.as_l2t12_w + (k - 128) * 95 + 90];
+    else if (k >= 144 && k < 159) {
+        v = m * raw[o.as_l2t22_w + (k - 144) * 95 + 90];
+        if (mpos_src) v += dot4w(raw + o.as_l2t22_p + (k - 144) * 4, mpos_src + g * 4, 4);
+    }
     pg[idx] = v;
+}
+
+__global__ void k_assoc_ps(const float* __restrict__ raw, AsPreOffs o, int S, const float* __restrict__ mpos_sta,
+                           const float* __restrict__ abs_sta, float* __restrict__ ps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * AS_PS) return;
+    const int s = idx / AS_PS, k = idx - s * AS_PS;
+    float v = 0.f;
+    if (k < 30) { if (abs_sta) v = dot4w(raw + o.as_init_abs + k * 6, abs_sta + s * 4, 3); }
+    else if (k >= 32 && k < 62) { if (mpos_sta) v = dot4w(raw + o.as_l1t12_p + (k - 32) * 4, mpos_sta + s * 4, 4); }
+    else if (k >= 64 && k < 79) { if (mpos_sta) v = dot4w(raw + o.as_l2t12_p + (k - 64) * 4, mpos_sta + s * 4, 4); }
+    ps[idx] = v;
 }
 
 __device__ __forceinline__ f32x4 ld_row30(const float* row, int b, int q) {     // channels 16b + 4q .. +3 of a 30-float row (8-B aligned)
@@ -2273,6 +2314,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 acc = *(const f32x4*)(lbias + (1 + t) * 16 + 4 * q) + *(const f32x4*)(pg + 32 + 16 * t + 4 * q);
+            if (a.ps != nullptr) acc += *(const f32x4*)(a.ps + (long long)su * AS_PS + 16 * t + 4 * q);
             acc = mma_block(acc, lw[GA_INIT(t, 0) * 64 + lane], sv);
             acc = mma_block(acc, lw[GA_INIT(t, 1) * 64 + lane], lat0);
             acc = mma_block(acc, lw[GA_INIT(t, 2) * 64 + lane], lat1);
@@ -2387,6 +2429,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             acc[k] = *(const f32x4*)(lbias + k * 16 + 4 * q) + *(const f32x4*)(pg + 64 + 32 * (k >> 1) + 16 * (k & 1) + 4 * q);
+        if (a.ps != nullptr) {
+            acc[0] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 32 + 4 * q);
+            acc[1] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 48 + 4 * q);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 0) * 64 + lane];
         mma_blocks<4>(acc, w4, x0);
@@ -2424,6 +2470,7 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
         o6[4] = *(const f32x4*)(lbias + 8 * 16 + 4 * q) + *(const f32x4*)(pg + 128 + 4 * q);
         o6[5] = *(const f32x4*)(lbias + 9 * 16 + 4 * q) + *(const f32x4*)(pg + 144 + 4 * q);
+        if (a.ps != nullptr) o6[4] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 64 + 4 * q);
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll
@@ -4423,6 +4470,7 @@ struct genie_ctx {
     int force_generic;         // set for the duration of a training call: the generic fp32 stage kernels (caller's station order,
                                // pre-activations saved) run whatever the context would normally select
     float* as_pg;              // [G][AS_PG] per-source-node terms of the association stages (allocated on first use)
+    float* as_ps;              // [S][AS_PS] per-station terms of the two model variants (allocated on first use)
     int32_t* d_b3tbl;          // k_pack_b3 source table
     // reversed base graphs (out-edges, weights 1 / in-degree of the target): built on the first genie_nbr_mean_bwd
     int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
@@ -5300,7 +5348,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_steps[4], c->d_steps[5], c->d_steps[6], c->d_bias[4], c->d_bias[5], c->d_bias[6], c->d_scal[4], c->d_scal[5],
                     c->d_scal[6], c->packed[4], c->packed[5], c->packed[6], c->d_acc[0], c->d_acc[1], c->d_acc[2], c->d_vec[0],
                     c->d_vec[1], c->d_vec[2], c->d_sc[0], c->d_sc[1], c->d_sc[2],
-                    c->as_pg, c->d_b3tbl, c->packed_b3, c->src_tab,
+                    c->as_pg, c->as_ps, c->d_b3tbl, c->packed_b3, c->src_tab,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
@@ -6253,7 +6301,12 @@ void assoc_pre_launch(genie_ctx* c, const float* y_latent, const float* mask_src
     o.ro_fc1_w = g_params[W_RO_FC1_W].off; o.ro_fc1_b = g_params[W_RO_FC1_B].off; o.as_init_w = g_params[W_AS_INIT_W].off;
     o.as_l1t12_w = g_params[W_AS_L1T12_W].off; o.as_l1t22_w = g_params[W_AS_L1T22_W].off;
     o.as_l2t12_w = g_params[W_AS_L2T12_W].off; o.as_l2t22_w = g_params[W_AS_L2T22_W].off;
-    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, c->as_pg);
+    o.as_init_abs = g_params[W_AS_INIT_ABS].off; o.as_l1t12_p = g_params[W_AS_L1T12_P].off; o.as_l1t22_p = g_params[W_AS_L1T22_P].off;
+    o.as_l2t12_p = g_params[W_AS_L2T12_P].off; o.as_l2t22_p = g_params[W_AS_L2T22_P].off;
+    const float* mpos_src = c->has_edges ? c->mpos_src : nullptr;
+    const float* mpos_sta = c->has_edges ? c->mpos_sta : nullptr;
+    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, mpos_src, c->abs_src, c->as_pg);
+    if (c->as_ps) k_assoc_ps<<<(c->S * AS_PS + 255) / 256, 256, 0, st>>>(c->raw, o, c->S, mpos_sta, c->abs_sta, c->as_ps);
 }
 }  // namespace
 
@@ -6274,6 +6327,9 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
+    const bool variant = c->has_edges || c->abs_sta != nullptr;
+    if (variant && save) return fail(GENIE_ERR_STATE, "genie_assoc_train_fwd: default model definition only");
+    if (variant && !c->as_ps) HIP_TRY(hipMalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)c->S));
     assoc_pre_launch(c, y_latent, mask_src, st);
     if (save) { c->force_generic = 1; c->train_save = save; }      // training forward: caller's station order, pre-activations kept
     DaArgs d = make_da_args(c, (float*)ws);
@@ -6283,7 +6339,7 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     a.order = c->order;
     a.sta_rowptr = d.sta_rowptr; a.sta_col = d.sta_col; a.src_rowptr = c->src_rowptr; a.src_col = c->src_col;
     a.sta_user = d.sta_user;
-    a.pg = c->as_pg; a.x_latent = x_latent; a.mask = mask; a.edge_attr = edge_attr;
+    a.pg = c->as_pg; a.ps = variant ? c->as_ps : nullptr; a.x_latent = x_latent; a.mask = mask; a.edge_attr = edge_attr;
     a.tr = (float*)assoc_ws; a.q1 = a.tr + 32 * (size_t)c->P; a.q2 = a.q1 + 32 * (size_t)c->P;
     a.c = d.c; a.wu = d.wu; a.wv = d.wv;
     a.save = save; a.Pn = c->P;

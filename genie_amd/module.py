@@ -42,21 +42,6 @@ def _path_param_dict(net):
     return out
 
 
-class _NbrMean(torch.autograd.Function):
-    """Neighbour means over the product graph with HIP forward (genie_nbr_mean) and HIP adjoint (genie_nbr_mean_bwd): the
-    irregular, P-sized part of a training step; everything dense around it is differentiated by autograd."""
-
-    @staticmethod
-    def forward(ctx, x_sta, x_src, hip):
-        ctx.hip = hip
-        return hip.nbr_mean(x_sta.detach(), x_src.detach())
-
-    @staticmethod
-    def backward(ctx, g_sta, g_src):
-        d_sta, d_src = ctx.hip.nbr_mean_bwd(g_sta.contiguous(), g_src.contiguous())
-        return d_sta, d_src, None
-
-
 def _train_path_params():
     """state_dict names of every parameter the HIP training step differentiates (the whole `forward_fixed_source` path): the
     dead layers of the reference (DataAggregation.l1_t1_1 / l1_t2_1, SpatialAttention.param_vector / f_direct) get no gradient
@@ -216,37 +201,6 @@ def _scatter_mean_rows(msg, index, n):
     return out / cnt.clamp(min=1).view(-1, 1)
 
 
-class _Linear(torch.autograd.Function):
-    """Per-node Linear over product-sized rows: forward and dX on the library GEMM, dW / db by genie_linear_bwd_wb (one pass
-    over x and dy; the library's [M, N] x [N, K] product with N = 2M rows plus the bias reduction is 10x slower)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, hip):
-        ctx.hip = hip
-        ctx.save_for_backward(x, weight)
-        return F.linear(x, weight, bias)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
-        dW, db = ctx.hip.linear_bwd_wb(x, dy)
-        return dx, dW, db, None
-
-
-def _dense(module, x, owner):
-    """`module(x)` for an nn.Linear; under autograd on a HIP-backed network (owner._hip set by set_adjacencies) and with enough
-    rows the weight / bias gradients come from genie_linear_bwd_wb (`_Linear`)."""
-    hip = getattr(owner, "_hip", None)
-    rows = x.numel() // max(1, x.shape[-1])
-    if (hip is None or not torch.is_grad_enabled() or not x.is_cuda or rows < 4096 or module.in_features > 128
-            or module.out_features > 128 or module.bias is None):
-        return module(x)
-    y = _Linear.apply(x.reshape(rows, x.shape[-1]).contiguous(), module.weight, module.bias, hip)
-    return y.view(*x.shape[:-1], module.out_features)
-
-
 class DataAggregation(nn.Module):
     """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
     applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
@@ -303,23 +257,32 @@ class DataAggregationEdges(nn.Module):
 
 def _split_abs_columns(named):
     """Registry view under use_absolute_pos: init_trns.weight [30, 14] = [Slice 4 | station pos 3 | source pos 3 | Mask 4]
-    -> the usual [30, 8] plus `init_trns.weight_abs` [30, 6] (include/genie_hip.h, genie_set_absolute_pos)."""
+    -> the usual [30, 8] plus `init_trns.weight_abs` [30, 6] (include/genie_hip.h, genie_set_absolute_pos); the association phase's
+    init_trns [30, 56] = [s 15 | station pos 3 | source pos 3 | x_latent 30 | mask 5] (module.py:987-988) likewise."""
     out = dict(named)
     W = named["DataAggregation.init_trns.weight"].detach()
     out["DataAggregation.init_trns.weight"] = torch.cat((W[:, :4], W[:, 10:]), dim=1).contiguous()
     out["DataAggregation.init_trns.weight_abs"] = W[:, 4:10].contiguous()
+    k = "DataAggregationAssociationPhase.init_trns.weight"
+    if k in named and named[k].shape[1] == 56:
+        W = named[k].detach()
+        out[k] = torch.cat((W[:, :15], W[:, 21:]), dim=1).contiguous()
+        out[k + "_abs"] = W[:, 15:21].contiguous()
     return out
 
 
 def _split_edge_columns(named):
-    """Registry view of DataAggregationEdges weights: the edge-feature columns of l?_t?_2 go to `<name>_pos`, the rest
-    keeps the DataAggregation column layout (include/genie_hip.h, genie_set_edge_features)."""
+    """Registry view of DataAggregationEdges / DataAggregationAssociationPhaseEdges weights: the edge-feature columns of l?_t?_2 go
+    to `<name>_pos`, the rest keeps the DataAggregation column layout (include/genie_hip.h, genie_set_edge_features)."""
     out = dict(named)
-    for lay, n_in in (("l1_t1_2", 60), ("l1_t2_2", 60), ("l2_t1_2", 90), ("l2_t2_2", 90)):
-        k = "DataAggregation.%s.weight" % lay
-        W = named[k].detach()
-        out[k] = torch.cat((W[:, :n_in], W[:, n_in + 4:]), dim=1).contiguous()
-        out[k + "_pos"] = W[:, n_in:n_in + 4].contiguous()
+    for mod in ("DataAggregation", "DataAggregationAssociationPhase"):
+        for lay, n_in in (("l1_t1_2", 60), ("l1_t2_2", 60), ("l2_t1_2", 90), ("l2_t2_2", 90)):
+            k = "%s.%s.weight" % (mod, lay)
+            if k not in named:
+                continue
+            W = named[k].detach()
+            out[k] = torch.cat((W[:, :n_in], W[:, n_in + 4:]), dim=1).contiguous()
+            out[k + "_pos"] = W[:, n_in:n_in + 4].contiguous()
     return out
 
 
@@ -425,9 +388,9 @@ class SpatialAttention(nn.Module):
         edge_attr = (x_query[i] - x_context[j]) / self.scale_rel
         x_j = inpts[j]
         cat = torch.cat((x_j, edge_attr), dim=-1)
-        q = _dense(self.f_queries, edge_attr, self).view(-1, H, L)
-        c = _dense(self.f_context, cat, self).view(-1, H, L)
-        v = _dense(self.f_values, cat, self).view(-1, H, L)
+        q = self.f_queries(edge_attr).view(-1, H, L)
+        c = self.f_context(cat).view(-1, H, L)
+        v = self.f_values(cat).view(-1, H, L)
         alpha = self.activate1((q * c).sum(-1) / self.scale)                       # [E, H]
         # segment softmax over the k edges of each query (edges are grouped by query, k each)
         alpha = alpha.view(-1, kk, H)
@@ -461,12 +424,12 @@ class TemporalAttention(nn.Module):
 
     def forward(self, inpts, t_query):
         H, L = self.n_heads, self.n_latent
-        context = _dense(self.f_context_2, self.activate1(_dense(self.f_context_1, inpts, self)), self).view(-1, H, L)
-        values = _dense(self.f_values_2, self.activate2(_dense(self.f_values_1, inpts, self)), self).view(-1, H, L)
+        context = self.f_context_2(self.activate1(self.f_context_1(inpts))).view(-1, H, L)
+        values = self.f_values_2(self.activate2(self.f_values_1(inpts))).view(-1, H, L)
         query = self.temporal_query_2(self.activate3(self.temporal_query_1(t_query / self.scale_t))).view(-1, H, L)
         score = torch.einsum("nhl,thl->nth", context, query) / self.scale           # [N, T, H]
         z = torch.einsum("nth,nhl->ntl", score, values) / H                         # mean over heads
-        return _dense(self.proj_2, self.activate5(_dense(self.proj_1, self.activate4(z), self)), self)
+        return self.proj_2(self.activate5(self.proj_1(self.activate4(z))))
 
 
 def _mean_over_sta(x, sta_nbr, n_sta, n_grid):
@@ -488,7 +451,8 @@ def _mean_over_src(x, src_nbr, n_sta, n_grid):
 
 
 class BipartiteGraphReadOutOperator(nn.Module):
-    """Association head, module.py:333-352 (PyTorch-ROCm restatement; not part of the HIP hot path).
+    """Association head, module.py:333-352: parameters + a literal restatement for CPU checks against the reference fixtures
+    (tests/test_assoc_cpu.py). GPU calls run genie_assoc_fwd / genie_assoc_train_fwd, never this forward.
     `A_Lg_in_src.edge_index = [g(p); p]`: one edge per product node, so the 'add' aggregation is the identity."""
 
     def __init__(self, ndim_in, ndim_out, ndim_edges=3):
@@ -499,29 +463,15 @@ class BipartiteGraphReadOutOperator(nn.Module):
         self.activate2 = nn.PReLU()
 
     def forward(self, inpt, edge_attr, mask, n_sta):
-        if inpt.is_cuda and not (torch.is_grad_enabled() and inpt.requires_grad):
-            return self._forward_blocked(inpt, edge_attr, mask, n_sta)
         g = torch.arange(edge_attr.shape[0], device=edge_attr.device) // n_sta
         msg = mask[g] * self.activate1(self.fc1(torch.cat((inpt[g], edge_attr), dim=-1)))            # :352
         return self.activate2(self.fc2(msg)), mask[g]                                                # :348
 
-    def _forward_blocked(self, inpt, edge_attr, mask, n_sta):
-        """Same arithmetic without materialising the [P, 33] concatenation: the source-node part of fc1 is computed once per
-        source node and broadcast over its stations (p = g * n_sta + s)."""
-        G, C = inpt.shape
-        W = self.fc1.weight
-        per_src = torch.addmm(self.fc1.bias, inpt, W[:, :C].t())                                     # [G, 30]
-        t = (edge_attr @ W[:, C:].t()).view(G, n_sta, -1)
-        t += per_src.view(G, 1, -1)
-        msg = torch.nn.functional.prelu(t, self.activate1.weight)
-        msg *= mask.view(G, 1, 1)
-        out = torch.nn.functional.prelu(self.fc2(msg.view(G * n_sta, -1)), self.activate2.weight)
-        return out, mask.repeat_interleave(n_sta, dim=0)
-
 
 class DataAggregationAssociationPhase(nn.Module):
-    """Association head, module.py:356-403: the dual-graph aggregation of DataAggregation on a 50-channel input, with
-    l1_t1_1 / l1_t2_1 applied (module.py:395-396). Structured form on the Cartesian product (base kNN tables)."""
+    """Association head, module.py:356-403 (and its Edges form, :407-480, with `n_edge = 4`): parameters + a structured restatement
+    on the Cartesian product (base kNN tables) for CPU checks against the reference fixtures. GPU calls run genie_assoc_fwd /
+    genie_assoc_train_fwd, never this forward."""
 
     def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5, n_edge=0):
         super().__init__()
@@ -543,66 +493,15 @@ class DataAggregationAssociationPhase(nn.Module):
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def _forward_blocked(self, s_in, latent, mask1, mask2, n_sta, n_grid, hip):
-        """GPU formulation of `forward` with the same arithmetic and no materialised concatenations: every Linear on
-        cat(a, b, ...) is a chain of in-place GEMMs on the column blocks of its weight, the two halves of a layer share one
-        output buffer, hidden rows are 32 wide so that genie_nbr_mean reads them in place, and mask1 (one value per source
-        node) enters as a broadcast rank-1 term. 21.7 ms (index gathers) -> 10.1 ms (HIP means) -> ~4 ms at config 2."""
-        F = torch.nn.functional
-        P = s_in.shape[0]
-        m1g = mask1.view(n_grid, n_sta, 1)[:, :1, :]                                                 # [G,1,1]: constant per source node
-
-        def pad_rows(W, b):                                                                            # 30 -> 32 output rows
-            return F.pad(W, (0, 0, 0, 2)), F.pad(b, (0, 2))
-
-        def add_mask1(t, wcol):                                                                        # t [P, C] += mask1 * wcol
-            t.view(n_grid, n_sta, -1).add_(m1g * wcol.view(1, 1, -1))
-
-        W0, ns = self.init_trns.weight, s_in.shape[1]
-        t = torch.addmm(self.init_trns.bias, s_in, W0[:, :ns].t())
-        t.addmm_(latent, W0[:, ns:ns + 30].t())
-        t.addmm_(mask2, W0[:, ns + 31:].t())
-        add_mask1(t, W0[:, ns + 30])
-        tr = F.prelu(t, self.activate.weight)                                                          # [P,30]
-        W, b = pad_rows(self.l1_t1_1.weight, self.l1_t1_1.bias)
-        q1 = F.prelu(torch.addmm(b, tr, W.t()), self.activate11.weight)                                # [P,32]
-        W, b = pad_rows(self.l1_t2_1.weight, self.l1_t2_1.bias)
-        q2 = F.prelu(torch.addmm(b, tr, W.t()), self.activate12.weight)
-        a1, a2 = hip.nbr_mean(q1, q2)
-
-        def layer(x, n_x, m_a, m_b, l1, l2):
-            """PReLU-less cat(l1(cat(x, m_a, mask)), l2(cat(x, m_b, mask))) -> [P, 2 * out]"""
-            W1, W2 = l1.weight, l2.weight
-            no = W1.shape[0]
-            out = torch.addmm(torch.cat((l1.bias, l2.bias)), x, torch.cat((W1[:, :n_x], W2[:, :n_x])).t())
-            z = W1.new_zeros((no, 32))
-            Wa = torch.cat((F.pad(W1[:, n_x:n_x + 30], (0, 2)), z))                                   # [2 no, 32], second half zero
-            Wb = torch.cat((z, F.pad(W2[:, n_x:n_x + 30], (0, 2))))
-            out.addmm_(m_a, Wa.t())
-            out.addmm_(m_b, Wb.t())
-            out.addmm_(mask2, torch.cat((W1[:, n_x + 31:], W2[:, n_x + 31:])).t())
-            add_mask1(out, torch.cat((W1[:, n_x + 30], W2[:, n_x + 30])))
-            return out
-
-        tr = F.prelu(layer(tr, 30, a1, a2, self.l1_t1_2, self.l1_t2_2), self.activate1.weight)       # [P,60]
-        W, b = pad_rows(self.l2_t1_1.weight, self.l2_t1_1.bias)
-        r1 = F.prelu(torch.addmm(b, tr, W.t()), self.activate21.weight)
-        W, b = pad_rows(self.l2_t2_1.weight, self.l2_t2_1.bias)
-        r2 = F.prelu(torch.addmm(b, tr, W.t()), self.activate22.weight)
-        b1, b2 = hip.nbr_mean(r1, r2)
-        return F.prelu(layer(tr, 60, b1, b2, self.l2_t1_2, self.l2_t2_2), self.activate2.weight)     # [P,30]
-
-    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid, hip=None):
-        """`hip`: an engine.HipPath on the same graphs -> the four neighbour means run as genie_nbr_mean (HIP) instead of
-        materialised index gathers (21 -> ~6 ms at config 2); the Linears stay on PyTorch-ROCm."""
-        grad = torch.is_grad_enabled() and tr.requires_grad
-        if hip is not None and tr.is_cuda and not grad and self.l1_t1_2.weight.shape[1] == 65:
-            return self._forward_blocked(tr, latent, mask1, mask2, n_sta, n_grid, hip)
-
+    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid, edge_means=None):
+        """`edge_means` = (m_sta [S, 4], m_src [G, 4]): the mean edge position feature of every base node's in-neighbourhood; on the
+        product graph the mean over a node's messages of cat(x_j, e_ij) is cat(mean x_j, m[node]) (module.py:462-480)."""
         def means(x1, x2):
-            if hip is not None and x1.is_cuda:
-                return _NbrMean.apply(x1, x2, hip) if grad else hip.nbr_mean(x1, x2)
-            return _mean_over_sta(x1, sta_nbr, n_sta, n_grid), _mean_over_src(x2, src_nbr, n_sta, n_grid)
+            a, b = _mean_over_sta(x1, sta_nbr, n_sta, n_grid), _mean_over_src(x2, src_nbr, n_sta, n_grid)
+            if edge_means is not None:
+                a = torch.cat((a, edge_means[0].repeat(n_grid, 1)), dim=1)
+                b = torch.cat((b, edge_means[1].repeat_interleave(n_sta, dim=0)), dim=1)
+            return a, b
 
         mask = torch.cat((mask1, mask2), dim=-1)
         tr = self.activate(self.init_trns(torch.cat((tr, latent, mask), dim=-1)))
@@ -614,35 +513,14 @@ class DataAggregationAssociationPhase(nn.Module):
                                          self.l2_t2_2(torch.cat((tr, b2, mask), dim=1))), dim=1))
 
 
-class _Gather(torch.autograd.Function):
-    """x[idx] whose backward is one index_add_ (atomic adds) instead of PyTorch's sort-based index_put: the arrival-association head
-    gathers every pick's rows ~80 times over (pick pairs x sources), where the sort-based kernel took 38 of the 70 ms of a config-3
-    training step. Used only by the one head whose backward still runs under autograd (StationSourceAttentionMergedPhases)."""
-
-    @staticmethod
-    def forward(ctx, x, idx):
-        ctx.n = x.shape[0]
-        ctx.save_for_backward(idx)
-        return x[idx]
-
-    @staticmethod
-    def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
-        return torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device).index_add_(0, idx, g.contiguous()), None
-
-
-def _gather(x, idx):
-    return _Gather.apply(x, idx) if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else x[idx]
-
-
 def _segment_softmax(src, index, n):
     """torch_geometric.utils.softmax semantics: per-segment max subtraction, exp, / (sum + 1e-16)."""
     idx = index.view(-1, 1).expand_as(src)
     mx = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype, device=src.device).scatter_reduce(
         0, idx, src, reduce="amax", include_self=True)
-    out = (src - _gather(mx, index)).exp()
+    out = (src - mx[index]).exp()
     den = torch.zeros((n, src.shape[1]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
-    return out / (_gather(den, index) + 1e-16)
+    return out / (den[index] + 1e-16)
 
 
 class LocalSliceLgCollapse(nn.Module):
@@ -738,10 +616,10 @@ class StationSourceAttentionMergedPhases(nn.Module):
         fs = torch.cat((torch.exp(-0.5 * rs ** 2 / eps ** 2), torch.sign(rs), phase[e0]), dim=1)
         self_link = (e0 == torch.remainder(e1, e0max)).view(-1, 1).to(dt_)
         null_link = (e0 == e0max).view(-1, 1).to(dt_)
-        x_j = _gather(arrival, e0)
-        d = lambda lin, x: _dense(lin, x, self)       # (weight gradients of the edge-sized Linears by genie_linear_bwd_wb under autograd)
+        x_j = arrival[e0]
+        d = lambda lin, x: lin(x)
         ctx = d(self.f_src_context_2, self.activate1(d(self.f_src_context_1,
-            torch.cat((_gather(src_embed, sidx), stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
+            torch.cat((src_embed[sidx], stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
         qry = d(self.f_arrival_query_2, self.activate2(d(self.f_arrival_query_1, torch.cat((x_j, fp, fs), dim=1)))).view(-1, H, L)
         val = d(self.f_values_2, self.activate3(d(self.f_values_1, torch.cat((x_j, fp, fs, self_link, null_link), dim=1)))).view(-1, H, L)
         alpha = _segment_softmax((qry * ctx).sum(-1) / math.sqrt(L), e1, n_arv * n_src)
@@ -755,8 +633,8 @@ class GCN_Detection_Network_extended(nn.Module):
     `forward_fixed_source` (module.py:999) runs DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3
     as ONE fused call into libgenie_hip (`genie_path_fwd`) on the graphs cached by `set_adjacencies`, then the
     read-out heads (`genie_readout_grid` / `genie_readout_query`). `use_absolute_pos=True` (config.yaml:92, +6 input
-    channels) and `use_updated_model_definition=True` (config.yaml:95) are served for `forward_fixed_source`; their
-    4-output `forward` / `forward_fixed` raise.
+    channels) and `use_updated_model_definition=True` (config.yaml:95) are served for `forward_fixed_source` and for the
+    4-output `forward` / `forward_fixed` in eval mode; training steps: default model definition.
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
@@ -791,11 +669,6 @@ class GCN_Detection_Network_extended(nn.Module):
         self._path_params = None
         self._edge_attr = None
 
-    def _share_engine(self):
-        # the G- / Q-sized heads take their Linear weight gradients from the HIP library in training steps (`_dense`)
-        for m in (self.SpatialAttention, self.TemporalAttention, self.Arrivals):
-            m._hip = self._hip
-
     # ---- graphs --------------------------------------------------------------------------------
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         order = _engine.sfc_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
@@ -803,7 +676,6 @@ class GCN_Detection_Network_extended(nn.Module):
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev, sta_order=sta_order)
-        self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         if self.use_updated_model_definition:
@@ -864,7 +736,6 @@ class GCN_Detection_Network_extended(nn.Module):
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)
-        self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
@@ -893,7 +764,6 @@ class GCN_Detection_Network_extended(nn.Module):
         sub = _engine.subgraph_csr_device(pairs, n_grid, _engine.csr_from_table(sta_tab), src_csr)
         order = _engine.sfc_order(pos_src.detach().cpu().numpy())
         self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
-        self._share_engine()
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         if edge_attr is None:
@@ -1021,69 +891,58 @@ class GCN_Detection_Network_extended(nn.Module):
 
     def forward_fixed(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
                       x_query_src_cart, t_query, tq_sample, trv_out_q):
-        """module.py:963-997: (y, x, arv_p, arv_s). The shared front (DataAggregation -> Bipartite_ReadIn ->
-        SpatialAggregation1..3 and the two read-outs) runs in HIP; the association heads (pick-count
-        dependent, host-built edge lists) are a PyTorch-ROCm restatement of module.py:333-775."""
-        if self.use_updated_model_definition:
-            raise NotImplementedError("the 4-output forward of the use_updated_model_definition class (module.py:1128-1161) "
-                                      "has different association heads; only forward_fixed_source is provided")
-        if self.use_absolute_pos:
-            raise NotImplementedError("forward_fixed with use_absolute_pos: only forward_fixed_source is provided")
+        """module.py:963-997 (and :1128-1161 of the use_updated_model_definition class): (y, x, arv_p, arv_s). Every module runs
+        in HIP: the shared front and read-outs, the P-sized association heads (genie_assoc_fwd; under use_updated_model_definition
+        / use_absolute_pos their static per-station / per-source-node terms are added inside the same kernels), LocalSliceLgCollapse
+        P / S (genie_lslc_fwd) and the arrival head (genie_arrivals_fwd). In train() mode with gradients enabled the same modules
+        differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; default model definition)."""
         if getattr(self, "_sta_tab", None) is None:
             raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
                                       "set_adjacencies_base): only forward_fixed_source is available here")
-        S, G = self._hip.n_sta, self._hip.n_grid
-        if self._differentiable():       # training step (train_GENIE_model.py:1786): the shared path in HIP in both directions
+        hp = self._hip
+        if not getattr(hp, "assoc_ready", False) and hp is not None:
+            hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        train = self._differentiable()
+        if train:       # training step (train_GENIE_model.py:1786): the shared path in HIP in both directions
             y, x, x_spatial, y_latent, x_latent, x_src = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True,
                                                                           x_query_src_cart=x_query_src_cart)      # :973-982
         else:
             x_spatial, x_latent, _ = self._path(Slice, Mask, x_temp_cuda_cart, want_x_latent=True)  # :973-977
-            y, y_latent = self._hip.readout_grid_latent(x_spatial, t_query)                          # :978-979
+            y, y_latent = hp.readout_grid_latent(x_spatial, t_query)                                 # :978-979
             knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
-            x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)     # :980,982
+            x = hp.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)            # :980,982
             knn_src = _engine.knn_device(x_temp_cuda_cart, x_query_src_cart, 10)
-            x_src = self._hip.spatial_attention(x_spatial, x_temp_cuda_cart, x_query_src_cart, knn_src, t_query)   # :981
+            x_src = hp.spatial_attention(x_spatial, x_temp_cuda_cart, x_query_src_cart, knn_src, t_query)   # :981
+        if not getattr(hp, "assoc_ready", False):
+            raise _engine._lib.GenieHipError("the association heads' parameters are not in the HIP context (unexpected shapes)")
         mask_out = 1.0 * (y[:, :, 0].detach().max(1, keepdim=True)[0] > 0.01)                        # :985
         Maskf = _engine._f32(Mask, "Mask")
-        if not self._differentiable() and getattr(self._hip, "assoc_ready", False):
-            # :986-990 as three P-sized HIP passes (genie_assoc_fwd)
-            s = self._hip.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
-        elif self._differentiable() and getattr(self._hip, "assoc_ready", False) and y_latent.is_cuda:
-            # training step: the same kernels with their pre-activations kept, backward in HIP (`_AssocTrain`)
-            s = _AssocTrain.apply(y_latent, mask_out, x_latent.detach(), Maskf, self._edge_attr, self._hip,
+        if train:       # the kernels of genie_assoc_fwd with their pre-activations kept, backward in HIP
+            s = _AssocTrain.apply(y_latent, mask_out, x_latent.detach(), Maskf, self._edge_attr, hp,
                                   *[self._path_params[n] for n in TRAIN_ASSOC_PARAMS])
-        else:       # CPU restatement (tests) / contexts without association-head weights
-            s, mask_out_1 = self.BipartiteGraphReadOutOperator(y_latent, self._edge_attr, mask_out, S)   # :986
-            s = self.DataAggregationAssociationPhase(s, x_latent.detach(), mask_out_1, Maskf, self._sta_tab, self._src_tab, S, G,
-                                                     hip=self._hip)                                  # :990
-        tl = self.tlatent
-        if getattr(self._hip, "assoc_ready", False) and len(tpick) > 0 and s.is_cuda:
-            # :991-992 in HIP (genie_lslc_fwd); the int32 copies of the static time-pointer tables are cached with the tables
-            key = (self.A_edges_p.data_ptr(), self.A_edges_s.data_ptr(), self.A_edges_p._version, self.A_edges_s._version)
-            if getattr(self, "_a_edges_key", None) != key:
-                self._a_edges_i32 = (self.A_edges_p.to(s.device).to(torch.int32).contiguous(),
-                                     self.A_edges_s.to(s.device).to(torch.int32).contiguous())
-                self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
-            ip32 = ipick.to(torch.int32)
-            eps = self.LocalSliceLgCollapseP.eps
-            if self._differentiable():      # training step: the same kernels, backward in HIP (`_LslcTrain`)
-                arv_p, arv_s = _LslcTrain.apply(s, self._a_edges_i32[0], self._a_edges_i32[1], self.dt_partition, _engine._f32(tpick, "tpick"),
-                                                ip32, _engine._f32(phase_label, "phase_label"), _engine._f32(tl, "tlatent"), eps, self._hip,
-                                                *[self._path_params[n] for n in TRAIN_LSLC_PARAMS])
-            else:
-                arv_p = self._hip.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
-                arv_s = self._hip.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
+        else:           # :986-990 as three P-sized HIP passes
+            s = hp.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
+        n_src = int(x_query_src_cart.shape[0])
+        if len(tpick) == 0:      # no pick in the window: the reference returns two empty [n_src, 0, 1] tensors
+            e = s.new_zeros((n_src, 0, 1))
+            return y, x, e, e.clone()
+        # :991-992 (genie_lslc_fwd); the int32 copies of the static time-pointer tables are cached with the tables
+        key = (self.A_edges_p.data_ptr(), self.A_edges_s.data_ptr(), self.A_edges_p._version, self.A_edges_s._version)
+        if getattr(self, "_a_edges_key", None) != key:
+            self._a_edges_i32 = (self.A_edges_p.to(s.device).to(torch.int32).contiguous(),
+                                 self.A_edges_s.to(s.device).to(torch.int32).contiguous())
+            self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
+        ip32, tl, eps = ipick.to(torch.int32), self.tlatent, self.LocalSliceLgCollapseP.eps
+        if train:
+            arv_p, arv_s = _LslcTrain.apply(s, self._a_edges_i32[0], self._a_edges_i32[1], self.dt_partition, _engine._f32(tpick, "tpick"),
+                                            ip32, _engine._f32(phase_label, "phase_label"), _engine._f32(tl, "tlatent"), eps, hp,
+                                            *[self._path_params[n] for n in TRAIN_LSLC_PARAMS])
+            arv = _ArrivalsTrain.apply(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps, hp,
+                                       *[self._path_params[n] for n in TRAIN_ARR_PARAMS])              # :993
         else:
-            arv_p = self.LocalSliceLgCollapseP(self.A_edges_p, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 0].reshape(-1, 1))
-            arv_s = self.LocalSliceLgCollapseS(self.A_edges_s, self.dt_partition, tpick, ipick, phase_label, s, tl[:, 1].reshape(-1, 1))
-        if not self._differentiable() and getattr(self._hip, "assoc_ready", False) and len(tpick) > 0:
-            arv = self._hip.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)   # :993 in HIP
-        elif getattr(self._hip, "assoc_ready", False) and len(tpick) > 0 and arv_p.is_cuda:
-            # training step: the same kernels keeping the per-target softmax state, backward in HIP (`_ArrivalsTrain`)
-            arv = _ArrivalsTrain.apply(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps, self._hip,
-                                       *[self._path_params[n] for n in TRAIN_ARR_PARAMS])
-        else:       # CPU restatement (tests), or a context without association-head weights
-            arv = self.Arrivals(x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label)   # :993
+            arv_p = hp.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
+            arv_s = hp.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
+            arv = hp.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 
     def invalidate_graph_cache(self):

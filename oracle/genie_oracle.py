@@ -337,17 +337,25 @@ def bipartite_read_out(w, y_latent, edge_attr, mask_src, n_sta, pre="BipartiteGr
     return act(linear(msg, w, pre + ".fc2"), w, pre + ".activate2"), mask_src[g]
 
 
-def data_aggregation_association(w, s, latent, mask1, mask2, A_in_sta, A_in_src, pre="DataAggregationAssociationPhase"):
-    """module.py:389-403 (unlike DataAggregation, l1_t1_1 / l1_t2_1 ARE applied before the layer-1 activations)."""
+def data_aggregation_association(w, s, latent, mask1, mask2, A_in_sta, A_in_src, pre="DataAggregationAssociationPhase", pos_rel=None):
+    """module.py:389-403 (unlike DataAggregation, l1_t1_1 / l1_t2_1 ARE applied before the layer-1 activations). `pos_rel` =
+    (pos_rel_sta, pos_rel_src): DataAggregationAssociationPhaseEdges (module.py:444-480), every message carries its edge's
+    position features (l?_t?_2 have 4 more input columns, between the mean and the mask)."""
+    if pos_rel is None:
+        mean1 = lambda x: propagate_mean(x, A_in_sta)
+        mean2 = lambda x: propagate_mean(x, A_in_src)
+    else:
+        mean1 = lambda x: propagate_mean_edges(x, pos_rel[0], A_in_sta)                              # :462, :476
+        mean2 = lambda x: propagate_mean_edges(x, pos_rel[1], A_in_src)                              # :463, :480
     mask = torch.cat((mask1, mask2), dim=-1)                                                          # :391
     tr = act(linear(torch.cat((s, latent, mask), dim=-1), w, pre + ".init_trns"), w, pre + ".activate")   # :392-393
-    a1 = propagate_mean(act(linear(tr, w, pre + ".l1_t1_1"), w, pre + ".activate11"), A_in_sta)       # :395
-    a2 = propagate_mean(act(linear(tr, w, pre + ".l1_t2_1"), w, pre + ".activate12"), A_in_src)       # :396
+    a1 = mean1(act(linear(tr, w, pre + ".l1_t1_1"), w, pre + ".activate11"))                          # :395
+    a2 = mean2(act(linear(tr, w, pre + ".l1_t2_1"), w, pre + ".activate12"))                          # :396
     tr1 = linear(torch.cat((tr, a1, mask), dim=1), w, pre + ".l1_t1_2")
     tr2 = linear(torch.cat((tr, a2, mask), dim=1), w, pre + ".l1_t2_2")
     tr = act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate1")                                     # :397
-    b1 = propagate_mean(act(linear(tr, w, pre + ".l2_t1_1"), w, pre + ".activate21"), A_in_sta)       # :399
-    b2 = propagate_mean(act(linear(tr, w, pre + ".l2_t2_1"), w, pre + ".activate22"), A_in_src)       # :400
+    b1 = mean1(act(linear(tr, w, pre + ".l2_t1_1"), w, pre + ".activate21"))                          # :399
+    b2 = mean2(act(linear(tr, w, pre + ".l2_t2_1"), w, pre + ".activate22"))                          # :400
     tr1 = linear(torch.cat((tr, b1, mask), dim=1), w, pre + ".l2_t1_2")
     tr2 = linear(torch.cat((tr, b2, mask), dim=1), w, pre + ".l2_t2_2")
     return act(torch.cat((tr1, tr2), dim=1), w, pre + ".activate2")                                   # :401
@@ -421,14 +429,23 @@ def station_source_attention(w, n_src, stime, src_embed, trv_src, arrival_p, arr
 
 def forward_fixed(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src, A_edges_p, A_edges_s, dt_partition,
                   tlatent, tpick, ipick, phase_label, x_grid_cart, x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q,
-                  n_sta):
-    """forward_fixed (module.py:963-997): (y, x, arv_p, arv_s)."""
+                  n_sta, pos_rel=None, abs_pos=None):
+    """forward_fixed (module.py:963-997): (y, x, arv_p, arv_s). `pos_rel` = (pos_rel_sta, pos_rel_src) per product edge: the
+    use_updated_model_definition class (module.py:1128-1161); `abs_pos` = (locs, A_src_in_sta): use_absolute_pos (the scaled
+    station / source positions appended to Slice, :969-970, and to the association embedding, :987-988)."""
+    scaled = None
+    if abs_pos is not None:
+        locs, A_src_in_sta = abs_pos
+        scaled = torch.cat((locs[A_src_in_sta[0]] / (3.0 * SCALE_REL), x_grid_cart[A_src_in_sta[1]] / (3.0 * SCALE_REL)), dim=1)
+        Slice = torch.cat((Slice, scaled), dim=1)                                                      # :969-970
     o = forward_fixed_source(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src, x_grid_cart, x_query_cart,
-                             t_query, full=True)
+                             t_query, full=True, pos_rel=pos_rel)
     x_src = spatial_attention(w, o["sa3"], x_query_src_cart, x_grid_cart)                              # :981
     mask_out = 1.0 * (o["y"][:, :, 0].max(1, keepdim=True)[0] > 0.01)                                  # :985
     s, m1 = bipartite_read_out(w, o["y_latent"], edge_attr, mask_out.to(Slice.dtype), n_sta)           # :986
-    s = data_aggregation_association(w, s, o["x_latent"].detach(), m1, Mask, A_in_sta, A_in_src)       # :990 (x_latent.detach())
+    if scaled is not None:
+        s = torch.cat((s, scaled), dim=1)                                                              # :987-988
+    s = data_aggregation_association(w, s, o["x_latent"].detach(), m1, Mask, A_in_sta, A_in_src, pos_rel=pos_rel)   # :990 (x_latent.detach())
     arv_p = local_slice_collapse(w, A_edges_p, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 0:1], "LocalSliceLgCollapseP")
     arv_s = local_slice_collapse(w, A_edges_s, dt_partition, tpick, ipick, phase_label, s, tlatent[:, 1:2], "LocalSliceLgCollapseS")
     arv = station_source_attention(w, x_query_src_cart.shape[0], tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick,

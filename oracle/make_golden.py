@@ -296,6 +296,18 @@ def main_abspos():
              keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
 
 
+def main_assoc_variant(flag):
+    """`python oracle/make_golden.py --assoc-edges` / `--assoc-abspos`: the 4-output `forward_fixed` of the live model with
+    `use_updated_model_definition: True` (DataAggregationAssociationPhaseEdges, module.py:407-480: the mean edge feature enters
+    l?_t?_2) resp. `use_absolute_pos: True` (positions appended to the association embedding, module.py:987-988); a separate process
+    each because the flags are fixed when the reference is imported."""
+    ref = _import_reference(updated_definition=(flag == "edges"), absolute_pos=(flag == "abspos"))
+    from genie_amd import synthetic as syn
+    geom = syn.Geometry(18, 50, L=70e3, n_query=20, seed=111 if flag == "edges" else 121)     # uniform 8 / 15 degrees, partial last tile
+    win = syn.make_window(geom, 220, seed=112 if flag == "edges" else 122)
+    run_assoc_case(ref, "assoc_%s_18x50" % flag, geom, win)
+
+
 def main_subgraph():
     """`python oracle/make_golden.py --subgraph`: the live model on an irregular product graph (`use_subgraph: True`): every
     source node keeps its 6 nearest stations plus a few random ones, as the reference's builder keeps the k nearest pairs plus
@@ -402,6 +414,10 @@ def main():
         return main_subgraph()
     if "--abspos" in sys.argv:
         return main_abspos()
+    if "--assoc-edges" in sys.argv:
+        return main_assoc_variant("edges")
+    if "--assoc-abspos" in sys.argv:
+        return main_assoc_variant("abspos")
     if "--assoc" in sys.argv:
         return main_assoc()
     ref = _import_reference()

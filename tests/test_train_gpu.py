@@ -56,7 +56,7 @@ def _oracle_curve(w0, geom, samples, n_steps):
 
 @pytest.mark.parametrize("shape", ["7x45"])
 def test_training_loss_curve_matches_oracle_adam(shape):
-    """24 Adam steps over a batch of two samples (same station set and grid, different pick windows): the loss of every step
+    """20 Adam steps over a batch of two samples (same station set and grid, different pick windows): the loss of every step
     within 1e-4 relative of the oracle's, the loss goes down, and the trained weights agree. (The 200-station curve is
     test_config3_station_count_loss_curve_matches_oracle_adam; a 20 x 500 curve was part of this test until round 3: 9e-8.)"""
     S, G, n_picks, nq = {"7x45": (7, 45, 90, 20), "20x500": (20, 500, 500, 300)}[shape]
@@ -69,7 +69,7 @@ def test_training_loss_curve_matches_oracle_adam(shape):
     net.train()
     opt = train.make_optimizer(net)
     batch = [_inputs(geom, smp, DEV) for smp in samples]
-    n_steps = 24
+    n_steps = 20
     got = [train.train_step(net, opt, batch) for _ in range(n_steps)]
     want, w = _oracle_curve(w0, geom, samples, n_steps)
     rel = [abs(a - b) / abs(b) for a, b in zip(got, want)]
@@ -78,7 +78,7 @@ def test_training_loss_curve_matches_oracle_adam(shape):
     assert max(rel) <= 1e-4, rel
     assert got[-1] < 0.9 * got[0]
     # the trained weights themselves: Adam's normalised update amplifies tiny gradient differences where a gradient is ~0,
-    # so compare the tensors that moved (24 steps x 1e-3) to 2 % of the distance they moved
+    # so compare the tensors that moved (20 steps x 1e-3) to 2 % of the distance they moved
     moved = 0
     for k, p in net.named_parameters():
         d = float((w[k].detach() - w0[k]).abs().max())
@@ -283,10 +283,10 @@ def test_config3_full_size_training_steps_200x10000():
 
 
 def test_config3_station_count_loss_curve_matches_oracle_adam():
-    """Loss-curve parity at the config-3 station count (200 stations x 300 source nodes: a size the CPU oracle affords in a minute;
-    200 x 500 measured 1.0e-7 in round 3): 20 Adam steps of the reference's 4-output step, every loss within 1e-4 relative of the
-    oracle's autograd + torch.optim.Adam."""
-    S, G, n_picks, nq = 200, 300, 2500, 200
+    """Loss-curve parity at the config-3 station count (200 stations x 120 source nodes: a size the CPU oracle affords in 20 s;
+    200 x 300 and 200 x 500 measured 1.0e-7 in round 3): 20 Adam steps of the reference's 4-output step, every loss within 1e-4
+    relative of the oracle's autograd + torch.optim.Adam."""
+    S, G, n_picks, nq = 200, 120, 1200, 100
     geom = synthetic.Geometry(S, G, L=300e3, n_query=nq, seed=1)
     samples = [synthetic.training_sample(geom, n_picks, seed=3, window=0)]
     w0 = Case("tiny_6x40").weights
@@ -299,6 +299,6 @@ def test_config3_station_count_loss_curve_matches_oracle_adam():
     got = [train.train_step(net, opt, batch) for _ in range(n_steps)]
     want, _ = _oracle_curve(w0, geom, samples, n_steps)
     rel = [abs(a - b) / abs(b) for a, b in zip(got, want)]
-    print("loss curve 200x300: first %.6g last %.6g (oracle %.6g -> %.6g), max relative deviation %.3g" % (got[0], got[-1], want[0], want[-1], max(rel)))
+    print("loss curve 200x120: first %.6g last %.6g (oracle %.6g -> %.6g), max relative deviation %.3g" % (got[0], got[-1], want[0], want[-1], max(rel)))
     assert max(rel) <= 1e-4, rel
     assert got[-1] < got[0]
