@@ -2574,14 +2574,44 @@ __device__ __forceinline__ f32x4 outer16(f32x4 acc, f32x4 at, f32x4 bt) {       
     for (int s = 0; s < 4; ++s) acc = MFMA16(at[s], bt[s], acc);
     return acc;
 }
-// transposed mean: sum over the out-edges e of `node` of w_e * rows[col_e], rows of 16 floats addressed by `rowof(col)`
-template <typename F>
-__device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, const float* w, int node, bool uniform, F rowof) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+// transposed mean: sum over the out-edges e of `node` of w_e * rows[col_e], rows of 16 floats addressed by `rowof(block, col)`,
+// for NB row blocks at once. The edges are taken EB at a time (indices, weights and the EB x NB rows of a batch are all in
+// flight together; a lane past its last edge re-reads edge 0 with weight zero): with one index -> row load chain per edge the
+// backward passes spent ~80 % of their time waiting on these gathers (one wave per SIMD, nothing to switch to). The sum keeps
+// the edge order.
+template <int NB, int EB = 4, typename F>
+__device__ __forceinline__ void tmean_n(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const float* __restrict__ w,
+                                        int node, bool uniform, F rowof, f32x4 (&out)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     int eb = rp[node], ee = rp[node + 1];
     if (uniform) { eb = __builtin_amdgcn_readfirstlane(eb); ee = __builtin_amdgcn_readfirstlane(ee); }
-    for (int e = eb; e < ee; ++e) s += rowof(col[e]) * w[e];
-    return s;
+    for (int e = eb; uniform ? (e < ee) : (bool)__any(e < ee); e += EB) {
+        int c[EB];
+        float ww[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const bool ok = e + k < ee;
+            const int ei = ok ? e + k : 0;
+            c[k] = col[ei];
+            ww[k] = ok ? w[ei] : 0.f;
+        }
+        f32x4 r[NB][EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, c[k]);
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * ww[k];
+    }
+}
+template <typename F>
+__device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, const float* w, int node, bool uniform, F rowof) {
+    f32x4 o[1];
+    tmean_n<1, 8>(rp, col, w, node, uniform, [&](int, int c) { return rowof(c); }, o);
+    return o[0];
 }
 __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
                                                const float* scal, int n_scal, int lane, int j, int q) {
@@ -2842,11 +2872,13 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
         for (int b = 0; b < 2; ++b) {
             z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
             h0[b] = prelu4u(z0[b], a0);
-            tmd1[b] = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                            [&](int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }) * vm;
-            tmd2[b] = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                            [&](int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }) * vm;
         }
+        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
         f32x4 dz0[2];
@@ -2900,8 +2932,18 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + o;
     float s = 0.f;
-    if (idx < stride)
-        for (int wv = grp; wv < n_waves; wv += 8) s += part[(size_t)wv * stride + idx];
+    if (idx < stride) {      // four independent partial sums (loads in flight), combined in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int wv = grp;
+        for (; wv + 24 < n_waves; wv += 32) {
+            s0 += part[(size_t)wv * stride + idx];
+            s1 += part[(size_t)(wv + 8) * stride + idx];
+            s2 += part[(size_t)(wv + 16) * stride + idx];
+            s3 += part[(size_t)(wv + 24) * stride + idx];
+        }
+        for (; wv < n_waves; wv += 8) s0 += part[(size_t)wv * stride + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
     ps[grp][o] = s;
     __syncthreads();
     if (grp != 0 || idx >= stride) return;
@@ -6003,7 +6045,7 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 }
 
 namespace {
-int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }
+int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }      // 2 workgroups per CU (1: +10 %, 3: +6 %, 4: +1 % step time)
 size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 12 * 16 + 16); }
 int train_check(const genie_ctx* c, const char* who) {
     if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");

@@ -109,11 +109,13 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
             tr[b] = prelu4u(zt[b], a0);
             qp[0][b] = ldb(a.save, AV_Q + b, P, p, q);
             qp[1][b] = ldb(a.save, AV_Q + 2 + b, P, p, q);
-            tmd1[b] = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                            [&](int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }) * vm;
-            tmd2[b] = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                            [&](int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }) * vm;
         }
+        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
         // d q = l1_t?_2[:, 30:60]^T (transposed mean of dt), through PReLU11' / PReLU12' -> d(l1_t?_1 output)

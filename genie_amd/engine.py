@@ -303,28 +303,40 @@ class HipPath(object):
 
     # ---- weights -------------------------------------------------------------------------------
     def set_weights(self, named_tensors):
-        """Upload the path's parameters (dict name -> tensor, the reference's state_dict names)."""
+        """Upload the path's parameters (dict name -> tensor, the reference's state_dict names): one fused multi-tensor copy into the
+        flat mirror (a training step re-uploads all ~160 tensors after every optimizer step) + genie_weights_set_blob."""
         self.assoc_ready = True
+        if getattr(self, "_w_views", None) is None:
+            self._w_views = [self._blob[off:off + n] for n, off in zip(self.w_numel, self.w_off)]
+        dst, src, zero = [], [], []
         with torch.no_grad():
-            for name, n, off in zip(self.w_names, self.w_numel, self.w_off):
+            for name, n, view in zip(self.w_names, self.w_numel, self._w_views):
                 assoc = name.startswith(ASSOC_PREFIXES)
                 if name not in named_tensors:
                     if name.endswith(".weight_pos") or name.endswith(".weight_abs"):   # optional columns: absent = plain DataAggregation
-                        self._blob[off:off + n].zero_()
+                        zero.append(view)
                         continue
                     if assoc:                       # a context used for forward_fixed_source only needs no association heads
-                        self._blob[off:off + n].zero_()
+                        zero.append(view)
                         self.assoc_ready = False
                         continue
                     raise KeyError("missing parameter %s" % name)
                 t = named_tensors[name]
                 if t.numel() != n:
-                    if assoc:                       # other model definitions (use_absolute_pos, ...) have other head shapes
-                        self._blob[off:off + n].zero_()
+                    if assoc:                       # unexpected head shapes
+                        zero.append(view)
                         self.assoc_ready = False
                         continue
                     raise ValueError("parameter %s: expected %d elements, got %d" % (name, n, t.numel()))
-                self._blob[off:off + n].copy_(t.detach().reshape(-1))
+                t = t.detach().reshape(-1)
+                if t.device != view.device or t.dtype != view.dtype:
+                    t = t.to(device=view.device, dtype=view.dtype)
+                dst.append(view)
+                src.append(t)
+            if zero:
+                torch._foreach_zero_(zero)
+            if dst:
+                torch._foreach_copy_(dst, src)
         _lib.check(self.lib.genie_weights_set_blob(self.ctx, _ptr(self._blob), self._blob.numel(), _stream()),
                    "genie_weights_set_blob")
 
