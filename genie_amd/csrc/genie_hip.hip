@@ -1397,7 +1397,6 @@ constexpr int XROW = 48;                 // bytes per split input row: three 16-
                                          // q * rows * 16 + p * 16): the 32 lanes of a half-wave then read the same piece of 32
                                          // consecutive rows as one contiguous 512 B instead of 16-B chunks 48 B apart
 constexpr int XPC = 16;                  // bytes per piece
-constexpr bool B3_ABS_READY = false;      // the bf16x3 kernel has no absolute-position form yet: use_absolute_pos runs k_stage1
 constexpr int B3_THREADS = 512;
 
 __device__ __forceinline__ float bf_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
@@ -1531,6 +1530,16 @@ __device__ __forceinline__ void mma6(f32x16 (&acc)[N], const f32x4* lw, const in
         for (int k = 0; k < N; ++k) acc[k] = MFMA32(w[k][WP[t]], b[BP[t]], acc[k]);
 }
 
+// training forward: a 32-channel accumulator (register r = channel 8 (r >> 2) + 4 h + (r & 3)) as two 16-float blocks of the
+// block-planar save buffer [blk][P][16] the backward passes read (channels 30, 31 are padding there: zero)
+__device__ __forceinline__ void b3_save32(float* __restrict__ save, long long Pn, int blk0, long long p, int h, const f32x16& v) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 o = {v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]};
+        if (m == 3 && h == 1) { o.z = 0.f; o.w = 0.f; }
+        *(f32x4*)(save + ((size_t)(blk0 + (m >> 1)) * Pn + p) * 16 + 8 * (m & 1) + 4 * h) = o;
+    }
+}
 template <int KS, int KP, bool EDGES, bool BIG>
 __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
     // byte offsets into the split rows: 32 bits (one VGPR per address, SGPR base) unless P x 48 B >= 4 GiB (BIG)
@@ -1640,6 +1649,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
                 const f32x16 z = d == 0 ? z0 : z1;
                 const int uu = u + d;
                 if (uu == 0) {
+                    if (a.save != nullptr && valid) b3_save32(a.save, a.Pn, SV_Z0, p, h, z);
                     h0 = prelu16(z, a0, sel0);
                     m01[0] = bufb[0].z; m23[0] = bufb[0].w;      // lane h = 1: bufb = x1, bufa = x2
                     m01[1] = bufa[0].z; m23[1] = bufa[0].w;
@@ -1721,6 +1731,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
                 acc[1] = MFMA32(wb[WP[t]], n2p[ks][BP[t]], acc[1]);
             }
         }
+        if (a.save != nullptr && valid) { b3_save32(a.save, a.Pn, SV_T, p, h, acc[0]); b3_save32(a.save, a.Pn, SV_T + 2, p, h, acc[1]); }
         acc[0] = prelu16(acc[0], a1, sel1);
         acc[1] = prelu16(acc[1], a1, sel1);
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
@@ -1763,6 +1774,7 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
             for (int b = 0; b < 4; ++b)
                 *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
         }
+        if (a.save != nullptr && valid) { b3_save32(a.save, a.Pn, SV_UP, p, h, o3[0]); b3_save32(a.save, a.Pn, SV_VP, p, h, o3[1]); }
         o3[0] = prelu16(o3[0], a21, sel21);
         o3[1] = prelu16(o3[1], a22, sel22);
         asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
@@ -5457,7 +5469,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (dbg_h0) a.dbg_h0 = dbg_tmp;
         if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
     }
-    if ((c->force_generic || c->abs_sta) && !c->pcsr && !(c->use_b3 && B3_ABS_READY && !c->force_generic)) {   // use_absolute_pos / training: generic kernel (64-bit safe, any graph)
+    if (((c->force_generic && !c->use_b3) || c->abs_sta) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
