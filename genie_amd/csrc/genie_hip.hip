@@ -594,7 +594,7 @@ void build_train_plans(StagePlan& p2, StagePlan& p1, StagePlan& p0) {
 
 // G- / Q-sized tail on fp32 MFMA tiles (k_bip_out_m, k_sa_pre_m, k_sa_layer_m, k_ro_pre_m, k_readout_m): a wave owns 16 nodes,
 // lane (j = lane&15, q = lane>>4) holds channels 16t + 4q + {0..3} of node j exactly as in the stage kernels, every per-node
-// Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack image in LDS (one ds_read_b128 per 16 x 16
+// Linear is a chain of v_mfma_f32_16x16x4_f32 whose A fragments come from a k_pack_all image in LDS (one ds_read_b128 per 16 x 16
 // weight block and wave instead of two LDS reads per scalar FMA) and whose result is the B operand of the next Linear.
 // Plans (genie_ctx::plan[PL_*]) and their group index maps:
 enum { PL_RO0 = 7, PL_RO1, PL_ROP, PL_SA1, PL_SA2, PL_SA3, PL_BIP, PL_LSP, PL_LSS, PL_ARR,
@@ -792,27 +792,33 @@ void build_tail_plans(StagePlan* plan) {
     }
 }
 
-__global__ void k_pack(const float* __restrict__ raw, const StepDesc* __restrict__ steps, int n_groups,
-                       const BiasDesc* __restrict__ bias, int n_bias, const int32_t* __restrict__ scal, int n_scal,
-                       float* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nw = n_groups * 256;
+// every plan of a context in ONE launch (a training step re-packs all ~30 images after each optimizer step): block -> plan by
+// the plans' block offsets
+struct PackPlan { const StepDesc* steps; const BiasDesc* bias; const int32_t* scal; float* out; int n_groups, n_bias, n_scal, block0; };
+__device__ __forceinline__ void pack_one(const float* __restrict__ raw, const PackPlan& pl, int idx) {
+    const int nw = pl.n_groups * 256;
     if (idx < nw) {
         const int grp = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
-        const StepDesc d = steps[grp * 4 + r];
+        const StepDesc d = pl.steps[grp * 4 + r];
         const int i = lane & 15, q = lane >> 4;
         float v = 0.f;
         if (d.mat_off >= 0 && i < d.rows && d.col[q] >= 0)
             v = d.tr ? raw[d.mat_off + d.col[q] * d.ld + (d.o0 + i)] : raw[d.mat_off + (d.o0 + i) * d.ld + d.col[q]];
-        out[idx] = v;
-    } else if (idx < nw + n_bias * 16) {
+        pl.out[idx] = v;
+    } else if (idx < nw + pl.n_bias * 16) {
         const int k = idx - nw, t = k >> 4, i = k & 15;
-        const BiasDesc b = bias[t];
-        out[idx] = i < b.rows ? raw[b.off + b.o0 + i] : 0.f;
-    } else if (idx < nw + n_bias * 16 + 16) {
-        const int k = idx - nw - n_bias * 16;
-        out[idx] = k < n_scal ? raw[scal[k]] : 0.f;
+        const BiasDesc bd = pl.bias[t];
+        pl.out[idx] = i < bd.rows ? raw[bd.off + bd.o0 + i] : 0.f;
+    } else if (idx < nw + pl.n_bias * 16 + 16) {
+        const int k = idx - nw - pl.n_bias * 16;
+        pl.out[idx] = k < pl.n_scal ? raw[pl.scal[k]] : 0.f;
     }
+}
+__global__ void k_pack_all(const float* __restrict__ raw, const PackPlan* __restrict__ plans, int n_plans) {
+    int s = 0;
+    while (s + 1 < n_plans && (int)blockIdx.x >= plans[s + 1].block0) ++s;
+    const PackPlan pl = plans[s];
+    pack_one(raw, pl, ((int)blockIdx.x - pl.block0) * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3065,7 +3071,7 @@ struct SaArgs {
     float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
     float* gpart_out;      // [gridDim][8]
     float* out;            // [G,30]
-    const float* img;      // k_sa_pre_m / k_sa_layer_m: the layer's k_pack image (plan PL_SA1 + layer - 1)
+    const float* img;      // k_sa_pre_m / k_sa_layer_m: the layer's k_pack_all image (plan PL_SA1 + layer - 1)
     // batched tail: blockIdx.y = window; the window's copy of each buffer sits this many floats further on
     long long ws_x_in, ws_slot, ws_out;
 };
@@ -3125,7 +3131,7 @@ constexpr int RO_TMAX = 10;   // time queries per call (the reference uses 9, pr
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
-struct TlImg {                 // LDS copy of a k_pack image
+struct TlImg {                 // LDS copy of a k_pack_all image
     const f32x4* w; const float* bias; const float* scal;
 };
 __device__ __forceinline__ TlImg tl_stage_image(float* sm, const float* __restrict__ img, int n_groups, int n_bias) {
@@ -4514,6 +4520,7 @@ struct genie_ctx {
     bool dirty;
     StagePlan plan[NPLAN];     // 0, 1: DataAggregation stage 1 / 2; 2, 3: association stages A / B; 4, 5, 6: backward passes 2', 1', 0';
                                // PL_RO0 ...: the MFMA kernels of the G- / Q-sized tail
+    void* d_packplans; int pack_blocks;     // k_pack_all's plan table (PackPlan[NPLAN]) and its grid
     StepDesc* d_steps[NPLAN];
     BiasDesc* d_bias[NPLAN];
     int32_t* d_scal[NPLAN];
@@ -4612,12 +4619,20 @@ int dev_copy(T** dst, const T* src_dev, size_t n) {
 
 int ensure_packed(genie_ctx* c, hipStream_t st) {
     if (!c->dirty) return GENIE_OK;
-    for (int s = 0; s < NPLAN; ++s) {
-        const StagePlan& p = c->plan[s];
-        const int total = p.packed_floats();
-        k_pack<<<(total + 255) / 256, 256, 0, st>>>(c->raw, c->d_steps[s], p.n_groups(), c->d_bias[s],
-                                                   (int)p.bias.size(), c->d_scal[s], (int)p.scal.size(), c->packed[s]);
+    if (!c->d_packplans) {
+        std::vector<PackPlan> pl(NPLAN);
+        int blocks = 0;
+        for (int s = 0; s < NPLAN; ++s) {
+            const StagePlan& p = c->plan[s];
+            pl[s].steps = c->d_steps[s]; pl[s].bias = c->d_bias[s]; pl[s].scal = c->d_scal[s]; pl[s].out = c->packed[s];
+            pl[s].n_groups = p.n_groups(); pl[s].n_bias = (int)p.bias.size(); pl[s].n_scal = (int)p.scal.size(); pl[s].block0 = blocks;
+            blocks += (p.packed_floats() + 255) / 256;
+        }
+        HIP_TRY(hipMalloc(&c->d_packplans, sizeof(PackPlan) * NPLAN));
+        HIP_TRY(hipMemcpy(c->d_packplans, pl.data(), sizeof(PackPlan) * NPLAN, hipMemcpyHostToDevice));
+        c->pack_blocks = blocks;
     }
+    k_pack_all<<<c->pack_blocks, 256, 0, st>>>(c->raw, (const PackPlan*)c->d_packplans, NPLAN);
     k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3, B3_FRAGS,
                                                                                B3_NBIAS * 32 + 16);
     if (c->has_edges) {
@@ -5393,6 +5408,7 @@ int genie_set_slot(genie_ctx* c, int slot) {
 
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
+    (void)hipFree(c->d_packplans);
     for (int s = 7; s < NPLAN; ++s) { (void)hipFree(c->d_steps[s]); (void)hipFree(c->d_bias[s]); (void)hipFree(c->d_scal[s]); (void)hipFree(c->packed[s]); }
     for (int s = 3; s < NTM; ++s) { (void)hipFree(c->d_acc[s]); (void)hipFree(c->d_vec[s]); (void)hipFree(c->d_sc[s]); }
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
