@@ -334,21 +334,33 @@ void add_bias(StagePlan& p, int vec, int o0, int rows) {
 // l2_t2_2 [144:159]
 constexpr int AS_PG = 160;
 
-// STAGE 1, bf16x3 form (k_stage1_b3): 1-KB A fragments of v_mfma_f32_32x32x16_bf16, lane (i = lane&31, h = lane>>5) holds
-// 8 bf16 = K slots (h, e = 0..7). Fragment ids: init_trns (3 mixed-piece fragments), then [block][K-step][piece].
-constexpr int B3_FA = 0;        // + m: [W1|W1], [W2|W2], [W1|W3] of init_trns (K = two 8-wide input slices)
-constexpr int B3_FL1 = 3;       // + ((t*4 + ks)*3 + piece): layer 1, half t, K-steps 0,1 = h0 block, 2,3 = mean block
-constexpr int B3_FUVC = 27;     // + ((blk*4 + ks)*3 + piece): blk 0 = u, 1 = v, 2 = c; K-steps over h1 = [half 0 | half 1]
-constexpr int B3_FW = 63;       // + (ks*3 + piece): [wu | wv] rows, K-steps 0,1 = u block, 2,3 = v block
-constexpr int B3_FRAGS = 75;
+// STAGE 1 on the 16-bit matrix pipe: 1-KB A fragments of v_mfma_f32_32x32x16_{bf16,f16}, lane (i = lane&31, h = lane>>5) holds
+// 8 values = K slots (h, e = 0..7). Fragment ids: init_trns (NP mixed-piece fragments), then [block][K-step][piece], NP pieces
+// per K-step: 3 in the bf16x3 form (k_stage1_b3), 2 in the f16x2 form (k_stage1_h2).
+struct S1Frags {
+    int np, fa, fl1, fuvc, fw, frags;
+    constexpr S1Frags(int n) : np(n), fa(0), fl1(n), fuvc(n + 8 * n), fw(n + 20 * n), frags(n + 24 * n) {}
+};
+constexpr S1Frags B3F(3), H2F(2);
+constexpr int B3_FA = B3F.fa;       // + m: [W1|W1], [W2|W2], [W1|W3] of init_trns (K = two 8-wide input slices)
+constexpr int B3_FL1 = B3F.fl1;     // + ((t*4 + ks)*3 + piece): layer 1, half t, K-steps 0,1 = h0 block, 2,3 = mean block
+constexpr int B3_FUVC = B3F.fuvc;   // + ((blk*4 + ks)*3 + piece): blk 0 = u, 1 = v, 2 = c; K-steps over h1 = [half 0 | half 1]
+constexpr int B3_FW = B3F.fw;       // + (ks*3 + piece): [wu | wv] rows, K-steps 0,1 = u block, 2,3 = v block
+constexpr int B3_FRAGS = B3F.frags;
+static_assert(B3_FL1 == 3 && B3_FUVC == 27 && B3_FW == 63 && B3_FRAGS == 75 && H2F.frags == 50, "fragment maps");
 constexpr int B3_NBIAS = 6;     // init_trns, l1_t1_2, l1_t2_2, l2_t1_1, l2_t2_1, [l2_t1_2 | l2_t2_2]
 constexpr int B3_IMG_FLOATS = B3_FRAGS * 256 + B3_NBIAS * 32 + 16;
+constexpr int H2_IMG_FLOATS = H2F.frags * 256 + B3_NBIAS * 32 + 16;
 constexpr int B3_TBL = B3_FRAGS * 512 + B3_NBIAS * 32 + 16;
 
 // table entry: raw-mirror offset | piece << 28, or -1 for zero. Slot (h, e) of K-step kb (0/1) of a 32-channel block is
 // channel 16 kb + 8 (e >> 2) + 4 h + (e & 3): registers 8kb..8kb+7 of the producing accumulator (see k_stage1_b3).
-void build_b3_table(std::vector<int32_t>& tbl) {
-    tbl.assign(B3_TBL, -1);
+// Piece codes, bf16x3 (F.np == 3): 0, 1, 2 = the truncated bf16 pieces of W. f16x2 (F.np == 2): 0 = W0 = rn16(W),
+// 1 = rn16(16 (W - W0)) (the product it enters takes x0 / 16 as its other operand, which keeps the second piece out of fp16's
+// subnormal range); 2 = rn16(16 W), 3 = rn16(16 W - piece 2): the input layer, computed 16 x too large as a whole.
+void build_b3_table(std::vector<int32_t>& tbl, const S1Frags F) {
+    const int NP = F.np;
+    tbl.assign((size_t)F.frags * 512 + B3_NBIAS * 32 + 16, -1);
     auto put = [&](int f, int i, int h, int e, int piece, int off) {
         tbl[((size_t)f * 64 + (h * 32 + i)) * 8 + e] = off < 0 ? -1 : (off | (piece << 28));
     };
@@ -356,9 +368,14 @@ void build_b3_table(std::vector<int32_t>& tbl) {
         for (int h = 0; h < 2; ++h)
             for (int e = 0; e < 8; ++e) {
                 const int off = i < 30 ? g_params[W_DA_INIT_W].off + i * 8 + e : -1;
-                put(B3_FA + 0, i, h, e, 0, off);
-                put(B3_FA + 1, i, h, e, 1, off);
-                put(B3_FA + 2, i, h, e, h == 0 ? 0 : 2, off);
+                if (NP == 3) {
+                    put(F.fa + 0, i, h, e, 0, off);
+                    put(F.fa + 1, i, h, e, 1, off);
+                    put(F.fa + 2, i, h, e, h == 0 ? 0 : 2, off);
+                } else {      // [P|P][x0;x1], [Q|Q][x0;x1] with P + Q = 16 W
+                    put(F.fa + 0, i, h, e, 2, off);
+                    put(F.fa + 1, i, h, e, 3, off);
+                }
             }
     // src(i, ch): raw offset of the weight multiplying channel ch (0..31) of the K-step's block into output row i
     auto dense = [&](int f0, int kb, auto src) {
@@ -367,13 +384,13 @@ void build_b3_table(std::vector<int32_t>& tbl) {
                 for (int e = 0; e < 8; ++e) {
                     const int ch = 16 * kb + 8 * (e >> 2) + 4 * h + (e & 3);
                     const int off = src(i, ch);
-                    for (int piece = 0; piece < 3; ++piece) put(f0 + piece, i, h, e, piece, off);
+                    for (int piece = 0; piece < NP; ++piece) put(f0 + piece, i, h, e, piece, off);
                 }
     };
     for (int t = 0; t < 2; ++t)
         for (int ks = 0; ks < 4; ++ks) {
             const int mat = g_params[t == 0 ? W_DA_L1T12_W : W_DA_L1T22_W].off, blk = ks >> 1;
-            dense(B3_FL1 + (t * 4 + ks) * 3, ks & 1, [&](int i, int ch) {
+            dense(F.fl1 + (t * 4 + ks) * NP, ks & 1, [&](int i, int ch) {
                 if (i >= 30) return -1;
                 return mat + i * 64 + (ch < 30 ? 30 * blk + ch : 60 + 2 * blk + (ch - 30));   // pads: Mask columns
             });
@@ -381,7 +398,7 @@ void build_b3_table(std::vector<int32_t>& tbl) {
     for (int b = 0; b < 3; ++b)
         for (int ks = 0; ks < 4; ++ks) {
             const int half = ks >> 1;
-            dense(B3_FUVC + (b * 4 + ks) * 3, ks & 1, [&](int i, int ch) {
+            dense(F.fuvc + (b * 4 + ks) * NP, ks & 1, [&](int i, int ch) {
                 if (b < 2) {
                     if (i >= 30 || ch >= 30) return -1;
                     return g_params[b == 0 ? W_DA_L2T11_W : W_DA_L2T21_W].off + i * 60 + 30 * half + ch;
@@ -395,13 +412,13 @@ void build_b3_table(std::vector<int32_t>& tbl) {
         }
     for (int ks = 0; ks < 4; ++ks) {
         const int blk = ks >> 1;
-        dense(B3_FW + ks * 3, ks & 1, [&](int i, int ch) {
+        dense(F.fw + ks * NP, ks & 1, [&](int i, int ch) {
             if (ch >= 30) return -1;
             if (blk == 0) return i < 15 ? g_params[W_DA_L2T12_W].off + i * 94 + 60 + ch : -1;
             return (i >= 16 && i < 31) ? g_params[W_DA_L2T22_W].off + (i - 16) * 94 + 60 + ch : -1;
         });
     }
-    int32_t* bias = tbl.data() + (size_t)B3_FRAGS * 512;
+    int32_t* bias = tbl.data() + (size_t)F.frags * 512;
     const int bvec[5] = {W_DA_INIT_B, W_DA_L1T12_B, W_DA_L1T22_B, W_DA_L2T11_B, W_DA_L2T21_B};
     for (int b = 0; b < 5; ++b)
         for (int i = 0; i < 30; ++i) bias[b * 32 + i] = g_params[bvec[b]].off + i;
@@ -1418,8 +1435,70 @@ __device__ __forceinline__ unsigned bf16_piece(float v, int piece) {
     return __float_as_uint(r - b) >> 16;
 }
 
+// ---- f16x2 form: x = x0 + x1 with x0 = rn16(x), x1 = rn16(x - x0): 11 + 1 + 11 significant bits, exact to half an fp32 ulp
+// while x1 stays a normal fp16 number (|x| >= 2^-2), to 2^-25 absolute below that (fp16 subnormals: the MFMA keeps them,
+// tools/h2_probe.hip). Overflow needs |x| > 65504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define MFMA32H(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {            // round to nearest even, both halves
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned p) {              // x - float(p.lo), one exact fp32 operation
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned p) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+constexpr unsigned H2_SIXTEENTH = 0x2c002c00u;        // (1/16, 1/16) as an fp16 pair
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned p, unsigned c) {
+    unsigned r;
+    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(c));
+    return r;
+}
+// one fp16 piece (low 16 bits) of v; codes as in build_b3_table
+__device__ __forceinline__ unsigned f16_piece(float v, int piece) {
+    if (piece >= 2) { v *= 16.f; piece -= 2; }
+    const unsigned p0 = cvt_pk_f16(v, 0.f);
+    if (piece == 0) return p0 & 0xffffu;
+    const float r = sub_f16_lo(v, p0);
+    return cvt_pk_f16(r, 0.f) & 0xffffu;
+}
+__device__ __forceinline__ unsigned f16_piece_w(float v, int piece) {            // weight pieces: code 1 = rn16(16 (W - W0))
+    if (piece != 1) return f16_piece(v, piece);
+    const unsigned p0 = cvt_pk_f16(v, 0.f);
+    return cvt_pk_f16(16.f * sub_f16_lo(v, p0), 0.f) & 0xffffu;
+}
+// the split rows of one [Slice || Mask] row: fmt 0 = three bf16 planes, fmt 1 = two fp16 planes
+__device__ __forceinline__ void store_split_row(unsigned* __restrict__ out, long long rows, long long p, const float (&v)[8], int fmt) {
+    if (fmt == 0) {
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
+            *(u32x4*)(out + ((long long)piece * rows + p) * 4) = o;
+        }
+    } else {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o0[d] = cvt_pk_f16(v[2 * d], v[2 * d + 1]);
+            o1[d] = cvt_pk_f16(sub_f16_lo(v[2 * d], o0[d]), sub_f16_hi(v[2 * d + 1], o0[d]));
+        }
+        *(u32x4*)(out + p * 4) = o0;
+        *(u32x4*)(out + (rows + p) * 4) = o1;
+    }
+}
+
 __global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out, int nfrag,
-                          int ntail) {
+                          int ntail, int fmt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < nfrag * 64) {
         u32x4 o;
@@ -1429,7 +1508,7 @@ __global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restri
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int32_t ent = tbl[idx * 8 + 2 * d + k];
-                u[k] = ent < 0 ? 0u : bf16_piece(raw[ent & 0x0fffffff], (ent >> 28) & 3);
+                u[k] = ent < 0 ? 0u : fmt == 0 ? bf16_piece(raw[ent & 0x0fffffff], (ent >> 28) & 3) : f16_piece_w(raw[ent & 0x0fffffff], (ent >> 28) & 3);
             }
             o[d] = u[0] | (u[1] << 16);
         }
@@ -1444,7 +1523,7 @@ __global__ void k_pack_b3(const float* __restrict__ raw, const int32_t* __restri
 // [Slice || Mask] rows (8 fp32) -> 48-B rows of three bf16x8 pieces
 // sta_user (internal station -> caller's station, or null): the rows of a source node are written in the station processing order
 __global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
-                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm) {
+                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm, int fmt) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
     long long pu = p;
@@ -1455,13 +1534,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
     const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
     if (sta_user != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));      // the message mask of stage 2 (module.py:226)
     const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
-#pragma unroll
-    for (int piece = 0; piece < 3; ++piece) {
-        u32x4 o;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-        *(u32x4*)(out + ((long long)piece * rows + p) * 4) = o;
-    }
+    store_split_row(out, rows, p, v, fmt);
 }
 
 // Same with a station processing order, one workgroup per source node: the node's S rows are read in the caller's order
@@ -1469,7 +1542,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
 constexpr int SPLIT_G_MAXS = 2048;
 __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
                                                       unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
-                                                      float* __restrict__ mm, long long rows) {
+                                                      float* __restrict__ mm, long long rows, int fmt) {
     extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
     const long long base = (long long)blockIdx.x * S;
     for (int r = threadIdx.x; r < S; r += blockDim.x) {
@@ -1482,13 +1555,7 @@ __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ 
         const f32x4 s = *(const f32x4*)(stg + u * 8), m = *(const f32x4*)(stg + u * 8 + 4);
         mm[base + r] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
         const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) {
-            u32x4 o;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-            *(u32x4*)(out + ((long long)piece * rows + base + r) * 4) = o;
-        }
+        store_split_row(out, rows, base + r, v, fmt);
     }
 }
 
@@ -1805,6 +1872,299 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
             for (int t = 0; t < 6; ++t) {
                 ow[0] = MFMA32(wa[WP[t]], up[BP[t]], ow[0]);
                 ow[1] = MFMA32(wb[WP[t]], vp[BP[t]], ow[1]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                *(f32x4*)(a.wu + p * ROWW + 8 * b + 4 * h) = f32x4{ow[0][4 * b], ow[0][4 * b + 1], ow[0][4 * b + 2], ow[0][4 * b + 3]};
+                *(f32x4*)(a.wv + p * ROWW + 8 * b + 4 * h) =
+                    f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
+            }
+        }
+        idv = idv_n; sc = sc_n; valid = valid_n;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STAGE 1, f16x2 form: the structure of k_stage1_b3 with fp16 pieces. An activation x is split into x0 = rn16(x),
+// x1 = rn16(x - x0) (one v_cvt_pk_f16_f32 per pair and piece, one v_fma_mix_f32 per value) and a weight into W0 = rn16(W),
+// W1' = rn16(16 (W - W0)); a K-step is THREE products, smallest first: W0 x1 + W1' (x0 / 16) + W0 x0 (x0 / 16: one
+// v_pk_mul_f16 per pair). The scaled pair keeps the weight's second piece a normal fp16 number; without it that piece falls
+// into fp16's subnormal range (absolute floor 2^-25) and the hidden states lose ~2x in accuracy (oracle-level emulation of the
+// arithmetic on the golden fixtures: x_latent rms error vs fp64 1.30e-7 unscaled, 0.81e-7 scaled, bf16x3 0.68e-7, the
+// reference's own fp32 1.13e-7). What is dropped: W1 x1 (2^-24 of a product) and the last-bit rounding of x1: the result is
+// fp32-CLASS like the bf16x3 form's. The input layer (K = 8: [x0 ; x1] fill one K = 16 step) is computed 16 x too large as a
+// whole, [P|P][x0;x1] + [Q|Q][x0;x1] with P + Q = 16 W and C = 16 b: the neighbour sums absorb the factor in their constants,
+// the node's own h0 pays 16 multiplies. Per wave-tile: 120 MFMAs (b3: 216), split work 2.5 vector instructions per value (5.5).
+// ------------------------------------------------------------------------------------------------
+template <int KS_>
+__device__ __forceinline__ void split8h(const f32x16& v, u32x4 (&p)[3], unsigned sixteenth) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float a = v[8 * KS_ + 2 * d], b = v[8 * KS_ + 2 * d + 1];
+        const unsigned p0 = cvt_pk_f16(a, b);
+        p[0][d] = p0;
+        p[1][d] = cvt_pk_f16(sub_f16_lo(a, p0), sub_f16_hi(b, p0));
+        p[2][d] = pk_mul_f16(p0, sixteenth);
+    }
+}
+// the three partial products of one K-step for N independent accumulators sharing the B pieces {x0, x1, x0 / 16}
+template <int N>
+__device__ __forceinline__ void mma3(f32x16 (&acc)[N], const f32x4* lw, const int (&f0)[N], int lane, const u32x4 (&b)[3]) {
+    f32x4 w[N][2];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w[k][p] = lw[(f0[k] + p) * 64 + lane];
+    constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = MFMA32H(w[k][WP[t]], b[BP[t]], acc[k]);
+}
+
+template <int KS, int KP, bool EDGES, bool BIG>
+__global__ __launch_bounds__(B3_THREADS) void k_stage1_h2(DaArgs a) {
+    typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
+    constexpr S1Frags F = H2F;
+    constexpr int NF4 = H2_IMG_FLOATS / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += B3_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + F.frags * 64);
+    const float* lscal = lbias + B3_NBIAS * 32;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    const float inf = __builtin_inff();
+    const float sel0 = a0 <= 1.f ? inf : -inf, sel1 = a1 <= 1.f ? inf : -inf;
+    const float sel21 = a21 <= 1.f ? inf : -inf, sel22 = a22 <= 1.f ? inf : -inf;
+    // mean_k PReLU_s(z_k) = al * sum z_k + be * sum |z_k|; the z_k arrive 16 x too large
+    const float al1 = (1.f + s11) / (32.f * KS), be1 = (1.f - s11) / (32.f * KS);
+    const float al2 = (1.f + s12) / (32.f * KP), be2 = (1.f - s12) / (32.f * KP);
+    const unsigned c16 = __builtin_amdgcn_readfirstlane(H2_SIXTEENTH);
+
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
+    const bool hi = h != 0;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    const char* xs = (const char*)a.xs;
+    const off_t_ la = hi ? (off_t_)a.xs_plane : (off_t_)0;          // lane h = 0 loads x0, lane h = 1 loads x1: [x0 ; x1] is one K = 16 step
+    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XPC);
+
+    const f32x4 fa0 = lw[(F.fa + 0) * 64 + lane], fa1 = lw[(F.fa + 1) * 64 + lane];
+    f32x16 biasA = bias16(lbias, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasA[r] *= 16.f;
+
+    int jt = jj;
+    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, bool& valid_, int (&sta_)[KS]) {
+        int gi0, tb0, gi1, tb1;
+        w.decode(2 * pit_, gi0, tb0);
+        const bool second = 2 * pit_ + 1 < w.nitems;
+        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
+        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
+        const int s = (half ? tb1 : tb0) * 16 + jt;
+        valid_ = s < S && (second || !half);
+        sc_ = s < S ? s : S - 1;
+        load_sta_ids<KS>(a.sta_col, sc_, sta_);
+    };
+    int idv = 0, sc = 0, sta_id[KS];
+    bool valid = false;
+    const long long pit0 = w.it;
+    if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
+    for (long long pit = pit0, pnext = 0; 2 * pit < w.nitems; pit = pnext) {
+        asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park them all in VGPRs)
+        const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
+        const int g = half ? g1 : g0;
+        const long long p = (long long)g * S + sc;
+        off_t_ gbase = (off_t_)(unsigned)g * gstride;
+        unsigned sbase = (unsigned)sc * (unsigned)XPC;
+        const int srcv = idv;
+
+        // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
+        constexpr int NU = 1 + KS + KP;
+        static_assert(NU % 2 == 0, "units are processed in pairs");
+        constexpr int DEPTH = 6;
+        u32x4 buf[NU];
+        auto issue = [&](int u) {
+            off_t_ off;
+            if (u == 0) off = gbase + sbase;
+            else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
+            else {
+                const int n0 = __builtin_amdgcn_readlane(srcv, u - KS), n1 = __builtin_amdgcn_readlane(srcv, 16 + u - KS);
+                off = (BIG ? (off_t_)(unsigned)(half ? n1 : n0) * gstride : (off_t_)__umul24((unsigned)(half ? n1 : n0), (unsigned)gstride)) + sbase;
+            }
+            if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
+            buf[u] = *(const u32x4*)(xs + (off + la));
+        };
+        const u32x4 own0 = *(const u32x4*)(xs + (gbase + sbase));           // x0 of the own row (lanes h = 1: Mask pads)
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) issue(u);
+
+        f32x16 sz, sa, h0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sz[r] = 0.f; sa[r] = 0.f; }
+        u32x4 h0p[2][3], n1p[2][3], n2p[2][3];
+        unsigned m01[3], m23[3];          // Mask pieces {x0, x1, x0 / 16} (lanes h = 1): fp16 pairs (M0,M1) and (M2,M3)
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                if (u + DEPTH + d < NU) issue(u + DEPTH + d);
+            asm volatile("" : "+v"(buf[u]), "+v"(buf[u + 1]));
+            f32x16 z0 = MFMA32H(fa1, buf[u], biasA), z1 = MFMA32H(fa1, buf[u + 1], biasA);
+            z0 = MFMA32H(fa0, buf[u], z0);
+            z1 = MFMA32H(fa0, buf[u + 1], z1);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                f32x16 z = d == 0 ? z0 : z1;
+                const int uu = u + d;
+                if (uu == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] *= 0.0625f;
+                    if (a.save != nullptr && valid) b3_save32(a.save, a.Pn, SV_Z0, p, h, z);
+                    h0 = prelu16(z, a0, sel0);
+                    m01[0] = own0.z;   m23[0] = own0.w;
+                    m01[1] = buf[0].z; m23[1] = buf[0].w;      // lane h = 1: buf = x1
+                    m01[2] = pk_mul_f16(own0.z, c16); m23[2] = pk_mul_f16(own0.w, c16);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { sz[r] += z[r]; sa[r] += __builtin_fabsf(z[r]); }
+                }
+                if (uu == KS || uu == NU - 1) {
+                    const float al = uu == KS ? al1 : al2, be = uu == KS ? be1 : be2;
+                    f32x16 n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { n[r] = fmaf(al, sz[r], be * sa[r]); sz[r] = 0.f; sa[r] = 0.f; }
+                    if (uu == KS) { split8h<0>(n, n1p[0], c16); split8h<1>(n, n1p[1], c16); }
+                    else { split8h<0>(n, n2p[0], c16); split8h<1>(n, n2p[1], c16); }
+                }
+            }
+            asm volatile("" : "+v"(sz), "+v"(sa), "+v"(gbase), "+v"(sbase), "+v"(jt));
+        }
+        int idv_n = 0, sc_n = 0, sta_n[KS];
+        bool valid_n = false;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
+        pnext = pit + w.stride;
+        const bool has_next = 2 * pnext < w.nitems;
+        if (has_next) fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
+        if (a.dbg_h0 != nullptr && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < 30) a.dbg_h0[p * 30 + ch] = h0[r];
+            }
+        }
+        split8h<0>(h0, h0p[0], c16);
+        split8h<1>(h0, h0p[1], c16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {     // padding slots (channels 30, 31) carry the Mask: [h0 | M0 M1], [n | M2 M3]
+            h0p[1][q].w = hi ? m01[q] : h0p[1][q].w;
+            n1p[1][q].w = hi ? m23[q] : n1p[1][q].w;
+            n2p[1][q].w = hi ? m23[q] : n2p[1][q].w;
+        }
+        // ---- layer 1: tr_t = l1_t{1,2}_2 [h0 || n_t || Mask], both halves at once
+        f32x16 acc[2] = {bias16(lbias, 1, h), bias16(lbias, 2, h)};
+        if (EDGES) {   // DataAggregationEdges: static per-station / per-source-node terms of layer 1
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[0][4 * b + e] += es[e]; acc[1][4 * b + e] += eg[e]; }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int f0[2] = {F.fl1 + (0 * 4 + ks) * 2, F.fl1 + (1 * 4 + ks) * 2};
+            mma3<2>(acc, lw, f0, lane, h0p[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {     // the neighbour-mean blocks differ per half: interleave by hand
+            const int fa_ = F.fl1 + (0 * 4 + 2 + ks) * 2, fb_ = F.fl1 + (1 * 4 + 2 + ks) * 2;
+            f32x4 wa[2], wb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { wa[q] = lw[(fa_ + q) * 64 + lane]; wb[q] = lw[(fb_ + q) * 64 + lane]; }
+            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[0] = MFMA32H(wa[WP[t]], n1p[ks][BP[t]], acc[0]);
+                acc[1] = MFMA32H(wb[WP[t]], n2p[ks][BP[t]], acc[1]);
+            }
+        }
+        if (a.save != nullptr && valid) { b3_save32(a.save, a.Pn, SV_T, p, h, acc[0]); b3_save32(a.save, a.Pn, SV_T + 2, p, h, acc[1]); }
+        acc[0] = prelu16(acc[0], a1, sel1);
+        acc[1] = prelu16(acc[1], a1, sel1);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        if (a.dbg_h1 != nullptr && valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (ch < 30) a.dbg_h1[p * 60 + 30 * t + ch] = acc[t][r];
+                }
+        }
+        // ---- u, v and the node-local layer-2 terms c from h1 = [h1a (30) | M0 M1 | h1b (30) | M2 M3]
+        f32x16 o3[3] = {bias16(lbias, 3, h), bias16(lbias, 4, h), bias16(lbias, 5, h)};
+        if (EDGES) {   // ... and of the node-local layer-2 block c = [o1 (15), 0 | o2 (15), 0]
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o3[2][4 * b + e] += es[e]; o3[2][8 + 4 * b + e] += eg[e]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 hp[2][3];
+            split8h<0>(acc[t], hp[0], c16);
+            split8h<1>(acc[t], hp[1], c16);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) hp[1][q].w = hi ? (t == 0 ? m01[q] : m23[q]) : hp[1][q].w;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int ks = 2 * t + kb;
+                const int f0[3] = {F.fuvc + (0 * 4 + ks) * 2, F.fuvc + (1 * 4 + ks) * 2, F.fuvc + (2 * 4 + ks) * 2};
+                mma3<3>(o3, lw, f0, lane, hp[kb]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
+        }
+        if (a.save != nullptr && valid) { b3_save32(a.save, a.Pn, SV_UP, p, h, o3[0]); b3_save32(a.save, a.Pn, SV_VP, p, h, o3[1]); }
+        o3[0] = prelu16(o3[0], a21, sel21);
+        o3[1] = prelu16(o3[1], a22, sel22);
+        asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
+        // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
+        f32x16 ow[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ow[0][r] = 0.f; ow[1][r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 up[3], vp[3];
+            if (kb == 0) { split8h<0>(o3[0], up, c16); split8h<0>(o3[1], vp, c16); }
+            else { split8h<1>(o3[0], up, c16); split8h<1>(o3[1], vp, c16); }
+            f32x4 wa[2], wb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wa[q] = lw[(F.fw + (0 + kb) * 2 + q) * 64 + lane];
+                wb[q] = lw[(F.fw + (2 + kb) * 2 + q) * 64 + lane];
+            }
+            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ow[0] = MFMA32H(wa[WP[t]], up[BP[t]], ow[0]);
+                ow[1] = MFMA32H(wb[WP[t]], vp[BP[t]], ow[1]);
             }
         }
         if (valid) {
@@ -4008,7 +4368,8 @@ struct EmbArgs {
     const float* trv;      // [rows, 2] theoretical P / S travel time of every product node
     long long rows;
     float* slice; float* mask;
-    unsigned* xs;          // optional: the 48-B split rows of k_stage1_b3, written together with Slice / Mask
+    unsigned* xs;          // optional: the split rows of k_stage1_b3 / k_stage1_h2, written together with Slice / Mask
+    int xs_fmt;            // 0 = three bf16 planes, 1 = two fp16 planes
     const int32_t* sta_inv; // station processing order of the split rows (caller's station -> internal), or null
     float* mm;              // with sta_inv: max of the Mask row, in processing order
 };
@@ -4061,13 +4422,7 @@ __global__ void k_embed_gather(EmbArgs a) {
         const float v[8] = {sl.x, sl.y, sl.z, sl.w, mk.x, mk.y, mk.z, mk.w};
         const long long px = a.sta_inv != nullptr ? p - sta + a.sta_inv[sta] : p;
         if (a.sta_inv != nullptr) a.mm[px] = fmaxf(fmaxf(mk.x, mk.y), fmaxf(mk.z, mk.w));
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) {
-            u32x4 o;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = bf16_piece(v[2 * d], piece) | (bf16_piece(v[2 * d + 1], piece) << 16);
-            *(u32x4*)(a.xs + ((long long)piece * a.rows + px) * 4) = o;
-        }
+        store_split_row(a.xs, a.rows, px, v, a.xs_fmt);
     }
 }
 
@@ -4560,7 +4915,8 @@ struct genie_ctx {
     int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: three per CU)
     int s2_wgmap;              // k_stage2_ord: blocks of 4 source nodes per workgroup (large station counts)
     int bpc1b;                 // workgroups of k_stage1_b3 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
-    int use_b3;                // stage 1 on the bf16 matrix pipe (k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
+    int use_b3;                // stage 1 on the 16-bit matrix pipe (k_stage1_h2 / k_stage1_b3); GENIE_S1=f32 selects the fp32-MFMA kernels
+    int s1_h2;                 // ... in the f16x2 form (default); GENIE_S1=b3 selects the bf16x3 form
     // workspace offsets (floats)
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
@@ -4633,8 +4989,11 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         c->pack_blocks = blocks;
     }
     k_pack_all<<<c->pack_blocks, 256, 0, st>>>(c->raw, (const PackPlan*)c->d_packplans, NPLAN);
-    k_pack_b3<<<(B3_FRAGS * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3, B3_FRAGS,
-                                                                               B3_NBIAS * 32 + 16);
+    {
+        const int nfrag = c->s1_h2 ? H2F.frags : B3F.frags;
+        k_pack_b3<<<(nfrag * 64 + B3_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_b3tbl, c->packed_b3, nfrag,
+                                                                                 B3_NBIAS * 32 + 16, c->s1_h2);
+    }
     if (c->has_edges) {
         k_edge_bias<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
                                                             c->mpos_sta, c->S, c->ebias_sta);
@@ -5182,8 +5541,10 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
     }
     {
+        const char* e = getenv("GENIE_S1");
+        c->s1_h2 = !(e && strcmp(e, "b3") == 0);
         std::vector<int32_t> tbl;
-        build_b3_table(tbl);
+        build_b3_table(tbl, c->s1_h2 ? H2F : B3F);
         HIP_TRY(hipMalloc((void**)&c->d_b3tbl, sizeof(int32_t) * tbl.size()));
         HIP_TRY(hipMemcpy(c->d_b3tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_b3, sizeof(float) * B3_IMG_FLOATS));
@@ -5505,15 +5866,23 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (!presplit) {
             if (sta_order_on(c) && c->S <= SPLIT_G_MAXS) {
                 HIP_TRY(hipFuncSetAttribute((const void*)k_split_rows_g, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_G_MAXS * 32));
-                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw, c->P_ext);
+                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw, c->P_ext, c->s1_h2);
             } else
                 k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs,
-                                                                                sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
+                                                                                sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw, c->s1_h2);
         }
         a.xs = xs; a.packed = c->packed_b3; a.xs_plane = c->P_ext * (long long)XPC;
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, B3_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
+        } else if (c->s1_h2) {
+            if (c->has_edges) {
+                if (big) k_stage1_h2<8, 15, true, true><<<grid, B3_THREADS, 0, st>>>(a);
+                else k_stage1_h2<8, 15, true, false><<<grid, B3_THREADS, 0, st>>>(a);
+            } else {
+                if (big) k_stage1_h2<8, 15, false, true><<<grid, B3_THREADS, 0, st>>>(a);
+                else k_stage1_h2<8, 15, false, false><<<grid, B3_THREADS, 0, st>>>(a);
+            }
         } else if (c->has_edges) {
             if (big) k_stage1_b3<8, 15, true, true><<<grid, B3_THREADS, 0, st>>>(a);
             else k_stage1_b3<8, 15, true, false><<<grid, B3_THREADS, 0, st>>>(a);
@@ -5943,7 +6312,7 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
     a.S = c->S; a.t0 = t0; a.tref0 = t0 - 3.0 * kernel_sig_t; a.dt = dt; a.sigma = kernel_sig_t;
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
     a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
-    a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs;
+    a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs; a.xs_fmt = c->s1_h2;
     a.sta_inv = (xs && sta_order_on(c)) ? c->sta_inv : nullptr;
     a.mm = xs ? (float*)xs - c->o_xs + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride : nullptr;   // xs = workspace + o_xs
     HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
