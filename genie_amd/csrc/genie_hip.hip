@@ -56,6 +56,9 @@
 #endif
 
 #ifndef GENIE_S1_PK
+#ifndef GENIE_H2_DEPTH
+#define GENIE_H2_DEPTH 6   // k_stage1_h2: row loads in flight ahead of their use
+#endif
 #define GENIE_S1_PK 0      // k_stage1_b3: packed fp32 adds in the neighbour accumulate (measured: see DESIGN.md section 5)
 #endif
 
@@ -1900,6 +1903,17 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_b3(DaArgs a) {
 // whole, [P|P][x0;x1] + [Q|Q][x0;x1] with P + Q = 16 W and C = 16 b: the neighbour sums absorb the factor in their constants,
 // the node's own h0 pays 16 multiplies. Per wave-tile: 120 MFMAs (b3: 216), split work 2.5 vector instructions per value (5.5).
 // ------------------------------------------------------------------------------------------------
+// lane k of every row of 16 lanes, broadcast to the row (DPP row_newbcast, gfx90a+)
+template <int K_>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K_, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_bcast_dyn(int v, int k) {     // k is a compile-time constant after unrolling
+    switch (k) {
+        case 0: return row_bcast<0>(v); case 1: return row_bcast<1>(v); case 2: return row_bcast<2>(v); case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v); case 5: return row_bcast<5>(v); case 6: return row_bcast<6>(v); case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v); case 9: return row_bcast<9>(v); case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
+    }
+}
 template <int KS_>
 __device__ __forceinline__ void split8h(const f32x16& v, u32x4 (&p)[3], unsigned sixteenth) {
 #pragma unroll
@@ -1979,36 +1993,36 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_h2(DaArgs a) {
     if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
     for (long long pit = pit0, pnext = 0; 2 * pit < w.nitems; pit = pnext) {
         asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park them all in VGPRs)
-        const int g0 = __builtin_amdgcn_readlane(idv, 0), g1 = __builtin_amdgcn_readlane(idv, 16);
-        const int g = half ? g1 : g0;
+        // idv: every row of 16 lanes holds {source node, its KP neighbours} of its own tile: one DPP row broadcast per id
+        const int g = row_bcast<0>(idv);
         const long long p = (long long)g * S + sc;
-        off_t_ gbase = (off_t_)(unsigned)g * gstride;
-        unsigned sbase = (unsigned)sc * (unsigned)XPC;
+        const off_t_ gbase0 = (off_t_)(unsigned)g * gstride;
+        const unsigned sbase0 = (unsigned)sc * (unsigned)XPC;
+        off_t_ gbase = gbase0 + la;                  // + this lane's plane: one multiply-add per neighbour row address
+        off_t_ sbase = (off_t_)sbase0 + la;
         const int srcv = idv;
 
         // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
         constexpr int NU = 1 + KS + KP;
         static_assert(NU % 2 == 0, "units are processed in pairs");
-        constexpr int DEPTH = 6;
+        constexpr int DEPTH = GENIE_H2_DEPTH;
         u32x4 buf[NU];
         auto issue = [&](int u) {
             off_t_ off;
-            if (u == 0) off = gbase + sbase;
+            if (u == 0) off = gbase + sbase0;
             else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
             else {
-                const int n0 = __builtin_amdgcn_readlane(srcv, u - KS), n1 = __builtin_amdgcn_readlane(srcv, 16 + u - KS);
-                off = (BIG ? (off_t_)(unsigned)(half ? n1 : n0) * gstride : (off_t_)__umul24((unsigned)(half ? n1 : n0), (unsigned)gstride)) + sbase;
+                const unsigned nb = (unsigned)row_bcast_dyn(srcv, u - KS);
+                off = (BIG ? (off_t_)nb * gstride : (off_t_)__umul24(nb, (unsigned)gstride)) + sbase;
             }
             if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
-            buf[u] = *(const u32x4*)(xs + (off + la));
+            buf[u] = *(const u32x4*)(xs + off);
         };
-        const u32x4 own0 = *(const u32x4*)(xs + (gbase + sbase));           // x0 of the own row (lanes h = 1: Mask pads)
+        const u32x4 own0 = *(const u32x4*)(xs + (gbase0 + sbase0));         // x0 of the own row (lanes h = 1: Mask pads)
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) issue(u);
 
-        f32x16 sz, sa, h0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sz[r] = 0.f; sa[r] = 0.f; }
+        f32x16 sn, h0;          // sn: running mean_k PReLU_s(z_k) = sum_k (al z_k + be |z_k|), two fused multiply-adds per value
         u32x4 h0p[2][3], n1p[2][3], n2p[2][3];
         unsigned m01[3], m23[3];          // Mask pieces {x0, x1, x0 / 16} (lanes h = 1): fp16 pairs (M0,M1) and (M2,M3)
 #pragma unroll
@@ -2025,27 +2039,31 @@ __global__ __launch_bounds__(B3_THREADS) void k_stage1_h2(DaArgs a) {
                 f32x16 z = d == 0 ? z0 : z1;
                 const int uu = u + d;
                 if (uu == 0) {
+                    if (a.save != nullptr && valid) {
+                        f32x16 zu;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] *= 0.0625f;
-                    if (a.save != nullptr && valid) b3_save32(a.save, a.Pn, SV_Z0, p, h, z);
-                    h0 = prelu16(z, a0, sel0);
+                        for (int r = 0; r < 16; ++r) zu[r] = z[r] * 0.0625f;
+                        b3_save32(a.save, a.Pn, SV_Z0, p, h, zu);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h0[r] = __builtin_amdgcn_fmed3f(z[r] * 0.0625f, z[r] * (0.0625f * a0), sel0);
                     m01[0] = own0.z;   m23[0] = own0.w;
                     m01[1] = buf[0].z; m23[1] = buf[0].w;      // lane h = 1: buf = x1
                     m01[2] = pk_mul_f16(own0.z, c16); m23[2] = pk_mul_f16(own0.w, c16);
                 } else {
+                    const float al = uu <= KS ? al1 : al2, be = uu <= KS ? be1 : be2;
+                    if (uu == 1 || uu == KS + 1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { sz[r] += z[r]; sa[r] += __builtin_fabsf(z[r]); }
-                }
-                if (uu == KS || uu == NU - 1) {
-                    const float al = uu == KS ? al1 : al2, be = uu == KS ? be1 : be2;
-                    f32x16 n;
+                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), al * z[r]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { n[r] = fmaf(al, sz[r], be * sa[r]); sz[r] = 0.f; sa[r] = 0.f; }
-                    if (uu == KS) { split8h<0>(n, n1p[0], c16); split8h<1>(n, n1p[1], c16); }
-                    else { split8h<0>(n, n2p[0], c16); split8h<1>(n, n2p[1], c16); }
+                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), fmaf(al, z[r], sn[r]));
+                    }
                 }
+                if (uu == KS) { split8h<0>(sn, n1p[0], c16); split8h<1>(sn, n1p[1], c16); }
+                if (uu == NU - 1) { split8h<0>(sn, n2p[0], c16); split8h<1>(sn, n2p[1], c16); }
             }
-            asm volatile("" : "+v"(sz), "+v"(sa), "+v"(gbase), "+v"(sbase), "+v"(jt));
+            asm volatile("" : "+v"(sn), "+v"(gbase), "+v"(sbase), "+v"(jt));
         }
         int idv_n = 0, sc_n = 0, sta_n[KS];
         bool valid_n = false;
