@@ -39,21 +39,21 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
 # Algorithmic bytes: whole path B_alg = 1532*P + 816*G bytes per window (reference dataflow at layer
 # granularity). The HIP path moves fewer real bytes than that because h0/h1/u/v never leave the registers; per
 # product node and per kernel group (gathers counted once per row = perfect cache):
-#   stage 1 = k_split_rows + k_stage1_b3: Slice+Mask 32 R, split rows 48 W + 48 R, c 120 W, wu+wv 120 W = 368 B
+#   stage 1 = k_split_rows + k_stage1_h2: Slice+Mask 32 R, split rows 32 W + 32 R, c 120 W, wu+wv 120 W = 336 B
 #   stage 2 = k_stage2_ord              : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R               = 268 B
-B_NODE = {"k_stage1": 368.0, "k_stage2": 268.0}
+B_NODE = {"k_stage1": 336.0, "k_stage2": 268.0}
 # ALGORITHMIC FLOPs per product node (SURVEY.md 8d split by kernel; 2 per MAC): stage 1 = init_trns 240 + layer-1 3840
 # + l2_t*_1 3600 + l2_t*_2 2820 MACs + 690 layer-1 gather adds; stage 2 = Bipartite fc1 990 MACs + 690 gather adds.
 F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 * 990 + 690.0}
-# What k_stage1_b3 EXECUTES on the bf16 matrix pipe: 216 v_mfma_f32_32x32x16_bf16 (32768 FLOP each) per 32 nodes = six
-# bf16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
-BF16_EXEC_FLOP_NODE = 216 * 32768.0 / 32.0
-BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16
+# What k_stage1_h2 EXECUTES on the 16-bit matrix pipe: 120 v_mfma_f32_32x32x16_f16 (32768 FLOP each) per 32 nodes = three
+# fp16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
+F16_EXEC_FLOP_NODE = 120 * 32768.0 / 32.0
+F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r02_j_pmc_stage_kernels.txt"
-TRAFFIC_CFG2 = {"k_stage1": (2.0 * (2.469e5 + 3.127e4) + (5.041e5 + 1.016e5)) * 1024.0,     # k_split_rows_g + k_stage1_b3
-                "k_stage2": (2.0 * 5.390e5 + 1.629e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
+TRAFFIC_SOURCE = "profiles/r03_x_pmc_stage_kernels.txt"
+TRAFFIC_CFG2 = {"k_stage1": (2.0 * (1.476e5 + 3.127e4) + (5.000e5 + 7.031e4)) * 1024.0,     # k_split_rows_g + k_stage1_h2
+                "k_stage2": (2.0 * 5.553e5 + 1.631e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
 ONE_GPU_CFG4 = {"ms_per_step": 37.80, "source": "profiles/r02_i_bench_cfg4_one_gpu.json (this code path with --gpus 1; the N = 1 line of this bench "
                                                  "measures it live as sharded_workload_on_one_gpu)"}
@@ -170,10 +170,10 @@ def measure_traffic(timeout_s=150):
                     key = (row["Kernel_Name"], row["Dispatch_Id"])
                     disp[key] = disp.get(key, 0.0) + float(row["Counter_Value"])
                 for (kname, _), v in disp.items():
-                    for tag in ("k_split_rows", "k_stage1_b3", "k_stage2_ord"):
+                    for tag in ("k_split_rows", "k_stage1_h2", "k_stage2_ord"):
                         if tag in kname:
                             acc.setdefault(tag, []).append(v)
-            if not all(t in acc for t in ("k_split_rows", "k_stage1_b3", "k_stage2_ord")):
+            if not all(t in acc for t in ("k_split_rows", "k_stage1_h2", "k_stage2_ord")):
                 return None
             per[counter] = {t: float(np.mean(v)) for t, v in acc.items()}
         except Exception:
@@ -181,7 +181,7 @@ def measure_traffic(timeout_s=150):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     byts = lambda t: (2.0 * per["FETCH_SIZE"][t] + per["WRITE_SIZE"][t]) * 1024.0
-    return {"k_stage1": byts("k_split_rows") + byts("k_stage1_b3"), "k_stage2": byts("k_stage2_ord")}
+    return {"k_stage1": byts("k_split_rows") + byts("k_stage1_h2"), "k_stage2": byts("k_stage2_ord")}
 
 
 def cpu_baseline(net, geom, win, n_timed=3):
@@ -781,7 +781,7 @@ def main():
     # the path is priced against the HBM roofline on its ALGORITHMIC bytes (reference dataflow at layer
     # granularity, B_alg per window); the fused kernels move fewer real bytes, so the per-kernel figures (algorithmic bytes of
     # what each kernel has to touch, HIP-event time on the launch stream, counter traffic from the committed PMC profile) are
-    # reported next to it. Stage 1 additionally reports the bf16 FLOPs it executes against the bf16 matrix peak: it is the
+    # reported next to it. Stage 1 additionally reports the fp16 FLOPs it executes against the 16-bit matrix peak: it is the
     # one compute-bound kernel of the path.
     kern = {}
     for k in ("k_stage1", "k_stage2"):
@@ -789,9 +789,10 @@ def main():
         kern[k] = {"ms": round(kms[k], 4), "alg_bytes_per_launch": B_NODE[k] * P, "achieved_GBs": round(gbs, 1),
                    "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                    "traffic": TRAFFIC_CFG2[k] if a.config == "cfg2_200x10k" else None}
-    exec_tf = BF16_EXEC_FLOP_NODE * P / (kms["k_stage1"] * 1e-3) / 1e12
-    kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_b3"
-    kern["k_stage1"]["executed_bf16"] = {"tflops": round(exec_tf, 1), "peak": BF16_MFMA_PEAK_TF, "frac": round(exec_tf / BF16_MFMA_PEAK_TF, 4)}
+    exec_tf = F16_EXEC_FLOP_NODE * P / (kms["k_stage1"] * 1e-3) / 1e12
+    kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_h2"
+    kern["k_stage1"]["executed_f16"] = {"tflops": round(exec_tf, 1), "peak": F16_MFMA_PEAK_TF, "frac": round(exec_tf / F16_MFMA_PEAK_TF, 4),
+                                         "note": "fp32 operands as two fp16 pieces, three partial products per product, fp32 accumulation"}
     kern["k_stage2"]["kernels"] = "k_stage2_ord"
     roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                 "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),

@@ -1064,7 +1064,7 @@ class HipPath(object):
     def embed_window(self, pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv, presplit=False):
         """Slice, Mask [n_grid_ext*n_sta, 4] for the window starting at t0, from picks resident on the GPU
         (process_utils.py:460-642). pick_t float64, pick_sta / pick_phase int32 GPU tensors; trv [rows, 2] fp32.
-        `presplit`: also leave the split rows of the bf16x3 stage-1 kernel in the workspace, so that the next stage-1 call on
+        `presplit`: also leave the split rows of the f16x2 stage-1 kernel in the workspace, so that the next stage-1 call on
         exactly these (Slice, Mask) skips its split pass (genie_embed_window_split; do not modify them in between)."""
         rows = self.n_grid_ext * self.n_sta
         trv = _f32(trv, "trv", (rows, 2))

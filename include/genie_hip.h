@@ -66,7 +66,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
  * (process_utils.py:790-794), so `seg_rowptr[g] .. seg_rowptr[g+1]` is the row range of source node g (seg_rowptr[n_grid] =
  * n_prod), and both DataAggregation edge sets are CSR lists over product-node ids: p_sta_* = in-edges of A_in_sta (same
  * source node, neighbouring stations), p_src_* = in-edges of A_in_src, in stable edge order. src_rowptr / src_col = the base
- * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The bf16x3 / pipelined
+ * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The f16x2 / pipelined
  * kernels (which rely on p = g * n_sta + s) are not used; genie_embed_window, genie_set_edge_features and genie_nbr_mean are
  * unavailable on such a context. */
 int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod,
@@ -79,7 +79,7 @@ int genie_ctx_destroy(genie_ctx* ctx);
  * stations of one source node, and a station's neighbours are its nearest stations: with spatially sorted stations the rows a
  * tile gathers are shared between its lanes and adjacent in memory (config 2: stage 2 -6 %, config 4 with 2000 stations: whole
  * path -10 %). Purely internal: every input and output keeps the caller's station order (the split rows, c / wu / wv live in
- * processing order inside the workspace; genie_ws_export un-permutes). Honoured by the bf16x3 stage 1 + pipelined stage 2
+ * processing order inside the workspace; genie_ws_export un-permutes). Honoured by the f16x2 stage 1 + pipelined stage 2
  * pair on Cartesian product graphs, ignored otherwise; NULL = off. All ranks of a sharded run must pass the same order. */
 int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
 /* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
@@ -244,10 +244,10 @@ int genie_embed_ntime(double t0, double max_t, double kernel_sig_t, double dt);
 int genie_embed_window(genie_ctx* ctx, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase, int n_picks,
                        double t0, double max_t, double kernel_sig_t, double dt, const float* trv, float* emb_ws,
                        float* slice_out, float* mask_out, void* stream);
-/* Same, and additionally leaves the split input rows of the bf16x3 stage-1 kernel in `workspace`: the NEXT genie_da_stage1 /
+/* Same, and additionally leaves the split input rows of the f16x2 stage-1 kernel in `workspace`: the NEXT genie_da_stage1 /
  * genie_path_fwd call on this context with exactly these slice_out / mask_out pointers and this workspace skips its
  * k_split_rows pass (one-shot; the caller must not modify Slice / Mask in between, and stage 1 must run on the same stream or
- * after it). A no-op extension on contexts that do not use the bf16x3 kernel. */
+ * after it). A no-op extension on contexts that do not use the f16x2 kernel. */
 int genie_embed_window_split(genie_ctx* ctx, const double* pick_t, const int32_t* pick_sta, const int32_t* pick_phase,
                              int n_picks, double t0, double max_t, double kernel_sig_t, double dt, const float* trv,
                              float* emb_ws, float* slice_out, float* mask_out, void* workspace, void* stream);

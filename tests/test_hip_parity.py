@@ -94,7 +94,7 @@ def test_forward_fixed_source_drop_in(name):
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_updated_model_definition_forward_fixed_source(name, stage1, monkeypatch):
     """a-9: the `use_updated_model_definition` class (DataAggregationEdges, module.py:102-174, :1163-1185) against fixtures
-    generated from the reference imported with that flag. edges_12x60 has uniform 8 / 15 degrees (bf16x3 stage 1, or the
+    generated from the reference imported with that flag. edges_12x60 has uniform 8 / 15 degrees (f16x2 stage 1, or the
     pipelined fp32 kernel with GENIE_S1=f32), edges_7x13 has 6 / 12 (generic CSR kernels)."""
     if stage1 == "f32":
         monkeypatch.setenv("GENIE_S1", "f32")
@@ -274,7 +274,7 @@ def test_bitwise_deterministic_and_order_independent():
 @pytest.mark.parametrize("case", ["cfg1_20x500", "random_50x700"])
 def test_kernel_variants_agree(case, monkeypatch):
     """The stage kernels exist in two forms: generic CSR fp32-MFMA (any graph; GENIE_S1=f32 selects them on the reference's kNN
-    graphs too: the A/B reference) and the production pair k_stage1_b3 (exact-split bf16 matrix pipe) + k_stage2_ord (pipelined,
+    graphs too: the A/B reference) and the production pair k_stage1_h2 (two-piece fp16 operands on the matrix pipe) + k_stage2_ord (pipelined,
     row-layout loads): another summation order, fp32 tolerance."""
     if case == "cfg1_20x500":
         c = Case(case)
@@ -289,7 +289,7 @@ def test_kernel_variants_agree(case, monkeypatch):
         Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
         ea, pos, xg = torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.x_grid).float(), geom.x_grid
     res = {}
-    for name, env in (("generic", {"GENIE_S1": "f32"}), ("b3", {})):
+    for name, env in (("generic", {"GENIE_S1": "f32"}), ("h2", {})):
         monkeypatch.delenv("GENIE_S1", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -299,13 +299,13 @@ def test_kernel_variants_agree(case, monkeypatch):
         _, _, h0, h1 = hp.da_stage1(Slice.to(DEV), Mask.to(DEV), debug=True)
         xl, bip = hp.da_stage2_bipartite(Mask.to(DEV), ea.to(DEV), want_x_latent=True)
         res[name] = [t.cpu() for t in (h0, h1, xl, bip)]
-    for a_, b_ in zip(res["generic"], res["b3"]):
+    for a_, b_ in zip(res["generic"], res["h2"]):
         assert max_abs(a_, b_) <= 0.2 * rel_tol(a_), max_abs(a_, b_)     # 2e-6 x max(1, max|ref|)
 
 
 def test_rows_beyond_4gib_offsets(monkeypatch):
     """Config-4 scale on one GPU: P x 48 B (split rows) and P x 64 B (wu / wv rows) both exceed 4 GiB, so the kernels that
-    address rows with 32-bit byte offsets must switch to their 64-bit forms (k_stage1_b3<.., BIG>, wave-uniform 64-bit row
+    address rows with 32-bit byte offsets must switch to their 64-bit forms (k_stage1_h2<.., BIG>, wave-uniform 64-bit row
     bases in k_stage2_ord). Property: same result as the generic CSR kernels (64-bit arithmetic throughout)."""
     S, G = 2000, 46000
     assert S * G * 48 > 2 ** 32
@@ -595,7 +595,7 @@ def test_sharded_kernels_two_virtual_ranks_match_unsharded():
 
 def test_config4_shape_two_virtual_ranks_vs_unsharded_generic_kernels_and_oracle(monkeypatch):
     """BASELINE config 4 at its full shape (2000 stations x 50 000 source nodes = 10^8 product nodes, 500 000 picks) on one
-    GPU: (1) the unsharded fast path; (2) the same window through the generic CSR kernels (64-bit row addressing, no bf16x3, no
+    GPU: (1) the unsharded fast path; (2) the same window through the generic CSR kernels (64-bit row addressing, no f16x2, no
     pipelining): Bipartite output equal to fp32 summation-order error; (3) two virtual ranks of the source-node sharding with
     the sub-range launch schedule of genie_amd.dist.ShardedPath.front (halo rows of `wv` copied between the ranks'
     workspaces instead of the RCCL all-to-all): Bipartite output and x_spatial BITWISE equal to the unsharded run; (4) the

@@ -182,7 +182,7 @@ def test_training_path_runs_in_hip_in_both_directions_and_is_bitwise_determinist
         assert torch.equal(g1[k], g2[k]), k
         assert bool(torch.isfinite(g1[k]).all()) and float(g1[k].abs().max()) > 0, k
     assert torch.equal(y1, y2) and torch.equal(x1, x2)
-    assert max_abs(y1, ye) <= 2e-6 and max_abs(x1, xe) <= 2e-6      # training forward (fp32-MFMA stage kernels) vs inference (bf16x3 stage 1)
+    assert max_abs(y1, ye) <= 2e-6 and max_abs(x1, xe) <= 2e-6      # training forward (fp32-MFMA stage kernels) vs inference (f16x2 stage 1)
 
 
 @pytest.mark.parametrize("stage1", ["f32", "default"])
@@ -190,7 +190,7 @@ def test_training_gradients_match_oracle_with_rough_cotangents_odd_sizes(stage1,
     """Every gradient of the path against the structured oracle's autograd with random N(0, 1) cotangents on (y, x) (no smoothing
     by an MSE), 33 stations x 257 source nodes x 100 queries (partial tiles everywhere), the scaled `o1` weights (outputs O(1)).
     With the fp32-MFMA stage-1 forward (GENIE_S1=f32) every gradient is within 1e-4 of its own scale (observed 4.9e-5; the fp32
-    oracle itself is 6e-5 from the fp64 one, tools/train_grad_fp64.py). The default training forward (bf16x3 stage 1, its saved
+    oracle itself is 6e-5 from the fp64 one, tools/train_grad_fp64.py). The default training forward (f16x2 stage 1, its saved
     pre-activations within 1.4e-6 of the fp32 ones, tools/train_save_cmp.py) puts ONE near-zero output pre-activation of this case
     on the other side of its PReLU kink, where the gradient is discontinuous: the source-neighbour branch then differs by up to
     4.7e-4 of its scale -- a different, equally valid fp32 evaluation, bounded here at 1e-3 (a wrong save would show as O(1))."""

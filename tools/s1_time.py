@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Stage-1 kernels alone (split pass + k_stage1_b3, HIP events over repeated launches, clocks settled first), for A/B runs of
+"""Stage-1 kernels alone (split pass + k_stage1_h2, HIP events over repeated launches, clocks settled first), for A/B runs of
 kernel variants selected by environment variables. Usage: python tools/s1_time.py [config] [iters]"""
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Saved pre-activations of the training forward: bf16x3 stage 1 vs the fp32-MFMA stage 1 (GENIE_S1=f32), block by block."""
+"""Saved pre-activations of the training forward: f16x2 stage 1 vs the fp32-MFMA stage 1 (GENIE_S1=f32), block by block."""
 import os, sys, subprocess
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,12 +21,12 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize()
     np.save(sys.argv[1], save.cpu().numpy())
     sys.exit(0)
-for mode in ("b3", "f32"):
+for mode in ("h2", "f32"):
     env = dict(os.environ)
     if mode == "f32":
         env["GENIE_S1"] = "f32"
     subprocess.run([sys.executable, __file__, "/tmp/save_%s.npy" % mode], env=env, check=True)
-a, b = np.load("/tmp/save_b3.npy"), np.load("/tmp/save_f32.npy")
+a, b = np.load("/tmp/save_h2.npy"), np.load("/tmp/save_f32.npy")
 P = 33 * 257
 a, b = a.reshape(14, P, 16), b.reshape(14, P, 16)
 names = ["z0a", "z0b", "t1a", "t1b", "t2a", "t2b", "upa", "upb", "vpa", "vpb", "o1", "o2", "zba", "zbb"]
@@ -34,4 +34,4 @@ for k in range(14):
     d = np.abs(a[k] - b[k])
     i = np.unravel_index(np.argmax(d), d.shape)
     flips = int(((a[k] > 0) != (b[k] > 0)).sum())
-    print("%-4s max|diff| %.3e at node %d ch %d (b3 %.6e f32 %.6e)  max|ref| %.3e  sign flips %d" % (names[k], d.max(), i[0], i[1], a[k][i], b[k][i], np.abs(b[k]).max(), flips))
+    print("%-4s max|diff| %.3e at node %d ch %d (h2 %.6e f32 %.6e)  max|ref| %.3e  sign flips %d" % (names[k], d.max(), i[0], i[1], a[k][i], b[k][i], np.abs(b[k]).max(), flips))
