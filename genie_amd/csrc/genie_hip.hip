@@ -340,7 +340,9 @@ constexpr int H2_FA = 0;        // + m: [P|P], [Q|Q] of init_trns with P + Q = 1
 constexpr int H2_FL1 = 2;       // + ((t*4 + ks)*2 + piece): layer 1, half t, K-steps 0,1 = h0 block, 2,3 = mean block
 constexpr int H2_FUVC = 18;     // + ((blk*4 + ks)*2 + piece): blk 0 = u, 1 = v, 2 = c; K-steps over h1 = [half 0 | half 1]
 constexpr int H2_FW = 42;       // + (ks*2 + piece): [wu | wv] rows, K-steps 0,1 = u block, 2,3 = v block
-constexpr int H2_FRAGS = 50;
+constexpr int H2_FABS = 50;     // + m: [P|P], [Q|Q] of init_trns' absolute-position columns (use_absolute_pos; zero otherwise): K slots
+                                // 0..2 = station position, 4..6 = source position of one piece (slots 3, 7 unused)
+constexpr int H2_FRAGS = 52;
 constexpr int H2_NBIAS = 6;     // init_trns, l1_t1_2, l1_t2_2, l2_t1_1, l2_t2_1, [l2_t1_2 | l2_t2_2]
 constexpr int H2_IMG_FLOATS = H2_FRAGS * 256 + H2_NBIAS * 32 + 16;
 constexpr int H2_TBL = H2_FRAGS * 512 + H2_NBIAS * 32 + 16;
@@ -362,6 +364,10 @@ void build_h2_table(std::vector<int32_t>& tbl) {
                 const int off = i < 30 ? g_params[W_DA_INIT_W].off + i * 8 + e : -1;
                 put(H2_FA + 0, i, h, e, 2, off);      // [P|P][x0;x1], [Q|Q][x0;x1] with P + Q = 16 W
                 put(H2_FA + 1, i, h, e, 3, off);
+                const int col = (e & 3) < 3 ? 3 * (e >> 2) + (e & 3) : -1;
+                const int offa = (i < 30 && col >= 0) ? g_params[W_DA_INIT_ABS].off + i * 6 + col : -1;
+                put(H2_FABS + 0, i, h, e, 2, offa);
+                put(H2_FABS + 1, i, h, e, 3, offa);
             }
     // src(i, ch): raw offset of the weight multiplying channel ch (0..31) of the K-step's block into output row i
     auto dense = [&](int f0, int kb, auto src) {
@@ -908,6 +914,8 @@ struct DaArgs {
     long long Pn;              // k_stage?_pcsr: number of product nodes (rowptr / col arrays are product-level there)
     const float* abs_sta;      // use_absolute_pos: [S][4] = {loc / (3 scale_rel), 0}, or null
     const float* abs_src;      // ... [G_ext][4] = {x_grid / (3 scale_rel), 0}
+    const unsigned* abs_ts;    // k_stage1_h2<.., ABS>: [S][2] x 8 B = the fp16 pieces of a station's scaled position {x, y, z, 0} (processing order)
+    const unsigned* abs_tg;    // ... [G_ext][2] x 8 B, source nodes
     const float* eb_sta;       // DataAggregationEdges: [S][48] per-station terms {layer 1 (30), 0, 0, layer 2 (15), 0}, or null
     const float* eb_src;       // ... [G][48] per-source-node terms
     const int32_t* src_tab;    // k_stage1_h2: [G][16] = {order[gi], its 15 source neighbours}, indexed by processing position gi
@@ -1590,7 +1598,7 @@ __device__ __forceinline__ void mma3(f32x16 (&acc)[N], const f32x4* lw, const in
         for (int k = 0; k < N; ++k) acc[k] = MFMA32H(w[k][WP[t]], b[BP[t]], acc[k]);
 }
 
-template <int KS, int KP, bool EDGES, bool BIG>
+template <int KS, int KP, bool EDGES, bool BIG, bool ABS = false>
 __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
     constexpr int NF4 = H2_IMG_FLOATS / 4;
@@ -1620,6 +1628,11 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XPC);
 
     const f32x4 fa0 = lw[(H2_FA + 0) * 64 + lane], fa1 = lw[(H2_FA + 1) * 64 + lane];
+    // use_absolute_pos: the six position columns of init_trns are one more K = 16 step per unit, B = {station piece, source piece}
+    f32x4 fp0, fp1;
+    if (ABS) { fp0 = lw[(H2_FABS + 0) * 64 + lane]; fp1 = lw[(H2_FABS + 1) * 64 + lane]; }
+    const unsigned tp_h = (unsigned)h * 8u;           // piece tables: [node][piece] x 8 B
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     f32x16 biasA = bias16(lbias, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) biasA[r] *= 16.f;
@@ -1654,8 +1667,13 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
         constexpr int NU = 1 + KS + KP;
         static_assert(NU % 2 == 0, "units are processed in pairs");
-        constexpr int DEPTH = GENIE_H2_DEPTH;
+        constexpr int DEPTH = ABS ? 4 : GENIE_H2_DEPTH;
         u32x4 buf[NU];
+        u32x2 tp[NU], tso, tgo;          // ABS: the unit's own position piece; this tile's station / source piece
+        if (ABS) {
+            tso = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sc * 16u));
+            tgo = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)g * 16u));
+        }
         auto issue = [&](int u) {
             off_t_ off;
             if (u == 0) off = gbase + sbase0;
@@ -1663,6 +1681,10 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
             else {
                 const unsigned nb = (unsigned)row_bcast_dyn(srcv, u - KS);
                 off = (BIG ? (off_t_)nb * gstride : (off_t_)__umul24(nb, (unsigned)gstride)) + sbase;
+            }
+            if (ABS && u > 0) {
+                if (u <= KS) tp[u] = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sta_id[u - 1] * 16u));
+                else tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)row_bcast_dyn(srcv, u - KS) * 16u));
             }
             if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
             buf[u] = *(const u32x4*)(xs + off);
@@ -1680,7 +1702,19 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
             for (int d = 0; d < 2; ++d)
                 if (u + DEPTH + d < NU) issue(u + DEPTH + d);
             asm volatile("" : "+v"(buf[u]), "+v"(buf[u + 1]));
-            f32x16 z0 = MFMA32H(fa1, buf[u], biasA), z1 = MFMA32H(fa1, buf[u + 1], biasA);
+            f32x16 z0, z1;
+            if (ABS) {
+                auto posb = [&](int uu) {
+                    return uu == 0 ? u32x4{tso.x, tso.y, tgo.x, tgo.y}
+                                   : uu <= KS ? u32x4{tp[uu].x, tp[uu].y, tgo.x, tgo.y} : u32x4{tso.x, tso.y, tp[uu].x, tp[uu].y};
+                };
+                const u32x4 p0 = posb(u), p1 = posb(u + 1);
+                z0 = MFMA32H(fp1, p0, biasA); z1 = MFMA32H(fp1, p1, biasA);
+                z0 = MFMA32H(fa1, buf[u], z0); z1 = MFMA32H(fa1, buf[u + 1], z1);
+                z0 = MFMA32H(fp0, p0, z0); z1 = MFMA32H(fp0, p1, z1);
+            } else {
+                z0 = MFMA32H(fa1, buf[u], biasA); z1 = MFMA32H(fa1, buf[u + 1], biasA);
+            }
             z0 = MFMA32H(fa0, buf[u], z0);
             z1 = MFMA32H(fa0, buf[u + 1], z1);
 #pragma unroll
@@ -4101,6 +4135,16 @@ __global__ void k_abs_table(const float* __restrict__ pos, int n, float inv, flo
     out[i] = k < 3 ? pos[r * 3 + k] * inv : 0.f;
 }
 
+// the two fp16 pieces of every row of an [n][4] scaled-position table, [n][2] x 8 B; `perm` (or null): row i = table row perm[i]
+__global__ void k_abs_pieces(const float* __restrict__ tab, const int32_t* __restrict__ perm, int n, unsigned* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f32x4 v = *(const f32x4*)(tab + (size_t)(perm ? perm[i] : i) * 4);
+    const unsigned a0 = cvt_pk_f16(v.x, v.y), b0 = cvt_pk_f16(v.z, 0.f);
+    const unsigned a1 = cvt_pk_f16(sub_f16_lo(v.x, a0), sub_f16_hi(v.y, a0)), b1 = cvt_pk_f16(sub_f16_lo(v.z, b0), 0.f);
+    *(u32x4*)(out + (size_t)i * 4) = u32x4{a0, b0, a1, b1};
+}
+
 // DataAggregationEdges (module.py:102-174, forward :1059-1072): every message carries phi(pos_j - pos_i) (3) and phi(|pos_j - pos_i|),
 // phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)); after mean aggregation that is a STATIC 4-vector per node of a base graph.
 __global__ void k_edge_feat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int n,
@@ -4561,6 +4605,8 @@ struct genie_ctx {
     const void* xs_ws;
     int xs_mm_copy;            // ... and the copy (slot % GENIE_NBIG at embed time) its message-mask row `mm` was written to
     float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
+    unsigned *abs_ts, *abs_tg; // ... their fp16 pieces for k_stage1_h2 (stations in processing order), rebuilt when abs_dirty
+    bool abs_dirty;
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
@@ -4593,10 +4639,11 @@ struct genie_ctx {
 namespace {
 
 // The station processing order is honoured by k_split_rows / the embedding's split rows, k_stage1_h2 (through the relabelled
-// station graph) and k_stage2_ord: active only while those are the kernels that run (not with use_absolute_pos, which takes
-// the generic stage-1 kernel).
+// station graph) and k_stage2_ord: active only while those are the kernels that run (use_absolute_pos together with the
+// edge-feature variant takes the generic stage-1 kernel).
+bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !c->use_h2); }
 bool sta_order_on(const genie_ctx* c) {
-    return c->sta_perm != nullptr && !c->pcsr && c->use_h2 && c->abs_sta == nullptr && !c->force_generic;
+    return c->sta_perm != nullptr && !c->pcsr && c->use_h2 && !abs_generic(c) && !c->force_generic;
 }
 
 constexpr int GENIE_NSLOT = 16;  // copies of the G-sized per-window buffers (genie_set_slot)
@@ -4699,7 +4746,7 @@ DaArgs make_da_args(const genie_ctx* c, float* ws) {
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
     }
     if (sta_order_on(c)) { a.sta_rowptr = c->sta_rowptr_p; a.sta_col = c->sta_col_p; a.sta_user = c->sta_perm; }
-    a.abs_sta = c->abs_sta; a.abs_src = c->abs_src;
+    a.abs_sta = c->abs_sta; a.abs_src = c->abs_src; a.abs_ts = c->abs_ts; a.abs_tg = c->abs_tg;
     a.eb_sta = c->has_edges ? (sta_order_on(c) ? c->ebias_sta_p : c->ebias_sta) : nullptr;
     a.eb_src = c->has_edges ? c->ebias_src : nullptr;
     a.seg = std::max(1, c->seg);
@@ -5212,7 +5259,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
     c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; c->xs_mm_copy = 0;
-    c->abs_sta = c->abs_src = nullptr;
+    c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr; c->abs_dirty = false;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
@@ -5330,8 +5377,8 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
 int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_absolute_pos: null context");
     if (!pos_sta || !pos_src) {
-        (void)hipFree(c->abs_sta); (void)hipFree(c->abs_src);
-        c->abs_sta = c->abs_src = nullptr;
+        (void)hipFree(c->abs_sta); (void)hipFree(c->abs_src); (void)hipFree(c->abs_ts); (void)hipFree(c->abs_tg);
+        c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr;
         return GENIE_OK;
     }
     if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_set_absolute_pos: not available on an irregular product graph");
@@ -5344,6 +5391,7 @@ int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_
     k_abs_table<<<(c->S * 4 + 255) / 256, 256, 0, st>>>(pos_sta, c->S, inv, c->abs_sta);
     k_abs_table<<<(c->G_ext * 4 + 255) / 256, 256, 0, st>>>(pos_src, c->G_ext, inv, c->abs_src);
     HIP_TRY(hipGetLastError());
+    c->abs_dirty = true;
     return GENIE_OK;
 }
 
@@ -5381,7 +5429,7 @@ int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
     for (void* q : old) (void)hipFree(q);
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
-    c->dirty = true;
+    c->dirty = true; c->abs_dirty = true;
     if (!order_host || c->pcsr) return GENIE_OK;
     const int S = c->S;
     std::vector<int32_t> perm(order_host, order_host + S), inv((size_t)S, -1);
@@ -5506,7 +5554,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (dbg_h0) a.dbg_h0 = dbg_tmp;
         if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
     }
-    if (((c->force_generic && !c->use_h2) || c->abs_sta) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
+    if (((c->force_generic && !c->use_h2) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
@@ -5535,6 +5583,19 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, H2_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
+        } else if (c->abs_sta) {
+            if (c->abs_dirty || !c->abs_ts) {
+                if (!c->abs_ts) {
+                    HIP_TRY(hipMalloc((void**)&c->abs_ts, 16 * (size_t)c->S));
+                    HIP_TRY(hipMalloc((void**)&c->abs_tg, 16 * (size_t)c->G_ext));
+                }
+                k_abs_pieces<<<(c->S + 255) / 256, 256, 0, st>>>(c->abs_sta, sta_order_on(c) ? c->sta_perm : nullptr, c->S, c->abs_ts);
+                k_abs_pieces<<<(c->G_ext + 255) / 256, 256, 0, st>>>(c->abs_src, nullptr, c->G_ext, c->abs_tg);
+                c->abs_dirty = false;
+                a.abs_ts = c->abs_ts; a.abs_tg = c->abs_tg;
+            }
+            if (big) k_stage1_h2<8, 15, false, true, true><<<grid, H2_THREADS, 0, st>>>(a);
+            else k_stage1_h2<8, 15, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
         } else if (c->has_edges) {
             if (big) k_stage1_h2<8, 15, true, true><<<grid, H2_THREADS, 0, st>>>(a);
             else k_stage1_h2<8, 15, true, false><<<grid, H2_THREADS, 0, st>>>(a);
