@@ -77,9 +77,8 @@ def parse():
                     help="with --tail-batch 1: push_window / flush_windows (genie_tail_batched over one window) instead of "
                          "forward_fixed_source_pipelined (the same tail launched call by call)")
     ap.add_argument("--tail-batch", type=int, default=None,
-                    help="windows per G-sized tail (push_window / flush_windows), 1..8; 1 = one tail per window. Default: 8 (with the "
-                         "fp32-MFMA tail kernels the batched tail is the faster form for resident windows too: 0.811 -> 0.776 ms per "
-                         "window on the same box, DESIGN.md section 5)")
+                    help="windows per G-sized tail (push_window / flush_windows), 1..16; 1 = one tail per window. Default: 16 (the tail "
+                         "kernels are latency-bound: same box 0.582 ms per window at 8, 0.576 at 16; DESIGN.md section 5)")
     ap.add_argument("--mode", default=None, choices=["replicas", "sharded", "stream", "train"],
                     help="default: the cfg2 window pipeline at N = 1; at N > 1 ONE cfg4 window sharded over source nodes with an "
                          "RCCL halo all-to-all + all-gather per window (strong scaling). replicas = window-parallel copies of "
@@ -257,7 +256,7 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
 
     acc = [None]
     first = [0]
-    net.window_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 8, 8))
+    net.window_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 16, 16))
 
     def flush(upto):
         y, x, _ = net.flush_windows(xg, xq, tq)
@@ -702,7 +701,7 @@ def main():
     xq = torch.from_numpy(geom.x_query).float().to(dev)
     tq = torch.from_numpy(geom.t_query).float().to(dev)
 
-    tail_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 8, 8))
+    tail_batch = max(1, min(a.tail_batch if a.tail_batch is not None else 16, 16))
     net.window_batch = tail_batch
 
     def step(i):

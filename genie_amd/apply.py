@@ -140,7 +140,7 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
 
 def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1,
                          n_grids=1.0, day_len=86400.0, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, max_t=None,
-                         times=None, tail_batch=8):
+                         times=None, tail_batch=16):
     """GPU-only apply loop: `P` [n,5] (t, station index in the model's station order, amp, prob, phase) sorted by time,
     `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used). `tail_batch`: windows
     per G-sized tail (1..8; 8 measured best with the device embedding in the loop, bench.py --mode stream)."""

@@ -503,11 +503,11 @@ class HipPath(object):
         return y, x, done
 
     # ---- window pipeline with batched tails: stage 1 / 2 per window, one G-sized tail per `window_batch` windows -------
-    MAX_BATCH = 8
+    MAX_BATCH = 16
     window_batch = 1      # windows per tail (set_window_batch); 1 = every window gets its own tail
 
     def set_window_batch(self, n):
-        """Windows per batched tail, 1..8. Measured at config 2: the batched tail needs 104 us of GPU time per window against 186
+        """Windows per batched tail, 1..16. Measured at config 2: the batched tail needs 104 us of GPU time per window against 186
         us for per-window tails, but its long persistent read-out workgroups hold CUs that the next stage-1 workgroups wait for:
         for resident windows one tail per window is ~1 % faster end to end, with the device embedding in the loop batches of 8
         are 3.6 % faster. Default 1 (results arrive per window); `apply_windows_device` uses 8."""
@@ -532,7 +532,7 @@ class HipPath(object):
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         self._refresh_static_edge_attr(edge_attr)
         if getattr(self, "_bt", None) is None:
-            groups = 3 if self.window_batch == 1 else 2        # batches in flight (16 workspace slots)
+            groups = 3 if self.window_batch == 1 else 2        # batches in flight (at most 32 workspace slots)
             self._bt = {"group": 0, "n": 0, "ev": [None] * groups, "turn": 0,
                         "streams": [self._new_side_stream() for _ in range(2)]}
             self.side_streams = list(getattr(self, "side_streams", None) or []) + self._bt["streams"]

@@ -916,7 +916,7 @@ def test_pipelined_forward_is_bitwise_equal_to_plain_forward():
         assert torch.equal(y0, y1) and torch.equal(x0, x1)
 
 
-@pytest.mark.parametrize("batch", [8, 1, 3])
+@pytest.mark.parametrize("batch", [16, 8, 1, 3])
 def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
     """push_window / flush_windows (stage 1 / 2 per window, ONE G-sized tail per batch of windows through genie_tail_batched):
     every window's (y, x) bit-identical to the single-stream forward_fixed_source; 19 windows = full batches in flight on
