@@ -92,6 +92,7 @@ def parse():
                     help="N = 1 default run: skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the line "
                          "then carries the constants of the committed profile)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the live config-3 training-step figure of the default line")
+    ap.add_argument("--no-stream", action="store_true", help="skip the live config-5 streaming figure of the default line")
     ap.add_argument("--no-cfg4-one-gpu", action="store_true",
                     help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
                          "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
@@ -225,7 +226,7 @@ def cpu_baseline(net, geom, win, n_timed=3):
     return y, x, float(np.median(times)), times, t1 * (G / float(Gs)), Gs
 
 
-def main_stream(a, geom, nq, rank, world, dev, dist):
+def main_stream(a, geom, nq, rank, world, dev, dist, emit=True):
     """BASELINE config 5: continuous-day sliding-window inference (86 400 s at 1 s stride), every rank holds the model
     and takes every world-th window; picks + travel-time table resident on the GPU, Slice/Mask embedded on device
     (genie_embed_window), Out_2 stacked on device. No collective in the loop (replicas)."""
@@ -321,10 +322,11 @@ def main_stream(a, geom, nq, rank, world, dev, dist):
         "windows_per_s": round(wps, 2), "seconds_of_data_per_wall_second": round(wps * stride, 2),
         "day_86400_windows_wall_s": round(86400.0 / wps, 1),
     }
-    if rank == 0:
+    if rank == 0 and emit:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out
 
 
 def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
@@ -853,6 +855,19 @@ def main():
                                             "phase_ms": o3["roofline"]["phase_ms"], "four_output_step": o3["four_output_step"]}
         except Exception as e:
             out["training_step_config3"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_stream:
+        # BASELINE config 5 (continuous-day sliding windows on this shape: device embedding + forward + Out_2 stacking), measured
+        # live through `--mode stream`'s code path
+        import copy
+        a5 = copy.copy(a)
+        a5.steps, a5.warmup = 320, 64
+        try:
+            o5 = main_stream(a5, geom, nq, 0, 1, dev, None, emit=False)
+            out["streaming_config5"] = {"config": o5["config"]["workload"], "steps": a5.steps, "ms_per_step": o5["ms_per_step"],
+                                        "windows_per_s": o5["windows_per_s"], "day_86400_windows_wall_s": o5["day_86400_windows_wall_s"]}
+        except Exception as e:
+            out["streaming_config5"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         yc, xc, cdt, ctimes, c1, gs = cpu_baseline(net, geom, wins[0], a.cpu_windows)

@@ -22,7 +22,12 @@
  *  - return value 0 = ok, negative = error; `genie_last_error()` gives the message (thread-local);
  *  - product-graph node id p = g * n_sta + s (process_utils.py:720-722). Source nodes [0, n_grid) are OWNED by
  *    this context; source nodes [n_grid, n_grid_ext) are HALO rows (owned by another GPU when the grid is
- *    sharded over source nodes) that only appear as neighbours in `src_col`.
+ *    sharded over source nodes) that only appear as neighbours in `src_col`;
+ *  - arithmetic: fp32 in, fp32 out, fp32 accumulation everywhere. On the reference's kNN graphs (8 station / 15 source
+ *    neighbours) stage 1 multiplies on the 16-bit matrix pipe with every fp32 operand as two fp16 pieces (x within one fp32
+ *    ulp, three partial products per product): fp32-class results, valid while the inputs and hidden states of
+ *    DataAggregation stay below 65504 in magnitude (beyond that the outputs turn non-finite; the environment variable
+ *    GENIE_S1=f32 selects the fp32-MFMA kernels, which have no such bound).
  */
 #ifndef GENIE_HIP_H
 #define GENIE_HIP_H
@@ -106,8 +111,9 @@ int genie_set_scale_t(genie_ctx* ctx, float scale_t);
 /* `use_absolute_pos: True` (config.yaml:92; module.py:916, :971, :1007): every product node's input gets its station position and
  * its source position, each divided by 3 * scale_rel, appended (in_channels 4 -> 10). Positions are [n_sta,3] / [n_grid_ext,3]
  * fp32 device pointers; the 6 extra columns of init_trns.weight go to the registry entry "DataAggregation.init_trns.weight_abs"
- * ([30,6] = weight[:, 4:10]) and "DataAggregation.init_trns.weight" keeps the [30,8] layout (weight[:, [0:4, 10:14]]). Stage 1 then
- * runs the generic fp32-MFMA kernel (the neighbours' hidden states are recomputed with their own positions). Null = off. */
+ * ([30,6] = weight[:, 4:10]) and "DataAggregation.init_trns.weight" keeps the [30,8] layout (weight[:, [0:4, 10:14]]). The
+ * neighbours' hidden states are recomputed with their own positions (one more K-step per neighbour in the f16x2 stage-1 kernel;
+ * two k-steps in the generic fp32-MFMA kernel that serves ragged graphs). Null = off. */
 int genie_set_absolute_pos(genie_ctx* ctx, const float* pos_sta, const float* pos_src, void* stream);
 /* DataAggregationEdges variant (`use_updated_model_definition: True`, config.yaml:95; module.py:102-174): every message is
  * [x_j || phi(pos_j - pos_i) || phi(|pos_j - pos_i|)], phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)) (forward :1059-1072,

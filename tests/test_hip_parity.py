@@ -90,6 +90,29 @@ def test_forward_fixed_source_drop_in(name):
         assert e32 <= 1e-5 + max_abs(c.ref(k), c.ref(k + "64")), (k, e32)
 
 
+@pytest.mark.parametrize("scale", [2.0 ** -12, 512.0])
+def test_stage1_piece_range_small_and_large_inputs(scale):
+    """The f16x2 stage 1 represents every activation by two fp16 pieces: normal fp16 numbers for |x| in [2^-2, 65504], an absolute
+    floor of 2^-25 below. Inputs scaled by 2^-12 (hidden states dominated by the biases, input terms far inside fp16's subnormal
+    range) and by 512 (hidden states up to ~1e3): stage 1's intermediates and x_latent against the oracle on the same inputs, to
+    the usual 1e-5 of their scale. (Beyond 65504 an activation overflows its first piece and the outputs turn non-finite:
+    GENIE_S1=f32 selects the fp32-MFMA kernels for such models.)"""
+    from oracle import genie_oracle as O
+    c = Case("odd_33x257")
+    Slice = (c.Slice * scale).contiguous()
+    w = {k: v.float() for k, v in c.weights.items()}
+    A_in_sta, A_in_src, _, _ = c.product_edges()
+    ref = O.data_aggregation(w, Slice, c.Mask, A_in_sta, A_in_src, full=True)
+    hp = make_engine(c)
+    _, _, h0, h1 = hp.da_stage1(Slice.to(DEV), c.Mask.to(DEV), debug=True)
+    x_latent, _ = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV), want_x_latent=True)
+    for got, k in ((h0, "h0"), (h1, "h1"), (x_latent, "x_latent")):
+        tol = 1e-5 * max(1.0, float(ref[k].abs().max()))
+        err = max_abs(got.cpu(), ref[k])
+        print("scale %g %s: max|ref| %.3g err %.3g" % (scale, k, float(ref[k].abs().max()), err))
+        assert torch.isfinite(got).all() and err <= tol, (k, err, tol)
+
+
 @pytest.mark.parametrize("name", EDGES_CASES)
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_updated_model_definition_forward_fixed_source(name, stage1, monkeypatch):
