@@ -1598,8 +1598,12 @@ __device__ __forceinline__ void mma3(f32x16 (&acc)[N], const f32x4* lw, const in
         for (int k = 0; k < N; ++k) acc[k] = MFMA32H(w[k][WP[t]], b[BP[t]], acc[k]);
 }
 
-template <int KS, int KP, bool EDGES, bool BIG, bool ABS = false>
+template <int KS, int KP, bool EDGES, bool BIG, bool ABS = false, bool PCSR = false>
 __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
+    // PCSR: irregular product graph (use_subgraph). A wave item is 32 consecutive product nodes; the neighbours of a node are
+    // product-node ids from the product-level CSRs (at most KS / KP of them: a missing one is the node itself with weight 0,
+    // the mean of an empty neighbourhood is 0); everything after the neighbour phase is the same code.
+    static_assert(!(PCSR && (EDGES || ABS)), "irregular product graphs: default model definition only");
     typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
     constexpr int NF4 = H2_IMG_FLOATS / 4;
     __shared__ f32x4 lw[NF4];
@@ -1649,20 +1653,53 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         sc_ = s < S ? s : S - 1;
         load_sta_ids<KS>(a.sta_col, sc_, sta_);
     };
-    int idv = 0, sc = 0, sta_id[KS];
+    constexpr int KPP = PCSR ? KP : 1;
+    auto fetch_pcsr = [&](long long pit_, long long& p_, bool& valid_, int (&sta_)[KS], int (&src_)[KPP], int& ds_, int& dp_) {
+        const long long pr = pit_ * 32 + (lane & 31);
+        valid_ = pr < a.Pn;
+        p_ = valid_ ? pr : a.Pn - 1;
+        const int eb = a.sta_rowptr[p_], fb = a.src_rowptr[p_];
+        ds_ = a.sta_rowptr[p_ + 1] - eb;
+        dp_ = a.src_rowptr[p_ + 1] - fb;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int v = a.sta_col[max(eb + min(q, ds_ - 1), 0)];
+            sta_[q] = q < ds_ ? v : (int)p_;
+        }
+#pragma unroll
+        for (int q = 0; q < KPP; ++q) {
+            const int v = a.src_col[max(fb + min(q, dp_ - 1), 0)];
+            src_[q] = q < dp_ ? v : (int)p_;
+        }
+    };
+    int idv = 0, sc = 0, sta_id[KS], src_id[KPP], dgs = 0, dgp = 0;
+    long long pcur = 0;
     bool valid = false;
-    const long long pit0 = w.it;
-    if (2 * pit0 < w.nitems) fetch_ids(pit0, idv, sc, valid, sta_id);
-    for (long long pit = pit0, pnext = 0; 2 * pit < w.nitems; pit = pnext) {
+    // wave items: Cartesian = pairs of (source node, station tile) items of the XCD-aware sweep; PCSR = 32 consecutive product nodes
+    const long long pit0 = PCSR ? (long long)blockIdx.x * (H2_THREADS / 64) + wave : w.it;
+    const long long pstride = PCSR ? (long long)gridDim.x * (H2_THREADS / 64) : w.stride;
+    const long long pend = PCSR ? (a.Pn + 31) / 32 : (w.nitems + 1) / 2;
+    if (pit0 < pend) {
+        if constexpr (PCSR) fetch_pcsr(pit0, pcur, valid, sta_id, src_id, dgs, dgp);
+        else fetch_ids(pit0, idv, sc, valid, sta_id);
+    }
+    for (long long pit = pit0, pnext = 0; pit < pend; pit = pnext) {
         asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park them all in VGPRs)
         // idv: every row of 16 lanes holds {source node, its KP neighbours} of its own tile: one DPP row broadcast per id
-        const int g = row_bcast<0>(idv);
-        const long long p = (long long)g * S + sc;
-        const off_t_ gbase0 = (off_t_)(unsigned)g * gstride;
-        const unsigned sbase0 = (unsigned)sc * (unsigned)XPC;
+        const int g = PCSR ? 0 : row_bcast<0>(idv);
+        const long long p = PCSR ? pcur : (long long)g * S + sc;
+        const off_t_ gbase0 = PCSR ? (off_t_)(unsigned long long)p * (off_t_)XPC : (off_t_)(unsigned)g * gstride;
+        const unsigned sbase0 = PCSR ? 0u : (unsigned)sc * (unsigned)XPC;
         off_t_ gbase = gbase0 + la;                  // + this lane's plane: one multiply-add per neighbour row address
         off_t_ sbase = (off_t_)sbase0 + la;
         const int srcv = idv;
+        // PCSR: per-lane weights of a present neighbour (16 x scaling and 1 / degree folded in)
+        float alS = 0.f, beS = 0.f, alP = 0.f, beP = 0.f;
+        if constexpr (PCSR) {
+            const float is = 1.f / (float)max(dgs, 1), ip = 1.f / (float)max(dgp, 1);
+            alS = (1.f + s11) * 0.03125f * is; beS = (1.f - s11) * 0.03125f * is;
+            alP = (1.f + s12) * 0.03125f * ip; beP = (1.f - s12) * 0.03125f * ip;
+        }
 
         // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
         constexpr int NU = 1 + KS + KP;
@@ -1677,6 +1714,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         auto issue = [&](int u) {
             off_t_ off;
             if (u == 0) off = gbase + sbase0;
+            else if (PCSR) off = (off_t_)(unsigned)(u <= KS ? sta_id[u - 1] : src_id[(u - KS - 1) % KPP]) * (off_t_)XPC + la;
             else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
             else {
                 const unsigned nb = (unsigned)row_bcast_dyn(srcv, u - KS);
@@ -1734,7 +1772,12 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                     m01[1] = buf[0].z; m23[1] = buf[0].w;      // lane h = 1: buf = x1
                     m01[2] = pk_mul_f16(own0.z, c16); m23[2] = pk_mul_f16(own0.w, c16);
                 } else {
-                    const float al = uu <= KS ? al1 : al2, be = uu <= KS ? be1 : be2;
+                    float al = uu <= KS ? al1 : al2, be = uu <= KS ? be1 : be2;
+                    if constexpr (PCSR) {
+                        const bool present = uu <= KS ? uu - 1 < dgs : uu - KS - 1 < dgp;
+                        al = present ? (uu <= KS ? alS : alP) : 0.f;
+                        be = present ? (uu <= KS ? beS : beP) : 0.f;
+                    }
                     if (uu == 1 || uu == KS + 1) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), al * z[r]);
@@ -1748,13 +1791,19 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
             }
             asm volatile("" : "+v"(sn), "+v"(gbase), "+v"(sbase), "+v"(jt));
         }
-        int idv_n = 0, sc_n = 0, sta_n[KS];
+        int idv_n = 0, sc_n = 0, sta_n[KS], src_n[KPP], dgs_n = 0, dgp_n = 0;
+        long long p_n = 0;
         bool valid_n = false;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_n[k] = 0;
-        pnext = pit + w.stride;
-        const bool has_next = 2 * pnext < w.nitems;
-        if (has_next) fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
+#pragma unroll
+        for (int k = 0; k < KPP; ++k) src_n[k] = 0;
+        pnext = pit + pstride;
+        const bool has_next = pnext < pend;
+        if (has_next) {
+            if constexpr (PCSR) fetch_pcsr(pnext, p_n, valid_n, sta_n, src_n, dgs_n, dgp_n);
+            else fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
+        }
         if (a.dbg_h0 != nullptr && valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1876,9 +1925,11 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                     f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
             }
         }
-        idv = idv_n; sc = sc_n; valid = valid_n;
+        idv = idv_n; sc = sc_n; valid = valid_n; pcur = p_n; dgs = dgs_n; dgp = dgp_n;
 #pragma unroll
         for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
+#pragma unroll
+        for (int k = 0; k < KPP; ++k) src_id[k] = src_n[k];
     }
 }
 
@@ -4609,6 +4660,7 @@ struct genie_ctx {
     bool abs_dirty;
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
+    bool pcsr_h2;              // ... with at most 8 / 15 neighbours per product node: k_stage1_h2<.., PCSR> applies
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
     float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
     bool has_edges;
@@ -5264,7 +5316,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr;
-    c->pcsr = false;
+    c->pcsr = false; c->pcsr_h2 = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
     if (c->kp_uni == 15) {
@@ -5366,6 +5418,16 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
     }
     c->pcsr = true;
     c->P = c->P_ext = n_prod;
+    {   // the f16x2 stage-1 kernel unrolls 8 station + 15 source neighbour slots per node: enough for every induced subgraph of
+        // the reference's kNN product graphs (process_utils.py:824-839); other graphs keep the generic fp32-MFMA kernel
+        std::vector<int32_t> r1((size_t)n_prod + 1), r2((size_t)n_prod + 1);
+        HIP_TRY(hipMemcpy(r1.data(), p_sta_rowptr, sizeof(int32_t) * r1.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r2.data(), p_src_rowptr, sizeof(int32_t) * r2.size(), hipMemcpyDeviceToHost));
+        int m1 = 0, m2 = 0;
+        for (long long i = 0; i < n_prod; ++i) { m1 = std::max(m1, r1[i + 1] - r1[i]); m2 = std::max(m2, r2[i + 1] - r2[i]); }
+        const char* e = getenv("GENIE_S1");
+        c->pcsr_h2 = m1 <= 8 && m2 <= 15 && !(e && strcmp(e, "f32") == 0);
+    }
     c->use_fast = c->use_h2 = 0;
     c->ks_uni = c->kp_uni = -1;
     layout_ws(c);
@@ -5556,6 +5618,14 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     }
     if (((c->force_generic && !c->use_h2) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
+    } else if (c->pcsr && c->pcsr_h2) {
+        unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
+        k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
+        a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
+        const long long nitems = (c->P + 31) / 32;
+        const int grid = (int)std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b);
+        if (c->P * XROW >= (1ll << 32)) k_stage1_h2<8, 15, false, true, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+        else k_stage1_h2<8, 15, false, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);

@@ -168,10 +168,14 @@ def test_use_absolute_pos_forward_fixed_source(name):
 
 
 @pytest.mark.parametrize("name", SUBGRAPH_CASES)
-def test_use_subgraph_irregular_product_graph(name):
+@pytest.mark.parametrize("stage1", ["default", "f32"])
+def test_use_subgraph_irregular_product_graph(name, stage1, monkeypatch):
     """f-4: `use_subgraph: True` (config.yaml:86, process_utils.py:744-849). set_adjacencies receives irregular product edge
-    lists; the module builds product-level CSRs (genie_ctx_create_subgraph) and the generic kernels k_stage1_pcsr /
-    k_stage2_pcsr / k_bip_out_seg run. Checked against the reference's own run on that graph and against the oracle."""
+    lists; the module builds product-level CSRs (genie_ctx_create_subgraph); stage 1 runs k_stage1_h2<.., PCSR> (neighbours as
+    product-node ids, missing ones with weight 0; GENIE_S1=f32: the generic fp32-MFMA k_stage1_pcsr), then k_stage2_pcsr /
+    k_bip_out_seg. Checked against the reference's own run on that graph and against the oracle."""
+    if stage1 == "f32":
+        monkeypatch.setenv("GENIE_S1", "f32")
     c = Case(name)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
