@@ -4698,7 +4698,8 @@ bool sta_order_on(const genie_ctx* c) {
     return c->sta_perm != nullptr && !c->pcsr && c->use_h2 && !abs_generic(c) && !c->force_generic;
 }
 
-constexpr int GENIE_NSLOT = 32;  // copies of the G-sized per-window buffers (genie_set_slot)
+constexpr int GENIE_NSLOT = 33;  // copies of the G-sized per-window buffers (genie_set_slot): two batches of 16 windows in flight + one
+                                 // for single-stream calls made while windows are pending
 constexpr int GENIE_NBIG = 4;    // copies of the P-sized c / wu / wv rows: slot % GENIE_NBIG
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -5984,7 +5985,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!pos || !t_query || !x_spatial_out || !y_out) return fail(GENIE_ERR_ARG, "genie_tail_batched: null argument");
-    if (nwin < 1 || slot0 < 0 || slot0 + nwin > GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_tail_batched: windows must fit slots [0, 32)");
+    if (nwin < 1 || slot0 < 0 || slot0 + nwin > GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_tail_batched: windows must fit slots [0, 33)");
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_batched: 1 <= n_t <= 10 required");
     if (x_out && (!x_query || !knn || n_query < 1 || k != RO_K)) return fail(GENIE_ERR_ARG, "genie_tail_batched: bad query arguments");
     if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_tail_batched: not available with use_subgraph product graphs");

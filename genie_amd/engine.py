@@ -277,6 +277,7 @@ class HipPath(object):
         self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
+        _lib.check(self.lib.genie_set_slot(self.ctx, self.PLAIN_SLOT), "genie_set_slot")
         # weight mirror
         n = self.lib.genie_weights_count()
         self.w_names = [self.lib.genie_weights_name(i).decode() for i in range(n)]
@@ -499,11 +500,12 @@ class HipPath(object):
         _lib.check(self.lib.genie_set_tail_grid(self.ctx, 0, 0), "genie_set_tail_grid")
         self._crosses_to(main, y, x)       # produced on the side stream, usually consumed by the caller on the main one
         self._ev_tail[slot] = done
-        _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
+        _lib.check(self.lib.genie_set_slot(self.ctx, self.PLAIN_SLOT), "genie_set_slot")
         return y, x, done
 
     # ---- window pipeline with batched tails: stage 1 / 2 per window, one G-sized tail per `window_batch` windows -------
     MAX_BATCH = 16
+    PLAIN_SLOT = 32       # workspace slot of the single-stream calls (path_fwd, read-outs): never one of a pending window's
     window_batch = 1      # windows per tail (set_window_batch); 1 = every window gets its own tail
 
     def set_window_batch(self, n):
@@ -524,8 +526,7 @@ class HipPath(object):
     def window_push(self, Slice, Mask, edge_attr):
         """Stage 1 + stage 2 of one window on the current stream, into the next workspace slot of the open batch; returns the
         number of windows now pending (call `windows_flush` when it reaches `window_batch`, or earlier). The plain
-        single-stream calls (`path_fwd`, read-outs) share workspace slot 0 with the first window of a batch: call
-        `wait_tails()` before mixing them with batches in flight."""
+        single-stream calls (`path_fwd`, read-outs) have a workspace slot of their own and may be mixed with pending windows."""
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -547,7 +548,7 @@ class HipPath(object):
         _lib.check(self.lib.genie_da_stage1(self.ctx, _ptr(Slice), _ptr(Mask), self._ws_ptr, st), "genie_da_stage1")
         _lib.check(self.lib.genie_da_stage2_partials(self.ctx, _ptr(Mask), _ptr(edge_attr), None, self._ws_ptr, st),
                    "genie_da_stage2_partials")
-        _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
+        _lib.check(self.lib.genie_set_slot(self.ctx, self.PLAIN_SLOT), "genie_set_slot")
         bt["n"] += 1
         return bt["n"]
 
@@ -1089,7 +1090,7 @@ class HipPath(object):
             try:
                 _lib.check(self.lib.genie_embed_window_split(*common, self._ws_ptr, _stream()), "genie_embed_window_split")
             finally:
-                _lib.check(self.lib.genie_set_slot(self.ctx, 0), "genie_set_slot")
+                _lib.check(self.lib.genie_set_slot(self.ctx, self.PLAIN_SLOT), "genie_set_slot")
         else:
             _lib.check(self.lib.genie_embed_window(*common, _stream()), "genie_embed_window")
         return Slice, Mask

@@ -93,7 +93,7 @@ int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
 int genie_set_static_edge_attr(genie_ctx* ctx, const float* edge_attr, void* stream);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
  * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists several times; `slot` (0..15) selects the copy
- * used by the calls issued next (32 copies of the G-sized buffers; the P-sized rows have 4, indexed slot % 4). With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
+ * used by the calls issued next (33 copies of the G-sized buffers: two batches of 16 windows in flight and one for single-stream calls; the P-sized rows have 4, indexed slot % 4). With several HIP streams a caller can run stage 1 of window i+1 (MFMA-bound), stage 2 of window
  * i (HBM-bound) and the G-sized tail of window i-1 (latency-bound) concurrently: all calls of one window use the same
  * slot, consecutive windows rotate through the slots, and the caller orders "stage 1 of window i+2 after stage 2 of window i" etc. with
  * events. Default slot 0. */
