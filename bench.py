@@ -51,7 +51,7 @@ F16_EXEC_FLOP_NODE = 120 * 32768.0 / 32.0
 F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r03_x_pmc_stage_kernels.txt"
+TRAFFIC_SOURCE = "profiles/r03_y_pmc_stage_kernels.txt"
 TRAFFIC_CFG2 = {"k_stage1": (2.0 * (1.476e5 + 3.127e4) + (5.000e5 + 7.031e4)) * 1024.0,     # k_split_rows_g + k_stage1_h2
                 "k_stage2": (2.0 * 5.553e5 + 1.631e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 # one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
