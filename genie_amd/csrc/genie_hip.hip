@@ -2209,8 +2209,14 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KP; ++k)
             if (k >= k0 && k < k1) {
-                const char* wvk = wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
-                rows.rv[k] = ABL(a, 1) ? rows.ru[0] : *(const f32x4*)(wvk + so);
+                // the row base of a source neighbour is wave-uniform: kept opaque in an SGPR pair, so that the load is
+                // `global_load v, voffset, s[base]` (left to itself hipcc hoists wvb + so into a VGPR pair and adds the
+                // scalar part with a 64-bit vector multiply-add per neighbour: 3 vector instructions each)
+                unsigned long long wvk = (unsigned long long)wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
+                asm volatile("" : "+s"(wvk));
+                typedef const __attribute__((address_space(1))) char* gbytes;
+                typedef const __attribute__((address_space(1))) f32x4* grow;
+                rows.rv[k] = ABL(a, 1) ? rows.ru[0] : *(grow)((gbytes)wvk + so);
             }
     };
     constexpr int KH = (KP + 1) / 2;
