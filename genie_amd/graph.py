@@ -196,12 +196,32 @@ def time_pointers(trv_out, max_t=None, dt=1.0, k=10, win=10.0):
         max_t = trv.max()
     dt_partition = np.arange(-win, win + max_t + dt, dt)
     k = int(min(k, n_src))
+    # The reference ranks ALL source nodes per (station, time step) with a stable argsort of |trv - t| and keeps k: ties go to
+    # the lower node id. Same result from the 2k candidates around t's insertion point in the station's sorted travel times,
+    # ranked by (distance, node id), as long as no node outside that window is as near as the k-th candidate (a tie the window
+    # cannot see); the rare rows where one is are ranked in full like the reference does.
+    n_t = len(dt_partition)
+    span = np.arange(-k, k)[None, :]
     out = []
     for ph in (0, 1):
-        e = np.empty((n_sta, len(dt_partition), k), dtype=np.int64)
+        e = np.empty((n_sta, n_t, k), dtype=np.int64)
         for i in range(n_sta):
-            d = np.abs(trv[:, i, ph].astype(np.float64)[None, :] - dt_partition[:, None])      # [n_t, G]
-            ip = np.argsort(d, axis=1, kind="stable")[:, :k]
-            e[i] = ip * n_sta + i
+            col = trv[:, i, ph].astype(np.float64)
+            order = np.argsort(col, kind="stable")
+            pos = np.searchsorted(col[order], dt_partition, side="left")[:, None] + span               # [n_t, 2k] sorted positions
+            ok = (pos >= 0) & (pos < n_src)
+            cand = order[np.clip(pos, 0, n_src - 1)]                                                    # node ids
+            d = np.where(ok, np.abs(col[cand] - dt_partition[:, None]), np.inf)
+            by_id = np.argsort(np.where(ok, cand, n_src), axis=1, kind="stable")
+            d_id, cand_id = np.take_along_axis(d, by_id, 1), np.take_along_axis(cand, by_id, 1)
+            by_d = np.argsort(d_id, axis=1, kind="stable")[:, :k]
+            e[i] = np.take_along_axis(cand_id, by_d, 1) * n_sta + i
+            d_k = np.take_along_axis(d_id, by_d[:, -1:], 1)[:, 0]
+            lo, hi = pos[:, 0] - 1, pos[:, -1] + 1
+            sv = col[order]
+            d_out = np.minimum(np.where(lo >= 0, np.abs(sv[np.clip(lo, 0, n_src - 1)] - dt_partition), np.inf),
+                               np.where(hi < n_src, np.abs(sv[np.clip(hi, 0, n_src - 1)] - dt_partition), np.inf))
+            for r in np.nonzero(d_out <= d_k)[0]:
+                e[i, r] = np.argsort(np.abs(col - dt_partition[r]), kind="stable")[:k] * n_sta + i
         out.append(e.reshape(-1))
     return out[0], out[1], dt_partition
