@@ -1104,3526 +1104,11 @@ __device__ __forceinline__ void gather_sum16(const float* __restrict__ base, lon
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// stage 1: everything of DataAggregation that does not need the SECOND pair of neighbour means
-//   h0 = PReLU(init_trns [X || M])                                        module.py:87-88 (own node + every neighbour)
-//   h1 = PReLU1([l1_t1_2 [h0 || mean_sta PReLU11(h0) || M] || l1_t2_2 [h0 || mean_src PReLU12(h0) || M]])   :90-92
-//   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)                      :94-95
-//   wu = l2_t1_2[:, 60:90] u,  wv = l2_t2_2[:, 60:90] v                  (operands of the second pair of means)
-//   c  = [l2_t1_2[:, 0:60] h1 + l2_t1_2[:, 90:94] M + b || l2_t2_2[...]]  (node-local part of :94-95)
-// Reads 32 B per product node (+ its neighbours' 32-B rows from L2), writes 256 B; h0 / h1 / u / v stay in VGPRs.
-// ------------------------------------------------------------------------------------------------
-// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
-// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
-// N independent accumulators x one 16-channel input block, k-step OUTER and accumulator INNER: consecutive MFMAs never
-// target the same accumulator, so the 40-cycle dependent-issue latency of v_mfma_f32_16x16x4_f32 (32-cycle issue) is
-// always covered (hipcc otherwise keeps the 4 dependent k-steps of one accumulator back to back).
-template <int N>
-__device__ __forceinline__ void mma_blocks(f32x4 (&acc)[N], const f32x4 (&w)[N], const f32x4 x) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = MFMA16(w[k][r], x[r], acc[k]);
-    }
-}
-
-// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
-// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
-__device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, const float* lbias, int lane, int q,
-                                             bool valid, long long p, int g, int sc, float mq, f32x4 x0, f32x4 x1, f32x4 n1a,
-                                             f32x4 n1b, f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
-    if (a.dbg_h0 != nullptr && valid) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            a.dbg_h0[p * 30 + 4 * q + r] = x0[r];
-            if (16 + 4 * q + r < 30) a.dbg_h0[p * 30 + 16 + 4 * q + r] = x1[r];
-        }
-    }
-    // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]; acc[k]: k = (half, tile)
-    f32x4 acc[4], w4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + (2 + k) * 16 + 4 * q);
-    if (a.eb_sta != nullptr) {   // DataAggregationEdges: the mean edge feature of a node is static, its Linear a per-node bias
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            acc[t] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 16 * t + 4 * q);
-            acc[2 + t] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 16 * t + 4 * q);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane];
-    mma_blocks<4>(acc, w4, x0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 1) * 64 + lane];
-    mma_blocks<4>(acc, w4, x1);
-    {   // the neighbour-mean blocks feed only their own half: two accumulators per operand, interleave the two operands
-        f32x4 wa[2], wb[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const f32x4 na = b == 0 ? n1a : n1b, nb = b == 0 ? n2a : n2b;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                wa[t] = lw[G1_L1(0, t, 2 + b) * 64 + lane];
-                wb[t] = lw[G1_L1(1, t, 2 + b) * 64 + lane];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[0] = MFMA16(wa[0][r], na[r], acc[0]);
-                acc[2] = MFMA16(wb[0][r], nb[r], acc[2]);
-                acc[1] = MFMA16(wa[1][r], na[r], acc[1]);
-                acc[3] = MFMA16(wb[1][r], nb[r], acc[3]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
-    if (a.save != nullptr && valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_T + k) * a.Pn + p) * 16 + 4 * q) = acc[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
-    if (a.dbg_h1 != nullptr && valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * (k & 1) + 4 * q + r < 30) a.dbg_h1[p * 60 + 30 * (k >> 1) + 16 * (k & 1) + 4 * q + r] = acc[k][r];
-    }
-    // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1); c_w = node-local layer-2 terms: 6 independent accumulators
-    f32x4 o6[6], w6[6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
-    o6[4] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
-    o6[5] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
-    if (a.eb_sta != nullptr) {
-        o6[4] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 4 * q);
-        o6[5] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 4 * q);
-    }
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w6[k] = lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane];
-        w6[4] = lw[G1_C(0, hb) * 64 + lane];
-        w6[5] = lw[G1_C(1, hb) * 64 + lane];
-        mma_blocks<6>(o6, w6, acc[hb]);
-    }
-    o6[4] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, o6[4]);
-    o6[5] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, o6[5]);
-    if (a.save != nullptr && valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_UP + k) * a.Pn + p) * 16 + 4 * q) = o6[k];
-    }
-    o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
-    o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
-    // wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v: two accumulators, interleaved
-    f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        w2[0] = lw[G1_W(0, b) * 64 + lane];
-        w2[1] = lw[G1_W(1, b) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            wuv[0] = MFMA16(w2[0][r], o6[b][r], wuv[0]);
-            wuv[1] = MFMA16(w2[1][r], o6[2 + b][r], wuv[1]);
-        }
-    }
-    if (valid && !ABL(a, 3)) {
-        *(f32x4*)(a.c + p * ROWC + 4 * q) = o6[4];
-        *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = o6[5];
-        *(f32x4*)(a.wu + p * ROWW + 4 * q) = wuv[0];
-        *(f32x4*)(a.wv + p * ROWW + 4 * q) = wuv[1];
-    }
-}
-
-// generic stage 1: any CSR graphs (ragged degrees, empty neighbourhoods)
-__global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
-    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
-    const float* lscal = lbias + G1_BIAS * 16;
-    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
-    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
-#endif
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const long long p = (long long)g * S + sc;
-        const float xs = a.slice[p * 4 + q];
-        const float mq = a.mask[p * 4 + q];
-        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
-        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-        // own hidden state
-        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
-        x0 = MFMA16(wi0.y, mq, x0);
-        x1 = MFMA16(wi1.y, mq, x1);
-        float lq = 0.f, gq = 0.f;                 // use_absolute_pos: this node's station / source position channel q
-        if (a.abs_sta != nullptr) {
-            lq = a.abs_sta[sc * 4 + q];
-            gq = a.abs_src[g * 4 + q];
-            x0 = MFMA16(wi0.z, lq, x0); x1 = MFMA16(wi1.z, lq, x1);
-            x0 = MFMA16(wi0.w, gq, x0); x1 = MFMA16(wi1.w, gq, x1);
-        }
-        if (a.save != nullptr && valid) {
-            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 0) * a.Pn + p) * 16 + 4 * q) = x0;
-            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 1) * a.Pn + p) * 16 + 4 * q) = x1;
-        }
-        x0 = prelu4u(x0, a0);
-        x1 = prelu4u(x1, a0);
-        // station-neighbour mean of PReLU11(h0): rows of the same source node
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
-        {
-            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            if (!ABL(a, 0)) {
-                if (s11 <= 1.f)
-                    gather_recompute<false, true>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
-                                                  bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
-                else
-                    gather_recompute<false, false>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
-                                                   bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n1a *= inv; n1b *= inv;
-        }
-        // source-neighbour mean of PReLU12(h0): same station, neighbouring source nodes (wave-uniform list)
-        f32x4 n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
-        {
-            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
-            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            if (!ABL(a, 1)) {
-                if (s12 <= 1.f)
-                    gather_recompute<true, true>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
-                                                 bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
-                else
-                    gather_recompute<true, false>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
-                                                  bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n2a *= inv; n2b *= inv;
-        }
-        stage1_dense(a, lw, lbias, lane, q, valid, p, g, sc, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
-    }
-}
-
-// Stage 1 on an IRREGULAR product graph (`use_subgraph: True`, process_utils.py:744-849): the product nodes are an arbitrary
-// list of (station, source) pairs and both edge sets are CSR lists over PRODUCT-node ids (a.sta_rowptr/col, a.src_rowptr/col
-// are indexed by product node here). A tile is 16 consecutive product nodes; same arithmetic as k_stage1.
-__global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
-    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
-    const float* lscal = lbias + G1_BIAS * 16;
-    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
-    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const long long ntiles = (a.Pn + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
-         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));
-#endif
-        const long long pr = tile * 16 + j;
-        const bool valid = pr < a.Pn;
-        const long long p = valid ? pr : a.Pn - 1;
-        const float xs = a.slice[p * 4 + q];
-        const float mq = a.mask[p * 4 + q];
-        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
-        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
-        x0 = MFMA16(wi0.y, mq, x0);
-        x1 = MFMA16(wi1.y, mq, x1);
-        x0 = prelu4u(x0, a0);
-        x1 = prelu4u(x1, a0);
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
-        {
-            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
-            if (s11 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
-            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n1a *= inv; n1b *= inv;
-        }
-        {
-            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
-            if (s12 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
-            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n2a *= inv; n2b *= inv;
-        }
-        stage1_dense(a, lw, lbias, lane, q, valid, p, 0, 0, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
-    }
-}
-
-// the KS station-neighbour ids of one station as wide loads: a dword load whose lanes hit 16 different 32-B segments costs the
-// texture path about as much as two and a half full 1-KB row loads (tools/: skeleton ablations of k_stage2_fast), and a tile
-// issued KS of them
-template <int KS>
-__device__ __forceinline__ void load_sta_ids(const int32_t* __restrict__ sta_col, int sc, int (&sta)[KS]) {
-    static_assert(KS % 4 == 0, "station-neighbour rows are read as 16-byte chunks");
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int c = 0; c < KS / 4; ++c) {
-        const i32x4 v = *(const i32x4*)(sta_col + sc * KS + 4 * c);
-        sta[4 * c] = v.x; sta[4 * c + 1] = v.y; sta[4 * c + 2] = v.z; sta[4 * c + 3] = v.w;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stage 1 on the 16-bit matrix pipe with fp32-class operands ("f16x2").
-//
-// Measured on MI355X (tools/mfma_peak*.hip, tools/valu_rate.hip, tools/mfma_overlap.hip): v_mfma_f32_16x16x4_f32 runs at the
-// fp32 VECTOR rate and does not overlap with VALU work, so the fp32-MFMA kernel above is bound by the sum of both; a 16-bit
-// 32x32x16 MFMA does 16x the FLOPs in the same 32 cycles (and hides ~10 of them behind vector work).
-//
-//  * v_mfma_f32_32x32x16_f16: D[ch, node] for 32 channels x 32 nodes. A wave owns TWO 16-station tiles (lanes
-//    0-15/32-47 and 16-31/48-63). Lane (j = lane&31, h = lane>>5) holds D channels 8*(r>>2) + 4h + (r&3), r = 0..15,
-//    of node j; K-step ks of the next layer consumes registers 8ks..8ks+7 of both lanes of a node (16 channels), so an
-//    accumulator block becomes B operands without any cross-lane movement. All our channel groups are 30 wide: one
-//    32-block each; the two padding slots of a block (channels 30, 31: lane h = 1, registers 14, 15) carry the Mask
-//    inputs of `cat(h, n, Mask)`.
-//  * raw inputs arrive as 32-B rows [x0 | x1] of 8 fp16 each (x = Slice || Mask), written by k_split_rows, stored PLANAR
-//    (piece q of row p at q * rows * 16 + p * 16: a half-wave reads one piece of 32 consecutive rows as 512 contiguous bytes).
-//    A neighbour's hidden state is 2 MFMAs (K = 16 = the two 8-wide pieces).
-//  * mean_k PReLU_s(z_k) = sum_k (al z_k + be |z_k|): two fused multiply-adds per neighbour value into one accumulator.
-// ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int XROW = 32;                 // bytes per split input row: two 16-B pieces
-constexpr int XPC = 16;                  // bytes per piece
-constexpr int H2_THREADS = 512;
-
-// ---- f16x2: x ~ x0 + x1 with x0 = rn16(x), x1 = rn16(x - x0): 11 + 1 + 11 significant bits, i.e. within one fp32 ulp of x
-// (exact when the residual needs <= 11 bits) while x1 stays a normal fp16 number (|x| >= 2^-2), within 2^-25 absolute below
-// that (fp16 subnormals: the MFMA keeps them, tools/h2_probe.hip). Overflow needs |x| > 65504.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define MFMA32H(a, b, c) \
-    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
-__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {            // round to nearest even, both halves
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float sub_f16_lo(float x, unsigned p) {              // x - float(p.lo), one exact fp32 operation
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
-}
-__device__ __forceinline__ float sub_f16_hi(float x, unsigned p) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
-}
-constexpr unsigned H2_SIXTEENTH = 0x2c002c00u;        // (1/16, 1/16) as an fp16 pair
-__device__ __forceinline__ unsigned pk_mul_f16(unsigned p, unsigned c) {
-    unsigned r;
-    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(c));
-    return r;
-}
-// one fp16 piece (low 16 bits) of v; codes as in build_h2_table
-__device__ __forceinline__ unsigned f16_piece(float v, int piece) {
-    if (piece >= 2) { v *= 16.f; piece -= 2; }
-    const unsigned p0 = cvt_pk_f16(v, 0.f);
-    if (piece == 0) return p0 & 0xffffu;
-    const float r = sub_f16_lo(v, p0);
-    return cvt_pk_f16(r, 0.f) & 0xffffu;
-}
-__device__ __forceinline__ unsigned f16_piece_w(float v, int piece) {            // weight pieces: code 1 = rn16(16 (W - W0))
-    if (piece != 1) return f16_piece(v, piece);
-    const unsigned p0 = cvt_pk_f16(v, 0.f);
-    return cvt_pk_f16(16.f * sub_f16_lo(v, p0), 0.f) & 0xffffu;
-}
-// the split rows of one [Slice || Mask] row: two fp16 planes
-__device__ __forceinline__ void store_split_row(unsigned* __restrict__ out, long long rows, long long p, const float (&v)[8]) {
-    u32x4 o0, o1;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        o0[d] = cvt_pk_f16(v[2 * d], v[2 * d + 1]);
-        o1[d] = cvt_pk_f16(sub_f16_lo(v[2 * d], o0[d]), sub_f16_hi(v[2 * d + 1], o0[d]));
-    }
-    *(u32x4*)(out + p * 4) = o0;
-    *(u32x4*)(out + (rows + p) * 4) = o1;
-}
-
-__global__ void k_pack_h2(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out, int nfrag,
-                          int ntail) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < nfrag * 64) {
-        u32x4 o;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            unsigned u[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int32_t ent = tbl[idx * 8 + 2 * d + k];
-                u[k] = ent < 0 ? 0u : f16_piece_w(raw[ent & 0x0fffffff], (ent >> 28) & 3);
-            }
-            o[d] = u[0] | (u[1] << 16);
-        }
-        ((u32x4*)out)[idx] = o;
-    } else if (idx < nfrag * 64 + ntail) {     // fp32 tail: bias blocks and PReLU slopes
-        const int k = idx - nfrag * 64;
-        const int32_t ent = tbl[nfrag * 512 + k];
-        out[nfrag * 256 + k] = ent < 0 ? 0.f : raw[ent];
-    }
-}
-
-// [Slice || Mask] rows (8 fp32) -> 32-B rows of two fp16x8 pieces
-// sta_user (internal station -> caller's station, or null): the rows of a source node are written in the station processing order
-__global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
-                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= rows) return;
-    long long pu = p;
-    if (sta_user != nullptr) {
-        const long long g = p / S;
-        pu = g * S + sta_user[(int)(p - g * S)];
-    }
-    const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
-    if (sta_user != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));      // the message mask of stage 2 (module.py:226)
-    const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
-    store_split_row(out, rows, p, v);
-}
-
-// Same with a station processing order, one workgroup per source node: the node's S rows are read in the caller's order
-// (coalesced), staged in LDS, and written in processing order (coalesced); S <= SPLIT_G_MAXS rows fit the 64-KB staging buffer.
-constexpr int SPLIT_G_MAXS = 2048;
-__global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
-                                                      unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
-                                                      float* __restrict__ mm, long long rows) {
-    extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
-    const long long base = (long long)blockIdx.x * S;
-    for (int r = threadIdx.x; r < S; r += blockDim.x) {
-        *(f32x4*)(stg + r * 8) = *(const f32x4*)(slice + (base + r) * 4);
-        *(f32x4*)(stg + r * 8 + 4) = *(const f32x4*)(mask + (base + r) * 4);
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < S; r += blockDim.x) {
-        const int u = sta_user[r];
-        const f32x4 s = *(const f32x4*)(stg + u * 8), m = *(const f32x4*)(stg + u * 8 + 4);
-        mm[base + r] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
-        const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
-        store_split_row(out, rows, base + r, v);
-    }
-}
-
-// exact PReLU in two VALU ops for any slope: max(x, s*x) when s <= 1, min(x, s*x) otherwise, as med3(x, s*x, +-inf)
-__device__ __forceinline__ f32x16 prelu16(f32x16 x, float s, float sel) {
-    f32x16 y;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = __builtin_amdgcn_fmed3f(x[r], x[r] * s, sel);
-    return y;
-}
-__device__ __forceinline__ f32x16 bias16(const float* lbias, int blk, int h) {
-    f32x16 y;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const f32x4 t = *(const f32x4*)(lbias + blk * 32 + 8 * b + 4 * h);
-        y[4 * b] = t.x; y[4 * b + 1] = t.y; y[4 * b + 2] = t.z; y[4 * b + 3] = t.w;
-    }
-    return y;
-}
-// training forward: a 32-channel accumulator (register r = channel 8 (r >> 2) + 4 h + (r & 3)) as two 16-float blocks of the
-// block-planar save buffer [blk][P][16] the backward passes read (channels 30, 31 are padding there: zero)
-__device__ __forceinline__ void h2_save32(float* __restrict__ save, long long Pn, int blk0, long long p, int h, const f32x16& v) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f32x4 o = {v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]};
-        if (m == 3 && h == 1) { o.z = 0.f; o.w = 0.f; }
-        *(f32x4*)(save + ((size_t)(blk0 + (m >> 1)) * Pn + p) * 16 + 8 * (m & 1) + 4 * h) = o;
-    }
-}
-// ------------------------------------------------------------------------------------------------
-// STAGE 1, f16x2 form. An activation x is split into x0 = rn16(x), x1 = rn16(x - x0) (one v_cvt_pk_f16_f32 per pair and
-// piece, one v_fma_mix_f32 per value) and a weight into W0 = rn16(W), W1' = rn16(16 (W - W0)); a K-step is THREE products,
-// smallest first: W0 x1 + W1' (x0 / 16) + W0 x0 (x0 / 16: one v_pk_mul_f16 per pair). The scaled pair keeps the weight's second
-// piece a normal fp16 number; without it that piece falls into fp16's subnormal range (absolute floor 2^-25) and the hidden
-// states lose ~2x in accuracy (oracle-level emulation of the arithmetic on the o1_20x500 fixture: x_latent rms error vs fp64
-// 1.30e-7 unscaled, 0.81e-7 scaled; three exact bf16 pieces with six products, the round-1..3 form: 0.68e-7; the reference's
-// own fp32: 1.13e-7). Dropped: W1 x1 (2^-24 of a product) and the last-bit rounding of x1: the result is fp32-CLASS, not
-// bit-for-bit fp32. The input layer (K = 8: [x0 ; x1] fill one K = 16 step) is computed 16 x too large as a whole,
-// [P|P][x0;x1] + [Q|Q][x0;x1] with P + Q = 16 W and C = 16 b: the neighbour sums absorb the factor in their constants, the
-// node's own h0 in its PReLU. Per wave-tile (32 nodes): 120 MFMAs (48 neighbour recompute, 24 layer 1, 36 u / v / c,
-// 12 wu / wv; the bf16x3 form needed 216) and ~1500 vector instructions (2050).
-// ------------------------------------------------------------------------------------------------
-// lane k of every row of 16 lanes, broadcast to the row (DPP row_newbcast, gfx90a+)
-template <int K_>
-__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K_, 0xf, 0xf, false); }
-__device__ __forceinline__ int row_bcast_dyn(int v, int k) {     // k is a compile-time constant after unrolling
-    switch (k) {
-        case 0: return row_bcast<0>(v); case 1: return row_bcast<1>(v); case 2: return row_bcast<2>(v); case 3: return row_bcast<3>(v);
-        case 4: return row_bcast<4>(v); case 5: return row_bcast<5>(v); case 6: return row_bcast<6>(v); case 7: return row_bcast<7>(v);
-        case 8: return row_bcast<8>(v); case 9: return row_bcast<9>(v); case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
-        case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
-    }
-}
-template <int KS_>
-__device__ __forceinline__ void split8h(const f32x16& v, u32x4 (&p)[3], unsigned sixteenth) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const float a = v[8 * KS_ + 2 * d], b = v[8 * KS_ + 2 * d + 1];
-        const unsigned p0 = cvt_pk_f16(a, b);
-        p[0][d] = p0;
-        p[1][d] = cvt_pk_f16(sub_f16_lo(a, p0), sub_f16_hi(b, p0));
-        p[2][d] = pk_mul_f16(p0, sixteenth);
-    }
-}
-// the three partial products of one K-step for N independent accumulators sharing the B pieces {x0, x1, x0 / 16}
-template <int N>
-__device__ __forceinline__ void mma3(f32x16 (&acc)[N], const f32x4* lw, const int (&f0)[N], int lane, const u32x4 (&b)[3]) {
-    f32x4 w[N][2];
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) w[k][p] = lw[(f0[k] + p) * 64 + lane];
-    constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = MFMA32H(w[k][WP[t]], b[BP[t]], acc[k]);
-}
-
-template <int KS, int KP, bool EDGES, bool BIG, bool ABS = false, bool PCSR = false>
-__global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
-    // PCSR: irregular product graph (use_subgraph). A wave item is 32 consecutive product nodes; the neighbours of a node are
-    // product-node ids from the product-level CSRs (at most KS / KP of them: a missing one is the node itself with weight 0,
-    // the mean of an empty neighbourhood is 0); everything after the neighbour phase is the same code.
-    static_assert(!(PCSR && (EDGES || ABS)), "irregular product graphs: default model definition only");
-    typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
-    constexpr int NF4 = H2_IMG_FLOATS / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += H2_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + H2_FRAGS * 64);
-    const float* lscal = lbias + H2_NBIAS * 32;
-    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
-    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
-    const float inf = __builtin_inff();
-    const float sel0 = a0 <= 1.f ? inf : -inf, sel1 = a1 <= 1.f ? inf : -inf;
-    const float sel21 = a21 <= 1.f ? inf : -inf, sel22 = a22 <= 1.f ? inf : -inf;
-    // mean_k PReLU_s(z_k) = al * sum z_k + be * sum |z_k|; the z_k arrive 16 x too large
-    const float al1 = (1.f + s11) / (32.f * KS), be1 = (1.f - s11) / (32.f * KS);
-    const float al2 = (1.f + s12) / (32.f * KP), be2 = (1.f - s12) / (32.f * KP);
-    const unsigned c16 = __builtin_amdgcn_readfirstlane(H2_SIXTEENTH);
-
-    int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
-    const bool hi = h != 0;
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    const char* xs = (const char*)a.xs;
-    const off_t_ la = hi ? (off_t_)a.xs_plane : (off_t_)0;          // lane h = 0 loads x0, lane h = 1 loads x1: [x0 ; x1] is one K = 16 step
-    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XPC);
-
-    const f32x4 fa0 = lw[(H2_FA + 0) * 64 + lane], fa1 = lw[(H2_FA + 1) * 64 + lane];
-    // use_absolute_pos: the six position columns of init_trns are one more K = 16 step per unit, B = {station piece, source piece}
-    f32x4 fp0, fp1;
-    if (ABS) { fp0 = lw[(H2_FABS + 0) * 64 + lane]; fp1 = lw[(H2_FABS + 1) * 64 + lane]; }
-    const unsigned tp_h = (unsigned)h * 8u;           // piece tables: [node][piece] x 8 B
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    f32x16 biasA = bias16(lbias, 0, h);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) biasA[r] *= 16.f;
-
-    int jt = jj;
-    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, bool& valid_, int (&sta_)[KS]) {
-        int gi0, tb0, gi1, tb1;
-        w.decode(2 * pit_, gi0, tb0);
-        const bool second = 2 * pit_ + 1 < w.nitems;
-        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
-        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
-        const int s = (half ? tb1 : tb0) * 16 + jt;
-        valid_ = s < S && (second || !half);
-        sc_ = s < S ? s : S - 1;
-        load_sta_ids<KS>(a.sta_col, sc_, sta_);
-    };
-    constexpr int KPP = PCSR ? KP : 1;
-    auto fetch_pcsr = [&](long long pit_, long long& p_, bool& valid_, int (&sta_)[KS], int (&src_)[KPP], int& ds_, int& dp_) {
-        const long long pr = pit_ * 32 + (lane & 31);
-        valid_ = pr < a.Pn;
-        p_ = valid_ ? pr : a.Pn - 1;
-        const int eb = a.sta_rowptr[p_], fb = a.src_rowptr[p_];
-        ds_ = a.sta_rowptr[p_ + 1] - eb;
-        dp_ = a.src_rowptr[p_ + 1] - fb;
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-            const int v = a.sta_col[max(eb + min(q, ds_ - 1), 0)];
-            sta_[q] = q < ds_ ? v : (int)p_;
-        }
-#pragma unroll
-        for (int q = 0; q < KPP; ++q) {
-            const int v = a.src_col[max(fb + min(q, dp_ - 1), 0)];
-            src_[q] = q < dp_ ? v : (int)p_;
-        }
-    };
-    int idv = 0, sc = 0, sta_id[KS], src_id[KPP], dgs = 0, dgp = 0;
-    long long pcur = 0;
-    bool valid = false;
-    // wave items: Cartesian = pairs of (source node, station tile) items of the XCD-aware sweep; PCSR = 32 consecutive product nodes
-    const long long pit0 = PCSR ? (long long)blockIdx.x * (H2_THREADS / 64) + wave : w.it;
-    const long long pstride = PCSR ? (long long)gridDim.x * (H2_THREADS / 64) : w.stride;
-    const long long pend = PCSR ? (a.Pn + 31) / 32 : (w.nitems + 1) / 2;
-    if (pit0 < pend) {
-        if constexpr (PCSR) fetch_pcsr(pit0, pcur, valid, sta_id, src_id, dgs, dgp);
-        else fetch_ids(pit0, idv, sc, valid, sta_id);
-    }
-    for (long long pit = pit0, pnext = 0; pit < pend; pit = pnext) {
-        asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park them all in VGPRs)
-        // idv: every row of 16 lanes holds {source node, its KP neighbours} of its own tile: one DPP row broadcast per id
-        const int g = PCSR ? 0 : row_bcast<0>(idv);
-        const long long p = PCSR ? pcur : (long long)g * S + sc;
-        const off_t_ gbase0 = PCSR ? (off_t_)(unsigned long long)p * (off_t_)XPC : (off_t_)(unsigned)g * gstride;
-        const unsigned sbase0 = PCSR ? 0u : (unsigned)sc * (unsigned)XPC;
-        off_t_ gbase = gbase0 + la;                  // + this lane's plane: one multiply-add per neighbour row address
-        off_t_ sbase = (off_t_)sbase0 + la;
-        const int srcv = idv;
-        // PCSR: per-lane weights of a present neighbour (16 x scaling and 1 / degree folded in)
-        float alS = 0.f, beS = 0.f, alP = 0.f, beP = 0.f;
-        if constexpr (PCSR) {
-            const float is = 1.f / (float)max(dgs, 1), ip = 1.f / (float)max(dgp, 1);
-            alS = (1.f + s11) * 0.03125f * is; beS = (1.f - s11) * 0.03125f * is;
-            alP = (1.f + s12) * 0.03125f * ip; beP = (1.f - s12) * 0.03125f * ip;
-        }
-
-        // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
-        constexpr int NU = 1 + KS + KP;
-        static_assert(NU % 2 == 0, "units are processed in pairs");
-        constexpr int DEPTH = ABS ? 4 : GENIE_H2_DEPTH;
-        u32x4 buf[NU];
-        u32x2 tp[NU], tso, tgo;          // ABS: the unit's own position piece; this tile's station / source piece
-        if (ABS) {
-            tso = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sc * 16u));
-            tgo = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)g * 16u));
-        }
-        auto issue = [&](int u) {
-            off_t_ off;
-            if (u == 0) off = gbase + sbase0;
-            else if (PCSR) off = (off_t_)(unsigned)(u <= KS ? sta_id[u - 1] : src_id[(u - KS - 1) % KPP]) * (off_t_)XPC + la;
-            else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
-            else {
-                const unsigned nb = (unsigned)row_bcast_dyn(srcv, u - KS);
-                off = (BIG ? (off_t_)nb * gstride : (off_t_)__umul24(nb, (unsigned)gstride)) + sbase;
-            }
-            if (ABS && u > 0) {
-                if (u <= KS) tp[u] = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sta_id[u - 1] * 16u));
-                else tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)row_bcast_dyn(srcv, u - KS) * 16u));
-            }
-            if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
-            buf[u] = *(const u32x4*)(xs + off);
-        };
-        const u32x4 own0 = *(const u32x4*)(xs + (gbase0 + sbase0));         // x0 of the own row (lanes h = 1: Mask pads)
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) issue(u);
-
-        f32x16 sn, h0;          // sn: running mean_k PReLU_s(z_k) = sum_k (al z_k + be |z_k|), two fused multiply-adds per value
-        u32x4 h0p[2][3], n1p[2][3], n2p[2][3];
-        unsigned m01[3], m23[3];          // Mask pieces {x0, x1, x0 / 16} (lanes h = 1): fp16 pairs (M0,M1) and (M2,M3)
-#pragma unroll
-        for (int u = 0; u < NU; u += 2) {
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-                if (u + DEPTH + d < NU) issue(u + DEPTH + d);
-            asm volatile("" : "+v"(buf[u]), "+v"(buf[u + 1]));
-            f32x16 z0, z1;
-            if (ABS) {
-                auto posb = [&](int uu) {
-                    return uu == 0 ? u32x4{tso.x, tso.y, tgo.x, tgo.y}
-                                   : uu <= KS ? u32x4{tp[uu].x, tp[uu].y, tgo.x, tgo.y} : u32x4{tso.x, tso.y, tp[uu].x, tp[uu].y};
-                };
-                const u32x4 p0 = posb(u), p1 = posb(u + 1);
-                z0 = MFMA32H(fp1, p0, biasA); z1 = MFMA32H(fp1, p1, biasA);
-                z0 = MFMA32H(fa1, buf[u], z0); z1 = MFMA32H(fa1, buf[u + 1], z1);
-                z0 = MFMA32H(fp0, p0, z0); z1 = MFMA32H(fp0, p1, z1);
-            } else {
-                z0 = MFMA32H(fa1, buf[u], biasA); z1 = MFMA32H(fa1, buf[u + 1], biasA);
-            }
-            z0 = MFMA32H(fa0, buf[u], z0);
-            z1 = MFMA32H(fa0, buf[u + 1], z1);
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                f32x16 z = d == 0 ? z0 : z1;
-                const int uu = u + d;
-                if (uu == 0) {
-                    if (a.save != nullptr && valid) {
-                        f32x16 zu;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) zu[r] = z[r] * 0.0625f;
-                        h2_save32(a.save, a.Pn, SV_Z0, p, h, zu);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h0[r] = __builtin_amdgcn_fmed3f(z[r] * 0.0625f, z[r] * (0.0625f * a0), sel0);
-                    m01[0] = own0.z;   m23[0] = own0.w;
-                    m01[1] = buf[0].z; m23[1] = buf[0].w;      // lane h = 1: buf = x1
-                    m01[2] = pk_mul_f16(own0.z, c16); m23[2] = pk_mul_f16(own0.w, c16);
-                } else {
-                    float al = uu <= KS ? al1 : al2, be = uu <= KS ? be1 : be2;
-                    if constexpr (PCSR) {
-                        const bool present = uu <= KS ? uu - 1 < dgs : uu - KS - 1 < dgp;
-                        al = present ? (uu <= KS ? alS : alP) : 0.f;
-                        be = present ? (uu <= KS ? beS : beP) : 0.f;
-                    }
-                    if (uu == 1 || uu == KS + 1) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), al * z[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), fmaf(al, z[r], sn[r]));
-                    }
-                }
-                if (uu == KS) { split8h<0>(sn, n1p[0], c16); split8h<1>(sn, n1p[1], c16); }
-                if (uu == NU - 1) { split8h<0>(sn, n2p[0], c16); split8h<1>(sn, n2p[1], c16); }
-            }
-            asm volatile("" : "+v"(sn), "+v"(gbase), "+v"(sbase), "+v"(jt));
-        }
-        int idv_n = 0, sc_n = 0, sta_n[KS], src_n[KPP], dgs_n = 0, dgp_n = 0;
-        long long p_n = 0;
-        bool valid_n = false;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
-#pragma unroll
-        for (int k = 0; k < KPP; ++k) src_n[k] = 0;
-        pnext = pit + pstride;
-        const bool has_next = pnext < pend;
-        if (has_next) {
-            if constexpr (PCSR) fetch_pcsr(pnext, p_n, valid_n, sta_n, src_n, dgs_n, dgp_n);
-            else fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
-        }
-        if (a.dbg_h0 != nullptr && valid) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
-                if (ch < 30) a.dbg_h0[p * 30 + ch] = h0[r];
-            }
-        }
-        split8h<0>(h0, h0p[0], c16);
-        split8h<1>(h0, h0p[1], c16);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {     // padding slots (channels 30, 31) carry the Mask: [h0 | M0 M1], [n | M2 M3]
-            h0p[1][q].w = hi ? m01[q] : h0p[1][q].w;
-            n1p[1][q].w = hi ? m23[q] : n1p[1][q].w;
-            n2p[1][q].w = hi ? m23[q] : n2p[1][q].w;
-        }
-        // ---- layer 1: tr_t = l1_t{1,2}_2 [h0 || n_t || Mask], both halves at once
-        f32x16 acc[2] = {bias16(lbias, 1, h), bias16(lbias, 2, h)};
-        if (EDGES) {   // DataAggregationEdges: static per-station / per-source-node terms of layer 1
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 8 * b + 4 * h);
-                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 8 * b + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[0][4 * b + e] += es[e]; acc[1][4 * b + e] += eg[e]; }
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int f0[2] = {H2_FL1 + (0 * 4 + ks) * 2, H2_FL1 + (1 * 4 + ks) * 2};
-            mma3<2>(acc, lw, f0, lane, h0p[ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {     // the neighbour-mean blocks differ per half: interleave by hand
-            const int fa_ = H2_FL1 + (0 * 4 + 2 + ks) * 2, fb_ = H2_FL1 + (1 * 4 + 2 + ks) * 2;
-            f32x4 wa[2], wb[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { wa[q] = lw[(fa_ + q) * 64 + lane]; wb[q] = lw[(fb_ + q) * 64 + lane]; }
-            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                acc[0] = MFMA32H(wa[WP[t]], n1p[ks][BP[t]], acc[0]);
-                acc[1] = MFMA32H(wb[WP[t]], n2p[ks][BP[t]], acc[1]);
-            }
-        }
-        if (a.save != nullptr && valid) { h2_save32(a.save, a.Pn, SV_T, p, h, acc[0]); h2_save32(a.save, a.Pn, SV_T + 2, p, h, acc[1]); }
-        acc[0] = prelu16(acc[0], a1, sel1);
-        acc[1] = prelu16(acc[1], a1, sel1);
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
-        if (a.dbg_h1 != nullptr && valid) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (ch < 30) a.dbg_h1[p * 60 + 30 * t + ch] = acc[t][r];
-                }
-        }
-        // ---- u, v and the node-local layer-2 terms c from h1 = [h1a (30) | M0 M1 | h1b (30) | M2 M3]
-        f32x16 o3[3] = {bias16(lbias, 3, h), bias16(lbias, 4, h), bias16(lbias, 5, h)};
-        if (EDGES) {   // ... and of the node-local layer-2 block c = [o1 (15), 0 | o2 (15), 0]
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 8 * b + 4 * h);
-                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 8 * b + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { o3[2][4 * b + e] += es[e]; o3[2][8 + 4 * b + e] += eg[e]; }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            u32x4 hp[2][3];
-            split8h<0>(acc[t], hp[0], c16);
-            split8h<1>(acc[t], hp[1], c16);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) hp[1][q].w = hi ? (t == 0 ? m01[q] : m23[q]) : hp[1][q].w;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int ks = 2 * t + kb;
-                const int f0[3] = {H2_FUVC + (0 * 4 + ks) * 2, H2_FUVC + (1 * 4 + ks) * 2, H2_FUVC + (2 * 4 + ks) * 2};
-                mma3<3>(o3, lw, f0, lane, hp[kb]);
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
-        }
-        if (a.save != nullptr && valid) { h2_save32(a.save, a.Pn, SV_UP, p, h, o3[0]); h2_save32(a.save, a.Pn, SV_VP, p, h, o3[1]); }
-        o3[0] = prelu16(o3[0], a21, sel21);
-        o3[1] = prelu16(o3[1], a22, sel22);
-        asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
-        // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
-        f32x16 ow[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ow[0][r] = 0.f; ow[1][r] = 0.f; }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            u32x4 up[3], vp[3];
-            if (kb == 0) { split8h<0>(o3[0], up, c16); split8h<0>(o3[1], vp, c16); }
-            else { split8h<1>(o3[0], up, c16); split8h<1>(o3[1], vp, c16); }
-            f32x4 wa[2], wb[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                wa[q] = lw[(H2_FW + (0 + kb) * 2 + q) * 64 + lane];
-                wb[q] = lw[(H2_FW + (2 + kb) * 2 + q) * 64 + lane];
-            }
-            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                ow[0] = MFMA32H(wa[WP[t]], up[BP[t]], ow[0]);
-                ow[1] = MFMA32H(wb[WP[t]], vp[BP[t]], ow[1]);
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                *(f32x4*)(a.wu + p * ROWW + 8 * b + 4 * h) = f32x4{ow[0][4 * b], ow[0][4 * b + 1], ow[0][4 * b + 2], ow[0][4 * b + 3]};
-                *(f32x4*)(a.wv + p * ROWW + 8 * b + 4 * h) =
-                    f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
-            }
-        }
-        idv = idv_n; sc = sc_n; valid = valid_n; pcur = p_n; dgs = dgs_n; dgp = dgp_n;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
-#pragma unroll
-        for (int k = 0; k < KPP; ++k) src_id[k] = src_n[k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage 2: second pair of neighbour means (of the projected operands), PReLU2 -> x_latent; Bipartite fc1 + PReLU,
-// mask gate, and the per-tile station sum.                      module.py:94-96, :229
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
-    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
-    const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));
-#endif
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const long long p = (long long)g * S + sc;
-        f32x4 o[2];
-        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
-        const float mq = a.mask[p * 4 + q];
-        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
-        // neighbour means of the projected operands (16-float rows): they ARE the accumulator contributions
-        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
-        {
-            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
-            const float* base = a.wu + (long long)g * S * ROWW + 4 * q;
-            if (!ABL(a, 0)) gather_sum16<false>(base, ROWW, a.sta_col, eb, ee, n1);
-            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
-        }
-        {
-            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
-            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.wv + (long long)sc * ROWW + 4 * q;
-            if (!ABL(a, 1)) gather_sum16<true>(base, (long long)S * ROWW, a.src_col, eb, ee, n2);
-            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
-        }
-        if (a.save != nullptr && valid) {
-            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p) * 16 + 4 * q) = o[0];
-            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p) * 16 + 4 * q) = o[1];
-        }
-        o[0] = prelu4u(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
-        o[1] = prelu4u(o[1], a2);   // x_latent[15:30]
-        if (a.x_latent != nullptr && valid) {
-            float* xl = a.x_latent + p * 30;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (4 * q + r < 15) {
-                    xl[4 * q + r] = o[0][r];
-                    xl[15 + 4 * q + r] = o[1][r];
-                }
-            }
-        }
-        if (a.no_bip) continue;
-        // Bipartite message: m_p * PReLU_b1(fc1 [x_latent || edge_attr])
-        f32x4 bp[2];
-        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + p) * 16 + 4 * q) = bp[t];
-            bp[t] = prelu4u(bp[t], ab1);
-        }
-        float mm = fmaxf(mq, __shfl_xor(mq, 16));
-        mm = fmaxf(mm, __shfl_xor(mm, 32));
-        if (!valid) mm = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 v = bp[t] * mm;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                v.x += __shfl_xor(v.x, d);
-                v.y += __shfl_xor(v.y, d);
-                v.z += __shfl_xor(v.z, d);
-                v.w += __shfl_xor(v.w, d);
-            }
-            if (j == 0) *(f32x4*)(a.part + ((long long)g * a.T + tb) * 32 + 16 * t + 4 * q) = v;
-        }
-    }
-}
-
-// Stage 2 on an irregular product graph (see k_stage1_pcsr). The Bipartite messages of a source node are not the rows of
-// whole tiles here, so every node's gated message row is written in place of its c row and k_bip_out_seg sums the row range
-// of each source node (product nodes are grouped by source node, process_utils.py:790-794) in row order.
-__global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
-    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
-    const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = lscal[0], ab1 = lscal[1];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const long long ntiles = (a.Pn + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
-         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
-#if !GENIE_HOIST_WEIGHTS
-        asm volatile("" : "+v"(lane));
-#endif
-        const long long pr = tile * 16 + j;
-        const bool valid = pr < a.Pn;
-        const long long p = valid ? pr : a.Pn - 1;
-        f32x4 o[2];
-        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
-        const float mq = a.mask[p * 4 + q];
-        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
-        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
-        {
-            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
-            gather_sum16<false>(a.wu + 4 * q, ROWW, a.sta_col, eb, ee, n1);
-            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
-        }
-        {
-            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
-            gather_sum16<false>(a.wv + 4 * q, ROWW, a.src_col, eb, ee, n2);
-            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
-        }
-        o[0] = prelu4u(o[0], a2);
-        o[1] = prelu4u(o[1], a2);
-        if (a.x_latent != nullptr && valid) {
-            float* xl = a.x_latent + p * 30;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (4 * q + r < 15) {
-                    xl[4 * q + r] = o[0][r];
-                    xl[15 + 4 * q + r] = o[1][r];
-                }
-            }
-        }
-        f32x4 bp[2];
-        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-            bp[t] = prelu4u(bp[t], ab1);
-        }
-        float mm = fmaxf(mq, __shfl_xor(mq, 16));
-        mm = fmaxf(mm, __shfl_xor(mm, 32));
-        if (valid) {      // the message row replaces the c row of the node (read above by these same lanes)
-            *(f32x4*)(a.c + p * ROWC + 4 * q) = bp[0] * mm;
-            *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = bp[1] * mm;
-        }
-    }
-}
-
-// k_stage2_fast for the production configuration (uniform-degree graphs, station processing order with a registered static
-// edge_attr, static item stream, Bipartite half on), straight-line: the ISA of k_stage2_fast spends a fifth of its vector
-// instructions on register copies at the joins of its option branches (the 15 source rows were copied out and back every tile),
-// 34 ds_bpermute per tile on the station sum and a dozen uniform branches. Here
-//  * the item after the last one is clamped to the last one, so every load of the software pipeline is unconditional and no
-//    value has two definitions at a join;
-//  * a tile's ids are its (wave-uniform) item number, one src_tab row and the 8 station-neighbour ids, which are loaded into the
-//    registers the previous tile's ids have just left: nothing rotates but one register;
-//  * the station sum over the 16 nodes of a tile is a DPP row reduction (row_shl:1, 2, 4, 8): lane 0 of every row adds the same
-//    operands in the same tree as the xor butterfly of k_stage2 (bitwise identical), without the LDS round trips;
-//  * the message mask is read by all four lanes of a node (one address) instead of max-reduced across them.
-// Same arithmetic and summation order as k_stage2 / k_stage2_fast (bitwise identical results; tests).
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of every row of 16: the butterfly's sum tree
-    v = dpp_add<0x101>(v);      // row_shl:1
-    v = dpp_add<0x102>(v);
-    v = dpp_add<0x104>(v);
-    v = dpp_add<0x108>(v);
-    return v;
-}
-// Row-layout loads: in the MFMA layout lane (j = lane & 15, q = lane >> 4) reads the 16-B chunk q of node j's row, so four
-// CONSECUTIVE lanes touch four different rows and the texture path works on 16 useful bytes per 64-B request (measured: 24 B per
-// clock and CU where contiguous row gathers reach 57). Every row is therefore loaded in the layout lane = 4 r + cq (node r = lane >> 2,
-// chunk cq = lane & 3): four consecutive lanes read one 64-B row, sixteen consecutive source rows one contiguous KB. Everything up
-// to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the gated mask then go through a
-// 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1.
-// XL: also store x_latent [P, 30] (caller's station order). NB: stop after x_latent (no Bipartite message / station sum): the
-// last pass of the association heads (genie_assoc_fwd).
-// Measured and dropped: other positions of the three load bursts (0.2627 / 0.2650 / 0.2649 ms), waves of a
-// workgroup phased half an iteration apart by barriers (0.262 -> 0.290), streamed rows two tiles ahead (246 VGPRs, 0.226 -> 0.240),
-// MFMA-layout loads (0.262 vs 0.226), station rows staged in LDS behind a barrier (0.282 -> 0.299 after a cold stage 1).
-template <int KS, int KP, bool XL, bool NB = false>
-__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
-    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
-    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
-    const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int jl = lane >> 2, ql = lane & 3;      // (node, chunk) this lane LOADS
-    float* ts = tsc + wave * 16 * 36;
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
-    // a.wgmap: a workgroup takes BLOCKS of 4 consecutive source nodes of its XCD's chunk, wave k sweeps the tiles of the k-th
-    // node of the block: the four waves of a CU then read the source-neighbour rows of four adjacent source nodes (half of
-    // them shared) for the same station tile at about the same time, and every station row wu[g] is gathered on one CU only
-    if (a.wgmap) {
-        const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
-        const int lb = blockIdx.x / nx, nbx = gridDim.x / nx, n = w.gend - w.gbeg, n_blk = (n + 3) / 4;
-        int n_my = lb < n_blk ? (n_blk - lb + nbx - 1) / nbx : 0;
-        if (n_my > 0 && 4 * (lb + (n_my - 1) * nbx) + wave >= n) --n_my;
-        w.it = 0; w.stride = 1; w.nitems = (long long)n_my * a.T;
-        w.lead_ = lb; w.chunk_ = nbx;                     // (reused as: first block, block stride)
-    }
-    if (w.it >= w.nitems) return;
-    const char* wub = (const char*)a.wu;
-    const char* wvb = (const char*)a.wv;
-    const unsigned q16 = 16u * (unsigned)ql;
-    const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
-    const unsigned m_T = ItemIter::recip((unsigned)a.T);
-
-    // item -> wave-uniform (processing position gi, station tile tb); every XCD's chunk is swept BACKWARDS: the c / wu / wv rows
-    // stage 1 wrote last (still in the Infinity Cache) are read first (0.278 -> 0.276 ms)
-    auto item_of = [&](long long it, int& gi, int& tb) {
-        const long long itr = w.nitems - 1 - it;
-        if (a.wgmap) {
-            unsigned rem;
-            const unsigned kb = a.T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)a.T, m_T, rem);
-            tb = (int)rem;
-            gi = w.gbeg + 4 * (w.lead_ + (int)kb * w.chunk_) + wave;
-        } else {
-            w.decode(itr, gi, tb);
-        }
-        gi = __builtin_amdgcn_readfirstlane(gi);
-        tb = __builtin_amdgcn_readfirstlane(tb);
-    };
-    struct Stream { f32x4 o[2]; float mq, eq; };                  // streamed rows of a tile: c, message mask, edge_attr
-    struct Rows { f32x4 ru[KS], rv[KP]; } rows;                    // gathered rows
-    Stream sA;
-    int sta[KS];
-    auto load_ids = [&](int gi, int tb, int& idv) {
-        idv = a.src_tab[gi * 16 + j];
-        const int s = tb * 16 + jl;
-        load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
-    };
-    auto issue0 = [&](Stream& st, int idv, int tb) {
-        const int g = __builtin_amdgcn_readlane(idv, 0);
-        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
-        long long p = (long long)g * S + sc;
-        if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
-        st.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
-        st.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
-        st.mq = NB ? 0.f : a.mm_int[p];
-        st.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
-        const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
-#pragma unroll
-        for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? st.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
-    };
-    auto issue_v = [&](int idv, int tb, int k0, int k1) {
-        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
-        const unsigned so = (unsigned)sc * 64u + q16;
-#pragma unroll
-        for (int k = 0; k < KP; ++k)
-            if (k >= k0 && k < k1) {
-                // the row base of a source neighbour is wave-uniform: kept opaque in an SGPR pair, so that the load is
-                // `global_load v, voffset, s[base]` (left to itself hipcc hoists wvb + so into a VGPR pair and adds the
-                // scalar part with a 64-bit vector multiply-add per neighbour: 3 vector instructions each)
-                unsigned long long wvk = (unsigned long long)wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
-                asm volatile("" : "+s"(wvk));
-                typedef const __attribute__((address_space(1))) char* gbytes;
-                typedef const __attribute__((address_space(1))) f32x4* grow;
-                rows.rv[k] = ABL(a, 1) ? rows.ru[0] : *(grow)((gbytes)wvk + so);
-            }
-    };
-    constexpr int KH = (KP + 1) / 2;
-
-    long long it = w.it;
-    int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
-    item_of(it, gi_c, tb_c);
-    load_ids(gi_c, tb_c, idv_c);
-    issue0(sA, idv_c, tb_c);
-    issue_v(idv_c, tb_c, 0, KP);
-    {
-        const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
-        item_of(itn, gi_n, tb_n);
-        load_ids(gi_n, tb_n, idv_n);
-    }
-    for (;;) {
-        asm volatile("" : "+v"(lane));
-        const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
-        const bool has_next = it + w.stride < w.nitems;
-        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
-        int gi_2, tb_2, idv_2;
-        item_of(it2, gi_2, tb_2);
-        // (1) consume the rows of this tile: neighbour means of the projected operands in edge order, PReLU2 -> x_latent
-        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KS; ++k) n1 += rows.ru[k];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
-        f32x4 o[2];
-        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sA.o[0]), a2);
-        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sA.o[1]), a2);
-        float mq = sA.mq, eq = sA.eq;
-        const int s_l = tb_c * 16 + jl;              // the node this lane loaded (not the node it holds in the MFMA layout)
-        const bool valid_l = s_l < S;
-        const f32x4 ol0 = o[0], ol1 = o[1];
-        if (!NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
-            *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
-            *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
-            ts[jl * 36 + 32 + ql] = ql < 3 ? eq : (valid_l ? mq : 0.f);
-            GSYNC();
-            o[0] = *(const f32x4*)(ts + j * 36 + 4 * q);
-            o[1] = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
-            eq = q < 3 ? ts[j * 36 + 32 + q] : 0.f;
-            mq = ts[j * 36 + 35];
-        }
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
-        // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
-        issue0(sA, idv_n, tb_n);
-        if (NB) issue_v(idv_n, tb_n, 0, KP);
-        if (XL && valid_l) {
-            const int su = a.sta_user[s_l];
-            float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * ql + r < 15) { xl[4 * ql + r] = ol0[r]; xl[15 + 4 * ql + r] = ol1[r]; }
-        }
-        f32x4 bp[2];
-        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (NB) break;
-            if (!ABL(a, 6)) {      // (tuning bit 6: no fc1 MFMAs)
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
-                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
-                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
-            } else bp[t] += o[0] + o[1] + eq;
-            bp[t] = prelu4u(bp[t], ab1);
-            // (3) second / third burst, behind the first / second output tile of fc1
-            asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
-            if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP);
-        }
-        // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
-        load_ids(gi_2, tb_2, idv_2);
-        // (5) mask gate and station sum of this tile
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (NB) break;
-            f32x4 v = bp[t] * mq;
-            v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
-            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
-        }
-        if (!has_next) break;
-        it += w.stride;
-        idv_c = idv_n; tb_c = tb_n;
-        idv_n = idv_2; tb_n = tb_2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Association heads on the product graph: BipartiteGraphReadOutOperator (module.py:333-352) and
-// DataAggregationAssociationPhase (:356-403) as three P-sized passes in the layout of the DataAggregation kernels
-// (fp32 MFMA, tile = 16 stations of one source node, outputs of one Linear are the B operands of the next):
-//   k_assoc_pre (G-sized): per-source-node terms pg[g] (the y_latent part of fc1, mask1 and the mask1 columns)
-//   k_assoc_a: s = PReLU2(fc2(mask1 PReLU1(fc1[y_latent[g] || e_p])))                       :343-352
-//              tr = PReLU(init_trns[s || x_latent || mask1 || Mask]), q1 = PReLU11(l1_t1_1 tr), q2 = PReLU12(l1_t2_1 tr)   :389-396
-//   k_assoc_b: tr1 = PReLU1([l1_t1_2[tr || mean_sta q1 || mask] || l1_t2_2[tr || mean_src q2 || mask]])             :397-398
-//              r1 = PReLU21(l2_t1_1 tr1), r2 = PReLU22(l2_t2_1 tr1); c / wu / wv exactly as stage 1 leaves them     :399-400
-//   stage-2 kernel with `no_bip` (second pair of means + PReLU2 -> [P, 30])                                          :401
-// Unlike DataAggregation the first-layer gather operand q is not a function of 8 raw floats, so q1 / q2 (32-float rows) are
-// stored and gathered. tr / q1 / q2 and c / wu / wv live in (station) processing order like the stage-1 outputs.
-// ------------------------------------------------------------------------------------------------
-struct AsArgs {
-    int S, G, T, seg, nxcd;
-    const int32_t* order;
-    const int32_t* sta_rowptr; const int32_t* sta_col; const int32_t* src_rowptr; const int32_t* src_col;
-    const int32_t* sta_user;     // internal station -> caller's station (inputs are in the caller's order), or null
-    const float* pg;             // [G][AS_PG]
-    const float* ps;             // [S][AS_PS] static per-station terms of the two model variants (caller's station order), or null
-    const float* x_latent; const float* mask; const float* edge_attr;   // caller's order: [P,30], [P,4], [P,3]
-    float* tr; float* q1; float* q2;                                    // [P,32]
-    float* c; float* wu; float* wv;
-    const float* packed;
-    float* save; long long Pn;   // training forward: pre-activations kept for the backward passes, [AV_*][Pn][16], or null
-};
-// blocks of the association phase's saved pre-activations: BipartiteGraphReadOutOperator fc1 (before PReLU and the mask gate) and
-// fc2, init_trns, l1_t1_1 / l1_t2_1 (w, tile), [10, 11] = the output layer (written by the stage-2 kernel as its SV_O), layer 1
-// (half, tile), l2_t1_1 / l2_t2_1 (w, tile)
-constexpr int AV_Z1 = 0, AV_SV = 2, AV_TR = 3, AV_Q = 5, AV_O = 10, AV_T = 12, AV_UV = 16, AV_BLOCKS = 20;
-static_assert(AV_O == SV_O, "the stage-2 kernel stores the output layer's pre-activations at SV_O");
-
-struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as_l2t12_w, as_l2t22_w;
-                   int as_init_abs, as_l1t12_p, as_l1t22_p, as_l2t12_p, as_l2t22_p; };
-
-// The two model variants in the association phase: under use_updated_model_definition the mean edge feature of a node's
-// in-neighbourhood (static: mpos_sta [S][4] / mpos_src [G][4], genie_set_edge_features) enters l1_t?_2 / l2_t?_2 (module.py:462-467,
-// :472-480); under use_absolute_pos the station / source positions / (3 scale_rel) (abs_sta [S][4] / abs_src [G][4]) are appended to
-// the head's input (module.py:987-988, 6 more columns of init_trns). Both are per-station / per-source-node ADDITIVE terms of a
-// pre-activation: the source-node ones are folded into pg, the station ones are ps [S][AS_PS]: [0:30] init_trns, [32:62]
-// l1_t1_2, [64:79] l2_t1_2.
-constexpr int AS_PS = 80;
-__device__ __forceinline__ float dot4w(const float* __restrict__ w, const float* __restrict__ m, int n) {
-    float v = 0.f;
-    for (int c = 0; c < n; ++c) v = fmaf(w[c], m[c], v);
-    return v;
-}
-
-__global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw, AsPreOffs o, const float* __restrict__ y_latent,
-                                                   const float* __restrict__ mask_src, int G, const float* __restrict__ mpos_src,
-                                                   const float* __restrict__ abs_src, float* __restrict__ pg) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= G * AS_PG) return;
-    const int g = idx / AS_PG, k = idx - g * AS_PG;
-    const float m = mask_src[g];
-    float v = 0.f;
-    if (k < 30) {
-        v = raw[o.ro_fc1_b + k];
-        const float* w = raw + o.ro_fc1_w + k * 33;
-        for (int c = 0; c < 30; ++c) v = fmaf(w[c], y_latent[g * 30 + c], v);
-    } else if (k == 31) v = m;
-    else if (k >= 32 && k < 62) {
-        v = m * raw[o.as_init_w + (k - 32) * 50 + 45];
-        if (abs_src) v += dot4w(raw + o.as_init_abs + (k - 32) * 6 + 3, abs_src + g * 4, 3);
-    } else if (k >= 64 && k < 94) v = m * raw[o.as_l1t12_w + (k - 64) * 65 + 60];
-    else if (k >= 96 && k < 126) {
-        v = m * raw[o.as_l1t22_w + (k - 96) * 65 + 60];
-        if (mpos_src) v += dot4w(raw + o.as_l1t22_p + (k - 96) * 4, mpos_src + g * 4, 4);
-    } else if (k >= 128 && k < 143) v = m * raw[o.as_l2t12_w + (k - 128) * 95 + 90];
-    else if (k >= 144 && k < 159) {
-        v = m * raw[o.as_l2t22_w + (k - 144) * 95 + 90];
-        if (mpos_src) v += dot4w(raw + o.as_l2t22_p + (k - 144) * 4, mpos_src + g * 4, 4);
-    }
-    pg[idx] = v;
-}
-
-__global__ void k_assoc_ps(const float* __restrict__ raw, AsPreOffs o, int S, const float* __restrict__ mpos_sta,
-                           const float* __restrict__ abs_sta, float* __restrict__ ps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * AS_PS) return;
-    const int s = idx / AS_PS, k = idx - s * AS_PS;
-    float v = 0.f;
-    if (k < 30) { if (abs_sta) v = dot4w(raw + o.as_init_abs + k * 6, abs_sta + s * 4, 3); }
-    else if (k >= 32 && k < 62) { if (mpos_sta) v = dot4w(raw + o.as_l1t12_p + (k - 32) * 4, mpos_sta + s * 4, 4); }
-    else if (k >= 64 && k < 79) { if (mpos_sta) v = dot4w(raw + o.as_l2t12_p + (k - 64) * 4, mpos_sta + s * 4, 4); }
-    ps[idx] = v;
-}
-
-__device__ __forceinline__ f32x4 ld_row30(const float* row, int b, int q) {     // channels 16b + 4q .. +3 of a 30-float row (8-B aligned)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 lo = *(const f32x2*)(row + 16 * b + 4 * q);
-    f32x2 hi = {0.f, 0.f};
-    if (b == 0 || q < 3) hi = *(const f32x2*)(row + 16 * b + 4 * q + 2);
-    return f32x4{lo.x, lo.y, hi.x, hi.y};
-}
-
-__global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
-    constexpr int NF4 = (GA_GROUPS * 256 + GA_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + GA_GROUPS * 64);
-    const float* lscal = lbias + GA_BIAS * 16;
-    const float r1 = lscal[0], r2 = lscal[1], a0 = lscal[2], a11 = lscal[3], a12 = lscal[4];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
-        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
-        const float* pg = a.pg + (long long)g * AS_PG;
-        const float eq = q < 3 ? a.edge_attr[pu * 3 + q] : 0.f;
-        const float mq = a.mask[pu * 4 + q];
-        const float m1 = pg[31];
-        const f32x4 lat0 = ld_row30(a.x_latent + pu * 30, 0, q), lat1 = ld_row30(a.x_latent + pu * 30, 1, q);
-        // BipartiteGraphReadOutOperator: one edge per product node, so aggr 'add' is the identity (module.py:343-352)
-        f32x4 msg[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 z = *(const f32x4*)(pg + 16 * t + 4 * q);
-            if (t == 1 && q == 3) z.w = 0.f;                                   // slot 31 carries mask1, not a channel
-            z = MFMA16(lw[GA_FC1E(t) * 64 + lane].x, eq, z);
-            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_Z1 + t) * a.Pn + pi) * 16 + 4 * q) = z;
-            msg[t] = prelu4u(z, r1) * m1;
-        }
-        f32x4 sv = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
-        sv = mma_block(sv, lw[GA_FC2(0) * 64 + lane], msg[0]);
-        sv = mma_block(sv, lw[GA_FC2(1) * 64 + lane], msg[1]);
-        if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)AV_SV * a.Pn + pi) * 16 + 4 * q) = sv;
-        sv = prelu4u(sv, r2);
-        // init_trns [s || x_latent || mask1 || Mask]
-        f32x4 tr[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 acc = *(const f32x4*)(lbias + (1 + t) * 16 + 4 * q) + *(const f32x4*)(pg + 32 + 16 * t + 4 * q);
-            if (a.ps != nullptr) acc += *(const f32x4*)(a.ps + (long long)su * AS_PS + 16 * t + 4 * q);
-            acc = mma_block(acc, lw[GA_INIT(t, 0) * 64 + lane], sv);
-            acc = mma_block(acc, lw[GA_INIT(t, 1) * 64 + lane], lat0);
-            acc = mma_block(acc, lw[GA_INIT(t, 2) * 64 + lane], lat1);
-            acc = MFMA16(lw[GA_INIT(t, 3) * 64 + lane].x, mq, acc);
-            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_TR + t) * a.Pn + pi) * 16 + 4 * q) = acc;
-            tr[t] = prelu4u(acc, a0);
-        }
-        f32x4 qv[2][2];
-#pragma unroll
-        for (int wq = 0; wq < 2; ++wq)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 acc = *(const f32x4*)(lbias + (3 + 2 * wq + t) * 16 + 4 * q);
-                acc = mma_block(acc, lw[GA_Q(wq, t, 0) * 64 + lane], tr[0]);
-                acc = mma_block(acc, lw[GA_Q(wq, t, 1) * 64 + lane], tr[1]);
-                if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(AV_Q + 2 * wq + t) * a.Pn + pi) * 16 + 4 * q) = acc;
-                qv[wq][t] = prelu4u(acc, wq == 0 ? a11 : a12);
-            }
-        if (valid) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                *(f32x4*)(a.tr + pi * 32 + 16 * t + 4 * q) = tr[t];
-                *(f32x4*)(a.q1 + pi * 32 + 16 * t + 4 * q) = qv[0][t];
-                *(f32x4*)(a.q2 + pi * 32 + 16 * t + 4 * q) = qv[1][t];
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
-    constexpr int NF4 = (GB_GROUPS * 256 + GB_BIAS * 16 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 68];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lbias = (const float*)(lw + GB_GROUPS * 64);
-    const float* lscal = lbias + GB_BIAS * 16;
-    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the 23 gathered 128-B rows of a node are read in the row layout lane = 4 r + cq (four consecutive lanes: one 64-B half of a
-    // row); the four neighbour means then cross a per-wave LDS scratch into the MFMA layout (see k_stage2_ord, RL)
-    const int jl = lane >> 2, ql = lane & 3;
-    float* ts = tsc + wave * 16 * 68;
-    const int S = a.S;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
-        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
-        const float* pg = a.pg + (long long)g * AS_PG;
-        const float mq = a.mask[pu * 4 + q];
-        const f32x4 x0 = *(const f32x4*)(a.tr + pi * 32 + 4 * q), x1 = *(const f32x4*)(a.tr + pi * 32 + 16 + 4 * q);
-        // neighbour means of q1 (stations of the same source node) and q2 (same station, neighbouring source nodes), edge order
-        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
-        const int s_l = tb * 16 + jl, scl = s_l < S ? s_l : S - 1;        // the node whose rows this lane gathers
-        {
-            const int eb = a.sta_rowptr[scl], ee = a.sta_rowptr[scl + 1];
-            const float* base = a.q1 + (long long)g * S * 32 + 4 * ql;
-            for (int e = eb; __any(e < ee); e += 4) {
-                f32x4 ra[4], rb[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool ok = e + k < ee;
-                    const float* r = base + (long long)a.sta_col[ok ? e + k : max(ee - 1, 0)] * 32;
-                    ra[k] = *(const f32x4*)r; rb[k] = *(const f32x4*)(r + 16);
-                    if (!ok) { ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[k] = ra[k]; }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { n1a += ra[k]; n1b += rb[k]; }
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n1a *= inv; n1b *= inv;
-        }
-        {
-            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
-            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
-            const float* base = a.q2 + (long long)scl * 32 + 4 * ql;
-            int e = eb;
-            for (; e + 4 <= ee; e += 4) {
-                f32x4 ra[4], rb[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float* r = base + (long long)a.src_col[e + k] * S * 32;
-                    ra[k] = *(const f32x4*)r; rb[k] = *(const f32x4*)(r + 16);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { n2a += ra[k]; n2b += rb[k]; }
-            }
-            for (; e < ee; ++e) {
-                const float* r = base + (long long)a.src_col[e] * S * 32;
-                n2a += *(const f32x4*)r; n2b += *(const f32x4*)(r + 16);
-            }
-            const float inv = 1.f / (float)max(ee - eb, 1);
-            n2a *= inv; n2b *= inv;
-        }
-        *(f32x4*)(ts + jl * 68 + 4 * ql) = n1a; *(f32x4*)(ts + jl * 68 + 16 + 4 * ql) = n1b;
-        *(f32x4*)(ts + jl * 68 + 32 + 4 * ql) = n2a; *(f32x4*)(ts + jl * 68 + 48 + 4 * ql) = n2b;
-        GSYNC();
-        n1a = *(const f32x4*)(ts + j * 68 + 4 * q); n1b = *(const f32x4*)(ts + j * 68 + 16 + 4 * q);
-        n2a = *(const f32x4*)(ts + j * 68 + 32 + 4 * q); n2b = *(const f32x4*)(ts + j * 68 + 48 + 4 * q);
-        GSYNC();
-        // layer 1
-        f32x4 acc[4], w4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            acc[k] = *(const f32x4*)(lbias + k * 16 + 4 * q) + *(const f32x4*)(pg + 64 + 32 * (k >> 1) + 16 * (k & 1) + 4 * q);
-        if (a.ps != nullptr) {
-            acc[0] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 32 + 4 * q);
-            acc[1] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 48 + 4 * q);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 0) * 64 + lane];
-        mma_blocks<4>(acc, w4, x0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 1) * 64 + lane];
-        mma_blocks<4>(acc, w4, x1);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const f32x4 na = b == 0 ? n1a : n1b, nb = b == 0 ? n2a : n2b;
-            f32x4 wa[2], wb[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                wa[t] = lw[GB_L1(0, t, 2 + b) * 64 + lane];
-                wb[t] = lw[GB_L1(1, t, 2 + b) * 64 + lane];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[0] = MFMA16(wa[0][r], na[r], acc[0]);
-                acc[2] = MFMA16(wb[0][r], nb[r], acc[2]);
-                acc[1] = MFMA16(wa[1][r], na[r], acc[1]);
-                acc[3] = MFMA16(wb[1][r], nb[r], acc[3]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[GB_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
-        if (a.save != nullptr && valid) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(AV_T + k) * a.Pn + pi) * 16 + 4 * q) = acc[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);
-        // r1 / r2 and the node-local layer-2 terms
-        f32x4 o6[6], w6[6];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
-        o6[4] = *(const f32x4*)(lbias + 8 * 16 + 4 * q) + *(const f32x4*)(pg + 128 + 4 * q);
-        o6[5] = *(const f32x4*)(lbias + 9 * 16 + 4 * q) + *(const f32x4*)(pg + 144 + 4 * q);
-        if (a.ps != nullptr) o6[4] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 64 + 4 * q);
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w6[k] = lw[GB_UV(k >> 1, k & 1, hb) * 64 + lane];
-            w6[4] = lw[GB_C(0, hb) * 64 + lane];
-            w6[5] = lw[GB_C(1, hb) * 64 + lane];
-            mma_blocks<6>(o6, w6, acc[hb]);
-        }
-        o6[4] = MFMA16(lw[GB_C(0, 4) * 64 + lane].x, mq, o6[4]);
-        o6[5] = MFMA16(lw[GB_C(1, 4) * 64 + lane].x, mq, o6[5]);
-        if (a.save != nullptr && valid) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(AV_UV + k) * a.Pn + pi) * 16 + 4 * q) = o6[k];
-        }
-        o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
-        o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
-        f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            w2[0] = lw[GB_W(0, b) * 64 + lane];
-            w2[1] = lw[GB_W(1, b) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                wuv[0] = MFMA16(w2[0][r], o6[b][r], wuv[0]);
-                wuv[1] = MFMA16(w2[1][r], o6[2 + b][r], wuv[1]);
-            }
-        }
-        if (valid) {
-            *(f32x4*)(a.c + pi * ROWC + 4 * q) = o6[4];
-            *(f32x4*)(a.c + pi * ROWC + 16 + 4 * q) = o6[5];
-            *(f32x4*)(a.wu + pi * ROWW + 4 * q) = wuv[0];
-            *(f32x4*)(a.wv + pi * ROWW + 4 * q) = wuv[1];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Backward of DataAggregation + Bipartite_ReadIn (training step, train_GENIE_model.py:1843-1861).
-// The training forward is the generic stage kernels with `save` set (pre-activations of h0, h1, u, v, x_latent and the
-// Bipartite message: 14 blocks of 16 floats per product node); the backward mirrors the stages in reverse order:
-//   k_train_b2: d(station sum)[g] -> dz (message) -> dx_latent = fc1[:, 0:30]^T dz -> do = dx_latent PReLU2'(o)      store do
-//   k_train_b1: transposed means of do1 / do2 (reversed base graphs) -> du, dv -> dh1 -> dt = dh1 PReLU1'(t)           store dt, dh0_local
-//   k_train_b0: transposed means of dt1 / dt2 -> dh0 -> dz0
-// Weight gradients are accumulated INSIDE the passes: dW[out, in] = sum over nodes dY[out] X[in] is an MFMA whose contraction
-// runs over the 16 nodes of a tile (operands transposed through a per-wave LDS scratch), into register accumulators that live
-// across all tiles of a wave; the terms that multiply a neighbour mean use the adjoint identity
-//   sum_p dY[p] (x) mean_{k in N(p)} x[k] = sum_k (transposed mean of dY)[k] (x) x[k],
-// so no mean is stored. Bias and PReLU-slope gradients are per-lane running sums. Every wave writes its partials once; a
-// fixed-order reduction over the waves (k_train_reduce) makes the result run-to-run deterministic.
-// ------------------------------------------------------------------------------------------------
-constexpr int GR_DO = 0, GR_DT = 2, GR_DH0 = 6, GR_BLOCKS = 8;      // gradient rows kept between the passes: [GR_*][P][16]
-
-struct AccDesc { int32_t mat_off, ld, row0, nrows, col0, ncols, n0, pad; };   // dW block: D[i][n] -> W[row0 + i][col0 + n], n0 <= n < ncols
-struct VecDesc { int32_t off, row0, nrows, stride; };                // bias block: sum dY[i] -> b[(row0 + i) * stride]
-
-struct TrArgs {
-    int S, G, T, seg, nxcd;
-    long long P;
-    const int32_t* order;
-    const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
-    const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
-    const float* slice; const float* mask; const float* edge_attr;
-    const float* save; float* gr;
-    const float* dr;             // [G][32] gradient of the per-source-node station sum (Bipartite, before fc2)
-    const float* packed;
-    float* part;                 // per-wave partials: [wave][n_acc * 256 + n_vec * 16 + 16]
-    int n_acc, n_vec;
-    int sv_t, sv_up, sv_vp;      // k_train_b1: blocks of `save` holding the pre-activations of h1 / u / v (SV_T, SV_UP, SV_VP, or the
-                                 // association phase's AV_T, AV_UV, AV_UV + 2)
-    const float* pg;             // association phase (k_train_b1<true>, k_as_*): [G][AS_PG] per-source-node terms, pg[31] = mask1[g]
-    const float* x_latent;       // association phase: [P, 30] DataAggregation output (an input of init_trns there)
-    float* zsum;                 // k_as_b0: [G * T][32] per-tile station sums of d z1 (-> d y_latent, fc1's y_latent columns)
-};
-
-__device__ __forceinline__ f32x4 ldb(const float* buf, int blk, long long P, long long p, int q) {
-    return *(const f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q);
-}
-__device__ __forceinline__ void stb(float* buf, int blk, long long P, long long p, int q, f32x4 v) {
-    *(f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q) = v;
-}
-__device__ __forceinline__ f32x4 dprelu4(f32x4 x, float s) {     // PReLU'(x): 1 for x > 0, the slope otherwise
-    return f32x4{x.x > 0.f ? 1.f : s, x.y > 0.f ? 1.f : s, x.z > 0.f ? 1.f : s, x.w > 0.f ? 1.f : s};
-}
-__device__ __forceinline__ float negsum4(f32x4 g, f32x4 x) {    // sum of g * min(x, 0): the slope gradient of PReLU
-    return g.x * fminf(x.x, 0.f) + g.y * fminf(x.y, 0.f) + g.z * fminf(x.z, 0.f) + g.w * fminf(x.w, 0.f);
-}
-// V[ch 4q + r][node j] held by lane (j, q) -> vt[s] = V[ch j][node 4s + q]: the operand form of a node-contracting MFMA
-__device__ __forceinline__ f32x4 tr16(f32x4 v, float* sc, int j, int q) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sc[(4 * q + r) * 17 + j] = v[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    f32x4 t;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) t[s] = sc[j * 17 + 4 * s + q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return t;
-}
-__device__ __forceinline__ f32x4 outer16(f32x4 acc, f32x4 at, f32x4 bt) {       // acc[out][in] += sum over the tile's nodes
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = MFMA16(at[s], bt[s], acc);
-    return acc;
-}
-// transposed mean: sum over the out-edges e of `node` of w_e * rows[col_e], rows of 16 floats addressed by `rowof(block, col)`,
-// for NB row blocks at once. The edges are taken EB at a time (indices, weights and the EB x NB rows of a batch are all in
-// flight together; a lane past its last edge re-reads edge 0 with weight zero): with one index -> row load chain per edge the
-// backward passes spent ~80 % of their time waiting on these gathers (one wave per SIMD, nothing to switch to). The sum keeps
-// the edge order.
-template <int NB, int EB = 4, typename F>
-__device__ __forceinline__ void tmean_n(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const float* __restrict__ w,
-                                        int node, bool uniform, F rowof, f32x4 (&out)[NB]) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int eb = rp[node], ee = rp[node + 1];
-    if (uniform) { eb = __builtin_amdgcn_readfirstlane(eb); ee = __builtin_amdgcn_readfirstlane(ee); }
-    for (int e = eb; uniform ? (e < ee) : (bool)__any(e < ee); e += EB) {
-        int c[EB];
-        float ww[EB];
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-            const bool ok = e + k < ee;
-            const int ei = ok ? e + k : 0;
-            c[k] = col[ei];
-            ww[k] = ok ? w[ei] : 0.f;
-        }
-        f32x4 r[NB][EB];
-#pragma unroll
-        for (int k = 0; k < EB; ++k)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, c[k]);
-#pragma unroll
-        for (int k = 0; k < EB; ++k)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * ww[k];
-    }
-}
-template <typename F>
-__device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, const float* w, int node, bool uniform, F rowof) {
-    f32x4 o[1];
-    tmean_n<1, 8>(rp, col, w, node, uniform, [&](int, int c) { return rowof(c); }, o);
-    return o[0];
-}
-__device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
-                                               const float* scal, int n_scal, int lane, int j, int q) {
-    float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
-    for (int k = 0; k < n_acc; ++k) *(f32x4*)(out + (size_t)k * 256 + lane * 4) = acc[k];
-    out += (size_t)a.n_acc * 256;
-    for (int k = 0; k < n_vec; ++k) {
-        f32x4 v = vec[k];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
-        }
-        if (j == 0) *(f32x4*)(out + k * 16 + 4 * q) = v;
-    }
-    out += (size_t)a.n_vec * 16;
-    for (int k = 0; k < n_scal; ++k) {
-        float v = scal[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if (lane == 0) out[k] = v;
-    }
-}
-
-// ---- pass 2': Bipartite message + PReLU2.  accumulators: fc1 (t, {x_latent 0:15, x_latent 15:30, edge_attr}) = 6; vec: fc1 bias (2)
-__global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
-    constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lscal = (const float*)(lw + GT2_GROUPS * 64);
-    const float a2 = lscal[0], ab1 = lscal[1];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sc = tsc[wave];
-    const int S = a.S;
-    const long long P = a.P;
-    f32x4 acc[6], vec[2];
-    float scal[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
-        float mq = a.mask[p * 4 + q];
-        float mm = fmaxf(mq, __shfl_xor(mq, 16));
-        mm = fmaxf(mm, __shfl_xor(mm, 32));
-        if (!valid) mm = 0.f;
-        f32x4 eb = {0.f, 0.f, 0.f, 0.f};
-        if (q == 0) { eb.x = a.edge_attr[p * 3]; eb.y = a.edge_attr[p * 3 + 1]; eb.z = a.edge_attr[p * 3 + 2]; }
-        f32x4 dz[2], o[2], xl[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 zb = ldb(a.save, SV_ZB + t, P, p, q);
-            const f32x4 d = *(const f32x4*)(a.dr + (long long)g * 32 + 16 * t + 4 * q) * mm;      // through the mask gate
-            scal[1] += negsum4(d, zb);
-            dz[t] = d * dprelu4(zb, ab1);
-            vec[t] += dz[t];
-            o[t] = ldb(a.save, SV_O + t, P, p, q);
-            xl[t] = prelu4u(o[t], a2);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-            dx = mma_block(dx, lw[GT2(b, 0) * 64 + lane], dz[0]);
-            dx = mma_block(dx, lw[GT2(b, 1) * 64 + lane], dz[1]);
-            if (!valid) dx = f32x4{0.f, 0.f, 0.f, 0.f};
-            scal[0] += negsum4(dx, o[b]);
-            const f32x4 dob = dx * dprelu4(o[b], a2);
-            if (valid) stb(a.gr, GR_DO + b, P, p, q, dob);
-        }
-        const f32x4 x0t = tr16(xl[0], sc, j, q), x1t = tr16(xl[1], sc, j, q), et = tr16(eb, sc, j, q);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 dt_ = tr16(dz[t], sc, j, q);
-            acc[t * 3 + 0] = outer16(acc[t * 3 + 0], dt_, x0t);
-            acc[t * 3 + 1] = outer16(acc[t * 3 + 1], dt_, x1t);
-            acc[t * 3 + 2] = outer16(acc[t * 3 + 2], dt_, et);
-        }
-    }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 6, vec, 2, scal, 2, threadIdx.x & 63, j, q);
-}
-
-// ---- pass 1': layer 2 and the activation of layer 1.
-// accumulators: l2_t1_2 {h1 x4, Mask, u x2 (adjoint)} = 7, l2_t2_2 = 7, l2_t1_1 (2 x h1 x4) = 8, l2_t2_1 = 8  -> 30
-// vec: b(l2_t1_2), b(l2_t2_2), b(l2_t1_1) x2, b(l2_t2_1) x2 = 6; scal: a1, a21, a22
-// AS: the same pass for DataAggregationAssociationPhase (module.py:397-401; 95-wide l2_t?_2 with mask width 5): the column of mask1
-// (one value per source node) gets its gradient as two extra vectors.
-template <bool AS>
-__global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
-    constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
-    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sc = tsc[wave];
-    const int S = a.S;
-    const long long P = a.P;
-    constexpr int NV = AS ? 8 : 6;
-    f32x4 acc[30], vec[NV];
-    float scal[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 30; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NV; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
-        const float vm = valid ? 1.f : 0.f;
-        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
-        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
-        const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
-        if (AS) {
-            const float m1 = a.pg[(long long)g * AS_PG + 31];
-            vec[6] += do1 * m1; vec[7] += do2 * m1;
-        }
-        const float* gr = a.gr;
-        const f32x4 tm1 = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                                [&](int c) { return ldb(gr, GR_DO + 0, P, (long long)g * S + c, q); }) * vm;
-        const f32x4 tm2 = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                                [&](int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn, q); }) * vm;
-        f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SVT + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            up[b] = ldb(a.save, SVU + b, P, p, q); u[b] = prelu4u(up[b], a21);
-            vp[b] = ldb(a.save, SVV + b, P, p, q); v[b] = prelu4u(vp[b], a22);
-        }
-        // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
-        f32x4 du[2], dv[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 gu = mma_block(z, lw[GT_U(b) * 64 + lane], tm1), gv = mma_block(z, lw[GT_V(b) * 64 + lane], tm2);
-            scal[1] += negsum4(gu, up[b]);
-            scal[2] += negsum4(gv, vp[b]);
-            du[b] = gu * dprelu4(up[b], a21);
-            dv[b] = gv * dprelu4(vp[b], a22);
-        }
-        // dh1 and dt
-        f32x4 dt[4];
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du[0]);
-            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du[1]);
-            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv[0]);
-            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv[1]);
-            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
-            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
-            scal[0] += negsum4(d, t[hb]);
-            dt[hb] = d * dprelu4(t[hb], a1);
-            if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(b, k) * 64 + lane], dt[k]);
-            if (valid) stb(a.gr, GR_DH0 + b, P, p, q, d);
-        }
-        vec[0] += do1; vec[1] += do2;
-        vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
-        // weight gradients
-        f32x4 h1t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) h1t[k] = tr16(h1[k], sc, j, q);
-        const f32x4 mt = tr16(mb, sc, j, q);
-        {
-            const f32x4 d1t = tr16(do1, sc, j, q), d2t = tr16(do2, sc, j, q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { acc[k] = outer16(acc[k], d1t, h1t[k]); acc[7 + k] = outer16(acc[7 + k], d2t, h1t[k]); }
-            acc[4] = outer16(acc[4], d1t, mt);
-            acc[11] = outer16(acc[11], d2t, mt);
-            const f32x4 m1t = tr16(tm1, sc, j, q), m2t = tr16(tm2, sc, j, q);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                acc[5 + b] = outer16(acc[5 + b], m1t, tr16(u[b], sc, j, q));
-                acc[12 + b] = outer16(acc[12 + b], m2t, tr16(v[b], sc, j, q));
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const f32x4 dut = tr16(du[b], sc, j, q), dvt = tr16(dv[b], sc, j, q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc[14 + b * 4 + k] = outer16(acc[14 + b * 4 + k], dut, h1t[k]);
-                acc[22 + b * 4 + k] = outer16(acc[22 + b * 4 + k], dvt, h1t[k]);
-            }
-        }
-    }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
-}
-
-// ---- pass 0': layer 1 and init_trns.
-// accumulators: init_trns (2 x [Slice || Mask]) = 2; l1_t1_2 {2 x (h0 x2, Mask), adjoint 2 x 2} = 10; l1_t2_2 = 10  -> 22
-// vec: b(init_trns) x2, b(l1_t1_2) x2, b(l1_t2_2) x2 = 6; scal: a, a11, a12
-__global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
-    constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
-    __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
-    __syncthreads();
-    const float* lscal = (const float*)(lw + GT0_GROUPS * 64);
-    const float a0 = lscal[0], a11 = lscal[1], a12 = lscal[2];
-    int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sc = tsc[wave];
-    const int S = a.S;
-    const long long P = a.P;
-    f32x4 acc[22], vec[6];
-    float scal[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 22; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
-        const float vm = valid ? 1.f : 0.f;
-        f32x4 xm = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
-        if (q == 0) { xm = *(const f32x4*)(a.slice + p * 4); mb = *(const f32x4*)(a.mask + p * 4); }
-        if (q == 1) xm = *(const f32x4*)(a.mask + p * 4);
-        const float* gr = a.gr;
-        f32x4 z0[2], h0[2], dt[4], tmd1[2], tmd2[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
-            h0[b] = prelu4u(z0[b], a0);
-        }
-        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
-        f32x4 dz0[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 dq1 = {0.f, 0.f, 0.f, 0.f}, dq2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                dq1 = mma_block(dq1, lw[GT_Q(0, b, k) * 64 + lane], tmd1[k]);
-                dq2 = mma_block(dq2, lw[GT_Q(1, b, k) * 64 + lane], tmd2[k]);
-            }
-            scal[1] += negsum4(dq1, h0[b]);
-            scal[2] += negsum4(dq2, h0[b]);
-            const f32x4 dh0 = ldb(a.gr, GR_DH0 + b, P, p, q) * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
-            scal[0] += negsum4(dh0, z0[b]);
-            dz0[b] = dh0 * dprelu4(z0[b], a0);
-        }
-        vec[0] += dz0[0]; vec[1] += dz0[1];
-        vec[2] += dt[0]; vec[3] += dt[1]; vec[4] += dt[2]; vec[5] += dt[3];
-        const f32x4 xmt = tr16(xm, sc, j, q), mt = tr16(mb, sc, j, q);
-        const f32x4 h0t[2] = {tr16(h0[0], sc, j, q), tr16(h0[1], sc, j, q)};
-        const f32x4 q1t[2] = {tr16(prelu4u(h0[0], a11), sc, j, q), tr16(prelu4u(h0[1], a11), sc, j, q)};
-        const f32x4 q2t[2] = {tr16(prelu4u(h0[0], a12), sc, j, q), tr16(prelu4u(h0[1], a12), sc, j, q)};
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[b] = outer16(acc[b], tr16(dz0[b], sc, j, q), xmt);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int base = 2 + 10 * h;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const f32x4 dtt = tr16(dt[2 * h + b], sc, j, q);
-                acc[base + b * 3 + 0] = outer16(acc[base + b * 3 + 0], dtt, h0t[0]);
-                acc[base + b * 3 + 1] = outer16(acc[base + b * 3 + 1], dtt, h0t[1]);
-                acc[base + b * 3 + 2] = outer16(acc[base + b * 3 + 2], dtt, mt);
-                const f32x4 tmt = tr16(h == 0 ? tmd1[b] : tmd2[b], sc, j, q);
-                acc[base + 6 + b * 2 + 0] = outer16(acc[base + 6 + b * 2 + 0], tmt, h == 0 ? q1t[0] : q2t[0]);
-                acc[base + 6 + b * 2 + 1] = outer16(acc[base + 6 + b * 2 + 1], tmt, h == 0 ? q1t[1] : q2t[1]);
-            }
-        }
-    }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 22, vec, 6, scal, 3, threadIdx.x & 63, j, q);
-}
-
-// fixed-order reduction of the per-wave partials into the gradient blob (registry layout of the weight mirror): a workgroup
-// owns 32 entries; its 8 groups of 32 threads sum the waves w = group, group + 8, ... and the 8 sums are added in group order
-__global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ part, int n_waves, int n_acc, int n_vec, int n_scal,
-                                                      const AccDesc* __restrict__ ad, const VecDesc* __restrict__ vd,
-                                                      const int32_t* __restrict__ sd, float* __restrict__ blob, int accumulate) {
-    __shared__ float ps[8][32];
-    const int stride = n_acc * 256 + n_vec * 16 + 16;
-    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + o;
-    float s = 0.f;
-    if (idx < stride) {      // four independent partial sums (loads in flight), combined in a fixed order
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int wv = grp;
-        for (; wv + 24 < n_waves; wv += 32) {
-            s0 += part[(size_t)wv * stride + idx];
-            s1 += part[(size_t)(wv + 8) * stride + idx];
-            s2 += part[(size_t)(wv + 16) * stride + idx];
-            s3 += part[(size_t)(wv + 24) * stride + idx];
-        }
-        for (; wv < n_waves; wv += 8) s0 += part[(size_t)wv * stride + idx];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    ps[grp][o] = s;
-    __syncthreads();
-    if (grp != 0 || idx >= stride) return;
-    int dst = -1;
-    if (idx < n_acc * 256) {
-        const int k = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
-        const int i = 4 * (lane >> 4) + r, n = lane & 15;
-        const AccDesc d = ad[k];
-        if (i < d.nrows && n < d.ncols && n >= d.n0) dst = d.mat_off + (d.row0 + i) * d.ld + d.col0 + n;
-    } else if (idx < n_acc * 256 + n_vec * 16) {
-        const int k = (idx - n_acc * 256) >> 4, i = (idx - n_acc * 256) & 15;
-        const VecDesc d = vd[k];
-        if (i < d.nrows) dst = d.off + (d.row0 + i) * d.stride;
-    } else {
-        const int k = idx - n_acc * 256 - n_vec * 16;
-        if (k < n_scal) dst = sd[k];
-    }
-    if (dst < 0) return;
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += ps[k][o];
-    blob[dst] = accumulate ? blob[dst] + t : t;      // accumulate: parameters that several passes contribute to (each pass in stream order)
-}
-
-__global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= G * 30) return;
-    const int g = idx / 30, c = idx - g * 30;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += part[((size_t)g * T + t) * 32 + (c < 16 ? c : c)];
-    r_out[idx] = s;
-}
-
-// sum over the 16 lanes of a DPP row (all lanes end with the total)
-__device__ __forceinline__ float row_sum16(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Bipartite read-out of an irregular product graph (32 lanes per source node, weights transposed in LDS). The scalar form of
-// the whole G-sized tail (32 lanes per node, both matvec operands from LDS: 3.5 LDS cycles per wave-FMA, tools/lds_matvec.hip)
-// was replaced by the fp32-MFMA tile kernels below in round 2 (103.5 -> 45.4 us per window).
-// ------------------------------------------------------------------------------------------------
-constexpr int NPB = 8;  // nodes per 256-thread block
-
-// Weight staging: global [rows][ld] row-major (nn.Linear layout) -> LDS [k][ldo] (k = input index, lane = output
-// channel; conflict-free LDS writes and reads, strided but L1-resident global reads)
-__device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
-    for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
-        const int k = i / ldo, c = i - k * ldo;
-        dst[i] = c < rows ? W[c * ld + k] : 0.f;
-    }
-}
-__device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
-    stage_transposed_ld(dst, W, rows, ld, 32);
-}
-
-// r_g = sum of the message rows [seg[g], seg[g+1]) of a [P, 32] buffer (k_stage2_pcsr) in row order, out = PReLU_b2(fc2 r_g)  module.py:229
-__global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ rows, int G, const int32_t* __restrict__ seg,
-                                                    const float* __restrict__ raw, int off_w, int off_b, int off_a,
-                                                    float* __restrict__ out) {
-    __shared__ float wt[30 * 32];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
-    stage_transposed(wt, raw + off_w, 15, 30);
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float bias = c < 15 ? raw[off_b + c] : 0.f;
-    const float act = raw[off_a];
-    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < G;
-        float r = 0.f;
-        if (ok)
-            for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) r += rows[pr * 32 + c];
-        gx[grp][c] = r;
-        GSYNC();
-        float o = bias;
-#pragma unroll
-        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * gx[grp][k];
-        GSYNC();
-        if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
-    }
-}
-
-// out-degree of every source node (number of edges whose message source is j)
-__global__ void k_outdeg(const int32_t* __restrict__ col, long long E, int32_t* __restrict__ deg) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < E) atomicAdd(&deg[col[i]], 1);
-}
-
-struct SaArgs {
-    int G, C;
-    long long E;
-    const float* x_in; const float* pos;
-    const int32_t* rowptr; const int32_t* col; const int32_t* outdeg;
-    const float* raw;
-    int fc1_w, fc1_b, fc2_w, fc2_b, fg_w, fg_b, act1, act2, act3;     // this layer
-    int nx_fc1_w, nx_fg_w, nx_fg_b, nx_act3;                           // next layer (k_sa_layer<.., NEXT = true>)
-    float scale_rel;
-    const float* pj_in;    // [G,32] x-part of this layer's messages: fc1.weight[:, 0:C] x_j
-    const float* gpart_in; // [n_gpart_in][8] per-block partials of sum_j outdeg(j) PReLU3(fglobal x_j)
-    int n_gpart_in;
-    float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
-    float* gpart_out;      // [gridDim][8]
-    float* out;            // [G,30]
-    const float* img;      // k_sa_pre_m / k_sa_layer_m: the layer's k_pack_all image (plan PL_SA1 + layer - 1)
-    // batched tail: blockIdx.y = window; the window's copy of each buffer sits this many floats further on
-    long long ws_x_in, ws_slot, ws_out;
-};
-__device__ __forceinline__ void sa_select_window(SaArgs& a) {
-    const long long w = blockIdx.y;
-    a.x_in += w * a.ws_x_in;
-    if (a.pj_in) a.pj_in += w * a.ws_slot;
-    if (a.gpart_in) a.gpart_in += w * a.ws_slot;
-    if (a.pj_out) a.pj_out += w * a.ws_slot;
-    if (a.gpart_out) a.gpart_out += w * a.ws_slot;
-    if (a.out) a.out += w * a.ws_out;
-}
-
-
-
-
-// read-out heads (module.py:251-331): arguments shared by k_ro_pre_m / k_readout_m and their backward passes
-
-struct RoArgs {
-    int N, G, T;                 // nodes handled (G for MODE 0, Q for MODE 1), grid size, number of time queries (<= 16)
-    int Nw;                      // batched tail: N = nwin * Nw node ids, window w = n / Nw reads x_spatial / cv of window w
-    long long cv_ws;             // floats between the cv buffers of consecutive windows
-    const float* x_spatial;      // [G,30]
-    const float* x_grid;         // [G,3]   (MODE 1)
-    const float* x_query;        // [Q,3]   (MODE 1)
-    const int32_t* knn;          // [Q,10]  (MODE 1)
-    const float* cv;             // [G,160] per-grid-node parts of f_context / f_values (MODE 1)
-    const float* img;            // pre-transposed weight image of this MODE (k_pack_t)
-    const float* t_query;        // [T]
-    const float* raw;
-    float scale_rel, scale_t;
-    float* out;                  // [N,T]
-    float* cv_out;               // MODE 0, optional: also write the per-grid-node table cv of MODE 1 (the work of k_ro_pre_m: one
-    const float* pimg;           // pass over x_spatial and one launch less), with the PL_ROP image `pimg`; cv_ws as for `cv`
-    float* lat_out;              // optional [N,30]: the head's latent input of TemporalAttention (MODE 0: SpatialDirect(x_spatial) = y_latent,
-                                 // MODE 1: SpatialAttention(x_spatial, x_query)); k_readout_m only
-    int o_sd_w, o_sd_b, o_sd_a;
-    int o_q1w, o_q1b, o_q2w, o_q2b, o_c1w, o_c1b, o_c2w, o_c2b, o_v1w, o_v1b, o_v2w, o_v2b, o_p1w, o_p1b, o_p2w, o_p2b;
-    int o_a1, o_a2, o_a3, o_a4, o_a5;
-    int o_sq_w, o_sq_b, o_sc_w, o_sc_b, o_sv_w, o_sv_b, o_sp_w, o_sp_b, o_sa1, o_sa2;
-};
-
-// Per-grid-node part of SpatialAttention's edge Linears (module.py:290-291): f_context / f_values act on
-// [x_j || edge_attr]; the x_j part  C_j = f_context.weight[:, 0:30] x_j,  V_j = f_values.weight[:, 0:30] x_j  is the same
-// for every query that has j as a neighbour, so it is computed once per grid node: cv[j] = [C_j (75, pad 80) | V_j].
-constexpr int CVP = 160;
-
-constexpr int RO_K = 10;   // SpatialAttention neighbours (module.py:280 default k, asserted 10 elsewhere in the reference)
-constexpr int RO_TMAX = 10;   // time queries per call (the reference uses 9, process_continuous_days.py:359)
-
-
-// ------------------------------------------------------------------------------------------------
-// The G- / Q-sized tail on fp32 MFMA tiles (plans PL_RO0 .. PL_BIP above): Bipartite read-out (module.py:229), SpatialAggregation
-// (:243-249), SpatialDirect / SpatialAttention / TemporalAttention (:251-331) with the per-node Linears as MFMA chains over 16
-// nodes per wave.
-// ------------------------------------------------------------------------------------------------
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-
-struct TlImg {                 // LDS copy of a k_pack_all image
-    const f32x4* w; const float* bias; const float* scal;
-};
-__device__ __forceinline__ TlImg tl_stage_image(float* sm, const float* __restrict__ img, int n_groups, int n_bias) {
-    const int n4 = (n_groups * 256 + n_bias * 16 + 16) / 4;
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) ((f32x4*)sm)[i] = ((const f32x4*)img)[i];
-    TlImg im;
-    im.w = (const f32x4*)sm; im.bias = sm + n_groups * 256; im.scal = im.bias + n_bias * 16;
-    return im;
-}
-#define TLW(im, g) ((im).w[(g) * 64 + lane])
-__device__ __forceinline__ f32x4 tl_bias(const TlImg& im, int tile, int q) { return *(const f32x4*)(im.bias + tile * 16 + 4 * q); }
-// channel block t (channels 16t + 4q + {0..3}) of a 30-float row; the row is only 4-byte aligned and ends at channel 29
-__device__ __forceinline__ f32x4 tl_load30(const float* __restrict__ row, int t, int q) {
-    if (t == 1 && q == 3) { const f32x2u v = *(const f32x2u*)(row + 28); return f32x4{v.x, v.y, 0.f, 0.f}; }
-    const f32x4u v = *(const f32x4u*)(row + 16 * t + 4 * q);
-    return f32x4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void tl_store30(float* __restrict__ row, int t, int q, f32x4 v) {
-    if (t == 1 && q == 3) { *(f32x2u*)(row + 28) = f32x2u{v.x, v.y}; return; }
-    *(f32x4u*)(row + 16 * t + 4 * q) = f32x4u{v.x, v.y, v.z, v.w};
-}
-// the single channel block of a 15-float row
-__device__ __forceinline__ f32x4 tl_load15(const float* __restrict__ row, int q) {
-    if (q == 3) return f32x4{row[12], row[13], row[14], 0.f};
-    const f32x4u v = *(const f32x4u*)(row + 4 * q);
-    return f32x4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ f32x4 tl_zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-// Bipartite read-out (module.py:229): r_g = sum over the tiles' partial rows in tile order, out = PReLU_b2(fc2 r_g).
-__global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ part, int G, int T, const float* __restrict__ img,
-                                                  float* __restrict__ out, long long part_ws, long long out_ws) {
-    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36];
-    const TlImg im = tl_stage_image(sm, img, GB_GROUPS2, GB_BIAS2);
-    __syncthreads();
-    part += blockIdx.y * part_ws;
-    out += blockIdx.y * out_ws;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const int jl = lane >> 2, ql = lane & 3;          // row layout of the partial-row loads: four consecutive lanes read 64 contiguous bytes
-    float* ts = sm + GB2_IMG_FLOATS + wave * 16 * 36;
-    const float act = im.scal[0];
-    const int ntiles = (G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int g = tile * 16 + j;
-        const bool ok = g < G;
-        const int gl = tile * 16 + jl;
-        const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
-        f32x4 r0 = tl_zero(), r1 = tl_zero();
-        int tb = 0;
-        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
-            f32x4 v0[4], v1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
-        }
-        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
-        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
-        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
-        GSYNC();
-        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
-        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
-        GSYNC();
-        f32x4 o = tl_bias(im, 0, q);
-        o = mma_block(o, TLW(im, 0), r0);
-        o = mma_block(o, TLW(im, 1), r1);
-        o = prelu4(o, act);
-        if (ok) {
-            float* og = out + (long long)g * 15 + 4 * q;
-            og[0] = o.x; og[1] = o.y; og[2] = o.z;
-            if (q < 3) og[3] = o.w;
-        }
-    }
-}
-
-// fixed-order reduction of the per-lane global-term partials (rows m = 4q + r < 5 of the fglobal tile) -> gpart[block][m]
-__device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, float* red, float* __restrict__ gpart_out) {
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d); acc.z += __shfl_xor(acc.z, d); acc.w += __shfl_xor(acc.w, d);
-    }
-    const int j = lane & 15, q = lane >> 4;
-    if (j == 0 && q < 2) *(f32x4*)(red + wave * 8 + 4 * q) = acc;
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        float s = 0.f;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k * 8 + threadIdx.x];
-        gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
-    }
-}
-
-// Pre-pass of a SpatialAggregation layer (see k_sa_pre): pj[j] = fc1.weight[:, 0:C] x_j and the block partial of
-// sum_j outdeg(j) PReLU3(fglobal x_j).
-template <int C>
-__global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
-    sa_select_window(a);
-    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 32];
-    const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
-    float* red = sm + GS_IMG_FLOATS;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const float act3 = im.scal[3];
-    f32x4 acc = tl_zero();
-    const int ntiles = (a.G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int g = tile * 16 + j;
-        const bool ok = g < a.G;
-        const float* row = a.x_in + (long long)(ok ? g : a.G - 1) * C;
-        f32x4 xb[2];
-        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
-        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJ(t, 0)), xb[0]);
-            if (C == 30) pj = mma_block(pj, TLW(im, GS_PJ(t, 1)), xb[1]);
-            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
-        }
-        f32x4 gl = mma_block(tl_bias(im, 5, q), TLW(im, GS_FG(0)), xb[0]);
-        if (C == 30) gl = mma_block(gl, TLW(im, GS_FG(1)), xb[1]);
-        if (ok) acc += prelu4(gl, act3) * (float)a.outdeg[g];
-    }
-    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
-}
-
-// k_bip_out_m + k_sa_pre_m<15> in one launch (the batched tail): the Bipartite output of a node is the input of
-// SpatialAggregation1's pre-pass of the same node. Same MFMA chains as the two kernels (bitwise equal results).
-__global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ part, int T, const float* __restrict__ img_bip, long long part_ws,
-                                                  SaArgs a) {
-    sa_select_window(a);
-    __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36 + GS_IMG_FLOATS + 32];
-    const TlImg im = tl_stage_image(sm, img_bip, GB_GROUPS2, GB_BIAS2);
-    float* tsc = sm + GB2_IMG_FLOATS;
-    const TlImg is = tl_stage_image(tsc + 4 * 16 * 36, a.img, GS_GROUPS, GS_BIAS);
-    float* red = tsc + 4 * 16 * 36 + GS_IMG_FLOATS;
-    __syncthreads();
-    part += blockIdx.y * part_ws;
-    const int G = a.G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const int jl = lane >> 2, ql = lane & 3;
-    float* ts = tsc + wave * 16 * 36;
-    const float act = im.scal[0], act3 = is.scal[3];
-    f32x4 acc = tl_zero();
-    const int ntiles = (G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int g = tile * 16 + j;
-        const bool ok = g < G;
-        const int gl = tile * 16 + jl;
-        const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
-        f32x4 r0 = tl_zero(), r1 = tl_zero();
-        int tb = 0;
-        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
-            f32x4 v0[4], v1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
-        }
-        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
-        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
-        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
-        GSYNC();
-        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
-        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
-        GSYNC();
-        f32x4 o = tl_bias(im, 0, q);
-        o = mma_block(o, TLW(im, 0), r0);
-        o = mma_block(o, TLW(im, 1), r1);
-        o = prelu4(o, act);
-        if (q == 3) o.w = 0.f;                    // channel 15 does not exist (tl_load15 of the stored row reads it as zero)
-        if (ok) {
-            float* og = a.out + (long long)g * 15 + 4 * q;
-            og[0] = o.x; og[1] = o.y; og[2] = o.z;
-            if (q < 3) og[3] = o.w;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 pj = mma_block(tl_zero(), TLW(is, GS_PJ(t, 0)), o);
-            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
-        }
-        const f32x4 glb = mma_block(tl_bias(is, 5, q), TLW(is, GS_FG(0)), o);
-        if (ok) acc += prelu4(glb, act3) * (float)a.outdeg[g];
-    }
-    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
-}
-
-// One SpatialAggregation layer (see k_sa_layer): per-edge messages on the VALU (8 channels per lane), fc2 and the next layer's
-// pre-pass as MFMA chains on the 16 nodes of the wave.
-template <int C, bool NEXT>
-__global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
-    sa_select_window(a);
-    __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 8 * 32 + 8 + 32 * 8 + 32 + 4 * 16 * 36];
-    const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
-    float* w1p = sm + GS_IMG_FLOATS;         // fc1 columns C..C+7 (3 position + 5 global), [k][32]
-    float* gsum = w1p + 8 * 32;
-    float* gred = gsum + 8;                  // [32][8]
-    float* red = gred + 32 * 8;
-    float* tsc = red + 32;                   // per wave [16][36]: edge means, row layout -> MFMA layout
-    for (int i = threadIdx.x; i < 8 * 32; i += blockDim.x) {
-        const int k = i >> 5, cc = i & 31;
-        w1p[i] = cc < 30 ? a.raw[a.fc1_w + cc * (C + 8) + C + k] : 0.f;
-    }
-    {   // global term: the producer's per-block partials in the same fixed two-level order as k_sa_layer
-        const int m = threadIdx.x & 7, chunk = threadIdx.x >> 3;
-        float sgl = 0.f;
-        for (int b = chunk; b < a.n_gpart_in; b += 32) sgl += a.gpart_in[b * 8 + m];
-        gred[chunk * 8 + m] = sgl;
-        __syncthreads();
-        if (threadIdx.x < 8) {
-            float t = 0.f;
-            for (int k = 0; k < 32; ++k) t += gred[k * 8 + threadIdx.x];
-            gsum[threadIdx.x] = t;
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    // The per-edge phase is elementwise per (node, channel) and runs in the ROW layout lane = 4 r + cq (node r, chunk cq): four
-    // consecutive lanes read one 64-B half of a gathered pj row (in the MFMA layout they read 16-B chunks of four different
-    // rows: a quarter of the texture path's rate); the edge means cross a per-wave LDS scratch into the MFMA layout for fc2.
-    const int jl = lane >> 2, ql = lane & 3;
-    float* ts = tsc + wave * 16 * 36;
-    const float act1 = im.scal[0], act2 = im.scal[1], act3n = im.scal[2];
-    f32x4 base[2], wp[3][2];
-    {
-        const float invE = 1.f / (float)(a.E > 0 ? a.E : 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            base[t] = tl_bias(im, 2 + t, ql);
-#pragma unroll
-            for (int m = 0; m < 5; ++m) base[t] += *(const f32x4*)(w1p + (3 + m) * 32 + 16 * t + 4 * ql) * (gsum[m] * invE);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * ql);
-        }
-    }
-    f32x4 acc = tl_zero();
-    const int ntiles = (a.G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int i = tile * 16 + j;
-        const bool ok = i < a.G;
-        const int ic = ok ? i : a.G - 1;
-        const float* row = a.x_in + (long long)ic * C;
-        f32x4 xb[2];
-        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
-        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
-        // ---- edges of node il (row layout)
-        const int il = tile * 16 + jl;
-        const bool okl = il < a.G;
-        const int icl = okl ? il : a.G - 1;
-        const float pi0 = a.pos[icl * 3 + 0] / a.scale_rel, pi1 = a.pos[icl * 3 + 1] / a.scale_rel, pi2 = a.pos[icl * 3 + 2] / a.scale_rel;
-        const int eb = a.rowptr[icl], ee = okl ? a.rowptr[icl + 1] : eb;
-        f32x4 as[2] = {tl_zero(), tl_zero()};
-        // edges in chunks of 4: ids, the gathered rows / positions in flight, then the arithmetic in edge order (no cross-lane
-        // operation inside: the nodes of a wave may differ in trip count)
-        for (int e0 = eb; e0 < ee; e0 += 4) {
-            int jn[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) jn[k] = a.col[min(e0 + k, ee - 1)];
-            f32x4 pjv[4][2];
-            float q0[4], q1[4], q2[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pjv[k][0] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 4 * ql);
-                pjv[k][1] = *(const f32x4*)(a.pj_in + (long long)jn[k] * 32 + 16 + 4 * ql);
-                q0[k] = a.pos[jn[k] * 3 + 0]; q1[k] = a.pos[jn[k] * 3 + 1]; q2[k] = a.pos[jn[k] * 3 + 2];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d0 = pi0 - q0[k] / a.scale_rel, d1 = pi1 - q1[k] / a.scale_rel, d2 = pi2 - q2[k] / a.scale_rel;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 m = pjv[k][t] + base[t];
-                    m += wp[0][t] * d0;
-                    m += wp[1][t] * d1;
-                    m += wp[2][t] * d2;
-                    if (e0 + k < ee) as[t] += prelu4(m, act1);
-                }
-            }
-        }
-        const float deg = (float)max(ee - eb, 1);
-        *(f32x4*)(ts + jl * 36 + 4 * ql) = as[0] / deg;
-        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = as[1] / deg;
-        GSYNC();
-        const f32x4 av[2] = {*(const f32x4*)(ts + j * 36 + 4 * q), *(const f32x4*)(ts + j * 36 + 16 + 4 * q)};
-        GSYNC();
-        f32x4 o[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 v = mma_block(tl_bias(im, t, q), TLW(im, GS_FC2(t, 0)), xb[0]);
-            if (C == 30) v = mma_block(v, TLW(im, GS_FC2(t, 1)), xb[1]);
-            v = mma_block(v, TLW(im, GS_FC2(t, 2)), av[0]);
-            v = mma_block(v, TLW(im, GS_FC2(t, 3)), av[1]);
-            o[t] = prelu4(v, act2);
-            if (ok) tl_store30(a.out + (long long)i * 30, t, q, o[t]);
-        }
-        if (NEXT) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJN(t, 0)), o[0]);
-                pj = mma_block(pj, TLW(im, GS_PJN(t, 1)), o[1]);
-                if (ok) *(f32x4*)(a.pj_out + (long long)i * 32 + 16 * t + 4 * q) = pj;
-            }
-            f32x4 gl = mma_block(tl_bias(im, 4, q), TLW(im, GS_FGN(0)), o[0]);
-            gl = mma_block(gl, TLW(im, GS_FGN(1)), o[1]);
-            if (ok) acc += prelu4(gl, act3n) * (float)a.outdeg[i];
-        }
-    }
-    if (NEXT) tl_store_gpart(acc, lane, wave, red, a.gpart_out);
-}
-
-// Per-grid-node part of SpatialAttention's edge Linears (see k_ro_pre), biases included, in a head-padded layout:
-// cv[j] = [f_context: head h at 16h + l (l < 15, slot 15 zero) | f_values: 80 + 16h + l], CVP floats per node.
-__global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_spatial, int G, const float* __restrict__ img,
-                                                 float* __restrict__ cv, int Gw, long long cv_ws) {
-    __shared__ __attribute__((aligned(16))) float sm[GP_IMG_FLOATS];
-    const TlImg im = tl_stage_image(sm, img, GP_GROUPS, GP_BIAS);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const int ntiles = (G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int g = tile * 16 + j;
-        const bool ok = g < G;
-        const int gc = ok ? g : G - 1;
-        const float* row = x_spatial + (long long)gc * 30;
-        const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
-        const int w = gc / Gw;
-        float* o = cv + w * cv_ws + (long long)(gc - w * Gw) * CVP + 4 * q;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int h = 0; h < 5; ++h) {
-                f32x4 v = mma_block(tl_bias(im, m * 5 + h, q), TLW(im, GP(m, h, 0)), xb0);
-                v = mma_block(v, TLW(im, GP(m, h, 1)), xb1);
-                if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
-            }
-    }
-}
-
-// Read-out heads (see k_readout). MODE 0: y = TemporalAttention(SpatialDirect(x_spatial)) per grid node; MODE 1:
-// x = TemporalAttention(SpatialAttention(x_spatial, x_query, x_grid)) per query. SpatialAttention's per-edge arithmetic runs on
-// the VALU head by head (a lane holds 4 of a head's 16 slots for its query; the head dot product is a 4-lane butterfly); the
-// attention scores of TemporalAttention are an MFMA against the time-query fragments (score[t] = Q_h[t, :] . ctx_h), and the
-// score x value products, per node, go through a per-wave LDS scratch (a lane needs all T x 5 scores of its node).
-constexpr int RO_SCS = 68;      // floats per node in the score scratch: [5 heads][12 time slots] + pad
-constexpr int ROM_LDS_FLOATS = GR_IMG_FLOATS + 5 * 256 + 10 * 80 + 4 * 16 * RO_SCS;
-template <int MODE>
-__global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const TlImg im = tl_stage_image(sm, a.img, GR_GROUPS, GR_BIAS);
-    float* qf = sm + GR_IMG_FLOATS;          // [5][64][4]: A fragments of the temporal queries, head h
-    float* et = qf + 5 * 256;                // [10][80] (MODE 1): f_queries columns 0..2, f_context / f_values edge columns, f_queries bias
-    float* scr = et + 10 * 80;
-    TlImg imp = im;                          // MODE 0 with cv_out: the PL_ROP image behind the score scratch
-    if (MODE == 0 && a.cv_out != nullptr) imp = tl_stage_image(scr + 4 * 16 * RO_SCS, a.pimg, GP_GROUPS, GP_BIAS);
-    {   // qf[h][lane][r] = query[t = lane & 15][head h][l = 4 (lane >> 4) + r], query = temporal_query_2(PReLU3(temporal_query_1(t / scale_t)))  :329
-        const float act3 = a.raw[a.o_a3];
-        for (int i = threadIdx.x; i < 5 * 256; i += blockDim.x) {
-            const int h = i >> 8, ln = (i & 255) >> 2, r = i & 3, t = ln & 15, l = 4 * (ln >> 4) + r;
-            float v = 0.f;
-            if (t < a.T && l < 15) {
-                const int ch = 15 * h + l;
-                const float tq = a.t_query[t] / a.scale_t;
-                v = a.raw[a.o_q2b + ch];
-                for (int k = 0; k < 30; ++k) {
-                    const float hq = prelu1(a.raw[a.o_q1w + k] * tq + a.raw[a.o_q1b + k], act3);
-                    v += a.raw[a.o_q2w + ch * 30 + k] * hq;
-                }
-            }
-            qf[i] = v;
-        }
-        if (MODE == 1) {
-            for (int i = threadIdx.x; i < 10 * 80; i += blockDim.x) {
-                const int m = i / 80, rem = i - m * 80, h = rem >> 4, l = rem & 15, ch = 15 * h + l;
-                float v = 0.f;
-                if (l < 15) {
-                    if (m < 3) v = a.raw[a.o_sq_w + ch * 3 + m];
-                    else if (m < 6) v = a.raw[a.o_sc_w + ch * 33 + 30 + (m - 3)];
-                    else if (m < 9) v = a.raw[a.o_sv_w + ch * 33 + 30 + (m - 6)];
-                    else v = a.raw[a.o_sq_b + ch];
-                }
-                et[i] = v;
-            }
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const float fa = im.scal[0], sa1 = im.scal[1], act1 = im.scal[2], act2 = im.scal[3], act4 = im.scal[4], act5 = im.scal[5];
-    const float b_p2 = im.scal[6];
-    const float inv_sqrt_l = 1.f / sqrtf(15.f);
-    float* ws = scr + (wave * 16 + j) * RO_SCS;
-    const int ntiles = (a.N + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int n = tile * 16 + j;
-        const bool ok = n < a.N;
-        const int nc = ok ? n : a.N - 1;
-        f32x4 xin[2];
-        if (MODE == 0) {
-            const float* row = a.x_spatial + (long long)nc * 30;
-            const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
-            if (a.cv_out != nullptr) {                                                  // k_ro_pre_m's work for this node (same MFMA chains)
-                const int w = nc / a.Nw;
-                float* o = a.cv_out + w * a.cv_ws + (long long)(nc - w * a.Nw) * CVP + 4 * q;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int h = 0; h < 5; ++h) {
-                        f32x4 v = mma_block(tl_bias(imp, m * 5 + h, q), TLW(imp, GP(m, h, 0)), xb0);
-                        v = mma_block(v, TLW(imp, GP(m, h, 1)), xb1);
-                        if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {                                               // SpatialDirect  :258-260
-                f32x4 y = mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xb0);
-                y = mma_block(y, TLW(im, GR_FRONT(t, 1)), xb1);
-                xin[t] = prelu4(y, fa);
-            }
-        } else {
-            // SpatialAttention in the ROW layout lane = 4 r + cq (query r = lane >> 2, chunk cq = lane & 3): four consecutive lanes
-            // read one 64-B head block of a gathered cv row (the MFMA layout reads 16-B chunks of four rows per quad: a quarter of
-            // the texture path's rate on the 6.4 KB a query gathers), the head sums are butterflies inside a quad; the aggregated
-            // vector crosses the wave's LDS scratch into the MFMA layout for proj.
-            const int jl = lane >> 2, ql = lane & 3;
-            const int n_l = tile * 16 + jl;
-            const int ncl = n_l < a.N ? n_l : a.N - 1;
-            const int wq = ncl / a.Nw, nl = ncl - wq * a.Nw;
-            const float* cvw = a.cv + wq * a.cv_ws + 4 * ql;
-            const float xq0 = a.x_query[nl * 3 + 0], xq1 = a.x_query[nl * 3 + 1], xq2 = a.x_query[nl * 3 + 2];
-            int jn[RO_K];
-            float e[RO_K][3];
-#pragma unroll
-            for (int k = 0; k < RO_K; ++k) jn[k] = a.knn[(long long)nl * RO_K + k];
-#pragma unroll
-            for (int k = 0; k < RO_K; ++k) {                                            // edge_attr  :283
-                e[k][0] = (xq0 - a.x_grid[jn[k] * 3 + 0]) / a.scale_rel;
-                e[k][1] = (xq1 - a.x_grid[jn[k] * 3 + 1]) / a.scale_rel;
-                e[k][2] = (xq2 - a.x_grid[jn[k] * 3 + 2]) / a.scale_rel;
-            }
-            f32x4 xm = tl_zero();
-#pragma unroll
-            for (int h = 0; h < 5; ++h) {
-                const float* eh = et + h * 16 + 4 * ql;
-                const f32x4 bq = *(const f32x4*)(eh + 9 * 80);
-                f32x4 wq_[3], wc_[3], wv_[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    wq_[d] = *(const f32x4*)(eh + d * 80); wc_[d] = *(const f32x4*)(eh + (3 + d) * 80); wv_[d] = *(const f32x4*)(eh + (6 + d) * 80);
-                }
-                f32x4 cvk[RO_K];
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + h * 16);
-                float al[RO_K];
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) {                                        // alpha = PReLU1(sum_l q c / sqrt(L))  :293
-                    f32x4 q4 = bq, c4 = cvk[k];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { q4 += wq_[d] * e[k][d]; c4 += wc_[d] * e[k][d]; }
-                    const f32x4 pr = q4 * c4;
-                    al[k] = ((pr.x + pr.y) + pr.z) + pr.w;
-                }
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + 80 + h * 16);
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) {
-                    al[k] += __shfl_xor(al[k], 1);
-                    al[k] += __shfl_xor(al[k], 2);
-                    al[k] = prelu1(al[k] * inv_sqrt_l, sa1);
-                }
-                float mx = al[0];                                                       // segment softmax over the K edges  :295
-#pragma unroll
-                for (int k = 1; k < RO_K; ++k) mx = fmaxf(mx, al[k]);
-                float ssum = 0.f;
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) { al[k] = expf(al[k] - mx); ssum += al[k]; }
-                const float den = ssum + 1e-16f;
-                f32x4 gh = tl_zero();
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) {                                        // 'add' aggregation of alpha * v  :264,297
-                    f32x4 v4 = cvk[k];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) v4 += wv_[d] * e[k][d];
-                    gh += v4 * (al[k] / den);
-                }
-                xm += gh;
-            }
-            xm *= 0.2f;                                                                 // mean over heads  :285
-            float* wsb = scr + wave * 16 * RO_SCS;
-            *(f32x4*)(wsb + jl * RO_SCS + 4 * ql) = xm;                                 // row layout -> MFMA layout
-            GSYNC();
-            xm = *(const f32x4*)(wsb + j * RO_SCS + 4 * q);
-            GSYNC();
-#pragma unroll
-            for (int t = 0; t < 2; ++t)                                                 // PReLU2(proj(.))  :285
-                xin[t] = prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa);
-        }
-        if (a.lat_out != nullptr && ok) {
-            tl_store30(a.lat_out + (long long)n * 30, 0, q, xin[0]);
-            tl_store30(a.lat_out + (long long)n * 30, 1, q, xin[1]);
-        }
-        // ------------------------------------------------------------------ TemporalAttention on xin  :325-331
-        f32x4 h1[2], h2[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 c1 = mma_block(tl_bias(im, 2 + t, q), TLW(im, GR_C1(t, 0)), xin[0]);
-            c1 = mma_block(c1, TLW(im, GR_C1(t, 1)), xin[1]);
-            h1[t] = prelu4(c1, act1);
-            f32x4 v1 = mma_block(tl_bias(im, 4 + t, q), TLW(im, GR_V1(t, 0)), xin[0]);
-            v1 = mma_block(v1, TLW(im, GR_V1(t, 1)), xin[1]);
-            h2[t] = prelu4(v1, act2);
-        }
-        f32x4 val[5];
-#pragma unroll
-        for (int h = 0; h < 5; ++h) {
-            f32x4 cx = mma_block(tl_bias(im, 6 + h, q), TLW(im, GR_C2(h, 0)), h1[0]);
-            cx = mma_block(cx, TLW(im, GR_C2(h, 1)), h1[1]);
-            // score[t, h] = ctx[h, :] . query[t, h, :] / sqrt(L): rows t = 4q + r of the result
-            const f32x4 sc = mma_block(tl_zero(), ((const f32x4*)qf)[h * 64 + lane], cx) * inv_sqrt_l;
-            if (q < 3) *(f32x4*)(ws + h * 12 + 4 * q) = sc;
-            f32x4 vx = mma_block(tl_bias(im, 11 + h, q), TLW(im, GR_V2(h, 0)), h2[0]);
-            val[h] = mma_block(vx, TLW(im, GR_V2(h, 1)), h2[1]);
-        }
-        GSYNC();
-        const f32x4 w2a = tl_bias(im, 18, q), w2b = tl_bias(im, 19, q);
-#pragma unroll 2
-        for (int t = 0; t < a.T; ++t) {
-            f32x4 z = tl_zero();                                                        // z[t, l] = mean_h score[t, h] val[h, l]
-#pragma unroll
-            for (int h = 0; h < 5; ++h) z += val[h] * ws[h * 12 + t];
-            z = prelu4(z * 0.2f, act4);
-            f32x4 pa = prelu4(mma_block(tl_bias(im, 16, q), TLW(im, GR_P1(0)), z), act5);        // proj_2(PReLU5(proj_1(.)))
-            f32x4 pb = prelu4(mma_block(tl_bias(im, 17, q), TLW(im, GR_P1(1)), z), act5);
-            float o = w2a.x * pa.x;
-            o += w2a.y * pa.y; o += w2a.z * pa.z; o += w2a.w * pa.w;
-            o += w2b.x * pb.x; o += w2b.y * pb.y; o += w2b.z * pb.z; o += w2b.w * pb.w;
-            o += __shfl_xor(o, 16);
-            o += __shfl_xor(o, 32);
-            if (ok && q == 0) a.out[(long long)n * a.T + t] = o + b_p2;
-        }
-        GSYNC();
-    }
-}
-
-// LocalSliceLgCollapse (module.py:610-659), pick-sized: per pick a the K = 10 product nodes of its station whose theoretical
-// arrival is nearest the pick time (time-pointer table A_edges[(ipick * l_dt + t_index) * K + k], :635-640), those within
-// 2 eps of the pick time kept (:642-647), message PReLU1(fc1[s[e] || (tpick - tlatent[e]) / eps || phase]) (:657-659), 'mean'
-// over the kept edges (:612), PReLU2(fc2 .) (:651). A wave owns 16 picks (fp32-MFMA tile layout of the tail kernels).
-constexpr int LS_K = 10;
-struct LsArgs {
-    int n_picks, l_dt;
-    long long n_edges;            // entries of the time-pointer table (indices are clamped into it)
-    float t0, dt, eps;
-    const float* s;               // [P, 30] association embedding (genie_assoc_fwd)
-    const int32_t* A_edges;       // [n_sta * l_dt * K] product-node ids
-    const float* tlatent; int tl_stride, tl_col;     // theoretical arrival of product node e: tlatent[e * tl_stride + tl_col]
-    const float* tpick; const int32_t* ipick; const float* phase;
-    const float* img;
-    float* out;                   // [n_picks, 15]
-};
-__global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[GL_IMG_FLOATS];
-    const TlImg im = tl_stage_image(sm, a.img, GL_GROUPS, GL_BIAS);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const float act1 = im.scal[0], act2 = im.scal[1];
-    const int ntiles = (a.n_picks + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int p = tile * 16 + j;
-        const bool ok = p < a.n_picks;
-        const int pc = ok ? p : a.n_picks - 1;
-        const float tp = a.tpick[pc], ph = a.phase[pc];
-        const int ti = (int)floorf((tp - a.t0) / a.dt);                                   // :635
-        long long base = ((long long)a.ipick[pc] * a.l_dt + ti) * LS_K;
-        base = base < 0 ? 0 : (base > a.n_edges - LS_K ? a.n_edges - LS_K : base);
-        f32x4 acc[2] = {tl_zero(), tl_zero()};
-        float cnt = 0.f;
-#pragma unroll 2
-        for (int k = 0; k < LS_K; ++k) {
-            const int e = a.A_edges[base + k];
-            const float rt = tp - a.tlatent[(long long)e * a.tl_stride + a.tl_col];
-            const bool keep = ok && fabsf(rt) < 2.0f * a.eps;                             // :642-645
-            const float* row = a.s + (long long)e * 30;
-            const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
-            const float xs = q == 0 ? rt / a.eps : (q == 1 ? ph : 0.f);                   // columns 30, 31 of fc1
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 m = mma_block(tl_bias(im, t, q), TLW(im, GL_FC1(t, 0)), xb0);
-                m = mma_block(m, TLW(im, GL_FC1(t, 1)), xb1);
-                m = MFMA16(TLW(im, GL_FC1(t, 2)).x, xs, m);
-                m = prelu4(m, act1);
-                if (keep) acc[t] += m;
-            }
-            cnt += keep ? 1.f : 0.f;
-        }
-        const float den = fmaxf(cnt, 1.f);
-        f32x4 o = mma_block(tl_bias(im, 2, q), TLW(im, GL_FC2(0)), acc[0] / den);
-        o = mma_block(o, TLW(im, GL_FC2(1)), acc[1] / den);
-        o = prelu4(o, act2);
-        if (ok) {
-            float* og = a.out + (long long)p * 15 + 4 * q;
-            og[0] = o.x; og[1] = o.y; og[2] = o.z;
-            if (q < 3) og[3] = o.w;
-        }
-    }
-}
-
-// StationSourceAttentionMergedPhases (module.py:662-775, use_sparse = True, use_neighbor_assoc_edges = False), pick-sized. For
-// every source i and pick a the reference attends over the picks b of a's station plus a null pick (:703-718), keeps the edges
-// whose observed - theoretical arrival time (P or S) is inside 2 eps (:722-729) -- a property of (b, i) alone --, and runs three
-// edge MLPs; queries and the relative-time features depend on (b, i) only, the context on (i, self_link, null_link), the values
-// on (b, i, self_link, null_link). One workgroup per (source i, station u with picks):
-//   A1  keep flags of the station's picks + the null pick, compacted in order into an LDS list;
-//   A2  per kept b (16 per wave, fp32-MFMA tiles): query -> the three head scores against the context of a plain edge and of a
-//       self edge (the null pick: of a null edge), values of a plain edge and of a self edge (null pick: of a null edge) -> LDS;
-//   B   per target a of the station (16 per wave): segment softmax over the kept list (the entry b == a takes its self variant),
-//       'add' aggregation, mean over heads, proj_2(PReLU4(proj_1(.))).
-// k_arr_ctx prepares the three context vectors of every source. Needs at least one source with |stime| < 2 eps (then the
-// reference's `edge_index[0].max()` (:762-763) is the null pick, as assumed here); the host checks it and otherwise keeps the
-// PyTorch restatement. The softmax runs in its streaming form over chunks of AR_CAP picks (running maximum, denominator and
-// weighted value sum per target; the sum is divided by (denominator + 1e-16) at the end instead of every weight being divided
-// first: rounding-order difference only), so a station may hold any number of picks.
-constexpr int AR_CAP = 192;       // picks of a station (null included) per LDS chunk
-constexpr int AR_ENT = 104;       // floats per kept entry: scores plain [3], self [3], pad 2, values plain [3][16], self [3][16]
-constexpr int AT_STAT = 64;       // training forward, per (source, pick): normalised head aggregates [3][16], running max [3], denominator [3]
-struct ArArgs {
-    int n_src, n_sta, n_arv, n_useg;
-    float eps;
-    const float* stime;           // [n_src]
-    const float* trv_src;         // [n_src, n_sta, 2]
-    const float* ctx;             // [n_src][4][48] (k_arr_ctx): plain, self, null, self + null edge; head h at 16h
-    const float* arv_p; const float* arv_s;          // [n_arv, 15]
-    const float* tpick; const float* phase;          // [n_arv]
-    const int32_t* order;         // picks sorted by station (stable)
-    const int32_t* seg_sta; const int32_t* seg_start; const int32_t* seg_len;     // [n_useg] stations with picks
-    const float* img;
-    float* out;                   // [n_src, n_arv, 2]
-    int* e0max;                   // [1] `edge_index[0].max()` over the kept edges (module.py:762-763), by k_arr_e0max: the pick the
-                                  // reference treats as "the null pick"; = n_arv (the real null pick) whenever some source has
-                                  // |stime| < 2 eps, i.e. always in practice
-    float* save;                  // training forward: [n_src * n_arv][AT_STAT] (else null)
-};
-
-// e0max = max over the kept (pick b, source i) pairs of b, the null pick (index n_arv) included (module.py:740-763). A pick's
-// edges towards source i survive the 2-eps filter or not as a whole (the test involves only b and i), and every pick has at
-// least its self pair, so "b has a kept edge towards i" = "its test passes".
-__global__ __launch_bounds__(256) void k_arr_e0max(ArArgs a) {
-    const int i = blockIdx.x / a.n_useg, ug = blockIdx.x - i * a.n_useg;
-    const int u = a.seg_sta[ug], r0 = a.seg_start[ug], L = a.seg_len[ug];
-    const float eps = a.eps, st = a.stime[i];
-    const float tp_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 0] + st, ts_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 1] + st;
-    int best = -1;
-    if (threadIdx.x == 0 && ug == 0 && fabsf(st) < 2.f * eps) best = a.n_arv;
-    for (int r = threadIdx.x; r < L; r += blockDim.x) {
-        const int b = a.order[r0 + r];
-        const float tp = a.tpick[b];
-        if (fabsf(tp - tp_src) < 2.f * eps || fabsf(tp - ts_src) < 2.f * eps) best = max(best, b);
-    }
-    if (best >= 0) atomicMax(a.e0max, best);
-}
-
-__global__ __launch_bounds__(128) void k_arr_ctx(const float* __restrict__ raw, int o_c1w, int o_c1b, int o_c2w, int o_c2b, int o_a1,
-                                                const float* __restrict__ src_embed, const float* __restrict__ stime, int n_src,
-                                                float* __restrict__ ctx) {
-    __shared__ float hid[4][32];
-    const int i = blockIdx.x;
-    if (i >= n_src) return;
-    const float act1 = raw[o_a1];
-    for (int idx = threadIdx.x; idx < 4 * 30; idx += blockDim.x) {
-        const int v = idx / 30, c = idx - v * 30;
-        float t = raw[o_c1b + c];
-        for (int k = 0; k < 30; ++k) t += raw[o_c1w + c * 33 + k] * src_embed[(long long)i * 30 + k];
-        t += raw[o_c1w + c * 33 + 30] * stime[i];
-        if (v & 1) t += raw[o_c1w + c * 33 + 31];      // self_link
-        if (v & 2) t += raw[o_c1w + c * 33 + 32];      // null_link
-        hid[v][c] = prelu1(t, act1);
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 4 * 48; idx += blockDim.x) {
-        const int v = idx / 48, r = idx - v * 48, h = r >> 4, l = r & 15;
-        float t = 0.f;
-        if (l < 15) {
-            const int ch = 15 * h + l;
-            t = raw[o_c2b + ch];
-            for (int k = 0; k < 30; ++k) t += raw[o_c2w + ch * 30 + k] * hid[v][k];
-        }
-        ctx[((long long)i * 4 + v) * 48 + r] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_arrivals(ArArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const TlImg im = tl_stage_image(sm, a.img, GA_GROUPS2, GA_BIAS2);
-    float* ent = sm + GA2_IMG_FLOATS;                 // [AR_CAP][AR_ENT]
-    int* kept = (int*)(ent + AR_CAP * AR_ENT);        // [AR_CAP] position r in the station's pick list (L = the null pick)
-    int* kbi = kept + AR_CAP;                         // [AR_CAP] its pick index (n_arv = the null pick)
-    float* cx = (float*)(kbi + AR_CAP);               // [4][48] context vectors of this source
-    int* wcnt = (int*)(cx + 192);                     // [4] per-wave counts of the compaction, [4] = total
-    const int i = blockIdx.x / a.n_useg, ug = blockIdx.x - i * a.n_useg;
-    const int u = a.seg_sta[ug], r0 = a.seg_start[ug], L = a.seg_len[ug];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const float eps = a.eps, st = a.stime[i];
-    const float tp_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 0] + st, ts_src = a.trv_src[((long long)i * a.n_sta + u) * 2 + 1] + st;
-    const float rel_null = -eps - (-eps + st);        // null pick: atime = -eps, theoretical time = -eps (:722-725)
-    for (int k = threadIdx.x; k < 192; k += blockDim.x) cx[k] = a.ctx[(long long)i * 192 + k];
-    // the pick index the reference takes for the null pick (:762-765): n_arv unless NO source keeps the real null pick
-    const int E = *a.e0max;
-    __syncthreads();      // the weight image and cx are complete before any wave reads them (the slopes and proj_2 rows below!)
-    const float act2 = im.scal[0], act3 = im.scal[1], act4 = im.scal[2];
-    const float e2 = eps * eps, sq = sqrtf(15.f);
-    const f32x4 w2[2][2] = {{tl_bias(im, 12, q), tl_bias(im, 13, q)}, {tl_bias(im, 14, q), tl_bias(im, 15, q)}};
-    // Targets in blocks of 256 (4 tiles of 16 per wave, their softmax state in registers); the station's picks + the null pick
-    // (r = 0 .. L) in chunks of AR_CAP: A1 / A2 fill the LDS list with the kept picks of the chunk, B folds them into the running
-    // (max, denominator, weighted value sum) of every target (one chunk = the plain two-pass segment softmax).
-    for (int tb0 = 0; tb0 < L; tb0 += 256) {
-        float mx[4][3], den[4][3];
-        f32x4 agg[4][3];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int h = 0; h < 3; ++h) { mx[tt][h] = -INFINITY; den[tt][h] = 0.f; agg[tt][h] = tl_zero(); }
-        for (int cb = 0; cb <= L; cb += AR_CAP) {
-            __syncthreads();                          // the previous chunk's list is no longer read
-            // ---- A1: ordered compaction of the kept picks of the chunk
-            {
-                const int r = cb + (int)threadIdx.x;
-                bool keep = false;
-                if ((int)threadIdx.x < AR_CAP) {
-                    if (r < L) {
-                        const float tp = a.tpick[a.order[r0 + r]];
-                        keep = fabsf(tp - tp_src) < 2.f * eps || fabsf(tp - ts_src) < 2.f * eps;
-                    } else if (r == L) keep = fabsf(rel_null) < 2.f * eps;
-                }
-                const unsigned long long bal = __ballot(keep);
-                if (lane == 0) wcnt[wave] = __popcll(bal);
-                __syncthreads();
-                int off = 0;
-                for (int k = 0; k < wave; ++k) off += wcnt[k];
-                if (keep) {
-                    const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-                    kept[pos] = r;
-                    kbi[pos] = r == L ? a.n_arv : a.order[r0 + r];
-                }
-                if (threadIdx.x == 0) wcnt[4] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                __syncthreads();
-            }
-            const int K = wcnt[4];
-            // ---- A2: queries / scores / values of the kept picks
-            for (int tile = wave; tile * 16 < K; tile += 4) {
-                const int kk = tile * 16 + j;
-                const bool ok = kk < K;
-                const int r = kept[ok ? kk : K - 1];
-                const bool nul = r == L;
-                const int b = nul ? 0 : a.order[r0 + r];
-                const bool nl = (nul ? a.n_arv : b) == E;          // null_link of this pick's edges (:765)
-                const float tp = nul ? 0.f : a.tpick[b];
-                const float rp = nul ? rel_null : tp - tp_src, rs = nul ? rel_null : tp - ts_src;
-                const float ph = nul ? -1.f : a.phase[b];
-                const float f6[6] = {expf(-0.5f * (rp * rp) / e2), (rp > 0.f) - (rp < 0.f) + 0.f, ph,
-                                     expf(-0.5f * (rs * rs) / e2), (rs > 0.f) - (rs < 0.f) + 0.f, ph};
-                const float x0 = q == 0 ? f6[0] : (q == 1 ? f6[1] : (q == 2 ? f6[2] : f6[3]));     // columns 30 + q
-                const float x1 = q == 0 ? f6[4] : (q == 1 ? f6[5] : 0.f);                          // columns 34 + q
-                const f32x4 xp = nul ? tl_zero() : tl_load15(a.arv_p + (long long)b * 15, q);
-                const f32x4 xs = nul ? tl_zero() : tl_load15(a.arv_s + (long long)b * 15, q);
-                f32x4 hq[2], hv[2], hw[2];   // hidden layers: query, values of an edge without / with self_link (null_link = nl in both)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 z = mma_block(tl_bias(im, t, q), TLW(im, GA_Q1(t, 0)), xp);
-                    z = mma_block(z, TLW(im, GA_Q1(t, 1)), xs);
-                    z = MFMA16(TLW(im, GA_Q1(t, 2)).x, x0, z);
-                    z = MFMA16(TLW(im, GA_Q1(t, 2)).y, x1, z);
-                    hq[t] = prelu4(z, act2);
-                    f32x4 v = mma_block(tl_bias(im, 2 + t, q), TLW(im, GA_V1(t, 0)), xp);
-                    v = mma_block(v, TLW(im, GA_V1(t, 1)), xs);
-                    v = MFMA16(TLW(im, GA_V1(t, 2)).x, x0, v);
-                    v = MFMA16(TLW(im, GA_V1(t, 2)).y, x1, v);
-                    const float lnk = (q == 1 && nl) ? 1.f : 0.f;          // k-step [self_link, null_link]: lane q = 0 / 1 supplies it
-                    const f32x4 vb = MFMA16(TLW(im, GA_V1(t, 3)).x, lnk, v);
-                    const f32x4 w = MFMA16(TLW(im, GA_V1(t, 3)).x, q == 0 ? 1.f : lnk, v);
-                    hv[t] = prelu4(vb, act3);
-                    hw[t] = prelu4(w, act3);
-                }
-                float* eo = ent + (long long)(ok ? kk : K - 1) * AR_ENT;
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    f32x4 qh = mma_block(tl_bias(im, 4 + h, q), TLW(im, GA_Q2(h, 0)), hq[0]);
-                    qh = mma_block(qh, TLW(im, GA_Q2(h, 1)), hq[1]);
-                    // context of an edge without / with self_link (variants: bit 0 self_link, bit 1 null_link)
-                    const f32x4 c0 = *(const f32x4*)(cx + (nl ? 96 : 0) + h * 16 + 4 * q), c1 = *(const f32x4*)(cx + (nl ? 144 : 48) + h * 16 + 4 * q);
-                    const f32x4 p0 = qh * c0, p1 = qh * c1;
-                    float s0 = ((p0.x + p0.y) + p0.z) + p0.w, s1 = ((p1.x + p1.y) + p1.z) + p1.w;
-                    s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
-                    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-                    f32x4 vh = mma_block(tl_bias(im, 7 + h, q), TLW(im, GA_V2(h, 0)), hv[0]);
-                    vh = mma_block(vh, TLW(im, GA_V2(h, 1)), hv[1]);
-                    f32x4 wh = mma_block(tl_bias(im, 7 + h, q), TLW(im, GA_V2(h, 0)), hw[0]);
-                    wh = mma_block(wh, TLW(im, GA_V2(h, 1)), hw[1]);
-                    if (ok) {
-                        if (q == 0) { eo[h] = s0 / sq; eo[3 + h] = s1 / sq; }
-                        *(f32x4*)(eo + 8 + h * 16 + 4 * q) = vh;
-                        *(f32x4*)(eo + 56 + h * 16 + 4 * q) = wh;
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- B: fold the chunk into the targets' softmax state
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int r = tb0 + (tt * 4 + wave) * 16 + j;
-                if (tb0 + (tt * 4 + wave) * 16 >= L || K == 0) continue;          // (uniform per wave)
-                // self_link = (e0 == e1 mod e0max), e1 = a + i n_arv (:764): the target pick itself when e0max = n_arv
-                const int tsel = (r < L && E > 0) ? (int)(((long long)a.order[r0 + r] + (long long)i * a.n_arv) % E) : -1;
-                float cm[3] = {mx[tt][0], mx[tt][1], mx[tt][2]};
-                for (int k = 0; k < K; ++k) {
-                    const float* e = ent + k * AR_ENT + (kbi[k] == tsel ? 3 : 0);
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) cm[h] = fmaxf(cm[h], e[h]);
-                }
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    const float sc = mx[tt][h] == -INFINITY ? 0.f : expf(mx[tt][h] - cm[h]);
-                    den[tt][h] *= sc; agg[tt][h] *= sc; mx[tt][h] = cm[h];
-                }
-                for (int k = 0; k < K; ++k) {
-                    const bool self = kbi[k] == tsel;
-                    const float* e = ent + k * AR_ENT;
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        const float ex = expf(e[(self ? 3 : 0) + h] - cm[h]);
-                        den[tt][h] += ex;
-                        agg[tt][h] += *(const f32x4*)(e + (self ? 56 : 8) + h * 16 + 4 * q) * ex;
-                    }
-                }
-            }
-        }
-        // ---- every pick of the block: normalise, mean over heads (:760), proj_2(PReLU4(proj_1(.)))
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int rb = tb0 + (tt * 4 + wave) * 16;
-            if (rb >= L) continue;
-            const int r = rb + j;
-            const bool ok = r < L;
-            const f32x4 z = ((agg[tt][0] / (den[tt][0] + 1e-16f) + agg[tt][1] / (den[tt][1] + 1e-16f)) + agg[tt][2] / (den[tt][2] + 1e-16f)) / 3.f;
-            if (a.save && ok) {
-                float* sv = a.save + ((long long)i * a.n_arv + a.order[r0 + r]) * AT_STAT;
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    *(f32x4*)(sv + 16 * h + 4 * q) = agg[tt][h] / (den[tt][h] + 1e-16f);
-                    if (q == 0) { sv[48 + h] = mx[tt][h]; sv[51 + h] = den[tt][h]; }
-                }
-            }
-            f32x4 pa = prelu4(mma_block(tl_bias(im, 10, q), TLW(im, GA_P1(0)), z), act4);
-            f32x4 pb = prelu4(mma_block(tl_bias(im, 11, q), TLW(im, GA_P1(1)), z), act4);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                float o = w2[m][0].x * pa.x;
-                o += w2[m][0].y * pa.y; o += w2[m][0].z * pa.z; o += w2[m][0].w * pa.w;
-                o += w2[m][1].x * pb.x; o += w2[m][1].y * pb.y; o += w2[m][1].z * pb.z; o += w2[m][1].w * pb.w;
-                o += __shfl_xor(o, 16);
-                o += __shfl_xor(o, 32);
-                if (ok && q == 0) a.out[((long long)i * a.n_arv + a.order[r0 + r]) * 2 + m] = o + im.scal[3 + m];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pick -> Slice/Mask embedding on device: `extract_input_from_data`,
-// /root/reference/Code/process_utils.py:460-642 (use_sign_input = False). Step 1: per-station Gaussian-kernel time
-// series of the P- and S-labelled picks by scatter-max (:499-569; max is order independent -> deterministic atomics).
-// Step 2: every product node reads the series of its station at the theoretical P / S arrival index (:599-629).
-// ------------------------------------------------------------------------------------------------
-struct EmbArgs {
-    const double* pick_t; const int32_t* pick_sta; const int32_t* pick_phase;
-    int n_picks, n_time, n_extra, S;
-    double t0, tref0, dt, sigma;
-    float* emb;            // [2][S][n_time]: P-labelled series, then S-labelled
-    const float* trv;      // [rows, 2] theoretical P / S travel time of every product node
-    long long rows;
-    float* slice; float* mask;
-    unsigned* xs;          // optional: the split rows of k_stage1_h2, written together with Slice / Mask
-    const int32_t* sta_inv; // station processing order of the split rows (caller's station -> internal), or null
-    float* mm;              // with sta_inv: max of the Mask row, in processing order
-};
-
-__global__ void k_embed_scatter(EmbArgs a) {
-    const int per = 2 * a.n_extra + 1;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)a.n_picks * per) return;
-    const int pk = (int)(i / per), off = (int)(i - (long long)pk * per) - a.n_extra;
-    const int sta = a.pick_sta[pk];
-    const int ph = a.pick_phase[pk];
-    if (sta < 0 || sta >= a.S || (ph != 0 && ph != 1)) return;
-    const double t = a.pick_t[pk];
-    const int idx = (int)((t - a.tref0) / a.dt) + off;                 // :514-515, :534
-    if (idx < 0 || idx >= a.n_time) return;                            // :537
-    const double tv = t - (a.tref0 + (double)idx * a.dt);              // abs_time_ref[idx] = arange(...)[idx]
-    const float val = (float)exp(-0.5 * tv * tv / (a.sigma * a.sigma));   // :545, cast at torch.Tensor(vals) :563
-    atomicMax((int*)(a.emb + ((long long)ph * a.S + sta) * a.n_time + idx), __float_as_int(val));   // val >= 0
-}
-
-__global__ void k_embed_edges(EmbArgs a) {   // overflow guard: first / last sample of every series is zero (:565-568)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * a.S) return;
-    a.emb[(long long)i * a.n_time] = 0.f;
-    a.emb[(long long)i * a.n_time + a.n_time - 1] = 0.f;
-}
-
-__global__ void k_embed_gather(EmbArgs a) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.rows) return;
-    const int sta = (int)(p % a.S);
-    const float2 tt = *(const float2*)(a.trv + p * 2);
-    int ip = (int)((((double)tt.x + a.t0) - a.tref0) / a.dt);           // :605 (float64 arithmetic, truncation)
-    int is = (int)((((double)tt.y + a.t0) - a.tref0) / a.dt);
-    ip = min(max(ip, 0), a.n_time - 1);
-    is = min(max(is, 0), a.n_time - 1);
-    const float* ep = a.emb + (long long)sta * a.n_time;
-    const float* es = a.emb + ((long long)a.S + sta) * a.n_time;
-    f32x4 sl;
-    sl.x = fmaxf(ep[ip], es[ip]);                                        // any-phase series = max(P, S)  :569, :612
-    sl.y = fmaxf(ep[is], es[is]);                                        // :613
-    sl.z = ep[ip];                                                       // :614
-    sl.w = es[is];                                                       // :615
-    f32x4 mk;
-    mk.x = fabsf(sl.x) > 0.01f ? 1.f : 0.f; mk.y = fabsf(sl.y) > 0.01f ? 1.f : 0.f;      // :629
-    mk.z = fabsf(sl.z) > 0.01f ? 1.f : 0.f; mk.w = fabsf(sl.w) > 0.01f ? 1.f : 0.f;
-    *(f32x4*)(a.slice + p * 4) = sl;
-    *(f32x4*)(a.mask + p * 4) = mk;
-    if (a.xs != nullptr) {            // same rows as k_split_rows would produce from (sl, mk)
-        const float v[8] = {sl.x, sl.y, sl.z, sl.w, mk.x, mk.y, mk.z, mk.w};
-        const long long px = a.sta_inv != nullptr ? p - sta + a.sta_inv[sta] : p;
-        if (a.sta_inv != nullptr) a.mm[px] = fmaxf(fmaxf(mk.x, mk.y), fmaxf(mk.z, mk.w));
-        store_split_row(a.xs, a.rows, px, v);
-    }
-}
-
-// de-pad rows of a workspace tensor for parity tests
-// use_absolute_pos (config.yaml:92; module.py:1007): Slice gets locs[sta] / (3 scale_rel) and x_grid[src] / (3 scale_rel) appended
-__global__ void k_abs_table(const float* __restrict__ pos, int n, float inv, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 4) return;
-    const int r = i >> 2, k = i & 3;
-    out[i] = k < 3 ? pos[r * 3 + k] * inv : 0.f;
-}
-
-// the two fp16 pieces of every row of an [n][4] scaled-position table, [n][2] x 8 B; `perm` (or null): row i = table row perm[i]
-__global__ void k_abs_pieces(const float* __restrict__ tab, const int32_t* __restrict__ perm, int n, unsigned* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const f32x4 v = *(const f32x4*)(tab + (size_t)(perm ? perm[i] : i) * 4);
-    const unsigned a0 = cvt_pk_f16(v.x, v.y), b0 = cvt_pk_f16(v.z, 0.f);
-    const unsigned a1 = cvt_pk_f16(sub_f16_lo(v.x, a0), sub_f16_hi(v.y, a0)), b1 = cvt_pk_f16(sub_f16_lo(v.z, b0), 0.f);
-    *(u32x4*)(out + (size_t)i * 4) = u32x4{a0, b0, a1, b1};
-}
-
-// DataAggregationEdges (module.py:102-174, forward :1059-1072): every message carries phi(pos_j - pos_i) (3) and phi(|pos_j - pos_i|),
-// phi(d) = sign(d) exp(-d^2 / (2 scale_rel^2)); after mean aggregation that is a STATIC 4-vector per node of a base graph.
-__global__ void k_edge_feat(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int n,
-                            const float* __restrict__ pos, float scale_rel, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int eb = rowptr[i], ee = rowptr[i + 1];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float inv = 1.f / (scale_rel * scale_rel);
-    for (int e = eb; e < ee; ++e) {
-        const int j = col[e];
-        float d[4];
-        d[0] = pos[j * 3] - pos[i * 3]; d[1] = pos[j * 3 + 1] - pos[i * 3 + 1]; d[2] = pos[j * 3 + 2] - pos[i * 3 + 2];
-        d[3] = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float sg = d[k] > 0.f ? 1.f : (d[k] < 0.f ? -1.f : 0.f);
-            acc[k] += sg * expf(-0.5f * d[k] * d[k] * inv);
-        }
-    }
-    const float w = ee > eb ? 1.f / (float)(ee - eb) : 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[i * 4 + k] = acc[k] * w;
-}
-// ... and its Linear a per-node additive term: row n = {W1pos (30x4) m_n, 0, 0, W2pos (15x4) m_n, 0}
-__global__ void k_edge_bias(const float* __restrict__ raw, int off1, int off2, const float* __restrict__ mpos, int n,
-                            float* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * 48) return;
-    const int i = idx / 48, ch = idx - i * 48;
-    const float* m = mpos + i * 4;
-    float v = 0.f;
-    if (ch < 30) { const float* wr = raw + off1 + ch * 4; v = wr[0] * m[0] + wr[1] * m[1] + wr[2] * m[2] + wr[3] * m[3]; }
-    else if (ch >= 32 && ch < 47) { const float* wr = raw + off2 + (ch - 32) * 4; v = wr[0] * m[0] + wr[1] * m[1] + wr[2] * m[2] + wr[3] * m[3]; }
-    out[idx] = v;
-}
-
-// Neighbour means on the implicit product graph for arbitrary row widths (association heads, module.py:389-403):
-//   out_sta[(g,s)] = mean_k x_sta[(g, sta_nbr_k(s))],   out_src[(g,s)] = mean_k x_src[(src_nbr_k(g), s)]
-// rows of CL * VW floats; CL lanes per node, every lane keeps up to 8 row chunks in flight; sums in edge order.
-// With per-edge weights (w_sta / w_src non-null) the same kernel is the ADJOINT of the mean on the reversed graphs:
-//   dx[j] = sum_{i : j in N(i)} g[i] / deg(i)   (genie_nbr_mean_bwd; edge lists = out-edges of j, weights 1 / in-degree of i)
-template <int CL, int VW>       // CL lanes per row, VW floats per lane: rows of CL * VW floats (16 / 32 padded, or 30 unpadded)
-__global__ __launch_bounds__(256) void k_nbr_mean(int S, int G, const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
-                                                  const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
-                                                  const float* __restrict__ x_sta, const float* __restrict__ x_src,
-                                                  float* __restrict__ out_sta, float* __restrict__ out_src,
-                                                  const float* __restrict__ w_sta = nullptr, const float* __restrict__ w_src = nullptr) {
-    typedef float V __attribute__((ext_vector_type(VW)));
-    constexpr int NPB_ = 256 / CL, RF = CL * VW;
-    if ((int)threadIdx.x >= NPB_ * CL) return;
-    const int cl = threadIdx.x % CL;
-    const long long P = (long long)S * G;
-    for (long long p = (long long)blockIdx.x * NPB_ + threadIdx.x / CL; p < P; p += (long long)gridDim.x * NPB_) {
-        const int g = (int)(p / S), s = (int)(p - (long long)g * S);
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const float* x = which == 0 ? x_sta : x_src;
-            float* out = which == 0 ? out_sta : out_src;
-            if (x == nullptr) continue;
-            const int32_t* col = which == 0 ? sta_col : src_col;
-            const float* ew = which == 0 ? w_sta : w_src;
-            const int eb = which == 0 ? sta_rowptr[s] : src_rowptr[g], ee = which == 0 ? sta_rowptr[s + 1] : src_rowptr[g + 1];
-            V acc = 0.f;
-            for (int e0 = eb; e0 < ee; e0 += 8) {
-                V v[8];
-                float wk[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = min(e0 + k, ee - 1);
-                    const int j = col[e];
-                    const long long row = which == 0 ? (long long)g * S + j : (long long)j * S + s;
-                    v[k] = *(const V*)(x + row * RF + VW * cl);
-                    wk[k] = ew ? ew[e] : 1.f;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (e0 + k < ee) acc += v[k] * wk[k];
-            }
-            const float w = ew ? 1.f : (ee > eb ? 1.f / (float)(ee - eb) : 0.f);
-            *(V*)(out + p * RF + VW * cl) = acc * w;
-        }
-    }
-}
-
-// PReLU backward for the training path (one slope per call): dx = dy * (x >= 0 ? 1 : a), da = sum_{x < 0} dy * x. PyTorch's
-// own backward materialises a full-size slope gradient and reduces it in a second pass (0.9 ms per [2M, 30] tensor); this
-// is one pass plus a fixed-order two-level sum (deterministic).
-constexpr int PRELU_BLOCKS = 2048;
-__global__ __launch_bounds__(256) void k_prelu_bwd(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ slope,
-                                                   long long n, float* __restrict__ dx, float* __restrict__ partial) {
-    const float a = slope[0];
-    float acc = 0.f;
-    const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const f32x4 xv = ((const f32x4*)x)[i], gv = ((const f32x4*)dy)[i];
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool neg = xv[k] < 0.f;
-            o[k] = neg ? gv[k] * a : gv[k];
-            acc += neg ? gv[k] * xv[k] : 0.f;
-        }
-        ((f32x4*)dx)[i] = o;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // tail elements
-        const long long i = (n4 << 2) + threadIdx.x;
-        const bool neg = x[i] < 0.f;
-        dx[i] = neg ? dy[i] * a : dy[i];
-        acc += neg ? dy[i] * x[i] : 0.f;
-    }
-    __shared__ float red[256];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void k_prelu_bwd_sum(const float* __restrict__ partial, int nb, float* __restrict__ da) {
-    __shared__ float red[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) da[0] = red[0];
-}
-
-// Weight and bias gradients of a per-node Linear over N rows (training path): dW[m][k] = sum_n dy[n][m] x[n][k],
-// db[m] = sum_n dy[n][m], M <= 32, K <= 64 KC. The library GEMM for this shape (a [M, N] x [N, K] product with N = 2M rows) runs
-// at 1-3 ms plus a separate 0.25 ms bias reduction; this reads x and dy once. Wave w owns outputs m in [8w, 8w+8), lane l the
-// columns k = l + 64 c; dy rows are staged through LDS and read back as wave-uniform broadcasts. Partials per workgroup are
-// summed by k_linear_bwd_sum in a fixed order.
-constexpr int LBW_ROWS = 32, LBW_BLOCKS = 1024;
-template <int KC>
-__global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ dy, long long N, int K, int M,
-                                                      int ldy, float* __restrict__ partial) {
-    __shared__ float sdy[LBW_ROWS][32];
-    __shared__ float sb[8][32];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sm = threadIdx.x & 31, sr = threadIdx.x >> 5;          // staging role: column sm of rows sr + 8 q
-    const int smc = min(sm, M - 1);
-    int kc[KC];                                                       // lanes beyond K re-read column K-1; their sums are dropped
-#pragma unroll
-    for (int c = 0; c < KC; ++c) kc[c] = min(lane + 64 * c, K - 1);
-    float acc[KC][8];
-    float accb = 0.f;
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
-    const long long ntile = (N + LBW_ROWS - 1) / LBW_ROWS;
-    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const long long n0 = t * LBW_ROWS;
-        const int nr = (int)min((long long)LBW_ROWS, N - n0);        // rows beyond N: dy staged as 0, x re-reads the last row
-        const float* __restrict__ xt = x + n0 * K;
-        const float* __restrict__ dt = dy + n0 * ldy;            // M <= 32 columns of rows that are ldy floats apart
-        float st[LBW_ROWS / 8];
-#pragma unroll
-        for (int q = 0; q < LBW_ROWS / 8; ++q) {
-            const int r = sr + 8 * q;
-            const float v = dt[min(r, nr - 1) * ldy + smc];
-            st[q] = (sm < M && r < nr) ? v : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < LBW_ROWS / 8; ++q) {
-            sdy[sr + 8 * q][sm] = st[q];
-            accb += st[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rb = 0; rb < LBW_ROWS; rb += 8) {
-            float xv[8][KC];
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-#pragma unroll
-                for (int c = 0; c < KC; ++c) xv[r][c] = xt[min(rb + r, nr - 1) * K + kc[c]];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const f32x4 d0 = *(const f32x4*)&sdy[rb + r][8 * w], d1 = *(const f32x4*)&sdy[rb + r][8 * w + 4];
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[c][j] += d0[j] * xv[r][c];
-                        acc[c][4 + j] += d1[j] * xv[r][c];
-                    }
-                }
-            }
-        }
-    }
-    float* out = partial + (size_t)blockIdx.x * (32 * 64 * KC + 32);
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[(8 * w + j) * (64 * KC) + 64 * c + lane] = acc[c][j];
-    sb[sr][sm] = accb;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float v = sb[0][sm];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) v += sb[q][sm];
-        out[32 * 64 * KC + sm] = v;
-    }
-}
-__global__ __launch_bounds__(256) void k_linear_bwd_sum(const float* __restrict__ partial, int nb, int KC, int K, int M,
-                                                        float* __restrict__ dW, float* __restrict__ db) {
-    // 32 outputs x 8 slices of the workgroup partials per block; slices combined in a fixed order
-    __shared__ float red[8][32];
-    const int per = 32 * 64 * KC + 32;
-    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < per) {
-        const int per_sl = (nb + 7) / 8, b0 = sl * per_sl, b1 = min(nb, b0 + per_sl);
-        int b = b0;
-        for (; b + 4 <= b1; b += 4) {
-            a0 += partial[(size_t)b * per + e];
-            a1 += partial[(size_t)(b + 1) * per + e];
-            a2 += partial[(size_t)(b + 2) * per + e];
-            a3 += partial[(size_t)(b + 3) * per + e];
-        }
-        for (; b < b1; ++b) a0 += partial[(size_t)b * per + e];
-    }
-    red[sl][el] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl != 0 || e >= per) return;
-    float v = red[0][el];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) v += red[q][el];
-    if (e < 32 * 64 * KC) {
-        const int m = e / (64 * KC), k = e % (64 * KC);
-        if (m < M && k < K) dW[m * K + k] = v;
-    } else if (db && e - 32 * 64 * KC < M) db[e - 32 * 64 * KC] = v;
-}
-
-// XCC (XCD) id and CU id of the CU a workgroup runs on (genie_where_am_i): workgroup b of a launch lands on XCD b % 8
-__global__ void k_where_am_i(int* __restrict__ out) {
-    int xcc, hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));       // HW_REG_XCC_ID
-    asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hwid));      // HW_REG_HW_ID
-    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hwid; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Exact k-nearest-neighbour search on the device: the `knn(x_context / 1000, x_query / 1000, k)` calls of the
-// reference -- SpatialAttention's query edges (module.py:282; a NEW 112 000-point query set per candidate in the refine pass,
-// process_continuous_days.py:926-980) and the base graphs of the product graph (`knn(x/1000, x/1000, k + 1)` +
-// `remove_self_loops`, process_utils.py:718-719). Brute force in fp64 on the fp32 coordinates themselves (the
-// common 1 / 1000 scale does not change the order; coordinate differences of fp32 values are exact in fp64) (3-D, n_context
-// is 10^4..10^5: 10^9 pair distances = a millisecond): one wave per query, lane l scans candidates l, l + 64, ... keeping its K
-// best in registers (sorted, ties by smaller index), then K rounds of a wave-wide lexicographic (distance, index) minimum pop
-// the global K best in order. exclude_self: skip candidate == query id (query set = context set).
-// ------------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ xc, int nc, const float* __restrict__ xq, int nq, int k,
-                                             int exclude_self, int32_t* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return;
-    const double q0 = (double)xq[qi * 3 + 0], q1 = (double)xq[qi * 3 + 1], q2 = (double)xq[qi * 3 + 2];
-    double bd[K];
-    int bi[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
-    for (int c = lane; c < nc; c += 64) {
-        if (exclude_self && c == qi) continue;
-        const double d0 = q0 - (double)xc[c * 3 + 0], d1 = q1 - (double)xc[c * 3 + 1], d2 = q2 - (double)xc[c * 3 + 2];   // exact
-        double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-        int id = c;
-        if (d < bd[K - 1]) {          // candidates arrive in increasing index order: a tie never displaces an earlier entry
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-                if (d < bd[t] || (d == bd[t] && id < bi[t])) {       // lexicographic (distance, index): a displaced entry that ties with
-                                                                      // the next slot goes in front of it (it has the smaller index)
-                    const double td = bd[t]; const int ti = bi[t];
-                    bd[t] = d; bi[t] = id; d = td; id = ti;
-                }
-            }
-        }
-    }
-    for (int r = 0; r < k; ++r) {
-        double md = bd[0];
-        int mi = bi[0];
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const double od = __shfl_xor(md, s);
-            const int oi = __shfl_xor(mi, s);
-            if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
-        }
-        if (bi[0] == mi && bd[0] == md) {        // the owner pops its head (indices are unique across lanes)
-#pragma unroll
-            for (int t = 0; t + 1 < K; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
-            bd[K - 1] = __builtin_inf(); bi[K - 1] = 0x7fffffff;
-        }
-        if (lane == 0) out[(long long)qi * k + r] = mi == 0x7fffffff ? -1 : mi;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Downstream reduction of the apply loop on the device: the stacked query output Out_2 [rows = queries,
-// cols = time steps] never leaves the GPU whole. MODE 0: entries above a threshold, `np.where(Out_2 > 0.01)`
-// (process_continuous_days.py:812-813). MODE 1: the local maxima of every row that reach `height`, i.e. the first two steps
-// of `scipy.signal.find_peaks(Out[i, :], height = thresh, ...)` (:846; scipy's `_local_maxima_1d`: a sample or the midpoint
-// of a flat run that is strictly higher than both neighbours, never the first or last sample; then `x >= height`).
-// One workgroup per row, chunks of 256 columns, selected entries written in column order at `offsets[row]` + rank
-// (two passes: COUNT fills counts[row], the caller scans them; the second pass fills) -> row-major order like np.where.
-// ------------------------------------------------------------------------------------------------
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(256) void k_row_select(const float* __restrict__ x, long long cols, float thr, int32_t* __restrict__ counts,
-                                                    const long long* __restrict__ offsets, int32_t* __restrict__ out_row,
-                                                    int32_t* __restrict__ out_col, float* __restrict__ out_val) {
-    __shared__ int wsum[4];
-    const long long row = blockIdx.x;
-    const float* xr = x + row * cols;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long base = COUNT ? 0 : offsets[row];
-    int total = 0;
-    for (long long c0 = 0; c0 < cols; c0 += 256) {
-        const long long i = c0 + threadIdx.x;
-        bool sel = false;
-        long long col = i;
-        float v = 0.f;
-        if (i < cols) {
-            v = xr[i];
-            if (MODE == 0) {
-                sel = v > thr;
-            } else if (i >= 1 && i + 1 < cols && v >= thr && xr[i - 1] < v) {      // rising edge into a candidate (flat) top
-                long long e = i + 1;
-                while (e < cols - 1 && xr[e] == v) ++e;
-                if (xr[e] < v) { sel = true; col = (i + e - 1) / 2; }
-            }
-        }
-        const unsigned long long b = __ballot(sel);
-        const int rank = __popcll(b & ((1ull << lane) - 1ull)), wtot = __popcll(b);
-        if (lane == 0) wsum[wave] = wtot;
-        __syncthreads();
-        int before = 0, all = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { if (k < wave) before += wsum[k]; all += wsum[k]; }
-        if (!COUNT && sel) {
-            const long long o = base + total + before + rank;
-            out_row[o] = (int32_t)row; out_col[o] = (int32_t)col; out_val[o] = v;
-        }
-        total += all;
-        __syncthreads();
-    }
-    if (COUNT && threadIdx.x == 0) counts[row] = total;
-}
-
-// Product-level CSRs of the IRREGULAR product graph of `use_subgraph` (process_utils.py:744-849) on the device. The product
-// nodes are the (station, source) pairs sorted by (source, station): node n = (pair_sta[n], pair_src[n]), source node g owns
-// nodes [seg[g], seg[g + 1]). In-edges of node n (the reference's `subgraph(...)` calls, :824-839):
-//   station graph: m -> n for every base edge j -> pair_sta[n] whose pair (j, pair_src[n]) exists, in base edge order;
-//   source graph:  m -> n for every base edge g' -> pair_src[n] whose pair (pair_sta[n], g') exists, in base edge order.
-// One thread per product node; a pair is looked up by binary search in the station list of its source node. FILL = false
-// counts the in-edges, FILL = true writes them behind the node's row pointer.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_subgraph_csr(const int32_t* __restrict__ pair_sta, const int32_t* __restrict__ pair_src,
-                                                     long long N, const int32_t* __restrict__ seg,
-                                                     const int32_t* __restrict__ sta_rowptr, const int32_t* __restrict__ sta_col,
-                                                     const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ src_col,
-                                                     int32_t* __restrict__ cnt_sta, int32_t* __restrict__ cnt_src,
-                                                     const int32_t* __restrict__ p_sta_rowptr, const int32_t* __restrict__ p_src_rowptr,
-                                                     int32_t* __restrict__ p_sta_col, int32_t* __restrict__ p_src_col) {
-    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int s = pair_sta[n], g = pair_src[n];
-    auto find = [&](int sta, int src) -> int {          // product node of the pair (sta, src), or -1
-        int lo = seg[src], hi = seg[src + 1];
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (pair_sta[mid] < sta) lo = mid + 1; else hi = mid;
-        }
-        return (lo < seg[src + 1] && pair_sta[lo] == sta) ? lo : -1;
-    };
-    int c1 = 0, c2 = 0;
-    int32_t* o1 = FILL ? p_sta_col + p_sta_rowptr[n] : nullptr;
-    int32_t* o2 = FILL ? p_src_col + p_src_rowptr[n] : nullptr;
-    for (int e = sta_rowptr[s]; e < sta_rowptr[s + 1]; ++e) {
-        const int m = find(sta_col[e], g);
-        if (m >= 0) { if (FILL) o1[c1] = m; ++c1; }
-    }
-    for (int e = src_rowptr[g]; e < src_rowptr[g + 1]; ++e) {
-        const int m = find(s, src_col[e]);
-        if (m >= 0) { if (FILL) o2[c2] = m; ++c2; }
-    }
-    if (!FILL) { cnt_sta[n] = c1; cnt_src[n] = c2; }
-}
-
-__global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst,
-                         const int32_t* __restrict__ sta_user, int S) {
-    // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one); rows in station processing order -> caller's order
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * ncol) return;
-    const long long r = idx / ncol;
-    const int cc = (int)(idx % ncol);
-    const int off = ncol == 15 ? cc : (cc / 15) * 16 + cc % 15;   // c = [c1 15,0 | c2 15,0]
-    long long ru = r;
-    if (sta_user != nullptr) {
-        const long long g = r / S;
-        ru = g * S + sta_user[(int)(r - g * S)];
-    }
-    dst[ru * ncol + cc] = src[r * pitch + off];
-}
-// rows [G][S][width] from station processing order to the caller's order (debug outputs) or, with `inv`, the other way (tables)
-__global__ void k_permute_sta_rows(const float* __restrict__ src, long long rows, int width, const int32_t* __restrict__ map, int S,
-                                   float* __restrict__ dst) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * width) return;
-    const long long r = idx / width;
-    const int cc = (int)(idx - r * width);
-    const long long g = r / S;
-    dst[(g * S + map[(int)(r - g * S)]) * width + cc] = src[idx];
-}
-
+#include "stage_kernels.hpp"
+#include "assoc_kernels.hpp"
+#include "train_front_kernels.hpp"
+#include "tail_kernels.hpp"
+#include "aux_kernels.hpp"
 #include "train_tail_kernels.hpp"
 #include "train_assoc_kernels.hpp"
 #include "train_arrival_kernels.hpp"

@@ -1,0 +1,1203 @@
+// Part of genie_hip.hip (one translation unit, included inside its anonymous namespace): the P-sized stage kernels of DataAggregation + Bipartite_ReadIn: generic fp32-MFMA stage 1 / stage 2 (any graph), the f16x2 stage 1 (k_stage1_h2) with its split / pack kernels, the straight-line stage 2 (k_stage2_ord).
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: everything of DataAggregation that does not need the SECOND pair of neighbour means
+//   h0 = PReLU(init_trns [X || M])                                        module.py:87-88 (own node + every neighbour)
+//   h1 = PReLU1([l1_t1_2 [h0 || mean_sta PReLU11(h0) || M] || l1_t2_2 [h0 || mean_src PReLU12(h0) || M]])   :90-92
+//   u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1)                      :94-95
+//   wu = l2_t1_2[:, 60:90] u,  wv = l2_t2_2[:, 60:90] v                  (operands of the second pair of means)
+//   c  = [l2_t1_2[:, 0:60] h1 + l2_t1_2[:, 90:94] M + b || l2_t2_2[...]]  (node-local part of :94-95)
+// Reads 32 B per product node (+ its neighbours' 32-B rows from L2), writes 256 B; h0 / h1 / u / v stay in VGPRs.
+// ------------------------------------------------------------------------------------------------
+// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
+// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
+// N independent accumulators x one 16-channel input block, k-step OUTER and accumulator INNER: consecutive MFMAs never
+// target the same accumulator, so the 40-cycle dependent-issue latency of v_mfma_f32_16x16x4_f32 (32-cycle issue) is
+// always covered (hipcc otherwise keeps the 4 dependent k-steps of one accumulator back to back).
+template <int N>
+__device__ __forceinline__ void mma_blocks(f32x4 (&acc)[N], const f32x4 (&w)[N], const f32x4 x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = MFMA16(w[k][r], x[r], acc[k]);
+    }
+}
+
+// dense tail of stage 1 for one tile: layer 1 from (x0,x1 = own h0; n1*, n2* = neighbour means), then u / v, the
+// projected operands wu / wv and the node-local layer-2 terms c; stores c, wu, wv (and h0 / h1 for parity runs)
+__device__ __forceinline__ void stage1_dense(const DaArgs& a, const f32x4* lw, const float* lbias, int lane, int q,
+                                             bool valid, long long p, int g, int sc, float mq, f32x4 x0, f32x4 x1, f32x4 n1a,
+                                             f32x4 n1b, f32x4 n2a, f32x4 n2b, float a1, float a21, float a22) {
+    if (a.dbg_h0 != nullptr && valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.dbg_h0[p * 30 + 4 * q + r] = x0[r];
+            if (16 + 4 * q + r < 30) a.dbg_h0[p * 30 + 16 + 4 * q + r] = x1[r];
+        }
+    }
+    // layer 1: tr1 = l1_t1_2 [h0 || n1 || M], tr2 = l1_t2_2 [h0 || n2 || M]; acc[k]: k = (half, tile)
+    f32x4 acc[4], w4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = *(const f32x4*)(lbias + (2 + k) * 16 + 4 * q);
+    if (a.eb_sta != nullptr) {   // DataAggregationEdges: the mean edge feature of a node is static, its Linear a per-node bias
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc[t] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 16 * t + 4 * q);
+            acc[2 + t] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 16 * t + 4 * q);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 0) * 64 + lane];
+    mma_blocks<4>(acc, w4, x0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = lw[G1_L1(k >> 1, k & 1, 1) * 64 + lane];
+    mma_blocks<4>(acc, w4, x1);
+    {   // the neighbour-mean blocks feed only their own half: two accumulators per operand, interleave the two operands
+        f32x4 wa[2], wb[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 na = b == 0 ? n1a : n1b, nb = b == 0 ? n2a : n2b;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wa[t] = lw[G1_L1(0, t, 2 + b) * 64 + lane];
+                wb[t] = lw[G1_L1(1, t, 2 + b) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0] = MFMA16(wa[0][r], na[r], acc[0]);
+                acc[2] = MFMA16(wb[0][r], nb[r], acc[2]);
+                acc[1] = MFMA16(wa[1][r], na[r], acc[1]);
+                acc[3] = MFMA16(wb[1][r], nb[r], acc[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = MFMA16(lw[G1_L1(k >> 1, k & 1, 4) * 64 + lane].x, mq, acc[k]);
+    if (a.save != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_T + k) * a.Pn + p) * 16 + 4 * q) = acc[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = prelu4u(acc[k], a1);                      // h1 block k = (half, tile)
+    if (a.dbg_h1 != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * (k & 1) + 4 * q + r < 30) a.dbg_h1[p * 60 + 30 * (k >> 1) + 16 * (k & 1) + 4 * q + r] = acc[k][r];
+    }
+    // u = PReLU21(l2_t1_1 h1), v = PReLU22(l2_t2_1 h1); c_w = node-local layer-2 terms: 6 independent accumulators
+    f32x4 o6[6], w6[6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (6 + k) * 16 + 4 * q);
+    o6[4] = *(const f32x4*)(lbias + 10 * 16 + 4 * q);
+    o6[5] = *(const f32x4*)(lbias + 11 * 16 + 4 * q);
+    if (a.eb_sta != nullptr) {
+        o6[4] += *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 4 * q);
+        o6[5] += *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 4 * q);
+    }
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w6[k] = lw[G1_UV(k >> 1, k & 1, hb) * 64 + lane];
+        w6[4] = lw[G1_C(0, hb) * 64 + lane];
+        w6[5] = lw[G1_C(1, hb) * 64 + lane];
+        mma_blocks<6>(o6, w6, acc[hb]);
+    }
+    o6[4] = MFMA16(lw[G1_C(0, 4) * 64 + lane].x, mq, o6[4]);
+    o6[5] = MFMA16(lw[G1_C(1, 4) * 64 + lane].x, mq, o6[5]);
+    if (a.save != nullptr && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)(a.save + ((size_t)(SV_UP + k) * a.Pn + p) * 16 + 4 * q) = o6[k];
+    }
+    o6[0] = prelu4u(o6[0], a21); o6[1] = prelu4u(o6[1], a21);
+    o6[2] = prelu4u(o6[2], a22); o6[3] = prelu4u(o6[3], a22);
+    // wu = l2_t1_2[:, 60:90] u, wv = l2_t2_2[:, 60:90] v: two accumulators, interleaved
+    f32x4 wuv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        w2[0] = lw[G1_W(0, b) * 64 + lane];
+        w2[1] = lw[G1_W(1, b) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wuv[0] = MFMA16(w2[0][r], o6[b][r], wuv[0]);
+            wuv[1] = MFMA16(w2[1][r], o6[2 + b][r], wuv[1]);
+        }
+    }
+    if (valid && !ABL(a, 3)) {
+        *(f32x4*)(a.c + p * ROWC + 4 * q) = o6[4];
+        *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = o6[5];
+        *(f32x4*)(a.wu + p * ROWW + 4 * q) = wuv[0];
+        *(f32x4*)(a.wv + p * ROWW + 4 * q) = wuv[1];
+    }
+}
+
+// generic stage 1: any CSR graphs (ragged degrees, empty neighbourhoods)
+__global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
+    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
+    const float* lscal = lbias + G1_BIAS * 16;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
+#endif
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const long long p = (long long)g * S + sc;
+        const float xs = a.slice[p * 4 + q];
+        const float mq = a.mask[p * 4 + q];
+        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
+        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        // own hidden state
+        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
+        x0 = MFMA16(wi0.y, mq, x0);
+        x1 = MFMA16(wi1.y, mq, x1);
+        float lq = 0.f, gq = 0.f;                 // use_absolute_pos: this node's station / source position channel q
+        if (a.abs_sta != nullptr) {
+            lq = a.abs_sta[sc * 4 + q];
+            gq = a.abs_src[g * 4 + q];
+            x0 = MFMA16(wi0.z, lq, x0); x1 = MFMA16(wi1.z, lq, x1);
+            x0 = MFMA16(wi0.w, gq, x0); x1 = MFMA16(wi1.w, gq, x1);
+        }
+        if (a.save != nullptr && valid) {
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 0) * a.Pn + p) * 16 + 4 * q) = x0;
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 1) * a.Pn + p) * 16 + 4 * q) = x1;
+        }
+        x0 = prelu4u(x0, a0);
+        x1 = prelu4u(x1, a0);
+        // station-neighbour mean of PReLU11(h0): rows of the same source node
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
+            if (!ABL(a, 0)) {
+                if (s11 <= 1.f)
+                    gather_recompute<false, true>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
+                                                  bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
+                else
+                    gather_recompute<false, false>(a.slice, a.mask, (long long)g * S, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0,
+                                                   bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        // source-neighbour mean of PReLU12(h0): same station, neighbouring source nodes (wave-uniform list)
+        f32x4 n2a = {0.f, 0.f, 0.f, 0.f}, n2b = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
+            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
+            if (!ABL(a, 1)) {
+                if (s12 <= 1.f)
+                    gather_recompute<true, true>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
+                                                 bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
+                else
+                    gather_recompute<true, false>(a.slice, a.mask, (long long)sc, (long long)S, q, a.src_col, eb, ee, wi0, wi1,
+                                                  bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
+            }
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        stage1_dense(a, lw, lbias, lane, q, valid, p, g, sc, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+    }
+}
+
+// Stage 1 on an IRREGULAR product graph (`use_subgraph: True`, process_utils.py:744-849): the product nodes are an arbitrary
+// list of (station, source) pairs and both edge sets are CSR lists over PRODUCT-node ids (a.sta_rowptr/col, a.src_rowptr/col
+// are indexed by product node here). A tile is 16 consecutive product nodes; same arithmetic as k_stage1.
+__global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
+    constexpr int NF4 = (G1_GROUPS * 256 + G1_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G1_GROUPS * 64);
+    const float* lscal = lbias + G1_BIAS * 16;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const long long ntiles = (a.Pn + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
+         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const long long pr = tile * 16 + j;
+        const bool valid = pr < a.Pn;
+        const long long p = valid ? pr : a.Pn - 1;
+        const float xs = a.slice[p * 4 + q];
+        const float mq = a.mask[p * 4 + q];
+        const f32x4 wi0 = lw[G1_INIT(0) * 64 + lane], wi1 = lw[G1_INIT(1) * 64 + lane];
+        const f32x4 bi0 = *(const f32x4*)(lbias + 0 * 16 + 4 * q), bi1 = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+        f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
+        x0 = MFMA16(wi0.y, mq, x0);
+        x1 = MFMA16(wi1.y, mq, x1);
+        x0 = prelu4u(x0, a0);
+        x1 = prelu4u(x1, a0);
+        f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
+        {
+            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
+            if (s11 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n1a *= inv; n1b *= inv;
+        }
+        {
+            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
+            if (s12 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
+            const float inv = 1.f / (float)max(ee - eb, 1);
+            n2a *= inv; n2b *= inv;
+        }
+        stage1_dense(a, lw, lbias, lane, q, valid, p, 0, 0, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+    }
+}
+
+// the KS station-neighbour ids of one station as wide loads: a dword load whose lanes hit 16 different 32-B segments costs the
+// texture path about as much as two and a half full 1-KB row loads (tools/: skeleton ablations of k_stage2_fast), and a tile
+// issued KS of them
+template <int KS>
+__device__ __forceinline__ void load_sta_ids(const int32_t* __restrict__ sta_col, int sc, int (&sta)[KS]) {
+    static_assert(KS % 4 == 0, "station-neighbour rows are read as 16-byte chunks");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int c = 0; c < KS / 4; ++c) {
+        const i32x4 v = *(const i32x4*)(sta_col + sc * KS + 4 * c);
+        sta[4 * c] = v.x; sta[4 * c + 1] = v.y; sta[4 * c + 2] = v.z; sta[4 * c + 3] = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1 on the 16-bit matrix pipe with fp32-class operands ("f16x2").
+//
+// Measured on MI355X (tools/mfma_peak*.hip, tools/valu_rate.hip, tools/mfma_overlap.hip): v_mfma_f32_16x16x4_f32 runs at the
+// fp32 VECTOR rate and does not overlap with VALU work, so the fp32-MFMA kernel above is bound by the sum of both; a 16-bit
+// 32x32x16 MFMA does 16x the FLOPs in the same 32 cycles (and hides ~10 of them behind vector work).
+//
+//  * v_mfma_f32_32x32x16_f16: D[ch, node] for 32 channels x 32 nodes. A wave owns TWO 16-station tiles (lanes
+//    0-15/32-47 and 16-31/48-63). Lane (j = lane&31, h = lane>>5) holds D channels 8*(r>>2) + 4h + (r&3), r = 0..15,
+//    of node j; K-step ks of the next layer consumes registers 8ks..8ks+7 of both lanes of a node (16 channels), so an
+//    accumulator block becomes B operands without any cross-lane movement. All our channel groups are 30 wide: one
+//    32-block each; the two padding slots of a block (channels 30, 31: lane h = 1, registers 14, 15) carry the Mask
+//    inputs of `cat(h, n, Mask)`.
+//  * raw inputs arrive as 32-B rows [x0 | x1] of 8 fp16 each (x = Slice || Mask), written by k_split_rows, stored PLANAR
+//    (piece q of row p at q * rows * 16 + p * 16: a half-wave reads one piece of 32 consecutive rows as 512 contiguous bytes).
+//    A neighbour's hidden state is 2 MFMAs (K = 16 = the two 8-wide pieces).
+//  * mean_k PReLU_s(z_k) = sum_k (al z_k + be |z_k|): two fused multiply-adds per neighbour value into one accumulator.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XROW = 32;                 // bytes per split input row: two 16-B pieces
+constexpr int XPC = 16;                  // bytes per piece
+constexpr int H2_THREADS = 512;
+
+// ---- f16x2: x ~ x0 + x1 with x0 = rn16(x), x1 = rn16(x - x0): 11 + 1 + 11 significant bits, i.e. within one fp32 ulp of x
+// (exact when the residual needs <= 11 bits) while x1 stays a normal fp16 number (|x| >= 2^-2), within 2^-25 absolute below
+// that (fp16 subnormals: the MFMA keeps them, tools/h2_probe.hip). Overflow needs |x| > 65504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define MFMA32H(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {            // round to nearest even, both halves
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned p) {              // x - float(p.lo), one exact fp32 operation
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned p) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+constexpr unsigned H2_SIXTEENTH = 0x2c002c00u;        // (1/16, 1/16) as an fp16 pair
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned p, unsigned c) {
+    unsigned r;
+    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(c));
+    return r;
+}
+// one fp16 piece (low 16 bits) of v; codes as in build_h2_table
+__device__ __forceinline__ unsigned f16_piece(float v, int piece) {
+    if (piece >= 2) { v *= 16.f; piece -= 2; }
+    const unsigned p0 = cvt_pk_f16(v, 0.f);
+    if (piece == 0) return p0 & 0xffffu;
+    const float r = sub_f16_lo(v, p0);
+    return cvt_pk_f16(r, 0.f) & 0xffffu;
+}
+__device__ __forceinline__ unsigned f16_piece_w(float v, int piece) {            // weight pieces: code 1 = rn16(16 (W - W0))
+    if (piece != 1) return f16_piece(v, piece);
+    const unsigned p0 = cvt_pk_f16(v, 0.f);
+    return cvt_pk_f16(16.f * sub_f16_lo(v, p0), 0.f) & 0xffffu;
+}
+// the split rows of one [Slice || Mask] row: two fp16 planes
+__device__ __forceinline__ void store_split_row(unsigned* __restrict__ out, long long rows, long long p, const float (&v)[8]) {
+    u32x4 o0, o1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        o0[d] = cvt_pk_f16(v[2 * d], v[2 * d + 1]);
+        o1[d] = cvt_pk_f16(sub_f16_lo(v[2 * d], o0[d]), sub_f16_hi(v[2 * d + 1], o0[d]));
+    }
+    *(u32x4*)(out + p * 4) = o0;
+    *(u32x4*)(out + (rows + p) * 4) = o1;
+}
+
+__global__ void k_pack_h2(const float* __restrict__ raw, const int32_t* __restrict__ tbl, float* __restrict__ out, int nfrag,
+                          int ntail) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nfrag * 64) {
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned u[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int32_t ent = tbl[idx * 8 + 2 * d + k];
+                u[k] = ent < 0 ? 0u : f16_piece_w(raw[ent & 0x0fffffff], (ent >> 28) & 3);
+            }
+            o[d] = u[0] | (u[1] << 16);
+        }
+        ((u32x4*)out)[idx] = o;
+    } else if (idx < nfrag * 64 + ntail) {     // fp32 tail: bias blocks and PReLU slopes
+        const int k = idx - nfrag * 64;
+        const int32_t ent = tbl[nfrag * 512 + k];
+        out[nfrag * 256 + k] = ent < 0 ? 0.f : raw[ent];
+    }
+}
+
+// [Slice || Mask] rows (8 fp32) -> 32-B rows of two fp16x8 pieces
+// sta_user (internal station -> caller's station, or null): the rows of a source node are written in the station processing order
+__global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
+                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    long long pu = p;
+    if (sta_user != nullptr) {
+        const long long g = p / S;
+        pu = g * S + sta_user[(int)(p - g * S)];
+    }
+    const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
+    if (sta_user != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));      // the message mask of stage 2 (module.py:226)
+    const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+    store_split_row(out, rows, p, v);
+}
+
+// Same with a station processing order, one workgroup per source node: the node's S rows are read in the caller's order
+// (coalesced), staged in LDS, and written in processing order (coalesced); S <= SPLIT_G_MAXS rows fit the 64-KB staging buffer.
+constexpr int SPLIT_G_MAXS = 2048;
+__global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
+                                                      unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
+                                                      float* __restrict__ mm, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
+    const long long base = (long long)blockIdx.x * S;
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        *(f32x4*)(stg + r * 8) = *(const f32x4*)(slice + (base + r) * 4);
+        *(f32x4*)(stg + r * 8 + 4) = *(const f32x4*)(mask + (base + r) * 4);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        const int u = sta_user[r];
+        const f32x4 s = *(const f32x4*)(stg + u * 8), m = *(const f32x4*)(stg + u * 8 + 4);
+        mm[base + r] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+        const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+        store_split_row(out, rows, base + r, v);
+    }
+}
+
+// exact PReLU in two VALU ops for any slope: max(x, s*x) when s <= 1, min(x, s*x) otherwise, as med3(x, s*x, +-inf)
+__device__ __forceinline__ f32x16 prelu16(f32x16 x, float s, float sel) {
+    f32x16 y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = __builtin_amdgcn_fmed3f(x[r], x[r] * s, sel);
+    return y;
+}
+__device__ __forceinline__ f32x16 bias16(const float* lbias, int blk, int h) {
+    f32x16 y;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x4 t = *(const f32x4*)(lbias + blk * 32 + 8 * b + 4 * h);
+        y[4 * b] = t.x; y[4 * b + 1] = t.y; y[4 * b + 2] = t.z; y[4 * b + 3] = t.w;
+    }
+    return y;
+}
+// training forward: a 32-channel accumulator (register r = channel 8 (r >> 2) + 4 h + (r & 3)) as two 16-float blocks of the
+// block-planar save buffer [blk][P][16] the backward passes read (channels 30, 31 are padding there: zero)
+__device__ __forceinline__ void h2_save32(float* __restrict__ save, long long Pn, int blk0, long long p, int h, const f32x16& v) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 o = {v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]};
+        if (m == 3 && h == 1) { o.z = 0.f; o.w = 0.f; }
+        *(f32x4*)(save + ((size_t)(blk0 + (m >> 1)) * Pn + p) * 16 + 8 * (m & 1) + 4 * h) = o;
+    }
+}
+// ------------------------------------------------------------------------------------------------
+// STAGE 1, f16x2 form. An activation x is split into x0 = rn16(x), x1 = rn16(x - x0) (one v_cvt_pk_f16_f32 per pair and
+// piece, one v_fma_mix_f32 per value) and a weight into W0 = rn16(W), W1' = rn16(16 (W - W0)); a K-step is THREE products,
+// smallest first: W0 x1 + W1' (x0 / 16) + W0 x0 (x0 / 16: one v_pk_mul_f16 per pair). The scaled pair keeps the weight's second
+// piece a normal fp16 number; without it that piece falls into fp16's subnormal range (absolute floor 2^-25) and the hidden
+// states lose ~2x in accuracy (oracle-level emulation of the arithmetic on the o1_20x500 fixture: x_latent rms error vs fp64
+// 1.30e-7 unscaled, 0.81e-7 scaled; three exact bf16 pieces with six products, the round-1..3 form: 0.68e-7; the reference's
+// own fp32: 1.13e-7). Dropped: W1 x1 (2^-24 of a product) and the last-bit rounding of x1: the result is fp32-CLASS, not
+// bit-for-bit fp32. The input layer (K = 8: [x0 ; x1] fill one K = 16 step) is computed 16 x too large as a whole,
+// [P|P][x0;x1] + [Q|Q][x0;x1] with P + Q = 16 W and C = 16 b: the neighbour sums absorb the factor in their constants, the
+// node's own h0 in its PReLU. Per wave-tile (32 nodes): 120 MFMAs (48 neighbour recompute, 24 layer 1, 36 u / v / c,
+// 12 wu / wv; the bf16x3 form needed 216) and ~1500 vector instructions (2050).
+// ------------------------------------------------------------------------------------------------
+// lane k of every row of 16 lanes, broadcast to the row (DPP row_newbcast, gfx90a+)
+template <int K_>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K_, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_bcast_dyn(int v, int k) {     // k is a compile-time constant after unrolling
+    switch (k) {
+        case 0: return row_bcast<0>(v); case 1: return row_bcast<1>(v); case 2: return row_bcast<2>(v); case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v); case 5: return row_bcast<5>(v); case 6: return row_bcast<6>(v); case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v); case 9: return row_bcast<9>(v); case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
+    }
+}
+template <int KS_>
+__device__ __forceinline__ void split8h(const f32x16& v, u32x4 (&p)[3], unsigned sixteenth) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float a = v[8 * KS_ + 2 * d], b = v[8 * KS_ + 2 * d + 1];
+        const unsigned p0 = cvt_pk_f16(a, b);
+        p[0][d] = p0;
+        p[1][d] = cvt_pk_f16(sub_f16_lo(a, p0), sub_f16_hi(b, p0));
+        p[2][d] = pk_mul_f16(p0, sixteenth);
+    }
+}
+// the three partial products of one K-step for N independent accumulators sharing the B pieces {x0, x1, x0 / 16}
+template <int N>
+__device__ __forceinline__ void mma3(f32x16 (&acc)[N], const f32x4* lw, const int (&f0)[N], int lane, const u32x4 (&b)[3]) {
+    f32x4 w[N][2];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w[k][p] = lw[(f0[k] + p) * 64 + lane];
+    constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = MFMA32H(w[k][WP[t]], b[BP[t]], acc[k]);
+}
+
+template <int KS, int KP, bool EDGES, bool BIG, bool ABS = false, bool PCSR = false>
+__global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
+    // PCSR: irregular product graph (use_subgraph). A wave item is 32 consecutive product nodes; the neighbours of a node are
+    // product-node ids from the product-level CSRs (at most KS / KP of them: a missing one is the node itself with weight 0,
+    // the mean of an empty neighbourhood is 0); everything after the neighbour phase is the same code.
+    static_assert(!(PCSR && (EDGES || ABS)), "irregular product graphs: default model definition only");
+    typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
+    constexpr int NF4 = H2_IMG_FLOATS / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += H2_THREADS) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + H2_FRAGS * 64);
+    const float* lscal = lbias + H2_NBIAS * 32;
+    const float a0 = lscal[0], a1 = lscal[3], a21 = lscal[4], a22 = lscal[5];
+    const float s11 = compose_slopes(a0, lscal[1]), s12 = compose_slopes(a0, lscal[2]);
+    const float inf = __builtin_inff();
+    const float sel0 = a0 <= 1.f ? inf : -inf, sel1 = a1 <= 1.f ? inf : -inf;
+    const float sel21 = a21 <= 1.f ? inf : -inf, sel22 = a22 <= 1.f ? inf : -inf;
+    // mean_k PReLU_s(z_k) = al * sum z_k + be * sum |z_k|; the z_k arrive 16 x too large
+    const float al1 = (1.f + s11) / (32.f * KS), be1 = (1.f - s11) / (32.f * KS);
+    const float al2 = (1.f + s12) / (32.f * KP), be2 = (1.f - s12) / (32.f * KP);
+    const unsigned c16 = __builtin_amdgcn_readfirstlane(H2_SIXTEENTH);
+
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, half = (lane >> 4) & 1, jj = lane & 15;
+    const bool hi = h != 0;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    const char* xs = (const char*)a.xs;
+    const off_t_ la = hi ? (off_t_)a.xs_plane : (off_t_)0;          // lane h = 0 loads x0, lane h = 1 loads x1: [x0 ; x1] is one K = 16 step
+    const off_t_ gstride = (off_t_)((unsigned)S * (unsigned)XPC);
+
+    const f32x4 fa0 = lw[(H2_FA + 0) * 64 + lane], fa1 = lw[(H2_FA + 1) * 64 + lane];
+    // use_absolute_pos: the six position columns of init_trns are one more K = 16 step per unit, B = {station piece, source piece}
+    f32x4 fp0, fp1;
+    if (ABS) { fp0 = lw[(H2_FABS + 0) * 64 + lane]; fp1 = lw[(H2_FABS + 1) * 64 + lane]; }
+    const unsigned tp_h = (unsigned)h * 8u;           // piece tables: [node][piece] x 8 B
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    f32x16 biasA = bias16(lbias, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasA[r] *= 16.f;
+
+    int jt = jj;
+    auto fetch_ids = [&](long long pit_, int& idv_, int& sc_, bool& valid_, int (&sta_)[KS]) {
+        int gi0, tb0, gi1, tb1;
+        w.decode(2 * pit_, gi0, tb0);
+        const bool second = 2 * pit_ + 1 < w.nitems;
+        w.decode(second ? 2 * pit_ + 1 : 2 * pit_, gi1, tb1);
+        idv_ = a.src_tab[(half ? gi1 : gi0) * 16 + jt];
+        const int s = (half ? tb1 : tb0) * 16 + jt;
+        valid_ = s < S && (second || !half);
+        sc_ = s < S ? s : S - 1;
+        load_sta_ids<KS>(a.sta_col, sc_, sta_);
+    };
+    constexpr int KPP = PCSR ? KP : 1;
+    auto fetch_pcsr = [&](long long pit_, long long& p_, bool& valid_, int (&sta_)[KS], int (&src_)[KPP], int& ds_, int& dp_) {
+        const long long pr = pit_ * 32 + (lane & 31);
+        valid_ = pr < a.Pn;
+        p_ = valid_ ? pr : a.Pn - 1;
+        const int eb = a.sta_rowptr[p_], fb = a.src_rowptr[p_];
+        ds_ = a.sta_rowptr[p_ + 1] - eb;
+        dp_ = a.src_rowptr[p_ + 1] - fb;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int v = a.sta_col[max(eb + min(q, ds_ - 1), 0)];
+            sta_[q] = q < ds_ ? v : (int)p_;
+        }
+#pragma unroll
+        for (int q = 0; q < KPP; ++q) {
+            const int v = a.src_col[max(fb + min(q, dp_ - 1), 0)];
+            src_[q] = q < dp_ ? v : (int)p_;
+        }
+    };
+    int idv = 0, sc = 0, sta_id[KS], src_id[KPP], dgs = 0, dgp = 0;
+    long long pcur = 0;
+    bool valid = false;
+    // wave items: Cartesian = pairs of (source node, station tile) items of the XCD-aware sweep; PCSR = 32 consecutive product nodes
+    const long long pit0 = PCSR ? (long long)blockIdx.x * (H2_THREADS / 64) + wave : w.it;
+    const long long pstride = PCSR ? (long long)gridDim.x * (H2_THREADS / 64) : w.stride;
+    const long long pend = PCSR ? (a.Pn + 31) / 32 : (w.nitems + 1) / 2;
+    if (pit0 < pend) {
+        if constexpr (PCSR) fetch_pcsr(pit0, pcur, valid, sta_id, src_id, dgs, dgp);
+        else fetch_ids(pit0, idv, sc, valid, sta_id);
+    }
+    for (long long pit = pit0, pnext = 0; pit < pend; pit = pnext) {
+        asm volatile("" : "+v"(lane));    // keeps the LDS fragment reads inside the loop (LICM would park them all in VGPRs)
+        // idv: every row of 16 lanes holds {source node, its KP neighbours} of its own tile: one DPP row broadcast per id
+        const int g = PCSR ? 0 : row_bcast<0>(idv);
+        const long long p = PCSR ? pcur : (long long)g * S + sc;
+        const off_t_ gbase0 = PCSR ? (off_t_)(unsigned long long)p * (off_t_)XPC : (off_t_)(unsigned)g * gstride;
+        const unsigned sbase0 = PCSR ? 0u : (unsigned)sc * (unsigned)XPC;
+        off_t_ gbase = gbase0 + la;                  // + this lane's plane: one multiply-add per neighbour row address
+        off_t_ sbase = (off_t_)sbase0 + la;
+        const int srcv = idv;
+        // PCSR: per-lane weights of a present neighbour (16 x scaling and 1 / degree folded in)
+        float alS = 0.f, beS = 0.f, alP = 0.f, beP = 0.f;
+        if constexpr (PCSR) {
+            const float is = 1.f / (float)max(dgs, 1), ip = 1.f / (float)max(dgp, 1);
+            alS = (1.f + s11) * 0.03125f * is; beS = (1.f - s11) * 0.03125f * is;
+            alP = (1.f + s12) * 0.03125f * ip; beP = (1.f - s12) * 0.03125f * ip;
+        }
+
+        // unit u: 0 = the node itself, 1..KS = station neighbours, KS+1..KS+KP = source neighbours
+        constexpr int NU = 1 + KS + KP;
+        static_assert(NU % 2 == 0, "units are processed in pairs");
+        constexpr int DEPTH = ABS ? 4 : GENIE_H2_DEPTH;
+        u32x4 buf[NU];
+        u32x2 tp[NU], tso, tgo;          // ABS: the unit's own position piece; this tile's station / source piece
+        if (ABS) {
+            tso = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sc * 16u));
+            tgo = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)g * 16u));
+        }
+        auto issue = [&](int u) {
+            off_t_ off;
+            if (u == 0) off = gbase + sbase0;
+            else if (PCSR) off = (off_t_)(unsigned)(u <= KS ? sta_id[u - 1] : src_id[(u - KS - 1) % KPP]) * (off_t_)XPC + la;
+            else if (u <= KS) off = gbase + (unsigned)sta_id[u - 1] * (unsigned)XPC;
+            else {
+                const unsigned nb = (unsigned)row_bcast_dyn(srcv, u - KS);
+                off = (BIG ? (off_t_)nb * gstride : (off_t_)__umul24(nb, (unsigned)gstride)) + sbase;
+            }
+            if (ABS && u > 0) {
+                if (u <= KS) tp[u] = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sta_id[u - 1] * 16u));
+                else tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)row_bcast_dyn(srcv, u - KS) * 16u));
+            }
+            if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
+            buf[u] = *(const u32x4*)(xs + off);
+        };
+        const u32x4 own0 = *(const u32x4*)(xs + (gbase0 + sbase0));         // x0 of the own row (lanes h = 1: Mask pads)
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) issue(u);
+
+        f32x16 sn, h0;          // sn: running mean_k PReLU_s(z_k) = sum_k (al z_k + be |z_k|), two fused multiply-adds per value
+        u32x4 h0p[2][3], n1p[2][3], n2p[2][3];
+        unsigned m01[3], m23[3];          // Mask pieces {x0, x1, x0 / 16} (lanes h = 1): fp16 pairs (M0,M1) and (M2,M3)
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                if (u + DEPTH + d < NU) issue(u + DEPTH + d);
+            asm volatile("" : "+v"(buf[u]), "+v"(buf[u + 1]));
+            f32x16 z0, z1;
+            if (ABS) {
+                auto posb = [&](int uu) {
+                    return uu == 0 ? u32x4{tso.x, tso.y, tgo.x, tgo.y}
+                                   : uu <= KS ? u32x4{tp[uu].x, tp[uu].y, tgo.x, tgo.y} : u32x4{tso.x, tso.y, tp[uu].x, tp[uu].y};
+                };
+                const u32x4 p0 = posb(u), p1 = posb(u + 1);
+                z0 = MFMA32H(fp1, p0, biasA); z1 = MFMA32H(fp1, p1, biasA);
+                z0 = MFMA32H(fa1, buf[u], z0); z1 = MFMA32H(fa1, buf[u + 1], z1);
+                z0 = MFMA32H(fp0, p0, z0); z1 = MFMA32H(fp0, p1, z1);
+            } else {
+                z0 = MFMA32H(fa1, buf[u], biasA); z1 = MFMA32H(fa1, buf[u + 1], biasA);
+            }
+            z0 = MFMA32H(fa0, buf[u], z0);
+            z1 = MFMA32H(fa0, buf[u + 1], z1);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                f32x16 z = d == 0 ? z0 : z1;
+                const int uu = u + d;
+                if (uu == 0) {
+                    if (a.save != nullptr && valid) {
+                        f32x16 zu;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zu[r] = z[r] * 0.0625f;
+                        h2_save32(a.save, a.Pn, SV_Z0, p, h, zu);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h0[r] = __builtin_amdgcn_fmed3f(z[r] * 0.0625f, z[r] * (0.0625f * a0), sel0);
+                    m01[0] = own0.z;   m23[0] = own0.w;
+                    m01[1] = buf[0].z; m23[1] = buf[0].w;      // lane h = 1: buf = x1
+                    m01[2] = pk_mul_f16(own0.z, c16); m23[2] = pk_mul_f16(own0.w, c16);
+                } else {
+                    float al = uu <= KS ? al1 : al2, be = uu <= KS ? be1 : be2;
+                    if constexpr (PCSR) {
+                        const bool present = uu <= KS ? uu - 1 < dgs : uu - KS - 1 < dgp;
+                        al = present ? (uu <= KS ? alS : alP) : 0.f;
+                        be = present ? (uu <= KS ? beS : beP) : 0.f;
+                    }
+                    if (uu == 1 || uu == KS + 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), al * z[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), fmaf(al, z[r], sn[r]));
+                    }
+                }
+                if (uu == KS) { split8h<0>(sn, n1p[0], c16); split8h<1>(sn, n1p[1], c16); }
+                if (uu == NU - 1) { split8h<0>(sn, n2p[0], c16); split8h<1>(sn, n2p[1], c16); }
+            }
+            asm volatile("" : "+v"(sn), "+v"(gbase), "+v"(sbase), "+v"(jt));
+        }
+        int idv_n = 0, sc_n = 0, sta_n[KS], src_n[KPP], dgs_n = 0, dgp_n = 0;
+        long long p_n = 0;
+        bool valid_n = false;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_n[k] = 0;
+#pragma unroll
+        for (int k = 0; k < KPP; ++k) src_n[k] = 0;
+        pnext = pit + pstride;
+        const bool has_next = pnext < pend;
+        if (has_next) {
+            if constexpr (PCSR) fetch_pcsr(pnext, p_n, valid_n, sta_n, src_n, dgs_n, dgp_n);
+            else fetch_ids(pnext, idv_n, sc_n, valid_n, sta_n);
+        }
+        if (a.dbg_h0 != nullptr && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < 30) a.dbg_h0[p * 30 + ch] = h0[r];
+            }
+        }
+        split8h<0>(h0, h0p[0], c16);
+        split8h<1>(h0, h0p[1], c16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {     // padding slots (channels 30, 31) carry the Mask: [h0 | M0 M1], [n | M2 M3]
+            h0p[1][q].w = hi ? m01[q] : h0p[1][q].w;
+            n1p[1][q].w = hi ? m23[q] : n1p[1][q].w;
+            n2p[1][q].w = hi ? m23[q] : n2p[1][q].w;
+        }
+        // ---- layer 1: tr_t = l1_t{1,2}_2 [h0 || n_t || Mask], both halves at once
+        f32x16 acc[2] = {bias16(lbias, 1, h), bias16(lbias, 2, h)};
+        if (EDGES) {   // DataAggregationEdges: static per-station / per-source-node terms of layer 1
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[0][4 * b + e] += es[e]; acc[1][4 * b + e] += eg[e]; }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int f0[2] = {H2_FL1 + (0 * 4 + ks) * 2, H2_FL1 + (1 * 4 + ks) * 2};
+            mma3<2>(acc, lw, f0, lane, h0p[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {     // the neighbour-mean blocks differ per half: interleave by hand
+            const int fa_ = H2_FL1 + (0 * 4 + 2 + ks) * 2, fb_ = H2_FL1 + (1 * 4 + 2 + ks) * 2;
+            f32x4 wa[2], wb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { wa[q] = lw[(fa_ + q) * 64 + lane]; wb[q] = lw[(fb_ + q) * 64 + lane]; }
+            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[0] = MFMA32H(wa[WP[t]], n1p[ks][BP[t]], acc[0]);
+                acc[1] = MFMA32H(wb[WP[t]], n2p[ks][BP[t]], acc[1]);
+            }
+        }
+        if (a.save != nullptr && valid) { h2_save32(a.save, a.Pn, SV_T, p, h, acc[0]); h2_save32(a.save, a.Pn, SV_T + 2, p, h, acc[1]); }
+        acc[0] = prelu16(acc[0], a1, sel1);
+        acc[1] = prelu16(acc[1], a1, sel1);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        if (a.dbg_h1 != nullptr && valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (ch < 30) a.dbg_h1[p * 60 + 30 * t + ch] = acc[t][r];
+                }
+        }
+        // ---- u, v and the node-local layer-2 terms c from h1 = [h1a (30) | M0 M1 | h1b (30) | M2 M3]
+        f32x16 o3[3] = {bias16(lbias, 3, h), bias16(lbias, 4, h), bias16(lbias, 5, h)};
+        if (EDGES) {   // ... and of the node-local layer-2 block c = [o1 (15), 0 | o2 (15), 0]
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 8 * b + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o3[2][4 * b + e] += es[e]; o3[2][8 + 4 * b + e] += eg[e]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 hp[2][3];
+            split8h<0>(acc[t], hp[0], c16);
+            split8h<1>(acc[t], hp[1], c16);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) hp[1][q].w = hi ? (t == 0 ? m01[q] : m23[q]) : hp[1][q].w;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int ks = 2 * t + kb;
+                const int f0[3] = {H2_FUVC + (0 * 4 + ks) * 2, H2_FUVC + (1 * 4 + ks) * 2, H2_FUVC + (2 * 4 + ks) * 2};
+                mma3<3>(o3, lw, f0, lane, hp[kb]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
+        }
+        if (a.save != nullptr && valid) { h2_save32(a.save, a.Pn, SV_UP, p, h, o3[0]); h2_save32(a.save, a.Pn, SV_VP, p, h, o3[1]); }
+        o3[0] = prelu16(o3[0], a21, sel21);
+        o3[1] = prelu16(o3[1], a22, sel22);
+        asm volatile("" : "+v"(o3[0]), "+v"(o3[1]));
+        // ---- projected gather operands [wu | wv] = [l2_t1_2[:, 60:90] u | l2_t2_2[:, 60:90] v]
+        f32x16 ow[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ow[0][r] = 0.f; ow[1][r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 up[3], vp[3];
+            if (kb == 0) { split8h<0>(o3[0], up, c16); split8h<0>(o3[1], vp, c16); }
+            else { split8h<1>(o3[0], up, c16); split8h<1>(o3[1], vp, c16); }
+            f32x4 wa[2], wb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wa[q] = lw[(H2_FW + (0 + kb) * 2 + q) * 64 + lane];
+                wb[q] = lw[(H2_FW + (2 + kb) * 2 + q) * 64 + lane];
+            }
+            constexpr int WP[3] = {0, 1, 0}, BP[3] = {1, 2, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ow[0] = MFMA32H(wa[WP[t]], up[BP[t]], ow[0]);
+                ow[1] = MFMA32H(wb[WP[t]], vp[BP[t]], ow[1]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                *(f32x4*)(a.wu + p * ROWW + 8 * b + 4 * h) = f32x4{ow[0][4 * b], ow[0][4 * b + 1], ow[0][4 * b + 2], ow[0][4 * b + 3]};
+                *(f32x4*)(a.wv + p * ROWW + 8 * b + 4 * h) =
+                    f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
+            }
+        }
+        idv = idv_n; sc = sc_n; valid = valid_n; pcur = p_n; dgs = dgs_n; dgp = dgp_n;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) sta_id[k] = sta_n[k];
+#pragma unroll
+        for (int k = 0; k < KPP; ++k) src_id[k] = src_n[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: second pair of neighbour means (of the projected operands), PReLU2 -> x_latent; Bipartite fc1 + PReLU,
+// mask gate, and the per-tile station sum.                      module.py:94-96, :229
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int sc = valid ? s : S - 1;
+        const long long p = (long long)g * S + sc;
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        const float mq = a.mask[p * 4 + q];
+        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        // neighbour means of the projected operands (16-float rows): they ARE the accumulator contributions
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[sc], ee = a.sta_rowptr[sc + 1];
+            const float* base = a.wu + (long long)g * S * ROWW + 4 * q;
+            if (!ABL(a, 0)) gather_sum16<false>(base, ROWW, a.sta_col, eb, ee, n1);
+            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
+        }
+        {
+            const int eb = __builtin_amdgcn_readfirstlane(a.src_rowptr[g]);
+            const int ee = __builtin_amdgcn_readfirstlane(a.src_rowptr[g + 1]);
+            const float* base = a.wv + (long long)sc * ROWW + 4 * q;
+            if (!ABL(a, 1)) gather_sum16<true>(base, (long long)S * ROWW, a.src_col, eb, ee, n2);
+            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
+        }
+        if (a.save != nullptr && valid) {
+            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p) * 16 + 4 * q) = o[0];
+            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p) * 16 + 4 * q) = o[1];
+        }
+        o[0] = prelu4u(o[0], a2);   // x_latent[0:15]  (lane (j,q) holds channels 4q..4q+3, channel 15 is zero)
+        o[1] = prelu4u(o[1], a2);   // x_latent[15:30]
+        if (a.x_latent != nullptr && valid) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * q + r < 15) {
+                    xl[4 * q + r] = o[0][r];
+                    xl[15 + 4 * q + r] = o[1][r];
+                }
+            }
+        }
+        if (a.no_bip) continue;
+        // Bipartite message: m_p * PReLU_b1(fc1 [x_latent || edge_attr])
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + p) * 16 + 4 * q) = bp[t];
+            bp[t] = prelu4u(bp[t], ab1);
+        }
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (!valid) mm = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = bp[t] * mm;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                v.x += __shfl_xor(v.x, d);
+                v.y += __shfl_xor(v.y, d);
+                v.z += __shfl_xor(v.z, d);
+                v.w += __shfl_xor(v.w, d);
+            }
+            if (j == 0) *(f32x4*)(a.part + ((long long)g * a.T + tb) * 32 + 16 * t + 4 * q) = v;
+        }
+    }
+}
+
+// Stage 2 on an irregular product graph (see k_stage1_pcsr). The Bipartite messages of a source node are not the rows of
+// whole tiles here, so every node's gated message row is written in place of its c row and k_bip_out_seg sums the row range
+// of each source node (product nodes are grouped by source node, process_utils.py:790-794) in row order.
+__global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const long long ntiles = (a.Pn + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
+         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+#if !GENIE_HOIST_WEIGHTS
+        asm volatile("" : "+v"(lane));
+#endif
+        const long long pr = tile * 16 + j;
+        const bool valid = pr < a.Pn;
+        const long long p = valid ? pr : a.Pn - 1;
+        f32x4 o[2];
+        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
+        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        const float mq = a.mask[p * 4 + q];
+        const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
+            gather_sum16<false>(a.wu + 4 * q, ROWW, a.sta_col, eb, ee, n1);
+            o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
+        }
+        {
+            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
+            gather_sum16<false>(a.wv + 4 * q, ROWW, a.src_col, eb, ee, n2);
+            o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
+        }
+        o[0] = prelu4u(o[0], a2);
+        o[1] = prelu4u(o[1], a2);
+        if (a.x_latent != nullptr && valid) {
+            float* xl = a.x_latent + p * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * q + r < 15) {
+                    xl[4 * q + r] = o[0][r];
+                    xl[15 + 4 * q + r] = o[1][r];
+                }
+            }
+        }
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+            bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+            bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            bp[t] = prelu4u(bp[t], ab1);
+        }
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (valid) {      // the message row replaces the c row of the node (read above by these same lanes)
+            *(f32x4*)(a.c + p * ROWC + 4 * q) = bp[0] * mm;
+            *(f32x4*)(a.c + p * ROWC + 16 + 4 * q) = bp[1] * mm;
+        }
+    }
+}
+
+// k_stage2_fast for the production configuration (uniform-degree graphs, station processing order with a registered static
+// edge_attr, static item stream, Bipartite half on), straight-line: the ISA of k_stage2_fast spends a fifth of its vector
+// instructions on register copies at the joins of its option branches (the 15 source rows were copied out and back every tile),
+// 34 ds_bpermute per tile on the station sum and a dozen uniform branches. Here
+//  * the item after the last one is clamped to the last one, so every load of the software pipeline is unconditional and no
+//    value has two definitions at a join;
+//  * a tile's ids are its (wave-uniform) item number, one src_tab row and the 8 station-neighbour ids, which are loaded into the
+//    registers the previous tile's ids have just left: nothing rotates but one register;
+//  * the station sum over the 16 nodes of a tile is a DPP row reduction (row_shl:1, 2, 4, 8): lane 0 of every row adds the same
+//    operands in the same tree as the xor butterfly of k_stage2 (bitwise identical), without the LDS round trips;
+//  * the message mask is read by all four lanes of a node (one address) instead of max-reduced across them.
+// Same arithmetic and summation order as k_stage2 / k_stage2_fast (bitwise identical results; tests).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of every row of 16: the butterfly's sum tree
+    v = dpp_add<0x101>(v);      // row_shl:1
+    v = dpp_add<0x102>(v);
+    v = dpp_add<0x104>(v);
+    v = dpp_add<0x108>(v);
+    return v;
+}
+// Row-layout loads: in the MFMA layout lane (j = lane & 15, q = lane >> 4) reads the 16-B chunk q of node j's row, so four
+// CONSECUTIVE lanes touch four different rows and the texture path works on 16 useful bytes per 64-B request (measured: 24 B per
+// clock and CU where contiguous row gathers reach 57). Every row is therefore loaded in the layout lane = 4 r + cq (node r = lane >> 2,
+// chunk cq = lane & 3): four consecutive lanes read one 64-B row, sixteen consecutive source rows one contiguous KB. Everything up
+// to x_latent is elementwise per (node, channel) and runs in that layout; x_latent, edge_attr and the gated mask then go through a
+// 2.3-KB per-wave LDS scratch (rows of 36 floats) into the MFMA layout for fc1.
+// XL: also store x_latent [P, 30] (caller's station order). NB: stop after x_latent (no Bipartite message / station sum): the
+// last pass of the association heads (genie_assoc_fwd).
+// Measured and dropped: other positions of the three load bursts (0.2627 / 0.2650 / 0.2649 ms), waves of a
+// workgroup phased half an iteration apart by barriers (0.262 -> 0.290), streamed rows two tiles ahead (246 VGPRs, 0.226 -> 0.240),
+// MFMA-layout loads (0.262 vs 0.226), station rows staged in LDS behind a barrier (0.282 -> 0.299 after a cold stage 1).
+template <int KS, int KP, bool XL, bool NB = false>
+__global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
+    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jl = lane >> 2, ql = lane & 3;      // (node, chunk) this lane LOADS
+    float* ts = tsc + wave * 16 * 36;
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    // a.wgmap: a workgroup takes BLOCKS of 4 consecutive source nodes of its XCD's chunk, wave k sweeps the tiles of the k-th
+    // node of the block: the four waves of a CU then read the source-neighbour rows of four adjacent source nodes (half of
+    // them shared) for the same station tile at about the same time, and every station row wu[g] is gathered on one CU only
+    if (a.wgmap) {
+        const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+        const int lb = blockIdx.x / nx, nbx = gridDim.x / nx, n = w.gend - w.gbeg, n_blk = (n + 3) / 4;
+        int n_my = lb < n_blk ? (n_blk - lb + nbx - 1) / nbx : 0;
+        if (n_my > 0 && 4 * (lb + (n_my - 1) * nbx) + wave >= n) --n_my;
+        w.it = 0; w.stride = 1; w.nitems = (long long)n_my * a.T;
+        w.lead_ = lb; w.chunk_ = nbx;                     // (reused as: first block, block stride)
+    }
+    if (w.it >= w.nitems) return;
+    const char* wub = (const char*)a.wu;
+    const char* wvb = (const char*)a.wv;
+    const unsigned q16 = 16u * (unsigned)ql;
+    const size_t gpitch = (size_t)S * 64u;                 // bytes of one source node's rows in wu / wv
+    const unsigned m_T = ItemIter::recip((unsigned)a.T);
+
+    // item -> wave-uniform (processing position gi, station tile tb); every XCD's chunk is swept BACKWARDS: the c / wu / wv rows
+    // stage 1 wrote last (still in the Infinity Cache) are read first (0.278 -> 0.276 ms)
+    auto item_of = [&](long long it, int& gi, int& tb) {
+        const long long itr = w.nitems - 1 - it;
+        if (a.wgmap) {
+            unsigned rem;
+            const unsigned kb = a.T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)a.T, m_T, rem);
+            tb = (int)rem;
+            gi = w.gbeg + 4 * (w.lead_ + (int)kb * w.chunk_) + wave;
+        } else {
+            w.decode(itr, gi, tb);
+        }
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        tb = __builtin_amdgcn_readfirstlane(tb);
+    };
+    struct Stream { f32x4 o[2]; float mq, eq; };                  // streamed rows of a tile: c, message mask, edge_attr
+    struct Rows { f32x4 ru[KS], rv[KP]; } rows;                    // gathered rows
+    Stream sA;
+    int sta[KS];
+    auto load_ids = [&](int gi, int tb, int& idv) {
+        idv = a.src_tab[gi * 16 + j];
+        const int s = tb * 16 + jl;
+        load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
+    };
+    auto issue0 = [&](Stream& st, int idv, int tb) {
+        const int g = __builtin_amdgcn_readlane(idv, 0);
+        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
+        long long p = (long long)g * S + sc;
+        if (ABL(a, 9)) p &= 4095;          // tuning: streamed rows from a cache-resident region
+        st.o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * ql);
+        st.o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * ql);
+        st.mq = NB ? 0.f : a.mm_int[p];
+        st.eq = (!NB && ql < 3) ? a.ea_int[p * 3 + ql] : 0.f;
+        const char* wug = wub + (ABL(a, 11) ? (size_t)0 : (size_t)g * gpitch);     // tuning bit 11: gathers hit one resident block
+#pragma unroll
+        for (int k = 0; k < KS; ++k) rows.ru[k] = ABL(a, 0) ? st.o[0] : *(const f32x4*)(wug + ((unsigned)sta[k] * 64u + q16));
+    };
+    auto issue_v = [&](int idv, int tb, int k0, int k1) {
+        const int s = tb * 16 + jl, sc = s < S ? s : S - 1;
+        const unsigned so = (unsigned)sc * 64u + q16;
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            if (k >= k0 && k < k1) {
+                // the row base of a source neighbour is wave-uniform: kept opaque in an SGPR pair, so that the load is
+                // `global_load v, voffset, s[base]` (left to itself hipcc hoists wvb + so into a VGPR pair and adds the
+                // scalar part with a 64-bit vector multiply-add per neighbour: 3 vector instructions each)
+                unsigned long long wvk = (unsigned long long)wvb + (ABL(a, 11) ? (size_t)k : (size_t)__builtin_amdgcn_readlane(idv, 1 + k)) * gpitch;
+                asm volatile("" : "+s"(wvk));
+                typedef const __attribute__((address_space(1))) char* gbytes;
+                typedef const __attribute__((address_space(1))) f32x4* grow;
+                rows.rv[k] = ABL(a, 1) ? rows.ru[0] : *(grow)((gbytes)wvk + so);
+            }
+    };
+    constexpr int KH = (KP + 1) / 2;
+
+    long long it = w.it;
+    int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
+    item_of(it, gi_c, tb_c);
+    load_ids(gi_c, tb_c, idv_c);
+    issue0(sA, idv_c, tb_c);
+    issue_v(idv_c, tb_c, 0, KP);
+    {
+        const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
+        item_of(itn, gi_n, tb_n);
+        load_ids(gi_n, tb_n, idv_n);
+    }
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
+        const bool has_next = it + w.stride < w.nitems;
+        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
+        int gi_2, tb_2, idv_2;
+        item_of(it2, gi_2, tb_2);
+        // (1) consume the rows of this tile: neighbour means of the projected operands in edge order, PReLU2 -> x_latent
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) n1 += rows.ru[k];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
+        f32x4 o[2];
+        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sA.o[0]), a2);
+        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sA.o[1]), a2);
+        float mq = sA.mq, eq = sA.eq;
+        const int s_l = tb_c * 16 + jl;              // the node this lane loaded (not the node it holds in the MFMA layout)
+        const bool valid_l = s_l < S;
+        const f32x4 ol0 = o[0], ol1 = o[1];
+        if (!NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
+            *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
+            *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
+            ts[jl * 36 + 32 + ql] = ql < 3 ? eq : (valid_l ? mq : 0.f);
+            GSYNC();
+            o[0] = *(const f32x4*)(ts + j * 36 + 4 * q);
+            o[1] = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+            eq = q < 3 ? ts[j * 36 + 32 + q] : 0.f;
+            mq = ts[j * 36 + 35];
+        }
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(idv_n));
+        // (2) first burst of the next tile's rows (the station-neighbour ids are dead after it)
+        issue0(sA, idv_n, tb_n);
+        if (NB) issue_v(idv_n, tb_n, 0, KP);
+        if (XL && valid_l) {
+            const int su = a.sta_user[s_l];
+            float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * ql + r < 15) { xl[4 * ql + r] = ol0[r]; xl[15 + 4 * ql + r] = ol1[r]; }
+        }
+        f32x4 bp[2];
+        bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
+        bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (NB) break;
+            if (!ABL(a, 6)) {      // (tuning bit 6: no fc1 MFMAs)
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
+                bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
+                bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            } else bp[t] += o[0] + o[1] + eq;
+            bp[t] = prelu4u(bp[t], ab1);
+            // (3) second / third burst, behind the first / second output tile of fc1
+            asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
+            if (t == 0) issue_v(idv_n, tb_n, 0, KH); else issue_v(idv_n, tb_n, KH, KP);
+        }
+        // (4) ids of the tile after next (the item after the last one repeats the last one: its loads are never consumed)
+        load_ids(gi_2, tb_2, idv_2);
+        // (5) mask gate and station sum of this tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (NB) break;
+            f32x4 v = bp[t] * mq;
+            v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
+            if (j == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * q) = v;
+        }
+        if (!has_next) break;
+        it += w.stride;
+        idv_c = idv_n; tb_c = tb_n;
+        idv_n = idv_2; tb_n = tb_2;
+    }
+}

@@ -1,0 +1,480 @@
+// Part of genie_hip.hip (one translation unit, included inside its anonymous namespace): the backward passes of the P-sized front (k_train_b2 / b1 / b0, k_train_reduce).
+
+// ------------------------------------------------------------------------------------------------
+// Backward of DataAggregation + Bipartite_ReadIn (training step, train_GENIE_model.py:1843-1861).
+// The training forward is the generic stage kernels with `save` set (pre-activations of h0, h1, u, v, x_latent and the
+// Bipartite message: 14 blocks of 16 floats per product node); the backward mirrors the stages in reverse order:
+//   k_train_b2: d(station sum)[g] -> dz (message) -> dx_latent = fc1[:, 0:30]^T dz -> do = dx_latent PReLU2'(o)      store do
+//   k_train_b1: transposed means of do1 / do2 (reversed base graphs) -> du, dv -> dh1 -> dt = dh1 PReLU1'(t)           store dt, dh0_local
+//   k_train_b0: transposed means of dt1 / dt2 -> dh0 -> dz0
+// Weight gradients are accumulated INSIDE the passes: dW[out, in] = sum over nodes dY[out] X[in] is an MFMA whose contraction
+// runs over the 16 nodes of a tile (operands transposed through a per-wave LDS scratch), into register accumulators that live
+// across all tiles of a wave; the terms that multiply a neighbour mean use the adjoint identity
+//   sum_p dY[p] (x) mean_{k in N(p)} x[k] = sum_k (transposed mean of dY)[k] (x) x[k],
+// so no mean is stored. Bias and PReLU-slope gradients are per-lane running sums. Every wave writes its partials once; a
+// fixed-order reduction over the waves (k_train_reduce) makes the result run-to-run deterministic.
+// ------------------------------------------------------------------------------------------------
+constexpr int GR_DO = 0, GR_DT = 2, GR_DH0 = 6, GR_BLOCKS = 8;      // gradient rows kept between the passes: [GR_*][P][16]
+
+struct AccDesc { int32_t mat_off, ld, row0, nrows, col0, ncols, n0, pad; };   // dW block: D[i][n] -> W[row0 + i][col0 + n], n0 <= n < ncols
+struct VecDesc { int32_t off, row0, nrows, stride; };                // bias block: sum dY[i] -> b[(row0 + i) * stride]
+
+struct TrArgs {
+    int S, G, T, seg, nxcd;
+    long long P;
+    const int32_t* order;
+    const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
+    const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
+    const float* slice; const float* mask; const float* edge_attr;
+    const float* save; float* gr;
+    const float* dr;             // [G][32] gradient of the per-source-node station sum (Bipartite, before fc2)
+    const float* packed;
+    float* part;                 // per-wave partials: [wave][n_acc * 256 + n_vec * 16 + 16]
+    int n_acc, n_vec;
+    int sv_t, sv_up, sv_vp;      // k_train_b1: blocks of `save` holding the pre-activations of h1 / u / v (SV_T, SV_UP, SV_VP, or the
+                                 // association phase's AV_T, AV_UV, AV_UV + 2)
+    const float* pg;             // association phase (k_train_b1<true>, k_as_*): [G][AS_PG] per-source-node terms, pg[31] = mask1[g]
+    const float* x_latent;       // association phase: [P, 30] DataAggregation output (an input of init_trns there)
+    float* zsum;                 // k_as_b0: [G * T][32] per-tile station sums of d z1 (-> d y_latent, fc1's y_latent columns)
+};
+
+__device__ __forceinline__ f32x4 ldb(const float* buf, int blk, long long P, long long p, int q) {
+    return *(const f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q);
+}
+__device__ __forceinline__ void stb(float* buf, int blk, long long P, long long p, int q, f32x4 v) {
+    *(f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q) = v;
+}
+__device__ __forceinline__ f32x4 dprelu4(f32x4 x, float s) {     // PReLU'(x): 1 for x > 0, the slope otherwise
+    return f32x4{x.x > 0.f ? 1.f : s, x.y > 0.f ? 1.f : s, x.z > 0.f ? 1.f : s, x.w > 0.f ? 1.f : s};
+}
+__device__ __forceinline__ float negsum4(f32x4 g, f32x4 x) {    // sum of g * min(x, 0): the slope gradient of PReLU
+    return g.x * fminf(x.x, 0.f) + g.y * fminf(x.y, 0.f) + g.z * fminf(x.z, 0.f) + g.w * fminf(x.w, 0.f);
+}
+// V[ch 4q + r][node j] held by lane (j, q) -> vt[s] = V[ch j][node 4s + q]: the operand form of a node-contracting MFMA
+__device__ __forceinline__ f32x4 tr16(f32x4 v, float* sc, int j, int q) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[(4 * q + r) * 17 + j] = v[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 t;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = sc[j * 17 + 4 * s + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+__device__ __forceinline__ f32x4 outer16(f32x4 acc, f32x4 at, f32x4 bt) {       // acc[out][in] += sum over the tile's nodes
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = MFMA16(at[s], bt[s], acc);
+    return acc;
+}
+// transposed mean: sum over the out-edges e of `node` of w_e * rows[col_e], rows of 16 floats addressed by `rowof(block, col)`,
+// for NB row blocks at once. The edges are taken EB at a time (indices, weights and the EB x NB rows of a batch are all in
+// flight together; a lane past its last edge re-reads edge 0 with weight zero): with one index -> row load chain per edge the
+// backward passes spent ~80 % of their time waiting on these gathers (one wave per SIMD, nothing to switch to). The sum keeps
+// the edge order.
+template <int NB, int EB = 4, typename F>
+__device__ __forceinline__ void tmean_n(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const float* __restrict__ w,
+                                        int node, bool uniform, F rowof, f32x4 (&out)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int eb = rp[node], ee = rp[node + 1];
+    if (uniform) { eb = __builtin_amdgcn_readfirstlane(eb); ee = __builtin_amdgcn_readfirstlane(ee); }
+    for (int e = eb; uniform ? (e < ee) : (bool)__any(e < ee); e += EB) {
+        int c[EB];
+        float ww[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const bool ok = e + k < ee;
+            const int ei = ok ? e + k : 0;
+            c[k] = col[ei];
+            ww[k] = ok ? w[ei] : 0.f;
+        }
+        f32x4 r[NB][EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, c[k]);
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * ww[k];
+    }
+}
+template <typename F>
+__device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, const float* w, int node, bool uniform, F rowof) {
+    f32x4 o[1];
+    tmean_n<1, 8>(rp, col, w, node, uniform, [&](int, int c) { return rowof(c); }, o);
+    return o[0];
+}
+__device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
+                                               const float* scal, int n_scal, int lane, int j, int q) {
+    float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
+    for (int k = 0; k < n_acc; ++k) *(f32x4*)(out + (size_t)k * 256 + lane * 4) = acc[k];
+    out += (size_t)a.n_acc * 256;
+    for (int k = 0; k < n_vec; ++k) {
+        f32x4 v = vec[k];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+        }
+        if (j == 0) *(f32x4*)(out + k * 16 + 4 * q) = v;
+    }
+    out += (size_t)a.n_vec * 16;
+    for (int k = 0; k < n_scal; ++k) {
+        float v = scal[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0) out[k] = v;
+    }
+}
+
+// ---- pass 2': Bipartite message + PReLU2.  accumulators: fc1 (t, {x_latent 0:15, x_latent 15:30, edge_attr}) = 6; vec: fc1 bias (2)
+__global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
+    constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT2_GROUPS * 64);
+    const float a2 = lscal[0], ab1 = lscal[1];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[6], vec[2];
+    float scal[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        float mq = a.mask[p * 4 + q];
+        float mm = fmaxf(mq, __shfl_xor(mq, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        if (!valid) mm = 0.f;
+        f32x4 eb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) { eb.x = a.edge_attr[p * 3]; eb.y = a.edge_attr[p * 3 + 1]; eb.z = a.edge_attr[p * 3 + 2]; }
+        f32x4 dz[2], o[2], xl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 zb = ldb(a.save, SV_ZB + t, P, p, q);
+            const f32x4 d = *(const f32x4*)(a.dr + (long long)g * 32 + 16 * t + 4 * q) * mm;      // through the mask gate
+            scal[1] += negsum4(d, zb);
+            dz[t] = d * dprelu4(zb, ab1);
+            vec[t] += dz[t];
+            o[t] = ldb(a.save, SV_O + t, P, p, q);
+            xl[t] = prelu4u(o[t], a2);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+            dx = mma_block(dx, lw[GT2(b, 0) * 64 + lane], dz[0]);
+            dx = mma_block(dx, lw[GT2(b, 1) * 64 + lane], dz[1]);
+            if (!valid) dx = f32x4{0.f, 0.f, 0.f, 0.f};
+            scal[0] += negsum4(dx, o[b]);
+            const f32x4 dob = dx * dprelu4(o[b], a2);
+            if (valid) stb(a.gr, GR_DO + b, P, p, q, dob);
+        }
+        const f32x4 x0t = tr16(xl[0], sc, j, q), x1t = tr16(xl[1], sc, j, q), et = tr16(eb, sc, j, q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 dt_ = tr16(dz[t], sc, j, q);
+            acc[t * 3 + 0] = outer16(acc[t * 3 + 0], dt_, x0t);
+            acc[t * 3 + 1] = outer16(acc[t * 3 + 1], dt_, x1t);
+            acc[t * 3 + 2] = outer16(acc[t * 3 + 2], dt_, et);
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 6, vec, 2, scal, 2, threadIdx.x & 63, j, q);
+}
+
+// ---- pass 1': layer 2 and the activation of layer 1.
+// accumulators: l2_t1_2 {h1 x4, Mask, u x2 (adjoint)} = 7, l2_t2_2 = 7, l2_t1_1 (2 x h1 x4) = 8, l2_t2_1 = 8  -> 30
+// vec: b(l2_t1_2), b(l2_t2_2), b(l2_t1_1) x2, b(l2_t2_1) x2 = 6; scal: a1, a21, a22
+// AS: the same pass for DataAggregationAssociationPhase (module.py:397-401; 95-wide l2_t?_2 with mask width 5): the column of mask1
+// (one value per source node) gets its gradient as two extra vectors.
+template <bool AS>
+__global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
+    constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
+    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    constexpr int NV = AS ? 8 : 6;
+    f32x4 acc[30], vec[NV];
+    float scal[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        const float vm = valid ? 1.f : 0.f;
+        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
+        const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
+        if (AS) {
+            const float m1 = a.pg[(long long)g * AS_PG + 31];
+            vec[6] += do1 * m1; vec[7] += do2 * m1;
+        }
+        const float* gr = a.gr;
+        const f32x4 tm1 = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                                [&](int c) { return ldb(gr, GR_DO + 0, P, (long long)g * S + c, q); }) * vm;
+        const f32x4 tm2 = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                                [&](int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn, q); }) * vm;
+        f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SVT + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            up[b] = ldb(a.save, SVU + b, P, p, q); u[b] = prelu4u(up[b], a21);
+            vp[b] = ldb(a.save, SVV + b, P, p, q); v[b] = prelu4u(vp[b], a22);
+        }
+        // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
+        f32x4 du[2], dv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 gu = mma_block(z, lw[GT_U(b) * 64 + lane], tm1), gv = mma_block(z, lw[GT_V(b) * 64 + lane], tm2);
+            scal[1] += negsum4(gu, up[b]);
+            scal[2] += negsum4(gv, vp[b]);
+            du[b] = gu * dprelu4(up[b], a21);
+            dv[b] = gv * dprelu4(vp[b], a22);
+        }
+        // dh1 and dt
+        f32x4 dt[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du[0]);
+            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du[1]);
+            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv[0]);
+            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv[1]);
+            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
+            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
+            scal[0] += negsum4(d, t[hb]);
+            dt[hb] = d * dprelu4(t[hb], a1);
+            if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(b, k) * 64 + lane], dt[k]);
+            if (valid) stb(a.gr, GR_DH0 + b, P, p, q, d);
+        }
+        vec[0] += do1; vec[1] += do2;
+        vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
+        // weight gradients
+        f32x4 h1t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h1t[k] = tr16(h1[k], sc, j, q);
+        const f32x4 mt = tr16(mb, sc, j, q);
+        {
+            const f32x4 d1t = tr16(do1, sc, j, q), d2t = tr16(do2, sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] = outer16(acc[k], d1t, h1t[k]); acc[7 + k] = outer16(acc[7 + k], d2t, h1t[k]); }
+            acc[4] = outer16(acc[4], d1t, mt);
+            acc[11] = outer16(acc[11], d2t, mt);
+            const f32x4 m1t = tr16(tm1, sc, j, q), m2t = tr16(tm2, sc, j, q);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[5 + b] = outer16(acc[5 + b], m1t, tr16(u[b], sc, j, q));
+                acc[12 + b] = outer16(acc[12 + b], m2t, tr16(v[b], sc, j, q));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 dut = tr16(du[b], sc, j, q), dvt = tr16(dv[b], sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[14 + b * 4 + k] = outer16(acc[14 + b * 4 + k], dut, h1t[k]);
+                acc[22 + b * 4 + k] = outer16(acc[22 + b * 4 + k], dvt, h1t[k]);
+            }
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
+}
+
+// ---- pass 0': layer 1 and init_trns.
+// accumulators: init_trns (2 x [Slice || Mask]) = 2; l1_t1_2 {2 x (h0 x2, Mask), adjoint 2 x 2} = 10; l1_t2_2 = 10  -> 22
+// vec: b(init_trns) x2, b(l1_t1_2) x2, b(l1_t2_2) x2 = 6; scal: a, a11, a12
+__global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
+    constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT0_GROUPS * 64);
+    const float a0 = lscal[0], a11 = lscal[1], a12 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[22], vec[6];
+    float scal[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 22; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
+    for (; w.it < w.nitems; w.it += w.stride) {
+        int gi, tb;
+        w.decode(w.it, gi, tb);
+        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        asm volatile("" : "+v"(lane));
+        const int s = tb * 16 + j;
+        const bool valid = s < S;
+        const int scn = valid ? s : S - 1;
+        const long long p = (long long)g * S + scn;
+        const float vm = valid ? 1.f : 0.f;
+        f32x4 xm = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) { xm = *(const f32x4*)(a.slice + p * 4); mb = *(const f32x4*)(a.mask + p * 4); }
+        if (q == 1) xm = *(const f32x4*)(a.mask + p * 4);
+        const float* gr = a.gr;
+        f32x4 z0[2], h0[2], dt[4], tmd1[2], tmd2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
+            h0[b] = prelu4u(z0[b], a0);
+        }
+        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
+                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
+                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
+        f32x4 dz0[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 dq1 = {0.f, 0.f, 0.f, 0.f}, dq2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                dq1 = mma_block(dq1, lw[GT_Q(0, b, k) * 64 + lane], tmd1[k]);
+                dq2 = mma_block(dq2, lw[GT_Q(1, b, k) * 64 + lane], tmd2[k]);
+            }
+            scal[1] += negsum4(dq1, h0[b]);
+            scal[2] += negsum4(dq2, h0[b]);
+            const f32x4 dh0 = ldb(a.gr, GR_DH0 + b, P, p, q) * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
+            scal[0] += negsum4(dh0, z0[b]);
+            dz0[b] = dh0 * dprelu4(z0[b], a0);
+        }
+        vec[0] += dz0[0]; vec[1] += dz0[1];
+        vec[2] += dt[0]; vec[3] += dt[1]; vec[4] += dt[2]; vec[5] += dt[3];
+        const f32x4 xmt = tr16(xm, sc, j, q), mt = tr16(mb, sc, j, q);
+        const f32x4 h0t[2] = {tr16(h0[0], sc, j, q), tr16(h0[1], sc, j, q)};
+        const f32x4 q1t[2] = {tr16(prelu4u(h0[0], a11), sc, j, q), tr16(prelu4u(h0[1], a11), sc, j, q)};
+        const f32x4 q2t[2] = {tr16(prelu4u(h0[0], a12), sc, j, q), tr16(prelu4u(h0[1], a12), sc, j, q)};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[b] = outer16(acc[b], tr16(dz0[b], sc, j, q), xmt);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int base = 2 + 10 * h;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 dtt = tr16(dt[2 * h + b], sc, j, q);
+                acc[base + b * 3 + 0] = outer16(acc[base + b * 3 + 0], dtt, h0t[0]);
+                acc[base + b * 3 + 1] = outer16(acc[base + b * 3 + 1], dtt, h0t[1]);
+                acc[base + b * 3 + 2] = outer16(acc[base + b * 3 + 2], dtt, mt);
+                const f32x4 tmt = tr16(h == 0 ? tmd1[b] : tmd2[b], sc, j, q);
+                acc[base + 6 + b * 2 + 0] = outer16(acc[base + 6 + b * 2 + 0], tmt, h == 0 ? q1t[0] : q2t[0]);
+                acc[base + 6 + b * 2 + 1] = outer16(acc[base + 6 + b * 2 + 1], tmt, h == 0 ? q1t[1] : q2t[1]);
+            }
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 22, vec, 6, scal, 3, threadIdx.x & 63, j, q);
+}
+
+// fixed-order reduction of the per-wave partials into the gradient blob (registry layout of the weight mirror): a workgroup
+// owns 32 entries; its 8 groups of 32 threads sum the waves w = group, group + 8, ... and the 8 sums are added in group order
+__global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ part, int n_waves, int n_acc, int n_vec, int n_scal,
+                                                      const AccDesc* __restrict__ ad, const VecDesc* __restrict__ vd,
+                                                      const int32_t* __restrict__ sd, float* __restrict__ blob, int accumulate) {
+    __shared__ float ps[8][32];
+    const int stride = n_acc * 256 + n_vec * 16 + 16;
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (idx < stride) {      // four independent partial sums (loads in flight), combined in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int wv = grp;
+        for (; wv + 24 < n_waves; wv += 32) {
+            s0 += part[(size_t)wv * stride + idx];
+            s1 += part[(size_t)(wv + 8) * stride + idx];
+            s2 += part[(size_t)(wv + 16) * stride + idx];
+            s3 += part[(size_t)(wv + 24) * stride + idx];
+        }
+        for (; wv < n_waves; wv += 8) s0 += part[(size_t)wv * stride + idx];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    ps[grp][o] = s;
+    __syncthreads();
+    if (grp != 0 || idx >= stride) return;
+    int dst = -1;
+    if (idx < n_acc * 256) {
+        const int k = idx >> 8, lane = (idx & 255) >> 2, r = idx & 3;
+        const int i = 4 * (lane >> 4) + r, n = lane & 15;
+        const AccDesc d = ad[k];
+        if (i < d.nrows && n < d.ncols && n >= d.n0) dst = d.mat_off + (d.row0 + i) * d.ld + d.col0 + n;
+    } else if (idx < n_acc * 256 + n_vec * 16) {
+        const int k = (idx - n_acc * 256) >> 4, i = (idx - n_acc * 256) & 15;
+        const VecDesc d = vd[k];
+        if (i < d.nrows) dst = d.off + (d.row0 + i) * d.stride;
+    } else {
+        const int k = idx - n_acc * 256 - n_vec * 16;
+        if (k < n_scal) dst = sd[k];
+    }
+    if (dst < 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += ps[k][o];
+    blob[dst] = accumulate ? blob[dst] + t : t;      // accumulate: parameters that several passes contribute to (each pass in stream order)
+}
+
+__global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * 30) return;
+    const int g = idx / 30, c = idx - g * 30;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += part[((size_t)g * T + t) * 32 + (c < 16 ? c : c)];
+    r_out[idx] = s;
+}
+
+// sum over the 16 lanes of a DPP row (all lanes end with the total)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
