@@ -2240,7 +2240,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
-        k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);
+        k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);    // 2 .. 12 workgroups per CU: +-1 %
     } else if (c->use_fast && a.sta_user != nullptr && (!no_bip || x_latent_out != nullptr)) {
         // the production configuration: uniform 8 / 15-degree graphs, station processing order; the static edge_attr is registered
         // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])

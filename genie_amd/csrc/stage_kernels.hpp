@@ -935,8 +935,11 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
     const float* lscal = lbias + G2_BIAS * 16;
     const float a2 = lscal[0], ab1 = lscal[1];
+    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
+    const int jl = lane >> 2, ql = lane & 3;      // (node, 16-B chunk) this lane LOADS: four consecutive lanes read one 64-B row
+    float* ts = tsc + (threadIdx.x >> 6) * 16 * 36;
     const long long ntiles = (a.Pn + 15) / 16;
     for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
          tile += (long long)gridDim.x * (blockDim.x >> 6)) {
@@ -946,34 +949,45 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
         const long long pr = tile * 16 + j;
         const bool valid = pr < a.Pn;
         const long long p = valid ? pr : a.Pn - 1;
+        // rows are loaded, summed and activated in the ROW layout (lane = 4 node + chunk: the four lanes of a node read one 64-B
+        // row, as in k_stage2_ord), then cross the wave's LDS scratch into the MFMA layout for fc1
+        const long long prl = tile * 16 + jl;
+        const bool valid_l = prl < a.Pn;
+        const long long pl = valid_l ? prl : a.Pn - 1;
         f32x4 o[2];
-        o[0] = *(const f32x4*)(a.c + p * ROWC + 4 * q);
-        o[1] = *(const f32x4*)(a.c + p * ROWC + 16 + 4 * q);
+        o[0] = *(const f32x4*)(a.c + pl * ROWC + 4 * ql);
+        o[1] = *(const f32x4*)(a.c + pl * ROWC + 16 + 4 * ql);
         const float mq = a.mask[p * 4 + q];
         const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
         f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
         {
-            const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
-            gather_sum16<false>(a.wu + 4 * q, ROWW, a.sta_col, eb, ee, n1);
+            const int eb = a.sta_rowptr[pl], ee = a.sta_rowptr[pl + 1];
+            gather_sum16<false>(a.wu + 4 * ql, ROWW, a.sta_col, eb, ee, n1);
             o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
         }
         {
-            const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
-            gather_sum16<false>(a.wv + 4 * q, ROWW, a.src_col, eb, ee, n2);
+            const int eb = a.src_rowptr[pl], ee = a.src_rowptr[pl + 1];
+            gather_sum16<false>(a.wv + 4 * ql, ROWW, a.src_col, eb, ee, n2);
             o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
         }
         o[0] = prelu4u(o[0], a2);
         o[1] = prelu4u(o[1], a2);
-        if (a.x_latent != nullptr && valid) {
-            float* xl = a.x_latent + p * 30;
+        if (a.x_latent != nullptr && valid_l) {
+            float* xl = a.x_latent + pl * 30;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (4 * q + r < 15) {
-                    xl[4 * q + r] = o[0][r];
-                    xl[15 + 4 * q + r] = o[1][r];
+                if (4 * ql + r < 15) {
+                    xl[4 * ql + r] = o[0][r];
+                    xl[15 + 4 * ql + r] = o[1][r];
                 }
             }
         }
+        *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
+        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
+        GSYNC();
+        o[0] = *(const f32x4*)(ts + j * 36 + 4 * q);
+        o[1] = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+        GSYNC();        // the scratch is rewritten by the next tile of this wave
         f32x4 bp[2];
         bp[0] = *(const f32x4*)(lbias + 0 * 16 + 4 * q);
         bp[1] = *(const f32x4*)(lbias + 1 * 16 + 4 * q);
