@@ -1158,6 +1158,7 @@ struct genie_ctx {
     // station processing order (genie_set_station_order): internal -> caller's station, its inverse, the station graph in
     // internal labels, the per-station edge terms in internal order; null = the caller's order
     int32_t *sta_perm, *sta_inv, *sta_rowptr_p, *sta_col_p;
+    int32_t* sta_ident;        // 0 .. S-1: the station order of the training forward (pre-activations are stored in the caller's order)
     float* ebias_sta_p;
     float* ea_int; const float* ea_user;   // genie_set_static_edge_attr: processing-order copy of the caller's static edge_attr
     float* ea_tmp;             // ... of an edge_attr that is not the registered one (permuted per call)
@@ -1805,7 +1806,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; c->xs_mm_copy = 0;
     c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr; c->abs_dirty = false;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
-    c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr;
+    c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr; c->sta_ident = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr;
     c->pcsr = false; c->pcsr_h2 = false;
@@ -2045,7 +2046,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
-                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp};
+                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident};
     for (void* p : ptrs) (void)hipFree(p);
     delete c;
     return GENIE_OK;
@@ -2236,7 +2237,20 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     a.ea_int = (sta_order_on(c) && c->ea_int && c->ea_user == edge_attr) ? c->ea_int : nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-    if (c->force_generic && !c->pcsr) {
+    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && c->use_h2 && c->src_tab != nullptr && !no_bip) {
+        // training forward on the reference's kNN graphs: the production stage 2 in the CALLER's station order (identity
+        // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass
+        if (!c->sta_ident) {
+            std::vector<int32_t> id((size_t)c->S);
+            for (int i = 0; i < c->S; ++i) id[i] = i;
+            HIP_TRY(hipMalloc((void**)&c->sta_ident, sizeof(int32_t) * id.size()));
+            HIP_TRY(hipMemcpy(c->sta_ident, id.data(), sizeof(int32_t) * id.size(), hipMemcpyHostToDevice));
+        }
+        a.sta_user = c->sta_ident; a.ea_int = edge_attr; a.wgmap = 0;
+        const int grid = da_grid(c, n_tiles, c->bpc2o);
+        if (x_latent_out) k_stage2_ord<8, 15, true, false, true><<<grid, 256, 0, st>>>(a);
+        else k_stage2_ord<8, 15, false, false, true><<<grid, 256, 0, st>>>(a);
+    } else if (c->force_generic && !c->pcsr) {
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;

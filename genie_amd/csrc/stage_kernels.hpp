@@ -391,7 +391,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
         pu = g * S + sta_user[(int)(p - g * S)];
     }
     const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
-    if (sta_user != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));      // the message mask of stage 2 (module.py:226)
+    if (mm != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));            // the message mask of stage 2 (module.py:226)
     const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
     store_split_row(out, rows, p, v);
 }
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ float row_sum16_tree(float v) {      // lane 0 of eve
 // Measured and dropped: other positions of the three load bursts (0.2627 / 0.2650 / 0.2649 ms), waves of a
 // workgroup phased half an iteration apart by barriers (0.262 -> 0.290), streamed rows two tiles ahead (246 VGPRs, 0.226 -> 0.240),
 // MFMA-layout loads (0.262 vs 0.226), station rows staged in LDS behind a barrier (0.282 -> 0.299 after a cold stage 1).
-template <int KS, int KP, bool XL, bool NB = false>
+template <int KS, int KP, bool XL, bool NB = false, bool SAVE = false>      // SAVE: training forward (pre-activations kept)
 __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -1156,11 +1156,18 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
 #pragma unroll
         for (int k = 0; k < KP; ++k) n2 += rows.rv[k];
         f32x4 o[2];
-        o[0] = prelu4u(fma4(n1, 1.f / (float)KS, sA.o[0]), a2);
-        o[1] = prelu4u(fma4(n2, 1.f / (float)KP, sA.o[1]), a2);
+        o[0] = fma4(n1, 1.f / (float)KS, sA.o[0]);
+        o[1] = fma4(n2, 1.f / (float)KP, sA.o[1]);
         float mq = sA.mq, eq = sA.eq;
         const int s_l = tb_c * 16 + jl;              // the node this lane loaded (not the node it holds in the MFMA layout)
         const bool valid_l = s_l < S;
+        if (SAVE && valid_l) {       // at the caller's product-node index, as 16-float blocks [o1 | o2]
+            const size_t pu = (size_t)g_c * S + a.sta_user[s_l];
+            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + pu) * 16 + 4 * ql) = o[0];
+            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + pu) * 16 + 4 * ql) = o[1];
+        }
+        o[0] = prelu4u(o[0], a2);
+        o[1] = prelu4u(o[1], a2);
         const f32x4 ol0 = o[0], ol1 = o[1];
         if (!NB) {      // row layout -> MFMA layout through the wave's LDS scratch: node r's row = [o1 (16) | o2 (16) | edge_attr (3) | gated mask]
             *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
@@ -1194,6 +1201,8 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
                 bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
                 bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
             } else bp[t] += o[0] + o[1] + eq;
+            if (SAVE && tb_c * 16 + j < S)
+                *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + (size_t)g_c * S + a.sta_user[tb_c * 16 + j]) * 16 + 4 * q) = bp[t];
             bp[t] = prelu4u(bp[t], ab1);
             // (3) second / third burst, behind the first / second output tile of fc1
             asm volatile("" : "+v"(bp[t]), "+v"(idv_n));
