@@ -1855,7 +1855,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
         // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
         c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
-        c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : (c->s2_wgmap ? std::min(2, std::max(1, occo)) : std::max(1, occo));
+        c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occo));     // round 3, after the f16x2 stage 1: 2 beat 3 at 200 stations too (window 0.593 -> 0.588 ms)
         // the reference's kNN graphs (8 station / 15 source neighbours everywhere): pipelined kernels k_stage1_h2 / k_stage2_ord
         c->use_fast = c->ks_uni == 8 && c->kp_uni == 15;
         // f16x2 stage 1: 24-bit multiplicands (64-bit row offsets are a template variant); GENIE_S1=f32 = the generic fp32-MFMA
@@ -1864,7 +1864,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
                      !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
         // 4 workgroups per CU in the grid, one resident: a workgroup held up by a tail kernel of the previous window then costs a
         // quarter of a share, not a whole one (pipelined window 0.877 -> 0.866 ms; no effect on the kernel alone)
-        c->bpc1b = 4;
+        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? atoi(e) : 4;
     }
 #if GENIE_TUNING
     {
