@@ -1862,9 +1862,10 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // kernels, the A/B reference
         c->use_h2 = (c->use_fast && n_grid_ext < (1 << 24) && (long long)n_sta * XROW < (1 << 24) &&
                      !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
-        // 4 workgroups per CU in the grid, one resident: a workgroup held up by a tail kernel of the previous window then costs a
-        // quarter of a share, not a whole one (pipelined window 0.877 -> 0.866 ms; no effect on the kernel alone)
-        c->bpc1b = (e = getenv("GENIE_BPC1B")) ? atoi(e) : 4;
+        // one workgroup per CU = fully persistent: with the f16x2 stage 1 and tails batched 16 windows at a time this beats the 4
+        // per CU of rounds 1-2 (window 0.5937 -> 0.5796 and 0.5663 -> 0.5532 ms on two boxes; 2: 0.5637, 3: 0.561, 6: 0.5726,
+        // 8: 0.579; the weight image is staged once per CU instead of four times)
+        c->bpc1b = 1;
     }
 #if GENIE_TUNING
     {
