@@ -54,9 +54,6 @@ F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16
 TRAFFIC_SOURCE = "profiles/r03_y_pmc_stage_kernels.txt"
 TRAFFIC_CFG2 = {"k_stage1": (2.0 * (1.476e5 + 3.127e4) + (5.000e5 + 7.031e4)) * 1024.0,     # k_split_rows_g + k_stage1_h2
                 "k_stage2": (2.0 * 5.553e5 + 1.631e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
-# one GPU on the sharded workload (bench.py --gpus 1 --mode sharded --config cfg4_2000x50k), for the N > 1 line's speed-up
-ONE_GPU_CFG4 = {"ms_per_step": 37.80, "source": "profiles/r02_i_bench_cfg4_one_gpu.json (this code path with --gpus 1; the N = 1 line of this bench "
-                                                 "measures it live as sharded_workload_on_one_gpu)"}
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -329,6 +326,28 @@ def main_stream(a, geom, nq, rank, world, dev, dist, emit=True):
     return out
 
 
+def single_rank_rccl(dev):
+    """A world-size-1 RCCL ("nccl") process group on its own TCP store: `--gpus 1 --mode sharded` and the one-GPU legs of the other
+    lines then drive the sharded path through the device collectives RCCL executes at N > 1 (all_to_all_single with split sizes
+    into workspace views, all_gather_into_tensor, communication / tail streams) instead of skipping them. Returns
+    (torch.distributed or None, error text or None)."""
+    import socket
+    import torch.distributed as dist
+    if not dist.is_available():
+        return None, "torch.distributed is not available"
+    if dist.is_initialized():
+        return dist, None
+    try:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+        return dist, None
+    except Exception as e:          # (the line is still produced, with the reason)
+        return None, repr(e)[:200]
+
+
 def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     """ONE window per step, product graph sharded over source nodes across the ranks (genie_amd/dist.py): per window one
     halo all-to-all (64 B per halo product node; issued as soon as stage 1 has produced the rows other ranks need, under the
@@ -337,6 +356,9 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     of the apply loop are independent, as in the N = 1 pipeline)."""
     from genie_amd import dist as gdist, engine
     S, G = geom.n_sta, geom.n_grid
+    rccl_err = None
+    if dist is None and world == 1:
+        dist, rccl_err = single_rank_rccl(dev)
     torch.manual_seed(0)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev).eval()
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
@@ -417,7 +439,9 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "source-node sharding x%d (halo all-to-all + all-gather per window, %s)"
                                   % (world, "sequential" if a.no_overlap else "exchange overlapped with compute"),
-                   "backend": "nccl (RCCL)" if dist is not None else "none", "rccl_ranks": ranks,
+                   "backend": "nccl (RCCL)" if dist is not None else "none", "rccl_ranks": ranks if dist is not None else 0,
+                   "device_collectives": bool(sp.transport.on and sp.transport.device_collectives),
+                   "rccl_single_rank_error": rccl_err,
                    "tail_pipelined": not a.no_pipeline,
                    "rank0_plan": {"n_own": p.n_own, "n_halo": p.n_halo, "send_nodes": p.n_send_nodes, "need_nodes": p.n_need_nodes,
                                   "halo_MB_in_per_window": round(halo_bytes / 1e6, 1)}},
@@ -684,7 +708,7 @@ def main():
                                               "rank0_phase_ms_sequential": o1["rank0_phase_ms_sequential"],
                                               "source": "measured live on rank 0 after the sharded run, same code path with one rank"}
             except Exception as e:
-                out["one_gpu_same_config"] = {"error": repr(e)[:200], "fallback": ONE_GPU_CFG4}
+                out["one_gpu_same_config"] = {"error": repr(e)[:200]}
             print(json.dumps(out))
         return out
     if a.mode == "stream":
@@ -839,7 +863,9 @@ def main():
             o4 = main_sharded(a4, synthetic.Geometry(S4, G4, L=L4, n_query=nq4, seed=1), np4, nq4, 0, 1, dev, None, emit=False)
             out["sharded_workload_on_one_gpu"] = {"config": o4["config"]["workload"], "steps": a4.steps, "ms_per_step": o4["ms_per_step"],
                                                   "value": o4["value"], "unit": "picks/s", "rank0_phase_ms_sequential": o4["rank0_phase_ms_sequential"],
-                                                  "roofline_frac": o4["roofline"]["frac"]}
+                                                  "roofline_frac": o4["roofline"]["frac"], "backend": o4["config"]["backend"],
+                                                  "rccl_ranks": o4["config"]["rccl_ranks"], "device_collectives": o4["config"]["device_collectives"],
+                                                  "rccl_single_rank_error": o4["config"]["rccl_single_rank_error"]}
         except Exception as e:       # (the headline line must not depend on it)
             out["sharded_workload_on_one_gpu"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()

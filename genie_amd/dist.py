@@ -230,8 +230,10 @@ class ShardedPath(object):
     def _exchange(self, wv):
         """Pack the SEND rows, all-to-all, halo rows received in place (the halo part of `wv` is contiguous, grouped by owner)."""
         p, S = self.plan, self.n_sta
-        if p.world == 1:
-            return                      # (with several ranks EVERY rank enters the collective, also one with nothing to exchange)
+        if p.world == 1 and not self.transport.on:
+            return                      # no process group at all. (With one, EVERY rank enters the collective, also a rank with
+                                        # nothing to exchange and the single rank of a world-size-1 group: the RCCL code path of the
+                                        # 1-GPU tests and of `bench.py --gpus 1 --mode sharded`)
         blocks = wv[: p.n_own * S].view(p.n_own, S * self._pitch)
         if self._send_idx.numel():
             torch.index_select(blocks, 0, self._send_idx, out=self._send_buf)
@@ -256,7 +258,7 @@ class ShardedPath(object):
         wv = self.wv_view()
         main = torch.cuda.current_stream(self.device)
         (s0, s1), (n0, n1), n = p.r_send, p.r_need, p.n_own
-        if not self.overlap or p.world == 1:
+        if not self.overlap or (p.world == 1 and not self.transport.on):
             lp.da_stage1_range(Slice_ext, Mask_ext, 0, n, True)
             self._exchange(wv)
             lp.da_stage2_partials_range(Mask_own, edge_attr_own, 0, n)

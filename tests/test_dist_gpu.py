@@ -4,6 +4,9 @@ all-to-all on the communication stream, all-gather, replicated tail -- with one 
 * two processes sharing ONE GPU over gloo (host-staged transport): every kernel launch, stream dependency and buffer of the
   multi-GPU schedule runs for real; only the collective itself is not RCCL. Runs on the 1-GPU test box.
 * two processes on two GPUs over RCCL ("nccl"): skipped unless the box has >= 2 GPUs.
+* ONE process with a world-size-1 RCCL group: the device-collective branch of `Transport` (`all_to_all_single` with explicit
+  split sizes received into a view of the workspace, `all_gather_into_tensor`) and the overlapped schedule with its
+  communication / tail streams execute over RCCL itself on the 1-GPU box.
 Both compare every rank's result with the unsharded HIP path bit for bit, with the overlap schedule on and off.
 """
 import os
@@ -107,3 +110,71 @@ def test_sharded_path_world2_rccl_matches_unsharded():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL over xGMI); the 1-GPU box runs the gloo form above")
     _run(2, "nccl", False)
+
+
+def _worker_world1_rccl(rank, port, ret):
+    import torch.distributed as dist
+    from genie_amd import dist as gdist
+    from genie_amd import engine, synthetic
+    from tests.util import Case
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = "cuda:0"
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        S, G = 40, 900
+        geom = synthetic.Geometry(S, G, L=200e3, n_query=20, seed=41)
+        wins = [synthetic.make_window(geom, 400, seed=42, window=k) for k in range(3)]
+        wd = {k: v.to(dev) for k, v in Case("odd_33x257").weights.items()}
+        ea = torch.from_numpy(geom.edge_attr()).to(dev)
+        pos = torch.from_numpy(geom.x_grid).float().to(dev)
+        sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
+        hp = engine.HipPath(S, G, sta_csr, engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
+                            grid_order=engine.sfc_order(geom.x_grid), device=dev, sta_order=engine.sfc_order(geom.locs))
+        hp.set_weights(wd)
+        refs = [hp.path_fwd(torch.from_numpy(w["Slice"]).to(dev), torch.from_numpy(w["Mask"]).to(dev), ea, pos)[0].clone() for w in wins]
+        res = {}
+        for overlap in (True, False):
+            sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, 1, 0, dev, pos_sta=geom.locs, overlap=overlap)
+            sp.set_weights(wd)
+            res["device_collectives"] = bool(sp.transport.on and sp.transport.device_collectives)
+            p = sp.plan
+            rows = (torch.from_numpy(p.ext_global).view(-1, 1) * S + torch.arange(S).view(1, -1)).reshape(-1)
+            sp.local.ws.fill_(255)
+            ok = True
+            for piped in (False, True):
+                outs = [sp.path_fwd(torch.from_numpy(w["Slice"])[rows].to(dev), torch.from_numpy(w["Mask"])[rows].to(dev),
+                                    ea[rows.to(dev)], pos, pipelined=piped) for w in wins]
+                sp.wait_tail()
+                torch.cuda.synchronize()
+                ok = ok and all(torch.equal(o, r) for o, r in zip(outs, refs))
+            res[overlap] = ok
+            # the transport itself with data: this rank's rows sent to itself with explicit split sizes, received IN PLACE into a
+            # view of the workspace's wv region on the communication stream; all-gather of a padded per-node tensor
+            wv = sp.wv_view()
+            n = 7 * S
+            send = torch.randn((7, S * sp._pitch), device=dev)
+            with torch.cuda.stream(sp.comm_stream):
+                recv = wv[:n].view(7, S * sp._pitch)
+                sp.transport.all_to_all_rows(recv, send, [7], [7])
+                buf = send.new_empty((1, 7, S * sp._pitch))
+                sp.transport.all_gather_rows(buf, send)
+            sp.comm_stream.synchronize()
+            res["transport_%s" % overlap] = bool(torch.equal(wv[:n].reshape(7, -1), send) and torch.equal(buf[0], send))
+        ret[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_path_world1_rccl_device_collectives():
+    """RCCL executes the sharded path's collectives (world size 1: the only form one GPU allows; RCCL refuses two ranks on one
+    device): same kernels, streams and buffers as N > 1, bitwise equal to the unsharded path."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_world1_rccl, args=(_free_port(), ret), nprocs=1, join=True)
+    r = ret[0]
+    assert r["device_collectives"], "the nccl (RCCL) process group must select the device-collective transport"
+    assert r[True] and r[False], r
+    assert r["transport_True"] and r["transport_False"], r
