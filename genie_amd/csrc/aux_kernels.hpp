@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_subgraph_csr(const int32_t* __restrict_
 }
 
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst,
-                         const int32_t* __restrict__ sta_user, int S) {
+                         const int32_t* __restrict__ sta_user, int S, int np) {
     // padded rows are [15 valid, 1 pad] blocks (c has two of them, wu / wv one); rows in station processing order -> caller's order
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * ncol) return;
@@ -498,6 +498,12 @@ __global__ void k_export(const float* __restrict__ src, long long rows, int pitc
     if (sta_user != nullptr) {
         const long long g = r / S;
         ru = g * S + sta_user[(int)(r - g * S)];
+    }
+    if (np) {      // node-planar rows (DaArgs.np): chunk off / 4 of station s at [g][chunk][s] x 4 floats inside the node's block
+        const long long g = r / S;
+        const long long s = r - g * S;
+        dst[ru * ncol + cc] = src[g * S * pitch + ((long long)(off >> 2) * S + s) * 4 + (off & 3)];
+        return;
     }
     dst[ru * ncol + cc] = src[r * pitch + off];
 }

@@ -55,6 +55,10 @@
                            // spills and more rows in flight than L2 keeps: 0.313 vs 0.302 ms, fabric reads +50 %)
 #endif
 
+#ifndef GENIE_S2H_WAVES
+#define GENIE_S2H_WAVES 2  // k_stage2_h2: waves per SIMD the register budget is held to (__launch_bounds__)
+#endif
+
 #ifndef GENIE_H2_DEPTH
 #define GENIE_H2_DEPTH 6   // k_stage1_h2: row loads in flight ahead of their use (3 .. 8 measured equal)
 #endif
@@ -347,6 +351,16 @@ constexpr int H2_NBIAS = 6;     // init_trns, l1_t1_2, l1_t2_2, l2_t1_1, l2_t2_1
 constexpr int H2_IMG_FLOATS = H2_FRAGS * 256 + H2_NBIAS * 32 + 16;
 constexpr int H2_TBL = H2_FRAGS * 512 + H2_NBIAS * 32 + 16;
 
+// STAGE 2 on the 16-bit matrix pipe (k_stage2_h2): 1-KB A fragments of v_mfma_f32_16x16x32_f16 for Bipartite_ReadIn.fc1, lane
+// (i = lane & 15, kg = lane >> 4) holds the 8 K slots (kg, e) of output row 16 t + i. K slots of the x_latent step: e < 4 = channel
+// 4 kg + e of the first half (o1, 15 channels + 1 zero), e >= 4 = channel 4 kg + e - 4 of the second half; of the edge_attr step:
+// group 0 = {e0, e1, e2, - | e0, e1, e2, -} (first | second pieces), group 1 = {e0, e1, e2 (/ 16), - | -}; see k_ea_frag.
+constexpr int S2H_FW = 0;       // + 2 t + piece
+constexpr int S2H_FE = 4;       // + t
+constexpr int S2H_FRAGS = 6;
+constexpr int S2H_IMG_FLOATS = S2H_FRAGS * 256 + 32 + 16;        // fragments, fc1 bias (32), slopes {DataAggregation.activate2, activate1}
+constexpr int S2H_TBL = S2H_FRAGS * 512 + 32 + 16;
+
 // table entry: raw-mirror offset | piece << 28, or -1 for zero. Slot (h, e) of K-step kb (0/1) of a 32-channel block is
 // channel 16 kb + 8 (e >> 2) + 4 h + (e & 3): registers 8kb..8kb+7 of the producing accumulator (see k_stage1_h2).
 // Piece codes: 0 = W0 = rn16(W); 1 = rn16(16 (W - W0)) (the product it enters takes x0 / 16 as its other operand, which keeps
@@ -421,6 +435,38 @@ void build_h2_table(std::vector<int32_t>& tbl) {
     int32_t* scal = bias + H2_NBIAS * 32;
     const int sv[6] = {W_DA_ACT, W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22};
     for (int k = 0; k < 6; ++k) scal[k] = g_params[sv[k]].off;
+}
+
+// k_stage2_h2's image: same entry format as build_h2_table (k_pack_h2 writes both)
+void build_s2h_table(std::vector<int32_t>& tbl) {
+    tbl.assign(S2H_TBL, -1);
+    auto put = [&](int f, int i, int kg, int e, int piece, int off) {
+        tbl[((size_t)f * 64 + (kg * 16 + i)) * 8 + e] = off < 0 ? -1 : (off | (piece << 28));
+    };
+    const int W = g_params[W_BP_FC1_W].off;
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 16; ++i) {
+            const int row = 16 * t + i;
+            if (row >= 30) continue;
+            for (int kg = 0; kg < 4; ++kg)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = 4 * kg + (e & 3);                  // channel inside its 15-wide half
+                    if (ch < 15) {
+                        const int off = W + row * 33 + (e < 4 ? ch : 15 + ch);
+                        put(S2H_FW + 2 * t + 0, i, kg, e, 0, off);
+                        put(S2H_FW + 2 * t + 1, i, kg, e, 1, off);
+                    }
+                    if ((e & 3) < 3) {                                // edge_attr step
+                        const int off = W + row * 33 + 30 + (e & 3);
+                        if (kg == 0) put(S2H_FE + t, i, kg, e, 0, off);                  // W0 x first / second pieces
+                        if (kg == 1 && e < 4) put(S2H_FE + t, i, kg, e, 1, off);          // W1' x (first pieces / 16)
+                    }
+                }
+        }
+    int32_t* bias = tbl.data() + (size_t)S2H_FRAGS * 512;
+    for (int i = 0; i < 30; ++i) bias[i] = g_params[W_BP_FC1_B].off + i;
+    bias[32] = g_params[W_DA_ACT2].off;
+    bias[33] = g_params[W_BP_ACT1].off;
 }
 
 void build_plans(StagePlan& p1, StagePlan& p2) {
@@ -925,6 +971,9 @@ struct DaArgs {
     int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
     int rev;                   // k_stage2_fast: sweep every XCD's chunk backwards (the rows stage 1 wrote last are read first)
     int wgmap;                 // k_stage2_ord: blocks of 4 source nodes per workgroup, one node per wave (see the kernel)
+    int np;                    // c / wv rows are NODE-PLANAR (k_stage1_h2 writes, k_stage2_h2 reads): inside the block of a source node,
+                               // chunk q (16 B) of all S stations is contiguous: c [g][8][S] x 16 B, wv [g][4][S] x 16 B
+    const unsigned* ea_frag;   // k_stage2_h2: edge_attr as B fragments (k_ea_frag), node-planar [g][2][S] x 16 B, processing order
 };
 
 // wave-uniform work item iterator. XCD x (blockIdx % 8, observed dispatch placement: used for speed only) sweeps
@@ -1169,9 +1218,21 @@ struct genie_ctx {
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
     int use_fast;              // the reference's kNN graphs (ks_uni == 8 && kp_uni == 15): the pipelined kernels k_stage1_h2 / k_stage2_ord apply
     int bpc2o;                 // workgroups of k_stage2_ord per CU (its occupancy: three per CU)
+    int bpc2h;                 // workgroups of k_stage2_h2 per CU
     int s2_wgmap;              // k_stage2_ord: blocks of 4 source nodes per workgroup (large station counts)
     int bpc1b;                 // workgroups of k_stage1_h2 per CU in the grid (one is resident; more = dynamic balancing by the dispatcher)
-    int use_h2;                // stage 1 on the 16-bit matrix pipe (k_stage1_h2); GENIE_S1=f32 selects the fp32-MFMA kernels
+    int use_h2;                // the SHAPE admits the f16x2 kernels (k_stage1_h2 / k_stage2_h2): uniform 8 / 15-degree graphs, 24-bit
+                               // multiplicands; whether they run is h2_on(): precision mode + the fp16 range guard below
+    int prec_mode;             // genie_set_stage_precision: 0 = auto (f16x2 while the range guard holds, else fp32 MFMA), 1 = f16x2, 2 = fp32
+    bool range_ok;             // fp16 range guard (k_h2_range, evaluated at every weight commit): every hidden state the f16x2 kernels
+                               // split into fp16 pieces is bounded below 60 000 for inputs in [-1, 1], and so is every weight
+    float range_act, range_w;  // ... the two bounds it found (largest hidden-state bound, largest weight magnitude incl. the 16 x forms)
+    float* d_range; float* h_range;     // device result / pinned host copy of k_h2_range
+    int32_t* d_s2htbl;         // k_pack_h2 source table of k_stage2_h2's image
+    float* packed_s2h;         // f16x2 weight image of k_stage2_h2 (Bipartite_ReadIn.fc1)
+    unsigned *ea_frag, *ea_frag_tmp;    // edge_attr as B fragments of k_stage2_h2 (k_ea_frag): of the registered static edge_attr / of any other one
+    bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
+    int xs_sta_order;          // genie_embed_window_split: the station-order state its split rows were written under
     // workspace offsets (floats)
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
@@ -1185,9 +1246,22 @@ namespace {
 // The station processing order is honoured by k_split_rows / the embedding's split rows, k_stage1_h2 (through the relabelled
 // station graph) and k_stage2_ord: active only while those are the kernels that run (use_absolute_pos together with the
 // edge-feature variant takes the generic stage-1 kernel).
-bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !c->use_h2); }
+// The f16x2 kernels run when the shape admits them AND the precision mode says so: auto = while the fp16 range guard holds for the
+// committed weights (k_h2_range), else the fp32-MFMA kernels take over -- no environment variable, no non-finite output.
+bool h2_on(const genie_ctx* c) { return c->use_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
+bool pcsr_h2_on(const genie_ctx* c) { return c->pcsr_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
+bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !h2_on(c)); }
 bool sta_order_on(const genie_ctx* c) {
-    return c->sta_perm != nullptr && !c->pcsr && c->use_h2 && !abs_generic(c) && !c->force_generic;
+    return c->sta_perm != nullptr && !c->pcsr && h2_on(c) && !abs_generic(c) && !c->force_generic;
+}
+
+// k_stage2_h2 is the stage 2 of the production configuration (the reference's kNN graphs in station processing order); the stage 1
+// that feeds it writes c / wv node-planar (DaArgs.np). Both launch sites ask this.
+bool s2h_on(const genie_ctx* c) {
+#if GENIE_TUNING
+    { static const bool old_pair = getenv("GENIE_S2_OLD") != nullptr; if (old_pair) return false; }   // A/B: row layout + k_stage2_ord
+#endif
+    return c->use_fast && sta_order_on(c);
 }
 
 constexpr int GENIE_NSLOT = 33;  // copies of the G-sized per-window buffers (genie_set_slot): two batches of 16 windows in flight + one
@@ -1248,6 +1322,7 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
     k_pack_all<<<c->pack_blocks, 256, 0, st>>>(c->raw, (const PackPlan*)c->d_packplans, NPLAN);
     k_pack_h2<<<(H2_FRAGS * 64 + H2_NBIAS * 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_h2tbl, c->packed_h2, H2_FRAGS,
                                                                                H2_NBIAS * 32 + 16);
+    k_pack_h2<<<(S2H_FRAGS * 64 + 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_s2htbl, c->packed_s2h, S2H_FRAGS, 32 + 16);
     if (c->has_edges) {
         k_edge_bias<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
                                                             c->mpos_sta, c->S, c->ebias_sta);
@@ -1259,6 +1334,29 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         }
     }
     HIP_TRY(hipGetLastError());
+    if (c->use_h2 || c->pcsr_h2) {
+        // fp16 range guard of the f16x2 kernels: rigorous per-channel bounds of every hidden state they split into fp16 pieces, from
+        // the weights just committed (inputs in [-1, 1]; the absolute-position / edge-term tables by their actual maxima). One tiny
+        // launch and a 16-byte read-back per weight commit: the only host synchronisation of the library, and not in the window loop.
+        RangeArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.raw = c->raw;
+        const int ids[RG_N] = {W_DA_INIT_W, W_DA_INIT_B, W_DA_INIT_ABS, W_DA_L1T12_W, W_DA_L1T12_B, W_DA_L1T22_W, W_DA_L1T22_B, W_DA_L2T11_W,
+                               W_DA_L2T11_B, W_DA_L2T21_W, W_DA_L2T21_B, W_DA_L2T12_W, W_DA_L2T12_B, W_DA_L2T22_W, W_DA_L2T22_B, W_DA_ACT,
+                               W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22, W_DA_ACT2, W_BP_FC1_W};
+        for (int k = 0; k < RG_N; ++k) ra.off[k] = g_params[ids[k]].off;
+        ra.abs_sta = c->abs_sta; ra.n_abs_sta = c->abs_sta ? c->S * 4 : 0;
+        ra.abs_src = c->abs_src; ra.n_abs_src = c->abs_src ? (long long)c->G_ext * 4 : 0;
+        ra.eb_sta = c->has_edges ? c->ebias_sta : nullptr; ra.n_eb_sta = c->has_edges ? (long long)c->S * 48 : 0;
+        ra.eb_src = c->has_edges ? c->ebias_src : nullptr; ra.n_eb_src = c->has_edges ? (long long)c->G * 48 : 0;
+        ra.out = c->d_range;
+        k_h2_range<<<1, 256, 0, st>>>(ra);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_range, c->d_range, sizeof(float) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        c->range_act = c->h_range[0]; c->range_w = c->h_range[1];
+        c->range_ok = c->h_range[2] != 0.f;
+    }
     c->dirty = false;
     return GENIE_OK;
 }
@@ -1800,6 +1898,13 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->d_h2tbl, sizeof(int32_t) * tbl.size()));
         HIP_TRY(hipMemcpy(c->d_h2tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_h2, sizeof(float) * H2_IMG_FLOATS));
+        build_s2h_table(tbl);
+        HIP_TRY(hipMalloc((void**)&c->d_s2htbl, sizeof(int32_t) * tbl.size()));
+        HIP_TRY(hipMemcpy(c->d_s2htbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->packed_s2h, sizeof(float) * S2H_IMG_FLOATS));
+        HIP_TRY(hipMalloc((void**)&c->d_range, sizeof(float) * 4));
+        HIP_TRY(hipHostMalloc((void**)&c->h_range, sizeof(float) * 4));
+        c->range_ok = true; c->prec_mode = 0;
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
@@ -1855,13 +1960,16 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
         // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
         c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
+        {
+            int occh = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occh, k_stage2_h2<false, false>, 256, 0));
+            c->bpc2h = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occh);
+        }
         c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occo));     // round 3, after the f16x2 stage 1: 2 beat 3 at 200 stations too (window 0.593 -> 0.588 ms)
         // the reference's kNN graphs (8 station / 15 source neighbours everywhere): pipelined kernels k_stage1_h2 / k_stage2_ord
         c->use_fast = c->ks_uni == 8 && c->kp_uni == 15;
-        // f16x2 stage 1: 24-bit multiplicands (64-bit row offsets are a template variant); GENIE_S1=f32 = the generic fp32-MFMA
-        // kernels, the A/B reference
-        c->use_h2 = (c->use_fast && n_grid_ext < (1 << 24) && (long long)n_sta * XROW < (1 << 24) &&
-                     !((e = getenv("GENIE_S1")) && strcmp(e, "f32") == 0));
+        // f16x2 kernels: 24-bit multiplicands (64-bit row offsets are a template variant). Whether they run: h2_on()
+        c->use_h2 = (c->use_fast && n_grid_ext < (1 << 24) && (long long)n_sta * XROW < (1 << 24));
         // one workgroup per CU = fully persistent: with the f16x2 stage 1 and tails batched 16 windows at a time this beats the 4
         // per CU of rounds 1-2 (window 0.5937 -> 0.5796 and 0.5663 -> 0.5532 ms on two boxes; 2: 0.5637, 3: 0.561, 6: 0.5726,
         // 8: 0.579; the weight image is staged once per CU instead of four times)
@@ -1919,8 +2027,7 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
         HIP_TRY(hipMemcpy(r2.data(), p_src_rowptr, sizeof(int32_t) * r2.size(), hipMemcpyDeviceToHost));
         int m1 = 0, m2 = 0;
         for (long long i = 0; i < n_prod; ++i) { m1 = std::max(m1, r1[i + 1] - r1[i]); m2 = std::max(m2, r2[i + 1] - r2[i]); }
-        const char* e = getenv("GENIE_S1");
-        c->pcsr_h2 = m1 <= 8 && m2 <= 15 && !(e && strcmp(e, "f32") == 0);
+        c->pcsr_h2 = m1 <= 8 && m2 <= 15;
     }
     c->use_fast = c->use_h2 = 0;
     c->ks_uni = c->kp_uni = -1;
@@ -1981,10 +2088,11 @@ int genie_set_scale_t(genie_ctx* c, float scale_t) {
 
 int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_station_order: null context");
-    void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int};
+    void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int, c->ea_tmp, c->ea_frag, c->ea_frag_tmp};
     for (void* q : old) (void)hipFree(q);
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr;
-    c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
+    c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr; c->ea_frag = c->ea_frag_tmp = nullptr;
+    c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;      // split rows of an embedding made under the previous order are void
     c->dirty = true; c->abs_dirty = true;
     if (!order_host || c->pcsr) return GENIE_OK;
     const int S = c->S;
@@ -2018,8 +2126,10 @@ int genie_set_static_edge_attr(genie_ctx* c, const float* edge_attr, void* strea
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_static_edge_attr: null context");
     c->ea_user = nullptr;
     if (!edge_attr || !c->sta_perm || c->pcsr) return GENIE_OK;       // nothing to prepare without a station processing order
-    if (!c->ea_int) HIP_TRY(hipMalloc((void**)&c->ea_int, sizeof(float) * 3 * (size_t)c->P));
-    k_permute_sta_rows<<<(unsigned)((c->P * 3 + 255) / 256), 256, 0, (hipStream_t)stream>>>(edge_attr, c->P, 3, c->sta_inv, c->S, c->ea_int);
+    if (!c->use_h2) return GENIE_OK;      // only k_stage2_h2 honours the station processing order in stage 2
+    // k_stage2_h2 reads the static edge_attr as ready-made B fragments (32 B per product node, processing order)
+    if (!c->ea_frag) HIP_TRY(hipMalloc((void**)&c->ea_frag, 32 * (size_t)c->P));
+    k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, (hipStream_t)stream>>>(edge_attr, c->P, c->S, c->sta_perm, c->ea_frag);
     HIP_TRY(hipGetLastError());
     c->ea_user = edge_attr;
     return GENIE_OK;
@@ -2047,8 +2157,10 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
-                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident};
+                    c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
+                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg};
     for (void* p : ptrs) (void)hipFree(p);
+    if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
     return GENIE_OK;
 }
@@ -2104,15 +2216,16 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     const long long n_tiles = (long long)a.G * c->T;
     a.slice = slice; a.mask = mask; a.packed = c->packed[0];
     a.dbg_h0 = dbg_h0; a.dbg_h1 = dbg_h1;
+    c->ws_np = false;
     float* dbg_tmp = nullptr;
     if ((dbg_h0 || dbg_h1) && sta_order_on(c)) {
         HIP_TRY(hipMalloc((void**)&dbg_tmp, sizeof(float) * 90 * (size_t)c->P));
         if (dbg_h0) a.dbg_h0 = dbg_tmp;
         if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
     }
-    if (((c->force_generic && !c->use_h2) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
+    if (((c->force_generic && !h2_on(c)) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
-    } else if (c->pcsr && c->pcsr_h2) {
+    } else if (c->pcsr && pcsr_h2_on(c)) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
@@ -2123,9 +2236,11 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
-    } else if (c->use_h2) {
+    } else if (h2_on(c)) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
-        const bool presplit = (c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws) || !do_split;   // genie_embed_window_split, one-shot
+        // genie_embed_window_split, one-shot; its rows count only if they were written under the station-order state of THIS call
+        // (a training forward, or other weights whose range guard flipped the kernels, re-split in their own order)
+        const bool presplit = (c->xs_slice == slice && c->xs_mask == mask && c->xs_ws == ws && c->xs_sta_order == (sta_order_on(c) ? 1 : 0)) || !do_split;
         if (do_split) { c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; }
         float* mmw = (float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
         if (presplit && do_split && sta_order_on(c) && c->xs_mm_copy != c->slot % GENIE_NBIG) {
@@ -2144,6 +2259,8 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P_ext * (long long)XPC;
+        a.np = s2h_on(c) ? 1 : 0;
+        c->ws_np = a.np != 0;
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, H2_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
@@ -2236,9 +2353,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     const long long n_tiles = (long long)a.G * c->T;
     if (n_tiles == 0) return GENIE_OK;
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
-    a.ea_int = (sta_order_on(c) && c->ea_int && c->ea_user == edge_attr) ? c->ea_int : nullptr;
+    a.ea_int = nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && c->use_h2 && c->src_tab != nullptr && !no_bip) {
+    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && h2_on(c) && c->src_tab != nullptr && !no_bip) {
         // training forward on the reference's kNN graphs: the production stage 2 in the CALLER's station order (identity
         // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass
         if (!c->sta_ident) {
@@ -2259,16 +2376,29 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     } else if (c->use_fast && a.sta_user != nullptr && (!no_bip || x_latent_out != nullptr)) {
         // the production configuration: uniform 8 / 15-degree graphs, station processing order; the static edge_attr is registered
         // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])
-        if (!no_bip && a.ea_int == nullptr) {
+        a.wgmap = no_bip ? 0 : c->s2_wgmap;
+        if (no_bip) {      // last pass of the association heads: row-layout c / wu / wv written by k_assoc_b
+            k_stage2_ord<8, 15, true, true><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
+#if GENIE_TUNING
+        } else if (!s2h_on(c)) {     // A/B reference (GENIE_S2_OLD): the round-3 stage 2 on row-layout c / wv
             if (!c->ea_tmp) HIP_TRY(hipMalloc((void**)&c->ea_tmp, sizeof(float) * 3 * (size_t)c->P));
             k_permute_sta_rows<<<(unsigned)((c->P * 3 + 255) / 256), 256, 0, st>>>(edge_attr, c->P, 3, c->sta_inv, c->S, c->ea_tmp);
             a.ea_int = c->ea_tmp;
+            k_stage2_ord<8, 15, false><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
+#endif
+        } else {           // s2h_on(c): stage 1 of this window wrote c / wv node-planar
+            a.np = 1; a.packed = c->packed_s2h;
+            if (c->ea_frag && c->ea_user == edge_attr) a.ea_frag = c->ea_frag;
+            else {
+                if (!c->ea_frag_tmp) HIP_TRY(hipMalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
+                k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(edge_attr, c->P, c->S, c->sta_perm, c->ea_frag_tmp);
+                a.ea_frag = c->ea_frag_tmp;
+            }
+            const bool big = c->P_ext * 128 >= (1ll << 32);
+            const int grid = da_grid(c, n_tiles, c->bpc2h);
+            if (x_latent_out) { if (big) k_stage2_h2<true, true><<<grid, 256, 0, st>>>(a); else k_stage2_h2<true, false><<<grid, 256, 0, st>>>(a); }
+            else { if (big) k_stage2_h2<false, true><<<grid, 256, 0, st>>>(a); else k_stage2_h2<false, false><<<grid, 256, 0, st>>>(a); }
         }
-        const int grid = da_grid(c, n_tiles, c->bpc2o);
-        a.wgmap = no_bip ? 0 : c->s2_wgmap;
-        if (no_bip) k_stage2_ord<8, 15, true, true><<<grid, 256, 0, st>>>(a);
-        else if (x_latent_out) k_stage2_ord<8, 15, true><<<grid, 256, 0, st>>>(a);
-        else k_stage2_ord<8, 15, false><<<grid, 256, 0, st>>>(a);
     }
     else
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
@@ -2580,10 +2710,14 @@ int genie_embed_window_split(genie_ctx* c, const double* pick_t, const int32_t* 
                              float* slice_out, float* mask_out, void* ws, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
-    unsigned* xs = c->use_h2 ? (unsigned*)((float*)ws + c->o_xs) : nullptr;
+    if ((rc = ensure_packed(c, (hipStream_t)stream))) return rc;       // (the range guard of the committed weights decides h2_on)
+    unsigned* xs = h2_on(c) ? (unsigned*)((float*)ws + c->o_xs) : nullptr;
     rc = embed_window_impl(c, pick_t, pick_sta, pick_phase, n_picks, t0, max_t, kernel_sig_t, dt, trv, emb_ws, slice_out, mask_out, xs,
                            stream);
-    if (rc == GENIE_OK && xs) { c->xs_slice = slice_out; c->xs_mask = mask_out; c->xs_ws = ws; c->xs_mm_copy = c->slot % GENIE_NBIG; }
+    if (rc == GENIE_OK && xs) {
+        c->xs_slice = slice_out; c->xs_mask = mask_out; c->xs_ws = ws; c->xs_mm_copy = c->slot % GENIE_NBIG;
+        c->xs_sta_order = sta_order_on(c) ? 1 : 0;
+    }
     return rc;
 }
 
@@ -3387,6 +3521,24 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
     return GENIE_OK;
 }
 
+int genie_set_stage_precision(genie_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(GENIE_ERR_ARG, "genie_set_stage_precision: mode must be 0 (auto), 1 (f16x2) or 2 (fp32)");
+    c->prec_mode = mode;
+    c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;
+    return GENIE_OK;
+}
+
+int genie_stage_precision(genie_ctx* c, int* mode, int* f16x2_active, float* act_bound, float* weight_bound, void* stream) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_stage_precision: null context");
+    int rc = ensure_packed(c, (hipStream_t)stream);        // the range guard belongs to the committed weights
+    if (rc) return rc;
+    if (mode) *mode = c->prec_mode;
+    if (f16x2_active) *f16x2_active = (c->pcsr ? pcsr_h2_on(c) : h2_on(c)) ? 1 : 0;
+    if (act_bound) *act_bound = c->range_act;
+    if (weight_bound) *weight_bound = c->range_w;
+    return GENIE_OK;
+}
+
 int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
@@ -3400,7 +3552,8 @@ int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream)
         default: return fail(GENIE_ERR_ARG, "genie_ws_export: which must be 0..2");
     }
     const long long n = rows * ncol;
-    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out, sta_order_on(c) ? c->sta_perm : nullptr, c->S);
+    k_export<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, rows, pitch, ncol, out, sta_order_on(c) ? c->sta_perm : nullptr, c->S,
+                                                                         (c->ws_np && which != 1) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

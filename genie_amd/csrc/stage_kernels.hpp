@@ -782,10 +782,15 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                 mma3<3>(o3, lw, f0, lane, hp[kb]);
             }
         }
+        // node-planar rows (a.np, read by k_stage2_h2): chunk q = 2 b + h of station sc at [g][q][sc] x 16 B inside the node's block
+        const long long npb = PCSR ? 0 : (long long)g * S;
+        const long long npl = (long long)S * 4;
         if (valid) {
+            float* cr = a.np ? a.c + npb * ROWC + (long long)h * npl + (long long)sc * 4 : a.c + p * ROWC + 4 * h;
+            const long long cs = a.np ? 2 * npl : 8;
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                *(f32x4*)(a.c + p * ROWC + 8 * b + 4 * h) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
+                *(f32x4*)(cr + b * cs) = f32x4{o3[2][4 * b], o3[2][4 * b + 1], o3[2][4 * b + 2], o3[2][4 * b + 3]};
         }
         if (a.save != nullptr && valid) { h2_save32(a.save, a.Pn, SV_UP, p, h, o3[0]); h2_save32(a.save, a.Pn, SV_VP, p, h, o3[1]); }
         o3[0] = prelu16(o3[0], a21, sel21);
@@ -814,11 +819,12 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
             }
         }
         if (valid) {
+            float* vr = a.np ? a.wv + npb * ROWW + (long long)h * npl + (long long)sc * 4 : a.wv + p * ROWW + 4 * h;
+            const long long vs = a.np ? 2 * npl : 8;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 *(f32x4*)(a.wu + p * ROWW + 8 * b + 4 * h) = f32x4{ow[0][4 * b], ow[0][4 * b + 1], ow[0][4 * b + 2], ow[0][4 * b + 3]};
-                *(f32x4*)(a.wv + p * ROWW + 8 * b + 4 * h) =
-                    f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
+                *(f32x4*)(vr + b * vs) = f32x4{ow[1][8 + 4 * b], ow[1][8 + 4 * b + 1], ow[1][8 + 4 * b + 2], ow[1][8 + 4 * b + 3]};
             }
         }
         idv = idv_n; sc = sc_n; valid = valid_n; pcur = p_n; dgs = dgs_n; dgp = dgp_n;
@@ -1222,5 +1228,337 @@ __global__ __launch_bounds__(256, GENIE_S2_WAVES) void k_stage2_ord(DaArgs a) {
         it += w.stride;
         idv_c = idv_n; tb_c = tb_n;
         idv_n = idv_2; tb_n = tb_2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STAGE 2 on the 16-bit matrix pipe (k_stage2_h2, round 4): the production stage 2 of the reference's kNN graphs.
+//
+// What k_stage2_ord spent its time on (profiles/r03_zz_pmc_stage_kernels.txt, r03_y_s2_ablations.txt): 18 fp32 MFMAs of 32 cycles
+// per 16 nodes that do not overlap with vector work, a round trip through LDS per tile (row layout -> MFMA layout) in the middle
+// of the dependency chain, 64-bit scalar address arithmetic per gathered row (as many scalar as vector instructions), and 47 % of
+// all wave cycles waiting. Here
+//  * Bipartite fc1 (33 -> 30) runs as v_mfma_f32_16x16x32_f16 with fp32 operands as two fp16 pieces (the f16x2 form of stage 1:
+//    W0 x1 + W1' (x0 / 16) + W0 x0): D[channel, node] for 16 channels x 16 nodes, K = 32 = [o1 chunk | o2 chunk] x 4 lane groups:
+//    ONE K-step for all of x_latent, so a tile takes 2 x 3 MFMAs of 16 cycles + 2 for edge_attr instead of 18 x 32 cycles;
+//  * lane (m = lane & 15, kg = lane >> 4) holds channels 4 kg .. 4 kg + 3 of BOTH halves of node m's x_latent, which is the
+//    MFMA's B operand as it stands: no LDS transpose. For that the rows stage 1 writes are NODE-PLANAR: inside the block of a
+//    source node, chunk q (16 B) of all S stations is contiguous (c: [g][8][S] x 16 B, wv: [g][4][S] x 16 B; DaArgs.np), so the 16
+//    lanes of a lane group read 256 contiguous bytes and the block of a source node stays contiguous (the halo exchange of the
+//    sharded path moves whole blocks, genie_amd/dist.py);
+//  * the station-neighbour rows (wu, row layout [p][16]) are still gathered four lanes to a 64-B row (the texture path's fast
+//    pattern), summed there, and the SUM crosses into the operand layout with four ds_bpermute_b32;
+//  * the static edge_attr arrives as a ready-made B fragment (k_ea_frag, written once per registered edge_attr): its K-step is one
+//    MFMA per channel block;
+//  * row bases are 32-bit scalar products on top of a 64-bit pointer (BIG: 64-bit products, config 4 on one GPU).
+// Same arithmetic up to x_latent as k_stage2_ord (bitwise equal x_latent); the Bipartite message is fp32-class like stage 1
+// (products exact in the fp32 accumulator, operands within one fp32 ulp), tests compare it with the oracle and the fp32 kernels.
+// ------------------------------------------------------------------------------------------------
+#define MFMA16H(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+
+// edge_attr [P, 3] (caller's station order) -> B fragments of the edge_attr K-step, node-planar [g][2][S] x 16 B in station
+// processing order: lane group 0 = {e0, e1, e2, 0 (first pieces) | e0, e1, e2, 0 (second pieces)}, group 1 = {e / 16 (3), 0 | 0}
+__global__ void k_ea_frag(const float* __restrict__ ea, long long rows, int S, const int32_t* __restrict__ sta_user,
+                          unsigned* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rows) return;
+    const long long g = p / S;
+    const int s = (int)(p - g * S);
+    const long long pu = g * S + (sta_user != nullptr ? sta_user[s] : s);
+    const float e0 = ea[pu * 3], e1 = ea[pu * 3 + 1], e2 = ea[pu * 3 + 2];
+    const unsigned a0 = cvt_pk_f16(e0, e1), b0 = cvt_pk_f16(e2, 0.f);
+    const unsigned a1 = cvt_pk_f16(sub_f16_lo(e0, a0), sub_f16_hi(e1, a0)), b1 = cvt_pk_f16(sub_f16_lo(e2, b0), 0.f);
+    *(u32x4*)(out + ((g * 2) * S + s) * 4) = u32x4{a0, b0, a1, b1};
+    *(u32x4*)(out + ((g * 2 + 1) * S + s) * 4) = u32x4{pk_mul_f16(a0, H2_SIXTEENTH), pk_mul_f16(b0, H2_SIXTEENTH), 0u, 0u};
+}
+
+template <bool BIG>
+__device__ __forceinline__ unsigned long long s2h_base(const void* b, int id, unsigned pitch) {
+    const unsigned long long off = BIG ? (unsigned long long)(unsigned)id * (unsigned long long)pitch
+                                       : (unsigned long long)((unsigned)id * pitch);
+    unsigned long long r = (unsigned long long)b + off;
+    asm volatile("" : "+s"(r));      // stays an SGPR pair: the load is `global_load v, voffset, s[base]`
+    return r;
+}
+
+template <bool XL, bool BIG>
+__global__ __launch_bounds__(256, GENIE_S2H_WAVES) void k_stage2_h2(DaArgs a) {
+    constexpr int KS = 8, KP = 15;
+    constexpr int NF4 = S2H_IMG_FLOATS / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + S2H_FRAGS * 64);
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lbias[32], ab1 = lbias[33];
+    int lane = threadIdx.x & 63;
+    const int m = lane & 15, kg = lane >> 4;      // operand layout: node m of the tile, K-slot group kg
+    const int jl = lane >> 2, ql = lane & 3;      // row layout of the station-neighbour gathers: node jl, 16-B chunk ql
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, wave, a.gi0);
+    if (a.wgmap) {     // blocks of 4 adjacent source nodes per workgroup, one node per wave (see k_stage2_ord)
+        const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+        const int lb = blockIdx.x / nx, nbx = gridDim.x / nx, n = w.gend - w.gbeg, n_blk = (n + 3) / 4;
+        int n_my = lb < n_blk ? (n_blk - lb + nbx - 1) / nbx : 0;
+        if (n_my > 0 && 4 * (lb + (n_my - 1) * nbx) + wave >= n) --n_my;
+        w.it = 0; w.stride = 1; w.nitems = (long long)n_my * a.T;
+        w.lead_ = lb; w.chunk_ = nbx;
+    }
+    if (w.it >= w.nitems) return;
+    const unsigned m_T = ItemIter::recip((unsigned)a.T);
+    auto item_of = [&](long long it, int& gi, int& tb) {      // every XCD's chunk is swept backwards (the rows stage 1 wrote last first)
+        const long long itr = w.nitems - 1 - it;
+        if (a.wgmap) {
+            unsigned rem;
+            const unsigned kb = a.T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)a.T, m_T, rem);
+            tb = (int)rem;
+            gi = w.gbeg + 4 * (w.lead_ + (int)kb * w.chunk_) + wave;
+        } else {
+            w.decode(itr, gi, tb);
+        }
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        tb = __builtin_amdgcn_readfirstlane(tb);
+    };
+    typedef const __attribute__((address_space(1))) char* gbytes;
+    typedef const __attribute__((address_space(1))) f32x4* grow;
+    typedef const __attribute__((address_space(1))) u32x4* gfrag;
+    typedef const __attribute__((address_space(1))) float* gflt;
+    const unsigned plane = (unsigned)S * 16u;          // bytes of one chunk plane inside a source node's block
+    const unsigned pc = (unsigned)S * 128u, pw = (unsigned)S * 64u, pe = (unsigned)S * 32u, pm = (unsigned)S * 4u;
+    const unsigned kgp = (unsigned)kg * plane, kge = (unsigned)min(kg, 1) * plane;
+    const unsigned q16 = 16u * (unsigned)ql;
+    const int bperm = (4 * m + kg) * 4;                // this lane's operand = the row-layout lane of (node m, chunk kg)
+
+    struct Tile { f32x4 ru[KS], rv[KP], c1, c2; u32x4 ea; float mq; } R;
+    int sta[KS];
+    auto load_ids = [&](int gi, int tb, int& idv) {
+        idv = a.src_tab[gi * 16 + m];
+        const int s = tb * 16 + jl;
+        load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
+    };
+    auto issue = [&](int idv, int tb) {
+        const int g = __builtin_amdgcn_readlane(idv, 0);
+        const int s = tb * 16 + m, sc = s < S ? s : S - 1;
+        const unsigned so = (unsigned)sc * 16u;
+        const unsigned lo = kgp + so;
+        const int gs = ABL(a, 9) ? (g & 7) : g;        // tuning bit 9: streamed rows (c, mask, edge_attr) from a cache-resident region
+        const unsigned long long cb = s2h_base<BIG>(a.c, gs, pc);
+        R.c1 = *(grow)((gbytes)cb + lo);
+        R.c2 = *(grow)((gbytes)cb + (lo + 4u * plane));
+        const unsigned long long mb = s2h_base<BIG>(a.mm_int, gs, pm);
+        R.mq = *(gflt)((gbytes)mb + (unsigned)sc * 4u);
+        if (s >= S) R.mq = 0.f;
+        const unsigned long long eb = s2h_base<BIG>(a.ea_frag, gs, pe);
+        R.ea = *(gfrag)((gbytes)eb + (kge + so));
+        const unsigned long long ub = s2h_base<BIG>(a.wu, ABL(a, 11) ? (g & 7) : g, pw);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) R.ru[k] = ABL(a, 0) ? R.c1 : *(grow)((gbytes)ub + ((unsigned)sta[k] * 64u + q16));
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            // tuning bit 11: every gather from a cache-resident block (same instruction stream); bit 12: the 15 source rows of a tile
+            // are ONE row (the L1 misses of the source gathers collapse to those of one row); bit 1: no source gathers
+            const int idk = ABL(a, 11) ? k : __builtin_amdgcn_readlane(idv, ABL(a, 12) ? 1 : 1 + k);
+            const unsigned long long vb = s2h_base<BIG>(a.wv, idk, pw);
+            R.rv[k] = ABL(a, 1) ? R.c2 : *(grow)((gbytes)vb + lo);
+        }
+    };
+
+    long long it = w.it;
+    int gi_c, tb_c, gi_n, tb_n, idv_c, idv_n;
+    item_of(it, gi_c, tb_c);
+    load_ids(gi_c, tb_c, idv_c);
+    issue(idv_c, tb_c);
+    {
+        const long long itn = it + w.stride < w.nitems ? it + w.stride : it;
+        item_of(itn, gi_n, tb_n);
+        load_ids(gi_n, tb_n, idv_n);
+    }
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        const int g_c = __builtin_amdgcn_readlane(idv_c, 0);
+        const bool has_next = it + w.stride < w.nitems;
+        const long long it2 = it + 2 * w.stride < w.nitems ? it + 2 * w.stride : (has_next ? it + w.stride : it);
+        int gi_2, tb_2, idv_2;
+        item_of(it2, gi_2, tb_2);
+        // (1) neighbour means of the projected operands in edge order (as k_stage2_ord), PReLU2 -> x_latent
+        f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) n1 += R.ru[k];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) n2 += R.rv[k];
+        f32x4 n1t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {     // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0, hipcc 7.0)
+            const float v = n1[r];
+            n1t[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm, __float_as_int(v)));
+        }
+        f32x4 o1 = fma4(n1t, 1.f / (float)KS, R.c1), o2 = fma4(n2, 1.f / (float)KP, R.c2);
+        const float mq = R.mq;
+        const u32x4 eab = R.ea;
+        o1 = prelu4u(o1, a2);
+        o2 = prelu4u(o2, a2);
+        asm volatile("" : "+v"(o1), "+v"(o2), "+v"(idv_n));
+        // (2) every row of the next tile (the item after the last repeats the last one: its rows are never consumed)
+        issue(idv_n, tb_n);
+        if (XL && tb_c * 16 + m < S) {
+            const int su = a.sta_user[tb_c * 16 + m];
+            float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kg + r < 15) { xl[4 * kg + r] = o1[r]; xl[15 + 4 * kg + r] = o2[r]; }
+        }
+        // (3) B operand: K slots (kg, e) = o1 channels 4 kg + e (e < 4), o2 channels 4 kg + e - 4; pieces {x0, x1, x0 / 16}
+        u32x4 p0, p1, p2;
+        p0[0] = cvt_pk_f16(o1[0], o1[1]); p0[1] = cvt_pk_f16(o1[2], o1[3]);
+        p0[2] = cvt_pk_f16(o2[0], o2[1]); p0[3] = cvt_pk_f16(o2[2], o2[3]);
+        p1[0] = cvt_pk_f16(sub_f16_lo(o1[0], p0[0]), sub_f16_hi(o1[1], p0[0]));
+        p1[1] = cvt_pk_f16(sub_f16_lo(o1[2], p0[1]), sub_f16_hi(o1[3], p0[1]));
+        p1[2] = cvt_pk_f16(sub_f16_lo(o2[0], p0[2]), sub_f16_hi(o2[1], p0[2]));
+        p1[3] = cvt_pk_f16(sub_f16_lo(o2[2], p0[3]), sub_f16_hi(o2[3], p0[3]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) p2[d] = pk_mul_f16(p0[d], H2_SIXTEENTH);
+        // (4) Bipartite fc1: D[channel 16 t + 4 kg + r, node m], smallest products first
+        f32x4 bp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bp[t] = *(const f32x4*)(lbias + 16 * t + 4 * kg);
+            const f32x4 w0 = lw[(S2H_FW + 2 * t) * 64 + lane], w1 = lw[(S2H_FW + 2 * t + 1) * 64 + lane];
+            const f32x4 we = lw[(S2H_FE + t) * 64 + lane];
+            bp[t] = MFMA16H(w0, p1, bp[t]);
+            bp[t] = MFMA16H(w1, p2, bp[t]);
+            bp[t] = MFMA16H(we, eab, bp[t]);
+            bp[t] = MFMA16H(w0, p0, bp[t]);
+        }
+        // (5) ids of the tile after next
+        load_ids(gi_2, tb_2, idv_2);
+        // (6) PReLU, mask gate, station sum of this tile (DPP row reduction in the butterfly's order), one partial row per tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = prelu4u(bp[t], ab1) * mq;
+            v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
+            if (m == 0) *(f32x4*)(a.part + ((long long)g_c * a.T + tb_c) * 32 + 16 * t + 4 * kg) = v;
+        }
+        if (!has_next) break;
+        it += w.stride;
+        idv_c = idv_n; tb_c = tb_n;
+        idv_n = idv_2; tb_n = tb_2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 range guard of the f16x2 kernels (k_stage1_h2, k_stage2_h2). They split every hidden state into fp16 pieces, so a value
+// above 65 504 would turn into inf where the reference's fp32 arithmetic is still fine. This kernel computes, from the weights
+// alone, a RIGOROUS bound of every such value (interval arithmetic per channel: |W x + b| <= sum_j |W_ij| X_j + |b_i|,
+// |PReLU_a(z)| <= max(1, |a|) |z|, |mean| <= max) for inputs Slice, Mask in [-1, 1] (process_utils.py:262-275: exp(-r^2 / 2 s^2) in
+// [0, 1], or +-1 with the sign input; Mask in {0, 1}) and the actual maxima of the static tables (absolute positions, edge-term
+// biases). out = {largest bound, largest weight magnitude in its fp16 form (init_trns enters 16 x), ok flag, 0}. The context
+// selects the fp32-MFMA kernels when ok == 0 (genie_ctx::range_ok; genie_set_stage_precision overrides).
+// ------------------------------------------------------------------------------------------------
+enum { RG_INIT_W, RG_INIT_B, RG_INIT_ABS, RG_L1T12_W, RG_L1T12_B, RG_L1T22_W, RG_L1T22_B, RG_L2T11_W, RG_L2T11_B, RG_L2T21_W,
+       RG_L2T21_B, RG_L2T12_W, RG_L2T12_B, RG_L2T22_W, RG_L2T22_B, RG_ACT, RG_ACT11, RG_ACT12, RG_ACT1, RG_ACT21, RG_ACT22, RG_ACT2,
+       RG_FC1_W, RG_N };
+struct RangeArgs {
+    const float* raw;
+    int off[RG_N];
+    const float *abs_sta, *abs_src, *eb_sta, *eb_src;
+    long long n_abs_sta, n_abs_src, n_eb_sta, n_eb_src;
+    float* out;
+};
+constexpr float H2_RANGE_LIMIT = 60000.f;
+
+__device__ __forceinline__ float blk_max256(float v, float* red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);     // (NaN-propagating where it matters: the flag test below is !(x < limit))
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float tab_max256(const float* p, long long n, float* red) {
+    float v = 0.f;
+    bool bad = false;
+    for (long long i = threadIdx.x; i < n; i += 256) { const float x = fabsf(p[i]); bad |= !(x <= 3.0e38f); v = fmaxf(v, x); }
+    return blk_max256(bad ? __builtin_inff() : v, red);
+}
+
+__global__ __launch_bounds__(256) void k_h2_range(RangeArgs a) {
+    __shared__ float red[256];
+    __shared__ float H0[32], N1[32], N2[32], H1a[32], H1b[32], U[32], V[32];
+    const int t = threadIdx.x;
+    const float* R = a.raw;
+    auto W = [&](int id) { return R + a.off[id]; };
+    auto g1 = [](float s) { return fmaxf(1.f, fabsf(s)); };
+    const float pos_sta = a.abs_sta ? tab_max256(a.abs_sta, a.n_abs_sta, red) : 0.f;
+    const float pos_src = a.abs_src ? tab_max256(a.abs_src, a.n_abs_src, red) : 0.f;
+    const float ebs = a.eb_sta ? tab_max256(a.eb_sta, a.n_eb_sta, red) : 0.f;
+    const float ebg = a.eb_src ? tab_max256(a.eb_src, a.n_eb_src, red) : 0.f;
+    const float a0 = *W(RG_ACT), a1 = *W(RG_ACT1), a21 = *W(RG_ACT21), a22 = *W(RG_ACT22), a2 = *W(RG_ACT2);
+    const float s11 = a0 >= 0.f ? a0 * *W(RG_ACT11) : a0, s12 = a0 >= 0.f ? a0 * *W(RG_ACT12) : a0;      // compose_slopes
+    float wmax = 0.f, amax = 0.f;
+    bool bad = false;
+    // largest weight magnitude in the form that is rounded to fp16 (the input layer enters as 16 W)
+    {
+        const int ids[8] = {RG_INIT_W, RG_INIT_ABS, RG_L1T12_W, RG_L1T22_W, RG_L2T11_W, RG_L2T21_W, RG_L2T12_W, RG_L2T22_W};
+        const int nel[8] = {240, 180, 1920, 1920, 1800, 1800, 1410, 1410};
+        for (int k = 0; k < 8; ++k)
+            for (int i = t; i < nel[k]; i += 256) {
+                const float x = fabsf(W(ids[k])[i]) * (k < 2 ? 16.f : 1.f);
+                bad |= !(x <= 3.0e38f);
+                wmax = fmaxf(wmax, x);
+            }
+        for (int i = t; i < 990; i += 256) { const float x = fabsf(W(RG_FC1_W)[i]); bad |= !(x <= 3.0e38f); wmax = fmaxf(wmax, x); }
+    }
+    // h0 and the two neighbour means of its re-activated forms
+    if (t < 30) {
+        float z = fabsf(W(RG_INIT_B)[t]);
+        for (int j = 0; j < 8; ++j) z += fabsf(W(RG_INIT_W)[t * 8 + j]);
+        for (int j = 0; j < 3; ++j) z += fabsf(W(RG_INIT_ABS)[t * 6 + j]) * pos_sta + fabsf(W(RG_INIT_ABS)[t * 6 + 3 + j]) * pos_src;
+        H0[t] = g1(a0) * z; N1[t] = g1(s11) * z; N2[t] = g1(s12) * z;
+        amax = fmaxf(fmaxf(amax, fmaxf(pos_sta, pos_src)), fmaxf(H0[t], fmaxf(N1[t], N2[t])));   // (the positions are fp16 operands too)
+    }
+    __syncthreads();
+    // h1 = [PReLU1(l1_t1_2 [h0 | n1 | M]) | PReLU1(l1_t2_2 [h0 | n2 | M])]
+    if (t < 60) {
+        const int i = t % 30, hf = t / 30;
+        const float* w = W(hf ? RG_L1T22_W : RG_L1T12_W) + i * 64;
+        const float* n = hf ? N2 : N1;
+        float z = fabsf(W(hf ? RG_L1T22_B : RG_L1T12_B)[i]) + (hf ? ebg : ebs);
+        for (int j = 0; j < 30; ++j) z += fabsf(w[j]) * H0[j] + fabsf(w[30 + j]) * n[j];
+        for (int j = 0; j < 4; ++j) z += fabsf(w[60 + j]);
+        (hf ? H1b : H1a)[i] = g1(a1) * z;
+        amax = fmaxf(amax, g1(a1) * z);
+    }
+    __syncthreads();
+    if (t < 60) {       // u, v
+        const int i = t % 30, hf = t / 30;
+        const float* w = W(hf ? RG_L2T21_W : RG_L2T11_W) + i * 60;
+        float z = fabsf(W(hf ? RG_L2T21_B : RG_L2T11_B)[i]);
+        for (int j = 0; j < 30; ++j) z += fabsf(w[j]) * H1a[j] + fabsf(w[30 + j]) * H1b[j];
+        const float s = hf ? a22 : a21;
+        (hf ? V : U)[i] = g1(s) * z;
+        amax = fmaxf(amax, g1(s) * z);
+    }
+    __syncthreads();
+    if (t < 30) {       // x_latent = PReLU2(c + mean of the projected u / v), the B operand of k_stage2_h2
+        const int i = t % 15, hf = t / 15;
+        const float* w = W(hf ? RG_L2T22_W : RG_L2T12_W) + i * 94;
+        const float* uv = hf ? V : U;
+        float z = fabsf(W(hf ? RG_L2T22_B : RG_L2T12_B)[i]) + (hf ? ebg : ebs);
+        for (int j = 0; j < 30; ++j) z += fabsf(w[j]) * H1a[j] + fabsf(w[30 + j]) * H1b[j] + fabsf(w[60 + j]) * uv[j];
+        for (int j = 0; j < 4; ++j) z += fabsf(w[90 + j]);
+        amax = fmaxf(amax, g1(a2) * z);
+    }
+    bad |= !(amax <= 3.0e38f);
+    const float am = blk_max256(bad ? __builtin_inff() : amax, red);
+    const float wm = blk_max256(bad ? __builtin_inff() : wmax, red);
+    if (t == 0) {
+        a.out[0] = am; a.out[1] = wm;
+        a.out[2] = (am < H2_RANGE_LIMIT && wm < H2_RANGE_LIMIT) ? 1.f : 0.f;
+        a.out[3] = 0.f;
     }
 }

@@ -217,6 +217,11 @@ ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationP
                   "LocalSliceLgCollapseS.", "Arrivals.")
 
 
+# default arithmetic of the P-sized stages of new contexts (HipPath(stage_precision=...)); the A/B tests patch it
+STAGE_PRECISION = "auto"
+_PRECISION_MODES = {"auto": 0, "f16x2": 1, "f32": 2}
+
+
 class HipPath(object):
     """One libgenie_hip context bound to the current CUDA(HIP) device.
 
@@ -225,8 +230,10 @@ class HipPath(object):
     """
 
     def __init__(self, n_sta, n_grid, sta_csr, src_csr, n_grid_ext=None, grid_order=None, scale_rel=30000.0,
-                 device=None, subgraph=None, sta_order=None):
-        """`subgraph` = dict(n_prod, sta_csr, src_csr, seg_rowptr): an irregular product graph (`use_subgraph`) given as
+                 device=None, subgraph=None, sta_order=None, stage_precision=None):
+        """`stage_precision`: "auto" (default: two-piece fp16 operands on the 16-bit matrix pipe while the library's fp16 range guard
+        holds for the committed weights, fp32 MFMA otherwise), "f16x2" or "f32" (A/B runs); None = `engine.STAGE_PRECISION`.
+        `subgraph` = dict(n_prod, sta_csr, src_csr, seg_rowptr): an irregular product graph (`use_subgraph`) given as
         product-level CSRs + the row range of every source node (genie_ctx_create_subgraph); `sta_csr` is then ignored.
         `grid_order` / `sta_order`: processing orders of the source nodes / stations (e.g. `sfc_order(positions)`);
         internal only, every input and output keeps the caller's order."""
@@ -269,11 +276,12 @@ class HipPath(object):
                                                _ptr(self._keep[0]), _ptr(self._keep[1]), _ptr(self._keep[2]),
                                                _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
             _lib.check(rc, "genie_ctx_create")
-            if True:      # without a station order the identity: stage 2's production kernel reads its rows in processing order
-                so = np.ascontiguousarray(np.asarray(sta_order if sta_order is not None else np.arange(self.n_sta)), dtype=np.int32)
-                if so.shape != (self.n_sta,):
-                    raise ValueError("sta_order must have n_sta entries")
-                _lib.check(self.lib.genie_set_station_order(self.ctx, ctypes.c_void_p(so.ctypes.data)), "genie_set_station_order")
+            # without a station order the identity: stage 2's production kernel reads its rows in processing order
+            so = np.ascontiguousarray(np.asarray(sta_order if sta_order is not None else np.arange(self.n_sta)), dtype=np.int32)
+            if so.shape != (self.n_sta,):
+                raise ValueError("sta_order must have n_sta entries")
+            _lib.check(self.lib.genie_set_station_order(self.ctx, ctypes.c_void_p(so.ctypes.data)), "genie_set_station_order")
+        self.set_stage_precision(stage_precision if stage_precision is not None else STAGE_PRECISION)
         self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
@@ -285,6 +293,22 @@ class HipPath(object):
         self.w_off = [int(self.lib.genie_weights_offset(i)) for i in range(n)]
         self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
         self._w_key = None
+
+    def set_stage_precision(self, mode):
+        """"auto" | "f16x2" | "f32": arithmetic of the P-sized stages (genie_set_stage_precision)."""
+        if mode not in _PRECISION_MODES:
+            raise ValueError("stage_precision must be one of %s" % (sorted(_PRECISION_MODES),))
+        _lib.check(self.lib.genie_set_stage_precision(self.ctx, _PRECISION_MODES[mode]), "genie_set_stage_precision")
+
+    def stage_precision(self):
+        """What runs for the weights set so far: dict(mode, f16x2_active, act_bound, weight_bound) -- the last two are the numbers
+        the library's fp16 range guard compares with 60000 (genie_stage_precision). Synchronises when weights were pending."""
+        mode, act = ctypes.c_int(0), ctypes.c_int(0)
+        ab, wb = ctypes.c_float(0), ctypes.c_float(0)
+        _lib.check(self.lib.genie_stage_precision(self.ctx, ctypes.byref(mode), ctypes.byref(act), ctypes.byref(ab), ctypes.byref(wb),
+                                                  _stream()), "genie_stage_precision")
+        names = {v: k for k, v in _PRECISION_MODES.items()}
+        return {"mode": names[mode.value], "f16x2_active": bool(act.value), "act_bound": float(ab.value), "weight_bound": float(wb.value)}
 
     def __del__(self):
         try:

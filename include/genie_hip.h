@@ -24,10 +24,12 @@
  *    this context; source nodes [n_grid, n_grid_ext) are HALO rows (owned by another GPU when the grid is
  *    sharded over source nodes) that only appear as neighbours in `src_col`;
  *  - arithmetic: fp32 in, fp32 out, fp32 accumulation everywhere. On the reference's kNN graphs (8 station / 15 source
- *    neighbours) stage 1 multiplies on the 16-bit matrix pipe with every fp32 operand as two fp16 pieces (x within one fp32
- *    ulp, three partial products per product): fp32-class results, valid while the inputs and hidden states of
- *    DataAggregation stay below 65504 in magnitude (beyond that the outputs turn non-finite; the environment variable
- *    GENIE_S1=f32 selects the fp32-MFMA kernels, which have no such bound).
+ *    neighbours) the P-sized stages multiply on the 16-bit matrix pipe with every fp32 operand as two fp16 pieces (x within
+ *    one fp32 ulp, three partial products per product): fp32-class results, which need every hidden state of DataAggregation
+ *    below 65504 in magnitude. The library checks that itself: at every weight commit it bounds those hidden states rigorously
+ *    from the weights (inputs Slice, Mask in [-1, 1], as the reference produces them) and runs the fp32-MFMA kernels instead
+ *    whenever the bound exceeds the fp16 range (genie_set_stage_precision / genie_stage_precision). edge_attr must stay
+ *    below 65504 in magnitude (it is (grid - station) / scale_x_extend, process_continuous_days.py:630: O(1)).
  */
 #ifndef GENIE_HIP_H
 #define GENIE_HIP_H
@@ -87,9 +89,20 @@ int genie_ctx_destroy(genie_ctx* ctx);
  * processing order inside the workspace; genie_ws_export un-permutes). Honoured by the f16x2 stage 1 + pipelined stage 2
  * pair on Cartesian product graphs, ignored otherwise; NULL = off. All ranks of a sharded run must pass the same order. */
 int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
+/* Arithmetic of the P-sized stages on the reference's kNN graphs. mode 0 (default) = automatic: two-piece fp16 operands on the
+ * 16-bit matrix pipe (k_stage1_h2 / k_stage2_h2) while the fp16 range guard of the committed weights holds, the fp32-MFMA kernels
+ * otherwise; 1 = two-piece fp16 operands regardless of the guard (A/B runs; hidden states above 65504 become non-finite);
+ * 2 = fp32 MFMA always. No environment variable takes part. */
+int genie_set_stage_precision(genie_ctx* ctx, int mode);
+/* What runs for the weights committed so far (commits pending ones): *mode as set, *f16x2_active 1 / 0, and the two numbers
+ * the range guard compares with 60000: the largest rigorous bound of a hidden state that is split into fp16 pieces, and the
+ * largest weight magnitude in the form that is rounded to fp16. Any out pointer may be NULL. Synchronises `stream` when weights
+ * were pending (the guard's 16-byte read-back). */
+int genie_stage_precision(genie_ctx* ctx, int* mode, int* f16x2_active, float* act_bound, float* weight_bound, void* stream);
 /* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
- * function of the geometry only); the library keeps a processing-order copy and uses it in every stage-2 call that is passed
- * this same pointer. Call again if the contents change; NULL unregisters. No-op without a station order. */
+ * function of the geometry only); the library keeps it in the form stage 2 consumes (two-piece fp16 operand fragments in
+ * processing order, 32 B per product node) and uses that in every stage-2 call that is passed this same pointer; any other
+ * edge_attr is converted per call. Call again if the contents change; NULL unregisters. No-op without a station order. */
 int genie_set_static_edge_attr(genie_ctx* ctx, const float* edge_attr, void* stream);
 /* Every buffer of the workspace that carries data from one call to the next (stage 1 -> stage 2: c, wu, wv; stage 2 ->
  * tail: Bipartite partials; SpatialAggregation / read-out scratch) exists several times; `slot` (0..15) selects the copy

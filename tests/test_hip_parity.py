@@ -96,7 +96,7 @@ def test_stage1_piece_range_small_and_large_inputs(scale):
     floor of 2^-25 below. Inputs scaled by 2^-12 (hidden states dominated by the biases, input terms far inside fp16's subnormal
     range) and by 512 (hidden states up to ~1e3): stage 1's intermediates and x_latent against the oracle on the same inputs, to
     the usual 1e-5 of their scale. (Beyond 65504 an activation overflows its first piece and the outputs turn non-finite:
-    GENIE_S1=f32 selects the fp32-MFMA kernels for such models.)"""
+    stage_precision="f32" selects the fp32-MFMA kernels for such models.)"""
     from oracle import genie_oracle as O
     c = Case("odd_33x257")
     Slice = (c.Slice * scale).contiguous()
@@ -113,14 +113,62 @@ def test_stage1_piece_range_small_and_large_inputs(scale):
         assert torch.isfinite(got).all() and err <= tol, (k, err, tol)
 
 
+@pytest.mark.parametrize("gains", [(1.0, 1.0, 1.0, 1.0), (64.0, 64.0, 64.0, 64.0), (4096.0, 4096.0, 1.0, 1.0)])
+def test_fp16_range_guard_selects_the_fp32_kernels_without_any_switch(gains):
+    """The f16x2 kernels split every hidden state of DataAggregation into fp16 pieces: beyond 65504 they would return inf / NaN
+    where the reference's fp32 arithmetic is fine. The library bounds those hidden states from the committed weights and runs the
+    fp32-MFMA kernels when the bound leaves the fp16 range -- automatically (no environment variable, no argument). Weights of
+    init_trns / layer 1 / l2_t?_1 / l2_t?_2 scaled by `gains`: hidden states reach ~3e5 (x64 everywhere) and ~4e8 (x4096 on the
+    first two layers). Every output finite and within 1e-5 of its scale from the fp64 oracle; the unscaled model keeps f16x2."""
+    from oracle import genie_oracle as O
+    c = Case("cfg1_20x500")             # uniform 8 / 15-degree graphs: the shape admits the f16x2 kernels
+    layer = {"init_trns": 0, "l1_t1_2": 1, "l1_t2_2": 1, "l2_t1_1": 2, "l2_t2_1": 2, "l2_t1_2": 3, "l2_t2_2": 3}
+    w = {}
+    for k, v in c.weights.items():
+        parts = k.split(".")
+        g = gains[layer[parts[1]]] if (parts[0] == "DataAggregation" and parts[1] in layer) else 1.0
+        w[k] = (v * g).contiguous()
+    sta_nbr, src_nbr = c.tables()
+    hp = engine.HipPath(c.S, c.G, engine.csr_from_table(sta_nbr), engine.csr_from_table(src_nbr),
+                        grid_order=engine.morton_order(c.x_grid.numpy()), device=DEV, sta_order=engine.sfc_order(c.locs.numpy()))
+    hp.set_weights({k: v.to(DEV) for k, v in w.items()})
+    info = hp.stage_precision()
+    print("gains %s: %s" % (gains, info))
+    assert info["mode"] == "auto"
+    assert info["f16x2_active"] == (gains[0] == 1.0), info
+    _, _, h0, h1 = hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV), debug=True)
+    x_latent, bip = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV), want_x_latent=True)
+    w64 = {k: v.double() for k, v in w.items()}
+    A_in_sta, A_in_src, A_src_in_prod, _ = c.product_edges()
+    ref = O.data_aggregation(w64, c.Slice.double(), c.Mask.double(), A_in_sta, A_in_src, full=True)
+    ref["bip"] = O.bipartite_read_in(w64, ref["x_latent"], c.edge_attr.double(), A_src_in_prod, c.Mask.double())
+    if gains[0] > 1.0:
+        assert max(float(ref[k].abs().max()) for k in ("h0", "h1", "u", "v", "x_latent")) > 65504.0     # the case the guard exists for
+    for got, k in ((h0, "h0"), (h1, "h1"), (x_latent, "x_latent"), (bip, "bip")):
+        scale = float(ref[k].abs().max())
+        err = max_abs(got.cpu(), ref[k])
+        print("  %s: max|ref| %.4g err %.3g (%.2g of scale)" % (k, scale, err, err / scale))
+        assert torch.isfinite(got).all(), k
+        assert err <= 1e-5 * max(1.0, scale), (k, err, scale)
+    if gains[0] > 1.0:
+        # forced f16x2 on the same weights (A/B mode): the overflow the guard prevents is real
+        hp.set_stage_precision("f16x2")
+        hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV))
+        _, bip_f16 = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV))
+        # (inf pieces turn into NaN in the matrix pipe and the NaN-dropping min / max of the PReLUs make them finite again: the
+        # forced mode is silently WRONG beyond the fp16 range, which is why the choice is not left to the caller)
+        bad = bip_f16.cpu().double()
+        assert (not torch.isfinite(bad).all()) or max_abs(bad, ref["bip"]) > 1e-3 * float(ref["bip"].abs().max())
+
+
 @pytest.mark.parametrize("name", EDGES_CASES)
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_updated_model_definition_forward_fixed_source(name, stage1, monkeypatch):
     """a-9: the `use_updated_model_definition` class (DataAggregationEdges, module.py:102-174, :1163-1185) against fixtures
     generated from the reference imported with that flag. edges_12x60 has uniform 8 / 15 degrees (f16x2 stage 1, or the
-    pipelined fp32 kernel with GENIE_S1=f32), edges_7x13 has 6 / 12 (generic CSR kernels)."""
+    pipelined fp32 kernel with stage_precision="f32"), edges_7x13 has 6 / 12 (generic CSR kernels)."""
     if stage1 == "f32":
-        monkeypatch.setenv("GENIE_S1", "f32")
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     c = Case(name)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=True)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
@@ -172,10 +220,10 @@ def test_use_absolute_pos_forward_fixed_source(name):
 def test_use_subgraph_irregular_product_graph(name, stage1, monkeypatch):
     """f-4: `use_subgraph: True` (config.yaml:86, process_utils.py:744-849). set_adjacencies receives irregular product edge
     lists; the module builds product-level CSRs (genie_ctx_create_subgraph); stage 1 runs k_stage1_h2<.., PCSR> (neighbours as
-    product-node ids, missing ones with weight 0; GENIE_S1=f32: the generic fp32-MFMA k_stage1_pcsr), then k_stage2_pcsr /
+    product-node ids, missing ones with weight 0; stage_precision="f32": the generic fp32-MFMA k_stage1_pcsr), then k_stage2_pcsr /
     k_bip_out_seg. Checked against the reference's own run on that graph and against the oracle."""
     if stage1 == "f32":
-        monkeypatch.setenv("GENIE_S1", "f32")
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     c = Case(name)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
@@ -300,7 +348,7 @@ def test_bitwise_deterministic_and_order_independent():
 
 @pytest.mark.parametrize("case", ["cfg1_20x500", "random_50x700"])
 def test_kernel_variants_agree(case, monkeypatch):
-    """The stage kernels exist in two forms: generic CSR fp32-MFMA (any graph; GENIE_S1=f32 selects them on the reference's kNN
+    """The stage kernels exist in two forms: generic CSR fp32-MFMA (any graph; stage_precision="f32" selects them on the reference's kNN
     graphs too: the A/B reference) and the production pair k_stage1_h2 (two-piece fp16 operands on the matrix pipe) + k_stage2_ord (pipelined,
     row-layout loads): another summation order, fp32 tolerance."""
     if case == "cfg1_20x500":
@@ -316,10 +364,8 @@ def test_kernel_variants_agree(case, monkeypatch):
         Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
         ea, pos, xg = torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.x_grid).float(), geom.x_grid
     res = {}
-    for name, env in (("generic", {"GENIE_S1": "f32"}), ("h2", {})):
-        monkeypatch.delenv("GENIE_S1", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for name, prec in (("generic", "f32"), ("h2", "auto")):
+        monkeypatch.setattr(engine, "STAGE_PRECISION", prec)
         hp = engine.HipPath(S, G, engine.csr_from_table(sta_nbr), engine.csr_from_table(src_nbr),
                             grid_order=engine.morton_order(xg), device=DEV)
         hp.set_weights({k: v.to(DEV) for k, v in w.items()})
@@ -346,10 +392,8 @@ def test_rows_beyond_4gib_offsets(monkeypatch):
     Mask = (torch.rand((P, 4), device=DEV, generator=g) < 0.3).float()
     ea = torch.rand((P, 3), device=DEV, generator=g) - 0.5
     res = {}
-    for name, env in (("generic", {"GENIE_S1": "f32"}), ("default", {})):
-        monkeypatch.delenv("GENIE_S1", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for name, prec in (("generic", "f32"), ("default", "auto")):
+        monkeypatch.setattr(engine, "STAGE_PRECISION", prec)
         hp = engine.HipPath(S, G, sta, src, grid_order=engine.morton_order(geom.x_grid), device=DEV)
         hp.set_weights(w)
         hp.da_stage1(Slice, Mask)
@@ -663,9 +707,9 @@ def test_config4_shape_two_virtual_ranks_vs_unsharded_generic_kernels_and_oracle
     out_ref, bip_ref = unsharded()
     assert torch.isfinite(out_ref).all() and torch.isfinite(bip_ref).all()
     # (2) generic kernels
-    monkeypatch.setenv("GENIE_S1", "f32")
+    monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     out_gen, bip_gen = unsharded()
-    monkeypatch.delenv("GENIE_S1")
+    monkeypatch.setattr(engine, "STAGE_PRECISION", "auto")
     scale = float(bip_ref.abs().max())
     print("config 4 shape: max|bip| %.4g, fast vs generic kernels %.3g" % (scale, max_abs(bip_ref, bip_gen)))
     assert max_abs(bip_ref, bip_gen) <= 1e-5 * max(1.0, scale)
