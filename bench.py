@@ -39,9 +39,9 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
 # Algorithmic bytes: whole path B_alg = 1532*P + 816*G bytes per window (reference dataflow at layer
 # granularity). The HIP path moves fewer real bytes than that because h0/h1/u/v never leave the registers; per
 # product node and per kernel group (gathers counted once per row = perfect cache):
-#   stage 1 = k_split_rows + k_stage1_h2: Slice+Mask 32 R, split rows 32 W + 32 R, c 120 W, wu+wv 120 W = 336 B
-#   stage 2 = k_stage2_ord              : c 120 R, wu+wv 120 R, Mask 16 R, edge_attr 12 R               = 268 B
-B_NODE = {"k_stage1": 336.0, "k_stage2": 268.0}
+#   stage 1 = k_split_rows + k_stage1_h2: Slice+Mask 32 R, split rows 32 W + 32 R, message mask 4 W, c 120 W, wu+wv 120 W = 340 B
+#   stage 2 = k_stage2_h2               : c 120 R, wu+wv 120 R, message mask 4 R, edge_attr fragments 32 R             = 276 B
+B_NODE = {"k_stage1": 340.0, "k_stage2": 276.0}
 # ALGORITHMIC FLOPs per product node (SURVEY.md 8d split by kernel; 2 per MAC): stage 1 = init_trns 240 + layer-1 3840
 # + l2_t*_1 3600 + l2_t*_2 2820 MACs + 690 layer-1 gather adds; stage 2 = Bipartite fc1 990 MACs + 690 gather adds.
 F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 * 990 + 690.0}
@@ -49,11 +49,6 @@ F_NODE = {"k_stage1": 2.0 * (240 + 3840 + 3600 + 2820) + 690.0, "k_stage2": 2.0 
 # fp16 partial products per fp32 product, init_trns recomputed for the 23 neighbours, 30-wide blocks padded to 32.
 F16_EXEC_FLOP_NODE = 120 * 32768.0 / 32.0
 F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16
-# HBM bytes per launch from rocprofv3 PMC passes of THIS command at cfg2 (separate --pmc runs; bytes = (2 x FETCH_SIZE +
-# WRITE_SIZE) KB x 1024, the guide's gfx950 correction): constants copied from the committed profile, not measured in the run
-TRAFFIC_SOURCE = "profiles/r03_y_pmc_stage_kernels.txt"
-TRAFFIC_CFG2 = {"k_stage1": (2.0 * (1.476e5 + 3.127e4) + (5.000e5 + 7.031e4)) * 1024.0,     # k_split_rows_g + k_stage1_h2
-                "k_stage2": (2.0 * 5.553e5 + 1.631e4) * 1024.0}                               # k_stage2_ord, three workgroups per CU
 FLOP_NODE = 22980.0 + 1380.0   # reference dense + gather adds per product node
 
 
@@ -137,7 +132,7 @@ def measure_traffic(timeout_s=150):
     the two do not fit one pass) over tools/stage_profile.py (the same kernels on the same config-2 workload, 5 windows), averaged
     per kernel; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at
     64 B). Returns {"k_stage1": bytes, "k_stage2": bytes} or None when rocprofv3 is unavailable / fails (the line then carries the
-    constants of the committed profile, labelled as such)."""
+    traffic fields of the line are then null: no constant stands in for a measurement)."""
     import csv
     import glob
     import shutil
@@ -167,10 +162,10 @@ def measure_traffic(timeout_s=150):
                     key = (row["Kernel_Name"], row["Dispatch_Id"])
                     disp[key] = disp.get(key, 0.0) + float(row["Counter_Value"])
                 for (kname, _), v in disp.items():
-                    for tag in ("k_split_rows", "k_stage1_h2", "k_stage2_ord"):
+                    for tag in ("k_split_rows", "k_stage1_h2", "k_stage2_h2"):
                         if tag in kname:
                             acc.setdefault(tag, []).append(v)
-            if not all(t in acc for t in ("k_split_rows", "k_stage1_h2", "k_stage2_ord")):
+            if not all(t in acc for t in ("k_split_rows", "k_stage1_h2", "k_stage2_h2")):
                 return None
             per[counter] = {t: float(np.mean(v)) for t, v in acc.items()}
         except Exception:
@@ -178,7 +173,7 @@ def measure_traffic(timeout_s=150):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     byts = lambda t: (2.0 * per["FETCH_SIZE"][t] + per["WRITE_SIZE"][t]) * 1024.0
-    return {"k_stage1": byts("k_split_rows") + byts("k_stage1_h2"), "k_stage2": byts("k_stage2_ord")}
+    return {"k_stage1": byts("k_split_rows") + byts("k_stage1_h2"), "k_stage2": byts("k_stage2_h2")}
 
 
 def cpu_baseline(net, geom, win, n_timed=3):
@@ -572,8 +567,7 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     four = None
     try:
         smp = synthetic.training_sample(geom, min(n_picks, 4000), n_src=4, seed=3, window=0)
-        net._sta_tab = graph.neighbour_table(geom.A_sta_sta, S).long().to(dev)
-        net._src_tab = graph.neighbour_table(geom.A_src_src, G).long().to(dev)
+        # (the time-pointer tables of this sample; the graphs were set by set_adjacencies_base above)
         net.A_edges_p, net.A_edges_s = t(smp["A_edges_p"]).long(), t(smp["A_edges_s"]).long()
         net.dt_partition, net.tlatent = t(smp["dt_partition"]), t(smp["tlatent"])
         from genie_amd import train as gtrain
@@ -778,8 +772,27 @@ def main():
     windows_per_s = world * a.steps / dt
     value = windows_per_s * n_picks
 
+    # ---- the literal drop-in call: forward_fixed_source(...) of the reference's signature, one call per window on ONE stream
+    # (path + both read-outs per call, no batching of tails across windows), HIP events around a run of calls
+    with torch.no_grad():
+        for i in range(10):
+            net.forward_fixed_source(dS[i % a.windows], dM[i % a.windows], None, None, None, locs, xg, xq, tq)
+        nd = max(20, min(a.steps, 100))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(nd):
+            net.forward_fixed_source(dS[i % a.windows], dM[i % a.windows], None, None, None, locs, xg, xq, tq)
+        e1.record()
+        torch.cuda.synchronize()
+    drop_in_ms = e0.elapsed_time(e1) / nd
+
     # ---- dominant-kernel timing with HIP events on the launch stream (staged API = same kernels) ----
     hp = net._hip
+    info = hp.stage_precision()
+    prec_detail = ("fp32 in / out, fp32 accumulation; P-sized stages %s (fp16 range guard of the committed weights: largest hidden-state bound "
+                   "%.4g, largest weight %.4g, limit 60000; mode %s)"
+                   % ("multiply on the 16-bit matrix pipe with every fp32 operand as two fp16 pieces (three partial products per product)"
+                      if info["f16x2_active"] else "on fp32 MFMA", info["act_bound"], info["weight_bound"], info["mode"]))
     P = S * G
     ev = {k: [] for k in ("k_stage1", "k_stage2", "path")}
     torch.cuda.synchronize()
@@ -813,17 +826,16 @@ def main():
         gbs = B_NODE[k] * P / (kms[k] * 1e-3) / 1e9
         kern[k] = {"ms": round(kms[k], 4), "alg_bytes_per_launch": B_NODE[k] * P, "achieved_GBs": round(gbs, 1),
                    "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                   "traffic": TRAFFIC_CFG2[k] if a.config == "cfg2_200x10k" else None}
+                   "traffic": None}
     exec_tf = F16_EXEC_FLOP_NODE * P / (kms["k_stage1"] * 1e-3) / 1e12
     kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_h2"
     kern["k_stage1"]["executed_f16"] = {"tflops": round(exec_tf, 1), "peak": F16_MFMA_PEAK_TF, "frac": round(exec_tf / F16_MFMA_PEAK_TF, 4),
                                          "note": "fp32 operands as two fp16 pieces, three partial products per product, fp32 accumulation"}
-    kern["k_stage2"]["kernels"] = "k_stage2_ord"
+    kern["k_stage2"]["kernels"] = "k_stage2_h2"
     roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                 "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
-                "traffic": (sum(TRAFFIC_CFG2.values()) if a.config == "cfg2_200x10k" else None),
-                "traffic_source": "constant from %s (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE of the "
-                                  "P-sized kernels), not measured in this run" % TRAFFIC_SOURCE,
+                "traffic": None, "hbm_real_frac": None,
+                "traffic_source": "not measured in this run (rocprofv3 unavailable, --no-live-traffic, or the bench is itself being profiled)",
                 "alg_bytes_per_window": b_alg, "kernels": kern, "single_stream_path_ms": round(kms["path"], 4),
                 "fp32_tflops": round(FLOP_NODE * P * (windows_per_s / world) / 1e12, 2)}
 
@@ -832,6 +844,7 @@ def main():
         "value": round(value, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "dtype_detail": prec_detail,
         "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, graphs preset, inputs "
                                "resident in HBM; independent windows as in the apply loop (P-sized kernels per window, G-sized tail "
                                "and read-outs of %d windows per set of launches); steady state after %d untimed clock-settle windows"
@@ -839,15 +852,22 @@ def main():
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq, "settle_windows": a.settle,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
         "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,
+        "drop_in_call_ms": round(drop_in_ms, 4),
+        "drop_in_call_note": "forward_fixed_source(Slice, Mask, ..., x_query, t_query) of the reference's signature, one call per window on one "
+                             "stream incl. both read-outs (HIP events over %d calls); `value` times the apply loop's window pipeline instead "
+                             "(push_window / flush_windows: tails of %d windows per set of launches on side streams)" % (nd, tail_batch),
+        "drop_in_call_roofline_frac": round(b_alg / (drop_in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_live_traffic:
         tr = measure_traffic()
         if tr is not None:
             roofline["traffic"] = tr["k_stage1"] + tr["k_stage2"]
+            # the same window time against the bytes the kernels REALLY move: the fused kernels keep h0 / h1 / u / v in registers,
+            # so this is far below `frac` (which prices the reference dataflow's bytes); neither P-sized kernel is HBM-bound
+            roofline["hbm_real_frac"] = round(roofline["traffic"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/stage_profile.py "
-                                          "(same kernels, same workload), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch of the P-sized kernels; "
-                                          "committed profile of the same passes: %s" % TRAFFIC_SOURCE)
+                                          "(same kernels, same workload), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch of the P-sized kernels")
             for k in ("k_stage1", "k_stage2"):
                 kern[k]["traffic"] = tr[k]
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_cfg4_one_gpu \
@@ -910,6 +930,8 @@ def main():
                                         "timed run, scaled x%.1f (linear in product nodes): %.1f s per full window"
                                         % (gs, G, G / float(gs), c1)},
             "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xgq.cpu() - xc).abs().max()),
+            "note": "`cores` is the thread count torch was given, not a scaling claim: the oracle's scatter (index_add_) is serial, so the "
+                    "all-thread and the single-thread time per window are about equal on every box seen",
         }
     if rank == 0:
         print(json.dumps(out))

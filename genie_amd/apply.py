@@ -131,6 +131,10 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
                 continue                                                      # process_continuous_days.py:792-793
             used.append(t0)
             Slice, Mask = embed(P[sel], t0)
+            if not getattr(net, "use_phase_types", True):        # process_continuous_days.py:783-786
+                Slice, Mask = np.array(Slice, copy=True), np.array(Mask, copy=True)
+                Slice[:, 2:] = 0.0
+                Mask[:, 2:] = 0.0
             y, x = net.forward_fixed_source(torch.from_numpy(Slice).to(dev), torch.from_numpy(Mask).to(dev), None, None, None,
                                             locs, xg, xq, tq)
             cols, keep = window_columns(tsteps_abs, t0, offsets, drop_last, asc)
@@ -143,7 +147,8 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
                          times=None, tail_batch=16):
     """GPU-only apply loop: `P` [n,5] (t, station index in the model's station order, amp, prob, phase) sorted by time,
     `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used). `tail_batch`: windows
-    per G-sized tail (1..8; 8 measured best with the device embedding in the loop, bench.py --mode stream)."""
+    per G-sized tail (1..16; 16 is the default of the bench and measured best with the device embedding in the loop, bench.py --mode
+    stream: the tail kernels are latency-bound, their fixed costs are paid once per batch)."""
     hp = net._hip
     net.window_batch = tail_batch
     dev = hp.device
@@ -159,7 +164,10 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     Ps = P[order]
     d_t = torch.from_numpy(Ps[:, 0].copy()).to(dev)
     d_sta = torch.from_numpy(Ps[:, 1].astype(np.int32)).to(dev)
-    d_ph = torch.from_numpy(Ps[:, 4].astype(np.int32)).to(dev)
+    ph = Ps[:, 4].astype(np.int32)
+    if not getattr(net, "use_phase_types", True):        # process_continuous_days.py:562-563 (the embedding zeroes columns 2, 3: :783-786)
+        ph = np.zeros_like(ph)
+    d_ph = torch.from_numpy(ph).to(dev)
     d_trv = torch.from_numpy(np.ascontiguousarray(trv_times, dtype=np.float32).reshape(-1, 2)).to(dev)
     Out_2 = torch.zeros((geom.x_query.shape[0], len(tsteps_abs)), dtype=torch.float32, device=dev)
     locs = torch.from_numpy(geom.locs).float().to(dev)

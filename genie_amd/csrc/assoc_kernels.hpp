@@ -25,6 +25,8 @@ struct AsArgs {
     float* c; float* wu; float* wv;
     const float* packed;
     float* save; long long Pn;   // training forward: pre-activations kept for the backward passes, [AV_*][Pn][16], or null
+    const int32_t* src_of;       // PCSR (irregular product graph, `use_subgraph`): source node of every product node; the CSR arrays
+                                 // above are then the PRODUCT-level ones (indexed by product node, columns = product-node ids)
 };
 // blocks of the association phase's saved pre-activations: BipartiteGraphReadOutOperator fc1 (before PReLU and the mask gate) and
 // fc2, init_trns, l1_t1_1 / l1_t2_1 (w, tile), [10, 11] = the output layer (written by the stage-2 kernel as its SV_O), layer 1
@@ -96,6 +98,8 @@ __device__ __forceinline__ f32x4 ld_row30(const float* row, int b, int q) {     
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
+// PCSR: irregular product graph: a tile is 16 consecutive product nodes, the source node (hence the pg row) is per lane
+template <bool PCSR>
 __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
     constexpr int NF4 = (GA_GROUPS * 256 + GA_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -109,16 +113,29 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_items = PCSR ? (a.Pn + 15) / 16 : w.nitems;
+    const long long it0 = PCSR ? (long long)blockIdx.x * (blockDim.x >> 6) + wave : w.it;
+    const long long its = PCSR ? (long long)gridDim.x * (blockDim.x >> 6) : w.stride;
+    for (long long it = it0; it < n_items; it += its) {
+        int gi = 0, tb = 0, g, su;
+        bool valid;
+        long long pi, pu;
+        if (PCSR) {
+            const long long pr = it * 16 + j;
+            valid = pr < a.Pn;
+            pi = pu = valid ? pr : a.Pn - 1;
+            g = a.src_of[pi];
+            su = 0;
+        } else {
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            const int sc = valid ? s : S - 1;
+            su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
+            pi = (long long)g * S + sc; pu = (long long)g * S + su;
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
-        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
         const float* pg = a.pg + (long long)g * AS_PG;
         const float eq = q < 3 ? a.edge_attr[pu * 3 + q] : 0.f;
         const float mq = a.mask[pu * 4 + q];
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
     }
 }
 
+template <bool PCSR>
 __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
     constexpr int NF4 = (GB_GROUPS * 256 + GB_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -192,22 +210,60 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
     float* ts = tsc + wave * 16 * 68;
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_items = PCSR ? (a.Pn + 15) / 16 : w.nitems;
+    const long long it0 = PCSR ? (long long)blockIdx.x * (blockDim.x >> 6) + wave : w.it;
+    const long long its = PCSR ? (long long)gridDim.x * (blockDim.x >> 6) : w.stride;
+    for (long long it = it0; it < n_items; it += its) {
+        int gi = 0, tb = 0, g, su;
+        bool valid;
+        long long pi, pu, pl = 0;            // pl (PCSR): the product node whose rows this lane gathers
+        if (PCSR) {
+            const long long pr = it * 16 + j;
+            valid = pr < a.Pn;
+            pi = pu = valid ? pr : a.Pn - 1;
+            g = a.src_of[pi];
+            su = 0;
+            pl = min(it * 16 + jl, a.Pn - 1);
+        } else {
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            const int sc = valid ? s : S - 1;
+            su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
+            pi = (long long)g * S + sc; pu = (long long)g * S + su;
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int sc = valid ? s : S - 1;
-        const int su = a.sta_user != nullptr ? a.sta_user[sc] : sc;
-        const long long pi = (long long)g * S + sc, pu = (long long)g * S + su;
         const float* pg = a.pg + (long long)g * AS_PG;
         const float mq = a.mask[pu * 4 + q];
         const f32x4 x0 = *(const f32x4*)(a.tr + pi * 32 + 4 * q), x1 = *(const f32x4*)(a.tr + pi * 32 + 16 + 4 * q);
         // neighbour means of q1 (stations of the same source node) and q2 (same station, neighbouring source nodes), edge order
         f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
         const int s_l = tb * 16 + jl, scl = s_l < S ? s_l : S - 1;        // the node whose rows this lane gathers
+        if (PCSR) {        // both neighbourhoods are lists of product-node ids, ragged: predicated chunks of four, edge order
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int32_t* rp = nb == 0 ? a.sta_rowptr : a.src_rowptr;
+                const int32_t* cl = nb == 0 ? a.sta_col : a.src_col;
+                const float* base = (nb == 0 ? a.q1 : a.q2) + 4 * ql;
+                const int eb = rp[pl], ee = rp[pl + 1];
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+                for (int e = eb; __any(e < ee); e += 4) {
+                    f32x4 ra[4], rb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool ok = e + k < ee;
+                        const float* r = base + (long long)cl[ok ? e + k : max(ee - 1, 0)] * 32;
+                        ra[k] = *(const f32x4*)r; rb[k] = *(const f32x4*)(r + 16);
+                        if (!ok) { ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[k] = ra[k]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sa += ra[k]; sb += rb[k]; }
+                }
+                const float inv = 1.f / (float)max(ee - eb, 1);
+                if (nb == 0) { n1a = sa * inv; n1b = sb * inv; } else { n2a = sa * inv; n2b = sb * inv; }
+            }
+        } else {
         {
             const int eb = a.sta_rowptr[scl], ee = a.sta_rowptr[scl + 1];
             const float* base = a.q1 + (long long)g * S * 32 + 4 * ql;
@@ -247,6 +303,7 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
             }
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
+        }
         }
         *(f32x4*)(ts + jl * 68 + 4 * ql) = n1a; *(f32x4*)(ts + jl * 68 + 16 + 4 * ql) = n1b;
         *(f32x4*)(ts + jl * 68 + 32 + 4 * ql) = n2a; *(f32x4*)(ts + jl * 68 + 48 + 4 * ql) = n2b;

@@ -17,6 +17,8 @@ struct EmbArgs {
     unsigned* xs;          // optional: the split rows of k_stage1_h2, written together with Slice / Mask
     const int32_t* sta_inv; // station processing order of the split rows (caller's station -> internal), or null
     float* mm;              // with sta_inv: max of the Mask row, in processing order
+    int no_phase;           // use_phase_types: False (config.yaml:91): the phase-informed columns 2, 3 of Slice / Mask are zero
+                            // (process_continuous_days.py:783-786; the caller passes every pick with phase 0, :562-563)
 };
 
 __global__ void k_embed_scatter(EmbArgs a) {
@@ -58,6 +60,7 @@ __global__ void k_embed_gather(EmbArgs a) {
     sl.y = fmaxf(ep[is], es[is]);                                        // :613
     sl.z = ep[ip];                                                       // :614
     sl.w = es[is];                                                       // :615
+    if (a.no_phase) { sl.z = 0.f; sl.w = 0.f; }
     f32x4 mk;
     mk.x = fabsf(sl.x) > 0.01f ? 1.f : 0.f; mk.y = fabsf(sl.y) > 0.01f ? 1.f : 0.f;      // :629
     mk.z = fabsf(sl.z) > 0.01f ? 1.f : 0.f; mk.w = fabsf(sl.w) > 0.01f ? 1.f : 0.f;
@@ -484,6 +487,13 @@ __global__ __launch_bounds__(256) void k_subgraph_csr(const int32_t* __restrict_
         if (m >= 0) { if (FILL) o2[c2] = m; ++c2; }
     }
     if (!FILL) { cnt_sta[n] = c1; cnt_src[n] = c2; }
+}
+
+// owner[p] = g for every product node p of the row range [seg_rowptr[g], seg_rowptr[g + 1]) (irregular product graphs)
+__global__ void k_seg_owner(const int32_t* __restrict__ seg_rowptr, int G, int32_t* __restrict__ owner) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    for (int p = seg_rowptr[g]; p < seg_rowptr[g + 1]; ++p) owner[p] = g;
 }
 
 __global__ void k_export(const float* __restrict__ src, long long rows, int pitch, int ncol, float* __restrict__ dst,

@@ -1202,6 +1202,7 @@ struct genie_ctx {
     bool pcsr;
     bool pcsr_h2;              // ... with at most 8 / 15 neighbours per product node: k_stage1_h2<.., PCSR> applies
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
+    int32_t* p_src_of;         // ... source node of every product node (built on the first genie_assoc_fwd)
     float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
     bool has_edges;
     // station processing order (genie_set_station_order): internal -> caller's station, its inverse, the station graph in
@@ -1233,6 +1234,7 @@ struct genie_ctx {
     unsigned *ea_frag, *ea_frag_tmp;    // edge_attr as B fragments of k_stage2_h2 (k_ea_frag): of the registered static edge_attr / of any other one
     bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
     int xs_sta_order;          // genie_embed_window_split: the station-order state its split rows were written under
+    int no_phase;              // genie_set_phase_types(0): the embedding zeroes the phase-informed columns of Slice / Mask
     // workspace offsets (floats)
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
@@ -2158,7 +2160,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
-                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg};
+                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
     for (void* p : ptrs) (void)hipFree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
@@ -2737,6 +2739,7 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
     a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
     a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs;
+    a.no_phase = c->no_phase;
     a.sta_inv = (xs && sta_order_on(c)) ? c->sta_inv : nullptr;
     a.mm = xs ? (float*)xs - c->o_xs + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride : nullptr;   // xs = workspace + o_xs
     HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
@@ -3185,7 +3188,8 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if (rc) return rc;
     if (!y_latent || !mask_src || !x_latent || !mask || !edge_attr || !out || !assoc_ws)
         return fail(GENIE_ERR_ARG, "genie_assoc_fwd: null argument");
-    if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_assoc_fwd: needs an unsharded Cartesian product graph");
+    if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_assoc_fwd: needs an unsharded product graph");
+    if (c->pcsr && save) return fail(GENIE_ERR_STATE, "genie_assoc_train_fwd: not available on an irregular product graph");
     if (((uintptr_t)assoc_ws & 15) != 0) return fail(GENIE_ERR_ARG, "genie_assoc_fwd: assoc_ws must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
@@ -3206,11 +3210,26 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     a.tr = (float*)assoc_ws; a.q1 = a.tr + 32 * (size_t)c->P; a.q2 = a.q1 + 32 * (size_t)c->P;
     a.c = d.c; a.wu = d.wu; a.wv = d.wv;
     a.save = save; a.Pn = c->P;
-    const int grid = da_grid(c, (long long)c->G * c->T, std::max(1, c->bpc1));
-    a.packed = c->packed[2];
-    k_assoc_a<<<grid, 256, 0, st>>>(a);
-    a.packed = c->packed[3];
-    k_assoc_b<<<grid, 256, 0, st>>>(a);
+    if (c->pcsr) {       // irregular product graph: product-level CSRs, the source node of every product node from the row ranges
+        if (!c->p_src_of) {
+            HIP_TRY(hipMalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
+            k_seg_owner<<<(c->G + 255) / 256, 256, 0, st>>>(c->seg_rowptr, c->G, c->p_src_of);
+        }
+        a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
+        a.sta_user = nullptr; a.src_of = c->p_src_of;
+        const long long ntiles = (c->P + 15) / 16;
+        const int grid = (int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * std::max(1, c->bpc1));
+        a.packed = c->packed[2];
+        k_assoc_a<true><<<grid, 256, 0, st>>>(a);
+        a.packed = c->packed[3];
+        k_assoc_b<true><<<grid, 256, 0, st>>>(a);
+    } else {
+        const int grid = da_grid(c, (long long)c->G * c->T, std::max(1, c->bpc1));
+        a.packed = c->packed[2];
+        k_assoc_a<false><<<grid, 256, 0, st>>>(a);
+        a.packed = c->packed[3];
+        k_assoc_b<false><<<grid, 256, 0, st>>>(a);
+    }
     // second pair of neighbour means + PReLU2 = the stage-2 kernel of this context without its Bipartite half
     rc = run_stage2(c, mask, edge_attr, out, ws, stream, 0, c->G, c->raw + g_params[W_AS_ACT2].off, 1);
     if (save) { c->force_generic = 0; c->train_save = nullptr; }
@@ -3518,6 +3537,12 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
         pair_sta, pair_src, n_prod, seg_rowptr, sta_rowptr, sta_col, src_rowptr, src_col, nullptr, nullptr, p_sta_rowptr, p_src_rowptr,
         p_sta_col, p_src_col);
     HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_phase_types: null context");
+    c->no_phase = use_phase_types ? 0 : 1;
     return GENIE_OK;
 }
 

@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     __syncthreads();
     const float* lbias = (const float*)(lw + G2_GROUPS * 64);
     const float* lscal = lbias + G2_BIAS * 16;
-    const float a2 = lscal[0], ab1 = lscal[1];
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
     __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -988,6 +988,7 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
                 }
             }
         }
+        if (a.no_bip) continue;         // last pass of the association heads: x_latent only (wave-uniform)
         *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
         *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
         GSYNC();

@@ -294,6 +294,10 @@ class HipPath(object):
         self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
         self._w_key = None
 
+    def set_phase_types(self, use_phase_types):
+        """`use_phase_types` of config.yaml:91 for the device embedding (genie_set_phase_types)."""
+        _lib.check(self.lib.genie_set_phase_types(self.ctx, 1 if use_phase_types else 0), "genie_set_phase_types")
+
     def set_stage_precision(self, mode):
         """"auto" | "f16x2" | "f32": arithmetic of the P-sized stages (genie_set_stage_precision)."""
         if mode not in _PRECISION_MODES:
@@ -536,7 +540,7 @@ class HipPath(object):
         """Windows per batched tail, 1..16. Measured at config 2: the batched tail needs 104 us of GPU time per window against 186
         us for per-window tails, but its long persistent read-out workgroups hold CUs that the next stage-1 workgroups wait for:
         for resident windows one tail per window is ~1 % faster end to end, with the device embedding in the loop batches of 8
-        are 3.6 % faster. Default 1 (results arrive per window); `apply_windows_device` uses 8."""
+        are 3.6 % faster. Default 1 (results arrive per window); `apply_windows_device` and the bench use 16."""
         n = int(n)
         if not 1 <= n <= self.MAX_BATCH:
             raise ValueError("window batch must be in [1, %d]" % self.MAX_BATCH)
@@ -550,7 +554,9 @@ class HipPath(object):
     def window_push(self, Slice, Mask, edge_attr):
         """Stage 1 + stage 2 of one window on the current stream, into the next workspace slot of the open batch; returns the
         number of windows now pending (call `windows_flush` when it reaches `window_batch`, or earlier). The plain
-        single-stream calls (`path_fwd`, read-outs) have a workspace slot of their own and may be mixed with pending windows."""
+        single-stream calls (`path_fwd`, read-outs) have a slot of their own for the G-sized buffers (PLAIN_SLOT) and may be mixed
+        with pending windows ON THE SAME STREAM only: the P-sized c / wu / wv rows exist GENIE_NBIG = 4 times (slot % 4), so a plain
+        call shares its copy with the window slots 0, 4, 8, ...; stream order is what keeps them apart."""
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -938,10 +944,15 @@ class HipPath(object):
         x_spatial, d_ylat [G, 30] on y_latent and d_qlat [Q, 30] on the SpatialAttention output of the query rows, from consumers
         outside the path) -> dict parameter name -> gradient (views into one blob laid out like the weight mirror), every
         parameter of the path."""
-        dev, G = self.device, self.n_grid
+        dev, G, P = self.device, self.n_grid, self.n_prod
+        Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))      # raw pointers below: same normalisation as the forward
+        edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         pos = _f32(pos, "pos", (G, 3))
         x_query = _f32(x_query, "x_query")
         nq = int(x_query.shape[0])
+        if tuple(knn_idx.shape) != (nq, 10) or knn_idx.dtype != torch.int32 or not knn_idx.is_cuda:
+            raise ValueError("knn_idx must be an int32 GPU tensor of shape [n_query, 10]")
+        knn_idx = knn_idx.contiguous()
         tq = _f32(t_query, "t_query").reshape(-1)
         T = tq.numel()
         d_y = _f32(d_y, "d_y").reshape(G, T)

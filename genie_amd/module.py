@@ -638,8 +638,12 @@ class GCN_Detection_Network_extended(nn.Module):
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
-                 use_updated_model_definition=False):
+                 use_updated_model_definition=False, use_phase_types=True):
         super().__init__()
+        # config.yaml:91. False = the pick phase labels are ignored: LocalSliceLgCollapse and StationSourceAttentionMergedPhases
+        # zero `phase_label` (module.py:632-633, :706-707); the callers also zero the phase-informed columns 2, 3 of Slice / Mask
+        # (process_continuous_days.py:783-786, train_GENIE_model.py:1707-1709), which `genie_amd.apply` does under the same flag
+        self.use_phase_types = bool(use_phase_types)
         # config.yaml:92: station / source positions appended to the inputs (module.py:916); forward_fixed_source only
         if use_absolute_pos and use_updated_model_definition:
             raise NotImplementedError("use_absolute_pos together with use_updated_model_definition")
@@ -678,6 +682,7 @@ class GCN_Detection_Network_extended(nn.Module):
                                     device=dev, sta_order=sta_order)
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        self._hip.set_phase_types(self.use_phase_types)
         if self.use_updated_model_definition:
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_updated_model_definition=True needs station and source positions")
@@ -716,7 +721,6 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr_version = self._edge_attr._version
         self._hip.set_static_edge_attr(self._edge_attr)
         dev = self._edge_attr.device
-        self._sta_tab, self._src_tab = sta_nbr.long().to(dev), src_nbr.long().to(dev)   # association heads (PyTorch)
 
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
@@ -739,7 +743,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
-        self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
+        self._edge_attr_version = self._edge_attr._version
 
     def set_adjacencies_subgraph_from_positions(self, pos_loc, pos_src, edge_attr=None, k_sta_edges=10, k_spc_edges=15,
                                                 max_deg_offset=5.0, k_nearest_pairs=30, scale_deg=110e3,
@@ -771,7 +775,6 @@ class GCN_Detection_Network_extended(nn.Module):
         elif callable(edge_attr):
             edge_attr = edge_attr(pairs)
         self._edge_attr = _engine._f32(edge_attr, "edge_attr", (sub["n_prod"], 3))
-        self._sta_tab = self._src_tab = None          # the association heads assume the Cartesian layout
         self.A_src = A_src
         return A_sta, A_src, pairs
 
@@ -791,13 +794,15 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
         self._edge_attr_version = self._edge_attr._version
         self._hip.set_static_edge_attr(self._edge_attr)
-        self._sta_tab, self._src_tab = sta_tab.long(), src_tab.long()
         return A_sta, A_src
 
-    def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src):
+    def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src, A_edges_p=None, A_edges_s=None,
+                             dt_partition=None, tlatent=None):
         """Same effect as `set_adjacencies` from the BASE graphs only (process_utils.py:718-719), for sizes
-        where the explicit product edge lists cannot be materialised (config 4: 2.3 G edges)."""
+        where the explicit product edge lists cannot be materialised (config 4: 2.3 G edges). The last four arguments are
+        `set_adjacencies`' time-pointer tables and travel times (module.py:941): needed by the 4-output `forward_fixed` only."""
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
+        self.A_edges_p, self.A_edges_s, self.dt_partition, self.tlatent = A_edges_p, A_edges_s, dt_partition, tlatent
         self.A_src = torch.as_tensor(A_src_src)
         self._build_engine(_engine.csr_from_edges(A_sta_sta, n_sta), _engine.csr_from_edges(A_src_src, n_grid),
                            n_sta, n_grid, pos_src, pos_loc)
@@ -831,6 +836,10 @@ class GCN_Detection_Network_extended(nn.Module):
             n_src_rows = int(x_query_src_cart.shape[0])
             knn = torch.cat((knn, _engine.knn_device(x_temp_cuda_cart, x_query_src_cart, 10)), 0)
             x_query_cart = torch.cat((_engine._f32(x_query_cart, "x_query"), _engine._f32(x_query_src_cart, "x_query_src")), 0)
+        # normalised ONCE, before autograd saves them: the backward hands these very buffers to genie_train_bwd as raw pointers (a
+        # float64 or non-contiguous Slice / Mask would otherwise give a correct forward and wrong DataAggregation gradients)
+        P = hp.n_prod
+        Slice, Mask = _engine._f32(Slice, "Slice", (P, 4)), _engine._f32(Mask, "Mask", (P, 4))
         return _PathTrain.apply(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query, hp, bool(want_latents), n_src_rows,
                                 *[self._path_params[n] for n in TRAIN_PATH_PARAMS])
 
@@ -896,9 +905,11 @@ class GCN_Detection_Network_extended(nn.Module):
         / use_absolute_pos their static per-station / per-source-node terms are added inside the same kernels), LocalSliceLgCollapse
         P / S (genie_lslc_fwd) and the arrival head (genie_arrivals_fwd). In train() mode with gradients enabled the same modules
         differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; default model definition)."""
-        if getattr(self, "_sta_tab", None) is None:
-            raise NotImplementedError("forward_fixed needs set_adjacencies(...) on a Cartesian product graph (not use_subgraph / "
-                                      "set_adjacencies_base): only forward_fixed_source is available here")
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) before forward_fixed")
+        if getattr(self, "A_edges_p", None) is None or getattr(self, "tlatent", None) is None:
+            raise RuntimeError("forward_fixed needs the time-pointer tables and travel times (A_edges_p, A_edges_s, dt_partition, tlatent) "
+                               "of set_adjacencies(...) / set_adjacencies_base(...)")
         hp = self._hip
         if not getattr(hp, "assoc_ready", False) and hp is not None:
             hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
@@ -923,6 +934,8 @@ class GCN_Detection_Network_extended(nn.Module):
         else:           # :986-990 as three P-sized HIP passes
             s = hp.assoc_fwd(y_latent, mask_out, x_latent, Maskf, self._edge_attr)
         n_src = int(x_query_src_cart.shape[0])
+        if not self.use_phase_types:      # module.py:632-633, :706-707
+            phase_label = phase_label * 0.0
         if len(tpick) == 0:      # no pick in the window: the reference returns two empty [n_src, 0, 1] tensors
             e = s.new_zeros((n_src, 0, 1))
             return y, x, e, e.clone()

@@ -89,6 +89,10 @@ int genie_ctx_destroy(genie_ctx* ctx);
  * processing order inside the workspace; genie_ws_export un-permutes). Honoured by the f16x2 stage 1 + pipelined stage 2
  * pair on Cartesian product graphs, ignored otherwise; NULL = off. All ranks of a sharded run must pass the same order. */
 int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
+/* `use_phase_types: False` (config.yaml:91): genie_embed_window* then writes zeros into the phase-informed columns 2, 3 of Slice /
+ * Mask (process_continuous_days.py:783-786); the caller passes every pick with phase 0 (:562-563) and zeroes `phase_label` for the
+ * association heads (module.py:632-633, :706-707). Default: phase types in use. */
+int genie_set_phase_types(genie_ctx* ctx, int use_phase_types);
 /* Arithmetic of the P-sized stages on the reference's kNN graphs. mode 0 (default) = automatic: two-piece fp16 operands on the
  * 16-bit matrix pipe (k_stage1_h2 / k_stage2_h2) while the fp16 range guard of the committed weights holds, the fp32-MFMA kernels
  * otherwise; 1 = two-piece fp16 operands regardless of the guard (A/B runs; hidden states above 65504 become non-finite);

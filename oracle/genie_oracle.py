@@ -328,11 +328,12 @@ def weights_from_npz(z, dtype=torch.float32, prefix="w/"):
 EPS = 5.0 * KERNEL_SIG_T     # module.py:41
 
 
-def bipartite_read_out(w, y_latent, edge_attr, mask_src, n_sta, pre="BipartiteGraphReadOutOperator"):
+def bipartite_read_out(w, y_latent, edge_attr, mask_src, n_sta, pre="BipartiteGraphReadOutOperator", src_of=None):
     """module.py:343-352 with A_Lg_in_src.edge_index = [g(p); p] (one edge per product node, in product order):
-    s_p = PReLU2(fc2(mask[g] * PReLU1(fc1([y_latent[g] || edge_attr[p]])))); second output mask[g(p)]."""
+    s_p = PReLU2(fc2(mask[g] * PReLU1(fc1([y_latent[g] || edge_attr[p]])))); second output mask[g(p)]. `src_of` = g(p) of an
+    irregular product graph (`use_subgraph`); default: the Cartesian numbering p = g * n_sta + s."""
     P = edge_attr.shape[0]
-    g = torch.arange(P) // n_sta
+    g = torch.arange(P) // n_sta if src_of is None else src_of.long()
     msg = mask_src[g] * act(linear(torch.cat((y_latent[g], edge_attr), dim=-1), w, pre + ".fc1"), w, pre + ".activate1")
     return act(linear(msg, w, pre + ".fc2"), w, pre + ".activate2"), mask_src[g]
 
@@ -429,8 +430,10 @@ def station_source_attention(w, n_src, stime, src_embed, trv_src, arrival_p, arr
 
 def forward_fixed(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, A_src, A_edges_p, A_edges_s, dt_partition,
                   tlatent, tpick, ipick, phase_label, x_grid_cart, x_query_cart, x_query_src_cart, t_query, tq_sample, trv_out_q,
-                  n_sta, pos_rel=None, abs_pos=None):
-    """forward_fixed (module.py:963-997): (y, x, arv_p, arv_s). `pos_rel` = (pos_rel_sta, pos_rel_src) per product edge: the
+                  n_sta, pos_rel=None, abs_pos=None, use_phase_types=True):
+    """forward_fixed (module.py:963-997): (y, x, arv_p, arv_s). `use_phase_types=False` (config.yaml:91): the two pick-sized heads
+    see phase_label * 0 (module.py:632-633, :706-707). The product graph may be irregular (`use_subgraph`: A_src_in_prod[1] is the
+    source node of every product node). `pos_rel` = (pos_rel_sta, pos_rel_src) per product edge: the
     use_updated_model_definition class (module.py:1128-1161); `abs_pos` = (locs, A_src_in_sta): use_absolute_pos (the scaled
     station / source positions appended to Slice, :969-970, and to the association embedding, :987-988)."""
     scaled = None
@@ -442,7 +445,9 @@ def forward_fixed(w, Slice, Mask, A_in_sta, A_in_src, edge_attr, A_src_in_prod, 
                              t_query, full=True, pos_rel=pos_rel)
     x_src = spatial_attention(w, o["sa3"], x_query_src_cart, x_grid_cart)                              # :981
     mask_out = 1.0 * (o["y"][:, :, 0].max(1, keepdim=True)[0] > 0.01)                                  # :985
-    s, m1 = bipartite_read_out(w, o["y_latent"], edge_attr, mask_out.to(Slice.dtype), n_sta)           # :986
+    if not use_phase_types:
+        phase_label = phase_label * 0.0
+    s, m1 = bipartite_read_out(w, o["y_latent"], edge_attr, mask_out.to(Slice.dtype), n_sta, src_of=A_src_in_prod[1])   # :986
     if scaled is not None:
         s = torch.cat((s, scaled), dim=1)                                                              # :987-988
     s = data_aggregation_association(w, s, o["x_latent"].detach(), m1, Mask, A_in_sta, A_in_src, pos_rel=pos_rel)   # :990 (x_latent.detach())

@@ -20,13 +20,13 @@ REF_CODE = "/root/reference/Code"
 OUT = os.path.join(REPO, "tests", "golden")
 
 
-def _import_reference(updated_definition=False, absolute_pos=False):
+def _import_reference(updated_definition=False, absolute_pos=False, phase_types=True):
     sys.dont_write_bytecode = True
     sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
     sys.path.insert(0, REF_CODE)
     sys.path.insert(0, REPO)
     cwd = REF_CODE                # module.py:27-31 reads config.yaml / train_config.yaml from the CWD
-    if updated_definition or absolute_pos:
+    if updated_definition or absolute_pos or not phase_types:
         # `use_updated_model_definition` / `use_absolute_pos` are read from config.yaml at import time (module.py:32-33): import
         # the reference from a scratch directory holding its YAML files with that one flag flipped
         import tempfile
@@ -40,11 +40,15 @@ def _import_reference(updated_definition=False, absolute_pos=False):
                 if f == "config.yaml" and absolute_pos:
                     assert "use_absolute_pos: False" in txt
                     txt = txt.replace("use_absolute_pos: False", "use_absolute_pos: True")
+                if f == "config.yaml" and not phase_types:
+                    assert "use_phase_types: True" in txt
+                    txt = txt.replace("use_phase_types: True", "use_phase_types: False")
                 open(os.path.join(cwd, f), "w").write(txt)
     os.chdir(cwd)
     import module as ref_module   # noqa: E402
     assert bool(ref_module.use_updated_model_definition) == bool(updated_definition)
     assert bool(ref_module.use_absolute_pos) == bool(absolute_pos)
+    assert bool(ref_module.use_phase_types) == bool(phase_types)
     return ref_module
 
 
@@ -178,7 +182,7 @@ def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "nonzero rows", int((Inpts[0].abs().sum(1) > 0).sum()))
 
 
-def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
+def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None, pairs=None, zero_phase_columns=False):
     """Golden vector for the 4-output `forward_fixed` (module.py:963-997): source branch + association heads
     (BipartiteGraphReadOutOperator, DataAggregationAssociationPhase, LocalSliceLgCollapse P/S,
     StationSourceAttentionMergedPhases), with the time-pointer tables built by the reference's own
@@ -187,11 +191,33 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
     import utils as ref_utils   # noqa: E402
     from genie_amd import graph as G
     S, Gn = geom.n_sta, geom.n_grid
-    A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
-        geom.A_sta_sta, geom.A_src_src, S, Gn)
     trv = geom.travel_times().astype(np.float32)                                   # [G,S,2]
     max_t = float(np.ceil(trv.max()))
-    A_edges_p, A_edges_s, dt_partition = ref_utils.assemble_time_pointers_for_stations(trv, k=10, max_t=max_t, dt=3.0 / 5.0, win=6.0)
+    Slice_in, Mask_in = win["Slice"], win["Mask"]
+    if pairs is None:
+        A_prod_sta_sta, A_prod_src_src, A_src_in_prod, A_src_in_sta = G.cartesian_product_edges(
+            geom.A_sta_sta, geom.A_src_src, S, Gn)
+        A_edges_p, A_edges_s, dt_partition = ref_utils.assemble_time_pointers_for_stations(trv, k=10, max_t=max_t, dt=3.0 / 5.0, win=6.0)
+        spatial_np, tlat_np = geom.edge_attr(), trv.reshape(-1, 2)
+    else:
+        # `use_subgraph: True`: the product nodes are the listed (station, source) pairs; the time-pointer tables come from the
+        # reference's own builder for such graphs (process_utils.py:851-877, called as at train_GENIE_model.py:1456)
+        import process_utils as ref_pu
+        A_src_in_sta = torch.from_numpy(np.asarray(pairs)).long()
+        A_prod_sta_sta, A_prod_src_src, A_src_in_prod = G.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+
+        def trv_pairwise(loc, src):
+            d = (src - loc).norm(dim=1)
+            return torch.stack((d / syn_VP, d / syn_VS), dim=1)
+        A_edges_p, A_edges_s, dt_partition = ref_pu.compute_time_embedding_vectors(
+            trv_pairwise, geom.locs.astype(np.float32), geom.x_grid.astype(np.float32), A_src_in_sta, max_t, dt_res=3.0 / 5.0, t_win=6.0)
+        rows = pairs[1] * S + pairs[0]
+        Slice_in, Mask_in = Slice_in[rows], Mask_in[rows]
+        spatial_np, tlat_np = geom.edge_attr()[rows], trv.reshape(-1, 2)[rows]
+    if zero_phase_columns:          # what the callers do under use_phase_types: False (process_continuous_days.py:783-786)
+        Slice_in, Mask_in = Slice_in.copy(), Mask_in.copy()
+        Slice_in[:, 2:] = 0.0
+        Mask_in[:, 2:] = 0.0
     torch.manual_seed(weights_seed)
     np.random.seed(weights_seed)
     mz = ref.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
@@ -202,10 +228,10 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
     sd32 = {k: v.detach().clone().numpy() for k, v in mz.state_dict().items()}
     mz.eval()
     Data = sys.modules["torch_geometric"].data.Data
-    spatial_vals = torch.from_numpy(geom.edge_attr())
+    spatial_vals = torch.from_numpy(np.ascontiguousarray(spatial_np))
     A_src_in_edges = Data(x=spatial_vals, edge_index=A_src_in_prod)
     A_Lg_in_src = Data(x=spatial_vals, edge_index=A_src_in_prod.flip(0).contiguous())
-    tlatent = torch.from_numpy(trv.reshape(-1, 2))
+    tlatent = torch.from_numpy(np.ascontiguousarray(tlat_np))
     mz.set_adjacencies(A_prod_sta_sta, A_prod_src_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, torch.from_numpy(geom.A_src_src).long(),
                        torch.from_numpy(A_edges_p).long(), torch.from_numpy(A_edges_s).long(), torch.from_numpy(dt_partition).float(),
                        tlatent, torch.from_numpy(geom.locs).float(), torch.from_numpy(geom.x_grid).float())
@@ -219,7 +245,7 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
     keep = (win["tpick"] > dt_partition[0] + 0.5) & (win["tpick"] < dt_partition[-1] - 0.5)
     tpick, ipick, phase = win["tpick"][keep], win["ipick"][keep], win["phase_label"][keep]
     with torch.no_grad():
-        out = mz.forward_fixed(torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"]), torch.from_numpy(tpick),
+        out = mz.forward_fixed(torch.from_numpy(np.ascontiguousarray(Slice_in)), torch.from_numpy(np.ascontiguousarray(Mask_in)), torch.from_numpy(tpick),
                                torch.from_numpy(ipick).long(), torch.from_numpy(phase), torch.from_numpy(geom.locs).float(),
                                torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
                                torch.from_numpy(x_query_src).float(), torch.from_numpy(geom.t_query).float(),
@@ -227,10 +253,13 @@ def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None):
     res = {"w/" + k: v.astype(np.float32) for k, v in sd32.items()}
     res.update({"y": out[0].numpy(), "x": out[1].numpy(), "arv_p": out[2].numpy(), "arv_s": out[3].numpy(),
                 "n_sta": np.int64(S), "n_grid": np.int64(Gn), "locs": geom.locs, "x_grid": geom.x_grid, "x_query": geom.x_query,
-                "t_query": geom.t_query, "A_sta_sta": geom.A_sta_sta, "A_src_src": geom.A_src_src, "edge_attr": geom.edge_attr(),
-                "Slice": win["Slice"], "Mask": win["Mask"].astype(np.uint8), "tpick": tpick, "ipick": ipick, "phase_label": phase,
-                "x_query_src": x_query_src, "tq_sample": tq_sample, "trv_out_q": trv_out_q, "tlatent": trv.reshape(-1, 2),
-                "A_edges_p": A_edges_p, "A_edges_s": A_edges_s, "dt_partition": dt_partition, "max_t": np.float64(max_t)})
+                "t_query": geom.t_query, "A_sta_sta": geom.A_sta_sta, "A_src_src": geom.A_src_src, "edge_attr": np.ascontiguousarray(spatial_np),
+                "Slice": Slice_in, "Mask": Mask_in.astype(np.uint8), "tpick": tpick, "ipick": ipick, "phase_label": phase,
+                "x_query_src": x_query_src, "tq_sample": tq_sample, "trv_out_q": trv_out_q, "tlatent": np.ascontiguousarray(tlat_np),
+                "A_edges_p": np.asarray(A_edges_p), "A_edges_s": np.asarray(A_edges_s), "dt_partition": np.asarray(dt_partition),
+                "max_t": np.float64(max_t)})
+    if pairs is not None:
+        res["pairs"] = np.asarray(pairs, dtype=np.int64)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **res)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "| picks", len(tpick),
@@ -306,6 +335,35 @@ def main_assoc_variant(flag):
     geom = syn.Geometry(18, 50, L=70e3, n_query=20, seed=111 if flag == "edges" else 121)     # uniform 8 / 15 degrees, partial last tile
     win = syn.make_window(geom, 220, seed=112 if flag == "edges" else 122)
     run_assoc_case(ref, "assoc_%s_18x50" % flag, geom, win)
+
+
+def main_assoc_subgraph():
+    """`python oracle/make_golden.py --assoc-subgraph`: the 4-output `forward_fixed` of the live model on an irregular product graph
+    (`use_subgraph: True`; the geometry and node list of `--subgraph`), time-pointer tables from the reference's own
+    `compute_time_embedding_vectors`."""
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+    geom = syn.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    rng = np.random.default_rng(72)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(d.shape[0])[:, None], np.argsort(d, axis=1)[:, :6]] = True
+    keep |= rng.random(d.shape) < 0.12
+    src_i, sta_i = np.nonzero(keep)
+    pairs = np.stack((sta_i, src_i))
+    win = syn.make_window(geom, 180, seed=73)
+    run_assoc_case(ref, "assoc_subgraph_14x50", geom, win, pairs=pairs)
+
+
+def main_assoc_nophase():
+    """`python oracle/make_golden.py --assoc-nophase`: the 4-output `forward_fixed` with `use_phase_types: False` (config.yaml:91): the
+    reference zeroes `phase_label` inside LocalSliceLgCollapse / StationSourceAttentionMergedPhases (module.py:632-633, :706-707), its
+    callers zero the phase-informed columns of Slice / Mask (process_continuous_days.py:783-786)."""
+    ref = _import_reference(phase_types=False)
+    from genie_amd import synthetic as syn
+    geom = syn.Geometry(18, 50, L=70e3, n_query=20, seed=131)
+    win = syn.make_window(geom, 220, seed=132)
+    run_assoc_case(ref, "assoc_nophase_18x50", geom, win, zero_phase_columns=True)
 
 
 def main_subgraph():
@@ -414,6 +472,10 @@ def main():
         return main_subgraph()
     if "--abspos" in sys.argv:
         return main_abspos()
+    if "--assoc-subgraph" in sys.argv:
+        return main_assoc_subgraph()
+    if "--assoc-nophase" in sys.argv:
+        return main_assoc_nophase()
     if "--assoc-edges" in sys.argv:
         return main_assoc_variant("edges")
     if "--assoc-abspos" in sys.argv:

@@ -820,6 +820,15 @@ def test_device_embedding_matches_reference_and_oracle(name):
     e = torch.zeros(0, device=DEV)
     S0, M0 = hp.embed_window(e.double(), e.int(), e.int(), t0, max_t, sig, dt, torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
     assert float(S0.abs().max()) == 0.0 and float(M0.abs().max()) == 0.0
+    # use_phase_types: False (config.yaml:91): every pick enters with phase 0 (process_continuous_days.py:562-563) and the
+    # phase-informed columns 2, 3 are zero (:783-786); columns 0, 1 (any-phase series) are those of the reference's embedding
+    hp.set_phase_types(False)
+    S1, M1 = hp.embed_window(torch.from_numpy(Ps[:, 0].copy()).to(DEV), torch.from_numpy(Ps[:, 1].astype(np.int32)).to(DEV),
+                             torch.zeros(Ps.shape[0], dtype=torch.int32, device=DEV), t0, max_t, sig, dt,
+                             torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
+    assert float((S1[:, :2].cpu() - torch.from_numpy(z["Slice"][:, :2])).abs().max()) <= 1e-6
+    assert torch.equal(M1[:, :2].cpu(), torch.from_numpy(z["Mask"][:, :2].astype(np.float32)))
+    assert float(S1[:, 2:].abs().max()) == 0.0 and float(M1[:, 2:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("batch", [1, 4])
@@ -1028,15 +1037,18 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50"])
+@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
+                                  "assoc_subgraph_14x50", "assoc_nophase_18x50"])
 def test_forward_fixed_and_forward_four_outputs_match_reference(name):
     """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) in HIP end to end (front, read-outs with their latents, association
     stages, LocalSliceLgCollapse, Arrivals) against the reference's own forward_fixed golden vectors: 7 stations (generic CSR
     kernels), 20 stations with 270 picks on one station and none on another (pipelined kernels, two LDS chunks of the arrival
     softmax), the same with no candidate source inside 2 eps (`edge_index[0].max()` is then a real pick, module.py:762-765), and
     the two other model definitions (fixtures from the reference imported with the flag set): `use_updated_model_definition`
-    (DataAggregationAssociationPhaseEdges, module.py:407-480, :1128-1161) and `use_absolute_pos` (module.py:969-970, :987-988).
-    No PyTorch restatement may run in eval mode."""
+    (DataAggregationAssociationPhaseEdges, module.py:407-480, :1128-1161) and `use_absolute_pos` (module.py:969-970, :987-988);
+    `assoc_subgraph_14x50`: an irregular product graph (`use_subgraph: True`: product-level CSR forms of the association kernels,
+    time-pointer tables from the reference's compute_time_embedding_vectors); `assoc_nophase_18x50`: `use_phase_types: False`
+    (config.yaml:91; reference imported with the flag flipped). No PyTorch restatement may run in eval mode."""
     import os
     from tests.util import GOLDEN_DIR
     from oracle import genie_oracle as O
@@ -1045,10 +1057,14 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
     S, G = int(z["n_sta"]), int(z["n_grid"])
     t = lambda k, dt=torch.float32: torch.from_numpy(np.asarray(z[k])).to(dt).to(DEV)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition="edges" in name,
-                                                use_absolute_pos="abspos" in name)
+                                                use_absolute_pos="abspos" in name, use_phase_types="nophase" not in name)
     net.load_state_dict({k: v.clone() for k, v in w.items()}, strict=True)
     net.eval()
-    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    if "pairs" in z.files:
+        A_src_in_sta = torch.from_numpy(z["pairs"]).long()
+        A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(z["A_sta_sta"], z["A_src_src"], z["pairs"])
+    else:
+        A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
     ea = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.to(DEV))
     ea_flip = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.flip(0).contiguous().to(DEV))
     graphs = (A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea_flip, A_src_in_sta.to(DEV), t("A_src_src", torch.long),
