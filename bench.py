@@ -315,7 +315,7 @@ def main_stream(a, geom, nq, rank, world, dev, dist, emit=True):
         "day_86400_windows_wall_s": round(86400.0 / wps, 1),
     }
     if rank == 0 and emit:
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     return out
@@ -448,7 +448,7 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                      "unit": "GB/s", "frac": round(b_alg * wps / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None},
     }
     if rank == 0 and emit:
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     return out
@@ -620,7 +620,7 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                                          "same window with their own kNN graph, 1 warm-up + 1 timed step (%.1f s), scaled x%.1f (linear in "
                                          "product nodes): %.1f s per full step" % (gs, G, c_s, G / float(gs), c_full)}
     if rank == 0 and emit:
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     if dist is not None and emit:
         dist.destroy_process_group()
     return out
@@ -649,7 +649,7 @@ def main_dry_run_cpu(a, rank, world):
     if dist is not None:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(json.dumps({"dry_run_cpu": True, "n_gpus": world, "ranks": world if dist is None else dist.get_world_size(),
+        emit_line(json.dumps({"dry_run_cpu": True, "n_gpus": world, "ranks": world if dist is None else dist.get_world_size(),
                           "backend": "gloo" if dist is not None else "none", "ok": bool(flag.item() == 1.0),
                           "config": {"workload": "%s sharding plan + collectives only" % (a.config or "cfg1_20x500")},
                           "rank0_plan": {"n_own": plan.n_own, "n_halo": plan.n_halo}}))
@@ -658,10 +658,33 @@ def main_dry_run_cpu(a, rank, world):
     return 0 if flag.item() == 1.0 else 1
 
 
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    """The driver reads ONE JSON line from stdout. Native libraries write there too (RCCL prints a version banner when a
+    communicator is created): from here on file descriptor 1 IS stderr, and the JSON line goes to a saved duplicate of the real
+    stdout (emit_line)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(respawn_under_torchrun(a))
+    guard_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -703,7 +726,7 @@ def main():
                                               "source": "measured live on rank 0 after the sharded run, same code path with one rank"}
             except Exception as e:
                 out["one_gpu_same_config"] = {"error": repr(e)[:200]}
-            print(json.dumps(out))
+            emit_line(json.dumps(out))
         return out
     if a.mode == "stream":
         return main_stream(a, geom, nq, rank, world, dev, dist)
@@ -934,7 +957,7 @@ def main():
                     "all-thread and the single-thread time per window are about equal on every box seen",
         }
     if rank == 0:
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

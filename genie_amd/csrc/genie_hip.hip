@@ -1235,6 +1235,8 @@ struct genie_ctx {
     bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
     int xs_sta_order;          // genie_embed_window_split: the station-order state its split rows were written under
     int no_phase;              // genie_set_phase_types(0): the embedding zeroes the phase-informed columns of Slice / Mask
+    int tail_f32;              // genie_set_tail_precision(0): the G-sized tail on fp32 MFMA chains (default: fp64 chains, tail_kernels.hpp)
+    int tail_train;            // set for the duration of a training forward: its tail keeps the fp32 chains (the backward recomputes with them)
     // workspace offsets (floats)
     size_t o_xs, o_mm, o_c, o_wu, o_wv, o_part, o_sa0, o_sa1, o_bip, o_gpart, o_pj0, o_pj1, o_cv, ws_floats;
     size_t slot_stride;        // the G-sized buffers (o_part ... o_cv) exist GENIE_NSLOT times; `slot` selects the copy
@@ -1259,6 +1261,8 @@ bool sta_order_on(const genie_ctx* c) {
 
 // k_stage2_h2 is the stage 2 of the production configuration (the reference's kNN graphs in station processing order); the stage 1
 // that feeds it writes c / wv node-planar (DaArgs.np). Both launch sites ask this.
+// the G-sized tail of inference calls runs its Linears as fp64 MFMA chains (WIDE kernels) unless told otherwise
+bool tail_wide(const genie_ctx* c) { return !c->tail_f32 && !c->tail_train; }
 bool s2h_on(const genie_ctx* c) {
 #if GENIE_TUNING
     { static const bool old_pair = getenv("GENIE_S2_OLD") != nullptr; if (old_pair) return false; }   // A/B: row layout + k_stage2_ord
@@ -2420,7 +2424,8 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
                                                           g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
     } else {
         { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
-        k_bip_out_m<<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
+        if (tail_wide(c)) k_bip_out_m<true><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
+        else k_bip_out_m<false><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -2468,10 +2473,13 @@ int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos
     const int nb = sa_blocks(c);
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
     a.img = c->packed[PL_SA1 + layer - 1];
-    if (layer == 1) {
-        if (with_next) k_sa_layer_m<15, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false><<<nb, 256, 0, st>>>(a);
+    if (tail_wide(c)) {
+        if (layer == 1) { if (with_next) k_sa_layer_m<15, true, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false, true><<<nb, 256, 0, st>>>(a); }
+        else { if (with_next) k_sa_layer_m<30, true, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false, true><<<nb, 256, 0, st>>>(a); }
+    } else if (layer == 1) {
+        if (with_next) k_sa_layer_m<15, true, false><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<15, false, false><<<nb, 256, 0, st>>>(a);
     } else {
-        if (with_next) k_sa_layer_m<30, true><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false><<<nb, 256, 0, st>>>(a);
+        if (with_next) k_sa_layer_m<30, true, false><<<nb, 256, 0, st>>>(a); else k_sa_layer_m<30, false, false><<<nb, 256, 0, st>>>(a);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -2486,7 +2494,8 @@ int sa_launch_pre(genie_ctx* c, int layer, const float* x_in, float* ws, int cur
     const int nb = sa_blocks(c);
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
     a.img = c->packed[PL_SA1 + layer - 1];
-    if (layer == 1) k_sa_pre_m<15><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30><<<nb, 256, 0, st>>>(a);
+    if (tail_wide(c)) { if (layer == 1) k_sa_pre_m<15, true><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30, true><<<nb, 256, 0, st>>>(a); }
+    else { if (layer == 1) k_sa_pre_m<15, false><<<nb, 256, 0, st>>>(a); else k_sa_pre_m<30, false><<<nb, 256, 0, st>>>(a); }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -2549,6 +2558,23 @@ RoArgs make_ro_args(const genie_ctx* c) {
 }
 }  // namespace
 
+namespace {
+// grid read-out (k_readout_m<0>): fp64 chains for inference calls (their score scratch holds doubles), fp32 for the training forward
+int launch_readout_grid(genie_ctx* c, const RoArgs& a, bool with_cv, hipStream_t st) {
+    const bool wide = tail_wide(c);
+    const size_t lds = sizeof(float) * (ROM_LDS_FLOATS + (wide ? 4 * 16 * RO_SCS : 0) + (with_cv ? GP_IMG_FLOATS : 0));
+    const int lds_max = (int)(sizeof(float) * (ROM_LDS_FLOATS + 4 * 16 * RO_SCS + GP_IMG_FLOATS));
+    if (wide) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        k_readout_m<0, true><<<tl_blocks(a.N, c->tail_cu_ro), 256, lds, st>>>(a);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        k_readout_m<0, false><<<tl_blocks(a.N, c->tail_cu_ro), 256, lds, st>>>(a);
+    }
+    return GENIE_OK;
+}
+}  // namespace
+
 int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_query, int n_t, float* y_out, void* stream) {
     if (!c || !x_spatial || !t_query || !y_out) return fail(GENIE_ERR_ARG, "genie_readout_grid: null argument");
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_readout_grid: 1 <= n_t <= 10 required");
@@ -2556,8 +2582,7 @@ int genie_readout_grid(genie_ctx* c, const float* x_spatial, const float* t_quer
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out;
     a.img = c->packed[PL_RO0];
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
-    k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    { int rl = launch_readout_grid(c, a, false, (hipStream_t)stream); if (rl) return rl; }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -2577,7 +2602,8 @@ int readout_query_impl(genie_ctx* c, const float* x_spatial, const float* x_grid
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     float* cvbuf = (float*)ws + c->o_cv + c->slot * c->slot_stride;
     a.cv = cvbuf;
-    k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+    if (tail_wide(c)) k_ro_pre_m<true><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+    else k_ro_pre_m<false><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
     a.img = c->packed[PL_RO1];
     HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
     k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
@@ -2601,8 +2627,7 @@ int genie_readout_grid_latent(genie_ctx* c, const float* x_spatial, const float*
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
     a.N = a.Nw = c->G; a.T = n_t; a.x_spatial = x_spatial; a.t_query = t_query; a.out = y_out; a.lat_out = y_latent_out;
     a.img = c->packed[PL_RO0];
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
-    k_readout_m<0><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    { int rl = launch_readout_grid(c, a, false, (hipStream_t)stream); if (rl) return rl; }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -2646,7 +2671,8 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.out = w + c->o_bip + so; a.ws_out = ss; a.ws_slot = ss;
         a.pj_out = pj[0]; a.gpart_out = gp[0];
         a.img = c->packed[PL_SA1];
-        k_bip_pre_m<<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
+        if (tail_wide(c)) k_bip_pre_m<true><<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
+        else k_bip_pre_m<false><<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
     }
     // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
     for (int layer = 1; layer <= 3; ++layer) {
@@ -2662,9 +2688,15 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = nbx;
         a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
         a.img = c->packed[PL_SA1 + layer - 1];
-        if (layer == 1) k_sa_layer_m<15, true><<<grid, 256, 0, st>>>(a);
-        else if (layer == 2) k_sa_layer_m<30, true><<<grid, 256, 0, st>>>(a);
-        else k_sa_layer_m<30, false><<<grid, 256, 0, st>>>(a);
+        if (tail_wide(c)) {
+            if (layer == 1) k_sa_layer_m<15, true, true><<<grid, 256, 0, st>>>(a);
+            else if (layer == 2) k_sa_layer_m<30, true, true><<<grid, 256, 0, st>>>(a);
+            else k_sa_layer_m<30, false, true><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (layer == 1) k_sa_layer_m<15, true, false><<<grid, 256, 0, st>>>(a);
+            else if (layer == 2) k_sa_layer_m<30, true, false><<<grid, 256, 0, st>>>(a);
+            else k_sa_layer_m<30, false, false><<<grid, 256, 0, st>>>(a);
+        }
     }
     // read-out heads over the nwin * G grid nodes / nwin * Q queries
     RoArgs a = make_ro_args(c);
@@ -2672,10 +2704,8 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     {   // the grid read-out also leaves the per-grid-node table cv of the query read-out (k_ro_pre_m's work)
         RoArgs g = a;
         g.N = nwin * c->G; g.Nw = c->G; g.out = y_out; g.img = c->packed[PL_RO0];
-        size_t lds = sizeof(float) * ROM_LDS_FLOATS;
-        if (x_out) { g.cv_out = w + c->o_cv + so; g.cv_ws = ss; g.pimg = c->packed[PL_ROP]; lds += sizeof(float) * GP_IMG_FLOATS; }
-        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
-        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, lds, st>>>(g);
+        if (x_out) { g.cv_out = w + c->o_cv + so; g.cv_ws = ss; g.pimg = c->packed[PL_ROP]; }
+        { int rl = launch_readout_grid(c, g, x_out != nullptr, st); if (rl) return rl; }
     }
     if (x_out) {
         RoArgs q = a;
@@ -3004,22 +3034,24 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     // the same kernels, in the same order, as the inference tail (genie_bipartite_readout, genie_spatial_agg3_fwd, read-outs); the layer
     // inputs land in `tsave` instead of the workspace slot
     k_part_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(w + c->o_part + so, c->G, c->T, r);
-    k_bip_out_m<<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], bip, 0, 0);
-    if ((rc = sa_launch_pre(c, 1, bip, w, 0, st))) return rc;
-    if ((rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st))) return rc;
-    if ((rc = sa_launch_layer(c, 2, sa1, pos, sa2, w, 1, true, st))) return rc;
-    if ((rc = sa_launch_layer(c, 3, sa2, pos, xs, w, 0, false, st))) return rc;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (ROM_LDS_FLOATS + GP_IMG_FLOATS))));
+    k_bip_out_m<false><<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], bip, 0, 0);
+    c->tail_train = 1;           // fp32 chains: the backward recomputes every pre-activation of the tail with them
+    rc = sa_launch_pre(c, 1, bip, w, 0, st);
+    if (!rc) rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st);
+    if (!rc) rc = sa_launch_layer(c, 2, sa1, pos, sa2, w, 1, true, st);
+    if (!rc) rc = sa_launch_layer(c, 3, sa2, pos, xs, w, 0, false, st);
     HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
     RoArgs a = make_ro_args(c);
     a.T = n_t; a.x_spatial = xs; a.t_query = t_query;
-    {
+    if (!rc) {
         RoArgs g = a;
         g.N = g.Nw = c->G; g.out = y_out; g.lat_out = y_latent_out; g.img = c->packed[PL_RO0];
-        k_readout_m<0><<<tl_blocks(g.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, st>>>(g);
+        rc = launch_readout_grid(c, g, false, st);
     }
+    c->tail_train = 0;
+    if (rc) return rc;
     float* cvbuf = w + c->o_cv + so;
-    k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
+    k_ro_pre_m<false><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
     {
         RoArgs q = a;
         q.N = q.Nw = n_query; q.x_grid = pos; q.x_query = x_query; q.knn = knn; q.out = x_out; q.img = c->packed[PL_RO1]; q.cv = cvbuf;
@@ -3062,7 +3094,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         tt_reduce(c, TM_RO0, b.part, grid * 4, grad_blob, st);
     }
     {   // x branch: TemporalAttention + SpatialAttention (query side), then its grid-node side
-        k_ro_pre_m<<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], S + L.cv, c->G, 0);
+        k_ro_pre_m<false><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], S + L.cv, c->G, 0);
         RbArgs b;
         memset(&b, 0, sizeof(b));
         b.ro = ro; b.ro.N = b.ro.Nw = n_query; b.ro.x_grid = pos; b.ro.x_query = x_query; b.ro.knn = knn; b.ro.cv = S + L.cv;
@@ -3094,7 +3126,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         sa_fill_layer(c, layer, pre);
         pre.x_in = x_in[layer - 1]; pre.pj_out = S + L.pj; pre.gpart_out = S + L.gpart; pre.img = c->packed[PL_SA1 + layer - 1];
         const int nbp = sa_blocks(c);
-        if (layer == 1) k_sa_pre_m<15><<<nbp, 256, 0, st>>>(pre); else k_sa_pre_m<30><<<nbp, 256, 0, st>>>(pre);
+        if (layer == 1) k_sa_pre_m<15, false><<<nbp, 256, 0, st>>>(pre); else k_sa_pre_m<30, false><<<nbp, 256, 0, st>>>(pre);
         SbArgs a;
         memset(&a, 0, sizeof(a));
         a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src; a.x_in = x_in[layer - 1]; a.pos = pos;
@@ -3543,6 +3575,12 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
 int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_phase_types: null context");
     c->no_phase = use_phase_types ? 0 : 1;
+    return GENIE_OK;
+}
+
+int genie_set_tail_precision(genie_ctx* c, int fp64_chains) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_tail_precision: null context");
+    c->tail_f32 = fp64_chains ? 0 : 1;
     return GENIE_OK;
 }
 

@@ -157,9 +157,109 @@ __device__ __forceinline__ f32x4 tl_load15(const float* __restrict__ row, int q)
 }
 __device__ __forceinline__ f32x4 tl_zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+// ------------------------------------------------------------------------------------------------
+// WIDE tail (round 4): the same kernels with every Linear of the G-sized tail as a chain of v_mfma_f64_16x16x4_f64 (same lane
+// layout as the fp32 form: lane (j, q) holds rows 4 q + r of column j), fp64 accumulators, PReLUs and per-node sums; inputs and
+// weights are the fp32 values (exact in fp64), results are rounded to fp32 once per kernel. Why: with fp32 chains the error of
+// (y, x) against the reference's fp64 run is made almost entirely HERE (oracle-level attribution on the o1_20x500 fixture,
+// profiles/r04_c_error_attribution.txt: grid read-out 1.15e-6 rms, SpatialAggregation 0.5-0.66e-6 per layer, Bipartite 0.34e-6,
+// DataAggregation 0.29e-6, of 1.50e-6 in total), and the reference's own fp32 run sits at 7.6e-6 of the 1e-5 bound on that
+// fixture. The G-sized tail is ~0.5 GFLOP per window: at the fp64 matrix rate (half the fp32 one) it stays latency-bound.
+// The training forward keeps the fp32 form (its backward recomputes pre-activations with fp32 chains).
+// ------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <bool W> struct TlV { typedef f32x4 v; };
+template <> struct TlV<true> { typedef f64x4 v; };
+__device__ __forceinline__ f64x4 mma_block(f64x4 acc, const f32x4 w, const f64x4 x) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w.x, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w.y, x.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w.z, x.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)w.w, x.w, acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f64x4 prelu4(f64x4 x, float a) {
+    const double ad = (double)a;
+    return f64x4{x.x >= 0. ? x.x : ad * x.x, x.y >= 0. ? x.y : ad * x.y, x.z >= 0. ? x.z : ad * x.z, x.w >= 0. ? x.w : ad * x.w};
+}
+// v_mfma_f64_16x16x4_f64 leaves row 4 r + q of D in register r of lane (j, q) (tools/mfma_f64_layout.hip), the fp32 form row
+// 4 q + r -- the order the packed weight fragments, the row loads and the stores of these kernels assume. A chain therefore runs
+// on accumulators in the instruction's own order and crosses over once at each end: tl_tr4 transposes the 4 x 4 (q, r) block of a
+// column with v_permlane32_swap / v_permlane16_swap (gfx950), eight swaps per four doubles; it is its own inverse.
+__device__ __forceinline__ void tl_swap32(double& x, double& y) {      // x of lanes 32..63 <-> y of lanes 0..31
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x), yb = __builtin_bit_cast(unsigned long long, y);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)xb, (unsigned)yb, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ void tl_swap16(double& x, double& y) {      // x of the odd rows of 16 lanes <-> y of the even rows
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x), yb = __builtin_bit_cast(unsigned long long, y);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ f64x4 tl_tr4(f64x4 v) {
+    double a = v.x, b = v.y, c = v.z, d = v.w;
+    tl_swap32(a, c); tl_swap32(b, d);        // (q bit 1) <-> (r bit 1)
+    tl_swap16(a, b); tl_swap16(c, d);        // (q bit 0) <-> (r bit 0)
+    return f64x4{a, b, c, d};
+}
+template <bool W> __device__ __forceinline__ typename TlV<W>::v tl_wide(f32x4 v);
+template <> __device__ __forceinline__ f32x4 tl_wide<false>(f32x4 v) { return v; }
+template <> __device__ __forceinline__ f64x4 tl_wide<true>(f32x4 v) { return f64x4{(double)v.x, (double)v.y, (double)v.z, (double)v.w}; }
+// start / end of a chain: the bias (usual order) as an accumulator in the instruction's order, the result back in the usual order
+template <bool W> __device__ __forceinline__ typename TlV<W>::v tl_cin(f32x4 v);
+template <> __device__ __forceinline__ f32x4 tl_cin<false>(f32x4 v) { return v; }
+template <> __device__ __forceinline__ f64x4 tl_cin<true>(f32x4 v) { return tl_tr4(f64x4{(double)v.x, (double)v.y, (double)v.z, (double)v.w}); }
+__device__ __forceinline__ f32x4 tl_cout(f32x4 v) { return v; }
+__device__ __forceinline__ f64x4 tl_cout(f64x4 v) { return tl_tr4(v); }
+__device__ __forceinline__ f32x4 tl_f32(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 tl_f32(f64x4 v) { return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+
+// r_g = the per-tile partial rows of a source node summed in tile order (row layout: four consecutive lanes read 64 contiguous
+// bytes), then across the wave's LDS scratch into the MFMA layout. WIDE: summed and carried in fp64.
+template <bool W> struct TlRowSum { typename TlV<W>::v r0, r1; };
+template <bool WIDE>
+__device__ __forceinline__ TlRowSum<WIDE> tl_sum_part_rows(const float* __restrict__ pg, int T, float* ts, int jl, int ql, int j, int q) {
+    typedef typename TlV<WIDE>::v V;
+    V r0 = tl_wide<WIDE>(tl_zero()), r1 = r0;
+    int tb = 0;
+    for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
+        f32x4 v0[4], v1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r0 += tl_wide<WIDE>(v0[k]); r1 += tl_wide<WIDE>(v1[k]); }
+    }
+    for (; tb < T; ++tb) { r0 += tl_wide<WIDE>(*(const f32x4*)(pg + tb * 32)); r1 += tl_wide<WIDE>(*(const f32x4*)(pg + tb * 32 + 16)); }
+    TlRowSum<WIDE> o;
+    if (WIDE) {      // scratch rows of 36 floats = 18 doubles: the two halves of a node's row go through in two rounds
+        double* td = (double*)ts;
+        *(V*)(td + jl * 18 + 4 * ql) = r0;
+        GSYNC();
+        o.r0 = *(const V*)(td + j * 18 + 4 * q);
+        GSYNC();
+        *(V*)(td + jl * 18 + 4 * ql) = r1;
+        GSYNC();
+        o.r1 = *(const V*)(td + j * 18 + 4 * q);
+        GSYNC();
+    } else {
+        *(V*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
+        *(V*)(ts + jl * 36 + 16 + 4 * ql) = r1;
+        GSYNC();
+        o.r0 = *(const V*)(ts + j * 36 + 4 * q);
+        o.r1 = *(const V*)(ts + j * 36 + 16 + 4 * q);
+        GSYNC();
+    }
+    return o;
+}
+
 // Bipartite read-out (module.py:229): r_g = sum over the tiles' partial rows in tile order, out = PReLU_b2(fc2 r_g).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ part, int G, int T, const float* __restrict__ img,
                                                   float* __restrict__ out, long long part_ws, long long out_ws) {
+    typedef typename TlV<WIDE>::v V;
     __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36];
     const TlImg im = tl_stage_image(sm, img, GB_GROUPS2, GB_BIAS2);
     __syncthreads();
@@ -175,35 +275,21 @@ __global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ par
         const bool ok = g < G;
         const int gl = tile * 16 + jl;
         const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
-        f32x4 r0 = tl_zero(), r1 = tl_zero();
-        int tb = 0;
-        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
-            f32x4 v0[4], v1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
-        }
-        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
-        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
-        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
-        GSYNC();
-        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
-        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
-        GSYNC();
-        f32x4 o = tl_bias(im, 0, q);
-        o = mma_block(o, TLW(im, 0), r0);
-        o = mma_block(o, TLW(im, 1), r1);
-        o = prelu4(o, act);
+        const TlRowSum<WIDE> rs = tl_sum_part_rows<WIDE>(pg, T, ts, jl, ql, j, q);
+        V o = tl_cin<WIDE>(tl_bias(im, 0, q));
+        o = mma_block(o, TLW(im, 0), rs.r0);
+        o = tl_cout(mma_block(o, TLW(im, 1), rs.r1));
+        const f32x4 of = tl_f32(prelu4(o, act));
         if (ok) {
             float* og = out + (long long)g * 15 + 4 * q;
-            og[0] = o.x; og[1] = o.y; og[2] = o.z;
-            if (q < 3) og[3] = o.w;
+            og[0] = of.x; og[1] = of.y; og[2] = of.z;
+            if (q < 3) og[3] = of.w;
         }
     }
 }
 
 // fixed-order reduction of the per-lane global-term partials (rows m = 4q + r < 5 of the fglobal tile) -> gpart[block][m]
+__device__ __forceinline__ void tl_store_gpart(f64x4 accw, int lane, int wave, float* red, float* __restrict__ gpart_out);
 __device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, float* red, float* __restrict__ gpart_out) {
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) {
@@ -218,11 +304,27 @@ __device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, fl
         gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
     }
 }
+// WIDE: the per-lane partials were accumulated in fp64; the cross-lane / cross-wave sums keep the fp32 buffers' fixed order
+__device__ __forceinline__ void tl_store_gpart(f64x4 accw, int lane, int wave, float* red, float* __restrict__ gpart_out) {
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        accw.x += __shfl_xor(accw.x, d); accw.y += __shfl_xor(accw.y, d); accw.z += __shfl_xor(accw.z, d); accw.w += __shfl_xor(accw.w, d);
+    }
+    const int j = lane & 15, q = lane >> 4;
+    if (j == 0 && q < 2) *(f32x4*)(red + wave * 8 + 4 * q) = tl_f32(accw);
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k * 8 + threadIdx.x];
+        gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
+    }
+}
 
 // Pre-pass of a SpatialAggregation layer (see k_sa_pre): pj[j] = fc1.weight[:, 0:C] x_j and the block partial of
 // sum_j outdeg(j) PReLU3(fglobal x_j).
-template <int C>
+template <int C, bool WIDE>
 __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
+    typedef typename TlV<WIDE>::v V;
     sa_select_window(a);
     __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 32];
     const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
@@ -230,32 +332,34 @@ __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const float act3 = im.scal[3];
-    f32x4 acc = tl_zero();
+    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (a.G + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int g = tile * 16 + j;
         const bool ok = g < a.G;
         const float* row = a.x_in + (long long)(ok ? g : a.G - 1) * C;
-        f32x4 xb[2];
-        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
-        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
+        V xb[2];
+        if (C == 15) { xb[0] = tl_wide<WIDE>(tl_load15(row, q)); xb[1] = tl_wide<WIDE>(tl_zero()); }
+        else { xb[0] = tl_wide<WIDE>(tl_load30(row, 0, q)); xb[1] = tl_wide<WIDE>(tl_load30(row, 1, q)); }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJ(t, 0)), xb[0]);
+            V pj = mma_block(tl_wide<WIDE>(tl_zero()), TLW(im, GS_PJ(t, 0)), xb[0]);
             if (C == 30) pj = mma_block(pj, TLW(im, GS_PJ(t, 1)), xb[1]);
-            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
+            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = tl_f32(tl_cout(pj));
         }
-        f32x4 gl = mma_block(tl_bias(im, 5, q), TLW(im, GS_FG(0)), xb[0]);
+        V gl = mma_block(tl_cin<WIDE>(tl_bias(im, 5, q)), TLW(im, GS_FG(0)), xb[0]);
         if (C == 30) gl = mma_block(gl, TLW(im, GS_FG(1)), xb[1]);
-        if (ok) acc += prelu4(gl, act3) * (float)a.outdeg[g];
+        if (ok) acc += prelu4(tl_cout(gl), act3) * (float)a.outdeg[g];
     }
     tl_store_gpart(acc, lane, wave, red, a.gpart_out);
 }
 
 // k_bip_out_m + k_sa_pre_m<15> in one launch (the batched tail): the Bipartite output of a node is the input of
 // SpatialAggregation1's pre-pass of the same node. Same MFMA chains as the two kernels (bitwise equal results).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ part, int T, const float* __restrict__ img_bip, long long part_ws,
                                                   SaArgs a) {
+    typedef typename TlV<WIDE>::v V;
     sa_select_window(a);
     __shared__ __attribute__((aligned(16))) float sm[GB2_IMG_FLOATS + 4 * 16 * 36 + GS_IMG_FLOATS + 32];
     const TlImg im = tl_stage_image(sm, img_bip, GB_GROUPS2, GB_BIAS2);
@@ -269,54 +373,43 @@ __global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ par
     const int jl = lane >> 2, ql = lane & 3;
     float* ts = tsc + wave * 16 * 36;
     const float act = im.scal[0], act3 = is.scal[3];
-    f32x4 acc = tl_zero();
+    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (G + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int g = tile * 16 + j;
         const bool ok = g < G;
         const int gl = tile * 16 + jl;
         const float* pg = part + (long long)(gl < G ? gl : G - 1) * T * 32 + 4 * ql;
-        f32x4 r0 = tl_zero(), r1 = tl_zero();
-        int tb = 0;
-        for (; tb + 4 <= T; tb += 4) {            // four rows in flight, added in tile order
-            f32x4 v0[4], v1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v0[k] = *(const f32x4*)(pg + (tb + k) * 32); v1[k] = *(const f32x4*)(pg + (tb + k) * 32 + 16); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r0 += v0[k]; r1 += v1[k]; }
-        }
-        for (; tb < T; ++tb) { r0 += *(const f32x4*)(pg + tb * 32); r1 += *(const f32x4*)(pg + tb * 32 + 16); }
-        *(f32x4*)(ts + jl * 36 + 4 * ql) = r0;    // row layout -> MFMA layout
-        *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = r1;
-        GSYNC();
-        r0 = *(const f32x4*)(ts + j * 36 + 4 * q);
-        r1 = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
-        GSYNC();
-        f32x4 o = tl_bias(im, 0, q);
-        o = mma_block(o, TLW(im, 0), r0);
-        o = mma_block(o, TLW(im, 1), r1);
-        o = prelu4(o, act);
-        if (q == 3) o.w = 0.f;                    // channel 15 does not exist (tl_load15 of the stored row reads it as zero)
+        const TlRowSum<WIDE> rs = tl_sum_part_rows<WIDE>(pg, T, ts, jl, ql, j, q);
+        V ow = tl_cin<WIDE>(tl_bias(im, 0, q));
+        ow = mma_block(ow, TLW(im, 0), rs.r0);
+        ow = tl_cout(mma_block(ow, TLW(im, 1), rs.r1));
+        ow = prelu4(ow, act);
+        // the stored row (fp32) is what every later consumer reads: SpatialAggregation1's pre-pass continues from the SAME values
+        f32x4 of = tl_f32(ow);
+        if (q == 3) of.w = 0.f;                   // channel 15 does not exist (tl_load15 of the stored row reads it as zero)
         if (ok) {
             float* og = a.out + (long long)g * 15 + 4 * q;
-            og[0] = o.x; og[1] = o.y; og[2] = o.z;
-            if (q < 3) og[3] = o.w;
+            og[0] = of.x; og[1] = of.y; og[2] = of.z;
+            if (q < 3) og[3] = of.w;
         }
+        const V o = tl_wide<WIDE>(of);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f32x4 pj = mma_block(tl_zero(), TLW(is, GS_PJ(t, 0)), o);
-            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = pj;
+            const V pj = mma_block(tl_wide<WIDE>(tl_zero()), TLW(is, GS_PJ(t, 0)), o);
+            if (ok) *(f32x4*)(a.pj_out + (long long)g * 32 + 16 * t + 4 * q) = tl_f32(tl_cout(pj));
         }
-        const f32x4 glb = mma_block(tl_bias(is, 5, q), TLW(is, GS_FG(0)), o);
-        if (ok) acc += prelu4(glb, act3) * (float)a.outdeg[g];
+        const V glb = mma_block(tl_cin<WIDE>(tl_bias(is, 5, q)), TLW(is, GS_FG(0)), o);
+        if (ok) acc += prelu4(tl_cout(glb), act3) * (float)a.outdeg[g];
     }
     tl_store_gpart(acc, lane, wave, red, a.gpart_out);
 }
 
 // One SpatialAggregation layer (see k_sa_layer): per-edge messages on the VALU (8 channels per lane), fc2 and the next layer's
 // pre-pass as MFMA chains on the 16 nodes of the wave.
-template <int C, bool NEXT>
+template <int C, bool NEXT, bool WIDE>
 __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
+    typedef typename TlV<WIDE>::v V;
     sa_select_window(a);
     __shared__ __attribute__((aligned(16))) float sm[GS_IMG_FLOATS + 8 * 32 + 8 + 32 * 8 + 32 + 4 * 16 * 36];
     const TlImg im = tl_stage_image(sm, a.img, GS_GROUPS, GS_BIAS);
@@ -361,17 +454,17 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
             for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * ql);
         }
     }
-    f32x4 acc = tl_zero();
+    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (a.G + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int i = tile * 16 + j;
         const bool ok = i < a.G;
         const int ic = ok ? i : a.G - 1;
         const float* row = a.x_in + (long long)ic * C;
-        f32x4 xb[2];
-        if (C == 15) { xb[0] = tl_load15(row, q); xb[1] = tl_zero(); }
-        else { xb[0] = tl_load30(row, 0, q); xb[1] = tl_load30(row, 1, q); }
-        // ---- edges of node il (row layout)
+        V xb[2];
+        if (C == 15) { xb[0] = tl_wide<WIDE>(tl_load15(row, q)); xb[1] = tl_wide<WIDE>(tl_zero()); }
+        else { xb[0] = tl_wide<WIDE>(tl_load30(row, 0, q)); xb[1] = tl_wide<WIDE>(tl_load30(row, 1, q)); }
+        // ---- edges of node il (row layout; fp32 in both forms: a message is a five-term sum, the mean runs over <= 15 of them)
         const int il = tile * 16 + jl;
         const bool okl = il < a.G;
         const int icl = okl ? il : a.G - 1;
@@ -409,28 +502,29 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
         *(f32x4*)(ts + jl * 36 + 4 * ql) = as[0] / deg;
         *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = as[1] / deg;
         GSYNC();
-        const f32x4 av[2] = {*(const f32x4*)(ts + j * 36 + 4 * q), *(const f32x4*)(ts + j * 36 + 16 + 4 * q)};
+        const V av[2] = {tl_wide<WIDE>(*(const f32x4*)(ts + j * 36 + 4 * q)), tl_wide<WIDE>(*(const f32x4*)(ts + j * 36 + 16 + 4 * q))};
         GSYNC();
-        f32x4 o[2];
+        V o[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 v = mma_block(tl_bias(im, t, q), TLW(im, GS_FC2(t, 0)), xb[0]);
+            V v = mma_block(tl_cin<WIDE>(tl_bias(im, t, q)), TLW(im, GS_FC2(t, 0)), xb[0]);
             if (C == 30) v = mma_block(v, TLW(im, GS_FC2(t, 1)), xb[1]);
             v = mma_block(v, TLW(im, GS_FC2(t, 2)), av[0]);
-            v = mma_block(v, TLW(im, GS_FC2(t, 3)), av[1]);
-            o[t] = prelu4(v, act2);
-            if (ok) tl_store30(a.out + (long long)i * 30, t, q, o[t]);
+            v = tl_cout(mma_block(v, TLW(im, GS_FC2(t, 3)), av[1]));
+            const f32x4 of = tl_f32(prelu4(v, act2));
+            if (ok) tl_store30(a.out + (long long)i * 30, t, q, of);
+            o[t] = tl_wide<WIDE>(of);            // the next layer's pre-pass continues from the stored (fp32) row
         }
         if (NEXT) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                f32x4 pj = mma_block(tl_zero(), TLW(im, GS_PJN(t, 0)), o[0]);
+                V pj = mma_block(tl_wide<WIDE>(tl_zero()), TLW(im, GS_PJN(t, 0)), o[0]);
                 pj = mma_block(pj, TLW(im, GS_PJN(t, 1)), o[1]);
-                if (ok) *(f32x4*)(a.pj_out + (long long)i * 32 + 16 * t + 4 * q) = pj;
+                if (ok) *(f32x4*)(a.pj_out + (long long)i * 32 + 16 * t + 4 * q) = tl_f32(tl_cout(pj));
             }
-            f32x4 gl = mma_block(tl_bias(im, 4, q), TLW(im, GS_FGN(0)), o[0]);
+            V gl = mma_block(tl_cin<WIDE>(tl_bias(im, 4, q)), TLW(im, GS_FGN(0)), o[0]);
             gl = mma_block(gl, TLW(im, GS_FGN(1)), o[1]);
-            if (ok) acc += prelu4(gl, act3n) * (float)a.outdeg[i];
+            if (ok) acc += prelu4(tl_cout(gl), act3n) * (float)a.outdeg[i];
         }
     }
     if (NEXT) tl_store_gpart(acc, lane, wave, red, a.gpart_out);
@@ -438,8 +532,10 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
 
 // Per-grid-node part of SpatialAttention's edge Linears (see k_ro_pre), biases included, in a head-padded layout:
 // cv[j] = [f_context: head h at 16h + l (l < 15, slot 15 zero) | f_values: 80 + 16h + l], CVP floats per node.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_spatial, int G, const float* __restrict__ img,
                                                  float* __restrict__ cv, int Gw, long long cv_ws) {
+    typedef typename TlV<WIDE>::v V;
     __shared__ __attribute__((aligned(16))) float sm[GP_IMG_FLOATS];
     const TlImg im = tl_stage_image(sm, img, GP_GROUPS, GP_BIAS);
     __syncthreads();
@@ -450,16 +546,16 @@ __global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_sp
         const bool ok = g < G;
         const int gc = ok ? g : G - 1;
         const float* row = x_spatial + (long long)gc * 30;
-        const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+        const V xb0 = tl_wide<WIDE>(tl_load30(row, 0, q)), xb1 = tl_wide<WIDE>(tl_load30(row, 1, q));
         const int w = gc / Gw;
         float* o = cv + w * cv_ws + (long long)(gc - w * Gw) * CVP + 4 * q;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int h = 0; h < 5; ++h) {
-                f32x4 v = mma_block(tl_bias(im, m * 5 + h, q), TLW(im, GP(m, h, 0)), xb0);
+                V v = mma_block(tl_cin<WIDE>(tl_bias(im, m * 5 + h, q)), TLW(im, GP(m, h, 0)), xb0);
                 v = mma_block(v, TLW(im, GP(m, h, 1)), xb1);
-                if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
+                if (ok) *(f32x4*)(o + m * 80 + h * 16) = tl_f32(tl_cout(v));
             }
     }
 }
@@ -471,15 +567,19 @@ __global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_sp
 // score x value products, per node, go through a per-wave LDS scratch (a lane needs all T x 5 scores of its node).
 constexpr int RO_SCS = 68;      // floats per node in the score scratch: [5 heads][12 time slots] + pad
 constexpr int ROM_LDS_FLOATS = GR_IMG_FLOATS + 5 * 256 + 10 * 80 + 4 * 16 * RO_SCS;
-template <int MODE>
+template <int MODE, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
+    static_assert(!(WIDE && MODE != 0), "the fp64 form exists for the grid read-out (MODE 0)");
+    typedef typename TlV<WIDE>::v V;
+    typedef typename std::conditional<WIDE, double, float>::type R;
+    constexpr int SCW = WIDE ? 2 : 1;        // the score scratch holds R values
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const TlImg im = tl_stage_image(sm, a.img, GR_GROUPS, GR_BIAS);
     float* qf = sm + GR_IMG_FLOATS;          // [5][64][4]: A fragments of the temporal queries, head h
     float* et = qf + 5 * 256;                // [10][80] (MODE 1): f_queries columns 0..2, f_context / f_values edge columns, f_queries bias
     float* scr = et + 10 * 80;
     TlImg imp = im;                          // MODE 0 with cv_out: the PL_ROP image behind the score scratch
-    if (MODE == 0 && a.cv_out != nullptr) imp = tl_stage_image(scr + 4 * 16 * RO_SCS, a.pimg, GP_GROUPS, GP_BIAS);
+    if (MODE == 0 && a.cv_out != nullptr) imp = tl_stage_image(scr + SCW * 4 * 16 * RO_SCS, a.pimg, GP_GROUPS, GP_BIAS);
     {   // qf[h][lane][r] = query[t = lane & 15][head h][l = 4 (lane >> 4) + r], query = temporal_query_2(PReLU3(temporal_query_1(t / scale_t)))  :329
         const float act3 = a.raw[a.o_a3];
         for (int i = threadIdx.x; i < 5 * 256; i += blockDim.x) {
@@ -514,17 +614,17 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const float fa = im.scal[0], sa1 = im.scal[1], act1 = im.scal[2], act2 = im.scal[3], act4 = im.scal[4], act5 = im.scal[5];
     const float b_p2 = im.scal[6];
-    const float inv_sqrt_l = 1.f / sqrtf(15.f);
-    float* ws = scr + (wave * 16 + j) * RO_SCS;
+    const R inv_sqrt_l = WIDE ? (R)(1.0 / sqrt(15.0)) : (R)(1.f / sqrtf(15.f));
+    R* ws = (R*)scr + (wave * 16 + j) * RO_SCS;
     const int ntiles = (a.N + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int n = tile * 16 + j;
         const bool ok = n < a.N;
         const int nc = ok ? n : a.N - 1;
-        f32x4 xin[2];
+        V xin[2];
         if (MODE == 0) {
             const float* row = a.x_spatial + (long long)nc * 30;
-            const f32x4 xb0 = tl_load30(row, 0, q), xb1 = tl_load30(row, 1, q);
+            const V xb0 = tl_wide<WIDE>(tl_load30(row, 0, q)), xb1 = tl_wide<WIDE>(tl_load30(row, 1, q));
             if (a.cv_out != nullptr) {                                                  // k_ro_pre_m's work for this node (same MFMA chains)
                 const int w = nc / a.Nw;
                 float* o = a.cv_out + w * a.cv_ws + (long long)(nc - w * a.Nw) * CVP + 4 * q;
@@ -532,16 +632,16 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int h = 0; h < 5; ++h) {
-                        f32x4 v = mma_block(tl_bias(imp, m * 5 + h, q), TLW(imp, GP(m, h, 0)), xb0);
+                        V v = mma_block(tl_cin<WIDE>(tl_bias(imp, m * 5 + h, q)), TLW(imp, GP(m, h, 0)), xb0);
                         v = mma_block(v, TLW(imp, GP(m, h, 1)), xb1);
-                        if (ok) *(f32x4*)(o + m * 80 + h * 16) = v;
+                        if (ok) *(f32x4*)(o + m * 80 + h * 16) = tl_f32(tl_cout(v));
                     }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {                                               // SpatialDirect  :258-260
-                f32x4 y = mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xb0);
+                V y = mma_block(tl_cin<WIDE>(tl_bias(im, t, q)), TLW(im, GR_FRONT(t, 0)), xb0);
                 y = mma_block(y, TLW(im, GR_FRONT(t, 1)), xb1);
-                xin[t] = prelu4(y, fa);
+                xin[t] = prelu4(tl_cout(y), fa);
             }
         } else {
             // SpatialAttention in the ROW layout lane = 4 r + cq (query r = lane >> 2, chunk cq = lane & 3): four consecutive lanes
@@ -619,50 +719,50 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
             GSYNC();
 #pragma unroll
             for (int t = 0; t < 2; ++t)                                                 // PReLU2(proj(.))  :285
-                xin[t] = prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa);
+                xin[t] = tl_wide<WIDE>(prelu4(mma_block(tl_bias(im, t, q), TLW(im, GR_FRONT(t, 0)), xm), fa));
         }
         if (a.lat_out != nullptr && ok) {
-            tl_store30(a.lat_out + (long long)n * 30, 0, q, xin[0]);
-            tl_store30(a.lat_out + (long long)n * 30, 1, q, xin[1]);
+            tl_store30(a.lat_out + (long long)n * 30, 0, q, tl_f32(xin[0]));
+            tl_store30(a.lat_out + (long long)n * 30, 1, q, tl_f32(xin[1]));
         }
         // ------------------------------------------------------------------ TemporalAttention on xin  :325-331
-        f32x4 h1[2], h2[2];
+        V h1[2], h2[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 c1 = mma_block(tl_bias(im, 2 + t, q), TLW(im, GR_C1(t, 0)), xin[0]);
+            V c1 = mma_block(tl_cin<WIDE>(tl_bias(im, 2 + t, q)), TLW(im, GR_C1(t, 0)), xin[0]);
             c1 = mma_block(c1, TLW(im, GR_C1(t, 1)), xin[1]);
-            h1[t] = prelu4(c1, act1);
-            f32x4 v1 = mma_block(tl_bias(im, 4 + t, q), TLW(im, GR_V1(t, 0)), xin[0]);
+            h1[t] = prelu4(tl_cout(c1), act1);
+            V v1 = mma_block(tl_cin<WIDE>(tl_bias(im, 4 + t, q)), TLW(im, GR_V1(t, 0)), xin[0]);
             v1 = mma_block(v1, TLW(im, GR_V1(t, 1)), xin[1]);
-            h2[t] = prelu4(v1, act2);
+            h2[t] = prelu4(tl_cout(v1), act2);
         }
-        f32x4 val[5];
+        V val[5];
 #pragma unroll
         for (int h = 0; h < 5; ++h) {
-            f32x4 cx = mma_block(tl_bias(im, 6 + h, q), TLW(im, GR_C2(h, 0)), h1[0]);
-            cx = mma_block(cx, TLW(im, GR_C2(h, 1)), h1[1]);
+            V cx = mma_block(tl_cin<WIDE>(tl_bias(im, 6 + h, q)), TLW(im, GR_C2(h, 0)), h1[0]);
+            cx = tl_cout(mma_block(cx, TLW(im, GR_C2(h, 1)), h1[1]));
             // score[t, h] = ctx[h, :] . query[t, h, :] / sqrt(L): rows t = 4q + r of the result
-            const f32x4 sc = mma_block(tl_zero(), ((const f32x4*)qf)[h * 64 + lane], cx) * inv_sqrt_l;
-            if (q < 3) *(f32x4*)(ws + h * 12 + 4 * q) = sc;
-            f32x4 vx = mma_block(tl_bias(im, 11 + h, q), TLW(im, GR_V2(h, 0)), h2[0]);
-            val[h] = mma_block(vx, TLW(im, GR_V2(h, 1)), h2[1]);
+            const V sc = tl_cout(mma_block(tl_wide<WIDE>(tl_zero()), ((const f32x4*)qf)[h * 64 + lane], cx)) * inv_sqrt_l;
+            if (q < 3) *(V*)(ws + h * 12 + 4 * q) = sc;
+            V vx = mma_block(tl_cin<WIDE>(tl_bias(im, 11 + h, q)), TLW(im, GR_V2(h, 0)), h2[0]);
+            val[h] = tl_cout(mma_block(vx, TLW(im, GR_V2(h, 1)), h2[1]));
         }
         GSYNC();
         const f32x4 w2a = tl_bias(im, 18, q), w2b = tl_bias(im, 19, q);
 #pragma unroll 2
         for (int t = 0; t < a.T; ++t) {
-            f32x4 z = tl_zero();                                                        // z[t, l] = mean_h score[t, h] val[h, l]
+            V z = tl_wide<WIDE>(tl_zero());                                             // z[t, l] = mean_h score[t, h] val[h, l]
 #pragma unroll
             for (int h = 0; h < 5; ++h) z += val[h] * ws[h * 12 + t];
-            z = prelu4(z * 0.2f, act4);
-            f32x4 pa = prelu4(mma_block(tl_bias(im, 16, q), TLW(im, GR_P1(0)), z), act5);        // proj_2(PReLU5(proj_1(.)))
-            f32x4 pb = prelu4(mma_block(tl_bias(im, 17, q), TLW(im, GR_P1(1)), z), act5);
-            float o = w2a.x * pa.x;
-            o += w2a.y * pa.y; o += w2a.z * pa.z; o += w2a.w * pa.w;
-            o += w2b.x * pb.x; o += w2b.y * pb.y; o += w2b.z * pb.z; o += w2b.w * pb.w;
+            z = prelu4(z * (WIDE ? (R)0.2 : (R)0.2f), act4);
+            V pa = prelu4(tl_cout(mma_block(tl_cin<WIDE>(tl_bias(im, 16, q)), TLW(im, GR_P1(0)), z)), act5);        // proj_2(PReLU5(proj_1(.)))
+            V pb = prelu4(tl_cout(mma_block(tl_cin<WIDE>(tl_bias(im, 17, q)), TLW(im, GR_P1(1)), z)), act5);
+            R o = (R)w2a.x * pa.x;
+            o += (R)w2a.y * pa.y; o += (R)w2a.z * pa.z; o += (R)w2a.w * pa.w;
+            o += (R)w2b.x * pb.x; o += (R)w2b.y * pb.y; o += (R)w2b.z * pb.z; o += (R)w2b.w * pb.w;
             o += __shfl_xor(o, 16);
             o += __shfl_xor(o, 32);
-            if (ok && q == 0) a.out[(long long)n * a.T + t] = o + b_p2;
+            if (ok && q == 0) a.out[(long long)n * a.T + t] = (float)(o + (R)b_p2);
         }
         GSYNC();
     }

@@ -298,6 +298,10 @@ class HipPath(object):
         """`use_phase_types` of config.yaml:91 for the device embedding (genie_set_phase_types)."""
         _lib.check(self.lib.genie_set_phase_types(self.ctx, 1 if use_phase_types else 0), "genie_set_phase_types")
 
+    def set_tail_precision(self, fp64_chains):
+        """Arithmetic of the G-sized tail of inference calls: fp64 MFMA chains (default) or fp32 ones (genie_set_tail_precision)."""
+        _lib.check(self.lib.genie_set_tail_precision(self.ctx, 1 if fp64_chains else 0), "genie_set_tail_precision")
+
     def set_stage_precision(self, mode):
         """"auto" | "f16x2" | "f32": arithmetic of the P-sized stages (genie_set_stage_precision)."""
         if mode not in _PRECISION_MODES:

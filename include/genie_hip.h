@@ -93,6 +93,11 @@ int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
  * Mask (process_continuous_days.py:783-786); the caller passes every pick with phase 0 (:562-563) and zeroes `phase_label` for the
  * association heads (module.py:632-633, :706-707). Default: phase types in use. */
 int genie_set_phase_types(genie_ctx* ctx, int use_phase_types);
+/* Arithmetic of the G-sized tail of inference calls (Bipartite read-out, SpatialAggregation x3, SpatialDirect + TemporalAttention
+ * on the grid): fp64_chains != 0 (default) = every Linear as a chain of fp64 MFMAs on the fp32 inputs and weights, fp64 PReLUs
+ * and sums, one rounding to fp32 per kernel; 0 = fp32 MFMA chains (the arithmetic of the training forward, and the A/B form).
+ * The fp32 chains are where almost all of the distance between (y, x) and the reference's fp64 run is made. */
+int genie_set_tail_precision(genie_ctx* ctx, int fp64_chains);
 /* Arithmetic of the P-sized stages on the reference's kNN graphs. mode 0 (default) = automatic: two-piece fp16 operands on the
  * 16-bit matrix pipe (k_stage1_h2 / k_stage2_h2) while the fp16 range guard of the committed weights holds, the fp32-MFMA kernels
  * otherwise; 1 = two-piece fp16 operands regardless of the guard (A/B runs; hidden states above 65504 become non-finite);

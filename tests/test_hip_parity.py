@@ -88,6 +88,10 @@ def test_forward_fixed_source_drop_in(name):
         print("%s %s: max|ref| %.3g  |hip - ref64| %.3g  |hip - ref32| %.3g" % (name, k, float(c.ref(k).abs().max()), e64, e32))
         assert e64 <= 1e-5, (k, e64)
         assert e32 <= 1e-5 + max_abs(c.ref(k), c.ref(k + "64")), (k, e32)
+        # round 4: the G-sized tail runs fp64 MFMA chains, so the grid read-out sits well inside the bound where the reference's
+        # own fp32 run uses three quarters of it (o1_20x500: 7.6e-6); observed 3.6e-6 (fp32 chains: 8.7e-6 .. 9.3e-6)
+        if k == "y":
+            assert e64 <= 5e-6, (k, e64)
 
 
 @pytest.mark.parametrize("scale", [2.0 ** -12, 512.0])

@@ -20,6 +20,8 @@ for name in sys.argv[1:] or ["tiny_6x40", "cfg1_20x500", "odd_33x257", "o1_20x50
     ea = graph.GraphEdges(x=c.edge_attr.to(dev), edge_index=A_src_in_prod.to(dev))
     net.set_adjacencies(A_in_sta.to(dev), A_in_src.to(dev), ea, ea, A_src_in_sta.to(dev), c.A_src_src.to(dev),
                         None, None, None, None, c.locs.float().to(dev), c.x_grid.float().to(dev))
+    if os.environ.get("TAIL") == "f32":
+        net._hip.set_tail_precision(False)
     with torch.no_grad():
         y, x = net.forward_fixed_source(c.Slice.to(dev), c.Mask.to(dev), None, None, None, c.locs.float().to(dev),
                                         c.x_grid.float().to(dev), c.x_query.float().to(dev), c.t_query.float().to(dev))

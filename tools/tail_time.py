@@ -20,6 +20,8 @@ win = synthetic.make_window(geom, n_picks, seed=2)
 Slice, Mask = torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev)
 xq, tq = torch.from_numpy(geom.x_query).float().to(dev), torch.from_numpy(geom.t_query).float().to(dev)
 hp = net._hip
+if os.environ.get("TAIL") == "f32":
+    hp.set_tail_precision(False)
 NB = int(os.environ.get("NB", "8"))
 with torch.no_grad():
     net.window_batch = NB
