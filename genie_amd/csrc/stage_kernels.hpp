@@ -1563,3 +1563,225 @@ __global__ __launch_bounds__(256) void k_h2_range(RangeArgs a) {
         a.out[3] = 0.f;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_stage2_h2u: k_stage2_h2 with the source-neighbour rows of BLOCKS of adjacent source nodes staged once in LDS (round 4).
+//
+// What bounds k_stage2_h2 is the vector-memory path: 27 KB per tile through the texture addresser and
+// 170 L1 misses per tile, 120 of them the 15 source-neighbour rows, which are never L1 hits: the ~15 users of a row (g', tile) are
+// the tiles (g, same station tile) of the source nodes g that list g', and they run on other CUs. Adjacent source nodes of the
+// space-filling-curve order share about half of their neighbours, so a workgroup takes a BLOCK of up to 8 consecutive source nodes
+// for ONE station tile: the union of their neighbour rows (<= S2U_UCAP, ~45 of 120) is copied into LDS once (each wave fetches a
+// quarter of the rows into registers while the previous block-tile computes), and every node of the block sums its 15 rows from
+// LDS (lane-contiguous 16-B reads, no bank conflicts). Texture traffic of the source rows 15 -> ~5.6 KB per tile, L1 misses 120 -> ~45.
+// Blocks and their union lists are static (genie_ctx_create: build_union_blocks); two workgroup barriers per block-tile (8 tiles).
+// Everything per node (streamed rows, station-neighbour gathers, f16x2 fc1, station sum) is k_stage2_h2's code: same results bit for
+// bit (the row sums keep the edge order).
+// ------------------------------------------------------------------------------------------------
+constexpr int S2U_NB = 8;            // source nodes per block (two per wave)
+constexpr int S2U_UCAP = 64;         // distinct neighbour rows of a block (a block is cut short where the union would exceed it)
+constexpr int S2U_NSTG = S2U_UCAP / 4;
+struct S2uBlock {                    // one block of the processing order
+    int32_t gi0, n, U, pad;          // first position, source nodes (1 .. 8), union size
+    int32_t ids[S2U_UCAP];           // source node of union row u (padded with row 0)
+    int32_t idx[S2U_NB][16];         // node b: [0] = its source node id (-1: the block has no node b), [1 + k] = union row of its k-th neighbour
+};
+
+template <bool XL, bool BIG>
+__global__ __launch_bounds__(256, 2) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
+    constexpr int KS = 8, KP = 15;
+    constexpr int NF4 = S2H_IMG_FLOATS / 4;
+    extern __shared__ __attribute__((aligned(16))) f32x4 s2u_smem[];
+    f32x4* lw = s2u_smem;
+    char* lrows = (char*)(s2u_smem + NF4);          // union rows of the current block-tile: row u at u * 1024, lane l's chunk at l * 16
+    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lw[i] = ((const f32x4*)a.packed)[i];
+    const float* lbias = (const float*)(lw + S2H_FRAGS * 64);
+    int lane = threadIdx.x & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    const int jl = lane >> 2, ql = lane & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.S, T = a.T;
+    const int nx = (a.nxcd > 1 && gridDim.x >= (unsigned)a.nxcd && (gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+    const int blk0 = nx == 1 ? xcd_blk0[0] : xcd_blk0[xcd], blk1 = nx == 1 ? xcd_blk0[a.nxcd] : xcd_blk0[xcd + 1];
+    const long long n_items = (long long)(blk1 - blk0) * T;          // item = (block, station tile), swept backwards
+    __syncthreads();
+    if (lb >= n_items) return;
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lbias[32], ab1 = lbias[33];
+    typedef const __attribute__((address_space(1))) char* gbytes;
+    typedef const __attribute__((address_space(1))) f32x4* grow;
+    typedef const __attribute__((address_space(1))) u32x4* gfrag;
+    typedef const __attribute__((address_space(1))) float* gflt;
+    const unsigned plane = (unsigned)S * 16u;
+    const unsigned pc = (unsigned)S * 128u, pw = (unsigned)S * 64u, pe = (unsigned)S * 32u, pm = (unsigned)S * 4u;
+    const unsigned kgp = (unsigned)kg * plane, kge = (unsigned)min(kg, 1) * plane;
+    const unsigned q16 = 16u * (unsigned)ql;
+    const int bperm = (4 * m + kg) * 4;
+    const unsigned m_T = ItemIter::recip((unsigned)T);
+
+    // item number (clamped to this workgroup's last one) -> (block, station tile)
+    long long it_last = lb;
+    while (it_last + nbx < n_items) it_last += nbx;
+    auto item_of = [&](long long it, int& blk, int& tb) {
+        const long long itr = n_items - 1 - (it <= it_last ? it : it_last);
+        unsigned rem;
+        const unsigned kb = T <= 1 ? (rem = 0u, (unsigned)itr) : ItemIter::fdiv((unsigned)itr, (unsigned)T, m_T, rem);
+        blk = __builtin_amdgcn_readfirstlane(blk0 + (int)kb);
+        tb = __builtin_amdgcn_readfirstlane((int)rem);
+    };
+    // ---- union rows of a block-tile: global -> registers (issued one block-tile ahead) -> LDS. `idl`: lane u holds the source node
+    // of union row u, lane 63's copy of U rides in `Uv` (both loaded one MORE block-tile ahead: nothing here waits on a fresh load)
+    f32x4 stg[S2U_NSTG];
+    auto stage_issue = [&](int idl, int U, int tb) {
+        const int s = tb * 16 + m, sc = s < S ? s : S - 1;
+        const unsigned lo = kgp + (unsigned)sc * 16u;
+#pragma unroll
+        for (int i = 0; i < S2U_NSTG; ++i) {
+            const int u = wave + 4 * i;
+            if (u < U) {
+                const unsigned long long vb = s2h_base<BIG>(a.wv, __builtin_amdgcn_readlane(idl, u), pw);
+                stg[i] = *(grow)((gbytes)vb + lo);
+            }
+        }
+    };
+    auto stage_write = [&](int U) {
+#pragma unroll
+        for (int i = 0; i < S2U_NSTG; ++i) {
+            const int u = wave + 4 * i;
+            if (u < U) *(f32x4*)(lrows + (unsigned)u * 1024u + (unsigned)lane * 16u) = stg[i];
+        }
+    };
+    // ---- per-node rows: streamed rows + station-neighbour gathers (one node-tile ahead), as in k_stage2_h2
+    struct Node { f32x4 ru[KS], c1, c2; u32x4 ea; float mq; } R;
+    int sta[KS];
+    auto load_sta = [&](int tb) {
+        const int s = tb * 16 + jl;
+        load_sta_ids<KS>(a.sta_col, s < S ? s : S - 1, sta);
+    };
+    auto issue = [&](int idv, int tb) {
+        const int g = max(__builtin_amdgcn_readlane(idv, 0), 0);         // (-1: an empty slot of a short block: rows of node 0, result dropped)
+        const int s = tb * 16 + m, sc = s < S ? s : S - 1;
+        const unsigned so = (unsigned)sc * 16u;
+        const unsigned lo = kgp + so;
+        const unsigned long long cb = s2h_base<BIG>(a.c, g, pc);
+        R.c1 = *(grow)((gbytes)cb + lo);
+        R.c2 = *(grow)((gbytes)cb + (lo + 4u * plane));
+        const unsigned long long mb = s2h_base<BIG>(a.mm_int, g, pm);
+        R.mq = *(gflt)((gbytes)mb + (unsigned)sc * 4u);
+        if (s >= S) R.mq = 0.f;
+        const unsigned long long eb = s2h_base<BIG>(a.ea_frag, g, pe);
+        R.ea = *(gfrag)((gbytes)eb + (kge + so));
+        const unsigned long long ub = s2h_base<BIG>(a.wu, g, pw);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) R.ru[k] = *(grow)((gbytes)ub + ((unsigned)sta[k] * 64u + q16));
+    };
+    // Every wave takes the two slots b = wave, wave + 4 of EVERY item of its workgroup (a short block leaves slots empty: their
+    // index row starts with -1): the slot sequence is regular, so no control decision waits on a table load.
+    // slot number j -> (item j / 2, half j % 2); index rows are loaded two slots ahead, station ids and per-node rows one ahead.
+    auto slot = [&](long long j, int& blk, int& tb, int& b) {
+        item_of(lb + (j >> 1) * nbx, blk, tb);
+        b = wave + 4 * (int)(j & 1);
+    };
+    auto idv_at = [&](long long j) {
+        int blk, tb, b;
+        slot(j, blk, tb, b);
+        return blocks[blk].idx[b][m];
+    };
+    const long long n_my_items = (n_items - lb + nbx - 1) / nbx;
+    int blk_c, tb_c, blk_n, tb_n, blk_2, tb_2, dummy;
+    item_of(lb, blk_c, tb_c);
+    item_of(lb + nbx, blk_n, tb_n);
+    int idl_c = blocks[blk_c].ids[lane], U_c = blocks[blk_c].U;
+    int idl_n = blocks[blk_n].ids[lane], U_n = blocks[blk_n].U;
+    stage_issue(idl_c, __builtin_amdgcn_readfirstlane(U_c), tb_c);
+    int idv_c = idv_at(0), idv_n = idv_at(1);
+    load_sta(tb_c);
+    issue(idv_c, tb_c);
+    for (long long ii = 0; ii < n_my_items; ++ii) {
+        const bool has_next_item = ii + 1 < n_my_items;
+        item_of(lb + (ii + 2) * nbx, blk_2, tb_2);
+        const int idl_2 = blocks[blk_2].ids[lane], U_2 = blocks[blk_2].U;       // two items ahead (clamped), consumed next iteration
+        stage_write(__builtin_amdgcn_readfirstlane(U_c));
+        __syncthreads();
+        if (has_next_item) stage_issue(idl_n, __builtin_amdgcn_readfirstlane(U_n), tb_n);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            asm volatile("" : "+v"(lane));
+            const long long j = 2 * ii + h;
+            const int idv_2 = idv_at(j + 2 < 2 * n_my_items ? j + 2 : j);
+            const int g_raw = __builtin_amdgcn_readlane(idv_c, 0);
+            const bool live = g_raw >= 0;
+            const int g_c = max(g_raw, 0);
+            const int tbc = tb_c;
+            const int tb_next = h == 0 ? tb_c : tb_n;          // station tile of the next slot
+            (void)dummy;
+            // (1) neighbour sums in edge order: station rows from their registers (row layout -> operand layout), source rows from LDS
+            f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) n1 += R.ru[k];
+#pragma unroll
+            for (int k0 = 0; k0 < KP; k0 += 5) {
+                f32x4 rv[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    rv[k] = *(const f32x4*)(lrows + (unsigned)__builtin_amdgcn_readlane(idv_c, 1 + k0 + k) * 1024u + (unsigned)lane * 16u);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) n2 += rv[k];
+            }
+            f32x4 n1t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = n1[r];
+                n1t[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm, __float_as_int(v)));
+            }
+            f32x4 o1 = fma4(n1t, 1.f / (float)KS, R.c1), o2 = fma4(n2, 1.f / (float)KP, R.c2);
+            const float mq = R.mq;
+            const u32x4 eab = R.ea;
+            o1 = prelu4u(o1, a2);
+            o2 = prelu4u(o2, a2);
+            asm volatile("" : "+v"(o1), "+v"(o2), "+v"(idv_n));
+            // (2) per-node rows of the next slot (it may belong to the next item: only LDS contents are per item). The two slots of an
+            // item share their station tile, so the station-neighbour ids change once per item and are loaded a slot ahead of their use
+            issue(idv_n, tb_next);
+            if (h == 0) load_sta(tb_n);
+            if (XL && live && tbc * 16 + m < S) {
+                const int su = a.sta_user[tbc * 16 + m];
+                float* xl = a.x_latent + ((long long)g_c * S + su) * 30;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kg + r < 15) { xl[4 * kg + r] = o1[r]; xl[15 + 4 * kg + r] = o2[r]; }
+            }
+            u32x4 p0, p1, p2;
+            p0[0] = cvt_pk_f16(o1[0], o1[1]); p0[1] = cvt_pk_f16(o1[2], o1[3]);
+            p0[2] = cvt_pk_f16(o2[0], o2[1]); p0[3] = cvt_pk_f16(o2[2], o2[3]);
+            p1[0] = cvt_pk_f16(sub_f16_lo(o1[0], p0[0]), sub_f16_hi(o1[1], p0[0]));
+            p1[1] = cvt_pk_f16(sub_f16_lo(o1[2], p0[1]), sub_f16_hi(o1[3], p0[1]));
+            p1[2] = cvt_pk_f16(sub_f16_lo(o2[0], p0[2]), sub_f16_hi(o2[1], p0[2]));
+            p1[3] = cvt_pk_f16(sub_f16_lo(o2[2], p0[3]), sub_f16_hi(o2[3], p0[3]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) p2[d] = pk_mul_f16(p0[d], H2_SIXTEENTH);
+            f32x4 bp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bp[t] = *(const f32x4*)(lbias + 16 * t + 4 * kg);
+                const f32x4 w0 = lw[(S2H_FW + 2 * t) * 64 + lane], w1 = lw[(S2H_FW + 2 * t + 1) * 64 + lane];
+                const f32x4 we = lw[(S2H_FE + t) * 64 + lane];
+                bp[t] = MFMA16H(w0, p1, bp[t]);
+                bp[t] = MFMA16H(w1, p2, bp[t]);
+                bp[t] = MFMA16H(we, eab, bp[t]);
+                bp[t] = MFMA16H(w0, p0, bp[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 v = prelu4u(bp[t], ab1) * mq;
+                v.x = row_sum16_tree(v.x); v.y = row_sum16_tree(v.y); v.z = row_sum16_tree(v.z); v.w = row_sum16_tree(v.w);
+                if (m == 0 && live) *(f32x4*)(a.part + ((long long)g_c * T + tbc) * 32 + 16 * t + 4 * kg) = v;
+            }
+            idv_c = idv_n; idv_n = idv_2;
+        }
+        if (!has_next_item) break;
+        __syncthreads();              // every wave has finished reading this block-tile's rows
+        blk_c = blk_n; tb_c = tb_n; blk_n = blk_2; tb_n = tb_2;
+        idl_c = idl_n; U_c = U_n; idl_n = idl_2; U_n = U_2;
+    }
+}
