@@ -23,6 +23,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <utility>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -1229,7 +1231,11 @@ struct genie_ctx {
                                // split into fp16 pieces is bounded below 60 000 for inputs in [-1, 1], and so is every weight
     float range_act, range_w;  // ... the two bounds it found (largest hidden-state bound, largest weight magnitude incl. the 16 x forms)
     float* d_range; float* h_range;     // device result / pinned host copy of k_h2_range
-    void* s2u_blocks; int32_t* s2u_xcd0; int s2u_nblk;   // k_stage2_h2u: blocks of adjacent source nodes with the union of their neighbour rows
+    // k_stage2_h2u: blocks of adjacent source nodes with the union of their neighbour rows, per launched range [gi_begin, gi_end) of the
+    // processing order (the whole grid; the sharded path's four static sub-ranges): built on first use from the host copy of src_tab
+    struct S2uTables { void* blocks; int32_t* xcd0; int nblk; };
+    std::map<std::pair<int, int>, S2uTables> s2u;
+    std::vector<int32_t> tab_host;
     int s2u_off;               // tuning: k_stage2_h2 (every source row through the texture path) where k_stage2_h2u applies
     int32_t* d_s2htbl;         // k_pack_h2 source table of k_stage2_h2's image
     float* packed_s2h;         // f16x2 weight image of k_stage2_h2 (Bipartite_ReadIn.fc1)
@@ -1937,51 +1943,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         }
         HIP_TRY(hipMalloc((void**)&c->src_tab, sizeof(int32_t) * tab.size()));
         HIP_TRY(hipMemcpy(c->src_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
-        if (n_grid_ext == n_grid) {
-            // k_stage2_h2u: per XCD chunk of the processing order, blocks of up to S2U_NB consecutive source nodes whose neighbour rows
-            // (their union, in first-use order) fit S2U_UCAP rows; a block is cut short where the union would grow past that
-            std::vector<S2uBlock> blks;
-            int32_t x0[9];
-            const int nxc = 8;
-            for (int x = 0; x < nxc; ++x) {
-                x0[x] = (int32_t)blks.size();
-                const int gb = (int)((long long)n_grid * x / nxc), ge = (int)((long long)n_grid * (x + 1) / nxc);
-                int pos = gb;
-                while (pos < ge) {
-                    S2uBlock b;
-                    memset(&b, 0, sizeof(b));
-                    b.gi0 = pos;
-                    std::vector<int32_t> uni;
-                    while (pos < ge && b.n < S2U_NB) {
-                        std::vector<int32_t> add;
-                        int32_t where[15];
-                        for (int k = 0; k < 15; ++k) {
-                            const int32_t nb = tab[(size_t)pos * 16 + 1 + k];
-                            int at = -1;
-                            for (size_t u = 0; u < uni.size(); ++u) if (uni[u] == nb) { at = (int)u; break; }
-                            if (at < 0) for (size_t u = 0; u < add.size(); ++u) if (add[u] == nb) { at = (int)(uni.size() + u); break; }
-                            if (at < 0) { at = (int)(uni.size() + add.size()); add.push_back(nb); }
-                            where[k] = at;
-                        }
-                        if (b.n > 0 && uni.size() + add.size() > (size_t)S2U_UCAP) break;
-                        uni.insert(uni.end(), add.begin(), add.end());
-                        b.idx[b.n][0] = tab[(size_t)pos * 16];
-                        for (int k = 0; k < 15; ++k) b.idx[b.n][1 + k] = where[k];
-                        ++b.n; ++pos;
-                    }
-                    for (int e = b.n; e < S2U_NB; ++e) b.idx[e][0] = -1;       // empty slots of a short block
-                    b.U = (int32_t)uni.size();
-                    for (int u = 0; u < S2U_UCAP; ++u) b.ids[u] = uni[(size_t)u < uni.size() ? u : 0];
-                    blks.push_back(b);
-                }
-            }
-            x0[nxc] = (int32_t)blks.size();
-            HIP_TRY(hipMalloc(&c->s2u_blocks, sizeof(S2uBlock) * std::max<size_t>(1, blks.size())));
-            HIP_TRY(hipMemcpy(c->s2u_blocks, blks.data(), sizeof(S2uBlock) * blks.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc((void**)&c->s2u_xcd0, sizeof(x0)));
-            HIP_TRY(hipMemcpy(c->s2u_xcd0, x0, sizeof(x0), hipMemcpyHostToDevice));
-            c->s2u_nblk = (int)blks.size();
-        }
+        c->tab_host = tab;
     }
     c->dirty = true;
     int dev = 0;
@@ -2213,9 +2175,10 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
-                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of, c->s2u_blocks, c->s2u_xcd0};
+                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
     for (void* p : ptrs) (void)hipFree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
+    for (auto& kv : c->s2u) { (void)hipFree(kv.second.blocks); (void)hipFree(kv.second.xcd0); }
     delete c;
     return GENIE_OK;
 }
@@ -2379,6 +2342,62 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                int gi_begin, int gi_end, const float* slope2 = nullptr, int no_bip = 0);
 }
 
+namespace {
+// k_stage2_h2u's tables for the range [gb0, ge0) of the processing order: per XCD chunk (the chunks of ItemIter), blocks of up to
+// S2U_NB consecutive source nodes whose neighbour rows (their union, in first-use order) fit S2U_UCAP rows; a block is cut short
+// where the union would grow past that. Built once per range and kept with the context.
+int get_s2u_tables(genie_ctx* c, int gb0, int ge0, const genie_ctx::S2uTables** out) {
+    const auto key = std::make_pair(gb0, ge0);
+    auto itf = c->s2u.find(key);
+    if (itf != c->s2u.end()) { *out = &itf->second; return GENIE_OK; }
+    const std::vector<int32_t>& tab = c->tab_host;
+    std::vector<S2uBlock> blks;
+    int32_t x0[9];
+    const int nxc = 8, n = ge0 - gb0;
+    for (int x = 0; x < nxc; ++x) {
+        x0[x] = (int32_t)blks.size();
+        const int gb = gb0 + (int)((long long)n * x / nxc), ge = gb0 + (int)((long long)n * (x + 1) / nxc);
+        int pos = gb;
+        while (pos < ge) {
+            S2uBlock b;
+            memset(&b, 0, sizeof(b));
+            b.gi0 = pos;
+            std::vector<int32_t> uni;
+            while (pos < ge && b.n < S2U_NB) {
+                std::vector<int32_t> add;
+                int32_t where[15];
+                for (int k = 0; k < 15; ++k) {
+                    const int32_t nb = tab[(size_t)pos * 16 + 1 + k];
+                    int at = -1;
+                    for (size_t u = 0; u < uni.size(); ++u) if (uni[u] == nb) { at = (int)u; break; }
+                    if (at < 0) for (size_t u = 0; u < add.size(); ++u) if (add[u] == nb) { at = (int)(uni.size() + u); break; }
+                    if (at < 0) { at = (int)(uni.size() + add.size()); add.push_back(nb); }
+                    where[k] = at;
+                }
+                if (b.n > 0 && uni.size() + add.size() > (size_t)S2U_UCAP) break;
+                uni.insert(uni.end(), add.begin(), add.end());
+                b.idx[b.n][0] = tab[(size_t)pos * 16];
+                for (int k = 0; k < 15; ++k) b.idx[b.n][1 + k] = where[k];
+                ++b.n; ++pos;
+            }
+            for (int e = b.n; e < S2U_NB; ++e) b.idx[e][0] = -1;       // empty slots of a short block
+            b.U = (int32_t)uni.size();
+            for (int u = 0; u < S2U_UCAP; ++u) b.ids[u] = uni[(size_t)u < uni.size() ? u : 0];
+            blks.push_back(b);
+        }
+    }
+    x0[nxc] = (int32_t)blks.size();
+    genie_ctx::S2uTables t;
+    t.blocks = nullptr; t.xcd0 = nullptr; t.nblk = (int)blks.size();
+    HIP_TRY(hipMalloc(&t.blocks, sizeof(S2uBlock) * std::max<size_t>(1, blks.size())));
+    HIP_TRY(hipMemcpy(t.blocks, blks.data(), sizeof(S2uBlock) * blks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&t.xcd0, sizeof(x0)));
+    HIP_TRY(hipMemcpy(t.xcd0, x0, sizeof(x0), hipMemcpyHostToDevice));
+    *out = &(c->s2u[key] = t);
+    return GENIE_OK;
+}
+}  // namespace
+
 int genie_da_stage2_partials(genie_ctx* c, const float* mask, const float* edge_attr, float* x_latent_out, void* ws,
                              void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "null context");
@@ -2450,15 +2469,17 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                 a.ea_frag = c->ea_frag_tmp;
             }
             const bool big = c->P_ext * 128 >= (1ll << 32);
-            if (c->s2u_blocks && !c->s2u_off && gi_begin == 0 && gi_end == c->G) {
-                // whole grid on one GPU: source-neighbour rows of blocks of adjacent source nodes staged once in LDS (k_stage2_h2u)
+            if (!c->tab_host.empty() && !c->s2u_off) {
+                // source-neighbour rows of blocks of adjacent source nodes staged once in LDS (k_stage2_h2u), for this range of the order
+                const genie_ctx::S2uTables* tb = nullptr;
+                if ((rc = get_s2u_tables(c, gi_begin, gi_end, &tb))) return rc;
                 const size_t lds = sizeof(float) * S2H_IMG_FLOATS + (size_t)S2U_UCAP * 1024;
-                const long long items = (long long)c->s2u_nblk * c->T;
+                const long long items = (long long)tb->nblk * c->T;
                 const long long gsz = std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8);
                 const int grid = (int)std::max<long long>(8, gsz / 8 * 8);
                 auto launch = [&](auto kern) {
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)c->s2u_blocks, c->s2u_xcd0);
+                    kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
                 };
                 if (x_latent_out) { if (big) launch(k_stage2_h2u<true, true>); else launch(k_stage2_h2u<true, false>); }
                 else { if (big) launch(k_stage2_h2u<false, true>); else launch(k_stage2_h2u<false, false>); }
