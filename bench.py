@@ -40,7 +40,7 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 matrix/vector peak
 # granularity). The HIP path moves fewer real bytes than that because h0/h1/u/v never leave the registers; per
 # product node and per kernel group (gathers counted once per row = perfect cache):
 #   stage 1 = k_split_rows + k_stage1_h2: Slice+Mask 32 R, split rows 32 W + 32 R, message mask 4 W, c 120 W, wu+wv 120 W = 340 B
-#   stage 2 = k_stage2_h2               : c 120 R, wu+wv 120 R, message mask 4 R, edge_attr fragments 32 R             = 276 B
+#   stage 2 = k_stage2_h2u              : c 120 R, wu+wv 120 R, message mask 4 R, edge_attr fragments 32 R             = 276 B
 B_NODE = {"k_stage1": 340.0, "k_stage2": 276.0}
 # ALGORITHMIC FLOPs per product node (SURVEY.md 8d split by kernel; 2 per MAC): stage 1 = init_trns 240 + layer-1 3840
 # + l2_t*_1 3600 + l2_t*_2 2820 MACs + 690 layer-1 gather adds; stage 2 = Bipartite fc1 990 MACs + 690 gather adds.
@@ -854,7 +854,7 @@ def main():
     kern["k_stage1"]["kernels"] = "k_split_rows_g + k_stage1_h2"
     kern["k_stage1"]["executed_f16"] = {"tflops": round(exec_tf, 1), "peak": F16_MFMA_PEAK_TF, "frac": round(exec_tf / F16_MFMA_PEAK_TF, 4),
                                          "note": "fp32 operands as two fp16 pieces, three partial products per product, fp32 accumulation"}
-    kern["k_stage2"]["kernels"] = "k_stage2_h2"
+    kern["k_stage2"]["kernels"] = "k_stage2_h2u"
     roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                 "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
                 "traffic": None, "hbm_real_frac": None,
