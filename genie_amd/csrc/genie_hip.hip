@@ -2478,7 +2478,8 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                 const long long gsz = std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8);
                 const int grid = (int)std::max<long long>(8, gsz / 8 * 8);
                 auto launch = [&](auto kern) {
-                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    static bool attr_set = false;       // (one per instantiation: the 70-KB dynamic LDS needs the attribute once)
+                    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
                     kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
                 };
                 if (x_latent_out) { if (big) launch(k_stage2_h2u<true, true>); else launch(k_stage2_h2u<true, false>); }
