@@ -1200,6 +1200,7 @@ struct genie_ctx {
     float *abs_sta, *abs_src;  // use_absolute_pos: [S][4], [G_ext][4] scaled positions; null = off
     unsigned *abs_ts, *abs_tg; // ... their fp16 pieces for k_stage1_h2 (stations in processing order), rebuilt when abs_dirty
     bool abs_dirty;
+    int abs_ts_order;          // station order the pieces were built in (1 = processing order)
     // irregular product graph (`use_subgraph`): product-level CSRs, row range of every source node
     bool pcsr;
     bool pcsr_h2;              // ... with at most 8 / 15 neighbours per product node: k_stage1_h2<.., PCSR> applies
@@ -1923,7 +1924,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
     c->has_edges = false;
     c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr; c->xs_mm_copy = 0;
-    c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr; c->abs_dirty = false;
+    c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr; c->abs_dirty = false; c->abs_ts_order = 0;
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr; c->sta_ident = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
@@ -2283,14 +2284,15 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         const bool big = c->P_ext * XROW >= (1ll << 32);
         if (!n_tiles) {
         } else if (c->abs_sta) {
-            if (c->abs_dirty || !c->abs_ts) {
+            const int so = sta_order_on(c) ? 1 : 0;      // a training forward runs in the caller's station order, inference in processing order
+            if (c->abs_dirty || !c->abs_ts || c->abs_ts_order != so) {
                 if (!c->abs_ts) {
                     HIP_TRY(hipMalloc((void**)&c->abs_ts, 16 * (size_t)c->S));
                     HIP_TRY(hipMalloc((void**)&c->abs_tg, 16 * (size_t)c->G_ext));
                 }
                 k_abs_pieces<<<(c->S + 255) / 256, 256, 0, st>>>(c->abs_sta, sta_order_on(c) ? c->sta_perm : nullptr, c->S, c->abs_ts);
                 k_abs_pieces<<<(c->G_ext + 255) / 256, 256, 0, st>>>(c->abs_src, nullptr, c->G_ext, c->abs_tg);
-                c->abs_dirty = false;
+                c->abs_dirty = false; c->abs_ts_order = so;
                 a.abs_ts = c->abs_ts; a.abs_tg = c->abs_tg;
             }
             if (big) k_stage1_h2<8, 15, false, true, true><<<grid, H2_THREADS, 0, st>>>(a);
@@ -2986,22 +2988,60 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 namespace {
 int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }      // 2 workgroups per CU (1: +10 %, 3: +6 %, 4: +1 % step time)
 size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 12 * 16 + 16); }
-int train_check(const genie_ctx* c, const char* who) {
+// `variants`: the call also serves DataAggregationEdges / use_absolute_pos (the forward_fixed_source step does; the association heads'
+// training step is the default model definition only)
+int train_check(const genie_ctx* c, const char* who, bool variants = false) {
     if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
-    if (c->has_edges || c->abs_sta) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
+    if (!variants && (c->has_edges || c->abs_sta)) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
+    if (c->has_edges && c->abs_sta) return fail(GENIE_ERR_STATE, std::string(who) + ": edge features together with absolute positions");
+    return GENIE_OK;
+}
+// scratch of static_term_grads: per-source-node sums [G][16], per-station partial sums [SG_CHUNKS][S][16], slices of one dW block
+size_t static_scratch_floats(const genie_ctx* c) { return (size_t)c->G * 16 + (size_t)SG_CHUNKS * c->S * 16 + (size_t)SG_SLICES * 64; }
+
+// Weight gradients of the static terms of DataAggregationEdges (l?_t?_2.weight_pos) and use_absolute_pos (init_trns.weight_abs) from
+// the gradient rows the three passes left in `gr` (train_front_kernels.hpp, k_gr_sum_* / k_static_dw*).
+int static_term_grads(genie_ctx* c, const float* gr, float* scr, float* grad_blob, hipStream_t st) {
+    struct Term { int blk; bool sta; const float* f; int nf, w, ld, row0, rows, col0; };
+    std::vector<Term> terms;
+    if (c->has_edges) {
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + b, true, c->mpos_sta, 4, W_DA_L1T12_P, 4, 16 * b, std::min(16, 30 - 16 * b), 0});
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + 2 + b, false, c->mpos_src, 4, W_DA_L1T22_P, 4, 16 * b, std::min(16, 30 - 16 * b), 0});
+        terms.push_back({GR_DO + 0, true, c->mpos_sta, 4, W_DA_L2T12_P, 4, 0, 15, 0});
+        terms.push_back({GR_DO + 1, false, c->mpos_src, 4, W_DA_L2T22_P, 4, 0, 15, 0});
+    }
+    if (c->abs_sta) {
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DH0 + b, true, c->abs_sta, 3, W_DA_INIT_ABS, 6, 16 * b, std::min(16, 30 - 16 * b), 0});
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DH0 + b, false, c->abs_src, 3, W_DA_INIT_ABS, 6, 16 * b, std::min(16, 30 - 16 * b), 3});
+    }
+    float* r_src = scr; float* r_sta = r_src + (size_t)c->G * 16; float* dpart = r_sta + (size_t)SG_CHUNKS * c->S * 16;
+    for (const Term& t : terms) {
+        const float* blk = gr + (size_t)t.blk * 16 * (size_t)c->P;
+        if (t.sta) {
+            k_gr_sum_sta<<<dim3((c->S * 4 + 255) / 256, SG_CHUNKS), 256, 0, st>>>(blk, c->S, c->G, r_sta);
+            k_static_dw<<<SG_SLICES, 64, 0, st>>>(r_sta, SG_CHUNKS, (long long)c->S * 16, t.f, c->S, dpart);
+        } else {
+            k_gr_sum_src<<<(c->G + 3) / 4, 256, 0, st>>>(blk, c->S, c->G, r_src);
+            k_static_dw<<<SG_SLICES, 64, 0, st>>>(r_src, 1, 0, t.f, c->G, dpart);
+        }
+        k_static_dw_sum<<<1, 64, 0, st>>>(dpart, t.rows, t.nf, grad_blob + g_params[t.w].off, t.ld, t.row0, t.col0);
+    }
+    HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 }  // namespace
 
 size_t genie_train_save_floats(const genie_ctx* c) { return c ? (size_t)SV_BLOCKS * 16 * (size_t)c->P : 0; }
-size_t genie_train_scratch_floats(const genie_ctx* c) { return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) : 0; }
+size_t genie_train_scratch_floats(const genie_ctx* c) {
+    return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) + static_scratch_floats(c) : 0;
+}
 
 int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, float* save,
                        float* x_latent_out, float* r_out, void* ws, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!slice || !mask || !edge_attr || !save || !r_out) return fail(GENIE_ERR_ARG, "genie_da_train_fwd: null argument");
-    if ((rc = train_check(c, "genie_da_train_fwd"))) return rc;
+    if ((rc = train_check(c, "genie_da_train_fwd", true))) return rc;
     c->force_generic = 1; c->train_save = save;
     rc = run_stage1(c, slice, mask, nullptr, nullptr, ws, stream, 0, c->G, true);
     if (!rc) rc = run_stage2(c, mask, edge_attr, x_latent_out, ws, stream, 0, c->G);
@@ -3035,7 +3075,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     if (!c || !slice || !mask || !edge_attr || !save || !d_r || !scratch || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_da_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_da_train_bwd"))) return rc;
+    if ((rc = train_check(c, "genie_da_train_bwd", true))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if ((rc = ensure_reversed(c))) return rc;
@@ -3050,6 +3090,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     a.slice = slice; a.mask = mask; a.edge_attr = edge_attr; a.save = save; a.dr = d_r;
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
     a.sv_t = SV_T; a.sv_up = SV_UP; a.sv_vp = SV_VP;
+    a.store_dz0 = c->abs_sta != nullptr;
     const int grid = train_grid(c), n_waves = grid * 4;
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
@@ -3059,6 +3100,9 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob, 0);
+    }
+    if (c->has_edges || c->abs_sta) {
+        if ((rc = static_term_grads(c, a.gr, a.part + train_part_floats(c), grad_blob, st))) return rc;
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -3107,7 +3151,7 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!pos || !x_query || !knn || !t_query || !tsave || !y_out || !x_out) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: null argument");
-    if ((rc = train_check(c, "genie_tail_train_fwd"))) return rc;
+    if ((rc = train_check(c, "genie_tail_train_fwd", true))) return rc;
     if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
@@ -3153,7 +3197,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
     if (!c || !pos || !x_query || !knn || !rknn_rowptr || !rknn_edge || !t_query || !tsave || !d_y || !d_x || !scratch || !d_r_out || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_tail_train_bwd"))) return rc;
+    if ((rc = train_check(c, "genie_tail_train_bwd", true))) return rc;
     if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;

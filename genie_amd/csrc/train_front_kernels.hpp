@@ -35,6 +35,7 @@ struct TrArgs {
                                  // association phase's AV_T, AV_UV, AV_UV + 2)
     const float* pg;             // association phase (k_train_b1<true>, k_as_*): [G][AS_PG] per-source-node terms, pg[31] = mask1[g]
     const float* x_latent;       // association phase: [P, 30] DataAggregation output (an input of init_trns there)
+    int store_dz0;               // k_train_b0: keep dz0 in the GR_DH0 blocks (read by the static-term gradients of use_absolute_pos)
     float* zsum;                 // k_as_b0: [G * T][32] per-tile station sums of d z1 (-> d y_latent, fc1's y_latent columns)
 };
 
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
             const f32x4 dh0 = ldb(a.gr, GR_DH0 + b, P, p, q) * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
             scal[0] += negsum4(dh0, z0[b]);
             dz0[b] = dh0 * dprelu4(z0[b], a0);
+            if (a.store_dz0 && valid) stb(a.gr, GR_DH0 + b, P, p, q, dz0[b]);
         }
         vec[0] += dz0[0]; vec[1] += dz0[1];
         vec[2] += dt[0]; vec[3] += dt[1]; vec[4] += dt[2]; vec[5] += dt[3];
@@ -459,6 +461,54 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += ps[k][o];
     blob[dst] = accumulate ? blob[dst] + t : t;      // accumulate: parameters that several passes contribute to (each pass in stream order)
+}
+
+// ---- weight gradients of the STATIC terms of the two other model definitions (DataAggregationEdges: mean edge features per
+// station / per source node, module.py:102-174; use_absolute_pos: the scaled positions of a product node's station and source node,
+// module.py:56-57). Such a term is W_f f[n] with f a fixed table over the nodes n of ONE base graph, so its weight gradient is
+//   dW_f[out][e] = sum_p dY[p][out] f[n(p)][e] = sum_n (sum over the product nodes p of n of dY[p][out]) f[n][e]:
+// the gradient rows the passes keep in `gr` (do, dt; dz0 when TrArgs.store_dz0) are summed per station / per source node
+// (k_gr_sum_sta / k_gr_sum_src, fixed order), then contracted with the table (k_static_dw, k_static_dw_sum: fixed order too).
+constexpr int SG_CHUNKS = 64, SG_SLICES = 64;
+__global__ __launch_bounds__(256) void k_gr_sum_src(const float* __restrict__ blk, int S, int G, float* __restrict__ out) {   // out[g][16]
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int st = j; st < S; st += 16) s += *(const f32x4*)(blk + ((size_t)g * S + st) * 16 + 4 * q);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d); s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d); }
+    if (j == 0) *(f32x4*)(out + (size_t)g * 16 + 4 * q) = s;
+}
+__global__ __launch_bounds__(256) void k_gr_sum_sta(const float* __restrict__ blk, int S, int G, float* __restrict__ part) {   // part[chunk][s][16]
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (s, q)
+    if (idx >= S * 4) return;
+    const int ch = blockIdx.y;
+    const int g0 = (int)((long long)G * ch / SG_CHUNKS), g1 = (int)((long long)G * (ch + 1) / SG_CHUNKS);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int g = g0; g < g1; ++g) s += *(const f32x4*)(blk + (size_t)g * S * 16 + (size_t)idx * 4);
+    *(f32x4*)(part + ((size_t)ch * S * 4 + idx) * 4) = s;
+}
+// R[n][16] (the sum of `nparts` copies `pstride` floats apart) contracted with f[n][4]: slice x of the nodes -> part[x][16 out][4 e]
+__global__ __launch_bounds__(64) void k_static_dw(const float* __restrict__ R, int nparts, long long pstride, const float* __restrict__ f, int n,
+                                                   float* __restrict__ part) {
+    const int o = threadIdx.x & 15, e = threadIdx.x >> 4, x = blockIdx.x;
+    const int n0 = (int)((long long)n * x / SG_SLICES), n1 = (int)((long long)n * (x + 1) / SG_SLICES);
+    float s = 0.f;
+    for (int i = n0; i < n1; ++i) {
+        float r = 0.f;
+        for (int k = 0; k < nparts; ++k) r += R[(size_t)k * pstride + (size_t)i * 16 + o];
+        s += r * f[(size_t)i * 4 + e];
+    }
+    part[x * 64 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void k_static_dw_sum(const float* __restrict__ part, int rows, int nf, float* __restrict__ dW, int ld, int row0,
+                                                       int col0) {
+    const int o = threadIdx.x & 15, e = threadIdx.x >> 4;
+    if (o >= rows || e >= nf) return;
+    float s = 0.f;
+    for (int x = 0; x < SG_SLICES; ++x) s += part[x * 64 + threadIdx.x];
+    dW[(row0 + o) * ld + col0 + e] = s;
 }
 
 __global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles

@@ -109,7 +109,7 @@ class _PathTrain(torch.autograd.Function):
             d_qlat = torch.zeros((nq_all, 30), dtype=torch.float32, device=dev)
             d_qlat[nq_all - ns:] = d_xsrc
         g = hp.path_train_bwd(Slice, Mask, edge_attr, pos, x_query, knn, t_query, save, tsave, d_y, d_xa, d_xs, d_ylat, d_qlat)
-        return (None,) * 10 + tuple(g[n].view(s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
+        return (None,) * 10 + tuple(_join_variant_columns(g, n, s) for n, s in zip(TRAIN_PATH_PARAMS, ctx.shapes))
 
 
 TRAIN_ASSOC_PARAMS = tuple(
@@ -284,6 +284,22 @@ def _split_edge_columns(named):
             out[k] = torch.cat((W[:, :n_in], W[:, n_in + 4:]), dim=1).contiguous()
             out[k + "_pos"] = W[:, n_in:n_in + 4].contiguous()
     return out
+
+
+def _join_variant_columns(g, name, shape):
+    """Inverse of `_split_edge_columns` / `_split_abs_columns` on a dict of registry-layout gradients: the gradient of state_dict
+    entry `name` in the parameter's own `shape` (the static-term columns, kept under `<name>_pos` / `<name>_abs` in the library's
+    weight mirror, go back between the node columns and the Mask columns)."""
+    w = g[name]
+    if name.endswith(".weight") and len(shape) == 2 and w.numel() != shape[0] * shape[1]:
+        extra = g.get(name + "_pos") if (name + "_pos") in g else g.get(name + "_abs")
+        ne = shape[1] - w.numel() // shape[0]
+        if extra is None or extra.numel() != shape[0] * ne:
+            raise RuntimeError("gradient of %s: registry columns do not add up to the parameter's shape %r" % (name, tuple(shape)))
+        w, extra = w.view(shape[0], -1), extra.view(shape[0], ne)
+        n_mask = 4                                                    # both variants keep the 4 Mask columns last
+        return torch.cat((w[:, :w.shape[1] - n_mask], extra, w[:, w.shape[1] - n_mask:]), dim=1)
+    return w.view(shape)
 
 
 class BipartiteGraphOperator(nn.Module):
@@ -826,10 +842,13 @@ class GCN_Detection_Network_extended(nn.Module):
         source queries, module.py:981) only with `x_query_src_cart` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
-        if self.use_updated_model_definition or self.use_absolute_pos or self._hip._n_prod is not None:
-            raise NotImplementedError("training-mode forward: default model definition on a Cartesian product graph only")
+        if self._hip._n_prod is not None:
+            raise NotImplementedError("training-mode forward: Cartesian product graphs only (not use_subgraph)")
+        variant = self.use_updated_model_definition or self.use_absolute_pos
+        if variant and want_latents:
+            raise NotImplementedError("training-mode 4-output forward: default model definition only")
         hp = self._hip
-        hp.sync_weights(self._path_params)
+        hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         n_src_rows = 0
         if x_query_src_cart is not None:          # the source queries ride along as extra query rows (same kernels, same backward)

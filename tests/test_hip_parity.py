@@ -522,6 +522,74 @@ def test_training_mode_forward_and_gradients_match_oracle_autograd(name):
     assert checked >= 80          # every tensor of DataAggregation, Bipartite_ReadIn, SpatialAggregation1..3 and the read-outs
 
 
+@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13"])
+@pytest.mark.parametrize("stage1", ["default", "f32"])
+def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(name, stage1, monkeypatch):
+    """a-8 / a-9: the training step of `forward_fixed_source` under `use_updated_model_definition` (DataAggregationEdges,
+    module.py:102-174) and `use_absolute_pos` (module.py:56-57, :1007). The forward is the inference kernels of those variants with
+    the pre-activations kept; their static terms (mean edge features per station / source node; scaled positions) add only WEIGHT
+    gradients, taken from per-station / per-source-node sums of the gradient rows the backward passes keep (k_gr_sum_*,
+    k_static_dw). Every parameter gradient -- in the parameter's own [30, 68] / [15, 98] / [30, 14] shape -- equals the oracle's
+    autograd (fp32 CPU) to 1e-5 of the gradient scale; an inference call after the step is unchanged (the station-order state of
+    the position tables is per call)."""
+    from oracle import genie_oracle as O
+    if stage1 == "f32":
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
+    c = Case(name)
+    kw = dict(use_updated_model_definition=True) if c.edges_variant else dict(use_absolute_pos=True)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, **kw)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea, A_src_in_sta.to(DEV), c.A_src_src.to(DEV),
+                        None, None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    args = (c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV),
+            c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    net.eval()
+    with torch.no_grad():
+        y_hip, x_hip = net.forward_fixed_source(*args)
+    net.train()
+    y, x = net.forward_fixed_source(*args)
+    assert y.requires_grad and x.requires_grad
+    assert max_abs(y.detach(), y_hip) <= 1e-5 and max_abs(x.detach(), x_hip) <= 1e-5
+    assert max_abs(y.detach().cpu(), c.ref("y")) <= 1e-5 and max_abs(x.detach().cpu(), c.ref("x")) <= 1e-5
+    g = torch.Generator().manual_seed(7)
+    ay, ax = torch.randn(y.shape, generator=g), torch.randn(x.shape, generator=g)
+    (y * ay.to(DEV)).sum().add((x * ax.to(DEV)).sum()).backward()
+    net.eval()
+    with torch.no_grad():
+        y2, x2 = net.forward_fixed_source(*args)
+    assert torch.equal(y2, y_hip) and torch.equal(x2, x_hip)
+    # oracle autograd on the CPU
+    w = {k: v.clone().requires_grad_(True) for k, v in c.weights.items()}
+    Slice, okw = c.Slice, {}
+    if c.abspos_variant:
+        Slice = O.absolute_pos_inputs(Slice, c.locs.float(), c.x_grid.float(), A_src_in_sta)
+    else:
+        okw["pos_rel"] = (O.edge_pos_features(c.locs.float(), A_in_sta, A_src_in_sta[0]),
+                          O.edge_pos_features(c.x_grid.float(), A_in_src, A_src_in_sta[1]))
+    yo, xo = O.forward_fixed_source(w, Slice, c.Mask, A_in_sta, A_in_src, c.edge_attr, A_src_in_prod, c.A_src_src,
+                                    c.x_grid.float(), c.x_query.float(), c.t_query.float(), **okw)
+    ((yo * ay).sum() + (xo * ax).sum()).backward()
+    checked = 0
+    for k, p in net.named_parameters():
+        if w[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = w[k].grad
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(ref.shape), k
+        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
+        checked += 1
+    assert checked >= 80
+    # the static-term columns themselves carry gradient (not a vacuous comparison of zeros)
+    if c.edges_variant:
+        assert float(w["DataAggregation.l1_t1_2.weight"].grad[:, 60:64].abs().max()) > 0
+        assert float(w["DataAggregation.l2_t2_2.weight"].grad[:, 90:94].abs().max()) > 0
+    else:
+        assert float(w["DataAggregation.init_trns.weight"].grad[:, 4:10].abs().max()) > 0
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")
