@@ -3001,18 +3001,25 @@ size_t static_scratch_floats(const genie_ctx* c) { return (size_t)c->G * 16 + (s
 
 // Weight gradients of the static terms of DataAggregationEdges (l?_t?_2.weight_pos) and use_absolute_pos (init_trns.weight_abs) from
 // the gradient rows the three passes left in `gr` (train_front_kernels.hpp, k_gr_sum_* / k_static_dw*).
-int static_term_grads(genie_ctx* c, const float* gr, float* scr, float* grad_blob, hipStream_t st) {
+// `which`: 1 = the layer-2 terms (from do), 2 = the layer-1 terms (dt), 4 = init_trns (dz0 / the association phase's dtrp); `assoc`:
+// the association phase's parameters (its passes overwrite do with dtrp, so its do terms are taken between two passes).
+int static_term_grads(genie_ctx* c, const float* gr, float* scr, float* grad_blob, hipStream_t st, int which = 7, bool assoc = false) {
     struct Term { int blk; bool sta; const float* f; int nf, w, ld, row0, rows, col0; };
     std::vector<Term> terms;
-    if (c->has_edges) {
-        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + b, true, c->mpos_sta, 4, W_DA_L1T12_P, 4, 16 * b, std::min(16, 30 - 16 * b), 0});
-        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + 2 + b, false, c->mpos_src, 4, W_DA_L1T22_P, 4, 16 * b, std::min(16, 30 - 16 * b), 0});
-        terms.push_back({GR_DO + 0, true, c->mpos_sta, 4, W_DA_L2T12_P, 4, 0, 15, 0});
-        terms.push_back({GR_DO + 1, false, c->mpos_src, 4, W_DA_L2T22_P, 4, 0, 15, 0});
+    const int w_l1[2] = {assoc ? W_AS_L1T12_P : W_DA_L1T12_P, assoc ? W_AS_L1T22_P : W_DA_L1T22_P};
+    const int w_l2[2] = {assoc ? W_AS_L2T12_P : W_DA_L2T12_P, assoc ? W_AS_L2T22_P : W_DA_L2T22_P};
+    const int w_abs = assoc ? W_AS_INIT_ABS : W_DA_INIT_ABS, blk_init = assoc ? GR_DTRP : GR_DH0;
+    if (c->has_edges && (which & 2)) {
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + b, true, c->mpos_sta, 4, w_l1[0], 4, 16 * b, std::min(16, 30 - 16 * b), 0});
+        for (int b = 0; b < 2; ++b) terms.push_back({GR_DT + 2 + b, false, c->mpos_src, 4, w_l1[1], 4, 16 * b, std::min(16, 30 - 16 * b), 0});
     }
-    if (c->abs_sta) {
-        for (int b = 0; b < 2; ++b) terms.push_back({GR_DH0 + b, true, c->abs_sta, 3, W_DA_INIT_ABS, 6, 16 * b, std::min(16, 30 - 16 * b), 0});
-        for (int b = 0; b < 2; ++b) terms.push_back({GR_DH0 + b, false, c->abs_src, 3, W_DA_INIT_ABS, 6, 16 * b, std::min(16, 30 - 16 * b), 3});
+    if (c->has_edges && (which & 1)) {
+        terms.push_back({GR_DO + 0, true, c->mpos_sta, 4, w_l2[0], 4, 0, 15, 0});
+        terms.push_back({GR_DO + 1, false, c->mpos_src, 4, w_l2[1], 4, 0, 15, 0});
+    }
+    if (c->abs_sta && (which & 4)) {
+        for (int b = 0; b < 2; ++b) terms.push_back({blk_init + b, true, c->abs_sta, 3, w_abs, 6, 16 * b, std::min(16, 30 - 16 * b), 0});
+        for (int b = 0; b < 2; ++b) terms.push_back({blk_init + b, false, c->abs_src, 3, w_abs, 6, 16 * b, std::min(16, 30 - 16 * b), 3});
     }
     float* r_src = scr; float* r_sta = r_src + (size_t)c->G * 16; float* dpart = r_sta + (size_t)SG_CHUNKS * c->S * 16;
     for (const Term& t : terms) {
@@ -3356,7 +3363,6 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if ((rc = ensure_packed(c, st))) return rc;
     if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
     const bool variant = c->has_edges || c->abs_sta != nullptr;
-    if (variant && save) return fail(GENIE_ERR_STATE, "genie_assoc_train_fwd: default model definition only");
     if (variant && !c->as_ps) HIP_TRY(hipMalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)c->S));
     assoc_pre_launch(c, y_latent, mask_src, st);
     if (save) { c->force_generic = 1; c->train_save = save; }      // training forward: caller's station order, pre-activations kept
@@ -3403,13 +3409,13 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
 // Training step of the P-sized association heads (train_assoc_kernels.hpp).
 size_t genie_assoc_train_save_floats(const genie_ctx* c) { return c ? (size_t)AV_BLOCKS * 16 * (size_t)c->P : 0; }
 size_t genie_assoc_train_scratch_floats(const genie_ctx* c) {
-    return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) + (size_t)c->G * c->T * 32 + 64 : 0;
+    return c ? (size_t)GR_BLOCKS * 16 * (size_t)c->P + train_part_floats(c) + (size_t)c->G * c->T * 32 + 64 + static_scratch_floats(c) : 0;
 }
 
 int genie_assoc_train_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
                           const float* edge_attr, float* out, float* asave, void* assoc_ws, void* ws, void* stream) {
     if (!c || !asave) return fail(GENIE_ERR_ARG, "genie_assoc_train_fwd: null argument");
-    int rc = train_check(c, "genie_assoc_train_fwd");
+    int rc = train_check(c, "genie_assoc_train_fwd", true);
     if (rc) return rc;
     return assoc_fwd_impl(c, y_latent, mask_src, x_latent, mask, edge_attr, out, assoc_ws, ws, stream, asave);
 }
@@ -3420,7 +3426,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     if (!c || !y_latent || !mask_src || !x_latent || !mask || !edge_attr || !asave || !d_s || !scratch || !d_ylat_out || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_assoc_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_assoc_train_bwd"))) return rc;
+    if ((rc = train_check(c, "genie_assoc_train_bwd", true))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if ((rc = ensure_reversed(c))) return rc;
@@ -3437,6 +3443,8 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     a.mask = mask; a.edge_attr = edge_attr; a.save = asave; a.x_latent = x_latent; a.pg = c->as_pg;
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
     a.zsum = a.part + train_part_floats(c);
+    float* sscr = a.zsum + (size_t)c->G * c->T * 32 + 64;
+    const bool variant = c->has_edges || c->abs_sta != nullptr;
     a.sv_t = AV_T; a.sv_up = AV_UV; a.sv_vp = AV_UV + 2;
     const int grid = train_grid(c), n_waves = grid * 4;
     const int tms[4] = {TM_AB3, TM_AB2, TM_AB1, TM_AB0};
@@ -3451,6 +3459,8 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
                                                             c->d_sc[tm], grad_blob, 0);
+        // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end
+        if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
     }
     {
         AgArgs g;

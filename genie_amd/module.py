@@ -138,7 +138,7 @@ class _AssocTrain(torch.autograd.Function):
     def backward(ctx, d_s):
         y_latent, mask_src, x_latent, Mask, edge_attr, asave = ctx.saved_tensors
         d_ylat, g = ctx.hip.assoc_train_bwd(y_latent, mask_src, x_latent, Mask, edge_attr, asave, d_s.contiguous())
-        return (d_ylat, None, None, None, None, None) + tuple(g[n].view(sh) for n, sh in zip(TRAIN_ASSOC_PARAMS, ctx.shapes))
+        return (d_ylat, None, None, None, None, None) + tuple(_join_variant_columns(g, n, sh) for n, sh in zip(TRAIN_ASSOC_PARAMS, ctx.shapes))
 
 
 TRAIN_LSLC_PARAMS = tuple("LocalSliceLgCollapse%s.%s" % (h, n) for h in ("P", "S")
@@ -289,16 +289,18 @@ def _split_edge_columns(named):
 def _join_variant_columns(g, name, shape):
     """Inverse of `_split_edge_columns` / `_split_abs_columns` on a dict of registry-layout gradients: the gradient of state_dict
     entry `name` in the parameter's own `shape` (the static-term columns, kept under `<name>_pos` / `<name>_abs` in the library's
-    weight mirror, go back between the node columns and the Mask columns)."""
+    weight mirror, go back where those functions cut them out)."""
     w = g[name]
     if name.endswith(".weight") and len(shape) == 2 and w.numel() != shape[0] * shape[1]:
         extra = g.get(name + "_pos") if (name + "_pos") in g else g.get(name + "_abs")
         ne = shape[1] - w.numel() // shape[0]
         if extra is None or extra.numel() != shape[0] * ne:
             raise RuntimeError("gradient of %s: registry columns do not add up to the parameter's shape %r" % (name, tuple(shape)))
+        mod, lay = name.split(".")[0], name.split(".")[1]
+        at = {"l1_t1_2": 60, "l1_t2_2": 60, "l2_t1_2": 90, "l2_t2_2": 90,
+              "init_trns": 15 if mod == "DataAggregationAssociationPhase" else 4}[lay]
         w, extra = w.view(shape[0], -1), extra.view(shape[0], ne)
-        n_mask = 4                                                    # both variants keep the 4 Mask columns last
-        return torch.cat((w[:, :w.shape[1] - n_mask], extra, w[:, w.shape[1] - n_mask:]), dim=1)
+        return torch.cat((w[:, :at], extra, w[:, at:]), dim=1)
     return w.view(shape)
 
 
@@ -650,7 +652,7 @@ class GCN_Detection_Network_extended(nn.Module):
     as ONE fused call into libgenie_hip (`genie_path_fwd`) on the graphs cached by `set_adjacencies`, then the
     read-out heads (`genie_readout_grid` / `genie_readout_query`). `use_absolute_pos=True` (config.yaml:92, +6 input
     channels) and `use_updated_model_definition=True` (config.yaml:95) are served for `forward_fixed_source` and for the
-    4-output `forward` / `forward_fixed` in eval mode; training steps: default model definition.
+    4-output `forward` / `forward_fixed`, in eval mode and as training steps (train() mode with gradients enabled).
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
@@ -844,9 +846,6 @@ class GCN_Detection_Network_extended(nn.Module):
             raise RuntimeError("call set_adjacencies(...) first")
         if self._hip._n_prod is not None:
             raise NotImplementedError("training-mode forward: Cartesian product graphs only (not use_subgraph)")
-        variant = self.use_updated_model_definition or self.use_absolute_pos
-        if variant and want_latents:
-            raise NotImplementedError("training-mode 4-output forward: default model definition only")
         hp = self._hip
         hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
@@ -923,7 +922,7 @@ class GCN_Detection_Network_extended(nn.Module):
         in HIP: the shared front and read-outs, the P-sized association heads (genie_assoc_fwd; under use_updated_model_definition
         / use_absolute_pos their static per-station / per-source-node terms are added inside the same kernels), LocalSliceLgCollapse
         P / S (genie_lslc_fwd) and the arrival head (genie_arrivals_fwd). In train() mode with gradients enabled the same modules
-        differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; default model definition)."""
+        differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; all three model definitions, Cartesian product graphs)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed")
         if getattr(self, "A_edges_p", None) is None or getattr(self, "tlatent", None) is None:

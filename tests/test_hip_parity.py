@@ -1160,14 +1160,16 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
         assert max_abs(out[3].cpu(), torch.from_numpy(z["arv_s"])) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull"])
+@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50"])
 def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name):
     """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
     mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones. Every module
     runs in HIP in both directions -- the shared path with the source queries riding along (`_PathTrain`), the P-sized association
     heads (`_AssocTrain`), LocalSliceLgCollapse P / S (`_LslcTrain`) and the arrival head (`_ArrivalsTrain`; assoc_20x60 has a
     station with 266 picks = two softmax chunks, _nonull a case where no source keeps the null pick) -- and no PyTorch restatement
-    may be called."""
+    may be called. The last two cases are the 4-output step of the two other model definitions (`use_updated_model_definition`,
+    `use_absolute_pos`; fixtures from the reference imported with the flag set): their static per-station / per-source-node
+    terms add weight gradients to DataAggregation AND to DataAggregationAssociationPhase (k_gr_sum_*, k_static_dw)."""
     import os
     from tests.util import GOLDEN_DIR
     from oracle import genie_oracle as O
@@ -1175,7 +1177,8 @@ def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name)
     w0 = O.weights_from_npz(z)
     S, G = int(z["n_sta"]), int(z["n_grid"])
     t = lambda k, dt=torch.float32, dev=DEV: torch.from_numpy(np.asarray(z[k])).to(dt).to(dev)
-    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition="edges" in name,
+                                                use_absolute_pos="abspos" in name)
     net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
     net.train()
     A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
@@ -1199,16 +1202,27 @@ def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name)
     sum((o * c_.to(DEV)).sum() for o, c_ in zip(outs, coef)).backward()
     c = lambda k, dt=torch.float32: t(k, dt, "cpu")
     w = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+    okw = {}
+    if "edges" in name:
+        okw["pos_rel"] = (O.edge_pos_features(c("locs"), A_in_sta, A_src_in_sta[0]), O.edge_pos_features(c("x_grid"), A_in_src, A_src_in_sta[1]))
+    if "abspos" in name:
+        okw["abs_pos"] = (c("locs"), A_src_in_sta)
     ref = O.forward_fixed(w, c("Slice"), c("Mask"), A_in_sta, A_in_src, c("edge_attr"), A_src_in_prod, c("A_src_src", torch.long),
                           c("A_edges_p", torch.long), c("A_edges_s", torch.long), c("dt_partition"), c("tlatent"), c("tpick"),
                           c("ipick", torch.long), c("phase_label"), c("x_grid"), c("x_query"), c("x_query_src"), c("t_query"),
-                          c("tq_sample"), c("trv_out_q"), S)
+                          c("tq_sample"), c("trv_out_q"), S, **okw)
     sum((o * c_).sum() for o, c_ in zip(ref, coef)).backward()
+    if "edges" in name:      # the static-term columns carry gradient in both P-sized modules
+        for mod in ("DataAggregation", "DataAggregationAssociationPhase"):
+            assert float(w[mod + ".l1_t1_2.weight"].grad[:, 60:64].abs().max()) > 0 and float(w[mod + ".l2_t2_2.weight"].grad[:, 90:94].abs().max()) > 0
+    if "abspos" in name:
+        assert float(w["DataAggregation.init_trns.weight"].grad[:, 4:10].abs().max()) > 0
+        assert float(w["DataAggregationAssociationPhase.init_trns.weight"].grad[:, 15:21].abs().max()) > 0
     checked = 0
     for k, p in net.named_parameters():
         if w[k].grad is None:
             continue
-        assert p.grad is not None, k
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(w[k].grad.shape), k
         # relative to the gradient's own scale (2e-4: f_arrival_query_2.bias of the _nonull case is a sum of cancelling terms, 1.3e-4)
         tol = 2e-4 * float(w[k].grad.abs().max()) + 1e-12
         assert max_abs(p.grad.cpu(), w[k].grad) <= tol, (k, max_abs(p.grad.cpu(), w[k].grad), tol)
