@@ -881,8 +881,15 @@ __global__ void k_pack_all(const float* __restrict__ raw, const PackPlan* __rest
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+#ifndef GENIE_ABL_MFMA
+#define GENIE_ABL_MFMA GENIE_TUNING      // the run-time MFMA switch costs every fp32 MFMA a branch: -DGENIE_ABL_MFMA=0 for timing other hooks
+#endif
 #if GENIE_TUNING
 __device__ int g_abl_mfma;  // set from the host in tuning builds
+#endif
+#if defined(GENIE_MFMA_OFF)      // timing experiment: every fp32 MFMA replaced by 4 VALU multiply-adds (wrong results)
+#define MFMA16(a, b, c) ((c) + (a) * (b))
+#elif GENIE_ABL_MFMA
 #define MFMA16(a, b, c) (g_abl_mfma ? ((c) + (a) * (b)) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0))
 #else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -1194,6 +1201,7 @@ struct genie_ctx {
     // reversed base graphs (out-edges, weights 1 / in-degree of the target): built on the first genie_nbr_mean_bwd
     int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
     float *r_sta_w, *r_src_w;
+    int2 *r_sta_cw, *r_src_cw;   // the same edges as (column, weight bits) pairs: one 8-byte load per edge (training passes)
     const float *xs_slice, *xs_mask;   // genie_embed_window_split: the (Slice, Mask) buffers whose split rows already sit in the workspace (one-shot)
     const void* xs_ws;
     int xs_mm_copy;            // ... and the copy (slot % GENIE_NBIG at embed time) its message-mask row `mm` was written to
@@ -1928,7 +1936,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr;
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr; c->sta_ident = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
-    c->r_sta_w = c->r_src_w = nullptr;
+    c->r_sta_w = c->r_src_w = nullptr; c->r_sta_cw = c->r_src_cw = nullptr;
     c->pcsr = false; c->pcsr_h2 = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
@@ -2174,7 +2182,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->as_pg, c->as_ps, c->d_h2tbl, c->packed_h2, c->src_tab,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
-                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w,
+                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
                     c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
     for (void* p : ptrs) (void)hipFree(p);
@@ -2895,7 +2903,8 @@ int genie_nbr_mean(genie_ctx* c, const float* x_sta, const float* x_src, float* 
 namespace {
 // out-edge CSR of a graph given as in-edge CSR (rowptr by target i, col = source j): for every j the targets i in increasing
 // order, with weight 1 / in-degree(i)
-int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int n_src, int32_t** r_rowptr, int32_t** r_col, float** r_w) {
+int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int n_src, int32_t** r_rowptr, int32_t** r_col, float** r_w,
+                   int2** r_cw = nullptr) {
     std::vector<int32_t> rp((size_t)n_tgt + 1);
     HIP_TRY(hipMemcpy(rp.data(), d_rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
     const size_t E = (size_t)rp[n_tgt];
@@ -2924,6 +2933,12 @@ int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int
     if (E) {
         HIP_TRY(hipMemcpy(*r_col, rcol.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(*r_w, rw.data(), sizeof(float) * E, hipMemcpyHostToDevice));
+    }
+    if (r_cw) {
+        std::vector<int2> cw(std::max<size_t>(E, 1), int2{0, 0});
+        for (size_t e = 0; e < E; ++e) { cw[e].x = rcol[e]; memcpy(&cw[e].y, &rw[e], 4); }
+        HIP_TRY(hipMalloc((void**)r_cw, sizeof(int2) * cw.size()));
+        HIP_TRY(hipMemcpy(*r_cw, cw.data(), sizeof(int2) * cw.size(), hipMemcpyHostToDevice));
     }
     return GENIE_OK;
 }
@@ -2986,7 +3001,12 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 }
 
 namespace {
-int train_grid(const genie_ctx* c) { return std::max(8, c->num_cu * 2 / 8 * 8); }      // 2 workgroups per CU (1: +10 %, 3: +6 %, 4: +1 % step time)
+int train_grid(const genie_ctx* c) {
+#if GENIE_TUNING
+    { static const char* e = getenv("GENIE_TRAIN_WG"); if (e) return std::max(8, c->num_cu * atoi(e) / 8 * 8); }
+#endif
+    return std::max(8, c->num_cu * 2 / 8 * 8);
+}      // 2 workgroups per CU (1: +10 %, 3: +6 %, 4: +1 % step time)
 size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 12 * 16 + 16); }
 // `variants`: the call also serves DataAggregationEdges / use_absolute_pos (the forward_fixed_source step does; the association heads'
 // training step is the default model definition only)
@@ -3062,10 +3082,15 @@ int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, cons
 
 namespace {
 int ensure_reversed(genie_ctx* c) {
-    if (c->r_sta_rowptr) return GENIE_OK;
+    if (c->r_sta_rowptr && c->r_sta_cw) return GENIE_OK;
     int rc;
-    if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w))) return rc;
-    return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w);
+    if (c->r_sta_rowptr) {      // built by genie_nbr_mean_bwd without the pair arrays: rebuild whole
+        void* old[] = {c->r_sta_rowptr, c->r_sta_col, c->r_sta_w, c->r_src_rowptr, c->r_src_col, c->r_src_w};
+        for (void* q : old) (void)hipFree(q);
+        c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr; c->r_sta_w = c->r_src_w = nullptr;
+    }
+    if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w, &c->r_sta_cw))) return rc;
+    return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w, &c->r_src_cw);
 }
 int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const float* edge_attr, const float* save,
                       const float* d_r, float* scratch, float* grad_blob, void* stream, bool zero_blob);
@@ -3094,10 +3119,14 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     a.P = c->P; a.order = c->order;
     a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
     a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
+    a.r_sta_cw = c->r_sta_cw; a.r_src_cw = c->r_src_cw;
     a.slice = slice; a.mask = mask; a.edge_attr = edge_attr; a.save = save; a.dr = d_r;
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
     a.sv_t = SV_T; a.sv_up = SV_UP; a.sv_vp = SV_VP;
     a.store_dz0 = c->abs_sta != nullptr;
+#if GENIE_TUNING
+    { static const char* e = getenv("GENIE_TRABL"); a.abl = e ? atoi(e) : 0; }
+#endif
     const int grid = train_grid(c), n_waves = grid * 4;
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
@@ -3440,6 +3469,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     a.P = c->P; a.order = c->order;
     a.r_sta_rowptr = c->r_sta_rowptr; a.r_sta_col = c->r_sta_col; a.r_sta_w = c->r_sta_w;
     a.r_src_rowptr = c->r_src_rowptr; a.r_src_col = c->r_src_col; a.r_src_w = c->r_src_w;
+    a.r_sta_cw = c->r_sta_cw; a.r_src_cw = c->r_src_cw;
     a.mask = mask; a.edge_attr = edge_attr; a.save = asave; a.x_latent = x_latent; a.pg = c->as_pg;
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
     a.zsum = a.part + train_part_floats(c);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
 __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
     constexpr int NF4 = (GA1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GA1_GROUPS * 64);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
 __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
     constexpr int NF4 = (GA0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GA0_GROUPS * 64);

@@ -25,6 +25,7 @@ struct TrArgs {
     const int32_t* order;
     const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
     const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
+    const int2* r_sta_cw; const int2* r_src_cw;    // the same edges as (column, weight bits) pairs
     const float* slice; const float* mask; const float* edge_attr;
     const float* save; float* gr;
     const float* dr;             // [G][32] gradient of the per-source-node station sum (Bipartite, before fc2)
@@ -35,6 +36,7 @@ struct TrArgs {
                                  // association phase's AV_T, AV_UV, AV_UV + 2)
     const float* pg;             // association phase (k_train_b1<true>, k_as_*): [G][AS_PG] per-source-node terms, pg[31] = mask1[g]
     const float* x_latent;       // association phase: [P, 30] DataAggregation output (an input of init_trns there)
+    int abl;                     // GENIE_TUNING builds: ablation bits of k_train_b1 (tools/train_abl.sh)
     int store_dz0;               // k_train_b0: keep dz0 in the GR_DH0 blocks (read by the static-term gradients of use_absolute_pos)
     float* zsum;                 // k_as_b0: [G * T][32] per-tile station sums of d z1 (-> d y_latent, fc1's y_latent columns)
 };
@@ -51,16 +53,21 @@ __device__ __forceinline__ f32x4 dprelu4(f32x4 x, float s) {     // PReLU'(x): 1
 __device__ __forceinline__ float negsum4(f32x4 g, f32x4 x) {    // sum of g * min(x, 0): the slope gradient of PReLU
     return g.x * fminf(x.x, 0.f) + g.y * fminf(x.y, 0.f) + g.z * fminf(x.z, 0.f) + g.w * fminf(x.w, 0.f);
 }
-// V[ch 4q + r][node j] held by lane (j, q) -> vt[s] = V[ch j][node 4s + q]: the operand form of a node-contracting MFMA
+// V[ch 4q + r][node j] held by lane (j, q) -> vt[s] = V[ch j][node 4s + q]: the operand form of a node-contracting MFMA.
+// Through a per-wave LDS scratch of 256 floats, [node][16 channels]: one 16-byte write per lane (the 64 lanes cover the scratch
+// contiguously), four 4-byte reads (row 4s + q, column j: the four q groups hit disjoint banks). The LDS executes the DS instructions of ONE
+// wave in issue order, so neither the write -> read dependence between lanes nor the reuse of the scratch by the next transposition
+// needs a counter drain (three `s_waitcnt lgkmcnt(0)` per transposition until round 4: seventeen transpositions per tile in
+// k_train_b1 were ~17 % of its time); the two compiler barriers only keep the compiler from moving the accesses across each other,
+// and the reads are waited for where their values are first used.
 __device__ __forceinline__ f32x4 tr16(f32x4 v, float* sc, int j, int q) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sc[(4 * q + r) * 17 + j] = v[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    *(f32x4*)(sc + j * 16 + 4 * q) = v;
+    asm volatile("" ::: "memory");
     f32x4 t;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) t[s] = sc[j * 17 + 4 * s + q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int s = 0; s < 4; ++s) t[s] = sc[(4 * s + q) * 16 + j];
+    asm volatile("" ::: "memory");
     return t;
 }
 __device__ __forceinline__ f32x4 outer16(f32x4 acc, f32x4 at, f32x4 bt) {       // acc[out][in] += sum over the tile's nodes
@@ -107,6 +114,48 @@ __device__ __forceinline__ f32x4 tmean(const int32_t* rp, const int32_t* col, co
     tmean_n<1, 8>(rp, col, w, node, uniform, [&](int, int c) { return rowof(c); }, o);
     return o[0];
 }
+// ---- the gathers of a tile, software-pipelined (round 4). With the means taken edge batch by edge batch inside the tile (tmean_n),
+// a tile paid the row pointers, then the columns / weights, then the rows, once per batch and side: ~8 dependent memory round trips
+// that nothing overlapped (per-phase clocks: 38 % of k_train_b1; more resident waves did not help). Now the (column, weight) pairs
+// of a tile's first edges are loaded while the PREVIOUS tile computes (NbrIdx, one 8-byte load per edge), so at the top of a tile
+// all its rows are requested at once: one round trip. Out-edges past the prefetched ones (a station / source node that many others
+// list as a neighbour) go through the batch loop as before. The sums keep the edge order.
+template <int EB> struct NbrIdx { int c[EB]; float w[EB]; int e_next, e_end; };
+template <int EB>
+__device__ __forceinline__ void nbr_idx_load(const int2* __restrict__ cw, int eb, int ee, NbrIdx<EB>& o) {
+#pragma unroll
+    for (int k = 0; k < EB; ++k) {
+        const bool ok = eb + k < ee;
+        const int2 v = cw[ok ? eb + k : 0];
+        o.c[k] = v.x;
+        o.w[k] = ok ? __int_as_float(v.y) : 0.f;
+    }
+    o.e_next = eb + EB; o.e_end = ee;
+}
+// the edges [e, ee) of a node beyond the prefetched ones, EB at a time (as tmean_n)
+template <int NB, int EB, typename F>
+__device__ __forceinline__ void tmean_rest(const int2* __restrict__ cw, int e, int ee, bool uniform, F rowof, f32x4 (&out)[NB]) {
+    for (; uniform ? (e < ee) : (bool)__any(e < ee); e += EB) {
+        int c[EB];
+        float ww[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const bool ok = e + k < ee;
+            const int2 v = cw[ok ? e + k : 0];
+            c[k] = v.x;
+            ww[k] = ok ? __int_as_float(v.y) : 0.f;
+        }
+        f32x4 r[NB][EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, c[k]);
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * ww[k];
+    }
+}
 __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
                                                const float* scal, int n_scal, int lane, int j, int q) {
     float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
@@ -133,7 +182,7 @@ __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f
 __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
     constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GT2_GROUPS * 64);
@@ -203,11 +252,20 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
 // vec: b(l2_t1_2), b(l2_t2_2), b(l2_t1_1) x2, b(l2_t2_1) x2 = 6; scal: a1, a21, a22
 // AS: the same pass for DataAggregationAssociationPhase (module.py:397-401; 95-wide l2_t?_2 with mask width 5): the column of mask1
 // (one value per source node) gets its gradient as two extra vectors.
+#if GENIE_TUNING
+#define TPH_DECL long long tph[6] = {0, 0, 0, 0, 0, 0}; long long tph_t0 = 0
+#define TPH_START() do { if (a.abl & 16) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tph_t0 = __builtin_amdgcn_s_memtime(); } } while (0)
+#define TPH_MARK(k) do { if (a.abl & 16) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tph_t0; tph_t0 = t_; } } while (0)
+#else
+#define TPH_DECL
+#define TPH_START()
+#define TPH_MARK(k)
+#endif
 template <bool AS>
 __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
@@ -227,35 +285,107 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     for (int k = 0; k < NV; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
+    TPH_DECL;
+    constexpr int EBS = 8, EBG = 16;            // prefetched out-edges per station (per lane) / per source node (uniform)
+    struct Tile { int g, scn; bool valid; };
+    struct Rp { int s0, s1, g0, g1; };
+    struct Own { f32x4 mb, do1, do2, t[4], up[2], vp[2]; };       // the node's own rows: Mask, do, the kept pre-activations
+    const float* gr = a.gr;
+    auto tile_of = [&](long long it) {
         int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        asm volatile("" : "+v"(lane));
+        w.decode(it < w.nitems ? it : w.it, gi, tb);               // past the end: the current tile again (loads nobody uses)
+        Tile t;
+        t.g = __builtin_amdgcn_readfirstlane(a.order[gi]);
         const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
+        t.valid = s < S;
+        t.scn = t.valid ? s : S - 1;
+        return t;
+    };
+    auto rp_of = [&](const Tile& t) {
+        return Rp{a.r_sta_rowptr[t.scn], a.r_sta_rowptr[t.scn + 1], __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g]),
+                  __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g + 1])};
+    };
+    auto own_load = [&](const Tile& t, Own& o) {
+        const long long p_ = (long long)t.g * S + t.scn;
+        o.mb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) o.mb = *(const f32x4*)(a.mask + p_ * 4);
+        o.do1 = ldb(a.gr, GR_DO + 0, P, p_, q); o.do2 = ldb(a.gr, GR_DO + 1, P, p_, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.t[k] = ldb(a.save, SVT + k, P, p_, q);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { o.up[b] = ldb(a.save, SVU + b, P, p_, q); o.vp[b] = ldb(a.save, SVV + b, P, p_, q); }
+    };
+    auto rows_issue = [&](const Tile& t, const NbrIdx<EBS>& xs, const NbrIdx<EBG>& xg, f32x4 (&rs)[EBS], f32x4 (&rg)[EBG]) {
+#pragma unroll
+        for (int k = 0; k < EBS; ++k) rs[k] = ldb(gr, GR_DO + 0, P, (long long)t.g * S + xs.c[k], q);
+#pragma unroll
+        for (int k = 0; k < EBG; ++k) rg[k] = ldb(gr, GR_DO + 1, P, (long long)xg.c[k] * S + t.scn, q);
+    };
+    auto rows_sum = [&](const Tile& t, const NbrIdx<EBS>& xs, const NbrIdx<EBG>& xg, const f32x4 (&rs)[EBS], const f32x4 (&rg)[EBG], f32x4& tm1,
+                        f32x4& tm2) {
+        f32x4 tms[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, tmg[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < EBS; ++k) tms[0] += rs[k] * xs.w[k];
+#pragma unroll
+        for (int k = 0; k < EBG; ++k) tmg[0] += rg[k] * xg.w[k];
+        const int g_ = t.g, scn_ = t.scn;
+        tmean_rest<1, 8>(a.r_sta_cw, xs.e_next, xs.e_end, false, [&](int, int c) { return ldb(gr, GR_DO + 0, P, (long long)g_ * S + c, q); }, tms);
+        tmean_rest<1, 8>(a.r_src_cw, xg.e_next, xg.e_end, true, [&](int, int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn_, q); }, tmg);
+        const float vm_ = t.valid ? 1.f : 0.f;
+        tm1 = tms[0] * vm_; tm2 = tmg[0] * vm_;
+    };
+    // Software pipeline over the tiles of a wave (one wave per SIMD: the 30 accumulator tiles leave no room for a second one, so
+    // nothing else hides a round trip to memory): while tile i computes, the row pointers of tile i + 2, the edge pairs and the own
+    // rows of tile i + 1 and -- from the middle of the tile -- the gathered rows of tile i + 1 are in flight; its transposed
+    // means are summed at the end of tile i.
+    Tile cur = {0, 0, false}, nxt = cur;
+    Rp rp_n = {0, 0, 0, 0};
+    Own own;
+    f32x4 tm1 = {0.f, 0.f, 0.f, 0.f}, tm2 = tm1;
+    if (w.it < w.nitems) {
+        cur = tile_of(w.it);
+        const Rp rp = rp_of(cur);
+        NbrIdx<EBS> xs;
+        NbrIdx<EBG> xg;
+        nbr_idx_load<EBS>(a.r_sta_cw, rp.s0, rp.s1, xs);
+        nbr_idx_load<EBG>(a.r_src_cw, rp.g0, rp.g1, xg);
+        own_load(cur, own);
+        f32x4 rs[EBS], rg[EBG];
+        rows_issue(cur, xs, xg, rs, rg);
+        rows_sum(cur, xs, xg, rs, rg, tm1, tm2);
+        nxt = tile_of(w.it + w.stride);
+        rp_n = rp_of(nxt);
+    }
+    for (; w.it < w.nitems; w.it += w.stride) {
+        TPH_START();
+        asm volatile("" : "+v"(lane));
+        const int g = cur.g, scn = cur.scn;
+        const bool valid = cur.valid;
         const long long p = (long long)g * S + scn;
         const float vm = valid ? 1.f : 0.f;
-        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
-        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
-        const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
+        const Tile nn = tile_of(w.it + 2 * w.stride);
+        const Rp rp_nn = rp_of(nn);
+        NbrIdx<EBS> xs_n;
+        NbrIdx<EBG> xg_n;
+        nbr_idx_load<EBS>(a.r_sta_cw, rp_n.s0, rp_n.s1, xs_n);
+        nbr_idx_load<EBG>(a.r_src_cw, rp_n.g0, rp_n.g1, xg_n);
+        Own own_n;
+        own_load(nxt, own_n);
+        const f32x4 mb = own.mb;
+        const f32x4 do1 = own.do1 * vm, do2 = own.do2 * vm;
+        TPH_MARK(0);
         if (AS) {
             const float m1 = a.pg[(long long)g * AS_PG + 31];
             vec[6] += do1 * m1; vec[7] += do2 * m1;
         }
-        const float* gr = a.gr;
-        const f32x4 tm1 = tmean(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                                [&](int c) { return ldb(gr, GR_DO + 0, P, (long long)g * S + c, q); }) * vm;
-        const f32x4 tm2 = tmean(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                                [&](int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn, q); }) * vm;
+        TPH_MARK(1);
         f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SVT + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
+        for (int k = 0; k < 4; ++k) { t[k] = own.t[k]; h1[k] = prelu4u(t[k], a1); }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            up[b] = ldb(a.save, SVU + b, P, p, q); u[b] = prelu4u(up[b], a21);
-            vp[b] = ldb(a.save, SVV + b, P, p, q); v[b] = prelu4u(vp[b], a22);
+            up[b] = own.up[b]; u[b] = prelu4u(up[b], a21);
+            vp[b] = own.vp[b]; v[b] = prelu4u(vp[b], a22);
         }
         // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
         f32x4 du[2], dv[2];
@@ -268,6 +398,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
             du[b] = gu * dprelu4(up[b], a21);
             dv[b] = gv * dprelu4(vp[b], a22);
         }
+        TPH_MARK(2);
         // dh1 and dt
         f32x4 dt[4];
 #pragma unroll
@@ -281,6 +412,9 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
             d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
             scal[0] += negsum4(d, t[hb]);
             dt[hb] = d * dprelu4(t[hb], a1);
+#if GENIE_TUNING
+            if (a.abl & 8) { if (dt[hb].x == 1.2345f) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]); continue; }
+#endif
             if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
         }
 #pragma unroll
@@ -292,6 +426,10 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
         }
         vec[0] += do1; vec[1] += do2;
         vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
+        TPH_MARK(3);
+        // the next tile's gathered rows: in flight under the weight gradients
+        f32x4 rs[EBS], rg[EBG];
+        rows_issue(nxt, xs_n, xg_n, rs, rg);
         // weight gradients
         f32x4 h1t[4];
 #pragma unroll
@@ -319,7 +457,15 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
                 acc[22 + b * 4 + k] = outer16(acc[22 + b * 4 + k], dvt, h1t[k]);
             }
         }
+        TPH_MARK(4);
+        rows_sum(nxt, xs_n, xg_n, rs, rg, tm1, tm2);
+        cur = nxt; nxt = nn; rp_n = rp_nn; own = own_n;
     }
+#if GENIE_TUNING
+    if ((a.abl & 16) && (threadIdx.x & 63) == 0 && wave == 1 && (blockIdx.x == 3 || blockIdx.x == 200))
+        printf("b1 blk %d: own loads %lld, gathers %lld, save loads + du/dv %lld, dh1/dt/dh0 + stores %lld, weight grads %lld\n", blockIdx.x,
+               tph[0], tph[1], tph[2], tph[3], tph[4]);
+#endif
     write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
 }
 
@@ -329,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
 __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
     constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ float tsc[4][16 * 17];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
     for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GT0_GROUPS * 64);
