@@ -3127,14 +3127,16 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
 #if GENIE_TUNING
     { static const char* e = getenv("GENIE_TRABL"); a.abl = e ? atoi(e) : 0; }
 #endif
-    const int grid = train_grid(c), n_waves = grid * 4;
+    const int grid = train_grid(c);
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
+        // k_train_b1 holds one wave per SIMD (442 registers): one workgroup per CU is all that is ever resident
+        const int grid_s = s == 1 ? std::max(8, grid / 2 / 8 * 8) : grid;
         if (s == 0) k_train_b2<<<grid, 256, 0, st>>>(a);
-        else if (s == 1) k_train_b1<false><<<grid, 256, 0, st>>>(a);
+        else if (s == 1) k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
         else k_train_b0<<<grid, 256, 0, st>>>(a);
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob, 0);
     }
     if (c->has_edges || c->abs_sta) {
@@ -3476,18 +3478,19 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     float* sscr = a.zsum + (size_t)c->G * c->T * 32 + 64;
     const bool variant = c->has_edges || c->abs_sta != nullptr;
     a.sv_t = AV_T; a.sv_up = AV_UV; a.sv_vp = AV_UV + 2;
-    const int grid = train_grid(c), n_waves = grid * 4;
+    const int grid = train_grid(c);
     const int tms[4] = {TM_AB3, TM_AB2, TM_AB1, TM_AB0};
     const int pls[4] = {-1, PL_TAB2, PL_TAB1, PL_TAB0};
     for (int s = 0; s < 4; ++s) {
         const int tm = tms[s];
         a.packed = pls[s] >= 0 ? c->packed[pls[s]] : nullptr; a.n_acc = c->n_acc[tm]; a.n_vec = c->n_vec[tm];
+        const int grid_s = s == 1 ? std::max(8, grid / 2 / 8 * 8) : grid;      // k_train_b1: one workgroup per CU (see da_train_bwd_impl)
         if (s == 0) k_as_b3<<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
-        else if (s == 1) k_train_b1<true><<<grid, 256, 0, st>>>(a);
+        else if (s == 1) k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
         else if (s == 2) k_as_b1<<<grid, 256, 0, st>>>(a);
         else k_as_b0<<<grid, 256, 0, st>>>(a);
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, n_waves, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
                                                             c->d_sc[tm], grad_blob, 0);
         // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end
         if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
