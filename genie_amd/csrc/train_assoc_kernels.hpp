@@ -110,14 +110,16 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
             qp[0][b] = ldb(a.save, AV_Q + b, P, p, q);
             qp[1][b] = ldb(a.save, AV_Q + 2 + b, P, p, q);
         }
-        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);       // (own rows requested before the gathers)
+        tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                           [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+        tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                            [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
 #pragma unroll
         for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
+        for (int k = 0; k < 4; ++k) dt[k] *= vm;
         // d q = l1_t?_2[:, 30:60]^T (transposed mean of dt), through PReLU11' / PReLU12' -> d(l1_t?_1 output)
         f32x4 dqp[2][2];
 #pragma unroll

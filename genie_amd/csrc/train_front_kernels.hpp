@@ -156,6 +156,34 @@ __device__ __forceinline__ void tmean_rest(const int2* __restrict__ cw, int e, i
             for (int b = 0; b < NB; ++b) out[b] += r[b][k] * ww[k];
     }
 }
+// transposed mean with every (column, weight) pair of the node's first EBI out-edges requested at once, then their rows EB edges at a
+// time (no index load between the row batches: the next batch's rows are in flight while this one is summed), then the rest of a
+// long edge list. Edge order kept.
+template <int NB, int EBI, int EB, typename F>
+__device__ __forceinline__ void tmean_pre(const int32_t* __restrict__ rp, const int2* __restrict__ cw, int node, bool uniform, F rowof,
+                                          f32x4 (&out)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int eb = rp[node], ee = rp[node + 1];
+    if (uniform) { eb = __builtin_amdgcn_readfirstlane(eb); ee = __builtin_amdgcn_readfirstlane(ee); }
+    NbrIdx<EBI> x;
+    nbr_idx_load<EBI>(cw, eb, ee, x);
+    static_assert(EBI % EB == 0, "whole batches");
+#pragma unroll
+    for (int k0 = 0; k0 < EBI; k0 += EB) {
+        if (k0 > 0 && (uniform ? !(eb + k0 < ee) : !(bool)__any(eb + k0 < ee))) break;
+        f32x4 r[NB][EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, x.c[k0 + k]);
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * x.w[k0 + k];
+    }
+    tmean_rest<NB, EB>(cw, x.e_next, x.e_end, uniform, rowof, out);
+}
 __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
                                                const float* scal, int n_scal, int lane, int j, int q) {
     float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
@@ -509,18 +537,17 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
         const float* gr = a.gr;
         f32x4 z0[2], h0[2], dt[4], tmd1[2], tmd2[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
-            h0[b] = prelu4u(z0[b], a0);
-        }
-        tmean_n<2>(a.r_sta_rowptr, a.r_sta_col, a.r_sta_w, scn, false,
-                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-        tmean_n<2>(a.r_src_rowptr, a.r_src_col, a.r_src_w, g, true,
-                   [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+        for (int b = 0; b < 2; ++b) z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
+        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);      // (own rows requested before the gathers, not after)
+        tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                           [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+        tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                            [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q) * vm;
+        for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; h0[b] = prelu4u(z0[b], a0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dt[k] *= vm;
         f32x4 dz0[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
