@@ -1372,6 +1372,16 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         ra.abs_src = c->abs_src; ra.n_abs_src = c->abs_src ? (long long)c->G_ext * 4 : 0;
         ra.eb_sta = c->has_edges ? c->ebias_sta : nullptr; ra.n_eb_sta = c->has_edges ? (long long)c->S * 48 : 0;
         ra.eb_src = c->has_edges ? c->ebias_src : nullptr; ra.n_eb_src = c->has_edges ? (long long)c->G * 48 : 0;
+        {   // long tables: partial maxima by many workgroups first (d_range[4 ..] holds 4 x RG_PART of them)
+            const float** tp[4] = {&ra.abs_sta, &ra.abs_src, &ra.eb_sta, &ra.eb_src};
+            long long* tn[4] = {&ra.n_abs_sta, &ra.n_abs_src, &ra.n_eb_sta, &ra.n_eb_src};
+            for (int k = 0; k < 4; ++k)
+                if (*tp[k] && *tn[k] > 4096) {
+                    float* part = c->d_range + 4 + k * RG_PART;
+                    k_tab_absmax<<<RG_PART, 256, 0, st>>>(*tp[k], *tn[k], part);
+                    *tp[k] = part; *tn[k] = RG_PART;
+                }
+        }
         ra.out = c->d_range;
         k_h2_range<<<1, 256, 0, st>>>(ra);
         HIP_TRY(hipGetLastError());
@@ -1925,7 +1935,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipMalloc((void**)&c->d_s2htbl, sizeof(int32_t) * tbl.size()));
         HIP_TRY(hipMemcpy(c->d_s2htbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&c->packed_s2h, sizeof(float) * S2H_IMG_FLOATS));
-        HIP_TRY(hipMalloc((void**)&c->d_range, sizeof(float) * 4));
+        HIP_TRY(hipMalloc((void**)&c->d_range, sizeof(float) * (4 + 4 * RG_PART)));
         HIP_TRY(hipHostMalloc((void**)&c->h_range, sizeof(float) * 4));
         c->range_ok = true; c->prec_mode = 0;
     }
@@ -3017,7 +3027,7 @@ int train_check(const genie_ctx* c, const char* who, bool variants = false) {
     return GENIE_OK;
 }
 // scratch of static_term_grads: per-source-node sums [G][16], per-station partial sums [SG_CHUNKS][S][16], slices of one dW block
-size_t static_scratch_floats(const genie_ctx* c) { return (size_t)c->G * 16 + (size_t)SG_CHUNKS * c->S * 16 + (size_t)SG_SLICES * 64; }
+size_t static_scratch_floats(const genie_ctx* c) { return (size_t)c->G * 16 + (size_t)(SG_CHUNKS + 1) * c->S * 16 + (size_t)SG_SLICES * 64; }
 
 // Weight gradients of the static terms of DataAggregationEdges (l?_t?_2.weight_pos) and use_absolute_pos (init_trns.weight_abs) from
 // the gradient rows the three passes left in `gr` (train_front_kernels.hpp, k_gr_sum_* / k_static_dw*).
@@ -3041,15 +3051,17 @@ int static_term_grads(genie_ctx* c, const float* gr, float* scr, float* grad_blo
         for (int b = 0; b < 2; ++b) terms.push_back({blk_init + b, true, c->abs_sta, 3, w_abs, 6, 16 * b, std::min(16, 30 - 16 * b), 0});
         for (int b = 0; b < 2; ++b) terms.push_back({blk_init + b, false, c->abs_src, 3, w_abs, 6, 16 * b, std::min(16, 30 - 16 * b), 3});
     }
-    float* r_src = scr; float* r_sta = r_src + (size_t)c->G * 16; float* dpart = r_sta + (size_t)SG_CHUNKS * c->S * 16;
+    float* r_src = scr; float* p_sta = r_src + (size_t)c->G * 16; float* r_sta = p_sta + (size_t)SG_CHUNKS * c->S * 16;
+    float* dpart = r_sta + (size_t)c->S * 16;
     for (const Term& t : terms) {
         const float* blk = gr + (size_t)t.blk * 16 * (size_t)c->P;
         if (t.sta) {
-            k_gr_sum_sta<<<dim3((c->S * 4 + 255) / 256, SG_CHUNKS), 256, 0, st>>>(blk, c->S, c->G, r_sta);
-            k_static_dw<<<SG_SLICES, 64, 0, st>>>(r_sta, SG_CHUNKS, (long long)c->S * 16, t.f, c->S, dpart);
+            k_gr_sum_sta<<<dim3((c->S * 4 + 255) / 256, SG_CHUNKS), 256, 0, st>>>(blk, c->S, c->G, p_sta);
+            k_gr_sum_parts<<<(c->S * 16 + 63) / 64, 64, 0, st>>>(p_sta, SG_CHUNKS, c->S * 16, r_sta);
+            k_static_dw<<<SG_SLICES, 256, 0, st>>>(r_sta, t.f, c->S, dpart);
         } else {
             k_gr_sum_src<<<(c->G + 3) / 4, 256, 0, st>>>(blk, c->S, c->G, r_src);
-            k_static_dw<<<SG_SLICES, 64, 0, st>>>(r_src, 1, 0, t.f, c->G, dpart);
+            k_static_dw<<<SG_SLICES, 256, 0, st>>>(r_src, t.f, c->G, dpart);
         }
         k_static_dw_sum<<<1, 64, 0, st>>>(dpart, t.rows, t.nf, grad_blob + g_params[t.w].off, t.ld, t.row0, t.col0);
     }

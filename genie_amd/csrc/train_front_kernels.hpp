@@ -641,8 +641,8 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
 // module.py:56-57). Such a term is W_f f[n] with f a fixed table over the nodes n of ONE base graph, so its weight gradient is
 //   dW_f[out][e] = sum_p dY[p][out] f[n(p)][e] = sum_n (sum over the product nodes p of n of dY[p][out]) f[n][e]:
 // the gradient rows the passes keep in `gr` (do, dt; dz0 when TrArgs.store_dz0) are summed per station / per source node
-// (k_gr_sum_sta / k_gr_sum_src, fixed order), then contracted with the table (k_static_dw, k_static_dw_sum: fixed order too).
-constexpr int SG_CHUNKS = 64, SG_SLICES = 64;
+// (k_gr_sum_sta + k_gr_sum_parts / k_gr_sum_src, fixed order), then contracted with the table (k_static_dw, k_static_dw_sum: fixed order too).
+constexpr int SG_CHUNKS = 256, SG_SLICES = 64;
 __global__ __launch_bounds__(256) void k_gr_sum_src(const float* __restrict__ blk, int S, int G, float* __restrict__ out) {   // out[g][16]
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -653,27 +653,46 @@ __global__ __launch_bounds__(256) void k_gr_sum_src(const float* __restrict__ bl
     for (int d = 1; d < 16; d <<= 1) { s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d); s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d); }
     if (j == 0) *(f32x4*)(out + (size_t)g * 16 + 4 * q) = s;
 }
-__global__ __launch_bounds__(256) void k_gr_sum_sta(const float* __restrict__ blk, int S, int G, float* __restrict__ part) {   // part[chunk][s][16]
+// per-station sums, two steps: chunk c of the source nodes -> part[c][s][16] (four independent running sums per thread, combined in
+// a fixed order), then the chunks in order -> out[s][16]
+__global__ __launch_bounds__(256) void k_gr_sum_sta(const float* __restrict__ blk, int S, int G, float* __restrict__ part) {
     const int idx = blockIdx.x * 256 + threadIdx.x;          // (s, q)
     if (idx >= S * 4) return;
     const int ch = blockIdx.y;
     const int g0 = (int)((long long)G * ch / SG_CHUNKS), g1 = (int)((long long)G * (ch + 1) / SG_CHUNKS);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int g = g0; g < g1; ++g) s += *(const f32x4*)(blk + (size_t)g * S * 16 + (size_t)idx * 4);
-    *(f32x4*)(part + ((size_t)ch * S * 4 + idx) * 4) = s;
+    const float* b = blk + (size_t)idx * 4;
+    const size_t gs = (size_t)S * 16;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+        s0 += *(const f32x4*)(b + (size_t)g * gs); s1 += *(const f32x4*)(b + (size_t)(g + 1) * gs);
+        s2 += *(const f32x4*)(b + (size_t)(g + 2) * gs); s3 += *(const f32x4*)(b + (size_t)(g + 3) * gs);
+    }
+    for (; g < g1; ++g) s0 += *(const f32x4*)(b + (size_t)g * gs);
+    *(f32x4*)(part + ((size_t)ch * S * 4 + idx) * 4) = (s0 + s1) + (s2 + s3);
 }
-// R[n][16] (the sum of `nparts` copies `pstride` floats apart) contracted with f[n][4]: slice x of the nodes -> part[x][16 out][4 e]
-__global__ __launch_bounds__(64) void k_static_dw(const float* __restrict__ R, int nparts, long long pstride, const float* __restrict__ f, int n,
-                                                   float* __restrict__ part) {
-    const int o = threadIdx.x & 15, e = threadIdx.x >> 4, x = blockIdx.x;
+__global__ __launch_bounds__(64) void k_gr_sum_parts(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // eight loads in flight per thread, combined in a fixed order
+    int k = 0;
+    for (; k + 7 < nparts; k += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(k + u) * n + idx];
+    for (; k < nparts; ++k) s[0] += part[(size_t)k * n + idx];
+    out[idx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+// R[n][16] contracted with f[n][4]: slice x of the nodes -> part[x][16 out][4 e]; the slice's nodes are taken by four groups of
+// 64 threads (node i of the slice by group i % 4) whose sums are added in group order
+__global__ __launch_bounds__(256) void k_static_dw(const float* __restrict__ R, const float* __restrict__ f, int n, float* __restrict__ part) {
+    __shared__ float ps[4][64];
+    const int t = threadIdx.x & 63, sub = threadIdx.x >> 6, o = t & 15, e = t >> 4, x = blockIdx.x;
     const int n0 = (int)((long long)n * x / SG_SLICES), n1 = (int)((long long)n * (x + 1) / SG_SLICES);
     float s = 0.f;
-    for (int i = n0; i < n1; ++i) {
-        float r = 0.f;
-        for (int k = 0; k < nparts; ++k) r += R[(size_t)k * pstride + (size_t)i * 16 + o];
-        s += r * f[(size_t)i * 4 + e];
-    }
-    part[x * 64 + threadIdx.x] = s;
+    for (int i = n0 + sub; i < n1; i += 4) s += R[(size_t)i * 16 + o] * f[(size_t)i * 4 + e];
+    ps[sub][t] = s;
+    __syncthreads();
+    if (sub == 0) part[x * 64 + t] = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
 }
 __global__ __launch_bounds__(64) void k_static_dw_sum(const float* __restrict__ part, int rows, int nf, float* __restrict__ dW, int ld, int row0,
                                                        int col0) {
