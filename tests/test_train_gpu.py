@@ -228,6 +228,61 @@ def test_training_gradients_match_oracle_with_rough_cotangents_odd_sizes(stage1,
     print("gradients vs oracle, rough cotangents 33x257: worst relative error %.2e" % worst)
 
 
+@pytest.mark.parametrize("variant", ["edges", "abspos"])
+def test_static_term_gradients_of_the_other_model_definitions_odd_sizes(variant, monkeypatch):
+    """Training step of `use_updated_model_definition` / `use_absolute_pos` at 33 stations x 257 source nodes (partial tiles, source
+    nodes not a multiple of the reduction chunks, stations not a multiple of the slices): the static-term weight columns -- per-station
+    / per-source-node sums of gradient rows contracted with the feature tables (k_gr_sum_sta + k_gr_sum_parts, k_gr_sum_src,
+    k_static_dw) -- and every other gradient of the path against the oracle's autograd (literal edge-list formulation), fp32 stage
+    kernels, 1e-4 of each gradient's own scale. Weights: the reference-generated fixture of the variant."""
+    from oracle import genie_oracle as O
+    monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
+    S, G, Q = 33, 257, 60
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=Q, seed=7)
+    win = synthetic.make_window(geom, 600, seed=8)
+    w0 = Case("edges_12x60" if variant == "edges" else "abspos_12x60").weights
+    rng = np.random.default_rng(9)
+    cy, cx = torch.from_numpy(rng.normal(0, 1, (G, 9)).astype(np.float32)), torch.from_numpy(rng.normal(0, 1, (Q, 9)).astype(np.float32))
+    kw = dict(use_updated_model_definition=True) if variant == "edges" else dict(use_absolute_pos=True)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, **kw)
+    net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
+    net.train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), t(geom.edge_attr()), t(geom.locs),
+                             t(geom.x_grid))
+    y, x = net.forward_fixed_source(t(win["Slice"]), t(win["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query),
+                                    t(geom.t_query))
+    ((y[:, :, 0] * cy.to(DEV)).sum() + (x[:, :, 0] * cx.to(DEV)).sum()).backward()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    w = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+    Slice, okw = c(win["Slice"]), {}
+    if variant == "abspos":
+        Slice = O.absolute_pos_inputs(Slice, c(geom.locs), c(geom.x_grid), A_src_in_sta)
+    else:
+        okw["pos_rel"] = (O.edge_pos_features(c(geom.locs), A_in_sta, A_src_in_sta[0]), O.edge_pos_features(c(geom.x_grid), A_in_src, A_src_in_sta[1]))
+    yo, xo = O.forward_fixed_source(w, Slice, c(win["Mask"]), A_in_sta, A_in_src, c(geom.edge_attr()), A_src_in_prod,
+                                    torch.from_numpy(geom.A_src_src), c(geom.x_grid), c(geom.x_query), c(geom.t_query), **okw)
+    assert max_abs(y.detach().cpu(), yo.detach()) <= 1e-5 and max_abs(x.detach().cpu(), xo.detach()) <= 1e-5
+    ((yo[:, :, 0] * cy).sum() + (xo[:, :, 0] * cx).sum()).backward()
+    worst = 0.0
+    for k in module.TRAIN_PATH_PARAMS:
+        sc = float(w[k].grad.abs().max())
+        g = net.get_parameter(k).grad
+        assert tuple(g.shape) == tuple(w[k].grad.shape), k
+        err = max_abs(g.cpu(), w[k].grad)
+        worst = max(worst, err / sc)
+        assert err <= 1e-4 * sc, (k, err, sc)
+    cols = (("DataAggregation.l1_t1_2.weight", slice(60, 64)), ("DataAggregation.l1_t2_2.weight", slice(60, 64)),
+            ("DataAggregation.l2_t1_2.weight", slice(90, 94)), ("DataAggregation.l2_t2_2.weight", slice(90, 94))) if variant == "edges" else \
+           (("DataAggregation.init_trns.weight", slice(4, 7)), ("DataAggregation.init_trns.weight", slice(7, 10)))
+    for k, sl in cols:           # the static-term columns themselves: non-zero and right to 1e-4 of THEIR scale
+        ref = w[k].grad[:, sl]
+        assert float(ref.abs().max()) > 0
+        assert max_abs(net.get_parameter(k).grad[:, sl].cpu(), ref) <= 1e-4 * float(ref.abs().max()), k
+    print("%s 33x257: worst relative gradient error %.2e" % (variant, worst))
+
+
 def _config3_net_and_inputs(G, nq, n_picks, n_src=4):
     S = 200
     geom = synthetic.Geometry(S, G, L=300e3, n_query=nq, seed=1)
