@@ -1280,6 +1280,12 @@ bool sta_order_on(const genie_ctx* c) {
 // that feeds it writes c / wv node-planar (DaArgs.np). Both launch sites ask this.
 // the G-sized tail of inference calls runs its Linears as fp64 MFMA chains (WIDE kernels) unless told otherwise
 bool tail_wide(const genie_ctx* c) { return !c->tail_f32 && !c->tail_train; }
+// training forward on the reference's kNN graphs with the f16x2 kernels in range: stage 2 is the production kernel (k_stage2_h2u,
+// SAVE) in the CALLER's station order, so the stage 1 of a training call writes c / wv node-planar too
+bool train_h2u_on(const genie_ctx* c) {
+    return c->force_generic && !c->pcsr && c->train_save != nullptr && c->use_fast && h2_on(c) && c->src_tab != nullptr && !c->tab_host.empty() &&
+           !c->s2u_off && !abs_generic(c);
+}
 bool s2h_on(const genie_ctx* c) {
 #if GENIE_TUNING
     { static const bool old_pair = getenv("GENIE_S2_OLD") != nullptr; if (old_pair) return false; }   // A/B: row layout + k_stage2_ord
@@ -2296,7 +2302,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
                                                                                 sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
         }
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P_ext * (long long)XPC;
-        a.np = s2h_on(c) ? 1 : 0;
+        a.np = (s2h_on(c) || train_h2u_on(c)) ? 1 : 0;
         c->ws_np = a.np != 0;
         const int grid = da_grid_w(c, (n_tiles + 1) / 2, c->bpc1b, H2_THREADS / 64);
         const bool big = c->P_ext * XROW >= (1ll << 32);
@@ -2459,9 +2465,30 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             HIP_TRY(hipMemcpy(c->sta_ident, id.data(), sizeof(int32_t) * id.size(), hipMemcpyHostToDevice));
         }
         a.sta_user = c->sta_ident; a.ea_int = edge_attr; a.wgmap = 0;
-        const int grid = da_grid(c, n_tiles, c->bpc2o);
-        if (x_latent_out) k_stage2_ord<8, 15, true, false, true><<<grid, 256, 0, st>>>(a);
-        else k_stage2_ord<8, 15, false, false, true><<<grid, 256, 0, st>>>(a);
+        if (train_h2u_on(c) && c->ws_np && gi_begin == 0 && gi_end == c->G) {
+            // k_stage2_h2u with the pre-activations kept (identity station order: edge_attr fragments built per call)
+            a.np = 1; a.packed = c->packed_s2h;
+            if (!c->ea_frag_tmp) HIP_TRY(hipMalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
+            k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(edge_attr, c->P, c->S, nullptr, c->ea_frag_tmp);
+            a.ea_frag = c->ea_frag_tmp;
+            const genie_ctx::S2uTables* tb = nullptr;
+            if ((rc = get_s2u_tables(c, gi_begin, gi_end, &tb))) return rc;
+            const size_t lds = sizeof(float) * S2H_IMG_FLOATS + (size_t)S2U_UCAP * 1024;
+            const long long items = (long long)tb->nblk * c->T;
+            const int grid = (int)std::max<long long>(8, std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8) / 8 * 8);
+            const bool big = c->P_ext * 128 >= (1ll << 32);
+            auto launch = [&](auto kern) {
+                static bool attr_set = false;
+                if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+                kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
+            };
+            if (x_latent_out) { if (big) launch(k_stage2_h2u<true, true, true>); else launch(k_stage2_h2u<true, false, true>); }
+            else { if (big) launch(k_stage2_h2u<false, true, true>); else launch(k_stage2_h2u<false, false, true>); }
+        } else {
+            const int grid = da_grid(c, n_tiles, c->bpc2o);
+            if (x_latent_out) k_stage2_ord<8, 15, true, false, true><<<grid, 256, 0, st>>>(a);
+            else k_stage2_ord<8, 15, false, false, true><<<grid, 256, 0, st>>>(a);
+        }
     } else if (c->force_generic && !c->pcsr) {
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     } else if (c->pcsr) {

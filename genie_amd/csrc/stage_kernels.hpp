@@ -1603,7 +1603,7 @@ struct S2uBlock {                    // one block of the processing order
     int32_t idx[S2U_NB][16];         // node b: [0] = its source node id (-1: the block has no node b), [1 + k] = union row of its k-th neighbour
 };
 
-template <bool XL, bool BIG>
+template <bool XL, bool BIG, bool SAVE = false>      // SAVE: training forward (pre-activations of x_latent and of the Bipartite message kept)
 __global__ __launch_bounds__(256, 2) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
     constexpr int KS = 8, KP = 15;
     constexpr int NF4 = S2H_IMG_FLOATS / 4;
@@ -1753,6 +1753,12 @@ __global__ __launch_bounds__(256, 2) void k_stage2_h2u(DaArgs a, const S2uBlock*
             f32x4 o1 = fma4(n1t, 1.f / (float)KS, R.c1), o2 = fma4(n2, 1.f / (float)KP, R.c2);
             const float mq = R.mq;
             const u32x4 eab = R.ea;
+            const long long p_sv = SAVE ? (long long)g_c * S + a.sta_user[min(tbc * 16 + m, S - 1)] : 0;
+            const bool sv_ok = SAVE && live && tbc * 16 + m < S;
+            if (sv_ok) {
+                *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + p_sv) * 16 + 4 * kg) = o1;
+                *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + p_sv) * 16 + 4 * kg) = o2;
+            }
             o1 = prelu4u(o1, a2);
             o2 = prelu4u(o2, a2);
             asm volatile("" : "+v"(o1), "+v"(o2), "+v"(idv_n));
@@ -1786,6 +1792,7 @@ __global__ __launch_bounds__(256, 2) void k_stage2_h2u(DaArgs a, const S2uBlock*
                 bp[t] = MFMA16H(w1, p2, bp[t]);
                 bp[t] = MFMA16H(we, eab, bp[t]);
                 bp[t] = MFMA16H(w0, p0, bp[t]);
+                if (sv_ok) *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + p_sv) * 16 + 4 * kg) = bp[t];
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
