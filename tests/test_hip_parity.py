@@ -165,6 +165,37 @@ def test_fp16_range_guard_selects_the_fp32_kernels_without_any_switch(gains):
         assert (not torch.isfinite(bad).all()) or max_abs(bad, ref["bip"]) > 1e-3 * float(ref["bip"].abs().max())
 
 
+def test_fp16_range_guard_sees_the_static_terms_of_long_tables():
+    """The range guard also bounds the static per-station / per-source-node terms of the two other model definitions. Their tables
+    are as long as the graph ([n_grid, 48] edge-feature terms, [n_grid, 4] positions): above 4096 entries they are reduced by many
+    workgroups first (k_tab_absmax) and the guard reads the partial maxima. 40 stations x 300 source nodes: the unscaled model keeps
+    f16x2; with the edge-feature columns of l1_t2_2 (source side, the long table) scaled until the term alone leaves the fp16 range the
+    library switches to the fp32 kernels by itself and the bound it reports grows accordingly."""
+    S, G = 40, 300
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=10, seed=11)
+    w0 = Case("edges_12x60").weights
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+
+    def info_for(gain):
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=True).eval()
+        w = {k: v.clone() for k, v in w0.items()}
+        w["DataAggregation.l1_t2_2.weight"][:, 60:64] *= gain
+        net.load_state_dict(w, strict=True)
+        net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), t(geom.edge_attr()), t(geom.locs),
+                                 t(geom.x_grid))
+        win = synthetic.make_window(geom, 500, seed=12)
+        with torch.no_grad():
+            y, x = net.forward_fixed_source(t(win["Slice"]), t(win["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query),
+                                            t(geom.t_query))
+        assert torch.isfinite(y).all() and torch.isfinite(x).all()
+        return net._hip.stage_precision()
+    a, b = info_for(1.0), info_for(3.0e6)
+    print(a, b)
+    assert G * 48 > 4096                         # the long-table path
+    assert a["f16x2_active"] and not b["f16x2_active"]
+    assert b["act_bound"] > 60000.0 > a["act_bound"]
+
+
 @pytest.mark.parametrize("name", EDGES_CASES)
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_updated_model_definition_forward_fixed_source(name, stage1, monkeypatch):
