@@ -3050,7 +3050,6 @@ size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 
 int train_check(const genie_ctx* c, const char* who, bool variants = false) {
     if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
     if (!variants && (c->has_edges || c->abs_sta)) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
-    if (c->has_edges && c->abs_sta) return fail(GENIE_ERR_STATE, std::string(who) + ": edge features together with absolute positions");
     return GENIE_OK;
 }
 // scratch of static_term_grads: per-source-node sums [G][16], per-station partial sums [SG_CHUNKS][S][16], slices of one dW block

@@ -234,8 +234,10 @@ class DataAggregationEdges(nn.Module):
     message carries 4 edge features, so l1_t?_2 is [30, 68] and l2_t?_2 is [15, 98] (columns: node, neighbour mean, EDGE
     FEATURES, Mask). Same state_dict keys and shapes as the reference class; computed by libgenie_hip."""
 
-    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4, ndim_proj=3):
+    def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_mask=4, ndim_proj=3, use_absolute_pos=False):
         super().__init__()
+        if use_absolute_pos:
+            in_channels = in_channels + 3 * 2          # module.py:106-107 (both options together)
         ne = ndim_proj + 1
         self.activate = nn.PReLU()
         self.init_trns = nn.Linear(in_channels + n_dim_mask, n_hidden)
@@ -662,13 +664,12 @@ class GCN_Detection_Network_extended(nn.Module):
         # zero `phase_label` (module.py:632-633, :706-707); the callers also zero the phase-informed columns 2, 3 of Slice / Mask
         # (process_continuous_days.py:783-786, train_GENIE_model.py:1707-1709), which `genie_amd.apply` does under the same flag
         self.use_phase_types = bool(use_phase_types)
-        # config.yaml:92: station / source positions appended to the inputs (module.py:916); forward_fixed_source only
-        if use_absolute_pos and use_updated_model_definition:
-            raise NotImplementedError("use_absolute_pos together with use_updated_model_definition")
+        # config.yaml:92: station / source positions appended to the inputs (module.py:916). It combines with
+        # use_updated_model_definition as in the reference (module.py:103-109, :408-412, :1056, :1153)
         # config.yaml:95. True = the class of module.py:1022-1185: DataAggregationEdges on the hot path; its
         # `forward_fixed_source` is served here, its 4-output `forward` / `forward_fixed` (different association heads) are not
         self.use_updated_model_definition = bool(use_updated_model_definition)
-        self.DataAggregation = (DataAggregationEdges(4, 15) if self.use_updated_model_definition
+        self.DataAggregation = (DataAggregationEdges(4, 15, use_absolute_pos=use_absolute_pos) if self.use_updated_model_definition
                                 else DataAggregation(4, 15, use_absolute_pos=use_absolute_pos)).to(device)
         self.Bipartite_ReadIn = BipartiteGraphOperator(30, 15, ndim_edges=3).to(device)
         self.SpatialAggregation1 = SpatialAggregation(15, 30, scale_rel=scale_rel).to(device)
@@ -690,6 +691,12 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip = None
         self._path_params = None
         self._edge_attr = None
+
+    def _weight_split(self):
+        """state_dict view -> the library's registry view (static-term columns of the two other model definitions under their own names)."""
+        if self.use_updated_model_definition and self.use_absolute_pos:
+            return lambda named: _split_edge_columns(_split_abs_columns(named))
+        return _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None)
 
     # ---- graphs --------------------------------------------------------------------------------
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
@@ -831,7 +838,7 @@ class GCN_Detection_Network_extended(nn.Module):
     def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        self._hip.sync_weights(self._path_params, self._weight_split())
         return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
 
     def _differentiable(self):
@@ -847,7 +854,7 @@ class GCN_Detection_Network_extended(nn.Module):
         if self._hip._n_prod is not None:
             raise NotImplementedError("training-mode forward: Cartesian product graphs only (not use_subgraph)")
         hp = self._hip
-        hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        hp.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         n_src_rows = 0
         if x_query_src_cart is not None:          # the source queries ride along as extra query rows (same kernels, same backward)
@@ -881,7 +888,7 @@ class GCN_Detection_Network_extended(nn.Module):
         y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        self._hip.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
         return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
 
@@ -892,7 +899,7 @@ class GCN_Detection_Network_extended(nn.Module):
         Same arithmetic, bit-identical results. Returns the number of pending windows."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+        self._hip.sync_weights(self._path_params, self._weight_split())
         return self._hip.window_push(Slice, Mask, self._edge_attr)
 
     def flush_windows(self, x_temp_cuda_cart, x_query_cart, t_query):
@@ -930,7 +937,7 @@ class GCN_Detection_Network_extended(nn.Module):
                                "of set_adjacencies(...) / set_adjacencies_base(...)")
         hp = self._hip
         if not getattr(hp, "assoc_ready", False) and hp is not None:
-            hp.sync_weights(self._path_params, _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None))
+            hp.sync_weights(self._path_params, self._weight_split())
         train = self._differentiable()
         if train:       # training step (train_GENIE_model.py:1786): the shared path in HIP in both directions
             y, x, x_spatial, y_latent, x_latent, x_src = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query, want_latents=True,

@@ -337,6 +337,22 @@ def main_assoc_variant(flag):
     run_assoc_case(ref, "assoc_%s_18x50" % flag, geom, win)
 
 
+def main_edges_abspos():
+    """`python oracle/make_golden.py --edges-abspos`: BOTH flags set (`use_updated_model_definition: True` and `use_absolute_pos: True`,
+    which the reference's classes accept together, module.py:103-109, :408-412, :1056, :1153): the 2-output fixture
+    `edges_abspos_12x60` and the 4-output one `assoc_edges_abspos_18x50`."""
+    ref = _import_reference(updated_definition=True, absolute_pos=True)
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(12, 60, L=80e3, n_query=30, seed=131)          # uniform 8 / 15 degrees
+    win = syn.make_window(geom, 150, seed=132)
+    run_case(ref, "edges_abspos_12x60", geom, win["Slice"], win["Mask"], perturb_prelu=True, window=win,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"))
+    geom = syn.Geometry(18, 50, L=70e3, n_query=20, seed=133)          # partial last tile
+    win = syn.make_window(geom, 220, seed=134)
+    run_assoc_case(ref, "assoc_edges_abspos_18x50", geom, win)
+
+
 def main_assoc_subgraph():
     """`python oracle/make_golden.py --assoc-subgraph`: the 4-output `forward_fixed` of the live model on an irregular product graph
     (`use_subgraph: True`; the geometry and node list of `--subgraph`), time-pointer tables from the reference's own
@@ -466,6 +482,8 @@ def main():
         return main_postproc()
     if "--scaled" in sys.argv:
         return main_scaled()
+    if "--edges-abspos" in sys.argv:
+        return main_edges_abspos()
     if "--edges" in sys.argv:
         return main_edges()
     if "--subgraph" in sys.argv:

@@ -250,6 +250,32 @@ def test_use_absolute_pos_forward_fixed_source(name):
     assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
 
 
+def test_both_model_options_together_forward_fixed_source():
+    """`use_updated_model_definition: True` with `use_absolute_pos: True` (the reference's classes take both, module.py:103-109,
+    :1056): the edge-feature terms and the position columns are both static additive terms of the stage-1 pre-activations
+    (genie_set_edge_features + genie_set_absolute_pos on one context; the generic fp32-MFMA stage 1 serves the combination). Fixture
+    from the reference imported with both flags set."""
+    c = Case("edges_abspos_12x60")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_absolute_pos=True, use_updated_model_definition=True)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea, A_src_in_sta.to(DEV), c.A_src_src.to(DEV),
+                        None, None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    with torch.no_grad():
+        y, x = net.forward_fixed_source(c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV),
+                                        c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+        hp = net._hip
+        _, _, h0, h1 = hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV), debug=True)
+        x_latent, bip = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV), want_x_latent=True)
+    for k, v in (("h0", h0), ("h1", h1), ("x_latent", x_latent), ("bip", bip)):
+        ref = c.ref(k)
+        assert max_abs(v.cpu(), ref) <= rel_tol(ref), (k, max_abs(v.cpu(), ref))
+    assert max_abs(y.cpu(), c.ref("y")) <= 1e-5 and max_abs(x.cpu(), c.ref("x")) <= 1e-5
+    assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
+
+
 @pytest.mark.parametrize("name", SUBGRAPH_CASES)
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_use_subgraph_irregular_product_graph(name, stage1, monkeypatch):
@@ -553,7 +579,7 @@ def test_training_mode_forward_and_gradients_match_oracle_autograd(name):
     assert checked >= 80          # every tensor of DataAggregation, Bipartite_ReadIn, SpatialAggregation1..3 and the read-outs
 
 
-@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13"])
+@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13", "edges_abspos_12x60"])
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(name, stage1, monkeypatch):
     """a-8 / a-9: the training step of `forward_fixed_source` under `use_updated_model_definition` (DataAggregationEdges,
@@ -567,7 +593,7 @@ def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(na
     if stage1 == "f32":
         monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     c = Case(name)
-    kw = dict(use_updated_model_definition=True) if c.edges_variant else dict(use_absolute_pos=True)
+    kw = dict(use_updated_model_definition=c.edges_variant, use_absolute_pos=c.abspos_variant)      # (edges_abspos_12x60: both)
     net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, **kw)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
     A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
@@ -596,7 +622,7 @@ def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(na
     Slice, okw = c.Slice, {}
     if c.abspos_variant:
         Slice = O.absolute_pos_inputs(Slice, c.locs.float(), c.x_grid.float(), A_src_in_sta)
-    else:
+    if c.edges_variant:
         okw["pos_rel"] = (O.edge_pos_features(c.locs.float(), A_in_sta, A_src_in_sta[0]),
                           O.edge_pos_features(c.x_grid.float(), A_in_src, A_src_in_sta[1]))
     yo, xo = O.forward_fixed_source(w, Slice, c.Mask, A_in_sta, A_in_src, c.edge_attr, A_src_in_prod, c.A_src_src,
@@ -617,7 +643,7 @@ def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(na
     if c.edges_variant:
         assert float(w["DataAggregation.l1_t1_2.weight"].grad[:, 60:64].abs().max()) > 0
         assert float(w["DataAggregation.l2_t2_2.weight"].grad[:, 90:94].abs().max()) > 0
-    else:
+    if c.abspos_variant:
         assert float(w["DataAggregation.init_trns.weight"].grad[:, 4:10].abs().max()) > 0
 
 
@@ -1141,7 +1167,7 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_subgraph_14x50", "assoc_nophase_18x50"])
+                                  "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50"])
 def test_forward_fixed_and_forward_four_outputs_match_reference(name):
     """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) in HIP end to end (front, read-outs with their latents, association
     stages, LocalSliceLgCollapse, Arrivals) against the reference's own forward_fixed golden vectors: 7 stations (generic CSR
@@ -1191,7 +1217,8 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
         assert max_abs(out[3].cpu(), torch.from_numpy(z["arv_s"])) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50"])
+@pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
+                                  "assoc_edges_abspos_18x50"])
 def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name):
     """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
     mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones. Every module

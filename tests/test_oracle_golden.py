@@ -105,3 +105,18 @@ def test_oracle_with_absolute_positions_matches_reference(name):
     for k in ["bip", "sa3", "y", "x"]:
         ref = c.ref(k + "64")
         assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
+
+
+def test_oracle_with_both_model_options_matches_reference():
+    """`use_updated_model_definition: True` AND `use_absolute_pos: True` (the reference's classes take both: module.py:103-109, :1056):
+    fixture `edges_abspos_12x60` from the reference imported with both flags (oracle/make_golden.py --edges-abspos)."""
+    c = Case("edges_abspos_12x60")
+    assert c.edges_variant and c.abspos_variant
+    out = c.oracle_forward(torch.float32)
+    for k in ["h0", "h1", "x_latent", "bip", "sa3", "y", "x"]:
+        ref = c.ref(k)
+        assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
