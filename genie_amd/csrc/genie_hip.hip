@@ -895,8 +895,10 @@ __device__ int g_abl_mfma;  // set from the host in tuning builds
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #endif
 
-// wave-level ordering point for data the lanes of one wave exchange through LDS (LDS operations of a wave complete in order)
-#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// wave-level ordering point for data the lanes of ONE wave exchange through LDS. The DS instructions of a wave execute in issue
+// order, so a wavefront-scope fence (compiler ordering only, no s_waitcnt) is enough; the workgroup-scope fence used until round 4
+// also drained every outstanding global load (vmcnt(0)) at each exchange.
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __device__ __forceinline__ float prelu1(float x, float a) { return x >= 0.f ? x : a * x; }
 __device__ __forceinline__ f32x4 prelu4(f32x4 x, float a) {
     f32x4 y;
