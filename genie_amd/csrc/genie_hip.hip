@@ -1204,6 +1204,7 @@ struct genie_ctx {
     int32_t *r_sta_rowptr, *r_sta_col, *r_src_rowptr, *r_src_col;
     float *r_sta_w, *r_src_w;
     int2 *r_sta_cw, *r_src_cw;   // the same edges as (column, weight bits) pairs: one 8-byte load per edge (training passes)
+    int32_t *rp_sta_rowptr, *rp_src_rowptr; int2 *rp_sta_cw, *rp_src_cw;   // irregular product graph: the reversed PRODUCT-level graphs
     const float *xs_slice, *xs_mask;   // genie_embed_window_split: the (Slice, Mask) buffers whose split rows already sit in the workspace (one-shot)
     const void* xs_ws;
     int xs_mm_copy;            // ... and the copy (slot % GENIE_NBIG at embed time) its message-mask row `mm` was written to
@@ -1955,6 +1956,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr; c->sta_ident = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr; c->r_sta_cw = c->r_src_cw = nullptr;
+    c->rp_sta_rowptr = c->rp_src_rowptr = nullptr; c->rp_sta_cw = c->rp_src_cw = nullptr;
     c->pcsr = false; c->pcsr_h2 = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
@@ -2200,7 +2202,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->as_pg, c->as_ps, c->d_h2tbl, c->packed_h2, c->src_tab,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
-                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw,
+                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw, c->rp_sta_rowptr, c->rp_src_rowptr, c->rp_sta_cw, c->rp_src_cw,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
                     c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
     for (void* p : ptrs) (void)hipFree(p);
@@ -3049,9 +3051,18 @@ int train_grid(const genie_ctx* c) {
 size_t train_part_floats(const genie_ctx* c) { return (size_t)train_grid(c) * 4 * (30 * 256 + 12 * 16 + 16); }
 // `variants`: the call also serves DataAggregationEdges / use_absolute_pos (the forward_fixed_source step does; the association heads'
 // training step is the default model definition only)
-int train_check(const genie_ctx* c, const char* who, bool variants = false) {
-    if (c->pcsr || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
+int train_check(const genie_ctx* c, const char* who, bool variants = false, bool pcsr_ok = false) {
+    if ((c->pcsr && !pcsr_ok) || c->G_ext != c->G) return fail(GENIE_ERR_STATE, std::string(who) + ": needs an unsharded Cartesian product graph");
     if (!variants && (c->has_edges || c->abs_sta)) return fail(GENIE_ERR_STATE, std::string(who) + ": default model definition only");
+    return GENIE_OK;
+}
+// station sums live as [G][T][32] partial rows; on an irregular product graph the training calls keep ONE row per source node there
+int part_T(const genie_ctx* c) { return c->pcsr ? 1 : c->T; }
+int ensure_src_of(genie_ctx* c, hipStream_t st) {
+    if (c->p_src_of || !c->pcsr) return GENIE_OK;
+    HIP_TRY(hipMalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
+    k_seg_owner<<<(c->G + 255) / 256, 256, 0, st>>>(c->seg_rowptr, c->G, c->p_src_of);
+    HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 // scratch of static_term_grads: per-source-node sums [G][16], per-station partial sums [SG_CHUNKS][S][16], slices of one dW block
@@ -3108,14 +3119,17 @@ int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, cons
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!slice || !mask || !edge_attr || !save || !r_out) return fail(GENIE_ERR_ARG, "genie_da_train_fwd: null argument");
-    if ((rc = train_check(c, "genie_da_train_fwd", true))) return rc;
+    if ((rc = train_check(c, "genie_da_train_fwd", true, true))) return rc;
     c->force_generic = 1; c->train_save = save;
     rc = run_stage1(c, slice, mask, nullptr, nullptr, ws, stream, 0, c->G, true);
     if (!rc) rc = run_stage2(c, mask, edge_attr, x_latent_out, ws, stream, 0, c->G);
     c->force_generic = 0; c->train_save = nullptr;
     if (rc) return rc;
-    const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
-    k_part_sum<<<(c->G * 30 + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, r_out);
+    float* part = (float*)ws + c->o_part + c->slot * c->slot_stride;
+    if (c->pcsr)      // the messages sit in the c rows (k_stage2_pcsr): one station-sum row per source node
+        k_seg_sum32<<<(c->G * 32 + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride,
+                                                                             c->seg_rowptr, c->G, part);
+    k_part_sum<<<(c->G * 30 + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, c->G, part_T(c), r_out);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -3128,6 +3142,24 @@ int ensure_reversed(genie_ctx* c) {
         void* old[] = {c->r_sta_rowptr, c->r_sta_col, c->r_sta_w, c->r_src_rowptr, c->r_src_col, c->r_src_w};
         for (void* q : old) (void)hipFree(q);
         c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr; c->r_sta_w = c->r_src_w = nullptr;
+    }
+    if (c->pcsr) {      // irregular product graph: the P-sized passes gather by product-node id over the reversed PRODUCT-level graphs
+        const int np = (int)c->P;    // (the G-sized tail keeps the reversed base source graph below)
+        int32_t* col_unused = nullptr;
+        float* w_unused = nullptr;
+        if ((rc = build_reversed(c->p_sta_rowptr, c->p_sta_col, np, np, &c->rp_sta_rowptr, &col_unused, &w_unused, &c->rp_sta_cw))) return rc;
+        (void)hipFree(col_unused); (void)hipFree(w_unused);
+        col_unused = nullptr; w_unused = nullptr;
+        if ((rc = build_reversed(c->p_src_rowptr, c->p_src_col, np, np, &c->rp_src_rowptr, &col_unused, &w_unused, &c->rp_src_cw))) return rc;
+        (void)hipFree(col_unused); (void)hipFree(w_unused);
+        // base station graph: not part of a subgraph context; an empty reversed graph keeps the non-null contract of the callers
+        std::vector<int32_t> zero((size_t)c->S + 1, 0);
+        HIP_TRY(hipMalloc((void**)&c->r_sta_rowptr, sizeof(int32_t) * zero.size()));
+        HIP_TRY(hipMemcpy(c->r_sta_rowptr, zero.data(), sizeof(int32_t) * zero.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->r_sta_col, sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void**)&c->r_sta_w, sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->r_sta_cw, sizeof(int2)));
+        return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w, &c->r_src_cw);
     }
     if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w, &c->r_sta_cw))) return rc;
     return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w, &c->r_src_cw);
@@ -3147,7 +3179,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     if (!c || !slice || !mask || !edge_attr || !save || !d_r || !scratch || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_da_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_da_train_bwd", true))) return rc;
+    if ((rc = train_check(c, "genie_da_train_bwd", true, true))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if ((rc = ensure_reversed(c))) return rc;
@@ -3164,6 +3196,12 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     a.gr = scratch; a.part = scratch + (size_t)GR_BLOCKS * 16 * (size_t)c->P;
     a.sv_t = SV_T; a.sv_up = SV_UP; a.sv_vp = SV_VP;
     a.store_dz0 = c->abs_sta != nullptr;
+    if (c->pcsr) {
+        if ((rc = ensure_src_of(c, st))) return rc;
+        a.src_of = c->p_src_of;
+        a.r_sta_rowptr = c->rp_sta_rowptr; a.r_sta_cw = c->rp_sta_cw; a.r_src_rowptr = c->rp_src_rowptr; a.r_src_cw = c->rp_src_cw;
+        a.r_sta_col = a.r_src_col = nullptr; a.r_sta_w = a.r_src_w = nullptr;       // (the PCSR passes read the pair arrays only)
+    }
 #if GENIE_TUNING
     { static const char* e = getenv("GENIE_TRABL"); a.abl = e ? atoi(e) : 0; }
 #endif
@@ -3172,11 +3210,18 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
         // k_train_b1 holds one wave per SIMD (442 registers): one workgroup per CU is all that is ever resident
         const int grid_s = s == 1 ? std::max(8, grid / 2 / 8 * 8) : grid;
-        if (s == 0) k_train_b2<<<grid, 256, 0, st>>>(a);
-        else if (s == 1) k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
-        else k_train_b0<<<grid, 256, 0, st>>>(a);
+        const int grid_w = (c->pcsr && s == 1) ? grid : grid_s;        // workgroups of this pass (= 4 waves of partials each)
+        if (c->pcsr) {
+            if (s == 0) k_train_b2<true><<<grid, 256, 0, st>>>(a);
+            else if (s == 1) k_train_b1p<false><<<grid, 256, 0, st>>>(a);
+            else k_train_b0<true><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (s == 0) k_train_b2<false><<<grid, 256, 0, st>>>(a);
+            else if (s == 1) k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
+            else k_train_b0<false><<<grid, 256, 0, st>>>(a);
+        }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_w * 4, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob, 0);
     }
     if (c->has_edges || c->abs_sta) {
@@ -3229,7 +3274,7 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if (!pos || !x_query || !knn || !t_query || !tsave || !y_out || !x_out) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: null argument");
-    if ((rc = train_check(c, "genie_tail_train_fwd", true))) return rc;
+    if ((rc = train_check(c, "genie_tail_train_fwd", true, true))) return rc;
     if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_fwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
@@ -3240,8 +3285,8 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     float* xs = tsave + TT_XS * G;
     // the same kernels, in the same order, as the inference tail (genie_bipartite_readout, genie_spatial_agg3_fwd, read-outs); the layer
     // inputs land in `tsave` instead of the workspace slot
-    k_part_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(w + c->o_part + so, c->G, c->T, r);
-    k_bip_out_m<false><<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, c->T, c->packed[PL_BIP], bip, 0, 0);
+    k_part_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(w + c->o_part + so, c->G, part_T(c), r);
+    k_bip_out_m<false><<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, part_T(c), c->packed[PL_BIP], bip, 0, 0);
     c->tail_train = 1;           // fp32 chains: the backward recomputes every pre-activation of the tail with them
     rc = sa_launch_pre(c, 1, bip, w, 0, st);
     if (!rc) rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st);
@@ -3275,7 +3320,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
     if (!c || !pos || !x_query || !knn || !rknn_rowptr || !rknn_edge || !t_query || !tsave || !d_y || !d_x || !scratch || !d_r_out || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_tail_train_bwd", true))) return rc;
+    if ((rc = train_check(c, "genie_tail_train_bwd", true, true))) return rc;
     if (k != RO_K || n_query < 1 || n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_train_bwd: k = 10, n_query >= 1, 1 <= n_t <= 10");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
@@ -3449,10 +3494,7 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     a.c = d.c; a.wu = d.wu; a.wv = d.wv;
     a.save = save; a.Pn = c->P;
     if (c->pcsr) {       // irregular product graph: product-level CSRs, the source node of every product node from the row ranges
-        if (!c->p_src_of) {
-            HIP_TRY(hipMalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
-            k_seg_owner<<<(c->G + 255) / 256, 256, 0, st>>>(c->seg_rowptr, c->G, c->p_src_of);
-        }
+        if ((rc = ensure_src_of(c, st))) return rc;
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
         a.sta_user = nullptr; a.src_of = c->p_src_of;
         const long long ntiles = (c->P + 15) / 16;

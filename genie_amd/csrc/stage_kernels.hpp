@@ -976,6 +976,10 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
             gather_sum16<false>(a.wv + 4 * ql, ROWW, a.src_col, eb, ee, n2);
             o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
         }
+        if (a.save != nullptr && valid_l) {      // training forward: pre-activations of x_latent (chunk ql of node jl: the blocks' own layout)
+            *(f32x4*)(a.save + ((size_t)(SV_O + 0) * a.Pn + pl) * 16 + 4 * ql) = o[0];
+            *(f32x4*)(a.save + ((size_t)(SV_O + 1) * a.Pn + pl) * 16 + 4 * ql) = o[1];
+        }
         o[0] = prelu4u(o[0], a2);
         o[1] = prelu4u(o[1], a2);
         if (a.x_latent != nullptr && valid_l) {
@@ -1003,6 +1007,7 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 0) * 64 + lane], o[0]);
             bp[t] = mma_block(bp[t], lw[G2_BP(t, 1) * 64 + lane], o[1]);
             bp[t] = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp[t]);
+            if (a.save != nullptr && valid) *(f32x4*)(a.save + ((size_t)(SV_ZB + t) * a.Pn + p) * 16 + 4 * q) = bp[t];
             bp[t] = prelu4u(bp[t], ab1);
         }
         float mm = fmaxf(mq, __shfl_xor(mq, 16));

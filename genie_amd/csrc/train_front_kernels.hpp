@@ -26,6 +26,8 @@ struct TrArgs {
     const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
     const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
     const int2* r_sta_cw; const int2* r_src_cw;    // the same edges as (column, weight bits) pairs
+    const int32_t* src_of;       // irregular product graph (PCSR kernels): source node of every product node; the r_* arrays are then
+                                 // the reversed PRODUCT-level graphs (indexed by product node, columns = product-node ids)
     const float* slice; const float* mask; const float* edge_attr;
     const float* save; float* gr;
     const float* dr;             // [G][32] gradient of the per-source-node station sum (Bipartite, before fc2)
@@ -207,6 +209,7 @@ __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f
 }
 
 // ---- pass 2': Bipartite message + PReLU2.  accumulators: fc1 (t, {x_latent 0:15, x_latent 15:30, edge_attr}) = 6; vec: fc1 bias (2)
+template <bool PCSR>
 __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
     constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -227,15 +230,26 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
     for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
+                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    for (long long it = it0; it < n_it; it += its) {
+        int g;
+        bool valid;
+        long long p;
+        if (PCSR) {       // a tile is 16 consecutive product nodes, the source node is per lane
+            const long long pr = it * 16 + j;
+            valid = pr < P;
+            p = valid ? pr : P - 1;
+            g = a.src_of[p];
+        } else {
+            int gi, tb;
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            p = (long long)g * S + (valid ? s : S - 1);
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
         float mq = a.mask[p * 4 + q];
         float mm = fmaxf(mq, __shfl_xor(mq, 16));
         mm = fmaxf(mm, __shfl_xor(mm, 32));
@@ -497,9 +511,131 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
 }
 
+// ---- pass 1' on an irregular product graph (`use_subgraph`): the structure k_train_b1 had before its software pipeline. A tile is 16
+// consecutive product nodes; the transposed means run over the reversed PRODUCT-level graphs (out-edges of a product node, per lane
+// on both sides), gradient rows are addressed by product-node id.
+template <bool AS>
+__global__ __launch_bounds__(256, 1) void k_train_b1p(TrArgs a) {
+    constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
+    const float a1 = lscal[0], a21 = lscal[1], a22 = lscal[2];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = tsc[wave];
+    const int S = a.S;
+    const long long P = a.P;
+    constexpr int NV = AS ? 8 : 6;
+    f32x4 acc[30], vec[NV];
+    float scal[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
+    (void)S;
+    const long long ntiles = (P + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        asm volatile("" : "+v"(lane));
+        const long long pr = tile * 16 + j;
+        const bool valid = pr < P;
+        const long long p = valid ? pr : P - 1;
+        const int g = a.src_of[p];               // per lane: a tile may straddle source nodes
+        const float vm = valid ? 1.f : 0.f;
+        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
+        const f32x4 do1 = ldb(a.gr, GR_DO + 0, P, p, q) * vm, do2 = ldb(a.gr, GR_DO + 1, P, p, q) * vm;
+        if (AS) {
+            const float m1 = a.pg[(long long)g * AS_PG + 31];
+            vec[6] += do1 * m1; vec[7] += do2 * m1;
+        }
+        const float* gr = a.gr;
+        f32x4 tms[1], tmg[1];                    // reversed PRODUCT-level graphs: out-edges of product node p, rows by product-node id
+        tmean_pre<1, 8, 8>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int, int c) { return ldb(gr, GR_DO + 0, P, c, q); }, tms);
+        tmean_pre<1, 16, 8>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int, int c) { return ldb(gr, GR_DO + 1, P, c, q); }, tmg);
+        const f32x4 tm1 = tms[0] * vm, tm2 = tmg[0] * vm;
+        f32x4 t[4], h1[4], up[2], vp[2], u[2], v[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { t[k] = ldb(a.save, SVT + k, P, p, q); h1[k] = prelu4u(t[k], a1); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            up[b] = ldb(a.save, SVU + b, P, p, q); u[b] = prelu4u(up[b], a21);
+            vp[b] = ldb(a.save, SVV + b, P, p, q); v[b] = prelu4u(vp[b], a22);
+        }
+        // du = l2_t1_2[:, 60:90]^T tm1 through PReLU21', dv likewise
+        f32x4 du[2], dv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 gu = mma_block(z, lw[GT_U(b) * 64 + lane], tm1), gv = mma_block(z, lw[GT_V(b) * 64 + lane], tm2);
+            scal[1] += negsum4(gu, up[b]);
+            scal[2] += negsum4(gv, vp[b]);
+            du[b] = gu * dprelu4(up[b], a21);
+            dv[b] = gv * dprelu4(vp[b], a22);
+        }
+        // dh1 and dt
+        f32x4 dt[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du[0]);
+            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du[1]);
+            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv[0]);
+            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv[1]);
+            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
+            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
+            scal[0] += negsum4(d, t[hb]);
+            dt[hb] = d * dprelu4(t[hb], a1);
+            if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(b, k) * 64 + lane], dt[k]);
+            if (valid) stb(a.gr, GR_DH0 + b, P, p, q, d);
+        }
+        vec[0] += do1; vec[1] += do2;
+        vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
+        // weight gradients
+        f32x4 h1t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h1t[k] = tr16(h1[k], sc, j, q);
+        const f32x4 mt = tr16(mb, sc, j, q);
+        {
+            const f32x4 d1t = tr16(do1, sc, j, q), d2t = tr16(do2, sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] = outer16(acc[k], d1t, h1t[k]); acc[7 + k] = outer16(acc[7 + k], d2t, h1t[k]); }
+            acc[4] = outer16(acc[4], d1t, mt);
+            acc[11] = outer16(acc[11], d2t, mt);
+            const f32x4 m1t = tr16(tm1, sc, j, q), m2t = tr16(tm2, sc, j, q);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[5 + b] = outer16(acc[5 + b], m1t, tr16(u[b], sc, j, q));
+                acc[12 + b] = outer16(acc[12 + b], m2t, tr16(v[b], sc, j, q));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 dut = tr16(du[b], sc, j, q), dvt = tr16(dv[b], sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[14 + b * 4 + k] = outer16(acc[14 + b * 4 + k], dut, h1t[k]);
+                acc[22 + b * 4 + k] = outer16(acc[22 + b * 4 + k], dvt, h1t[k]);
+            }
+        }
+    }
+    write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
+}
+
 // ---- pass 0': layer 1 and init_trns.
 // accumulators: init_trns (2 x [Slice || Mask]) = 2; l1_t1_2 {2 x (h0 x2, Mask), adjoint 2 x 2} = 10; l1_t2_2 = 10  -> 22
 // vec: b(init_trns) x2, b(l1_t1_2) x2, b(l1_t2_2) x2 = 6; scal: a, a11, a12
+template <bool PCSR>
 __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
     constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -521,15 +657,26 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
+                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    for (long long it = it0; it < n_it; it += its) {
+        int g = 0, scn = 0;
+        bool valid;
+        long long p;
+        if (PCSR) {       // 16 consecutive product nodes; the transposed means run over the reversed PRODUCT-level graphs
+            const long long pr = it * 16 + j;
+            valid = pr < P;
+            p = valid ? pr : P - 1;
+        } else {
+            int gi, tb;
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            scn = valid ? s : S - 1;
+            p = (long long)g * S + scn;
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
         const float vm = valid ? 1.f : 0.f;
         f32x4 xm = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
         if (q == 0) { xm = *(const f32x4*)(a.slice + p * 4); mb = *(const f32x4*)(a.mask + p * 4); }
@@ -540,10 +687,15 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
         for (int b = 0; b < 2; ++b) z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
 #pragma unroll
         for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);      // (own rows requested before the gathers, not after)
-        tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
-                           [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-        tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
-                            [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+        if (PCSR) {
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
+        } else {
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                               [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                                [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; h0[b] = prelu4u(z0[b], a0); }
 #pragma unroll
@@ -701,6 +853,16 @@ __global__ __launch_bounds__(64) void k_static_dw_sum(const float* __restrict__ 
     float s = 0.f;
     for (int x = 0; x < SG_SLICES; ++x) s += part[x * 64 + threadIdx.x];
     dW[(row0 + o) * ld + col0 + e] = s;
+}
+
+// irregular product graph: r[g][32] = sum of the 32-float rows of the product nodes of source node g (seg[g] .. seg[g + 1]), in row order
+__global__ void k_seg_sum32(const float* __restrict__ rows, const int32_t* __restrict__ seg, int G, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * 32) return;
+    const int g = idx >> 5, c = idx & 31;
+    float s = 0.f;
+    for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) s += rows[pr * 32 + c];
+    out[idx] = s;
 }
 
 __global__ void k_part_sum(const float* __restrict__ part, int G, int T, float* __restrict__ r_out) {   // r[g] = sum over tiles

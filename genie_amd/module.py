@@ -851,8 +851,9 @@ class GCN_Detection_Network_extended(nn.Module):
         source queries, module.py:981) only with `x_query_src_cart` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
-        if self._hip._n_prod is not None:
-            raise NotImplementedError("training-mode forward: Cartesian product graphs only (not use_subgraph)")
+        if self._hip._n_prod is not None and want_latents:
+            raise NotImplementedError("training-mode 4-output forward: Cartesian product graphs only (not use_subgraph); "
+                                      "forward_fixed_source trains on irregular product graphs")
         hp = self._hip
         hp.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)

@@ -647,6 +647,58 @@ def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(na
         assert float(w["DataAggregation.init_trns.weight"].grad[:, 4:10].abs().max()) > 0
 
 
+@pytest.mark.parametrize("stage1", ["default", "f32"])
+def test_training_step_on_an_irregular_product_graph_matches_oracle_autograd(stage1, monkeypatch):
+    """`use_subgraph: True` (config.yaml:86): the training step of `forward_fixed_source` on an irregular product graph. Forward = the
+    PCSR stage kernels with the pre-activations kept (k_stage1_h2<.., PCSR> / k_stage1_pcsr, k_stage2_pcsr, per-source-node segment
+    sums of the messages); backward = k_train_b2<PCSR>, k_train_b1p, k_train_b0<PCSR>: tiles of 16 consecutive product nodes, the
+    transposed means over the reversed PRODUCT-level graphs. Outputs equal the eval path and the reference's fixture; every parameter
+    gradient equals the oracle's autograd (literal edge-list formulation on the same irregular graph) to 1e-5 of the gradient scale."""
+    from oracle import genie_oracle as O
+    if stage1 == "f32":
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
+    c = Case("subgraph_14x50")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea, A_src_in_sta.to(DEV), c.A_src_src.to(DEV),
+                        None, None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    assert net._hip._n_prod is not None and net._hip.n_prod < c.S * c.G
+    args = (c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV),
+            c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    net.eval()
+    with torch.no_grad():
+        y_hip, x_hip = net.forward_fixed_source(*args)
+    net.train()
+    y, x = net.forward_fixed_source(*args)
+    assert y.requires_grad and x.requires_grad
+    assert max_abs(y.detach(), y_hip) <= 1e-5 and max_abs(x.detach(), x_hip) <= 1e-5
+    assert max_abs(y.detach().cpu(), c.ref("y")) <= 1e-5 and max_abs(x.detach().cpu(), c.ref("x")) <= 1e-5
+    g = torch.Generator().manual_seed(7)
+    ay, ax = torch.randn(y.shape, generator=g), torch.randn(x.shape, generator=g)
+    (y * ay.to(DEV)).sum().add((x * ax.to(DEV)).sum()).backward()
+    w = {k: v.clone().requires_grad_(True) for k, v in c.weights.items()}
+    yo, xo = O.forward_fixed_source(w, c.Slice, c.Mask, A_in_sta, A_in_src, c.edge_attr, A_src_in_prod, c.A_src_src,
+                                    c.x_grid.float(), c.x_query.float(), c.t_query.float())
+    ((yo * ay).sum() + (xo * ax).sum()).backward()
+    checked = 0
+    for k, p in net.named_parameters():
+        if w[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = w[k].grad
+        assert p.grad is not None, k
+        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
+        checked += 1
+    assert checked >= 80
+    net.eval()
+    with torch.no_grad():
+        y2, x2 = net.forward_fixed_source(*args)
+    assert torch.equal(y2, y_hip) and torch.equal(x2, x_hip)
+
+
 def test_all_zero_mask_gates_bipartite_sum():
     """m_p = max_c Mask[p,c] gates every message (module.py:229): Mask = 0 -> r_g = 0 -> out_g = PReLU(fc2.bias)."""
     c = Case("tiny_6x40")
