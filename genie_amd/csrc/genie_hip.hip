@@ -3473,7 +3473,6 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if (!y_latent || !mask_src || !x_latent || !mask || !edge_attr || !out || !assoc_ws)
         return fail(GENIE_ERR_ARG, "genie_assoc_fwd: null argument");
     if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_assoc_fwd: needs an unsharded product graph");
-    if (c->pcsr && save) return fail(GENIE_ERR_STATE, "genie_assoc_train_fwd: not available on an irregular product graph");
     if (((uintptr_t)assoc_ws & 15) != 0) return fail(GENIE_ERR_ARG, "genie_assoc_fwd: assoc_ws must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
@@ -3528,7 +3527,7 @@ size_t genie_assoc_train_scratch_floats(const genie_ctx* c) {
 int genie_assoc_train_fwd(genie_ctx* c, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
                           const float* edge_attr, float* out, float* asave, void* assoc_ws, void* ws, void* stream) {
     if (!c || !asave) return fail(GENIE_ERR_ARG, "genie_assoc_train_fwd: null argument");
-    int rc = train_check(c, "genie_assoc_train_fwd", true);
+    int rc = train_check(c, "genie_assoc_train_fwd", true, true);
     if (rc) return rc;
     return assoc_fwd_impl(c, y_latent, mask_src, x_latent, mask, edge_attr, out, assoc_ws, ws, stream, asave);
 }
@@ -3539,7 +3538,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     if (!c || !y_latent || !mask_src || !x_latent || !mask || !edge_attr || !asave || !d_s || !scratch || !d_ylat_out || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_assoc_train_bwd: null argument");
     int rc;
-    if ((rc = train_check(c, "genie_assoc_train_bwd", true))) return rc;
+    if ((rc = train_check(c, "genie_assoc_train_bwd", true, true))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if ((rc = ensure_reversed(c))) return rc;
@@ -3559,6 +3558,12 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     a.zsum = a.part + train_part_floats(c);
     float* sscr = a.zsum + (size_t)c->G * c->T * 32 + 64;
     const bool variant = c->has_edges || c->abs_sta != nullptr;
+    if (c->pcsr) {
+        if ((rc = ensure_src_of(c, st))) return rc;
+        a.src_of = c->p_src_of;
+        a.r_sta_rowptr = c->rp_sta_rowptr; a.r_sta_cw = c->rp_sta_cw; a.r_src_rowptr = c->rp_src_rowptr; a.r_src_cw = c->rp_src_cw;
+        a.r_sta_col = a.r_src_col = nullptr; a.r_sta_w = a.r_src_w = nullptr;
+    }
     a.sv_t = AV_T; a.sv_up = AV_UV; a.sv_vp = AV_UV + 2;
     const int grid = train_grid(c);
     const int tms[4] = {TM_AB3, TM_AB2, TM_AB1, TM_AB0};
@@ -3566,21 +3571,30 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     for (int s = 0; s < 4; ++s) {
         const int tm = tms[s];
         a.packed = pls[s] >= 0 ? c->packed[pls[s]] : nullptr; a.n_acc = c->n_acc[tm]; a.n_vec = c->n_vec[tm];
-        const int grid_s = s == 1 ? std::max(8, grid / 2 / 8 * 8) : grid;      // k_train_b1: one workgroup per CU (see da_train_bwd_impl)
-        if (s == 0) k_as_b3<<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
-        else if (s == 1) k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
-        else if (s == 2) k_as_b1<<<grid, 256, 0, st>>>(a);
-        else k_as_b0<<<grid, 256, 0, st>>>(a);
+        const int grid_s = (s == 1 && !c->pcsr) ? std::max(8, grid / 2 / 8 * 8) : grid;      // k_train_b1: one workgroup per CU (see da_train_bwd_impl)
+        if (c->pcsr) {
+            if (s == 0) k_as_b3<true><<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
+            else if (s == 1) k_train_b1p<true><<<grid, 256, 0, st>>>(a);
+            else if (s == 2) k_as_b1<true><<<grid, 256, 0, st>>>(a);
+            else k_as_b0<true><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (s == 0) k_as_b3<false><<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
+            else if (s == 1) k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
+            else if (s == 2) k_as_b1<false><<<grid, 256, 0, st>>>(a);
+            else k_as_b0<false><<<grid, 256, 0, st>>>(a);
+        }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
                                                             c->d_sc[tm], grad_blob, 0);
         // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end
         if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
     }
+    if (c->pcsr)      // k_as_b0<PCSR> left the d z1 rows in the dt blocks: one sum row per source node
+        k_seg_sum_blocks<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(a.gr + (size_t)GR_DT * 16 * (size_t)c->P, c->P, c->seg_rowptr, c->G, a.zsum);
     {
         AgArgs g;
         memset(&g, 0, sizeof(g));
-        g.G = c->G; g.T = c->T; g.zsum = a.zsum; g.y_latent = y_latent; g.timg = c->packed[PL_TAG]; g.d_ylat = d_ylat_out;
+        g.G = c->G; g.T = part_T(c); g.zsum = a.zsum; g.y_latent = y_latent; g.timg = c->packed[PL_TAG]; g.d_ylat = d_ylat_out;
         g.part = a.part; g.n_acc = c->n_acc[TM_AG]; g.n_vec = c->n_vec[TM_AG];
         const int gg = tt_grid(c->G);
         k_as_g<<<gg, 256, 0, st>>>(g);

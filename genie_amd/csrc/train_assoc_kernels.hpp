@@ -37,6 +37,7 @@ __device__ __forceinline__ f32x4 ld30_half(const float* __restrict__ row, int t,
 }
 
 // ---- d s -> do
+template <bool PCSR>
 __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict__ ds, const float* __restrict__ slope) {
     const float a2 = *slope;
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -45,13 +46,23 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
     const long long P = a.P;
     float scal[1] = {0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const long long p = (long long)g * S + (valid ? s : S - 1);
+    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
+                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    for (long long it = it0; it < n_it; it += its) {
+        bool valid;
+        long long p;
+        if (PCSR) {
+            const long long pr = it * 16 + j;
+            valid = pr < P;
+            p = valid ? pr : P - 1;
+        } else {
+            int gi, tb;
+            w.decode(it, gi, tb);
+            const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            p = (long long)g * S + (valid ? s : S - 1);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const f32x4 o = ldb(a.save, AV_O + t, P, p, q);
@@ -67,6 +78,7 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
 // ---- layer 1, l1_t1_1 / l1_t2_1 and the activation of init_trns
 // accumulators: l1_t1_2 {2 x (tr x2, Mask), adjoint 2 x 2} = 10, l1_t2_2 = 10, l1_t1_1 (2 x 2) = 4, l1_t2_1 = 4  -> 28
 // vec: b(l1_t1_2) x2, b(l1_t2_2) x2, mask1 column of l1_t1_2 x2, of l1_t2_2 x2, b(l1_t1_1) x2, b(l1_t2_1) x2 = 12; scal: a, a11, a12
+template <bool PCSR>
 __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
     constexpr int NF4 = (GA1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -88,15 +100,27 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
+                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    for (long long it = it0; it < n_it; it += its) {
+        int g, scn = 0, tb = 0;
+        bool valid;
+        long long p;
+        if (PCSR) {       // 16 consecutive product nodes of an irregular product graph; the source node is per lane
+            const long long pr = it * 16 + j;
+            valid = pr < P;
+            p = valid ? pr : P - 1;
+            g = a.src_of[p];
+        } else {
+            int gi;
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            scn = valid ? s : S - 1;
+            p = (long long)g * S + scn;
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
         const float vm = valid ? 1.f : 0.f;
         const float m1 = a.pg[(long long)g * AS_PG + 31];
         f32x4 mb = {0.f, 0.f, 0.f, 0.f};
@@ -112,10 +136,15 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);       // (own rows requested before the gathers)
-        tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
-                           [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-        tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
-                            [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+        if (PCSR) {      // reversed PRODUCT-level graphs, rows by product-node id
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
+        } else {
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                               [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                                [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
 #pragma unroll
@@ -182,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
 // ---- init_trns and BipartiteGraphReadOutOperator
 // accumulators: init_trns (tile t) x {s, x_latent 0:16, x_latent 16:30, Mask} = 8; fc2 (msg blocks) = 2; fc1 edge_attr columns (t) = 2 -> 12
 // vec: b(init_trns) x2, its mask1 column x2, b(fc2), b(fc1) x2 = 7; scal: activate1, activate2 of the read-out operator
+template <bool PCSR>
 __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
     constexpr int NF4 = (GA0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -203,15 +233,27 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    for (; w.it < w.nitems; w.it += w.stride) {
-        int gi, tb;
-        w.decode(w.it, gi, tb);
-        const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
+                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    for (long long it = it0; it < n_it; it += its) {
+        int g, scn = 0, tb = 0;
+        bool valid;
+        long long p;
+        if (PCSR) {       // 16 consecutive product nodes of an irregular product graph; the source node is per lane
+            const long long pr = it * 16 + j;
+            valid = pr < P;
+            p = valid ? pr : P - 1;
+            g = a.src_of[p];
+        } else {
+            int gi;
+            w.decode(it, gi, tb);
+            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s = tb * 16 + j;
+            valid = s < S;
+            scn = valid ? s : S - 1;
+            p = (long long)g * S + scn;
+        }
         asm volatile("" : "+v"(lane));
-        const int s = tb * 16 + j;
-        const bool valid = s < S;
-        const int scn = valid ? s : S - 1;
-        const long long p = (long long)g * S + scn;
         const float vm = valid ? 1.f : 0.f;
         const float m1 = a.pg[(long long)g * AS_PG + 31];
         f32x4 mb = {0.f, 0.f, 0.f, 0.f}, eb = {0.f, 0.f, 0.f, 0.f};
@@ -240,6 +282,10 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
         // station sums of d z1 of this tile (-> d y_latent[g] and fc1's y_latent columns, k_as_g)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+            if (PCSR) {      // a tile may straddle source nodes: the rows go to the (spent) dt blocks and are summed per source node after the pass
+                if (valid) stb(a.gr, GR_DT + b, P, p, q, dz1[b]);
+                continue;
+            }
             f32x4 v = dz1[b];
             v.x = row_sum16(v.x); v.y = row_sum16(v.y); v.z = row_sum16(v.z); v.w = row_sum16(v.w);
             if (j == 0) *(f32x4*)(a.zsum + ((long long)g * a.T + tb) * 32 + 16 * b + 4 * q) = v;
@@ -263,6 +309,16 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
         acc[9] = outer16(acc[9], dspt, tr16(msg[1], sc, j, q));
     }
     write_partials(a, blockIdx.x * 4 + wave, acc, 12, vec, 7, scal, 2, threadIdx.x & 63, j, q);
+}
+
+// irregular product graph: out[g][16 b + c] = sum over the product nodes of source node g of block b's rows ([2][P][16], row order)
+__global__ void k_seg_sum_blocks(const float* __restrict__ blk, long long P, const int32_t* __restrict__ seg, int G, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * 32) return;
+    const int g = idx >> 5, c = idx & 31, b = c >> 4;
+    float s = 0.f;
+    for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) s += blk[((size_t)b * P + pr) * 16 + (c & 15)];
+    out[idx] = s;
 }
 
 // ---- per source node: d y_latent[g] = fc1[:, 0:30]^T sum_s d z1[g, s]; fc1[:, 0:30] += (sum_s d z1) (x) y_latent[g]

@@ -851,9 +851,6 @@ class GCN_Detection_Network_extended(nn.Module):
         source queries, module.py:981) only with `x_query_src_cart` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
-        if self._hip._n_prod is not None and want_latents:
-            raise NotImplementedError("training-mode 4-output forward: Cartesian product graphs only (not use_subgraph); "
-                                      "forward_fixed_source trains on irregular product graphs")
         hp = self._hip
         hp.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
@@ -930,7 +927,7 @@ class GCN_Detection_Network_extended(nn.Module):
         in HIP: the shared front and read-outs, the P-sized association heads (genie_assoc_fwd; under use_updated_model_definition
         / use_absolute_pos their static per-station / per-source-node terms are added inside the same kernels), LocalSliceLgCollapse
         P / S (genie_lslc_fwd) and the arrival head (genie_arrivals_fwd). In train() mode with gradients enabled the same modules
-        differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; all three model definitions, Cartesian product graphs)."""
+        differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; all three model definitions on Cartesian product graphs, the default one on irregular ones too)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed")
         if getattr(self, "A_edges_p", None) is None or getattr(self, "tlatent", None) is None:

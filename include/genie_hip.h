@@ -322,7 +322,8 @@ int genie_set_tail_grid(genie_ctx* ctx, int readout_workgroups, int sa_workgroup
  *     DataAggregation parameter and of Bipartite_ReadIn.fc1 / activate1, laid out like the weight mirror
  *     (genie_weights_offset(i), genie_weights_blob_floats() floats; entries of other parameters are zero). `scratch`:
  *     genie_train_scratch_floats(ctx) floats. Deterministic (fixed-order reduction of per-wave partials).
- * Unsharded Cartesian product graphs. With genie_set_edge_features / genie_set_absolute_pos in force (the two other model
+ * Unsharded product graphs, Cartesian or irregular (genie_ctx_create_subgraph: tiles of 16 consecutive product nodes, the transposed
+ * means of the backward over the reversed PRODUCT-level graphs; round 4). With genie_set_edge_features / genie_set_absolute_pos in force (the two other model
  * definitions) the forward is those variants' inference kernels and the backward adds the gradients of their static-term weights
  * ("<layer>.weight_pos", "init_trns.weight_abs"): such a term is W_f f[n] with f a fixed table over the stations or the source
  * nodes, so dW_f = sum_n (sum of the kept gradient rows over the product nodes of n) (x) f[n] -- per-station / per-source-node
@@ -376,7 +377,7 @@ int genie_train_bwd(genie_ctx* ctx, const float* slice, const float* mask, const
  * wv buffers of the current workspace slot: issue it after the DataAggregation stage 2 of the same window. Parameters under
  * their state_dict names ("BipartiteGraphReadOutOperator.*", "DataAggregationAssociationPhase.*"; the static-term columns of the two
  * other model definitions under "<name>_pos" / "<name>_abs", as for DataAggregation).
- * Unsharded Cartesian product graphs only. */
+ * Unsharded product graphs (Cartesian, or irregular since round 4: product-level CSR forms of the kernels). */
 size_t genie_assoc_workspace_bytes(const genie_ctx* ctx);
 int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src, const float* x_latent, const float* mask,
                     const float* edge_attr, float* out, void* assoc_ws, void* ws, void* stream);
@@ -396,7 +397,7 @@ int genie_knn(const float* x_context, int n_context, const float* x_query, int n
  *     detached at module.py:990) and grad_blob (genie_weights_blob_floats() floats, zeroed by the call, weight-mirror layout): gradients of
  *     every BipartiteGraphReadOutOperator / DataAggregationAssociationPhase parameter. Four P-sized passes (k_as_b3, k_train_b1<true>,
  *     k_as_b1, k_as_b0: the structure of DataAggregation's backward) + one G-sized (k_as_g); `scratch`:
- *     genie_assoc_train_scratch_floats(ctx) floats. Deterministic. Unsharded Cartesian product graphs; under the two other model
+ *     genie_assoc_train_scratch_floats(ctx) floats. Deterministic. Unsharded product graphs, Cartesian or irregular; under the two other model
  *     definitions the static-term weight gradients are added as in genie_da_train_bwd. */
 size_t genie_assoc_train_save_floats(const genie_ctx* ctx);
 size_t genie_assoc_train_scratch_floats(const genie_ctx* ctx);

@@ -1270,7 +1270,7 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
 
 
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_edges_abspos_18x50"])
+                                  "assoc_edges_abspos_18x50", "assoc_subgraph_14x50"])
 def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name):
     """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
     mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones. Every module
@@ -1291,7 +1291,11 @@ def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name)
                                                 use_absolute_pos="abspos" in name)
     net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
     net.train()
-    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    if "pairs" in z.files:      # `use_subgraph`: irregular product graph (PCSR forms of every P-sized pass, both directions)
+        A_src_in_sta = torch.from_numpy(z["pairs"]).long()
+        A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(z["A_sta_sta"], z["A_src_src"], z["pairs"])
+    else:
+        A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
     ea = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.to(DEV))
     ea_flip = graph.GraphEdges(x=t("edge_attr"), edge_index=A_src_in_prod.flip(0).contiguous().to(DEV))
     graphs = (A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea_flip, A_src_in_sta.to(DEV), t("A_src_src", torch.long),
