@@ -1272,6 +1272,9 @@ namespace {
 // edge-feature variant takes the generic stage-1 kernel).
 // The f16x2 kernels run when the shape admits them AND the precision mode says so: auto = while the fp16 range guard holds for the
 // committed weights (k_h2_range), else the fp32-MFMA kernels take over -- no environment variable, no non-finite output.
+// rows of the static edge-feature tables (DataAggregationEdges): per station / per source node, per product node on an irregular graph
+long long edge_rows_sta(const genie_ctx* c) { return c->pcsr ? c->P : c->S; }
+long long edge_rows_src(const genie_ctx* c) { return c->pcsr ? c->P : c->G; }
 bool h2_on(const genie_ctx* c) { return c->use_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool pcsr_h2_on(const genie_ctx* c) { return c->pcsr_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !h2_on(c)); }
@@ -1356,10 +1359,11 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
                                                                                H2_NBIAS * 32 + 16);
     k_pack_h2<<<(S2H_FRAGS * 64 + 32 + 16 + 255) / 256, 256, 0, st>>>(c->raw, c->d_s2htbl, c->packed_s2h, S2H_FRAGS, 32 + 16);
     if (c->has_edges) {
-        k_edge_bias<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
-                                                            c->mpos_sta, c->S, c->ebias_sta);
-        k_edge_bias<<<(c->G * 48 + 255) / 256, 256, 0, st>>>(c->raw, g_params[W_DA_L1T22_P].off, g_params[W_DA_L2T22_P].off,
-                                                            c->mpos_src, c->G, c->ebias_src);
+        const long long ns = edge_rows_sta(c), ng = edge_rows_src(c);
+        k_edge_bias<<<(unsigned)((ns * 48 + 255) / 256), 256, 0, st>>>(c->raw, g_params[W_DA_L1T12_P].off, g_params[W_DA_L2T12_P].off,
+                                                                      c->mpos_sta, (int)ns, c->ebias_sta);
+        k_edge_bias<<<(unsigned)((ng * 48 + 255) / 256), 256, 0, st>>>(c->raw, g_params[W_DA_L1T22_P].off, g_params[W_DA_L2T22_P].off,
+                                                                      c->mpos_src, (int)ng, c->ebias_src);
         if (c->sta_perm) {
             if (!c->ebias_sta_p) HIP_TRY(hipMalloc((void**)&c->ebias_sta_p, sizeof(float) * 48 * (size_t)c->S));
             k_permute_sta_rows<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->ebias_sta, c->S, 48, c->sta_inv, c->S, c->ebias_sta_p);
@@ -1379,8 +1383,8 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         for (int k = 0; k < RG_N; ++k) ra.off[k] = g_params[ids[k]].off;
         ra.abs_sta = c->abs_sta; ra.n_abs_sta = c->abs_sta ? c->S * 4 : 0;
         ra.abs_src = c->abs_src; ra.n_abs_src = c->abs_src ? (long long)c->G_ext * 4 : 0;
-        ra.eb_sta = c->has_edges ? c->ebias_sta : nullptr; ra.n_eb_sta = c->has_edges ? (long long)c->S * 48 : 0;
-        ra.eb_src = c->has_edges ? c->ebias_src : nullptr; ra.n_eb_src = c->has_edges ? (long long)c->G * 48 : 0;
+        ra.eb_sta = c->has_edges ? c->ebias_sta : nullptr; ra.n_eb_sta = c->has_edges ? edge_rows_sta(c) * 48 : 0;
+        ra.eb_src = c->has_edges ? c->ebias_src : nullptr; ra.n_eb_src = c->has_edges ? edge_rows_src(c) * 48 : 0;
         {   // long tables: partial maxima by many workgroups first (d_range[4 ..] holds 4 x RG_PART of them)
             const float** tp[4] = {&ra.abs_sta, &ra.abs_src, &ra.eb_sta, &ra.eb_src};
             long long* tn[4] = {&ra.n_abs_sta, &ra.n_abs_src, &ra.n_eb_sta, &ra.n_eb_src};
@@ -2106,20 +2110,27 @@ int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_
 
 int genie_set_edge_features(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_edge_features: null context");
-    if (c->pcsr && pos_sta) return fail(GENIE_ERR_STATE, "genie_set_edge_features: not available on an irregular product graph");
     hipStream_t st = (hipStream_t)stream;
     if (!pos_sta || !pos_src) {      // back to plain DataAggregation
         c->has_edges = false;
         return GENIE_OK;
     }
+    // irregular product graph: the mean runs over the PRESENT neighbours of a product node, so both tables are per product node and the
+    // positions arrive per product node too ([n_prod, 3]: the station's, the source node's)
+    const long long ns = edge_rows_sta(c), ng = edge_rows_src(c);
     if (!c->mpos_sta) {
-        HIP_TRY(hipMalloc((void**)&c->mpos_sta, sizeof(float) * 4 * (size_t)c->S));
-        HIP_TRY(hipMalloc((void**)&c->mpos_src, sizeof(float) * 4 * (size_t)c->G));
-        HIP_TRY(hipMalloc((void**)&c->ebias_sta, sizeof(float) * 48 * (size_t)c->S));
-        HIP_TRY(hipMalloc((void**)&c->ebias_src, sizeof(float) * 48 * (size_t)c->G));
+        HIP_TRY(hipMalloc((void**)&c->mpos_sta, sizeof(float) * 4 * (size_t)ns));
+        HIP_TRY(hipMalloc((void**)&c->mpos_src, sizeof(float) * 4 * (size_t)ng));
+        HIP_TRY(hipMalloc((void**)&c->ebias_sta, sizeof(float) * 48 * (size_t)ns));
+        HIP_TRY(hipMalloc((void**)&c->ebias_src, sizeof(float) * 48 * (size_t)ng));
     }
-    k_edge_feat<<<(c->S + 255) / 256, 256, 0, st>>>(c->sta_rowptr, c->sta_col, c->S, pos_sta, c->scale_rel, c->mpos_sta);
-    k_edge_feat<<<(c->G + 255) / 256, 256, 0, st>>>(c->src_rowptr, c->src_col, c->G, pos_src, c->scale_rel, c->mpos_src);
+    if (c->pcsr) {
+        k_edge_feat<<<(unsigned)((ns + 255) / 256), 256, 0, st>>>(c->p_sta_rowptr, c->p_sta_col, (int)ns, pos_sta, c->scale_rel, c->mpos_sta);
+        k_edge_feat<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(c->p_src_rowptr, c->p_src_col, (int)ng, pos_src, c->scale_rel, c->mpos_src);
+    } else {
+        k_edge_feat<<<(c->S + 255) / 256, 256, 0, st>>>(c->sta_rowptr, c->sta_col, c->S, pos_sta, c->scale_rel, c->mpos_sta);
+        k_edge_feat<<<(c->G + 255) / 256, 256, 0, st>>>(c->src_rowptr, c->src_col, c->G, pos_src, c->scale_rel, c->mpos_src);
+    }
     HIP_TRY(hipGetLastError());
     c->has_edges = true;
     c->dirty = true;
@@ -2278,8 +2289,14 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
         const long long nitems = (c->P + 31) / 32;
         const int grid = (int)std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b);
-        if (c->P * XROW >= (1ll << 32)) k_stage1_h2<8, 15, false, true, false, true><<<grid, H2_THREADS, 0, st>>>(a);
-        else k_stage1_h2<8, 15, false, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+        const bool bigp = c->P * XROW >= (1ll << 32);
+        if (c->has_edges) {
+            if (bigp) k_stage1_h2<8, 15, true, true, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+            else k_stage1_h2<8, 15, true, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+        } else {
+            if (bigp) k_stage1_h2<8, 15, false, true, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+            else k_stage1_h2<8, 15, false, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
+        }
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
         k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);

@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }
-        stage1_dense(a, lw, lbias, lane, q, valid, p, 0, 0, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
+        // (DataAggregationEdges on an irregular graph: the static-term tables are per product node, indexed by p on both sides)
+        stage1_dense(a, lw, lbias, lane, q, valid, p, (int)p, (int)p, mq, x0, x1, n1a, n1b, n2a, n2b, a1, a21, a22);
     }
 }
 
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     // PCSR: irregular product graph (use_subgraph). A wave item is 32 consecutive product nodes; the neighbours of a node are
     // product-node ids from the product-level CSRs (at most KS / KP of them: a missing one is the node itself with weight 0,
     // the mean of an empty neighbourhood is 0); everything after the neighbour phase is the same code.
-    static_assert(!(PCSR && (EDGES || ABS)), "irregular product graphs: default model definition only");
+    static_assert(!(PCSR && ABS), "irregular product graphs: no use_absolute_pos");   // (EDGES: the static terms are per PRODUCT node there)
     typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
     constexpr int NF4 = H2_IMG_FLOATS / 4;
     __shared__ f32x4 lw[NF4];
@@ -720,8 +721,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         if (EDGES) {   // DataAggregationEdges: static per-station / per-source-node terms of layer 1
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 8 * b + 4 * h);
-                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 8 * b + 4 * h);
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (PCSR ? p : (long long)sc) * 48 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (PCSR ? p : (long long)g) * 48 + 8 * b + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { acc[0][4 * b + e] += es[e]; acc[1][4 * b + e] += eg[e]; }
             }
@@ -762,8 +763,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         if (EDGES) {   // ... and of the node-local layer-2 block c = [o1 (15), 0 | o2 (15), 0]
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 es = *(const f32x4*)(a.eb_sta + (long long)sc * 48 + 32 + 8 * b + 4 * h);
-                const f32x4 eg = *(const f32x4*)(a.eb_src + (long long)g * 48 + 32 + 8 * b + 4 * h);
+                const f32x4 es = *(const f32x4*)(a.eb_sta + (PCSR ? p : (long long)sc) * 48 + 32 + 8 * b + 4 * h);
+                const f32x4 eg = *(const f32x4*)(a.eb_src + (PCSR ? p : (long long)g) * 48 + 32 + 8 * b + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o3[2][4 * b + e] += es[e]; o3[2][8 + 4 * b + e] += eg[e]; }
             }

@@ -1089,12 +1089,18 @@ class HipPath(object):
 
     def set_edge_features(self, pos_sta, pos_src):
         """DataAggregationEdges (module.py:102-174): station / source-node positions [n,3] from which the library derives
-        the mean edge features; `None, None` switches back to plain DataAggregation (genie_set_edge_features)."""
+        the mean edge features; `None, None` switches back to plain DataAggregation (genie_set_edge_features). On an irregular product
+        graph both arguments are [n_prod, 3]: the station's and the source node's position of every product node (the mean edge
+        feature of a node runs over its present neighbours, so the static terms are per product node there)."""
         if pos_sta is None or pos_src is None:
             _lib.check(self.lib.genie_set_edge_features(self.ctx, None, None, _stream()), "genie_set_edge_features")
             return
-        pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
-        pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
+        if self._n_prod is not None:      # irregular product graph: positions per PRODUCT node (the station's, the source node's)
+            pos_sta = _f32(pos_sta, "pos_sta", (self._n_prod, 3))
+            pos_src = _f32(pos_src, "pos_src", (self._n_prod, 3))
+        else:
+            pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
+            pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
         _lib.check(self.lib.genie_set_edge_features(self.ctx, _ptr(pos_sta), _ptr(pos_src), _stream()), "genie_set_edge_features")
         torch.cuda.current_stream(self.device).synchronize()     # the position tensors may be temporaries
 

@@ -750,8 +750,8 @@ class GCN_Detection_Network_extended(nn.Module):
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
         A_src_in_sta (grouped by source node) and the edge lists are irregular: product-level CSRs, generic HIP kernels."""
-        if self.use_updated_model_definition or self.use_absolute_pos:
-            raise NotImplementedError("use_updated_model_definition / use_absolute_pos with use_subgraph")
+        if self.use_absolute_pos:
+            raise NotImplementedError("use_absolute_pos with use_subgraph")
         pairs = torch.as_tensor(A_src_in_sta).long().cpu()
         n_prod = int(pairs.shape[1])
         src_of = pairs[1]
@@ -767,6 +767,12 @@ class GCN_Detection_Network_extended(nn.Module):
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        self._hip.set_phase_types(self.use_phase_types)
+        if self.use_updated_model_definition:       # module.py:1059-1072 on the irregular edge lists: positions per product node
+            if pos_loc is None or pos_src is None:
+                raise ValueError("use_updated_model_definition=True needs station and source positions")
+            pl, ps = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
+            self._hip.set_edge_features(pl[pairs[0].to(dev)].contiguous(), ps[pairs[1].to(dev)].contiguous())
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
         self._edge_attr_version = self._edge_attr._version
 

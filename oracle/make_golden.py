@@ -411,6 +411,29 @@ def main_subgraph():
     print("wrote subgraph_builder_14x50.npz: %d product nodes" % out[5].shape[1])
 
 
+def main_subgraph_edges():
+    """`python oracle/make_golden.py --subgraph-edges`: `use_updated_model_definition: True` on an irregular product graph
+    (`use_subgraph: True`): the mean edge feature of a product node runs over its PRESENT neighbours only, so the static term is per
+    product node there. Fixtures `subgraph_edges_14x50` (2 outputs) and `assoc_subgraph_edges_14x50` (4 outputs); geometry and node list
+    of `--subgraph`."""
+    ref = _import_reference(updated_definition=True)
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    rng = np.random.default_rng(72)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(d.shape[0])[:, None], np.argsort(d, axis=1)[:, :6]] = True
+    keep |= rng.random(d.shape) < 0.12
+    src_i, sta_i = np.nonzero(keep)
+    pairs = np.stack((sta_i, src_i))
+    full = syn.make_window(geom, 180, seed=73)
+    rows = src_i * geom.n_sta + sta_i
+    run_case(ref, "subgraph_edges_14x50", geom, full["Slice"][rows], full["Mask"][rows], perturb_prelu=True, window=full,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"), pairs=pairs)
+    run_assoc_case(ref, "assoc_subgraph_edges_14x50", geom, full, pairs=pairs)
+
+
 def main_scaled():
     """`python oracle/make_golden.py --scaled`: (vi) config-1 shape with every Linear weight multiplied by a common gain chosen
     so that max|y|, max|x| are O(1) (with default-initialised weights the outputs are ~0.03 and the 1e-5 absolute tolerance of
@@ -482,6 +505,8 @@ def main():
         return main_postproc()
     if "--scaled" in sys.argv:
         return main_scaled()
+    if "--subgraph-edges" in sys.argv:
+        return main_subgraph_edges()
     if "--edges-abspos" in sys.argv:
         return main_edges_abspos()
     if "--edges" in sys.argv:

@@ -250,6 +250,36 @@ def test_use_absolute_pos_forward_fixed_source(name):
     assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
 
 
+@pytest.mark.parametrize("stage1", ["default", "f32"])
+def test_updated_model_definition_on_an_irregular_product_graph(stage1, monkeypatch):
+    """`use_updated_model_definition: True` with `use_subgraph: True`: the mean edge feature of a product node runs over its PRESENT
+    neighbours, so the static terms are per product node (genie_set_edge_features with positions per product node: `k_edge_feat` on
+    the product-level CSRs, `[n_prod, 48]` term tables indexed by product node in k_stage1_h2<EDGES, .., PCSR> / k_stage1_pcsr).
+    Fixture: the reference imported with the flag, run on the irregular graph of `subgraph_14x50`."""
+    if stage1 == "f32":
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
+    c = Case("subgraph_edges_14x50")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=True)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), ea, ea, A_src_in_sta.to(DEV), c.A_src_src.to(DEV),
+                        None, None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    assert net._hip._n_prod is not None
+    with torch.no_grad():
+        y, x = net.forward_fixed_source(c.Slice.to(DEV), c.Mask.to(DEV), None, None, None, c.locs.float().to(DEV),
+                                        c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+        hp = net._hip
+        _, _, h0, h1 = hp.da_stage1(c.Slice.to(DEV), c.Mask.to(DEV), debug=True)
+        x_latent, bip = hp.da_stage2_bipartite(c.Mask.to(DEV), c.edge_attr.to(DEV), want_x_latent=True)
+    for k, v in (("h0", h0), ("h1", h1), ("x_latent", x_latent), ("bip", bip)):
+        ref = c.ref(k)
+        assert max_abs(v.cpu(), ref) <= rel_tol(ref), (k, max_abs(v.cpu(), ref))
+    assert max_abs(y.cpu(), c.ref("y")) <= 1e-5 and max_abs(x.cpu(), c.ref("x")) <= 1e-5
+    assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
+
+
 def test_both_model_options_together_forward_fixed_source():
     """`use_updated_model_definition: True` with `use_absolute_pos: True` (the reference's classes take both, module.py:103-109,
     :1056): the edge-feature terms and the position columns are both static additive terms of the stage-1 pre-activations

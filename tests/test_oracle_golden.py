@@ -120,3 +120,19 @@ def test_oracle_with_both_model_options_matches_reference():
     for k in ["bip", "sa3", "y", "x"]:
         ref = c.ref(k + "64")
         assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
+
+
+def test_oracle_updated_model_on_irregular_product_graph_matches_reference():
+    """`use_updated_model_definition: True` on a `use_subgraph: True` graph: the per-edge position features of the reference
+    (module.py:1059-1072) on the irregular edge lists; fixture from the reference imported with the flag, run on such a graph."""
+    c = Case("subgraph_edges_14x50")
+    assert c.edges_variant and "pairs" in c.z.files
+    out = c.oracle_forward(torch.float32)
+    assert out["x_latent"].shape[0] == c.z["pairs"].shape[1] < c.S * c.G
+    for k in ["h0", "h1", "x_latent", "bip", "sa3", "y", "x"]:
+        ref = c.ref(k)
+        assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
