@@ -42,8 +42,10 @@ struct AsPreOffs { int ro_fc1_w, ro_fc1_b, as_init_w, as_l1t12_w, as_l1t22_w, as
 // :472-480); under use_absolute_pos the station / source positions / (3 scale_rel) (abs_sta [S][4] / abs_src [G][4]) are appended to
 // the head's input (module.py:987-988, 6 more columns of init_trns). Both are per-station / per-source-node ADDITIVE terms of a
 // pre-activation: the source-node ones are folded into pg, the station ones are ps [S][AS_PS]: [0:30] init_trns, [32:62]
-// l1_t1_2, [64:79] l2_t1_2.
-constexpr int AS_PS = 80;
+// l1_t1_2, [64:79] l2_t1_2. On an irregular product graph under use_updated_model_definition the mean edge feature of a node runs over its
+// PRESENT neighbours: ps is then [n_prod][AS_PS], indexed by product node, and also carries the source-side terms ([80:110] l1_t2_2,
+// [112:127] l2_t2_2) that pg holds per source node on Cartesian graphs.
+constexpr int AS_PS = 128;
 __device__ __forceinline__ float dot4w(const float* __restrict__ w, const float* __restrict__ m, int n) {
     float v = 0.f;
     for (int c = 0; c < n; ++c) v = fmaf(w[c], m[c], v);
@@ -78,15 +80,18 @@ __global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw
     pg[idx] = v;
 }
 
-__global__ void k_assoc_ps(const float* __restrict__ raw, AsPreOffs o, int S, const float* __restrict__ mpos_sta,
-                           const float* __restrict__ abs_sta, float* __restrict__ ps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_assoc_ps(const float* __restrict__ raw, AsPreOffs o, long long S, const float* __restrict__ mpos_sta,
+                           const float* __restrict__ abs_sta, const float* __restrict__ mpos_src_p, float* __restrict__ ps) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * AS_PS) return;
-    const int s = idx / AS_PS, k = idx - s * AS_PS;
+    const long long s = idx / AS_PS;
+    const int k = (int)(idx - s * AS_PS);
     float v = 0.f;
     if (k < 30) { if (abs_sta) v = dot4w(raw + o.as_init_abs + k * 6, abs_sta + s * 4, 3); }
     else if (k >= 32 && k < 62) { if (mpos_sta) v = dot4w(raw + o.as_l1t12_p + (k - 32) * 4, mpos_sta + s * 4, 4); }
     else if (k >= 64 && k < 79) { if (mpos_sta) v = dot4w(raw + o.as_l2t12_p + (k - 64) * 4, mpos_sta + s * 4, 4); }
+    else if (k >= 80 && k < 110) { if (mpos_src_p) v = dot4w(raw + o.as_l1t22_p + (k - 80) * 4, mpos_src_p + s * 4, 4); }      // rows = product nodes
+    else if (k >= 112 && k < 127) { if (mpos_src_p) v = dot4w(raw + o.as_l2t22_p + (k - 112) * 4, mpos_src_p + s * 4, 4); }
     ps[idx] = v;
 }
 
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
             valid = pr < a.Pn;
             pi = pu = valid ? pr : a.Pn - 1;
             g = a.src_of[pi];
-            su = 0;
+            su = (int)pi;          // (ps, when present, is per product node on an irregular graph)
         } else {
             w.decode(it, gi, tb);
             g = __builtin_amdgcn_readfirstlane(a.order[gi]);
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
             valid = pr < a.Pn;
             pi = pu = valid ? pr : a.Pn - 1;
             g = a.src_of[pi];
-            su = 0;
+            su = (int)pi;          // (ps, when present, is per product node on an irregular graph)
             pl = min(it * 16 + jl, a.Pn - 1);
         } else {
             w.decode(it, gi, tb);
@@ -319,6 +324,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         if (a.ps != nullptr) {
             acc[0] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 32 + 4 * q);
             acc[1] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 48 + 4 * q);
+            if (PCSR) {
+                acc[2] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 80 + 4 * q);
+                acc[3] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 96 + 4 * q);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) w4[k] = lw[GB_L1(k >> 1, k & 1, 0) * 64 + lane];
@@ -357,7 +366,10 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
         for (int k = 0; k < 4; ++k) o6[k] = *(const f32x4*)(lbias + (4 + k) * 16 + 4 * q);
         o6[4] = *(const f32x4*)(lbias + 8 * 16 + 4 * q) + *(const f32x4*)(pg + 128 + 4 * q);
         o6[5] = *(const f32x4*)(lbias + 9 * 16 + 4 * q) + *(const f32x4*)(pg + 144 + 4 * q);
-        if (a.ps != nullptr) o6[4] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 64 + 4 * q);
+        if (a.ps != nullptr) {
+            o6[4] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 64 + 4 * q);
+            if (PCSR) o6[5] += *(const f32x4*)(a.ps + (long long)su * AS_PS + 112 + 4 * q);
+        }
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll

@@ -3111,7 +3111,9 @@ int static_term_grads(genie_ctx* c, const float* gr, float* scr, float* grad_blo
     float* dpart = r_sta + (size_t)c->S * 16;
     for (const Term& t : terms) {
         const float* blk = gr + (size_t)t.blk * 16 * (size_t)c->P;
-        if (t.sta) {
+        if (c->pcsr) {      // irregular product graph: the tables are per product node, the gradient rows contract with them as they are
+            k_static_dw<<<SG_SLICES, 256, 0, st>>>(blk, t.f, (int)c->P, dpart);
+        } else if (t.sta) {
             k_gr_sum_sta<<<dim3((c->S * 4 + 255) / 256, SG_CHUNKS), 256, 0, st>>>(blk, c->S, c->G, p_sta);
             k_gr_sum_parts<<<(c->S * 16 + 63) / 64, 64, 0, st>>>(p_sta, SG_CHUNKS, c->S * 16, r_sta);
             k_static_dw<<<SG_SLICES, 256, 0, st>>>(r_sta, t.f, c->S, dpart);
@@ -3470,10 +3472,15 @@ void assoc_pre_launch(genie_ctx* c, const float* y_latent, const float* mask_src
     o.as_l2t12_w = g_params[W_AS_L2T12_W].off; o.as_l2t22_w = g_params[W_AS_L2T22_W].off;
     o.as_init_abs = g_params[W_AS_INIT_ABS].off; o.as_l1t12_p = g_params[W_AS_L1T12_P].off; o.as_l1t22_p = g_params[W_AS_L1T22_P].off;
     o.as_l2t12_p = g_params[W_AS_L2T12_P].off; o.as_l2t22_p = g_params[W_AS_L2T22_P].off;
-    const float* mpos_src = c->has_edges ? c->mpos_src : nullptr;
+    // irregular product graph: the edge-feature terms of BOTH sides are per product node (ps rows = product nodes), none in pg
+    const float* mpos_src = (c->has_edges && !c->pcsr) ? c->mpos_src : nullptr;
     const float* mpos_sta = c->has_edges ? c->mpos_sta : nullptr;
     k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, mpos_src, c->abs_src, c->as_pg);
-    if (c->as_ps) k_assoc_ps<<<(c->S * AS_PS + 255) / 256, 256, 0, st>>>(c->raw, o, c->S, mpos_sta, c->abs_sta, c->as_ps);
+    if (c->as_ps) {
+        const long long rows = edge_rows_sta(c);
+        k_assoc_ps<<<(unsigned)((rows * AS_PS + 255) / 256), 256, 0, st>>>(c->raw, o, rows, mpos_sta, c->abs_sta,
+                                                                          (c->has_edges && c->pcsr) ? c->mpos_src : nullptr, c->as_ps);
+    }
 }
 }  // namespace
 
@@ -3495,7 +3502,7 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if ((rc = ensure_packed(c, st))) return rc;
     if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
     const bool variant = c->has_edges || c->abs_sta != nullptr;
-    if (variant && !c->as_ps) HIP_TRY(hipMalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)c->S));
+    if (variant && !c->as_ps) HIP_TRY(hipMalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)edge_rows_sta(c)));
     assoc_pre_launch(c, y_latent, mask_src, st);
     if (save) { c->force_generic = 1; c->train_save = save; }      // training forward: caller's station order, pre-activations kept
     DaArgs d = make_da_args(c, (float*)ws);
@@ -3603,8 +3610,11 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
                                                             c->d_sc[tm], grad_blob, 0);
-        // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end
-        if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
+        // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end;
+        // on an irregular product graph the layer-1 ones after k_as_b1 already (k_as_b0<PCSR> leaves its d z1 rows in the dt blocks)
+        if (variant && c->pcsr) {
+            if ((s == 1 || s == 2) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 2, true))) return rc;
+        } else if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
     }
     if (c->pcsr)      // k_as_b0<PCSR> left the d z1 rows in the dt blocks: one sum row per source node
         k_seg_sum_blocks<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(a.gr + (size_t)GR_DT * 16 * (size_t)c->P, c->P, c->seg_rowptr, c->G, a.zsum);

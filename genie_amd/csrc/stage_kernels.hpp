@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
         f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
         x0 = MFMA16(wi0.y, mq, x0);
         x1 = MFMA16(wi1.y, mq, x1);
+        if (a.save != nullptr && valid) {      // training forward: the pre-activation of h0
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 0) * a.Pn + p) * 16 + 4 * q) = x0;
+            *(f32x4*)(a.save + ((size_t)(SV_Z0 + 1) * a.Pn + p) * 16 + 4 * q) = x1;
+        }
         x0 = prelu4u(x0, a0);
         x1 = prelu4u(x1, a0);
         f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;

@@ -787,8 +787,8 @@ class GCN_Detection_Network_extended(nn.Module):
         `edge_attr(pairs) -> [N, 3]`, or None = `(pos_src[source] - pos_loc[station]) / scale_pairwise_sta_in_src_distances`
         (:811). Returns (A_sta_sta, A_src_src, A_src_in_sta) with A_src_in_sta int64 [2, N] = the product nodes as
         (station, source) pairs in node order; Slice / Mask / edge_attr rows follow that order."""
-        if self.use_updated_model_definition or self.use_absolute_pos:
-            raise NotImplementedError("use_updated_model_definition / use_absolute_pos with use_subgraph")
+        if self.use_absolute_pos:
+            raise NotImplementedError("use_absolute_pos with use_subgraph")
         dev = next(self.parameters()).device
         pos_loc, pos_src = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
@@ -801,6 +801,9 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        self._hip.set_phase_types(self.use_phase_types)
+        if self.use_updated_model_definition:
+            self._hip.set_edge_features(pos_loc[pairs[0].long()].contiguous(), pos_src[pairs[1].long()].contiguous())
         if edge_attr is None:
             edge_attr = (pos_src[pairs[1]] - pos_loc[pairs[0]]) / float(scale_pairwise_sta_in_src_distances)
         elif callable(edge_attr):

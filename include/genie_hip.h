@@ -73,9 +73,9 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
  * (process_utils.py:790-794), so `seg_rowptr[g] .. seg_rowptr[g+1]` is the row range of source node g (seg_rowptr[n_grid] =
  * n_prod), and both DataAggregation edge sets are CSR lists over product-node ids: p_sta_* = in-edges of A_in_sta (same
  * source node, neighbouring stations), p_src_* = in-edges of A_in_src, in stable edge order. src_rowptr / src_col = the base
- * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The f16x2 / pipelined
- * kernels (which rely on p = g * n_sta + s) are not used; genie_embed_window, genie_set_edge_features and genie_nbr_mean are
- * unavailable on such a context. */
+ * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The kernels that rely on
+ * p = g * n_sta + s are not used (product-level CSR forms instead, inference and training); genie_embed_window, genie_set_absolute_pos
+ * and genie_nbr_mean are unavailable on such a context, genie_set_edge_features takes positions per product node. */
 int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod,
                               const int32_t* p_sta_rowptr, const int32_t* p_sta_col,
                               const int32_t* p_src_rowptr, const int32_t* p_src_col, const int32_t* seg_rowptr,
@@ -144,7 +144,9 @@ int genie_set_absolute_pos(genie_ctx* ctx, const float* pos_sta, const float* po
  * [n_grid_ext,3] device pointers, fp32) and applies the 4 edge-feature columns of l1_t?_2 / l2_t?_2 (registry entries
  * "DataAggregation.l?_t?_2.weight_pos", [out,4]) as per-node additive terms. The other columns keep the DataAggregation
  * layout: the caller passes `l1_t?_2.weight[:, [0:60, 64:68]]` and `l2_t?_2.weight[:, [0:90, 94:98]]` under the usual names.
- * Null positions switch back to plain DataAggregation. */
+ * Null positions switch back to plain DataAggregation. On an irregular product graph (genie_ctx_create_subgraph) the mean runs over
+ * the PRESENT neighbours of a product node: both arguments are then [n_prod, 3] (the station's / the source node's position of every
+ * product node) and the additive terms are per product node. */
 int genie_set_edge_features(genie_ctx* ctx, const float* pos_sta, const float* pos_src, void* stream);
 
 /*

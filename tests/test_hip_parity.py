@@ -597,19 +597,22 @@ def test_training_mode_forward_and_gradients_match_oracle_autograd(name):
                                     c.x_grid.float(), c.x_query.float(), c.t_query.float())
     ((yo * ay).sum() + (xo * ax).sum()).backward()
     checked = 0
+    gmax = max(float(v.grad.abs().max()) for v in w.values() if v.grad is not None)
     for k, p in net.named_parameters():
         if w[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         ref = w[k].grad
         assert p.grad is not None, k
-        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        # relative to the gradient's OWN scale (1e-5 of max(1, scale) hid a missing save once); scalars that are sums of cancelling
+        # terms get a floor of 1e-3 of the largest gradient of the model
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3 * gmax) + 1e-12
         assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
         checked += 1
     assert checked >= 80          # every tensor of DataAggregation, Bipartite_ReadIn, SpatialAggregation1..3 and the read-outs
 
 
-@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13", "edges_abspos_12x60"])
+@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13", "edges_abspos_12x60", "subgraph_edges_14x50"])
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(name, stage1, monkeypatch):
     """a-8 / a-9: the training step of `forward_fixed_source` under `use_updated_model_definition` (DataAggregationEdges,
@@ -659,13 +662,14 @@ def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(na
                                     c.x_grid.float(), c.x_query.float(), c.t_query.float(), **okw)
     ((yo * ay).sum() + (xo * ax).sum()).backward()
     checked = 0
+    gmax = max(float(v.grad.abs().max()) for v in w.values() if v.grad is not None)
     for k, p in net.named_parameters():
         if w[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         ref = w[k].grad
         assert p.grad is not None and tuple(p.grad.shape) == tuple(ref.shape), k
-        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3 * gmax) + 1e-12      # own scale; floor for scalars that are sums of cancelling terms
         assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
         checked += 1
     assert checked >= 80
@@ -713,13 +717,14 @@ def test_training_step_on_an_irregular_product_graph_matches_oracle_autograd(sta
                                     c.x_grid.float(), c.x_query.float(), c.t_query.float())
     ((yo * ay).sum() + (xo * ax).sum()).backward()
     checked = 0
+    gmax = max(float(v.grad.abs().max()) for v in w.values() if v.grad is not None)
     for k, p in net.named_parameters():
         if w[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         ref = w[k].grad
         assert p.grad is not None, k
-        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3 * gmax) + 1e-12      # own scale; floor for scalars that are sums of cancelling terms
         assert max_abs(p.grad.cpu(), ref) <= tol, (k, max_abs(p.grad.cpu(), ref), tol)
         checked += 1
     assert checked >= 80
@@ -1249,7 +1254,7 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50"])
+                                  "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50", "assoc_subgraph_edges_14x50"])
 def test_forward_fixed_and_forward_four_outputs_match_reference(name):
     """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) in HIP end to end (front, read-outs with their latents, association
     stages, LocalSliceLgCollapse, Arrivals) against the reference's own forward_fixed golden vectors: 7 stations (generic CSR
@@ -1300,7 +1305,7 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
 
 
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_edges_abspos_18x50", "assoc_subgraph_14x50"])
+                                  "assoc_edges_abspos_18x50", "assoc_subgraph_14x50", "assoc_subgraph_edges_14x50"])
 def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name):
     """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
     mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones. Every module
@@ -1363,12 +1368,13 @@ def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name)
         assert float(w["DataAggregation.init_trns.weight"].grad[:, 4:10].abs().max()) > 0
         assert float(w["DataAggregationAssociationPhase.init_trns.weight"].grad[:, 15:21].abs().max()) > 0
     checked = 0
+    gmax4 = max(float(v.grad.abs().max()) for v in w.values() if v.grad is not None)
     for k, p in net.named_parameters():
         if w[k].grad is None:
             continue
         assert p.grad is not None and tuple(p.grad.shape) == tuple(w[k].grad.shape), k
         # relative to the gradient's own scale (2e-4: f_arrival_query_2.bias of the _nonull case is a sum of cancelling terms, 1.3e-4)
-        tol = 2e-4 * float(w[k].grad.abs().max()) + 1e-12
+        tol = 2e-4 * max(float(w[k].grad.abs().max()), 1e-3 * gmax4) + 1e-12
         assert max_abs(p.grad.cpu(), w[k].grad) <= tol, (k, max_abs(p.grad.cpu(), w[k].grad), tol)
         checked += 1
     assert checked >= 130
