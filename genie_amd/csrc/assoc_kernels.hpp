@@ -81,13 +81,17 @@ __global__ __launch_bounds__(256) void k_assoc_pre(const float* __restrict__ raw
 }
 
 __global__ void k_assoc_ps(const float* __restrict__ raw, AsPreOffs o, long long S, const float* __restrict__ mpos_sta,
-                           const float* __restrict__ abs_sta, const float* __restrict__ mpos_src_p, float* __restrict__ ps) {
+                           const float* __restrict__ abs_sta, const float* __restrict__ mpos_src_p, const float* __restrict__ abs_src_p,
+                           float* __restrict__ ps) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * AS_PS) return;
     const long long s = idx / AS_PS;
     const int k = (int)(idx - s * AS_PS);
     float v = 0.f;
-    if (k < 30) { if (abs_sta) v = dot4w(raw + o.as_init_abs + k * 6, abs_sta + s * 4, 3); }
+    if (k < 30) {
+        if (abs_sta) v = dot4w(raw + o.as_init_abs + k * 6, abs_sta + s * 4, 3);
+        if (abs_src_p) v += dot4w(raw + o.as_init_abs + k * 6 + 3, abs_src_p + s * 4, 3);      // rows = product nodes: the source side too
+    }
     else if (k >= 32 && k < 62) { if (mpos_sta) v = dot4w(raw + o.as_l1t12_p + (k - 32) * 4, mpos_sta + s * 4, 4); }
     else if (k >= 64 && k < 79) { if (mpos_sta) v = dot4w(raw + o.as_l2t12_p + (k - 64) * 4, mpos_sta + s * 4, 4); }
     else if (k >= 80 && k < 110) { if (mpos_src_p) v = dot4w(raw + o.as_l1t22_p + (k - 80) * 4, mpos_src_p + s * 4, 4); }      // rows = product nodes

@@ -1381,8 +1381,8 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
                                W_DA_L2T11_B, W_DA_L2T21_W, W_DA_L2T21_B, W_DA_L2T12_W, W_DA_L2T12_B, W_DA_L2T22_W, W_DA_L2T22_B, W_DA_ACT,
                                W_DA_ACT11, W_DA_ACT12, W_DA_ACT1, W_DA_ACT21, W_DA_ACT22, W_DA_ACT2, W_BP_FC1_W};
         for (int k = 0; k < RG_N; ++k) ra.off[k] = g_params[ids[k]].off;
-        ra.abs_sta = c->abs_sta; ra.n_abs_sta = c->abs_sta ? c->S * 4 : 0;
-        ra.abs_src = c->abs_src; ra.n_abs_src = c->abs_src ? (long long)c->G_ext * 4 : 0;
+        ra.abs_sta = c->abs_sta; ra.n_abs_sta = c->abs_sta ? (c->pcsr ? c->P : (long long)c->S) * 4 : 0;
+        ra.abs_src = c->abs_src; ra.n_abs_src = c->abs_src ? (c->pcsr ? c->P : (long long)c->G_ext) * 4 : 0;
         ra.eb_sta = c->has_edges ? c->ebias_sta : nullptr; ra.n_eb_sta = c->has_edges ? edge_rows_sta(c) * 48 : 0;
         ra.eb_src = c->has_edges ? c->ebias_src : nullptr; ra.n_eb_src = c->has_edges ? edge_rows_src(c) * 48 : 0;
         {   // long tables: partial maxima by many workgroups first (d_range[4 ..] holds 4 x RG_PART of them)
@@ -2094,15 +2094,17 @@ int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_
         c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr;
         return GENIE_OK;
     }
-    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_set_absolute_pos: not available on an irregular product graph");
+    // irregular product graph: both arguments are [n_prod, 3] (the station's / the source node's position of every product node) and the
+    // tables are per product node: a neighbour (a product-node id) is looked up like the node itself
+    const long long ns = c->pcsr ? c->P : c->S, ng = c->pcsr ? c->P : c->G_ext;
     if (!c->abs_sta) {
-        HIP_TRY(hipMalloc((void**)&c->abs_sta, sizeof(float) * 4 * (size_t)c->S));
-        HIP_TRY(hipMalloc((void**)&c->abs_src, sizeof(float) * 4 * (size_t)c->G_ext));
+        HIP_TRY(hipMalloc((void**)&c->abs_sta, sizeof(float) * 4 * (size_t)ns));
+        HIP_TRY(hipMalloc((void**)&c->abs_src, sizeof(float) * 4 * (size_t)ng));
     }
     const float inv = 1.f / (3.f * c->scale_rel);
     hipStream_t st = (hipStream_t)stream;
-    k_abs_table<<<(c->S * 4 + 255) / 256, 256, 0, st>>>(pos_sta, c->S, inv, c->abs_sta);
-    k_abs_table<<<(c->G_ext * 4 + 255) / 256, 256, 0, st>>>(pos_src, c->G_ext, inv, c->abs_src);
+    k_abs_table<<<(unsigned)((ns * 4 + 255) / 256), 256, 0, st>>>(pos_sta, (int)ns, inv, c->abs_sta);
+    k_abs_table<<<(unsigned)((ng * 4 + 255) / 256), 256, 0, st>>>(pos_src, (int)ng, inv, c->abs_src);
     HIP_TRY(hipGetLastError());
     c->abs_dirty = true;
     return GENIE_OK;
@@ -2283,7 +2285,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     }
     if (((c->force_generic && !h2_on(c)) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
-    } else if (c->pcsr && pcsr_h2_on(c)) {
+    } else if (c->pcsr && pcsr_h2_on(c) && !c->abs_sta) {      // (use_absolute_pos on an irregular graph: the generic fp32-MFMA kernel below)
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
@@ -3475,11 +3477,12 @@ void assoc_pre_launch(genie_ctx* c, const float* y_latent, const float* mask_src
     // irregular product graph: the edge-feature terms of BOTH sides are per product node (ps rows = product nodes), none in pg
     const float* mpos_src = (c->has_edges && !c->pcsr) ? c->mpos_src : nullptr;
     const float* mpos_sta = c->has_edges ? c->mpos_sta : nullptr;
-    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, mpos_src, c->abs_src, c->as_pg);
+    k_assoc_pre<<<(c->G * AS_PG + 255) / 256, 256, 0, st>>>(c->raw, o, y_latent, mask_src, c->G, mpos_src, c->pcsr ? nullptr : c->abs_src, c->as_pg);
     if (c->as_ps) {
         const long long rows = edge_rows_sta(c);
         k_assoc_ps<<<(unsigned)((rows * AS_PS + 255) / 256), 256, 0, st>>>(c->raw, o, rows, mpos_sta, c->abs_sta,
-                                                                          (c->has_edges && c->pcsr) ? c->mpos_src : nullptr, c->as_ps);
+                                                                          (c->has_edges && c->pcsr) ? c->mpos_src : nullptr,
+                                                                          c->pcsr ? c->abs_src : nullptr, c->as_ps);
     }
 }
 }  // namespace
@@ -3613,7 +3616,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
         // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end;
         // on an irregular product graph the layer-1 ones after k_as_b1 already (k_as_b0<PCSR> leaves its d z1 rows in the dt blocks)
         if (variant && c->pcsr) {
-            if ((s == 1 || s == 2) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 2, true))) return rc;
+            if ((s == 1 || s == 2) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
         } else if (variant && (s == 1 || s == 3) && (rc = static_term_grads(c, a.gr, sscr, grad_blob, st, s == 1 ? 1 : 6, true))) return rc;
     }
     if (c->pcsr)      // k_as_b0<PCSR> left the d z1 rows in the dt blocks: one sum row per source node

@@ -244,6 +244,13 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
         f32x4 x0 = MFMA16(wi0.x, xs, bi0), x1 = MFMA16(wi1.x, xs, bi1);
         x0 = MFMA16(wi0.y, mq, x0);
         x1 = MFMA16(wi1.y, mq, x1);
+        float lq = 0.f, gq = 0.f;     // use_absolute_pos: the position tables are per PRODUCT node here (genie_set_absolute_pos on a subgraph context)
+        if (a.abs_sta != nullptr) {
+            lq = a.abs_sta[p * 4 + q];
+            gq = a.abs_src[p * 4 + q];
+            x0 = MFMA16(wi0.z, lq, x0); x1 = MFMA16(wi1.z, lq, x1);
+            x0 = MFMA16(wi0.w, gq, x0); x1 = MFMA16(wi1.w, gq, x1);
+        }
         if (a.save != nullptr && valid) {      // training forward: the pre-activation of h0
             *(f32x4*)(a.save + ((size_t)(SV_Z0 + 0) * a.Pn + p) * 16 + 4 * q) = x0;
             *(f32x4*)(a.save + ((size_t)(SV_Z0 + 1) * a.Pn + p) * 16 + 4 * q) = x1;
@@ -251,17 +258,17 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
         x0 = prelu4u(x0, a0);
         x1 = prelu4u(x1, a0);
         f32x4 n1a = {0.f, 0.f, 0.f, 0.f}, n1b = n1a, n2a = n1a, n2b = n1a;
-        {
+        {       // a station-type neighbour shares the source node: its source position is this node's; its station position is its own row
             const int eb = a.sta_rowptr[p], ee = a.sta_rowptr[p + 1];
-            if (s11 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
-            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b);
+            if (s11 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.sta_col, eb, ee, wi0, wi1, bi0, bi1, s11, n1a, n1b, AbsNbr{a.abs_sta, true, gq});
             const float inv = 1.f / (float)max(ee - eb, 1);
             n1a *= inv; n1b *= inv;
         }
         {
             const int eb = a.src_rowptr[p], ee = a.src_rowptr[p + 1];
-            if (s12 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
-            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b);
+            if (s12 <= 1.f) gather_recompute<false, true>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
+            else gather_recompute<false, false>(a.slice, a.mask, 0, 1, q, a.src_col, eb, ee, wi0, wi1, bi0, bi1, s12, n2a, n2b, AbsNbr{a.abs_src, false, lq});
             const float inv = 1.f / (float)max(ee - eb, 1);
             n2a *= inv; n2b *= inv;
         }

@@ -1082,8 +1082,12 @@ class HipPath(object):
         if pos_sta is None or pos_src is None:
             _lib.check(self.lib.genie_set_absolute_pos(self.ctx, None, None, _stream()), "genie_set_absolute_pos")
             return
-        pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
-        pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
+        if self._n_prod is not None:      # irregular product graph: positions per PRODUCT node (the station's, the source node's)
+            pos_sta = _f32(pos_sta, "pos_sta", (self._n_prod, 3))
+            pos_src = _f32(pos_src, "pos_src", (self._n_prod, 3))
+        else:
+            pos_sta = _f32(pos_sta, "pos_sta", (self.n_sta, 3))
+            pos_src = _f32(pos_src, "pos_src", (self.n_grid_ext, 3))
         _lib.check(self.lib.genie_set_absolute_pos(self.ctx, _ptr(pos_sta), _ptr(pos_src), _stream()), "genie_set_absolute_pos")
         torch.cuda.current_stream(self.device).synchronize()
 

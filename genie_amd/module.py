@@ -750,8 +750,6 @@ class GCN_Detection_Network_extended(nn.Module):
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
         A_src_in_sta (grouped by source node) and the edge lists are irregular: product-level CSRs, generic HIP kernels."""
-        if self.use_absolute_pos:
-            raise NotImplementedError("use_absolute_pos with use_subgraph")
         pairs = torch.as_tensor(A_src_in_sta).long().cpu()
         n_prod = int(pairs.shape[1])
         src_of = pairs[1]
@@ -773,6 +771,11 @@ class GCN_Detection_Network_extended(nn.Module):
                 raise ValueError("use_updated_model_definition=True needs station and source positions")
             pl, ps = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
             self._hip.set_edge_features(pl[pairs[0].to(dev)].contiguous(), ps[pairs[1].to(dev)].contiguous())
+        if self.use_absolute_pos:                   # module.py:1007 / :1056: the positions of a product node's station and source node
+            if pos_loc is None or pos_src is None:
+                raise ValueError("use_absolute_pos=True needs station and source positions")
+            pl, ps = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
+            self._hip.set_absolute_pos(pl[pairs[0].to(dev)].contiguous(), ps[pairs[1].to(dev)].contiguous())
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_prod, 3))
         self._edge_attr_version = self._edge_attr._version
 
@@ -787,8 +790,6 @@ class GCN_Detection_Network_extended(nn.Module):
         `edge_attr(pairs) -> [N, 3]`, or None = `(pos_src[source] - pos_loc[station]) / scale_pairwise_sta_in_src_distances`
         (:811). Returns (A_sta_sta, A_src_src, A_src_in_sta) with A_src_in_sta int64 [2, N] = the product nodes as
         (station, source) pairs in node order; Slice / Mask / edge_attr rows follow that order."""
-        if self.use_absolute_pos:
-            raise NotImplementedError("use_absolute_pos with use_subgraph")
         dev = next(self.parameters()).device
         pos_loc, pos_src = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
@@ -804,6 +805,8 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip.set_phase_types(self.use_phase_types)
         if self.use_updated_model_definition:
             self._hip.set_edge_features(pos_loc[pairs[0].long()].contiguous(), pos_src[pairs[1].long()].contiguous())
+        if self.use_absolute_pos:
+            self._hip.set_absolute_pos(pos_loc[pairs[0].long()].contiguous(), pos_src[pairs[1].long()].contiguous())
         if edge_attr is None:
             edge_attr = (pos_src[pairs[1]] - pos_loc[pairs[0]]) / float(scale_pairwise_sta_in_src_distances)
         elif callable(edge_attr):

@@ -74,8 +74,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
  * n_prod), and both DataAggregation edge sets are CSR lists over product-node ids: p_sta_* = in-edges of A_in_sta (same
  * source node, neighbouring stations), p_src_* = in-edges of A_in_src, in stable edge order. src_rowptr / src_col = the base
  * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The kernels that rely on
- * p = g * n_sta + s are not used (product-level CSR forms instead, inference and training); genie_embed_window, genie_set_absolute_pos
- * and genie_nbr_mean are unavailable on such a context, genie_set_edge_features takes positions per product node. */
+ * p = g * n_sta + s are not used (product-level CSR forms instead, inference and training); genie_embed_window and genie_nbr_mean are
+ * unavailable on such a context; genie_set_edge_features / genie_set_absolute_pos take positions per product node there ([n_prod, 3]). */
 int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod,
                               const int32_t* p_sta_rowptr, const int32_t* p_sta_col,
                               const int32_t* p_src_rowptr, const int32_t* p_src_col, const int32_t* seg_rowptr,

@@ -411,6 +411,45 @@ def main_subgraph():
     print("wrote subgraph_builder_14x50.npz: %d product nodes" % out[5].shape[1])
 
 
+def main_subgraph_abspos():
+    """`python oracle/make_golden.py --subgraph-abspos`: `use_absolute_pos: True` on an irregular product graph (`use_subgraph: True`):
+    fixtures `subgraph_abspos_14x50` (2 outputs) and `assoc_subgraph_abspos_14x50` (4 outputs); geometry and node list of `--subgraph`."""
+    ref = _import_reference(absolute_pos=True)
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    rng = np.random.default_rng(72)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(d.shape[0])[:, None], np.argsort(d, axis=1)[:, :6]] = True
+    keep |= rng.random(d.shape) < 0.12
+    src_i, sta_i = np.nonzero(keep)
+    pairs = np.stack((sta_i, src_i))
+    full = syn.make_window(geom, 180, seed=73)
+    rows = src_i * geom.n_sta + sta_i
+    run_case(ref, "subgraph_abspos_14x50", geom, full["Slice"][rows], full["Mask"][rows], perturb_prelu=True, window=full,
+             keep=("h0", "h1", "x_latent", "bip", "sa3"), keep64=("bip", "sa3"), pairs=pairs)
+    run_assoc_case(ref, "assoc_subgraph_abspos_14x50", geom, full, pairs=pairs)
+
+
+def main_subgraph_edges_abspos():
+    """`python oracle/make_golden.py --subgraph-edges-abspos`: both model options on an irregular product graph: `assoc_subgraph_edges_abspos_14x50`
+    (4 outputs; its (y, x) are the 2-output path)."""
+    ref = _import_reference(updated_definition=True, absolute_pos=True)
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 50, L=80e3, n_query=21, seed=71)
+    rng = np.random.default_rng(72)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(d.shape[0])[:, None], np.argsort(d, axis=1)[:, :6]] = True
+    keep |= rng.random(d.shape) < 0.12
+    src_i, sta_i = np.nonzero(keep)
+    pairs = np.stack((sta_i, src_i))
+    full = syn.make_window(geom, 180, seed=73)
+    run_assoc_case(ref, "assoc_subgraph_edges_abspos_14x50", geom, full, pairs=pairs)
+
+
 def main_subgraph_edges():
     """`python oracle/make_golden.py --subgraph-edges`: `use_updated_model_definition: True` on an irregular product graph
     (`use_subgraph: True`): the mean edge feature of a product node runs over its PRESENT neighbours only, so the static term is per
@@ -505,6 +544,10 @@ def main():
         return main_postproc()
     if "--scaled" in sys.argv:
         return main_scaled()
+    if "--subgraph-edges-abspos" in sys.argv:
+        return main_subgraph_edges_abspos()
+    if "--subgraph-abspos" in sys.argv:
+        return main_subgraph_abspos()
     if "--subgraph-edges" in sys.argv:
         return main_subgraph_edges()
     if "--edges-abspos" in sys.argv:

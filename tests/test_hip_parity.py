@@ -250,16 +250,19 @@ def test_use_absolute_pos_forward_fixed_source(name):
     assert max_abs(y.cpu(), c.ref("y64")) <= 1e-5 and max_abs(x.cpu(), c.ref("x64")) <= 1e-5
 
 
+@pytest.mark.parametrize("name", ["subgraph_edges_14x50", "subgraph_abspos_14x50"])
 @pytest.mark.parametrize("stage1", ["default", "f32"])
-def test_updated_model_definition_on_an_irregular_product_graph(stage1, monkeypatch):
+def test_updated_model_definition_on_an_irregular_product_graph(name, stage1, monkeypatch):
     """`use_updated_model_definition: True` with `use_subgraph: True`: the mean edge feature of a product node runs over its PRESENT
     neighbours, so the static terms are per product node (genie_set_edge_features with positions per product node: `k_edge_feat` on
     the product-level CSRs, `[n_prod, 48]` term tables indexed by product node in k_stage1_h2<EDGES, .., PCSR> / k_stage1_pcsr).
     Fixture: the reference imported with the flag, run on the irregular graph of `subgraph_14x50`."""
     if stage1 == "f32":
         monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
-    c = Case("subgraph_edges_14x50")
-    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=True)
+    # (subgraph_abspos_14x50: `use_absolute_pos: True` on the same graph -- position tables per product node, the generic fp32-MFMA stage 1)
+    c = Case(name)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=c.edges_variant,
+                                                use_absolute_pos=c.abspos_variant)
     net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
     net.eval()
     A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = c.product_edges()
@@ -612,7 +615,8 @@ def test_training_mode_forward_and_gradients_match_oracle_autograd(name):
     assert checked >= 80          # every tensor of DataAggregation, Bipartite_ReadIn, SpatialAggregation1..3 and the read-outs
 
 
-@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13", "edges_abspos_12x60", "subgraph_edges_14x50"])
+@pytest.mark.parametrize("name", ["edges_12x60", "edges_7x13", "abspos_12x60", "abspos_7x13", "edges_abspos_12x60", "subgraph_edges_14x50",
+                                  "subgraph_abspos_14x50"])
 @pytest.mark.parametrize("stage1", ["default", "f32"])
 def test_training_step_of_the_other_model_definitions_matches_oracle_autograd(name, stage1, monkeypatch):
     """a-8 / a-9: the training step of `forward_fixed_source` under `use_updated_model_definition` (DataAggregationEdges,
@@ -1254,7 +1258,8 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50", "assoc_subgraph_edges_14x50"])
+                                  "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50", "assoc_subgraph_edges_14x50",
+                                  "assoc_subgraph_abspos_14x50", "assoc_subgraph_edges_abspos_14x50"])
 def test_forward_fixed_and_forward_four_outputs_match_reference(name):
     """module.py:963-997 / :908-939: (y, x, arv_p, arv_s) in HIP end to end (front, read-outs with their latents, association
     stages, LocalSliceLgCollapse, Arrivals) against the reference's own forward_fixed golden vectors: 7 stations (generic CSR
@@ -1305,7 +1310,8 @@ def test_forward_fixed_and_forward_four_outputs_match_reference(name):
 
 
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
-                                  "assoc_edges_abspos_18x50", "assoc_subgraph_14x50", "assoc_subgraph_edges_14x50"])
+                                  "assoc_edges_abspos_18x50", "assoc_subgraph_14x50", "assoc_subgraph_edges_14x50",
+                                  "assoc_subgraph_abspos_14x50", "assoc_subgraph_edges_abspos_14x50"])
 def test_training_mode_four_output_forward_gradients_match_oracle_autograd(name):
     """a-8 / f-2: the training call convention `net(Slice, Mask, graphs..., picks...)` (train_GENIE_model.py:1786) in train()
     mode: all four outputs carry gradients and the gradients of every parameter equal the oracle's autograd ones. Every module

@@ -136,3 +136,17 @@ def test_oracle_updated_model_on_irregular_product_graph_matches_reference():
     for k in ["bip", "sa3", "y", "x"]:
         ref = c.ref(k + "64")
         assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
+
+
+def test_oracle_absolute_positions_on_irregular_product_graph_matches_reference():
+    """`use_absolute_pos: True` on a `use_subgraph: True` graph (oracle/make_golden.py --subgraph-abspos)."""
+    c = Case("subgraph_abspos_14x50")
+    assert c.abspos_variant and "pairs" in c.z.files
+    out = c.oracle_forward(torch.float32)
+    for k in ["h0", "h1", "x_latent", "bip", "sa3", "y", "x"]:
+        ref = c.ref(k)
+        assert max_abs(out[k], ref) <= 2e-6 * max(1.0, float(ref.abs().max())), k
+    out64 = c.oracle_forward(torch.float64)
+    for k in ["bip", "sa3", "y", "x"]:
+        ref = c.ref(k + "64")
+        assert max_abs(out64[k], ref) <= 1e-12 * max(1.0, float(ref.abs().max())), k
