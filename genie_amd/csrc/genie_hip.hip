@@ -2285,14 +2285,27 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     }
     if (((c->force_generic && !h2_on(c)) || abs_generic(c)) && !c->pcsr) {   // use_absolute_pos, training on other graph shapes: generic kernel (64-bit safe, any graph)
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
-    } else if (c->pcsr && pcsr_h2_on(c) && !c->abs_sta) {      // (use_absolute_pos on an irregular graph: the generic fp32-MFMA kernel below)
+    } else if (c->pcsr && pcsr_h2_on(c) && !(c->abs_sta && c->has_edges)) {      // (both options at once: the generic fp32-MFMA kernel below)
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
         const long long nitems = (c->P + 31) / 32;
         const int grid = (int)std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b);
         const bool bigp = c->P * XROW >= (1ll << 32);
-        if (c->has_edges) {
+        if (c->abs_sta) {      // position pieces per product node (genie_set_absolute_pos on a subgraph context)
+            if (c->abs_dirty || !c->abs_ts) {
+                if (!c->abs_ts) {
+                    HIP_TRY(hipMalloc((void**)&c->abs_ts, 16 * (size_t)c->P));
+                    HIP_TRY(hipMalloc((void**)&c->abs_tg, 16 * (size_t)c->P));
+                }
+                k_abs_pieces<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(c->abs_sta, nullptr, (int)c->P, c->abs_ts);
+                k_abs_pieces<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(c->abs_src, nullptr, (int)c->P, c->abs_tg);
+                c->abs_dirty = false; c->abs_ts_order = 0;
+            }
+            a.abs_ts = c->abs_ts; a.abs_tg = c->abs_tg;
+            if (bigp) k_stage1_h2<8, 15, false, true, true, true><<<grid, H2_THREADS, 0, st>>>(a);
+            else k_stage1_h2<8, 15, false, false, true, true><<<grid, H2_THREADS, 0, st>>>(a);
+        } else if (c->has_edges) {
             if (bigp) k_stage1_h2<8, 15, true, true, false, true><<<grid, H2_THREADS, 0, st>>>(a);
             else k_stage1_h2<8, 15, true, false, false, true><<<grid, H2_THREADS, 0, st>>>(a);
         } else {

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     // PCSR: irregular product graph (use_subgraph). A wave item is 32 consecutive product nodes; the neighbours of a node are
     // product-node ids from the product-level CSRs (at most KS / KP of them: a missing one is the node itself with weight 0,
     // the mean of an empty neighbourhood is 0); everything after the neighbour phase is the same code.
-    static_assert(!(PCSR && ABS), "irregular product graphs: no use_absolute_pos");   // (EDGES: the static terms are per PRODUCT node there)
+    // (irregular product graphs: the EDGES terms and the ABS position pieces are per PRODUCT node there, indexed by product-node id)
     typedef typename std::conditional<BIG, unsigned long long, unsigned>::type off_t_;
     constexpr int NF4 = H2_IMG_FLOATS / 4;
     __shared__ f32x4 lw[NF4];
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
         u32x4 buf[NU];
         u32x2 tp[NU], tso, tgo;          // ABS: the unit's own position piece; this tile's station / source piece
         if (ABS) {
-            tso = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sc * 16u));
-            tgo = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)g * 16u));
+            tso = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)(PCSR ? (int)p : sc) * 16u));
+            tgo = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)(PCSR ? (int)p : g) * 16u));
         }
         auto issue = [&](int u) {
             off_t_ off;
@@ -630,6 +630,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
             }
             if (ABS && u > 0) {
                 if (u <= KS) tp[u] = *(const u32x2*)((const char*)a.abs_ts + (tp_h + (unsigned)sta_id[u - 1] * 16u));
+                else if (PCSR) tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)src_id[(u - KS - 1) % KPP] * 16u));
                 else tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)row_bcast_dyn(srcv, u - KS) * 16u));
             }
             if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
