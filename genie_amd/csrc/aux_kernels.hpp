@@ -2,7 +2,7 @@
 
 // ------------------------------------------------------------------------------------------------
 // Pick -> Slice/Mask embedding on device: `extract_input_from_data`,
-// /root/reference/Code/process_utils.py:460-642 (use_sign_input = False). Step 1: per-station Gaussian-kernel time
+// /root/reference/Code/process_utils.py:460-642 (use_sign_input False or True). Step 1: per-station Gaussian-kernel time
 // series of the P- and S-labelled picks by scatter-max (:499-569; max is order independent -> deterministic atomics).
 // Step 2: every product node reads the series of its station at the theoretical P / S arrival index (:599-629).
 // ------------------------------------------------------------------------------------------------
@@ -17,6 +17,8 @@ struct EmbArgs {
     unsigned* xs;          // optional: the split rows of k_stage1_h2, written together with Slice / Mask
     const int32_t* sta_inv; // station processing order of the split rows (caller's station -> internal), or null
     float* mm;              // with sta_inv: max of the Mask row, in processing order
+    int sign_input;         // use_sign_input: True (config.yaml:93, process_utils.py:610-614): every feature times the sign of the negative
+                            // forward difference of the series it is read from, at the index it is read at
     int no_phase;           // use_phase_types: False (config.yaml:91): the phase-informed columns 2, 3 of Slice / Mask are zero
                             // (process_continuous_days.py:783-786; the caller passes every pick with phase 0, :562-563)
 };
@@ -60,6 +62,14 @@ __global__ void k_embed_gather(EmbArgs a) {
     sl.y = fmaxf(ep[is], es[is]);                                        // :613
     sl.z = ep[ip];                                                       // :614
     sl.w = es[is];                                                       // :615
+    if (a.sign_input) {      // :610-614. (The sample after a series' last one is the next series' first: both are zero, so is the value read there.)
+        auto sg = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
+        const int ip1 = min(ip + 1, a.n_time - 1), is1 = min(is + 1, a.n_time - 1);
+        sl.x *= sg(sl.x - fmaxf(ep[ip1], es[ip1]));
+        sl.y *= sg(sl.y - fmaxf(ep[is1], es[is1]));
+        sl.z *= sg(sl.z - ep[ip1]);
+        sl.w *= sg(sl.w - es[is1]);
+    }
     if (a.no_phase) { sl.z = 0.f; sl.w = 0.f; }
     f32x4 mk;
     mk.x = fabsf(sl.x) > 0.01f ? 1.f : 0.f; mk.y = fabsf(sl.y) > 0.01f ? 1.f : 0.f;      // :629

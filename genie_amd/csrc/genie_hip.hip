@@ -1254,6 +1254,7 @@ struct genie_ctx {
     unsigned *ea_frag, *ea_frag_tmp;    // edge_attr as B fragments of k_stage2_h2 (k_ea_frag): of the registered static edge_attr / of any other one
     bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
     int xs_sta_order;          // genie_embed_window_split: the station-order state its split rows were written under
+    int sign_input;            // genie_set_sign_input(1): the embedding tags every feature with the sign of the series' negative slope
     int no_phase;              // genie_set_phase_types(0): the embedding zeroes the phase-informed columns of Slice / Mask
     int tail_f32;              // genie_set_tail_precision(0): the G-sized tail on fp32 MFMA chains (default: fp64 chains, tail_kernels.hpp)
     int tail_train;            // set for the duration of a training forward: its tail keeps the fp32 chains (the backward recomputes with them)
@@ -2937,7 +2938,7 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
     a.n_extra = (int)ceil(3.0 * kernel_sig_t / dt);                                       // process_utils.py:518
     a.emb = emb_ws; a.trv = trv; a.rows = c->P_ext; a.slice = slice_out; a.mask = mask_out; a.xs = xs;
-    a.no_phase = c->no_phase;
+    a.no_phase = c->no_phase; a.sign_input = c->sign_input;
     a.sta_inv = (xs && sta_order_on(c)) ? c->sta_inv : nullptr;
     a.mm = xs ? (float*)xs - c->o_xs + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride : nullptr;   // xs = workspace + o_xs
     HIP_TRY(hipMemsetAsync(emb_ws, 0, sizeof(float) * 2 * (size_t)a.S * a.n_time, st));
@@ -3886,6 +3887,12 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
 int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_phase_types: null context");
     c->no_phase = use_phase_types ? 0 : 1;
+    return GENIE_OK;
+}
+
+int genie_set_sign_input(genie_ctx* c, int use_sign_input) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_sign_input: null context");
+    c->sign_input = use_sign_input ? 1 : 0;
     return GENIE_OK;
 }
 

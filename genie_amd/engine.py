@@ -294,6 +294,10 @@ class HipPath(object):
         self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
         self._w_key = None
 
+    def set_sign_input(self, use_sign_input):
+        """`use_sign_input` of config.yaml:93 for the device embedding (genie_set_sign_input): features signed by the series' negative slope."""
+        _lib.check(self.lib.genie_set_sign_input(self.ctx, 1 if use_sign_input else 0), "genie_set_sign_input")
+
     def set_phase_types(self, use_phase_types):
         """`use_phase_types` of config.yaml:91 for the device embedding (genie_set_phase_types)."""
         _lib.check(self.lib.genie_set_phase_types(self.ctx, 1 if use_phase_types else 0), "genie_set_phase_types")

@@ -658,8 +658,11 @@ class GCN_Detection_Network_extended(nn.Module):
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
-                 use_updated_model_definition=False, use_phase_types=True):
+                 use_updated_model_definition=False, use_phase_types=True, use_sign_input=False):
         super().__init__()
+        # config.yaml:93: the pick -> Slice / Mask embedding tags every feature with the sign of the negative slope of the series it is read
+        # from (process_utils.py:610-614); the model itself is unchanged. Applies to the device embedding (`genie_amd.apply`, `embed_window`)
+        self.use_sign_input = bool(use_sign_input)
         # config.yaml:91. False = the pick phase labels are ignored: LocalSliceLgCollapse and StationSourceAttentionMergedPhases
         # zero `phase_label` (module.py:632-633, :706-707); the callers also zero the phase-informed columns 2, 3 of Slice / Mask
         # (process_continuous_days.py:783-786, train_GENIE_model.py:1707-1709), which `genie_amd.apply` does under the same flag
@@ -708,6 +711,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._hip.set_phase_types(self.use_phase_types)
+        self._hip.set_sign_input(self.use_sign_input)
         if self.use_updated_model_definition:
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_updated_model_definition=True needs station and source positions")

@@ -93,6 +93,11 @@ int genie_set_station_order(genie_ctx* ctx, const int32_t* order);
  * Mask (process_continuous_days.py:783-786); the caller passes every pick with phase 0 (:562-563) and zeroes `phase_label` for the
  * association heads (module.py:632-633, :706-707). Default: phase types in use. */
 int genie_set_phase_types(genie_ctx* ctx, int use_phase_types);
+/* `use_sign_input: True` (config.yaml:93; process_utils.py:610-614, the `use_sign_input` argument of extract_input_from_data): the
+ * device embedding (genie_embed_window*) multiplies each of the four features of a product node by the sign of the NEGATIVE forward
+ * difference of the series it is read from, at the index it is read at (+1 on the falling side of a pick's kernel, -1 on the rising
+ * side, 0 on a flat stretch); Mask = |Slice| > 0.01 as before. Default off. */
+int genie_set_sign_input(genie_ctx* ctx, int use_sign_input);
 /* Arithmetic of the G-sized tail of inference calls (Bipartite read-out, SpatialAggregation x3, SpatialDirect + TemporalAttention
  * on the grid): fp64_chains != 0 (default) = every Linear as a chain of fp64 MFMAs on the fp32 inputs and weights, fp64 PReLUs
  * and sums, one rounding to fp32 per kernel; 0 = fp32 MFMA chains (the arithmetic of the training forward, and the A/B form).

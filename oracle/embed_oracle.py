@@ -2,7 +2,7 @@
 
 numpy restatement of the pick -> per-product-node feature embedding that feeds the hot path,
 `extract_input_from_data` (`/root/reference/Code/process_utils.py:460-642`, live path `use_updated_input = True`,
-`process_continuous_days.py:607,776`; `use_sign_input = False`, `trv_times` given, `batch_grids = False`).
+`process_continuous_days.py:607,776`; `use_sign_input` False or True, `trv_times` given, `batch_grids = False`).
 
 Pinned by `tests/golden/embed_*.npz`, produced by the reference's own function in the build container
 (`oracle/make_golden.py`); checked in `tests/test_embed_cpu.py`.
@@ -39,7 +39,16 @@ def embed_time_series(P_slice, t0, max_t, kernel_sig_t, dt, sta_index, n_sta):
     return out[0], out[1], abs_time_ref
 
 
-def extract_input_from_data(P, t0, ind_use, n_sta_all, trv_times, A_src_in_sta, max_t, kernel_sig_t, dt):
+def _neg_slope_sign(emb):
+    """sign(-diff(flat series)) of process_utils.py:610-614 (`use_sign_input: True`, config.yaml:93): the series of the embedded stations
+    are concatenated; the element after a series' last sample is the next series' first one (both are zero), the one after the very last
+    sample is linearly extrapolated. Every product node reads the sign at the index it reads the value at."""
+    flat = emb.reshape(-1).astype(np.float32)
+    nxt = np.concatenate((flat[1:], flat[-1:] + (flat[-1:] - flat[-2:-1])))
+    return np.sign(-(nxt - flat)).reshape(emb.shape).astype(np.float32)
+
+
+def extract_input_from_data(P, t0, ind_use, n_sta_all, trv_times, A_src_in_sta, max_t, kernel_sig_t, dt, use_sign_input=False):
     """Slice [P,4], Mask [P,4] float32 for the window starting at t0 (process_utils.py:460-642).
 
     trv_times [G, n_sta_all, 2]; A_src_in_sta [2, P] = [station index within ind_use; source node] per product node."""
@@ -65,5 +74,13 @@ def extract_input_from_data(P, t0, ind_use, n_sta_all, trv_times, A_src_in_sta, 
     Slice[ok, 1] = embed[sta[ok], is_[ok]]                                                                    # :613
     Slice[ok, 2] = embed_p[sta[ok], ip[ok]]                                                                   # :614
     Slice[ok, 3] = embed_s[sta[ok], is_[ok]]                                                                  # :615
+    if use_sign_input:                                                                                        # :610-614
+        # (the reference's flat series hold the stations WITH picks only; a series starts and ends with a zero sample, so which series
+        # follows which does not matter)
+        sg, sp, ss = _neg_slope_sign(embed), _neg_slope_sign(embed_p), _neg_slope_sign(embed_s)
+        Slice[ok, 0] *= sg[sta[ok], ip[ok]]
+        Slice[ok, 1] *= sg[sta[ok], is_[ok]]
+        Slice[ok, 2] *= sp[sta[ok], ip[ok]]
+        Slice[ok, 3] *= ss[sta[ok], is_[ok]]
     Mask = (np.abs(Slice) > 0.01).astype(np.float32)                                                          # :629
     return Slice, Mask

@@ -161,7 +161,7 @@ def run_case(ref, name, geom, Slice, Mask, weights_seed=0, perturb_prelu=False, 
           "| y max %.3e x max %.3e" % (np.abs(results["y"]).max(), np.abs(results["x"]).max()))
 
 
-def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
+def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0, use_sign_input=False):
     """Golden vector for the pick -> Slice/Mask embedding: the reference's own `extract_input_from_data`
     (process_utils.py:460-642) on synthetic picks."""
     import torch
@@ -174,7 +174,7 @@ def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0):
     max_t = float(np.ceil(trv_times.max() + 1.0))
     [Inpts, Masks], _ = ref_pu.extract_input_from_data(None, P, np.array([t0]), ind_use, geom.locs, geom.x_grid, A_src_in_sta,
                                                         trv_times=trv_times, max_t=max_t, kernel_sig_t=kernel_sig_t, dt=dt,
-                                                        use_sign_input=False, device="cpu")
+                                                        use_sign_input=use_sign_input, device="cpu")
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, P=P, t0=np.float64(t0), n_sta=np.int64(S), n_grid=np.int64(Gn), trv_times=trv_times,
                         max_t=np.float64(max_t), kernel_sig_t=np.float64(kernel_sig_t), dt=np.float64(dt),
@@ -432,6 +432,22 @@ def main_subgraph_abspos():
     run_assoc_case(ref, "assoc_subgraph_abspos_14x50", geom, full, pairs=pairs)
 
 
+def main_embed_sign():
+    """`python oracle/make_golden.py --embed-sign`: the pick -> Slice/Mask embedding with `use_sign_input: True` (config.yaml:93): the two
+    windows of `embed_14x60_a / _b` through the reference's extract_input_from_data with the flag set."""
+    _import_reference()
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 60, L=90e3, n_query=5, seed=61)
+    P = syn.make_picks(geom, 260, seed=62)
+    P[:, 0] += 1000.0
+    run_embed_case("embed_sign_14x60_a", geom, P, 1000.0, use_sign_input=True)
+    P2 = P.copy()
+    P2[:, 0] += 80000.3
+    P2 = P2[P2[:, 1] != 5]
+    run_embed_case("embed_sign_14x60_b", geom, P2, 81003.1, use_sign_input=True)
+
+
 def main_subgraph_edges_abspos():
     """`python oracle/make_golden.py --subgraph-edges-abspos`: both model options on an irregular product graph: `assoc_subgraph_edges_abspos_14x50`
     (4 outputs; its (y, x) are the 2-output path)."""
@@ -544,6 +560,8 @@ def main():
         return main_postproc()
     if "--scaled" in sys.argv:
         return main_scaled()
+    if "--embed-sign" in sys.argv:
+        return main_embed_sign()
     if "--subgraph-edges-abspos" in sys.argv:
         return main_subgraph_edges_abspos()
     if "--subgraph-abspos" in sys.argv:
@@ -587,6 +605,8 @@ def main():
     P2[:, 0] += 80000.3
     P2 = P2[P2[:, 1] != 5]                                                  # one station without any pick
     run_embed_case("embed_14x60_b", geom, P2, 81003.1)
+    run_embed_case("embed_sign_14x60_a", geom, P, 1000.0, use_sign_input=True)          # config.yaml:93 (process_utils.py:610-614)
+    run_embed_case("embed_sign_14x60_b", geom, P2, 81003.1, use_sign_input=True)
 
     # (i) tiny, exhaustive intermediates, fp32 + fp64, distinct PReLU slopes, event-structured picks
     geom = syn.Geometry(6, 40, L=60e3, n_query=25, seed=11)

@@ -27,3 +27,15 @@ def test_embed_oracle_matches_reference(name):
     assert np.abs(Slice - z["Slice"]).max() <= 1e-6
     assert np.array_equal(Mask.astype(np.uint8), z["Mask"])
     assert (z["Slice"] > 0.5).sum() > 50          # the fixture is not trivial
+
+
+@pytest.mark.parametrize("name", ["embed_sign_14x60_a", "embed_sign_14x60_b"])
+def test_embed_oracle_with_sign_input_matches_reference(name):
+    """`use_sign_input: True` (config.yaml:93, process_utils.py:610-614): every feature carries the sign of the negative slope of the
+    series it was read from. Fixtures: the reference's extract_input_from_data with the flag set (oracle/make_golden.py --embed-sign)."""
+    z, S, G, A = load(name)
+    Slice, Mask = E.extract_input_from_data(z["P"], float(z["t0"]), np.arange(S), S, z["trv_times"], A, float(z["max_t"]),
+                                            float(z["kernel_sig_t"]), float(z["dt"]), use_sign_input=True)
+    assert np.abs(Slice - z["Slice"]).max() <= 1e-6
+    assert np.array_equal(Mask.astype(np.uint8), z["Mask"])
+    assert (z["Slice"] < -0.5).sum() > 20 and (z["Slice"] > 0.5).sum() > 20          # both signs occur

@@ -1016,6 +1016,35 @@ def test_apply_loop_matches_oracle_windows():
     assert max_abs(Out_2.cpu(), want) <= 1e-5
 
 
+@pytest.mark.parametrize("name", ["embed_sign_14x60_a", "embed_sign_14x60_b"])
+def test_device_embedding_with_sign_input_matches_reference(name):
+    """`use_sign_input: True` (config.yaml:93; process_utils.py:610-614): genie_set_sign_input(1) makes the embedding kernel multiply each
+    feature by the sign of the negative forward difference of the series it reads (any-phase series for columns 0, 1; the P / S
+    series for columns 2, 3). Fixtures from the reference's extract_input_from_data with the flag set; the split rows written for
+    stage 1 carry the same signed values (path output equal to the one computed from the returned Slice / Mask)."""
+    import os
+    from tests.util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t0, max_t, sig, dt = float(z["t0"]), float(z["max_t"]), float(z["kernel_sig_t"]), float(z["dt"])
+    geom = synthetic.Geometry(S, G, L=90e3, n_query=5, seed=61)
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                        engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), device=DEV)
+    hp.set_sign_input(True)
+    P = z["P"]
+    sel = (P[:, 0] > t0 - 2.0 * sig) & (P[:, 0] < t0 + max_t + 2.0 * sig)
+    Ps = P[sel]
+    args = (torch.from_numpy(Ps[:, 0].copy()).to(DEV), torch.from_numpy(Ps[:, 1].astype(np.int32)).to(DEV),
+            torch.from_numpy(Ps[:, 4].astype(np.int32)).to(DEV), t0, max_t, sig, dt, torch.from_numpy(z["trv_times"].reshape(-1, 2)).to(DEV))
+    Slice, Mask = hp.embed_window(*args)
+    assert float((Slice.cpu() - torch.from_numpy(z["Slice"])).abs().max()) <= 1e-6
+    assert torch.equal(Mask.cpu(), torch.from_numpy(z["Mask"].astype(np.float32)))
+    assert int((Slice < -0.5).sum()) > 20 and int((Slice > 0.5).sum()) > 20
+    hp.set_sign_input(False)
+    S0, _ = hp.embed_window(*args)
+    assert float((S0.abs() - Slice.abs()).abs().max()) == 0.0 and float(S0.min()) >= 0.0
+
+
 @pytest.mark.parametrize("name", ["embed_14x60_a", "embed_14x60_b"])
 def test_device_embedding_matches_reference_and_oracle(name):
     """Pick -> Slice/Mask embedding kernels (f-1) against the reference's extract_input_from_data golden vectors
