@@ -25,6 +25,7 @@ struct AsArgs {
     float* c; float* wu; float* wv;
     const float* packed;
     float* save; long long Pn;   // training forward: pre-activations kept for the backward passes, [AV_*][Pn][16], or null
+    const int32_t* ptile;        // PCSR: processing order of the 16-node tiles (PtileIter), or null
     const int32_t* src_of;       // PCSR (irregular product graph, `use_subgraph`): source node of every product node; the CSR arrays
                                  // above are then the PRODUCT-level ones (indexed by product node, columns = product-node ids)
 };
@@ -122,15 +123,16 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_items = PCSR ? (a.Pn + 15) / 16 : w.nitems;
-    const long long it0 = PCSR ? (long long)blockIdx.x * (blockDim.x >> 6) + wave : w.it;
-    const long long its = PCSR ? (long long)gridDim.x * (blockDim.x >> 6) : w.stride;
+    PtileIter ptw(PCSR ? (a.Pn + 15) / 16 : 0, blockDim.x >> 6, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_items = PCSR ? ptw.end : w.nitems;
+    const long long it0 = PCSR ? ptw.i : w.it;
+    const long long its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_items; it += its) {
         int gi = 0, tb = 0, g, su;
         bool valid;
         long long pi, pu;
         if (PCSR) {
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < a.Pn;
             pi = pu = valid ? pr : a.Pn - 1;
             g = a.src_of[pi];
@@ -219,20 +221,21 @@ __global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
     float* ts = tsc + wave * 16 * 68;
     const int S = a.S;
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_items = PCSR ? (a.Pn + 15) / 16 : w.nitems;
-    const long long it0 = PCSR ? (long long)blockIdx.x * (blockDim.x >> 6) + wave : w.it;
-    const long long its = PCSR ? (long long)gridDim.x * (blockDim.x >> 6) : w.stride;
+    PtileIter ptw(PCSR ? (a.Pn + 15) / 16 : 0, blockDim.x >> 6, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_items = PCSR ? ptw.end : w.nitems;
+    const long long it0 = PCSR ? ptw.i : w.it;
+    const long long its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_items; it += its) {
         int gi = 0, tb = 0, g, su;
         bool valid;
         long long pi, pu, pl = 0;            // pl (PCSR): the product node whose rows this lane gathers
         if (PCSR) {
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < a.Pn;
             pi = pu = valid ? pr : a.Pn - 1;
             g = a.src_of[pi];
             su = (int)pi;          // (ps, when present, is per product node on an irregular graph)
-            pl = min(it * 16 + jl, a.Pn - 1);
+            pl = min(ptile_at(a.ptile, it) * 16 + jl, a.Pn - 1);
         } else {
             w.decode(it, gi, tb);
             g = __builtin_amdgcn_readfirstlane(a.order[gi]);

@@ -982,6 +982,7 @@ struct DaArgs {
     int no_bip;                // stage 2: stop after x_latent (no Bipartite message / station sum): the association heads' last pass
     int rev;                   // k_stage2_fast: sweep every XCD's chunk backwards (the rows stage 1 wrote last are read first)
     int wgmap;                 // k_stage2_ord: blocks of 4 source nodes per workgroup, one node per wave (see the kernel)
+    const int32_t* ptile;      // irregular product graph: processing order of the kernel's tiles (16 or 32 consecutive product nodes), or null
     int np;                    // c / wv rows are NODE-PLANAR (k_stage1_h2 writes, k_stage2_h2 reads): inside the block of a source node,
                                // chunk q (16 B) of all S stations is contiguous: c [g][8][S] x 16 B, wv [g][4][S] x 16 B
     const unsigned* ea_frag;   // k_stage2_h2: edge_attr as B fragments (k_ea_frag), node-planar [g][2][S] x 16 B, processing order
@@ -1038,6 +1039,21 @@ struct ItemIter {
         gi = gbeg + (int)(sidx * (unsigned)seg) + (int)r2;
     }
 };
+
+// Irregular product graph: the n tiles of a kernel in processing order (DaArgs / TrArgs / AsArgs .ptile: by the space-filling-curve rank of their source
+// node). XCD x (workgroup b runs on XCD b % 8) takes the contiguous chunk [n x / 8, n (x + 1) / 8) of that list and its workgroups
+// stride over it, so the rows a tile gathers from neighbouring source nodes are in the L2 that is reading them anyway.
+struct PtileIter {
+    long long i, end, stride;
+    __device__ PtileIter(long long n, int waves_per_wg, int wave) {
+        const int nx = (gridDim.x >= 8 && (gridDim.x % 8) == 0) ? 8 : 1;
+        const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+        i = n * xcd / nx + (long long)lb * waves_per_wg + wave;
+        end = n * (xcd + 1) / nx;
+        stride = (long long)nbx * waves_per_wg;
+    }
+};
+__device__ __forceinline__ long long ptile_at(const int32_t* ptile, long long i) { return ptile != nullptr ? (long long)ptile[i] : i; }
 
 // Neighbour sum of PReLU_s(init_trns [Slice || Mask]) with the 30-channel hidden state RECOMPUTED from the raw
 // 8 input floats of every neighbour (2 k-steps x 2 out tiles = 4 MFMAs) instead of gathered from memory: a
@@ -1205,6 +1221,8 @@ struct genie_ctx {
     float *r_sta_w, *r_src_w;
     int2 *r_sta_cw, *r_src_cw;   // the same edges as (column, weight bits) pairs: one 8-byte load per edge (training passes)
     int32_t *rp_sta_rowptr, *rp_src_rowptr; int2 *rp_sta_cw, *rp_src_cw;   // irregular product graph: the reversed PRODUCT-level graphs
+    int32_t *ptile16, *ptile32;  // irregular product graph: the tiles of 16 / 32 consecutive product nodes in the ORDER they are processed in
+                                 // (by the space-filling-curve rank of their source node): neighbouring source nodes run together on one XCD
     const float *xs_slice, *xs_mask;   // genie_embed_window_split: the (Slice, Mask) buffers whose split rows already sit in the workspace (one-shot)
     const void* xs_ws;
     int xs_mm_copy;            // ... and the copy (slot % GENIE_NBIG at embed time) its message-mask row `mm` was written to
@@ -1961,7 +1979,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr; c->ebias_sta_p = nullptr; c->sta_ident = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr;
     c->r_sta_w = c->r_src_w = nullptr; c->r_sta_cw = c->r_src_cw = nullptr;
-    c->rp_sta_rowptr = c->rp_src_rowptr = nullptr; c->rp_sta_cw = c->rp_src_cw = nullptr;
+    c->rp_sta_rowptr = c->rp_src_rowptr = nullptr; c->rp_sta_cw = c->rp_src_cw = nullptr; c->ptile16 = c->ptile32 = nullptr;
     c->pcsr = false; c->pcsr_h2 = false;
     c->p_sta_rowptr = c->p_sta_col = c->p_src_rowptr = c->p_src_col = c->seg_rowptr = nullptr;
     c->src_tab = nullptr;
@@ -2079,6 +2097,25 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
         int m1 = 0, m2 = 0;
         for (long long i = 0; i < n_prod; ++i) { m1 = std::max(m1, r1[i + 1] - r1[i]); m2 = std::max(m2, r2[i + 1] - r2[i]); }
         c->pcsr_h2 = m1 <= 8 && m2 <= 15;
+    }
+    {   // processing order of the tiles: the product nodes stay where the caller put them (grouped by source node in HIS order), but
+        // the tiles are taken in the space-filling-curve order of their source nodes, one contiguous chunk of that list per XCD, so
+        // the rows a tile gathers (neighbouring source nodes) are being read by the same L2 at about the same time
+        std::vector<int32_t> seg((size_t)n_grid + 1), ord((size_t)n_grid), rank((size_t)n_grid, 0);
+        HIP_TRY(hipMemcpy(seg.data(), seg_rowptr, sizeof(int32_t) * seg.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ord.data(), c->order, sizeof(int32_t) * ord.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_grid; ++i) rank[ord[i]] = i;
+        std::vector<int32_t> src_of((size_t)n_prod);
+        for (int g = 0; g < n_grid; ++g) for (int32_t pr = seg[g]; pr < seg[g + 1]; ++pr) src_of[pr] = g;
+        for (int w = 16; w <= 32; w += 16) {
+            const int nt = (int)((n_prod + w - 1) / w);
+            std::vector<int32_t> t((size_t)nt);
+            for (int i = 0; i < nt; ++i) t[i] = i;
+            std::stable_sort(t.begin(), t.end(), [&](int32_t x, int32_t y) { return rank[src_of[(size_t)x * w]] < rank[src_of[(size_t)y * w]]; });
+            int32_t** dst = w == 16 ? &c->ptile16 : &c->ptile32;
+            HIP_TRY(hipMalloc((void**)dst, sizeof(int32_t) * (size_t)std::max(nt, 1)));
+            HIP_TRY(hipMemcpy(*dst, t.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
+        }
     }
     c->use_fast = c->use_h2 = 0;
     c->ks_uni = c->kp_uni = -1;
@@ -2216,7 +2253,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->as_pg, c->as_ps, c->d_h2tbl, c->packed_h2, c->src_tab,
                     c->mpos_sta, c->mpos_src, c->ebias_sta, c->ebias_src,
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
-                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw, c->rp_sta_rowptr, c->rp_src_rowptr, c->rp_sta_cw, c->rp_src_cw,
+                    c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw, c->rp_sta_rowptr, c->rp_src_rowptr, c->rp_sta_cw, c->rp_src_cw, c->ptile16, c->ptile32,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
                     c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
     for (void* p : ptrs) (void)hipFree(p);
@@ -2291,8 +2328,9 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
         const long long nitems = (c->P + 31) / 32;
-        const int grid = (int)std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b);
+        const int grid = (int)std::max<long long>(8, std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b) / 8 * 8);
         const bool bigp = c->P * XROW >= (1ll << 32);
+        a.ptile = c->ptile32;
         if (c->abs_sta) {      // position pieces per product node (genie_set_absolute_pos on a subgraph context)
             if (c->abs_dirty || !c->abs_ts) {
                 if (!c->abs_ts) {
@@ -2315,7 +2353,9 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         }
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
-        k_stage1_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1), 256, 0, st>>>(a);
+        a.ptile = c->ptile16;
+        const long long gw = std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc1);
+        k_stage1_pcsr<<<(int)std::max<long long>(8, gw / 8 * 8), 256, 0, st>>>(a);
     } else if (h2_on(c)) {
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
         // genie_embed_window_split, one-shot; its rows count only if they were written under the station-order state of THIS call
@@ -2530,7 +2570,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
     } else if (c->pcsr) {
         const long long ntiles = (c->P + 15) / 16;
-        k_stage2_pcsr<<<(int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2), 256, 0, st>>>(a);    // 2 .. 12 workgroups per CU: +-1 %
+        a.ptile = c->ptile16;
+        const long long gw = std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2);      // 2 .. 12 workgroups per CU: +-1 %
+        k_stage2_pcsr<<<(int)std::max<long long>(8, gw / 8 * 8), 256, 0, st>>>(a);                       // (a multiple of the 8 XCDs)
     } else if (c->use_fast && a.sta_user != nullptr && (!no_bip || x_latent_out != nullptr)) {
         // the production configuration: uniform 8 / 15-degree graphs, station processing order; the static edge_attr is registered
         // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])
@@ -3233,7 +3275,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     a.store_dz0 = c->abs_sta != nullptr;
     if (c->pcsr) {
         if ((rc = ensure_src_of(c, st))) return rc;
-        a.src_of = c->p_src_of;
+        a.src_of = c->p_src_of; a.ptile = c->ptile16;
         a.r_sta_rowptr = c->rp_sta_rowptr; a.r_sta_cw = c->rp_sta_cw; a.r_src_rowptr = c->rp_src_rowptr; a.r_src_cw = c->rp_src_cw;
         a.r_sta_col = a.r_src_col = nullptr; a.r_sta_w = a.r_src_w = nullptr;       // (the PCSR passes read the pair arrays only)
     }
@@ -3536,9 +3578,9 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if (c->pcsr) {       // irregular product graph: product-level CSRs, the source node of every product node from the row ranges
         if ((rc = ensure_src_of(c, st))) return rc;
         a.sta_rowptr = c->p_sta_rowptr; a.sta_col = c->p_sta_col; a.src_rowptr = c->p_src_rowptr; a.src_col = c->p_src_col;
-        a.sta_user = nullptr; a.src_of = c->p_src_of;
+        a.sta_user = nullptr; a.src_of = c->p_src_of; a.ptile = c->ptile16;
         const long long ntiles = (c->P + 15) / 16;
-        const int grid = (int)std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * std::max(1, c->bpc1));
+        const int grid = (int)std::max<long long>(8, std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * std::max(1, c->bpc1)) / 8 * 8);
         a.packed = c->packed[2];
         k_assoc_a<true><<<grid, 256, 0, st>>>(a);
         a.packed = c->packed[3];
@@ -3601,7 +3643,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     const bool variant = c->has_edges || c->abs_sta != nullptr;
     if (c->pcsr) {
         if ((rc = ensure_src_of(c, st))) return rc;
-        a.src_of = c->p_src_of;
+        a.src_of = c->p_src_of; a.ptile = c->ptile16;
         a.r_sta_rowptr = c->rp_sta_rowptr; a.r_sta_cw = c->rp_sta_cw; a.r_src_rowptr = c->rp_src_rowptr; a.r_src_cw = c->rp_src_cw;
         a.r_sta_col = a.r_src_col = nullptr; a.r_sta_w = a.r_src_w = nullptr;
     }

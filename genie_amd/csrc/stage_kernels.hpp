@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
     int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const long long ntiles = (a.Pn + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
-         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+    PtileIter pt(ntiles, blockDim.x >> 6, threadIdx.x >> 6);
+    for (; pt.i < pt.end; pt.i += pt.stride) {
+        const long long tile = ptile_at(a.ptile, pt.i);
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
 #endif
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     };
     constexpr int KPP = PCSR ? KP : 1;
     auto fetch_pcsr = [&](long long pit_, long long& p_, bool& valid_, int (&sta_)[KS], int (&src_)[KPP], int& ds_, int& dp_) {
-        const long long pr = pit_ * 32 + (lane & 31);
+        const long long pr = ptile_at(a.ptile, pit_) * 32 + (lane & 31);
         valid_ = pr < a.Pn;
         p_ = valid_ ? pr : a.Pn - 1;
         const int eb = a.sta_rowptr[p_], fb = a.src_rowptr[p_];
@@ -584,9 +585,10 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
     long long pcur = 0;
     bool valid = false;
     // wave items: Cartesian = pairs of (source node, station tile) items of the XCD-aware sweep; PCSR = 32 consecutive product nodes
-    const long long pit0 = PCSR ? (long long)blockIdx.x * (H2_THREADS / 64) + wave : w.it;
-    const long long pstride = PCSR ? (long long)gridDim.x * (H2_THREADS / 64) : w.stride;
-    const long long pend = PCSR ? (a.Pn + 31) / 32 : (w.nitems + 1) / 2;
+    PtileIter ptw(PCSR ? (a.Pn + 31) / 32 : 0, H2_THREADS / 64, wave);       // PCSR: positions in the processing order of the 32-node items
+    const long long pit0 = PCSR ? ptw.i : w.it;
+    const long long pstride = PCSR ? ptw.stride : w.stride;
+    const long long pend = PCSR ? ptw.end : (w.nitems + 1) / 2;
     if (pit0 < pend) {
         if constexpr (PCSR) fetch_pcsr(pit0, pcur, valid, sta_id, src_id, dgs, dgp);
         else fetch_ids(pit0, idv, sc, valid, sta_id);
@@ -960,8 +962,9 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     const int jl = lane >> 2, ql = lane & 3;      // (node, 16-B chunk) this lane LOADS: four consecutive lanes read one 64-B row
     float* ts = tsc + (threadIdx.x >> 6) * 16 * 36;
     const long long ntiles = (a.Pn + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles;
-         tile += (long long)gridDim.x * (blockDim.x >> 6)) {
+    PtileIter pt(ntiles, blockDim.x >> 6, threadIdx.x >> 6);
+    for (; pt.i < pt.end; pt.i += pt.stride) {
+        const long long tile = ptile_at(a.ptile, pt.i);
 #if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
 #endif

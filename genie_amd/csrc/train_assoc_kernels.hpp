@@ -46,13 +46,13 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
     const long long P = a.P;
     float scal[1] = {0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
-                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         bool valid;
         long long p;
         if (PCSR) {
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < P;
             p = valid ? pr : P - 1;
         } else {
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
-                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g, scn = 0, tb = 0;
         bool valid;
         long long p;
         if (PCSR) {       // 16 consecutive product nodes of an irregular product graph; the source node is per lane
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < P;
             p = valid ? pr : P - 1;
             g = a.src_of[p];
@@ -233,14 +233,14 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
-                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g, scn = 0, tb = 0;
         bool valid;
         long long p;
         if (PCSR) {       // 16 consecutive product nodes of an irregular product graph; the source node is per lane
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < P;
             p = valid ? pr : P - 1;
             g = a.src_of[p];

@@ -26,6 +26,7 @@ struct TrArgs {
     const int32_t* r_sta_rowptr; const int32_t* r_sta_col; const float* r_sta_w;    // reversed base graphs (out-edges, 1 / in-degree)
     const int32_t* r_src_rowptr; const int32_t* r_src_col; const float* r_src_w;
     const int2* r_sta_cw; const int2* r_src_cw;    // the same edges as (column, weight bits) pairs
+    const int32_t* ptile;        // irregular product graph: processing order of the 16-node tiles (PtileIter), or null
     const int32_t* src_of;       // irregular product graph (PCSR kernels): source node of every product node; the r_* arrays are then
                                  // the reversed PRODUCT-level graphs (indexed by product node, columns = product-node ids)
     const float* slice; const float* mask; const float* edge_attr;
@@ -230,14 +231,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
     for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
-                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g;
         bool valid;
         long long p;
         if (PCSR) {       // a tile is 16 consecutive product nodes, the source node is per lane
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < P;
             p = valid ? pr : P - 1;
             g = a.src_of[p];
@@ -539,9 +540,10 @@ __global__ __launch_bounds__(256, 1) void k_train_b1p(TrArgs a) {
     const int SVT = a.sv_t, SVU = a.sv_up, SVV = a.sv_vp;
     (void)S;
     const long long ntiles = (P + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    PtileIter ptw(ntiles, 4, wave);
+    for (; ptw.i < ptw.end; ptw.i += ptw.stride) {
         asm volatile("" : "+v"(lane));
-        const long long pr = tile * 16 + j;
+        const long long pr = ptile_at(a.ptile, ptw.i) * 16 + j;
         const bool valid = pr < P;
         const long long p = valid ? pr : P - 1;
         const int g = a.src_of[p];               // per lane: a tile may straddle source nodes
@@ -657,14 +659,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    const long long n_it = PCSR ? (P + 15) / 16 : w.nitems, it0 = PCSR ? (long long)blockIdx.x * 4 + wave : w.it,
-                    its = PCSR ? (long long)gridDim.x * 4 : w.stride;
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g = 0, scn = 0;
         bool valid;
         long long p;
         if (PCSR) {       // 16 consecutive product nodes; the transposed means run over the reversed PRODUCT-level graphs
-            const long long pr = it * 16 + j;
+            const long long pr = ptile_at(a.ptile, it) * 16 + j;
             valid = pr < P;
             p = valid ? pr : P - 1;
         } else {
