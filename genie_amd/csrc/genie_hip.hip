@@ -1294,6 +1294,16 @@ namespace {
 // rows of the static edge-feature tables (DataAggregationEdges): per station / per source node, per product node on an irregular graph
 long long edge_rows_sta(const genie_ctx* c) { return c->pcsr ? c->P : c->S; }
 long long edge_rows_src(const genie_ctx* c) { return c->pcsr ? c->P : c->G; }
+// scheduling overrides of the tuning builds (-DGENIE_TUNING=1: tools/tune.py, tools/*_sweep.sh); the product library reads no
+// environment variable
+const char* tune_env(const char* name) {
+#if GENIE_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 bool h2_on(const genie_ctx* c) { return c->use_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool pcsr_h2_on(const genie_ctx* c) { return c->pcsr_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !h2_on(c)); }
@@ -2007,7 +2017,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         const char* e;
         // scheduling segments: node-major sweeps (1) at config 2; at 2000 stations station-tile-major sweeps over segments of 16
         // source nodes keep the source-neighbour rows of stage 1 in L2 (config 4 on one GPU: stage 1 25.8 -> 24.8 ms)
-        c->seg = (e = getenv("GENIE_SEG")) ? atoi(e) : (n_sta >= 1024 ? 16 : 1);
+        c->seg = (e = tune_env("GENIE_SEG")) ? atoi(e) : (n_sta >= 1024 ? 16 : 1);
         // G-sized tail: few, long-lived workgroups. Next to the persistent P-sized kernels a tail workgroup only runs when one
         // of theirs retires and keeps that CU until it ends, so what the tail costs the main stream is its CU-time = workgroups x
         // duration, and most of a short tail workgroup is fixed cost (its LDS weight image). Two 62-KB read-out workgroups per CU
@@ -2020,21 +2030,21 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false>, 256, 0));
         c->bpc1 = std::max(1, occ1);
-        c->bpc2 = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
+        c->bpc2 = (e = tune_env("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
         // Large station counts (config 4: 2000 stations, 128 KB of wu / wv rows per source node): the gathers leave L2, and what
         // pays is locality, not concurrency: blocks of 4 adjacent source nodes per workgroup (one node per wave: the four waves
         // share half of their source rows, every wu block is gathered on one CU) and two workgroups per CU. Config 4 on one
         // GPU: stage 2 16.1 -> 11.8 ms (three workgroups, interleaved items: 16.1; two: 14.8; block map alone: 13.1). At 200
         // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
-        c->s2_wgmap = (e = getenv("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
+        c->s2_wgmap = (e = tune_env("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
         {
             int occh = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occh, k_stage2_h2<false, false>, 256, 0));
             // two workgroups per CU: as fast as three (0.2367 / 0.2370 ms) with 8 % less fabric traffic (FETCH_SIZE 5.18e5 vs 5.62e5 KB)
-            c->bpc2h = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occh));
-            c->s2u_off = getenv("GENIE_S2_NOUNION") != nullptr;
+            c->bpc2h = (e = tune_env("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occh));
+            c->s2u_off = tune_env("GENIE_S2_NOUNION") != nullptr;
         }
-        c->bpc2o = (e = getenv("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occo));     // round 3, after the f16x2 stage 1: 2 beat 3 at 200 stations too (window 0.593 -> 0.588 ms)
+        c->bpc2o = (e = tune_env("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occo));     // round 3, after the f16x2 stage 1: 2 beat 3 at 200 stations too (window 0.593 -> 0.588 ms)
         // the reference's kNN graphs (8 station / 15 source neighbours everywhere): pipelined kernels k_stage1_h2 / k_stage2_ord
         c->use_fast = c->ks_uni == 8 && c->kp_uni == 15;
         // f16x2 kernels: 24-bit multiplicands (64-bit row offsets are a template variant). Whether they run: h2_on()
@@ -3929,6 +3939,12 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
 int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_phase_types: null context");
     c->no_phase = use_phase_types ? 0 : 1;
+    return GENIE_OK;
+}
+
+int genie_set_stage2_workmap(genie_ctx* c, int blocks_of_four) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_set_stage2_workmap: null context");
+    c->s2_wgmap = blocks_of_four < 0 ? (c->S >= 1024) : (blocks_of_four != 0);
     return GENIE_OK;
 }
 

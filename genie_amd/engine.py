@@ -294,6 +294,11 @@ class HipPath(object):
         self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
         self._w_key = None
 
+    def set_stage2_workmap(self, blocks_of_four):
+        """Work map of the row-layout stage 2 (genie_set_stage2_workmap): True / False, None = the default for the station count."""
+        v = -1 if blocks_of_four is None else (1 if blocks_of_four else 0)
+        _lib.check(self.lib.genie_set_stage2_workmap(self.ctx, v), "genie_set_stage2_workmap")
+
     def set_sign_input(self, use_sign_input):
         """`use_sign_input` of config.yaml:93 for the device embedding (genie_set_sign_input): features signed by the series' negative slope."""
         _lib.check(self.lib.genie_set_sign_input(self.ctx, 1 if use_sign_input else 0), "genie_set_sign_input")

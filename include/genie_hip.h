@@ -98,6 +98,11 @@ int genie_set_phase_types(genie_ctx* ctx, int use_phase_types);
  * difference of the series it is read from, at the index it is read at (+1 on the falling side of a pick's kernel, -1 on the rising
  * side, 0 on a flat stretch); Mask = |Slice| > 0.01 as before. Default off. */
 int genie_set_sign_input(genie_ctx* ctx, int use_sign_input);
+/* Work map of the row-layout stage 2 (k_stage2_ord: the association pass, the training forward of other graph shapes): 1 = blocks of 4
+ * adjacent source nodes per workgroup, one node per wave (the default from 1024 stations up: the gathers leave L2 there and locality
+ * pays), 0 = interleaved items, -1 = the default for the context's station count. Results do not depend on it (tests). The library reads
+ * no environment variable; this is the one scheduling choice a caller can make. */
+int genie_set_stage2_workmap(genie_ctx* ctx, int blocks_of_four);
 /* Arithmetic of the G-sized tail of inference calls (Bipartite read-out, SpatialAggregation x3, SpatialDirect + TemporalAttention
  * on the grid): fp64_chains != 0 (default) = every Linear as a chain of fp64 MFMAs on the fp32 inputs and weights, fp64 PReLUs
  * and sums, one rounding to fp32 per kernel; 0 = fp32 MFMA chains (the arithmetic of the training forward, and the A/B form).

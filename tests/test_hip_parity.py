@@ -1524,8 +1524,7 @@ def test_association_heads_hip_match_oracle(S, G):
 
 
 @pytest.mark.parametrize("S,G", [(200, 300), (40, 90), (100, 64)])
-@pytest.mark.parametrize("env", [("GENIE_S2_WGMAP", "1")])
-def test_stage2_work_maps_are_bitwise_equal(S, G, env, monkeypatch):
+def test_stage2_work_maps_are_bitwise_equal(S, G):
     """k_stage2_ord with its large-station-count work map (blocks of 4 source nodes per workgroup, one node per wave; the default
     from 1024 stations up) against the interleaved map: x_latent, Bipartite output and the association pass (stage 2 without its
     Bipartite half) bit for bit -- per-tile results do not depend on which wave computes them."""
@@ -1538,17 +1537,17 @@ def test_stage2_work_maps_are_bitwise_equal(S, G, env, monkeypatch):
     yl = torch.from_numpy(rng.normal(0, 1, (G, 30)).astype(np.float32)).to(DEV)
     ms = torch.from_numpy((rng.random(G) < 0.5).astype(np.float32)).to(DEV)
 
-    def run():
+    def run(blocks_of_four):
         hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
                             engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), grid_order=engine.sfc_order(geom.x_grid),
                             device=DEV, sta_order=engine.sfc_order(geom.locs))
+        hp.set_stage2_workmap(blocks_of_four)          # (genie_set_stage2_workmap: the library reads no environment variable)
         hp.set_weights(wd)
         out, xl, bip = hp.path_fwd(Slice, Mask, ea, pos, True, True)
         return out, xl, bip, hp.assoc_fwd(yl, ms, xl, Mask, ea)
 
-    base = run()
-    monkeypatch.setenv(*env)
-    got = run()
+    base = run(False)
+    got = run(True)
     for a, b in zip(base, got):
         assert torch.equal(a, b)
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Stage-2 kernel alone (HIP events over repeated launches after one stage 1), for A/B runs of kernel variants selected by
-environment variables (GENIE_BPC2 = workgroups per CU, GENIE_S2_WGMAP = work map).
+environment variables (GENIE_BPC2 = workgroups per CU, GENIE_S2_WGMAP = work map; read by -DGENIE_TUNING=1 builds only:
+GENIE_LIB_PATH=genie_amd/lib/libgenie_tune.so).
 Usage: python tools/s2_time.py [config] [iters]"""
 import os
 import sys
