@@ -2542,9 +2542,10 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     a.ea_int = nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && h2_on(c) && c->src_tab != nullptr && !no_bip) {
+    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && h2_on(c) && !abs_generic(c) && c->src_tab != nullptr && !no_bip) {
         // training forward on the reference's kNN graphs: the production stage 2 in the CALLER's station order (identity
-        // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass
+        // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass of
+        // k_stage1_h2's launch (both model options at once run the generic stage 1, which has no split pass: generic stage 2 below)
         if (!c->sta_ident) {
             std::vector<int32_t> id((size_t)c->S);
             for (int i = 0; i < c->S; ++i) id[i] = i;
