@@ -26,9 +26,23 @@ def _draw(seed):
     rng = np.random.default_rng(1000 + seed)
     S = int(rng.choice([3, 4, 7, 15, 16, 17, 31, 33, 48, 64, 70]))
     G = int(rng.choice([10, 16, 17, 40, 63, 129, 257, 400]))       # (the read-out takes the 10 nearest source nodes of a query)
-    return dict(S=S, G=G, Q=int(rng.integers(1, 80)), n_picks=int(rng.choice([0, 1, 50, 400, 2000])),
-                edges=bool(rng.integers(2)), abspos=bool(rng.integers(2)), subgraph=bool(rng.integers(2)),
-                stage="f32" if rng.integers(3) == 0 else "default", L=float(rng.choice([40e3, 150e3, 400e3])), seed=seed)
+    cfg = dict(S=S, G=G, Q=int(rng.integers(1, 80)), n_picks=int(rng.choice([0, 1, 50, 400, 2000])),
+               edges=bool(rng.integers(2)), abspos=bool(rng.integers(2)), subgraph=bool(rng.integers(2)),
+               stage="f32" if rng.integers(3) == 0 else "default", L=float(rng.choice([40e3, 150e3, 400e3])), seed=seed)
+    # (drawn after the fields above so that the cases of earlier sweeps keep their seeds)
+    cfg["ragged"] = bool(rng.integers(4) == 0)      # base graphs with edges dropped at random: non-uniform degrees, empty neighbourhoods
+    if rng.integers(5) == 0:                        # the production station counts (k_stage2_h2u, work maps), fewer source nodes
+        cfg["S"], cfg["G"] = int(rng.choice([100, 200, 333])), int(rng.choice([16, 40, 129]))
+    return cfg
+
+
+def _geometry(cfg):
+    geom = synthetic.Geometry(cfg["S"], cfg["G"], L=cfg["L"], n_query=cfg["Q"], seed=300 + cfg["seed"])
+    if cfg.get("ragged"):
+        rng = np.random.default_rng(1300 + cfg["seed"])
+        geom.A_sta_sta = np.ascontiguousarray(geom.A_sta_sta[:, rng.random(geom.A_sta_sta.shape[1]) >= 0.25])
+        geom.A_src_src = np.ascontiguousarray(geom.A_src_src[:, rng.random(geom.A_src_src.shape[1]) >= 0.25])
+    return geom
 
 
 def _weights(cfg):
@@ -50,7 +64,7 @@ def test_random_case_forward_and_gradients_match_the_oracle(i, monkeypatch):
     if cfg["stage"] == "f32":
         monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     S, G, Q = cfg["S"], cfg["G"], cfg["Q"]
-    geom = synthetic.Geometry(S, G, L=cfg["L"], n_query=Q, seed=300 + cfg["seed"])
+    geom = _geometry(cfg)
     win = synthetic.make_window(geom, cfg["n_picks"], seed=500 + cfg["seed"])
     c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
     t = lambda a: c(a).to(DEV)
@@ -105,7 +119,7 @@ def test_random_case_forward_and_gradients_match_the_oracle(i, monkeypatch):
     assert ey <= 1e-5 and ex <= 1e-5, (cfg, ey, ex)
     assert ty <= 1e-5 and tx <= 1e-5, (cfg, ty, tx)
     gmax = max(float(v.abs().max()) for v in gref.values() if v is not None)
-    checked, worst, nudged = 0, 0.0, None
+    checked, worst, nudged, excused = 0, 0.0, None, 0
     for k, p in net.named_parameters():
         ref = gref[k]
         if ref is None:
@@ -123,10 +137,11 @@ def test_random_case_forward_and_gradients_match_the_oracle(i, monkeypatch):
             jump = max(max_abs(g[k], ref) for g in nudged)
             print("kink check %s: error %.2e, oracle's own jump under a 1e-6 weight scaling %.2e" % (k, err, jump))
             assert jump >= 0.5 * err, (cfg, k, err, tol, jump)
+            excused += 1
             continue
         worst = max(worst, err / tol)
         checked += 1
-    assert checked >= 80
+    assert checked + excused >= 80
     print("worst gradient error / tolerance %.3f over %d parameters" % (worst, checked))
 
 
@@ -164,7 +179,7 @@ def test_random_case_four_outputs_and_gradients_match_the_oracle(i, monkeypatch)
     if cfg["stage"] == "f32":
         monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
     S, G, Q = cfg["S"], cfg["G"], cfg["Q"]
-    geom = synthetic.Geometry(S, G, L=cfg["L"], n_query=Q, seed=300 + cfg["seed"])
+    geom = _geometry(cfg)
     smp = synthetic.training_sample(geom, cfg["n_picks"], n_src=min(cfg["n_src"], G), seed=600 + cfg["seed"], window=0)
     Slice, Mask, ea, tlat = smp["Slice"], smp["Mask"], geom.edge_attr(), smp["tlatent"]
     A_edges_p, A_edges_s, dtp = smp["A_edges_p"], smp["A_edges_s"], smp["dt_partition"]
