@@ -823,15 +823,15 @@ def test_config2_full_size_properties():
     assert ey <= 1e-5 and ex <= 1e-5                  # fp32 max-abs tolerance of BASELINE.json
 
 
-def test_sharded_kernels_two_virtual_ranks_match_unsharded():
-    """Source-node sharding on ONE GPU: two virtual ranks (halo rows, local CSR numbering, n_grid_ext > n_grid), the
+@pytest.mark.parametrize("S,G,W", [(40, 600, 2), (200, 300, 3), (17, 95, 4), (64, 1000, 8), (33, 257, 5)])
+def test_sharded_kernels_virtual_ranks_match_unsharded(S, G, W):
+    """Source-node sharding on ONE GPU: W virtual ranks (halo rows, local CSR numbering, n_grid_ext > n_grid), the
     halo all-to-all replaced by direct copies. The result must equal the unsharded HIP path bit for bit (same kernels,
     same per-node arithmetic) and the oracle to tolerance. The RCCL collective itself is covered by tests/test_dist_cpu.py
     (gloo) and runs for real only on a multi-GPU node."""
     from genie_amd import dist as gdist
     from oracle import genie_oracle as O
-    S, G = 40, 600
-    geom = synthetic.Geometry(S, G, L=200e3, n_query=20, seed=41)
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=20, seed=41 + W)
     win = synthetic.make_window(geom, 400, seed=42)
     w = Case("odd_33x257").weights
     wd = {k: v.to(DEV) for k, v in w.items()}
@@ -844,8 +844,7 @@ def test_sharded_kernels_two_virtual_ranks_match_unsharded():
                         grid_order=engine.sfc_order(geom.x_grid), device=DEV, sta_order=engine.sfc_order(geom.locs))
     hp.set_weights(wd)
     out_ref, xl_ref, bip_ref = hp.path_fwd(Slice.to(DEV), Mask.to(DEV), ea.to(DEV), pos.to(DEV), True, True)
-    # two virtual ranks (same station processing order: the per-tile station sums then add in the same order)
-    W = 2
+    # virtual ranks (same station processing order: the per-tile station sums then add in the same order)
     ranks = [gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, W, r, DEV, pos_sta=geom.locs) for r in range(W)]
     rows = []
     for sp in ranks:
