@@ -1079,17 +1079,17 @@ def test_device_embedding_matches_reference_and_oracle(name):
     assert float(S1[:, 2:].abs().max()) == 0.0 and float(M1[:, 2:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("batch", [1, 4])
-def test_device_apply_loop_matches_oracle(batch):
+@pytest.mark.parametrize("batch,S,G,n_picks,step_size", [(1, 10, 70, 120, "half"), (4, 10, 70, 120, "half"), (4, 40, 150, 700, "full"),
+                                                         (3, 17, 64, 300, "partial")])
+def test_device_apply_loop_matches_oracle(batch, S, G, n_picks, step_size):
     """GPU-only apply loop (device embedding + forward + Out_2 stacking; one tail per window, or tails batched 4 windows at a
     time) vs the oracle chain embed_oracle.extract_input_from_data -> genie_oracle.forward_fixed_source_structured -> same
     stacking."""
     from genie_amd import apply
     from oracle import embed_oracle as E
     from oracle import genie_oracle as O
-    S, G = 10, 70
     geom = synthetic.Geometry(S, G, L=60e3, n_query=12, seed=71)
-    P = synthetic.make_picks(geom, 120, seed=72)
+    P = synthetic.make_picks(geom, n_picks, seed=72)
     P[:, 0] = P[:, 0] * 0.25 + 5000.0
     P = P[np.argsort(P[:, 0], kind="stable")]
     trv = geom.travel_times().astype(np.float32)
@@ -1101,10 +1101,10 @@ def test_device_apply_loop_matches_oracle(batch):
                              torch.from_numpy(geom.edge_attr()).to(DEV), torch.from_numpy(geom.locs).float().to(DEV),
                              torch.from_numpy(geom.x_grid).float().to(DEV))
     max_t = float(np.ceil(trv.max() + 1.0))
-    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size="half", min_required_picks=5, max_t=max_t,
+    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size=step_size, min_required_picks=5, max_t=max_t,
                                               tail_batch=batch)
-    assert 2 <= len(times) <= 40
-    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size="half")
+    assert 2 <= len(times) <= 60
+    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size=step_size)
     tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
     A = np.stack([np.tile(np.arange(S), G), np.repeat(np.arange(G), S)], axis=0)
     sta_nbr = graph.neighbour_table(geom.A_sta_sta, S)
@@ -1116,8 +1116,9 @@ def test_device_apply_loop_matches_oracle(batch):
                                                  torch.from_numpy(geom.edge_attr()), torch.from_numpy(geom.A_src_src),
                                                  torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
                                                  torch.from_numpy(offsets.reshape(-1, 1)).float(), S, G)
-        ip = np.abs(tsteps_abs.reshape(-1, 1) - (t0 + offsets).reshape(1, -1)).argmin(0)
-        want[:, ip[:-1]] += x[:, :-1, 0] / 2.0
+        cols, keep = apply.window_columns(tsteps_abs, float(t0), offsets, step_size == "half")      # (process_continuous_days.py:766,797-805)
+        want[:, cols] += x[:, keep, 0] / n_overlap
+    assert float(want.abs().max()) > 0
     assert max_abs(Out_2.cpu(), want) <= 1e-5
 
 
