@@ -1306,6 +1306,7 @@ const char* tune_env(const char* name) {
 }
 bool h2_on(const genie_ctx* c) { return c->use_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool pcsr_h2_on(const genie_ctx* c) { return c->pcsr_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
+int part_T(const genie_ctx* c) { return c->pcsr ? 1 : c->T; }      // rows of station-sum partials per source node in `part`
 bool abs_generic(const genie_ctx* c) { return c->abs_sta != nullptr && (c->has_edges || !h2_on(c)); }
 bool sta_order_on(const genie_ctx* c) {
     return c->sta_perm != nullptr && !c->pcsr && h2_on(c) && !abs_generic(c) && !c->force_generic;
@@ -2584,6 +2585,12 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         a.ptile = c->ptile16;
         const long long gw = std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2);      // 2 .. 12 workgroups per CU: +-1 %
         k_stage2_pcsr<<<(int)std::max<long long>(8, gw / 8 * 8), 256, 0, st>>>(a);                       // (a multiple of the 8 XCDs)
+        // the gated messages sit in the c rows, which exist GENIE_NBIG times only: their station sums (row order) go to the window's
+        // own slot right away, one partial row per source node, so that every tail form (per window, side streams, batched) reads
+        // `part` as it does on a Cartesian graph
+        if (!no_bip)
+            k_seg_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride, c->seg_rowptr,
+                                                                 c->G, (float*)ws + c->o_part + c->slot * c->slot_stride);
     } else if (c->use_fast && a.sta_user != nullptr && (!no_bip || x_latent_out != nullptr)) {
         // the production configuration: uniform 8 / 15-degree graphs, station processing order; the static edge_attr is registered
         // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])
@@ -2640,15 +2647,9 @@ int genie_bipartite_readout(genie_ctx* c, float* bip_out, void* ws, void* stream
     if (rc) return rc;
     if (!bip_out) return fail(GENIE_ERR_ARG, "genie_bipartite_readout: null output");
     const float* part = (const float*)ws + c->o_part + c->slot * c->slot_stride;
-    if (c->pcsr) {     // the messages sit in the c rows (k_stage2_pcsr)
-        const int nb = std::min((c->G + NPB - 1) / NPB, c->num_cu * 8);
-        k_bip_out_seg<<<nb, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride, c->G, c->seg_rowptr, c->raw,
-                                                          g_params[W_BP_FC2_W].off, g_params[W_BP_FC2_B].off, g_params[W_BP_ACT2].off, bip_out);
-    } else {
-        { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
-        if (tail_wide(c)) k_bip_out_m<true><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
-        else k_bip_out_m<false><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, c->T, c->packed[PL_BIP], bip_out, 0, 0);
-    }
+    { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
+    if (tail_wide(c)) k_bip_out_m<true><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, part_T(c), c->packed[PL_BIP], bip_out, 0, 0);
+    else k_bip_out_m<false><<<tl_blocks(c->G, c->num_cu * 2), 256, 0, (hipStream_t)stream>>>(part, c->G, part_T(c), c->packed[PL_BIP], bip_out, 0, 0);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -2873,7 +2874,6 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
     if (nwin < 1 || slot0 < 0 || slot0 + nwin > GENIE_NSLOT) return fail(GENIE_ERR_ARG, "genie_tail_batched: windows must fit slots [0, 33)");
     if (n_t < 1 || n_t > RO_TMAX) return fail(GENIE_ERR_ARG, "genie_tail_batched: 1 <= n_t <= 10 required");
     if (x_out && (!x_query || !knn || n_query < 1 || k != RO_K)) return fail(GENIE_ERR_ARG, "genie_tail_batched: bad query arguments");
-    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_tail_batched: not available with use_subgraph product graphs");
     if (c->G_ext != c->G) return fail(GENIE_ERR_STATE, "genie_tail_batched needs an unsharded source graph");
     if ((long long)nwin * std::max(c->G, n_query) > 0x7fffffffLL) return fail(GENIE_ERR_ARG, "genie_tail_batched: batch too large");
     { int rcp = ensure_packed(c, (hipStream_t)stream); if (rcp) return rcp; }
@@ -2893,8 +2893,8 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.out = w + c->o_bip + so; a.ws_out = ss; a.ws_slot = ss;
         a.pj_out = pj[0]; a.gpart_out = gp[0];
         a.img = c->packed[PL_SA1];
-        if (tail_wide(c)) k_bip_pre_m<true><<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
-        else k_bip_pre_m<false><<<grid, 256, 0, st>>>(w + c->o_part + so, c->T, c->packed[PL_BIP], ss, a);
+        if (tail_wide(c)) k_bip_pre_m<true><<<grid, 256, 0, st>>>(w + c->o_part + so, part_T(c), c->packed[PL_BIP], ss, a);
+        else k_bip_pre_m<false><<<grid, 256, 0, st>>>(w + c->o_part + so, part_T(c), c->packed[PL_BIP], ss, a);
     }
     // SpatialAggregation x3: bip -> sa0 -> sa1 -> x_spatial_out [nwin, G, 30]
     for (int layer = 1; layer <= 3; ++layer) {
@@ -3143,7 +3143,6 @@ int train_check(const genie_ctx* c, const char* who, bool variants = false, bool
     return GENIE_OK;
 }
 // station sums live as [G][T][32] partial rows; on an irregular product graph the training calls keep ONE row per source node there
-int part_T(const genie_ctx* c) { return c->pcsr ? 1 : c->T; }
 int ensure_src_of(genie_ctx* c, hipStream_t st) {
     if (c->p_src_of || !c->pcsr) return GENIE_OK;
     HIP_TRY(hipMalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
@@ -3214,9 +3213,6 @@ int genie_da_train_fwd(genie_ctx* c, const float* slice, const float* mask, cons
     c->force_generic = 0; c->train_save = nullptr;
     if (rc) return rc;
     float* part = (float*)ws + c->o_part + c->slot * c->slot_stride;
-    if (c->pcsr)      // the messages sit in the c rows (k_stage2_pcsr): one station-sum row per source node
-        k_seg_sum32<<<(c->G * 32 + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float*)ws + c->o_c + (c->slot % GENIE_NBIG) * c->big_stride,
-                                                                             c->seg_rowptr, c->G, part);
     k_part_sum<<<(c->G * 30 + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, c->G, part_T(c), r_out);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;

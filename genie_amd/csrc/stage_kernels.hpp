@@ -946,8 +946,8 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
 }
 
 // Stage 2 on an irregular product graph (see k_stage1_pcsr). The Bipartite messages of a source node are not the rows of
-// whole tiles here, so every node's gated message row is written in place of its c row and k_bip_out_seg sums the row range
-// of each source node (product nodes are grouped by source node, process_utils.py:790-794) in row order.
+// whole tiles here, so every node's gated message row is written in place of its c row and k_seg_sum32 sums the row range
+// of each source node (product nodes are grouped by source node, process_utils.py:790-794) in row order into the window's `part` slot.
 __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];

@@ -1,50 +1,8 @@
 // Part of genie_hip.hip (one translation unit, included inside its anonymous namespace): the G- / Q-sized tail (Bipartite read-out, SpatialAggregation x3, read-out heads) and the pick-sized heads (k_lslc, k_arrivals).
 
-// ------------------------------------------------------------------------------------------------
-// Bipartite read-out of an irregular product graph (32 lanes per source node, weights transposed in LDS). The scalar form of
-// the whole G-sized tail (32 lanes per node, both matvec operands from LDS: 3.5 LDS cycles per wave-FMA, tools/lds_matvec.hip)
-// was replaced by the fp32-MFMA tile kernels below in round 2 (103.5 -> 45.4 us per window).
-// ------------------------------------------------------------------------------------------------
-constexpr int NPB = 8;  // nodes per 256-thread block
-
-// Weight staging: global [rows][ld] row-major (nn.Linear layout) -> LDS [k][ldo] (k = input index, lane = output
-// channel; conflict-free LDS writes and reads, strided but L1-resident global reads)
-__device__ __forceinline__ void stage_transposed_ld(float* dst, const float* __restrict__ W, int rows, int ld, int ldo) {
-    for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) {
-        const int k = i / ldo, c = i - k * ldo;
-        dst[i] = c < rows ? W[c * ld + k] : 0.f;
-    }
-}
-__device__ __forceinline__ void stage_transposed(float* dst, const float* __restrict__ W, int rows, int ld) {
-    stage_transposed_ld(dst, W, rows, ld, 32);
-}
-
-// r_g = sum of the message rows [seg[g], seg[g+1]) of a [P, 32] buffer (k_stage2_pcsr) in row order, out = PReLU_b2(fc2 r_g)  module.py:229
-__global__ __launch_bounds__(256) void k_bip_out_seg(const float* __restrict__ rows, int G, const int32_t* __restrict__ seg,
-                                                    const float* __restrict__ raw, int off_w, int off_b, int off_a,
-                                                    float* __restrict__ out) {
-    __shared__ float wt[30 * 32];
-    __shared__ __attribute__((aligned(16))) float gx[NPB][32];
-    stage_transposed(wt, raw + off_w, 15, 30);
-    __syncthreads();
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float bias = c < 15 ? raw[off_b + c] : 0.f;
-    const float act = raw[off_a];
-    for (int g0 = blockIdx.x * NPB; g0 < G; g0 += gridDim.x * NPB) {
-        const int g = g0 + grp;
-        const bool ok = g < G;
-        float r = 0.f;
-        if (ok)
-            for (long long pr = seg[g]; pr < seg[g + 1]; ++pr) r += rows[pr * 32 + c];
-        gx[grp][c] = r;
-        GSYNC();
-        float o = bias;
-#pragma unroll
-        for (int k = 0; k < 30; ++k) o += wt[k * 32 + c] * gx[grp][k];
-        GSYNC();
-        if (ok && c < 15) out[(long long)g * 15 + c] = prelu1(o, act);
-    }
-}
+// The scalar form of the G-sized tail (32 lanes per node, both matvec operands from LDS: 3.5 LDS cycles per wave-FMA,
+// tools/lds_matvec.hip) was replaced by the fp32-MFMA tile kernels below in round 2 (103.5 -> 45.4 us per window, DESIGN.md section
+// 4e); its last user, the Bipartite read-out of irregular product graphs, went in round 4 (k_seg_sum32 + k_bip_out_m).
 
 // out-degree of every source node (number of edges whose message source is j)
 __global__ void k_outdeg(const int32_t* __restrict__ col, long long E, int32_t* __restrict__ deg) {

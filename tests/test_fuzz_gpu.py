@@ -145,6 +145,67 @@ def test_random_case_forward_and_gradients_match_the_oracle(i, monkeypatch):
     print("worst gradient error / tolerance %.3f over %d parameters" % (worst, checked))
 
 
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_case_window_pipelines_are_bitwise_equal_to_the_plain_forward(i, monkeypatch):
+    """The apply loop's two ways of overlapping windows -- `forward_fixed_source_pipelined` (tails on side streams) and
+    `push_window` / `flush_windows` (one G-sized tail per batch of windows) -- on the drawn model definition / graph shape /
+    precision: every window's (y, x) bit-identical to the single-stream `forward_fixed_source`."""
+    cfg = _draw(9000 + SEED0 + i)
+    print(cfg)
+    if cfg["stage"] == "f32":
+        monkeypatch.setattr(engine, "STAGE_PRECISION", "f32")
+    S, G = cfg["S"], cfg["G"]
+    geom = _geometry(cfg)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    ea = geom.edge_attr()
+    rows = None
+    if cfg["subgraph"]:
+        rng = np.random.default_rng(900 + cfg["seed"])
+        d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+        keep = np.zeros(d.shape, dtype=bool)
+        keep[np.arange(G)[:, None], np.argsort(d, axis=1)[:, :int(rng.integers(1, min(6, S) + 1))]] = True
+        keep |= rng.random(d.shape) < rng.choice([0.0, 0.1, 0.5])
+        src_i, sta_i = np.nonzero(keep)
+        pairs = np.stack((sta_i, src_i))
+        rows = src_i * S + sta_i
+        ea = ea.reshape(G, S, 3)[src_i, sta_i]
+        A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+        A_src_in_sta = torch.from_numpy(pairs).long()
+    else:
+        A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=cfg["edges"],
+                                                use_absolute_pos=cfg["abspos"])
+    net.load_state_dict({k: v.clone() for k, v in _weights(cfg).items()}, strict=True)
+    net.eval()
+    gea = graph.GraphEdges(x=t(ea), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), gea, gea, A_src_in_sta.to(DEV), torch.from_numpy(geom.A_src_src).to(DEV),
+                        None, None, None, None, t(geom.locs), t(geom.x_grid))
+    wins = []
+    for k in range(5):
+        win = synthetic.make_window(geom, max(cfg["n_picks"], 20), seed=700 + 10 * cfg["seed"] + k)
+        Sl, Mk = (win["Slice"], win["Mask"]) if rows is None else (win["Slice"][rows], win["Mask"][rows])
+        wins.append((t(Sl), t(Mk)))
+    xg, xq, tq = t(geom.x_grid), t(geom.x_query), t(geom.t_query)
+    fixed = (None, None, None, t(geom.locs), xg, xq, tq)
+    with torch.no_grad():
+        plain = [net.forward_fixed_source(s_, m_, *fixed) for s_, m_ in wins]
+        torch.cuda.synchronize()
+        piped = [net.forward_fixed_source_pipelined(s_, m_, *fixed) for s_, m_ in wins]
+        torch.cuda.synchronize()
+        for k, ((y0, x0), (y1, x1, ev)) in enumerate(zip(plain, piped)):
+            assert torch.equal(y0, y1) and torch.equal(x0, x1), (cfg, "pipelined", k)
+        net._hip.wait_tails()
+        net.window_batch = 2
+        got = []
+        for k, (s_, m_) in enumerate(wins):
+            if net.push_window(s_, m_) == net.window_batch or k == len(wins) - 1:
+                got.append(net.flush_windows(xg, xq, tq))
+        torch.cuda.synchronize()
+    ys, xs = torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got])
+    for k, (y0, x0) in enumerate(plain):
+        assert torch.equal(y0, ys[k]) and torch.equal(x0, xs[k]), (cfg, "batched", k)
+
+
 def _subgraph_time_pointers(trv, pairs, max_t, dt, k, win):
     """Time-pointer tables of an irregular product graph for the sweep: per station and time step of `dt_partition` the k product
     nodes OF THAT STATION whose travel time is nearest (cycled when a station has fewer than k), as product-node ids -- the layout
