@@ -337,3 +337,38 @@ def test_random_case_four_outputs_and_gradients_match_the_oracle(i, monkeypatch)
         checked += 1
     assert checked + excused >= 120
     print("worst gradient error / tolerance %.3f over %d parameters" % (worst, checked))
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_case_device_embedding_matches_the_oracle(i):
+    """Pick -> Slice / Mask embedding on the device (genie_embed_window; f-1) against oracle/embed_oracle.py (pinned to the reference's
+    `extract_input_from_data`, process_utils.py:460-642, by tests/golden/embed_*): random station / source counts, pick counts
+    (none, one, thousands), window start, kernel width, time step, `use_sign_input`. Slice to 1e-6 (float cast of a float64 exp),
+    Mask exact."""
+    from oracle import embed_oracle as E
+    rng = np.random.default_rng(7000 + SEED0 + i)
+    S, G = int(rng.choice([3, 7, 16, 33, 64, 200])), int(rng.choice([10, 17, 129, 400]))
+    n_picks = int(rng.choice([0, 1, 40, 700, 5000]))
+    sig, dt = float(rng.choice([1.5, 3.0, 4.5])), float(rng.choice([0.25, 0.3, 0.6]))
+    sign = bool(rng.integers(2))
+    cfg = dict(S=S, G=G, n_picks=n_picks, sig=sig, dt=dt, sign=sign, seed=7000 + SEED0 + i)
+    print(cfg)
+    geom = synthetic.Geometry(S, G, L=float(rng.choice([40e3, 150e3])), n_query=3, seed=int(rng.integers(1 << 30)))
+    P = synthetic.make_picks(geom, n_picks, seed=int(rng.integers(1 << 30))) if n_picks else np.zeros((0, 5))
+    t0 = float(rng.uniform(-4.0, 4.0)) + float(rng.choice([0.0, 5000.0]))
+    P[:, 0] += t0 - float(rng.uniform(-1.0, 1.0))
+    trv = geom.travel_times().astype(np.float32)
+    max_t = float(np.ceil(trv.max() + 1.0))
+    A = np.stack([np.tile(np.arange(S), G), np.repeat(np.arange(G), S)], axis=0)
+    want_S, want_M = E.extract_input_from_data(P, t0, np.arange(S), S, trv, A, max_t, sig, dt, use_sign_input=sign)
+    hp = engine.HipPath(S, G, engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S),
+                        engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G), device=DEV)
+    hp.set_sign_input(sign)
+    sel = (P[:, 0] > t0 - 2.0 * sig) & (P[:, 0] < t0 + max_t + 2.0 * sig)           # process_utils.py:476
+    Ps = P[sel]
+    Slice, Mask = hp.embed_window(torch.from_numpy(Ps[:, 0].copy()).to(DEV), torch.from_numpy(Ps[:, 1].astype(np.int32)).to(DEV),
+                                  torch.from_numpy(Ps[:, 4].astype(np.int32)).to(DEV), t0, max_t, sig, dt,
+                                  torch.from_numpy(trv.reshape(-1, 2)).to(DEV))
+    err = float((Slice.cpu() - torch.from_numpy(want_S)).abs().max())
+    assert err <= 1e-6, (cfg, err)
+    assert torch.equal(Mask.cpu(), torch.from_numpy(np.asarray(want_M, dtype=np.float32))), (cfg, int((Mask.cpu() != torch.from_numpy(np.asarray(want_M, dtype=np.float32))).sum()))
