@@ -37,6 +37,7 @@ SYMBOLS = [
     ("genie_set_phase_types", _c.c_int, [_P, _c.c_int]),
     ("genie_set_sign_input", _c.c_int, [_P, _c.c_int]),
     ("genie_set_stage2_workmap", _c.c_int, [_P, _c.c_int]),
+    ("genie_set_subgraph_stations", _c.c_int, [_P, _P, _P]),
     ("genie_set_tail_precision", _c.c_int, [_P, _c.c_int]),
     ("genie_set_stage_precision", _c.c_int, [_P, _c.c_int]),
     ("genie_stage_precision", _c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _P]),

@@ -144,9 +144,10 @@ def apply_windows(net, geom, P, tsteps_abs=None, t_win=6.0, step_size="half", mi
 
 def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, step_size="half", min_required_picks=1,
                          n_grids=1.0, day_len=86400.0, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, max_t=None,
-                         times=None, tail_batch=16):
+                         times=None, tail_batch=16, pairs=None):
     """GPU-only apply loop: `P` [n,5] (t, station index in the model's station order, amp, prob, phase) sorted by time,
-    `trv_times` [G, S, 2] theoretical travel times. Returns (Out_2 on device, window start times used). `tail_batch`: windows
+    `trv_times` [G, S, 2] theoretical travel times; `pairs` [2, N] (station, source) = the product nodes of a `use_subgraph` model
+    (`A_src_in_sta`), whose Slice / Mask rows follow that list. Returns (Out_2 on device, window start times used). `tail_batch`: windows
     per G-sized tail (1..16; 16 is the default of the bench and measured best with the device embedding in the loop, bench.py --mode
     stream: the tail kernels are latency-bound, their fixed costs are paid once per batch)."""
     hp = net._hip
@@ -168,7 +169,11 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     if not getattr(net, "use_phase_types", True):        # process_continuous_days.py:562-563 (the embedding zeroes columns 2, 3: :783-786)
         ph = np.zeros_like(ph)
     d_ph = torch.from_numpy(ph).to(dev)
-    d_trv = torch.from_numpy(np.ascontiguousarray(trv_times, dtype=np.float32).reshape(-1, 2)).to(dev)
+    if pairs is not None:        # process_utils.py:605 `trv_times[src, ind_use[sta], :]` per listed product node
+        pairs = np.asarray(pairs)
+        d_trv = torch.from_numpy(np.ascontiguousarray(np.asarray(trv_times, dtype=np.float32)[pairs[1], pairs[0]])).to(dev)
+    else:
+        d_trv = torch.from_numpy(np.ascontiguousarray(trv_times, dtype=np.float32).reshape(-1, 2)).to(dev)
     Out_2 = torch.zeros((geom.x_query.shape[0], len(tsteps_abs)), dtype=torch.float32, device=dev)
     locs = torch.from_numpy(geom.locs).float().to(dev)
     xg = torch.from_numpy(geom.x_grid).float().to(dev)

@@ -19,6 +19,7 @@ struct EmbArgs {
     float* mm;              // with sta_inv: max of the Mask row, in processing order
     int sign_input;         // use_sign_input: True (config.yaml:93, process_utils.py:610-614): every feature times the sign of the negative
                             // forward difference of the series it is read from, at the index it is read at
+    const int32_t* sta_of;  // irregular product graph: station of every product node (else p % S)
     int no_phase;           // use_phase_types: False (config.yaml:91): the phase-informed columns 2, 3 of Slice / Mask are zero
                             // (process_continuous_days.py:783-786; the caller passes every pick with phase 0, :562-563)
 };
@@ -49,7 +50,7 @@ __global__ void k_embed_edges(EmbArgs a) {   // overflow guard: first / last sam
 __global__ void k_embed_gather(EmbArgs a) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.rows) return;
-    const int sta = (int)(p % a.S);
+    const int sta = a.sta_of != nullptr ? a.sta_of[p] : (int)(p % a.S);
     const float2 tt = *(const float2*)(a.trv + p * 2);
     int ip = (int)((((double)tt.x + a.t0) - a.tref0) / a.dt);           // :605 (float64 arithmetic, truncation)
     int is = (int)((((double)tt.y + a.t0) - a.tref0) / a.dt);

@@ -1235,6 +1235,7 @@ struct genie_ctx {
     bool pcsr_h2;              // ... with at most 8 / 15 neighbours per product node: k_stage1_h2<.., PCSR> applies
     int32_t *p_sta_rowptr, *p_sta_col, *p_src_rowptr, *p_src_col, *seg_rowptr;
     int32_t* p_src_of;         // ... source node of every product node (built on the first genie_assoc_fwd)
+    int32_t* p_sta_of = nullptr;   // ... station of every product node (genie_set_subgraph_stations: the device embedding needs it)
     float *mpos_sta, *mpos_src, *ebias_sta, *ebias_src;   // DataAggregationEdges: mean edge features [n,4] and their Linear [n,48]
     bool has_edges;
     // station processing order (genie_set_station_order): internal -> caller's station, its inverse, the station graph in
@@ -2266,7 +2267,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->p_sta_rowptr, c->p_sta_col, c->p_src_rowptr, c->p_src_col, c->seg_rowptr, c->abs_sta, c->abs_src,
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw, c->rp_sta_rowptr, c->rp_src_rowptr, c->rp_sta_cw, c->rp_src_cw, c->ptile16, c->ptile32,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
-                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of};
+                    c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of, c->p_sta_of};
     for (void* p : ptrs) (void)hipFree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
     for (auto& kv : c->s2u) { (void)hipFree(kv.second.blocks); (void)hipFree(kv.second.xcd0); }
@@ -2965,7 +2966,7 @@ int genie_embed_window_split(genie_ctx* c, const double* pick_t, const int32_t* 
     int rc = check_ws(c, ws);
     if (rc) return rc;
     if ((rc = ensure_packed(c, (hipStream_t)stream))) return rc;       // (the range guard of the committed weights decides h2_on)
-    unsigned* xs = h2_on(c) ? (unsigned*)((float*)ws + c->o_xs) : nullptr;
+    unsigned* xs = (h2_on(c) && !c->pcsr) ? (unsigned*)((float*)ws + c->o_xs) : nullptr;     // (stage 1 of an irregular graph splits its rows itself)
     rc = embed_window_impl(c, pick_t, pick_sta, pick_phase, n_picks, t0, max_t, kernel_sig_t, dt, trv, emb_ws, slice_out, mask_out, xs,
                            stream);
     if (rc == GENIE_OK && xs) {
@@ -2982,10 +2983,12 @@ int embed_window_impl(genie_ctx* c, const double* pick_t, const int32_t* pick_st
     if (!c || !trv || !emb_ws || !slice_out || !mask_out) return fail(GENIE_ERR_ARG, "genie_embed_window: null argument");
     if (n_picks > 0 && (!pick_t || !pick_sta || !pick_phase)) return fail(GENIE_ERR_ARG, "genie_embed_window: null pick array");
     if (!(dt > 0.0) || !(kernel_sig_t > 0.0) || !(max_t > 0.0)) return fail(GENIE_ERR_ARG, "genie_embed_window: bad dt / sigma / max_t");
-    if (c->pcsr) return fail(GENIE_ERR_STATE, "genie_embed_window: not available on an irregular product graph");
+    if (c->pcsr && !c->p_sta_of)
+        return fail(GENIE_ERR_STATE, "genie_embed_window: an irregular product graph needs the station of every product node (genie_set_subgraph_stations)");
     hipStream_t st = (hipStream_t)stream;
     EmbArgs a;
     memset(&a, 0, sizeof(a));
+    a.sta_of = c->pcsr ? c->p_sta_of : nullptr;
     a.pick_t = pick_t; a.pick_sta = pick_sta; a.pick_phase = pick_phase; a.n_picks = n_picks;
     a.S = c->S; a.t0 = t0; a.tref0 = t0 - 3.0 * kernel_sig_t; a.dt = dt; a.sigma = kernel_sig_t;
     a.n_time = genie_embed_ntime(t0, max_t, kernel_sig_t, dt);
@@ -3936,6 +3939,14 @@ int genie_subgraph_csr_fill(const int32_t* pair_sta, const int32_t* pair_src, in
 int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_phase_types: null context");
     c->no_phase = use_phase_types ? 0 : 1;
+    return GENIE_OK;
+}
+
+int genie_set_subgraph_stations(genie_ctx* c, const int32_t* sta_of_prod, void* stream) {
+    if (!c || !sta_of_prod) return fail(GENIE_ERR_ARG, "genie_set_subgraph_stations: null argument");
+    if (!c->pcsr) return fail(GENIE_ERR_STATE, "genie_set_subgraph_stations: the context is a Cartesian product graph (station = p % n_sta)");
+    if (!c->p_sta_of) HIP_TRY(hipMalloc((void**)&c->p_sta_of, sizeof(int32_t) * (size_t)c->P));
+    HIP_TRY(hipMemcpyAsync(c->p_sta_of, sta_of_prod, sizeof(int32_t) * (size_t)c->P, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GENIE_OK;
 }
 

@@ -294,6 +294,16 @@ class HipPath(object):
         self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
         self._w_key = None
 
+    def set_subgraph_stations(self, sta_of_prod):
+        """Station index of every product node of an irregular product graph (genie_set_subgraph_stations): enables `embed_window`."""
+        if self._n_prod is None:
+            raise ValueError("set_subgraph_stations: not an irregular product graph")
+        t = torch.as_tensor(sta_of_prod).to(self.device, torch.int32).contiguous()
+        if t.numel() != self._n_prod:
+            raise ValueError("sta_of_prod must have n_prod entries")
+        _lib.check(self.lib.genie_set_subgraph_stations(self.ctx, _ptr(t), _stream()), "genie_set_subgraph_stations")
+        torch.cuda.current_stream().synchronize()      # (the library keeps its own copy)
+
     def set_stage2_workmap(self, blocks_of_four):
         """Work map of the row-layout stage 2 (genie_set_stage2_workmap): True / False, None = the default for the station count."""
         v = -1 if blocks_of_four is None else (1 if blocks_of_four else 0)
@@ -1125,7 +1135,7 @@ class HipPath(object):
         (process_utils.py:460-642). pick_t float64, pick_sta / pick_phase int32 GPU tensors; trv [rows, 2] fp32.
         `presplit`: also leave the split rows of the f16x2 stage-1 kernel in the workspace, so that the next stage-1 call on
         exactly these (Slice, Mask) skips its split pass (genie_embed_window_split; do not modify them in between)."""
-        rows = self.n_grid_ext * self.n_sta
+        rows = self.n_prod_ext
         trv = _f32(trv, "trv", (rows, 2))
         n = int(pick_t.numel())
         if n:

@@ -767,6 +767,7 @@ class GCN_Detection_Network_extended(nn.Module):
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._hip.set_subgraph_stations(pairs[0])
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._hip.set_phase_types(self.use_phase_types)
@@ -804,6 +805,7 @@ class GCN_Detection_Network_extended(nn.Module):
         sub = _engine.subgraph_csr_device(pairs, n_grid, _engine.csr_from_table(sta_tab), src_csr)
         order = _engine.sfc_order(pos_src.detach().cpu().numpy())
         self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._hip.set_subgraph_stations(pairs[0])
         self._path_params = _path_param_dict(self)
         self._hip.set_scale_t(self.TemporalAttention.scale_t)
         self._hip.set_phase_types(self.use_phase_types)

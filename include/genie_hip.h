@@ -74,12 +74,18 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext,
  * n_prod), and both DataAggregation edge sets are CSR lists over product-node ids: p_sta_* = in-edges of A_in_sta (same
  * source node, neighbouring stations), p_src_* = in-edges of A_in_src, in stable edge order. src_rowptr / src_col = the base
  * source graph A_src (SpatialAggregation). Every [P, .] argument of the stage calls then has n_prod rows. The kernels that rely on
- * p = g * n_sta + s are not used (product-level CSR forms instead, inference and training); genie_embed_window and genie_nbr_mean are
- * unavailable on such a context; genie_set_edge_features / genie_set_absolute_pos take positions per product node there ([n_prod, 3]). */
+ * p = g * n_sta + s are not used (product-level CSR forms instead, inference and training); genie_nbr_mean is unavailable on such a
+ * context, genie_embed_window* needs genie_set_subgraph_stations first; genie_set_edge_features / genie_set_absolute_pos take
+ * positions per product node there ([n_prod, 3]). */
 int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_prod,
                               const int32_t* p_sta_rowptr, const int32_t* p_sta_col,
                               const int32_t* p_src_rowptr, const int32_t* p_src_col, const int32_t* seg_rowptr,
                               const int32_t* src_rowptr, const int32_t* src_col, const int32_t* grid_order, float scale_rel);
+/* Station index of every product node of an irregular product graph (device pointer, n_prod int32 = row 0 of the reference's
+ * A_src_in_sta, process_utils.py:790-794; copied): what the device embedding reads where a Cartesian graph has p % n_sta. `trv` of
+ * genie_embed_window* is then [n_prod, 2], the travel times of the listed (station, source) pairs
+ * (`trv_times[src, ind_use[sta], :]`, process_utils.py:605). */
+int genie_set_subgraph_stations(genie_ctx* ctx, const int32_t* sta_of_prod, void* stream);
 int genie_ctx_destroy(genie_ctx* ctx);
 /* Optional station processing order: `order` (HOST pointer, n_sta int32, a permutation; typically the stations sorted along a
  * space-filling curve) = the caller's station id of the i-th station processed. A tile of the P-sized kernels is 16 consecutive

@@ -372,3 +372,56 @@ def test_random_case_device_embedding_matches_the_oracle(i):
     err = float((Slice.cpu() - torch.from_numpy(want_S)).abs().max())
     assert err <= 1e-6, (cfg, err)
     assert torch.equal(Mask.cpu(), torch.from_numpy(np.asarray(want_M, dtype=np.float32))), (cfg, int((Mask.cpu() != torch.from_numpy(np.asarray(want_M, dtype=np.float32))).sum()))
+
+
+@pytest.mark.parametrize("i", range(max(2, N_CASES // 4)))
+def test_random_case_device_apply_loop_on_an_irregular_product_graph(i):
+    """The GPU-only apply loop (device embedding per listed product node, genie_set_subgraph_stations; batched tails) of a
+    `use_subgraph` model against the oracle chain embed_oracle.extract_input_from_data (pairs as `A_src_in_sta`) ->
+    genie_oracle.forward_fixed_source on the irregular edge lists -> the reference's stacking (process_continuous_days.py:766,797-805)."""
+    from genie_amd import apply
+    from oracle import embed_oracle as E
+    from oracle import genie_oracle as O
+    rng = np.random.default_rng(11000 + SEED0 + i)
+    S, G = int(rng.choice([7, 16, 33])), int(rng.choice([17, 40, 70]))
+    batch = int(rng.choice([1, 3, 16]))
+    step_size = str(rng.choice(["half", "full", "partial"]))
+    print(dict(S=S, G=G, batch=batch, step_size=step_size, seed=11000 + SEED0 + i))
+    geom = synthetic.Geometry(S, G, L=60e3, n_query=12, seed=int(rng.integers(1 << 30)))
+    P = synthetic.make_picks(geom, int(rng.choice([100, 400])), seed=int(rng.integers(1 << 30)))
+    P[:, 0] = P[:, 0] * 0.25 + 5000.0
+    P = P[np.argsort(P[:, 0], kind="stable")]
+    trv = geom.travel_times().astype(np.float32)
+    d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+    keep = np.zeros(d.shape, dtype=bool)
+    keep[np.arange(G)[:, None], np.argsort(d, axis=1)[:, :int(rng.integers(2, min(6, S) + 1))]] = True
+    keep |= rng.random(d.shape) < 0.2
+    src_i, sta_i = np.nonzero(keep)
+    pairs = np.stack((sta_i, src_i))
+    A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+    ea = geom.edge_attr().reshape(G, S, 3)[src_i, sta_i]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    w = Case("tiny_6x40").weights
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in w.items()})
+    net.eval()
+    gea = graph.GraphEdges(x=t(ea), edge_index=A_src_in_prod.to(DEV))
+    net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), gea, gea, torch.from_numpy(pairs).to(DEV), torch.from_numpy(geom.A_src_src).to(DEV),
+                        None, None, None, None, t(geom.locs), t(geom.x_grid))
+    max_t = float(np.ceil(trv.max() + 1.0))
+    Out_2, times = apply.apply_windows_device(net, geom, P, trv, step_size=step_size, min_required_picks=5, max_t=max_t, tail_batch=batch,
+                                              pairs=pairs)
+    assert 1 <= len(times) <= 60
+    tsteps, offsets, step, n_overlap, dt_win = apply.window_schedule(P[:, 0], max_t, t_win=6.0, step_size=step_size)
+    tsteps_abs = np.arange(tsteps.min() - 3.0, tsteps.max() + 3.0 + dt_win, dt_win)
+    want = torch.zeros(Out_2.shape)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    for t0 in times:
+        Slice, Mask = E.extract_input_from_data(P, float(t0), np.arange(S), S, trv, pairs, max_t, 3.0, 0.3)
+        with torch.no_grad():
+            _, x = O.forward_fixed_source(w, torch.from_numpy(Slice), torch.from_numpy(Mask), A_in_sta, A_in_src, c(ea), A_src_in_prod,
+                                          torch.from_numpy(geom.A_src_src), c(geom.x_grid), c(geom.x_query), c(offsets.reshape(-1, 1)))
+        cols, kp = apply.window_columns(tsteps_abs, float(t0), offsets, step_size == "half")
+        want[:, cols] += x[:, kp, 0] / n_overlap
+    assert float(want.abs().max()) > 0
+    assert max_abs(Out_2.cpu(), want) <= 1e-5
