@@ -2664,9 +2664,12 @@ int genie_da_stage2_bipartite(genie_ctx* c, const float* mask, const float* edge
 }
 
 namespace {
+// virtual blocks of SpatialAggregation's grid-wide mean (SaArgs.vg): a function of the source-node count only, so that the sum's
+// partition -- hence every output bit -- is the same for any launch grid (per window, side streams, batches of 1..16 windows)
+int sa_vg(const genie_ctx* c) { return tl_blocks(c->G, 512); }
 void sa_fill_layer(const genie_ctx* c, int layer, SaArgs& a) {
     const int base = layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W);
-    a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src;
+    a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src; a.vg = sa_vg(c);
     a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg;
     a.raw = c->raw; a.scale_rel = c->scale_rel;
     a.fc1_w = g_params[base + 0].off; a.fc1_b = g_params[base + 1].off;
@@ -2692,7 +2695,7 @@ int sa_launch_layer(genie_ctx* c, int layer, const float* x_in, const float* pos
     const size_t so = c->slot * c->slot_stride;
     float* pj[2] = {ws + c->o_pj0 + so, ws + c->o_pj1 + so};
     float* gp[2] = {ws + c->o_gpart + so, ws + c->o_gpart + so + 1024 * 8};
-    a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_blocks(c);
+    a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_vg(c);
     a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
     const int nb = sa_blocks(c);
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
@@ -2908,7 +2911,7 @@ int genie_tail_batched(genie_ctx* c, int slot0, int nwin, const float* pos, cons
         a.ws_x_in = ss;
         a.out = layer == 1 ? w + c->o_sa0 + so : (layer == 2 ? w + c->o_sa1 + so : x_spatial_out);
         a.ws_out = layer == 3 ? (long long)c->G * 30 : ss;
-        a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = nbx;
+        a.pj_in = pj[cur]; a.gpart_in = gp[cur]; a.n_gpart_in = sa_vg(c);
         a.pj_out = pj[cur ^ 1]; a.gpart_out = gp[cur ^ 1];
         a.img = c->packed[PL_SA1 + layer - 1];
         if (tail_wide(c)) {
@@ -3471,7 +3474,7 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         a.G = c->G; a.C = layer == 1 ? 15 : 30; a.E = c->E_src; a.x_in = x_in[layer - 1]; a.pos = pos;
         a.rowptr = c->src_rowptr; a.col = c->src_col; a.outdeg = c->outdeg; a.r_rowptr = c->r_src_rowptr; a.r_col = c->r_src_col;
         a.raw = c->raw; a.fc1_w = g_params[(layer == 1 ? W_SA1_FC1_W : (layer == 2 ? W_SA2_FC1_W : W_SA3_FC1_W))].off;
-        a.scale_rel = c->scale_rel; a.pj = S + L.pj; a.gpart = S + L.gpart; a.n_gpart = nbp;
+        a.scale_rel = c->scale_rel; a.pj = S + L.pj; a.gpart = S + L.gpart; a.n_gpart = sa_vg(c);
         a.img = c->packed[PL_SA1 + layer - 1]; a.timg = c->packed[PL_TSA1 + layer - 1];
         if (layer == 3) { a.dout_a = S + L.dxs_a; a.dout_b = S + L.dxs_b; a.dout_x30 = d_xs_extra; }
         else a.dout_a = dxl[layer & 1];

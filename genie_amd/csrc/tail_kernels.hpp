@@ -23,7 +23,9 @@ struct SaArgs {
     const float* gpart_in; // [n_gpart_in][8] per-block partials of sum_j outdeg(j) PReLU3(fglobal x_j)
     int n_gpart_in;
     float* pj_out;         // [G,32] same for the next layer (NEXT) / for this layer (k_sa_pre)
-    float* gpart_out;      // [gridDim][8]
+    float* gpart_out;      // [vg][8]
+    int vg;                // virtual blocks of the global-term sum: tile t belongs to virtual block (t / 4) % vg whatever the launch's
+                           // grid is, so the partials -- and with them every output -- do not depend on the number of workgroups
     float* out;            // [G,30]
     const float* img;      // k_sa_pre_m / k_sa_layer_m: the layer's k_pack_all image (plan PL_SA1 + layer - 1)
     // batched tail: blockIdx.y = window; the window's copy of each buffer sits this many floats further on
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void k_bip_out_m(const float* __restrict__ par
     }
 }
 
-// fixed-order reduction of the per-lane global-term partials (rows m = 4q + r < 5 of the fglobal tile) -> gpart[block][m]
+// fixed-order reduction of the per-lane global-term partials (rows m = 4q + r < 5 of the fglobal tile) -> gpart_out[m] (the row of one virtual block)
 __device__ __forceinline__ void tl_store_gpart(f64x4 accw, int lane, int wave, float* red, float* __restrict__ gpart_out);
 __device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, float* red, float* __restrict__ gpart_out) {
 #pragma unroll
@@ -254,12 +256,13 @@ __device__ __forceinline__ void tl_store_gpart(f32x4 acc, int lane, int wave, fl
         acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d); acc.z += __shfl_xor(acc.z, d); acc.w += __shfl_xor(acc.w, d);
     }
     const int j = lane & 15, q = lane >> 4;
+    __syncthreads();                          // (`red` of the previous virtual block has been read)
     if (j == 0 && q < 2) *(f32x4*)(red + wave * 8 + 4 * q) = acc;
     __syncthreads();
     if (threadIdx.x < 8) {
         float s = 0.f;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k * 8 + threadIdx.x];
-        gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
+        gpart_out[threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
     }
 }
 // WIDE: the per-lane partials were accumulated in fp64; the cross-lane / cross-wave sums keep the fp32 buffers' fixed order
@@ -269,12 +272,13 @@ __device__ __forceinline__ void tl_store_gpart(f64x4 accw, int lane, int wave, f
         accw.x += __shfl_xor(accw.x, d); accw.y += __shfl_xor(accw.y, d); accw.z += __shfl_xor(accw.z, d); accw.w += __shfl_xor(accw.w, d);
     }
     const int j = lane & 15, q = lane >> 4;
+    __syncthreads();                          // (`red` of the previous virtual block has been read)
     if (j == 0 && q < 2) *(f32x4*)(red + wave * 8 + 4 * q) = tl_f32(accw);
     __syncthreads();
     if (threadIdx.x < 8) {
         float s = 0.f;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k * 8 + threadIdx.x];
-        gpart_out[blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
+        gpart_out[threadIdx.x] = threadIdx.x < 5 ? s : 0.f;
     }
 }
 
@@ -290,9 +294,10 @@ __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const float act3 = im.scal[3];
-    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (a.G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    for (int vb = blockIdx.x; vb < a.vg; vb += gridDim.x) {
+    V acc = tl_wide<WIDE>(tl_zero());
+    for (int tile = vb * 4 + wave; tile < ntiles; tile += a.vg * 4) {
         const int g = tile * 16 + j;
         const bool ok = g < a.G;
         const float* row = a.x_in + (long long)(ok ? g : a.G - 1) * C;
@@ -309,7 +314,8 @@ __global__ __launch_bounds__(256) void k_sa_pre_m(SaArgs a) {
         if (C == 30) gl = mma_block(gl, TLW(im, GS_FG(1)), xb[1]);
         if (ok) acc += prelu4(tl_cout(gl), act3) * (float)a.outdeg[g];
     }
-    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+    tl_store_gpart(acc, lane, wave, red, a.gpart_out + vb * 8);
+    }
 }
 
 // k_bip_out_m + k_sa_pre_m<15> in one launch (the batched tail): the Bipartite output of a node is the input of
@@ -331,9 +337,10 @@ __global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ par
     const int jl = lane >> 2, ql = lane & 3;
     float* ts = tsc + wave * 16 * 36;
     const float act = im.scal[0], act3 = is.scal[3];
-    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    for (int vb = blockIdx.x; vb < a.vg; vb += gridDim.x) {
+    V acc = tl_wide<WIDE>(tl_zero());
+    for (int tile = vb * 4 + wave; tile < ntiles; tile += a.vg * 4) {
         const int g = tile * 16 + j;
         const bool ok = g < G;
         const int gl = tile * 16 + jl;
@@ -360,7 +367,8 @@ __global__ __launch_bounds__(256) void k_bip_pre_m(const float* __restrict__ par
         const V glb = mma_block(tl_cin<WIDE>(tl_bias(is, 5, q)), TLW(is, GS_FG(0)), o);
         if (ok) acc += prelu4(tl_cout(glb), act3) * (float)a.outdeg[g];
     }
-    tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+    tl_store_gpart(acc, lane, wave, red, a.gpart_out + vb * 8);
+    }
 }
 
 // One SpatialAggregation layer (see k_sa_layer): per-edge messages on the VALU (8 channels per lane), fc2 and the next layer's
@@ -412,9 +420,10 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
             for (int d = 0; d < 3; ++d) wp[d][t] = *(const f32x4*)(w1p + d * 32 + 16 * t + 4 * ql);
         }
     }
-    V acc = tl_wide<WIDE>(tl_zero());
     const int ntiles = (a.G + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    for (int vb = blockIdx.x; vb < a.vg; vb += gridDim.x) {
+    V acc = tl_wide<WIDE>(tl_zero());
+    for (int tile = vb * 4 + wave; tile < ntiles; tile += a.vg * 4) {
         const int i = tile * 16 + j;
         const bool ok = i < a.G;
         const int ic = ok ? i : a.G - 1;
@@ -485,7 +494,8 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
             if (ok) acc += prelu4(tl_cout(gl), act3n) * (float)a.outdeg[i];
         }
     }
-    if (NEXT) tl_store_gpart(acc, lane, wave, red, a.gpart_out);
+    if (NEXT) tl_store_gpart(acc, lane, wave, red, a.gpart_out + vb * 8);
+    }
 }
 
 // Per-grid-node part of SpatialAttention's edge Linears (see k_ro_pre), biases included, in a head-padded layout:

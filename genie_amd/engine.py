@@ -510,14 +510,21 @@ class HipPath(object):
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
         self._refresh_static_edge_attr(edge_attr)
         pos = _f32(pos, "pos", (self.n_grid, 3))
-        if getattr(self, "side_streams", None) is None:
+        if getattr(self, "_ev_tail", None) is None:
             n_tail = 2
-            self.side_streams = [self._new_side_stream() for _ in range(n_tail)]
+            self._pl_streams = [self._new_side_stream() for _ in range(n_tail)]
+            self.side_streams = list(getattr(self, "side_streams", None) or []) + self._pl_streams
             self._win = 0
             self._ev_tail = [None] * (n_tail + 1)
         main = torch.cuda.current_stream(self.device)
+        bt = getattr(self, "_bt", None)
+        if bt is not None:          # batched tails (window_push / windows_flush) use the same workspace slots: join them first
+            for k, ev in enumerate(bt["ev"]):
+                if ev is not None:
+                    main.wait_event(ev)
+                    bt["ev"][k] = None
         slot = self._win % len(self._ev_tail)
-        side = self.side_stream = self.side_streams[self._win % len(self.side_streams)]   # where this window's y / x are produced
+        side = self.side_stream = self._pl_streams[self._win % len(self._pl_streams)]   # where this window's y / x are produced
         self._win += 1
         _lib.check(self.lib.genie_set_slot(self.ctx, slot), "genie_set_slot")
         if self._ev_tail[slot] is not None:
@@ -594,6 +601,11 @@ class HipPath(object):
         if bt["n"] >= self.window_batch:
             raise RuntimeError("window_push: %d windows pending, call windows_flush first" % bt["n"])
         main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_ev_tail", None) is not None:      # tails of forward_pipelined windows use the same workspace slots: join them first
+            for k, ev in enumerate(self._ev_tail):
+                if ev is not None:
+                    main.wait_event(ev)
+                    self._ev_tail[k] = None
         if bt["n"] == 0 and bt["ev"][bt["group"]] is not None:
             main.wait_event(bt["ev"][bt["group"]])          # the tail that last read these slots has finished
         _lib.check(self.lib.genie_set_slot(self.ctx, bt["group"] * self.window_batch + bt["n"]), "genie_set_slot")

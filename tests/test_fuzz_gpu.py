@@ -194,16 +194,21 @@ def test_random_case_window_pipelines_are_bitwise_equal_to_the_plain_forward(i, 
         torch.cuda.synchronize()
         for k, ((y0, x0), (y1, x1, ev)) in enumerate(zip(plain, piped)):
             assert torch.equal(y0, y1) and torch.equal(x0, x1), (cfg, "pipelined", k)
-        net._hip.wait_tails()
-        net.window_batch = 2
+        net.window_batch = 2           # (no wait_tails in between: the switch joins the pending tails itself)
         got = []
         for k, (s_, m_) in enumerate(wins):
             if net.push_window(s_, m_) == net.window_batch or k == len(wins) - 1:
                 got.append(net.flush_windows(xg, xq, tq))
         torch.cuda.synchronize()
+        # ... and back to the side-stream form with batched tails still in flight (both forms share the workspace slots)
+        again = [net.forward_fixed_source_pipelined(s_, m_, *fixed) for s_, m_ in wins[:3]]
+        net._hip.wait_tails()
+        torch.cuda.synchronize()
     ys, xs = torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got])
     for k, (y0, x0) in enumerate(plain):
         assert torch.equal(y0, ys[k]) and torch.equal(x0, xs[k]), (cfg, "batched", k)
+    for k, (y1, x1, ev) in enumerate(again):
+        assert torch.equal(plain[k][0], y1) and torch.equal(plain[k][1], x1), (cfg, "pipelined after batched", k)
 
 
 def _subgraph_time_pointers(trv, pairs, max_t, dt, k, win):

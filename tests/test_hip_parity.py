@@ -1285,6 +1285,42 @@ def test_batched_windows_are_bitwise_equal_to_plain_forward(batch):
         net.flush_windows(xg, xq, tq)
 
 
+@pytest.mark.parametrize("G", [10000, 50000])
+def test_window_pipelines_are_bitwise_equal_at_the_baseline_source_counts(G):
+    """The grid-wide mean of SpatialAggregation's global term is summed over `vg` virtual blocks that depend on the source-node
+    count only (SaArgs.vg), not on the launch grid: at 10 000 / 50 000 source nodes (configs 2 / 4) the tail of a plain call runs
+    157 / 512 workgroups, a batch of 16 windows 32 per window, and every output bit must still be the same (round 4: it was not --
+    3.7e-9 on y, 1.5e-8 on x -- while the fixtures' 500 source nodes fit one partition in every form). Also: switching from batched
+    tails to `forward_fixed_source_pipelined` on one object."""
+    S = 16
+    geom = synthetic.Geometry(S, G, L=300e3, n_query=500, seed=5)
+    win = synthetic.make_window(geom, 4000, seed=6)
+    torch.manual_seed(0)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV).eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), t(geom.edge_attr()), t(geom.locs), t(geom.x_grid))
+    dS, dM, xg, xq, tq = t(win["Slice"]), t(win["Mask"]), t(geom.x_grid), t(geom.x_query), t(geom.t_query)
+    fixed = (None, None, None, t(geom.locs), xg, xq, tq)
+    with torch.no_grad():
+        y, x = net.forward_fixed_source(dS, dM, *fixed)
+        for nb in (1, 3, 16):
+            net.window_batch = nb
+            for _ in range(nb):
+                net.push_window(dS, dM)
+            yb, xb, ev = net.flush_windows(xg, xq, tq)
+            net._hip.wait_tails()
+            torch.cuda.synchronize()
+            for k in range(nb):
+                assert torch.equal(yb[k], y) and torch.equal(xb[k], x), (nb, k)
+        for _ in range(nb):
+            net.push_window(dS, dM)
+        net.flush_windows(xg, xq, tq)
+        yp, xp, ev = net.forward_fixed_source_pipelined(dS, dM, *fixed)       # batched tails still in flight
+        net._hip.wait_tails()
+        torch.cuda.synchronize()
+        assert torch.equal(yp, y) and torch.equal(xp, x)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["assoc_7x45", "assoc_20x60", "assoc_20x60_nonull", "assoc_edges_18x50", "assoc_abspos_18x50",
                                   "assoc_subgraph_14x50", "assoc_nophase_18x50", "assoc_edges_abspos_18x50", "assoc_subgraph_edges_14x50",

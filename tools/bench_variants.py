@@ -69,6 +69,18 @@ def main():
         dS, dM = Slice.to(dev), Mask.to(dev)
         with torch.no_grad():
             dt, (y, x) = time_gpu(lambda: net.forward_fixed_source(dS, dM, None, None, None, locs, xg, xq, tq))
+            # independent windows as in the apply loop: P-sized kernels per window, one G-sized tail per 16 windows on a side stream
+            net.window_batch = 16
+
+            def batch16():
+                for _ in range(16):
+                    net.push_window(dS, dM)
+                return net.flush_windows(xg, xq, tq)
+            dtb, (yb, xb, _ev) = time_gpu(batch16, n_settle=20, n=15)
+            net._hip.wait_tails()
+            torch.cuda.synchronize()
+            dtb /= 16.0
+            same = bool(torch.equal(yb[3], y) and torch.equal(xb[3], x))
             w = {k: t.detach().cpu() for k, t in net.state_dict().items()}
             kw = {}
             if v == "edges":
@@ -87,6 +99,8 @@ def main():
         print(json.dumps({
             "variant": v, "workload": "200 stations / 10000 grid nodes / 50000 picks per window, " + label, "n_product_nodes": n_prod,
             "ms_per_window": round(dt * 1e3, 4), "picks_per_s": round(n_picks / dt, 1), "single_stream": True,
+            "ms_per_window_batched_tails": round(dtb * 1e3, 4), "picks_per_s_batched_tails": round(n_picks / dtb, 1),
+            "batched_equals_single_stream_bitwise": same,
             "ns_per_product_node": round(ns, 4), "vs_default_per_product_node": round(ns / ns_default, 3) if ns_default else None,
             "cpu_oracle_s_per_window": round(cdt, 2), "cpu_cores": int(torch.get_num_threads()),
             "max_abs_y_vs_cpu": float((y.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((x.cpu() - xc).abs().max())}), flush=True)
