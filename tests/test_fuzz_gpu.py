@@ -430,3 +430,71 @@ def test_random_case_device_apply_loop_on_an_irregular_product_graph(i):
         want[:, cols] += x[:, kp, 0] / n_overlap
     assert float(want.abs().max()) > 0
     assert max_abs(Out_2.cpu(), want) <= 1e-5
+
+
+def _two_output_case(cfg):
+    """Graphs and one window of a drawn configuration (numpy / CPU tensors), as the 2-output sweep builds them."""
+    S, G = cfg["S"], cfg["G"]
+    geom = _geometry(cfg)
+    win = synthetic.make_window(geom, cfg["n_picks"], seed=500 + cfg["seed"])
+    Slice, Mask, ea = win["Slice"], win["Mask"], geom.edge_attr()
+    if cfg["subgraph"]:
+        rng = np.random.default_rng(900 + cfg["seed"])
+        d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+        keep = np.zeros(d.shape, dtype=bool)
+        keep[np.arange(G)[:, None], np.argsort(d, axis=1)[:, :int(rng.integers(1, min(6, S) + 1))]] = True
+        keep |= rng.random(d.shape) < rng.choice([0.0, 0.1, 0.5])
+        src_i, sta_i = np.nonzero(keep)
+        pairs = np.stack((sta_i, src_i))
+        rows = src_i * S + sta_i
+        Slice, Mask, ea = Slice[rows], Mask[rows], ea.reshape(G, S, 3)[src_i, sta_i]
+        A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+        A_src_in_sta = torch.from_numpy(pairs).long()
+    else:
+        A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    return dict(geom=geom, Slice=Slice, Mask=Mask, ea=ea, A_in_sta=A_in_sta, A_in_src=A_in_src, A_src_in_prod=A_src_in_prod,
+                A_src_in_sta=A_src_in_sta)
+
+
+@pytest.mark.parametrize("i", range(max(2, N_CASES // 2)))
+def test_random_case_one_model_object_across_changing_graphs(i):
+    """One drop-in object, three `set_adjacencies` calls (graph A, graph B of another size and shape, graph A again) with an
+    in-place weight update in between, as a job that processes several station sets does: every `(y, x)` equals the oracle on
+    that graph with the weights of that moment (no stale context, table, static term or weight mirror)."""
+    from oracle import genie_oracle as O
+    cfgs = [_draw(13000 + 2 * (SEED0 + i)), _draw(13001 + 2 * (SEED0 + i))]
+    for k in ("edges", "abspos", "stage"):
+        cfgs[1][k] = cfgs[0][k]                     # one object: one model definition
+    print(cfgs)
+    w0 = _weights(cfgs[0])
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=cfgs[0]["edges"],
+                                                use_absolute_pos=cfgs[0]["abspos"])
+    net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
+    net.eval()
+    cases = [_two_output_case(c_) for c_ in cfgs]
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    t = lambda a: c(a).to(DEV)
+    for step, k in enumerate((0, 1, 0)):
+        cfg, cs = cfgs[k], cases[k]
+        geom = cs["geom"]
+        if step == 2:                                # an optimizer-like in-place update of every parameter
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(1.01)
+        gea = graph.GraphEdges(x=t(cs["ea"]), edge_index=cs["A_src_in_prod"].to(DEV))
+        net.set_adjacencies(cs["A_in_sta"].to(DEV), cs["A_in_src"].to(DEV), gea, gea, cs["A_src_in_sta"].to(DEV),
+                            torch.from_numpy(geom.A_src_src).to(DEV), None, None, None, None, t(geom.locs), t(geom.x_grid))
+        with torch.no_grad():
+            y, x = net.forward_fixed_source(t(cs["Slice"]), t(cs["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query),
+                                            t(geom.t_query))
+            w = {n: v.detach().cpu().clone() for n, v in net.state_dict().items()}
+            So, okw = c(cs["Slice"]), {}
+            if cfg["abspos"]:
+                So = O.absolute_pos_inputs(So, c(geom.locs), c(geom.x_grid), cs["A_src_in_sta"])
+            if cfg["edges"]:
+                okw["pos_rel"] = (O.edge_pos_features(c(geom.locs), cs["A_in_sta"], cs["A_src_in_sta"][0]),
+                                  O.edge_pos_features(c(geom.x_grid), cs["A_in_src"], cs["A_src_in_sta"][1]))
+            yo, xo = O.forward_fixed_source(w, So, c(cs["Mask"]), cs["A_in_sta"], cs["A_in_src"], c(cs["ea"]), cs["A_src_in_prod"],
+                                            torch.from_numpy(geom.A_src_src), c(geom.x_grid), c(geom.x_query), c(geom.t_query), **okw)
+        ey, ex = max_abs(y.cpu(), yo), max_abs(x.cpu(), xo)
+        assert ey <= 1e-5 and ex <= 1e-5, (step, cfg, ey, ex)
