@@ -1796,3 +1796,33 @@ def test_bench_line_contract_on_the_gpu():
     assert abs(d["value"] - 50000.0 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
     assert abs(rf["achieved"] - 3.07216 / d["ms_per_step"] * 1e3) <= 2e-3 * rf["achieved"]          # B_alg = 3.072 GB per window
     assert 0.1 < d["ms_per_step"] < 5.0 and set(rf["kernels"]) == {"k_stage1", "k_stage2"}
+
+
+def test_drop_in_accepts_the_tensor_forms_pytorch_callers_pass():
+    """The reference's methods are plain PyTorch and take whatever tensors a caller has: float64 / non-contiguous Slice, a uint8 or
+    bool Mask, positions in float64, a strided view of the query table. The drop-in normalises them (host side, before the C ABI)
+    and returns the same bits as for contiguous fp32 inputs."""
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    net.set_adjacencies_base(c.A_sta_sta, c.A_src_src, c.edge_attr.to(DEV), c.locs.float().to(DEV), c.x_grid.float().to(DEV))
+    Sl, Mk = c.Slice.to(DEV), c.Mask.to(DEV)
+    locs, xg, xq, tq = c.locs.float().to(DEV), c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV)
+    with torch.no_grad():
+        y0, x0 = net.forward_fixed_source(Sl, Mk, None, None, None, locs, xg, xq, tq)
+        wide = torch.zeros((Sl.shape[0], 8), device=DEV)
+        wide[:, ::2] = Sl
+        xq_wide = torch.zeros((xq.shape[0], 6), device=DEV)
+        xq_wide[:, :3] = xq
+        forms = [
+            (Sl.double(), Mk, locs, xg, xq, tq),                                   # float64 features
+            (wide[:, ::2], Mk, locs, xg, xq, tq),                                  # strided view
+            (Sl, Mk.to(torch.uint8), locs, xg, xq, tq),                            # uint8 mask
+            (Sl, Mk.bool(), locs, xg, xq, tq),                                     # bool mask
+            (Sl, Mk, locs.double(), xg.double(), xq_wide[:, :3], tq.double()),     # float64 positions, strided queries
+            (Sl, Mk, locs, xg, xq, tq.reshape(-1)),                                # flat t_query
+        ]
+        for k, (s_, m_, l_, g_, q_, t_) in enumerate(forms):
+            y, x = net.forward_fixed_source(s_, m_, None, None, None, l_, g_, q_, t_)
+            assert torch.equal(y, y0) and torch.equal(x, x0), k
