@@ -219,6 +219,19 @@ class ShardedPath(object):
         self.local.set_weights(named)
         self.full.set_weights(named)
 
+    def set_edge_features(self, pos_sta, pos_src_global):
+        """`use_updated_model_definition` on the shard (genie_set_edge_features): the mean edge features of the owned source nodes
+        come from the local CSR over the EXTENDED node list, so the positions of the halo nodes travel with the plan, not per window."""
+        ext = torch.as_tensor(self.plan.ext_global, dtype=torch.long)
+        pos = torch.as_tensor(pos_src_global).float()
+        self.local.set_edge_features(torch.as_tensor(pos_sta).float().to(self.device), pos[ext].contiguous().to(self.device))
+
+    def set_absolute_pos(self, pos_sta, pos_src_global):
+        """`use_absolute_pos` on the shard (genie_set_absolute_pos): scaled positions of the stations and of the extended node list."""
+        ext = torch.as_tensor(self.plan.ext_global, dtype=torch.long)
+        pos = torch.as_tensor(pos_src_global).float()
+        self.local.set_absolute_pos(torch.as_tensor(pos_sta).float().to(self.device), pos[ext].contiguous().to(self.device))
+
     def wv_view(self):
         """Float view [n_ext*S, 16] of the projected operand `wv` inside the local workspace."""
         lp = self.local

@@ -823,8 +823,9 @@ def test_config2_full_size_properties():
     assert ey <= 1e-5 and ex <= 1e-5                  # fp32 max-abs tolerance of BASELINE.json
 
 
-@pytest.mark.parametrize("S,G,W", [(40, 600, 2), (200, 300, 3), (17, 95, 4), (64, 1000, 8), (33, 257, 5)])
-def test_sharded_kernels_virtual_ranks_match_unsharded(S, G, W):
+@pytest.mark.parametrize("S,G,W,variant", [(40, 600, 2, None), (200, 300, 3, None), (17, 95, 4, None), (64, 1000, 8, None), (33, 257, 5, None),
+                                           (40, 600, 3, "edges"), (40, 600, 3, "abspos"), (200, 300, 2, "edges")])
+def test_sharded_kernels_virtual_ranks_match_unsharded(S, G, W, variant):
     """Source-node sharding on ONE GPU: W virtual ranks (halo rows, local CSR numbering, n_grid_ext > n_grid), the
     halo all-to-all replaced by direct copies. The result must equal the unsharded HIP path bit for bit (same kernels,
     same per-node arithmetic) and the oracle to tolerance. The RCCL collective itself is covered by tests/test_dist_cpu.py
@@ -833,21 +834,35 @@ def test_sharded_kernels_virtual_ranks_match_unsharded(S, G, W):
     from oracle import genie_oracle as O
     geom = synthetic.Geometry(S, G, L=200e3, n_query=20, seed=41 + W)
     win = synthetic.make_window(geom, 400, seed=42)
-    w = Case("odd_33x257").weights
+    # the two other model definitions on a shard: their static terms are per station / per source node of the EXTENDED list
+    w = Case({None: "odd_33x257", "edges": "edges_12x60", "abspos": "abspos_12x60"}[variant]).weights
+    if variant == "edges":
+        w = module._split_edge_columns(w)
+    if variant == "abspos":
+        w = module._split_abs_columns(w)
     wd = {k: v.to(DEV) for k, v in w.items()}
     Slice, Mask = torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"])
     ea = torch.from_numpy(geom.edge_attr())
     pos = torch.from_numpy(geom.x_grid).float()
+    locs = torch.from_numpy(geom.locs).float()
     sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
     # unsharded reference run
     hp = engine.HipPath(S, G, sta_csr, engine.csr_from_edges(torch.from_numpy(geom.A_src_src), G),
                         grid_order=engine.sfc_order(geom.x_grid), device=DEV, sta_order=engine.sfc_order(geom.locs))
+    if variant == "edges":
+        hp.set_edge_features(locs.to(DEV), pos.to(DEV))
+    if variant == "abspos":
+        hp.set_absolute_pos(locs.to(DEV), pos.to(DEV))
     hp.set_weights(wd)
     out_ref, xl_ref, bip_ref = hp.path_fwd(Slice.to(DEV), Mask.to(DEV), ea.to(DEV), pos.to(DEV), True, True)
     # virtual ranks (same station processing order: the per-tile station sums then add in the same order)
     ranks = [gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, W, r, DEV, pos_sta=geom.locs) for r in range(W)]
     rows = []
     for sp in ranks:
+        if variant == "edges":
+            sp.set_edge_features(locs, pos)
+        if variant == "abspos":
+            sp.set_absolute_pos(locs, pos)
         sp.set_weights(wd)
         ext = torch.from_numpy(sp.plan.ext_global)
         r = (ext.view(-1, 1) * S + torch.arange(S).view(1, -1)).reshape(-1)
