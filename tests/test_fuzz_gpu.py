@@ -498,3 +498,60 @@ def test_random_case_one_model_object_across_changing_graphs(i):
                                             torch.from_numpy(geom.A_src_src), c(geom.x_grid), c(geom.x_query), c(geom.t_query), **okw)
         ey, ex = max_abs(y.cpu(), yo), max_abs(x.cpu(), xo)
         assert ey <= 1e-5 and ex <= 1e-5, (step, cfg, ey, ex)
+
+
+@pytest.mark.parametrize("i", range(max(2, N_CASES // 2)))
+def test_random_case_adam_steps_match_the_oracle(i):
+    """Four Adam(1e-3) steps of the `forward_fixed_source` training step (MSE against random labels) on the drawn model definition
+    and graph shape: the loss of every step equals the oracle's autograd + torch.optim.Adam on the CPU to 1e-5 relative -- gradients,
+    and the refresh of the library's weight mirror (static-term columns under their own names included) after every in-place update."""
+    from oracle import genie_oracle as O
+    cfg = _draw(15000 + SEED0 + i)
+    cfg["n_picks"] = max(cfg["n_picks"], 50)
+    print(cfg)
+    cs = _two_output_case(cfg)
+    geom = cs["geom"]
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    t = lambda a: c(a).to(DEV)
+    w0 = _weights(cfg)
+    rng = np.random.default_rng(99 + cfg["seed"])
+    ly = c(rng.random((cfg["G"], 9, 1)))
+    lx = c(rng.random((cfg["Q"], 9, 1)))
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_updated_model_definition=cfg["edges"],
+                                                use_absolute_pos=cfg["abspos"])
+    net.load_state_dict({k: v.clone() for k, v in w0.items()}, strict=True)
+    net.train()
+    gea = graph.GraphEdges(x=t(cs["ea"]), edge_index=cs["A_src_in_prod"].to(DEV))
+    net.set_adjacencies(cs["A_in_sta"].to(DEV), cs["A_in_src"].to(DEV), gea, gea, cs["A_src_in_sta"].to(DEV),
+                        torch.from_numpy(geom.A_src_src).to(DEV), None, None, None, None, t(geom.locs), t(geom.x_grid))
+    args = (t(cs["Slice"]), t(cs["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query), t(geom.t_query))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    got = []
+    for _ in range(4):
+        opt.zero_grad()
+        y, x = net.forward_fixed_source(*args)
+        loss = ((y - ly.to(DEV)) ** 2).mean() + ((x - lx.to(DEV)) ** 2).mean()
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    w = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+    opt_o = torch.optim.Adam(list(w.values()), lr=1e-3)
+    So, okw = c(cs["Slice"]), {}
+    if cfg["abspos"]:
+        So = O.absolute_pos_inputs(So, c(geom.locs), c(geom.x_grid), cs["A_src_in_sta"])
+    if cfg["edges"]:
+        okw["pos_rel"] = (O.edge_pos_features(c(geom.locs), cs["A_in_sta"], cs["A_src_in_sta"][0]),
+                          O.edge_pos_features(c(geom.x_grid), cs["A_in_src"], cs["A_src_in_sta"][1]))
+    want = []
+    for _ in range(4):
+        opt_o.zero_grad()
+        yo, xo = O.forward_fixed_source(w, So, c(cs["Mask"]), cs["A_in_sta"], cs["A_in_src"], c(cs["ea"]), cs["A_src_in_prod"],
+                                        torch.from_numpy(geom.A_src_src), c(geom.x_grid), c(geom.x_query), c(geom.t_query), **okw)
+        lo = ((yo - ly) ** 2).mean() + ((xo - lx) ** 2).mean()
+        lo.backward()
+        opt_o.step()
+        want.append(float(lo))
+    print(got, want)
+    assert want[-1] < want[0]
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 1e-5 * abs(b), (cfg, got, want)
