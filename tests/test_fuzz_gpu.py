@@ -282,6 +282,9 @@ def test_random_case_four_outputs_and_gradients_match_the_oracle(i, monkeypatch)
     net.eval()
     with torch.no_grad():
         out_e = net(t(Slice), t(Mask), *graphs, *tail)
+        net.set_adjacencies(*graphs, t(geom.locs), t(geom.x_grid))                  # the cached-graph form (module.py:941-997)
+        out_f = net.forward_fixed(t(Slice), t(Mask), *tail)
+    assert all(torch.equal(a, b) for a, b in zip(out_e, out_f)), cfg
     net.train()
     outs = net(t(Slice), t(Mask), *graphs, *tail)
     gen = torch.Generator().manual_seed(11 + cfg["seed"])
