@@ -6,7 +6,7 @@ oracle's literal edge-list formulation (oracle/genie_oracle.py, pinned to the re
 `forward_fixed_source` (module.py:999-1020) in eval mode to 1e-5 absolute, train mode equal to eval mode, and every parameter
 gradient of a random cotangent to 2e-4 of that gradient's own scale (a mismatch is accepted only where the oracle's own gradient is
 discontinuous: a pre-activation within rounding of a PReLU kink). `GENIE_FUZZ_CASES` / `GENIE_FUZZ_SEED` widen the sweep
-(e.g. GENIE_FUZZ_SEED=20000 GENIE_FUZZ_CASES=160: 832 cases, 7.5 min on an MI355X); the default is a handful of fixed seeds."""
+(e.g. GENIE_FUZZ_SEED=20000 GENIE_FUZZ_CASES=160: 832 cases, 7.5 min on an MI355X; GENIE_FUZZ_BIG=1: 200 stations x 1000 / 2500 source nodes); the default is a handful of fixed seeds."""
 import os
 
 import numpy as np
@@ -34,6 +34,8 @@ def _draw(seed):
     cfg["ragged"] = bool(rng.integers(4) == 0)      # base graphs with edges dropped at random: non-uniform degrees, empty neighbourhoods
     if rng.integers(5) == 0:                        # the production station counts (k_stage2_h2u, work maps), fewer source nodes
         cfg["S"], cfg["G"] = int(rng.choice([100, 200, 333])), int(rng.choice([16, 40, 129]))
+    if os.environ.get("GENIE_FUZZ_BIG"):            # production-like sizes (the CPU oracle then takes seconds per case)
+        cfg["S"], cfg["G"], cfg["n_picks"] = 200, int(rng.choice([1000, 2500])), int(rng.choice([2000, 20000]))
     return cfg
 
 
