@@ -232,3 +232,207 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
                 first = w + 1
         hp.wait_tails()
     return Out_2, times
+
+
+# ---- per-window pick lists (process_utils.py:644-699) and the two other per-day loops of the caller ------------------------------------
+
+class ResidentPicks(object):
+    """The picks of a day resident on one device, in the form every per-window step of the caller needs.
+
+    `P` [n, 5] float64 (t, ABSOLUTE station index, amp, prob, phase) in the caller's order (`load_picks`, utils.py:983: the pick file's
+    order, not a time order); `ind_use` = the stations of the model, positions into the absolute station set of `n_sta_all` entries
+    (`perm_vec`, process_utils.py:486-487 / :678-679). Kept here: the picks of those stations (the reference drops the others per
+    window, :480-483 and :684 -- the filter does not depend on the window), stable-sorted by time, so that
+      * the picks a window's embedding reads, `t0 - 2 sigma < t < t0 + max_t + 2 sigma` (:476), are ONE contiguous range `embed_range`
+        found by two binary searches on a host copy of the times -- the tensors handed to `genie_embed_window` are views, and
+      * the lists `forward_fixed` consumes (`extract_pick_inputs_from_data`, :644-699) are that range cut by the ball query (:665) and
+        stable-sorted by station on the device: `np.lexsort((times, indices))` (:690) orders by station, then time, ties in the
+        caller's order, which a stable sort by station of a stable time order reproduces exactly.
+    Works on CPU tensors too (the CPU tests pin it to the reference's fixtures); nothing here touches the HIP library."""
+
+    def __init__(self, P, ind_use, n_sta_all, device, use_phase_types=True):
+        P = np.asarray(P, dtype=np.float64)
+        ind_use = np.asarray(ind_use).astype(np.int64)
+        perm_vec = -np.ones(int(n_sta_all), dtype=np.int64)
+        perm_vec[ind_use] = np.arange(len(ind_use))
+        sta = perm_vec[P[:, 1].astype(np.int64)]
+        keep = np.nonzero(sta > -1)[0]
+        keep = keep[np.argsort(P[keep, 0], kind="stable")]
+        self.P = P
+        self.index_host = keep                                   # rows of the caller's P, in this object's (time) order
+        self.t_host = np.ascontiguousarray(P[keep, 0])
+        self.device = torch.device(device)
+        self.n_sta = int(len(ind_use))
+        ph = P[keep, 4].copy()
+        if not use_phase_types:                                  # process_continuous_days.py:562-563
+            ph[:] = 0.0
+        self.t = torch.from_numpy(self.t_host).to(self.device)
+        self.sta = torch.from_numpy(sta[keep].astype(np.int32)).to(self.device)
+        self.phase = torch.from_numpy(ph.astype(np.int32)).to(self.device)
+        self.phase_f = torch.from_numpy(ph).to(self.device)
+        self.index = torch.from_numpy(keep).to(self.device)
+
+    def __len__(self):
+        return int(self.t_host.shape[0])
+
+    def embed_range(self, t0, max_t, kernel_sig_t):
+        """[lo, hi) of the picks with `t0 - 2 sigma < t < t0 + max_t + 2 sigma` (strict, process_utils.py:476)."""
+        return picks_in_embed_range(self.t_host, float(t0), float(max_t), float(kernel_sig_t))
+
+    def embed_args(self, t0, max_t, kernel_sig_t):
+        """(pick_t float64, pick_sta int32, pick_phase int32) views for `HipPath.embed_window`, or None for an empty range."""
+        lo, hi = self.embed_range(t0, max_t, kernel_sig_t)
+        if hi <= lo:
+            return None
+        return self.t[lo:hi], self.sta[lo:hi], self.phase[lo:hi]
+
+    def pick_inputs(self, t0, max_t, kernel_sig_t, t_win=10.0):
+        """`lp_times, lp_stations, lp_phases` of `extract_input_from_data(...)[1]` for the window starting at `t0`
+        (process_utils.py:637 -> :644-699) as device tensors (float64 [m], int64 [m], float64 [m]) plus `index` int64 [m]: the rows of
+        the caller's `P` they come from (`lp_meta = P[index]`). The ball query of :665 keeps `|t - (t0 + max_t / 2)| <= t_win + max_t / 2`
+        of the window's slice; with `2 sigma <= t_win` that is all of it."""
+        lo, hi = self.embed_range(t0, max_t, kernel_sig_t)
+        t, sta, ph, idx = self.t[lo:hi], self.sta[lo:hi], self.phase_f[lo:hi], self.index[lo:hi]
+        if 2.0 * float(kernel_sig_t) > float(t_win) and hi > lo:
+            inside = (t - (float(t0) + float(max_t) / 2.0)).abs() <= (float(t_win) + float(max_t) / 2.0)
+            t, sta, ph, idx = t[inside], sta[inside], ph[inside], idx[inside]
+        order = torch.sort(sta, stable=True)[1]
+        return t[order] - float(t0), sta[order].long(), ph[order], idx[order]
+
+    def meta(self, index):
+        """`lp_meta` rows (host float64 [m, 5]) of a `pick_inputs` index."""
+        return self.P[index.cpu().numpy()]
+
+
+class GridLeg(object):
+    """One source grid of the per-day loops (`x_grid_ind` of process_continuous_days.py:770, :950, :1020): the model whose adjacencies were
+    set on that grid, the grid's Cartesian node positions and its travel-time table `x_grids_trv[x_grid_ind]` [G, S, 2] resident on the
+    device ([N, 2] rows per listed product node for a `use_subgraph` model: `pairs` [2, N] = `A_src_in_sta`)."""
+
+    def __init__(self, net, x_grid_cart, trv_times, pairs=None):
+        self.net = net
+        hp = net._hip
+        if hp is None:
+            raise RuntimeError("GridLeg: call net.set_adjacencies*(...) first")
+        self.device = hp.device
+        self.x_grid_cart = torch.as_tensor(x_grid_cart).float().to(self.device)
+        trv_times = np.asarray(trv_times, dtype=np.float32)
+        if pairs is not None:
+            pairs = np.asarray(pairs)
+            trv_times = trv_times[pairs[1], pairs[0]]
+        self.trv = torch.from_numpy(np.ascontiguousarray(trv_times).reshape(-1, 2)).to(self.device)
+
+    def embed(self, picks, t0, max_t, kernel_sig_t, dt):
+        """(Slice, Mask) of the window starting at t0 (genie_embed_window = extract_input_from_data, process_utils.py:460-642), or None
+        when no pick falls in the embedding range."""
+        args = picks.embed_args(t0, max_t, kernel_sig_t)
+        if args is None:
+            return None
+        return self.net._hip.embed_window(args[0], args[1], args[2], float(t0), float(max_t), float(kernel_sig_t), float(dt), self.trv)
+
+
+def _dt_embed(kernel_sig_t, dt_embed):
+    return float(dt_embed if dt_embed is not None else np.round(kernel_sig_t / 10.0, 2))          # process_continuous_days.py:608
+
+
+def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offset_range, n_rand_query, ftrns1, ftrns2,
+                   lat_range, lon_range, depth_range, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, rand=None):
+    """The refine pass of the caller (process_continuous_days.py:926-980) on the device: for every candidate source `srcs[i]` = (lat, lon,
+    depth, origin time, value) a cloud of `n_rand_query` random queries around it (`ftrns1(src) + rand(n, 3) * X_offset_range +
+    X_offset_min`, kept where `ftrns2` of it lies strictly inside the three ranges, :929-936), one `forward_fixed_source` per grid
+    leg on the window that STARTS at the source's origin time, read out at those queries (:971-972; the kNN of the cloud into the grid
+    by `genie_knn`), the clouds' outputs averaged over the legs, and the refined source = the query and time offset of the maximum
+    (`argmax` of the row maxima, then of that row, :976-978: first maximum in both). Sources whose window holds no pick keep an all-zero
+    read-out (:966-967), i.e. their first query and `tq[0]`. Returns (srcs_refined float64 [n, 5] sorted by origin time (:981-982),
+    `order` = that sort's permutation of the input rows). `rand(n, 3)` defaults to `np.random.rand` (the reference's draw); the
+    per-source results stay on the device until one copy at the end."""
+    rand = rand or np.random.rand
+    srcs = np.asarray(srcs, dtype=np.float64)
+    tq_host = np.asarray(tq.detach().cpu() if torch.is_tensor(tq) else tq, dtype=np.float64).reshape(-1)
+    dev = legs[0].device
+    tq_d = torch.as_tensor(tq_host.reshape(-1, 1)).float().to(dev)
+    locs_d = torch.as_tensor(locs_cart).float().to(dev)
+    dt = _dt_embed(kernel_sig_t, dt_embed)
+    n_scale = float(len(legs))
+    clouds, found = [], []
+    with torch.no_grad():
+        for i in range(srcs.shape[0]):
+            Xc = ftrns1(srcs[i, 0:3].reshape(1, -1)) + (rand(n_rand_query, 3) * X_offset_range + X_offset_min)      # :929
+            X1 = ftrns2(Xc)
+            inside = np.where((X1[:, 0] > lat_range[0]) * (X1[:, 0] < lat_range[1]) * (X1[:, 1] > lon_range[0]) * (X1[:, 1] < lon_range[1])
+                              * (X1[:, 2] > depth_range[0]) * (X1[:, 2] < depth_range[1]))[0]
+            X1, Xc = X1[inside], Xc[inside]
+            clouds.append(X1)
+            xq = torch.from_numpy(np.ascontiguousarray(Xc)).float().to(dev)                                           # torch.Tensor(...) :934
+            acc = torch.zeros((xq.shape[0], tq_host.shape[0]), dtype=torch.float32, device=dev)
+            if xq.shape[0]:
+                for leg in legs:
+                    em = leg.embed(picks, srcs[i, 3], max_t, kernel_sig_t, dt)
+                    if em is None:
+                        continue                                                                                        # :966-967
+                    _, x = leg.net.forward_fixed_source(em[0], em[1], None, None, None, locs_d, leg.x_grid_cart, xq, tq_d)
+                    acc += x[:, :, 0] / n_scale                                                                         # :972
+            if xq.shape[0]:
+                ip = torch.argmax(acc.max(1)[0])
+                it = torch.argmax(acc[ip])
+                found.append(torch.stack((ip.double(), it.double(), acc[ip, it].double())))
+            else:
+                found.append(torch.full((3,), float("nan"), dtype=torch.float64, device=dev))
+    found = torch.stack(found).cpu().numpy() if found else np.zeros((0, 3))
+    out = np.zeros((srcs.shape[0], 5))
+    for i in range(srcs.shape[0]):
+        if clouds[i].shape[0] == 0:
+            raise ValueError("refine_sources: no query of source %d lies inside the region (the reference's argmax raises here too)" % i)
+        ip, it = int(found[i, 0]), int(found[i, 1])
+        out[i, 0:3] = clouds[i][ip]
+        out[i, 3] = srcs[i, 3] + tq_host[it]
+        out[i, 4] = found[i, 2]
+    order = np.argsort(out[:, 3])
+    return out[order], order
+
+
+def associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out_srcs, ftrns1, x_save, kernel_sig_t=synthetic.KERNEL_SIG_T,
+                      dt_embed=None, t_win=10.0):
+    """The association pass of the caller (process_continuous_days.py:1020-1065) on the device: for every refined source one 4-output
+    `forward_fixed` per grid leg on the window that starts at its origin time, with the window's pick lists (`ResidentPicks.pick_inputs`
+    = extract_pick_inputs_from_data), ONE spatial query `x_save` (lat, lon of the first node of the reference's coarse map; its depth
+    replaced by the source's, :1046) and the source itself as the only candidate (`x_query_src = ftrns1(src)`, `tq_sample = 0`,
+    `trv_out_q = trv_out_srcs[[i]]` [1, S, 2], :1052). Returns (Out_p_save, Out_s_save: lists of float32 device tensors [m_i] = the
+    P / S association likelihood of every pick of the window, averaged over the legs (:1054-1055); Save_picks: list of host [m_i, 2]
+    (relative time, station, :1042); lp_meta: list of host [m_i, 5]). A window without picks yields empty entries (:1049-1050)."""
+    srcs = np.asarray(srcs_refined, dtype=np.float64)
+    dev = legs[0].device
+    tq_d = torch.as_tensor(np.asarray(tq.detach().cpu() if torch.is_tensor(tq) else tq, dtype=np.float32).reshape(-1, 1)).to(dev)
+    locs_d = torch.as_tensor(locs_cart).float().to(dev)
+    trv_out_srcs = torch.as_tensor(trv_out_srcs).float().to(dev)
+    dt = _dt_embed(kernel_sig_t, dt_embed)
+    n_scale = float(len(legs))
+    zero = torch.zeros(1, device=dev)
+    x_save = np.array(x_save, dtype=np.float64).reshape(1, 3)
+    Out_p, Out_s, Save_picks, lp_meta = [], [], [], []
+    with torch.no_grad():
+        for i in range(srcs.shape[0]):
+            tp, ip, ph, idx = picks.pick_inputs(srcs[i, 3], max_t, kernel_sig_t, t_win)
+            Save_picks.append((tp, ip))
+            lp_meta.append(idx)
+            acc_p = torch.zeros(tp.shape[0], dtype=torch.float32, device=dev)
+            acc_s = torch.zeros(tp.shape[0], dtype=torch.float32, device=dev)
+            Out_p.append(acc_p)
+            Out_s.append(acc_s)
+            if tp.shape[0] == 0:
+                continue                                                                                                # :1049-1050
+            x_save[0, 2] = srcs[i, 2]                                                                                   # :1046
+            xs_cart = torch.from_numpy(np.ascontiguousarray(ftrns1(x_save))).float().to(dev)
+            src_cart = torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[i, 0:3].reshape(1, -1)))).float().to(dev)
+            tpf, phf = tp.float(), ph.long().float().reshape(-1, 1)
+            for leg in legs:
+                em = leg.embed(picks, srcs[i, 3], max_t, kernel_sig_t, dt)
+                if em is None:
+                    continue
+                out = leg.net.forward_fixed(em[0], em[1], tpf, ip, phf, locs_d, leg.x_grid_cart, xs_cart, src_cart, tq_d, zero,
+                                            trv_out_srcs[i:i + 1])                                                      # :1052
+                acc_p += out[2][0, :, 0] / n_scale                                                                      # :1054
+                acc_s += out[3][0, :, 0] / n_scale                                                                      # :1055
+    Save_picks = [np.stack((a.cpu().numpy(), b.cpu().numpy().astype(np.float64)), axis=1) for a, b in Save_picks]
+    lp_meta = [picks.meta(ix) for ix in lp_meta]
+    return Out_p, Out_s, Save_picks, lp_meta

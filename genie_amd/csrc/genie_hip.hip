@@ -1272,6 +1272,8 @@ struct genie_ctx {
     float* packed_s2h;         // f16x2 weight image of k_stage2_h2 (Bipartite_ReadIn.fc1)
     unsigned *ea_frag, *ea_frag_tmp;    // edge_attr as B fragments of k_stage2_h2 (k_ea_frag): of the registered static edge_attr / of any other one
     bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
+    std::vector<const void*> lds_attr_done;   // kernels whose MaxDynamicSharedMemorySize was raised for THIS context's device (the attribute
+                               // is per device: a process-wide flag would skip the second GPU of a multi-GPU process)
     int xs_sta_order;          // genie_embed_window_split: the station-order state its split rows were written under
     int sign_input;            // genie_set_sign_input(1): the embedding tags every feature with the sign of the series' negative slope
     int no_phase;              // genie_set_phase_types(0): the embedding zeroes the phase-informed columns of Slice / Mask
@@ -1286,6 +1288,14 @@ struct genie_ctx {
 };
 
 namespace {
+
+// raise a kernel's dynamic-LDS limit once per context (= per device)
+int raise_lds_limit(genie_ctx* c, const void* kern, int bytes) {
+    for (const void* k : c->lds_attr_done) if (k == kern) return GENIE_OK;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    c->lds_attr_done.push_back(kern);
+    return GENIE_OK;
+}
 
 // The station processing order is honoured by k_split_rows / the embedding's split rows, k_stage1_h2 (through the relabelled
 // station graph) and k_stage2_ord: active only while those are the kernels that run (use_absolute_pos together with the
@@ -2157,6 +2167,7 @@ int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_
     k_abs_table<<<(unsigned)((ng * 4 + 255) / 256), 256, 0, st>>>(pos_src, (int)ng, inv, c->abs_src);
     HIP_TRY(hipGetLastError());
     c->abs_dirty = true;
+    c->dirty = true;             // the fp16 range guard bounds the hidden states with the maxima of these tables: re-evaluate it
     return GENIE_OK;
 }
 
@@ -2567,13 +2578,14 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             const long long items = (long long)tb->nblk * c->T;
             const int grid = (int)std::max<long long>(8, std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8) / 8 * 8);
             const bool big = c->P_ext * 128 >= (1ll << 32);
-            auto launch = [&](auto kern) {
-                static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            auto launch = [&](auto kern) -> int {
+                if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;
                 kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
+                return GENIE_OK;
             };
-            if (x_latent_out) { if (big) launch(k_stage2_h2u<true, true, true>); else launch(k_stage2_h2u<true, false, true>); }
-            else { if (big) launch(k_stage2_h2u<false, true, true>); else launch(k_stage2_h2u<false, false, true>); }
+            if (x_latent_out) rc = big ? launch(k_stage2_h2u<true, true, true>) : launch(k_stage2_h2u<true, false, true>);
+            else rc = big ? launch(k_stage2_h2u<false, true, true>) : launch(k_stage2_h2u<false, false, true>);
+            if (rc) return rc;
         } else {
             const int grid = da_grid(c, n_tiles, c->bpc2o);
             if (x_latent_out) k_stage2_ord<8, 15, true, false, true><<<grid, 256, 0, st>>>(a);
@@ -2606,6 +2618,9 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             k_stage2_ord<8, 15, false><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
 #endif
         } else {           // s2h_on(c): stage 1 of this window wrote c / wv node-planar
+            if (!c->ws_np)     // (genie_set_stage_precision between a window's two stages would get here)
+                return fail(GENIE_ERR_STATE, "stage 2: the last stage 1 left row-layout c / wv but the f16x2 stage 2 reads them node-planar "
+                                             "(stage precision changed between the two stages of a window?)");
             a.np = 1; a.packed = c->packed_s2h;
             if (c->ea_frag && c->ea_user == edge_attr) a.ea_frag = c->ea_frag;
             else {
@@ -2622,13 +2637,14 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                 const long long items = (long long)tb->nblk * c->T;
                 const long long gsz = std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8);
                 const int grid = (int)std::max<long long>(8, gsz / 8 * 8);
-                auto launch = [&](auto kern) {
-                    static bool attr_set = false;       // (one per instantiation: the 70-KB dynamic LDS needs the attribute once)
-                    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+                auto launch = [&](auto kern) -> int {      // (the 70-KB dynamic LDS needs the attribute once per kernel and device)
+                    if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;
                     kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
+                    return GENIE_OK;
                 };
-                if (x_latent_out) { if (big) launch(k_stage2_h2u<true, true>); else launch(k_stage2_h2u<true, false>); }
-                else { if (big) launch(k_stage2_h2u<false, true>); else launch(k_stage2_h2u<false, false>); }
+                if (x_latent_out) rc = big ? launch(k_stage2_h2u<true, true>) : launch(k_stage2_h2u<true, false>);
+                else rc = big ? launch(k_stage2_h2u<false, true>) : launch(k_stage2_h2u<false, false>);
+                if (rc) return rc;
             } else {
                 const int grid = da_grid(c, n_tiles, c->bpc2h);
                 if (x_latent_out) { if (big) k_stage2_h2<true, true><<<grid, 256, 0, st>>>(a); else k_stage2_h2<true, false><<<grid, 256, 0, st>>>(a); }
@@ -2636,8 +2652,12 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             }
         }
     }
-    else
+    else {
+        if (c->ws_np && !no_bip)       // (no_bip: the association heads' last pass reads the rows k_assoc_b wrote, whatever stage 1 left)
+            return fail(GENIE_ERR_STATE, "stage 2: the last stage 1 left node-planar c / wv but the fp32 stage 2 reads rows (stage precision "
+                                         "changed between the two stages of a window?)");
         k_stage2<<<da_grid(c, n_tiles, c->bpc2), 256, 0, st>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -3377,12 +3397,13 @@ int genie_tail_train_fwd(genie_ctx* c, const float* pos, const float* x_query, c
     // inputs land in `tsave` instead of the workspace slot
     k_part_sum32<<<(c->G * 32 + 255) / 256, 256, 0, st>>>(w + c->o_part + so, c->G, part_T(c), r);
     k_bip_out_m<false><<<tl_blocks(c->G, c->tail_cu_sa), 256, 0, st>>>(w + c->o_part + so, c->G, part_T(c), c->packed[PL_BIP], bip, 0, 0);
+    if ((rc = raise_lds_limit(c, (const void*)k_readout_m<1>, (int)(sizeof(float) * ROM_LDS_FLOATS)))) return rc;   // (before tail_train is set: no
+                                                                                                                     // early return may leave it on)
     c->tail_train = 1;           // fp32 chains: the backward recomputes every pre-activation of the tail with them
     rc = sa_launch_pre(c, 1, bip, w, 0, st);
     if (!rc) rc = sa_launch_layer(c, 1, bip, pos, sa1, w, 0, true, st);
     if (!rc) rc = sa_launch_layer(c, 2, sa1, pos, sa2, w, 1, true, st);
     if (!rc) rc = sa_launch_layer(c, 3, sa2, pos, xs, w, 0, false, st);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
     RoArgs a = make_ro_args(c);
     a.T = n_t; a.x_spatial = xs; a.t_query = t_query;
     if (!rc) {

@@ -109,10 +109,17 @@ class Transport(object):
     group without device collectives (gloo: the CPU tests and the several-processes-on-one-GPU test) is served by staging
     through host memory, which synchronises the calling stream -- test plumbing, not a data path."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, world=None):
+        """`world`: the rank count of the plan the collectives serve. A process group of another size cannot carry them: a one-rank
+        plan inside an N-rank job (a single-GPU leg of a multi-rank run) then runs without collectives -- pass an explicit one-rank
+        `group` to exercise the RCCL path there --, any other mismatch is an error."""
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.on = dist.is_available() and dist.is_initialized()
+        if self.on and world is not None and dist.get_world_size(group) != int(world):
+            if int(world) != 1:
+                raise ValueError("process group of %d ranks cannot serve a %d-rank shard plan" % (dist.get_world_size(group), int(world)))
+            self.on = False
         self.device_collectives = self.on and dist.get_backend(group) == "nccl"
 
     def all_to_all_rows(self, recv, send, recv_counts, send_counts):
@@ -151,7 +158,7 @@ def exchange_halo_rows(rows_own, plan, n_sta, group=None):
     send = blocks.index_select(0, send_idx).contiguous() if send_idx.numel() else blocks.new_zeros((0, S * C))
     recv = blocks.new_empty((plan.n_halo, S * C))
     if plan.world > 1:
-        Transport(group).all_to_all_rows(recv, send, plan.recv_counts, plan.send_counts)
+        Transport(group, plan.world).all_to_all_rows(recv, send, plan.recv_counts, plan.send_counts)
     return recv.view(plan.n_halo * S, C)
 
 
@@ -173,7 +180,7 @@ def allgather_owned(x_own, plan, group=None, index=None):
     idx_t, n_max = index
     pad = x_own if plan.n_own == n_max else torch.cat((x_own, x_own.new_zeros((n_max - plan.n_own, x_own.shape[1]))))
     buf = x_own.new_empty((plan.world, n_max, x_own.shape[1]))
-    Transport(group).all_gather_rows(buf, pad.contiguous())
+    Transport(group, plan.world).all_gather_rows(buf, pad.contiguous())
     return buf.view(-1, x_own.shape[1]).index_select(0, idx_t)
 
 
@@ -201,7 +208,7 @@ class ShardedPath(object):
                                    engine.csr_from_edges(torch.as_tensor(A_src_src), n_grid), grid_order=None,
                                    scale_rel=scale_rel, device=device)
         self.device = dev = self.local.device
-        self.transport = Transport(group)
+        self.transport = Transport(group, world)
         S = self.n_sta
         pitch = int(self.local.lib.genie_ws_v_pitch(self.local.ctx))
         self._pitch = pitch

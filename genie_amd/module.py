@@ -702,16 +702,21 @@ class GCN_Detection_Network_extended(nn.Module):
         return _split_edge_columns if self.use_updated_model_definition else (_split_abs_columns if self.use_absolute_pos else None)
 
     # ---- graphs --------------------------------------------------------------------------------
+    def _configure_engine(self):
+        """The model-level options every new HIP context gets, whichever builder made it (Cartesian or `use_subgraph`): the weight
+        registry view, TemporalAttention's time scale, and the two flags of the device pick embedding (config.yaml:91, :93)."""
+        self._path_params = _path_param_dict(self)
+        self._hip.set_scale_t(self.TemporalAttention.scale_t)
+        self._hip.set_phase_types(self.use_phase_types)
+        self._hip.set_sign_input(self.use_sign_input)
+
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         order = _engine.sfc_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
         sta_order = _engine.sfc_order(pos_loc.detach().cpu().numpy()) if pos_loc is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev, sta_order=sta_order)
-        self._path_params = _path_param_dict(self)
-        self._hip.set_scale_t(self.TemporalAttention.scale_t)
-        self._hip.set_phase_types(self.use_phase_types)
-        self._hip.set_sign_input(self.use_sign_input)
+        self._configure_engine()
         if self.use_updated_model_definition:
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_updated_model_definition=True needs station and source positions")
@@ -768,9 +773,7 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
                                     scale_rel=self.scale_rel, device=dev, subgraph=sub)
         self._hip.set_subgraph_stations(pairs[0])
-        self._path_params = _path_param_dict(self)
-        self._hip.set_scale_t(self.TemporalAttention.scale_t)
-        self._hip.set_phase_types(self.use_phase_types)
+        self._configure_engine()
         if self.use_updated_model_definition:       # module.py:1059-1072 on the irregular edge lists: positions per product node
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_updated_model_definition=True needs station and source positions")
@@ -806,9 +809,7 @@ class GCN_Detection_Network_extended(nn.Module):
         order = _engine.sfc_order(pos_src.detach().cpu().numpy())
         self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
         self._hip.set_subgraph_stations(pairs[0])
-        self._path_params = _path_param_dict(self)
-        self._hip.set_scale_t(self.TemporalAttention.scale_t)
-        self._hip.set_phase_types(self.use_phase_types)
+        self._configure_engine()
         if self.use_updated_model_definition:
             self._hip.set_edge_features(pos_loc[pairs[0].long()].contiguous(), pos_src[pairs[1].long()].contiguous())
         if self.use_absolute_pos:

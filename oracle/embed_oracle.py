@@ -84,3 +84,34 @@ def extract_input_from_data(P, t0, ind_use, n_sta_all, trv_times, A_src_in_sta, 
         Slice[ok, 3] *= ss[sta[ok], is_[ok]]
     Mask = (np.abs(Slice) > 0.01).astype(np.float32)                                                          # :629
     return Slice, Mask
+
+
+def extract_pick_inputs_from_data(P_slice, n_sta_all, ind_use, t0, max_t, t_win=10.0):
+    """The per-window pick lists a `forward_fixed` call consumes (process_utils.py:644-699, `use_batch = False`): from the picks
+    `P_slice` [n, 5] (t, ABSOLUTE station index, amp, prob, phase) in the caller's order, those within `t_win + max_t / 2` of the
+    window centre `t0 + max_t / 2` (cKDTree.query_ball_point, :665: inclusive; a multi-point query returns ascending indices) whose
+    station is one of `ind_use` (:680-687), station indices mapped through `perm_vec` to positions in `ind_use` (:678-679), sorted by
+    `np.lexsort((times, indices))` (:690: station, then time, ties in the caller's order), times relative to the window start (:691).
+    Returns (lp_times float64 [m], lp_stations int [m], lp_phases float64 [m], lp_meta float64 [m, 5])."""
+    P_slice = np.asarray(P_slice, dtype=np.float64)
+    centre, radius = float(t0) + max_t / 2.0, t_win + max_t / 2.0
+    lp = np.where(np.abs(P_slice[:, 0] - centre) <= radius)[0]                                     # :665
+    perm_vec = -1 * np.ones(n_sta_all).astype("int")
+    perm_vec[ind_use] = np.arange(len(ind_use))                                                    # :678-679
+    meta = P_slice[lp, :]
+    phase_vals = P_slice[lp, 4]
+    times = meta[:, 0]
+    indices = perm_vec[meta[:, 1].astype("int")]
+    ineed = np.where(indices > -1)[0]                                                              # :684
+    times, indices, phase_vals, meta = times[ineed], indices[ineed], phase_vals[ineed], meta[ineed]
+    lex_sort = np.lexsort((times, indices))                                                        # :690
+    return times[lex_sort] - float(t0), indices[lex_sort], phase_vals[lex_sort], meta[lex_sort]    # :691-694
+
+
+def window_pick_slice(P, t0, ind_use, max_t, kernel_sig_t):
+    """`P_slice` as extract_input_from_data hands it to extract_pick_inputs_from_data (process_utils.py:476-483): picks strictly inside
+    `(t0 - 2 sigma, t0 + max_t + 2 sigma)` whose station is in `ind_use`, in the caller's order."""
+    P = np.asarray(P, dtype=np.float64)
+    ineed = np.where((P[:, 0] > (t0 - 2.0 * kernel_sig_t)) * (P[:, 0] < (t0 + max_t + 2.0 * kernel_sig_t)))[0]   # :476
+    P_slice = P[ineed]
+    return P_slice[np.isin(P_slice[:, 1].astype("int"), np.asarray(ind_use))]                                     # :480-483

@@ -182,6 +182,65 @@ def run_embed_case(name, geom, P, t0, kernel_sig_t=3.0, use_sign_input=False):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "nonzero rows", int((Inpts[0].abs().sum(1) > 0).sum()))
 
 
+def run_pick_inputs_case(name, geom, P, t0, ind_use, kernel_sig_t=3.0, t_win_direct=None):
+    """Golden vector for the per-window pick lists: the `[lp_times, lp_stations, lp_phases, lp_meta]` the reference's
+    `extract_input_from_data` returns next to `[Inpts, Masks]` (process_utils.py:637, = `extract_pick_inputs_from_data` :644-699 on the
+    window's `P_slice`), with `ind_use` a SUBSET of the station file (`P[:, 1]` holds absolute station indices, `locs` the absolute
+    set); `t_win_direct`: additionally the reference function called directly on that `P_slice` with another `t_win`, so that the ball
+    query trims the list."""
+    import process_utils as ref_pu   # noqa: E402
+    ind_use = np.asarray(ind_use).astype("int")
+    S_all, Gn = geom.n_sta, geom.n_grid
+    trv_times = geom.travel_times().astype(np.float32)                     # [G, S_all, 2]
+    n_use = len(ind_use)
+    A_src_in_sta = np.stack([np.tile(np.arange(n_use), Gn), np.repeat(np.arange(Gn), n_use)], axis=0)
+    dt = np.round(kernel_sig_t / 10.0, 2)
+    max_t = float(np.ceil(trv_times.max() + 1.0))
+    [Inpts, Masks], lp = ref_pu.extract_input_from_data(None, P, np.array([t0]), ind_use, geom.locs, geom.x_grid, A_src_in_sta,
+                                                         trv_times=trv_times, max_t=max_t, kernel_sig_t=kernel_sig_t, dt=dt, device="cpu")
+    out = dict(P=P, t0=np.float64(t0), n_sta_all=np.int64(S_all), n_grid=np.int64(Gn), ind_use=ind_use.astype(np.int64),
+               trv_times=trv_times, max_t=np.float64(max_t), kernel_sig_t=np.float64(kernel_sig_t), dt=np.float64(dt),
+               Slice=Inpts[0].numpy().astype(np.float32), Mask=Masks[0].numpy().astype(np.uint8),
+               lp_times=np.asarray(lp[0][0], dtype=np.float64), lp_stations=np.asarray(lp[1][0], dtype=np.int64),
+               lp_phases=np.asarray(lp[2][0], dtype=np.float64), lp_meta=np.asarray(lp[3][0], dtype=np.float64))
+    if t_win_direct is not None:
+        from oracle import embed_oracle as E
+        P_slice = E.window_pick_slice(P, t0, ind_use, max_t, kernel_sig_t)
+        lp2 = ref_pu.extract_pick_inputs_from_data(P_slice, geom.locs, ind_use, np.array([t0]), max_t, t_win=t_win_direct)
+        out.update(t_win_direct=np.float64(t_win_direct), lp2_times=np.asarray(lp2[0][0], dtype=np.float64),
+                   lp2_stations=np.asarray(lp2[1][0], dtype=np.int64), lp2_phases=np.asarray(lp2[2][0], dtype=np.float64),
+                   lp2_meta=np.asarray(lp2[3][0], dtype=np.float64))
+        assert len(out["lp2_times"]) < len(out["lp_times"])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "picks in window", len(out["lp_times"]), "of", P.shape[0])
+
+
+def main_picks():
+    """`python oracle/make_golden.py --picks`: fixtures `picks_*.npz` of the reference's per-window pick selection."""
+    _import_reference()
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(14, 60, L=90e3, n_query=5, seed=61)
+    rng = np.random.default_rng(63)
+    P = syn.make_picks(geom, 420, seed=62)
+    P[:, 0] = P[:, 0] * 1.5 + 1000.0
+    P[:, 2] = rng.random(P.shape[0])                          # distinct amplitudes / probabilities: lp_meta rows are identifiable
+    P[:, 3] = rng.random(P.shape[0])
+    # duplicates in (station, time) with the other phase label: their order in the output is the caller's order (stable sorts)
+    dup = P[rng.choice(P.shape[0], 25, replace=False)].copy()
+    dup[:, 4] = 1.0 - dup[:, 4]
+    dup[:, 2] += 1.0
+    P = np.concatenate((P, dup), 0)
+    P = P[rng.permutation(P.shape[0])]                        # load_picks returns the pick file's order, not a time order (utils.py:983)
+    ind_use = np.array([0, 2, 3, 5, 6, 7, 9, 10, 12, 13])     # 10 of the 14 stations of the station file
+    run_pick_inputs_case("picks_14x60_a", geom, P, 1004.0, ind_use, kernel_sig_t=3.0, t_win_direct=2.0)
+    run_pick_inputs_case("picks_14x60_b", geom, P, 1010.5, np.arange(14), kernel_sig_t=7.0)      # 2 sigma > t_win = 10: the ball trims
+    P2 = P.copy()
+    P2[:, 0] += 80000.3
+    run_pick_inputs_case("picks_14x60_c", geom, P2, 81001.7, ind_use[::2], kernel_sig_t=3.0)
+
+
 def run_assoc_case(ref, name, geom, win, n_src=4, weights_seed=0, stime=None, pairs=None, zero_phase_columns=False):
     """Golden vector for the 4-output `forward_fixed` (module.py:963-997): source branch + association heads
     (BipartiteGraphReadOutOperator, DataAggregationAssociationPhase, LocalSliceLgCollapse P/S,
@@ -558,6 +617,8 @@ def main_postproc():
 def main():
     if "--postproc" in sys.argv:
         return main_postproc()
+    if "--picks" in sys.argv:
+        return main_picks()
     if "--scaled" in sys.argv:
         return main_scaled()
     if "--embed-sign" in sys.argv:

@@ -1059,6 +1059,56 @@ def test_device_embedding_with_sign_input_matches_reference(name):
     assert float((S0.abs() - Slice.abs()).abs().max()) == 0.0 and float(S0.min()) >= 0.0
 
 
+@pytest.mark.parametrize("builder", ["cartesian", "subgraph_lists", "subgraph_positions"])
+def test_sign_input_flag_reaches_every_context_builder(builder):
+    """a model built with `use_sign_input=True` must hand the flag to the HIP context whichever `set_adjacencies*`
+    form built it (the Cartesian one, the `use_subgraph` one from product edge lists, the device builder from positions): the
+    embedding of the MODULE's context equals embed_oracle.extract_input_from_data(..., use_sign_input=True) on that graph's product
+    nodes (process_utils.py:610-614), and carries negative features."""
+    import os
+    from oracle import embed_oracle as E
+    from tests.util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "embed_sign_14x60_a.npz"))
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t0, max_t, sig, dt = float(z["t0"]), float(z["max_t"]), float(z["kernel_sig_t"]), float(z["dt"])
+    geom = synthetic.Geometry(S, G, L=90e3, n_query=5, seed=61)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV, use_sign_input=True)
+    net.eval()
+    if builder == "cartesian":
+        A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+        pairs = A_src_in_sta.numpy()
+        ea = geom.edge_attr()
+    elif builder == "subgraph_lists":
+        d = np.linalg.norm(geom.x_grid[:, None, :2] - geom.locs[None, :, :2], axis=2)
+        keep = np.zeros(d.shape, dtype=bool)
+        keep[np.arange(G)[:, None], np.argsort(d, axis=1)[:, :5]] = True
+        src_i, sta_i = np.nonzero(keep)
+        pairs = np.stack((sta_i, src_i))
+        A_in_sta, A_in_src, A_src_in_prod = graph.subgraph_product_edges(geom.A_sta_sta, geom.A_src_src, pairs)
+        A_src_in_sta = torch.from_numpy(pairs).long()
+        ea = geom.edge_attr().reshape(G, S, 3)[src_i, sta_i]
+    if builder == "subgraph_positions":
+        _, _, prs = net.set_adjacencies_subgraph_from_positions(t(geom.locs), t(geom.x_grid), max_deg_offset=0.25, k_nearest_pairs=4)
+        pairs = prs.cpu().numpy()
+        assert pairs.shape[1] < S * G
+    else:
+        gea = graph.GraphEdges(x=t(ea), edge_index=A_src_in_prod.to(DEV))
+        net.set_adjacencies(A_in_sta.to(DEV), A_in_src.to(DEV), gea, gea, A_src_in_sta.to(DEV), torch.from_numpy(geom.A_src_src).to(DEV),
+                            None, None, None, None, t(geom.locs), t(geom.x_grid))
+    P = z["P"]
+    sel = (P[:, 0] > t0 - 2.0 * sig) & (P[:, 0] < t0 + max_t + 2.0 * sig)
+    Ps = P[sel]
+    trv = z["trv_times"]
+    Slice, Mask = net._hip.embed_window(torch.from_numpy(Ps[:, 0].copy()).to(DEV), torch.from_numpy(Ps[:, 1].astype(np.int32)).to(DEV),
+                                        torch.from_numpy(Ps[:, 4].astype(np.int32)).to(DEV), t0, max_t, sig, dt,
+                                        t(trv[pairs[1], pairs[0]]))
+    want_S, want_M = E.extract_input_from_data(P, t0, np.arange(S), S, trv, pairs, max_t, sig, dt, use_sign_input=True)
+    assert float((Slice.cpu() - torch.from_numpy(want_S)).abs().max()) <= 1e-6
+    assert torch.equal(Mask.cpu(), torch.from_numpy(want_M))
+    assert int((Slice < -0.5).sum()) > 5
+
+
 @pytest.mark.parametrize("name", ["embed_14x60_a", "embed_14x60_b"])
 def test_device_embedding_matches_reference_and_oracle(name):
     """Pick -> Slice/Mask embedding kernels (f-1) against the reference's extract_input_from_data golden vectors
