@@ -85,6 +85,7 @@ def parse():
                          "then carries the constants of the committed profile)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the live config-3 training-step figure of the default line")
     ap.add_argument("--no-stream", action="store_true", help="skip the live config-5 streaming figure of the default line")
+    ap.add_argument("--no-day-loops", action="store_true", help="skip the refine / association loop figures of the default line")
     ap.add_argument("--no-cfg4-one-gpu", action="store_true",
                     help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
                          "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
@@ -216,6 +217,101 @@ def cpu_baseline(net, geom, win, n_timed=3):
     finally:
         torch.set_num_threads(nthreads)
     return y, x, float(np.median(times)), times, t1 * (G / float(Gs)), Gs
+
+
+SPARSE_PICKS = 5000     # picks of the parity window whose masks gate (the headline window of 50 000 picks saturates Mask: mean 0.999997)
+
+
+def sparse_window(geom, n_picks=SPARSE_PICKS, seed=9):
+    """A window of the same shape with FEW picks (default 5 000 on 200 stations), so that a large fraction of the product nodes has an
+    all-zero `Mask` row and the `mask.max(1)` gate of Bipartite_ReadIn (module.py:226-229) and the mask inputs of DataAggregation really
+    select: the parity check VERDICT round 4 asked for next to the saturated headline window."""
+    return synthetic.make_window(geom, n_picks, seed=seed, window=7)
+
+
+def sparse_window_parity(net, geom, locs, xg, xq, tq, dev):
+    """max |HIP - oracle| on `sparse_window` (one oracle run on the host cores, reference formulation)."""
+    from oracle import genie_oracle as O
+    win = sparse_window(geom)
+    w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    S, G = geom.n_sta, geom.n_grid
+    A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    with torch.no_grad():
+        yc, xc = O.forward_fixed_source(w, torch.from_numpy(win["Slice"]), torch.from_numpy(win["Mask"]), A_in_sta, A_in_src,
+                                        torch.from_numpy(geom.edge_attr()), A_src_in_prod, torch.from_numpy(geom.A_src_src),
+                                        torch.from_numpy(geom.x_grid).float(), torch.from_numpy(geom.x_query).float(),
+                                        torch.from_numpy(geom.t_query).float())
+        yg, xg_ = net.forward_fixed_source(torch.from_numpy(win["Slice"]).to(dev), torch.from_numpy(win["Mask"]).to(dev), None, None, None,
+                                           locs, xg, xq, tq)
+    M = win["Mask"]
+    return {"n_picks": int(win["n_picks"]), "mask_mean": round(float(M.mean()), 4), "all_zero_mask_rows": round(float((M.max(1) == 0).mean()), 4),
+            "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xg_.cpu() - xc).abs().max()),
+            "max_abs_y": float(yc.abs().max())}
+
+
+def day_loops_leg(net, geom, dev, n_sources=8, n_rand_query=112000):
+    """The two other per-day loops of the caller on the config-2 shape (genie_amd/apply.py): the refine pass (process_continuous_days.py:926-980:
+    per candidate source one window embedded on the device, forward_fixed_source read out at a cloud of 112 000 random queries,
+    process_config.yaml:25, argmax) and the association pass (:1020-1065: per refined source a 4-output forward_fixed with the window's
+    pick lists). A synthetic hour of picks (250 picks / station / day + a few events), 8 candidate sources. Wall clock, synchronised."""
+    from genie_amd import apply
+    S, G = geom.n_sta, geom.n_grid
+    rng = np.random.default_rng(11)
+    n_bg = int(250 * S / 24)
+    P = np.stack([rng.uniform(0.0, 3600.0, n_bg), rng.integers(0, S, n_bg).astype(np.float64), np.ones(n_bg), np.ones(n_bg),
+                  rng.integers(0, 2, n_bg).astype(np.float64)], axis=1)
+    trv = geom.travel_times().astype(np.float32)
+    max_t = float(np.ceil(trv.max() + 1.0))
+    nodes = rng.choice(G, n_sources, replace=False)
+    t_org = np.sort(rng.uniform(300.0, 3300.0, n_sources))
+    ev = []
+    for g, t0 in zip(nodes, t_org):
+        for ph in (0, 1):
+            keep = rng.random(S) < 0.8
+            tt = t0 + trv[g, keep, ph] + rng.normal(0.0, 0.1, int(keep.sum()))
+            ev.append(np.stack([tt, np.nonzero(keep)[0].astype(np.float64), np.ones_like(tt), np.ones_like(tt), np.full_like(tt, ph)], axis=1))
+    P = np.concatenate([P] + ev, axis=0)
+    P = P[rng.permutation(P.shape[0])]
+    sig = synthetic.KERNEL_SIG_T
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).float().to(dev)
+    A_edges_p, A_edges_s, dt_partition = graph.time_pointers(trv, max_t=max_t, dt=sig / 5.0, k=10, win=2.0 * sig)
+    net.A_edges_p, net.A_edges_s = torch.from_numpy(A_edges_p).to(dev), torch.from_numpy(A_edges_s).to(dev)
+    net.dt_partition, net.tlatent = t(dt_partition), t(trv.reshape(-1, 2))
+    picks = apply.ResidentPicks(P, np.arange(S), S, dev)
+    leg = apply.GridLeg(net, geom.x_grid, trv)
+    srcs = np.concatenate((geom.x_grid[nodes] + rng.normal(0.0, 2000.0, (n_sources, 3)), (t_org + rng.normal(0.0, 0.5, n_sources)).reshape(-1, 1),
+                           np.full((n_sources, 1), 0.5)), axis=1)
+    ident = lambda x: x
+    L = geom.L
+    kw = dict(kernel_sig_t=sig, dt_embed=0.3)
+    refine = lambda: apply.refine_sources([leg], picks, srcs, geom.locs, geom.t_query, max_t, np.array([[-15e3, -15e3, -7.5e3]]),
+                                          np.array([[30e3, 30e3, 15e3]]), n_rand_query, ident, ident, (0.0, L), (0.0, L), (-40e3, 2e3),
+                                          rand=np.random.RandomState(3).rand, **kw)
+    refine()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    refined, _ = refine()
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    d = np.linalg.norm(refined[:, None, 0:3] - geom.locs[None, :, :], axis=2)
+    trv_out_srcs = np.stack((d / synthetic.VP, d / synthetic.VS), axis=2).astype(np.float32)
+    assoc = lambda: apply.associate_sources([leg], picks, refined, geom.locs, geom.t_query, max_t, trv_out_srcs, ident,
+                                            np.array([0.0, 0.0, 0.0]), **kw)
+    assoc()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Out_p, Out_s, Save_picks, _ = assoc()
+    torch.cuda.synchronize()
+    t_as = time.perf_counter() - t0
+    n_assoc = int(sum(int(((p > 0.1) | (s_ > 0.1)).sum()) for p, s_ in zip(Out_p, Out_s)))
+    return {"config": "synthetic hour on the config-2 shape: %d picks, %d candidate sources" % (P.shape[0], n_sources),
+            "refine_ms_per_source": round(t_ref / n_sources * 1e3, 3), "refine_queries_per_source": n_rand_query,
+            "refine_max_value": round(float(refined[:, 4].max()), 4),
+            "association_ms_per_source": round(t_as / n_sources * 1e3, 3), "picks_per_window": round(float(np.mean([len(x) for x in Save_picks])), 1),
+            "picks_above_0.1": n_assoc,
+            "note": "refine: device embedding + kNN of the query cloud (genie_knn) + forward_fixed_source + argmax per source, one host copy at the "
+                    "end; association: device embedding + pick lists (ResidentPicks.pick_inputs) + forward_fixed per source; Out_p_save / "
+                    "Out_s_save stay on the device"}
 
 
 def main_stream(a, geom, nq, rank, world, dev, dist, emit=True):
@@ -487,6 +583,59 @@ def cpu_train_baseline(geom, win, lbl, lbl_q, frac=10):
     return times[-1] * (G / float(Gs)), Gs, times[-1]
 
 
+def rebuild_leg(net, opt, geom, n_picks, dev, n_samples=3, reps=3):
+    """The 4-output training step in the reference's call convention, `mz(*input_tensors)` with the graphs passed per call
+    (train_GENIE_model.py:1786), over `n_samples` samples that each bring ANOTHER station subset, source grid and set of product edge
+    lists [2, P ks] / [2, P kp] (int64, resident on the GPU as `torch.Tensor(...).to(device)` leaves them, :1722-1783): every step
+    verifies the lists (genie_product_check), orders the new grid, rebuilds the HIP context and its tables. Timed against the same
+    samples called twice in a row (second call: same tensors, the context is reused). Wall clock around synchronised steps."""
+    from genie_amd import train as gtrain
+    S, G = geom.n_sta, geom.n_grid
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).float().to(dev)
+    samples = []
+    for i in range(n_samples):
+        g = synthetic.Geometry(S - i, G, L=geom.L, n_query=geom.x_query.shape[0], seed=40 + i)
+        smp = synthetic.training_sample(g, min(n_picks, 4000), n_src=4, seed=50 + i, window=0)
+        A1, A2, A3, A4 = graph.cartesian_product_edges(g.A_sta_sta, g.A_src_src, g.n_sta, G, device=dev)
+        ea = graph.GraphEdges(x=t(g.edge_attr()), edge_index=A3)
+        eaf = graph.GraphEdges(x=ea.x, edge_index=A3.flip(0).contiguous())
+        args = (t(smp["Slice"]), t(smp["Mask"]), A1, A2, ea, eaf, A4, torch.from_numpy(g.A_src_src).to(dev), t(smp["A_edges_p"]).long(),
+                t(smp["A_edges_s"]).long(), t(smp["dt_partition"]), t(smp["tlatent"]), t(smp["tpick"]), t(smp["ipick"]).long(),
+                t(smp["phase_label"]), t(g.locs), t(g.x_grid), t(g.x_query), t(smp["x_query_src"]), t(g.t_query), t(smp["tq_sample"]),
+                t(smp["trv_out_q"]))
+        samples.append((args, (t(smp["Lbls"]), t(smp["Lbls_query"]), t(smp["pick_lbls"]))))
+
+    def step(k):
+        args, lab = samples[k]
+        opt.zero_grad(set_to_none=True)
+        loss = gtrain.reference_loss(net(*args), lab, 1)
+        loss.backward()
+        opt.step()
+
+    for k in range(n_samples):          # warm-up: allocator size classes, the library's memory pool, kernels
+        step(k)
+        step(k)
+    fresh, again = [], []
+    for _ in range(reps):
+        for k in range(n_samples):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(k)                      # another sample than the previous step: new graph
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(k)                      # the same tensors again: context reused
+            torch.cuda.synchronize()
+            fresh.append((t1 - t0) * 1e3)
+            again.append((time.perf_counter() - t1) * 1e3)
+    f, g2 = float(np.median(fresh)), float(np.median(again))
+    net.invalidate_graph_cache()
+    return {"step_with_rebuild_ms": round(f, 3), "step_same_graph_ms": round(g2, 3), "rebuild_ms": round(f - g2, 3),
+            "samples": n_samples, "stations": [S - i for i in range(n_samples)], "n_grid": G,
+            "product_edges_per_sample": int(samples[0][0][2].shape[1] + samples[0][0][3].shape[1]),
+            "note": "median over %d steps each; rebuild = Cartesian check of the int64 product edge lists on the device (genie_product_check), base "
+                    "tables, space-filling-curve orders on the device, context + tables from the library's memory pool" % (reps * n_samples)}
+
+
 def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     """BASELINE config 3: the training step on the config-2 shape. One step = forward_fixed_source in train() mode (the whole
     path in HIP in both directions, module._PathTrain) + the y / x terms of the reference's weighted MSE (train_GENIE_model.py:1789)
@@ -593,6 +742,14 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                         "StationSourceAttentionMergedPhases; PyTorch: the loss, Adam, index plumbing"}
     except Exception as e:
         four = {"error": repr(e)[:200]}
+    # ---- the reference's call convention: `mz(*input_tensors)` with NEW graphs per sample (train_GENIE_model.py:1722-1786: another
+    # station subset, grid and product edge lists every sample), so `forward` verifies the lists and rebuilds the HIP context per step
+    rebuild = None
+    if four is not None and "error" not in four:
+        try:
+            rebuild = rebuild_leg(net, opt, geom, n_picks, dev)
+        except Exception as e:
+            rebuild = {"error": repr(e)[:200]}
     flops = TRAIN_FLOP_FACTOR * (FLOP_NODE * P)
     tf = flops / (ms * 1e-3) / 1e12 * 1.0
     out = {
@@ -611,6 +768,11 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                      "hbm_view": {"alg_bytes_per_step": 3.0 * (1532.0 * P + 816.0 * G),
                                   "frac_of_hbm_peak": round(3.0 * (1532.0 * P + 816.0 * G) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
         "four_output_step": four,
+        "four_output_step_new_graph_per_sample": rebuild,
+        "loss_curve_parity": "asserted against the oracle's autograd + Adam (1e-7 relative over 20-24 steps) at 7 x 45, 20 x 500 and 200 x 300, "
+                             "every parameter gradient at 33 x 257 and 200 x 1500 (tests/test_train_gpu.py, tests/test_hip_parity.py); at this "
+                             "size (200 x 10 000: the oracle's autograd needs minutes per step) the tests assert finite, decreasing, "
+                             "bitwise-reproducible steps only",
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline and emit:
         c_full, gs, c_s = cpu_train_baseline(geom, wins[0], lbl, lbl_q)
@@ -771,20 +933,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import contextlib
+    def literal(i):
+        # THE call of the metric: forward_fixed_source(Slice, Mask, tpick, ipick, phase_label, locs, x_grid, x_query, t_query) of the
+        # reference's signature (module.py:999), one call per window on the current stream, both read-outs included
+        k = i % a.windows
+        return net.forward_fixed_source(dS[k], dM[k], None, None, None, locs, xg, xq, tq)
+
     with torch.no_grad():
-        for i in range(a.settle):       # set-up (clock settle), not part of the W warm-up or the K timed steps
-            step(i)
-        drain()
-        torch.cuda.synchronize()
+        for i in range(a.settle):       # clock settle: untimed windows, counted in `warmup` below
+            literal(i)
         for i in range(a.warmup):
-            step(i)
-        drain()
+            literal(i)
         barrier()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            step(i)
-        drain()
+            literal(i)
         barrier()
         dt = time.perf_counter() - t0
     if dist is not None:
@@ -795,19 +958,23 @@ def main():
     windows_per_s = world * a.steps / dt
     value = windows_per_s * n_picks
 
-    # ---- the literal drop-in call: forward_fixed_source(...) of the reference's signature, one call per window on ONE stream
-    # (path + both read-outs per call, no batching of tails across windows), HIP events around a run of calls
-    with torch.no_grad():
-        for i in range(10):
-            net.forward_fixed_source(dS[i % a.windows], dM[i % a.windows], None, None, None, locs, xg, xq, tq)
-        nd = max(20, min(a.steps, 100))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(nd):
-            net.forward_fixed_source(dS[i % a.windows], dM[i % a.windows], None, None, None, locs, xg, xq, tq)
-        e1.record()
-        torch.cuda.synchronize()
-    drop_in_ms = e0.elapsed_time(e1) / nd
+    # ---- the apply loop's window pipeline over independent windows (push_window / flush_windows: P-sized kernels per window on the
+    # main stream, G-sized tails of `tail_batch` windows per set of launches on side streams): an extra, not the headline
+    pipe_ms = None
+    if not a.no_pipeline:
+        npipe = max(a.steps, 160)
+        with torch.no_grad():
+            for i in range(64):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(npipe):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            pipe_ms = (time.perf_counter() - t0) / npipe * 1e3
+    drop_in_ms = ms_per_step
 
     # ---- dominant-kernel timing with HIP events on the launch stream (staged API = same kernels) ----
     hp = net._hip
@@ -855,31 +1022,39 @@ def main():
     kern["k_stage1"]["executed_f16"] = {"tflops": round(exec_tf, 1), "peak": F16_MFMA_PEAK_TF, "frac": round(exec_tf / F16_MFMA_PEAK_TF, 4),
                                          "note": "fp32 operands as two fp16 pieces, three partial products per product, fp32 accumulation"}
     kern["k_stage2"]["kernels"] = "k_stage2_h2u"
+    fused_bytes = (B_NODE["k_stage1"] + B_NODE["k_stage2"]) * P + 816.0 * G
     roofline = {"bound": "hbm", "kernel": "path (B_alg = 1532 P + 816 G bytes per window, SURVEY.md 8d)",
                 "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
                 "traffic": None, "hbm_real_frac": None,
+                # the same window time against the bytes the FUSED design itself has to move (616 B per product node: h0 / h1 / u / v never
+                # leave the registers) -- the design's own HBM floor, far below `frac`, which prices the reference dataflow's bytes
+                "fused_bytes_per_window": fused_bytes,
+                "fused_bytes_frac": round(fused_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipelined_frac": round(b_alg / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pipe_ms else None,
                 "traffic_source": "not measured in this run (rocprofv3 unavailable, --no-live-traffic, or the bench is itself being profiled)",
                 "alg_bytes_per_window": b_alg, "kernels": kern, "single_stream_path_ms": round(kms["path"], 4),
                 "fp32_tflops": round(FLOP_NODE * P * (windows_per_s / world) / 1e12, 2)}
 
     out = {
         "metric": "picks/sec through GCN_Detection_Network_extended.forward_fixed_source (GCS_Network.forward)",
-        "value": round(value, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 1), "unit": "picks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup + a.settle,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "dtype_detail": prec_detail,
-        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source, graphs preset, inputs "
-                               "resident in HBM; independent windows as in the apply loop (P-sized kernels per window, G-sized tail "
-                               "and read-outs of %d windows per set of launches); steady state after %d untimed clock-settle windows"
-                               % (a.config, S, G, n_picks, 1 if a.no_pipeline else tail_batch, a.settle),
-                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq, "settle_windows": a.settle,
+        "warmup_requested": a.warmup, "settle_windows": a.settle,
+        "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window; one step = ONE literal call forward_fixed_source(Slice, "
+                               "Mask, tpick, ipick, phase_label, locs, x_grid, x_query, t_query) of the reference's signature on one stream, both "
+                               "read-outs included, graphs preset, inputs resident in HBM; %d untimed calls before the timed ones (%d requested "
+                               "warm-up + %d clock-settle windows)"
+                               % (a.config, S, G, n_picks, a.warmup + a.settle, a.warmup, a.settle),
+                   "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "window-parallel replicas x%d" % world if world > 1 else "single GPU"},
-        "windows_per_s": round(windows_per_s, 2), "pipelined_windows": not a.no_pipeline, "tail_batch": 1 if a.no_pipeline else tail_batch,
+        "windows_per_s": round(windows_per_s, 2),
+        "pipelined_windows_ms": round(pipe_ms, 4) if pipe_ms else None, "tail_batch": 1 if a.no_pipeline else tail_batch,
+        "pipelined_windows_note": "the apply loop's form over independent windows (push_window / flush_windows: P-sized kernels per window, G-sized "
+                                  "tails and read-outs of %d windows per set of launches on side streams; bit-identical results): an extra, `value` "
+                                  "is the literal call" % tail_batch,
         "drop_in_call_ms": round(drop_in_ms, 4),
-        "drop_in_call_note": "forward_fixed_source(Slice, Mask, ..., x_query, t_query) of the reference's signature, one call per window on one "
-                             "stream incl. both read-outs (HIP events over %d calls); `value` times the apply loop's window pipeline instead "
-                             "(push_window / flush_windows: tails of %d windows per set of launches on side streams)" % (nd, tail_batch),
-        "drop_in_call_roofline_frac": round(b_alg / (drop_in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_live_traffic:
@@ -889,6 +1064,7 @@ def main():
             # the same window time against the bytes the kernels REALLY move: the fused kernels keep h0 / h1 / u / v in registers,
             # so this is far below `frac` (which prices the reference dataflow's bytes); neither P-sized kernel is HBM-bound
             roofline["hbm_real_frac"] = round(roofline["traffic"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["traffic_over_fused_bytes"] = round(roofline["traffic"] / fused_bytes, 3)
             roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/stage_profile.py "
                                           "(same kernels, same workload), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch of the P-sized kernels")
             for k in ("k_stage1", "k_stage2"):
@@ -921,7 +1097,9 @@ def main():
             o3 = main_train(a3, geom, n_picks, nq, 0, 1, dev, None, emit=False)
             out["training_step_config3"] = {"config": o3["config"]["workload"], "steps": a3.steps, "ms_per_step": o3["ms_per_step"],
                                             "value": o3["value"], "unit": "picks/s", "roofline_frac_fp32_mfma": o3["roofline"]["frac"],
-                                            "phase_ms": o3["roofline"]["phase_ms"], "four_output_step": o3["four_output_step"]}
+                                            "phase_ms": o3["roofline"]["phase_ms"], "four_output_step": o3["four_output_step"],
+                                            "four_output_step_new_graph_per_sample": o3["four_output_step_new_graph_per_sample"],
+                                            "loss_curve_parity": o3["loss_curve_parity"]}
         except Exception as e:
             out["training_step_config3"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
@@ -938,6 +1116,12 @@ def main():
         except Exception as e:
             out["streaming_config5"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_day_loops:
+        try:
+            out["day_loops_config2"] = day_loops_leg(net, geom, dev)
+        except Exception as e:
+            out["day_loops_config2"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         yc, xc, cdt, ctimes, c1, gs = cpu_baseline(net, geom, wins[0], a.cpu_windows)
         with torch.no_grad():
@@ -953,6 +1137,8 @@ def main():
                                         "timed run, scaled x%.1f (linear in product nodes): %.1f s per full window"
                                         % (gs, G, G / float(gs), c1)},
             "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xgq.cpu() - xc).abs().max()),
+            "mask_mean_of_that_window": round(float(wins[0]["Mask"].mean()), 6),
+            "sparse_window": sparse_window_parity(net, geom, locs, xg, xq, tq, dev),
             "note": "`cores` is the thread count torch was given, not a scaling claim: the oracle's scatter (index_add_) is serial, so the "
                     "all-thread and the single-thread time per window are about equal on every box seen",
         }

@@ -23,7 +23,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
+#include <mutex>
 #include <utility>
 #include <type_traits>
 #include <string>
@@ -86,6 +88,84 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                      \
             return fail(GENIE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device-memory pool of the library's own allocations (graph tables, weight images, plan tables).
+// The reference's training loop hands `forward` a new graph per sample (train_GENIE_model.py:1722-1786), so a context is destroyed
+// and created per sample: ~100 hipMalloc / hipFree pairs through the driver (each hipFree also drains the device) were most of
+// that cost. Freed blocks are kept per device and size class (sizes rounded up to 1/8-octave steps, so a context of 199 stations
+// reuses the blocks of one of 200) and handed out again; above POOL_CAP cached bytes a freed block goes back to the driver.
+// Blocks are reused without an implicit device synchronisation: gfree_sync() (one hipDeviceSynchronize, then gfree) where work
+// that may still read the block can be in flight; genie_ctx_destroy synchronises once for all of its blocks.
+// ------------------------------------------------------------------------------------------------
+struct DevPool {
+    std::multimap<size_t, void*> free_;
+    std::map<void*, size_t> size_;
+    size_t cached = 0;
+};
+std::map<int, DevPool> g_pools;
+std::mutex g_pool_mutex;
+constexpr size_t POOL_CAP = (size_t)3 << 30;
+
+size_t pool_class(size_t n) {
+    if (n < 256) return 256;
+    int sh = 0;
+    while ((n >> sh) >= 16) ++sh;                 // n = m * 2^sh with 8 <= m < 16
+    const size_t step = (size_t)1 << sh;
+    return (n + step - 1) / step * step;
+}
+
+hipError_t gmalloc(void** p, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t cls = pool_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        DevPool& P = g_pools[dev];
+        auto it = P.free_.find(cls);
+        if (it != P.free_.end()) {
+            *p = it->second;
+            P.cached -= cls;
+            P.free_.erase(it);
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess) {          // give the cache back to the driver and try once more
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        DevPool& P = g_pools[dev];
+        (void)hipDeviceSynchronize();
+        for (auto& kv : P.free_) { P.size_.erase(kv.second); (void)hipFree(kv.second); }
+        P.free_.clear(); P.cached = 0;
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    g_pools[dev].size_[*p] = cls;
+    return hipSuccess;
+}
+template <typename T> hipError_t gmalloc(T** p, size_t bytes) { return gmalloc((void**)p, bytes); }
+
+hipError_t gfree(void* p) {         // the caller guarantees that no launched work still uses the block
+    if (!p) return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevPool& P = g_pools[dev];
+    auto it = P.size_.find(p);
+    if (it == P.size_.end()) return hipFree(p);
+    if (P.cached + it->second > POOL_CAP) { P.size_.erase(it); return hipFree(p); }
+    P.free_.emplace(it->second, p);
+    P.cached += it->second;
+    return hipSuccess;
+}
+
+hipError_t gfree_sync(void* p) {
+    if (!p) return hipSuccess;
+    (void)hipDeviceSynchronize();
+    return gfree(p);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Weight registry: the path's parameters under the reference's state_dict names.
@@ -1271,6 +1351,7 @@ struct genie_ctx {
     int32_t* d_s2htbl;         // k_pack_h2 source table of k_stage2_h2's image
     float* packed_s2h;         // f16x2 weight image of k_stage2_h2 (Bipartite_ReadIn.fc1)
     unsigned *ea_frag, *ea_frag_tmp;    // edge_attr as B fragments of k_stage2_h2 (k_ea_frag): of the registered static edge_attr / of any other one
+    bool tables_shared = false;   // the graph-independent tables below belong to the device's template context (model_tables): not freed here
     bool ws_np;                // layout of the c / wv rows the last stage 1 left in the workspace: node-planar (DaArgs.np) or rows
     std::vector<const void*> lds_attr_done;   // kernels whose MaxDynamicSharedMemorySize was raised for THIS context's device (the attribute
                                // is per device: a process-wide flag would skip the second GPU of a multi-GPU process)
@@ -1375,7 +1456,7 @@ template <typename T>
 int dev_copy(T** dst, const T* src_dev, size_t n) {
     *dst = nullptr;
     if (n == 0) n = 1;
-    HIP_TRY(hipMalloc((void**)dst, n * sizeof(T)));
+    HIP_TRY(gmalloc((void**)dst, n * sizeof(T)));
     if (src_dev) HIP_TRY(hipMemcpy(*dst, src_dev, n * sizeof(T), hipMemcpyDeviceToDevice));
     return GENIE_OK;
 }
@@ -1391,7 +1472,7 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
             pl[s].n_groups = p.n_groups(); pl[s].n_bias = (int)p.bias.size(); pl[s].n_scal = (int)p.scal.size(); pl[s].block0 = blocks;
             blocks += (p.packed_floats() + 255) / 256;
         }
-        HIP_TRY(hipMalloc(&c->d_packplans, sizeof(PackPlan) * NPLAN));
+        HIP_TRY(gmalloc(&c->d_packplans, sizeof(PackPlan) * NPLAN));
         HIP_TRY(hipMemcpy(c->d_packplans, pl.data(), sizeof(PackPlan) * NPLAN, hipMemcpyHostToDevice));
         c->pack_blocks = blocks;
     }
@@ -1406,7 +1487,7 @@ int ensure_packed(genie_ctx* c, hipStream_t st) {
         k_edge_bias<<<(unsigned)((ng * 48 + 255) / 256), 256, 0, st>>>(c->raw, g_params[W_DA_L1T22_P].off, g_params[W_DA_L2T22_P].off,
                                                                       c->mpos_src, (int)ng, c->ebias_src);
         if (c->sta_perm) {
-            if (!c->ebias_sta_p) HIP_TRY(hipMalloc((void**)&c->ebias_sta_p, sizeof(float) * 48 * (size_t)c->S));
+            if (!c->ebias_sta_p) HIP_TRY(gmalloc((void**)&c->ebias_sta_p, sizeof(float) * 48 * (size_t)c->S));
             k_permute_sta_rows<<<(c->S * 48 + 255) / 256, 256, 0, st>>>(c->ebias_sta, c->S, 48, c->sta_inv, c->S, c->ebias_sta_p);
         }
     }
@@ -1549,11 +1630,11 @@ int build_grad_maps(genie_ctx* c) {
         if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s])
             return fail(GENIE_ERR_STATE, "internal: gradient maps do not match the backward kernels");
         c->n_acc[s] = (int)acc[s].size(); c->n_vec[s] = (int)vec[s].size(); c->n_sc[s] = (int)sc[s].size();
-        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * acc[s].size()));
+        HIP_TRY(gmalloc((void**)&c->d_acc[s], sizeof(AccDesc) * acc[s].size()));
         HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * vec[s].size()));
+        HIP_TRY(gmalloc((void**)&c->d_vec[s], sizeof(VecDesc) * vec[s].size()));
         HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * sc[s].size()));
+        HIP_TRY(gmalloc((void**)&c->d_sc[s], sizeof(int32_t) * sc[s].size()));
         HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
     }
     return GENIE_OK;
@@ -1856,11 +1937,11 @@ int build_tail_grad_maps(genie_ctx* c) {
         if ((int)acc[s].size() != want_acc[s] || (int)vec[s].size() != want_vec[s] || sc[s].size() > 16)
             return fail(GENIE_ERR_STATE, "internal: tail gradient maps do not match the backward kernels");
         c->n_acc[s] = (int)acc[s].size(); c->n_vec[s] = (int)vec[s].size(); c->n_sc[s] = (int)sc[s].size();
-        HIP_TRY(hipMalloc((void**)&c->d_acc[s], sizeof(AccDesc) * std::max<size_t>(1, acc[s].size())));
+        HIP_TRY(gmalloc((void**)&c->d_acc[s], sizeof(AccDesc) * std::max<size_t>(1, acc[s].size())));
         if (!acc[s].empty()) HIP_TRY(hipMemcpy(c->d_acc[s], acc[s].data(), sizeof(AccDesc) * acc[s].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_vec[s], sizeof(VecDesc) * std::max<size_t>(1, vec[s].size())));
+        HIP_TRY(gmalloc((void**)&c->d_vec[s], sizeof(VecDesc) * std::max<size_t>(1, vec[s].size())));
         if (!vec[s].empty()) HIP_TRY(hipMemcpy(c->d_vec[s], vec[s].data(), sizeof(VecDesc) * vec[s].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_sc[s], sizeof(int32_t) * std::max<size_t>(1, sc[s].size())));
+        HIP_TRY(gmalloc((void**)&c->d_sc[s], sizeof(int32_t) * std::max<size_t>(1, sc[s].size())));
         if (!sc[s].empty()) HIP_TRY(hipMemcpy(c->d_sc[s], sc[s].data(), sizeof(int32_t) * sc[s].size(), hipMemcpyHostToDevice));
     }
     return GENIE_OK;
@@ -1881,6 +1962,76 @@ int check_ws(const genie_ctx* c, const void* ws) {
     return GENIE_OK;
 }
 
+}  // namespace
+
+
+namespace {
+// The tables of a context that do not depend on its graph or its weights -- the stage plans (host), their step / bias / scalar descriptors,
+// the gradient maps of the backward passes and the source tables of the f16x2 weight images (device) -- are built ONCE per device and
+// process on a template context that is never destroyed; every context points at them (`tables_shared`). Building them per context was
+// ~45 blocking host-to-device copies = most of the 2.4 ms genie_ctx_create cost per training sample (train_GENIE_model.py:1722-1786).
+int init_model_tables(genie_ctx* c) {
+    build_plans(c->plan[0], c->plan[1]);
+    build_assoc_plans(c->plan[2], c->plan[3]);
+    build_train_plans(c->plan[4], c->plan[5], c->plan[6]);
+    build_tail_plans(c->plan);
+    build_tail_train_plans(c->plan);
+    if (c->plan[PL_TRO0].n_groups() != GTR_GROUPS || c->plan[PL_TRO1].n_groups() != GTR_GROUPS || c->plan[PL_TSN].n_groups() != GTN_GROUPS ||
+        c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS ||
+        c->plan[PL_TAB2].n_groups() != GT1_GROUPS || c->plan[PL_TAB1].n_groups() != GA1_GROUPS || c->plan[PL_TAB0].n_groups() != GA0_GROUPS ||
+        c->plan[PL_TAG].n_groups() != GAG_GROUPS || c->plan[PL_TLSP].n_groups() != GLT_GROUPS || c->plan[PL_TLSS].n_groups() != GLT_GROUPS ||
+        c->plan[PL_TARR].n_groups() != GTA_GROUPS)
+        return fail(GENIE_ERR_STATE, "internal: transposed tail plan does not match kernel group maps");
+    if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
+        (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
+        c->plan[PL_SA1].n_groups() != GS_GROUPS || c->plan[PL_SA2].n_groups() != GS_GROUPS || c->plan[PL_SA3].n_groups() != GS_GROUPS ||
+        (int)c->plan[PL_SA1].bias.size() != GS_BIAS || (int)c->plan[PL_SA3].bias.size() != GS_BIAS || c->plan[PL_BIP].n_groups() != GB_GROUPS2)
+        return fail(GENIE_ERR_STATE, "internal: tail plan does not match kernel group maps");
+    if (c->plan[4].n_groups() != GT2_GROUPS || c->plan[5].n_groups() != GT1_GROUPS || c->plan[6].n_groups() != GT0_GROUPS)
+        return fail(GENIE_ERR_STATE, "internal: backward plan does not match kernel group maps");
+    { int rc_tr; if ((rc_tr = build_grad_maps(c))) return rc_tr; if ((rc_tr = build_tail_grad_maps(c))) return rc_tr; }
+    if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
+        (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS ||
+        c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
+        (int)c->plan[2].bias.size() != GA_BIAS || (int)c->plan[3].bias.size() != GB_BIAS)
+        return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
+    for (int s = 0; s < NPLAN; ++s) {
+        const StagePlan& p = c->plan[s];
+        HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
+        HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_bias[s], sizeof(BiasDesc) * std::max<size_t>(1, p.bias.size())));
+        if (!p.bias.empty()) HIP_TRY(hipMemcpy(c->d_bias[s], p.bias.data(), sizeof(BiasDesc) * p.bias.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->d_scal[s], sizeof(int32_t) * 16));
+        HIP_TRY(hipMemcpy(c->d_scal[s], p.scal.data(), sizeof(int32_t) * p.scal.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<int32_t> tbl;
+        build_h2_table(tbl);
+        HIP_TRY(hipMalloc((void**)&c->d_h2tbl, sizeof(int32_t) * tbl.size()));
+        HIP_TRY(hipMemcpy(c->d_h2tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
+        build_s2h_table(tbl);
+        HIP_TRY(hipMalloc((void**)&c->d_s2htbl, sizeof(int32_t) * tbl.size()));
+        HIP_TRY(hipMemcpy(c->d_s2htbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
+    }
+    return GENIE_OK;
+}
+
+int model_tables(genie_ctx** out) {
+    static std::map<int, genie_ctx*> tmpl;
+    static std::mutex mu;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tmpl.find(dev);
+    if (it == tmpl.end()) {
+        genie_ctx* t = new genie_ctx();
+        int rc = init_model_tables(t);
+        if (rc) return rc;              // (the half-built template leaks a few KB; the process cannot create contexts anyway)
+        it = tmpl.emplace(dev, t).first;
+    }
+    *out = it->second;
+    return GENIE_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1925,7 +2076,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->ks_uni = uniform(sta_rowptr, n_sta);
         c->kp_uni = uniform(src_rowptr, n_grid);
     }
-    int rc, rc_tr = 0;
+    int rc;
     if ((rc = dev_copy(&c->sta_rowptr, sta_rowptr, (size_t)n_sta + 1))) return rc;
     if ((rc = dev_copy(&c->sta_col, sta_col, (size_t)e_sta))) return rc;
     if ((rc = dev_copy(&c->src_rowptr, src_rowptr, (size_t)n_grid + 1))) return rc;
@@ -1935,61 +2086,32 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     } else {
         std::vector<int32_t> id(n_grid);
         for (int i = 0; i < n_grid; ++i) id[i] = i;
-        HIP_TRY(hipMalloc((void**)&c->order, sizeof(int32_t) * n_grid));
+        HIP_TRY(gmalloc((void**)&c->order, sizeof(int32_t) * n_grid));
         HIP_TRY(hipMemcpy(c->order, id.data(), sizeof(int32_t) * n_grid, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void**)&c->outdeg, sizeof(int32_t) * (size_t)n_grid_ext));
+    HIP_TRY(gmalloc((void**)&c->outdeg, sizeof(int32_t) * (size_t)n_grid_ext));
     HIP_TRY(hipMemset(c->outdeg, 0, sizeof(int32_t) * (size_t)n_grid_ext));
     if (e_src > 0) k_outdeg<<<(e_src + 255) / 256, 256>>>(c->src_col, e_src, c->outdeg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMalloc((void**)&c->raw, sizeof(float) * g_raw_total));
+    HIP_TRY(gmalloc((void**)&c->raw, sizeof(float) * g_raw_total));
     HIP_TRY(hipMemset(c->raw, 0, sizeof(float) * g_raw_total));
-    build_plans(c->plan[0], c->plan[1]);
-    build_assoc_plans(c->plan[2], c->plan[3]);
-    build_train_plans(c->plan[4], c->plan[5], c->plan[6]);
-    build_tail_plans(c->plan);
-    build_tail_train_plans(c->plan);
-    if (c->plan[PL_TRO0].n_groups() != GTR_GROUPS || c->plan[PL_TRO1].n_groups() != GTR_GROUPS || c->plan[PL_TSN].n_groups() != GTN_GROUPS ||
-        c->plan[PL_TSA1].n_groups() != GTS_GROUPS || c->plan[PL_TSA3].n_groups() != GTS_GROUPS || c->plan[PL_TBIP].n_groups() != GTB_GROUPS ||
-        c->plan[PL_TAB2].n_groups() != GT1_GROUPS || c->plan[PL_TAB1].n_groups() != GA1_GROUPS || c->plan[PL_TAB0].n_groups() != GA0_GROUPS ||
-        c->plan[PL_TAG].n_groups() != GAG_GROUPS || c->plan[PL_TLSP].n_groups() != GLT_GROUPS || c->plan[PL_TLSS].n_groups() != GLT_GROUPS ||
-        c->plan[PL_TARR].n_groups() != GTA_GROUPS)
-        return fail(GENIE_ERR_STATE, "internal: transposed tail plan does not match kernel group maps");
-    if (c->plan[PL_RO0].n_groups() != GR_GROUPS || c->plan[PL_RO1].n_groups() != GR_GROUPS || (int)c->plan[PL_RO0].bias.size() != GR_BIAS ||
-        (int)c->plan[PL_RO1].bias.size() != GR_BIAS || c->plan[PL_ROP].n_groups() != GP_GROUPS || (int)c->plan[PL_ROP].bias.size() != GP_BIAS ||
-        c->plan[PL_SA1].n_groups() != GS_GROUPS || c->plan[PL_SA2].n_groups() != GS_GROUPS || c->plan[PL_SA3].n_groups() != GS_GROUPS ||
-        (int)c->plan[PL_SA1].bias.size() != GS_BIAS || (int)c->plan[PL_SA3].bias.size() != GS_BIAS || c->plan[PL_BIP].n_groups() != GB_GROUPS2)
-        return fail(GENIE_ERR_STATE, "internal: tail plan does not match kernel group maps");
-    if (c->plan[4].n_groups() != GT2_GROUPS || c->plan[5].n_groups() != GT1_GROUPS || c->plan[6].n_groups() != GT0_GROUPS)
-        return fail(GENIE_ERR_STATE, "internal: backward plan does not match kernel group maps");
-    if ((rc_tr = build_grad_maps(c))) return rc_tr;
-    if ((rc_tr = build_tail_grad_maps(c))) return rc_tr;
-    if (c->plan[0].n_groups() != G1_GROUPS || c->plan[1].n_groups() != G2_GROUPS ||
-        (int)c->plan[0].bias.size() != G1_BIAS || (int)c->plan[1].bias.size() != G2_BIAS ||
-        c->plan[2].n_groups() != GA_GROUPS || c->plan[3].n_groups() != GB_GROUPS ||
-        (int)c->plan[2].bias.size() != GA_BIAS || (int)c->plan[3].bias.size() != GB_BIAS)
-        return fail(GENIE_ERR_STATE, "internal: stage plan does not match kernel group maps");
-    for (int s = 0; s < NPLAN; ++s) {
-        const StagePlan& p = c->plan[s];
-        HIP_TRY(hipMalloc((void**)&c->d_steps[s], sizeof(StepDesc) * p.steps.size()));
-        HIP_TRY(hipMemcpy(c->d_steps[s], p.steps.data(), sizeof(StepDesc) * p.steps.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_bias[s], sizeof(BiasDesc) * std::max<size_t>(1, p.bias.size())));
-        if (!p.bias.empty()) HIP_TRY(hipMemcpy(c->d_bias[s], p.bias.data(), sizeof(BiasDesc) * p.bias.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->d_scal[s], sizeof(int32_t) * 16));
-        HIP_TRY(hipMemcpy(c->d_scal[s], p.scal.data(), sizeof(int32_t) * p.scal.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->packed[s], sizeof(float) * p.packed_floats()));
-    }
-    {
-        std::vector<int32_t> tbl;
-        build_h2_table(tbl);
-        HIP_TRY(hipMalloc((void**)&c->d_h2tbl, sizeof(int32_t) * tbl.size()));
-        HIP_TRY(hipMemcpy(c->d_h2tbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->packed_h2, sizeof(float) * H2_IMG_FLOATS));
-        build_s2h_table(tbl);
-        HIP_TRY(hipMalloc((void**)&c->d_s2htbl, sizeof(int32_t) * tbl.size()));
-        HIP_TRY(hipMemcpy(c->d_s2htbl, tbl.data(), sizeof(int32_t) * tbl.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->packed_s2h, sizeof(float) * S2H_IMG_FLOATS));
-        HIP_TRY(hipMalloc((void**)&c->d_range, sizeof(float) * (4 + 4 * RG_PART)));
+    {   // graph- and weight-independent tables: shared with the device's template context (model_tables)
+        genie_ctx* tm = nullptr;
+        if ((rc = model_tables(&tm))) return rc;
+        for (int s = 0; s < NPLAN; ++s) {
+            c->plan[s] = tm->plan[s];
+            c->d_steps[s] = tm->d_steps[s]; c->d_bias[s] = tm->d_bias[s]; c->d_scal[s] = tm->d_scal[s];
+            HIP_TRY(gmalloc((void**)&c->packed[s], sizeof(float) * c->plan[s].packed_floats()));
+        }
+        for (int s = 0; s < NTM; ++s) {
+            c->d_acc[s] = tm->d_acc[s]; c->d_vec[s] = tm->d_vec[s]; c->d_sc[s] = tm->d_sc[s];
+            c->n_acc[s] = tm->n_acc[s]; c->n_vec[s] = tm->n_vec[s]; c->n_sc[s] = tm->n_sc[s];
+        }
+        c->d_h2tbl = tm->d_h2tbl; c->d_s2htbl = tm->d_s2htbl;
+        c->tables_shared = true;
+        HIP_TRY(gmalloc((void**)&c->packed_h2, sizeof(float) * H2_IMG_FLOATS));
+        HIP_TRY(gmalloc((void**)&c->packed_s2h, sizeof(float) * S2H_IMG_FLOATS));
+        HIP_TRY(gmalloc((void**)&c->d_range, sizeof(float) * (4 + 4 * RG_PART)));
         HIP_TRY(hipHostMalloc((void**)&c->h_range, sizeof(float) * 4));
         c->range_ok = true; c->prec_mode = 0;
     }
@@ -2015,16 +2137,25 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
             tab[(size_t)gi * 16] = gg;
             for (int k = 0; k < 15; ++k) tab[(size_t)gi * 16 + 1 + k] = col[(size_t)gg * 15 + k];
         }
-        HIP_TRY(hipMalloc((void**)&c->src_tab, sizeof(int32_t) * tab.size()));
+        HIP_TRY(gmalloc((void**)&c->src_tab, sizeof(int32_t) * tab.size()));
         HIP_TRY(hipMemcpy(c->src_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
         c->tab_host = tab;
     }
     c->dirty = true;
     int dev = 0;
-    hipDeviceProp_t prop;
     HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // (hipGetDeviceProperties fills a 1.5-KB struct through the driver: once per device and process)
+        static std::map<int, int> cus;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cus.find(dev);
+        if (it == cus.end()) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            it = cus.emplace(dev, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256).first;
+        }
+        c->num_cu = it->second;
+    }
     {
         const char* e;
         // scheduling segments: node-major sweeps (1) at config 2; at 2000 stations station-tile-major sweeps over segments of 16
@@ -2037,10 +2168,22 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         c->tail_cu_ro = c->num_cu * 2;          // genie_set_tail_grid
         c->tail_cu_sa = c->num_cu * 2;
         // persistent grids: exactly as many workgroups as are co-resident (a larger grid runs in two uneven rounds)
-        int occ1 = 0, occ2 = 0, occo = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, k_stage1, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, k_stage2, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occo, k_stage2_ord<8, 15, false>, 256, 0));
+        int occ1 = 0, occ2 = 0, occo = 0, occh = 0;
+        {   // (four driver queries: once per device and process)
+            static std::map<int, std::array<int, 4>> occ;
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = occ.find(dev);
+            if (it == occ.end()) {
+                std::array<int, 4> o{};
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o[0], k_stage1, 256, 0));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o[1], k_stage2, 256, 0));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o[2], k_stage2_ord<8, 15, false>, 256, 0));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o[3], k_stage2_h2<false, false>, 256, 0));
+                it = occ.emplace(dev, o).first;
+            }
+            occ1 = it->second[0]; occ2 = it->second[1]; occo = it->second[2]; occh = it->second[3];
+        }
         c->bpc1 = std::max(1, occ1);
         c->bpc2 = (e = tune_env("GENIE_BPC2")) ? atoi(e) : std::max(1, occ2);
         // Large station counts (config 4: 2000 stations, 128 KB of wu / wv rows per source node): the gathers leave L2, and what
@@ -2050,8 +2193,6 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         // stations the same settings lose (0.266 -> 0.268 ms), hence by size.
         c->s2_wgmap = (e = tune_env("GENIE_S2_WGMAP")) ? (atoi(e) != 0) : (n_sta >= 1024);
         {
-            int occh = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occh, k_stage2_h2<false, false>, 256, 0));
             // two workgroups per CU: as fast as three (0.2367 / 0.2370 ms) with 8 % less fabric traffic (FETCH_SIZE 5.18e5 vs 5.62e5 KB)
             c->bpc2h = (e = tune_env("GENIE_BPC2")) ? atoi(e) : std::min(2, std::max(1, occh));
             c->s2u_off = tune_env("GENIE_S2_NOUNION") != nullptr;
@@ -2089,12 +2230,12 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
     if (n_prod < 1 || n_prod >= (1ll << 31)) return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: bad n_prod");
     if (!p_sta_rowptr || !p_src_rowptr || !seg_rowptr) return fail(GENIE_ERR_ARG, "genie_ctx_create_subgraph: null rowptr");
     int32_t* zeros = nullptr;       // empty base station graph: the station edges live in the product-level CSR
-    HIP_TRY(hipMalloc((void**)&zeros, sizeof(int32_t) * ((size_t)n_sta + 1)));
+    HIP_TRY(gmalloc((void**)&zeros, sizeof(int32_t) * ((size_t)n_sta + 1)));
     genie_ctx* c = nullptr;
     int rc = hipMemset(zeros, 0, sizeof(int32_t) * ((size_t)n_sta + 1)) == hipSuccess
                  ? genie_ctx_create(&c, n_sta, n_grid, n_grid, zeros, nullptr, src_rowptr, src_col, grid_order, scale_rel)
                  : fail(GENIE_ERR_HIP, "genie_ctx_create_subgraph: hipMemset failed");
-    (void)hipFree(zeros);
+    (void)gfree(zeros);
     if (rc) return rc;
     CtxGuard guard{c};
     int32_t e1 = 0, e2 = 0, last = 0;
@@ -2135,7 +2276,7 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
             for (int i = 0; i < nt; ++i) t[i] = i;
             std::stable_sort(t.begin(), t.end(), [&](int32_t x, int32_t y) { return rank[src_of[(size_t)x * w]] < rank[src_of[(size_t)y * w]]; });
             int32_t** dst = w == 16 ? &c->ptile16 : &c->ptile32;
-            HIP_TRY(hipMalloc((void**)dst, sizeof(int32_t) * (size_t)std::max(nt, 1)));
+            HIP_TRY(gmalloc((void**)dst, sizeof(int32_t) * (size_t)std::max(nt, 1)));
             HIP_TRY(hipMemcpy(*dst, t.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
         }
     }
@@ -2150,7 +2291,8 @@ int genie_ctx_create_subgraph(genie_ctx** out, int n_sta, int n_grid, int64_t n_
 int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_src, void* stream) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_absolute_pos: null context");
     if (!pos_sta || !pos_src) {
-        (void)hipFree(c->abs_sta); (void)hipFree(c->abs_src); (void)hipFree(c->abs_ts); (void)hipFree(c->abs_tg);
+        (void)hipDeviceSynchronize();        // pooled blocks are reused without the driver's implicit drain
+        (void)gfree(c->abs_sta); (void)gfree(c->abs_src); (void)gfree(c->abs_ts); (void)gfree(c->abs_tg);
         c->abs_sta = c->abs_src = nullptr; c->abs_ts = c->abs_tg = nullptr;
         return GENIE_OK;
     }
@@ -2158,8 +2300,8 @@ int genie_set_absolute_pos(genie_ctx* c, const float* pos_sta, const float* pos_
     // tables are per product node: a neighbour (a product-node id) is looked up like the node itself
     const long long ns = c->pcsr ? c->P : c->S, ng = c->pcsr ? c->P : c->G_ext;
     if (!c->abs_sta) {
-        HIP_TRY(hipMalloc((void**)&c->abs_sta, sizeof(float) * 4 * (size_t)ns));
-        HIP_TRY(hipMalloc((void**)&c->abs_src, sizeof(float) * 4 * (size_t)ng));
+        HIP_TRY(gmalloc((void**)&c->abs_sta, sizeof(float) * 4 * (size_t)ns));
+        HIP_TRY(gmalloc((void**)&c->abs_src, sizeof(float) * 4 * (size_t)ng));
     }
     const float inv = 1.f / (3.f * c->scale_rel);
     hipStream_t st = (hipStream_t)stream;
@@ -2182,10 +2324,10 @@ int genie_set_edge_features(genie_ctx* c, const float* pos_sta, const float* pos
     // positions arrive per product node too ([n_prod, 3]: the station's, the source node's)
     const long long ns = edge_rows_sta(c), ng = edge_rows_src(c);
     if (!c->mpos_sta) {
-        HIP_TRY(hipMalloc((void**)&c->mpos_sta, sizeof(float) * 4 * (size_t)ns));
-        HIP_TRY(hipMalloc((void**)&c->mpos_src, sizeof(float) * 4 * (size_t)ng));
-        HIP_TRY(hipMalloc((void**)&c->ebias_sta, sizeof(float) * 48 * (size_t)ns));
-        HIP_TRY(hipMalloc((void**)&c->ebias_src, sizeof(float) * 48 * (size_t)ng));
+        HIP_TRY(gmalloc((void**)&c->mpos_sta, sizeof(float) * 4 * (size_t)ns));
+        HIP_TRY(gmalloc((void**)&c->mpos_src, sizeof(float) * 4 * (size_t)ng));
+        HIP_TRY(gmalloc((void**)&c->ebias_sta, sizeof(float) * 48 * (size_t)ns));
+        HIP_TRY(gmalloc((void**)&c->ebias_src, sizeof(float) * 48 * (size_t)ng));
     }
     if (c->pcsr) {
         k_edge_feat<<<(unsigned)((ns + 255) / 256), 256, 0, st>>>(c->p_sta_rowptr, c->p_sta_col, (int)ns, pos_sta, c->scale_rel, c->mpos_sta);
@@ -2209,7 +2351,10 @@ int genie_set_scale_t(genie_ctx* c, float scale_t) {
 int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_set_station_order: null context");
     void* old[] = {c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ea_int, c->ea_tmp, c->ea_frag, c->ea_frag_tmp};
-    for (void* q : old) (void)hipFree(q);
+    bool any_old = false;
+    for (void* q : old) any_old = any_old || q != nullptr;
+    if (any_old) (void)hipDeviceSynchronize();      // (a first call on a fresh context has nothing in flight and nothing to free)
+    for (void* q : old) (void)gfree(q);
     c->sta_perm = c->sta_inv = c->sta_rowptr_p = c->sta_col_p = nullptr;
     c->ea_int = c->ea_tmp = nullptr; c->ea_user = nullptr; c->ea_frag = c->ea_frag_tmp = nullptr;
     c->xs_slice = c->xs_mask = nullptr; c->xs_ws = nullptr;      // split rows of an embedding made under the previous order are void
@@ -2231,10 +2376,10 @@ int genie_set_station_order(genie_ctx* c, const int32_t* order_host) {
         rpp[(size_t)i + 1] = rpp[i] + (rp[u + 1] - rp[u]);
         for (int e = rp[u]; e < rp[u + 1]; ++e) colp[(size_t)rpp[i] + (e - rp[u])] = inv[col[e]];
     }
-    HIP_TRY(hipMalloc((void**)&c->sta_perm, sizeof(int32_t) * S));
-    HIP_TRY(hipMalloc((void**)&c->sta_inv, sizeof(int32_t) * S));
-    HIP_TRY(hipMalloc((void**)&c->sta_rowptr_p, sizeof(int32_t) * ((size_t)S + 1)));
-    HIP_TRY(hipMalloc((void**)&c->sta_col_p, sizeof(int32_t) * std::max<size_t>(E, 1)));
+    HIP_TRY(gmalloc((void**)&c->sta_perm, sizeof(int32_t) * S));
+    HIP_TRY(gmalloc((void**)&c->sta_inv, sizeof(int32_t) * S));
+    HIP_TRY(gmalloc((void**)&c->sta_rowptr_p, sizeof(int32_t) * ((size_t)S + 1)));
+    HIP_TRY(gmalloc((void**)&c->sta_col_p, sizeof(int32_t) * std::max<size_t>(E, 1)));
     HIP_TRY(hipMemcpy(c->sta_perm, perm.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->sta_inv, inv.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->sta_rowptr_p, rpp.data(), sizeof(int32_t) * rpp.size(), hipMemcpyHostToDevice));
@@ -2248,7 +2393,7 @@ int genie_set_static_edge_attr(genie_ctx* c, const float* edge_attr, void* strea
     if (!edge_attr || !c->sta_perm || c->pcsr) return GENIE_OK;       // nothing to prepare without a station processing order
     if (!c->use_h2) return GENIE_OK;      // only k_stage2_h2 honours the station processing order in stage 2
     // k_stage2_h2 reads the static edge_attr as ready-made B fragments (32 B per product node, processing order)
-    if (!c->ea_frag) HIP_TRY(hipMalloc((void**)&c->ea_frag, 32 * (size_t)c->P));
+    if (!c->ea_frag) HIP_TRY(gmalloc((void**)&c->ea_frag, 32 * (size_t)c->P));
     k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, (hipStream_t)stream>>>(edge_attr, c->P, c->S, c->sta_perm, c->ea_frag);
     HIP_TRY(hipGetLastError());
     c->ea_user = edge_attr;
@@ -2263,9 +2408,15 @@ int genie_set_slot(genie_ctx* c, int slot) {
 
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
-    (void)hipFree(c->d_packplans);
-    for (int s = 7; s < NPLAN; ++s) { (void)hipFree(c->d_steps[s]); (void)hipFree(c->d_bias[s]); (void)hipFree(c->d_scal[s]); (void)hipFree(c->packed[s]); }
-    for (int s = 3; s < NTM; ++s) { (void)hipFree(c->d_acc[s]); (void)hipFree(c->d_vec[s]); (void)hipFree(c->d_sc[s]); }
+    (void)hipDeviceSynchronize();        // one drain for every block below: the pool hands them out again without one
+    (void)gfree(c->d_packplans);
+    if (c->tables_shared) {
+        for (int s = 0; s < NPLAN; ++s) c->d_steps[s] = nullptr, c->d_bias[s] = nullptr, c->d_scal[s] = nullptr;
+        for (int s = 0; s < NTM; ++s) c->d_acc[s] = nullptr, c->d_vec[s] = nullptr, c->d_sc[s] = nullptr;
+        c->d_h2tbl = c->d_s2htbl = nullptr;
+    }
+    for (int s = 7; s < NPLAN; ++s) { (void)gfree(c->d_steps[s]); (void)gfree(c->d_bias[s]); (void)gfree(c->d_scal[s]); (void)gfree(c->packed[s]); }
+    for (int s = 3; s < NTM; ++s) { (void)gfree(c->d_acc[s]); (void)gfree(c->d_vec[s]); (void)gfree(c->d_sc[s]); }
     void* ptrs[] = {c->sta_rowptr, c->sta_col, c->src_rowptr, c->src_col, c->order, c->outdeg, c->raw,
                     c->d_steps[0], c->d_steps[1], c->d_bias[0], c->d_bias[1],
                     c->d_scal[0], c->d_scal[1], c->packed[0], c->packed[1],
@@ -2279,9 +2430,9 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->r_sta_rowptr, c->r_sta_col, c->r_src_rowptr, c->r_src_col, c->r_sta_w, c->r_src_w, c->r_sta_cw, c->r_src_cw, c->rp_sta_rowptr, c->rp_src_rowptr, c->rp_sta_cw, c->rp_src_cw, c->ptile16, c->ptile32,
                     c->sta_perm, c->sta_inv, c->sta_rowptr_p, c->sta_col_p, c->ebias_sta_p, c->ea_int, c->ea_tmp, c->sta_ident,
                     c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of, c->p_sta_of};
-    for (void* p : ptrs) (void)hipFree(p);
+    for (void* p : ptrs) (void)gfree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
-    for (auto& kv : c->s2u) { (void)hipFree(kv.second.blocks); (void)hipFree(kv.second.xcd0); }
+    for (auto& kv : c->s2u) { (void)gfree(kv.second.blocks); (void)gfree(kv.second.xcd0); }
     delete c;
     return GENIE_OK;
 }
@@ -2340,7 +2491,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
     c->ws_np = false;
     float* dbg_tmp = nullptr;
     if ((dbg_h0 || dbg_h1) && sta_order_on(c)) {
-        HIP_TRY(hipMalloc((void**)&dbg_tmp, sizeof(float) * 90 * (size_t)c->P));
+        HIP_TRY(gmalloc((void**)&dbg_tmp, sizeof(float) * 90 * (size_t)c->P));
         if (dbg_h0) a.dbg_h0 = dbg_tmp;
         if (dbg_h1) a.dbg_h1 = dbg_tmp + c->P * 30;
     }
@@ -2357,8 +2508,8 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (c->abs_sta) {      // position pieces per product node (genie_set_absolute_pos on a subgraph context)
             if (c->abs_dirty || !c->abs_ts) {
                 if (!c->abs_ts) {
-                    HIP_TRY(hipMalloc((void**)&c->abs_ts, 16 * (size_t)c->P));
-                    HIP_TRY(hipMalloc((void**)&c->abs_tg, 16 * (size_t)c->P));
+                    HIP_TRY(gmalloc((void**)&c->abs_ts, 16 * (size_t)c->P));
+                    HIP_TRY(gmalloc((void**)&c->abs_tg, 16 * (size_t)c->P));
                 }
                 k_abs_pieces<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(c->abs_sta, nullptr, (int)c->P, c->abs_ts);
                 k_abs_pieces<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(c->abs_src, nullptr, (int)c->P, c->abs_tg);
@@ -2411,8 +2562,8 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
             const int so = sta_order_on(c) ? 1 : 0;      // a training forward runs in the caller's station order, inference in processing order
             if (c->abs_dirty || !c->abs_ts || c->abs_ts_order != so) {
                 if (!c->abs_ts) {
-                    HIP_TRY(hipMalloc((void**)&c->abs_ts, 16 * (size_t)c->S));
-                    HIP_TRY(hipMalloc((void**)&c->abs_tg, 16 * (size_t)c->G_ext));
+                    HIP_TRY(gmalloc((void**)&c->abs_ts, 16 * (size_t)c->S));
+                    HIP_TRY(gmalloc((void**)&c->abs_tg, 16 * (size_t)c->G_ext));
                 }
                 k_abs_pieces<<<(c->S + 255) / 256, 256, 0, st>>>(c->abs_sta, sta_order_on(c) ? c->sta_perm : nullptr, c->S, c->abs_ts);
                 k_abs_pieces<<<(c->G_ext + 255) / 256, 256, 0, st>>>(c->abs_src, nullptr, c->G_ext, c->abs_tg);
@@ -2435,7 +2586,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (dbg_h0) k_permute_sta_rows<<<(unsigned)((c->P * 30 + 255) / 256), 256, 0, st>>>(dbg_tmp, c->P, 30, c->sta_perm, c->S, dbg_h0);
         if (dbg_h1) k_permute_sta_rows<<<(unsigned)((c->P * 60 + 255) / 256), 256, 0, st>>>(dbg_tmp + c->P * 30, c->P, 60, c->sta_perm, c->S, dbg_h1);
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipFree(dbg_tmp));
+        HIP_TRY(gfree(dbg_tmp));
     }
     return GENIE_OK;
 }
@@ -2478,6 +2629,8 @@ int get_s2u_tables(genie_ctx* c, int gb0, int ge0, const genie_ctx::S2uTables** 
     if (itf != c->s2u.end()) { *out = &itf->second; return GENIE_OK; }
     const std::vector<int32_t>& tab = c->tab_host;
     std::vector<S2uBlock> blks;
+    std::vector<int32_t> seen_blk((size_t)c->G_ext, -1), seen_at((size_t)c->G_ext, 0);
+    int32_t serial = 0;
     int32_t x0[9];
     const int nxc = 8, n = ge0 - gb0;
     for (int x = 0; x < nxc; ++x) {
@@ -2488,36 +2641,41 @@ int get_s2u_tables(genie_ctx* c, int gb0, int ge0, const genie_ctx::S2uTables** 
             S2uBlock b;
             memset(&b, 0, sizeof(b));
             b.gi0 = pos;
-            std::vector<int32_t> uni;
+            // membership of a neighbour row in the block's union by a stamp per source node (`seen_blk[nb]` = serial of the block that
+            // listed it, `seen_at[nb]` = its position there): the table of 10 000 source nodes builds in ~0.2 ms, where a linear search
+            // of the union per neighbour took 2.5 ms of every context (re)build of a training sample
+            ++serial;
+            int32_t uni[S2U_UCAP + 15];
+            int nuni = 0;
             while (pos < ge && b.n < S2U_NB) {
-                std::vector<int32_t> add;
                 int32_t where[15];
+                const int before = nuni;
                 for (int k = 0; k < 15; ++k) {
                     const int32_t nb = tab[(size_t)pos * 16 + 1 + k];
-                    int at = -1;
-                    for (size_t u = 0; u < uni.size(); ++u) if (uni[u] == nb) { at = (int)u; break; }
-                    if (at < 0) for (size_t u = 0; u < add.size(); ++u) if (add[u] == nb) { at = (int)(uni.size() + u); break; }
-                    if (at < 0) { at = (int)(uni.size() + add.size()); add.push_back(nb); }
-                    where[k] = at;
+                    if (seen_blk[(size_t)nb] != serial) { seen_blk[(size_t)nb] = serial; seen_at[(size_t)nb] = nuni; uni[nuni++] = nb; }
+                    where[k] = seen_at[(size_t)nb];
                 }
-                if (b.n > 0 && uni.size() + add.size() > (size_t)S2U_UCAP) break;
-                uni.insert(uni.end(), add.begin(), add.end());
+                if (b.n > 0 && nuni > S2U_UCAP) {       // the node does not fit: take its additions back, it opens the next block
+                    for (int u = before; u < nuni; ++u) seen_blk[(size_t)uni[u]] = -1;
+                    nuni = before;
+                    break;
+                }
                 b.idx[b.n][0] = tab[(size_t)pos * 16];
                 for (int k = 0; k < 15; ++k) b.idx[b.n][1 + k] = where[k];
                 ++b.n; ++pos;
             }
             for (int e = b.n; e < S2U_NB; ++e) b.idx[e][0] = -1;       // empty slots of a short block
-            b.U = (int32_t)uni.size();
-            for (int u = 0; u < S2U_UCAP; ++u) b.ids[u] = uni[(size_t)u < uni.size() ? u : 0];
+            b.U = (int32_t)nuni;
+            for (int u = 0; u < S2U_UCAP; ++u) b.ids[u] = uni[u < nuni ? u : 0];
             blks.push_back(b);
         }
     }
     x0[nxc] = (int32_t)blks.size();
     genie_ctx::S2uTables t;
     t.blocks = nullptr; t.xcd0 = nullptr; t.nblk = (int)blks.size();
-    HIP_TRY(hipMalloc(&t.blocks, sizeof(S2uBlock) * std::max<size_t>(1, blks.size())));
+    HIP_TRY(gmalloc(&t.blocks, sizeof(S2uBlock) * std::max<size_t>(1, blks.size())));
     HIP_TRY(hipMemcpy(t.blocks, blks.data(), sizeof(S2uBlock) * blks.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&t.xcd0, sizeof(x0)));
+    HIP_TRY(gmalloc((void**)&t.xcd0, sizeof(x0)));
     HIP_TRY(hipMemcpy(t.xcd0, x0, sizeof(x0), hipMemcpyHostToDevice));
     *out = &(c->s2u[key] = t);
     return GENIE_OK;
@@ -2562,14 +2720,14 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         if (!c->sta_ident) {
             std::vector<int32_t> id((size_t)c->S);
             for (int i = 0; i < c->S; ++i) id[i] = i;
-            HIP_TRY(hipMalloc((void**)&c->sta_ident, sizeof(int32_t) * id.size()));
+            HIP_TRY(gmalloc((void**)&c->sta_ident, sizeof(int32_t) * id.size()));
             HIP_TRY(hipMemcpy(c->sta_ident, id.data(), sizeof(int32_t) * id.size(), hipMemcpyHostToDevice));
         }
         a.sta_user = c->sta_ident; a.ea_int = edge_attr; a.wgmap = 0;
         if (train_h2u_on(c) && c->ws_np && gi_begin == 0 && gi_end == c->G) {
             // k_stage2_h2u with the pre-activations kept (identity station order: edge_attr fragments built per call)
             a.np = 1; a.packed = c->packed_s2h;
-            if (!c->ea_frag_tmp) HIP_TRY(hipMalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
+            if (!c->ea_frag_tmp) HIP_TRY(gmalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
             k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(edge_attr, c->P, c->S, nullptr, c->ea_frag_tmp);
             a.ea_frag = c->ea_frag_tmp;
             const genie_ctx::S2uTables* tb = nullptr;
@@ -2612,7 +2770,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             k_stage2_ord<8, 15, true, true><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
 #if GENIE_TUNING
         } else if (!s2h_on(c)) {     // A/B reference (GENIE_S2_OLD): the round-3 stage 2 on row-layout c / wv
-            if (!c->ea_tmp) HIP_TRY(hipMalloc((void**)&c->ea_tmp, sizeof(float) * 3 * (size_t)c->P));
+            if (!c->ea_tmp) HIP_TRY(gmalloc((void**)&c->ea_tmp, sizeof(float) * 3 * (size_t)c->P));
             k_permute_sta_rows<<<(unsigned)((c->P * 3 + 255) / 256), 256, 0, st>>>(edge_attr, c->P, 3, c->sta_inv, c->S, c->ea_tmp);
             a.ea_int = c->ea_tmp;
             k_stage2_ord<8, 15, false><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
@@ -2624,7 +2782,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             a.np = 1; a.packed = c->packed_s2h;
             if (c->ea_frag && c->ea_user == edge_attr) a.ea_frag = c->ea_frag;
             else {
-                if (!c->ea_frag_tmp) HIP_TRY(hipMalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
+                if (!c->ea_frag_tmp) HIP_TRY(gmalloc((void**)&c->ea_frag_tmp, 32 * (size_t)c->P));
                 k_ea_frag<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(edge_attr, c->P, c->S, c->sta_perm, c->ea_frag_tmp);
                 a.ea_frag = c->ea_frag_tmp;
             }
@@ -3079,10 +3237,10 @@ int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int
             rw[pos] = w;
         }
     }
-    HIP_TRY(hipMalloc((void**)r_rowptr, sizeof(int32_t) * rrp.size()));
+    HIP_TRY(gmalloc((void**)r_rowptr, sizeof(int32_t) * rrp.size()));
     HIP_TRY(hipMemcpy(*r_rowptr, rrp.data(), sizeof(int32_t) * rrp.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)r_col, sizeof(int32_t) * std::max<size_t>(E, 1)));
-    HIP_TRY(hipMalloc((void**)r_w, sizeof(float) * std::max<size_t>(E, 1)));
+    HIP_TRY(gmalloc((void**)r_col, sizeof(int32_t) * std::max<size_t>(E, 1)));
+    HIP_TRY(gmalloc((void**)r_w, sizeof(float) * std::max<size_t>(E, 1)));
     if (E) {
         HIP_TRY(hipMemcpy(*r_col, rcol.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(*r_w, rw.data(), sizeof(float) * E, hipMemcpyHostToDevice));
@@ -3090,7 +3248,7 @@ int build_reversed(const int32_t* d_rowptr, const int32_t* d_col, int n_tgt, int
     if (r_cw) {
         std::vector<int2> cw(std::max<size_t>(E, 1), int2{0, 0});
         for (size_t e = 0; e < E; ++e) { cw[e].x = rcol[e]; memcpy(&cw[e].y, &rw[e], 4); }
-        HIP_TRY(hipMalloc((void**)r_cw, sizeof(int2) * cw.size()));
+        HIP_TRY(gmalloc((void**)r_cw, sizeof(int2) * cw.size()));
         HIP_TRY(hipMemcpy(*r_cw, cw.data(), sizeof(int2) * cw.size(), hipMemcpyHostToDevice));
     }
     return GENIE_OK;
@@ -3171,7 +3329,7 @@ int train_check(const genie_ctx* c, const char* who, bool variants = false, bool
 // station sums live as [G][T][32] partial rows; on an irregular product graph the training calls keep ONE row per source node there
 int ensure_src_of(genie_ctx* c, hipStream_t st) {
     if (c->p_src_of || !c->pcsr) return GENIE_OK;
-    HIP_TRY(hipMalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
+    HIP_TRY(gmalloc((void**)&c->p_src_of, sizeof(int32_t) * (size_t)c->P));
     k_seg_owner<<<(c->G + 255) / 256, 256, 0, st>>>(c->seg_rowptr, c->G, c->p_src_of);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -3250,7 +3408,8 @@ int ensure_reversed(genie_ctx* c) {
     int rc;
     if (c->r_sta_rowptr) {      // built by genie_nbr_mean_bwd without the pair arrays: rebuild whole
         void* old[] = {c->r_sta_rowptr, c->r_sta_col, c->r_sta_w, c->r_src_rowptr, c->r_src_col, c->r_src_w};
-        for (void* q : old) (void)hipFree(q);
+        (void)hipDeviceSynchronize();
+        for (void* q : old) (void)gfree(q);
         c->r_sta_rowptr = c->r_sta_col = c->r_src_rowptr = c->r_src_col = nullptr; c->r_sta_w = c->r_src_w = nullptr;
     }
     if (c->pcsr) {      // irregular product graph: the P-sized passes gather by product-node id over the reversed PRODUCT-level graphs
@@ -3258,17 +3417,17 @@ int ensure_reversed(genie_ctx* c) {
         int32_t* col_unused = nullptr;
         float* w_unused = nullptr;
         if ((rc = build_reversed(c->p_sta_rowptr, c->p_sta_col, np, np, &c->rp_sta_rowptr, &col_unused, &w_unused, &c->rp_sta_cw))) return rc;
-        (void)hipFree(col_unused); (void)hipFree(w_unused);
+        (void)gfree(col_unused); (void)gfree(w_unused);
         col_unused = nullptr; w_unused = nullptr;
         if ((rc = build_reversed(c->p_src_rowptr, c->p_src_col, np, np, &c->rp_src_rowptr, &col_unused, &w_unused, &c->rp_src_cw))) return rc;
-        (void)hipFree(col_unused); (void)hipFree(w_unused);
+        (void)gfree(col_unused); (void)gfree(w_unused);
         // base station graph: not part of a subgraph context; an empty reversed graph keeps the non-null contract of the callers
         std::vector<int32_t> zero((size_t)c->S + 1, 0);
-        HIP_TRY(hipMalloc((void**)&c->r_sta_rowptr, sizeof(int32_t) * zero.size()));
+        HIP_TRY(gmalloc((void**)&c->r_sta_rowptr, sizeof(int32_t) * zero.size()));
         HIP_TRY(hipMemcpy(c->r_sta_rowptr, zero.data(), sizeof(int32_t) * zero.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&c->r_sta_col, sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void**)&c->r_sta_w, sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&c->r_sta_cw, sizeof(int2)));
+        HIP_TRY(gmalloc((void**)&c->r_sta_col, sizeof(int32_t)));
+        HIP_TRY(gmalloc((void**)&c->r_sta_w, sizeof(float)));
+        HIP_TRY(gmalloc((void**)&c->r_sta_cw, sizeof(int2)));
         return build_reversed(c->src_rowptr, c->src_col, c->G, c->G, &c->r_src_rowptr, &c->r_src_col, &c->r_src_w, &c->r_src_cw);
     }
     if ((rc = build_reversed(c->sta_rowptr, c->sta_col, c->S, c->S, &c->r_sta_rowptr, &c->r_sta_col, &c->r_sta_w, &c->r_sta_cw))) return rc;
@@ -3593,9 +3752,9 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     if (((uintptr_t)assoc_ws & 15) != 0) return fail(GENIE_ERR_ARG, "genie_assoc_fwd: assoc_ws must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
-    if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
+    if (!c->as_pg) HIP_TRY(gmalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
     const bool variant = c->has_edges || c->abs_sta != nullptr;
-    if (variant && !c->as_ps) HIP_TRY(hipMalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)edge_rows_sta(c)));
+    if (variant && !c->as_ps) HIP_TRY(gmalloc((void**)&c->as_ps, sizeof(float) * AS_PS * (size_t)edge_rows_sta(c)));
     assoc_pre_launch(c, y_latent, mask_src, st);
     if (save) { c->force_generic = 1; c->train_save = save; }      // training forward: caller's station order, pre-activations kept
     DaArgs d = make_da_args(c, (float*)ws);
@@ -3659,7 +3818,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_packed(c, st))) return rc;
     if ((rc = ensure_reversed(c))) return rc;
-    if (!c->as_pg) HIP_TRY(hipMalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
+    if (!c->as_pg) HIP_TRY(gmalloc((void**)&c->as_pg, sizeof(float) * AS_PG * (size_t)c->G));
     assoc_pre_launch(c, y_latent, mask_src, st);          // pg[31] = mask1[g] (another forward may have overwritten the table)
     HIP_TRY(hipMemsetAsync(grad_blob, 0, sizeof(float) * g_raw_total, st));
     TrArgs a;
@@ -3734,6 +3893,20 @@ int genie_knn(const float* x_context, int n_context, const float* x_query, int n
     if (k <= 8) k_knn<8><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
     else if (k <= 10) k_knn<10><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
     else k_knn<16><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_product_check(const int64_t* A_in_sta, int64_t E_sta, const int64_t* A_in_src, int64_t E_src, int n_sta, int n_grid,
+                        int32_t* flags, void* stream) {
+    if (!A_in_sta || !A_in_src || !flags) return fail(GENIE_ERR_ARG, "genie_product_check: null argument");
+    if (n_sta < 1 || n_grid < 1 || E_sta < 1 || E_src < 1 || E_sta % n_grid != 0 || E_src % n_sta != 0 ||
+        E_sta / n_grid >= (1ll << 31) || E_src / n_sta >= (1ll << 31))
+        return fail(GENIE_ERR_ARG, "genie_product_check: edge counts must be positive multiples of (n_grid, n_sta)");
+    const long long n = (long long)E_sta + E_src;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 256 * 32);
+    k_product_check<<<grid, 256, 0, (hipStream_t)stream>>>((const long long*)A_in_sta, (long long)E_sta, (int)(E_sta / n_grid),
+                                                          (const long long*)A_in_src, (long long)E_src, (int)(E_src / n_sta), n_sta, n_grid, flags);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -3969,7 +4142,7 @@ int genie_set_phase_types(genie_ctx* c, int use_phase_types) {
 int genie_set_subgraph_stations(genie_ctx* c, const int32_t* sta_of_prod, void* stream) {
     if (!c || !sta_of_prod) return fail(GENIE_ERR_ARG, "genie_set_subgraph_stations: null argument");
     if (!c->pcsr) return fail(GENIE_ERR_STATE, "genie_set_subgraph_stations: the context is a Cartesian product graph (station = p % n_sta)");
-    if (!c->p_sta_of) HIP_TRY(hipMalloc((void**)&c->p_sta_of, sizeof(int32_t) * (size_t)c->P));
+    if (!c->p_sta_of) HIP_TRY(gmalloc((void**)&c->p_sta_of, sizeof(int32_t) * (size_t)c->P));
     HIP_TRY(hipMemcpyAsync(c->p_sta_of, sta_of_prod, sizeof(int32_t) * (size_t)c->P, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GENIE_OK;
 }

@@ -129,7 +129,8 @@ def csr_from_edges(edge_index, n_target):
     if ei.numel() == 0:
         return torch.zeros(n_target + 1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
     j, i = ei[0], ei[1]
-    if int(i.max()) >= n_target or int(i.min()) < 0:
+    lo_hi = torch.stack((i.min(), i.max())).tolist()           # (one read-back for both bounds)
+    if lo_hi[1] >= n_target or lo_hi[0] < 0:
         raise ValueError("edge target out of range")
     order = torch.sort(i, stable=True)[1]
     deg = torch.bincount(i, minlength=n_target)
@@ -209,8 +210,53 @@ def hilbert_order(points, bits=10):
 
 def sfc_order(points):
     """The processing order used for source nodes and stations: the Z-curve (measured at config 2: 0.781 ms/window against
-    0.785 with the Hilbert curve `hilbert_order`; config 4: 42.1 against 41.7 ms)."""
-    return morton_order(points)
+    0.785 with the Hilbert curve `hilbert_order`; config 4: 42.1 against 41.7 ms). A GPU tensor is ordered on the GPU
+    (`morton_order_device`: the same permutation, no host round trip of the positions) and returned as an int32 GPU tensor."""
+    if torch.is_tensor(points) and points.is_cuda:
+        return morton_order_device(points)
+    return morton_order(points.detach().cpu().numpy() if torch.is_tensor(points) else points)
+
+
+def morton_order_device(points):
+    """`morton_order` of positions resident on the GPU, computed there: the float64 quantisation of `_quantise_isotropic` (IEEE
+    arithmetic, truncation toward zero: the same integers), the same bit interleave, a stable sort of the codes -- the same
+    permutation as the numpy form (tests/test_hip_parity.py), as an int32 GPU tensor. A context rebuild per training sample
+    (train_GENIE_model.py:1722-1786) then costs no copy of the grid to the host and back."""
+    x = points.detach().to(torch.float64)
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise ValueError("positions must be [n, 3]")
+    lo, hi = x.min(0)[0], x.max(0)[0]
+    top = float((1 << 10) - 1)
+    scale = top / torch.clamp((hi - lo).max(), min=1e-9)
+    q = ((x - lo) * scale).long().clamp_(0, (1 << 10) - 1)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.sort(code, stable=True)[1].to(torch.int32)
+
+
+def size_class(n):
+    """Allocation sizes of the big per-context / per-step buffers (workspace, kept pre-activations, scratch) rounded up to 1/8-octave
+    steps: the reference's training loop changes the station subset per sample, so these sizes change by a fraction of a percent from
+    step to step, and PyTorch's caching allocator only reuses a cached block for a request it fits -- exact sizes made every other
+    rebuild pay a fresh 1-2 GB hipMalloc (60-80 ms). With size classes a handful of blocks serve every sample."""
+    n = int(n)
+    if n < 4096:
+        return max(n, 1)
+    sh = n.bit_length() - 4
+    step = 1 << sh
+    return (n + step - 1) // step * step
+
+
+def empty_f32(n, device):
+    """Flat float32 buffer of `n` elements cut from a size-class allocation (`size_class`)."""
+    return torch.empty(size_class(n), dtype=torch.float32, device=device)[:n]
 
 
 ASSOC_PREFIXES = ("BipartiteGraphReadOutOperator.", "DataAggregationAssociationPhase.", "LocalSliceLgCollapseP.",
@@ -248,7 +294,7 @@ class HipPath(object):
         dev = self.device
         order = None
         if grid_order is not None:
-            order = torch.as_tensor(np.asarray(grid_order)).to(dev, torch.int32).contiguous()
+            order = (grid_order if torch.is_tensor(grid_order) else torch.as_tensor(np.asarray(grid_order))).to(dev, torch.int32).contiguous()
             if order.numel() != self.n_grid:
                 raise ValueError("grid_order must have n_grid entries")
         self.ctx = ctypes.c_void_p(0)
@@ -277,22 +323,28 @@ class HipPath(object):
                                                _ptr(self._keep[3]), _ptr(order), ctypes.c_float(self.scale_rel))
             _lib.check(rc, "genie_ctx_create")
             # without a station order the identity: stage 2's production kernel reads its rows in processing order
+            if torch.is_tensor(sta_order):
+                sta_order = sta_order.cpu().numpy()
             so = np.ascontiguousarray(np.asarray(sta_order if sta_order is not None else np.arange(self.n_sta)), dtype=np.int32)
             if so.shape != (self.n_sta,):
                 raise ValueError("sta_order must have n_sta entries")
             _lib.check(self.lib.genie_set_station_order(self.ctx, ctypes.c_void_p(so.ctypes.data)), "genie_set_station_order")
         self.set_stage_precision(stage_precision if stage_precision is not None else STAGE_PRECISION)
-        self.ws = torch.empty(int(self.lib.genie_workspace_bytes(self.ctx)) + 256, dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(size_class(int(self.lib.genie_workspace_bytes(self.ctx)) + 256), dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.ws.data_ptr() + off)
         _lib.check(self.lib.genie_set_slot(self.ctx, self.PLAIN_SLOT), "genie_set_slot")
-        # weight mirror
-        n = self.lib.genie_weights_count()
-        self.w_names = [self.lib.genie_weights_name(i).decode() for i in range(n)]
-        self.w_numel = [int(self.lib.genie_weights_numel(i)) for i in range(n)]
-        self.w_off = [int(self.lib.genie_weights_offset(i)) for i in range(n)]
-        self._blob = torch.zeros(int(self.lib.genie_weights_blob_floats()), dtype=torch.float32, device=dev)
+        # weight mirror (the registry is a property of the library, read once per process: 3 x 161 ctypes calls otherwise)
+        if HipPath._registry is None:
+            n = self.lib.genie_weights_count()
+            HipPath._registry = ([self.lib.genie_weights_name(i).decode() for i in range(n)],
+                                 [int(self.lib.genie_weights_numel(i)) for i in range(n)],
+                                 [int(self.lib.genie_weights_offset(i)) for i in range(n)], int(self.lib.genie_weights_blob_floats()))
+        self.w_names, self.w_numel, self.w_off, n_blob = HipPath._registry
+        self._blob = torch.zeros(n_blob, dtype=torch.float32, device=dev)
         self._w_key = None
+
+    _registry = None
 
     def set_subgraph_stations(self, sta_of_prod):
         """Station index of every product node of an irregular product graph (genie_set_subgraph_stations): enables `embed_window`."""
@@ -746,7 +798,7 @@ class HipPath(object):
         self._refresh_static_edge_attr(edge_attr)
         need = int(self.lib.genie_assoc_workspace_bytes(self.ctx))
         if getattr(self, "_assoc_ws", None) is None or self._assoc_ws.numel() * 4 < need:
-            self._assoc_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            self._assoc_ws = empty_f32((need + 3) // 4, self.device)
         out = torch.empty((P, 30), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_assoc_fwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
                                             _ptr(out), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_fwd")
@@ -762,9 +814,9 @@ class HipPath(object):
         x_latent, Mask, edge_attr = _f32(x_latent, "x_latent", (P, 30)), _f32(Mask, "Mask", (P, 4)), _f32(edge_attr, "edge_attr", (P, 3))
         need = int(self.lib.genie_assoc_workspace_bytes(self.ctx))
         if getattr(self, "_assoc_ws", None) is None or self._assoc_ws.numel() * 4 < need:
-            self._assoc_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-        asave = torch.empty(int(self.lib.genie_assoc_train_save_floats(self.ctx)), dtype=torch.float32, device=self.device)
-        out = torch.empty((P, 30), dtype=torch.float32, device=self.device)
+            self._assoc_ws = empty_f32((need + 3) // 4, self.device)
+        asave = empty_f32(int(self.lib.genie_assoc_train_save_floats(self.ctx)), self.device)
+        out = empty_f32(P * 30, self.device).view(P, 30)
         _lib.check(self.lib.genie_assoc_train_fwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
                                                   _ptr(out), _ptr(asave), _ptr(self._assoc_ws), self._ws_ptr, _stream()), "genie_assoc_train_fwd")
         return out, asave
@@ -776,7 +828,7 @@ class HipPath(object):
         mask_src = _f32(mask_src, "mask_src").reshape(-1)
         need = int(self.lib.genie_assoc_train_scratch_floats(self.ctx))
         if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need:
-            self._train_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._train_scratch = empty_f32(need, self.device)
         d_ylat = torch.empty((G, 30), dtype=torch.float32, device=self.device)
         blob = torch.empty(self._blob.numel(), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_assoc_train_bwd(self.ctx, _ptr(y_latent), _ptr(mask_src), _ptr(x_latent), _ptr(Mask), _ptr(edge_attr),
@@ -910,9 +962,9 @@ class HipPath(object):
         P = self.n_prod
         Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
-        save = torch.empty(int(self.lib.genie_train_save_floats(self.ctx)), dtype=torch.float32, device=self.device)
+        save = empty_f32(int(self.lib.genie_train_save_floats(self.ctx)), self.device)
         r = torch.empty((self.n_grid, 30), dtype=torch.float32, device=self.device)
-        x_latent = torch.empty((P, 30), dtype=torch.float32, device=self.device) if want_x_latent else None
+        x_latent = empty_f32(P * 30, self.device).view(P, 30) if want_x_latent else None
         _lib.check(self.lib.genie_da_train_fwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(x_latent), _ptr(r),
                                                self._ws_ptr, _stream()), "genie_da_train_fwd")
         return r, x_latent, save
@@ -924,7 +976,7 @@ class HipPath(object):
         d[:, :30] = d_r
         need = int(self.lib.genie_train_scratch_floats(self.ctx))
         if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need:
-            self._train_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._train_scratch = empty_f32(need, self.device)
         blob = torch.empty(self._blob.numel(), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_da_train_bwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(d),
                                                _ptr(self._train_scratch), _ptr(blob), _stream()), "genie_da_train_bwd")
@@ -958,10 +1010,10 @@ class HipPath(object):
         knn_idx = knn_idx.contiguous()
         tq = _f32(t_query, "t_query").reshape(-1)
         dev, G = self.device, self.n_grid
-        save = torch.empty(int(self.lib.genie_train_save_floats(self.ctx)), dtype=torch.float32, device=dev)
-        tsave = torch.empty(int(self.lib.genie_tail_train_save_floats(self.ctx)), dtype=torch.float32, device=dev)
+        save = empty_f32(int(self.lib.genie_train_save_floats(self.ctx)), dev)
+        tsave = empty_f32(int(self.lib.genie_tail_train_save_floats(self.ctx)), dev)
         r = torch.empty((G, 30), dtype=torch.float32, device=dev)
-        x_latent = torch.empty((P, 30), dtype=torch.float32, device=dev) if want_x_latent else None
+        x_latent = empty_f32(P * 30, dev).view(P, 30) if want_x_latent else None
         y_latent = torch.empty((G, 30), dtype=torch.float32, device=dev) if want_y_latent else None
         y = torch.empty((G, tq.numel(), 1), dtype=torch.float32, device=dev)
         x = torch.empty((nq, tq.numel(), 1), dtype=torch.float32, device=dev)
@@ -999,9 +1051,9 @@ class HipPath(object):
         need_t = int(self.lib.genie_tail_train_scratch_floats(self.ctx, nq))
         need_f = int(self.lib.genie_train_scratch_floats(self.ctx))
         if getattr(self, "_tail_scratch", None) is None or self._tail_scratch.numel() < need_t:
-            self._tail_scratch = torch.empty(need_t, dtype=torch.float32, device=dev)
+            self._tail_scratch = empty_f32(need_t, dev)
         if getattr(self, "_train_scratch", None) is None or self._train_scratch.numel() < need_f:
-            self._train_scratch = torch.empty(need_f, dtype=torch.float32, device=dev)
+            self._train_scratch = empty_f32(need_f, dev)
         d_r = torch.empty((G, 32), dtype=torch.float32, device=dev)
         blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
         _lib.check(self.lib.genie_train_bwd(self.ctx, _ptr(Slice), _ptr(Mask), _ptr(edge_attr), _ptr(save), _ptr(pos), _ptr(x_query),
@@ -1022,7 +1074,7 @@ class HipPath(object):
         rp, re = self.reverse_query_table(knn_idx)
         need_t = int(self.lib.genie_tail_train_scratch_floats(self.ctx, nq))
         if getattr(self, "_tail_scratch", None) is None or self._tail_scratch.numel() < need_t:
-            self._tail_scratch = torch.empty(need_t, dtype=torch.float32, device=dev)
+            self._tail_scratch = empty_f32(need_t, dev)
         d_r = torch.empty((G, 32), dtype=torch.float32, device=dev)
         blob = torch.empty(int(self.lib.genie_train_grad_floats()), dtype=torch.float32, device=dev)
         _lib.check(self.lib.genie_tail_train_bwd(self.ctx, _ptr(_f32(pos, "pos", (G, 3))), _ptr(x_query), _ptr(knn_idx), _ptr(rp), _ptr(re), nq, 10,

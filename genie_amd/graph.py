@@ -115,6 +115,8 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
         raise ValueError("product edge lists are not a multiple of (n_grid, n_sta): not Cartesian")
     e_sta = A_in_sta.shape[1] // G
     e_src = A_in_src.shape[1] // S
+    if A_in_sta.is_cuda and A_in_src.is_cuda and check and e_sta > 0 and e_src > 0:
+        return _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src)
     base_sta = A_in_sta[:, :e_sta]
     if int(base_sta.max().item()) >= S:
         raise ValueError("first block of A_in_sta leaves source node 0: not Cartesian")
@@ -132,6 +134,45 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
         if not torch.equal(A_in_src, S * base_src.repeat(1, S) + off):
             raise ValueError("A_in_src is not I_S (x) A_src_src: not Cartesian")
     return neighbour_table(base_sta, S), neighbour_table(base_src, G)
+
+
+def _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src):
+    """`base_tables_from_product` for edge lists resident on the GPU (the training call convention hands `forward` new lists per
+    sample, train_GENIE_model.py:1722-1786): the Cartesian structure is verified by one pass of `genie_product_check` over the lists
+    (no materialised copy), the base tables are cut from their first blocks on the device, and every verdict is read back with ONE
+    synchronisation. Returns int32 GPU tables."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev = A_in_sta.device
+    A1 = A_in_sta if (A_in_sta.dtype == torch.int64 and A_in_sta.is_contiguous()) else A_in_sta.long().contiguous()
+    A2 = A_in_src if (A_in_src.dtype == torch.int64 and A_in_src.is_contiguous()) else A_in_src.long().contiguous()
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.genie_product_check(ctypes.c_void_p(A1.data_ptr()), int(A1.shape[1]), ctypes.c_void_p(A2.data_ptr()), int(A2.shape[1]),
+                                           S, G, ctypes.c_void_p(flags.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "genie_product_check")
+    base_sta = A1[:, :e_sta]
+    base_src = torch.div(A2[:, :e_src], S, rounding_mode="floor")
+
+    def table(base, n, e):
+        # uniform in-degree k = e / n, in-edges of a node in edge order (neighbour_table's contract); ids clamped so that a list the
+        # check above rejects cannot index out of range before the verdict is read
+        k = e // n
+        i = base[1].clamp(0, n - 1)
+        deg_bad = (torch.bincount(i, minlength=n) != k).any() if k * n == e else torch.ones((), dtype=torch.bool, device=dev)
+        order = torch.sort(i, stable=True)[1]
+        return base[0][order][: n * k].view(n, k).to(torch.int32).contiguous(), deg_bad
+
+    sta_tab, bad1 = table(base_sta, S, e_sta)
+    src_tab, bad2 = table(base_src, G, e_src)
+    verdict = torch.stack((flags[0] != 0, bad1, bad2)).tolist()          # the one synchronisation
+    if verdict[0]:
+        which = int(flags.item())
+        raise ValueError("%s: not Cartesian" % ("A_in_sta is not A_sta_sta (x) I_G" if which & 1 else "A_in_src is not I_S (x) A_src_src"))
+    if verdict[1] or verdict[2]:
+        raise ValueError("neighbour_table: non-uniform in-degree; use the CSR path")
+    return sta_tab, src_tab
 
 
 def subgraph_product_edges(A_sta_sta, A_src_src, A_src_in_sta):

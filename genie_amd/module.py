@@ -711,8 +711,9 @@ class GCN_Detection_Network_extended(nn.Module):
         self._hip.set_sign_input(self.use_sign_input)
 
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
-        order = _engine.sfc_order(pos_src.detach().cpu().numpy()) if pos_src is not None else None
-        sta_order = _engine.sfc_order(pos_loc.detach().cpu().numpy()) if pos_loc is not None else None
+        # (positions on the GPU are ordered there: no host round trip per context, which the training call convention builds per sample)
+        order = _engine.sfc_order(pos_src) if pos_src is not None else None
+        sta_order = _engine.sfc_order(pos_loc) if pos_loc is not None else None
         dev = next(self.parameters()).device
         self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
                                     device=dev, sta_order=sta_order)
@@ -746,10 +747,20 @@ class GCN_Detection_Network_extended(nn.Module):
         if not cartesian:
             return self._set_adjacencies_subgraph(A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid,
                                                   pos_loc, pos_src)
-        src_from_A = _engine.csr_from_edges(A_src, n_grid)
         src_csr = _engine.csr_from_table(src_nbr)
-        if not (torch.equal(src_from_A[0].cpu(), src_csr[0].cpu()) and torch.equal(src_from_A[1].cpu(), src_csr[1].cpu())):
-            raise ValueError("A_src is not the base graph of A_in_src")
+        A_src_t = torch.as_tensor(A_src)
+        kp = int(src_nbr.shape[1])
+        # the reference hands over the very edge list the product was built from (process_utils.py:719-721: in-edges grouped by centre,
+        # centres ascending): one comparison on the lists' own device; any other ordering of the same graph takes the CSR comparison
+        literal = A_src_t.device == src_nbr.device and tuple(A_src_t.shape) == (2, n_grid * kp) and kp > 0
+        if literal:
+            centre = torch.arange(n_grid, device=A_src_t.device, dtype=A_src_t.dtype).view(-1, 1)
+            literal = bool(((A_src_t[0].view(n_grid, kp) == src_nbr) & (A_src_t[1].view(n_grid, kp) == centre)).all())     # one read-back
+        if not literal:
+            src_from_A = _engine.csr_from_edges(A_src, n_grid)
+            a, b = [t.cpu() for t in src_from_A], [t.cpu() for t in src_csr]
+            if a[0].shape != b[0].shape or a[1].shape != b[1].shape or not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])):
+                raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
         self._edge_attr_version = self._edge_attr._version

@@ -408,6 +408,16 @@ int genie_assoc_fwd(genie_ctx* ctx, const float* y_latent, const float* mask_src
 int genie_knn(const float* x_context, int n_context, const float* x_query, int n_query, int k, int exclude_self,
               int32_t* out_idx, void* stream);
 
+/* One-time graph setup, training call convention (round 5): `forward` receives the product edge lists of a NEW graph per sample
+ * (train_GENIE_model.py:1722-1786; built at :1140-1149 as process_utils.py:720-721 builds them) and the library consumes only their base
+ * graphs, so every sample's lists are verified to be the Cartesian product of their own first blocks:
+ *   A_in_sta int64 [2][E_sta] (row 0 then row 1), E_sta = n_grid * e_sta, entry e = base_sta[e % e_sta] + n_sta * (e / e_sta);
+ *   A_in_src int64 [2][E_src], E_src = n_sta * e_src, entry e = base_src[e % e_src] + (e / e_src), base_src multiples of n_sta.
+ * `flags` (device int32, zeroed by the caller) gets bit 0 set when A_in_sta is not of that form, bit 1 when A_in_src is not. One pass,
+ * no allocation, no synchronisation (replaces the `torch.equal` of two materialised copies in genie_amd/graph.py). */
+int genie_product_check(const int64_t* A_in_sta, int64_t E_sta, const int64_t* A_in_src, int64_t E_src, int n_sta, int n_grid,
+                        int32_t* flags, void* stream);
+
 /* Training step of the P-sized association heads (round 3; module.py:986-990 inside train_GENIE_model.py:1786-1861):
  *   genie_assoc_train_fwd = genie_assoc_fwd in the caller's station order with the pre-activations of every layer kept in `asave`
  *     (genie_assoc_train_save_floats(ctx) floats: 20 blocks of 16 floats per product node);
