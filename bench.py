@@ -219,20 +219,21 @@ def cpu_baseline(net, geom, win, n_timed=3):
     return y, x, float(np.median(times)), times, t1 * (G / float(Gs)), Gs
 
 
-SPARSE_PICKS = 5000     # picks of the parity window whose masks gate (the headline window of 50 000 picks saturates Mask: mean 0.999997)
+SPARSE_PICKS = 400      # picks of the parity window whose masks gate (the headline window of 50 000 picks saturates Mask: mean 0.999997;
+                        # 5 000 picks = 25 per station in a 140-s window under the 3-s kernel still leave only 0.04 % all-zero rows)
 
 
 def sparse_window(geom, n_picks=SPARSE_PICKS, seed=9):
-    """A window of the same shape with FEW picks (default 5 000 on 200 stations), so that a large fraction of the product nodes has an
-    all-zero `Mask` row and the `mask.max(1)` gate of Bipartite_ReadIn (module.py:226-229) and the mask inputs of DataAggregation really
+    """A window of the same shape with FEW picks (default 400 on 200 stations), so that a third of the product nodes has an all-zero
+    `Mask` row and the `mask.max(1)` gate of Bipartite_ReadIn (module.py:226-229) and the mask inputs of DataAggregation really
     select: the parity check VERDICT round 4 asked for next to the saturated headline window."""
     return synthetic.make_window(geom, n_picks, seed=seed, window=7)
 
 
-def sparse_window_parity(net, geom, locs, xg, xq, tq, dev):
+def sparse_window_parity(net, geom, locs, xg, xq, tq, dev, n_picks=SPARSE_PICKS):
     """max |HIP - oracle| on `sparse_window` (one oracle run on the host cores, reference formulation)."""
     from oracle import genie_oracle as O
-    win = sparse_window(geom)
+    win = sparse_window(geom, n_picks)
     w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     S, G = geom.n_sta, geom.n_grid
     A_in_sta, A_in_src, A_src_in_prod, _ = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
@@ -1139,6 +1140,7 @@ def main():
             "max_abs_y_vs_cpu": float((yg.cpu() - yc).abs().max()), "max_abs_x_vs_cpu": float((xgq.cpu() - xc).abs().max()),
             "mask_mean_of_that_window": round(float(wins[0]["Mask"].mean()), 6),
             "sparse_window": sparse_window_parity(net, geom, locs, xg, xq, tq, dev),
+            "window_of_5000_picks": sparse_window_parity(net, geom, locs, xg, xq, tq, dev, 5000),
             "note": "`cores` is the thread count torch was given, not a scaling claim: the oracle's scatter (index_add_) is serial, so the "
                     "all-thread and the single-thread time per window are about equal on every box seen",
         }

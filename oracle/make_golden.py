@@ -216,6 +216,24 @@ def run_pick_inputs_case(name, geom, P, t0, ind_use, kernel_sig_t=3.0, t_win_dir
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "picks in window", len(out["lp_times"]), "of", P.shape[0])
 
 
+def main_cfg1_events():
+    """`python oracle/make_golden.py --cfg1-events`: SURVEY.md 8c (ii) as specified -- the config-1 shape (20 stations / 500 grid nodes)
+    with EVENT-STRUCTURED, non-saturated picks: one synthetic event + 6 noise picks (`cfg1_20x500` holds BASELINE config 1's literal
+    2 000 random picks, which saturate Slice / Mask: Mask.mean() = 1.000; under the 3-s kernel even 3 events = 120 picks on 20
+    stations still give Mask.mean() 0.95). Here 39 % of the Mask entries are zero and 20 % of the product nodes have an all-zero
+    row, so the fixture exercises the mask inputs and the `mask.max(1)` gate at the config-1 shape."""
+    ref = _import_reference()
+    from genie_amd import synthetic as syn
+    os.makedirs(OUT, exist_ok=True)
+    geom = syn.Geometry(20, 500, L=100e3, n_query=300, seed=1)
+    win = syn.make_window(geom, 30, seed=5)
+    M = win["Mask"]
+    print("cfg1e window: %d picks, Mask.mean() %.4f, all-zero rows %.4f, Slice > 0.5: %.4f" % (win["n_picks"], M.mean(), (M.max(1) == 0).mean(),
+                                                                                              (win["Slice"] > 0.5).mean()))
+    run_case(ref, "cfg1e_20x500", geom, win["Slice"], win["Mask"], window=win, row_stride=7, perturb_prelu=True,
+             keep=("h0", "h1", "x_latent", "bip", "sa1", "sa2", "sa3", "y_latent", "xq"), keep64=("bip", "sa3"))
+
+
 def main_picks():
     """`python oracle/make_golden.py --picks`: fixtures `picks_*.npz` of the reference's per-window pick selection."""
     _import_reference()
@@ -619,6 +637,8 @@ def main():
         return main_postproc()
     if "--picks" in sys.argv:
         return main_picks()
+    if "--cfg1-events" in sys.argv:
+        return main_cfg1_events()
     if "--scaled" in sys.argv:
         return main_scaled()
     if "--embed-sign" in sys.argv:

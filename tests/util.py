@@ -8,7 +8,7 @@ from genie_amd import graph as G
 from oracle import genie_oracle as O
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["tiny_6x40", "cfg1_20x500", "odd_33x257", "o1_20x500", "s2000_2000x24"]
+GOLDEN_CASES = ["tiny_6x40", "cfg1_20x500", "cfg1e_20x500", "odd_33x257", "o1_20x500", "s2000_2000x24"]
 EDGES_CASES = ["edges_12x60", "edges_7x13"]      # use_updated_model_definition class (DataAggregationEdges)
 SUBGRAPH_CASES = ["subgraph_14x50"]               # use_subgraph: irregular product graph
 ABSPOS_CASES = ["abspos_12x60", "abspos_7x13"]    # use_absolute_pos: positions appended to the inputs
