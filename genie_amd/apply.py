@@ -363,7 +363,7 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
                               * (X1[:, 2] > depth_range[0]) * (X1[:, 2] < depth_range[1]))[0]
             X1, Xc = X1[inside], Xc[inside]
             clouds.append(X1)
-            xq = torch.from_numpy(np.ascontiguousarray(Xc)).float().to(dev)                                           # torch.Tensor(...) :934
+            xq = torch.from_numpy(np.ascontiguousarray(Xc)).to(dev).float()                                           # torch.Tensor(...) :934 (rounded on the device)
             acc = torch.zeros((xq.shape[0], tq_host.shape[0]), dtype=torch.float32, device=dev)
             if xq.shape[0]:
                 for leg in legs:
