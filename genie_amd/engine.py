@@ -754,6 +754,30 @@ class HipPath(object):
                                                 _ptr(tq), tq.numel(), _ptr(out), self._ws_ptr, _stream()), "genie_readout_query")
         return out
 
+    def readouts_forked(self, x_spatial, x_grid, x_query, knn_idx, t_query):
+        """Both read-outs of one window, (y [n_grid, T, 1], x [Q, T, 1]), with the grid read-out forked onto a side stream: the two are
+        independent given x_spatial (module.py:1015-1016 / :1017-1018) and each is a short launch that fills a fraction of the GPU (10 000
+        nodes = 625 wave tiles on 1 024 SIMDs), so one stream runs them back to back for 26 + 37 us where two streams overlap them.
+        The current stream joins the side stream before returning: both results are valid on the current stream, as with the plain
+        calls, and bit-identical to them."""
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_ro_stream", None)
+        if side is None:
+            side = self._ro_stream = self._new_side_stream()
+        x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))
+        tq = _f32(t_query, "t_query").reshape(-1)
+        y = torch.empty((self.n_grid, tq.numel(), 1), dtype=torch.float32, device=self.device)      # (allocated on the current stream)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        _lib.check(self.lib.genie_readout_grid(self.ctx, _ptr(x_spatial), _ptr(tq), tq.numel(), _ptr(y), ctypes.c_void_p(side.cuda_stream)),
+                   "genie_readout_grid")
+        join = torch.cuda.Event()
+        join.record(side)
+        x = self.readout_query(x_spatial, x_grid, x_query, knn_idx, tq)
+        main.wait_event(join)
+        return y, x
+
     def readout_grid_latent(self, x_spatial, t_query):
         """(y [n_grid, T, 1], y_latent [n_grid, 30] = SpatialDirect(x_spatial)) (module.py:978-979; genie_readout_grid_latent)."""
         x_spatial = _f32(x_spatial, "x_spatial", (self.n_grid, 30))

@@ -7,18 +7,19 @@ Class / attribute / parameter names follow `/root/reference/Code/module.py` so t
       .DataAggregation        DataAggregation          module.py:52-98     -> HIP (libgenie_hip)
       .Bipartite_ReadIn       BipartiteGraphOperator   module.py:214-229   -> HIP
       .SpatialAggregation1..3 SpatialAggregation       module.py:231-249   -> HIP
-      .SpatialDirect / .TemporalAttention / .SpatialAttention               module.py:251-331 (read-out, PyTorch-ROCm)
+      .SpatialDirect / .TemporalAttention / .SpatialAttention               module.py:251-331   -> HIP (read-out kernels)
+      .BipartiteGraphReadOutOperator / .DataAggregationAssociationPhase / .LocalSliceLgCollapseP/S / .Arrivals   -> HIP
 
-The three starred modules have NO PyTorch implementation here: their `forward` hands device pointers to
-`libgenie_hip.so` and raises if the library or a GPU is missing (no CPU / eager fallback).
+The sub-module classes hold PARAMETERS only (names and shapes of the reference, so checkpoints load strictly): none of them has a
+PyTorch `forward` here. Every computation goes through `libgenie_hip.so` from the model's `forward*` methods and raises if the
+library or a GPU is missing (no CPU / eager fallback). The plain-PyTorch restatements of the heads that the tests compare the
+kernels with live in `tests/restatements.py`.
 """
 import math
-import os
 
 import numpy as np
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from . import engine as _engine
 from . import graph as _graph
@@ -195,12 +196,6 @@ class _ArrivalsTrain(torch.autograd.Function):
         return (None, d_src, None, d_p, d_s, None, None, None, None, None) + tuple(g[n].view(sh) for n, sh in zip(TRAIN_ARR_PARAMS, ctx.shapes))
 
 
-def _scatter_mean_rows(msg, index, n):
-    out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device).index_add_(0, index, msg)
-    cnt = torch.zeros(n, dtype=msg.dtype, device=msg.device).index_add_(0, index, torch.ones_like(index, dtype=msg.dtype))
-    return out / cnt.clamp(min=1).view(-1, 1)
-
-
 class DataAggregation(nn.Module):
     """Parameters of reference `DataAggregation` (module.py:53-83), incl. the two layers it defines but never
     applies (`l1_t1_1`, `l1_t2_1`) so checkpoints load strictly. Compute: HIP stages 0-2."""
@@ -332,38 +327,29 @@ class SpatialAggregation(nn.Module):
 
 
 class SpatialDirect(nn.Module):
-    """module.py:251-260."""
+    """Parameters of module.py:251-260 (computed by k_readout_m<0>)."""
 
     def __init__(self, inpt_dim, out_channels):
         super().__init__()
         self.f_direct = nn.Linear(inpt_dim, out_channels)
         self.activate = nn.PReLU()
 
-    def forward(self, inpts):
-        return self.activate(self.f_direct(inpts))
 
 
 def knn_query_edges(x_context, x_query, k):
-    """Exact kNN of each query in the context set on `x/1000` (module.py:282), evaluated in fp64 on the device.
-    Returns LongTensor [2, Q*k]: row 0 = context j, row 1 = query i (the `.flip(0)` layout)."""
-    if x_context.is_cuda:         # exact brute-force search in one HIP kernel (genie_knn); the torch form below serves CPU tests
-        idx = _engine.knn_device(x_context, x_query, k).long()
-        row_q = torch.arange(x_query.shape[0], device=x_query.device).repeat_interleave(idx.shape[1])
-        return torch.stack([idx.reshape(-1), row_q], dim=0)
-    xc = (x_context.double() / 1000.0)
-    xq = (x_query.double() / 1000.0)
-    k = min(k, xc.shape[0])
-    idx = torch.empty((xq.shape[0], k), dtype=torch.long, device=xq.device)
-    chunk = max(1, min(xq.shape[0], int(4e7 // max(1, xc.shape[0]))))
-    for a in range(0, xq.shape[0], chunk):
-        d = ((xq[a:a + chunk, None, :] - xc[None, :, :]) ** 2).sum(-1)
-        idx[a:a + chunk] = torch.topk(d, k, dim=1, largest=False, sorted=True)[1]
-    row_q = torch.arange(xq.shape[0], device=xq.device).repeat_interleave(k)
+    """Exact kNN of each query in the context set on `x/1000` (module.py:282), by one HIP kernel (genie_knn: brute force, fp64
+    distances). Returns LongTensor [2, Q*k]: row 0 = context j, row 1 = query i (the `.flip(0)` layout). GPU tensors only: the
+    product has no CPU path (the torch form the CPU tests use lives in tests/restatements.py)."""
+    if not x_context.is_cuda:
+        raise _engine._lib.GenieHipError("knn_query_edges: positions must live on the GPU (no CPU fallback)")
+    idx = _engine.knn_device(x_context, x_query, k).long()
+    row_q = torch.arange(x_query.shape[0], device=x_query.device).repeat_interleave(idx.shape[1])
     return torch.stack([idx.reshape(-1), row_q], dim=0)
 
 
 class SpatialAttention(nn.Module):
-    """module.py:262-297 (kNN k=10 of the queries into the grid, per-edge q/c/v, segment softmax, mean over heads)."""
+    """Parameters of module.py:262-297 (kNN k=10 of the queries into the grid, per-edge q/c/v, segment softmax, mean over heads:
+    k_ro_pre_m + k_readout_m<1>) and the cache of the query set's kNN table (genie_knn)."""
 
     def __init__(self, inpt_dim, out_channels, n_dim, n_latent, n_hidden=30, n_heads=5, scale_rel=SCALE_REL):
         super().__init__()
@@ -400,29 +386,9 @@ class SpatialAttention(nn.Module):
         self.query_edges(x_query, x_context, k)
         return self._edge_cache["table"]
 
-    def forward(self, inpts, x_query, x_context, k=10):
-        H, L = self.n_heads, self.n_latent
-        edge_index = self.query_edges(x_query, x_context, k)
-        j, i = edge_index[0], edge_index[1]
-        kk = edge_index.shape[1] // x_query.shape[0]
-        edge_attr = (x_query[i] - x_context[j]) / self.scale_rel
-        x_j = inpts[j]
-        cat = torch.cat((x_j, edge_attr), dim=-1)
-        q = self.f_queries(edge_attr).view(-1, H, L)
-        c = self.f_context(cat).view(-1, H, L)
-        v = self.f_values(cat).view(-1, H, L)
-        alpha = self.activate1((q * c).sum(-1) / self.scale)                       # [E, H]
-        # segment softmax over the k edges of each query (edges are grouped by query, k each)
-        alpha = alpha.view(-1, kk, H)
-        alpha = alpha - alpha.max(dim=1, keepdim=True)[0]
-        alpha = alpha.exp()
-        alpha = alpha / (alpha.sum(dim=1, keepdim=True) + 1e-16)
-        agg = (alpha.unsqueeze(-1) * v.view(-1, kk, H, L)).sum(dim=1)               # [Q, H, L]
-        return self.activate2(self.proj(agg.mean(1)))
-
 
 class TemporalAttention(nn.Module):
-    """module.py:299-331 (dense: score * value, mean over heads; no softmax)."""
+    """Parameters of module.py:299-331 (dense: score * value, mean over heads; no softmax; inside k_readout_m)."""
 
     def __init__(self, inpt_dim, out_channels, n_latent, n_hidden=30, n_heads=5, scale_t=SCALE_T):
         super().__init__()
@@ -442,37 +408,9 @@ class TemporalAttention(nn.Module):
         self.activate4 = nn.PReLU()
         self.activate5 = nn.PReLU()
 
-    def forward(self, inpts, t_query):
-        H, L = self.n_heads, self.n_latent
-        context = self.f_context_2(self.activate1(self.f_context_1(inpts))).view(-1, H, L)
-        values = self.f_values_2(self.activate2(self.f_values_1(inpts))).view(-1, H, L)
-        query = self.temporal_query_2(self.activate3(self.temporal_query_1(t_query / self.scale_t))).view(-1, H, L)
-        score = torch.einsum("nhl,thl->nth", context, query) / self.scale           # [N, T, H]
-        z = torch.einsum("nth,nhl->ntl", score, values) / H                         # mean over heads
-        return self.proj_2(self.activate5(self.proj_1(self.activate4(z))))
-
-
-def _mean_over_sta(x, sta_nbr, n_sta, n_grid):
-    """mean over the station neighbours inside the same source node; x [P,C], sta_nbr Long [S,ks]."""
-    if sta_nbr.shape[1] == 0:
-        return torch.zeros_like(x)
-    return x.view(n_grid, n_sta, -1)[:, sta_nbr, :].mean(dim=2).reshape(n_grid * n_sta, -1)
-
-
-def _mean_over_src(x, src_nbr, n_sta, n_grid):
-    """mean over the source-node neighbours for the same station; x [P,C], src_nbr Long [G,kp] (summed in edge order)."""
-    if src_nbr.shape[1] == 0:
-        return torch.zeros_like(x)
-    x3 = x.view(n_grid, n_sta, -1)
-    out = torch.zeros_like(x3)
-    for k in range(src_nbr.shape[1]):
-        out += x3[src_nbr[:, k]]
-    return (out / src_nbr.shape[1]).reshape(n_grid * n_sta, -1)
-
 
 class BipartiteGraphReadOutOperator(nn.Module):
-    """Association head, module.py:333-352: parameters + a literal restatement for CPU checks against the reference fixtures
-    (tests/test_assoc_cpu.py). GPU calls run genie_assoc_fwd / genie_assoc_train_fwd, never this forward.
+    """Association head, module.py:333-352: parameters (computed by genie_assoc_fwd / genie_assoc_train_fwd).
     `A_Lg_in_src.edge_index = [g(p); p]`: one edge per product node, so the 'add' aggregation is the identity."""
 
     def __init__(self, ndim_in, ndim_out, ndim_edges=3):
@@ -482,16 +420,10 @@ class BipartiteGraphReadOutOperator(nn.Module):
         self.activate1 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def forward(self, inpt, edge_attr, mask, n_sta):
-        g = torch.arange(edge_attr.shape[0], device=edge_attr.device) // n_sta
-        msg = mask[g] * self.activate1(self.fc1(torch.cat((inpt[g], edge_attr), dim=-1)))            # :352
-        return self.activate2(self.fc2(msg)), mask[g]                                                # :348
-
 
 class DataAggregationAssociationPhase(nn.Module):
-    """Association head, module.py:356-403 (and its Edges form, :407-480, with `n_edge = 4`): parameters + a structured restatement
-    on the Cartesian product (base kNN tables) for CPU checks against the reference fixtures. GPU calls run genie_assoc_fwd /
-    genie_assoc_train_fwd, never this forward."""
+    """Association head, module.py:356-403 (and its Edges form, :407-480, with `n_edge = 4`): parameters (computed by genie_assoc_fwd /
+    genie_assoc_train_fwd)."""
 
     def __init__(self, in_channels, out_channels, n_hidden=30, n_dim_latent=30, n_dim_mask=5, n_edge=0):
         super().__init__()
@@ -513,39 +445,10 @@ class DataAggregationAssociationPhase(nn.Module):
         self.activate22 = nn.PReLU()
         self.activate2 = nn.PReLU()
 
-    def forward(self, tr, latent, mask1, mask2, sta_nbr, src_nbr, n_sta, n_grid, edge_means=None):
-        """`edge_means` = (m_sta [S, 4], m_src [G, 4]): the mean edge position feature of every base node's in-neighbourhood; on the
-        product graph the mean over a node's messages of cat(x_j, e_ij) is cat(mean x_j, m[node]) (module.py:462-480)."""
-        def means(x1, x2):
-            a, b = _mean_over_sta(x1, sta_nbr, n_sta, n_grid), _mean_over_src(x2, src_nbr, n_sta, n_grid)
-            if edge_means is not None:
-                a = torch.cat((a, edge_means[0].repeat(n_grid, 1)), dim=1)
-                b = torch.cat((b, edge_means[1].repeat_interleave(n_sta, dim=0)), dim=1)
-            return a, b
-
-        mask = torch.cat((mask1, mask2), dim=-1)
-        tr = self.activate(self.init_trns(torch.cat((tr, latent, mask), dim=-1)))
-        a1, a2 = means(self.activate11(self.l1_t1_1(tr)), self.activate12(self.l1_t2_1(tr)))
-        tr = self.activate1(torch.cat((self.l1_t1_2(torch.cat((tr, a1, mask), dim=1)),
-                                       self.l1_t2_2(torch.cat((tr, a2, mask), dim=1))), dim=1))
-        b1, b2 = means(self.activate21(self.l2_t1_1(tr)), self.activate22(self.l2_t2_1(tr)))
-        return self.activate2(torch.cat((self.l2_t1_2(torch.cat((tr, b1, mask), dim=1)),
-                                         self.l2_t2_2(torch.cat((tr, b2, mask), dim=1))), dim=1))
-
-
-def _segment_softmax(src, index, n):
-    """torch_geometric.utils.softmax semantics: per-segment max subtraction, exp, / (sum + 1e-16)."""
-    idx = index.view(-1, 1).expand_as(src)
-    mx = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype, device=src.device).scatter_reduce(
-        0, idx, src, reduce="amax", include_self=True)
-    out = (src - mx[index]).exp()
-    den = torch.zeros((n, src.shape[1]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
-    return out / (den[index] + 1e-16)
-
 
 class LocalSliceLgCollapse(nn.Module):
     """Association head, module.py:610-659: per pick, the k = 10 product nodes of its station whose theoretical arrival is
-    nearest the pick time (time-pointer table `A_edges`), edge MLP, mean."""
+    nearest the pick time (time-pointer table `A_edges`), edge MLP, mean. Parameters (computed by genie_lslc_fwd / genie_lslc_bwd)."""
 
     def __init__(self, ndim_in, ndim_out, n_edge=2, n_hidden=30, eps=EPS):
         super().__init__()
@@ -555,43 +458,10 @@ class LocalSliceLgCollapse(nn.Module):
         self.activate2 = nn.PReLU()
         self.eps = eps
 
-    def forward(self, A_edges, dt_partition, tpick, ipick, phase_label, inpt, tlatent, k_infer=10):
-        dev = inpt.device
-        n_arvs, l_dt = len(tpick), len(dt_partition)
-        dt = dt_partition[1] - dt_partition[0]
-        t_index = torch.floor((tpick - dt_partition[0]) / dt).long()                                           # :635
-        t_index = ((ipick * l_dt * k_infer + t_index * k_infer).view(-1, 1) + torch.arange(k_infer, device=dev).view(1, -1)).reshape(-1)
-        e1 = torch.arange(n_arvs, device=dev).view(-1, 1).repeat(1, k_infer).view(-1)                         # :638
-        e0 = A_edges[t_index].long()
-        keep = torch.where((tpick[e1] - tlatent[e0, 0]).abs() < 2.0 * self.eps)[0]                             # :642-645
-        e0, e1 = e0[keep], e1[keep]
-        msg = self.activate1(self.fc1(torch.cat((inpt[e0], (tpick.view(-1, 1)[e1] - tlatent[e0]) / self.eps, phase_label[e1]), dim=-1)))
-        agg = torch.zeros((n_arvs, msg.shape[1]), dtype=msg.dtype, device=dev).index_add_(0, e1, msg)
-        cnt = torch.zeros(n_arvs, dtype=msg.dtype, device=dev).index_add_(0, e1, torch.ones_like(e1, dtype=msg.dtype))
-        return self.activate2(self.fc2(agg / cnt.clamp(min=1).view(-1, 1)))                                    # 'mean' :612
-
-
-def station_pick_pairs(ipick):
-    """Pick x pick edge list of the arrival-association head, built where `ipick` lives (module.py:703-713 does it on the host
-    with cKDTree / itertools per call): for every station u with picks l_u (in pick order) all pairs (a, b), a in l_u,
-    b in l_u + [n_arv] (the null pick), a-major, stations ascending. Returns LongTensor [2, sum n_u (n_u + 1)], rows (b; a)."""
-    n = int(ipick.shape[0])
-    dev = ipick.device
-    order = torch.sort(ipick, stable=True)[1]
-    _, inv, counts = torch.unique_consecutive(ipick[order], return_inverse=True, return_counts=True)
-    seg_len = counts[inv]
-    seg_start = (torch.cumsum(counts, 0) - counts)[inv]
-    cnt = seg_len + 1
-    a_rep = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
-    pos = torch.arange(a_rep.shape[0], device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
-    real = pos < seg_len[a_rep]
-    b = torch.where(real, order[(seg_start[a_rep] + pos).clamp(max=max(n - 1, 0))], torch.full_like(pos, n))
-    return torch.stack((b, order[a_rep]), dim=0)
-
 
 class StationSourceAttentionMergedPhases(nn.Module):
-    """Association head, module.py:662-775 (use_sparse = True, use_neighbor_assoc_edges = False). The pick x pick edge
-    list per station (module.py:703-718) comes from `station_pick_pairs`, on the device the picks live on."""
+    """Association head, module.py:662-775 (use_sparse = True, use_neighbor_assoc_edges = False): parameters (computed by
+    genie_arrivals_fwd / genie_arrivals_bwd, which never materialise the pick x pick edge list of module.py:703-718)."""
 
     def __init__(self, ndim_src_in, ndim_arv_in, ndim_out, n_latent, ndim_extra=1, n_heads=5, n_hidden=30, eps=EPS):
         super().__init__()
@@ -608,43 +478,6 @@ class StationSourceAttentionMergedPhases(nn.Module):
         self.activate3 = nn.PReLU()
         self.activate4 = nn.PReLU()
         self.n_heads, self.n_latent, self.eps = n_heads, n_latent, eps
-
-    def forward(self, n_src, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label):
-        dev, dt_ = tpick.device, tpick.dtype
-        n_sta, n_arv, H, L, eps = trv_src.shape[1], len(tpick), self.n_heads, self.n_latent, self.eps
-        edges = station_pick_pairs(ipick)                                                                       # rows (b; a)  :703-713
-        n_edge = edges.shape[1]
-        edges = edges.repeat(1, n_src) + torch.cat((torch.zeros(1, n_src * n_edge, dtype=torch.long, device=dev),
-                                                    (torch.arange(n_src, device=dev) * n_arv).repeat_interleave(n_edge).view(1, -1)), 0)
-        sidx = torch.arange(n_src, device=dev).repeat_interleave(n_edge)
-        arrival = torch.cat((torch.cat((arrival_p, arrival_p.new_zeros(1, arrival_p.shape[1])), 0),
-                             torch.cat((arrival_s, arrival_s.new_zeros(1, arrival_s.shape[1])), 0)), dim=1)
-        atime = torch.cat((tpick, tpick.new_full((1,), -eps)))
-        stindex = torch.cat((ipick, ipick.new_full((1,), n_sta)))
-        tsrc_p = torch.cat((trv_src[:, :, 0], trv_src.new_full((n_src, 1), -eps)), dim=1)
-        tsrc_s = torch.cat((trv_src[:, :, 1], trv_src.new_full((n_src, 1), -eps)), dim=1)
-        phase = torch.cat((phase_label, phase_label.new_full((1, 1), -1.0)), dim=0)
-
-        def rel(e0, si, tsrc):
-            return atime[e0] - (tsrc[si, stindex[e0]] + stime[si])
-        keep = torch.where((rel(edges[0], sidx, tsrc_p).abs() < 2.0 * eps) | (rel(edges[0], sidx, tsrc_s).abs() < 2.0 * eps))[0]
-        edges, sidx = edges[:, keep], sidx[keep]
-        e0, e1 = edges[0], edges[1]
-        e0max = int(e0.max().item())                                                                            # :762-763
-        rp, rs = rel(e0, sidx, tsrc_p).view(-1, 1), rel(e0, sidx, tsrc_s).view(-1, 1)
-        fp = torch.cat((torch.exp(-0.5 * rp ** 2 / eps ** 2), torch.sign(rp), phase[e0]), dim=1)
-        fs = torch.cat((torch.exp(-0.5 * rs ** 2 / eps ** 2), torch.sign(rs), phase[e0]), dim=1)
-        self_link = (e0 == torch.remainder(e1, e0max)).view(-1, 1).to(dt_)
-        null_link = (e0 == e0max).view(-1, 1).to(dt_)
-        x_j = arrival[e0]
-        d = lambda lin, x: lin(x)
-        ctx = d(self.f_src_context_2, self.activate1(d(self.f_src_context_1,
-            torch.cat((src_embed[sidx], stime[sidx].view(-1, 1), self_link, null_link), dim=1)))).view(-1, H, L)
-        qry = d(self.f_arrival_query_2, self.activate2(d(self.f_arrival_query_1, torch.cat((x_j, fp, fs), dim=1)))).view(-1, H, L)
-        val = d(self.f_values_2, self.activate3(d(self.f_values_1, torch.cat((x_j, fp, fs, self_link, null_link), dim=1)))).view(-1, H, L)
-        alpha = _segment_softmax((qry * ctx).sum(-1) / math.sqrt(L), e1, n_arv * n_src)
-        agg = torch.zeros((n_arv * n_src, H, L), dtype=dt_, device=dev).index_add_(0, e1, alpha.unsqueeze(-1) * val)
-        return self.proj_2(self.activate4(self.proj_1(agg.mean(1)))).view(n_src, n_arv, -1)
 
 
 class GCN_Detection_Network_extended(nn.Module):
@@ -903,10 +736,9 @@ class GCN_Detection_Network_extended(nn.Module):
             y, x = self._path_train(Slice, Mask, x_temp_cuda_cart, x_query_cart, t_query)[:2]
             return y, x
         x_spatial, _, _ = self._path(Slice, Mask, x_temp_cuda_cart)                       # :1010-1014
-        y = self._hip.readout_grid(x_spatial, t_query)                                     # :1015-1016
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)        # :282 (cached per query set)
-        x = self._hip.readout_query(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)   # :1017-1018
-        return y, x
+        # :1015-1018: the grid read-out (y) and the query read-out (x) side by side on two streams, joined before returning
+        return self._hip.readouts_forked(x_spatial, x_temp_cuda_cart, x_query_cart, knn, t_query)
 
     def forward_fixed_source_pipelined(self, Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart,
                                        x_query_cart, t_query):

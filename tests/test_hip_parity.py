@@ -540,7 +540,7 @@ def test_prelu_bwd_matches_autograd(n):
 def test_nbr_mean_matches_torch_gathers(S, G, C):
     """genie_nbr_mean (neighbour means of arbitrary [P, C] rows on the product graph, used by the association heads) against the
     index-gather formulation; (21, 40) uses ragged graphs with an empty neighbourhood."""
-    from genie_amd.module import _mean_over_src, _mean_over_sta
+    from tests.restatements import _mean_over_src, _mean_over_sta
     geom = synthetic.Geometry(S, G, L=100e3, n_query=5, seed=S + G)
     A_sta, A_src = geom.A_sta_sta, geom.A_src_src
     ragged = (S, G) == (21, 40)
@@ -1787,6 +1787,8 @@ def test_local_slice_collapse_hip_matches_module(S, G, n_picks):
     s = torch.from_numpy(rng.normal(0, 1, (G * S, 30)).astype(np.float32)).to(DEV)
     dtp_t = torch.from_numpy(dtp.astype(np.float32)).to(DEV)
     net._hip.sync_weights(net._path_params)
+    from tests import restatements as R
+    R.attach(net)            # the PyTorch restatement of the head (test infrastructure) on this model's parameters
     for head, (mod, tab, col) in enumerate(((net.LocalSliceLgCollapseP, ep, 0), (net.LocalSliceLgCollapseS, es, 1))):
         tab_t = torch.from_numpy(tab).to(DEV)
         with torch.no_grad():
@@ -1828,6 +1830,8 @@ def test_arrivals_head_hip_matches_module(S, n_src, n_picks):
     arv_s = t(rng.normal(0, 1, (n_picks, 15)).astype(np.float32))
     phase = t(rng.integers(0, 2, (n_picks, 1)).astype(np.float32))
     x_src = t(rng.normal(0, 1, (n_src, 30)).astype(np.float32))
+    from tests import restatements as R
+    R.attach(net)
     with torch.no_grad():
         ref = net.Arrivals(n_src, t(stime), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase)
     got = net._hip.arrivals_fwd(t(stime), x_src, t(trv), arv_p, arv_s, t(tpick), t(ipick), phase, eps)

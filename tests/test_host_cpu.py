@@ -167,12 +167,14 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_readout_heads_match_oracle_cpu():
-    """The PyTorch read-out heads (SpatialDirect / TemporalAttention / SpatialAttention) against the golden
-    vectors, fed with the reference's own sa3 — isolates the heads from the HIP path."""
+    """The PyTorch restatements of the read-out heads (tests/restatements.py: SpatialDirect / TemporalAttention / SpatialAttention on
+    the product module's parameters) against the golden vectors, fed with the reference's own sa3."""
+    from tests import restatements as R
     for name in GOLDEN_CASES:
         c = Case(name)
         net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device="cpu")
         net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+        R.attach(net)
         with torch.no_grad():
             sa3 = c.ref("sa3")
             y = net.TemporalAttention(net.SpatialDirect(sa3), c.t_query.float())
@@ -208,11 +210,13 @@ def test_space_filling_curve_orders():
         engine.morton_order(np.zeros((5, 2)))
 
 
-def test_query_knn_cache_cannot_return_a_stale_table():
+def test_query_knn_cache_cannot_return_a_stale_table(monkeypatch):
     """SpatialAttention.query_edges caches the kNN table of the last query set by (address, version, shape) and holds the
     tensors, so a query set freed and re-allocated at the same address, or edited in place, is never served the old table."""
     import gc
     from genie_amd import module
+    from tests import restatements as R
+    monkeypatch.setattr(module, "knn_query_edges", R.knn_query_edges)       # (the product's search is a HIP kernel: GPU tensors only)
     sa = module.SpatialAttention(30, 30, 3, 15)
     g = torch.Generator().manual_seed(3)
     xc = torch.rand(200, 3, generator=g) * 1e5
