@@ -791,7 +791,10 @@ def main_train(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
 
 def main_dry_run_cpu(a, rank, world):
     """Launcher / plan / collective check without a GPU (tests/test_bench_cpu.py): every rank builds its ShardPlan, sends the
-    row blocks its peers list and all-gathers a per-node tensor, over gloo on CPU tensors; values encode (node, station)."""
+    row blocks its peers list and all-gathers a per-node tensor, over gloo on CPU tensors; values encode (node, station). The line also
+    carries what the first real multi-GPU run should see on the wire: per rank the halo bytes IN per window (64 B of `wv` per halo
+    product node), the largest single (sender -> receiver) pair and its time on one 153-GB/s xGMI link -- the halo is a point-to-point
+    pattern, every pair on its own link, so that pair bounds the exchange."""
     from genie_amd import dist as gdist, engine
     dist = None
     if world > 1:
@@ -800,22 +803,40 @@ def main_dry_run_cpu(a, rank, world):
     S, G, n_picks, L, nq = synthetic.CONFIGS[a.config or "cfg1_20x500"]
     geom = synthetic.Geometry(S, G, L=L, n_query=8, seed=1)
     plan = gdist.ShardPlan(geom.A_src_src, G, world, rank, engine.sfc_order(geom.x_grid))
-    code = (torch.arange(G).view(-1, 1) * 4096 + torch.arange(S).view(1, -1)).float()                 # [G, S]
-    rows_global = torch.stack((code, -code), dim=2)                                                    # [G, S, 2]
+    Sp = min(S, 4)               # stations of the test payload (the byte counts below use the real S)
+    code = (torch.arange(G).view(-1, 1) * 4096 + torch.arange(Sp).view(1, -1)).float()                # [G, Sp]
+    rows_global = torch.stack((code, -code), dim=2)                                                    # [G, Sp, 2]
     own = rows_global[torch.from_numpy(plan.own_global)].reshape(-1, 2).contiguous()
-    halo = gdist.exchange_halo_rows(own, plan, S)
-    ok = torch.equal(halo.view(plan.n_halo, S, 2), rows_global[torch.from_numpy(plan.halo_global)])
+    ok = True
+    for mode in ("a2a", "p2p"):
+        halo = gdist.exchange_halo_rows(own, plan, Sp, mode=mode)
+        ok = ok and torch.equal(halo.view(plan.n_halo, Sp, 2), rows_global[torch.from_numpy(plan.halo_global)])
     per_node = torch.stack([torch.from_numpy(plan.own_global).float() * k for k in (1.0, 2.0, 3.0)], dim=1)
     gathered = gdist.allgather_owned(per_node, plan)
     ok = ok and torch.equal(gathered[:, 0], torch.arange(G).float()) and torch.equal(gathered[:, 2], 3.0 * torch.arange(G).float())
     flag = torch.tensor([1.0 if ok else 0.0])
+    row_bytes = float(S) * 64.0                                  # one halo source node = S rows of wv, 64 B each
+    mine = {"rank": rank, "n_own": plan.n_own, "n_halo": plan.n_halo, "recv_nodes": list(plan.recv_counts), "send_nodes": list(plan.send_counts)}
+    everyone = [mine]
     if dist is not None:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
     if rank == 0:
+        everyone = sorted(everyone, key=lambda d: d["rank"])
+        consistent = all(everyone[r]["recv_nodes"][q] == everyone[q]["send_nodes"][r] for r in range(world) for q in range(world))
+        mb_in = [round(sum(d["recv_nodes"]) * row_bytes / 1e6, 1) for d in everyone]
+        pair = max((d["recv_nodes"][q] * row_bytes / 1e6, q, d["rank"]) for d in everyone for q in range(world)) if world > 1 else (0.0, 0, 0)
         emit_line(json.dumps({"dry_run_cpu": True, "n_gpus": world, "ranks": world if dist is None else dist.get_world_size(),
-                          "backend": "gloo" if dist is not None else "none", "ok": bool(flag.item() == 1.0),
-                          "config": {"workload": "%s sharding plan + collectives only" % (a.config or "cfg1_20x500")},
-                          "rank0_plan": {"n_own": plan.n_own, "n_halo": plan.n_halo}}))
+                              "backend": "gloo" if dist is not None else "none", "ok": bool(flag.item() == 1.0) and consistent,
+                              "config": {"workload": "%s sharding plan + collectives only" % (a.config or "cfg1_20x500")},
+                              "rank0_plan": {"n_own": plan.n_own, "n_halo": plan.n_halo},
+                              "halo": {"bytes_per_halo_source_node": row_bytes, "MB_in_per_rank": mb_in, "MB_in_max": max(mb_in),
+                                       "MB_in_mean": round(float(np.mean(mb_in)), 1),
+                                       "largest_pair_MB": round(pair[0], 1), "largest_pair": "rank %d -> rank %d" % (pair[1], pair[2]),
+                                       "largest_pair_ms_at_153_GBs": round(pair[0] / 153.0, 3),
+                                       "peers_per_rank": [sum(1 for v in d["recv_nodes"] if v) for d in everyone],
+                                       "send_recv_consistent": consistent, "exchange_modes_checked": ["a2a", "p2p"]}}))
     if dist is not None:
         dist.destroy_process_group()
     return 0 if flag.item() == 1.0 else 1

@@ -1342,6 +1342,8 @@ struct genie_ctx {
                                // split into fp16 pieces is bounded below 60 000 for inputs in [-1, 1], and so is every weight
     float range_act, range_w;  // ... the two bounds it found (largest hidden-state bound, largest weight magnitude incl. the 16 x forms)
     float* d_range; float* h_range;     // device result / pinned host copy of k_h2_range
+    unsigned* h_inflag = nullptr;       // host-mapped word: bits of the largest |input| a split pass saw BEYOND what the range guard verified
+                                        // (flag_input_range), 0 = none; read by genie_input_range without synchronising
     // k_stage2_h2u: blocks of adjacent source nodes with the union of their neighbour rows, per launched range [gi_begin, gi_end) of the
     // processing order (the whole grid; the sharded path's four static sub-ranges): built on first use from the host copy of src_tab
     struct S2uTables { void* blocks; int32_t* xcd0; int nblk; };
@@ -1419,6 +1421,13 @@ bool s2h_on(const genie_ctx* c) {
     { static const bool old_pair = getenv("GENIE_S2_OLD") != nullptr; if (old_pair) return false; }   // A/B: row layout + k_stage2_ord
 #endif
     return c->use_fast && sta_order_on(c);
+}
+
+// largest |Slice| / |Mask| entry for which the committed weights keep every hidden state of the f16x2 kernels below the fp16 range: the
+// guard's bound holds for inputs in [-1, 1] and grows at most linearly with them (and the inputs themselves are split into fp16 pieces)
+float input_limit(const genie_ctx* c) {
+    const float lim = 60000.f / std::max(c->range_act, 1.f);
+    return std::max(1.f, std::min(lim, 60000.f));
 }
 
 constexpr int GENIE_NSLOT = 33;  // copies of the G-sized per-window buffers (genie_set_slot): two batches of 16 windows in flight + one
@@ -2113,6 +2122,8 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(gmalloc((void**)&c->packed_s2h, sizeof(float) * S2H_IMG_FLOATS));
         HIP_TRY(gmalloc((void**)&c->d_range, sizeof(float) * (4 + 4 * RG_PART)));
         HIP_TRY(hipHostMalloc((void**)&c->h_range, sizeof(float) * 4));
+        HIP_TRY(hipHostMalloc((void**)&c->h_inflag, 64, hipHostMallocMapped));
+        *c->h_inflag = 0u;
         c->range_ok = true; c->prec_mode = 0;
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
@@ -2432,6 +2443,7 @@ int genie_ctx_destroy(genie_ctx* c) {
                     c->d_s2htbl, c->packed_s2h, c->ea_frag, c->ea_frag_tmp, c->d_range, c->abs_ts, c->abs_tg, c->p_src_of, c->p_sta_of};
     for (void* p : ptrs) (void)gfree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
+    if (c->h_inflag) (void)hipHostFree(c->h_inflag);
     for (auto& kv : c->s2u) { (void)gfree(kv.second.blocks); (void)gfree(kv.second.xcd0); }
     delete c;
     return GENIE_OK;
@@ -2499,7 +2511,7 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (n_tiles) k_stage1<<<da_grid(c, n_tiles, c->bpc1), 256, 0, st>>>(a);
     } else if (c->pcsr && pcsr_h2_on(c) && !(c->abs_sta && c->has_edges)) {      // (both options at once: the generic fp32-MFMA kernel below)
         unsigned* xs = (unsigned*)((float*)ws + c->o_xs);
-        k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr);
+        k_split_rows<<<(unsigned)((c->P + 255) / 256), 256, 0, st>>>(slice, mask, c->P, xs, nullptr, c->S, nullptr, input_limit(c), c->h_inflag);
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P * (long long)XPC;
         const long long nitems = (c->P + 31) / 32;
         const int grid = (int)std::max<long long>(8, std::min<long long>((nitems + H2_THREADS / 64 - 1) / (H2_THREADS / 64), (long long)c->num_cu * c->bpc1b) / 8 * 8);
@@ -2547,10 +2559,12 @@ int run_stage1(genie_ctx* c, const float* slice, const float* mask, float* dbg_h
         if (!presplit) {
             if (sta_order_on(c) && c->S <= SPLIT_G_MAXS) {
                 HIP_TRY(hipFuncSetAttribute((const void*)k_split_rows_g, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_G_MAXS * 32));
-                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw, c->P_ext);
+                k_split_rows_g<<<(unsigned)(c->P_ext / c->S), 256, (size_t)c->S * 32, st>>>(slice, mask, c->S, xs, c->sta_perm, mmw, c->P_ext,
+                                                                                            input_limit(c), c->h_inflag);
             } else
                 k_split_rows<<<(unsigned)((c->P_ext + 255) / 256), 256, 0, st>>>(slice, mask, c->P_ext, xs,
-                                                                                sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw);
+                                                                                sta_order_on(c) ? c->sta_perm : nullptr, c->S, mmw,
+                                                                                input_limit(c), c->h_inflag);
         }
         a.xs = xs; a.packed = c->packed_h2; a.xs_plane = c->P_ext * (long long)XPC;
         a.np = (s2h_on(c) || train_h2u_on(c)) ? 1 : 0;
@@ -4180,6 +4194,19 @@ int genie_stage_precision(genie_ctx* c, int* mode, int* f16x2_active, float* act
     if (f16x2_active) *f16x2_active = (c->pcsr ? pcsr_h2_on(c) : h2_on(c)) ? 1 : 0;
     if (act_bound) *act_bound = c->range_act;
     if (weight_bound) *weight_bound = c->range_w;
+    return GENIE_OK;
+}
+
+int genie_input_range(genie_ctx* c, float* max_seen, float* limit, int reset) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_input_range: null context");
+    if (max_seen) {
+        const unsigned u = c->h_inflag ? *(volatile unsigned*)c->h_inflag : 0u;
+        float f;
+        memcpy(&f, &u, 4);
+        *max_seen = f;
+    }
+    if (limit) *limit = input_limit(c);
+    if (reset && c->h_inflag) *(volatile unsigned*)c->h_inflag = 0u;
     return GENIE_OK;
 }
 

@@ -392,10 +392,25 @@ __global__ void k_pack_h2(const float* __restrict__ raw, const int32_t* __restri
     }
 }
 
+// Input-range check of the f16x2 path (round 5). The fp16 range guard (k_h2_range) bounds the hidden states for inputs in [-1, 1],
+// what the reference's embedding produces; the bound is linear in the input magnitude, so the kernels are valid up to
+// |input| <= x_ok = 60000 / bound (~900 with default-initialised weights). A row beyond that -- not producible by the reference's
+// pipeline, but accepted by its fp32 arithmetic -- would overflow to inf without a trace: the split pass, which touches every input
+// anyway, reports it through a word of host-mapped memory (one system-scope atomic max, executed by offending rows only), which the
+// host reads without synchronising at its next call (genie_input_range): the call fails loudly and the context falls back to the
+// fp32 kernels.
+__device__ __forceinline__ void flag_input_range(const float (&v)[8], float x_ok, unsigned* __restrict__ flag) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                          fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+    if (!(m <= x_ok) && flag != nullptr)          // (also true for NaN)
+        __hip_atomic_fetch_max(flag, __float_as_uint(m == m ? m : __builtin_inff()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // [Slice || Mask] rows (8 fp32) -> 32-B rows of two fp16x8 pieces
 // sta_user (internal station -> caller's station, or null): the rows of a source node are written in the station processing order
 __global__ void k_split_rows(const float* __restrict__ slice, const float* __restrict__ mask, long long rows,
-                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm) {
+                             unsigned* __restrict__ out, const int32_t* __restrict__ sta_user, int S, float* __restrict__ mm,
+                             float x_ok = __builtin_inff(), unsigned* __restrict__ flag = nullptr) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rows) return;
     long long pu = p;
@@ -406,6 +421,7 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
     const f32x4 s = *(const f32x4*)(slice + pu * 4), m = *(const f32x4*)(mask + pu * 4);
     if (mm != nullptr) mm[p] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));            // the message mask of stage 2 (module.py:226)
     const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+    flag_input_range(v, x_ok, flag);
     store_split_row(out, rows, p, v);
 }
 
@@ -414,7 +430,8 @@ __global__ void k_split_rows(const float* __restrict__ slice, const float* __res
 constexpr int SPLIT_G_MAXS = 2048;
 __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ slice, const float* __restrict__ mask, int S,
                                                       unsigned* __restrict__ out, const int32_t* __restrict__ sta_user,
-                                                      float* __restrict__ mm, long long rows) {
+                                                      float* __restrict__ mm, long long rows, float x_ok = __builtin_inff(),
+                                                      unsigned* __restrict__ flag = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float stg[];        // [S][8]: Slice row | Mask row
     const long long base = (long long)blockIdx.x * S;
     for (int r = threadIdx.x; r < S; r += blockDim.x) {
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(256) void k_split_rows_g(const float* __restrict__ 
         const f32x4 s = *(const f32x4*)(stg + u * 8), m = *(const f32x4*)(stg + u * 8 + 4);
         mm[base + r] = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
         const float v[8] = {s.x, s.y, s.z, s.w, m.x, m.y, m.z, m.w};
+        flag_input_range(v, x_ok, flag);
         store_split_row(out, rows, base + r, v);
     }
 }

@@ -133,6 +133,40 @@ class Transport(object):
         self.dist.all_to_all_single(r, send.cpu(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
         recv.copy_(r)
 
+    def halo_p2p_rows(self, recv, send, recv_counts, send_counts, rank, pack=None):
+        """The halo exchange bucketed by destination: one (send, receive) pair per peer this rank really exchanges rows with, the
+        largest transfer first, each pair its own group (`batch_isend_irecv`: on RCCL one fused send / receive per peer = per
+        xGMI link, the pairs independent of each other). `pack(q, view)` fills the send rows of peer q right before that peer's
+        transfer is posted, so the packing of peer q + 1 runs under the transfer of peer q. Same rows in the same places as
+        `all_to_all_rows` (tests/test_dist_cpu.py: both forms over gloo)."""
+        if not self.on:
+            return
+        dist = self.dist
+        so = np.concatenate(([0], np.cumsum(send_counts))).astype(np.int64)
+        ro = np.concatenate(([0], np.cumsum(recv_counts))).astype(np.int64)
+        peers = [q for q in range(len(send_counts)) if q != rank and (send_counts[q] or recv_counts[q])]
+        peers.sort(key=lambda q: -(send_counts[q] + recv_counts[q]))
+        device = self.device_collectives or not send.is_cuda
+        works, staged = [], []
+        for q in peers:
+            sv, rv = send[so[q]:so[q + 1]], recv[ro[q]:ro[q + 1]]
+            if pack is not None and send_counts[q]:
+                pack(q, sv)
+            ops = []
+            if not device:               # process group without device collectives: staged through host memory (test plumbing)
+                sv, rh = sv.cpu(), torch.empty(tuple(rv.shape), dtype=rv.dtype)
+                staged.append((rv, rh))
+                rv = rh
+            if send_counts[q]:
+                ops.append(dist.P2POp(dist.isend, sv, q if self.group is None else dist.get_global_rank(self.group, q), self.group))
+            if recv_counts[q]:
+                ops.append(dist.P2POp(dist.irecv, rv, q if self.group is None else dist.get_global_rank(self.group, q), self.group))
+            works += dist.batch_isend_irecv(ops)
+        for w in works:
+            w.wait()
+        for rv, rh in staged:
+            rv.copy_(rh)
+
     def all_gather_rows(self, out, x):
         """out [world, n, C] <- x [n, C] of every rank."""
         if not self.on:
@@ -146,17 +180,24 @@ class Transport(object):
         out.copy_(torch.stack(parts))
 
 
-def exchange_halo_rows(rows_own, plan, n_sta, group=None):
-    """All-to-all of per-source-node row blocks: `rows_own` [n_own*S, C] -> halo rows [n_halo*S, C] in halo order.
-
-    One `all_to_all_single` (RCCL on GPUs; gloo in the CPU tests): rank r sends, to every peer q, the S-row blocks of
-    its owned nodes that q lists in `need[q][r]`."""
+def exchange_halo_rows(rows_own, plan, n_sta, group=None, mode="a2a"):
+    """Exchange of per-source-node row blocks: `rows_own` [n_own*S, C] -> halo rows [n_halo*S, C] in halo order: rank r sends, to
+    every peer q, the S-row blocks of its owned nodes that q lists in `need[q][r]`. mode "a2a": one `all_to_all_single` with split
+    sizes (RCCL on GPUs; gloo in the CPU tests); "p2p": one send / receive pair per peer, packed per destination
+    (`Transport.halo_p2p_rows`)."""
     C = rows_own.shape[1]
     S = int(n_sta)
     blocks = rows_own.view(plan.n_own, S * C)
+    recv = blocks.new_empty((plan.n_halo, S * C))
+    if mode == "p2p":
+        send = blocks.new_empty((int(sum(plan.send_counts)), S * C))
+        if plan.world > 1:
+            idx = [torch.as_tensor(x.astype(np.int64), device=rows_own.device) for x in plan.send_local]
+            Transport(group, plan.world).halo_p2p_rows(recv, send, plan.recv_counts, plan.send_counts, plan.rank,
+                                                       pack=lambda q, view: torch.index_select(blocks, 0, idx[q], out=view))
+        return recv.view(plan.n_halo * S, C)
     send_idx = torch.as_tensor(np.concatenate(plan.send_local).astype(np.int64), device=rows_own.device)
     send = blocks.index_select(0, send_idx).contiguous() if send_idx.numel() else blocks.new_zeros((0, S * C))
-    recv = blocks.new_empty((plan.n_halo, S * C))
     if plan.world > 1:
         Transport(group, plan.world).all_to_all_rows(recv, send, plan.recv_counts, plan.send_counts)
     return recv.view(plan.n_halo * S, C)
@@ -193,7 +234,7 @@ class ShardedPath(object):
     A/B reference for the overlapped schedule (bit-identical results)."""
 
     def __init__(self, n_sta, n_grid, sta_csr, A_src_src, pos_global, world, rank, device, group=None, scale_rel=30000.0,
-                 pos_sta=None, overlap=True):
+                 pos_sta=None, overlap=True, halo="a2a"):
         from . import engine
         self.group = group
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
@@ -201,6 +242,9 @@ class ShardedPath(object):
         self.plan = ShardPlan(A_src_src, n_grid, world, rank, order)
         p = self.plan
         self.overlap = bool(overlap)
+        if halo not in ("a2a", "p2p"):
+            raise ValueError("halo must be 'a2a' (one all_to_all_single) or 'p2p' (one send / receive pair per peer)")
+        self.halo = halo
         self.local = engine.HipPath(n_sta, p.n_own, sta_csr, (torch.from_numpy(p.src_rowptr), torch.from_numpy(p.src_col)),
                                     n_grid_ext=p.n_ext, grid_order=p.proc_order, scale_rel=scale_rel, device=device,
                                     sta_order=engine.sfc_order(np.asarray(pos_sta)) if pos_sta is not None else None)
@@ -255,9 +299,15 @@ class ShardedPath(object):
                                         # nothing to exchange and the single rank of a world-size-1 group: the RCCL code path of the
                                         # 1-GPU tests and of `bench.py --gpus 1 --mode sharded`)
         blocks = wv[: p.n_own * S].view(p.n_own, S * self._pitch)
+        recv = wv[p.n_own * S:].view(p.n_halo, S * self._pitch)
+        if self.halo == "p2p":       # bucketed by destination: pack of peer q + 1 under the transfer of peer q, largest pair first
+            if getattr(self, "_send_idx_q", None) is None:
+                self._send_idx_q = [torch.as_tensor(x.astype(np.int64), device=self.device) for x in p.send_local]
+            self.transport.halo_p2p_rows(recv, self._send_buf, p.recv_counts, p.send_counts, p.rank,
+                                         pack=lambda q, view: torch.index_select(blocks, 0, self._send_idx_q[q], out=view))
+            return
         if self._send_idx.numel():
             torch.index_select(blocks, 0, self._send_idx, out=self._send_buf)
-        recv = wv[p.n_own * S:].view(p.n_halo, S * self._pitch)
         self.transport.all_to_all_rows(recv, self._send_buf, p.recv_counts, p.send_counts)
 
     def front(self, Slice_ext, Mask_ext, edge_attr_own):

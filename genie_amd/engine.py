@@ -454,9 +454,33 @@ class HipPath(object):
             self.set_weights(view(params) if view is not None else params)
             self._w_key = key
 
+    def input_limit(self):
+        """Largest |Slice| / |Mask| entry the f16x2 kernels are verified for with the weights committed so far (genie_input_range)."""
+        lim = ctypes.c_float(0.0)
+        _lib.check(self.lib.genie_input_range(self.ctx, None, ctypes.byref(lim), 0), "genie_input_range")
+        return float(lim.value)
+
+    def check_input_range(self):
+        """Fail loudly when a split pass of an earlier call met inputs beyond what the fp16 range guard verified (genie_input_range: a
+        word of host-mapped memory, read without synchronising -- it reflects the calls that have completed). The context is switched to
+        the fp32 kernels, which take any input the reference's fp32 arithmetic takes, before the error is raised: the results of the
+        calls issued since the last check are invalid and must be recomputed. Called at the top of every entry point that runs stage 1
+        and by `wait_tails`."""
+        mx, lim = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        _lib.check(self.lib.genie_input_range(self.ctx, ctypes.byref(mx), ctypes.byref(lim), 0), "genie_input_range")
+        if mx.value != 0.0:
+            _lib.check(self.lib.genie_input_range(self.ctx, None, None, 1), "genie_input_range")
+            self.set_stage_precision("f32")
+            raise _lib.GenieHipError(
+                "an earlier call handed the f16x2 stage kernels Slice / Mask entries of magnitude %.6g; the committed weights keep their "
+                "hidden states inside the fp16 range only up to |input| <= %.6g (the reference's embedding produces [-1, 1]). The results "
+                "of the calls issued since the last check are invalid; this context now runs the fp32 kernels (stage_precision 'f32'): "
+                "repeat those calls." % (mx.value, lim.value))
+
     # ---- stages --------------------------------------------------------------------------------
     def da_stage1(self, Slice, Mask, debug=False):
         """Stage 1 (genie_da_stage1). Returns the validated (Slice, Mask) [, h0, h1 when debug]."""
+        self.check_input_range()
         Slice = _f32(Slice, "Slice", (self.n_prod_ext, 4))
         Mask = _f32(Mask, "Mask", (self.n_prod_ext, 4))
         if not debug:
@@ -513,6 +537,7 @@ class HipPath(object):
 
     def path_fwd(self, Slice, Mask, edge_attr, pos, want_x_latent=False, want_bip=False):
         """Fused DataAggregation -> Bipartite_ReadIn -> SpatialAggregation1..3 (module.py:1010-1014)."""
+        self.check_input_range()
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -556,6 +581,7 @@ class HipPath(object):
         bit-identical to `path_fwd` + read-outs. Returns (y, x, done_event); y / x are produced on `self.side_stream` (the
         side stream of THIS window) — consume them there or wait for `done_event`; `wait_tails()` joins all of them. (Measured alternative, rejected: also moving stage 2 to its own stream so that it overlaps the
         next stage 1 — the two P-sized kernels slow each other down more than the overlap gains)"""
+        self.check_input_range()
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -639,6 +665,7 @@ class HipPath(object):
         single-stream calls (`path_fwd`, read-outs) have a slot of their own for the G-sized buffers (PLAIN_SLOT) and may be mixed
         with pending windows ON THE SAME STREAM only: the P-sized c / wu / wv rows exist GENIE_NBIG = 4 times (slot % 4), so a plain
         call shares its copy with the window slots 0, 4, 8, ...; stream order is what keeps them apart."""
+        self.check_input_range()
         P = self.n_prod
         Slice = _f32(Slice, "Slice", (P, 4))
         Mask = _f32(Mask, "Mask", (P, 4))
@@ -725,6 +752,7 @@ class HipPath(object):
 
     def wait_tails(self, stream=None):
         """Make `stream` (default: the current one) wait for every window tail issued so far by `forward_pipelined`."""
+        self.check_input_range()
         stream = stream or torch.cuda.current_stream(self.device)
         for s in getattr(self, "side_streams", None) or ():
             stream.wait_stream(s)
@@ -983,6 +1011,7 @@ class HipPath(object):
     def train_fwd(self, Slice, Mask, edge_attr, want_x_latent=True):
         """Training forward of DataAggregation + the P-sized half of Bipartite_ReadIn (genie_da_train_fwd): returns
         (r [G, 30] = station sums of the gated messages, x_latent [P, 30] or None, save = the pre-activations the backward needs)."""
+        self.check_input_range()
         P = self.n_prod
         Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))
@@ -1023,6 +1052,7 @@ class HipPath(object):
     def path_train_fwd(self, Slice, Mask, edge_attr, pos, x_query, knn_idx, t_query, want_x_latent=False, want_y_latent=False):
         """Training forward of `forward_fixed_source` (genie_da_train_fwd + genie_tail_train_fwd): returns (y [G, T, 1], x [Q, T, 1],
         x_spatial [G, 30] (a view into tsave), y_latent [G, 30] or None, x_latent [P, 30] or None, save, tsave)."""
+        self.check_input_range()
         P = self.n_prod
         Slice, Mask = _f32(Slice, "Slice", (P, 4)), _f32(Mask, "Mask", (P, 4))
         edge_attr = _f32(edge_attr, "edge_attr", (P, 3))

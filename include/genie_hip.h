@@ -124,6 +124,14 @@ int genie_set_stage_precision(genie_ctx* ctx, int mode);
  * largest weight magnitude in the form that is rounded to fp16. Any out pointer may be NULL. Synchronises `stream` when weights
  * were pending (the guard's 16-byte read-back). */
 int genie_stage_precision(genie_ctx* ctx, int* mode, int* f16x2_active, float* act_bound, float* weight_bound, void* stream);
+/* Input range of the f16x2 kernels (round 5). The range guard above holds for inputs in [-1, 1] (process_utils.py:262-275, :610-629: the
+ * only inputs the reference's pipeline produces) and, its bound being linear in the input magnitude, up to |input| <= *limit = 60000 /
+ * act_bound. The split pass of every f16x2 stage-1 call checks the rows it reads and records the largest magnitude BEYOND that limit in a
+ * word of host-mapped memory; this call returns it in *max_seen (0 = every input so far was inside the limit) WITHOUT synchronising: it
+ * reflects the split passes that have completed. reset != 0 clears the word. A caller that sees a non-zero value must discard the
+ * results of the calls issued since its last check and switch to genie_set_stage_precision(ctx, 2) (the Python host does both and
+ * raises). Never set by the fp32 kernels, by the device embedding's split rows (values in [-1, 1] by construction) or in mode 2. */
+int genie_input_range(genie_ctx* ctx, float* max_seen, float* limit, int reset);
 /* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
  * function of the geometry only); the library keeps it in the form stage 2 consumes (two-piece fp16 operand fragments in
  * processing order, 32 B per product node) and uses that in every stage-2 call that is passed this same pointer; any other

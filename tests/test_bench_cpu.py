@@ -58,3 +58,18 @@ def test_bench_refuses_more_ranks_than_visible_gpus_instead_of_hanging():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=REPO)
     assert r.returncode == 2 and "needs 8 visible GPUs" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_dry_run_halo_bytes_at_the_config4_shape_with_eight_ranks():
+    """What the first real 8-GPU run of config 4 (2000 stations / 50 000 source nodes sharded over source nodes) should see on the wire,
+    from the sharding plan alone: the halo of `wv` rows per window is ~55-110 MB inbound per rank (64 B per halo product node), from
+    2-6 peers, the largest single pair ~45 MB = 0.3 ms on one 153-GB/s xGMI link -- against ~4 ms of compute per rank. (DESIGN.md
+    section 6 had guessed 240 MB from a 30 % halo fraction; the space-filling-curve partition needs 7-13 %.) Both exchange forms (one
+    all_to_all_single; one send / receive pair per peer) move the right rows over gloo."""
+    out = _run(["--gpus", "8", "--dry-run-cpu", "--config", "cfg4_2000x50k"])
+    h = out["halo"]
+    assert out["ok"] is True and out["ranks"] == 8 and h["send_recv_consistent"] is True
+    assert h["bytes_per_halo_source_node"] == 2000 * 64.0 and out["rank0_plan"]["n_own"] == 6250
+    assert len(h["MB_in_per_rank"]) == 8 and 30.0 < min(h["MB_in_per_rank"]) and h["MB_in_max"] < 160.0
+    assert 20.0 < h["largest_pair_MB"] < 80.0 and h["largest_pair_ms_at_153_GBs"] < 0.55
+    assert all(1 <= n <= 7 for n in h["peers_per_rank"])

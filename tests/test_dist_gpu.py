@@ -54,8 +54,9 @@ def _worker(rank, world, port, backend, same_gpu, ret):
         refs = [hp.path_fwd(torch.from_numpy(w["Slice"]).to(dev), torch.from_numpy(w["Mask"]).to(dev), ea.to(dev), pos)[0].clone()
                 for w in wins]
         res = {}
-        for overlap in (True, False):
-            sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs, overlap=overlap)
+        for overlap in (True, False, "p2p"):     # "p2p": the overlapped schedule with the halo bucketed by destination (one send / receive pair per peer)
+            sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs, overlap=bool(overlap),
+                                   halo="p2p" if overlap == "p2p" else "a2a")
             sp.set_weights(wd)
             p = sp.plan
             ext = torch.from_numpy(p.ext_global)
@@ -76,7 +77,7 @@ def _worker(rank, world, port, backend, same_gpu, ret):
             torch.cuda.synchronize()
             ok_piped = all(torch.equal(o, r) for o, r in zip(outs, refs))
             res[overlap] = (ok_plain, ok_piped)
-            if overlap:
+            if overlap is True:
                 res["plan"] = (p.n_own, p.n_halo, p.r_send, p.r_need)
         ret[rank] = res
     finally:
@@ -96,6 +97,7 @@ def _run(world, backend, same_gpu):
         assert r_need[1] < n_own, "the test geometry must leave interior nodes for the overlapped stage-2 launch"
         assert r[True] == (True, True), (rank, "overlapped schedule", r[True])
         assert r[False] == (True, True), (rank, "sequential schedule", r[False])
+        assert r["p2p"] == (True, True), (rank, "halo bucketed by destination", r["p2p"])
 
 
 def test_sharded_path_two_processes_on_one_gpu_match_unsharded():

@@ -117,6 +117,53 @@ def test_stage1_piece_range_small_and_large_inputs(scale):
         assert torch.isfinite(got).all() and err <= tol, (k, err, tol)
 
 
+def test_inputs_beyond_the_verified_range_fail_loudly_and_fall_back_to_fp32():
+    """the static fp16 range guard bounds the hidden states for inputs in [-1, 1]; the bound is linear
+    in the input magnitude, so the f16x2 kernels are valid up to |Slice| <= 60000 / bound (genie_input_range). Inputs beyond that --
+    not producible by the reference's embedding, but fine for its fp32 arithmetic -- used to overflow to inf silently. Now the split
+    pass flags them through host-mapped memory: the NEXT entry into the library raises, the context has switched to the fp32
+    kernels, and the repeated call is finite and equal to the oracle. Inputs inside the limit (scale 512: the test above) raise nothing."""
+    from genie_amd import _lib
+    from oracle import genie_oracle as O
+    c = Case("odd_33x257")
+    hp = make_engine(c)
+    Mask = c.Mask.to(DEV)
+    hp.da_stage1(c.Slice.to(DEV), Mask)                      # commits the weights: the limit is known afterwards
+    lim = hp.input_limit()
+    assert 100.0 < lim <= 60000.0
+    hp.check_input_range()                                   # nothing flagged so far
+    big = (c.Slice * (4.0 * lim)).contiguous()
+    hp.da_stage1(big.to(DEV), Mask)                          # f16x2 kernels on out-of-range inputs: flagged by the split pass
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.GenieHipError, match="magnitude"):
+        hp.da_stage1(big.to(DEV), Mask)
+    assert hp.stage_precision()["mode"] == "f32"
+    hp.check_input_range()                                   # the flag was cleared with the error
+    w = {k: v.float() for k, v in c.weights.items()}
+    A_in_sta, A_in_src, _, _ = c.product_edges()
+    ref = O.data_aggregation(w, big, c.Mask, A_in_sta, A_in_src, full=True)
+    hp.da_stage1(big.to(DEV), Mask)                          # the repeated call: fp32 kernels
+    x_latent, _ = hp.da_stage2_bipartite(Mask, c.edge_attr.to(DEV), want_x_latent=True)
+    assert torch.isfinite(x_latent).all()
+    assert max_abs(x_latent.cpu(), ref["x_latent"]) <= 1e-5 * max(1.0, float(ref["x_latent"].abs().max()))
+    # the drop-in class: the error surfaces at the next forward, the one after that succeeds
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+    net.eval()
+    A1, A2, A3, A4 = c.product_edges()
+    ea = graph.GraphEdges(x=c.edge_attr.to(DEV), edge_index=A3.to(DEV))
+    net.set_adjacencies(A1.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), c.A_src_src.to(DEV), None, None, None, None, c.locs.float().to(DEV),
+                        c.x_grid.float().to(DEV))
+    args = (None, None, None, c.locs.float().to(DEV), c.x_grid.float().to(DEV), c.x_query.float().to(DEV), c.t_query.float().to(DEV))
+    with torch.no_grad():
+        net.forward_fixed_source(big.to(DEV), Mask, *args)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.GenieHipError):
+            net.forward_fixed_source(big.to(DEV), Mask, *args)
+        y, x = net.forward_fixed_source(big.to(DEV), Mask, *args)
+    assert torch.isfinite(y).all() and torch.isfinite(x).all()
+
+
 @pytest.mark.parametrize("gains", [(1.0, 1.0, 1.0, 1.0), (64.0, 64.0, 64.0, 64.0), (4096.0, 4096.0, 1.0, 1.0)])
 def test_fp16_range_guard_selects_the_fp32_kernels_without_any_switch(gains):
     """The f16x2 kernels split every hidden state of DataAggregation into fp16 pieces: beyond 65504 they would return inf / NaN
