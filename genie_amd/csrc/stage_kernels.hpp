@@ -654,6 +654,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                 else tp[u] = *(const u32x2*)((const char*)a.abs_tg + (tp_h + (unsigned)row_bcast_dyn(srcv, u - KS) * 16u));
             }
             if (ABL(a, 12) && u > 0) { buf[u] = buf[0]; return; }     // tuning: no neighbour-row loads
+            if (ABL(a, 13) && u >= 1 && u <= KS) { buf[u] = buf[0]; return; }     // tuning bit 13: the station-neighbour units cost nothing (upper bound of ANY caching of them)
             buf[u] = *(const u32x4*)(xs + off);
         };
         const u32x4 own0 = *(const u32x4*)(xs + (gbase0 + sbase0));         // x0 of the own row (lanes h = 1: Mask pads)
@@ -680,10 +681,17 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                 z0 = MFMA32H(fa1, buf[u], z0); z1 = MFMA32H(fa1, buf[u + 1], z1);
                 z0 = MFMA32H(fp0, p0, z0); z1 = MFMA32H(fp0, p1, z1);
             } else {
-                z0 = MFMA32H(fa1, buf[u], biasA); z1 = MFMA32H(fa1, buf[u + 1], biasA);
+                const bool skip0 = ABL(a, 13) && u >= 1 && u <= KS, skip1 = ABL(a, 13) && u + 1 >= 1 && u + 1 <= KS;
+                z0 = biasA; z1 = biasA;
+                if (!skip0) z0 = MFMA32H(fa1, buf[u], biasA);
+                if (!skip1) z1 = MFMA32H(fa1, buf[u + 1], biasA);
+                if (!skip0) z0 = MFMA32H(fa0, buf[u], z0);
+                if (!skip1) z1 = MFMA32H(fa0, buf[u + 1], z1);
             }
+            if (ABS) {
             z0 = MFMA32H(fa0, buf[u], z0);
             z1 = MFMA32H(fa0, buf[u + 1], z1);
+            }
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 f32x16 z = d == 0 ? z0 : z1;
@@ -707,7 +715,23 @@ __global__ __launch_bounds__(H2_THREADS) void k_stage1_h2(DaArgs a) {
                         al = present ? (uu <= KS ? alS : alP) : 0.f;
                         be = present ? (uu <= KS ? beS : beP) : 0.f;
                     }
-                    if (uu == 1 || uu == KS + 1) {
+                    if (ABL(a, 13) && uu <= KS) {
+                        // tuning bit 14 (with 13): what a cache of the station neighbours' rows in LDS would cost instead: address, four
+                        // ds_read_b128 of a 136-B-pitch row picked by the neighbour's station id, sixteen adds (stand-in data: the weight image)
+                        if (uu == 1) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+                        }
+                        if (ABL(a, 14)) {
+                            const unsigned x = ((unsigned)sta_id[uu - 1] * 136u + (unsigned)h * 64u) % 49152u;
+                            const char* lb = (const char*)lw + (x & ~15u);
+#pragma unroll
+                            for (int k4 = 0; k4 < 4; ++k4) {
+                                const f32x4 t = *(const f32x4*)(lb + 16 * k4);
+                                sn[4 * k4] += t.x; sn[4 * k4 + 1] += t.y; sn[4 * k4 + 2] += t.z; sn[4 * k4 + 3] += t.w;
+                            }
+                        }
+                    } else if (uu == 1 || uu == KS + 1) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sn[r] = fmaf(be, __builtin_fabsf(z[r]), al * z[r]);
                     } else {
