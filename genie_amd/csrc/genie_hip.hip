@@ -3489,6 +3489,8 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     { static const char* e = getenv("GENIE_TRABL"); a.abl = e ? atoi(e) : 0; }
 #endif
     const int grid = train_grid(c);
+    // 32-bit row offsets on scalar bases (ldo / sto) while every block of the kept rows lies below 4 GiB
+    const bool o32 = !c->pcsr && (unsigned long long)SV_BLOCKS * (unsigned long long)c->P * 64ull < (1ull << 32);
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
         // k_train_b1 holds one wave per SIMD (442 registers): one workgroup per CU is all that is ever resident
@@ -3500,7 +3502,10 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
             else k_train_b0<true><<<grid, 256, 0, st>>>(a);
         } else {
             if (s == 0) k_train_b2<false><<<grid, 256, 0, st>>>(a);
-            else if (s == 1) k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
+            else if (s == 1) {
+                if (o32) k_train_b1<false, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
+            }
+            else if (o32) k_train_b0<false, true><<<grid, 256, 0, st>>>(a);
             else k_train_b0<false><<<grid, 256, 0, st>>>(a);
         }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
@@ -3856,6 +3861,7 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     }
     a.sv_t = AV_T; a.sv_up = AV_UV; a.sv_vp = AV_UV + 2;
     const int grid = train_grid(c);
+    const bool o32a = !c->pcsr && (unsigned long long)AV_BLOCKS * (unsigned long long)c->P * 64ull < (1ull << 32);      // (20 kept blocks: P < 3.35 M)
     const int tms[4] = {TM_AB3, TM_AB2, TM_AB1, TM_AB0};
     const int pls[4] = {-1, PL_TAB2, PL_TAB1, PL_TAB0};
     for (int s = 0; s < 4; ++s) {
@@ -3869,8 +3875,10 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
             else k_as_b0<true><<<grid, 256, 0, st>>>(a);
         } else {
             if (s == 0) k_as_b3<false><<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
-            else if (s == 1) k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
-            else if (s == 2) k_as_b1<false><<<grid, 256, 0, st>>>(a);
+            else if (s == 1) {
+                if (o32a) k_train_b1<true, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
+            }
+            else if (s == 2) { if (o32a) k_as_b1<false, true><<<grid, 256, 0, st>>>(a); else k_as_b1<false><<<grid, 256, 0, st>>>(a); }
             else k_as_b0<false><<<grid, 256, 0, st>>>(a);
         }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
 // ---- layer 1, l1_t1_1 / l1_t2_1 and the activation of init_trns
 // accumulators: l1_t1_2 {2 x (tr x2, Mask), adjoint 2 x 2} = 10, l1_t2_2 = 10, l1_t1_1 (2 x 2) = 4, l1_t2_1 = 4  -> 28
 // vec: b(l1_t1_2) x2, b(l1_t2_2) x2, mask1 column of l1_t1_2 x2, of l1_t2_2 x2, b(l1_t1_1) x2, b(l1_t2_1) x2 = 12; scal: a, a11, a12
-template <bool PCSR>
+template <bool PCSR, bool O32 = false>      // O32: rows addressed by 32-bit offsets on scalar bases (ldo / sto, train_front_kernels.hpp; 20 x P x 64 B < 4 GiB)
 __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
+    static_assert(!(PCSR && O32), "32-bit row offsets: Cartesian product graphs only");
     constexpr int NF4 = (GA1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
     __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
     for (int k = 0; k < 28; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 12; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned q16 = 16u * (unsigned)q, P64 = (unsigned)P * 64u;
+    const unsigned long long grb = sbase(a.gr), svb = sbase(a.save);
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
@@ -127,16 +130,25 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
         if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
         const float* gr = a.gr;
         f32x4 zt[2], tr[2], qp[2][2], dt[4], tmd1[2], tmd2[2];
+        const unsigned pofs = (unsigned)p * 64u + q16;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            zt[b] = ldb(a.save, AV_TR + b, P, p, q);
+            zt[b] = O32 ? ldo(svb, (unsigned)(AV_TR + b) * P64 + pofs) : ldb(a.save, AV_TR + b, P, p, q);
             tr[b] = prelu4u(zt[b], a0);
-            qp[0][b] = ldb(a.save, AV_Q + b, P, p, q);
-            qp[1][b] = ldb(a.save, AV_Q + 2 + b, P, p, q);
+            qp[0][b] = O32 ? ldo(svb, (unsigned)(AV_Q + b) * P64 + pofs) : ldb(a.save, AV_Q + b, P, p, q);
+            qp[1][b] = O32 ? ldo(svb, (unsigned)(AV_Q + 2 + b) * P64 + pofs) : ldb(a.save, AV_Q + 2 + b, P, p, q);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);       // (own rows requested before the gathers)
-        if (PCSR) {      // reversed PRODUCT-level graphs, rows by product-node id
+        for (int k = 0; k < 4; ++k) dt[k] = O32 ? ldo(grb, (unsigned)(GR_DT + k) * P64 + pofs) : ldb(a.gr, GR_DT + k, P, p, q);       // (own rows requested before the gathers)
+        if (O32) {       // one vector instruction per gathered row (as in k_train_b0<false, true>)
+            const unsigned gs64 = (unsigned)(g * S) * 64u, S64 = (unsigned)S * 64u;
+            const unsigned vs0 = (unsigned)(GR_DT + 0) * P64 + gs64 + q16, vs1 = (unsigned)(GR_DT + 1) * P64 + gs64 + q16;
+            const unsigned vg0 = (unsigned)(GR_DT + 2) * P64 + (unsigned)scn * 64u + q16, vg1 = (unsigned)(GR_DT + 3) * P64 + (unsigned)scn * 64u + q16;
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                               [&](int b, int c) { return ldo(grb, (b == 0 ? vs0 : vs1) + ((unsigned)c << 6)); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                                [&](int b, int c) { return ldo(grb, __umul24((unsigned)c, S64) + (b == 0 ? vg0 : vg1)); }, tmd2);
+        } else if (PCSR) {      // reversed PRODUCT-level graphs, rows by product-node id
             tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
             tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
         } else {
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
         // d tr = node-local part (pass before) + l1_t1_1^T d q1-pre + l1_t2_1^T d q2-pre; through the activation of init_trns
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            f32x4 d = ldb(a.gr, GR_DH0 + b, P, p, q) * vm;
+            f32x4 d = (O32 ? ldo(grb, (unsigned)(GR_DH0 + b) * P64 + pofs) : ldb(a.gr, GR_DH0 + b, P, p, q)) * vm;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 d = mma_block(d, lw[GA1_L(0, b, k) * 64 + lane], dqp[0][k]);
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
             }
             scal[0] += negsum4(d, zt[b]);
             const f32x4 dz = d * dprelu4(zt[b], a0);
-            if (valid) stb(a.gr, GR_DTRP + b, P, p, q, dz);
+            if (valid) { if (O32) sto(grb, (unsigned)(GR_DTRP + b) * P64 + pofs, dz); else stb(a.gr, GR_DTRP + b, P, p, q, dz); }
         }
         vec[0] += dt[0]; vec[1] += dt[1]; vec[2] += dt[2]; vec[3] += dt[3];
         vec[4] += dt[0] * m1; vec[5] += dt[1] * m1; vec[6] += dt[2] * m1; vec[7] += dt[3] * m1;

@@ -50,6 +50,23 @@ __device__ __forceinline__ f32x4 ldb(const float* buf, int blk, long long P, lon
 __device__ __forceinline__ void stb(float* buf, int blk, long long P, long long p, int q, f32x4 v) {
     *(f32x4*)(buf + ((size_t)blk * P + p) * 16 + 4 * q) = v;
 }
+// The same rows addressed as `global_load v, voffset, s[base]`: the buffer's base stays a scalar register pair and the byte offset
+// (block x P x 64 + row x 64 + 16 q) is ONE 32-bit vector value, where `ldb` made the compiler build a 64-bit address per load (a shift, a
+// 64-bit multiply-add and a 64-bit add: a third of the backward passes' vector instructions were address arithmetic, and these passes are
+// bound by their vector-instruction stream: DESIGN.md section 5, round 5). Valid while every block offset fits 32 bits (O32 launches:
+// 14 x P x 64 B < 4 GiB, i.e. P < 4.79 M product nodes; config 3 has 2 M).
+typedef const __attribute__((address_space(1))) char* gbyte_p;
+typedef const __attribute__((address_space(1))) f32x4* grow_p;
+typedef __attribute__((address_space(1))) f32x4* groww_p;
+__device__ __forceinline__ unsigned long long sbase(const void* b) {
+    unsigned long long r = (unsigned long long)b;
+    asm volatile("" : "+s"(r));
+    return r;
+}
+__device__ __forceinline__ f32x4 ldo(unsigned long long base, unsigned off) { return *(grow_p)((gbyte_p)base + off); }
+__device__ __forceinline__ void sto(unsigned long long base, unsigned off, f32x4 v) {
+    *(groww_p)((__attribute__((address_space(1))) char*)base + off) = v;
+}
 __device__ __forceinline__ f32x4 dprelu4(f32x4 x, float s) {     // PReLU'(x): 1 for x > 0, the slope otherwise
     return f32x4{x.x > 0.f ? 1.f : s, x.y > 0.f ? 1.f : s, x.z > 0.f ? 1.f : s, x.w > 0.f ? 1.f : s};
 }
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
 #define TPH_START()
 #define TPH_MARK(k)
 #endif
-template <bool AS>
+template <bool AS, bool O32 = false>      // O32: rows addressed by 32-bit offsets on scalar bases (ldo / sto; P < 4.79 M)
 __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
@@ -334,6 +351,9 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     struct Rp { int s0, s1, g0, g1; };
     struct Own { f32x4 mb, do1, do2, t[4], up[2], vp[2]; };       // the node's own rows: Mask, do, the kept pre-activations
     const float* gr = a.gr;
+    const unsigned q16 = 16u * (unsigned)q, P64 = (unsigned)P * 64u, S64 = (unsigned)S * 64u;
+    const unsigned long long grb = sbase(a.gr), svb = sbase(a.save);
+    const unsigned oDO0 = (unsigned)(GR_DO + 0) * P64, oDO1 = (unsigned)(GR_DO + 1) * P64;
     auto tile_of = [&](long long it) {
         int gi, tb;
         w.decode(it < w.nitems ? it : w.it, gi, tb);               // past the end: the current tile again (loads nobody uses)
@@ -352,6 +372,15 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
         const long long p_ = (long long)t.g * S + t.scn;
         o.mb = f32x4{0.f, 0.f, 0.f, 0.f};
         if (q == 0) o.mb = *(const f32x4*)(a.mask + p_ * 4);
+        if (O32) {
+            const unsigned po = (unsigned)p_ * 64u + q16;
+            o.do1 = ldo(grb, oDO0 + po); o.do2 = ldo(grb, oDO1 + po);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.t[k] = ldo(svb, (unsigned)(SVT + k) * P64 + po);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { o.up[b] = ldo(svb, (unsigned)(SVU + b) * P64 + po); o.vp[b] = ldo(svb, (unsigned)(SVV + b) * P64 + po); }
+            return;
+        }
         o.do1 = ldb(a.gr, GR_DO + 0, P, p_, q); o.do2 = ldb(a.gr, GR_DO + 1, P, p_, q);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o.t[k] = ldb(a.save, SVT + k, P, p_, q);
@@ -359,6 +388,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
         for (int b = 0; b < 2; ++b) { o.up[b] = ldb(a.save, SVU + b, P, p_, q); o.vp[b] = ldb(a.save, SVV + b, P, p_, q); }
     };
     auto rows_issue = [&](const Tile& t, const NbrIdx<EBS>& xs, const NbrIdx<EBG>& xg, f32x4 (&rs)[EBS], f32x4 (&rg)[EBG]) {
+        if (O32) {      // station rows of this source node: v_lshl_add_u32 per row; this station's row of another source node: scalar row base + one add
+            const unsigned vs = oDO0 + (unsigned)(t.g * S) * 64u + q16, vg = oDO1 + (unsigned)t.scn * 64u + q16;
+#pragma unroll
+            for (int k = 0; k < EBS; ++k) rs[k] = ldo(grb, vs + ((unsigned)xs.c[k] << 6));
+#pragma unroll
+            for (int k = 0; k < EBG; ++k) rg[k] = ldo(grb, (unsigned)xg.c[k] * S64 + vg);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < EBS; ++k) rs[k] = ldb(gr, GR_DO + 0, P, (long long)t.g * S + xs.c[k], q);
 #pragma unroll
@@ -372,8 +409,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
 #pragma unroll
         for (int k = 0; k < EBG; ++k) tmg[0] += rg[k] * xg.w[k];
         const int g_ = t.g, scn_ = t.scn;
-        tmean_rest<1, 8>(a.r_sta_cw, xs.e_next, xs.e_end, false, [&](int, int c) { return ldb(gr, GR_DO + 0, P, (long long)g_ * S + c, q); }, tms);
-        tmean_rest<1, 8>(a.r_src_cw, xg.e_next, xg.e_end, true, [&](int, int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn_, q); }, tmg);
+        if (O32) {
+            const unsigned vs = oDO0 + (unsigned)(g_ * S) * 64u + q16, vg = oDO1 + (unsigned)scn_ * 64u + q16;
+            tmean_rest<1, 8>(a.r_sta_cw, xs.e_next, xs.e_end, false, [&](int, int c) { return ldo(grb, vs + ((unsigned)c << 6)); }, tms);
+            tmean_rest<1, 8>(a.r_src_cw, xg.e_next, xg.e_end, true, [&](int, int c) { return ldo(grb, (unsigned)c * S64 + vg); }, tmg);
+        } else {
+            tmean_rest<1, 8>(a.r_sta_cw, xs.e_next, xs.e_end, false, [&](int, int c) { return ldb(gr, GR_DO + 0, P, (long long)g_ * S + c, q); }, tms);
+            tmean_rest<1, 8>(a.r_src_cw, xg.e_next, xg.e_end, true, [&](int, int c) { return ldb(gr, GR_DO + 1, P, (long long)c * S + scn_, q); }, tmg);
+        }
         const float vm_ = t.valid ? 1.f : 0.f;
         tm1 = tms[0] * vm_; tm2 = tmg[0] * vm_;
     };
@@ -458,14 +501,14 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
 #if GENIE_TUNING
             if (a.abl & 8) { if (dt[hb].x == 1.2345f) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]); continue; }
 #endif
-            if (valid) stb(a.gr, GR_DT + hb, P, p, q, dt[hb]);
+            if (valid) { if (O32) sto(grb, (unsigned)(GR_DT + hb) * P64 + (unsigned)p * 64u + q16, dt[hb]); else stb(a.gr, GR_DT + hb, P, p, q, dt[hb]); }
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(b, k) * 64 + lane], dt[k]);
-            if (valid) stb(a.gr, GR_DH0 + b, P, p, q, d);
+            if (valid) { if (O32) sto(grb, (unsigned)(GR_DH0 + b) * P64 + (unsigned)p * 64u + q16, d); else stb(a.gr, GR_DH0 + b, P, p, q, d); }
         }
         vec[0] += do1; vec[1] += do2;
         vec[2] += du[0]; vec[3] += du[1]; vec[4] += dv[0]; vec[5] += dv[1];
@@ -637,8 +680,10 @@ __global__ __launch_bounds__(256, 1) void k_train_b1p(TrArgs a) {
 // ---- pass 0': layer 1 and init_trns.
 // accumulators: init_trns (2 x [Slice || Mask]) = 2; l1_t1_2 {2 x (h0 x2, Mask), adjoint 2 x 2} = 10; l1_t2_2 = 10  -> 22
 // vec: b(init_trns) x2, b(l1_t1_2) x2, b(l1_t2_2) x2 = 6; scal: a, a11, a12
-template <bool PCSR>
+// O32 (Cartesian graphs, P < 4.79 M): rows addressed by 32-bit offsets on scalar bases (ldo / sto)
+template <bool PCSR, bool O32 = false>
 __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
+    static_assert(!(PCSR && O32), "32-bit row offsets: Cartesian product graphs only");
     constexpr int NF4 = (GT0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
     __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
@@ -658,6 +703,8 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
     for (int k = 0; k < 22; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 6; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned q16 = 16u * (unsigned)q, P64 = (unsigned)P * 64u;
+    const unsigned long long grb = sbase(a.gr), svb = sbase(a.save);
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
@@ -685,11 +732,23 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
         if (q == 1) xm = *(const f32x4*)(a.mask + p * 4);
         const float* gr = a.gr;
         f32x4 z0[2], h0[2], dt[4], tmd1[2], tmd2[2];
+        const unsigned pofs = (unsigned)p * 64u + q16;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) z0[b] = ldb(a.save, SV_Z0 + b, P, p, q);
+        for (int b = 0; b < 2; ++b) z0[b] = O32 ? ldo(svb, (unsigned)(SV_Z0 + b) * P64 + pofs) : ldb(a.save, SV_Z0 + b, P, p, q);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = ldb(a.gr, GR_DT + k, P, p, q);      // (own rows requested before the gathers, not after)
-        if (PCSR) {
+        for (int k = 0; k < 4; ++k) dt[k] = O32 ? ldo(grb, (unsigned)(GR_DT + k) * P64 + pofs) : ldb(a.gr, GR_DT + k, P, p, q);      // (own rows requested before the gathers, not after)
+        if (O32) {
+            // one vector instruction per gathered row: v_lshl_add_u32 (station rows of this source node) / v_mad_u32_u24 (this station's row
+            // of another source node) on per-tile offsets that already hold the block, the tile's own coordinate and the lane's 16 q
+            const unsigned gs64 = (unsigned)(g * S) * 64u;
+            const unsigned vs0 = (unsigned)(GR_DT + 0) * P64 + gs64 + q16, vs1 = (unsigned)(GR_DT + 1) * P64 + gs64 + q16;
+            const unsigned vg0 = (unsigned)(GR_DT + 2) * P64 + (unsigned)scn * 64u + q16, vg1 = (unsigned)(GR_DT + 3) * P64 + (unsigned)scn * 64u + q16;
+            const unsigned S64 = (unsigned)S * 64u;
+            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                               [&](int b, int c) { return ldo(grb, (b == 0 ? vs0 : vs1) + ((unsigned)c << 6)); }, tmd1);
+            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                                [&](int b, int c) { return ldo(grb, __umul24((unsigned)c, S64) + (b == 0 ? vg0 : vg1)); }, tmd2);
+        } else if (PCSR) {
             tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
             tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
         } else {
@@ -713,7 +772,8 @@ __global__ __launch_bounds__(256, 1) void k_train_b0(TrArgs a) {
             }
             scal[1] += negsum4(dq1, h0[b]);
             scal[2] += negsum4(dq2, h0[b]);
-            const f32x4 dh0 = ldb(a.gr, GR_DH0 + b, P, p, q) * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
+            const f32x4 dh0l = O32 ? ldo(grb, (unsigned)(GR_DH0 + b) * P64 + pofs) : ldb(a.gr, GR_DH0 + b, P, p, q);
+            const f32x4 dh0 = dh0l * vm + dq1 * dprelu4(h0[b], a11) + dq2 * dprelu4(h0[b], a12);
             scal[0] += negsum4(dh0, z0[b]);
             dz0[b] = dh0 * dprelu4(z0[b], a0);
             if (a.store_dz0 && valid) stb(a.gr, GR_DH0 + b, P, p, q, dz0[b]);
