@@ -287,7 +287,7 @@ def day_loops_leg(net, geom, dev, n_sources=8, n_rand_query=112000):
     kw = dict(kernel_sig_t=sig, dt_embed=0.3)
     refine = lambda: apply.refine_sources([leg], picks, srcs, geom.locs, geom.t_query, max_t, np.array([[-15e3, -15e3, -7.5e3]]),
                                           np.array([[30e3, 30e3, 15e3]]), n_rand_query, ident, ident, (0.0, L), (0.0, L), (-40e3, 2e3),
-                                          rand=np.random.RandomState(3).rand, **kw)
+                                          rand=np.random.RandomState(3).rand, ftrns2_device=ident, **kw)
     refine()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -310,8 +310,8 @@ def day_loops_leg(net, geom, dev, n_sources=8, n_rand_query=112000):
             "refine_max_value": round(float(refined[:, 4].max()), 4),
             "association_ms_per_source": round(t_as / n_sources * 1e3, 3), "picks_per_window": round(float(np.mean([len(x) for x in Save_picks])), 1),
             "picks_above_0.1": n_assoc,
-            "note": "refine: device embedding + kNN of the query cloud (genie_knn) + forward_fixed_source + argmax per source, one host copy at the "
-                    "end; association: device embedding + pick lists (ResidentPicks.pick_inputs) + forward_fixed per source; Out_p_save / "
+            "note": "refine: query cloud on the device (host draw; `ftrns2_device`), device embedding + kNN of the cloud (genie_knn) + "
+                    "forward_fixed_source + argmax per source, one host copy at the end; association: device embedding + pick lists (ResidentPicks.pick_inputs) + forward_fixed per source; Out_p_save / "
                     "Out_s_save stay on the device"}
 
 

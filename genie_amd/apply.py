@@ -336,7 +336,7 @@ def _dt_embed(kernel_sig_t, dt_embed):
 
 
 def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offset_range, n_rand_query, ftrns1, ftrns2,
-                   lat_range, lon_range, depth_range, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, rand=None):
+                   lat_range, lon_range, depth_range, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, rand=None, ftrns2_device=None):
     """The refine pass of the caller (process_continuous_days.py:926-980) on the device: for every candidate source `srcs[i]` = (lat, lon,
     depth, origin time, value) a cloud of `n_rand_query` random queries around it (`ftrns1(src) + rand(n, 3) * X_offset_range +
     X_offset_min`, kept where `ftrns2` of it lies strictly inside the three ranges, :929-936), one `forward_fixed_source` per grid
@@ -345,7 +345,11 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
     (`argmax` of the row maxima, then of that row, :976-978: first maximum in both). Sources whose window holds no pick keep an all-zero
     read-out (:966-967), i.e. their first query and `tq[0]`. Returns (srcs_refined float64 [n, 5] sorted by origin time (:981-982),
     `order` = that sort's permutation of the input rows). `rand(n, 3)` defaults to `np.random.rand` (the reference's draw); the
-    per-source results stay on the device until one copy at the end."""
+    per-source results stay on the device until one copy at the end. `ftrns2_device`: the inverse transform as a function of a float64
+    GPU tensor [n, 3] (the reference also carries torch forms of its transforms, `ftrns2_diff`): the cloud's arithmetic, the region
+    filter and the float32 rounding then run on the device in float64 -- the same values as the numpy path, whose 112 000 x 3 float64
+    temporaries per source otherwise make the pass host-bound (37 ms per source at config 2 against ~6 ms of GPU work) -- and only the
+    refined source's own query is transformed back on the host."""
     rand = rand or np.random.rand
     srcs = np.asarray(srcs, dtype=np.float64)
     tq_host = np.asarray(tq.detach().cpu() if torch.is_tensor(tq) else tq, dtype=np.float64).reshape(-1)
@@ -357,13 +361,25 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
     clouds, found = [], []
     with torch.no_grad():
         for i in range(srcs.shape[0]):
-            Xc = ftrns1(srcs[i, 0:3].reshape(1, -1)) + (rand(n_rand_query, 3) * X_offset_range + X_offset_min)      # :929
-            X1 = ftrns2(Xc)
-            inside = np.where((X1[:, 0] > lat_range[0]) * (X1[:, 0] < lat_range[1]) * (X1[:, 1] > lon_range[0]) * (X1[:, 1] < lon_range[1])
-                              * (X1[:, 2] > depth_range[0]) * (X1[:, 2] < depth_range[1]))[0]
-            X1, Xc = X1[inside], Xc[inside]
-            clouds.append(X1)
-            xq = torch.from_numpy(np.ascontiguousarray(Xc)).to(dev).float()                                           # torch.Tensor(...) :934 (rounded on the device)
+            if ftrns2_device is not None:
+                r = torch.from_numpy(np.ascontiguousarray(rand(n_rand_query, 3))).to(dev)                               # the host's draw, float64
+                Xc_d = (torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[i, 0:3].reshape(1, -1)))).to(dev)
+                        + (r * torch.as_tensor(np.asarray(X_offset_range, dtype=np.float64).reshape(1, 3), device=dev)
+                           + torch.as_tensor(np.asarray(X_offset_min, dtype=np.float64).reshape(1, 3), device=dev)))           # :929
+                X1_d = ftrns2_device(Xc_d)
+                keep = ((X1_d[:, 0] > lat_range[0]) & (X1_d[:, 0] < lat_range[1]) & (X1_d[:, 1] > lon_range[0]) & (X1_d[:, 1] < lon_range[1])
+                        & (X1_d[:, 2] > depth_range[0]) & (X1_d[:, 2] < depth_range[1]))
+                Xc_d = Xc_d[keep]
+                clouds.append(Xc_d)                                   # (Cartesian, on the device: transformed back for the one refined query)
+                xq = Xc_d.float()
+            else:
+                Xc = ftrns1(srcs[i, 0:3].reshape(1, -1)) + (rand(n_rand_query, 3) * X_offset_range + X_offset_min)      # :929
+                X1 = ftrns2(Xc)
+                inside = np.where((X1[:, 0] > lat_range[0]) * (X1[:, 0] < lat_range[1]) * (X1[:, 1] > lon_range[0]) * (X1[:, 1] < lon_range[1])
+                                  * (X1[:, 2] > depth_range[0]) * (X1[:, 2] < depth_range[1]))[0]
+                X1, Xc = X1[inside], Xc[inside]
+                clouds.append(X1)
+                xq = torch.from_numpy(np.ascontiguousarray(Xc)).to(dev).float()                                       # torch.Tensor(...) :934 (rounded on the device)
             acc = torch.zeros((xq.shape[0], tq_host.shape[0]), dtype=torch.float32, device=dev)
             if xq.shape[0]:
                 for leg in legs:
@@ -384,7 +400,7 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
         if clouds[i].shape[0] == 0:
             raise ValueError("refine_sources: no query of source %d lies inside the region (the reference's argmax raises here too)" % i)
         ip, it = int(found[i, 0]), int(found[i, 1])
-        out[i, 0:3] = clouds[i][ip]
+        out[i, 0:3] = ftrns2(clouds[i][ip:ip + 1].cpu().numpy())[0] if torch.is_tensor(clouds[i]) else clouds[i][ip]
         out[i, 3] = srcs[i, 3] + tq_host[it]
         out[i, 4] = found[i, 2]
     order = np.argsort(out[:, 3])

@@ -108,6 +108,10 @@ def test_refine_pass_matches_the_oracle_chain():
     got, order = apply.refine_sources([s.leg], s.picks, srcs, s.locs, s.tq, s.max_t, off_min, off_rng, 300, ident, ident, *ranges,
                                       kernel_sig_t=s.sig, dt_embed=s.dt, rand=np.random.RandomState(77).rand)
     assert got.shape == (6, 5) and np.all(np.diff(got[:, 3]) >= 0)
+    # the same pass with the cloud's arithmetic on the device (`ftrns2_device`): the same refined sources, bit for bit
+    got_d, order_d = apply.refine_sources([s.leg], s.picks, srcs, s.locs, s.tq, s.max_t, off_min, off_rng, 300, ident, ident, *ranges,
+                                          kernel_sig_t=s.sig, dt_embed=s.dt, rand=np.random.RandomState(77).rand, ftrns2_device=ident)
+    assert np.array_equal(order, order_d) and np.array_equal(got, got_d)
     rs = np.random.RandomState(77)
     sta_nbr, src_nbr = graph.neighbour_table(s.A_sta_sta, s.S), graph.neighbour_table(ga.A_src_src, s.G)
     n_out = 0
