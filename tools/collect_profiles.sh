@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 python /root/repo/bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 rm -rf /tmp/kt
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-cfg4-one-gpu --no-live-traffic --no-stream > /tmp/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-cfg4-one-gpu --no-live-traffic --no-stream --no-day-loops > /tmp/kt.log 2>&1
 grep "^{" /tmp/kt.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 DB=$(find /tmp/kt -name "*.db" | head -1)
 python /root/repo/tools/prof_summary.py $DB 24 > $OUT/${TAG}_kernel_stats.txt
