@@ -100,10 +100,10 @@ int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 struct DevPool {
     std::multimap<size_t, void*> free_;
-    std::map<void*, size_t> size_;
     size_t cached = 0;
 };
 std::map<int, DevPool> g_pools;
+std::map<void*, std::pair<int, size_t>> g_pool_blocks;      // every block the pool handed out: (device, size class)
 std::mutex g_pool_mutex;
 constexpr size_t POOL_CAP = (size_t)3 << 30;
 
@@ -136,28 +136,27 @@ hipError_t gmalloc(void** p, size_t bytes) {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         DevPool& P = g_pools[dev];
         (void)hipDeviceSynchronize();
-        for (auto& kv : P.free_) { P.size_.erase(kv.second); (void)hipFree(kv.second); }
+        for (auto& kv : P.free_) { g_pool_blocks.erase(kv.second); (void)hipFree(kv.second); }
         P.free_.clear(); P.cached = 0;
         e = hipMalloc(p, cls);
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    g_pools[dev].size_[*p] = cls;
+    g_pool_blocks[*p] = std::make_pair(dev, cls);
     return hipSuccess;
 }
 template <typename T> hipError_t gmalloc(T** p, size_t bytes) { return gmalloc((void**)p, bytes); }
 
 hipError_t gfree(void* p) {         // the caller guarantees that no launched work still uses the block
     if (!p) return hipSuccess;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    DevPool& P = g_pools[dev];
-    auto it = P.size_.find(p);
-    if (it == P.size_.end()) return hipFree(p);
-    if (P.cached + it->second > POOL_CAP) { P.size_.erase(it); return hipFree(p); }
-    P.free_.emplace(it->second, p);
-    P.cached += it->second;
+    auto it = g_pool_blocks.find(p);
+    if (it == g_pool_blocks.end()) return hipFree(p);
+    DevPool& P = g_pools[it->second.first];          // the pool of the device the block lives on, whatever the current device is
+    const size_t cls = it->second.second;
+    if (P.cached + cls > POOL_CAP) { g_pool_blocks.erase(it); return hipFree(p); }
+    P.free_.emplace(cls, p);
+    P.cached += cls;
     return hipSuccess;
 }
 
@@ -1327,6 +1326,7 @@ struct genie_ctx {
     float* ea_tmp;             // ... of an edge_attr that is not the registered one (permuted per call)
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_h2 (null unless kp_uni == 15)
     float* packed_h2;          // f16x2 weight image of k_stage1_h2
+    int device = 0;            // the HIP device the context was created on (genie_ctx_destroy drains THAT device)
     int num_cu;
     int seg, bpc1, bpc2;       // sweep segments (env GENIE_SEG), workgroups per CU of the generic stage kernels
     int ks_uni, kp_uni;        // uniform in-degree of the station / source graph, -1 when ragged
@@ -2155,6 +2155,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
     c->dirty = true;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    c->device = dev;
     {   // (hipGetDeviceProperties fills a 1.5-KB struct through the driver: once per device and process)
         static std::map<int, int> cus;
         static std::mutex mu;
@@ -2419,6 +2420,9 @@ int genie_set_slot(genie_ctx* c, int slot) {
 
 int genie_ctx_destroy(genie_ctx* c) {
     if (!c) return GENIE_OK;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != c->device) (void)hipSetDevice(c->device);      // (a Python finaliser may run with another device current)
     (void)hipDeviceSynchronize();        // one drain for every block below: the pool hands them out again without one
     (void)gfree(c->d_packplans);
     if (c->tables_shared) {
@@ -2445,6 +2449,7 @@ int genie_ctx_destroy(genie_ctx* c) {
     if (c->h_range) (void)hipHostFree(c->h_range);
     if (c->h_inflag) (void)hipHostFree(c->h_inflag);
     for (auto& kv : c->s2u) { (void)gfree(kv.second.blocks); (void)gfree(kv.second.xcd0); }
+    if (cur != c->device) (void)hipSetDevice(cur);
     delete c;
     return GENIE_OK;
 }
@@ -2954,8 +2959,31 @@ int genie_path_fwd(genie_ctx* c, const float* slice, const float* mask, const fl
     float* w = (float*)ws;
     float* bip = bip_out ? bip_out : w + c->o_bip + c->slot * c->slot_stride;
     if ((rc = genie_da_stage1(c, slice, mask, ws, stream))) return rc;
-    if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
-    return genie_spatial_agg3_fwd(c, bip, pos, x_spatial_out, ws, stream);
+    if (c->G_ext != c->G) {
+        if ((rc = genie_da_stage2_bipartite(c, mask, edge_attr, x_latent_out, bip, ws, stream))) return rc;
+        return genie_spatial_agg3_fwd(c, bip, pos, x_spatial_out, ws, stream);
+    }
+    // the Bipartite read-out and the pre-pass of SpatialAggregation1 in ONE launch (k_bip_pre_m, the batched tail's first kernel:
+    // the same MFMA chains, bitwise equal results), then the three layers: one launch less on the literal call's critical path
+    if ((rc = genie_da_stage2_partials(c, mask, edge_attr, x_latent_out, ws, stream))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_packed(c, st))) return rc;
+    const size_t so = c->slot * c->slot_stride;
+    {
+        SaArgs a;
+        memset(&a, 0, sizeof(a));
+        sa_fill_layer(c, 1, a);
+        a.out = bip;
+        a.pj_out = w + c->o_pj0 + so; a.gpart_out = w + c->o_gpart + so;
+        a.img = c->packed[PL_SA1];
+        const int nb = sa_blocks(c);
+        if (tail_wide(c)) k_bip_pre_m<true><<<nb, 256, 0, st>>>(w + c->o_part + so, part_T(c), c->packed[PL_BIP], 0, a);
+        else k_bip_pre_m<false><<<nb, 256, 0, st>>>(w + c->o_part + so, part_T(c), c->packed[PL_BIP], 0, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if ((rc = sa_launch_layer(c, 1, bip, pos, w + c->o_sa0 + so, w, 0, true, st))) return rc;
+    if ((rc = sa_launch_layer(c, 2, w + c->o_sa0 + so, pos, w + c->o_sa1 + so, w, 1, true, st))) return rc;
+    return sa_launch_layer(c, 3, w + c->o_sa1 + so, pos, x_spatial_out, w, 0, false, st);
 }
 
 namespace {
