@@ -1326,6 +1326,8 @@ struct genie_ctx {
     float* ea_tmp;             // ... of an edge_attr that is not the registered one (permuted per call)
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_h2 (null unless kp_uni == 15)
     float* packed_h2;          // f16x2 weight image of k_stage1_h2
+    hipStream_t side_stream = nullptr;      // fork / join inside one call (genie_tail_train_bwd: the grid branch beside the query branch)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = 0;            // the HIP device the context was created on (genie_ctx_destroy drains THAT device)
     int num_cu;
     int seg, bpc1, bpc2;       // sweep segments (env GENIE_SEG), workgroups per CU of the generic stage kernels
@@ -2448,6 +2450,9 @@ int genie_ctx_destroy(genie_ctx* c) {
     for (void* p : ptrs) (void)gfree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
     if (c->h_inflag) (void)hipHostFree(c->h_inflag);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& kv : c->s2u) { (void)gfree(kv.second.blocks); (void)gfree(kv.second.xcd0); }
     if (cur != c->device) (void)hipSetDevice(cur);
     delete c;
@@ -3554,7 +3559,7 @@ constexpr int TT_R = 0, TT_BIP = 32, TT_SA1 = 48, TT_SA2 = 80, TT_XS = 112, TT_R
 int tt_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, 160)); }
 size_t tt_part_floats(int n_acc, int n_vec, int grid) { return (size_t)grid * 4 * ((size_t)n_acc * 256 + (size_t)n_vec * 16 + 16); }
 struct TtScratch {           // offsets (floats) into the backward's scratch
-    size_t dxs_a, dxs_b, eb, dxm, cv, pj, gpart, dxd, dan, dx0, dx1, part_ro, part_a, part_b, total;
+    size_t dxs_a, dxs_b, eb, dxm, cv, pj, gpart, dxd, dan, dx0, dx1, part_ro, part_ro0, part_a, part_b, total;
 };
 TtScratch tt_layout(const genie_ctx* c, int n_query) {
     TtScratch t;
@@ -3567,6 +3572,7 @@ TtScratch tt_layout(const genie_ctx* c, int n_query) {
     t.pj = take(G * 32); t.gpart = take(1024 * 8);
     t.dxd = take(G * 32); t.dan = take(G * 32); t.dx0 = take(G * 32); t.dx1 = take(G * 32);
     t.part_ro = take(tt_part_floats(RB_NACC1, RB_NVEC, tt_grid(std::max(G, Q))));
+    t.part_ro0 = take(tt_part_floats(RB_NACC1, RB_NVEC, tt_grid(G)));      // the grid branch's own partials: it runs beside the query branch
     t.part_a = take(tt_part_floats(GTN_GROUPS, 10, tt_grid(G)));      // also k_sat_node_bwd / k_bip_bwd (largest of the G-sized maps)
     t.part_b = take(tt_part_floats(SBA_NACC, SBA_NVEC, tt_grid(G)));
     t.total = o;
@@ -3652,15 +3658,25 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
     HIP_TRY(hipFuncSetAttribute((const void*)k_ro_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS)));
     RoArgs ro = make_ro_args(c);
     ro.T = n_t; ro.x_spatial = xs; ro.t_query = t_query;
+    // The y branch (grid read-out: 61 us) and the x branch (query read-out + its grid-node side: 159 + 37 us) are independent until
+    // SpatialAggregation3 and each is ONE wave tile per wave on a fraction of the CUs: the y branch runs on the context's side stream
+    // beside the x branch and is joined (and reduced: both branches add into TemporalAttention's gradients) before the layers.
+    if (!c->side_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    const int grid_y = tt_grid(c->G);
+    HIP_TRY(hipEventRecord(c->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     {   // y branch: TemporalAttention + SpatialDirect
         RbArgs b;
         memset(&b, 0, sizeof(b));
         b.ro = ro; b.ro.N = b.ro.Nw = c->G; b.ro.img = c->packed[PL_RO0];
         b.timg = c->packed[PL_TRO0]; b.d_out = d_y; b.d_lat = d_ylat_extra; b.dxs = S + L.dxs_a;
-        b.part = S + L.part_ro; b.n_acc = c->n_acc[TM_RO0]; b.n_vec = c->n_vec[TM_RO0];
-        const int grid = tt_grid(c->G);
-        k_ro_bwd<0><<<grid, 256, sizeof(float) * RB_LDS_FLOATS, st>>>(b);
-        tt_reduce(c, TM_RO0, b.part, grid * 4, grad_blob, st);
+        b.part = S + L.part_ro0; b.n_acc = c->n_acc[TM_RO0]; b.n_vec = c->n_vec[TM_RO0];
+        k_ro_bwd<0><<<grid_y, 256, sizeof(float) * RB_LDS_FLOATS, c->side_stream>>>(b);
+        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
     }
     {   // x branch: TemporalAttention + SpatialAttention (query side), then its grid-node side
         k_ro_pre_m<false><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, st>>>(xs, c->G, c->packed[PL_ROP], S + L.cv, c->G, 0);
@@ -3673,8 +3689,6 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         const int grid = tt_grid(n_query);
         k_ro_bwd<1><<<grid, 256, sizeof(float) * RB_LDS_FLOATS, st>>>(b);
         tt_reduce(c, TM_RO1, b.part, grid * 4, grad_blob, st);
-        k_tq_bwd<<<1, 256, 0, st>>>(c->raw, grad_blob + g_raw_total, t_query, n_t, c->scale_t, g_params[W_TA_Q1_W].off, g_params[W_TA_Q1_B].off,
-                                    g_params[W_TA_Q2_W].off, g_params[W_TA_Q2_B].off, g_params[W_TA_ACT3].off, grad_blob);
         SnArgs n;
         memset(&n, 0, sizeof(n));
         n.G = c->G; n.nq = n_query; n.x_spatial = xs; n.x_grid = pos; n.x_query = x_query; n.r_rowptr = rknn_rowptr; n.r_edge = rknn_edge;
@@ -3685,6 +3699,10 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
         k_sat_node_bwd<<<gn, 256, 0, st>>>(n);
         tt_reduce(c, TM_SN, n.part, gn * 4, grad_blob, st);
     }
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));          // join: the y branch's d x_spatial (dxs_a) and partials are complete
+    tt_reduce(c, TM_RO0, S + L.part_ro0, grid_y * 4, grad_blob, st);
+    k_tq_bwd<<<1, 256, 0, st>>>(c->raw, grad_blob + g_raw_total, t_query, n_t, c->scale_t, g_params[W_TA_Q1_W].off, g_params[W_TA_Q1_B].off,
+                                g_params[W_TA_Q2_W].off, g_params[W_TA_Q2_B].off, g_params[W_TA_ACT3].off, grad_blob);
     // SpatialAggregation 3, 2, 1
     const float* x_in[3] = {bip, sa1, sa2};
     float* dxl[2] = {S + L.dx0, S + L.dx1};
