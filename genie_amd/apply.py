@@ -452,3 +452,60 @@ def associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out_s
     Save_picks = [np.stack((a.cpu().numpy(), b.cpu().numpy().astype(np.float64)), axis=1) for a, b in Save_picks]
     lp_meta = [picks.meta(ix) for ix in lp_meta]
     return Out_p, Out_s, Save_picks, lp_meta
+
+
+def retained_after_marching(srcs_refined, ftrns1, tc_win, sp_win, scale_depth_clustering=0.2, scale_time_ref=3500.0):
+    """The second LocalMarching of the caller and the match back to the refined list (process_continuous_days.py:1072-1085): the
+    refined sources that survive it (`n_steps_max = 2, use_directed = False`), found as the nearest refined source of each survivor in
+    (Cartesian position, `scale_time_ref` * origin time), `np.unique`d. Returns the retained row indices (ascending)."""
+    from scipy.spatial import cKDTree
+    from . import postproc
+    srcs_refined = np.asarray(srcs_refined, dtype=np.float64)
+    if len(srcs_refined) == 0:
+        return np.zeros(0, dtype=np.int64)
+    kept = postproc.local_marching(srcs_refined, ftrns1, tc_win=tc_win, sp_win=sp_win, scale_depth=scale_depth_clustering, n_steps_max=2,
+                                   use_directed=False)
+    tree = cKDTree(np.concatenate((ftrns1(srcs_refined), scale_time_ref * srcs_refined[:, [3]]), axis=1))
+    return np.unique(tree.query(np.concatenate((ftrns1(kept), scale_time_ref * kept[:, [3]]), axis=1))[1])
+
+
+def detect_refine_associate(legs, picks, Out_2, X_query, tsteps_abs, locs, trv, tq, max_t, ftrns1, ftrns2, lat_range, lon_range,
+                            depth_range, X_offset_min, X_offset_range, n_rand_query, thresh, src_t_kernel, dt_win, break_win, tc_win,
+                            sp_win, scale_depth_clustering=0.2, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, t_win_assoc=10.0,
+                            rand=None, ftrns2_device=None):
+    """Everything the caller does between the apply loop and the competitive assignment, with the network calls on the device
+    (process_continuous_days.py:811-1105): peaks of the device-resident `Out_2` -> time groups -> LocalMarching (`postproc.
+    detect_sources`, :811-891), the refine pass (`refine_sources`, :926-982), travel times of the refined sources (`trv(locs, srcs)`
+    [n, S, 2], :1004), the association pass (`associate_sources`, :1006-1068: `X_save` = the first node of the 15 x 15 map of the region,
+    :1008-1014), the second LocalMarching with its match back (`retained_after_marching`, :1072-1090), the travel times of the retained
+    sources (:1092) and the final sort by origin time (:1097-1105). `locs` [S, 3] (lat, lon, depth) of the stations in use; `trv`: the
+    travel-time callable of the reference, (float tensor [S, 3], float tensor [n, 3]) -> [n, S, 2]. Returns a dict: `srcs` (after the
+    first marching), `srcs_refined` [m, 5], `trv_out_srcs` (device [m, S, 2]), `Out_p_save`, `Out_s_save` (lists of device tensors),
+    `Save_picks`, `lp_meta` (lists of host arrays) -- the inputs of `competitive_assignment`, which is out of scope."""
+    from . import postproc
+    dev = legs[0].device
+    empty = {"srcs": np.zeros((0, 5)), "srcs_refined": np.zeros((0, 5)), "trv_out_srcs": None, "Out_p_save": [], "Out_s_save": [],
+             "Save_picks": [], "lp_meta": []}
+    srcs = postproc.detect_sources(Out_2, X_query, tsteps_abs, ftrns1, thresh, src_t_kernel, dt_win, break_win, tc_win, sp_win,
+                                   scale_depth_clustering)
+    if len(srcs) == 0:
+        return empty                                                                                                    # :886-888
+    locs = np.asarray(locs, dtype=np.float64)
+    locs_cart = ftrns1(locs)
+    locs_d = torch.as_tensor(locs).float().to(dev)
+    srcs_refined, _ = refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offset_range, n_rand_query, ftrns1, ftrns2,
+                                     lat_range, lon_range, depth_range, kernel_sig_t, dt_embed, rand, ftrns2_device)
+    with torch.no_grad():
+        trv_out = trv(locs_d, torch.as_tensor(srcs_refined[:, 0:3]).float().to(dev)).detach()                           # :1004
+    x_save = np.array([lat_range[0], lon_range[0], 0.0])                              # xx[0] of the meshgrid of :1008-1014
+    Out_p, Out_s, Save_picks, lp_meta = associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out, ftrns1, x_save,
+                                                          kernel_sig_t, dt_embed, t_win_assoc)
+    keep = retained_after_marching(srcs_refined, ftrns1, tc_win, sp_win, scale_depth_clustering)
+    srcs_kept = srcs_refined[keep]
+    with torch.no_grad():
+        trv_kept = trv(locs_d, torch.as_tensor(srcs_kept[:, 0:3]).float().to(dev)).detach()                             # :1092
+    order = np.argsort(srcs_kept[:, 3])                                                                                 # :1097
+    pick = [int(keep[j]) for j in order]
+    return {"srcs": srcs, "srcs_refined": srcs_kept[order], "trv_out_srcs": trv_kept[torch.as_tensor(order, device=trv_kept.device)],
+            "Out_p_save": [Out_p[j] for j in pick], "Out_s_save": [Out_s[j] for j in pick],
+            "Save_picks": [Save_picks[j] for j in pick], "lp_meta": [lp_meta[j] for j in pick]}

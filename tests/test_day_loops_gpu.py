@@ -181,3 +181,62 @@ def test_association_pass_matches_the_oracle_chain():
         assert ep <= 1e-5 and es <= 1e-5, (i, ep, es)
         seen += int(float(out[2].abs().max()) > 1e-4)
     assert seen >= 2 and any(len(m) == 0 for m in lp_meta)
+
+
+def test_detection_to_association_chain_matches_its_steps():
+    """process_continuous_days.py:811-1105 in one call (apply.detect_refine_associate) against the same statements made step by step
+    from pieces that each have their own oracle test (detect_sources, refine_sources, associate_sources, local_marching): what the
+    composition adds is the glue -- travel times of the refined sources, X_save, the second LocalMarching's match back (cKDTree in
+    position + 3500 x time, np.unique), the final sort -- and those are restated here in the reference's own words."""
+    from scipy.spatial import cKDTree
+    from genie_amd import postproc
+    s = _Setup()
+    rng = np.random.default_rng(23)
+    Q, dt_win, src_t_kernel, thresh = 150, 0.75, 5.0, 0.15
+    xq = np.c_[rng.uniform(0, 60e3, (Q, 2)), rng.uniform(-30e3, 0, Q)]
+    ts = 6990.0 + np.arange(400) * dt_win
+    out = np.zeros((Q, len(ts)), dtype=np.float32)
+    far = int(np.argmax(np.linalg.norm(xq - xq[3], axis=1)))
+    # the picks of the setup lie in 6997 .. 7017 s: two sources inside that stretch (one of them a double peak), two in quiet stretches
+    centres = [(xq[3], 7001.0), (xq[3] + [2e3, 0, 0], 7002.5), (xq[far], 7011.0), (xq[90], 7100.0), (xq[91], 7190.0)]
+    for c, t0 in centres:
+        d = np.linalg.norm((xq - c) * np.array([1, 1, 0.3]), axis=1)
+        out += (0.7 * np.exp(-0.5 * (d / 12e3) ** 2)[:, None] * np.exp(-0.5 * ((ts - t0) / 3.0) ** 2)[None, :]).astype(np.float32)
+    Out_2 = torch.from_numpy(out).to(DEV)
+    ident = lambda x: x
+    ranges = ((0.0, 60e3), (0.0, 60e3), (-40e3, 2e3))
+    off_min, off_rng = np.array([[-5e3, -5e3, -3e3]]), np.array([[10e3, 10e3, 6e3]])
+    tc_win, sp_win, break_win = src_t_kernel * 1.35, 20e3, 15.0
+
+    def trv(locs, srcs):                                                        # [n, S, 2], the call shape of the reference's `trv`
+        d = torch.linalg.norm(locs[None, :, :] - srcs[:, None, :], dim=2)
+        return torch.stack((d / 6000.0, d / 3500.0), dim=2)
+
+    kw = dict(kernel_sig_t=s.sig, dt_embed=s.dt)
+    got = apply.detect_refine_associate([s.leg], s.picks, Out_2, xq, ts, s.locs, trv, s.tq, s.max_t, ident, ident, *ranges, off_min, off_rng,
+                                        200, thresh, src_t_kernel, dt_win, break_win, tc_win, sp_win, rand=np.random.RandomState(3).rand,
+                                        ftrns2_device=ident, **kw)
+    srcs = postproc.detect_sources(Out_2, xq, ts, ident, thresh, src_t_kernel, dt_win, break_win, tc_win, sp_win)
+    assert 3 <= len(srcs) <= len(centres) and np.array_equal(got["srcs"], srcs)
+    ref, _ = apply.refine_sources([s.leg], s.picks, srcs, s.locs, s.tq, s.max_t, off_min, off_rng, 200, ident, ident, *ranges,
+                                  rand=np.random.RandomState(3).rand, ftrns2_device=ident, **kw)
+    trv_out = trv(_t(s.locs), _t(ref[:, 0:3]))                                                                          # :1004
+    Op, Os, Sp, Lm = apply.associate_sources([s.leg], s.picks, ref, s.locs, s.tq, s.max_t, trv_out, ident,
+                                             np.array([ranges[0][0], ranges[1][0], 0.0]), **kw)
+    ref_1 = postproc.local_marching(ref, ident, tc_win=tc_win, sp_win=sp_win, scale_depth=0.2, n_steps_max=2, use_directed=False)  # :1075
+    tree = cKDTree(np.concatenate((ref, 3500.0 * ref[:, [3]]), axis=1)[:, [0, 1, 2, 5]])                                # :1083
+    ip = np.unique(tree.query(np.concatenate((ref_1[:, 0:3], 3500.0 * ref_1[:, [3]]), axis=1))[1])                      # :1084-1085
+    want = ref[ip]
+    io = np.argsort(want[:, 3])                                                                                         # :1097
+    assert np.array_equal(got["srcs_refined"], want[io]) and len(got["Out_p_save"]) == len(ip)
+    assert torch.equal(got["trv_out_srcs"], trv(_t(s.locs), _t(want[io][:, 0:3])))                                      # :1092, :1099
+    n_assoc = 0
+    for j, i in enumerate(ip[io]):
+        assert torch.equal(got["Out_p_save"][j], Op[i]) and torch.equal(got["Out_s_save"][j], Os[i])
+        assert np.array_equal(got["Save_picks"][j], Sp[i]) and np.array_equal(got["lp_meta"][j], Lm[i])
+        n_assoc += int(Op[i].numel() > 0)
+    assert n_assoc >= 2
+    # nothing above the threshold: the caller's early exit (:886-888)
+    none = apply.detect_refine_associate([s.leg], s.picks, torch.zeros_like(Out_2), xq, ts, s.locs, trv, s.tq, s.max_t, ident, ident, *ranges,
+                                         off_min, off_rng, 200, thresh, src_t_kernel, dt_win, break_win, tc_win, sp_win, **kw)
+    assert len(none["srcs"]) == 0 and none["Out_p_save"] == []
