@@ -3057,8 +3057,13 @@ int readout_query_impl(genie_ctx* c, const float* x_spatial, const float* x_grid
     if (tail_wide(c)) k_ro_pre_m<true><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
     else k_ro_pre_m<false><<<tl_blocks(c->G, c->tail_cu_ro), 256, 0, (hipStream_t)stream>>>(x_spatial, c->G, c->packed[PL_ROP], cvbuf, c->G, 0);
     a.img = c->packed[PL_RO1];
-    HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
-    k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    if (n_query <= 16384) {      // about one 16-query tile per wave of the launch: nothing else hides a wave's round trips (PF)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<1, false, true><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_readout_m<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ROM_LDS_FLOATS)));
+        k_readout_m<1><<<tl_blocks(a.N, c->tail_cu_ro), 256, sizeof(float) * ROM_LDS_FLOATS, (hipStream_t)stream>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

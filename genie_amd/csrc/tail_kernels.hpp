@@ -439,7 +439,10 @@ __global__ __launch_bounds__(256) void k_sa_layer_m(SaArgs a) {
         const int eb = a.rowptr[icl], ee = okl ? a.rowptr[icl + 1] : eb;
         f32x4 as[2] = {tl_zero(), tl_zero()};
         // edges in chunks of 4: ids, the gathered rows / positions in flight, then the arithmetic in edge order (no cross-lane
-        // operation inside: the nodes of a wave may differ in trip count)
+        // operation inside: the nodes of a wave may differ in trip count). (Round 5: the ids of 16 edges in one request and rows 8
+        // edges at a time -- 3 round trips per node instead of 8 -- changed nothing, 16.4 / 17.9 / 15.0 us against 15.3 / 16.9 /
+        // 15.2 for the three layers of a single window: these launches are not bound by this chain. A launch that returns before its
+        // tile loop takes 4-5 us: image staging, the global term and the launch itself; the one tile a wave owns is the other ~11 us.)
         for (int e0 = eb; e0 < ee; e0 += 4) {
             int jn[4];
 #pragma unroll
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256) void k_ro_pre_m(const float* __restrict__ x_sp
 // score x value products, per node, go through a per-wave LDS scratch (a lane needs all T x 5 scores of its node).
 constexpr int RO_SCS = 68;      // floats per node in the score scratch: [5 heads][12 time slots] + pad
 constexpr int ROM_LDS_FLOATS = GR_IMG_FLOATS + 5 * 256 + 10 * 80 + 4 * 16 * RO_SCS;
-template <int MODE, bool WIDE = false>
+template <int MODE, bool WIDE = false, bool PF = false>      // PF (MODE 1): the gathered rows of head h + 1 requested before head h is worked on
 __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
     static_assert(!(WIDE && MODE != 0), "the fp64 form exists for the grid read-out (MODE 0)");
     typedef typename TlV<WIDE>::v V;
@@ -633,8 +636,26 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                 e[k][2] = (xq2 - a.x_grid[jn[k] * 3 + 2]) / a.scale_rel;
             }
             f32x4 xm = tl_zero();
+            // PF: the context and value rows of head h + 1 are requested before head h is worked on (two register sets, the head loop
+            // is unrolled). A call on ONE window gives every wave one tile and a CU four such waves, so each round trip a head waits
+            // for is exposed: ten in a row (context, then values, per head); 32 -> 28 us at 10 000 queries. With the tiles of a batch
+            // of windows in flight the waves hide each other's round trips and the extra requests only queue (+2.5 %): PF is for
+            // single-window calls.
+            f32x4 cck[2][RO_K], cvv[2][RO_K];
+            unsigned jo[RO_K];
+#pragma unroll
+            for (int k = 0; k < RO_K; ++k) jo[k] = (unsigned)jn[k] * (unsigned)CVP;
+            if (PF) {
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) { cck[0][k] = *(const f32x4*)(cvw + jo[k]); cvv[0][k] = *(const f32x4*)(cvw + jo[k] + 80); }
+            }
 #pragma unroll
             for (int h = 0; h < 5; ++h) {
+                const int hl = PF ? h + 1 : h;                  // the head whose rows are requested now
+                if (hl < 5) {
+#pragma unroll
+                    for (int k = 0; k < RO_K; ++k) cck[hl & 1][k] = *(const f32x4*)(cvw + jo[k] + hl * 16);
+                }
                 const float* eh = et + h * 16 + 4 * ql;
                 const f32x4 bq = *(const f32x4*)(eh + 9 * 80);
                 f32x4 wq_[3], wc_[3], wv_[3];
@@ -643,19 +664,21 @@ __global__ __launch_bounds__(256) void k_readout_m(RoArgs a) {
                     wq_[d] = *(const f32x4*)(eh + d * 80); wc_[d] = *(const f32x4*)(eh + (3 + d) * 80); wv_[d] = *(const f32x4*)(eh + (6 + d) * 80);
                 }
                 f32x4 cvk[RO_K];
-#pragma unroll
-                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + h * 16);
                 float al[RO_K];
 #pragma unroll
                 for (int k = 0; k < RO_K; ++k) {                                        // alpha = PReLU1(sum_l q c / sqrt(L))  :293
-                    f32x4 q4 = bq, c4 = cvk[k];
+                    f32x4 q4 = bq, c4 = cck[h & 1][k];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) { q4 += wq_[d] * e[k][d]; c4 += wc_[d] * e[k][d]; }
                     const f32x4 pr = q4 * c4;
                     al[k] = ((pr.x + pr.y) + pr.z) + pr.w;
                 }
+                if (hl < 5) {                                   // (not PF: this head's value rows, in flight under the scores)
 #pragma unroll
-                for (int k = 0; k < RO_K; ++k) cvk[k] = *(const f32x4*)(cvw + (long long)jn[k] * CVP + 80 + h * 16);
+                    for (int k = 0; k < RO_K; ++k) cvv[hl & 1][k] = *(const f32x4*)(cvw + jo[k] + 80 + hl * 16);
+                }
+#pragma unroll
+                for (int k = 0; k < RO_K; ++k) cvk[k] = cvv[h & 1][k];
 #pragma unroll
                 for (int k = 0; k < RO_K; ++k) {
                     al[k] += __shfl_xor(al[k], 1);
