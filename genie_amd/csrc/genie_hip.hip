@@ -2125,7 +2125,7 @@ int genie_ctx_create(genie_ctx** out, int n_sta, int n_grid, int n_grid_ext, con
         HIP_TRY(gmalloc((void**)&c->d_range, sizeof(float) * (4 + 4 * RG_PART)));
         HIP_TRY(hipHostMalloc((void**)&c->h_range, sizeof(float) * 4));
         HIP_TRY(hipHostMalloc((void**)&c->h_inflag, 64, hipHostMallocMapped));
-        *c->h_inflag = 0u;
+        c->h_inflag[0] = 0u; c->h_inflag[1] = 0u;
         c->range_ok = true; c->prec_mode = 0;
     }
     c->mpos_sta = c->mpos_src = c->ebias_sta = c->ebias_src = nullptr;
@@ -4022,6 +4022,7 @@ int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int3
     a.n_picks = n_picks; a.l_dt = l_dt; a.n_edges = n_edges; a.t0 = t0; a.dt = dt; a.eps = eps;
     a.s = s_rows; a.A_edges = a_edges; a.tlatent = tlatent; a.tl_stride = tl_stride; a.tl_col = tl_col;
     a.tpick = tpick; a.ipick = ipick; a.phase = phase_label; a.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS]; a.out = out;
+    a.flag = c->h_inflag ? c->h_inflag + 1 : nullptr;
     k_lslc<<<tl_blocks(n_picks, c->num_cu * 4), 256, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -4266,6 +4267,13 @@ int genie_input_range(genie_ctx* c, float* max_seen, float* limit, int reset) {
     }
     if (limit) *limit = input_limit(c);
     if (reset && c->h_inflag) *(volatile unsigned*)c->h_inflag = 0u;
+    return GENIE_OK;
+}
+
+int genie_index_flags(genie_ctx* c, unsigned* flags, int reset) {
+    if (!c) return fail(GENIE_ERR_ARG, "genie_index_flags: null context");
+    if (flags) *flags = c->h_inflag ? *(volatile unsigned*)(c->h_inflag + 1) : 0u;
+    if (reset && c->h_inflag) *(volatile unsigned*)(c->h_inflag + 1) = 0u;
     return GENIE_OK;
 }
 

@@ -774,6 +774,7 @@ struct LsArgs {
     const float* tpick; const int32_t* ipick; const float* phase;
     const float* img;
     float* out;                   // [n_picks, 15]
+    unsigned* flag;               // host-mapped word: bit 0 set when a pick indexes outside the time-pointer table (genie_index_flags)
 };
 __global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[GL_IMG_FLOATS];
@@ -788,7 +789,12 @@ __global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
         const int pc = ok ? p : a.n_picks - 1;
         const float tp = a.tpick[pc], ph = a.phase[pc];
         const int ti = (int)floorf((tp - a.t0) / a.dt);                                   // :635
-        long long base = ((long long)a.ipick[pc] * a.l_dt + ti) * LS_K;
+        const int ipk = a.ipick[pc];
+        long long base = ((long long)ipk * a.l_dt + ti) * LS_K;
+        // the reference indexes the table with these and fails on an index outside it (module.py:635-640: a device-side assertion,
+        // reported at the next synchronisation); here the index is clamped and the call that follows on the host raises
+        if (ok && (ti < 0 || ti >= a.l_dt || ipk < 0 || base + LS_K > a.n_edges) && a.flag != nullptr)
+            __hip_atomic_fetch_or(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         base = base < 0 ? 0 : (base > a.n_edges - LS_K ? a.n_edges - LS_K : base);
         f32x4 acc[2] = {tl_zero(), tl_zero()};
         float cnt = 0.f;

@@ -268,6 +268,18 @@ STAGE_PRECISION = "auto"
 _PRECISION_MODES = {"auto": 0, "f16x2": 1, "f32": 2}
 
 
+def time_partition(dt_partition):
+    """(t0, dt, length) of the uniform time partition behind the time-pointer tables (`dt_partition`, module.py:635), as host numbers.
+    A tuple is passed through: the module reads a device tensor back ONCE when the tables are set, not per call."""
+    if isinstance(dt_partition, tuple):
+        return dt_partition
+    if torch.is_tensor(dt_partition):
+        first = dt_partition[:2].detach().cpu().tolist()
+    else:
+        first = [float(dt_partition[0]), float(dt_partition[1])]
+    return (float(first[0]), float(first[1] - first[0]), int(len(dt_partition)))
+
+
 class HipPath(object):
     """One libgenie_hip context bound to the current CUDA(HIP) device.
 
@@ -466,6 +478,7 @@ class HipPath(object):
         the fp32 kernels, which take any input the reference's fp32 arithmetic takes, before the error is raised: the results of the
         calls issued since the last check are invalid and must be recomputed. Called at the top of every entry point that runs stage 1
         and by `wait_tails`."""
+        self.check_index_flags()
         mx, lim = ctypes.c_float(0.0), ctypes.c_float(0.0)
         _lib.check(self.lib.genie_input_range(self.ctx, ctypes.byref(mx), ctypes.byref(lim), 0), "genie_input_range")
         if mx.value != 0.0:
@@ -476,6 +489,19 @@ class HipPath(object):
                 "hidden states inside the fp16 range only up to |input| <= %.6g (the reference's embedding produces [-1, 1]). The results "
                 "of the calls issued since the last check are invalid; this context now runs the fp32 kernels (stage_precision 'f32'): "
                 "repeat those calls." % (mx.value, lim.value))
+
+    def check_index_flags(self):
+        """Raise IndexError when a pick of an earlier `lslc_fwd` call indexed outside the time-pointer table (genie_index_flags: host-mapped
+        memory, no synchronisation -- it reflects the calls that have completed; the kernel clamps such an index). The reference's own
+        indexing (module.py:635-640) fails the same deferred way on a GPU: a device-side assertion reported at the next synchronisation.
+        Called by every entry point that checks the input range, by `lslc_fwd` itself and by `wait_tails`; `synchronize=True` waits
+        for the device first, so that the calls issued so far are covered."""
+        fl = ctypes.c_uint(0)
+        _lib.check(self.lib.genie_index_flags(self.ctx, ctypes.byref(fl), 0), "genie_index_flags")
+        if fl.value & 1:
+            _lib.check(self.lib.genie_index_flags(self.ctx, None, 1), "genie_index_flags")
+            raise IndexError("lslc_fwd: a pick of an earlier call lies outside the time-pointer table (tpick outside dt_partition, or ipick "
+                             "outside the stations of A_edges); its rows were computed from a clamped index and are invalid")
 
     # ---- stages --------------------------------------------------------------------------------
     def da_stage1(self, Slice, Mask, debug=False):
@@ -903,17 +929,13 @@ class HipPath(object):
                 or phase_label.numel() != n or tlatent.dim() != 2 or tlatent.shape[0] != self.n_prod):
             raise ValueError("lslc_fwd: a_edges / ipick must be int32 GPU tensors, one ipick / phase_label per pick, tlatent [P, C]")
         a_edges, ipick = a_edges.contiguous(), ipick.contiguous()
-        t0, dt = float(dt_partition[0]), float(dt_partition[1] - dt_partition[0])
-        if n:
-            # the reference indexes the time-pointer table with these and raises on an index outside it (module.py:635-640); the
-            # kernel would clamp silently, so a pick outside `dt_partition` / the station range is refused here
-            ti = torch.floor((tpick - t0) / dt)
-            lim = torch.stack((ti.min(), ti.max(), ipick.min().float(), ipick.max().float())).tolist()
-            if lim[0] < 0 or lim[1] >= len(dt_partition) or lim[2] < 0 or (lim[3] * len(dt_partition) + lim[1]) * 10 + 9 >= a_edges.numel():
-                raise IndexError("lslc_fwd: a pick lies outside the time-pointer table (tpick outside dt_partition, or ipick outside "
-                                 "the stations of A_edges)")
+        # the reference indexes the time-pointer table with floor((tpick - t0) / dt) and ipick and fails on an index outside it
+        # (module.py:635-640); the kernel clamps such an index and reports it (check_index_flags: raised at the next call, no host
+        # synchronisation here -- until round 5 the bounds were read back per call)
+        self.check_index_flags()
+        t0, dt, l_dt = time_partition(dt_partition)
         out = torch.empty((n, 15), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)),
+        _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), l_dt,
                                            t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
                                            _ptr(phase_label), n, _ptr(out), _stream()), "genie_lslc_fwd")
         return out
@@ -926,7 +948,7 @@ class HipPath(object):
         n = int(tpick.numel())
         phase_label = _f32(phase_label, "phase_label").reshape(-1)
         tlatent = _f32(tlatent, "tlatent")
-        t0, dt = float(dt_partition[0]), float(dt_partition[1] - dt_partition[0])
+        t0, dt, l_dt = time_partition(dt_partition)
         dev = self.device
         ds = torch.zeros((self.n_prod, 30), dtype=torch.float32, device=dev)
         blob = torch.zeros(self._blob.numel(), dtype=torch.float32, device=dev)
@@ -938,7 +960,7 @@ class HipPath(object):
             a_edges = a_edges_ps[head]
             erow = torch.empty((n * 10, 32), dtype=torch.float32, device=dev)
             etgt = torch.empty(n * 10, dtype=torch.int32, device=dev)
-            _lib.check(self.lib.genie_lslc_bwd(self.ctx, head, _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), int(len(dt_partition)), t0, dt,
+            _lib.check(self.lib.genie_lslc_bwd(self.ctx, head, _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), l_dt, t0, dt,
                                                float(eps), _ptr(tlatent), int(tlatent.shape[1]), head, _ptr(tpick), _ptr(ipick), _ptr(phase_label),
                                                n, _ptr(d_out), _ptr(erow), _ptr(etgt), _ptr(part), _ptr(blob), _stream()), "genie_lslc_bwd")
             order = torch.sort(etgt, stable=True)[1].to(torch.int32)

@@ -831,15 +831,20 @@ class GCN_Detection_Network_extended(nn.Module):
                                  self.A_edges_s.to(s.device).to(torch.int32).contiguous())
             self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
         ip32, tl, eps = ipick.to(torch.int32), self.tlatent, self.LocalSliceLgCollapseP.eps
+        dtp = self.dt_partition                   # (t0, dt, length) on the host, read back once per table (not per call)
+        dkey = (dtp.data_ptr(), dtp._version) if torch.is_tensor(dtp) else id(dtp)
+        if getattr(self, "_dt_host_key", None) != dkey:
+            self._dt_host, self._dt_host_key, self._dt_host_ref = _engine.time_partition(dtp), dkey, dtp
+        dth = self._dt_host
         if train:
-            arv_p, arv_s = _LslcTrain.apply(s, self._a_edges_i32[0], self._a_edges_i32[1], self.dt_partition, _engine._f32(tpick, "tpick"),
+            arv_p, arv_s = _LslcTrain.apply(s, self._a_edges_i32[0], self._a_edges_i32[1], dth, _engine._f32(tpick, "tpick"),
                                             ip32, _engine._f32(phase_label, "phase_label"), _engine._f32(tl, "tlatent"), eps, hp,
                                             *[self._path_params[n] for n in TRAIN_LSLC_PARAMS])
             arv = _ArrivalsTrain.apply(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps, hp,
                                        *[self._path_params[n] for n in TRAIN_ARR_PARAMS])              # :993
         else:
-            arv_p = hp.lslc_fwd(0, s, self._a_edges_i32[0], self.dt_partition, tpick, ip32, phase_label, tl, 0, eps)
-            arv_s = hp.lslc_fwd(1, s, self._a_edges_i32[1], self.dt_partition, tpick, ip32, phase_label, tl, 1, eps)
+            arv_p = hp.lslc_fwd(0, s, self._a_edges_i32[0], dth, tpick, ip32, phase_label, tl, 0, eps)
+            arv_s = hp.lslc_fwd(1, s, self._a_edges_i32[1], dth, tpick, ip32, phase_label, tl, 1, eps)
             arv = hp.arrivals_fwd(tq_sample, x_src, trv_out_q, arv_p, arv_s, tpick, ipick, phase_label, self.Arrivals.eps)   # :993
         return y, x, arv[:, :, 0].unsqueeze(-1), arv[:, :, 1].unsqueeze(-1)                          # :995-997
 

@@ -132,6 +132,11 @@ int genie_stage_precision(genie_ctx* ctx, int* mode, int* f16x2_active, float* a
  * results of the calls issued since its last check and switch to genie_set_stage_precision(ctx, 2) (the Python host does both and
  * raises). Never set by the fp32 kernels, by the device embedding's split rows (values in [-1, 1] by construction) or in mode 2. */
 int genie_input_range(genie_ctx* ctx, float* max_seen, float* limit, int reset);
+/* Index errors found on the device since the last reset, read from host-mapped memory without synchronising (like genie_input_range):
+ * bit 0 = a pick of a genie_lslc_fwd call indexed outside the time-pointer table (tpick outside dt_partition, or ipick outside the
+ * stations of A_edges; the kernel clamps the index, the reference's indexing at Code/module.py:635-640 fails with a device-side
+ * assertion reported at its next synchronisation). The Python host raises IndexError at its next call on the context. */
+int genie_index_flags(genie_ctx* ctx, unsigned* flags, int reset);
 /* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
  * function of the geometry only); the library keeps it in the form stage 2 consumes (two-piece fp16 operand fragments in
  * processing order, 32 B per product node) and uses that in every stage-2 call that is passed this same pointer; any other

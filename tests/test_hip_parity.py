@@ -1845,6 +1845,54 @@ def test_local_slice_collapse_hip_matches_module(S, G, n_picks):
         assert max_abs(got.cpu(), ref.cpu()) <= 2e-6 * max(1.0, float(ref.abs().max())), head
 
 
+def test_local_slice_collapse_reports_a_pick_outside_the_table_at_the_next_call():
+    """module.py:635-640 indexes the time-pointer table with floor((tpick - t0) / dt) and ipick; an index outside the table is a
+    device-side assertion there (reported at the next synchronisation). Here the kernel clamps the index and sets a bit in host-mapped
+    memory (genie_index_flags); the host raises IndexError at its next call on the context, without a synchronisation per call (the
+    bounds used to be read back in every lslc_fwd). Covered: a time beyond the partition, a station beyond the table, and that the
+    report is made once."""
+    S, G, n = 7, 45, 12
+    rng = np.random.default_rng(3)
+    geom = synthetic.Geometry(S, G, L=150e3, n_query=10, seed=S)
+    c = Case("cfg1_20x500")
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in c.weights.items()}, strict=True)
+    net.eval()
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), torch.from_numpy(geom.edge_attr()).to(DEV),
+                             torch.from_numpy(geom.locs).float().to(DEV), torch.from_numpy(geom.x_grid).float().to(DEV))
+    d = np.linalg.norm(geom.x_grid[:, None, :] - geom.locs[None, :, :], axis=2)
+    trv = np.stack((d / 6000.0, d / 3500.0), axis=2).astype(np.float32)
+    ep, es, dtp = graph.time_pointers(trv, max_t=float(trv.max()), dt=0.6, k=10, win=6.0)
+    tlatent = torch.from_numpy(trv.reshape(G * S, 2)).to(DEV)
+    s = torch.from_numpy(rng.normal(0, 1, (G * S, 30)).astype(np.float32)).to(DEV)
+    dtp_t = torch.from_numpy(dtp.astype(np.float32)).to(DEV)
+    tab = torch.from_numpy(ep).to(DEV).to(torch.int32)
+    phase = torch.zeros((n, 1), device=DEV)
+    net._hip.sync_weights(net._path_params)
+    hp, eps = net._hip, net.LocalSliceLgCollapseP.eps
+    ip_ok = torch.from_numpy(rng.integers(0, S, n)).to(DEV).to(torch.int32)
+    tp_ok = torch.from_numpy(rng.uniform(0.0, float(trv.max()), n).astype(np.float32)).to(DEV)
+    call = lambda tp, ip: hp.lslc_fwd(0, s, tab, dtp_t, tp, ip, phase, tlatent, 0, eps)
+    good = call(tp_ok, ip_ok)
+    for bad in ("time", "station", "negative time"):
+        tp, ip = tp_ok.clone(), ip_ok.clone()
+        if bad == "time":
+            tp[5] = float(dtp[-1]) + 100.0
+        elif bad == "negative time":
+            tp[0] = float(dtp[0]) - 50.0
+        else:
+            ip[n - 1] = S + 3
+        out = call(tp, ip)                                   # not refused here: the index is clamped on the device ...
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        with pytest.raises(IndexError, match="outside the time-pointer table"):
+            call(tp_ok, ip_ok)                               # ... and reported by the next call
+        again = call(tp_ok, ip_ok)                           # once
+        torch.cuda.synchronize()
+        assert torch.equal(again, good)
+    hp.check_index_flags()
+
+
 @pytest.mark.parametrize("S,n_src,n_picks", [(7, 4, 23), (40, 9, 1500), (12, 1, 1), (30, 3, 600), (3, 2, 1300)])
 def test_arrivals_head_hip_matches_module(S, n_src, n_picks):
     """f-2: StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775) in HIP (genie_arrivals_fwd) against the PyTorch
