@@ -43,6 +43,7 @@ SYMBOLS = [
     ("genie_stage_precision", _c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _P]),
     ("genie_input_range", _c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
     ("genie_index_flags", _c.c_int, [_P, _c.POINTER(_c.c_uint), _c.c_int]),
+    ("genie_index_check", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_uint, _P]),
     ("genie_set_static_edge_attr", _c.c_int, [_P, _P, _P]),
     ("genie_tail_batched", _c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P]),
     ("genie_readout_grid", _c.c_int, [_P, _P, _P, _c.c_int, _P, _P]),

@@ -577,3 +577,16 @@ __global__ void __launch_bounds__(256) k_product_check(const long long* __restri
     }
     if (bad) atomicOr(flags, bad);
 }
+
+// Range check of an index list without a host round trip: bit `bit` of the host-mapped flag word is set when some idx[i] lies outside
+// [lo, hi) (genie_index_check -> genie_index_flags). The callers clamp such indices for their own use; the host raises at its next call.
+__global__ void __launch_bounds__(256) k_index_check(const long long* __restrict__ idx, long long n, long long lo, long long hi, unsigned bit,
+                                                      unsigned* __restrict__ flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long v = idx[i];
+        bad |= v < lo || v >= hi;
+    }
+    if (bad) __hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+

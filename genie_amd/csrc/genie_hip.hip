@@ -4277,6 +4277,16 @@ int genie_index_flags(genie_ctx* c, unsigned* flags, int reset) {
     return GENIE_OK;
 }
 
+int genie_index_check(genie_ctx* c, const int64_t* idx, int64_t n, int64_t lo, int64_t hi, unsigned bit, void* stream) {
+    if (!c || (!idx && n > 0)) return fail(GENIE_ERR_ARG, "genie_index_check: null argument");
+    if (bit == 0u || (bit & (bit - 1u)) != 0u || bit == 1u) return fail(GENIE_ERR_ARG, "genie_index_check: `bit` must be one bit above bit 0");
+    if (n < 1 || !c->h_inflag) return GENIE_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    k_index_check<<<grid, 256, 0, (hipStream_t)stream>>>((const long long*)idx, n, lo, hi, bit, c->h_inflag + 1);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
 int genie_ws_export(genie_ctx* c, int which, void* ws, float* out, void* stream) {
     int rc = check_ws(c, ws);
     if (rc) return rc;

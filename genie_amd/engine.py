@@ -498,10 +498,16 @@ class HipPath(object):
         for the device first, so that the calls issued so far are covered."""
         fl = ctypes.c_uint(0)
         _lib.check(self.lib.genie_index_flags(self.ctx, ctypes.byref(fl), 0), "genie_index_flags")
-        if fl.value & 1:
+        if fl.value:
             _lib.check(self.lib.genie_index_flags(self.ctx, None, 1), "genie_index_flags")
-            raise IndexError("lslc_fwd: a pick of an earlier call lies outside the time-pointer table (tpick outside dt_partition, or ipick "
-                             "outside the stations of A_edges); its rows were computed from a clamped index and are invalid")
+            what = []
+            if fl.value & 1:
+                what.append("lslc_fwd: a pick lies outside the time-pointer table (tpick outside dt_partition, or ipick outside the stations "
+                            "of A_edges)")
+            if fl.value & 2:
+                what.append("arrivals: a station index `ipick` outside [0, n_sta)")
+            raise IndexError("an earlier call on this context met " + "; ".join(what) + ". Its results were computed from clamped indices "
+                             "and are invalid")
 
     # ---- stages --------------------------------------------------------------------------------
     def da_stage1(self, Slice, Mask, debug=False):
@@ -983,14 +989,20 @@ class HipPath(object):
         phase_label = _f32(phase_label, "phase_label").reshape(-1)
         if n == 0 or n_src == 0:
             raise ValueError("arrivals: needs at least one pick and one source")
-        ip = ipick.reshape(-1).long()
-        if ip.numel() != n or phase_label.numel() != n or int(ip.max()) >= n_sta or int(ip.min()) < 0:
-            raise ValueError("arrivals: one station index in [0, n_sta) and one phase label per pick")
-        order = torch.sort(ip, stable=True)[1]
-        seg_sta, counts = torch.unique_consecutive(ip[order], return_counts=True)
+        ip = ipick.reshape(-1).long().contiguous()
+        if ip.numel() != n or phase_label.numel() != n:
+            raise ValueError("arrivals: one station index and one phase label per pick")
+        # one segment per station, empty ones included (their launches find no target and return): every size is known on the host, so
+        # nothing here waits for the device (until round 5: two read-backs for the index range and torch.unique_consecutive's own). A
+        # station index outside [0, n_sta) is reported by the device (check_index_flags: IndexError at the next call) and clamped here.
+        self.check_index_flags()
+        _lib.check(self.lib.genie_index_check(self.ctx, _ptr(ip), n, 0, n_sta, 2, _stream()), "genie_index_check")
+        ipc = ip.clamp(0, n_sta - 1)
+        order = torch.sort(ipc, stable=True)[1]
+        counts = torch.zeros(n_sta, dtype=torch.int64, device=ip.device).scatter_add_(0, ipc, torch.ones_like(ipc))
         seg_start = torch.cumsum(counts, 0) - counts
         i32 = lambda t: t.to(torch.int32).contiguous()
-        segs = (i32(order), i32(seg_sta), i32(seg_start), i32(counts))
+        segs = (i32(order), torch.arange(n_sta, dtype=torch.int32, device=ip.device), i32(seg_start), i32(counts))
         return n_src, n_sta, n, (stime, src_embed, trv_src, arrival_p, arrival_s, tpick, phase_label), segs
 
     def arrivals_fwd(self, stime, src_embed, trv_src, arrival_p, arrival_s, tpick, ipick, phase_label, eps, train=False):

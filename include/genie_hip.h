@@ -137,6 +137,10 @@ int genie_input_range(genie_ctx* ctx, float* max_seen, float* limit, int reset);
  * stations of A_edges; the kernel clamps the index, the reference's indexing at Code/module.py:635-640 fails with a device-side
  * assertion reported at its next synchronisation). The Python host raises IndexError at its next call on the context. */
 int genie_index_flags(genie_ctx* ctx, unsigned* flags, int reset);
+/* Range check of a caller's index list on the device, no host round trip: sets `bit` (2, 4, ...; bit 0 belongs to genie_lslc_fwd) in the
+ * word genie_index_flags returns when some idx[i] lies outside [lo, hi). The Python host uses bit 1 (value 2) for the station indices
+ * `ipick` of the Arrivals head (Code/module.py:703-713 indexes `trv_out[:, ipick]` with them), which it clamps for its own use. */
+int genie_index_check(genie_ctx* ctx, const int64_t* idx, int64_t n, int64_t lo, int64_t hi, unsigned bit, void* stream);
 /* With a station processing order: registers the caller's STATIC edge_attr [P, 3] (A_src_in_edges.x, process_utils.py:722: a
  * function of the geometry only); the library keeps it in the form stage 2 consumes (two-piece fp16 operand fragments in
  * processing order, 32 B per product node) and uses that in every stage-2 call that is passed this same pointer; any other

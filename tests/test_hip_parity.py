@@ -1891,6 +1891,20 @@ def test_local_slice_collapse_reports_a_pick_outside_the_table_at_the_next_call(
         torch.cuda.synchronize()
         assert torch.equal(again, good)
     hp.check_index_flags()
+    # the same report for the Arrivals head's station indices (bit 1, genie_index_check): clamped for the call, raised by the next one
+    n_src = 2
+    trv_src = torch.from_numpy(np.stack((d[:n_src] / 6000.0, d[:n_src] / 3500.0), axis=2).astype(np.float32)).to(DEV)
+    stime, emb = torch.zeros(n_src, device=DEV), torch.zeros((n_src, 30), device=DEV)
+    arr = lambda ip: hp.arrivals_fwd(stime, emb, trv_src, good, good, tp_ok, ip, phase, net.Arrivals.eps)
+    ref = arr(ip_ok.long())
+    ip_bad = ip_ok.long().clone()
+    ip_bad[3] = S
+    out = arr(ip_bad)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    with pytest.raises(IndexError, match="station index"):
+        arr(ip_ok.long())
+    assert torch.equal(arr(ip_ok.long()), ref)
 
 
 @pytest.mark.parametrize("S,n_src,n_picks", [(7, 4, 23), (40, 9, 1500), (12, 1, 1), (30, 3, 600), (3, 2, 1300)])
