@@ -92,10 +92,10 @@ SYMBOLS = [
     ("genie_assoc_train_bwd", _c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("genie_knn", _c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     ("genie_product_check", _c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P]),
-    ("genie_lslc_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
+    ("genie_lslc_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _P, _c.c_float, _P, _c.c_int, _c.c_int,
                                   _P, _P, _P, _c.c_int, _P, _P]),
     ("genie_lslc_bwd_part_floats", _c.c_size_t, [_c.c_int]),
-    ("genie_lslc_bwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _P, _c.c_int, _c.c_int,
+    ("genie_lslc_bwd", _c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _P, _c.c_float, _P, _c.c_int, _c.c_int,
                                   _P, _P, _P, _c.c_int, _P, _P, _P, _P, _P, _P]),
     ("genie_seg_rows", _c.c_int, [_P, _P, _P, _c.c_int64, _P, _P]),
     ("genie_arrivals_fwd", _c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_float,

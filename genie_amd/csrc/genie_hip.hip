@@ -1326,7 +1326,7 @@ struct genie_ctx {
     float* ea_tmp;             // ... of an edge_attr that is not the registered one (permuted per call)
     int32_t* src_tab;          // [G][16] processing-order table of k_stage1_h2 (null unless kp_uni == 15)
     float* packed_h2;          // f16x2 weight image of k_stage1_h2
-    hipStream_t side_stream = nullptr;      // fork / join inside one call (genie_tail_train_bwd: the grid branch beside the query branch)
+    hipStream_t side_stream = nullptr;      // fork / join inside one call (genie_tail_train_bwd: the grid branch beside the query branch); the device's, not owned
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = 0;            // the HIP device the context was created on (genie_ctx_destroy drains THAT device)
     int num_cu;
@@ -2450,7 +2450,6 @@ int genie_ctx_destroy(genie_ctx* c) {
     for (void* p : ptrs) (void)gfree(p);
     if (c->h_range) (void)hipHostFree(c->h_range);
     if (c->h_inflag) (void)hipHostFree(c->h_inflag);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& kv : c->s2u) { (void)gfree(kv.second.blocks); (void)gfree(kv.second.xcd0); }
@@ -3667,9 +3666,16 @@ int genie_tail_train_bwd(genie_ctx* c, const float* pos, const float* x_query, c
     // SpatialAggregation3 and each is ONE wave tile per wave on a fraction of the CUs: the y branch runs on the context's side stream
     // beside the x branch and is joined (and reduced: both branches add into TemporalAttention's gradients) before the layers.
     if (!c->side_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        // ONE side stream per device for every context (a stream is a hardware queue: creating one per context cost the first
+        // backward of every rebuilt context ~10 ms -- the reference's training loop builds a context per sample); events per context
+        static std::map<int, hipStream_t> side;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        hipStream_t& s = side[c->device];
+        if (!s) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        c->side_stream = s;
     }
     const int grid_y = tt_grid(c->G);
     HIP_TRY(hipEventRecord(c->ev_fork, st));
@@ -4009,17 +4015,18 @@ int genie_row_select_fill(const float* x, int rows, int64_t cols, float threshol
 }
 
 int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
-                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
-                   const float* phase_label, int n_picks, float* out, void* stream) {
+                   float dt, const float* dt_partition, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick,
+                   const int32_t* ipick, const float* phase_label, int n_picks, float* out, void* stream) {
     if (!c || !s_rows || !a_edges || !tlatent || !tpick || !ipick || !phase_label || !out) return fail(GENIE_ERR_ARG, "genie_lslc_fwd: null argument");
-    if (phase_head < 0 || phase_head > 1 || l_dt < 1 || n_edges < LS_K || !(dt > 0.f) || !(eps > 0.f) || tl_stride < 1 || tl_col < 0 || tl_col >= tl_stride)
+    if (phase_head < 0 || phase_head > 1 || l_dt < (dt_partition ? 2 : 1) || n_edges < LS_K || (!dt_partition && !(dt > 0.f)) || !(eps > 0.f) || tl_stride < 1 ||
+        tl_col < 0 || tl_col >= tl_stride)
         return fail(GENIE_ERR_ARG, "genie_lslc_fwd: bad argument");
     if (n_picks < 1) return GENIE_OK;
     hipStream_t st = (hipStream_t)stream;
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
     LsArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_picks = n_picks; a.l_dt = l_dt; a.n_edges = n_edges; a.t0 = t0; a.dt = dt; a.eps = eps;
+    a.n_picks = n_picks; a.l_dt = l_dt; a.n_edges = n_edges; a.t0 = t0; a.dt = dt; a.dtp = dt_partition; a.eps = eps;
     a.s = s_rows; a.A_edges = a_edges; a.tlatent = tlatent; a.tl_stride = tl_stride; a.tl_col = tl_col;
     a.tpick = tpick; a.ipick = ipick; a.phase = phase_label; a.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS]; a.out = out;
     a.flag = c->h_inflag ? c->h_inflag + 1 : nullptr;
@@ -4035,19 +4042,19 @@ int genie_lslc_fwd(genie_ctx* c, int phase_head, const float* s_rows, const int3
 size_t genie_lslc_bwd_part_floats(int n_picks) { return tt_part_floats(8, 3, tt_grid(std::max(1, n_picks))); }
 
 int genie_lslc_bwd(genie_ctx* c, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
-                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
-                   const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt, float* part_scratch,
-                   float* grad_blob, void* stream) {
+                   float dt, const float* dt_partition, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick,
+                   const int32_t* ipick, const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt,
+                   float* part_scratch, float* grad_blob, void* stream) {
     if (!c || !s_rows || !a_edges || !tlatent || !tpick || !ipick || !phase_label || !d_out || !erow || !etgt || !part_scratch || !grad_blob)
         return fail(GENIE_ERR_ARG, "genie_lslc_bwd: null argument");
-    if (phase_head < 0 || phase_head > 1 || l_dt < 1 || n_edges < LS_K || !(dt > 0.f) || !(eps > 0.f) || tl_stride < 1 || tl_col < 0 || tl_col >= tl_stride ||
-        n_picks < 1)
+    if (phase_head < 0 || phase_head > 1 || l_dt < (dt_partition ? 2 : 1) || n_edges < LS_K || (!dt_partition && !(dt > 0.f)) || !(eps > 0.f) || tl_stride < 1 ||
+        tl_col < 0 || tl_col >= tl_stride || n_picks < 1)
         return fail(GENIE_ERR_ARG, "genie_lslc_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     { int rcp = ensure_packed(c, st); if (rcp) return rcp; }
     LbArgs b;
     memset(&b, 0, sizeof(b));
-    b.f.n_picks = n_picks; b.f.l_dt = l_dt; b.f.n_edges = n_edges; b.f.t0 = t0; b.f.dt = dt; b.f.eps = eps;
+    b.f.n_picks = n_picks; b.f.l_dt = l_dt; b.f.n_edges = n_edges; b.f.t0 = t0; b.f.dt = dt; b.f.dtp = dt_partition; b.f.eps = eps;
     b.f.s = s_rows; b.f.A_edges = a_edges; b.f.tlatent = tlatent; b.f.tl_stride = tl_stride; b.f.tl_col = tl_col;
     b.f.tpick = tpick; b.f.ipick = ipick; b.f.phase = phase_label; b.f.img = c->packed[phase_head == 0 ? PL_LSP : PL_LSS];
     b.timg = c->packed[phase_head == 0 ? PL_TLSP : PL_TLSS];

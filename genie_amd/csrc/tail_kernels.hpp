@@ -768,6 +768,7 @@ struct LsArgs {
     int n_picks, l_dt;
     long long n_edges;            // entries of the time-pointer table (indices are clamped into it)
     float t0, dt, eps;
+    const float* dtp;             // device copy of dt_partition (or null): t0 = dtp[0], dt = dtp[1] - dtp[0] replace the two above
     const float* s;               // [P, 30] association embedding (genie_assoc_fwd)
     const int32_t* A_edges;       // [n_sta * l_dt * K] product-node ids
     const float* tlatent; int tl_stride, tl_col;     // theoretical arrival of product node e: tlatent[e * tl_stride + tl_col]
@@ -782,13 +783,14 @@ __global__ __launch_bounds__(256) void k_lslc(LsArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const float act1 = im.scal[0], act2 = im.scal[1];
+    const float t0_ = a.dtp ? a.dtp[0] : a.t0, dt_ = a.dtp ? a.dtp[1] - a.dtp[0] : a.dt;
     const int ntiles = (a.n_picks + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int p = tile * 16 + j;
         const bool ok = p < a.n_picks;
         const int pc = ok ? p : a.n_picks - 1;
         const float tp = a.tpick[pc], ph = a.phase[pc];
-        const int ti = (int)floorf((tp - a.t0) / a.dt);                                   // :635
+        const int ti = (int)floorf((tp - t0_) / dt_);                                     // :635
         const int ipk = a.ipick[pc];
         long long base = ((long long)ipk * a.l_dt + ti) * LS_K;
         // the reference indexes the table with these and fails on an index outside it (module.py:635-640: a device-side assertion,

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_lslc_bwd(LbArgs b) {
         const bool ok = p < a.n_picks;
         const int pc = ok ? p : a.n_picks - 1;
         const float tp = a.tpick[pc], ph = a.phase[pc];
-        const int ti = (int)floorf((tp - a.t0) / a.dt);
+        const int ti = (int)floorf((tp - (a.dtp ? a.dtp[0] : a.t0)) / (a.dtp ? a.dtp[1] - a.dtp[0] : a.dt));
         long long base = ((long long)a.ipick[pc] * a.l_dt + ti) * LS_K;
         base = base < 0 ? 0 : (base > a.n_edges - LS_K ? a.n_edges - LS_K : base);
         // ---- forward: mean message, output pre-activation

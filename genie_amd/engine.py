@@ -269,15 +269,20 @@ _PRECISION_MODES = {"auto": 0, "f16x2": 1, "f32": 2}
 
 
 def time_partition(dt_partition):
-    """(t0, dt, length) of the uniform time partition behind the time-pointer tables (`dt_partition`, module.py:635), as host numbers.
-    A tuple is passed through: the module reads a device tensor back ONCE when the tables are set, not per call."""
+    """The uniform time partition behind the time-pointer tables (`dt_partition`, module.py:635) as genie_lslc_fwd / _bwd take it:
+    (t0, dt, device tensor or None, length). A GPU tensor stays on the device -- the kernels read t0 = p[0], dt = p[1] - p[0]
+    themselves, nothing is read back --; host data (numpy / CPU tensor / list) gives the two numbers. A tuple is passed through."""
     if isinstance(dt_partition, tuple):
         return dt_partition
+    n = int(len(dt_partition))
+    if torch.is_tensor(dt_partition) and dt_partition.is_cuda:
+        if n < 2:
+            raise ValueError("dt_partition needs at least two entries")
+        return (0.0, 0.0, dt_partition.detach().float().contiguous(), n)
     if torch.is_tensor(dt_partition):
-        first = dt_partition[:2].detach().cpu().tolist()
-    else:
-        first = [float(dt_partition[0]), float(dt_partition[1])]
-    return (float(first[0]), float(first[1] - first[0]), int(len(dt_partition)))
+        dt_partition = dt_partition.detach().float().numpy()           # fp32 difference, as the reference's tensor arithmetic
+        return (float(dt_partition[0]), float(dt_partition[1] - dt_partition[0]), None, n)
+    return (float(dt_partition[0]), float(dt_partition[1] - dt_partition[0]), None, n)
 
 
 class HipPath(object):
@@ -939,10 +944,10 @@ class HipPath(object):
         # (module.py:635-640); the kernel clamps such an index and reports it (check_index_flags: raised at the next call, no host
         # synchronisation here -- until round 5 the bounds were read back per call)
         self.check_index_flags()
-        t0, dt, l_dt = time_partition(dt_partition)
+        t0, dt, dtp, l_dt = time_partition(dt_partition)
         out = torch.empty((n, 15), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.genie_lslc_fwd(self.ctx, int(head), _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), l_dt,
-                                           t0, dt, float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
+                                           t0, dt, _ptr(dtp), float(eps), _ptr(tlatent), int(tlatent.shape[1]), int(col), _ptr(tpick), _ptr(ipick),
                                            _ptr(phase_label), n, _ptr(out), _stream()), "genie_lslc_fwd")
         return out
 
@@ -954,7 +959,7 @@ class HipPath(object):
         n = int(tpick.numel())
         phase_label = _f32(phase_label, "phase_label").reshape(-1)
         tlatent = _f32(tlatent, "tlatent")
-        t0, dt, l_dt = time_partition(dt_partition)
+        t0, dt, dtp, l_dt = time_partition(dt_partition)
         dev = self.device
         ds = torch.zeros((self.n_prod, 30), dtype=torch.float32, device=dev)
         blob = torch.zeros(self._blob.numel(), dtype=torch.float32, device=dev)
@@ -967,7 +972,7 @@ class HipPath(object):
             erow = torch.empty((n * 10, 32), dtype=torch.float32, device=dev)
             etgt = torch.empty(n * 10, dtype=torch.int32, device=dev)
             _lib.check(self.lib.genie_lslc_bwd(self.ctx, head, _ptr(s_rows), _ptr(a_edges), int(a_edges.numel()), l_dt, t0, dt,
-                                               float(eps), _ptr(tlatent), int(tlatent.shape[1]), head, _ptr(tpick), _ptr(ipick), _ptr(phase_label),
+                                               _ptr(dtp), float(eps), _ptr(tlatent), int(tlatent.shape[1]), head, _ptr(tpick), _ptr(ipick), _ptr(phase_label),
                                                n, _ptr(d_out), _ptr(erow), _ptr(etgt), _ptr(part), _ptr(blob), _stream()), "genie_lslc_bwd")
             order = torch.sort(etgt, stable=True)[1].to(torch.int32)
             _lib.check(self.lib.genie_seg_rows(_ptr(erow), _ptr(etgt), _ptr(order), n * 10, _ptr(ds), _stream()), "genie_seg_rows")

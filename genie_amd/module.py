@@ -831,7 +831,7 @@ class GCN_Detection_Network_extended(nn.Module):
                                  self.A_edges_s.to(s.device).to(torch.int32).contiguous())
             self._a_edges_key, self._a_edges_refs = key, (self.A_edges_p, self.A_edges_s)
         ip32, tl, eps = ipick.to(torch.int32), self.tlatent, self.LocalSliceLgCollapseP.eps
-        dtp = self.dt_partition                   # (t0, dt, length) on the host, read back once per table (not per call)
+        dtp = self.dt_partition                   # in the form the lslc calls take it (a GPU tensor stays on the device: no read-back)
         dkey = (dtp.data_ptr(), dtp._version) if torch.is_tensor(dtp) else id(dtp)
         if getattr(self, "_dt_host_key", None) != dkey:
             self._dt_host, self._dt_host_key, self._dt_host_ref = _engine.time_partition(dtp), dkey, dtp

@@ -455,11 +455,13 @@ int genie_assoc_train_bwd(genie_ctx* ctx, const float* y_latent, const float* ma
 /* LocalSliceLgCollapse P (phase_head 0) / S (1), module.py:610-659, on the device: for every pick the 10 product nodes listed in the
  * time-pointer table a_edges [n_sta * l_dt * 10] (int32 product-node ids, `assemble_time_pointers_for_stations`, utils.py:602-622)
  * at (ipick, floor((tpick - t0) / dt)), those with |tpick - tlatent[e * tl_stride + tl_col]| < 2 eps kept, edge MLP on the rows of
- * s_rows [P, 30] (genie_assoc_fwd), mean, fc2: out [n_picks, 15]. t0 = dt_partition[0], dt = dt_partition[1] - dt_partition[0];
- * tpick / phase_label fp32 [n_picks], ipick int32. */
+ * s_rows [P, 30] (genie_assoc_fwd), mean, fc2: out [n_picks, 15]. t0 = dt_partition[0], dt = dt_partition[1] - dt_partition[0]: either
+ * passed as numbers (dt_partition NULL) or read by the kernel from the caller's DEVICE array dt_partition [l_dt >= 2] (t0 / dt ignored:
+ * a caller holding the partition on the device needs no read-back). tpick / phase_label fp32 [n_picks], ipick int32. An index outside
+ * the table is clamped and reported through genie_index_flags. */
 int genie_lslc_fwd(genie_ctx* ctx, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
-                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
-                   const float* phase_label, int n_picks, float* out, void* stream);
+                   float dt, const float* dt_partition, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick,
+                   const int32_t* ipick, const float* phase_label, int n_picks, float* out, void* stream);
 
 /* Backward of genie_lslc_fwd for training steps (round 3; k_lslc_bwd, forward recomputed per tile): d_out [n_picks, 15] -> the head's
  * fc1 / fc2 / PReLU-slope gradients ADDED into grad_blob (weight-mirror layout; zero it once before the two heads), the gradient of every
@@ -468,9 +470,9 @@ int genie_lslc_fwd(genie_ctx* ctx, int phase_head, const float* s_rows, const in
  * picks may gather the same node, and the sum must not depend on scheduling. part_scratch: genie_lslc_bwd_part_floats(n_picks) floats. */
 size_t genie_lslc_bwd_part_floats(int n_picks);
 int genie_lslc_bwd(genie_ctx* ctx, int phase_head, const float* s_rows, const int32_t* a_edges, int64_t n_edges, int l_dt, float t0,
-                   float dt, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick, const int32_t* ipick,
-                   const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt, float* part_scratch,
-                   float* grad_blob, void* stream);
+                   float dt, const float* dt_partition, float eps, const float* tlatent, int tl_stride, int tl_col, const float* tpick,
+                   const int32_t* ipick, const float* phase_label, int n_picks, const float* d_out, float* erow, int32_t* etgt,
+                   float* part_scratch, float* grad_blob, void* stream);
 int genie_seg_rows(const float* erow, const int32_t* etgt, const int32_t* order, int64_t n_edges, float* d_s, void* stream);
 
 /* StationSourceAttentionMergedPhases (`Arrivals`, module.py:662-775; use_sparse = True, use_neighbor_assoc_edges = False) on
