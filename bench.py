@@ -629,8 +629,25 @@ def rebuild_leg(net, opt, geom, n_picks, dev, n_samples=3, reps=3):
             fresh.append((t1 - t0) * 1e3)
             again.append((time.perf_counter() - t1) * 1e3)
     f, g2 = float(np.median(fresh)), float(np.median(again))
+    # the same two loops WITHOUT a synchronisation between the steps (a training loop that does not read the loss back every step):
+    # the host prepares a sample's context while the GPU still works on the previous step's backward
+    def loop(ks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in ks:
+            step(k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / len(ks)
+    ks = [k for _ in range(reps + 1) for k in range(n_samples)]
+    loop(ks[:n_samples])
+    fu = loop(ks)
+    step(0)
+    gu = loop([0] * len(ks))
     net.invalidate_graph_cache()
     return {"step_with_rebuild_ms": round(f, 3), "step_same_graph_ms": round(g2, 3), "rebuild_ms": round(f - g2, 3),
+            "unsynchronised_loop": {"step_with_rebuild_ms": round(fu, 3), "step_same_graph_ms": round(gu, 3), "rebuild_ms": round(fu - gu, 3),
+                                    "steps": len(ks), "note": "no synchronisation between the steps: the structure checks of a new graph are "
+                                    "read after the forward's kernels are issued, so the rebuild runs under the previous step's backward"},
             "samples": n_samples, "stations": [S - i for i in range(n_samples)], "n_grid": G,
             "product_edges_per_sample": int(samples[0][0][2].shape[1] + samples[0][0][3].shape[1]),
             "note": "median over %d steps each; rebuild = Cartesian check of the int64 product edge lists on the device (genie_product_check), base "

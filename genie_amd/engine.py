@@ -1083,7 +1083,8 @@ class HipPath(object):
             flat = knn_idx.reshape(-1).long()
             order = torch.sort(flat, stable=True)[1]
             rowptr = torch.zeros(self.n_grid + 1, dtype=torch.int64, device=knn_idx.device)
-            rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=self.n_grid), 0)
+            counts = torch.zeros(self.n_grid, dtype=torch.int64, device=knn_idx.device).scatter_add_(0, flat, torch.ones_like(flat))
+            rowptr[1:] = torch.cumsum(counts, 0)          # (torch.bincount would read the largest index back: a host wait mid-backward)
             self._rknn = (rowptr.to(torch.int32), order.to(torch.int32).contiguous())
             self._rknn_key, self._rknn_ref = key, knn_idx
         return self._rknn

@@ -101,12 +101,16 @@ def neighbour_table(edge_index, n_nodes):
     return j[order].view(n_nodes, k).to(torch.int32).contiguous()
 
 
-def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
+def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True, defer=False):
     """Recover base tables from the reference's product edge lists and verify the Cartesian structure.
 
     A_in_sta [2, P*ks], A_in_src [2, P*kp] as built at process_utils.py:720-721. Returns
     (sta_nbr int32 [S, ks], src_nbr int32 [G, kp]). Raises ValueError when the lists are not the
     full Cartesian product of two uniform-degree base graphs (e.g. `use_subgraph: True`).
+    `defer` (GPU lists only): nothing is read back; returns (sta_nbr, src_nbr, verdict) with `verdict` a bool GPU tensor [3]
+    (not Cartesian, non-uniform station degree, non-uniform source degree) the caller reads when it next synchronises anyway --
+    the tables are cut from the lists' first blocks either way, so a caller may build on them and discard the work if the verdict
+    turns out bad.
     """
     A_in_sta = torch.as_tensor(A_in_sta)
     A_in_src = torch.as_tensor(A_in_src)
@@ -116,7 +120,9 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
     e_sta = A_in_sta.shape[1] // G
     e_src = A_in_src.shape[1] // S
     if A_in_sta.is_cuda and A_in_src.is_cuda and check and e_sta > 0 and e_src > 0:
-        return _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src)
+        return _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src, defer)
+    if defer:
+        raise ValueError("base_tables_from_product(defer=True) takes edge lists resident on the GPU")
     base_sta = A_in_sta[:, :e_sta]
     if int(base_sta.max().item()) >= S:
         raise ValueError("first block of A_in_sta leaves source node 0: not Cartesian")
@@ -136,7 +142,7 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True):
     return neighbour_table(base_sta, S), neighbour_table(base_src, G)
 
 
-def _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src):
+def _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src, defer=False):
     """`base_tables_from_product` for edge lists resident on the GPU (the training call convention hands `forward` new lists per
     sample, train_GENIE_model.py:1722-1786): the Cartesian structure is verified by one pass of `genie_product_check` over the lists
     (no materialised copy), the base tables are cut from their first blocks on the device, and every verdict is read back with ONE
@@ -160,13 +166,18 @@ def _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src):
         # check above rejects cannot index out of range before the verdict is read
         k = e // n
         i = base[1].clamp(0, n - 1)
-        deg_bad = (torch.bincount(i, minlength=n) != k).any() if k * n == e else torch.ones((), dtype=torch.bool, device=dev)
+        # (scatter_add_ on a size known here: torch.bincount reads the largest index back)
+        deg = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(0, i, torch.ones_like(i))
+        deg_bad = (deg != k).any() if k * n == e else torch.ones((), dtype=torch.bool, device=dev)
         order = torch.sort(i, stable=True)[1]
         return base[0][order][: n * k].view(n, k).to(torch.int32).contiguous(), deg_bad
 
     sta_tab, bad1 = table(base_sta, S, e_sta)
     src_tab, bad2 = table(base_src, G, e_src)
-    verdict = torch.stack((flags[0] != 0, bad1, bad2)).tolist()          # the one synchronisation
+    verdict = torch.stack((flags[0] != 0, bad1, bad2))
+    if defer:
+        return sta_tab, src_tab, verdict
+    verdict = verdict.tolist()          # the one synchronisation
     if verdict[0]:
         which = int(flags.item())
         raise ValueError("%s: not Cartesian" % ("A_in_sta is not A_sta_sta (x) I_G" if which & 1 else "A_in_src is not I_S (x) A_src_src"))

@@ -561,9 +561,14 @@ class GCN_Detection_Network_extended(nn.Module):
             self._hip.set_absolute_pos(pos_loc.to(dev), pos_src.to(dev))                  # module.py:1007
 
     def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
-                        A_edges_s, dt_partition, tlatent, pos_loc, pos_src):
+                        A_edges_s, dt_partition, tlatent, pos_loc, pos_src, _defer_checks=False):
         """Same 12 arguments as module.py:941. The product edge lists are reduced to the base kNN graphs (the
-        Cartesian structure is verified) and handed to libgenie_hip once; nothing is rebuilt per window."""
+        Cartesian structure is verified) and handed to libgenie_hip once; nothing is rebuilt per window.
+        `_defer_checks` (used by `forward`, whose graphs change per training sample): with GPU lists of the full product's size the
+        context is built from the lists' first blocks at once and the verdicts of the structure checks stay on the device
+        (`self._pending_checks`) until `_resolve_pending_checks` reads them -- `forward` does after issuing its kernels, so the host
+        prepares a sample's context while the GPU still works on the previous step instead of waiting for it to drain."""
+        self._pending_checks = None
         self.A_in_sta, self.A_in_src = A_in_sta, A_in_src
         self.A_src_in_edges, self.A_Lg_in_src = A_src_in_edges, A_Lg_in_src
         self.A_src_in_sta, self.A_src = A_src_in_sta, A_src
@@ -572,9 +577,15 @@ class GCN_Detection_Network_extended(nn.Module):
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
         n_prod = int(A_src_in_sta.shape[1])
         cartesian = n_prod == n_sta * n_grid
+        verdict = None
+        defer = (_defer_checks and cartesian and torch.is_tensor(A_in_sta) and torch.is_tensor(A_in_src) and A_in_sta.is_cuda and A_in_src.is_cuda
+                 and A_in_sta.shape[1] > 0 and A_in_src.shape[1] > 0 and A_in_sta.shape[1] % n_grid == 0 and A_in_src.shape[1] % n_sta == 0)
         if cartesian:
             try:
-                sta_nbr, src_nbr = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid)
+                if defer:
+                    sta_nbr, src_nbr, verdict = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, defer=True)
+                else:
+                    sta_nbr, src_nbr = _graph.base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid)
             except ValueError:
                 cartesian = False
         if not cartesian:
@@ -588,7 +599,12 @@ class GCN_Detection_Network_extended(nn.Module):
         literal = A_src_t.device == src_nbr.device and tuple(A_src_t.shape) == (2, n_grid * kp) and kp > 0
         if literal:
             centre = torch.arange(n_grid, device=A_src_t.device, dtype=A_src_t.dtype).view(-1, 1)
-            literal = bool(((A_src_t[0].view(n_grid, kp) == src_nbr) & (A_src_t[1].view(n_grid, kp) == centre)).all())     # one read-back
+            literal = ((A_src_t[0].view(n_grid, kp) == src_nbr) & (A_src_t[1].view(n_grid, kp) == centre)).all()
+            if verdict is not None:
+                verdict = torch.cat((verdict, (~literal).view(1)))           # read with the others (_resolve_pending_checks)
+                literal = True
+            else:
+                literal = bool(literal)                                       # one read-back
         if not literal:
             src_from_A = _engine.csr_from_edges(A_src, n_grid)
             a, b = [t.cpu() for t in src_from_A], [t.cpu() for t in src_csr]
@@ -598,7 +614,14 @@ class GCN_Detection_Network_extended(nn.Module):
         self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
         self._edge_attr_version = self._edge_attr._version
         self._hip.set_static_edge_attr(self._edge_attr)
-        dev = self._edge_attr.device
+        self._pending_checks = verdict
+
+    def _resolve_pending_checks(self):
+        """Read the verdicts a deferred `set_adjacencies` left on the device (ONE read-back). True: the context stands. False: the lists
+        are not the Cartesian product the context was built for (or A_src is not written as the product's base graph): the caller
+        repeats `set_adjacencies` without deferral -- which takes the general path or raises, as it always did -- and recomputes."""
+        v, self._pending_checks = getattr(self, "_pending_checks", None), None
+        return v is None or not any(v.tolist())
 
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
@@ -867,7 +890,7 @@ class GCN_Detection_Network_extended(nn.Module):
         key = tuple(tk(t) for t in graph_tensors)
         if getattr(self, "_fwd_key", None) != key:
             self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
-                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart)
+                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart, _defer_checks=True)
             self._fwd_key, self._fwd_refs = key, graph_tensors
         else:
             self.A_src_in_edges, self.A_Lg_in_src = A_src_in_edges, A_Lg_in_src
@@ -876,5 +899,14 @@ class GCN_Detection_Network_extended(nn.Module):
             if ea.data_ptr() != self._edge_attr.data_ptr() or ea._version != getattr(self, "_edge_attr_version", None):
                 self._edge_attr, self._edge_attr_version = ea, ea._version
                 self._hip.set_static_edge_attr(ea)
-        return self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
-                                  x_query_src_cart, t_query, tq_sample, trv_out_q)
+        out = self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
+                                 x_query_src_cart, t_query, tq_sample, trv_out_q)
+        if getattr(self, "_pending_checks", None) is not None and not self._resolve_pending_checks():
+            # the graphs were not what the context was built for: build again with the checks up front (general path or ValueError)
+            self._fwd_key = self._fwd_refs = None
+            self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
+                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart)
+            self._fwd_key, self._fwd_refs = key, graph_tensors
+            out = self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
+                                     x_query_src_cart, t_query, tq_sample, trv_out_q)
+        return out

@@ -2054,6 +2054,50 @@ def test_product_edge_lists_are_verified_on_the_device():
         graph.base_tables_from_product(A1.flip(1).contiguous().to(DEV), A2.to(DEV), S, G)
 
 
+def test_forward_defers_the_structure_checks_and_recovers_when_they_fail():
+    """`forward` (graphs per call, train_GENIE_model.py:1786) builds its context from the first blocks of the GPU product edge lists at
+    once and reads the verdicts of the structure checks after issuing its kernels (one read-back where set_adjacencies made two before any
+    kernel could be queued). Covered: the verdicts are consumed; the same graph with A_src written in another edge ORDER fails the
+    literal comparison, is rebuilt with the checks up front (CSR comparison) and gives bit-identical outputs; a product list with one
+    altered entry is not Cartesian: the call falls back to the general builder with the checks up front, as it always did."""
+    import os
+    from tests.util import GOLDEN_DIR
+    from oracle import genie_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "assoc_7x45.npz"))
+    S, G = int(z["n_sta"]), int(z["n_grid"])
+    t = lambda k, dt=torch.float32: torch.from_numpy(np.asarray(z[k])).to(dt).to(DEV)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net.load_state_dict({k: v.clone() for k, v in O.weights_from_npz(z).items()}, strict=True)
+    net.eval()
+    A1, A2, A3, A4 = graph.cartesian_product_edges(z["A_sta_sta"], z["A_src_src"], S, G)
+    ea = graph.GraphEdges(x=t("edge_attr"), edge_index=A3.to(DEV))
+    tabs = (t("A_edges_p", torch.long), t("A_edges_s", torch.long), t("dt_partition"), t("tlatent"))
+    tail = (t("tpick"), t("ipick", torch.long), t("phase_label"), t("locs"), t("x_grid"), t("x_query"), t("x_query_src"), t("t_query"),
+            t("tq_sample"), t("trv_out_q"))
+    A_src = t("A_src_src", torch.long)
+    calls = []
+    plain = net.set_adjacencies
+    net.set_adjacencies = lambda *a, **k: (calls.append(bool(k.get("_defer_checks"))), plain(*a, **k))[1]
+    with torch.no_grad():
+        ref = net(t("Slice"), t("Mask"), A1.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src, *tabs, *tail)
+        assert calls == [True] and net._pending_checks is None
+        assert max_abs(ref[0].cpu(), torch.from_numpy(z["y"])) <= 1e-5 and max_abs(ref[2].cpu(), torch.from_numpy(z["arv_p"])) <= 1e-5
+        perm = torch.sort(-A_src[1], stable=True)[1]          # in-edges still grouped by centre and in their order, centres descending
+        got = net(t("Slice"), t("Mask"), A1.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src[:, perm].contiguous(), *tabs, *tail)
+        assert calls == [True, True, False] and net._pending_checks is None
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+        bad = A1.clone()
+        bad[0, bad.shape[1] // 2] = (bad[0, bad.shape[1] // 2] + 1) % (S * G)
+        try:           # (the general builder takes the altered list as the irregular graph it describes, or refuses it: as before deferral)
+            other = net(t("Slice"), t("Mask"), bad.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src, *tabs, *tail)
+            assert other[0].shape == ref[0].shape and torch.isfinite(other[0]).all()
+        except (ValueError, RuntimeError):
+            pass
+        assert calls[-2:] == [True, False] and getattr(net, "_pending_checks", None) is None
+        again = net(t("Slice"), t("Mask"), A1.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src, *tabs, *tail)      # and the model still works
+        assert all(torch.equal(a, b) for a, b in zip(ref, again))
+
+
 @pytest.mark.parametrize("n", [3, 200, 10000, 50000])
 def test_device_space_filling_curve_order_equals_the_host_one(n):
     rng = np.random.default_rng(n)

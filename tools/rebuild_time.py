@@ -48,6 +48,7 @@ for rep in range(2):
         t2 = time.perf_counter()
         print("rep %d sample %d: step with rebuild %.2f ms, same graphs again %.2f ms" % (rep, i, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 net(*samples[1])
+torch.cuda.synchronize()          # the profile below starts with an idle device, as the timed steps above do
 pr = cProfile.Profile()
 pr.enable()
 out = net(*samples[0])
