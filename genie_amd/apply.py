@@ -335,6 +335,16 @@ def _dt_embed(kernel_sig_t, dt_embed):
     return float(dt_embed if dt_embed is not None else np.round(kernel_sig_t / 10.0, 2))          # process_continuous_days.py:608
 
 
+_PINNED = {}
+
+
+def _pinned_pair(n):
+    """Two page-locked float64 [n, 3] staging buffers, kept for the life of the process (pinning 2.7 MB costs ~20 ms: not per call)."""
+    if n not in _PINNED:
+        _PINNED[n] = [torch.empty((n, 3), dtype=torch.float64).pin_memory() for _ in range(2)]
+    return _PINNED[n]
+
+
 def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offset_range, n_rand_query, ftrns1, ftrns2,
                    lat_range, lon_range, depth_range, kernel_sig_t=synthetic.KERNEL_SIG_T, dt_embed=None, rand=None, ftrns2_device=None):
     """The refine pass of the caller (process_continuous_days.py:926-980) on the device: for every candidate source `srcs[i]` = (lat, lon,
@@ -359,18 +369,32 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
     dt = _dt_embed(kernel_sig_t, dt_embed)
     n_scale = float(len(legs))
     clouds, found = [], []
+    on_device = ftrns2_device is not None
+    if on_device:      # constants of the loop and every source's Cartesian position: copied once
+        off_rng_d = torch.as_tensor(np.asarray(X_offset_range, dtype=np.float64).reshape(1, 3), device=dev)
+        off_min_d = torch.as_tensor(np.asarray(X_offset_min, dtype=np.float64).reshape(1, 3), device=dev)
+        src_cart_d = torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[:, 0:3]), dtype=np.float64)).to(dev) if srcs.shape[0] else None
+        ninf = torch.full((), float("-inf"), dtype=torch.float32, device=dev)
+        stage, stage_ev = _pinned_pair(n_rand_query), [None, None]
     with torch.no_grad():
         for i in range(srcs.shape[0]):
-            if ftrns2_device is not None:
-                r = torch.from_numpy(np.ascontiguousarray(rand(n_rand_query, 3))).to(dev)                               # the host's draw, float64
-                Xc_d = (torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[i, 0:3].reshape(1, -1)))).to(dev)
-                        + (r * torch.as_tensor(np.asarray(X_offset_range, dtype=np.float64).reshape(1, 3), device=dev)
-                           + torch.as_tensor(np.asarray(X_offset_min, dtype=np.float64).reshape(1, 3), device=dev)))           # :929
+            if on_device:
+                # Nothing in this branch waits for the device (round 5, tools/sync_probe_day.py: eight waits per source before -- pageable
+                # copies, the boolean-mask compaction, three tensor-indexed reads): the draw goes through pinned memory, the queries outside
+                # the region stay in the cloud and are masked out of the argmax (a query's read-out depends on no other query: the same
+                # values and the same refined query as after the reference's compaction), and the refined query's row is gathered on the
+                # device. The host draws source i + 1's cloud while the GPU works on source i.
+                k = i % 2
+                if stage_ev[k] is not None:
+                    stage_ev[k].synchronize()              # the copy that last read this staging buffer (two sources ago) has finished
+                stage[k].numpy()[...] = rand(n_rand_query, 3)                                                         # the host's draw, float64
+                r = stage[k].to(dev, non_blocking=True)
+                stage_ev[k] = torch.cuda.Event()
+                stage_ev[k].record()
+                Xc_d = src_cart_d[i:i + 1] + (r * off_rng_d + off_min_d)                                                  # :929
                 X1_d = ftrns2_device(Xc_d)
                 keep = ((X1_d[:, 0] > lat_range[0]) & (X1_d[:, 0] < lat_range[1]) & (X1_d[:, 1] > lon_range[0]) & (X1_d[:, 1] < lon_range[1])
                         & (X1_d[:, 2] > depth_range[0]) & (X1_d[:, 2] < depth_range[1]))
-                Xc_d = Xc_d[keep]
-                clouds.append(Xc_d)                                   # (Cartesian, on the device: transformed back for the one refined query)
                 xq = Xc_d.float()
             else:
                 Xc = ftrns1(srcs[i, 0:3].reshape(1, -1)) + (rand(n_rand_query, 3) * X_offset_range + X_offset_min)      # :929
@@ -388,19 +412,26 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
                         continue                                                                                        # :966-967
                     _, x = leg.net.forward_fixed_source(em[0], em[1], None, None, None, locs_d, leg.x_grid_cart, xq, tq_d)
                     acc += x[:, :, 0] / n_scale                                                                         # :972
-            if xq.shape[0]:
+            if on_device:
+                accm = torch.where(keep.view(-1, 1), acc, ninf)
+                ip = torch.argmax(accm.max(1)[0]).view(1)                                                               # :976 (first maximum)
+                row = accm.index_select(0, ip)[0]
+                it = torch.argmax(row).view(1)                                                                          # :977
+                found.append(torch.cat((ip.double(), it.double(), row.index_select(0, it).double(), keep.any().double().view(1),
+                                        Xc_d.index_select(0, ip).view(3))))
+            elif xq.shape[0]:
                 ip = torch.argmax(acc.max(1)[0])
                 it = torch.argmax(acc[ip])
                 found.append(torch.stack((ip.double(), it.double(), acc[ip, it].double())))
             else:
                 found.append(torch.full((3,), float("nan"), dtype=torch.float64, device=dev))
-    found = torch.stack(found).cpu().numpy() if found else np.zeros((0, 3))
+    found = torch.stack(found).cpu().numpy() if found else np.zeros((0, 7 if on_device else 3))
     out = np.zeros((srcs.shape[0], 5))
     for i in range(srcs.shape[0]):
-        if clouds[i].shape[0] == 0:
+        if (found[i, 3] == 0.0) if on_device else (clouds[i].shape[0] == 0):
             raise ValueError("refine_sources: no query of source %d lies inside the region (the reference's argmax raises here too)" % i)
         ip, it = int(found[i, 0]), int(found[i, 1])
-        out[i, 0:3] = ftrns2(clouds[i][ip:ip + 1].cpu().numpy())[0] if torch.is_tensor(clouds[i]) else clouds[i][ip]
+        out[i, 0:3] = ftrns2(found[i, 4:7].reshape(1, 3))[0] if on_device else clouds[i][ip]
         out[i, 3] = srcs[i, 3] + tq_host[it]
         out[i, 4] = found[i, 2]
     order = np.argsort(out[:, 3])
@@ -426,6 +457,11 @@ def associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out_s
     zero = torch.zeros(1, device=dev)
     x_save = np.array(x_save, dtype=np.float64).reshape(1, 3)
     Out_p, Out_s, Save_picks, lp_meta = [], [], [], []
+    # the per-source positions of the loop, copied once (a pageable host-to-device copy per source made the host wait for the device)
+    xs_all = np.repeat(x_save, max(srcs.shape[0], 1), axis=0)
+    xs_all[: srcs.shape[0], 2] = srcs[:, 2]                                                                          # :1046
+    xs_cart_all = torch.from_numpy(np.ascontiguousarray(ftrns1(xs_all))).float().to(dev)
+    src_cart_all = torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[:, 0:3]))).float().to(dev) if srcs.shape[0] else None
     with torch.no_grad():
         for i in range(srcs.shape[0]):
             tp, ip, ph, idx = picks.pick_inputs(srcs[i, 3], max_t, kernel_sig_t, t_win)
@@ -437,9 +473,7 @@ def associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out_s
             Out_s.append(acc_s)
             if tp.shape[0] == 0:
                 continue                                                                                                # :1049-1050
-            x_save[0, 2] = srcs[i, 2]                                                                                   # :1046
-            xs_cart = torch.from_numpy(np.ascontiguousarray(ftrns1(x_save))).float().to(dev)
-            src_cart = torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[i, 0:3].reshape(1, -1)))).float().to(dev)
+            xs_cart, src_cart = xs_cart_all[i:i + 1], src_cart_all[i:i + 1]
             tpf, phf = tp.float(), ph.long().float().reshape(-1, 1)
             for leg in legs:
                 em = leg.embed(picks, srcs[i, 3], max_t, kernel_sig_t, dt)

@@ -422,6 +422,63 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ xc, int n
     }
 }
 
+// The same search with ONE LANE per query, for large query sets (the refine pass's 112 000-point clouds, process_continuous_days.py:929:
+// with a wave per query every candidate step paid a lane's insertion -- 156 candidates per lane, a quarter of them enter its list -- and
+// the 64 partial lists were merged afterwards: 4.3 ms of the pass's 4.9 ms per source). Here a lane scans every candidate (tiles of the
+// context staged in LDS, read by all lanes at the same address: a broadcast), its list only ever holds the K best so far, and an
+// insertion happens ~K ln(n / K) times per query: after the first few hundred candidates a wave rarely leaves the distance-and-compare
+// path. That path is fp32 with a guard band (a candidate is dropped only if its fp32 distance exceeds the list's worst by more than
+// 1e-5 relative: fp32 rounding is < 1e-6); everything that passes is decided on the EXACT distance (fp64 of the fp32 coordinates,
+// as k_knn): same neighbours in the same order (distance, then index), bit for bit.
+constexpr int KNN_TILE = 2048;
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_t(const float* __restrict__ xc, int nc, const float* __restrict__ xq, int nq, int k,
+                                               int exclude_self, int32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[KNN_TILE * 4];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int qc = qi < nq ? qi : nq - 1;
+    const float f0 = xq[qc * 3 + 0], f1 = xq[qc * 3 + 1], f2 = xq[qc * 3 + 2];
+    const double q0 = (double)f0, q1 = (double)f1, q2 = (double)f2;
+    double bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
+    float thr = __builtin_inff();                    // fp32 guard of bd[K - 1]
+    for (int c0 = 0; c0 < nc; c0 += KNN_TILE) {
+        const int n = min(KNN_TILE, nc - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float* p = xc + (long long)(c0 + i) * 3;
+            *(f32x4*)(tile + i * 4) = f32x4{p[0], p[1], p[2], 0.f};
+        }
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            const f32x4 cv = *(const f32x4*)(tile + i * 4);
+            const float e0 = f0 - cv.x, e1 = f1 - cv.y, e2 = f2 - cv.z;
+            const float d32 = e0 * e0 + e1 * e1 + e2 * e2;
+            if (!(d32 <= thr)) continue;
+            const int c = c0 + i;
+            if (exclude_self && c == qi) continue;
+            const double d0 = q0 - (double)cv.x, d1 = q1 - (double)cv.y, d2 = q2 - (double)cv.z;                       // exact
+            double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+            if (!(d < bd[K - 1])) continue;              // candidates arrive in increasing index order: a tie never displaces an entry
+            int id = c;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                if (d < bd[t] || (d == bd[t] && id < bi[t])) {      // lexicographic (distance, index), as k_knn: a displaced entry that
+                                                                     // ties with the next slot goes in front of it (smaller index)
+                    const double td = bd[t]; const int ti = bi[t];
+                    bd[t] = d; bi[t] = id; d = td; id = ti;
+                }
+            }
+            thr = (float)bd[K - 1];
+            thr = thr + thr * 1e-5f;                    // inf stays inf
+        }
+    }
+    if (qi < nq)
+        for (int r = 0; r < k; ++r) out[(long long)qi * k + r] = bi[r] == 0x7fffffff ? -1 : bi[r];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Downstream reduction of the apply loop on the device: the stacked query output Out_2 [rows = queries,
 // cols = time steps] never leaves the GPU whole. MODE 0: entries above a threshold, `np.where(Out_2 > 0.01)`

@@ -3968,6 +3968,13 @@ int genie_knn(const float* x_context, int n_context, const float* x_query, int n
         return fail(GENIE_ERR_ARG, "genie_knn: bad argument (1 <= k <= 16)");
     if (n_query == 0) return GENIE_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (n_query >= 16384 && k <= 10) {        // a lane per query (k_knn_t): enough queries to fill the device that way
+        const int nbt = (n_query + 255) / 256;
+        if (k <= 8) k_knn_t<8><<<nbt, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+        else k_knn_t<10><<<nbt, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+        HIP_TRY(hipGetLastError());
+        return GENIE_OK;
+    }
     const int nb = (n_query + 3) / 4;
     if (k <= 8) k_knn<8><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
     else if (k <= 10) k_knn<10><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);

@@ -1629,6 +1629,37 @@ def test_device_knn_matches_exact_search(nc, nq, k):
         assert np.array_equal(tab.cpu().numpy().reshape(-1), ref[0])
 
 
+@pytest.mark.parametrize("nc,nq,k,self_", [(3000, 20000, 10, False), (5, 16400, 10, False), (2049, 17000, 8, False), (16500, 16500, 10, True)])
+def test_device_knn_lane_per_query_kernel(nc, nq, k, self_):
+    """Query sets of >= 16 384 points take k_knn_t (one lane per query, fp32 guard band in front of the exact fp64 decision; the refine
+    pass's 112 000-point clouds, process_continuous_days.py:929): same table as the exact host search, nearest first, ties by index --
+    the context holds DUPLICATED points (equal distances) and a cluster the queries sit in (the guard band's job), fewer context
+    points than k, a context one point past an LDS tile, and the base graph of a set with itself (`exclude_self`)."""
+    rng = np.random.default_rng(nc + nq)
+    xc = np.stack([rng.uniform(0, 300e3, nc), rng.uniform(0, 300e3, nc), rng.uniform(-40e3, 2e3, nc)], axis=1).astype(np.float32)
+    if nc >= 100:
+        xc[nc // 2: nc // 2 + 20] = xc[10:30]                                  # duplicates: ties in distance, decided by index
+        xc[60:90] = xc[59] + rng.uniform(-40.0, 40.0, (30, 3)).astype(np.float32)  # a tight cluster
+    if self_:
+        xq = xc
+    else:
+        xq = np.stack([rng.uniform(0, 300e3, nq), rng.uniform(0, 300e3, nq), rng.uniform(-40e3, 2e3, nq)], axis=1).astype(np.float32)
+        if nc >= 100:
+            xq[:4000] = xc[59] + rng.uniform(-15e3, 15e3, (4000, 3)).astype(np.float32)   # a cloud around the cluster
+            xq[4000:4040] = xc[10:50]                                                     # queries ON context points (distance 0, tied)
+    got = engine.knn_device(torch.from_numpy(xc).to(DEV), torch.from_numpy(xq).to(DEV), k, exclude_self=self_).cpu().numpy()
+    kk = min(k, nc - (1 if self_ else 0))
+    assert got.shape == (xq.shape[0], kk)
+    c64 = xc.astype(np.float64)
+    for a in range(0, xq.shape[0], 2000):
+        q = xq[a:a + 2000].astype(np.float64)
+        d = ((q[:, None, :] - c64[None, :, :]) ** 2).sum(-1)
+        if self_:
+            d[np.arange(q.shape[0]), np.arange(a, a + q.shape[0])] = np.inf
+        want = np.argsort(d, axis=1, kind="stable")[:, :kk]
+        assert np.array_equal(got[a:a + 2000], want), a
+
+
 def test_set_adjacencies_from_positions_equals_host_built_graphs():
     """Graph setup on the device (genie_knn -> device CSR) gives the same forward as the host-built base graphs."""
     c = Case("cfg1_20x500")
