@@ -170,7 +170,9 @@ def _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src, def
         deg = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(0, i, torch.ones_like(i))
         deg_bad = (deg != k).any() if k * n == e else torch.ones((), dtype=torch.bool, device=dev)
         order = torch.sort(i, stable=True)[1]
-        return base[0][order][: n * k].view(n, k).to(torch.int32).contiguous(), deg_bad
+        # (neighbour ids clamped as well: with `defer` a context is built on this table before the verdict is read, and a list whose first
+        # block leaves its node range -- which the check flags -- must not make a kernel read out of bounds meanwhile)
+        return base[0][order][: n * k].clamp(0, n - 1).view(n, k).to(torch.int32).contiguous(), deg_bad
 
     sta_tab, bad1 = table(base_sta, S, e_sta)
     src_tab, bad2 = table(base_src, G, e_src)

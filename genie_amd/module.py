@@ -597,6 +597,11 @@ class GCN_Detection_Network_extended(nn.Module):
         # the reference hands over the very edge list the product was built from (process_utils.py:719-721: in-edges grouped by centre,
         # centres ascending): one comparison on the lists' own device; any other ordering of the same graph takes the CSR comparison
         literal = A_src_t.device == src_nbr.device and tuple(A_src_t.shape) == (2, n_grid * kp) and kp > 0
+        if verdict is not None and not literal:
+            # not even the shape of the literal form (e.g. base graphs of non-uniform degree, whose tables above are meaningless): nothing
+            # to build on, take the path with the checks up front
+            return self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
+                                        dt_partition, tlatent, pos_loc, pos_src)
         if literal:
             centre = torch.arange(n_grid, device=A_src_t.device, dtype=A_src_t.dtype).view(-1, 1)
             literal = ((A_src_t[0].view(n_grid, kp) == src_nbr) & (A_src_t[1].view(n_grid, kp) == centre)).all()
