@@ -422,6 +422,70 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ xc, int n
     }
 }
 
+// A handful of queries (the one spatial query and the one candidate source of the association pass, process_continuous_days.py:1052;
+// the 4-8 source queries of a training sample): with a wave per query ONE wave walked the whole context -- 134-170 us per call at 10 000
+// grid nodes, twice per forward_fixed -- so a query gets a workgroup of 16 waves instead: every lane scans a 1024-th of the context
+// (same exact arithmetic and per-lane lists as k_knn), every wave pops its K best into LDS, wave 0 merges the 16 lists. Same table.
+template <int K>
+__global__ __launch_bounds__(1024) void k_knn_b(const float* __restrict__ xc, int nc, const float* __restrict__ xq, int nq, int k,
+                                                int exclude_self, int32_t* __restrict__ out) {
+    __shared__ double sd[16 * K];
+    __shared__ int si[16 * K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    const double q0 = (double)xq[qi * 3 + 0], q1 = (double)xq[qi * 3 + 1], q2 = (double)xq[qi * 3 + 2];
+    double bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
+    auto insert = [&](double d, int id) {
+        if (d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1])) {
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                if (d < bd[t] || (d == bd[t] && id < bi[t])) {
+                    const double td = bd[t]; const int ti = bi[t];
+                    bd[t] = d; bi[t] = id; d = td; id = ti;
+                }
+            }
+        }
+    };
+    auto pop = [&](double& md, int& mi) {          // the wave's smallest (distance, index); its owner drops it
+        md = bd[0]; mi = bi[0];
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const double od = __shfl_xor(md, s);
+            const int oi = __shfl_xor(mi, s);
+            if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (bi[0] == mi && bd[0] == md && mi != 0x7fffffff) {
+#pragma unroll
+            for (int t = 0; t + 1 < K; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+            bd[K - 1] = __builtin_inf(); bi[K - 1] = 0x7fffffff;
+        }
+    };
+    for (int c = threadIdx.x; c < nc; c += 1024) {
+        if (exclude_self && c == qi) continue;
+        const double d0 = q0 - (double)xc[c * 3 + 0], d1 = q1 - (double)xc[c * 3 + 1], d2 = q2 - (double)xc[c * 3 + 2];   // exact
+        insert(__dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2)), c);
+    }
+    for (int r = 0; r < K; ++r) {
+        double md; int mi;
+        pop(md, mi);
+        if (lane == 0) { sd[wave * K + r] = md; si[wave * K + r] = mi; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
+    for (int e = lane; e < 16 * K; e += 64)
+        if (si[e] != 0x7fffffff) insert(sd[e], si[e]);
+    for (int r = 0; r < k; ++r) {
+        double md; int mi;
+        pop(md, mi);
+        if (lane == 0) out[(long long)qi * k + r] = mi == 0x7fffffff ? -1 : mi;
+    }
+}
+
 // The same search with ONE LANE per query, for large query sets (the refine pass's 112 000-point clouds, process_continuous_days.py:929:
 // with a wave per query every candidate step paid a lane's insertion -- 156 candidates per lane, a quarter of them enter its list -- and
 // the 64 partial lists were merged afterwards: 4.3 ms of the pass's 4.9 ms per source). Here a lane scans every candidate (tiles of the

@@ -3975,6 +3975,12 @@ int genie_knn(const float* x_context, int n_context, const float* x_query, int n
         HIP_TRY(hipGetLastError());
         return GENIE_OK;
     }
+    if (n_query <= 64 && n_context >= 4096 && k <= 10) {      // a workgroup of 16 waves per query (k_knn_b)
+        if (k <= 8) k_knn_b<8><<<n_query, 1024, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+        else k_knn_b<10><<<n_query, 1024, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
+        HIP_TRY(hipGetLastError());
+        return GENIE_OK;
+    }
     const int nb = (n_query + 3) / 4;
     if (k <= 8) k_knn<8><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);
     else if (k <= 10) k_knn<10><<<nb, 256, 0, st>>>(x_context, n_context, x_query, n_query, k, exclude_self, out_idx);

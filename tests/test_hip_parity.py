@@ -1610,13 +1610,17 @@ def test_station_processing_order_is_internal_only(S, G):
         engine.HipPath(S, G, sta, src, device=DEV, sta_order=np.zeros(S, dtype=np.int64))
 
 
-@pytest.mark.parametrize("nc,nq,k", [(500, 300, 10), (10000, 2500, 10), (37, 50, 10), (5, 7, 10), (3000, 3000, 15), (200, 200, 8)])
+@pytest.mark.parametrize("nc,nq,k", [(500, 300, 10), (10000, 2500, 10), (37, 50, 10), (5, 7, 10), (3000, 3000, 15), (200, 200, 8),
+                                     (5000, 1, 10), (10000, 8, 10), (4096, 64, 8), (4097, 3, 10)])      # (the last four: k_knn_b)
 def test_device_knn_matches_exact_search(nc, nq, k):
     """genie_knn (module.py:282 / process_utils.py:718-719) against an exact fp64 search on the host: same neighbour sets in
     the same (nearest-first) order; with `exclude_self` the table equals genie_amd.graph.knn_graph (cKDTree, self removed)."""
     rng = np.random.default_rng(nc + nq)
     xc = np.stack([rng.uniform(0, 300e3, nc), rng.uniform(0, 300e3, nc), rng.uniform(-40e3, 2e3, nc)], axis=1).astype(np.float32)
     xq = np.stack([rng.uniform(0, 300e3, nq), rng.uniform(0, 300e3, nq), rng.uniform(-40e3, 2e3, nq)], axis=1).astype(np.float32)
+    if nc >= 4096:                                                              # ties: duplicated context points, a query on one of them
+        xc[nc // 2: nc // 2 + 12] = xc[100:112]
+        xq[0] = xc[105]
     got = engine.knn_device(torch.from_numpy(xc).to(DEV), torch.from_numpy(xq).to(DEV), k).cpu().numpy()
     kk = min(k, nc)
     d = ((xq.astype(np.float64)[:, None, :] - xc.astype(np.float64)[None, :, :]) ** 2).sum(-1)
