@@ -503,11 +503,20 @@ __global__ __launch_bounds__(256) void k_knn_t(const float* __restrict__ xc, int
     const int qc = qi < nq ? qi : nq - 1;
     const float f0 = xq[qc * 3 + 0], f1 = xq[qc * 3 + 1], f2 = xq[qc * 3 + 2];
     const double q0 = (double)f0, q1 = (double)f1, q2 = (double)f2;
+    // The K best so far UNSORTED, with the slot of the worst one (largest (distance, index)) tracked: an accepted candidate overwrites
+    // that slot and the worst is found again (K compares) -- about half the instructions of keeping the list sorted by a K-step
+    // bubble, and in this kernel the accept path is what a wave mostly pays for (some lane accepts in ~a quarter of the steps). The
+    // list is sorted once per query at the end.
     double bd[K];
     int bi[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff; }
-    float thr = __builtin_inff();                    // fp32 guard of bd[K - 1]
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inf(); bi[t] = 0x7fffffff - t; }      // (placeholders with distinct indices; slot 0 is the worst)
+    double wd = __builtin_inf();
+    int wi = 0x7fffffff;                             // the worst entry: candidates arrive in increasing index order, so a tie never displaces it
+    float thr = __builtin_inff();                    // fp32 guard of wd
+    // tiles of the context staged in LDS, read by all lanes at the same address (a broadcast). (Reading the wave-uniform candidate
+    // through the scalar cache instead -- three 16-byte scalar loads per four candidates, no staging, no barrier -- measured the same:
+    // 2.44 against 2.38 ms at 112 000 x 10 000.)
     for (int c0 = 0; c0 < nc; c0 += KNN_TILE) {
         const int n = min(KNN_TILE, nc - c0);
         __syncthreads();
@@ -524,23 +533,33 @@ __global__ __launch_bounds__(256) void k_knn_t(const float* __restrict__ xc, int
             const int c = c0 + i;
             if (exclude_self && c == qi) continue;
             const double d0 = q0 - (double)cv.x, d1 = q1 - (double)cv.y, d2 = q2 - (double)cv.z;                       // exact
-            double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-            if (!(d < bd[K - 1])) continue;              // candidates arrive in increasing index order: a tie never displaces an entry
-            int id = c;
+            const double d = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+            if (!(d < wd)) continue;
+            double nd = -1.0;                            // replace the worst, find the new worst (lexicographic maximum)
+            int ni = 0;
 #pragma unroll
             for (int t = 0; t < K; ++t) {
-                if (d < bd[t] || (d == bd[t] && id < bi[t])) {      // lexicographic (distance, index), as k_knn: a displaced entry that
-                                                                     // ties with the next slot goes in front of it (smaller index)
-                    const double td = bd[t]; const int ti = bi[t];
-                    bd[t] = d; bi[t] = id; d = td; id = ti;
-                }
+                if (bi[t] == wi) { bd[t] = d; bi[t] = c; }
+                if (bd[t] > nd || (bd[t] == nd && bi[t] > ni)) { nd = bd[t]; ni = bi[t]; }
             }
-            thr = (float)bd[K - 1];
+            wd = nd; wi = ni;
+            thr = (float)wd;
             thr = thr + thr * 1e-5f;                    // inf stays inf
         }
     }
+    // sort by (distance, index): K is small, once per query
+#pragma unroll
+    for (int a = 0; a < K - 1; ++a) {
+#pragma unroll
+        for (int t = 0; t < K - 1 - a; ++t) {
+            if (bd[t + 1] < bd[t] || (bd[t + 1] == bd[t] && bi[t + 1] < bi[t])) {
+                const double td = bd[t]; const int ti = bi[t];
+                bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; bd[t + 1] = td; bi[t + 1] = ti;
+            }
+        }
+    }
     if (qi < nq)
-        for (int r = 0; r < k; ++r) out[(long long)qi * k + r] = bi[r] == 0x7fffffff ? -1 : bi[r];
+        for (int r = 0; r < k; ++r) out[(long long)qi * k + r] = bi[r] >= 0x7fffffff - K ? -1 : bi[r];
 }
 
 // ------------------------------------------------------------------------------------------------
