@@ -240,3 +240,31 @@ def test_detection_to_association_chain_matches_its_steps():
     none = apply.detect_refine_associate([s.leg], s.picks, torch.zeros_like(Out_2), xq, ts, s.locs, trv, s.tq, s.max_t, ident, ident, *ranges,
                                          off_min, off_rng, 200, thresh, src_t_kernel, dt_win, break_win, tc_win, sp_win, **kw)
     assert len(none["srcs"]) == 0 and none["Out_p_save"] == []
+
+
+def test_two_identical_grid_legs_equal_one():
+    """The reference averages the loops' outputs over its source grids (`x_grid_ind` loops, `/ n_scale_x_grid_1`, process_continuous_days.py
+    :972, :1054-1055). With the same grid listed twice the average is exact in fp32 (x / 2 + x / 2), so both passes must return what one
+    leg returns, bit for bit: the accumulation over legs, the scale and the per-leg embedding calls are what this exercises."""
+    s = _Setup()
+    ga = s.geom_all
+    rng = np.random.default_rng(9)
+    nodes = rng.choice(s.G, 3, replace=False)
+    srcs = np.concatenate((ga.x_grid[nodes], rng.uniform(6998.0, 7008.0, (3, 1)), np.full((3, 1), 0.5)), axis=1)
+    off_min, off_rng = np.array([[-5e3, -5e3, -3e3]]), np.array([[10e3, 10e3, 6e3]])
+    ident = lambda x: x
+    ranges = ((0.0, 60e3), (0.0, 60e3), (-40e3, 2e3))
+    kw = dict(kernel_sig_t=s.sig, dt_embed=s.dt)
+    outs = []
+    for legs in ([s.leg], [s.leg, s.leg]):
+        ref, order = apply.refine_sources(legs, s.picks, srcs, s.locs, s.tq, s.max_t, off_min, off_rng, 250, ident, ident, *ranges,
+                                          rand=np.random.RandomState(5).rand, ftrns2_device=ident, **kw)
+        d = np.linalg.norm(s.locs[None, :, :] - ref[:, None, 0:3], axis=2)
+        trv = np.stack((d / 6000.0, d / 3500.0), axis=2)
+        Op, Os, Sp, Lm = apply.associate_sources(legs, s.picks, ref, s.locs, s.tq, s.max_t, trv, ident, np.array([0.0, 0.0, 0.0]), **kw)
+        outs.append((ref, order, Op, Os, Sp))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert len(a[2]) == len(b[2]) == 3 and sum(int(o.numel()) for o in a[2]) > 0
+    for i in range(3):
+        assert torch.equal(a[2][i], b[2][i]) and torch.equal(a[3][i], b[3][i]) and np.array_equal(a[4][i], b[4][i])
