@@ -202,12 +202,12 @@ __global__ __launch_bounds__(256) void k_assoc_a(AsArgs a) {
     }
 }
 
-template <bool PCSR>
-__global__ __launch_bounds__(256) void k_assoc_b(AsArgs a) {
+template <bool PCSR, int WPB = 4>      // WPB: waves per workgroup (they share one copy of the weight image: more of them fit a CU)
+__global__ __launch_bounds__(WPB * 64) void k_assoc_b(AsArgs a) {
     constexpr int NF4 = (GB_GROUPS * 256 + GB_BIAS * 16 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 68];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __shared__ __attribute__((aligned(16))) float tsc[WPB * 16 * 68];
+    for (int i = threadIdx.x; i < NF4; i += WPB * 64) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lbias = (const float*)(lw + GB_GROUPS * 64);
     const float* lscal = lbias + GB_BIAS * 16;

@@ -3859,7 +3859,10 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
         a.packed = c->packed[2];
         k_assoc_a<false><<<grid, 256, 0, st>>>(a);
         a.packed = c->packed[3];
-        k_assoc_b<false><<<grid, 256, 0, st>>>(a);
+        // k_assoc_b is bound by its 23 gathered 128-B rows per node and, at 4 waves per workgroup, by LDS to 8 waves per CU (every
+        // workgroup holds its own 52-KB copy of the weight image): ONE workgroup of 16 waves per CU shares one copy -- 969 -> 824 us at
+        // config 2 (12 waves: 882; 8 waves in one workgroup: 987; `tools/assoc_ab.sh`)
+        k_assoc_b<false, 16><<<std::max(8, c->num_cu / 8 * 8), 1024, 0, st>>>(a);
     }
     // second pair of neighbour means + PReLU2 = the stage-2 kernel of this context without its Bipartite half
     rc = run_stage2(c, mask, edge_attr, out, ws, stream, 0, c->G, c->raw + g_params[W_AS_ACT2].off, 1);
