@@ -2689,7 +2689,7 @@ int get_s2u_tables(genie_ctx* c, int gb0, int ge0, const genie_ctx::S2uTables** 
             }
             for (int e = b.n; e < S2U_NB; ++e) b.idx[e][0] = -1;       // empty slots of a short block
             b.U = (int32_t)nuni;
-            for (int u = 0; u < S2U_UCAP; ++u) b.ids[u] = uni[u < nuni ? u : 0];
+            for (int u = 0; u < 64; ++u) b.ids[u] = uni[u < nuni ? u : 0];
             blks.push_back(b);
         }
     }
@@ -2757,7 +2757,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             if ((rc = get_s2u_tables(c, gi_begin, gi_end, &tb))) return rc;
             const size_t lds = sizeof(float) * S2H_IMG_FLOATS + (size_t)S2U_UCAP * 1024;
             const long long items = (long long)tb->nblk * c->T;
-            const int grid = (int)std::max<long long>(8, std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8) / 8 * 8);
+            const int grid = (int)std::max<long long>(8, std::min<long long>((long long)c->num_cu * GENIE_S2U_BPC, (items + 7) / 8 * 8) / 8 * 8);
             const bool big = c->P_ext * 128 >= (1ll << 32);
             auto launch = [&](auto kern) -> int {
                 if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;
@@ -2816,7 +2816,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                 if ((rc = get_s2u_tables(c, gi_begin, gi_end, &tb))) return rc;
                 const size_t lds = sizeof(float) * S2H_IMG_FLOATS + (size_t)S2U_UCAP * 1024;
                 const long long items = (long long)tb->nblk * c->T;
-                const long long gsz = std::min<long long>((long long)c->num_cu * 2, (items + 7) / 8 * 8);
+                const long long gsz = std::min<long long>((long long)c->num_cu * GENIE_S2U_BPC, (items + 7) / 8 * 8);
                 const int grid = (int)std::max<long long>(8, gsz / 8 * 8);
                 auto launch = [&](auto kern) -> int {      // (the 70-KB dynamic LDS needs the attribute once per kernel and device)
                     if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;

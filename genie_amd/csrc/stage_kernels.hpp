@@ -1658,16 +1658,24 @@ __global__ __launch_bounds__(256) void k_h2_range(RangeArgs a) {
 // bit (the row sums keep the edge order).
 // ------------------------------------------------------------------------------------------------
 constexpr int S2U_NB = 8;            // source nodes per block (two per wave)
-constexpr int S2U_UCAP = 64;         // distinct neighbour rows of a block (a block is cut short where the union would exceed it)
+#ifndef GENIE_S2U_UCAP
+#define GENIE_S2U_UCAP 64
+#endif
+#ifndef GENIE_S2U_BPC
+#define GENIE_S2U_BPC 2
+#endif
+constexpr int S2U_UCAP = GENIE_S2U_UCAP;   // distinct neighbour rows of a block (a block is cut short where the union would exceed it), <= 64.
+                                           // (Round 5: 32 rows at 4 workgroups per CU, 48 at 3 -- more resident waves, less sharing and blocks cut short
+                                           // with empty node slots -- 0.711 and 0.374 ms against 0.202: the staging is what this kernel lives on.)
 constexpr int S2U_NSTG = S2U_UCAP / 4;
 struct S2uBlock {                    // one block of the processing order
     int32_t gi0, n, U, pad;          // first position, source nodes (1 .. 8), union size
-    int32_t ids[S2U_UCAP];           // source node of union row u (padded with row 0)
+    int32_t ids[64];                 // source node of union row u (padded with row 0); one per lane of the wave that stages them
     int32_t idx[S2U_NB][16];         // node b: [0] = its source node id (-1: the block has no node b), [1 + k] = union row of its k-th neighbour
 };
 
 template <bool XL, bool BIG, bool SAVE = false>      // SAVE: training forward (pre-activations of x_latent and of the Bipartite message kept)
-__global__ __launch_bounds__(256, 2) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
+__global__ __launch_bounds__(256, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
     constexpr int KS = 8, KP = 15;
     constexpr int NF4 = S2H_IMG_FLOATS / 4;
     extern __shared__ __attribute__((aligned(16))) f32x4 s2u_smem[];
