@@ -2761,7 +2761,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
             const bool big = c->P_ext * 128 >= (1ll << 32);
             auto launch = [&](auto kern) -> int {
                 if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;
-                kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
+                kern<<<grid, S2U_WPB * 64, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
                 return GENIE_OK;
             };
             if (x_latent_out) rc = big ? launch(k_stage2_h2u<true, true, true>) : launch(k_stage2_h2u<true, false, true>);
@@ -2820,7 +2820,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
                 const int grid = (int)std::max<long long>(8, gsz / 8 * 8);
                 auto launch = [&](auto kern) -> int {      // (the 70-KB dynamic LDS needs the attribute once per kernel and device)
                     if (int r = raise_lds_limit(c, (const void*)kern, 160 * 1024)) return r;
-                    kern<<<grid, 256, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
+                    kern<<<grid, S2U_WPB * 64, lds, st>>>(a, (const S2uBlock*)tb->blocks, tb->xcd0);
                     return GENIE_OK;
                 };
                 if (x_latent_out) rc = big ? launch(k_stage2_h2u<true, true>) : launch(k_stage2_h2u<true, false>);

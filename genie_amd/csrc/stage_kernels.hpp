@@ -1657,7 +1657,12 @@ __global__ __launch_bounds__(256) void k_h2_range(RangeArgs a) {
 // Everything per node (streamed rows, station-neighbour gathers, f16x2 fc1, station sum) is k_stage2_h2's code: same results bit for
 // bit (the row sums keep the edge order).
 // ------------------------------------------------------------------------------------------------
-constexpr int S2U_NB = 8;            // source nodes per block (two per wave)
+#ifndef GENIE_S2U_WPB
+#define GENIE_S2U_WPB 4
+#endif
+constexpr int S2U_WPB = GENIE_S2U_WPB;   // waves per workgroup (round 5: 8 waves = blocks of 16 source nodes on the same 64-row union, twice the resident
+                                         // waves: 0.264 against 0.198 ms -- the 64-row cap cuts such blocks at 11-13 nodes and leaves a quarter of the slots empty)
+constexpr int S2U_NB = 2 * S2U_WPB;  // source nodes per block (two per wave)
 #ifndef GENIE_S2U_UCAP
 #define GENIE_S2U_UCAP 64
 #endif
@@ -1667,7 +1672,7 @@ constexpr int S2U_NB = 8;            // source nodes per block (two per wave)
 constexpr int S2U_UCAP = GENIE_S2U_UCAP;   // distinct neighbour rows of a block (a block is cut short where the union would exceed it), <= 64.
                                            // (Round 5: 32 rows at 4 workgroups per CU, 48 at 3 -- more resident waves, less sharing and blocks cut short
                                            // with empty node slots -- 0.711 and 0.374 ms against 0.202: the staging is what this kernel lives on.)
-constexpr int S2U_NSTG = S2U_UCAP / 4;
+constexpr int S2U_NSTG = S2U_UCAP / S2U_WPB;
 struct S2uBlock {                    // one block of the processing order
     int32_t gi0, n, U, pad;          // first position, source nodes (1 .. 8), union size
     int32_t ids[64];                 // source node of union row u (padded with row 0); one per lane of the wave that stages them
@@ -1675,7 +1680,7 @@ struct S2uBlock {                    // one block of the processing order
 };
 
 template <bool XL, bool BIG, bool SAVE = false>      // SAVE: training forward (pre-activations of x_latent and of the Bipartite message kept)
-__global__ __launch_bounds__(256, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
+__global__ __launch_bounds__(S2U_WPB * 64, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, const S2uBlock* __restrict__ blocks, const int32_t* __restrict__ xcd_blk0) {
     constexpr int KS = 8, KP = 15;
     constexpr int NF4 = S2H_IMG_FLOATS / 4;
     extern __shared__ __attribute__((aligned(16))) f32x4 s2u_smem[];
@@ -1724,7 +1729,7 @@ __global__ __launch_bounds__(256, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, con
         const unsigned lo = kgp + (unsigned)sc * 16u;
 #pragma unroll
         for (int i = 0; i < S2U_NSTG; ++i) {
-            const int u = wave + 4 * i;
+            const int u = wave + S2U_WPB * i;
             if (u < U) {
                 const unsigned long long vb = s2h_base<BIG>(a.wv, __builtin_amdgcn_readlane(idl, u), pw);
                 stg[i] = *(grow)((gbytes)vb + lo);
@@ -1734,7 +1739,7 @@ __global__ __launch_bounds__(256, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, con
     auto stage_write = [&](int U) {
 #pragma unroll
         for (int i = 0; i < S2U_NSTG; ++i) {
-            const int u = wave + 4 * i;
+            const int u = wave + S2U_WPB * i;
             if (u < U) *(f32x4*)(lrows + (unsigned)u * 1024u + (unsigned)lane * 16u) = stg[i];
         }
     };
@@ -1767,7 +1772,7 @@ __global__ __launch_bounds__(256, GENIE_S2U_BPC) void k_stage2_h2u(DaArgs a, con
     // slot number j -> (item j / 2, half j % 2); index rows are loaded two slots ahead, station ids and per-node rows one ahead.
     auto slot = [&](long long j, int& blk, int& tb, int& b) {
         item_of(lb + (j >> 1) * nbx, blk, tb);
-        b = wave + 4 * (int)(j & 1);
+        b = wave + S2U_WPB * (int)(j & 1);
     };
     auto idv_at = [&](long long j) {
         int blk, tb, b;
