@@ -3363,6 +3363,12 @@ int genie_linear_bwd_wb(const float* x, const float* dy, int64_t N, int K, int M
 }
 
 namespace {
+// Waves per workgroup of the lightest backward pass on a Cartesian graph (k_train_b2: 60 registers, 6 accumulator tiles). It streams
+// its rows once and is bound by the latency of those loads; at the 4 waves of the heavy passes a CU held 8 such waves. 8 per
+// workgroup: 289 -> 202 us (16: the same, and four times the partials for the reduction to read); tools/train_ab.sh. The same for the
+// association phase's light passes did not pay: k_as_b3 174 -> 167 us, k_as_b0 (88 registers, 12 tiles) 301 -> 334 us: they keep 4.
+// Every wave still writes its own partial slot; the scratch is sized by the heaviest pass (30 tiles x 4 waves).
+constexpr int TR_WPB_LIGHT = 8;
 int train_grid(const genie_ctx* c) {
 #if GENIE_TUNING
     { static const char* e = getenv("GENIE_TRAIN_WG"); if (e) return std::max(8, c->num_cu * atoi(e) / 8 * 8); }
@@ -3538,7 +3544,7 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
             else if (s == 1) k_train_b1p<false><<<grid, 256, 0, st>>>(a);
             else k_train_b0<true><<<grid, 256, 0, st>>>(a);
         } else {
-            if (s == 0) k_train_b2<false><<<grid, 256, 0, st>>>(a);
+            if (s == 0) k_train_b2<false, TR_WPB_LIGHT><<<grid, TR_WPB_LIGHT * 64, 0, st>>>(a);
             else if (s == 1) {
                 if (o32) k_train_b1<false, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
             }
@@ -3546,7 +3552,8 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
             else k_train_b0<false><<<grid, 256, 0, st>>>(a);
         }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_w * 4, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
+        const int wpb_s = (s == 0 && !c->pcsr) ? TR_WPB_LIGHT : 4;
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_w * wpb_s, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob, 0);
     }
     if (c->has_edges || c->abs_sta) {

@@ -37,8 +37,8 @@ __device__ __forceinline__ f32x4 ld30_half(const float* __restrict__ row, int t,
 }
 
 // ---- d s -> do
-template <bool PCSR>
-__global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict__ ds, const float* __restrict__ slope) {
+template <bool PCSR, int WPB = 4>      // WPB: waves per workgroup (as k_train_b2: a streaming pass, more resident waves hide its latency)
+__global__ __launch_bounds__(WPB * 64) void k_as_b3(TrArgs a, const float* __restrict__ ds, const float* __restrict__ slope) {
     const float a2 = *slope;
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
     const long long P = a.P;
     float scal[1] = {0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, WPB, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         bool valid;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_as_b3(TrArgs a, const float* __restrict
             if (valid) stb(a.gr, GR_DO + t, P, p, q, d * dprelu4(o, a2));
         }
     }
-    write_partials(a, blockIdx.x * 4 + wave, nullptr, 0, nullptr, 0, scal, 1, lane, j, q);
+    write_partials(a, blockIdx.x * WPB + wave, nullptr, 0, nullptr, 0, scal, 1, lane, j, q);
 }
 
 // ---- layer 1, l1_t1_1 / l1_t2_1 and the activation of init_trns
@@ -223,12 +223,12 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
 // ---- init_trns and BipartiteGraphReadOutOperator
 // accumulators: init_trns (tile t) x {s, x_latent 0:16, x_latent 16:30, Mask} = 8; fc2 (msg blocks) = 2; fc1 edge_attr columns (t) = 2 -> 12
 // vec: b(init_trns) x2, its mask1 column x2, b(fc2), b(fc1) x2 = 7; scal: activate1, activate2 of the read-out operator
-template <bool PCSR>
-__global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
+template <bool PCSR, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64, 1) void k_as_b0(TrArgs a) {
     constexpr int NF4 = (GA0_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __shared__ __attribute__((aligned(16))) float tsc[WPB][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += WPB * 64) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GA0_GROUPS * 64);
     const float r1 = lscal[0], r2 = lscal[1];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, WPB, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g, scn = 0, tb = 0;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b0(TrArgs a) {
         acc[8] = outer16(acc[8], dspt, tr16(msg[0], sc, j, q));
         acc[9] = outer16(acc[9], dspt, tr16(msg[1], sc, j, q));
     }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 12, vec, 7, scal, 2, threadIdx.x & 63, j, q);
+    write_partials(a, blockIdx.x * WPB + wave, acc, 12, vec, 7, scal, 2, threadIdx.x & 63, j, q);
 }
 
 // irregular product graph: out[g][16 b + c] = sum over the product nodes of source node g of block b's rows ([2][P][16], row order)

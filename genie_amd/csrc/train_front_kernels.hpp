@@ -227,12 +227,13 @@ __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f
 }
 
 // ---- pass 2': Bipartite message + PReLU2.  accumulators: fc1 (t, {x_latent 0:15, x_latent 15:30, edge_attr}) = 6; vec: fc1 bias (2)
-template <bool PCSR>
-__global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
+template <bool PCSR, int WPB = 4>      // WPB: waves per workgroup (60 registers, 6 accumulator tiles: this pass is bound by the latency of its
+                                       // streamed rows, and more resident waves are what hides it)
+__global__ __launch_bounds__(WPB * 64, 1) void k_train_b2(TrArgs a) {
     constexpr int NF4 = (GT2_GROUPS * 256 + 16) / 4;
     __shared__ f32x4 lw[NF4];
-    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
-    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __shared__ __attribute__((aligned(16))) float tsc[WPB][16 * 17];
+    for (int i = threadIdx.x; i < NF4; i += WPB * 64) lw[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const float* lscal = (const float*)(lw + GT2_GROUPS * 64);
     const float a2 = lscal[0], ab1 = lscal[1];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
     for (int k = 0; k < 6; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     vec[0] = vec[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
-    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
+    PtileIter ptw(PCSR ? (P + 15) / 16 : 0, WPB, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
     for (long long it = it0; it < n_it; it += its) {
         int g;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_train_b2(TrArgs a) {
             acc[t * 3 + 2] = outer16(acc[t * 3 + 2], dt_, et);
         }
     }
-    write_partials(a, blockIdx.x * 4 + wave, acc, 6, vec, 2, scal, 2, threadIdx.x & 63, j, q);
+    write_partials(a, blockIdx.x * WPB + wave, acc, 6, vec, 2, scal, 2, threadIdx.x & 63, j, q);
 }
 
 // ---- pass 1': layer 2 and the activation of layer 1.
