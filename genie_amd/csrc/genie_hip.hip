@@ -2790,7 +2790,7 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         // (genie_set_static_edge_attr), any other one is brought into processing order here (one extra pass over [P, 3])
         a.wgmap = no_bip ? 0 : c->s2_wgmap;
         if (no_bip) {      // last pass of the association heads: row-layout c / wu / wv written by k_assoc_b
-            k_stage2_ord<8, 15, true, true><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
+            k_stage2_ord<8, 15, true, true><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);       // (3 / 4 / 6 workgroups per CU: 291-298 us against 286)
 #if GENIE_TUNING
         } else if (!s2h_on(c)) {     // A/B reference (GENIE_S2_OLD): the round-3 stage 2 on row-layout c / wv
             if (!c->ea_tmp) HIP_TRY(gmalloc((void**)&c->ea_tmp, sizeof(float) * 3 * (size_t)c->P));
@@ -3864,7 +3864,8 @@ int assoc_fwd_impl(genie_ctx* c, const float* y_latent, const float* mask_src, c
     } else {
         const int grid = da_grid(c, (long long)c->G * c->T, std::max(1, c->bpc1));
         a.packed = c->packed[2];
-        k_assoc_a<false><<<grid, 256, 0, st>>>(a);
+        // (40 registers, 21 KB of LDS: four workgroups per CU where stage 1's occupancy gave two -- 369 -> 322 us, six: 330; tools/assoc_ab.sh)
+        k_assoc_a<false><<<da_grid(c, (long long)c->G * c->T, 4), 256, 0, st>>>(a);
         a.packed = c->packed[3];
         // k_assoc_b is bound by its 23 gathered 128-B rows per node and, at 4 waves per workgroup, by LDS to 8 waves per CU (every
         // workgroup holds its own 52-KB copy of the weight image): ONE workgroup of 16 waves per CU shares one copy -- 969 -> 824 us at
