@@ -105,62 +105,56 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
     ItemIter w(a.G, a.T, a.seg, a.nxcd, wave);
     PtileIter ptw(PCSR ? (P + 15) / 16 : 0, 4, wave);      // PCSR: positions in the processing order of the tiles
     const long long n_it = PCSR ? ptw.end : w.nitems, it0 = PCSR ? ptw.i : w.it, its = PCSR ? ptw.stride : w.stride;
-    for (long long it = it0; it < n_it; it += its) {
-        int g, scn = 0, tb = 0;
-        bool valid;
-        long long p;
+    struct Tile { int g, scn; bool valid; long long p; };
+    struct Own { f32x4 mb, zt[2], qp[2][2], dt[4], dh0[2]; float m1; };       // the node's own rows
+    auto tile_of = [&](long long it) {
+        Tile t;
         if (PCSR) {       // 16 consecutive product nodes of an irregular product graph; the source node is per lane
             const long long pr = ptile_at(a.ptile, it) * 16 + j;
-            valid = pr < P;
-            p = valid ? pr : P - 1;
-            g = a.src_of[p];
+            t.valid = pr < P;
+            t.p = t.valid ? pr : P - 1;
+            t.g = a.src_of[t.p];
+            t.scn = 0;
         } else {
-            int gi;
-            w.decode(it, gi, tb);
-            g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-            const int s = tb * 16 + j;
-            valid = s < S;
-            scn = valid ? s : S - 1;
-            p = (long long)g * S + scn;
+            int gi, tb;
+            w.decode(it < n_it ? it : it0, gi, tb);              // past the end: a tile of this wave again (loads nobody uses)
+            t.g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+            const int s_ = tb * 16 + j;
+            t.valid = s_ < S;
+            t.scn = t.valid ? s_ : S - 1;
+            t.p = (long long)t.g * S + t.scn;
         }
-        asm volatile("" : "+v"(lane));
-        const float vm = valid ? 1.f : 0.f;
-        const float m1 = a.pg[(long long)g * AS_PG + 31];
-        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
-        if (q == 0) mb = *(const f32x4*)(a.mask + p * 4);
-        const float* gr = a.gr;
-        f32x4 zt[2], tr[2], qp[2][2], dt[4], tmd1[2], tmd2[2];
+        return t;
+    };
+    auto own_load = [&](const Tile& t, Own& o) {
+        const long long p = t.p;
+        o.m1 = a.pg[(long long)t.g * AS_PG + 31];
+        o.mb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) o.mb = *(const f32x4*)(a.mask + p * 4);
         const unsigned pofs = (unsigned)p * 64u + q16;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            zt[b] = O32 ? ldo(svb, (unsigned)(AV_TR + b) * P64 + pofs) : ldb(a.save, AV_TR + b, P, p, q);
-            tr[b] = prelu4u(zt[b], a0);
-            qp[0][b] = O32 ? ldo(svb, (unsigned)(AV_Q + b) * P64 + pofs) : ldb(a.save, AV_Q + b, P, p, q);
-            qp[1][b] = O32 ? ldo(svb, (unsigned)(AV_Q + 2 + b) * P64 + pofs) : ldb(a.save, AV_Q + 2 + b, P, p, q);
+            o.zt[b] = O32 ? ldo(svb, (unsigned)(AV_TR + b) * P64 + pofs) : ldb(a.save, AV_TR + b, P, p, q);
+            o.qp[0][b] = O32 ? ldo(svb, (unsigned)(AV_Q + b) * P64 + pofs) : ldb(a.save, AV_Q + b, P, p, q);
+            o.qp[1][b] = O32 ? ldo(svb, (unsigned)(AV_Q + 2 + b) * P64 + pofs) : ldb(a.save, AV_Q + 2 + b, P, p, q);
+            o.dh0[b] = O32 ? ldo(grb, (unsigned)(GR_DH0 + b) * P64 + pofs) : ldb(a.gr, GR_DH0 + b, P, p, q);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] = O32 ? ldo(grb, (unsigned)(GR_DT + k) * P64 + pofs) : ldb(a.gr, GR_DT + k, P, p, q);       // (own rows requested before the gathers)
-        if (O32) {       // one vector instruction per gathered row (as in k_train_b0<false, true>)
-            const unsigned gs64 = (unsigned)(g * S) * 64u, S64 = (unsigned)S * 64u;
-            const unsigned vs0 = (unsigned)(GR_DT + 0) * P64 + gs64 + q16, vs1 = (unsigned)(GR_DT + 1) * P64 + gs64 + q16;
-            const unsigned vg0 = (unsigned)(GR_DT + 2) * P64 + (unsigned)scn * 64u + q16, vg1 = (unsigned)(GR_DT + 3) * P64 + (unsigned)scn * 64u + q16;
-            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
-                               [&](int b, int c) { return ldo(grb, (b == 0 ? vs0 : vs1) + ((unsigned)c << 6)); }, tmd1);
-            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
-                                [&](int b, int c) { return ldo(grb, __umul24((unsigned)c, S64) + (b == 0 ? vg0 : vg1)); }, tmd2);
-        } else if (PCSR) {      // reversed PRODUCT-level graphs, rows by product-node id
-            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
-            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
-        } else {
-            tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
-                               [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
-            tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
-                                [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
-        }
+        for (int k = 0; k < 4; ++k) o.dt[k] = O32 ? ldo(grb, (unsigned)(GR_DT + k) * P64 + pofs) : ldb(a.gr, GR_DT + k, P, p, q);
+    };
+    // everything of a tile after its transposed means
+    auto compute = [&](const Tile& t, const Own& o, f32x4 (&tmd1)[2], f32x4 (&tmd2)[2]) {
+        const bool valid = t.valid;
+        const long long p = t.p;
+        const float vm = valid ? 1.f : 0.f, m1 = o.m1;
+        const unsigned pofs = (unsigned)p * 64u + q16;
+        f32x4 zt[2], tr[2], qp[2][2], dt[4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { zt[b] = o.zt[b]; tr[b] = prelu4u(zt[b], a0); qp[0][b] = o.qp[0][b]; qp[1][b] = o.qp[1][b]; }
 #pragma unroll
         for (int b = 0; b < 2; ++b) { tmd1[b] *= vm; tmd2[b] *= vm; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dt[k] *= vm;
+        for (int k = 0; k < 4; ++k) dt[k] = o.dt[k] * vm;
         // d q = l1_t?_2[:, 30:60]^T (transposed mean of dt), through PReLU11' / PReLU12' -> d(l1_t?_1 output)
         f32x4 dqp[2][2];
 #pragma unroll
@@ -179,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
         // d tr = node-local part (pass before) + l1_t1_1^T d q1-pre + l1_t2_1^T d q2-pre; through the activation of init_trns
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            f32x4 d = (O32 ? ldo(grb, (unsigned)(GR_DH0 + b) * P64 + pofs) : ldb(a.gr, GR_DH0 + b, P, p, q)) * vm;
+            f32x4 d = o.dh0[b] * vm;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 d = mma_block(d, lw[GA1_L(0, b, k) * 64 + lane], dqp[0][k]);
@@ -193,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
         vec[4] += dt[0] * m1; vec[5] += dt[1] * m1; vec[6] += dt[2] * m1; vec[7] += dt[3] * m1;
         vec[8] += dqp[0][0]; vec[9] += dqp[0][1]; vec[10] += dqp[1][0]; vec[11] += dqp[1][1];
         // weight gradients
-        const f32x4 mt = tr16(mb, sc, j, q);
+        const f32x4 mt = tr16(o.mb, sc, j, q);
         const f32x4 trt[2] = {tr16(tr[0], sc, j, q), tr16(tr[1], sc, j, q)};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -215,6 +209,77 @@ __global__ __launch_bounds__(256, 1) void k_as_b1(TrArgs a) {
                 acc[20 + 4 * h + b * 2 + 0] = outer16(acc[20 + 4 * h + b * 2 + 0], dqt, trt[0]);
                 acc[20 + 4 * h + b * 2 + 1] = outer16(acc[20 + 4 * h + b * 2 + 1], dqt, trt[1]);
             }
+        }
+    };
+    if (O32) {
+        // Software pipeline over the tiles of a wave (one wave per SIMD, as k_train_b1): while tile i computes, the row pointers of tile
+        // i + 2 and the (column, weight) pairs and own rows of tile i + 1 are in flight; a tile waits for ONE round trip (its gathered
+        // rows: 48 of them, too many registers to hold a tile ahead) where it waited for three in a row.
+        constexpr int EBS = 8, EBG = 16;
+        struct Rp { int s0, s1, g0, g1; };
+        auto rp_of = [&](const Tile& t) {
+            return Rp{a.r_sta_rowptr[t.scn], a.r_sta_rowptr[t.scn + 1], __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g]),
+                      __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g + 1])};
+        };
+        const unsigned S64 = (unsigned)S * 64u;
+        Tile cur = {0, 0, false, 0}, nxt = cur;
+        Rp rp_n = {0, 0, 0, 0};
+        Own own;
+        NbrIdx<EBS> xs;
+        NbrIdx<EBG> xg;
+        if (it0 < n_it) {
+            cur = tile_of(it0);
+            const Rp rp = rp_of(cur);
+            nbr_idx_load<EBS>(a.r_sta_cw, rp.s0, rp.s1, xs);
+            nbr_idx_load<EBG>(a.r_src_cw, rp.g0, rp.g1, xg);
+            own_load(cur, own);
+            nxt = tile_of(it0 + its);
+            rp_n = rp_of(nxt);
+        }
+        for (long long it = it0; it < n_it; it += its) {
+            asm volatile("" : "+v"(lane));
+            const Tile nn = tile_of(it + 2 * its);
+            const Rp rp_nn = rp_of(nn);
+            NbrIdx<EBS> xs_n;
+            NbrIdx<EBG> xg_n;
+            nbr_idx_load<EBS>(a.r_sta_cw, rp_n.s0, rp_n.s1, xs_n);
+            nbr_idx_load<EBG>(a.r_src_cw, rp_n.g0, rp_n.g1, xg_n);
+            Own own_n;
+            own_load(nxt, own_n);
+            // this tile's transposed means: rows of its first 8 / 16 out-edges in batches of four, then the rest of a long list; edge order kept
+            const unsigned gs64 = (unsigned)(cur.g * S) * 64u;
+            const unsigned vs0 = (unsigned)(GR_DT + 0) * P64 + gs64 + q16, vs1 = (unsigned)(GR_DT + 1) * P64 + gs64 + q16;
+            const unsigned vg0 = (unsigned)(GR_DT + 2) * P64 + (unsigned)cur.scn * 64u + q16, vg1 = (unsigned)(GR_DT + 3) * P64 + (unsigned)cur.scn * 64u + q16;
+            auto rows_s = [&](int b, int c) { return ldo(grb, (b == 0 ? vs0 : vs1) + ((unsigned)c << 6)); };
+            auto rows_g = [&](int b, int c) { return ldo(grb, __umul24((unsigned)c, S64) + (b == 0 ? vg0 : vg1)); };
+            f32x4 tmd1[2], tmd2[2];
+            tmean_idx<2, EBS, 4>(xs, false, rows_s, tmd1);
+            tmean_rest<2, 4>(a.r_sta_cw, xs.e_next, xs.e_end, false, rows_s, tmd1);
+            tmean_idx<2, EBG, 4>(xg, true, rows_g, tmd2);
+            tmean_rest<2, 4>(a.r_src_cw, xg.e_next, xg.e_end, true, rows_g, tmd2);
+            compute(cur, own, tmd1, tmd2);
+            cur = nxt; nxt = nn; rp_n = rp_nn; own = own_n; xs = xs_n; xg = xg_n;
+        }
+    } else {
+        for (long long it = it0; it < n_it; it += its) {
+            const Tile t = tile_of(it);
+            asm volatile("" : "+v"(lane));
+            Own own;
+            own_load(t, own);                       // (own rows requested before the gathers)
+            const float* gr = a.gr;
+            const int g = t.g, scn = t.scn;
+            const long long p = t.p;
+            f32x4 tmd1[2], tmd2[2];
+            if (PCSR) {      // reversed PRODUCT-level graphs, rows by product-node id
+                tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + b, P, c, q); }, tmd1);
+                tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, (int)p, false, [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, c, q); }, tmd2);
+            } else {
+                tmean_pre<2, 8, 4>(a.r_sta_rowptr, a.r_sta_cw, scn, false,
+                                   [&](int b, int c) { return ldb(gr, GR_DT + b, P, (long long)g * S + c, q); }, tmd1);
+                tmean_pre<2, 16, 4>(a.r_src_rowptr, a.r_src_cw, g, true,
+                                    [&](int b, int c) { return ldb(gr, GR_DT + 2 + b, P, (long long)c * S + scn, q); }, tmd2);
+            }
+            compute(t, own, tmd1, tmd2);
         }
     }
     write_partials(a, blockIdx.x * 4 + wave, acc, 28, vec, 12, scal, 3, threadIdx.x & 63, j, q);

@@ -204,6 +204,28 @@ __device__ __forceinline__ void tmean_pre(const int32_t* __restrict__ rp, const 
     }
     tmean_rest<NB, EB>(cw, x.e_next, x.e_end, uniform, rowof, out);
 }
+// transposed mean over the out-edges whose (column, weight) pairs were loaded earlier (NbrIdx: by the previous tile of a software
+// pipeline): their rows EB edges at a time, edge order kept. The edges past the prefetched ones go through tmean_rest.
+template <int NB, int EBI, int EB, typename F>
+__device__ __forceinline__ void tmean_idx(const NbrIdx<EBI>& x, bool uniform, F rowof, f32x4 (&out)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_assert(EBI % EB == 0, "whole batches");
+    const int eb = x.e_next - EBI, ee = x.e_end;
+#pragma unroll
+    for (int k0 = 0; k0 < EBI; k0 += EB) {
+        if (k0 > 0 && (uniform ? !(eb + k0 < ee) : !(bool)__any(eb + k0 < ee))) break;
+        f32x4 r[NB][EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r[b][k] = rowof(b, x.c[k0 + k]);
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] += r[b][k] * x.w[k0 + k];
+    }
+}
 __device__ __forceinline__ void write_partials(const TrArgs& a, int wid, const f32x4* acc, int n_acc, const f32x4* vec, int n_vec,
                                                const float* scal, int n_scal, int lane, int j, int q) {
     float* out = a.part + (size_t)wid * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
