@@ -2736,16 +2736,30 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
     a.mask = mask; a.edge_attr = edge_attr; a.x_latent = x_latent_out; a.packed = c->packed[1];
     a.ea_int = nullptr;
     a.mm_int = (const float*)ws + c->o_mm + (c->slot % GENIE_NBIG) * c->big_stride;
-    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && h2_on(c) && !abs_generic(c) && c->src_tab != nullptr && !no_bip) {
-        // training forward on the reference's kNN graphs: the production stage 2 in the CALLER's station order (identity
-        // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass of
-        // k_stage1_h2's launch (both model options at once run the generic stage 1, which has no split pass: generic stage 2 below)
+    auto identity_order = [&]() -> int {
         if (!c->sta_ident) {
             std::vector<int32_t> id((size_t)c->S);
             for (int i = 0; i < c->S; ++i) id[i] = i;
             HIP_TRY(gmalloc((void**)&c->sta_ident, sizeof(int32_t) * id.size()));
             HIP_TRY(hipMemcpy(c->sta_ident, id.data(), sizeof(int32_t) * id.size(), hipMemcpyHostToDevice));
         }
+        return GENIE_OK;
+    };
+    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && !abs_generic(c) && no_bip && x_latent_out != nullptr &&
+        gi_begin == 0 && gi_end == c->G) {
+        // training forward of the association phase (its last pass): the pipelined fp32 stage 2 in the caller's station order with the
+        // output layer's pre-activations kept, instead of the generic kernel (427 -> ~300 us at config 3)
+        if ((rc = identity_order())) return rc;
+        a.sta_user = c->sta_ident; a.wgmap = 0;
+        k_stage2_ord<8, 15, true, true, true><<<da_grid(c, n_tiles, c->bpc2o), 256, 0, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        return GENIE_OK;
+    }
+    if (c->force_generic && !c->pcsr && a.save != nullptr && c->use_fast && h2_on(c) && !abs_generic(c) && c->src_tab != nullptr && !no_bip) {
+        // training forward on the reference's kNN graphs: the production stage 2 in the CALLER's station order (identity
+        // processing order: the saved pre-activations of 1.8 GB stay contiguous stores), message mask from the split pass of
+        // k_stage1_h2's launch (both model options at once run the generic stage 1, which has no split pass: generic stage 2 below)
+        if ((rc = identity_order())) return rc;
         a.sta_user = c->sta_ident; a.ea_int = edge_attr; a.wgmap = 0;
         if (train_h2u_on(c) && c->ws_np && gi_begin == 0 && gi_end == c->G) {
             // k_stage2_h2u with the pre-activations kept (identity station order: edge_attr fragments built per call)
