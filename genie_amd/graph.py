@@ -123,6 +123,10 @@ def base_tables_from_product(A_in_sta, A_in_src, n_sta, n_grid, check=True, defe
         return _base_tables_from_product_device(A_in_sta, A_in_src, S, G, e_sta, e_src, defer)
     if defer:
         raise ValueError("base_tables_from_product(defer=True) takes edge lists resident on the GPU")
+    if e_sta == 0 or e_src == 0:
+        # a base graph without any edge (found by the randomized sweep: 3 stations whose few edges were all dropped): no uniform-degree
+        # table to cut -- the caller's general (CSR) path takes it
+        raise ValueError("neighbour_table: a base graph has no edges; use the CSR path")
     base_sta = A_in_sta[:, :e_sta]
     if int(base_sta.max().item()) >= S:
         raise ValueError("first block of A_in_sta leaves source node 0: not Cartesian")

@@ -130,6 +130,11 @@ def test_random_case_forward_and_gradients_match_the_oracle(i, monkeypatch):
             continue
         assert p.grad is not None, (cfg, k)
         tol = 2e-4 * max(float(ref.abs().max()), 1e-3 * gmax) + 1e-12
+        if k == "TemporalAttention.proj_2.bias":
+            # this gradient IS the sum of the cotangent (d out / d bias = 1): ~1 400 terms of size 1 that cancel to ~1e-2 (sweep seed
+            # 47118: 0.0285), so the two fp32 sums -- the oracle's and the kernel's, in different orders -- differ at the rounding
+            # level of the TERMS, not of the result: a floor of 2e-8 of the sum of their magnitudes (a third of one fp32 ulp per term)
+            tol = max(tol, 2e-8 * float(ay.abs().sum() + ax.abs().sum()))
         err = max_abs(p.grad.cpu(), ref)
         if err > tol:
             # A pre-activation within rounding of a PReLU kink makes the REFERENCE's gradient discontinuous there (seed 108: |z| = 5e-9
@@ -558,6 +563,6 @@ def test_random_case_adam_steps_match_the_oracle(i):
         opt_o.step()
         want.append(float(lo.detach()))
     print(got, want)
-    assert want[-1] < want[0]
+    assert min(want[1:]) < want[0]          # (the oracle's own curve: Adam at 1e-3 may overshoot within four steps -- sweep seed 62070)
     for a, b in zip(got, want):
         assert abs(a - b) <= 1e-5 * abs(b), (cfg, got, want)
