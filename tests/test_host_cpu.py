@@ -113,6 +113,31 @@ def test_cartesian_edges_roundtrip():
         graph.base_tables_from_product(bad, A_in_src, 7, 31)
 
 
+def test_base_tables_refuse_what_they_cannot_cut():
+    """graph.base_tables_from_product on host lists: a base graph without any edge (the randomized sweep drew 3 stations whose edges were
+    all dropped: an empty `max()` crashed here until round 5), lists that are not a multiple of the node counts, non-uniform degrees and
+    the deferred form on host tensors all raise ValueError -- the signal `set_adjacencies` takes its general path on."""
+    geom = synthetic.Geometry(6, 40, L=60e3, n_query=4, seed=3)
+    A1, A2, _, _ = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, 6, 40)
+    sta, src = graph.base_tables_from_product(A1, A2, 6, 40)
+    assert sta.shape[0] == 6 and src.shape[0] == 40
+    empty = torch.zeros((2, 0), dtype=torch.long)
+    for args in ((empty, A2), (A1, empty), (A1[:, :-1], A2)):
+        with pytest.raises(ValueError):
+            graph.base_tables_from_product(*args, 6, 40)
+    ragged = np.ascontiguousarray(geom.A_sta_sta[:, 1:])                      # one station with one neighbour fewer
+    B1, _, _, _ = graph.cartesian_product_edges(ragged, geom.A_src_src, 6, 40)
+    with pytest.raises(ValueError):
+        graph.base_tables_from_product(B1, A2, 6, 40)
+    with pytest.raises(ValueError):
+        graph.base_tables_from_product(A1, A2, 6, 40, defer=True)             # (device lists only)
+    t0, dt, dev_t, n = engine.time_partition(np.arange(-3.0, 9.0, 0.6))
+    assert dev_t is None and n == 20 and t0 == -3.0 and abs(dt - 0.6) < 1e-12
+    assert engine.time_partition((1.0, 2.0, None, 7)) == (1.0, 2.0, None, 7)
+    t0, dt, dev_t, n = engine.time_partition(torch.arange(5, dtype=torch.float32) * 0.25)
+    assert (t0, dt, dev_t, n) == (0.0, 0.25, None, 5)
+
+
 def test_knn_graph_matches_bruteforce():
     rng = np.random.default_rng(0)
     x = rng.random((60, 3))
