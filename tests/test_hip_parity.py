@@ -1664,6 +1664,23 @@ def test_device_knn_lane_per_query_kernel(nc, nq, k, self_):
         assert np.array_equal(got[a:a + 2000], want), a
 
 
+@pytest.mark.parametrize("nc,nq,k", [(4096, 64, 10), (4096, 65, 10), (4095, 64, 10), (3000, 16383, 10), (3000, 16384, 8), (5000, 33, 8)])
+def test_device_knn_kernel_dispatch_boundaries(nc, nq, k):
+    """genie_knn picks one of three kernels by the sizes (a workgroup per query up to 64 queries against >= 4096 points, a wave per query,
+    a lane per query from 16 384 queries): the same exact table on either side of every boundary."""
+    rng = np.random.default_rng(nc * 7 + nq)
+    xc = np.stack([rng.uniform(0, 100e3, nc), rng.uniform(0, 100e3, nc), rng.uniform(-40e3, 2e3, nc)], axis=1).astype(np.float32)
+    xq = np.stack([rng.uniform(0, 100e3, nq), rng.uniform(0, 100e3, nq), rng.uniform(-40e3, 2e3, nq)], axis=1).astype(np.float32)
+    xc[7] = xc[3]                                                              # a tie
+    xq[0] = xc[3]
+    got = engine.knn_device(torch.from_numpy(xc).to(DEV), torch.from_numpy(xq).to(DEV), k).cpu().numpy()
+    c64 = xc.astype(np.float64)
+    for a in range(0, nq, 4000):
+        q = xq[a:a + 4000].astype(np.float64)
+        d = ((q[:, None, :] - c64[None, :, :]) ** 2).sum(-1)
+        assert np.array_equal(got[a:a + 4000], np.argsort(d, axis=1, kind="stable")[:, :k]), a
+
+
 def test_set_adjacencies_from_positions_equals_host_built_graphs():
     """Graph setup on the device (genie_knn -> device CSR) gives the same forward as the host-built base graphs."""
     c = Case("cfg1_20x500")
