@@ -86,6 +86,11 @@ def parse():
     ap.add_argument("--no-train-step", action="store_true", help="skip the live config-3 training-step figure of the default line")
     ap.add_argument("--no-stream", action="store_true", help="skip the live config-5 streaming figure of the default line")
     ap.add_argument("--no-day-loops", action="store_true", help="skip the refine / association loop figures of the default line")
+    ap.add_argument("--emulate-world", type=int, default=None,
+                    help="N = 1: time every rank of the W-rank shard plan of the sharded workload alone on this GPU (collectives replaced by "
+                         "device copies of the same size) and report per-rank ms, imbalance, halo MB and the projected speed-up over the "
+                         "one-GPU time -- labelled projected, no xGMI. With --mode sharded: only that. The default N = 1 line carries it "
+                         "for W = 8 as `projected_scaling_8` (skip with --no-cfg4-one-gpu)")
     ap.add_argument("--no-cfg4-one-gpu", action="store_true",
                     help="N = 1 default run: skip the short measurement of the N > 1 workload (config 4, one window sharded over source "
                          "nodes) on this one GPU that the line carries as `sharded_workload_on_one_gpu`")
@@ -440,43 +445,83 @@ def single_rank_rccl(dev):
         return None, repr(e)[:200]
 
 
+def sharded_setup(a, geom, n_picks, rank, world, dev, group_on, emulate=False):
+    """The drop-in model of rank `rank` of a `world`-rank job on `dev`, with its adjacencies set, and ONE resident window embedded on the
+    device for the rank's own rows: `GCN_Detection_Network_extended(..., process_group=True)` -> `set_adjacencies_base` (config 4's product
+    edge lists, 2.3 G edges, cannot be materialised: the base graphs stand for them) -> `node_rows(travel times)` -> `embed_window`
+    (genie_embed_window over the owned + halo source nodes only; nothing of the window is made on the host)."""
+    torch.manual_seed(0)
+    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev, process_group=True if group_on else None,
+                                                shard=(rank, world), shard_overlap=not a.no_overlap, shard_emulate=emulate).eval()
+    locs = torch.from_numpy(geom.locs).float().to(dev)
+    xg = torch.from_numpy(geom.x_grid).float().to(dev)
+    xq = torch.from_numpy(geom.x_query).float().to(dev)
+    tq = torch.from_numpy(geom.t_query).float().to(dev)
+    net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), geom.edge_attr, locs, xg)
+    P = synthetic.make_picks(geom, n_picks, seed=2, window=0)
+    d_trv = net.node_rows(geom.travel_times)
+    sig = synthetic.KERNEL_SIG_T
+    Slice, Mask = net.embed_window(torch.from_numpy(P[:, 0].copy()).to(dev), torch.from_numpy(P[:, 1].astype(np.int32)).to(dev),
+                                   torch.from_numpy(P[:, 4].astype(np.int32)).to(dev), 0.0, float(np.ceil(geom.max_t + 1.0)), sig,
+                                   float(np.round(sig / 10.0, 2)), d_trv)
+    del d_trv
+    return net, Slice, Mask, locs, xg, xq, tq
+
+
+def sharded_phases(net, Slice, Mask, xg, xq, tq, barrier, reps):
+    """Per-phase HIP-event times of the SEQUENTIAL schedule on this rank: stage 1, exchange, stage 2 (+ Bipartite read-out),
+    all-gather + replicated tail + read-outs."""
+    sp = net._shard
+    p, S, lp = sp.plan, sp.n_sta, sp.local
+    dS, dM = sp.local_rows(Slice, "Slice", 4), sp.local_rows(Mask, "Mask", 4)
+    knn = net.SpatialAttention.query_table(xq, xg, 10)
+    full = net._hip
+
+    def readouts(x_spatial):
+        return full.readout_grid(x_spatial, tq), full.readout_query(x_spatial, xg, xq, knn, tq)
+
+    ph = {k: [] for k in ("stage1", "exchange", "stage2", "gather_tail")}
+    with torch.no_grad():
+        wv = sp.wv_view()
+        for _ in range(reps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            barrier()
+            e[0].record()
+            lp.da_stage1_range(dS, dM, 0, p.n_own, True)
+            e[1].record()
+            sp._exchange(wv)
+            e[2].record()
+            lp.da_stage2_partials_range(dM[: p.n_own * S], net._edge_attr, 0, p.n_own)
+            bip_own = lp.bipartite_readout()
+            e[3].record()
+            sp.gather_and_tail(bip_own, xg, readouts)
+            e[4].record()
+            torch.cuda.synchronize()
+            for k, name in enumerate(("stage1", "exchange", "stage2", "gather_tail")):
+                ph[name].append(e[k].elapsed_time(e[k + 1]))
+    return {k: round(float(np.median(v)), 4) for k, v in ph.items()}
+
+
 def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
-    """ONE window per step, product graph sharded over source nodes across the ranks (genie_amd/dist.py): per window one
-    halo all-to-all (64 B per halo product node; issued as soon as stage 1 has produced the rows other ranks need, under the
-    rest of stage 1 and the halo-free part of stage 2) and one all-gather of the [G,15] Bipartite output over RCCL/xGMI; the
-    replicated G-sized tail + read-outs of window i run on a tail stream under the P-sized kernels of window i+1 (the windows
-    of the apply loop are independent, as in the N = 1 pipeline)."""
-    from genie_amd import dist as gdist, engine
+    """ONE window per step, product graph sharded over source nodes across the ranks, THROUGH THE DROP-IN CLASS: the model is built
+    with `process_group=`, `set_adjacencies_base` makes this rank's shard plan and contexts, every step is one
+    `forward_fixed_source_pipelined(Slice, Mask, ...)` (the reference's arguments; Slice / Mask = the rank's own rows from the device
+    embedding). Per window one halo all-to-all (64 B per halo product node; issued as soon as stage 1 has produced the rows other ranks
+    need, under the rest of stage 1 and the halo-free part of stage 2) and one all-gather of the [G,15] Bipartite output over RCCL/xGMI;
+    the replicated G-sized tail + read-outs of window i run on a tail stream under the P-sized kernels of window i+1 (the windows of the
+    apply loop are independent, as in the N = 1 pipeline). --no-pipeline: `forward_fixed_source` (everything on one stream)."""
     S, G = geom.n_sta, geom.n_grid
     rccl_err = None
     if dist is None and world == 1:
         dist, rccl_err = single_rank_rccl(dev)
-    torch.manual_seed(0)
-    net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev).eval()
-    sta_csr = engine.csr_from_edges(torch.from_numpy(geom.A_sta_sta), S)
-    sp = gdist.ShardedPath(S, G, sta_csr, geom.A_src_src, geom.x_grid, world, rank, dev, pos_sta=geom.locs,
-                           overlap=not a.no_overlap)
-    sp.set_weights(module._path_param_dict(net))
-    sp.full.set_scale_t(net.TemporalAttention.scale_t)
+    net, Slice, Mask, locs, xg, xq, tq = sharded_setup(a, geom, n_picks, rank, world, dev, dist is not None)
+    sp = net._shard
     p = sp.plan
-    ext = p.ext_global
-    P = synthetic.make_picks(geom, n_picks, seed=2, window=0)
-    # every rank embeds the picks for its owned + halo source nodes (input distribution, no collective)
-    chunks = [synthetic.make_slice_mask(geom, P, 0.0, g_slice=ext[i:i + 2048]) for i in range(0, ext.size, 2048)]
-    dS = torch.from_numpy(np.concatenate([c[0] for c in chunks])).to(dev)
-    dM = torch.from_numpy(np.concatenate([c[1] for c in chunks])).to(dev)
-    del chunks
-    ea = torch.from_numpy(np.concatenate([geom.edge_attr(p.own_global[i:i + 2048]) for i in range(0, p.n_own, 2048)])).to(dev)
-    xg = torch.from_numpy(geom.x_grid).float().to(dev)
-    xq = torch.from_numpy(geom.x_query).float().to(dev)
-    tq = torch.from_numpy(geom.t_query).float().to(dev)
-    knn = net.SpatialAttention.query_table(xq, xg, 10)
-
-    def readouts(x_spatial):
-        return sp.full.readout_grid(x_spatial, tq), sp.full.readout_query(x_spatial, xg, xq, knn, tq)
 
     def step():
-        return sp.path_fwd(dS, dM, ea, xg, tail=readouts, pipelined=not a.no_pipeline)
+        if a.no_pipeline:
+            return net.forward_fixed_source(Slice, Mask, None, None, None, locs, xg, xq, tq)
+        return net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)[:2]
 
     def barrier():
         if dist is not None:
@@ -496,27 +541,7 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # per-phase HIP-event times of the sequential schedule on this rank (stage 1, exchange, stage 2, gather + tail)
-    ph = {k: [] for k in ("stage1", "exchange", "stage2", "gather_tail")}
-    with torch.no_grad():
-        lp, wv = sp.local, sp.wv_view()
-        for _ in range(min(a.steps, 5)):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-            barrier()
-            e[0].record()
-            lp.da_stage1_range(dS, dM, 0, p.n_own, True)
-            e[1].record()
-            sp._exchange(wv)
-            e[2].record()
-            lp.da_stage2_partials_range(dM[: p.n_own * S], ea, 0, p.n_own)
-            bip_own = lp.bipartite_readout()
-            e[3].record()
-            sp.gather_and_tail(bip_own, xg, readouts)
-            e[4].record()
-            torch.cuda.synchronize()
-            for k, name in enumerate(("stage1", "exchange", "stage2", "gather_tail")):
-                ph[name].append(e[k].elapsed_time(e[k + 1]))
-    phases = {k: round(float(np.median(v)), 4) for k, v in ph.items()}
+    phases = sharded_phases(net, Slice, Mask, xg, xq, tq, barrier, min(a.steps, 5))
     ranks = world if dist is None else int(dist.get_world_size())
     wps = a.steps / dt
     b_alg = 1532.0 * S * G + 816.0 * G
@@ -527,10 +552,13 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d stations / %d grid nodes / %d picks per window, forward_fixed_source of ONE window sharded "
-                               "over source nodes, graphs preset, inputs resident in HBM" % (a.config, S, G, n_picks),
+                               "over source nodes behind the drop-in class (process_group=), graphs preset, inputs resident in HBM "
+                               "(each rank's own rows, embedded on the device)" % (a.config, S, G, n_picks),
                    "n_stations": S, "n_grid": G, "n_picks": n_picks, "n_query": nq,
                    "parallelism": "source-node sharding x%d (halo all-to-all + all-gather per window, %s)"
                                   % (world, "sequential" if a.no_overlap else "exchange overlapped with compute"),
+                   "entry_point": "GCN_Detection_Network_extended(process_group=...).set_adjacencies_base / .embed_window / "
+                                  + (".forward_fixed_source" if a.no_pipeline else ".forward_fixed_source_pipelined"),
                    "backend": "nccl (RCCL)" if dist is not None else "none", "rccl_ranks": ranks if dist is not None else 0,
                    "device_collectives": bool(sp.transport.on and sp.transport.device_collectives),
                    "rccl_single_rank_error": rccl_err,
@@ -548,6 +576,72 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
         emit_line(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out
+
+
+XGMI_LINK_GBS = 153.0      # MI355X_MICROARCH.md: one xGMI link, per direction
+
+
+def emulate_world(a, geom, n_picks, dev, W, one_gpu_ms=None, steps=8, warmup=3):
+    """What ONE GPU can say about N = W: every rank of the W-rank shard plan of this workload, one after the other, alone on this GPU
+    through the drop-in class with `shard_emulate=True` -- its own plan, contexts, device embedding of its owned + halo rows, sub-range
+    stage launches, communication / tail streams; the halo all-to-all and the all-gather replaced by device-to-device copies of the
+    same number of bytes (no peer exists: the results are not the model's output, only the times mean something). Per rank: the
+    overlapped pipelined window (front on the main stream + tail on the tail stream), the front alone (the tail hidden under the next
+    window), the sequential phases, halo MB in / out and what those bytes cost on xGMI at %.0f GB/s per peer link if NOT hidden.
+    Projection = one-GPU time of the same workload / slowest rank; labelled projected, no xGMI."""
+    import copy
+    S, G = geom.n_sta, geom.n_grid
+    a = copy.copy(a)
+    a.no_overlap, a.no_pipeline = False, False
+    ranks = []
+    for r in range(W):
+        net, Slice, Mask, locs, xg, xq, tq = sharded_setup(a, geom, n_picks, r, W, dev, False, emulate=True)
+        sp = net._shard
+        p = sp.plan
+        with torch.no_grad():
+            for _ in range(warmup):
+                net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
+            torch.cuda.synchronize()
+            piped = (time.perf_counter() - t0) / steps * 1e3
+            # the front alone (stage 1 | copy standing in for the exchange | stage 2 | Bipartite read-out), overlapped schedule
+            dS, dM = sp.local_rows(Slice, "Slice", 4), sp.local_rows(Mask, "Mask", 4)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(steps):
+                sp.front(dS, dM, net._edge_attr)
+            ev[1].record()
+            torch.cuda.synchronize()
+            front = ev[0].elapsed_time(ev[1]) / steps
+        phases = sharded_phases(net, Slice, Mask, xg, xq, tq, torch.cuda.synchronize, 3)
+        per_peer_in = [c * S * 64.0 for c in p.recv_counts]
+        per_peer_out = [c * S * 64.0 for c in p.send_counts]
+        ranks.append({"rank": r, "n_own": p.n_own, "n_halo": p.n_halo, "send_nodes": p.n_send_nodes, "need_nodes": p.n_need_nodes,
+                      "pipelined_window_ms": round(piped, 3), "front_ms": round(front, 3), "phase_ms_sequential": phases,
+                      "halo_MB_in": round(sum(per_peer_in) / 1e6, 1), "halo_MB_out": round(sum(per_peer_out) / 1e6, 1),
+                      "xgmi_ms_if_not_hidden": round(max(max(per_peer_in), max(per_peer_out)) / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
+                      "allgather_KB_in": round((W - 1) * max(len(o) for o in p.owned) * 15 * 4 / 1e3, 1)})
+        del net, sp, Slice, Mask, dS, dM
+        torch.cuda.empty_cache()
+    piped = [x["pipelined_window_ms"] for x in ranks]
+    seq = [sum(x["phase_ms_sequential"].values()) for x in ranks]
+    out = {"world": W, "config": "%d stations / %d grid nodes / %d picks" % (S, G, n_picks), "per_rank": ranks,
+           "max_rank_ms": round(max(piped), 3), "mean_rank_ms": round(float(np.mean(piped)), 3),
+           "imbalance_max_over_mean": round(max(piped) / float(np.mean(piped)), 3),
+           "max_rank_ms_sequential_tail_not_hidden": round(max(seq), 3),
+           "max_xgmi_ms_if_not_hidden": max(x["xgmi_ms_if_not_hidden"] for x in ranks),
+           "label": "projected, no xGMI: each rank timed alone on one GPU, collectives replaced by device copies of the same size",
+           "how": "drop-in class with shard=(r, %d), shard_emulate=True; %d pipelined windows per rank after %d warm-ups" % (W, steps, warmup)}
+    if one_gpu_ms is not None:
+        worst = max(x["pipelined_window_ms"] + x["xgmi_ms_if_not_hidden"] for x in ranks)
+        out["one_gpu_ms"] = one_gpu_ms
+        out["projected_speedup_tail_hidden"] = round(one_gpu_ms / max(piped), 2)
+        out["projected_speedup_tail_not_hidden"] = round(one_gpu_ms / max(seq), 2)
+        out["projected_speedup_tail_hidden_exchange_not_hidden"] = round(one_gpu_ms / worst, 2)
     return out
 
 
@@ -911,6 +1005,12 @@ def main():
     S, G, n_picks, L, nq = synthetic.CONFIGS[a.config]
     geom = synthetic.Geometry(S, G, L=L, n_query=nq, seed=1)
     if a.mode == "sharded":
+        if world == 1 and a.emulate_world:
+            o1 = main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=False)
+            torch.cuda.empty_cache()
+            o1["projected_scaling_%d" % a.emulate_world] = emulate_world(a, geom, n_picks, dev, a.emulate_world, one_gpu_ms=o1["ms_per_step"])
+            emit_line(json.dumps(o1))
+            return o1
         if world == 1:
             return main_sharded(a, geom, n_picks, nq, rank, world, dev, dist)
         out = main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=False)       # (destroys the process group)
@@ -1124,8 +1224,14 @@ def main():
                                                   "roofline_frac": o4["roofline"]["frac"], "backend": o4["config"]["backend"],
                                                   "rccl_ranks": o4["config"]["rccl_ranks"], "device_collectives": o4["config"]["device_collectives"],
                                                   "rccl_single_rank_error": o4["config"]["rccl_single_rank_error"]}
+            torch.cuda.empty_cache()
+            # ... and what this one GPU can say about N = 8 of it: every rank of the 8-rank plan timed alone (projected, no xGMI)
+            W = a.emulate_world or 8
+            out["projected_scaling_%d" % W] = emulate_world(a4, synthetic.Geometry(S4, G4, L=L4, n_query=nq4, seed=1), np4, dev, W,
+                                                            one_gpu_ms=o4["ms_per_step"])
         except Exception as e:       # (the headline line must not depend on it)
-            out["sharded_workload_on_one_gpu"] = {"error": repr(e)[:200]}
+            out.setdefault("sharded_workload_on_one_gpu", {"error": repr(e)[:200]})
+            out.setdefault("projected_scaling_%d" % (a.emulate_world or 8), {"error": repr(e)[:200]})
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and a.config == "cfg2_200x10k" and not a.no_pipeline and not a.no_train_step:
         # BASELINE config 3 (the training step on this same shape), measured live through `--mode train`'s code path

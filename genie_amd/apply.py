@@ -151,7 +151,8 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
     per G-sized tail (1..16; 16 is the default of the bench and measured best with the device embedding in the loop, bench.py --mode
     stream: the tail kernels are latency-bound, their fixed costs are paid once per batch)."""
     hp = net._hip
-    net.window_batch = tail_batch
+    sharded = getattr(net, "is_sharded", False)       # source-node-sharded model: this rank embeds and runs its owned + halo rows only;
+    net.window_batch = 1 if sharded else tail_batch   # the tail follows the shard's all-gather, one per window (module.py docstring)
     dev = hp.device
     max_t = float(max_t if max_t is not None else np.ceil(trv_times.max() + 1.0))
     dt_embed = float(dt_embed if dt_embed is not None else np.round(kernel_sig_t / 10.0, 2))      # process_continuous_days.py:608
@@ -173,7 +174,7 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
         pairs = np.asarray(pairs)
         d_trv = torch.from_numpy(np.ascontiguousarray(np.asarray(trv_times, dtype=np.float32)[pairs[1], pairs[0]])).to(dev)
     else:
-        d_trv = torch.from_numpy(np.ascontiguousarray(trv_times, dtype=np.float32).reshape(-1, 2)).to(dev)
+        d_trv = net.node_rows(np.asarray(trv_times, dtype=np.float32), 2)          # (a shard: its own rows, cut out on the host)
     Out_2 = torch.zeros((geom.x_query.shape[0], len(tsteps_abs)), dtype=torch.float32, device=dev)
     locs = torch.from_numpy(geom.locs).float().to(dev)
     xg = torch.from_numpy(geom.x_grid).float().to(dev)
@@ -217,8 +218,8 @@ def apply_windows_device(net, geom, P, trv_times, tsteps_abs=None, t_win=6.0, st
         first = 0
         for w, t0 in enumerate(times):
             a, b = int(lo[w]), int(hi[w])
-            Slice, Mask = hp.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
-                                          presplit=True)     # the push below is the only consumer of (Slice, Mask)
+            Slice, Mask = net.embed_window(d_t[a:b], d_sta[a:b], d_ph[a:b], float(t0), max_t, kernel_sig_t, dt_embed, d_trv,
+                                           presplit=True)    # the push below is the only consumer of (Slice, Mask)
             if net.window_batch == 1:     # one tail per window (forward_fixed_source_pipelined), accumulated in window order
                 y, x, _ = net.forward_fixed_source_pipelined(Slice, Mask, None, None, None, locs, xg, xq, tq)
                 with torch.cuda.stream(hp.side_stream):
@@ -309,7 +310,10 @@ class GridLeg(object):
     set on that grid, the grid's Cartesian node positions and its travel-time table `x_grids_trv[x_grid_ind]` [G, S, 2] resident on the
     device ([N, 2] rows per listed product node for a `use_subgraph` model: `pairs` [2, N] = `A_src_in_sta`)."""
 
-    def __init__(self, net, x_grid_cart, trv_times, pairs=None):
+    def __init__(self, net, x_grid_cart, trv_times, pairs=None, ind_use=None):
+        """`trv_times` [G, S', 2]: with `ind_use` the reference's table over ALL stations (`compute_travel_times(trv, locs, ...)`), cut to
+        the model's stations here as process_utils.py:599 does (`trv_times[:, ind_use]`); without it the table must already be restricted
+        to the model's stations, in the model's station order (its station axis is checked against the model's station count)."""
         self.net = net
         hp = net._hip
         if hp is None:
@@ -317,10 +321,24 @@ class GridLeg(object):
         self.device = hp.device
         self.x_grid_cart = torch.as_tensor(x_grid_cart).float().to(self.device)
         trv_times = np.asarray(trv_times, dtype=np.float32)
+        if ind_use is not None:
+            trv_times = trv_times[:, np.asarray(ind_use).astype(np.int64)]
+        n_sta = net._shard.n_sta if getattr(net, "_shard", None) is not None else hp.n_sta
+        if trv_times.ndim != 3 or trv_times.shape[1] != n_sta or trv_times.shape[2] != 2:
+            raise ValueError("GridLeg: trv_times must be [G, %d, 2] over the model's stations (pass ind_use= to cut the table of all "
+                             "stations down, process_utils.py:599), got %s" % (n_sta, tuple(trv_times.shape)))
         if pairs is not None:
             pairs = np.asarray(pairs)
-            trv_times = trv_times[pairs[1], pairs[0]]
-        self.trv = torch.from_numpy(np.ascontiguousarray(trv_times).reshape(-1, 2)).to(self.device)
+            self.trv = torch.from_numpy(np.ascontiguousarray(trv_times[pairs[1], pairs[0]]).reshape(-1, 2)).to(self.device)
+        else:
+            self.trv = net.node_rows(trv_times, 2)
+
+    def check(self):
+        """Raise what the device-side checks of the calls COMPLETED so far found (`HipPath.check_input_range` / `check_index_flags`);
+        the per-day loops call it after their final copy to the host, which has waited for every window."""
+        net = self.net
+        for hp in ((net._hip,) if getattr(net, "_shard", None) is None else (net._shard.local, net._shard.full)):
+            hp.check_input_range()
 
     def embed(self, picks, t0, max_t, kernel_sig_t, dt):
         """(Slice, Mask) of the window starting at t0 (genie_embed_window = extract_input_from_data, process_utils.py:460-642), or None
@@ -328,7 +346,7 @@ class GridLeg(object):
         args = picks.embed_args(t0, max_t, kernel_sig_t)
         if args is None:
             return None
-        return self.net._hip.embed_window(args[0], args[1], args[2], float(t0), float(max_t), float(kernel_sig_t), float(dt), self.trv)
+        return self.net.embed_window(args[0], args[1], args[2], float(t0), float(max_t), float(kernel_sig_t), float(dt), self.trv)
 
 
 def _dt_embed(kernel_sig_t, dt_embed):
@@ -338,11 +356,14 @@ def _dt_embed(kernel_sig_t, dt_embed):
 _PINNED = {}
 
 
-def _pinned_pair(n):
-    """Two page-locked float64 [n, 3] staging buffers, kept for the life of the process (pinning 2.7 MB costs ~20 ms: not per call)."""
-    if n not in _PINNED:
-        _PINNED[n] = [torch.empty((n, 3), dtype=torch.float64).pin_memory() for _ in range(2)]
-    return _PINNED[n]
+def _pinned_pair(n, device):
+    """Two page-locked float64 [n, 3] staging buffers per (size, device, calling thread), kept for the life of the process (pinning
+    2.7 MB costs ~20 ms: not per call). Keyed so that concurrent refine passes -- one per GPU, or one per thread -- never share a pair."""
+    import threading
+    key = (int(n), str(device), threading.get_ident())
+    if key not in _PINNED:
+        _PINNED[key] = [torch.empty((n, 3), dtype=torch.float64).pin_memory() for _ in range(2)]
+    return _PINNED[key]
 
 
 def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offset_range, n_rand_query, ftrns1, ftrns2,
@@ -375,7 +396,7 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
         off_min_d = torch.as_tensor(np.asarray(X_offset_min, dtype=np.float64).reshape(1, 3), device=dev)
         src_cart_d = torch.from_numpy(np.ascontiguousarray(ftrns1(srcs[:, 0:3]), dtype=np.float64)).to(dev) if srcs.shape[0] else None
         ninf = torch.full((), float("-inf"), dtype=torch.float32, device=dev)
-        stage, stage_ev = _pinned_pair(n_rand_query), [None, None]
+        stage, stage_ev = _pinned_pair(n_rand_query, dev), [None, None]
     with torch.no_grad():
         for i in range(srcs.shape[0]):
             if on_device:
@@ -390,7 +411,7 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
                 stage[k].numpy()[...] = rand(n_rand_query, 3)                                                         # the host's draw, float64
                 r = stage[k].to(dev, non_blocking=True)
                 stage_ev[k] = torch.cuda.Event()
-                stage_ev[k].record()
+                stage_ev[k].record(torch.cuda.current_stream(dev))       # the stream of `dev` the copy was issued on
                 Xc_d = src_cart_d[i:i + 1] + (r * off_rng_d + off_min_d)                                                  # :929
                 X1_d = ftrns2_device(Xc_d)
                 keep = ((X1_d[:, 0] > lat_range[0]) & (X1_d[:, 0] < lat_range[1]) & (X1_d[:, 1] > lon_range[0]) & (X1_d[:, 1] < lon_range[1])
@@ -426,6 +447,8 @@ def refine_sources(legs, picks, srcs, locs_cart, tq, max_t, X_offset_min, X_offs
             else:
                 found.append(torch.full((3,), float("nan"), dtype=torch.float64, device=dev))
     found = torch.stack(found).cpu().numpy() if found else np.zeros((0, 7 if on_device else 3))
+    for leg in legs:       # the copy above waited for the device: the verdicts of every window of this pass are in
+        leg.check()
     out = np.zeros((srcs.shape[0], 5))
     for i in range(srcs.shape[0]):
         if (found[i, 3] == 0.0) if on_device else (clouds[i].shape[0] == 0):
@@ -485,6 +508,10 @@ def associate_sources(legs, picks, srcs_refined, locs_cart, tq, max_t, trv_out_s
                 acc_s += out[3][0, :, 0] / n_scale                                                                      # :1055
     Save_picks = [np.stack((a.cpu().numpy(), b.cpu().numpy().astype(np.float64)), axis=1) for a, b in Save_picks]
     lp_meta = [picks.meta(ix) for ix in lp_meta]
+    if srcs.shape[0]:
+        torch.cuda.current_stream(dev).synchronize()      # (windows without picks copy nothing back)
+    for leg in legs:       # device-side verdicts (a pick outside the time-pointer table, a station index outside the model) of every call above
+        leg.check()
     return Out_p, Out_s, Save_picks, lp_meta
 
 

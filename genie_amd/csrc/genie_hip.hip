@@ -4304,21 +4304,24 @@ int genie_stage_precision(genie_ctx* c, int* mode, int* f16x2_active, float* act
 
 int genie_input_range(genie_ctx* c, float* max_seen, float* limit, int reset) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_input_range: null context");
+    // reset = one atomic fetch-and-clear (kernels still in flight may be OR-ing / max-ing into the word: a plain store after a separate
+    // read could drop what they wrote in between); the value reported is exactly the value cleared
+    unsigned u = 0u;
+    if (c->h_inflag) u = reset ? __atomic_exchange_n(c->h_inflag, 0u, __ATOMIC_SEQ_CST) : *(volatile unsigned*)c->h_inflag;
     if (max_seen) {
-        const unsigned u = c->h_inflag ? *(volatile unsigned*)c->h_inflag : 0u;
         float f;
         memcpy(&f, &u, 4);
         *max_seen = f;
     }
     if (limit) *limit = input_limit(c);
-    if (reset && c->h_inflag) *(volatile unsigned*)c->h_inflag = 0u;
     return GENIE_OK;
 }
 
 int genie_index_flags(genie_ctx* c, unsigned* flags, int reset) {
     if (!c) return fail(GENIE_ERR_ARG, "genie_index_flags: null context");
-    if (flags) *flags = c->h_inflag ? *(volatile unsigned*)(c->h_inflag + 1) : 0u;
-    if (reset && c->h_inflag) *(volatile unsigned*)(c->h_inflag + 1) = 0u;
+    unsigned u = 0u;      // (reset: atomic fetch-and-clear, see genie_input_range)
+    if (c->h_inflag) u = reset ? __atomic_exchange_n(c->h_inflag + 1, 0u, __ATOMIC_SEQ_CST) : *(volatile unsigned*)(c->h_inflag + 1);
+    if (flags) *flags = u;
     return GENIE_OK;
 }
 

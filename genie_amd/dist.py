@@ -27,6 +27,42 @@ import numpy as np
 import torch
 
 
+class ShardRows(object):
+    """Rows of a per-product-node tensor in a rank's LOCAL order: the S-row blocks of its owned source nodes (space-filling-curve
+    order), then of its halo nodes (`ShardPlan.ext_global`), or of the owned nodes only (`own_only`). What the sharded drop-in model
+    produces (`embed_window`, `node_rows`) and accepts in place of the reference's full `[P, C]` tensors -- a full tensor and a
+    local one can have the same shape (world size 1), so the local form is a type of its own, never guessed from a shape."""
+    __slots__ = ("t", "own_only")
+
+    def __init__(self, t, own_only=False):
+        self.t, self.own_only = t, bool(own_only)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def resolve_shard(process_group=None, shard=None):
+    """(rank, world, group) of a sharded model, or None for an unsharded one. `process_group`: a `torch.distributed` group, or True
+    for the default group; `shard` = (rank, world) overrides what the group reports (and is all there is without a group: a virtual
+    rank, whose collectives the caller replaces -- `bench.py --emulate-world`)."""
+    if process_group is None and shard is None:
+        return None
+    import torch.distributed as dist
+    group = None
+    if process_group is not None and process_group is not True:
+        group = process_group
+    if shard is not None:
+        rank, world = int(shard[0]), int(shard[1])
+    else:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("process_group given but torch.distributed is not initialised (init_process_group first)")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if not 0 <= rank < world:
+        raise ValueError("shard = (rank, world) needs 0 <= rank < world")
+    return rank, world, group
+
+
 class ShardPlan(object):
     """Static plan for one rank (pure numpy, deterministic and identical logic on every rank).
 
@@ -109,12 +145,21 @@ class Transport(object):
     group without device collectives (gloo: the CPU tests and the several-processes-on-one-GPU test) is served by staging
     through host memory, which synchronises the calling stream -- test plumbing, not a data path."""
 
-    def __init__(self, group=None, world=None):
+    def __init__(self, group=None, world=None, emulate=False):
         """`world`: the rank count of the plan the collectives serve. A process group of another size cannot carry them: a one-rank
         plan inside an N-rank job (a single-GPU leg of a multi-rank run) then runs without collectives -- pass an explicit one-rank
-        `group` to exercise the RCCL path there --, any other mismatch is an error."""
+        `group` to exercise the RCCL path there --, any other mismatch is an error.
+        `emulate`: ONE virtual rank of a `world`-rank plan alone on its GPU (`bench.py --emulate-world`): no peer exists, every
+        collective is replaced by a device-to-device copy of the same number of bytes (this rank's own rows stand in for the peers'), so
+        the kernels, sub-range launches, stream dependencies and buffer sizes are those of rank r at N = world and the RESULTS ARE NOT
+        the model's output. For timing only."""
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        self.emulate = bool(emulate)
+        self.world = int(world or 1)
+        if self.emulate:
+            self.on, self.device_collectives = False, False
+            return
         self.on = dist.is_available() and dist.is_initialized()
         if self.on and world is not None and dist.get_world_size(group) != int(world):
             if int(world) != 1:
@@ -122,10 +167,20 @@ class Transport(object):
             self.on = False
         self.device_collectives = self.on and dist.get_backend(group) == "nccl"
 
+    def _no_group(self):
+        """A collective of a plan of several ranks without a process group: the result would silently miss the peers' rows."""
+        if self.world > 1:
+            raise RuntimeError("a %d-rank shard plan needs an initialised torch.distributed process group for its collectives (or "
+                               "emulate=True: one virtual rank timed alone, results meaningless)" % self.world)
+
     def all_to_all_rows(self, recv, send, recv_counts, send_counts):
         """recv [sum(recv_counts), C] <- send [sum(send_counts), C], row blocks grouped by peer."""
-        if not self.on:
+        if self.emulate:
+            if recv.shape[0] and send.shape[0]:
+                torch.index_select(send, 0, torch.arange(recv.shape[0], device=send.device) % send.shape[0], out=recv)
             return
+        if not self.on:
+            return self._no_group()
         if self.device_collectives or not send.is_cuda:
             self.dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
             return
@@ -139,8 +194,14 @@ class Transport(object):
         xGMI link, the pairs independent of each other). `pack(q, view)` fills the send rows of peer q right before that peer's
         transfer is posted, so the packing of peer q + 1 runs under the transfer of peer q. Same rows in the same places as
         `all_to_all_rows` (tests/test_dist_cpu.py: both forms over gloo)."""
+        if self.emulate:
+            so = np.concatenate(([0], np.cumsum(send_counts))).astype(np.int64)
+            for q in range(len(send_counts)):
+                if pack is not None and q != rank and send_counts[q]:
+                    pack(q, send[so[q]:so[q + 1]])
+            return self.all_to_all_rows(recv, send, recv_counts, send_counts)
         if not self.on:
-            return
+            return self._no_group()
         dist = self.dist
         so = np.concatenate(([0], np.cumsum(send_counts))).astype(np.int64)
         ro = np.concatenate(([0], np.cumsum(recv_counts))).astype(np.int64)
@@ -169,7 +230,11 @@ class Transport(object):
 
     def all_gather_rows(self, out, x):
         """out [world, n, C] <- x [n, C] of every rank."""
+        if self.emulate:
+            out.copy_(x.unsqueeze(0).expand_as(out))
+            return
         if not self.on:
+            self._no_group()
             out[0].copy_(x)
             return
         if self.device_collectives:
@@ -234,7 +299,7 @@ class ShardedPath(object):
     A/B reference for the overlapped schedule (bit-identical results)."""
 
     def __init__(self, n_sta, n_grid, sta_csr, A_src_src, pos_global, world, rank, device, group=None, scale_rel=30000.0,
-                 pos_sta=None, overlap=True, halo="a2a"):
+                 pos_sta=None, overlap=True, halo="a2a", emulate=False):
         from . import engine
         self.group = group
         self.n_sta, self.n_grid = int(n_sta), int(n_grid)
@@ -252,7 +317,7 @@ class ShardedPath(object):
                                    engine.csr_from_edges(torch.as_tensor(A_src_src), n_grid), grid_order=None,
                                    scale_rel=scale_rel, device=device)
         self.device = dev = self.local.device
-        self.transport = Transport(group, world)
+        self.transport = Transport(group, world, emulate=emulate)
         S = self.n_sta
         pitch = int(self.local.lib.genie_ws_v_pitch(self.local.ctx))
         self._pitch = pitch
@@ -269,6 +334,41 @@ class ShardedPath(object):
     def set_weights(self, named):
         self.local.set_weights(named)
         self.full.set_weights(named)
+
+    def sync_weights(self, params, view=None):
+        """`HipPath.sync_weights` for both contexts (the P-sized shard and the replicated G-sized tail)."""
+        self.local.sync_weights(params, view)
+        self.full.sync_weights(params, view)
+
+    def row_index(self, own_only=False):
+        """int64 device tensor: the rows of a full `[G * S, C]` per-product-node tensor (p = g * S + s, process_utils.py:720-722)
+        that make up this rank's local rows (owned + halo blocks, or the owned blocks only). Built once."""
+        key = "_rows_own" if own_only else "_rows_ext"
+        idx = getattr(self, key, None)
+        if idx is None:
+            g = torch.as_tensor(self.plan.own_global if own_only else self.plan.ext_global, dtype=torch.int64, device=self.device)
+            idx = (g.view(-1, 1) * self.n_sta + torch.arange(self.n_sta, dtype=torch.int64, device=self.device).view(1, -1)).reshape(-1)
+            setattr(self, key, idx)
+        return idx
+
+    def local_rows(self, t, name, cols, own_only=False):
+        """This rank's rows of a per-product-node input: a `ShardRows` is taken as it is (its row count is checked), a full
+        `[G * S, cols]` tensor (the reference's argument) is cut down by ONE `index_select` on the device it lives on."""
+        n_loc = (self.plan.n_own if own_only else self.plan.n_ext) * self.n_sta
+        if isinstance(t, ShardRows):
+            if t.own_only != own_only and self.plan.n_halo:
+                if own_only and not t.own_only:           # owned blocks come first in the local order
+                    return lp_f32(t.t, name)[:n_loc]
+                raise ValueError("%s: rows of the owned source nodes only, the halo rows are needed too" % name)
+            return lp_f32(t.t, name, (n_loc, cols))
+        t = torch.as_tensor(t)
+        if tuple(t.shape) != (self.n_grid * self.n_sta, cols):
+            raise ValueError("%s: expected shape (%d, %d) (all product nodes) or a ShardRows of %d local rows, got %s"
+                             % (name, self.n_grid * self.n_sta, cols, n_loc, tuple(t.shape)))
+        idx = self.row_index(own_only)
+        if t.device != idx.device:
+            return t.index_select(0, idx.to(t.device)).to(self.device, torch.float32)
+        return t.index_select(0, idx).float()
 
     def set_edge_features(self, pos_sta, pos_src_global):
         """`use_updated_model_definition` on the shard (genie_set_edge_features): the mean edge features of the owned source nodes
@@ -294,7 +394,7 @@ class ShardedPath(object):
     def _exchange(self, wv):
         """Pack the SEND rows, all-to-all, halo rows received in place (the halo part of `wv` is contiguous, grouped by owner)."""
         p, S = self.plan, self.n_sta
-        if p.world == 1 and not self.transport.on:
+        if p.world == 1 and not self.transport.on and not self.transport.emulate:
             return                      # no process group at all. (With one, EVERY rank enters the collective, also a rank with
                                         # nothing to exchange and the single rank of a world-size-1 group: the RCCL code path of the
                                         # 1-GPU tests and of `bench.py --gpus 1 --mode sharded`)
@@ -315,6 +415,7 @@ class ShardedPath(object):
         all-gathered Bipartite output `[G, 15]` in global order, produced on the current stream."""
         p, S = self.plan, self.n_sta
         lp = self.local
+        lp.check_input_range()         # (verdicts of the windows that have completed: engine.HipPath.check_input_range)
         P_ext = p.n_ext * S
         Slice_ext = lp_f32(Slice_ext, "Slice", (P_ext, 4))
         Mask_ext = lp_f32(Mask_ext, "Mask", (P_ext, 4))
@@ -328,7 +429,7 @@ class ShardedPath(object):
         wv = self.wv_view()
         main = torch.cuda.current_stream(self.device)
         (s0, s1), (n0, n1), n = p.r_send, p.r_need, p.n_own
-        if not self.overlap or (p.world == 1 and not self.transport.on):
+        if not self.overlap or (p.world == 1 and not self.transport.on and not self.transport.emulate):
             lp.da_stage1_range(Slice_ext, Mask_ext, 0, n, True)
             self._exchange(wv)
             lp.da_stage2_partials_range(Mask_own, edge_attr_own, 0, n)

@@ -409,6 +409,14 @@ class HipPath(object):
     def __del__(self):
         try:
             if getattr(self, "ctx", None) and self.ctx.value:
+                fl, mx = ctypes.c_uint(0), ctypes.c_float(0.0)
+                self.lib.genie_index_flags(self.ctx, ctypes.byref(fl), 0)
+                self.lib.genie_input_range(self.ctx, ctypes.byref(mx), None, 0)
+                if fl.value or mx.value != 0.0:
+                    import warnings
+                    warnings.warn("genie_amd: a HIP context is destroyed with unread device-side verdicts (index flags %#x, input magnitude "
+                                  "%.6g): results of its last calls were computed from clamped indices / outside the verified fp16 range"
+                                  % (fl.value, mx.value), RuntimeWarning)
                 self.lib.genie_ctx_destroy(self.ctx)
                 self.ctx = ctypes.c_void_p(0)
         except Exception:
@@ -477,17 +485,18 @@ class HipPath(object):
         _lib.check(self.lib.genie_input_range(self.ctx, None, ctypes.byref(lim), 0), "genie_input_range")
         return float(lim.value)
 
-    def check_input_range(self):
+    def check_input_range(self, synchronize=False):
         """Fail loudly when a split pass of an earlier call met inputs beyond what the fp16 range guard verified (genie_input_range: a
-        word of host-mapped memory, read without synchronising -- it reflects the calls that have completed). The context is switched to
-        the fp32 kernels, which take any input the reference's fp32 arithmetic takes, before the error is raised: the results of the
-        calls issued since the last check are invalid and must be recomputed. Called at the top of every entry point that runs stage 1
-        and by `wait_tails`."""
-        self.check_index_flags()
+        word of host-mapped memory, read without synchronising -- it reflects the calls that have completed; `synchronize=True` waits for
+        the device's current stream first, so that every call issued so far is covered). The context is switched to the fp32 kernels,
+        which take any input the reference's fp32 arithmetic takes, before the error is raised: the results of the calls issued since the
+        last check are invalid and must be recomputed. Called at the top of every entry point that runs stage 1, by `wait_tails`, and
+        wherever the host has just waited for the device anyway (module.forward's deferred verdicts, the per-day loops' final copies)."""
+        self.check_index_flags(synchronize)
         mx, lim = ctypes.c_float(0.0), ctypes.c_float(0.0)
         _lib.check(self.lib.genie_input_range(self.ctx, ctypes.byref(mx), ctypes.byref(lim), 0), "genie_input_range")
         if mx.value != 0.0:
-            _lib.check(self.lib.genie_input_range(self.ctx, None, None, 1), "genie_input_range")
+            _lib.check(self.lib.genie_input_range(self.ctx, ctypes.byref(mx), None, 1), "genie_input_range")   # atomic fetch-and-clear
             self.set_stage_precision("f32")
             raise _lib.GenieHipError(
                 "an earlier call handed the f16x2 stage kernels Slice / Mask entries of magnitude %.6g; the committed weights keep their "
@@ -495,16 +504,18 @@ class HipPath(object):
                 "of the calls issued since the last check are invalid; this context now runs the fp32 kernels (stage_precision 'f32'): "
                 "repeat those calls." % (mx.value, lim.value))
 
-    def check_index_flags(self):
-        """Raise IndexError when a pick of an earlier `lslc_fwd` call indexed outside the time-pointer table (genie_index_flags: host-mapped
+    def check_index_flags(self, synchronize=False):
+        """Raise IndexError when a pick of an earlier `lslc_fwd` / arrivals call indexed outside its table (genie_index_flags: host-mapped
         memory, no synchronisation -- it reflects the calls that have completed; the kernel clamps such an index). The reference's own
         indexing (module.py:635-640) fails the same deferred way on a GPU: a device-side assertion reported at the next synchronisation.
         Called by every entry point that checks the input range, by `lslc_fwd` itself and by `wait_tails`; `synchronize=True` waits
-        for the device first, so that the calls issued so far are covered."""
+        for the device's current stream first, so that the calls issued so far are covered."""
+        if synchronize:
+            torch.cuda.current_stream(self.device).synchronize()
         fl = ctypes.c_uint(0)
         _lib.check(self.lib.genie_index_flags(self.ctx, ctypes.byref(fl), 0), "genie_index_flags")
         if fl.value:
-            _lib.check(self.lib.genie_index_flags(self.ctx, None, 1), "genie_index_flags")
+            _lib.check(self.lib.genie_index_flags(self.ctx, ctypes.byref(fl), 1), "genie_index_flags")          # atomic fetch-and-clear
             what = []
             if fl.value & 1:
                 what.append("lslc_fwd: a pick lies outside the time-pointer table (tpick outside dt_partition, or ipick outside the stations "
@@ -513,6 +524,23 @@ class HipPath(object):
                 what.append("arrivals: a station index `ipick` outside [0, n_sta)")
             raise IndexError("an earlier call on this context met " + "; ".join(what) + ". Its results were computed from clamped indices "
                              "and are invalid")
+
+    def retire(self, synchronize=True):
+        """Last look at the device-side verdicts of a context that is being replaced or dropped (`module.forward` builds a new context
+        per training sample; nothing reads the flag word once the context is gone): raises what `check_input_range` would.
+        `synchronize=False` when the caller has just waited for the device (the constructor of the replacing context does).
+        `__del__` cannot raise; it warns instead."""
+        if getattr(self, "ctx", None) and self.ctx.value:
+            if synchronize:
+                with torch.cuda.device(self.device):
+                    torch.cuda.synchronize()
+            self.check_input_range()
+
+    def discard_flags(self):
+        """Forget the device-side verdicts (calls whose results the caller throws away anyway, e.g. a context built on graphs that the
+        deferred structure checks then rejected)."""
+        _lib.check(self.lib.genie_index_flags(self.ctx, None, 1), "genie_index_flags")
+        _lib.check(self.lib.genie_input_range(self.ctx, None, None, 1), "genie_input_range")
 
     # ---- stages --------------------------------------------------------------------------------
     def da_stage1(self, Slice, Mask, debug=False):

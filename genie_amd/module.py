@@ -21,6 +21,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import dist as _dist
 from . import engine as _engine
 from . import graph as _graph
 
@@ -488,11 +489,24 @@ class GCN_Detection_Network_extended(nn.Module):
     read-out heads (`genie_readout_grid` / `genie_readout_query`). `use_absolute_pos=True` (config.yaml:92, +6 input
     channels) and `use_updated_model_definition=True` (config.yaml:95) are served for `forward_fixed_source` and for the
     4-output `forward` / `forward_fixed`, in eval mode and as training steps (train() mode with gradients enabled).
+
+    Multi-GPU (genie_amd/dist.py): `process_group=` (a `torch.distributed` group, True = the default group; one process
+    per GPU, RCCL over xGMI) makes the SAME calls run source-node sharded: `set_adjacencies*` build this rank's shard plan and contexts,
+    `forward_fixed_source` takes the reference's arguments and returns the replicated `(y, x)` -- bit-equal to the unsharded model --,
+    `embed_window` / `node_rows` / `genie_amd.apply` produce and consume only the rank's owned + halo rows. `forward` / `forward_fixed`
+    (association heads) and training steps are not sharded and raise.
     """
 
     def __init__(self, ftrns1, ftrns2, scale_rel=SCALE_REL, use_absolute_pos=False, device="cuda",
-                 use_updated_model_definition=False, use_phase_types=True, use_sign_input=False):
+                 use_updated_model_definition=False, use_phase_types=True, use_sign_input=False, process_group=None, shard=None,
+                 shard_overlap=True, shard_halo="a2a", shard_emulate=False):
         super().__init__()
+        # (rank, world, group) of a source-node-sharded model, None = one GPU holds the whole product graph
+        self._shard_cfg = _dist.resolve_shard(process_group, shard)
+        # shard_emulate: ONE virtual rank alone on its GPU, collectives replaced by copies of the same size -- timing only, results
+        # are not the model's output (dist.Transport; bench.py --emulate-world)
+        self._shard_opts = {"overlap": bool(shard_overlap), "halo": shard_halo, "emulate": bool(shard_emulate)}
+        self._shard = None
         # config.yaml:93: the pick -> Slice / Mask embedding tags every feature with the sign of the negative slope of the series it is read
         # from (process_utils.py:610-614); the model itself is unchanged. Applies to the device embedding (`genie_amd.apply`, `embed_window`)
         self.use_sign_input = bool(use_sign_input)
@@ -539,17 +553,22 @@ class GCN_Detection_Network_extended(nn.Module):
         """The model-level options every new HIP context gets, whichever builder made it (Cartesian or `use_subgraph`): the weight
         registry view, TemporalAttention's time scale, and the two flags of the device pick embedding (config.yaml:91, :93)."""
         self._path_params = _path_param_dict(self)
-        self._hip.set_scale_t(self.TemporalAttention.scale_t)
-        self._hip.set_phase_types(self.use_phase_types)
-        self._hip.set_sign_input(self.use_sign_input)
+        for hp in ((self._hip,) if self._shard is None else (self._shard.local, self._shard.full)):
+            hp.set_scale_t(self.TemporalAttention.scale_t)
+            hp.set_phase_types(self.use_phase_types)
+            hp.set_sign_input(self.use_sign_input)
 
     def _build_engine(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc=None):
         # (positions on the GPU are ordered there: no host round trip per context, which the training call convention builds per sample)
+        dev = next(self.parameters()).device
+        if self._shard_cfg is not None:
+            return self._build_engine_sharded(sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc, dev)
         order = _engine.sfc_order(pos_src) if pos_src is not None else None
         sta_order = _engine.sfc_order(pos_loc) if pos_loc is not None else None
-        dev = next(self.parameters()).device
-        self._hip = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
-                                    device=dev, sta_order=sta_order)
+        new = _engine.HipPath(n_sta, n_grid, sta_csr, src_csr, grid_order=order, scale_rel=self.scale_rel,
+                              device=dev, sta_order=sta_order)
+        self._retire_engine()
+        self._hip = new
         self._configure_engine()
         if self.use_updated_model_definition:
             if pos_loc is None or pos_src is None:
@@ -559,6 +578,75 @@ class GCN_Detection_Network_extended(nn.Module):
             if pos_loc is None or pos_src is None:
                 raise ValueError("use_absolute_pos=True needs station and source positions")
             self._hip.set_absolute_pos(pos_loc.to(dev), pos_src.to(dev))                  # module.py:1007
+
+    def _build_engine_sharded(self, sta_csr, src_csr, n_sta, n_grid, pos_src, pos_loc, dev):
+        """This rank's part of the product graph (genie_amd/dist.py): the shard plan from the base source graph and the space-filling-
+        curve order of the source nodes (the same arithmetic on every rank, no collective), the local context over the owned + halo
+        source nodes, the replicated G-sized context. `self._hip` is the replicated one: the read-out heads run on it unchanged."""
+        if pos_src is None or pos_loc is None:
+            raise ValueError("a sharded model needs station and source positions (the shard plan follows the source nodes' order)")
+        rank, world, group = self._shard_cfg
+        rp, col = [torch.as_tensor(t).cpu().long().numpy() for t in src_csr]
+        A_src = np.stack((col, np.repeat(np.arange(n_grid, dtype=np.int64), np.diff(rp))))
+        to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+        new = _dist.ShardedPath(n_sta, n_grid, sta_csr, A_src, to_np(pos_src), world, rank, dev, group=group,
+                                scale_rel=self.scale_rel, pos_sta=to_np(pos_loc), **self._shard_opts)
+        self._retire_engine()
+        self._shard = new
+        self._hip = self._shard.full
+        self._hip.side_stream = self._shard.tail_stream                    # where the pipelined windows' (y, x) are produced
+        self._hip.side_streams = [self._shard.tail_stream, self._shard.comm_stream]
+        self._configure_engine()
+        if self.use_updated_model_definition:
+            self._shard.set_edge_features(pos_loc, pos_src)
+        if self.use_absolute_pos:
+            self._shard.set_absolute_pos(pos_loc, pos_src)
+
+    def _set_edge_attr(self, edge_attr, n_sta, n_grid):
+        """`A_src_in_edges.x` [P, 3] registered with the context(s); a sharded model keeps the rows of its owned source nodes only (a full
+        tensor is cut down once, a `ShardRows` of the owned rows is taken as it is: config 4's 1.2 GB need not exist on any rank).
+        A callable `edge_attr(source_node_ids) -> [len(ids) * S, 3]` is evaluated for the source nodes this model holds, in blocks."""
+        if callable(edge_attr):
+            edge_attr = self._rows_from_callable(edge_attr, n_grid, own_only=True)
+        if self._shard is not None:
+            self._edge_attr = self._shard.local_rows(edge_attr, "A_src_in_edges.x", 3, own_only=True).contiguous()
+            self._edge_attr_version = self._edge_attr._version
+            self._shard.local.set_static_edge_attr(self._edge_attr)
+            return
+        self._edge_attr = _engine._f32(edge_attr, "A_src_in_edges.x", (n_sta * n_grid, 3))
+        self._edge_attr_version = self._edge_attr._version
+        self._hip.set_static_edge_attr(self._edge_attr)
+
+    def _rows_from_callable(self, fn, n_grid, own_only=False, block=2048):
+        """`fn(ids)` -> rows of the source nodes `ids` ([len, S, C] or [len * S, C]), evaluated block by block for every source node of
+        an unsharded model, or for the owned (+ halo) source nodes of this rank; returned on the device (a `ShardRows` when sharded)."""
+        dev = self._hip.device
+        if self._shard is not None:
+            p = self._shard.plan
+            ids = p.own_global if own_only else p.ext_global
+        else:
+            ids = np.arange(n_grid, dtype=np.int64)
+        parts = []
+        for i in range(0, len(ids), block):
+            r = fn(ids[i:i + block])
+            r = r if torch.is_tensor(r) else torch.from_numpy(np.ascontiguousarray(r))
+            parts.append(r.reshape(-1, r.shape[-1]).to(dev, torch.float32))
+        t = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
+        return _dist.ShardRows(t, own_only=own_only) if self._shard is not None else t
+
+    @property
+    def is_sharded(self):
+        return self._shard_cfg is not None
+
+    @property
+    def shard_plan(self):
+        """The `genie_amd.dist.ShardPlan` of this rank (after `set_adjacencies*`), None for an unsharded model."""
+        return self._shard.plan if self._shard is not None else None
+
+    def _not_sharded(self, what):
+        if self._shard_cfg is not None:
+            raise NotImplementedError("%s is not available on a source-node-sharded model (process_group / shard): the sharded calls are "
+                                      "set_adjacencies*, forward_fixed_source[_pipelined], embed_window, node_rows and genie_amd.apply" % what)
 
     def set_adjacencies(self, A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p,
                         A_edges_s, dt_partition, tlatent, pos_loc, pos_src, _defer_checks=False):
@@ -589,6 +677,7 @@ class GCN_Detection_Network_extended(nn.Module):
             except ValueError:
                 cartesian = False
         if not cartesian:
+            self._not_sharded("an irregular product graph (use_subgraph)")
             return self._set_adjacencies_subgraph(A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid,
                                                   pos_loc, pos_src)
         src_csr = _engine.csr_from_table(src_nbr)
@@ -616,9 +705,7 @@ class GCN_Detection_Network_extended(nn.Module):
             if a[0].shape != b[0].shape or a[1].shape != b[1].shape or not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])):
                 raise ValueError("A_src is not the base graph of A_in_src")
         self._build_engine(_engine.csr_from_table(sta_nbr), src_csr, n_sta, n_grid, pos_src, pos_loc)
-        self._edge_attr = _engine._f32(A_src_in_edges.x, "A_src_in_edges.x", (n_sta * n_grid, 3))
-        self._edge_attr_version = self._edge_attr._version
-        self._hip.set_static_edge_attr(self._edge_attr)
+        self._set_edge_attr(A_src_in_edges.x, n_sta, n_grid)
         self._pending_checks = verdict
 
     def _resolve_pending_checks(self):
@@ -626,7 +713,25 @@ class GCN_Detection_Network_extended(nn.Module):
         are not the Cartesian product the context was built for (or A_src is not written as the product's base graph): the caller
         repeats `set_adjacencies` without deferral -- which takes the general path or raises, as it always did -- and recomputes."""
         v, self._pending_checks = getattr(self, "_pending_checks", None), None
-        return v is None or not any(v.tolist())
+        if v is None:
+            return True
+        ok = not any(v.tolist())
+        # the read-back has waited for every kernel this forward issued on the stream: their device-side verdicts (a pick outside the
+        # time-pointer table, a station index outside the model, inputs beyond the verified fp16 range) are in -- raise them now, the
+        # next sample brings a new context and nothing would read them again
+        if ok:
+            self._hip.check_input_range()
+        else:
+            self._hip.discard_flags()
+        return ok
+
+    def _retire_engine(self):
+        """The context(s) about to be replaced: called right AFTER the replacing context was constructed (its constructor waits for the
+        device), so the verdicts of every call issued on the old one are in; raises what they hold."""
+        old = [h for h in ((self._hip,) if self._shard is None else (self._shard.local, self._shard.full)) if h is not None]
+        self._hip = self._shard = None
+        for h in old:
+            h.retire(synchronize=False)
 
     def _set_adjacencies_subgraph(self, A_in_sta, A_in_src, A_src_in_edges, A_src_in_sta, A_src, n_sta, n_grid, pos_loc, pos_src):
         """`use_subgraph: True` (config.yaml:86, process_utils.py:744-849): the product nodes are the pairs listed in
@@ -642,8 +747,10 @@ class GCN_Detection_Network_extended(nn.Module):
                "src_csr": _engine.csr_from_edges(A_in_src, n_prod), "seg_rowptr": seg}
         order = _engine.sfc_order(pos_src.detach().cpu().numpy())
         dev = next(self.parameters()).device
-        self._hip = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
-                                    scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        new = _engine.HipPath(n_sta, n_grid, None, _engine.csr_from_edges(A_src, n_grid), grid_order=order,
+                              scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._retire_engine()
+        self._hip = new
         self._hip.set_subgraph_stations(pairs[0])
         self._configure_engine()
         if self.use_updated_model_definition:       # module.py:1059-1072 on the irregular edge lists: positions per product node
@@ -670,6 +777,7 @@ class GCN_Detection_Network_extended(nn.Module):
         `edge_attr(pairs) -> [N, 3]`, or None = `(pos_src[source] - pos_loc[station]) / scale_pairwise_sta_in_src_distances`
         (:811). Returns (A_sta_sta, A_src_src, A_src_in_sta) with A_src_in_sta int64 [2, N] = the product nodes as
         (station, source) pairs in node order; Slice / Mask / edge_attr rows follow that order."""
+        self._not_sharded("an irregular product graph (use_subgraph)")
         dev = next(self.parameters()).device
         pos_loc, pos_src = _engine._f32(pos_loc.to(dev), "pos_loc"), _engine._f32(pos_src.to(dev), "pos_src")
         n_sta, n_grid = int(pos_loc.shape[0]), int(pos_src.shape[0])
@@ -679,7 +787,9 @@ class GCN_Detection_Network_extended(nn.Module):
         src_csr = _engine.csr_from_table(src_tab)
         sub = _engine.subgraph_csr_device(pairs, n_grid, _engine.csr_from_table(sta_tab), src_csr)
         order = _engine.sfc_order(pos_src.detach().cpu().numpy())
-        self._hip = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        new = _engine.HipPath(n_sta, n_grid, None, src_csr, grid_order=order, scale_rel=self.scale_rel, device=dev, subgraph=sub)
+        self._retire_engine()
+        self._hip = new
         self._hip.set_subgraph_stations(pairs[0])
         self._configure_engine()
         if self.use_updated_model_definition:
@@ -707,9 +817,7 @@ class GCN_Detection_Network_extended(nn.Module):
         src_tab, A_src = _engine.knn_graph_device(pos_src, min(k_spc_edges, n_grid - 1))
         self.A_src = A_src
         self._build_engine(_engine.csr_from_table(sta_tab), _engine.csr_from_table(src_tab), n_sta, n_grid, pos_src, pos_loc)
-        self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
-        self._edge_attr_version = self._edge_attr._version
-        self._hip.set_static_edge_attr(self._edge_attr)
+        self._set_edge_attr(edge_attr, n_sta, n_grid)
         return A_sta, A_src
 
     def set_adjacencies_base(self, A_sta_sta, A_src_src, edge_attr, pos_loc, pos_src, A_edges_p=None, A_edges_s=None,
@@ -722,13 +830,20 @@ class GCN_Detection_Network_extended(nn.Module):
         self.A_src = torch.as_tensor(A_src_src)
         self._build_engine(_engine.csr_from_edges(A_sta_sta, n_sta), _engine.csr_from_edges(A_src_src, n_grid),
                            n_sta, n_grid, pos_src, pos_loc)
-        self._edge_attr = _engine._f32(edge_attr, "edge_attr", (n_sta * n_grid, 3))
-        self._hip.set_static_edge_attr(self._edge_attr)
+        self._set_edge_attr(edge_attr, n_sta, n_grid)
 
     # ---- hot path ------------------------------------------------------------------------------
     def _path(self, Slice, Mask, x_temp_cuda_cart, want_x_latent=False, want_bip=False):
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
+        if self._shard is not None:
+            # this rank's owned + halo rows -> stage 1 | halo exchange | stage 2 -> all-gather of [G, 15] -> replicated tail
+            if want_x_latent or want_bip:
+                self._not_sharded("x_latent / the Bipartite output of the whole grid")
+            sp = self._shard
+            sp.sync_weights(self._path_params, self._weight_split())
+            return sp.path_fwd(sp.local_rows(Slice, "Slice", 4), sp.local_rows(Mask, "Mask", 4), self._edge_attr,
+                               x_temp_cuda_cart), None, None
         self._hip.sync_weights(self._path_params, self._weight_split())
         return self._hip.path_fwd(Slice, Mask, self._edge_attr, x_temp_cuda_cart, want_x_latent, want_bip)
 
@@ -742,6 +857,7 @@ class GCN_Detection_Network_extended(nn.Module):
         source queries, module.py:981) only with `x_query_src_cart` (the 4-output forward)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
+        self._not_sharded("a training step (train() mode with gradients enabled; use eval() / no_grad)")
         hp = self._hip
         hp.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
@@ -776,9 +892,53 @@ class GCN_Detection_Network_extended(nn.Module):
         y / x on that stream (`with torch.cuda.stream(net._hip.side_stream)`) or after `done_event.wait()`."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
-        self._hip.sync_weights(self._path_params, self._weight_split())
         knn = self.SpatialAttention.query_table(x_query_cart, x_temp_cuda_cart, 10)
+        if self._shard is not None:
+            # the all-gather, the replicated tail and both read-outs of this window on the shard's tail stream (= `_hip.side_stream`),
+            # under the P-sized kernels and the halo exchange of the next window
+            sp, full = self._shard, self._hip
+            sp.sync_weights(self._path_params, self._weight_split())
+            xq, tq = _engine._f32(x_query_cart, "x_query"), _engine._f32(t_query, "t_query")
+            full._crosses_to(sp.tail_stream, x_temp_cuda_cart, xq, knn, tq)
+            y, x = sp.path_fwd(sp.local_rows(Slice, "Slice", 4), sp.local_rows(Mask, "Mask", 4), self._edge_attr, x_temp_cuda_cart,
+                               tail=lambda xs: (full.readout_grid(xs, tq), full.readout_query(xs, x_temp_cuda_cart, xq, knn, tq)),
+                               pipelined=True)
+            full._crosses_to(torch.cuda.current_stream(full.device), y, x)
+            return y, x, sp._tail_done
+        self._hip.sync_weights(self._path_params, self._weight_split())
         return self._hip.forward_pipelined(Slice, Mask, self._edge_attr, x_temp_cuda_cart, x_query_cart, knn, t_query)
+
+    def node_rows(self, table, cols=None):
+        """A per-product-node table of the caller ([G, S, C] or [G * S, C]; numpy or tensor; e.g. the travel times `x_grids_trv[i]` the
+        embedding gathers, process_utils.py:599-608) as a float32 tensor on the model's device, in the form `embed_window` and the
+        forward calls take: all rows for an unsharded model; for a sharded one a `ShardRows` of this rank's owned + halo rows only, cut out
+        where the table lives (a host table never reaches the device in full)."""
+        dev = self._hip.device
+        if isinstance(table, _dist.ShardRows):
+            return table
+        if callable(table):          # table(source_node_ids) -> their rows: evaluated for the source nodes this model / rank holds
+            n_grid = self._shard.n_grid if self._shard is not None else self._hip.n_grid
+            return self._rows_from_callable(table, n_grid)
+        t = table if torch.is_tensor(table) else torch.from_numpy(np.ascontiguousarray(table))
+        if t.dim() == 3:
+            t = t.reshape(t.shape[0] * t.shape[1], t.shape[2])
+        if cols is not None and t.shape[1] != cols:
+            raise ValueError("node_rows: expected %d columns, got %d" % (cols, t.shape[1]))
+        if self._shard is None:
+            return t.to(dev, torch.float32).contiguous()
+        return _dist.ShardRows(self._shard.local_rows(t, "table", int(t.shape[1])).contiguous())
+
+    def embed_window(self, pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv, presplit=False):
+        """(Slice, Mask) of the window starting at t0 from picks resident on the GPU (genie_embed_window = extract_input_from_data,
+        process_utils.py:460-642; arguments of `engine.HipPath.embed_window`). `trv`: `node_rows(travel times)`. On a sharded model the
+        rank embeds its owned + halo source nodes only and gets a pair of `ShardRows`, which the forward calls take as they are."""
+        if self._hip is None:
+            raise RuntimeError("call set_adjacencies(...) first")
+        if self._shard is None:
+            return self._hip.embed_window(pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv, presplit=presplit)
+        trv = self._shard.local_rows(trv, "trv", 2)
+        Slice, Mask = self._shard.local.embed_window(pick_t, pick_sta, pick_phase, t0, max_t, kernel_sig_t, dt, trv, presplit=presplit)
+        return _dist.ShardRows(Slice), _dist.ShardRows(Mask)
 
     def push_window(self, Slice, Mask):
         """Batched throughput form of `forward_fixed_source` for loops over independent windows (the apply loop,
@@ -787,6 +947,7 @@ class GCN_Detection_Network_extended(nn.Module):
         Same arithmetic, bit-identical results. Returns the number of pending windows."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed*/forward_fixed_source")
+        self._not_sharded("push_window / flush_windows (batched tails; use forward_fixed_source_pipelined)")
         self._hip.sync_weights(self._path_params, self._weight_split())
         return self._hip.window_push(Slice, Mask, self._edge_attr)
 
@@ -804,6 +965,10 @@ class GCN_Detection_Network_extended(nn.Module):
     def window_batch(self, n):
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) first")
+        if self._shard is not None:          # a shard's tail follows its own all-gather: one tail per window
+            if int(n) != 1:
+                self._not_sharded("window_batch > 1")
+            return
         self._hip.set_window_batch(n)
 
     @property
@@ -820,6 +985,7 @@ class GCN_Detection_Network_extended(nn.Module):
         differentiate in HIP (`_PathTrain`, `_AssocTrain`, `_LslcTrain`, `_ArrivalsTrain`; all three model definitions on Cartesian product graphs, the default one on irregular ones too)."""
         if self._hip is None:
             raise RuntimeError("call set_adjacencies(...) before forward_fixed")
+        self._not_sharded("forward / forward_fixed (the association heads)")
         if getattr(self, "A_edges_p", None) is None or getattr(self, "tlatent", None) is None:
             raise RuntimeError("forward_fixed needs the time-pointer tables and travel times (A_edges_p, A_edges_s, dt_partition, tlatent) "
                                "of set_adjacencies(...) / set_adjacencies_base(...)")
@@ -889,13 +1055,30 @@ class GCN_Detection_Network_extended(nn.Module):
         node list, positions) changes address, shape or in-place version; the cache holds those tensors, so an address cannot
         be recycled while it is the key. The per-call tensors that do not shape the context (edge_attr, time-pointer tables,
         tlatent) are simply taken from this call. `invalidate_graph_cache()` forces a rebuild."""
+        self._not_sharded("forward / forward_fixed (the association heads)")
+
         def tk(t):
             return (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if torch.is_tensor(t) else id(t)
         graph_tensors = (A_in_sta, A_in_src, A_src, A_src_in_sta, locs_use_cart, x_temp_cuda_cart)
         key = tuple(tk(t) for t in graph_tensors)
+        adj = (A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s, dt_partition, tlatent,
+               locs_use_cart, x_temp_cuda_cart)
+        call = (Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart, x_query_src_cart, t_query, tq_sample,
+                trv_out_q)
         if getattr(self, "_fwd_key", None) != key:
-            self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
-                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart, _defer_checks=True)
+            self._fwd_key = self._fwd_refs = None
+            # deferral pays only while the callers' lists are written in the literal form the device checks recognise: once a sample
+            # failed them (valid graphs in another edge order, base graphs of non-uniform degree, ...) every later sample would pay a
+            # discarded forward + a second build, so the model remembers and builds with the checks up front from then on
+            if getattr(self, "_defer_failed", False):
+                self.set_adjacencies(*adj)
+            else:
+                try:
+                    self.set_adjacencies(*adj, _defer_checks=True)
+                except Exception:
+                    # building on unverified (clamped) tables can fail in ways the checked path reports properly or does not hit at all
+                    self._defer_failed = True
+                    self.set_adjacencies(*adj)
             self._fwd_key, self._fwd_refs = key, graph_tensors
         else:
             self.A_src_in_edges, self.A_Lg_in_src = A_src_in_edges, A_Lg_in_src
@@ -904,14 +1087,22 @@ class GCN_Detection_Network_extended(nn.Module):
             if ea.data_ptr() != self._edge_attr.data_ptr() or ea._version != getattr(self, "_edge_attr_version", None):
                 self._edge_attr, self._edge_attr_version = ea, ea._version
                 self._hip.set_static_edge_attr(ea)
-        out = self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
-                                 x_query_src_cart, t_query, tq_sample, trv_out_q)
-        if getattr(self, "_pending_checks", None) is not None and not self._resolve_pending_checks():
+        deferred = getattr(self, "_pending_checks", None) is not None
+        try:
+            out = self.forward_fixed(*call)
+            standing = not deferred or self._resolve_pending_checks()
+        except (IndexError, _engine._lib.GenieHipError):
+            if not deferred or getattr(self, "_pending_checks", None) is None:
+                raise        # a checked context (or verdicts already read as good): a genuine error of this call
+            # raised while running on tables that were never verified: decide below, with the checks up front
+            self._pending_checks = None
+            self._hip.discard_flags()
+            standing = False
+        if not standing:
             # the graphs were not what the context was built for: build again with the checks up front (general path or ValueError)
+            self._defer_failed = True
             self._fwd_key = self._fwd_refs = None
-            self.set_adjacencies(A_in_sta, A_in_src, A_src_in_edges, A_Lg_in_src, A_src_in_sta, A_src, A_edges_p, A_edges_s,
-                                 dt_partition, tlatent, locs_use_cart, x_temp_cuda_cart)
+            self.set_adjacencies(*adj)
             self._fwd_key, self._fwd_refs = key, graph_tensors
-            out = self.forward_fixed(Slice, Mask, tpick, ipick, phase_label, locs_use_cart, x_temp_cuda_cart, x_query_cart,
-                                     x_query_src_cart, t_query, tq_sample, trv_out_q)
+            out = self.forward_fixed(*call)
         return out

@@ -8,6 +8,12 @@ all-to-all on the communication stream, all-gather, replicated tail -- with one 
   split sizes received into a view of the workspace, `all_gather_into_tensor`) and the overlapped schedule with its
   communication / tail streams execute over RCCL itself on the 1-GPU box.
 Both compare every rank's result with the unsharded HIP path bit for bit, with the overlap schedule on and off.
+
+The `*_drop_in_*` tests run the same three process layouts THROUGH THE DROP-IN CLASS (`GCN_Detection_Network_extended(...,
+process_group=True)`): the reference's `set_adjacencies(12 arguments)` once, `forward_fixed_source(Slice, Mask, ...)` with the full
+`[P, 4]` tensors per window (module.py:941-961, :999-1020; called at process_continuous_days.py:634, :797), the device embedding of the
+rank's own rows (`embed_window` / `node_rows`) and the whole apply loop (`apply.apply_windows_device`) -- `(y, x)` and `Out_2` bit-equal
+to the unsharded class on every rank.
 """
 import os
 import socket
@@ -180,3 +186,133 @@ def test_sharded_path_world1_rccl_device_collectives():
     assert r["device_collectives"], "the nccl (RCCL) process group must select the device-collective transport"
     assert r[True] and r[False], r
     assert r["transport_True"] and r["transport_False"], r
+
+
+# ---- the sharded path behind the reference's interface (row e-b) -------------------------------------------------------------------------
+
+def _drop_in_body(rank, world, dev, res):
+    """Unsharded vs sharded drop-in model on this rank: the reference's call sequence, then the device embedding and the apply loop."""
+    import torch.distributed as dist
+    from genie_amd import apply, dist as gdist, graph, module, synthetic
+    from tests.util import Case
+    S, G = 40, 900
+    geom = synthetic.Geometry(S, G, L=200e3, n_query=20, seed=41)
+    wins = [synthetic.make_window(geom, 400, seed=42, window=k) for k in range(3)]
+    c = Case("o1_20x500")            # weights with O(1) outputs
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+    A_in_sta, A_in_src, A_src_in_prod, A_src_in_sta = graph.cartesian_product_edges(geom.A_sta_sta, geom.A_src_src, S, G)
+    ea = graph.GraphEdges(x=t(geom.edge_attr()), edge_index=A_src_in_prod.to(dev))
+    locs, xg, xq, tq = t(geom.locs), t(geom.x_grid), t(geom.x_query), t(geom.t_query)
+    adj = (A_in_sta.to(dev), A_in_src.to(dev), ea, ea, A_src_in_sta.to(dev), torch.from_numpy(geom.A_src_src).to(dev), None, None, None, None,
+           locs, xg)
+
+    def make(**kw):
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=dev, **kw)
+        net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+        return net.eval()
+
+    ref_net = make()
+    ref_net.set_adjacencies(*adj)                                                   # process_continuous_days.py:634
+    with torch.no_grad():
+        refs = [ref_net.forward_fixed_source(t(w["Slice"]), t(w["Mask"]), None, None, None, locs, xg, xq, tq) for w in wins]   # :797
+        refs = [(y.clone(), x.clone()) for y, x in refs]
+    assert float(refs[0][0].abs().max()) > 0.05
+    # the apply loop's reference: the unsharded model, one tail per window
+    P = synthetic.make_picks(geom, 900, seed=72)
+    P[:, 0] = P[:, 0] * 0.25 + 5000.0
+    P = P[np.argsort(P[:, 0], kind="stable")]
+    trv = geom.travel_times().astype(np.float32)
+    max_t = float(np.ceil(trv.max() + 1.0))
+    Out_ref, times_ref = apply.apply_windows_device(ref_net, geom, P, trv, min_required_picks=5, max_t=max_t, tail_batch=1)
+    torch.cuda.synchronize()
+    for overlap, halo in ((True, "a2a"), (False, "a2a"), (True, "p2p")):
+        net = make(process_group=True, shard_overlap=overlap, shard_halo=halo)
+        assert net.is_sharded and net.shard_plan is None
+        net.set_adjacencies(*adj)                                                   # the same 12 arguments
+        p = net.shard_plan
+        assert (p.rank, p.world) == (rank, world) and p.n_own == len(p.own_global) > 0
+        net._shard.local.ws.fill_(255)                                              # NaN-poisoned workspace
+        ok = True
+        with torch.no_grad():
+            for w, (y0, x0) in zip(wins, refs):                                     # full [P, 4] tensors, as the reference hands them over
+                y, x = net.forward_fixed_source(t(w["Slice"]), t(w["Mask"]), None, None, None, locs, xg, xq, tq)
+                ok = ok and torch.equal(y, y0) and torch.equal(x, x0)
+            outs = [net.forward_fixed_source_pipelined(t(w["Slice"]), t(w["Mask"]), None, None, None, locs, xg, xq, tq) for w in wins]
+            net._hip.wait_tails()
+            torch.cuda.synchronize()
+            ok_piped = all(torch.equal(y, y0) and torch.equal(x, x0) for (y, x, _), (y0, x0) in zip(outs, refs))
+            # rows in the rank's local form (what embed_window produces): accepted as they are
+            rows = net._shard.row_index()
+            w = wins[1]
+            y, x = net.forward_fixed_source(gdist.ShardRows(t(w["Slice"])[rows]), gdist.ShardRows(t(w["Mask"])[rows]), None, None, None,
+                                            locs, xg, xq, tq)
+            ok_local = torch.equal(y, refs[1][0]) and torch.equal(x, refs[1][1])
+        # the apply loop: this rank embeds its owned + halo rows only
+        Out, times = apply.apply_windows_device(net, geom, P, trv, min_required_picks=5, max_t=max_t)
+        torch.cuda.synchronize()
+        ok_apply = np.array_equal(times, times_ref) and len(times) >= 3 and torch.equal(Out, Out_ref)
+        # what stays unsharded says so
+        raised = 0
+        for call in (lambda: net.forward_fixed(t(w["Slice"]), t(w["Mask"]), None, None, None, locs, xg, xq, xq[:2], tq, None, None),
+                     lambda: net.push_window(t(w["Slice"]), t(w["Mask"]))):
+            try:
+                call()
+            except NotImplementedError:
+                raised += 1
+        res[(overlap, halo)] = (ok, ok_piped, ok_local, ok_apply, raised == 2, float(Out_ref.abs().max()) > 0)
+        if dist.is_initialized():
+            dist.barrier()
+    res["plan"] = (p.n_own, p.n_halo)
+    res["device_collectives"] = bool(net._shard.transport.on and net._shard.transport.device_collectives)
+
+
+def _worker_drop_in(rank, world, port, backend, same_gpu, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = "cuda:0" if same_gpu else "cuda:%d" % rank
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        _drop_in_body(rank, world, dev, res)
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_drop_in(world, backend, same_gpu):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_drop_in, args=(world, _free_port(), backend, same_gpu, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        r = ret[rank]
+        if world > 1:
+            assert r["plan"][1] > 0
+        for k in ((True, "a2a"), (False, "a2a"), (True, "p2p")):
+            assert r[k] == (True,) * 6, (rank, k, r[k], "(full inputs, pipelined, local rows, apply loop, unsharded calls raise, non-trivial)")
+    return ret
+
+
+def test_drop_in_class_two_processes_on_one_gpu_bit_equal_to_unsharded():
+    _run_drop_in(2, "gloo", True)
+
+
+def test_drop_in_class_three_processes_on_one_gpu_bit_equal_to_unsharded():
+    _run_drop_in(3, "gloo", True)
+
+
+def test_drop_in_class_world1_rccl_bit_equal_to_unsharded():
+    ret = _run_drop_in(1, "nccl", True)
+    assert ret[0]["device_collectives"], "the nccl (RCCL) process group must select the device-collective transport"
+
+
+def test_drop_in_class_world2_rccl_bit_equal_to_unsharded():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI); the 1-GPU box runs the gloo form above")
+    _run_drop_in(2, "nccl", False)
