@@ -136,3 +136,39 @@ def test_shard_plan_invariants(world):
             assert np.array_equal(idx[q.own_global], q.rank * n_max + np.arange(q.n_own))
     if world == 1:
         assert plans[0].n_halo == 0 and plans[0].r_send == (0, 0) and plans[0].r_need == (0, 0)
+
+
+def test_shard_rows_and_shard_resolution():
+    """The plumbing of the sharded drop-in class that needs no GPU: how (rank, world, group) is resolved, that a plan of several ranks
+    without a process group refuses its collectives instead of silently missing the peers' rows, and the emulation transport (one
+    virtual rank alone: copies of the same size)."""
+    assert gdist.resolve_shard(None, None) is None
+    assert gdist.resolve_shard(None, (3, 8)) == (3, 8, None)
+    with pytest.raises(ValueError):
+        gdist.resolve_shard(None, (8, 8))
+    if not dist.is_initialized():
+        with pytest.raises(RuntimeError, match="not initialised"):
+            gdist.resolve_shard(True, None)
+    r = gdist.ShardRows(torch.zeros(6, 4), own_only=True)
+    assert r.own_only and tuple(r.shape) == (6, 4)
+    t = gdist.Transport(None, world=4)
+    if not t.on:
+        with pytest.raises(RuntimeError, match="process group"):
+            t.all_to_all_rows(torch.zeros(2, 3), torch.zeros(2, 3), [2, 0, 0, 0], [2, 0, 0, 0])
+        with pytest.raises(RuntimeError, match="process group"):
+            t.all_gather_rows(torch.zeros(4, 2, 3), torch.zeros(2, 3))
+    one = gdist.Transport(None, world=1)
+    if not one.on:
+        out = torch.zeros(1, 2, 3)
+        one.all_gather_rows(out, torch.ones(2, 3))            # a one-rank plan needs no group
+        assert float(out.sum()) == 6.0
+    e = gdist.Transport(None, world=4, emulate=True)
+    send, recv = torch.arange(6.0).view(3, 2), torch.zeros(5, 2)
+    e.all_to_all_rows(recv, send, [5, 0, 0, 0], [3, 0, 0, 0])
+    assert torch.equal(recv, send[torch.arange(5) % 3])
+    packed = []
+    e.halo_p2p_rows(recv, send, [0, 5, 0, 0], [0, 3, 0, 0], 0, pack=lambda q, view: packed.append(q))
+    assert packed == [1]
+    out = torch.zeros(4, 3, 2)
+    e.all_gather_rows(out, send)
+    assert all(torch.equal(out[k], send) for k in range(4))
