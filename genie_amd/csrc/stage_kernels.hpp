@@ -315,7 +315,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XROW = 32;                 // bytes per split input row: two 16-B pieces
 constexpr int XPC = 16;                  // bytes per piece
-constexpr int H2_THREADS = 512;
+#ifndef GENIE_H2_THREADS
+#define GENIE_H2_THREADS 512             // waves x 64 of one k_stage1_h2 workgroup (tuning builds: 1024 = 16 waves sharing the weight image)
+#endif
+constexpr int H2_THREADS = GENIE_H2_THREADS;
 
 // ---- f16x2: x ~ x0 + x1 with x0 = rn16(x), x1 = rn16(x - x0): 11 + 1 + 11 significant bits, i.e. within one fp32 ulp of x
 // (exact when the residual needs <= 11 bits) while x1 stays a normal fp16 number (|x| >= 2^-2), within 2^-25 absolute below
