@@ -3383,6 +3383,14 @@ namespace {
 // association phase's light passes did not pay: k_as_b3 174 -> 167 us, k_as_b0 (88 registers, 12 tiles) 301 -> 334 us: they keep 4.
 // Every wave still writes its own partial slot; the scratch is sized by the heaviest pass (30 tiles x 4 waves).
 constexpr int TR_WPB_LIGHT = 8;
+// pass 1' as two waves per tile (k_train_b1s); the tuning builds can switch back to the one-wave kernel for A/B runs
+#ifndef GENIE_B1_SPLIT_DEFAULT
+#define GENIE_B1_SPLIT_DEFAULT 1          // (a build with 0 = the one-wave kernel, for same-box A/B runs of production code generation)
+#endif
+bool b1_split_on() {
+    static const char* e = tune_env("GENIE_B1_SPLIT");
+    return e ? atoi(e) != 0 : GENIE_B1_SPLIT_DEFAULT != 0;
+}
 int train_grid(const genie_ctx* c) {
 #if GENIE_TUNING
     { static const char* e = getenv("GENIE_TRAIN_WG"); if (e) return std::max(8, c->num_cu * atoi(e) / 8 * 8); }
@@ -3550,8 +3558,10 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
     const bool o32 = !c->pcsr && (unsigned long long)SV_BLOCKS * (unsigned long long)c->P * 64ull < (1ull << 32);
     for (int s = 0; s < 3; ++s) {
         a.packed = c->packed[4 + s]; a.n_acc = c->n_acc[s]; a.n_vec = c->n_vec[s];
-        // k_train_b1 holds one wave per SIMD (442 registers): one workgroup per CU is all that is ever resident
-        const int grid_s = s == 1 ? std::max(8, grid / 2 / 8 * 8) : grid;
+        // k_train_b1 holds one wave per SIMD (442 registers): one workgroup per CU is all that is ever resident. Its pair-split form
+        // k_train_b1s (two waves per tile, <= 256 registers) runs two workgroups per CU and writes one partial per PAIR
+        const bool split1 = s == 1 && o32 && b1_split_on();
+        const int grid_s = (s == 1 && !split1) ? std::max(8, grid / 2 / 8 * 8) : grid;
         const int grid_w = (c->pcsr && s == 1) ? grid : grid_s;        // workgroups of this pass (= 4 waves of partials each)
         if (c->pcsr) {
             if (s == 0) k_train_b2<true><<<grid, 256, 0, st>>>(a);
@@ -3560,13 +3570,14 @@ int da_train_bwd_impl(genie_ctx* c, const float* slice, const float* mask, const
         } else {
             if (s == 0) k_train_b2<false, TR_WPB_LIGHT><<<grid, TR_WPB_LIGHT * 64, 0, st>>>(a);
             else if (s == 1) {
-                if (o32) k_train_b1<false, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
+                if (split1) k_train_b1s<false><<<grid_s, 256, 0, st>>>(a);
+                else if (o32) k_train_b1<false, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<false><<<grid_s, 256, 0, st>>>(a);
             }
             else if (o32) k_train_b0<false, true><<<grid, 256, 0, st>>>(a);
             else k_train_b0<false><<<grid, 256, 0, st>>>(a);
         }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        const int wpb_s = (s == 0 && !c->pcsr) ? TR_WPB_LIGHT : 4;
+        const int wpb_s = (s == 0 && !c->pcsr) ? TR_WPB_LIGHT : (split1 ? 2 : 4);
         k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_w * wpb_s, a.n_acc, a.n_vec, c->n_sc[s], c->d_acc[s], c->d_vec[s],
                                                             c->d_sc[s], grad_blob, 0);
     }
@@ -3949,7 +3960,8 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
     for (int s = 0; s < 4; ++s) {
         const int tm = tms[s];
         a.packed = pls[s] >= 0 ? c->packed[pls[s]] : nullptr; a.n_acc = c->n_acc[tm]; a.n_vec = c->n_vec[tm];
-        const int grid_s = (s == 1 && !c->pcsr) ? std::max(8, grid / 2 / 8 * 8) : grid;      // k_train_b1: one workgroup per CU (see da_train_bwd_impl)
+        const bool split1 = s == 1 && !c->pcsr && o32a && b1_split_on();      // k_train_b1s: two waves per tile, one partial per pair
+        const int grid_s = (s == 1 && !c->pcsr && !split1) ? std::max(8, grid / 2 / 8 * 8) : grid;      // k_train_b1: one workgroup per CU (see da_train_bwd_impl)
         if (c->pcsr) {
             if (s == 0) k_as_b3<true><<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
             else if (s == 1) k_train_b1p<true><<<grid, 256, 0, st>>>(a);
@@ -3958,13 +3970,14 @@ int genie_assoc_train_bwd(genie_ctx* c, const float* y_latent, const float* mask
         } else {
             if (s == 0) k_as_b3<false><<<grid, 256, 0, st>>>(a, d_s, c->raw + g_params[W_AS_ACT2].off);
             else if (s == 1) {
-                if (o32a) k_train_b1<true, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
+                if (split1) k_train_b1s<true><<<grid_s, 256, 0, st>>>(a);
+                else if (o32a) k_train_b1<true, true><<<grid_s, 256, 0, st>>>(a); else k_train_b1<true><<<grid_s, 256, 0, st>>>(a);
             }
             else if (s == 2) { if (o32a) k_as_b1<false, true><<<grid, 256, 0, st>>>(a); else k_as_b1<false><<<grid, 256, 0, st>>>(a); }
             else k_as_b0<false><<<grid, 256, 0, st>>>(a);
         }
         const int stride = a.n_acc * 256 + a.n_vec * 16 + 16;
-        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * 4, a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
+        k_train_reduce<<<(stride + 31) / 32, 256, 0, st>>>(a.part, grid_s * (split1 ? 2 : 4), a.n_acc, a.n_vec, c->n_sc[tm], c->d_acc[tm], c->d_vec[tm],
                                                             c->d_sc[tm], grad_blob, 0);
         // static terms of the two other model definitions: the layer-2 ones now (the next pass writes dtrp over do), the rest at the end;
         // on an irregular product graph the layer-1 ones after k_as_b1 already (k_as_b0<PCSR> leaves its d z1 rows in the dt blocks)

@@ -578,6 +578,221 @@ __global__ __launch_bounds__(256, 1) void k_train_b1(TrArgs a) {
     write_partials(a, blockIdx.x * 4 + wave, acc, 30, vec, NV, scal, 3, threadIdx.x & 63, j, q);
 }
 
+// ---- pass 1' with a tile shared by TWO waves (round 6). k_train_b1 holds 30 accumulator tiles, the gathered rows of both reversed
+// graphs and the next tile's prefetch in ONE wave: 434-452 unified registers = one wave per SIMD, and its counters say what that costs
+// (profiles/r05_d_pmc_train_b1_f16x2.txt, quad-cycle units: SQ_WAIT_ANY 3.4e8 of SQ_WAVE_CYCLES 7.2e8 = 48 % of the wave's life parked
+// on a counter, 22 % issuing vector instructions, the matrix pipe busy 22 %): nothing else is resident to run meanwhile. Here the two
+// branches of the layer (`l?_t1_*` = station side, `l?_t2_*` = source side, module.py:90-96) go to the two waves of a PAIR:
+//   role 0: transposed mean of do1 over the reversed station graph, du, dh1 / dt blocks 0-1, dh0 block 0, the 15 weight-gradient tiles
+//           of l2_t1_2 and l2_t1_1;   role 1: the same with do2 / the reversed source graph / dv / blocks 2-3 / block 1 / l2_t2_*.
+// dh1 needs both branches' du and dv, dh0 all four dt blocks: two exchanges of two rows per lane through LDS with a workgroup barrier
+// each (a workgroup = two pairs with the same trip count). Every sum keeps the order it has in k_train_b1, so dt / dh0 and the
+// per-tile products are the same bits; only the grouping of the per-wave partials changes. <= 256 registers: two workgroups = two
+// waves per SIMD. Cartesian graphs with 32-bit row offsets (the O32 form of k_train_b1) only.
+template <bool AS, int ROLE>
+__device__ __forceinline__ void train_b1s_role(const TrArgs& a, const f32x4* lw, float* sc, f32x4* ex1, f32x4* ex2, float* sx, int pair) {
+    const float* lscal = (const float*)(lw + GT1_GROUPS * 64);
+    const float a1 = lscal[0], ax = lscal[1 + ROLE];            // a21 (u) / a22 (v)
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int S = a.S;
+    const long long P = a.P;
+    f32x4 acc[15], vec[4];
+    float scal0 = 0.f, scalx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vec[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int SVT = a.sv_t, SVX = ROLE == 0 ? a.sv_up : a.sv_vp;
+    ItemIter w(a.G, a.T, a.seg, a.nxcd, 0);
+    // a workgroup takes its chunk's items two at a time (one per pair): both pairs run the same number of tiles (and barriers)
+    const int nx = (a.nxcd > 1 && (int)gridDim.x >= a.nxcd && ((int)gridDim.x % a.nxcd) == 0) ? a.nxcd : 1;
+    const long long lb = blockIdx.x / nx, nbx = gridDim.x / nx;
+    constexpr int EB = ROLE == 0 ? 8 : 16;          // prefetched out-edges: per station (per lane) / per source node (uniform)
+    struct Tile { int g, scn; bool valid; };
+    const unsigned q16 = 16u * (unsigned)q, P64 = (unsigned)P * 64u, S64 = (unsigned)S * 64u;
+    const unsigned long long grb = sbase(a.gr), svb = sbase(a.save);
+    const unsigned oDO0 = (unsigned)(GR_DO + 0) * P64, oDO1 = (unsigned)(GR_DO + 1) * P64;
+    const int2* cw = ROLE == 0 ? a.r_sta_cw : a.r_src_cw;
+    auto tile_of = [&](long long base) {         // base: the workgroup's item pair; past the end or an odd last item: pair 0's tile, all lanes invalid
+        const bool live = base < w.nitems;
+        const long long b_ = live ? base : lb * 2;
+        const bool mine = live && b_ + pair < w.nitems;
+        int gi, tb;
+        w.decode(mine ? b_ + pair : b_, gi, tb);
+        Tile t;
+        t.g = __builtin_amdgcn_readfirstlane(a.order[gi]);
+        const int s_ = tb * 16 + j;
+        t.valid = mine && s_ < S;
+        t.scn = s_ < S ? s_ : S - 1;
+        return t;
+    };
+    auto idx_of = [&](const Tile& t, NbrIdx<EB>& x) {
+        if (ROLE == 0) nbr_idx_load<EB>(cw, a.r_sta_rowptr[t.scn], a.r_sta_rowptr[t.scn + 1], x);
+        else nbr_idx_load<EB>(cw, __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g]), __builtin_amdgcn_readfirstlane(a.r_src_rowptr[t.g + 1]), x);
+    };
+    auto row_at = [&](const Tile& t, int c) {      // the row of out-neighbour c: this source node's station c / source node c's row of this station
+        if (ROLE == 0) return ldo(grb, oDO0 + (unsigned)(t.g * S) * 64u + q16 + ((unsigned)c << 6));
+        return ldo(grb, (unsigned)c * S64 + oDO1 + (unsigned)t.scn * 64u + q16);
+    };
+    auto rows_sum = [&](const Tile& t, const NbrIdx<EB>& x, const f32x4 (&r)[EB]) {
+        f32x4 tm[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < EB; ++k) tm[0] += r[k] * x.w[k];
+        tmean_rest<1, 8>(cw, x.e_next, x.e_end, ROLE == 1, [&](int, int c) { return row_at(t, c); }, tm);
+        return tm[0] * (t.valid ? 1.f : 0.f);
+    };
+    struct Own { f32x4 mb, do1, do2, t[4], xp[2]; };
+    auto own_load = [&](const Tile& t, Own& o) {
+        const long long p_ = (long long)t.g * S + t.scn;
+        o.mb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) o.mb = *(const f32x4*)(a.mask + p_ * 4);
+        const unsigned po = (unsigned)p_ * 64u + q16;
+        o.do1 = ldo(grb, oDO0 + po); o.do2 = ldo(grb, oDO1 + po);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.t[k] = ldo(svb, (unsigned)(SVT + k) * P64 + po);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) o.xp[b] = ldo(svb, (unsigned)(SVX + b) * P64 + po);
+    };
+    long long base = lb * 2;
+    Tile cur = {0, 0, false}, nxt = cur;
+    f32x4 tm = {0.f, 0.f, 0.f, 0.f};
+    if (base < w.nitems) {
+        cur = tile_of(base);
+        NbrIdx<EB> x;
+        idx_of(cur, x);
+        f32x4 r[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) r[k] = row_at(cur, x.c[k]);
+        tm = rows_sum(cur, x, r);
+        nxt = tile_of(base + nbx * 2);
+    }
+    for (; base < w.nitems; base += nbx * 2) {
+        asm volatile("" : "+v"(lane));
+        const int g = cur.g, scn = cur.scn;
+        const bool valid = cur.valid;
+        const unsigned po = (unsigned)((long long)g * S + scn) * 64u + q16;
+        const float vm = valid ? 1.f : 0.f;
+        Own own;
+        own_load(cur, own);
+        NbrIdx<EB> xn;
+        idx_of(nxt, xn);                      // the next tile's (column, weight) pairs: in flight under this tile
+        const f32x4 do1 = own.do1 * vm, do2 = own.do2 * vm;
+        const f32x4 dob = ROLE == 0 ? do1 : do2;
+        if (AS) vec[3] += dob * a.pg[(long long)g * AS_PG + 31];
+        // this branch's du (dv) = l2_t?_2[:, 60:90]^T tm through PReLU2?'
+        f32x4 dx[2], xv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 gx = mma_block(z, lw[(ROLE == 0 ? GT_U(b) : GT_V(b)) * 64 + lane], tm);
+            scalx += negsum4(gx, own.xp[b]);
+            dx[b] = gx * dprelu4(own.xp[b], ax);
+            xv[b] = prelu4u(own.xp[b], ax);
+            ex1[b * 64 + lane] = dx[b];
+        }
+        __syncthreads();
+        const f32x4 dy0 = ex1[(ROLE == 0 ? 128 : -128) + lane], dy1 = ex1[(ROLE == 0 ? 128 : -128) + 64 + lane];     // the partner's rows
+        const f32x4 du0 = ROLE == 0 ? dx[0] : dy0, du1 = ROLE == 0 ? dx[1] : dy1;
+        const f32x4 dv0 = ROLE == 0 ? dy0 : dx[0], dv1 = ROLE == 0 ? dy1 : dx[1];
+        // dh1 / dt of this wave's two blocks (the six-term chain of k_train_b1, same order)
+        f32x4 dt[4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hb = 2 * ROLE + hh;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du0);
+            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du1);
+            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv0);
+            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv1);
+            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
+            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
+            scal0 += negsum4(d, own.t[hb]);
+            dt[hb] = d * dprelu4(own.t[hb], a1);
+            if (valid) sto(grb, (unsigned)(GR_DT + hb) * P64 + po, dt[hb]);
+            ex2[hh * 64 + lane] = dt[hb];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) dt[2 * (1 - ROLE) + hh] = ex2[(ROLE == 0 ? 128 : -128) + hh * 64 + lane];
+        {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d = mma_block(d, lw[GT_D(ROLE, k) * 64 + lane], dt[k]);
+            if (valid) sto(grb, (unsigned)(GR_DH0 + ROLE) * P64 + po, d);
+        }
+        vec[0] += dob; vec[1] += dx[0]; vec[2] += dx[1];
+        // the next tile's gathered rows: in flight under the weight gradients
+        f32x4 r[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) r[k] = row_at(nxt, xn.c[k]);
+        // weight gradients of this branch: l2_t?_2 {h1 x4, Mask, x x2 (adjoint)} = 7 tiles, l2_t?_1 (2 x h1 x4) = 8 tiles
+        f32x4 h1t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h1t[k] = tr16(prelu4u(own.t[k], a1), sc, j, q);
+        {
+            const f32x4 dbt = tr16(dob, sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = outer16(acc[k], dbt, h1t[k]);
+            acc[4] = outer16(acc[4], dbt, tr16(own.mb, sc, j, q));
+            const f32x4 mt = tr16(tm, sc, j, q);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[5 + b] = outer16(acc[5 + b], mt, tr16(xv[b], sc, j, q));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 dxt = tr16(dx[b], sc, j, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[7 + b * 4 + k] = outer16(acc[7 + b * 4 + k], dxt, h1t[k]);
+        }
+        tm = rows_sum(nxt, xn, r);
+        cur = nxt;
+        nxt = tile_of(base + nbx * 4);
+    }
+    // partials of the PAIR in the layout of k_train_b1's wave (k_train_reduce): accumulator tiles 0-6 / 14-21 (role 0), 7-13 / 22-29
+    // (role 1); vectors b(l2_t1_2) 0, b(l2_t2_2) 1, b(l2_t1_1) 2-3, b(l2_t2_1) 4-5, AS: the mask1 column 6 / 7; slopes a1 (both), a21, a22
+    float* out = a.part + (size_t)(blockIdx.x * 2 + pair) * ((size_t)a.n_acc * 256 + (size_t)a.n_vec * 16 + 16);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const int gk = ROLE == 0 ? (k < 7 ? k : k + 7) : (k < 7 ? k + 7 : k + 15);
+        *(f32x4*)(out + (size_t)gk * 256 + lane * 4) = acc[k];
+    }
+    out += (size_t)a.n_acc * 256;
+    constexpr int NVW = AS ? 4 : 3;
+#pragma unroll
+    for (int k = 0; k < NVW; ++k) {
+        f32x4 v = vec[k];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+        }
+        const int gk = k == 0 ? ROLE : (k == 3 ? 6 + ROLE : 2 + 2 * ROLE + (k - 1));
+        if (j == 0) *(f32x4*)(out + gk * 16 + 4 * q) = v;
+    }
+    out += (size_t)a.n_vec * 16;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { scal0 += __shfl_xor(scal0, d); scalx += __shfl_xor(scalx, d); }
+    if (ROLE == 1 && lane == 0) sx[pair] = scal0;
+    __syncthreads();
+    if (lane == 0) {
+        if (ROLE == 0) out[0] = scal0 + sx[pair];
+        out[1 + ROLE] = scalx;
+    }
+}
+template <bool AS>
+__global__ __launch_bounds__(256, 2) void k_train_b1s(TrArgs a) {
+    constexpr int NF4 = (GT1_GROUPS * 256 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    __shared__ __attribute__((aligned(16))) float tsc[4][16 * 17];
+    __shared__ f32x4 ex1[4 * 2 * 64], ex2[4 * 2 * 64];      // [wave][row][lane]: the rows a wave hands to its partner (du | dv, then dt)
+    __shared__ float sx[2];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((wave & 1) == 0) train_b1s_role<AS, 0>(a, lw, tsc[wave], ex1 + wave * 128, ex2 + wave * 128, sx, wave >> 1);
+    else train_b1s_role<AS, 1>(a, lw, tsc[wave], ex1 + wave * 128, ex2 + wave * 128, sx, wave >> 1);
+}
+
 // ---- pass 1' on an irregular product graph (`use_subgraph`): the structure k_train_b1 had before its software pipeline. A tile is 16
 // consecutive product nodes; the transposed means run over the reversed PRODUCT-level graphs (out-edges of a product node, per lane
 // on both sides), gradient rows are addressed by product-node id.
