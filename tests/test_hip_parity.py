@@ -2387,9 +2387,24 @@ def test_forward_defers_the_structure_checks_and_recovers_when_they_fail():
             assert other[0].shape == ref[0].shape and torch.isfinite(other[0]).all()
         except (ValueError, RuntimeError):
             pass
-        assert calls[-2:] == [True, False] and getattr(net, "_pending_checks", None) is None
+        # a model whose lists failed the literal checks once stops deferring (every later sample would pay a discarded forward and a
+        # second build): the altered list goes straight to the checked path
+        assert net._defer_failed and calls == [True, True, False, False] and getattr(net, "_pending_checks", None) is None
         again = net(t("Slice"), t("Mask"), A1.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src, *tabs, *tail)      # and the model still works
-        assert all(torch.equal(a, b) for a, b in zip(ref, again))
+        assert all(torch.equal(a, b) for a, b in zip(ref, again)) and calls[-1] is False
+    # a fresh model with an altered list as its FIRST sample: deferred build, verdict bad, rebuilt with the checks up front
+    net2 = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+    net2.load_state_dict({k: v.clone() for k, v in O.weights_from_npz(z).items()}, strict=True)
+    net2.eval()
+    calls2 = []
+    plain2 = net2.set_adjacencies
+    net2.set_adjacencies = lambda *a, **k: (calls2.append(bool(k.get("_defer_checks"))), plain2(*a, **k))[1]
+    with torch.no_grad():
+        try:
+            net2(t("Slice"), t("Mask"), bad.to(DEV), A2.to(DEV), ea, ea, A4.to(DEV), A_src, *tabs, *tail)
+        except (ValueError, RuntimeError):
+            pass
+        assert calls2 == [True, False] and net2._defer_failed and getattr(net2, "_pending_checks", None) is None
 
 
 @pytest.mark.parametrize("n", [3, 200, 10000, 50000])
