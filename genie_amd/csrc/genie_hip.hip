@@ -1400,6 +1400,11 @@ const char* tune_env(const char* name) {
     return nullptr;
 #endif
 }
+// stage 2 of an irregular product graph with the station sum folded in (k_stage2_pseg); tuning builds can switch back for A/B runs
+bool pseg_on() {
+    static const char* e = tune_env("GENIE_S2_PSEG");
+    return !e || atoi(e) != 0;
+}
 bool h2_on(const genie_ctx* c) { return c->use_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 bool pcsr_h2_on(const genie_ctx* c) { return c->pcsr_h2 && (c->prec_mode == 1 || (c->prec_mode == 0 && c->range_ok)); }
 int part_T(const genie_ctx* c) { return c->pcsr ? 1 : c->T; }      // rows of station-sum partials per source node in `part`
@@ -2792,6 +2797,14 @@ int run_stage2(genie_ctx* c, const float* mask, const float* edge_attr, float* x
         const long long ntiles = (c->P + 15) / 16;
         a.ptile = c->ptile16;
         const long long gw = std::min<long long>((ntiles + 3) / 4, (long long)c->num_cu * c->bpc2);      // 2 .. 12 workgroups per CU: +-1 %
+        if (!no_bip && !x_latent_out && !a.save && pseg_on()) {
+            // inference: a wave per source node, the station sum folded into the pass (k_stage2_pseg), straight into the window's slot
+            a.part = (float*)ws + c->o_part + c->slot * c->slot_stride;
+            const long long gs = std::min<long long>((c->G + 3) / 4, (long long)c->num_cu * c->bpc2);
+            k_stage2_pseg<<<(int)std::max<long long>(8, gs / 8 * 8), 256, 0, st>>>(a, c->seg_rowptr, c->G);
+            HIP_TRY(hipGetLastError());
+            return GENIE_OK;
+        }
         k_stage2_pcsr<<<(int)std::max<long long>(8, gw / 8 * 8), 256, 0, st>>>(a);                       // (a multiple of the 8 XCDs)
         // the gated messages sit in the c rows, which exist GENIE_NBIG times only: their station sums (row order) go to the window's
         // own slot right away, one partial row per source node, so that every tail form (per window, side streams, batched) reads

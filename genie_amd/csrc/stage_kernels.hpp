@@ -1080,6 +1080,89 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     }
 }
 
+// Stage 2 on an irregular product graph with the station sum FOLDED IN (round 6): a wave owns whole source nodes. The product nodes
+// of a source node are one contiguous row range (process_utils.py:790-794: `seg_rowptr`), so the wave walks that range 16 nodes at a
+// time -- the arithmetic of k_stage2_pcsr per tile -- and keeps the gated Bipartite messages of its node columns in two accumulators
+// across the tiles; one butterfly over the 16 columns at the end gives the source node's station sum, written straight to the
+// window's `part` row. No message row is written back over c (128 B per product node) and read again by k_seg_sum32 (one launch
+// less). Source nodes are taken in processing order (space-filling curve), chunked by XCD as the tiles of k_stage2_pcsr are, so the
+// wv rows the waves of a CU gather overlap. Inference only (no kept pre-activations, no x_latent output): the other calls keep
+// k_stage2_pcsr + k_seg_sum32. Station sum order: per node column over the tiles (rows j, j + 16, ...), then the butterfly.
+// Measured and dropped (profiles/EXPERIMENTS.md, round 6): the range's own `wu` rows staged in the wave's LDS for the 8 station
+// gathers of every node (48 KB per workgroup, a bounds check per neighbour): 0.310 -> 0.345 ms per window, back to the unfused time.
+__global__ __launch_bounds__(256) void k_stage2_pseg(DaArgs a, const int32_t* __restrict__ seg_rowptr, int n_src) {
+    constexpr int NF4 = (G2_GROUPS * 256 + G2_BIAS * 16 + 16) / 4;
+    __shared__ f32x4 lw[NF4];
+    for (int i = threadIdx.x; i < NF4; i += 256) lw[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lbias = (const float*)(lw + G2_GROUPS * 64);
+    const float* lscal = lbias + G2_BIAS * 16;
+    const float a2 = a.slope2 != nullptr ? *a.slope2 : lscal[0], ab1 = lscal[1];
+    __shared__ __attribute__((aligned(16))) float tsc[4 * 16 * 36];
+    int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int jl = lane >> 2, ql = lane & 3;
+    float* ts = tsc + (threadIdx.x >> 6) * 16 * 36;
+    PtileIter pt(n_src, blockDim.x >> 6, threadIdx.x >> 6);
+    for (; pt.i < pt.end; pt.i += pt.stride) {
+        const int g = __builtin_amdgcn_readfirstlane(a.order != nullptr ? a.order[pt.i] : (int)pt.i);
+        const long long r0 = __builtin_amdgcn_readfirstlane(seg_rowptr[g]), r1 = __builtin_amdgcn_readfirstlane(seg_rowptr[g + 1]);
+        f32x4 sum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (long long base = r0; base < r1; base += 16) {
+            asm volatile("" : "+v"(lane));
+            const long long pr = base + j;
+            const bool valid = pr < r1;
+            const long long p = valid ? pr : r1 - 1;
+            const long long prl = base + jl;
+            const long long pl = prl < r1 ? prl : r1 - 1;
+            f32x4 o[2];
+            o[0] = *(const f32x4*)(a.c + pl * ROWC + 4 * ql);
+            o[1] = *(const f32x4*)(a.c + pl * ROWC + 16 + 4 * ql);
+            const float mq = a.mask[p * 4 + q];
+            const float eq = q < 3 ? a.edge_attr[p * 3 + q] : 0.f;
+            f32x4 n1 = {0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const int eb = a.sta_rowptr[pl], ee = a.sta_rowptr[pl + 1];
+                gather_sum16<false>(a.wu + 4 * ql, ROWW, a.sta_col, eb, ee, n1);
+                o[0] = fma4(n1, 1.f / (float)max(ee - eb, 1), o[0]);
+            }
+            {
+                const int eb = a.src_rowptr[pl], ee = a.src_rowptr[pl + 1];
+                gather_sum16<false>(a.wv + 4 * ql, ROWW, a.src_col, eb, ee, n2);
+                o[1] = fma4(n2, 1.f / (float)max(ee - eb, 1), o[1]);
+            }
+            o[0] = prelu4u(o[0], a2);
+            o[1] = prelu4u(o[1], a2);
+            *(f32x4*)(ts + jl * 36 + 4 * ql) = o[0];
+            *(f32x4*)(ts + jl * 36 + 16 + 4 * ql) = o[1];
+            GSYNC();
+            o[0] = *(const f32x4*)(ts + j * 36 + 4 * q);
+            o[1] = *(const f32x4*)(ts + j * 36 + 16 + 4 * q);
+            GSYNC();
+            float mm = fmaxf(mq, __shfl_xor(mq, 16));
+            mm = fmaxf(mm, __shfl_xor(mm, 32));
+            mm = valid ? mm : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 bp = *(const f32x4*)(lbias + t * 16 + 4 * q);
+                bp = mma_block(bp, lw[G2_BP(t, 0) * 64 + lane], o[0]);
+                bp = mma_block(bp, lw[G2_BP(t, 1) * 64 + lane], o[1]);
+                bp = MFMA16(lw[G2_BP(t, 2) * 64 + lane].x, eq, bp);
+                sum[t] += prelu4u(bp, ab1) * mm;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v = sum[t];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+            }
+            if (j == 0) *(f32x4*)(a.part + (long long)g * 32 + 16 * t + 4 * q) = v;
+        }
+    }
+}
+
 // k_stage2_fast for the production configuration (uniform-degree graphs, station processing order with a registered static
 // edge_attr, static item stream, Bipartite half on), straight-line: the ISA of k_stage2_fast spends a fifth of its vector
 // instructions on register copies at the joins of its option branches (the 15 source rows were copied out and back every tile),
