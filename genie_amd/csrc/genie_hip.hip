@@ -44,32 +44,13 @@
 #define ABL(a, bit) 0
 #endif
 
-// read-once rows (c, Mask, edge_attr of stage 2) as non-temporal loads: measured SLOWER (0.354 vs 0.326 ms), off
-#ifndef GENIE_S2_NT
-#define GENIE_S2_NT 0
-#endif
-#if GENIE_S2_NT
-#define GENIE_LD_STREAM(ptr) __builtin_nontemporal_load(ptr)
-#else
+// read-once rows (c, Mask, edge_attr of stage 2): plain loads (non-temporal ones measured slower, 0.354 vs 0.326 ms)
 #define GENIE_LD_STREAM(ptr) (*(ptr))
-#endif
-
-#ifndef GENIE_S2_WAVES
-#define GENIE_S2_WAVES 2   // minimum waves per SIMD the register allocator of k_stage2_fast is held to (3 = 168 VGPRs with
-                           // spills and more rows in flight than L2 keeps: 0.313 vs 0.302 ms, fabric reads +50 %)
-#endif
-
-#ifndef GENIE_S2H_WAVES
-#define GENIE_S2H_WAVES 2  // k_stage2_h2: waves per SIMD the register budget is held to (__launch_bounds__)
-#endif
-
-#ifndef GENIE_H2_DEPTH
-#define GENIE_H2_DEPTH 6   // k_stage1_h2: row loads in flight ahead of their use (3 .. 8 measured equal)
-#endif
-
-#ifndef GENIE_HOIST_WEIGHTS
-#define GENIE_HOIST_WEIGHTS 0
-#endif
+// Register budgets and depths settled by measurement (profiles/EXPERIMENTS.md): k_stage2_ord / k_stage2_h2 are held to two waves per
+// SIMD (three: spills, +50 % fabric reads, 0.313 vs 0.302 ms); k_stage1_h2 keeps 6 row loads in flight ahead of their use (3..8 equal)
+#define GENIE_S2_WAVES 2
+#define GENIE_S2H_WAVES 2
+#define GENIE_H2_DEPTH 6
 
 namespace {
 
@@ -966,9 +947,7 @@ __global__ void k_pack_all(const float* __restrict__ raw, const PackPlan* __rest
 #if GENIE_TUNING
 __device__ int g_abl_mfma;  // set from the host in tuning builds
 #endif
-#if defined(GENIE_MFMA_OFF)      // timing experiment: every fp32 MFMA replaced by 4 VALU multiply-adds (wrong results)
-#define MFMA16(a, b, c) ((c) + (a) * (b))
-#elif GENIE_ABL_MFMA
+#if GENIE_ABL_MFMA
 #define MFMA16(a, b, c) (g_abl_mfma ? ((c) + (a) * (b)) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0))
 #else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)

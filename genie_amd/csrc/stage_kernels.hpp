@@ -151,9 +151,7 @@ __global__ __launch_bounds__(256) void k_stage1(DaArgs a) {
         int gi, tb;
         w.decode(w.it, gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-#if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));  // A fragments are re-read from LDS per tile, not held in VGPRs across tiles
-#endif
         const int s = tb * 16 + j;
         const bool valid = s < S;
         const int sc = valid ? s : S - 1;
@@ -232,9 +230,7 @@ __global__ __launch_bounds__(256) void k_stage1_pcsr(DaArgs a) {
     PtileIter pt(ntiles, blockDim.x >> 6, threadIdx.x >> 6);
     for (; pt.i < pt.end; pt.i += pt.stride) {
         const long long tile = ptile_at(a.ptile, pt.i);
-#if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
-#endif
         const long long pr = tile * 16 + j;
         const bool valid = pr < a.Pn;
         const long long p = valid ? pr : a.Pn - 1;
@@ -916,9 +912,7 @@ __global__ __launch_bounds__(256) void k_stage2(DaArgs a) {
         int gi, tb;
         w.decode(w.it, gi, tb);
         const int g = __builtin_amdgcn_readfirstlane(a.order[gi]);
-#if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
-#endif
         const int s = tb * 16 + j;
         const bool valid = s < S;
         const int sc = valid ? s : S - 1;
@@ -1010,9 +1004,7 @@ __global__ __launch_bounds__(256) void k_stage2_pcsr(DaArgs a) {
     PtileIter pt(ntiles, blockDim.x >> 6, threadIdx.x >> 6);
     for (; pt.i < pt.end; pt.i += pt.stride) {
         const long long tile = ptile_at(a.ptile, pt.i);
-#if !GENIE_HOIST_WEIGHTS
         asm volatile("" : "+v"(lane));
-#endif
         const long long pr = tile * 16 + j;
         const bool valid = pr < a.Pn;
         const long long p = valid ? pr : a.Pn - 1;
@@ -1743,18 +1735,11 @@ __global__ __launch_bounds__(256) void k_h2_range(RangeArgs a) {
 // Everything per node (streamed rows, station-neighbour gathers, f16x2 fc1, station sum) is k_stage2_h2's code: same results bit for
 // bit (the row sums keep the edge order).
 // ------------------------------------------------------------------------------------------------
-#ifndef GENIE_S2U_WPB
-#define GENIE_S2U_WPB 4
-#endif
-constexpr int S2U_WPB = GENIE_S2U_WPB;   // waves per workgroup (round 5: 8 waves = blocks of 16 source nodes on the same 64-row union, twice the resident
-                                         // waves: 0.264 against 0.198 ms -- the 64-row cap cuts such blocks at 11-13 nodes and leaves a quarter of the slots empty)
+constexpr int S2U_WPB = 4;           // waves per workgroup (round 5: 8 waves = blocks of 16 source nodes on the same 64-row union, twice the resident
+                                     // waves: 0.264 against 0.198 ms -- the 64-row cap cuts such blocks at 11-13 nodes and leaves a quarter of the slots empty)
 constexpr int S2U_NB = 2 * S2U_WPB;  // source nodes per block (two per wave)
-#ifndef GENIE_S2U_UCAP
+#define GENIE_S2U_BPC 2              // workgroups per CU
 #define GENIE_S2U_UCAP 64
-#endif
-#ifndef GENIE_S2U_BPC
-#define GENIE_S2U_BPC 2
-#endif
 constexpr int S2U_UCAP = GENIE_S2U_UCAP;   // distinct neighbour rows of a block (a block is cut short where the union would exceed it), <= 64.
                                            // (Round 5: 32 rows at 4 workgroups per CU, 48 at 3 -- more resident waves, less sharing and blocks cut short
                                            // with empty node slots -- 0.711 and 0.374 ms against 0.202: the staging is what this kernel lives on.)
