@@ -190,8 +190,8 @@ def test_training_gradients_match_oracle_with_rough_cotangents_odd_sizes(stage1,
     """Every gradient of the path against the structured oracle's autograd with random N(0, 1) cotangents on (y, x) (no smoothing
     by an MSE), 33 stations x 257 source nodes x 100 queries (partial tiles everywhere), the scaled `o1` weights (outputs O(1)).
     With the fp32-MFMA stage-1 forward (stage_precision="f32") every gradient is within 1e-4 of its own scale (observed 4.9e-5; the fp32
-    oracle itself is 6e-5 from the fp64 one, tools/train_grad_fp64.py). The default training forward (f16x2 stage 1, its saved
-    pre-activations within 1.4e-6 of the fp32 ones, tools/train_save_cmp.py) puts ONE near-zero output pre-activation of this case
+    oracle itself is 6e-5 from the fp64 one, tools/archive/train_grad_fp64.py). The default training forward (f16x2 stage 1, its saved
+    pre-activations within 1.4e-6 of the fp32 ones, tools/archive/train_save_cmp.py) puts ONE near-zero output pre-activation of this case
     on the other side of its PReLU kink, where the gradient is discontinuous: the source-neighbour branch then differs by up to
     4.7e-4 of its scale -- a different, equally valid fp32 evaluation, bounded here at 1e-3 (a wrong save would show as O(1))."""
     from oracle import genie_oracle as O
