@@ -695,22 +695,37 @@ __device__ __forceinline__ void train_b1s_role(const TrArgs& a, const f32x4* lw,
         const f32x4 dy0 = ex1[(ROLE == 0 ? 128 : -128) + lane], dy1 = ex1[(ROLE == 0 ? 128 : -128) + 64 + lane];     // the partner's rows
         const f32x4 du0 = ROLE == 0 ? dx[0] : dy0, du1 = ROLE == 0 ? dx[1] : dy1;
         const f32x4 dv0 = ROLE == 0 ? dy0 : dx[0], dv1 = ROLE == 0 ? dy1 : dx[1];
-        // dh1 / dt of this wave's two blocks (the six-term chain of k_train_b1, same order)
+        // dh1 / dt of this wave's two blocks: the six-term chain of k_train_b1 per block, same order inside a chain. The two chains are
+        // written INTERLEAVED, MFMA by MFMA, with the next pair of weight fragments read from LDS one step ahead: left to itself the
+        // compiler ran chain 0 then chain 1, 48 dependent MFMAs in a row (40-cycle dependent latency on a 32-cycle instruction) with an
+        // LDS read and a full lgkmcnt(0) wait in front of every fourth one (round-6 disassembly)
         f32x4 dt[4];
+        {
+            const f32x4 xs6[6] = {du0, du1, dv0, dv1, do1, do2};
+            constexpr int hb0 = 2 * ROLE, hb1 = 2 * ROLE + 1;
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+            f32x4 wa = lw[GT_H(hb0, 0) * 64 + lane], wb = lw[GT_H(hb1, 0) * 64 + lane];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int hb = 2 * ROLE + hh;
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            d = mma_block(d, lw[GT_H(hb, 0) * 64 + lane], du0);
-            d = mma_block(d, lw[GT_H(hb, 1) * 64 + lane], du1);
-            d = mma_block(d, lw[GT_H(hb, 2) * 64 + lane], dv0);
-            d = mma_block(d, lw[GT_H(hb, 3) * 64 + lane], dv1);
-            d = mma_block(d, lw[GT_H(hb, 4) * 64 + lane], do1);
-            d = mma_block(d, lw[GT_H(hb, 5) * 64 + lane], do2);
-            scal0 += negsum4(d, own.t[hb]);
-            dt[hb] = d * dprelu4(own.t[hb], a1);
-            if (valid) sto(grb, (unsigned)(GR_DT + hb) * P64 + po, dt[hb]);
-            ex2[hh * 64 + lane] = dt[hb];
+            for (int sidx = 0; sidx < 6; ++sidx) {
+                f32x4 na = wa, nb = wb;
+                if (sidx < 5) { na = lw[GT_H(hb0, sidx + 1) * 64 + lane]; nb = lw[GT_H(hb1, sidx + 1) * 64 + lane]; }
+                const f32x4 x = xs6[sidx];
+                d0 = MFMA16(wa.x, x.x, d0); d1 = MFMA16(wb.x, x.x, d1);
+                d0 = MFMA16(wa.y, x.y, d0); d1 = MFMA16(wb.y, x.y, d1);
+                d0 = MFMA16(wa.z, x.z, d0); d1 = MFMA16(wb.z, x.z, d1);
+                d0 = MFMA16(wa.w, x.w, d0); d1 = MFMA16(wb.w, x.w, d1);
+                wa = na; wb = nb;
+            }
+            scal0 += negsum4(d0, own.t[hb0]);
+            scal0 += negsum4(d1, own.t[hb1]);
+            dt[hb0] = d0 * dprelu4(own.t[hb0], a1);
+            dt[hb1] = d1 * dprelu4(own.t[hb1], a1);
+            if (valid) {
+                sto(grb, (unsigned)(GR_DT + hb0) * P64 + po, dt[hb0]);
+                sto(grb, (unsigned)(GR_DT + hb1) * P64 + po, dt[hb1]);
+            }
+            ex2[lane] = dt[hb0];
+            ex2[64 + lane] = dt[hb1];
         }
         __syncthreads();
 #pragma unroll
