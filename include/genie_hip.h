@@ -128,14 +128,18 @@ int genie_stage_precision(genie_ctx* ctx, int* mode, int* f16x2_active, float* a
  * only inputs the reference's pipeline produces) and, its bound being linear in the input magnitude, up to |input| <= *limit = 60000 /
  * act_bound. The split pass of every f16x2 stage-1 call checks the rows it reads and records the largest magnitude BEYOND that limit in a
  * word of host-mapped memory; this call returns it in *max_seen (0 = every input so far was inside the limit) WITHOUT synchronising: it
- * reflects the split passes that have completed. reset != 0 clears the word. A caller that sees a non-zero value must discard the
+ * reflects the split passes that have completed. reset != 0 = ONE atomic fetch-and-clear: the value returned is exactly the value cleared
+ * (kernels still in flight may be writing the word: a read followed by a separate store could drop what they wrote in between). Nobody
+ * reads the word once the context is destroyed: check after the LAST call on a context too (the Python host does when it replaces a
+ * context, at the read-backs it makes anyway, and warns from the destructor). A caller that sees a non-zero value must discard the
  * results of the calls issued since its last check and switch to genie_set_stage_precision(ctx, 2) (the Python host does both and
  * raises). Never set by the fp32 kernels, by the device embedding's split rows (values in [-1, 1] by construction) or in mode 2. */
 int genie_input_range(genie_ctx* ctx, float* max_seen, float* limit, int reset);
 /* Index errors found on the device since the last reset, read from host-mapped memory without synchronising (like genie_input_range):
  * bit 0 = a pick of a genie_lslc_fwd call indexed outside the time-pointer table (tpick outside dt_partition, or ipick outside the
  * stations of A_edges; the kernel clamps the index, the reference's indexing at Code/module.py:635-640 fails with a device-side
- * assertion reported at its next synchronisation). The Python host raises IndexError at its next call on the context. */
+ * assertion reported at its next synchronisation). reset != 0 = atomic fetch-and-clear (see genie_input_range). The Python host raises
+ * IndexError at its next call on the context, where it has just waited for the device anyway, and when it replaces the context. */
 int genie_index_flags(genie_ctx* ctx, unsigned* flags, int reset);
 /* Range check of a caller's index list on the device, no host round trip: sets `bit` (2, 4, ...; bit 0 belongs to genie_lslc_fwd) in the
  * word genie_index_flags returns when some idx[i] lies outside [lo, hi). The Python host uses bit 1 (value 2) for the station indices
