@@ -1022,7 +1022,11 @@ def main():
             torch.cuda.empty_cache()
             try:
                 o1 = main_sharded(a1, geom, n_picks, nq, 0, 1, dev, None, emit=False)
-                out["one_gpu_same_config"] = {"ms_per_step": o1["ms_per_step"], "steps": a1.steps, "speedup": round(o1["ms_per_step"] / out["ms_per_step"], 2),
+                out["one_gpu_same_config"] = {"ms_per_step": o1["ms_per_step"], "value": o1["value"], "unit": "picks/s", "steps": a1.steps,
+                                              "speedup": round(o1["ms_per_step"] / out["ms_per_step"], 2),
+                                              "scaling_efficiency": round(o1["ms_per_step"] / out["ms_per_step"] / world, 3),
+                                              "note": "the N = 1 line of `bench.py --gpus 1` is ANOTHER workload (config 2, the literal call): the strong-"
+                                                      "scaling curve of this line's workload starts at this figure",
                                               "rank0_phase_ms_sequential": o1["rank0_phase_ms_sequential"],
                                               "source": "measured live on rank 0 after the sharded run, same code path with one rank"}
             except Exception as e:
