@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs: python -c "from genie_amd import _lib; _lib.build(extra_flags=['-DGENIE_TUNING=1','-DGENIE_ABL_MFMA=0'], out_path='genie_amd/lib/variants/libgenie_tune.so')"
 # Round 6, VERDICT item 4: pass 1' of the training backward as ONE wave per tile (k_train_b1: 434 registers, one wave per SIMD) against
 # TWO waves per tile (k_train_b1s: 256 registers, two waves per SIMD). Same box, tuning build (GENIE_B1_SPLIT=0 / 1 selects the kernel):
 # step time + phases (bench --mode train), kernel-trace averages, SQ counters of both. Output: gpurun_out/r06_b1_split_ab.txt

@@ -1,3 +1,4 @@
+# Production code generation, split against one-wave pass 1' (round 6). needs: python -c "from genie_amd import _lib; _lib.build(extra_flags=['-DGENIE_B1_SPLIT_DEFAULT=0'], out_path='genie_amd/lib/variants/libgenie_b1_one_wave.so')"
 R=$GRAFT_REPO_ROOT
 for rep in 1 2 3; do
 for lib in $R/genie_amd/lib/libgenie_hip.so $R/genie_amd/lib/variants/libgenie_b1_one_wave.so; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs: python -c "from genie_amd import _lib; _lib.build(extra_flags=['-DGENIE_TUNING=1','-DGENIE_ABL_MFMA=0'], out_path='genie_amd/lib/variants/libgenie_tune.so')"
 # Round 6, VERDICT item 7: stage 2 of the irregular product graph (use_subgraph) as k_stage2_pcsr + k_seg_sum32 (GENIE_S2_PSEG=0) against
 # k_stage2_pseg (a wave per source node, station sum folded in). Same box, tuning build. Output: gpurun_out/r06_pseg_ab.txt
 R=$(cd "$(dirname "$0")/.." && pwd)

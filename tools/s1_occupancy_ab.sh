@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs: python -c "from genie_amd import _lib; _lib.build(extra_flags=['-DGENIE_H2_THREADS=1024'], out_path='genie_amd/lib/variants/libgenie_h2t1024.so')"
 # Round 6, VERDICT item 6: k_stage1_h2 with one 8-wave workgroup per CU (production: 256 unified registers per wave, two waves per SIMD)
 # against one 16-wave workgroup per CU sharing the weight image (GENIE_H2_THREADS=1024: the compiler is held to 128 registers).
 # Same box: HIP-event time of stage 1 (tools/s1_time.py) + SQ counters of both. Output: gpurun_out/r06_s1_occupancy_ab.txt
