@@ -126,6 +126,8 @@ class GenieHipError(RuntimeError):
 def build(verbose=False, extra_flags=(), out_path=None):
     """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
     os.makedirs(LIB_DIR, exist_ok=True)
+    if out_path:
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
