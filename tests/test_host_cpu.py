@@ -295,3 +295,37 @@ def test_subgraph_pairs_match_the_reference_builder_on_cpu():
     pairs = engine.subgraph_pairs_device(torch.from_numpy(geom.locs), torch.from_numpy(geom.x_grid), max_deg_offset=0.15,
                                          k_nearest_pairs=6, scale_deg=110e3)
     assert np.array_equal(pairs.numpy(), z["A_src_in_sta"])
+
+
+def test_sharded_drop_in_keeps_the_reference_signatures_and_state_dict():
+    """The multi-GPU form is the SAME class with two more keyword arguments (`process_group`, `shard`): positional signatures of the
+    reference's methods (module.py:908, :941, :963, :999) and the 158 state_dict keys are unchanged; what is not sharded says so before it
+    touches a GPU; a sharded model without adjacencies refuses like an unsharded one."""
+    import inspect
+    ref_args = {
+        "set_adjacencies": ["A_in_sta", "A_in_src", "A_src_in_edges", "A_Lg_in_src", "A_src_in_sta", "A_src", "A_edges_p", "A_edges_s",
+                            "dt_partition", "tlatent", "pos_loc", "pos_src"],
+        "forward_fixed_source": ["Slice", "Mask", "tpick", "ipick", "phase_label", "locs_use_cart", "x_temp_cuda_cart", "x_query_cart", "t_query"],
+        "forward_fixed": ["Slice", "Mask", "tpick", "ipick", "phase_label", "locs_use_cart", "x_temp_cuda_cart", "x_query_cart",
+                          "x_query_src_cart", "t_query", "tq_sample", "trv_out_q"],
+    }
+    cls = module.GCN_Detection_Network_extended
+    for name, args in ref_args.items():
+        got = [p for p in inspect.signature(getattr(cls, name)).parameters if p != "self" and not p.startswith("_")]
+        assert got == args, (name, got)
+    assert len([p for p in inspect.signature(cls.forward).parameters if p != "self"]) == 22
+    plain = cls(lambda x: x, lambda x: x, device="cpu")
+    net = cls(lambda x: x, lambda x: x, device="cpu", shard=(1, 4))
+    assert net.is_sharded and not plain.is_sharded and net.shard_plan is None
+    assert list(net.state_dict().keys()) == list(plain.state_dict().keys()) and len(net.state_dict()) == 158
+    z = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError, match="set_adjacencies"):
+        net.forward_fixed_source(z, z, None, None, None, None, z, z, z)
+    net._hip = object()                      # (pretend the adjacencies are set: the refusals below come before any use of the context)
+    for call in (lambda: net.forward_fixed(z, z, None, None, None, None, z, z, z, z, None, None), lambda: net.push_window(z, z),
+                 lambda: net(*([z] * 22))):
+        with pytest.raises(NotImplementedError, match="source-node-sharded"):
+            call()
+    net._hip = None
+    with pytest.raises(ValueError):
+        cls(lambda x: x, lambda x: x, device="cpu", shard=(4, 4))
