@@ -79,6 +79,10 @@ def parse():
                     help="no GPU: launch the ranks, build the sharding plan and run the two collectives of the sharded path on CPU "
                          "tensors over gloo (checks the launcher / rank plumbing and the exchange; prints a JSON line, no timing)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded: sequential schedule (stage 1, exchange, stage 2, all-gather)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: nccl = RCCL over xGMI, one GPU per rank (the measurement). gloo = a FUNCTIONAL check of the N > 1 code path on "
+                         "a box with fewer GPUs than ranks: the ranks share the visible GPUs round robin and the collectives are staged through "
+                         "host memory (dist.Transport); its timings mean nothing and the line says so")
     ap.add_argument("--cpu-windows", type=int, default=3, help="cpu_baseline: timed windows after one warm-up (median)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1 default run: skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the line "
@@ -102,7 +106,7 @@ def respawn_under_torchrun(a):
     import socket
     import subprocess
     n_vis = torch.cuda.device_count()
-    if a.gpus > n_vis and not a.dry_run_cpu:
+    if a.gpus > n_vis and not a.dry_run_cpu and a.backend != "gloo":
         print("bench.py: --gpus %d needs %d visible GPUs, this node shows %d; nothing was launched" % (a.gpus, a.gpus, n_vis), file=sys.stderr)
         return 2
     s = socket.socket()
@@ -439,7 +443,10 @@ def single_rank_rccl(dev):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+        # an explicit store hosted HERE: under torchrun `init_method="tcp://..."` makes even rank 0 a client of the launcher's agent
+        # store (TORCHELASTIC_USE_AGENT_STORE), i.e. of a store nobody hosts on this port -- a ten-minute connect timeout
+        store = dist.TCPStore("127.0.0.1", port, 1, is_master=True, use_libuv=False)
+        dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=torch.device(dev))
         return dist, None
     except Exception as e:          # (the line is still produced, with the reason)
         return None, repr(e)[:200]
@@ -502,7 +509,7 @@ def sharded_phases(net, Slice, Mask, xg, xq, tq, barrier, reps):
     return {k: round(float(np.median(v)), 4) for k, v in ph.items()}
 
 
-def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
+def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True, one_rank_group=True):
     """ONE window per step, product graph sharded over source nodes across the ranks, THROUGH THE DROP-IN CLASS: the model is built
     with `process_group=`, `set_adjacencies_base` makes this rank's shard plan and contexts, every step is one
     `forward_fixed_source_pipelined(Slice, Mask, ...)` (the reference's arguments; Slice / Mask = the rank's own rows from the device
@@ -512,8 +519,10 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
     apply loop are independent, as in the N = 1 pipeline). --no-pipeline: `forward_fixed_source` (everything on one stream)."""
     S, G = geom.n_sta, geom.n_grid
     rccl_err = None
-    if dist is None and world == 1:
+    if dist is None and world == 1 and one_rank_group:
         dist, rccl_err = single_rank_rccl(dev)
+    elif dist is None and world == 1:
+        rccl_err = "not requested (the one-GPU leg after an N > 1 run: no second rendezvous under the launcher)"
     net, Slice, Mask, locs, xg, xq, tq = sharded_setup(a, geom, n_picks, rank, world, dev, dist is not None)
     sp = net._shard
     p = sp.plan
@@ -538,7 +547,7 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
         barrier()
         dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     phases = sharded_phases(net, Slice, Mask, xg, xq, tq, barrier, min(a.steps, 5))
@@ -559,7 +568,9 @@ def main_sharded(a, geom, n_picks, nq, rank, world, dev, dist, emit=True):
                                   % (world, "sequential" if a.no_overlap else "exchange overlapped with compute"),
                    "entry_point": "GCN_Detection_Network_extended(process_group=...).set_adjacencies_base / .embed_window / "
                                   + (".forward_fixed_source" if a.no_pipeline else ".forward_fixed_source_pipelined"),
-                   "backend": "nccl (RCCL)" if dist is not None else "none", "rccl_ranks": ranks if dist is not None else 0,
+                   "backend": ("nccl (RCCL)" if dist.get_backend() == "nccl" else "gloo: FUNCTIONAL CHECK ONLY, ranks share GPUs, collectives "
+                               "staged through the host -- the timings of this line mean nothing") if dist is not None else "none",
+                   "rccl_ranks": ranks if dist is not None and dist.get_backend() == "nccl" else 0,
                    "device_collectives": bool(sp.transport.on and sp.transport.device_collectives),
                    "rccl_single_rank_error": rccl_err,
                    "tail_pipelined": not a.no_pipeline,
@@ -993,12 +1004,16 @@ def main():
         a.config = "cfg4_2000x50k" if (a.mode == "sharded" and world > 1) else "cfg2_200x10k"
     dist = None
     if world > 1:
-        if local_rank >= torch.cuda.device_count():      # (under an external launcher: fail before any rendezvous can hang)
-            print("bench.py: rank %d has no GPU (WORLD_SIZE %d, %d visible GPUs): one GPU per rank is required"
-                  % (rank, world, torch.cuda.device_count()), file=sys.stderr)
-            sys.exit(2)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "gloo":         # functional check only: ranks share the visible GPUs, collectives staged through the host
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo")
+        else:
+            if local_rank >= torch.cuda.device_count():      # (under an external launcher: fail before any rendezvous can hang)
+                print("bench.py: rank %d has no GPU (WORLD_SIZE %d, %d visible GPUs): one GPU per rank is required"
+                      % (rank, world, torch.cuda.device_count()), file=sys.stderr)
+                sys.exit(2)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
@@ -1021,7 +1036,7 @@ def main():
             a1.steps, a1.warmup, a1.no_overlap = 5, 2, False
             torch.cuda.empty_cache()
             try:
-                o1 = main_sharded(a1, geom, n_picks, nq, 0, 1, dev, None, emit=False)
+                o1 = main_sharded(a1, geom, n_picks, nq, 0, 1, dev, None, emit=False, one_rank_group=False)
                 out["one_gpu_same_config"] = {"ms_per_step": o1["ms_per_step"], "value": o1["value"], "unit": "picks/s", "steps": a1.steps,
                                               "speedup": round(o1["ms_per_step"] / out["ms_per_step"], 2),
                                               "scaling_efficiency": round(o1["ms_per_step"] / out["ms_per_step"] / world, 3),

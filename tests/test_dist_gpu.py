@@ -316,3 +316,29 @@ def test_drop_in_class_world2_rccl_bit_equal_to_unsharded():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL over xGMI); the 1-GPU box runs the gloo form above")
     _run_drop_in(2, "nccl", False)
+
+
+def test_bench_n_ranks_control_flow_over_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the 1-GPU box (`--backend gloo`: the ranks share the GPU, collectives staged through the
+    host; timings meaningless and labelled so): the launcher, the drop-in class on every rank, the max-over-ranks timing, and the
+    one-GPU leg rank 0 runs AFTER the sharded run under the launcher -- which, with a second rendezvous through `init_method="tcp://"`,
+    made rank 0 a client of the launcher's agent store and hung for ten minutes (round 6; no N > 1 run had ever reached that line)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "cfg2_200x10k", "--steps", "3",
+                        "--warmup", "1"], cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["unit"] == "picks/s"
+    assert "FUNCTIONAL CHECK ONLY" in d["config"]["backend"] and d["config"]["rccl_ranks"] == 0
+    assert d["config"]["rank0_plan"]["n_own"] == 5000 and d["config"]["rank0_plan"]["n_halo"] > 0
+    assert "forward_fixed_source_pipelined" in d["config"]["entry_point"]
+    one = d["one_gpu_same_config"]
+    assert "error" not in one and one["ms_per_step"] > 0 and one["value"] > 0 and 0 < one["scaling_efficiency"]
