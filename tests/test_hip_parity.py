@@ -2450,3 +2450,33 @@ def test_contexts_rebuilt_per_sample_reuse_pooled_memory_and_stay_correct():
         y, x = run(fresh, s)
         assert torch.equal(y, outs[k][0]) and torch.equal(x, outs[k][1]), k
         del fresh
+
+
+def test_edge_attr_and_node_tables_as_callables_equal_the_tensor_forms():
+    """`set_adjacencies_base(..., edge_attr=callable)` and `node_rows(callable)` evaluate the caller's function for the source nodes the
+    model holds, block by block (what keeps config 4's 1.2 GB `edge_attr` and 0.8 GB travel-time table off every rank of a sharded job);
+    on an unsharded model they must give exactly what the full tensors give."""
+    S, G = 12, 70
+    geom = synthetic.Geometry(S, G, L=80e3, n_query=9, seed=15)
+    win = synthetic.make_window(geom, 150, seed=16)
+    c = Case("tiny_6x40")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+
+    def make(edge_attr):
+        net = module.GCN_Detection_Network_extended(lambda x: x, lambda x: x, device=DEV)
+        net.load_state_dict({k: v.clone() for k, v in c.weights.items()})
+        net.eval()
+        net.set_adjacencies_base(torch.from_numpy(geom.A_sta_sta), torch.from_numpy(geom.A_src_src), edge_attr, t(geom.locs), t(geom.x_grid))
+        return net
+
+    a, b = make(t(geom.edge_attr())), make(geom.edge_attr)
+    assert torch.equal(a._edge_attr, b._edge_attr)
+    with torch.no_grad():
+        ya, xa = a.forward_fixed_source(t(win["Slice"]), t(win["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query), t(geom.t_query))
+        yb, xb = b.forward_fixed_source(t(win["Slice"]), t(win["Mask"]), None, None, None, t(geom.locs), t(geom.x_grid), t(geom.x_query), t(geom.t_query))
+    assert torch.equal(ya, yb) and torch.equal(xa, xb)
+    trv = geom.travel_times().astype(np.float32)
+    r1, r2, r3 = a.node_rows(trv, 2), a.node_rows(geom.travel_times), a.node_rows(torch.from_numpy(trv).reshape(-1, 2))
+    assert tuple(r1.shape) == (S * G, 2) and torch.equal(r1, r2) and torch.equal(r1, r3)
+    with pytest.raises(ValueError):
+        a.node_rows(trv, 3)
