@@ -2,7 +2,7 @@
 """Stage-by-stage comparison of the eval forward_fixed (HIP) with the oracle on an association fixture: assoc_dbg.py <name>"""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, engine as E  # noqa
 from oracle import genie_oracle as O  # noqa

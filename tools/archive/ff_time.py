@@ -3,7 +3,7 @@
 association part; torch profiler table of one call."""
 import os, sys, time
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, synthetic  # noqa
 

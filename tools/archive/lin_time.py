@@ -2,7 +2,7 @@
 """Time genie_linear_bwd_wb against the library GEMM + column sum it replaces, at the product-sized shapes of config 2."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from genie_amd import engine
 dev = "cuda:0"
 e = torch.zeros((2, 0), dtype=torch.long)

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import _lib, engine, synthetic  # noqa: E402
 from tests.util import Case  # noqa: E402

@@ -4,7 +4,7 @@ medians of stage 1 and stage 2 (+ the segmented Bipartite sum), with the f16x2 k
 stage_precision="f32" (k_stage1_pcsr, k_stage2_pcsr). Usage: python tools/s2p_time.py"""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import engine, graph, module, synthetic  # noqa
 

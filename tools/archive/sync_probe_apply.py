@@ -1,6 +1,6 @@
 """Host synchronisations inside the GPU-only apply loop (apply.apply_windows_device) on a small setup: python tools/sync_probe_apply.py"""
 import os, sys, traceback, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from genie_amd import apply, module, synthetic
 from tests.util import Case

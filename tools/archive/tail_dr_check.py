@@ -2,7 +2,7 @@
 """Debug: d r of genie_tail_train_bwd against the oracle's autograd of the tail (r -> y, x) on the CPU."""
 import os, sys, ctypes
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, synthetic, engine, _lib  # noqa
 from tests.util import Case  # noqa

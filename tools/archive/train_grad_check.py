@@ -3,7 +3,7 @@
 oracle's autograd on the CPU: prints max |diff| / scale for every path parameter. Usage: train_grad_check.py [S G Q]"""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, synthetic  # noqa
 from tests.util import Case  # noqa

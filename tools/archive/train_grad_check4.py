@@ -3,7 +3,7 @@
 association fixture: train_grad_check4.py [fixture]"""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module  # noqa
 from oracle import genie_oracle as O  # noqa

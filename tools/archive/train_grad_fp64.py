@@ -4,7 +4,7 @@ is the HIP training step from the fp64 truth, and how far is the fp32 oracle its
 function of the pre-activations: two fp32 evaluations of the same forward differ by sign flips of near-zero pre-activations.)"""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, synthetic  # noqa
 from oracle import genie_oracle as O  # noqa

@@ -2,7 +2,7 @@
 """torch profiler table of one training step at config 2 (which kernels the 17 ms go to)."""
 import os, sys
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import module, synthetic  # noqa
 S, G, n_picks, L, nq = synthetic.CONFIGS["cfg2_200x10k"]

@@ -2,7 +2,7 @@
 """torch profiler table of the reference's 4-output training step at config 3 (which kernels the step goes to)."""
 import os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import graph, module, synthetic, train as gtrain  # noqa
 S, G, n_picks, L, nq = synthetic.CONFIGS["cfg2_200x10k"]

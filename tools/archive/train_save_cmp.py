@@ -2,7 +2,7 @@
 """Saved pre-activations of the training forward: f16x2 stage 1 vs the fp32-MFMA stage 1 (GENIE_S1=f32), block by block."""
 import os, sys, subprocess
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 if len(sys.argv) > 1:
     from genie_amd import module, synthetic

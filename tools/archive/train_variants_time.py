@@ -3,7 +3,7 @@
 backward + Adam) and a finiteness / non-zero check of the static-term gradient columns. Usage: python tools/train_variants_time.py"""
 import os, sys, time
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from genie_amd import module, synthetic  # noqa
 
